@@ -1,0 +1,159 @@
+/*
+ * pav_amd.h - C ABI of libpav_amd.so: the MI355X (gfx950) variant-calling core for PAV's hot path.
+ *
+ * This is the drop-in boundary.  PAV (EichlerLab/pav 2.4.6) is pure Python and has no FFI of its own, so each
+ * entry point below cites the Python interface it replaces (file:line in the reference snapshot); the ctypes
+ * binding a PAV maintainer would add is shown in INTEGRATION.md and implemented in pav_amd/_lib.py.
+ *
+ * Conventions
+ *   - plain C types, caller-owned host buffers; no torch / numpy types.
+ *   - every function returns 0 (PAV_OK) or a negative PAV_E* code; pav_last_error() gives the message.
+ *   - one pav_ctx per (process, GPU).  Calls on one context are serialised on its HIP stream; contexts are
+ *     independent, so N Snakemake jobs / N ranks drive N GPUs with no collective.
+ *   - there is NO CPU fallback: without a usable gfx950 device pav_create() fails.
+ *   - coordinates are 0-based half-open (BED) unless stated; sequence lengths must be < 2^32 - 256 bases
+ *     and CIGAR operation lengths < 2^28 (the BAM limit).
+ */
+#ifndef PAV_AMD_H
+#define PAV_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PAV_ABI_VERSION 1
+
+enum {
+    PAV_OK = 0,
+    PAV_E_ARG = -1,        /* bad argument                                                             */
+    PAV_E_HIP = -2,        /* HIP runtime error (message has the HIP error string)                     */
+    PAV_E_NODEV = -3,      /* no usable gfx950 device                                                  */
+    PAV_E_CIGAR = -4,      /* illegal / malformed CIGAR: details via pav_cigar_error()                 */
+    PAV_E_STATE = -5,      /* call order violated (e.g. call before load)                              */
+    PAV_E_LIMIT = -6       /* a documented size limit was exceeded                                     */
+};
+
+enum { PAV_ROLE_REF = 0, PAV_ROLE_TIG = 1 };
+
+typedef struct pav_ctx pav_ctx;
+
+/* ---- context ------------------------------------------------------------------------------------------ */
+int pav_abi_version(void);
+int pav_device_count(void);                       /* number of visible HIP devices (0 if none / no driver) */
+pav_ctx *pav_create(int device_id);               /* NULL on failure; then pav_last_error(NULL) explains   */
+void pav_destroy(pav_ctx *ctx);
+const char *pav_last_error(const pav_ctx *ctx);
+int pav_device_name(const pav_ctx *ctx, char *buf, int buf_len);
+int pav_sync(pav_ctx *ctx);                       /* hipStreamSynchronize on the context's stream          */
+
+/* ---- sequence store ----------------------------------------------------------------------------------- *
+ * Replaces: pysam.FastaFile.fetch of whole records + str.upper() of the whole chromosome / contig per
+ * alignment row (pavlib/cigarcall.py:58-75) and Bio reverse_complement (:70).  All records of one role are
+ * uploaded as ASCII (kept in HBM for case-exact REF/ALT/SEQ output) and packed on the device into a 2-bit
+ * plane (A0 C1 G2 T3, case folded) plus a 1-bit non-ACGT plane: the "upper-case view" the reference builds
+ * with str.upper().  Reverse-complemented contigs are never materialised; kernels index them in place.
+ */
+int pav_seq_load(pav_ctx *ctx, int role, uint32_t n_seq, const uint8_t *const *ascii, const uint64_t *len);
+int pav_seq_pack(pav_ctx *ctx, int role);         /* re-run the pack kernel on the resident ASCII (bench)  */
+int pav_seq_count(const pav_ctx *ctx, int role, uint32_t *n_seq, uint64_t *total_bases);
+
+/* ---- CIGAR variant calling ---------------------------------------------------------------------------- *
+ * Replaces pavlib.cigarcall.make_insdel_snv_calls (pavlib/cigarcall.py:24-311) together with
+ * pavlib.align.cigar_str_to_tuples (pavlib/align/align.py:286-322) and pavlib.call.left_homology /
+ * right_homology (pavlib/call.py:542-647).  The host keeps names/strings; the device returns integer
+ * records in the reference's emission order (row, op, base) plus case-exact bases / SEQ bytes.
+ */
+typedef struct {          /* one alignment BED row (API_ALIGN.md:33-57), only what the walk reads          */
+    uint32_t ref_id;      /* index of #CHROM in the PAV_ROLE_REF store                                      */
+    uint32_t tig_id;      /* index of QRY_ID in the PAV_ROLE_TIG store                                      */
+    uint32_t pos;         /* POS                                                                            */
+    uint32_t rev;         /* REV (0 / 1)                                                                    */
+} pav_aln;
+
+typedef struct {          /* one SNV row (pavlib/cigarcall.py:95-135); END = pos + 1, SVLEN = 1             */
+    uint32_t aln;         /* row number in the table given to pav_cigar_load                                */
+    uint32_t pos;         /* POS                                                                            */
+    uint32_t qry_pos;     /* 0-based position on the stored contig: QRY_REGION = tig:(qry_pos+1)-(qry_pos+1) */
+    uint8_t ref, alt;     /* REF, ALT exactly as in the FASTA (alt in reference orientation)                */
+    uint16_t pad;
+} pav_snv;
+
+typedef struct {          /* one INS / DEL row (pavlib/cigarcall.py:141-282)                                */
+    uint32_t aln;
+    uint32_t op_index;    /* 1-based CIGAR operation index within the row                                   */
+    uint32_t pos, end;    /* POS, END (INS: shifted, END = POS + 1; DEL: un-shifted, cigarcall.py:258)      */
+    uint32_t svlen;
+    uint32_t qry_pos, qry_end;   /* QRY_REGION = tig:(qry_pos+1)-qry_end                                    */
+    uint32_t left_shift;  /* LEFT_SHIFT                                                                     */
+    uint32_t hom_ref_l, hom_ref_r, hom_tig_l, hom_tig_r;   /* HOM_REF = "l,r", HOM_TIG = "l,r"              */
+    uint64_t seq_off;     /* offset of SEQ (svlen bytes) in the SEQ blob                                    */
+    uint8_t svtype;       /* 0 = INS, 1 = DEL                                                               */
+    uint8_t pad[7];
+} pav_indel;
+
+typedef struct {
+    uint64_t n_ops;       /* CIGAR operations tokenised                                                     */
+    uint64_t n_snv;
+    uint64_t n_indel;
+    uint64_t seq_bytes;   /* size of the SEQ blob                                                           */
+    uint64_t aligned_bases;   /* sum of '=' and 'X' lengths: the numerator of the Gbp/s metric              */
+} pav_cigar_counts;
+
+enum {                    /* pav_cigar_err.kind                                                             */
+    PAV_CIGAR_ERR_NONE = 0,
+    PAV_CIGAR_ERR_M = 1,             /* 'M' op: RuntimeError of pavlib/cigarcall.py:292-299                 */
+    PAV_CIGAR_ERR_OP = 2,            /* 'N' / 'P' op: RuntimeError of pavlib/cigarcall.py:301-307           */
+    PAV_CIGAR_ERR_MISSING_LEN = 3,   /* pavlib/align/align.py:310-313                                       */
+    PAV_CIGAR_ERR_UNKNOWN_OP = 4,    /* pavlib/align/align.py:315-318                                       */
+    PAV_CIGAR_ERR_TRUNCATED = 5,     /* text ends inside a length: IndexError at align.py:307               */
+    PAV_CIGAR_ERR_LEN_OVERFLOW = 6   /* operation length >= 2^28 (not representable in BAM either)          */
+};
+
+typedef struct {
+    int32_t kind;
+    uint32_t aln;         /* row                                                                            */
+    uint32_t op_index;    /* kinds 1,2: 1-based op index; kinds 3-6: byte offset of the token in the row    */
+    uint32_t op_char;     /* offending character as the reference prints it                                 */
+    uint32_t pos_ref;     /* subject position when the walk reached the op (kinds 1,2)                      */
+    uint32_t pos_tig;     /* query position (reference orientation) when the walk reached the op            */
+} pav_cigar_err;
+
+/* Upload the alignment table and the concatenated CIGAR text (row r = cigar_text[cigar_off[r] .. cigar_off[r+1]));
+ * inputs are borrowed for the duration of the call only. */
+int pav_cigar_load(pav_ctx *ctx, uint32_t n_aln, const pav_aln *aln, const uint8_t *cigar_text,
+                   const uint64_t *cigar_off);
+/* Tokenise + walk + homology on the device.  Results stay in HBM until fetched.  PAV_E_CIGAR when the
+ * reference would have raised (first error in row order, then operation order, like the sequential walk). */
+int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts);
+int pav_cigar_error(const pav_ctx *ctx, pav_cigar_err *err);
+/* Copy results to caller buffers sized from pav_cigar_counts (any pointer may be NULL to skip it). */
+int pav_cigar_fetch(pav_ctx *ctx, pav_snv *snv, pav_indel *indel, uint8_t *seq_blob);
+/* Tokenised operations of the last pav_cigar_call: ops[i] = len << 4 | BAM opcode; op_off has n_aln + 1 entries. */
+int pav_cigar_fetch_ops(pav_ctx *ctx, uint32_t *ops, uint64_t *op_off);
+
+/* Direct entry to the device homology routines (unit parity tests against pavlib/call.py:542-647).
+ * Sequence `seq_id` / `sv_seq_id` index the store of the given role; `rev` views that record reverse-
+ * complemented (pavlib/cigarcall.py:69-70).  dir 0 = left_homology, 1 = right_homology. */
+typedef struct {
+    int32_t role, seq_id, rev;          /* the sequence scanned (seq_tig argument)                          */
+    int64_t pos;                        /* pos_tig argument                                                 */
+    int32_t sv_role, sv_seq_id, sv_rev; /* where seq_sv lives                                               */
+    int64_t sv_pos;                     /* start of seq_sv in that (oriented) record                        */
+    uint32_t svlen;
+    int32_t dir;
+} pav_hom_query;
+int pav_homology(pav_ctx *ctx, uint32_t n, const pav_hom_query *q, uint32_t *out);
+
+/* ---- profiling ---------------------------------------------------------------------------------------- *
+ * HIP-event timing of every kernel the library launches on its stream (bench.py's roofline leg).         */
+int pav_prof_enable(pav_ctx *ctx, int on);
+int pav_prof_reset(pav_ctx *ctx);
+int pav_prof_count(pav_ctx *ctx);                                     /* number of distinct kernels seen    */
+int pav_prof_get(pav_ctx *ctx, int i, char *name, int name_len, uint64_t *launches, double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAV_AMD_H */

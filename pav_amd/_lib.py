@@ -1,0 +1,259 @@
+"""
+ctypes binding of ``libpav_amd.so`` (C ABI: ``include/pav_amd.h``).
+
+This is the binding a PAV maintainer adds.  There is no CPU fallback: if the HIP library is
+missing or no gfx950 device is usable, every entry point raises ``PavDeviceError`` - loudly, by design.
+"""
+
+import ctypes
+import importlib.util
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libpav_amd.so')
+
+PAV_ROLE_REF, PAV_ROLE_TIG = 0, 1
+PAV_OK, PAV_E_ARG, PAV_E_HIP, PAV_E_NODEV, PAV_E_CIGAR, PAV_E_STATE, PAV_E_LIMIT = 0, -1, -2, -3, -4, -5, -6
+
+
+class PavDeviceError(RuntimeError):
+    """The HIP library or the GPU is unavailable / failed.  Never swallowed into a CPU path."""
+
+
+# numpy dtypes mirroring the C structs (include/pav_amd.h)
+ALN_DTYPE = np.dtype([('ref_id', '<u4'), ('tig_id', '<u4'), ('pos', '<u4'), ('rev', '<u4')])
+SNV_DTYPE = np.dtype([('aln', '<u4'), ('pos', '<u4'), ('qry_pos', '<u4'), ('ref', 'u1'), ('alt', 'u1'),
+                      ('pad', '<u2')])
+INDEL_DTYPE = np.dtype([('aln', '<u4'), ('op_index', '<u4'), ('pos', '<u4'), ('end', '<u4'), ('svlen', '<u4'),
+                        ('qry_pos', '<u4'), ('qry_end', '<u4'), ('left_shift', '<u4'),
+                        ('hom_ref_l', '<u4'), ('hom_ref_r', '<u4'), ('hom_tig_l', '<u4'), ('hom_tig_r', '<u4'),
+                        ('seq_off', '<u8'), ('svtype', 'u1'), ('pad', 'u1', (7,))])
+HOM_QUERY_DTYPE = np.dtype([('role', '<i4'), ('seq_id', '<i4'), ('rev', '<i4'), ('_p0', '<i4'), ('pos', '<i8'),
+                            ('sv_role', '<i4'), ('sv_seq_id', '<i4'), ('sv_rev', '<i4'), ('_p1', '<i4'),
+                            ('sv_pos', '<i8'), ('svlen', '<u4'), ('dir', '<i4')])
+assert SNV_DTYPE.itemsize == 16 and INDEL_DTYPE.itemsize == 64 and ALN_DTYPE.itemsize == 16
+assert HOM_QUERY_DTYPE.itemsize == 56
+
+
+class CigarCounts(ctypes.Structure):
+    _fields_ = [('n_ops', ctypes.c_uint64), ('n_snv', ctypes.c_uint64), ('n_indel', ctypes.c_uint64),
+                ('seq_bytes', ctypes.c_uint64), ('aligned_bases', ctypes.c_uint64)]
+
+
+class CigarErr(ctypes.Structure):
+    _fields_ = [('kind', ctypes.c_int32), ('aln', ctypes.c_uint32), ('op_index', ctypes.c_uint32),
+                ('op_char', ctypes.c_uint32), ('pos_ref', ctypes.c_uint32), ('pos_tig', ctypes.c_uint32)]
+
+
+# Every symbol include/pav_amd.h declares: (restype, argtypes).  tests/test_abi.py checks the header against this.
+_P = ctypes.c_void_p
+SYMBOLS = {
+    'pav_abi_version': (ctypes.c_int, []),
+    'pav_device_count': (ctypes.c_int, []),
+    'pav_create': (_P, [ctypes.c_int]),
+    'pav_destroy': (None, [_P]),
+    'pav_last_error': (ctypes.c_char_p, [_P]),
+    'pav_device_name': (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int]),
+    'pav_sync': (ctypes.c_int, [_P]),
+    'pav_seq_load': (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_uint32, _P, _P]),
+    'pav_seq_pack': (ctypes.c_int, [_P, ctypes.c_int]),
+    'pav_seq_count': (ctypes.c_int, [_P, ctypes.c_int, _P, _P]),
+    'pav_cigar_load': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P]),
+    'pav_cigar_call': (ctypes.c_int, [_P, _P]),
+    'pav_cigar_error': (ctypes.c_int, [_P, _P]),
+    'pav_cigar_fetch': (ctypes.c_int, [_P, _P, _P, _P]),
+    'pav_cigar_fetch_ops': (ctypes.c_int, [_P, _P, _P]),
+    'pav_homology': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P]),
+    'pav_prof_enable': (ctypes.c_int, [_P, ctypes.c_int]),
+    'pav_prof_reset': (ctypes.c_int, [_P]),
+    'pav_prof_count': (ctypes.c_int, [_P]),
+    'pav_prof_get': (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, _P, _P]),
+}
+
+_LIB = None
+
+
+def _preload_hip_runtime():
+    """If PyTorch-ROCm is installed, make its bundled HIP runtime the process-wide one *before* libpav_amd.so
+    resolves ``libamdhip64.so.7``: bench.py uses torch.distributed in the same process and two HIP runtimes in
+    one process must be avoided.  Uses find_spec only (no ``import torch``)."""
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], 'lib', 'libamdhip64.so')
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
+def load():
+    """Load libpav_amd.so and declare every prototype.  Raises PavDeviceError if it is not built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise PavDeviceError(
+            f'{LIB_PATH} is not built (run: python -c "import __graft_entry__ as g; g.build()"). '
+            'pav_amd has no CPU fallback.')
+    _preload_hip_runtime()
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as ex:
+        raise PavDeviceError(f'cannot load {LIB_PATH}: {ex}') from ex
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _LIB = lib
+    return lib
+
+
+def _ptr(arr):
+    return ctypes.c_void_p(arr.ctypes.data) if arr is not None and arr.size else None
+
+
+class Context:
+    """One GPU context (``pav_ctx``).  Use as a context manager or call :meth:`close`."""
+
+    def __init__(self, device_id=0):
+        self.lib = load()
+        self.handle = self.lib.pav_create(int(device_id))
+        if not self.handle:
+            msg = self.lib.pav_last_error(None)
+            raise PavDeviceError('pav_create(%d) failed: %s' % (device_id, msg.decode() if msg else 'unknown'))
+        self.device_id = int(device_id)
+        self._seq_names = {PAV_ROLE_REF: [], PAV_ROLE_TIG: []}
+
+    # -- lifecycle ----------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.pav_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc == PAV_OK:
+            return
+        msg = self.lib.pav_last_error(self.handle)
+        msg = msg.decode() if msg else ''
+        if rc == PAV_E_CIGAR:
+            raise CigarDeviceError(msg)
+        raise PavDeviceError(f'{what} failed ({rc}): {msg}')
+
+    @property
+    def device_name(self):
+        buf = ctypes.create_string_buffer(256)
+        self._check(self.lib.pav_device_name(self.handle, buf, 256), 'pav_device_name')
+        return buf.value.decode()
+
+    def sync(self):
+        self._check(self.lib.pav_sync(self.handle), 'pav_sync')
+
+    # -- sequences ----------------------------------------------------------------------------------------
+    def seq_load(self, role, names, arrays):
+        """Upload and pack all records of one role.  ``arrays``: list of contiguous uint8 ASCII arrays."""
+        arrays = [np.ascontiguousarray(a, dtype=np.uint8) for a in arrays]
+        n = len(arrays)
+        ptrs = (ctypes.c_void_p * max(n, 1))(*[a.ctypes.data for a in arrays])
+        lens = (ctypes.c_uint64 * max(n, 1))(*[a.shape[0] for a in arrays])
+        self._check(self.lib.pav_seq_load(self.handle, role, n, ptrs, lens), 'pav_seq_load')
+        self._seq_names[role] = [str(x) for x in names]
+
+    def seq_pack(self, role):
+        self._check(self.lib.pav_seq_pack(self.handle, role), 'pav_seq_pack')
+
+    def seq_names(self, role):
+        return self._seq_names[role]
+
+    # -- CIGAR --------------------------------------------------------------------------------------------
+    def cigar_load(self, aln, cigar_text, cigar_off):
+        aln = np.ascontiguousarray(aln, dtype=ALN_DTYPE)
+        cigar_text = np.ascontiguousarray(cigar_text, dtype=np.uint8)
+        cigar_off = np.ascontiguousarray(cigar_off, dtype=np.uint64)
+        if cigar_off.shape[0] != aln.shape[0] + 1:
+            raise ValueError('cigar_off must have n_aln + 1 entries')
+        self._check(self.lib.pav_cigar_load(self.handle, aln.shape[0], _ptr(aln), _ptr(cigar_text),
+                                            ctypes.c_void_p(cigar_off.ctypes.data)), 'pav_cigar_load')
+
+    def cigar_call(self):
+        c = CigarCounts()
+        rc = self.lib.pav_cigar_call(self.handle, ctypes.byref(c))
+        if rc == PAV_E_CIGAR:
+            e = CigarErr()
+            self.lib.pav_cigar_error(self.handle, ctypes.byref(e))
+            raise CigarDeviceError(self.lib.pav_last_error(self.handle).decode(), e)
+        self._check(rc, 'pav_cigar_call')
+        return c
+
+    def cigar_fetch(self, counts):
+        snv = np.empty(counts.n_snv, dtype=SNV_DTYPE)
+        indel = np.empty(counts.n_indel, dtype=INDEL_DTYPE)
+        blob = np.empty(counts.seq_bytes, dtype=np.uint8)
+        self._check(self.lib.pav_cigar_fetch(self.handle, _ptr(snv), _ptr(indel), _ptr(blob)), 'pav_cigar_fetch')
+        return snv, indel, blob
+
+    def cigar_fetch_ops(self, n_ops, n_aln):
+        ops = np.empty(n_ops, dtype=np.uint32)
+        off = np.empty(n_aln + 1, dtype=np.uint64)
+        self._check(self.lib.pav_cigar_fetch_ops(self.handle, _ptr(ops), ctypes.c_void_p(off.ctypes.data)),
+                    'pav_cigar_fetch_ops')
+        return ops, off
+
+    def homology(self, queries):
+        q = np.ascontiguousarray(queries, dtype=HOM_QUERY_DTYPE)
+        out = np.zeros(q.shape[0], dtype=np.uint32)
+        self._check(self.lib.pav_homology(self.handle, q.shape[0], _ptr(q), _ptr(out)), 'pav_homology')
+        return out
+
+    # -- profiling ----------------------------------------------------------------------------------------
+    def prof_enable(self, on=True):
+        self._check(self.lib.pav_prof_enable(self.handle, 1 if on else 0), 'pav_prof_enable')
+
+    def prof_reset(self):
+        self._check(self.lib.pav_prof_reset(self.handle), 'pav_prof_reset')
+
+    def prof_read(self):
+        """{kernel name: (launches, total_ms)} measured with HIP events on the library's stream."""
+        n = self.lib.pav_prof_count(self.handle)
+        if n < 0:
+            self._check(n, 'pav_prof_count')
+        out = {}
+        for i in range(n):
+            name = ctypes.create_string_buffer(128)
+            launches = ctypes.c_uint64(0)
+            ms = ctypes.c_double(0.0)
+            self._check(self.lib.pav_prof_get(self.handle, i, name, 128, ctypes.byref(launches), ctypes.byref(ms)),
+                        'pav_prof_get')
+            out[name.value.decode()] = (int(launches.value), float(ms.value))
+        return out
+
+
+class CigarDeviceError(RuntimeError):
+    """The device walk hit what the reference raises on; ``detail`` is the ``pav_cigar_err`` struct."""
+
+    def __init__(self, message, detail=None):
+        super().__init__(message)
+        self.detail = detail
+
+
+def device_count():
+    return int(load().pav_device_count())

@@ -1,0 +1,714 @@
+// CIGAR variant calling on gfx950: device tokenizer, flat prefix-scan walk, SNV / INDEL emission with
+// deterministic (row, op, base) ordering, breakpoint-homology kernel, SEQ gather.
+//
+// Replaces (file:line in the PAV 2.4.6 snapshot):
+//   pavlib/align/align.py:286-322    cigar_str_to_tuples          -> tok_count / tok_emit / row_ops
+//   pavlib/cigarcall.py:78-93,286    position bookkeeping          -> walk_reduce / walk_chunks / row_base
+//   pavlib/cigarcall.py:95-139       SNV rows                      -> walk_emit (X ops)
+//   pavlib/cigarcall.py:141-282      INS / DEL rows                -> walk_emit (I/D ops) + homology_kernel
+//   pavlib/call.py:542-647           left / right homology         -> left_hom / right_hom
+// Integer / byte work only: no MFMA.  All kernels are launched on the context's stream.
+#include "common.h"
+
+namespace pav {
+
+constexpr int TOK_CHUNK = 4096;          // text bytes per workgroup (256 lanes x 16 B)
+constexpr int OPS_PER_LANE = 8;
+constexpr int WALK_CHUNK = 256 * OPS_PER_LANE;   // CIGAR ops per workgroup
+constexpr int NQ = 6;                    // scanned quantities: ref_adv, tig_adv, n_snv, n_indel, seq_bytes, aligned
+
+
+__device__ __forceinline__ bool is_digit(uint32_t c) { return c - (uint32_t)'0' <= 9u; }
+
+__device__ __forceinline__ int op_code_of(uint32_t c) {
+    switch (c) {
+        case 'M': return 0; case 'I': return 1; case 'D': return 2; case 'N': return 3; case 'S': return 4;
+        case 'H': return 5; case 'P': return 6; case '=': return 7; case 'X': return 8; default: return -1;
+    }
+}
+
+// ---- block-wide exclusive scan of N u64 values per lane (256 lanes = 4 waves) ------------------------------
+template <int N>
+__device__ __forceinline__ void block_excl_scan(uint64_t (&v)[N], uint64_t (&total)[N], uint64_t *lds /* 4*N */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t inc[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        uint64_t x = v[q];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint64_t y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        inc[q] = x;
+        if (lane == 63) lds[wave * N + q] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        uint64_t base = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint64_t s = lds[w * N + q];
+            if (w < wave) base += s;
+            tot += s;
+        }
+        total[q] = tot;
+        v[q] = base + inc[q] - v[q];
+    }
+    __syncthreads();
+}
+
+// ---- tokenizer -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tok_count(const uint4 *__restrict__ text, uint32_t *__restrict__ chunk_cnt) {
+    __shared__ uint32_t s_cnt[4];
+    const uint4 v = text[(uint64_t)blockIdx.x * 256 + threadIdx.x];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) c += !is_digit((w[k] >> (8 * b)) & 0xFFu);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_cnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// Single-workgroup exclusive scan of u32 counts into u64 prefixes; out[n] = total.
+__global__ __launch_bounds__(256) void scan_counts(const uint32_t *__restrict__ in, uint64_t *__restrict__ out,
+                                                   uint32_t n) {
+    __shared__ uint64_t lds[4];
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        uint64_t v[1] = {i < n ? (uint64_t)in[i] : 0}, tot[1];
+        block_excl_scan<1>(v, tot, lds);
+        if (i < n) out[i] = carry + v[0];
+        __syncthreads();
+        if (threadIdx.x == 0) carry += tot[0];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[n] = carry;
+}
+
+// Each op character parses the digits in front of it and writes ops[ordinal] = len << 4 | code.
+// Tokenizer errors: atomicMin of (byte position of the token start << 3 | kind); the smallest position is the
+// first error the sequential reference would hit (rows are concatenated in table order).
+__global__ __launch_bounds__(256) void tok_emit(const uint8_t *__restrict__ text, const uint64_t *__restrict__ chunk_pre,
+                                                uint32_t *__restrict__ ops, unsigned long long *__restrict__ tok_err) {
+    __shared__ uint64_t lds[4];
+    const uint64_t p0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    const uint4 v = *reinterpret_cast<const uint4 *>(text + p0);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t flags = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) flags |= (uint32_t)!is_digit((w[j >> 2] >> (8 * (j & 3))) & 0xFFu) << j;
+    uint64_t cnt[1] = {(uint64_t)__popc(flags)}, tot[1];
+    block_excl_scan<1>(cnt, tot, lds);
+    uint64_t ord = chunk_pre[blockIdx.x] + cnt[0];
+    while (flags) {
+        const int j = __ffs((int)flags) - 1;
+        flags &= flags - 1;
+        const uint64_t p = p0 + (uint64_t)j;
+        const uint32_t ch = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        // digits in front of the op character (never more than 19 are read)
+        uint64_t val = 0, mul = 1;
+        int nd = 0;
+        bool over = false;
+        int64_t q = (int64_t)p - 1;
+        while (q >= 0 && is_digit(text[q])) {
+            if (nd < 18) { val += (uint64_t)(text[q] - '0') * mul; mul *= 10; } else if (text[q] != '0') over = true;
+            ++nd; --q;
+        }
+        const int code = op_code_of(ch);
+        int kind = 0;
+        if (nd == 0) kind = PAV_CIGAR_ERR_MISSING_LEN;              // align.py:310 (checked before the op set)
+        else if (code < 0) kind = PAV_CIGAR_ERR_UNKNOWN_OP;         // align.py:315
+        else if (over || val >= (1ull << 28)) kind = PAV_CIGAR_ERR_LEN_OVERFLOW;
+        if (kind) atomicMin(tok_err, (unsigned long long)(((uint64_t)(q + 1)) << 3 | (uint64_t)kind));
+        ops[ord] = kind ? 0x7u /* 0= : harmless */ : ((uint32_t)val << 4 | (uint32_t)code);
+        ++ord;
+    }
+}
+
+// One lane per row boundary r in [0, n_aln]: op_off[r] = number of op characters before text_off[r];
+// also flags rows whose text ends inside a length (IndexError in the reference).
+__global__ void row_ops(const uint8_t *__restrict__ text, const uint64_t *__restrict__ text_off,
+                        const uint64_t *__restrict__ chunk_pre, uint64_t *__restrict__ op_off, uint32_t n_aln,
+                        unsigned long long *__restrict__ tok_err) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_aln) return;
+    const uint64_t p = text_off[r];
+    const uint64_t c = p / TOK_CHUNK;
+    uint64_t cnt = chunk_pre[c];
+    for (uint64_t q = c * TOK_CHUNK; q < p; ++q) cnt += !is_digit(text[q]);
+    op_off[r] = cnt;
+    if (r < n_aln) {
+        const uint64_t e = text_off[r + 1];
+        if (e > p && is_digit(text[e - 1])) {
+            uint64_t q = e - 1;
+            while (q > p && is_digit(text[q - 1])) --q;
+            atomicMin(tok_err, (unsigned long long)(q << 3 | (uint64_t)PAV_CIGAR_ERR_TRUNCATED));
+        }
+    }
+}
+
+// ---- the walk --------------------------------------------------------------------------------------------
+__device__ __forceinline__ void op_contrib(uint32_t op, uint64_t (&c)[NQ]) {
+    const uint32_t code = op & 15u;
+    const uint64_t len = op >> 4;
+    const bool eq = code == 7, x = code == 8, ins = code == 1, del = code == 2, clip = code == 4 || code == 5;
+    c[0] = (eq || x || del) ? len : 0;            // reference advance  (cigarcall.py:92,138,282)
+    c[1] = (eq || x || ins || clip) ? len : 0;    // query advance      (cigarcall.py:93,139,213,287)
+    c[2] = x ? len : 0;                           // SNV rows
+    c[3] = (ins || del) ? 1 : 0;                  // INS/DEL rows
+    c[4] = (ins || del) ? len : 0;                // SEQ bytes
+    c[5] = (eq || x) ? len : 0;                   // aligned bases (metric numerator)
+}
+
+__device__ __forceinline__ void load_ops(const uint32_t *__restrict__ ops, uint64_t n_ops, uint64_t first,
+                                         uint32_t (&o)[OPS_PER_LANE]) {
+    if (first + OPS_PER_LANE <= n_ops) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(ops + first);
+        const uint4 b = *reinterpret_cast<const uint4 *>(ops + first + 4);
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < OPS_PER_LANE; ++j) o[j] = first + j < n_ops ? ops[first + j] : 0x5u /* 0H */;
+    }
+}
+
+__global__ __launch_bounds__(256) void walk_reduce(const uint32_t *__restrict__ ops, uint64_t n_ops,
+                                                   uint64_t *__restrict__ chunk_sum /* [n_chunks][NQ] */) {
+    __shared__ uint64_t lds[4 * NQ];
+    uint32_t o[OPS_PER_LANE];
+    load_ops(ops, n_ops, (uint64_t)blockIdx.x * WALK_CHUNK + (uint64_t)threadIdx.x * OPS_PER_LANE, o);
+    uint64_t s[NQ] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < OPS_PER_LANE; ++j) {
+        uint64_t c[NQ];
+        op_contrib(o[j], c);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) s[q] += c[q];
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s[q] += __shfl_xor(s[q], d);
+    }
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) lds[(threadIdx.x >> 6) * NQ + q] = s[q];
+    __syncthreads();
+    if (threadIdx.x < NQ)
+        chunk_sum[(uint64_t)blockIdx.x * NQ + threadIdx.x] =
+            lds[threadIdx.x] + lds[NQ + threadIdx.x] + lds[2 * NQ + threadIdx.x] + lds[3 * NQ + threadIdx.x];
+}
+
+// Single workgroup: exclusive scan of the per-chunk sums; totals[NQ] = grand totals.
+__global__ __launch_bounds__(256) void walk_chunks(const uint64_t *__restrict__ chunk_sum, uint64_t *__restrict__ chunk_pre,
+                                                   uint64_t *__restrict__ totals, uint32_t n_chunks) {
+    __shared__ uint64_t lds[4 * NQ];
+    __shared__ uint64_t carry[NQ];
+    if (threadIdx.x < NQ) carry[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_chunks; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        uint64_t v[NQ], tot[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) v[q] = i < n_chunks ? chunk_sum[(uint64_t)i * NQ + q] : 0;
+        block_excl_scan<NQ>(v, tot, lds);
+        if (i < n_chunks)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) chunk_pre[(uint64_t)i * NQ + q] = carry[q] + v[q];
+        __syncthreads();
+        if (threadIdx.x == 0)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) carry[q] += tot[q];
+        __syncthreads();
+    }
+    if (threadIdx.x < NQ) totals[threadIdx.x] = carry[threadIdx.x];
+}
+
+// One wave per row: running (ref, tig) advance of all ops before the row's first op.
+__global__ __launch_bounds__(256) void row_base(const uint32_t *__restrict__ ops, const uint64_t *__restrict__ op_off,
+                                                const uint64_t *__restrict__ chunk_pre, uint64_t *__restrict__ rowbase,
+                                                uint32_t n_aln) {
+    const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_aln) return;
+    const int lane = threadIdx.x & 63;
+    const uint64_t first = op_off[r];
+    const uint64_t c = first / WALK_CHUNK;
+    uint64_t a = 0, b = 0;
+    for (uint64_t i = c * WALK_CHUNK + lane; i < first; i += 64) {
+        uint64_t q[NQ];
+        op_contrib(ops[i], q);
+        a += q[0]; b += q[1];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); }
+    if (lane == 0) {
+        rowbase[2ull * r] = chunk_pre[c * NQ + 0] + a;
+        rowbase[2ull * r + 1] = chunk_pre[c * NQ + 1] + b;
+    }
+}
+
+struct WalkArgs {
+    const uint32_t *ops; uint64_t n_ops;
+    const uint64_t *op_off; const pav_aln *aln; uint32_t n_aln;
+    const uint64_t *chunk_pre; const uint64_t *rowbase;
+    SeqView ref, tig;
+    pav_snv *snv; pav_indel *indel;
+    unsigned long long *err_op;          // smallest global ordinal of an illegal op (M, N, P)
+};
+
+// Emit SNV rows and INDEL stubs.  Each lane owns 8 consecutive ops; the block scan gives every op its running
+// positions and its output slots, so the output order is exactly the reference's (row, op, base) order.
+__global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
+    __shared__ uint64_t lds[4 * NQ];
+    const uint64_t first = (uint64_t)blockIdx.x * WALK_CHUNK + (uint64_t)threadIdx.x * OPS_PER_LANE;
+    uint32_t o[OPS_PER_LANE];
+    load_ops(A.ops, A.n_ops, first, o);
+    uint64_t run[NQ] = {0, 0, 0, 0, 0, 0}, tot[NQ];
+#pragma unroll
+    for (int j = 0; j < OPS_PER_LANE; ++j) {
+        uint64_t c[NQ];
+        op_contrib(o[j], c);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) run[q] += c[q];
+    }
+    block_excl_scan<NQ>(run, tot, lds);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) run[q] += A.chunk_pre[(uint64_t)blockIdx.x * NQ + q];
+    if (first >= A.n_ops) return;
+
+    // row of this lane's first op: last r with op_off[r] <= first
+    uint32_t lo = 0, hi = A.n_aln;            // invariant: op_off[lo] <= first < op_off[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (A.op_off[mid] <= first) lo = mid; else hi = mid;
+    }
+    uint32_t row = lo;
+    uint64_t row_end = A.op_off[row + 1];
+    while (row_end <= first && row + 1 < A.n_aln) { ++row; row_end = A.op_off[row + 1]; }   // skip empty rows
+    pav_aln al = A.aln[row];
+    uint64_t rb_ref = A.rowbase[2ull * row], rb_tig = A.rowbase[2ull * row + 1];
+
+    uint32_t prev = first > 0 ? A.ops[first - 1] : 0x5u;   // last_op / last_oplen carried across lanes
+#pragma unroll
+    for (int j = 0; j < OPS_PER_LANE; ++j) {
+        const uint64_t k = first + j;
+        if (k >= A.n_ops) break;
+        while (k >= row_end) {                 // next row (rows without ops are skipped)
+            ++row; row_end = A.op_off[row + 1];
+            al = A.aln[row];
+            rb_ref = A.rowbase[2ull * row]; rb_tig = A.rowbase[2ull * row + 1];
+        }
+        const uint32_t code = o[j] & 15u, len = o[j] >> 4;
+        const int64_t pos_ref = (int64_t)al.pos + (int64_t)(run[0] - rb_ref);
+        const int64_t pos_tig = (int64_t)(run[1] - rb_tig);
+        const int rev = al.rev != 0;
+        if (code == 8) {                                                   // 'X'  cigarcall.py:95-139
+            const uint64_t roff = A.ref.off[al.ref_id], rlen = A.ref.len[al.ref_id];
+            const uint64_t toff = A.tig.off[al.tig_id], tlen = A.tig.len[al.tig_id];
+            pav_snv *out = A.snv + run[2];
+            for (uint32_t i = 0; i < len; ++i) {
+                pav_snv s;
+                s.aln = row;
+                s.pos = (uint32_t)(pos_ref + i);
+                const int64_t pt = pos_tig + i;
+                s.qry_pos = (uint32_t)(rev ? (int64_t)tlen - pt - 1 : pt);   // cigarcall.py:108-109
+                s.ref = ascii_at(A.ref.ascii, roff, rlen, 0, pos_ref + i);
+                s.alt = ascii_at(A.tig.ascii, toff, tlen, rev, pt);
+                s.pad = 0;
+                out[i] = s;
+            }
+        } else if (code == 1 || code == 2) {                               // 'I' / 'D' stub
+            pav_indel r;
+            r.aln = row;
+            r.op_index = (uint32_t)(k - A.op_off[row]) + 1;                // cigar_index, cigarcall.py:89
+            r.pos = (uint32_t)pos_ref;                                     // un-shifted; finalised by homology_kernel
+            r.end = 0;
+            r.svlen = len;
+            r.qry_pos = (uint32_t)pos_tig;                                 // oriented, un-shifted
+            r.qry_end = 0;
+            // last_op / last_oplen (cigarcall.py:149-151,310-311): previous op of the same row
+            const bool has_prev = k > A.op_off[row];                       // first op of a row: last_op is None
+            r.left_shift = (has_prev && (prev & 15u) == 7u) ? (prev >> 4) : 0u;   // shift cap; 0 when last_op != '='
+            r.hom_ref_l = r.hom_ref_r = r.hom_tig_l = r.hom_tig_r = 0;
+            r.seq_off = run[4];
+            r.svtype = code == 1 ? 0 : 1;
+#pragma unroll
+            for (int b = 0; b < 7; ++b) r.pad[b] = 0;
+            A.indel[run[3]] = r;
+        } else if (code != 7 && code != 4 && code != 5) {                  // M, N, P: cigarcall.py:289-307
+            atomicMin(A.err_op, (unsigned long long)k);               // first one in walk order wins
+        }
+        uint64_t c[NQ];
+        op_contrib(o[j], c);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) run[q] += c[q];
+        prev = o[j];
+    }
+}
+
+// ---- breakpoint homology (pavlib/call.py:542-647) -----------------------------------------------------------
+struct SeqRef {                 // one oriented record of a store
+    const uint32_t *two, *mask;
+    uint64_t off, len;
+    int rev;
+};
+__device__ __forceinline__ uint32_t base(const SeqRef &s, int64_t p) { return base_at(s.two, s.mask, s.off, s.len, s.rev, p); }
+
+// left_homology(pos_tig, seq_tig, seq_sv): seq_sv = sv[sv_pos .. sv_pos + svlen)
+__device__ uint32_t left_hom(const SeqRef &t, int64_t pos, const SeqRef &sv, int64_t sv_pos, int64_t svlen) {
+    if (svlen <= 0) return 0;
+    int64_t h = 0, idx = svlen - 1;                    // seq_sv[-((h + 1) % svlen)]  (call.py:579)
+    while (h <= pos) {                                 // call.py:572
+        const uint32_t b = base(t, pos - h);
+        if (b > 3u) break;                             // not in {A,C,G,T}: call.py:576
+        if (base(sv, sv_pos + idx) != b) break;
+        ++h;
+        idx = idx == 0 ? svlen - 1 : idx - 1;
+    }
+    return (uint32_t)h;
+}
+
+// right_homology(pos_tig, seq_tig, seq_sv)
+__device__ uint32_t right_hom(const SeqRef &t, int64_t pos, const SeqRef &sv, int64_t sv_pos, int64_t svlen) {
+    if (svlen <= 0) return 0;
+    const int64_t limit = (int64_t)t.len - pos;        // call.py:627
+    int64_t h = 0, idx = 0;                            // seq_sv[h % svlen]  (call.py:637)
+    while (h < limit) {
+        const uint32_t b = base(t, pos + h);
+        if (b > 3u) break;
+        if (base(sv, sv_pos + idx) != b) break;
+        ++h;
+        idx = idx + 1 == svlen ? 0 : idx + 1;
+    }
+    return (uint32_t)h;
+}
+
+// One lane per INS/DEL stub: left shift + four breakpoint homologies, then the final coordinates.
+__global__ __launch_bounds__(256) void homology_kernel(pav_indel *__restrict__ indel, uint64_t n_indel,
+                                                       const pav_aln *__restrict__ aln, SeqView R, SeqView T) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_indel) return;
+    pav_indel r = indel[i];
+    const pav_aln al = aln[r.aln];
+    const int rev = al.rev != 0;
+    const SeqRef ref{R.two, R.mask, R.off[al.ref_id], R.len[al.ref_id], 0};
+    const SeqRef tig{T.two, T.mask, T.off[al.tig_id], T.len[al.tig_id], rev};
+    const int64_t pos_ref = r.pos, pos_tig = r.qry_pos, oplen = r.svlen, tig_len = (int64_t)tig.len;
+    const bool ins = r.svtype == 0;
+    const SeqRef &svs = ins ? tig : ref;               // seq = seq_tig[pos_tig:+oplen] / seq_ref[pos_ref:+oplen]
+    int64_t sv_at = ins ? pos_tig : pos_ref;
+    int64_t shift = 0;
+    if (r.left_shift) {                                // last_op == '=' (cigarcall.py:149-155 / :225-231)
+        const int64_t h = left_hom(ref, pos_ref - 1, svs, sv_at, oplen);
+        shift = h < (int64_t)r.left_shift ? h : (int64_t)r.left_shift;
+    }
+    const int64_t sv_pos_ref = pos_ref - shift, sv_pos_tig = pos_tig - shift;
+    if (ins) {
+        if (shift) sv_at = sv_pos_tig;                 // seq re-sliced at the shifted position (:162-163)
+        r.hom_ref_l = left_hom(ref, sv_pos_ref - 1, svs, sv_at, oplen);             // :178
+        r.hom_ref_r = right_hom(ref, sv_pos_ref, svs, sv_at, oplen);                // :179
+        r.hom_tig_l = left_hom(tig, sv_pos_tig - 1, svs, sv_at, oplen);             // :181
+        r.hom_tig_r = right_hom(tig, sv_pos_tig + oplen, svs, sv_at, oplen);        // :182
+        r.pos = (uint32_t)sv_pos_ref; r.end = (uint32_t)(sv_pos_ref + 1);           // :157-158
+        if (rev) { r.qry_end = (uint32_t)(tig_len - sv_pos_tig); r.qry_pos = r.qry_end - (uint32_t)oplen; }   // :167-169
+        else { r.qry_pos = (uint32_t)sv_pos_tig; r.qry_end = (uint32_t)(sv_pos_tig + oplen); }                // :171-173
+    } else {
+        r.hom_ref_l = left_hom(ref, sv_pos_ref - 1, svs, sv_at, oplen);             // :247
+        r.hom_ref_r = right_hom(ref, sv_pos_ref + oplen, svs, sv_at, oplen);        // :248
+        r.hom_tig_l = left_hom(tig, sv_pos_tig - 1, svs, sv_at, oplen);             // :250
+        r.hom_tig_r = right_hom(tig, sv_pos_tig, svs, sv_at, oplen);                // :251
+        r.pos = (uint32_t)pos_ref; r.end = (uint32_t)(pos_ref + oplen);             // :258 (un-shifted)
+        const int64_t q = rev ? tig_len - sv_pos_tig : sv_pos_tig;                  // :239-242
+        r.qry_pos = (uint32_t)q; r.qry_end = (uint32_t)(q + 1);
+    }
+    r.left_shift = (uint32_t)shift;
+    // SEQ source for the gather kernel: oriented start of the slice (INS: shifted; DEL: un-shifted)
+    r.pad[0] = 0;
+    indel[i] = r;
+}
+
+// SEQ blob: one lane per output byte; the owning record is found by binary search on seq_off.
+__global__ __launch_bounds__(256) void seq_gather(const pav_indel *__restrict__ indel, uint64_t n_indel,
+                                                  const pav_aln *__restrict__ aln, SeqView R, SeqView T,
+                                                  uint8_t *__restrict__ blob, uint64_t n_bytes) {
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_bytes) return;
+    uint64_t lo = 0, hi = n_indel;                     // last record with seq_off <= b
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (indel[mid].seq_off <= b) lo = mid; else hi = mid;
+    }
+    const pav_indel r = indel[lo];
+    const pav_aln al = aln[r.aln];
+    const int64_t k = (int64_t)(b - r.seq_off);
+    uint8_t c;
+    if (r.svtype == 0) {                               // INS: seq_tig[sv_pos_tig : +oplen]  (cigarcall.py:145,163)
+        const int rev = al.rev != 0;
+        const uint64_t tlen = T.len[al.tig_id];
+        const int64_t sv_pos_tig = rev ? (int64_t)tlen - (int64_t)r.qry_end : (int64_t)r.qry_pos;
+        c = ascii_at(T.ascii, T.off[al.tig_id], tlen, rev, sv_pos_tig + k);
+    } else {                                           // DEL: seq_ref[pos_ref : +oplen]      (cigarcall.py:221)
+        c = R.ascii[R.off[al.ref_id] + r.pos + (uint64_t)k];
+    }
+    blob[b] = c;
+}
+
+__global__ void homology_query_kernel(const pav_hom_query *__restrict__ q, uint32_t n, SeqView R, SeqView T,
+                                      uint32_t *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const pav_hom_query h = q[i];
+    const SeqView &a = h.role == PAV_ROLE_REF ? R : T;
+    const SeqView &b = h.sv_role == PAV_ROLE_REF ? R : T;
+    const SeqRef t{a.two, a.mask, a.off[h.seq_id], a.len[h.seq_id], h.rev != 0};
+    const SeqRef sv{b.two, b.mask, b.off[h.sv_seq_id], b.len[h.sv_seq_id], h.sv_rev != 0};
+    out[i] = h.dir == 0 ? left_hom(t, h.pos, sv, h.sv_pos, h.svlen) : right_hom(t, h.pos, sv, h.sv_pos, h.svlen);
+}
+
+}  // namespace pav
+
+using namespace pav;
+
+static uint64_t round_up(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }
+
+extern "C" {
+
+int pav_cigar_load(pav_ctx *ctx, uint32_t n_aln, const pav_aln *aln, const uint8_t *cigar_text,
+                   const uint64_t *cigar_off) {
+    if (!ctx) return PAV_E_ARG;
+    if (n_aln && (!aln || !cigar_off)) return fail(ctx, PAV_E_ARG, "pav_cigar_load: null input");
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t T = n_aln ? cigar_off[n_aln] : 0;
+    if (T && !cigar_text) return fail(ctx, PAV_E_ARG, "pav_cigar_load: null CIGAR text");
+    for (uint32_t r = 0; r < n_aln; ++r) {
+        if (cigar_off[r + 1] < cigar_off[r]) return fail(ctx, PAV_E_ARG, "pav_cigar_load: cigar_off not monotone at row %u", r);
+        if (aln[r].ref_id >= ctx->seq[PAV_ROLE_REF].n || aln[r].tig_id >= ctx->seq[PAV_ROLE_TIG].n)
+            return fail(ctx, PAV_E_ARG, "pav_cigar_load: row %u references a sequence that is not loaded", r);
+    }
+    ctx->n_aln = n_aln;
+    ctx->text_bytes = T;
+    ctx->cigar_called = false;
+    const uint64_t Tpad = round_up(T + 1, TOK_CHUNK);
+    PAV_HIP(ctx, ctx->d_text.reserve(Tpad));
+    PAV_HIP(ctx, ctx->d_text_off.reserve(sizeof(uint64_t) * ((size_t)n_aln + 1)));
+    PAV_HIP(ctx, ctx->d_aln.reserve(sizeof(pav_aln) * ((size_t)n_aln + 1)));
+    PAV_HIP(ctx, hipMemsetAsync(ctx->d_text.p, '0', Tpad, ctx->stream));          // padding: digits, never ops
+    if (T) PAV_HIP(ctx, hipMemcpyAsync(ctx->d_text.p, cigar_text, T, hipMemcpyHostToDevice, ctx->stream));
+    uint64_t zero = 0;
+    PAV_HIP(ctx, hipMemcpyAsync(ctx->d_text_off.p, n_aln ? cigar_off : &zero, sizeof(uint64_t) * ((size_t)n_aln + 1),
+                                hipMemcpyHostToDevice, ctx->stream));
+    if (n_aln) PAV_HIP(ctx, hipMemcpyAsync(ctx->d_aln.p, aln, sizeof(pav_aln) * n_aln, hipMemcpyHostToDevice, ctx->stream));
+    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->cigar_loaded = true;
+    return PAV_OK;
+}
+
+int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
+    if (!ctx) return PAV_E_ARG;
+    if (!ctx->cigar_loaded) return fail(ctx, PAV_E_STATE, "pav_cigar_call: pav_cigar_load has not been called");
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    memset(&ctx->counts, 0, sizeof ctx->counts);
+    memset(&ctx->cigar_err, 0, sizeof ctx->cigar_err);
+    ctx->cigar_called = false;
+    const uint32_t n_aln = ctx->n_aln;
+    const uint64_t T = ctx->text_bytes;
+    const uint64_t Tpad = round_up(T + 1, TOK_CHUNK);
+    const uint32_t n_tchunks = (uint32_t)(Tpad / TOK_CHUNK);
+
+    // d_err: [0] tokenizer error key, [1] illegal-op ordinal; d_totals: NQ walk totals
+    PAV_HIP(ctx, ctx->d_err.reserve(2 * sizeof(uint64_t)));
+    PAV_HIP(ctx, hipMemsetAsync(ctx->d_err.p, 0xFF, 2 * sizeof(uint64_t), ctx->stream));
+    PAV_HIP(ctx, ctx->d_totals.reserve(NQ * sizeof(uint64_t)));
+    unsigned long long *d_tok_err = ctx->d_err.as<unsigned long long>();
+    unsigned long long *d_err_op = d_tok_err + 1;
+
+    // --- tokenise -------------------------------------------------------------------------------------
+    PAV_HIP(ctx, ctx->d_chunk.reserve(sizeof(uint32_t) * n_tchunks + sizeof(uint64_t) * ((size_t)n_tchunks + 1) + 64));
+    uint32_t *d_tcnt = ctx->d_chunk.as<uint32_t>();
+    uint64_t *d_tpre = reinterpret_cast<uint64_t *>(ctx->d_chunk.as<uint8_t>() + round_up(sizeof(uint32_t) * n_tchunks, 16));
+    PAV_LAUNCH(ctx, "tok_count", tok_count, n_tchunks, 256, 0, ctx->d_text.as<uint4>(), d_tcnt);
+    PAV_LAUNCH(ctx, "scan_counts", scan_counts, 1, 256, 0, d_tcnt, d_tpre, n_tchunks);
+    uint64_t n_ops = 0;
+    PAV_HIP(ctx, hipMemcpyAsync(&n_ops, d_tpre + n_tchunks, sizeof n_ops, hipMemcpyDeviceToHost, ctx->stream));
+    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_ops = n_ops;
+    PAV_HIP(ctx, ctx->d_ops.reserve(sizeof(uint32_t) * (n_ops + 16)));
+    PAV_HIP(ctx, ctx->d_op_off.reserve(sizeof(uint64_t) * ((size_t)n_aln + 1)));
+    PAV_LAUNCH(ctx, "tok_emit", tok_emit, n_tchunks, 256, 0, ctx->d_text.as<uint8_t>(), d_tpre, ctx->d_ops.as<uint32_t>(),
+               d_tok_err);
+    PAV_LAUNCH(ctx, "row_ops", row_ops, (n_aln + 1 + 255) / 256, 256, 0, ctx->d_text.as<uint8_t>(),
+               ctx->d_text_off.as<uint64_t>(), d_tpre, ctx->d_op_off.as<uint64_t>(), n_aln, d_tok_err);
+
+    // --- walk: reduce, chunk scan, row bases -------------------------------------------------------------
+    const uint32_t n_wchunks = (uint32_t)((n_ops + WALK_CHUNK - 1) / WALK_CHUNK);
+    uint64_t totals[NQ] = {0, 0, 0, 0, 0, 0};
+    uint64_t errs[2] = {~0ull, ~0ull};
+    uint64_t *d_csum = nullptr, *d_cpre = nullptr;
+    if (n_wchunks) {
+        PAV_HIP(ctx, ctx->d_chunk2.reserve(2 * sizeof(uint64_t) * NQ * (size_t)n_wchunks));
+        d_csum = ctx->d_chunk2.as<uint64_t>();
+        d_cpre = d_csum + (size_t)NQ * n_wchunks;
+        PAV_HIP(ctx, ctx->d_rowbase.reserve(2 * sizeof(uint64_t) * ((size_t)n_aln + 1)));
+        PAV_LAUNCH(ctx, "walk_reduce", walk_reduce, n_wchunks, 256, 0, ctx->d_ops.as<uint32_t>(), n_ops, d_csum);
+        PAV_LAUNCH(ctx, "walk_chunks", walk_chunks, 1, 256, 0, d_csum, d_cpre, ctx->d_totals.as<uint64_t>(), n_wchunks);
+        PAV_LAUNCH(ctx, "row_base", row_base, (n_aln + 3) / 4, 256, 0, ctx->d_ops.as<uint32_t>(),
+                   ctx->d_op_off.as<uint64_t>(), d_cpre, ctx->d_rowbase.as<uint64_t>(), n_aln);
+        PAV_HIP(ctx, hipMemcpyAsync(totals, ctx->d_totals.p, sizeof totals, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    PAV_HIP(ctx, hipMemcpyAsync(errs, ctx->d_err.p, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+    ctx->counts.n_ops = n_ops;
+    ctx->counts.n_snv = totals[2];
+    ctx->counts.n_indel = totals[3];
+    ctx->counts.seq_bytes = totals[4];
+    ctx->counts.aligned_bases = totals[5];
+
+    // --- emit + homology + SEQ gather ---------------------------------------------------------------------
+    if (n_wchunks) {
+        PAV_HIP(ctx, ctx->d_snv.reserve(sizeof(pav_snv) * (totals[2] + 1)));
+        PAV_HIP(ctx, ctx->d_indel.reserve(sizeof(pav_indel) * (totals[3] + 1)));
+        PAV_HIP(ctx, ctx->d_seqblob.reserve(totals[4] + 16));
+        WalkArgs A;
+        A.ops = ctx->d_ops.as<uint32_t>(); A.n_ops = n_ops;
+        A.op_off = ctx->d_op_off.as<uint64_t>(); A.aln = ctx->d_aln.as<pav_aln>(); A.n_aln = n_aln;
+        A.chunk_pre = d_cpre; A.rowbase = ctx->d_rowbase.as<uint64_t>();
+        A.ref = ctx->seq[PAV_ROLE_REF].view(); A.tig = ctx->seq[PAV_ROLE_TIG].view();
+        A.snv = ctx->d_snv.as<pav_snv>(); A.indel = ctx->d_indel.as<pav_indel>();
+        A.err_op = d_err_op;
+        PAV_LAUNCH(ctx, "walk_emit", walk_emit, n_wchunks, 256, 0, A);
+        if (totals[3]) {
+            PAV_LAUNCH(ctx, "homology_kernel", homology_kernel, (uint32_t)((totals[3] + 255) / 256), 256, 0,
+                       ctx->d_indel.as<pav_indel>(), totals[3], ctx->d_aln.as<pav_aln>(), A.ref, A.tig);
+            if (totals[4])
+                PAV_LAUNCH(ctx, "seq_gather", seq_gather, (uint32_t)((totals[4] + 255) / 256), 256, 0,
+                           ctx->d_indel.as<pav_indel>(), totals[3], ctx->d_aln.as<pav_aln>(), A.ref, A.tig,
+                           ctx->d_seqblob.as<uint8_t>(), totals[4]);
+        }
+        PAV_HIP(ctx, hipMemcpyAsync(errs, ctx->d_err.p, sizeof errs, hipMemcpyDeviceToHost, ctx->stream));
+        PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (counts) *counts = ctx->counts;
+    ctx->cigar_called = true;
+
+    // --- errors: the first one the sequential walk would have hit ------------------------------------------
+    if (errs[0] != ~0ull || errs[1] != ~0ull) {
+        // Resolve on the host (error path only): fetch op offsets and, for an illegal op, the row's ops.
+        std::vector<uint64_t> op_off((size_t)n_aln + 1), text_off((size_t)n_aln + 1);
+        PAV_HIP(ctx, hipMemcpy(op_off.data(), ctx->d_op_off.p, sizeof(uint64_t) * op_off.size(), hipMemcpyDeviceToHost));
+        PAV_HIP(ctx, hipMemcpy(text_off.data(), ctx->d_text_off.p, sizeof(uint64_t) * text_off.size(), hipMemcpyDeviceToHost));
+        auto row_of = [&](const std::vector<uint64_t> &off, uint64_t x) {
+            uint32_t lo = 0, hi = n_aln;
+            while (hi - lo > 1) { uint32_t mid = (lo + hi) / 2; if (off[mid] <= x) lo = mid; else hi = mid; }
+            while (lo + 1 < n_aln && off[lo + 1] <= x) ++lo;
+            return lo;
+        };
+        pav_cigar_err tok{}, ill{};
+        uint64_t tok_ord = ~0ull, ill_ord = ~0ull;     // (row << 32 | ordinal-in-row) walk order keys
+        if (errs[0] != ~0ull) {
+            const uint64_t bytepos = errs[0] >> 3;
+            tok.kind = (int32_t)(errs[0] & 7);
+            tok.aln = row_of(text_off, bytepos);
+            tok.op_index = (uint32_t)(bytepos - text_off[tok.aln]);
+            std::vector<uint8_t> rowtext((size_t)(text_off[tok.aln + 1] - text_off[tok.aln]));
+            if (!rowtext.empty())
+                PAV_HIP(ctx, hipMemcpy(rowtext.data(), ctx->d_text.as<uint8_t>() + text_off[tok.aln], rowtext.size(),
+                                       hipMemcpyDeviceToHost));
+            tok.op_char = tok.op_index < rowtext.size() ? rowtext[tok.op_index] : 0;
+            uint32_t before = 0;
+            for (uint32_t i = 0; i < tok.op_index && i < rowtext.size(); ++i) before += !(rowtext[i] >= '0' && rowtext[i] <= '9');
+            tok_ord = ((uint64_t)tok.aln << 32) | (uint64_t)(before + 1);
+        }
+        if (errs[1] != ~0ull) {
+            const uint64_t k = errs[1];
+            ill.aln = row_of(op_off, k);
+            const uint64_t first = op_off[ill.aln];
+            std::vector<uint32_t> rops((size_t)(k - first + 1));
+            PAV_HIP(ctx, hipMemcpy(rops.data(), ctx->d_ops.as<uint32_t>() + first, sizeof(uint32_t) * rops.size(),
+                                   hipMemcpyDeviceToHost));
+            std::vector<pav_aln> al(1);
+            PAV_HIP(ctx, hipMemcpy(al.data(), ctx->d_aln.as<pav_aln>() + ill.aln, sizeof(pav_aln), hipMemcpyDeviceToHost));
+            uint64_t pr = al[0].pos, pt = 0;
+            for (size_t i = 0; i + 1 < rops.size(); ++i) {
+                const uint32_t c = rops[i] & 15u, l = rops[i] >> 4;
+                if (c == 7 || c == 8 || c == 2) pr += l;
+                if (c == 7 || c == 8 || c == 1 || c == 4 || c == 5) pt += l;
+            }
+            const uint32_t code = rops.back() & 15u;
+            ill.kind = code == 0 ? PAV_CIGAR_ERR_M : PAV_CIGAR_ERR_OP;
+            ill.op_index = (uint32_t)(k - first) + 1;
+            ill.op_char = (uint32_t)"MIDNSHP=X???????"[code];
+            ill.pos_ref = (uint32_t)pr; ill.pos_tig = (uint32_t)pt;
+            ill_ord = ((uint64_t)ill.aln << 32) | (uint64_t)ill.op_index;
+        }
+        ctx->cigar_err = (ill_ord < tok_ord) ? ill : tok;
+        ctx->cigar_called = false;
+        return fail(ctx, PAV_E_CIGAR, "CIGAR error kind %d at alignment row %u", ctx->cigar_err.kind, ctx->cigar_err.aln);
+    }
+    return PAV_OK;
+}
+
+int pav_cigar_error(const pav_ctx *ctx, pav_cigar_err *err) {
+    if (!ctx || !err) return PAV_E_ARG;
+    *err = ctx->cigar_err;
+    return PAV_OK;
+}
+
+int pav_cigar_fetch(pav_ctx *ctx, pav_snv *snv, pav_indel *indel, uint8_t *seq_blob) {
+    if (!ctx) return PAV_E_ARG;
+    if (!ctx->cigar_called) return fail(ctx, PAV_E_STATE, "pav_cigar_fetch: no successful pav_cigar_call to fetch from");
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    if (snv && ctx->counts.n_snv)
+        PAV_HIP(ctx, hipMemcpyAsync(snv, ctx->d_snv.p, sizeof(pav_snv) * ctx->counts.n_snv, hipMemcpyDeviceToHost, ctx->stream));
+    if (indel && ctx->counts.n_indel)
+        PAV_HIP(ctx, hipMemcpyAsync(indel, ctx->d_indel.p, sizeof(pav_indel) * ctx->counts.n_indel, hipMemcpyDeviceToHost, ctx->stream));
+    if (seq_blob && ctx->counts.seq_bytes)
+        PAV_HIP(ctx, hipMemcpyAsync(seq_blob, ctx->d_seqblob.p, ctx->counts.seq_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PAV_OK;
+}
+
+int pav_cigar_fetch_ops(pav_ctx *ctx, uint32_t *ops, uint64_t *op_off) {
+    if (!ctx) return PAV_E_ARG;
+    if (!ctx->cigar_loaded) return fail(ctx, PAV_E_STATE, "pav_cigar_fetch_ops: nothing loaded");
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    if (ops && ctx->n_ops)
+        PAV_HIP(ctx, hipMemcpyAsync(ops, ctx->d_ops.p, sizeof(uint32_t) * ctx->n_ops, hipMemcpyDeviceToHost, ctx->stream));
+    if (op_off)
+        PAV_HIP(ctx, hipMemcpyAsync(op_off, ctx->d_op_off.p, sizeof(uint64_t) * ((size_t)ctx->n_aln + 1), hipMemcpyDeviceToHost, ctx->stream));
+    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PAV_OK;
+}
+
+int pav_homology(pav_ctx *ctx, uint32_t n, const pav_hom_query *q, uint32_t *out) {
+    if (!ctx || (n && (!q || !out))) return PAV_E_ARG;
+    if (!n) return PAV_OK;
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    for (uint32_t i = 0; i < n; ++i) {
+        const pav_hom_query &h = q[i];
+        if (h.role < 0 || h.role > 1 || h.sv_role < 0 || h.sv_role > 1 || h.seq_id < 0 || h.sv_seq_id < 0 ||
+            (uint32_t)h.seq_id >= ctx->seq[h.role].n || (uint32_t)h.sv_seq_id >= ctx->seq[h.sv_role].n)
+            return fail(ctx, PAV_E_ARG, "pav_homology: query %u references a sequence that is not loaded", i);
+    }
+    PAV_HIP(ctx, ctx->d_tmp.reserve(sizeof(pav_hom_query) * n + sizeof(uint32_t) * n + 64));
+    pav_hom_query *dq = ctx->d_tmp.as<pav_hom_query>();
+    uint32_t *dout = reinterpret_cast<uint32_t *>(dq + n);
+    PAV_HIP(ctx, hipMemcpyAsync(dq, q, sizeof(pav_hom_query) * n, hipMemcpyHostToDevice, ctx->stream));
+    PAV_LAUNCH(ctx, "homology_query_kernel", homology_query_kernel, (n + 255) / 256, 256, 0, dq, n,
+               ctx->seq[PAV_ROLE_REF].view(), ctx->seq[PAV_ROLE_TIG].view(), dout);
+    PAV_HIP(ctx, hipMemcpyAsync(out, dout, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
+    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PAV_OK;
+}
+
+}  // extern "C"

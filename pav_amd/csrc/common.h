@@ -1,0 +1,153 @@
+// Internal shared declarations of libpav_amd.so (gfx950 only).  Public ABI: include/pav_amd.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pav_amd.h"
+
+namespace pav {
+
+constexpr int WAVE = 64;                 // CDNA wavefront
+constexpr uint64_t SEQ_ALIGN = 256;      // every record starts on a 256-base boundary of the arena
+
+// ---- grow-only device buffer ------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// ---- sequence store (one per role) ------------------------------------------------------------------------
+struct SeqView {                          // passed by value to kernels
+    const uint8_t *ascii;                 // arena bytes
+    const uint32_t *two;                  // 2-bit plane, 16 bases / word, base i at bits 2*(i&15)
+    const uint32_t *mask;                 // non-ACGT plane, 32 bases / word, base i at bit (i&31)
+    const uint64_t *off;                  // per record: first base in the arena (multiple of SEQ_ALIGN)
+    const uint64_t *len;                  // per record: length
+    uint32_t n;
+};
+
+struct SeqStore {
+    uint32_t n = 0;
+    uint64_t arena = 0;                   // bases incl. padding
+    uint64_t total = 0;                   // bases excl. padding
+    std::vector<uint64_t> off, len;
+    DevBuf d_ascii, d_two, d_mask, d_off, d_len;
+    SeqView view() const {
+        return SeqView{d_ascii.as<uint8_t>(), d_two.as<uint32_t>(), d_mask.as<uint32_t>(),
+                       d_off.as<uint64_t>(), d_len.as<uint64_t>(), n};
+    }
+};
+
+// ---- profiling --------------------------------------------------------------------------------------------
+struct ProfEntry { std::string name; uint64_t launches = 0; double ms = 0.0; };
+struct ProfPending { int entry; hipEvent_t a, b; };
+
+}  // namespace pav
+
+struct pav_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::string err;
+    char dev_name[256] = {0};
+    int n_cu = 0;
+
+    pav::SeqStore seq[2];
+
+    // CIGAR state
+    uint32_t n_aln = 0;
+    uint64_t text_bytes = 0;
+    bool cigar_loaded = false, cigar_called = false;
+    pav_cigar_counts counts{};
+    pav_cigar_err cigar_err{};
+    pav::DevBuf d_aln, d_text, d_text_off, d_ops, d_op_off, d_chunk, d_chunk2, d_rowbase, d_err, d_totals;
+    pav::DevBuf d_snv, d_indel, d_seqblob, d_tmp;
+    uint64_t n_ops = 0;
+
+    // density state lives in density.hip (opaque here)
+    void *density = nullptr;
+
+    // profiling
+    bool prof_on = false;
+    std::vector<pav::ProfEntry> prof;
+    std::vector<pav::ProfPending> prof_pending;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+namespace pav {
+
+extern thread_local std::string g_err;   // pav_last_error(NULL)
+
+int fail(pav_ctx *ctx, int code, const char *fmt, ...);
+
+#define PAV_HIP(ctx, call)                                                                         \
+    do {                                                                                           \
+        hipError_t e__ = (call);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return pav::fail((ctx), PAV_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                             __FILE__, __LINE__);                                                  \
+    } while (0)
+
+// Profiled launch: records a HIP event pair around the launch on ctx->stream when profiling is on.
+int prof_begin(pav_ctx *ctx, const char *name);
+void prof_end(pav_ctx *ctx, int token);
+int prof_flush(pav_ctx *ctx);
+
+#define PAV_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                                      \
+    do {                                                                                           \
+        int tok__ = pav::prof_begin((ctx), name);                                                  \
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (shmem), (ctx)->stream, __VA_ARGS__);  \
+        pav::prof_end((ctx), tok__);                                                               \
+        PAV_HIP((ctx), hipGetLastError());                                                         \
+    } while (0)
+
+// ---- device helpers shared by kernels ---------------------------------------------------------------------
+
+// Base code at oriented position p of record (off,len): 0..3 = A,C,G,T (complemented when rev), 4 = non-ACGT.
+__device__ __forceinline__ uint32_t base_at(const uint32_t *__restrict__ two, const uint32_t *__restrict__ mask,
+                                            uint64_t off, uint64_t len, int rev, int64_t p) {
+    const uint64_t a = off + (uint64_t)(rev ? (int64_t)len - 1 - p : p);
+    const uint32_t m = (mask[a >> 5] >> (a & 31)) & 1u;
+    uint32_t c = (two[a >> 4] >> ((a & 15) * 2)) & 3u;
+    if (rev) c ^= 3u;
+    return m ? 4u : c;
+}
+
+// IUPAC-aware, case-preserving complement of one ASCII base (Bio.Seq.reverse_complement semantics).
+__device__ __forceinline__ uint8_t comp_ascii(uint8_t c) {
+    switch (c) {
+        case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A';
+        case 'a': return 't'; case 'c': return 'g'; case 'g': return 'c'; case 't': return 'a';
+        case 'R': return 'Y'; case 'Y': return 'R'; case 'K': return 'M'; case 'M': return 'K';
+        case 'r': return 'y'; case 'y': return 'r'; case 'k': return 'm'; case 'm': return 'k';
+        case 'B': return 'V'; case 'V': return 'B'; case 'D': return 'H'; case 'H': return 'D';
+        case 'b': return 'v'; case 'v': return 'b'; case 'd': return 'h'; case 'h': return 'd';
+        case 'U': return 'A'; case 'u': return 'a';
+        default: return c;                     // S, W, N and anything else map to themselves
+    }
+}
+
+__device__ __forceinline__ uint8_t ascii_at(const uint8_t *__restrict__ ascii, uint64_t off, uint64_t len, int rev,
+                                            int64_t p) {
+    if (rev) return comp_ascii(ascii[off + (uint64_t)((int64_t)len - 1 - p)]);
+    return ascii[off + (uint64_t)p];
+}
+
+}  // namespace pav

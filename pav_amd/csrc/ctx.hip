@@ -1,0 +1,267 @@
+// Context, sequence store (ASCII arena -> 2-bit + non-ACGT planes) and HIP-event profiling.
+// gfx950 only; public ABI in include/pav_amd.h.
+#include "common.h"
+
+namespace pav {
+
+thread_local std::string g_err;
+
+int fail(pav_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    g_err = buf;
+    return code;
+}
+
+// ---- profiling ------------------------------------------------------------------------------------------
+int prof_begin(pav_ctx *ctx, const char *name) {
+    if (!ctx->prof_on) return -1;
+    int entry = -1;
+    for (size_t i = 0; i < ctx->prof.size(); ++i)
+        if (ctx->prof[i].name == name) { entry = (int)i; break; }
+    if (entry < 0) { ctx->prof.push_back(ProfEntry{name, 0, 0.0}); entry = (int)ctx->prof.size() - 1; }
+    hipEvent_t a, b;
+    if (ctx->ev_pool.size() >= 2) {
+        a = ctx->ev_pool.back(); ctx->ev_pool.pop_back();
+        b = ctx->ev_pool.back(); ctx->ev_pool.pop_back();
+    } else {
+        if (hipEventCreate(&a) != hipSuccess) return -1;
+        if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return -1; }
+    }
+    (void)hipEventRecord(a, ctx->stream);
+    ctx->prof_pending.push_back(ProfPending{entry, a, b});
+    return (int)ctx->prof_pending.size() - 1;
+}
+
+void prof_end(pav_ctx *ctx, int token) {
+    if (token < 0) return;
+    (void)hipEventRecord(ctx->prof_pending[(size_t)token].b, ctx->stream);
+}
+
+int prof_flush(pav_ctx *ctx) {
+    if (ctx->prof_pending.empty()) return PAV_OK;
+    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &p : ctx->prof_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            ctx->prof[(size_t)p.entry].launches += 1;
+            ctx->prof[(size_t)p.entry].ms += (double)ms;
+        }
+        ctx->ev_pool.push_back(p.a);
+        ctx->ev_pool.push_back(p.b);
+    }
+    ctx->prof_pending.clear();
+    return PAV_OK;
+}
+
+// ---- pack kernel ----------------------------------------------------------------------------------------
+// One lane packs 16 bases (one 16-byte load): a u32 of 2-bit codes and 16 non-ACGT bits; lane pairs merge
+// their halves of the 32-base mask word with one cross-lane move.  Pure streaming: 1 B/base in,
+// 0.25 + 0.125 B/base out; HBM-bound.
+__device__ __forceinline__ void pack4(uint32_t x, uint32_t &codes8, uint32_t &bad4) {
+    const uint32_t t = ((x >> 1) ^ (x >> 2)) & 0x03030303u;          // A0 C1 G2 T3, either case
+    uint32_t c = t | (t >> 6);
+    codes8 = (c | (c >> 12)) & 0xFFu;
+    const uint32_t lo = t & 0x01010101u, hi = (t >> 1) & 0x01010101u, both = lo & hi;
+    const uint32_t expect = 0x41414141u + lo * 2u + hi * 6u + both * 11u;   // 'A','C','G','T' for the code
+    const uint32_t d = (x & 0xDFDFDFDFu) ^ expect;                    // non-zero byte <=> not ACGT/acgt
+    uint32_t nz = ((((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u) >> 7;
+    bad4 = (nz | (nz >> 7) | (nz >> 14) | (nz >> 21)) & 0xFu;
+}
+
+__global__ __launch_bounds__(256) void pack_kernel(const uint4 *__restrict__ ascii, uint32_t *__restrict__ two,
+                                                   uint32_t *__restrict__ mask, uint64_t n16) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        const uint4 v = ascii[i];
+        uint32_t c0, c1, c2, c3, b0, b1, b2, b3;
+        pack4(v.x, c0, b0); pack4(v.y, c1, b1); pack4(v.z, c2, b2); pack4(v.w, c3, b3);
+        two[i] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+        const uint32_t m16 = b0 | (b1 << 4) | (b2 << 8) | (b3 << 12);
+        const uint32_t other = __shfl_xor(m16, 1);                    // n16 is even: the partner always exists
+        if ((threadIdx.x & 1) == 0) mask[i >> 1] = m16 | (other << 16);
+    }
+}
+
+static int run_pack(pav_ctx *ctx, SeqStore &s) {
+    if (s.arena == 0) return PAV_OK;
+    const uint64_t n16 = s.arena / 16;
+    uint64_t blocks = (n16 + 255) / 256;
+    const uint64_t cap = (uint64_t)ctx->n_cu * 8;
+    if (blocks > cap) blocks = cap;
+    PAV_LAUNCH(ctx, "pack_kernel", pack_kernel, (uint32_t)blocks, 256, 0, s.d_ascii.as<uint4>(),
+               s.d_two.as<uint32_t>(), s.d_mask.as<uint32_t>(), n16);
+    return PAV_OK;
+}
+
+}  // namespace pav
+
+using namespace pav;
+
+extern "C" {
+
+int pav_abi_version(void) { return PAV_ABI_VERSION; }
+
+int pav_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *pav_last_error(const pav_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+pav_ctx *pav_create(int device_id) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        fail(nullptr, PAV_E_NODEV, "no HIP device visible (%s): libpav_amd has no CPU fallback",
+             e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        return nullptr;
+    }
+    if (device_id < 0 || device_id >= n) {
+        fail(nullptr, PAV_E_ARG, "device_id %d out of range [0, %d)", device_id, n);
+        return nullptr;
+    }
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) {
+        fail(nullptr, PAV_E_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+        return nullptr;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fail(nullptr, PAV_E_NODEV, "device %d is %s; libpav_amd is built for gfx950 (MI355X) only", device_id,
+             prop.gcnArchName);
+        return nullptr;
+    }
+    pav_ctx *ctx = new pav_ctx();
+    ctx->device = device_id;
+    ctx->n_cu = prop.multiProcessorCount;
+    snprintf(ctx->dev_name, sizeof ctx->dev_name, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, ctx->n_cu);
+    if ((e = hipSetDevice(device_id)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+        fail(nullptr, PAV_E_HIP, "device init: %s", hipGetErrorString(e));
+        delete ctx;
+        return nullptr;
+    }
+    return ctx;
+}
+
+void pav_density_release(pav_ctx *ctx);   // density.hip
+
+void pav_destroy(pav_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    pav_density_release(ctx);
+    for (auto &p : ctx->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto ev : ctx->ev_pool) (void)hipEventDestroy(ev);
+    for (int r = 0; r < 2; ++r) {
+        SeqStore &s = ctx->seq[r];
+        s.d_ascii.release(); s.d_two.release(); s.d_mask.release(); s.d_off.release(); s.d_len.release();
+    }
+    DevBuf *bufs[] = {&ctx->d_aln, &ctx->d_text, &ctx->d_text_off, &ctx->d_ops, &ctx->d_op_off, &ctx->d_chunk,
+                      &ctx->d_chunk2, &ctx->d_rowbase, &ctx->d_err, &ctx->d_totals, &ctx->d_snv, &ctx->d_indel,
+                      &ctx->d_seqblob, &ctx->d_tmp};
+    for (DevBuf *b : bufs) b->release();
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int pav_device_name(const pav_ctx *ctx, char *buf, int buf_len) {
+    if (!ctx || !buf || buf_len <= 0) return PAV_E_ARG;
+    snprintf(buf, (size_t)buf_len, "%s", ctx->dev_name);
+    return PAV_OK;
+}
+
+int pav_sync(pav_ctx *ctx) {
+    if (!ctx) return PAV_E_ARG;
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PAV_OK;
+}
+
+int pav_seq_load(pav_ctx *ctx, int role, uint32_t n_seq, const uint8_t *const *ascii, const uint64_t *len) {
+    if (!ctx || (role != PAV_ROLE_REF && role != PAV_ROLE_TIG)) return fail(ctx, PAV_E_ARG, "pav_seq_load: bad role");
+    if (n_seq && (!ascii || !len)) return fail(ctx, PAV_E_ARG, "pav_seq_load: null input");
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    SeqStore &s = ctx->seq[role];
+    s.n = n_seq;
+    s.off.assign(n_seq, 0);
+    s.len.assign(len, len + n_seq);
+    uint64_t a = 0, total = 0;
+    for (uint32_t i = 0; i < n_seq; ++i) {
+        if (len[i] >= 0xFFFFFF00ull)
+            return fail(ctx, PAV_E_LIMIT, "pav_seq_load: record %u has %llu bases (limit 2^32 - 256)", i,
+                        (unsigned long long)len[i]);
+        s.off[i] = a;
+        a += (len[i] + SEQ_ALIGN - 1) / SEQ_ALIGN * SEQ_ALIGN + SEQ_ALIGN;   // one pad block between records
+        total += len[i];
+    }
+    s.arena = a;
+    s.total = total;
+    if (a == 0) return PAV_OK;
+    PAV_HIP(ctx, s.d_ascii.reserve(a));
+    PAV_HIP(ctx, s.d_two.reserve(a / 4));
+    PAV_HIP(ctx, s.d_mask.reserve(a / 8));
+    PAV_HIP(ctx, s.d_off.reserve(sizeof(uint64_t) * n_seq));
+    PAV_HIP(ctx, s.d_len.reserve(sizeof(uint64_t) * n_seq));
+    PAV_HIP(ctx, hipMemsetAsync(s.d_ascii.p, 'N', a, ctx->stream));          // padding reads as non-ACGT
+    for (uint32_t i = 0; i < n_seq; ++i)
+        if (len[i])
+            PAV_HIP(ctx, hipMemcpyAsync(s.d_ascii.as<uint8_t>() + s.off[i], ascii[i], len[i], hipMemcpyHostToDevice,
+                                        ctx->stream));
+    PAV_HIP(ctx, hipMemcpyAsync(s.d_off.p, s.off.data(), sizeof(uint64_t) * n_seq, hipMemcpyHostToDevice, ctx->stream));
+    PAV_HIP(ctx, hipMemcpyAsync(s.d_len.p, s.len.data(), sizeof(uint64_t) * n_seq, hipMemcpyHostToDevice, ctx->stream));
+    int rc = run_pack(ctx, s);
+    if (rc != PAV_OK) return rc;
+    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));   // inputs are borrowed only for the duration of the call
+    if (role == PAV_ROLE_TIG || role == PAV_ROLE_REF) { ctx->cigar_called = false; }
+    return PAV_OK;
+}
+
+int pav_seq_pack(pav_ctx *ctx, int role) {
+    if (!ctx || (role != PAV_ROLE_REF && role != PAV_ROLE_TIG)) return fail(ctx, PAV_E_ARG, "pav_seq_pack: bad role");
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    return run_pack(ctx, ctx->seq[role]);
+}
+
+int pav_seq_count(const pav_ctx *ctx, int role, uint32_t *n_seq, uint64_t *total_bases) {
+    if (!ctx || (role != PAV_ROLE_REF && role != PAV_ROLE_TIG)) return PAV_E_ARG;
+    if (n_seq) *n_seq = ctx->seq[role].n;
+    if (total_bases) *total_bases = ctx->seq[role].total;
+    return PAV_OK;
+}
+
+int pav_prof_enable(pav_ctx *ctx, int on) {
+    if (!ctx) return PAV_E_ARG;
+    int rc = prof_flush(ctx);
+    ctx->prof_on = on != 0;
+    return rc;
+}
+
+int pav_prof_reset(pav_ctx *ctx) {
+    if (!ctx) return PAV_E_ARG;
+    int rc = prof_flush(ctx);
+    ctx->prof.clear();
+    return rc;
+}
+
+int pav_prof_count(pav_ctx *ctx) {
+    if (!ctx) return PAV_E_ARG;
+    if (prof_flush(ctx) != PAV_OK) return PAV_E_HIP;
+    return (int)ctx->prof.size();
+}
+
+int pav_prof_get(pav_ctx *ctx, int i, char *name, int name_len, uint64_t *launches, double *total_ms) {
+    if (!ctx || i < 0 || (size_t)i >= ctx->prof.size()) return PAV_E_ARG;
+    const ProfEntry &e = ctx->prof[(size_t)i];
+    if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s", e.name.c_str());
+    if (launches) *launches = e.launches;
+    if (total_ms) *total_ms = e.ms;
+    return PAV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,341 @@
+"""
+Deterministic synthetic workloads for tests and bench.py (SURVEY.md section 8(d) profile).
+
+PAV ships no generator or test data; everything here is this repo's own workload
+tooling.  The per-base work (random soft-masked sequence, contig mutation with a base-exact =/X/I/D/H CIGAR)
+is plain C in ``csrc/synth.c`` (``lib/libpavsynth.so``); this module plans segments, inversions, flagged
+regions and produces the tables in the reference's file schemas:
+
+* alignment BED columns: API_ALIGN.md:33-57 (``CALL_BATCH = INDEX % 10``: rules/align.snakefile:163)
+* flagged-region BED columns: rules/call_inv.snakefile:420-470
+
+Seeds follow SURVEY.md: config ``n`` uses seed ``1000 + n``; haplotype ``h`` uses ``seed * 64 + h``.
+"""
+
+import ctypes
+import gzip
+import os
+from concurrent.futures import ThreadPoolExecutor
+from dataclasses import dataclass, field
+
+import numpy as np
+import pandas as pd
+
+_LIB = None
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libpavsynth.so')
+        if not os.path.exists(path):
+            raise RuntimeError(f'{path} is missing: run `python -c "import __graft_entry__ as g; g.build()"` first')
+        lib = ctypes.CDLL(path)
+        lib.pavsynth_random_seq.argtypes = [ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_double]
+        lib.pavsynth_random_seq.restype = ctypes.c_int
+        lib.pavsynth_revcomp.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
+        lib.pavsynth_revcomp.restype = None
+        lib.pavsynth_contig.argtypes = [
+            ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
+            ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int,
+            ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
+            ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+        lib.pavsynth_contig.restype = ctypes.c_int
+        _LIB = lib
+    return _LIB
+
+
+class _Params(ctypes.Structure):
+    _fields_ = [('snv_rate', ctypes.c_double), ('indel_rate', ctypes.c_double),
+                ('pareto_alpha', ctypes.c_double), ('max_indel', ctypes.c_uint32),
+                ('tandem_frac', ctypes.c_double), ('clip', ctypes.c_uint32)]
+
+
+# hg38 no-ALT primary assembly lengths (chr1..22, X, Y); T2T-CHM13v2.0 lengths.
+HG38_LENGTHS = {
+    'chr1': 248956422, 'chr2': 242193529, 'chr3': 198295559, 'chr4': 190214555, 'chr5': 181538259,
+    'chr6': 170805979, 'chr7': 159345973, 'chr8': 145138636, 'chr9': 138394717, 'chr10': 133797422,
+    'chr11': 135086622, 'chr12': 133275309, 'chr13': 114364328, 'chr14': 107043718, 'chr15': 101991189,
+    'chr16': 90338345, 'chr17': 83257441, 'chr18': 80373285, 'chr19': 58617616, 'chr20': 64444167,
+    'chr21': 46709983, 'chr22': 50818468, 'chrX': 156040895, 'chrY': 57227415,
+}
+CHM13_LENGTHS = {
+    'chr1': 248387328, 'chr2': 242696752, 'chr3': 201105948, 'chr4': 193574945, 'chr5': 182045439,
+    'chr6': 172126628, 'chr7': 160567428, 'chr8': 146259331, 'chr9': 150617247, 'chr10': 134758134,
+    'chr11': 135127769, 'chr12': 133324548, 'chr13': 113566686, 'chr14': 101161492, 'chr15': 99753195,
+    'chr16': 96330374, 'chr17': 84276897, 'chr18': 80542538, 'chr19': 61707364, 'chr20': 66210255,
+    'chr21': 45090682, 'chr22': 51324926, 'chrX': 154259566, 'chrY': 62460029,
+}
+
+_COMP = np.arange(256, dtype=np.uint8)
+for _a, _b in zip(b'ACGTRYSWKMBDHVNUacgtryswkmbdhvnu', b'TGCAYRSWMKVHDBNAtgcayrswmkvhdbna'):
+    _COMP[_a] = _b
+
+
+def revcomp(arr):
+    """IUPAC-aware, case-preserving reverse complement of a uint8 ASCII array."""
+    return _COMP[arr[::-1]]
+
+
+@dataclass
+class Inversion:
+    chrom: str
+    pos: int          # inverted interval [pos, end) on the reference (includes inverted-repeat flanks)
+    end: int
+    repeat: int       # length of each inverted-repeat flank (0 = none)
+
+
+@dataclass
+class Reference:
+    names: list
+    seqs: dict                     # name -> np.uint8 ASCII
+    inversions: list = field(default_factory=list)
+
+    @property
+    def lengths(self):
+        return {n: int(self.seqs[n].shape[0]) for n in self.names}
+
+
+@dataclass
+class Haplotype:
+    hap: str
+    ref: Reference
+    tig_names: list
+    tig_seqs: dict                 # name -> np.uint8 ASCII (stored orientation)
+    df_align: pd.DataFrame         # trim-none alignment BED
+    df_trim: pd.DataFrame          # trim-tigref alignment BED
+    df_flag: pd.DataFrame          # flagged regions
+    stats: dict
+
+    @property
+    def tig_lengths(self):
+        return pd.Series({n: int(self.tig_seqs[n].shape[0]) for n in self.tig_names}, dtype=np.int64)
+
+
+def make_reference(seed, lengths, case_run=300.0, n_every=50_000_000, n_len=10_000,
+                   inv_every=25_000_000, inv_min=2_000, inv_max=200_000, threads=8):
+    """Random soft-masked reference with N runs and planted inverted repeats for half the inversion loci."""
+    lib = _lib()
+    names = list(lengths)
+    seqs = {n: np.empty(int(lengths[n]), dtype=np.uint8) for n in names}
+
+    def fill(i):
+        n = names[i]
+        lib.pavsynth_random_seq(seed * 1000003 + i, seqs[n].ctypes.data, seqs[n].shape[0], float(case_run))
+
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(fill, range(len(names))))
+
+    rng = np.random.default_rng(seed)
+    inversions = []
+    for n in names:
+        L = seqs[n].shape[0]
+        # N runs
+        n_runs = int(L // n_every) if n_every else 0
+        for _ in range(n_runs):
+            p = int(rng.integers(0, max(1, L - n_len)))
+            seqs[n][p:p + n_len] = ord('N')
+        # inversions
+        n_inv = int(L // inv_every) if inv_every else 0
+        taken = []
+        for _ in range(n_inv):
+            ln = int(np.exp(rng.uniform(np.log(inv_min), np.log(inv_max))))
+            rep = 0
+            if rng.random() < 0.5:
+                rep = int(rng.integers(500, 5001))
+                rep = min(rep, ln // 4)
+            margin = 3 * ln + 20_000
+            if L < ln + 2 * margin:
+                continue
+            p = int(rng.integers(margin, L - ln - margin))
+            if any(p < e + margin and s < p + ln + margin for s, e in taken):
+                continue
+            if np.any(seqs[n][p - 10_000:p + ln + 10_000] == ord('N')):
+                continue
+            taken.append((p, p + ln))
+            if rep:
+                seqs[n][p + ln - rep:p + ln] = revcomp(seqs[n][p:p + rep])
+            inversions.append(Inversion(n, p, p + ln, rep))
+    inversions.sort(key=lambda v: (names.index(v.chrom), v.pos))
+    return Reference(names, seqs, inversions)
+
+
+def _plan_segments(rng, L, median, sigma, cap, zones=(), gap_min=1_000, gap_max=10_000, min_len=2_000):
+    """Tile [0, L) with non-overlapping aligned segments separated by small unaligned gaps.
+
+    ``zones`` are [start, end) intervals (an inversion plus the flank its scan may expand into) that no
+    segment boundary may cut: a boundary falling inside one is pushed past its end.
+    """
+    def push(x):
+        for zs, ze in zones:
+            if zs <= x < ze:
+                return ze
+        return x
+
+    segs = []
+    p = push(int(rng.integers(0, gap_max)))
+    while p < L - min_len:
+        ln = int(min(cap, max(min_len, rng.lognormal(np.log(median), sigma))))
+        e = min(L, push(p + ln))
+        if e - p >= min_len:
+            segs.append((p, e))
+        p = push(e + int(rng.integers(gap_min, gap_max)))
+    return segs
+
+
+def make_haplotype(ref, seed, hap='h1', snv_rate=1.0e-3, indel_rate=2.0e-4, pareto_alpha=1.2, max_indel=5000,
+                   tandem_frac=0.5, clip=100, seg_median=1_000_000, seg_sigma=1.4, seg_cap=150_000_000,
+                   rev_frac=0.5, decoys_per_inv=9, min_decoys=0, flag_batches=60, threads=8, segments=None):
+    """One haplotype: contigs, alignment BEDs (trim-none and trim-tigref) and flagged regions."""
+    lib = _lib()
+    rng = np.random.default_rng(seed)
+    params = _Params(snv_rate, indel_rate, pareto_alpha, max_indel, tandem_frac, clip)
+
+    # Plan alignment rows: (chrom, pos, end, rev, inversions inside)
+    plan = []
+    for n in ref.names:
+        L = ref.seqs[n].shape[0]
+        invs = [v for v in ref.inversions if v.chrom == n]
+        zones = [(max(0, v.pos - 3 * (v.end - v.pos) - 20_000), min(L, v.end + 3 * (v.end - v.pos) + 20_000))
+                 for v in invs]
+        segs = segments[n] if segments is not None and n in segments else \
+            _plan_segments(rng, L, seg_median, seg_sigma, seg_cap, zones)
+        for s, e in segs:
+            inside = [v for v, (zs, ze) in zip(invs, zones) if s <= zs and ze <= e]
+            plan.append((n, s, e, bool(rng.random() < rev_frac), inside))
+
+    n_rows = len(plan)
+    tig_names = [f'tig{i:06d}' for i in range(n_rows)]
+    tig_seqs = [None] * n_rows
+    cigars = [None] * n_rows
+    counts = np.zeros((n_rows, 6), dtype=np.uint64)
+
+    def build(i):
+        chrom, s, e, rev, inside = plan[i]
+        seg = ref.seqs[chrom][s:e]
+        L = e - s
+        cap_t = int(L * 1.02) + 2 * clip + 200_000
+        cap_c = max(4096, int(L * (snv_rate + indel_rate) * 40) + 16 * sum(v.end - v.pos for v in inside) + 65536)
+        inv_arr = np.asarray([x for v in inside for x in (v.pos - s, v.end - s)], dtype=np.uint64)
+        while True:
+            tig = np.empty(cap_t, dtype=np.uint8)
+            cig = ctypes.create_string_buffer(cap_c)
+            tl = ctypes.c_uint64(0)
+            rc = lib.pavsynth_contig(
+                seed * 1000003 + i, seg.ctypes.data, L, ctypes.byref(params),
+                inv_arr.ctypes.data if inv_arr.size else None, len(inside), int(rev),
+                tig.ctypes.data, cap_t, ctypes.byref(tl), cig, cap_c, counts[i].ctypes.data)
+            if rc == 0:
+                break
+            cap_t *= 2
+            cap_c *= 2
+        tig_seqs[i] = tig[:tl.value].copy()
+        cigars[i] = cig.value.decode()
+
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(build, range(n_rows)))
+
+    rows = []
+    for i, (chrom, s, e, rev, inside) in enumerate(plan):
+        tl = int(tig_seqs[i].shape[0])
+        rows.append((chrom, s, e, i, tig_names[i], clip, tl - clip, tl, 'NA', 'NA', 60, rev,
+                     '0x0010' if rev else '0x0000', hap, cigars[i], i % 10))
+    df_align = pd.DataFrame(rows, columns=[
+        '#CHROM', 'POS', 'END', 'INDEX', 'QRY_ID', 'QRY_POS', 'QRY_END', 'QRY_LEN', 'RG', 'AO', 'MAPQ', 'REV',
+        'FLAGS', 'HAP', 'CIGAR', 'CALL_BATCH'])
+    # get_align_bed order: pavlib/align/align.py:786
+    chrom_rank = {n: k for k, n in enumerate(sorted(ref.names))}
+    df_align = df_align.iloc[np.lexsort((df_align['QRY_ID'].values, -df_align['END'].values,
+                                         df_align['POS'].values,
+                                         df_align['#CHROM'].map(chrom_rank).values))].reset_index(drop=True)
+
+    # trim-tigref: same rows; every 7th row loses a few flank bases (exercises FILTER=TRIM), every 13th row is
+    # dropped (reindex fill -1 => TRIM, rules/call.snakefile:813-842).
+    df_trim = df_align.copy()
+    for c in ('TRIM_REF_L', 'TRIM_REF_R', 'TRIM_QRY_L', 'TRIM_QRY_R'):
+        df_trim[c] = 0
+    # Only the POS/END columns are consumed on the hot path (call.snakefile:813); shrink them directly.
+    shrink = (df_trim['INDEX'] % 7 == 3)
+    df_trim.loc[shrink, 'POS'] += 700
+    df_trim.loc[shrink, 'END'] -= 900
+    df_trim.loc[shrink, 'TRIM_REF_L'] = 700
+    df_trim.loc[shrink, 'TRIM_REF_R'] = 900
+    df_trim = df_trim.loc[df_trim['INDEX'] % 13 != 11].reset_index(drop=True)
+
+    # Flagged regions: planted inversions + decoys
+    flag = []
+    for (chrom, s, e, rev, inside) in plan:
+        for v in inside:
+            flag.append((chrom, v.pos, v.end, 'CLUSTER_SNV'))
+    n_decoy = max(min_decoys, decoys_per_inv * len(flag))
+    for _ in range(n_decoy):
+        chrom, s, e, rev, inside = plan[int(rng.integers(0, n_rows))]
+        ln = int(rng.integers(500, 5001))
+        if e - s <= ln + 2:
+            continue
+        p = int(rng.integers(s, e - ln))
+        flag.append((chrom, p, p + ln, 'CLUSTER_INDEL,MATCH_INDEL'))
+    flag.sort(key=lambda t: (chrom_rank[t[0]], t[1]))
+    df_flag = pd.DataFrame(
+        [(c, p, e, f'{c}-{p}-RGN-{e - p}', 'RGN', e - p, t, 0, 0, True, k % flag_batches)
+         for k, (c, p, e, t) in enumerate(flag)],
+        columns=['#CHROM', 'POS', 'END', 'ID', 'SVTYPE', 'SVLEN', 'TYPE', 'COUNT_INDEL', 'COUNT_SNV', 'TRY_INV',
+                 'BATCH'])
+
+    stats = dict(n_aln=n_rows, n_ops=int(counts[:, 0].sum()), n_snv=int(counts[:, 1].sum()),
+                 n_ins=int(counts[:, 2].sum()), n_del=int(counts[:, 3].sum()),
+                 aligned_bp=int(counts[:, 4].sum()), n_inv=sum(len(p[4]) for p in plan), n_flag=len(flag))
+    return Haplotype(hap, ref, tig_names, dict(zip(tig_names, tig_seqs)), df_align, df_trim, df_flag, stats)
+
+
+def write_fasta(path, names, seqs, line=0):
+    """Write FASTA (+ .fai).  ``line=0`` writes each record on one line.  ``.gz`` paths are gzip'd."""
+    opener = gzip.open if path.endswith('.gz') else open
+    off = 0
+    fai = []
+    with opener(path, 'wb') as fh:
+        for n in names:
+            hdr = f'>{n}\n'.encode()
+            fh.write(hdr)
+            off += len(hdr)
+            s = seqs[n]
+            L = int(s.shape[0])
+            w = L if not line else line
+            fai.append(f'{n}\t{L}\t{off}\t{w}\t{w + 1}\n')
+            if not line:
+                fh.write(s.tobytes())
+                fh.write(b'\n')
+                off += L + 1
+            else:
+                for i in range(0, L, line):
+                    fh.write(s[i:i + line].tobytes())
+                    fh.write(b'\n')
+                off += L + (L + line - 1) // line
+    with open(path + '.fai', 'w') as fh:
+        fh.writelines(fai)
+
+
+def scaled_lengths(lengths, scale):
+    return {n: max(20_000, int(L * scale)) for n, L in lengths.items()}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Config presets (BASELINE.json:configs, restated in SURVEY.md section 8(d))
+# ---------------------------------------------------------------------------------------------------------
+
+def config1(seed=1001):
+    """One 1 Mb contig vs a 1 Mb "chr20 slice"; 1 row, ~2.4 k ops (plumbing case)."""
+    ref = make_reference(seed, {'chr20': 1_000_000}, n_every=0, inv_every=0, threads=1)
+    hap = make_haplotype(ref, seed * 64, 'h1', segments={'chr20': [(0, 1_000_000)]}, rev_frac=0.0, threads=1,
+                         min_decoys=0)
+    return hap
+
+
+def config2(seed=1002, scale=1.0, hap_index=0, ref=None, lengths=None, threads=8, **kw):
+    """One haplotype vs an hg38-shaped reference (24 sequences); ``scale`` shrinks every length."""
+    if ref is None:
+        ref = make_reference(seed, scaled_lengths(lengths or HG38_LENGTHS, scale), threads=threads,
+                             n_every=int(50_000_000 * max(scale, 0.02)) if scale < 1 else 50_000_000,
+                             inv_every=int(25_000_000 * max(scale, 0.02)) if scale < 1 else 25_000_000)
+    med = max(20_000, int(1_000_000 * min(1.0, scale * 10)))
+    return make_haplotype(ref, seed * 64 + hap_index, f'h{hap_index + 1}', seg_median=med, threads=threads, **kw)

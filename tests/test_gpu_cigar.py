@@ -1,0 +1,175 @@
+"""GPU parity tests of the CIGAR-call path: device (through the C ABI) vs golden vectors and vs the CPU oracle."""
+import numpy as np
+import pytest
+
+import util
+from pav_amd import _lib, cigarcall, rules, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _load_case(ctx, d):
+    ref_fa, tig_fa = util.seq_arrays(d, None)
+    ctx.seq_load(_lib.PAV_ROLE_REF, ref_fa.names, [ref_fa[n] for n in ref_fa.names])
+    ctx.seq_load(_lib.PAV_ROLE_TIG, tig_fa.names, [tig_fa[n] for n in tig_fa.names])
+    return ref_fa, tig_fa
+
+
+def test_homology_known_answers(built, gpu_ctx):
+    """pavlib/call.py:542-647 known answers through pav_homology (sequences upper-cased as the caller does)."""
+    kats = [k for k in util.kat()['homology'] if len(k['seq']) > 0 and len(k['sv']) > 0]
+    seqs, index = [], {}
+    for k in kats:
+        for s in (k['seq'], k['sv']):
+            if s not in index:
+                index[s] = len(seqs)
+                seqs.append(np.frombuffer(s.encode(), dtype=np.uint8))
+    gpu_ctx.seq_load(_lib.PAV_ROLE_REF, [str(i) for i in range(len(seqs))], seqs)
+    q = np.zeros(len(kats), dtype=_lib.HOM_QUERY_DTYPE)
+    for i, k in enumerate(kats):
+        q[i]['role'] = q[i]['sv_role'] = _lib.PAV_ROLE_REF
+        q[i]['seq_id'] = index[k['seq']]
+        q[i]['sv_seq_id'] = index[k['sv']]
+        q[i]['pos'] = k['pos']
+        q[i]['svlen'] = len(k['sv'])
+        q[i]['dir'] = 0 if k['dir'] == 'L' else 1
+    out = gpu_ctx.homology(q)
+    for i, k in enumerate(kats):
+        # the reference functions never match lower case; the device folds case like the caller's .upper()
+        expect = k['value'] if k['seq'] == k['seq'].upper() else None
+        if expect is not None:
+            assert int(out[i]) == expect, k
+
+
+def test_homology_reverse_view(built, gpu_ctx):
+    """rev=1 views a record reverse-complemented in place (pavlib/cigarcall.py:69-70)."""
+    from oracle import oracle
+    rng = np.random.default_rng(5)
+    seqs = [''.join('ACGTN'[i] for i in rng.choice(5, 200, p=[.24, .24, .24, .24, .04])) for _ in range(8)]
+    comp = str.maketrans('ACGTN', 'TGCAN')
+    gpu_ctx.seq_load(_lib.PAV_ROLE_TIG, [str(i) for i in range(8)], [np.frombuffer(s.encode(), np.uint8) for s in seqs])
+    q = np.zeros(400, dtype=_lib.HOM_QUERY_DTYPE)
+    expect = []
+    for i in range(400):
+        a, b = int(rng.integers(0, 8)), int(rng.integers(0, 8))
+        ra, rb = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        sa = seqs[a].translate(comp)[::-1] if ra else seqs[a]
+        sb = seqs[b].translate(comp)[::-1] if rb else seqs[b]
+        svlen = int(rng.integers(1, 12))
+        sv_pos = int(rng.integers(0, 200 - svlen))
+        pos = int(rng.integers(-1, 200))
+        d = int(rng.integers(0, 2))
+        # plant homology half of the time
+        q[i] = (1, a, ra, 0, pos, 1, b, rb, 0, sv_pos, svlen, d)
+        f = oracle.left_homology if d == 0 else oracle.right_homology
+        expect.append(f(pos, sa, sb[sv_pos:sv_pos + svlen]))
+    out = gpu_ctx.homology(q)
+    assert [int(x) for x in out] == expect
+
+
+@pytest.mark.parametrize('case', ['cigar_synth', 'cigar_edge'])
+def test_tables_byte_exact_vs_reference(built, gpu_ctx, case):
+    """Device output formatted by the host mirror == the TSV text the reference rule wrote."""
+    d, df_align, df_trim = util.golden_case(case)
+    _load_case(gpu_ctx, d)
+    snv, indel, blob, counts = cigarcall.call_records(gpu_ctx, df_align)
+    df_snv, df_insdel = cigarcall.records_to_frames(snv, indel, blob, df_align, 'h1')
+    df_snv = rules.apply_trim_filter(df_snv, df_trim)
+    df_insdel = rules.apply_trim_filter(df_insdel, df_trim)
+    assert util.frame_text(df_snv) == util.golden_text(case, 'snv')
+    assert util.frame_text(df_insdel) == util.golden_text(case, 'insdel')
+
+
+def test_public_entry_point(built, gpu_ctx, tmp_path):
+    """make_insdel_snv_calls / rules.call_cigar: the drop-in surface, from files, all 10 batches merged."""
+    d, df_align, df_trim = util.golden_case('cigar_synth')
+    ins, snvs = [], []
+    for batch in range(10):
+        o1, o2 = str(tmp_path / f'insdel_{batch}.bed.gz'), str(tmp_path / f'snv_{batch}.bed.gz')
+        rules.call_cigar(f'{d}/align.tsv', f'{d}/trim.tsv', f'{d}/tig.fa', f'{d}/ref.fa', 'h1', batch, o1, o2, ctx=gpu_ctx)
+        ins.append(o1)
+        snvs.append(o2)
+    df_snv, df_insdel = rules.call_cigar_merge(ins, snvs)
+    import io
+    import pandas as pd
+    g_snv = pd.read_csv(io.StringIO(util.golden_text('cigar_synth', 'snv')), sep='\t', keep_default_na=False)
+    g_ins = pd.read_csv(io.StringIO(util.golden_text('cigar_synth', 'insdel')), sep='\t', keep_default_na=False)
+    assert util.frame_text(df_insdel) == util.frame_text(g_ins.sort_values(['#CHROM', 'POS', 'END', 'ID']))
+    assert util.frame_text(df_snv.sort_values(['#CHROM', 'POS', 'END', 'ID'])) == \
+        util.frame_text(g_snv.sort_values(['#CHROM', 'POS', 'END', 'ID']))
+
+
+def test_empty_table(built, gpu_ctx):
+    d, df_align, _ = util.golden_case('cigar_empty')
+    _load_case(gpu_ctx, d)
+    snv, indel, blob, counts = cigarcall.call_records(gpu_ctx, df_align)
+    df_snv, df_insdel = cigarcall.records_to_frames(snv, indel, blob, df_align, 'h1')
+    assert util.frame_text(df_snv) == util.golden_text('cigar_empty', 'snv')
+    assert util.frame_text(df_insdel) == util.golden_text('cigar_empty', 'insdel')
+
+
+def test_error_cases(built, gpu_ctx):
+    """Illegal / malformed CIGARs raise the reference's exception type and message, first error in walk order."""
+    d, df_align, _ = util.golden_case('cigar_edge')
+    _load_case(gpu_ctx, d)
+    for e in util.cigar_errors():
+        df = df_align.copy()
+        for idx, cig in e['edits'].items():
+            df.loc[df['INDEX'] == int(idx), 'CIGAR'] = cig
+        with pytest.raises((RuntimeError, IndexError)) as ei:
+            cigarcall.call_records(gpu_ctx, df)
+        assert type(ei.value).__name__ == e['type'], e['label']
+        assert str(ei.value) == e['message'], e['label']
+
+
+def test_tokenizer_matches_oracle(built, gpu_ctx):
+    d, df_align, _ = util.golden_case('cigar_synth')
+    _load_case(gpu_ctx, d)
+    snv, indel, blob, counts = cigarcall.call_records(gpu_ctx, df_align)
+    ops, off = gpu_ctx.cigar_fetch_ops(counts.n_ops, df_align.shape[0])
+    from oracle import oracle
+    for r, cig in enumerate(df_align['CIGAR']):
+        rc, tuples, _, _ = oracle.cigar_tokenize(cig)
+        got = [(int(o >> 4), 'MIDNSHP=X'[int(o & 15)]) for o in ops[int(off[r]):int(off[r + 1])]]
+        assert rc == 0 and got == tuples
+
+
+@pytest.mark.parametrize('seed,scale', [(11, 0.002), (12, 0.01), (13, 0.03)])
+def test_records_bit_exact_vs_oracle(built, gpu_ctx, seed, scale):
+    """Seeded synthetic haplotypes (N runs, soft-masking, reverse rows, planted inversions): every record field,
+    the SEQ blob and the counts equal the scalar oracle's."""
+    hap = synth.config2(seed=seed, scale=scale, threads=4)
+    names = hap.ref.names
+    gpu_ctx.seq_load(_lib.PAV_ROLE_REF, names, [hap.ref.seqs[n] for n in names])
+    gpu_ctx.seq_load(_lib.PAV_ROLE_TIG, hap.tig_names, [hap.tig_seqs[n] for n in hap.tig_names])
+    snv, indel, blob, counts = cigarcall.call_records(gpu_ctx, hap.df_align)
+    o_snv, o_indel, o_blob, err = util.oracle_records(names, [hap.ref.seqs[n] for n in names], hap.tig_names,
+                                                      [hap.tig_seqs[n] for n in hap.tig_names], hap.df_align)
+    assert err.kind == 0
+    assert counts.n_ops == hap.stats['n_ops'] and counts.aligned_bases == hap.stats['aligned_bp']
+    util.assert_records_equal(snv, o_snv, 'snv')
+    util.assert_records_equal(indel, o_indel, 'indel')
+    assert blob.tobytes() == o_blob.tobytes()
+
+
+def test_full_size_properties(built, gpu_ctx):
+    """A larger haplotype (>= 100 Mbp aligned) checked through size-independent properties:
+    counts equal the generator's ground truth; records are in (row, position) order; every SNV has REF != ALT
+    (case-folded); INS SEQ length == SVLEN; re-running is idempotent (checksum of the record streams)."""
+    hap = synth.config2(seed=21, scale=0.04, threads=8)
+    names = hap.ref.names
+    gpu_ctx.seq_load(_lib.PAV_ROLE_REF, names, [hap.ref.seqs[n] for n in names])
+    gpu_ctx.seq_load(_lib.PAV_ROLE_TIG, hap.tig_names, [hap.tig_seqs[n] for n in hap.tig_names])
+    snv, indel, blob, counts = cigarcall.call_records(gpu_ctx, hap.df_align)
+    st = hap.stats
+    assert (counts.n_ops, counts.n_snv, counts.n_indel, counts.aligned_bases) == \
+        (st['n_ops'], st['n_snv'], st['n_ins'] + st['n_del'], st['aligned_bp'])
+    key = snv['aln'].astype(np.int64) << 32 | snv['pos'].astype(np.int64)
+    assert np.all(np.diff(key) > 0)
+    fold = lambda a: a & 0xDF
+    assert np.all(fold(snv['ref']) != fold(snv['alt']))
+    assert int(indel['svlen'].sum()) == counts.seq_bytes == blob.shape[0]
+    assert np.all(np.diff(indel['seq_off'].astype(np.int64)) == indel['svlen'][:-1])
+    assert int((indel['svtype'] == 0).sum()) == st['n_ins']
+    snv2, indel2, blob2, _ = cigarcall.call_records(gpu_ctx, hap.df_align)
+    assert snv.tobytes() == snv2.tobytes() and indel.tobytes() == indel2.tobytes() and blob.tobytes() == blob2.tobytes()

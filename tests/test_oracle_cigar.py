@@ -1,0 +1,51 @@
+"""CPU oracle (oracle/) against the golden vectors produced by the reference itself.  No GPU needed."""
+import pytest
+
+import util
+from oracle import oracle
+
+
+def test_homology_known_answers(built):
+    for k in util.kat()['homology']:
+        f = oracle.left_homology if k['dir'] == 'L' else oracle.right_homology
+        assert f(k['pos'], k['seq'], k['sv']) == k['value'], k
+
+
+def test_tokenizer_known_answers(built):
+    for k in util.kat()['tokenize']:
+        rc, tuples, _, _ = oracle.cigar_tokenize(k['cigar'])
+        assert rc == 0
+        assert [[l, o] for l, o in tuples] == k['tuples']
+
+
+@pytest.mark.parametrize('case', ['cigar_synth', 'cigar_edge'])
+def test_tables_byte_exact(built, case):
+    d, df_align, df_trim = util.golden_case(case)
+    df_snv, df_insdel = util.oracle_frames(d, df_align, df_trim)
+    assert util.frame_text(df_snv) == util.golden_text(case, 'snv')
+    assert util.frame_text(df_insdel) == util.golden_text(case, 'insdel')
+
+
+def test_empty_table(built):
+    d, df_align, df_trim = util.golden_case('cigar_empty')
+    df_snv, df_insdel = util.oracle_frames(d, df_align, df_trim, with_filter=False)
+    assert util.frame_text(df_snv) == util.golden_text('cigar_empty', 'snv')
+    assert util.frame_text(df_insdel) == util.golden_text('cigar_empty', 'insdel')
+
+
+def test_error_cases(built):
+    """Same exception type and message as the reference (tests/golden/cigar_errors.json)."""
+    from pav_amd import cigarcall
+    d, df_align, _ = util.golden_case('cigar_edge')
+    ref_fa, tig_fa = util.seq_arrays(d, df_align)
+    for e in util.cigar_errors():
+        df = df_align.copy()
+        for idx, cig in e['edits'].items():
+            df.loc[df['INDEX'] == int(idx), 'CIGAR'] = cig
+        _, _, _, err = util.oracle_records(ref_fa.names, [ref_fa[n] for n in ref_fa.names], tig_fa.names,
+                                           [tig_fa[n] for n in tig_fa.names], df)
+        assert err.kind != 0, e['label']
+        with pytest.raises((RuntimeError, IndexError)) as ei:
+            cigarcall._raise_reference_error(err, df)
+        assert type(ei.value).__name__ == e['type'], e['label']
+        assert str(ei.value) == e['message'], e['label']

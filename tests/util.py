@@ -1,0 +1,77 @@
+"""Shared helpers for the parity tests (golden-case loading, oracle pipeline, frame comparison)."""
+import io
+import json
+import os
+
+import numpy as np
+import pandas as pd
+
+from pav_amd import cigarcall, rules
+from pav_amd.fasta import open_fasta
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def golden_case(name):
+    d = os.path.join(GOLD, name)
+    df_align = rules.read_align_bed(os.path.join(d, 'align.tsv'))
+    df_trim = rules.read_trim_bed(os.path.join(d, 'trim.tsv'))
+    return d, df_align, df_trim
+
+
+def golden_text(name, table):
+    with open(os.path.join(GOLD, name, table + '.tsv')) as fh:
+        return fh.read()
+
+
+def frame_text(df):
+    buf = io.StringIO()
+    df.to_csv(buf, sep='\t', index=False)
+    return buf.getvalue()
+
+
+def kat():
+    with open(os.path.join(GOLD, 'kat.json')) as fh:
+        return json.load(fh)
+
+
+def cigar_errors():
+    with open(os.path.join(GOLD, 'cigar_errors.json')) as fh:
+        return json.load(fh)
+
+
+def seq_arrays(case_dir, df_align):
+    ref_fa = open_fasta(os.path.join(case_dir, 'ref.fa'))
+    tig_fa = open_fasta(os.path.join(case_dir, 'tig.fa'))
+    return ref_fa, tig_fa
+
+
+def oracle_records(ref_names, ref_arrays, tig_names, tig_arrays, df_align):
+    """Run the CPU oracle on the same marshalled inputs the device gets."""
+    from oracle import oracle
+    aln, text, off = cigarcall.pack_alignments(df_align, ref_names, tig_names)
+    return oracle.cigar_call(ref_arrays, tig_arrays, aln, text, off)
+
+
+def oracle_frames(case_dir, df_align, df_trim, hap='h1', with_filter=True):
+    ref_fa, tig_fa = seq_arrays(case_dir, df_align)
+    snv, indel, blob, err = oracle_records(ref_fa.names, [ref_fa[n] for n in ref_fa.names],
+                                           tig_fa.names, [tig_fa[n] for n in tig_fa.names], df_align)
+    assert err.kind == 0, f'oracle error kind {err.kind}'
+    df_snv, df_insdel = cigarcall.records_to_frames(snv, indel, blob, df_align, hap)
+    if with_filter:
+        df_snv = rules.apply_trim_filter(df_snv, df_trim)
+        df_insdel = rules.apply_trim_filter(df_insdel, df_trim)
+    return df_snv, df_insdel
+
+
+def assert_records_equal(a, b, what):
+    assert a.dtype == b.dtype, what
+    assert a.shape == b.shape, f'{what}: {a.shape} vs {b.shape}'
+    if a.shape[0] == 0:
+        return
+    for name in a.dtype.names:
+        if name == 'pad':
+            continue
+        bad = np.flatnonzero(a[name] != b[name])
+        assert bad.size == 0, f'{what}.{name}: {bad.size} mismatches, first at {bad[0]}: {a[bad[0]]} vs {b[bad[0]]}'
