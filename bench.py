@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""
+bench.py - aligned Gbp/s through the MI355X CIGAR-call hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): BASELINE.json configs[1] - one synthetic hg38-shaped haplotype (24 reference
+sequences with hg38 no-ALT lengths, ~3.0 Gbp aligned, SURVEY.md section 8(d) profile, seed 1002), CIGAR-call
+only, one haplotype per GPU.  With N > 1 every rank processes its own haplotype (seed 1002*64 + rank) against the
+same reference: weak scaling, no data-path collective; torch.distributed (RCCL) is used
+only for the barrier and the max-over-ranks of the timed region.
+
+A "step" is one pass of the hot path over one haplotype with inputs already resident in HBM
+(reference ASCII + packed planes, contig ASCII, alignment table, CIGAR text):
+    pack contigs (2-bit + non-ACGT planes)  ->  tokenise CIGAR text  ->  prefix-scan walk  ->  SNV/INDEL emission
+    ->  left-shift + breakpoint homology  ->  SEQ gather.        Results stay in HBM (D2H reported separately).
+
+Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed on the library's stream) and
+"cpu_baseline" (oracle/ scalar C port timed on a bounded sample of the same workload, rank 0, N = 1 only).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--scale', type=float, default=1.0, help='shrink every sequence length (tests only; 1.0 = the named workload)')
+    ap.add_argument('--seed', type=int, default=1002)
+    ap.add_argument('--cpu-sample-bp', type=float, default=4e9,
+                    help='reference span (bp) of the CPU-baseline sample; default = the whole haplotype (a few seconds of CPU)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--threads', type=int, default=0, help='host threads for the generator (0 = auto)')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+
+    import torch  # first: its bundled HIP runtime becomes the process-wide one (pav_amd/_lib.py docstring)
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (no CPU fallback exists)')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    import numpy as np
+    import __graft_entry__ as g
+    if rank == 0:
+        g.build_cpu_side()
+    if world > 1:
+        dist.barrier()
+    from pav_amd import _lib, cigarcall, synth
+
+    threads = args.threads or max(1, (os.cpu_count() or 8) // max(1, world))
+    threads = min(threads, 16)
+
+    # ---- synthetic inputs (host) ------------------------------------------------------------------------
+    t0 = time.time()
+    hap = synth.config2(seed=args.seed, scale=args.scale, hap_index=rank, threads=threads)
+    names = hap.ref.names
+    t_gen = time.time() - t0
+
+    ctx = _lib.Context(local_rank)
+    t0 = time.time()
+    ctx.seq_load(_lib.PAV_ROLE_REF, names, [hap.ref.seqs[n] for n in names])
+    ctx.seq_load(_lib.PAV_ROLE_TIG, hap.tig_names, [hap.tig_seqs[n] for n in hap.tig_names])
+    aln, text, off = cigarcall.pack_alignments(hap.df_align, names, hap.tig_names)
+    ctx.cigar_load(aln, text, off)
+    ctx.sync()
+    t_h2d = time.time() - t0
+    tig_bases = int(sum(hap.tig_seqs[n].shape[0] for n in hap.tig_names))
+
+    def step():
+        ctx.seq_pack(_lib.PAV_ROLE_TIG)
+        return ctx.cigar_call()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        counts = step()
+    counts = step() if args.warmup == 0 else counts
+
+    # ---- timed region: exactly K steps, profiling off ---------------------------------------------------
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        counts = step()
+    torch.cuda.synchronize()
+    t_local = time.perf_counter() - t0
+    fence()
+    if world > 1:
+        tt = torch.tensor([t_local], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_max = float(tt.item())
+        ab = torch.tensor([float(counts.aligned_bases)], dtype=torch.float64, device='cuda')
+        dist.all_reduce(ab, op=dist.ReduceOp.SUM)
+        aligned_total = float(ab.item())
+    else:
+        t_max, aligned_total = t_local, float(counts.aligned_bases)
+
+    # ---- same K steps again with HIP events around every kernel (roofline leg) ---------------------------
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    for _ in range(args.steps):
+        step()
+    prof = ctx.prof_read()
+    ctx.prof_enable(False)
+
+    # D2H of the record streams (reported, never part of `value`)
+    t0 = time.perf_counter()
+    snv, indel, blob = ctx.cigar_fetch(counts)
+    t_d2h = time.perf_counter() - t0
+
+    if rank == 0:
+        ms_per_step = t_max / args.steps * 1e3
+        value = aligned_total * args.steps / t_max / 1e9
+        kern = {k: {'launches': v[0], 'avg_ms': v[1] / max(1, v[0])} for k, v in prof.items()}
+        dom = max(kern, key=lambda k: kern[k]['avg_ms'] * kern[k]['launches'])
+        # algorithmic bytes per launch of each kernel (DESIGN.md section "Kernels")
+        n_ops, n_snv, n_indel = counts.n_ops, counts.n_snv, counts.n_indel
+        alg_bytes = {
+            'pack_kernel': tig_bases * (1.0 + 0.25 + 0.125),
+            'tok_count': float(text.shape[0]),
+            'tok_emit': float(text.shape[0]) + 4.0 * n_ops,
+            'walk_reduce': 4.0 * n_ops,
+            'walk_emit': 4.0 * n_ops + 16.0 * n_snv + 2.0 * n_snv + 64.0 * n_indel,
+            'homology_kernel': 128.0 * n_indel,
+            'seq_gather': 2.0 * counts.seq_bytes,
+        }
+        a_bytes = alg_bytes.get(dom, 0.0)
+        achieved = a_bytes / (kern[dom]['avg_ms'] * 1e-3) / 1e9 if kern[dom]['avg_ms'] > 0 else 0.0
+        roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'avg_kernel_ms': round(kern[dom]['avg_ms'], 4), 'algorithmic_bytes_per_launch': a_bytes,
+                    'kernels_ms': {k: round(v['avg_ms'], 4) for k, v in sorted(kern.items())}}
+
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle
+            df = hap.df_align
+            span = (df['END'] - df['POS']).cumsum()
+            n_rows = int(np.searchsorted(span.to_numpy(), args.cpu_sample_bp * min(1.0, args.scale))) + 1
+            sub = df.iloc[:min(n_rows, df.shape[0])]
+            a2, t2, o2 = cigarcall.pack_alignments(sub, names, hap.tig_names)
+            c0 = time.perf_counter()
+            o_snv, o_indel, o_blob, err = oracle.cigar_call([hap.ref.seqs[n] for n in names],
+                                                            [hap.tig_seqs[n] for n in hap.tig_names], a2, t2, o2)
+            c1 = time.perf_counter() - c0
+            # aligned bases of the sample = (=,X) lengths: recount from the device ops of those rows
+            ops, op_off = ctx.cigar_fetch_ops(counts.n_ops, df.shape[0])
+            sel = ops[:int(op_off[sub.shape[0]])]
+            code = sel & 15
+            sample_bp = int((sel[(code == 7) | (code == 8)] >> 4).astype(np.int64).sum())
+            # the sample doubles as a full-size parity check of the leading rows
+            ok = snv[:o_snv.shape[0]].tobytes() == o_snv.tobytes() and blob[:o_blob.shape[0]].tobytes() == o_blob.tobytes()
+            for f in o_indel.dtype.names:
+                if f != 'pad':
+                    ok = ok and bool(np.array_equal(indel[f][:o_indel.shape[0]], o_indel[f]))
+            cpu = {'value': round(sample_bp / c1 / 1e9, 4), 'unit': 'Gbp/s', 'cores': 1, 'kind': 'port',
+                   'sample': f'first {sub.shape[0]} alignment rows of the same haplotype ({sample_bp / 1e9:.3f} Gbp aligned, '
+                             f'{o_snv.shape[0]} SNV, {o_indel.shape[0]} INDEL), oracle/ scalar C walk incl. per-contig '
+                             f'upper-casing and reverse complement, {c1:.1f} s wall',
+                   'records_match_gpu': bool(ok)}
+
+        line = {
+            'metric': 'aligned Gbp/s through CIGAR-call (tokenise + walk + homology + SEQ gather + contig pack); bit-exact vs pavlib',
+            'value': round(value, 2), 'unit': 'Gbp/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'u8/u32 (integer + byte)', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: one hg38-shaped haplotype, CIGAR-call only, one haplotype per GPU',
+                       'scale': args.scale, 'seed': args.seed, 'aligned_bp_per_gpu': int(counts.aligned_bases),
+                       'n_aln': int(aln.shape[0]), 'n_ops': int(n_ops), 'n_snv': int(n_snv), 'n_indel': int(n_indel),
+                       'parallelism': f'{world} x (1 haplotype / GPU), no collective'},
+            'roofline': roofline, 'cpu_baseline': cpu,
+            'host': {'generate_s': round(t_gen, 1), 'h2d_and_ref_pack_s': round(t_h2d, 2), 'd2h_records_s': round(t_d2h, 3),
+                     'device': ctx.device_name},
+        }
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

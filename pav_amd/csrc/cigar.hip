@@ -135,18 +135,22 @@ __global__ __launch_bounds__(256) void tok_emit(const uint8_t *__restrict__ text
     }
 }
 
-// One lane per row boundary r in [0, n_aln]: op_off[r] = number of op characters before text_off[r];
+// One wave per row boundary r in [0, n_aln]: op_off[r] = number of op characters before text_off[r];
 // also flags rows whose text ends inside a length (IndexError in the reference).
-__global__ void row_ops(const uint8_t *__restrict__ text, const uint64_t *__restrict__ text_off,
-                        const uint64_t *__restrict__ chunk_pre, uint64_t *__restrict__ op_off, uint32_t n_aln,
-                        unsigned long long *__restrict__ tok_err) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void row_ops(const uint8_t *__restrict__ text, const uint64_t *__restrict__ text_off,
+                                               const uint64_t *__restrict__ chunk_pre, uint64_t *__restrict__ op_off,
+                                               uint32_t n_aln, unsigned long long *__restrict__ tok_err) {
+    const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r > n_aln) return;
+    const int lane = threadIdx.x & 63;
     const uint64_t p = text_off[r];
     const uint64_t c = p / TOK_CHUNK;
-    uint64_t cnt = chunk_pre[c];
-    for (uint64_t q = c * TOK_CHUNK; q < p; ++q) cnt += !is_digit(text[q]);
-    op_off[r] = cnt;
+    uint32_t cnt = 0;
+    for (uint64_t q = c * TOK_CHUNK + lane; q < p; q += 64) cnt += !is_digit(text[q]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+    if (lane != 0) return;
+    op_off[r] = chunk_pre[c] + cnt;
     if (r < n_aln) {
         const uint64_t e = text_off[r + 1];
         if (e > p && is_digit(text[e - 1])) {
@@ -357,40 +361,109 @@ __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
 }
 
 // ---- breakpoint homology (pavlib/call.py:542-647) -----------------------------------------------------------
+// The reference walks one base at a time; here a lane compares up to 32 bases per step straight from the packed
+// planes: an unaligned 64-bit window of the 2-bit plane (and 32 bits of the non-ACGT plane) for the scanned
+// sequence against the SV sequence laid out in scan order.  The circular index into seq_sv (call.py:579,637)
+// becomes a periodic pattern: for svlen <= 32 one period is fetched once and replicated so that every step
+// starts at phase 0; longer SVs are compared window by window up to the wrap point.
 struct SeqRef {                 // one oriented record of a store
     const uint32_t *two, *mask;
     uint64_t off, len;
     int rev;
 };
-__device__ __forceinline__ uint32_t base(const SeqRef &s, int64_t p) { return base_at(s.two, s.mask, s.off, s.len, s.rev, p); }
 
-// left_homology(pos_tig, seq_tig, seq_sv): seq_sv = sv[sv_pos .. sv_pos + svlen)
-__device__ uint32_t left_hom(const SeqRef &t, int64_t pos, const SeqRef &sv, int64_t sv_pos, int64_t svlen) {
-    if (svlen <= 0) return 0;
-    int64_t h = 0, idx = svlen - 1;                    // seq_sv[-((h + 1) % svlen)]  (call.py:579)
-    while (h <= pos) {                                 // call.py:572
-        const uint32_t b = base(t, pos - h);
-        if (b > 3u) break;                             // not in {A,C,G,T}: call.py:576
-        if (base(sv, sv_pos + idx) != b) break;
-        ++h;
-        idx = idx == 0 ? svlen - 1 : idx - 1;
+__device__ __forceinline__ uint64_t low_bits64(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
+
+// Reverse the order of the n 2-bit groups held in the low 2n bits of x.
+__device__ __forceinline__ uint64_t reverse_groups(uint64_t x, int n) {
+    uint64_t r = __brevll(x) >> (64 - 2 * n);
+    return ((r & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((r & 0x5555555555555555ull) << 1);
+}
+
+// n (1..32) bases of s starting at oriented position p and continuing in direction dir (+1 / -1), returned in
+// scan order: base j in bits [2j, 2j+1] of codes, non-ACGT flag in bit j of bad.
+__device__ __forceinline__ void fetch_run(const SeqRef &s, int64_t p, int dir, int n, uint64_t &codes, uint32_t &bad) {
+    const int64_t st = s.rev ? (int64_t)s.len - 1 - p : p;          // stored position of the first scanned base
+    const int sdir = s.rev ? -dir : dir;                              // direction in stored coordinates
+    const uint64_t abs = s.off + (uint64_t)(sdir > 0 ? st : st - (n - 1));
+    const uint64_t *two64 = reinterpret_cast<const uint64_t *>(s.two);
+    const uint64_t *mask64 = reinterpret_cast<const uint64_t *>(s.mask);
+    const uint64_t w = abs >> 5;
+    const int b = (int)(abs & 31) * 2;
+    uint64_t x = two64[w] >> b;
+    if (b) x |= two64[w + 1] << (64 - b);
+    const uint64_t w2 = abs >> 6;
+    const int b2 = (int)(abs & 63);
+    uint64_t y = mask64[w2] >> b2;
+    if (b2) y |= mask64[w2 + 1] << (64 - b2);
+    uint32_t m = (uint32_t)y;
+    if (n < 32) { x &= low_bits64(2 * n); m &= (1u << n) - 1u; }
+    if (sdir < 0) { x = reverse_groups(x, n); m = __brev(m) >> (32 - n); }
+    if (s.rev) x ^= low_bits64(2 * n);                                // complement every base
+    codes = x;
+    bad = m;
+}
+
+// First scan offset (0..m-1) where the bases differ or either side is non-ACGT; m when none.
+__device__ __forceinline__ int first_stop(uint64_t a, uint64_t b, uint32_t bad, int m) {
+    uint64_t d = a ^ b;
+    d = (d | (d >> 1)) & 0x5555555555555555ull & low_bits64(2 * m);
+    if (m < 32) bad &= (1u << m) - 1u;
+    const int pd = d ? (__ffsll((long long)d) - 1) >> 1 : 64;
+    const int pm = bad ? __ffs((int)bad) - 1 : 64;
+    const int st = pd < pm ? pd : pm;
+    return st < m ? st : m;
+}
+
+// Shared scan: t is walked from t_pos in direction dir for at most avail bases; seq_sv = sv[sv_pos, sv_pos+svlen)
+// is walked circularly from its last base backwards (dir < 0) or its first base forwards (dir > 0).
+__device__ uint32_t hom_scan(const SeqRef &t, int64_t t_pos, int dir, int64_t avail, const SeqRef &sv, int64_t sv_pos,
+                             int64_t svlen) {
+    if (svlen <= 0 || avail <= 0) return 0;
+    int64_t h = 0;
+    if (svlen <= 32) {
+        const int L = (int)svlen;
+        uint64_t pc; uint32_t pm;
+        fetch_run(sv, dir < 0 ? sv_pos + svlen - 1 : sv_pos, dir, L, pc, pm);
+        const int reps = 32 / L, n = reps * L;
+        uint64_t P = pc; uint32_t M = pm;
+        for (int r = 1; r < reps; ++r) { P |= pc << (2 * L * r); M |= pm << (L * r); }
+        while (h < avail) {
+            const int m = (int)(avail - h < n ? avail - h : n);
+            uint64_t tc; uint32_t tm;
+            fetch_run(t, t_pos + dir * h, dir, m, tc, tm);
+            const int st = first_stop(tc, P, tm | M, m);
+            if (st < m) return (uint32_t)(h + st);
+            h += m;
+        }
+        return (uint32_t)h;
+    }
+    int64_t idx = dir < 0 ? svlen - 1 : 0;
+    while (h < avail) {
+        const int64_t to_wrap = dir < 0 ? idx + 1 : svlen - idx;
+        int64_t mm = avail - h < 32 ? avail - h : 32;
+        if (to_wrap < mm) mm = to_wrap;
+        const int m = (int)mm;
+        uint64_t tc, sc; uint32_t tm, sm;
+        fetch_run(t, t_pos + dir * h, dir, m, tc, tm);
+        fetch_run(sv, sv_pos + idx, dir, m, sc, sm);
+        const int st = first_stop(tc, sc, tm | sm, m);
+        if (st < m) return (uint32_t)(h + st);
+        h += m;
+        idx += dir * m;
+        if (idx < 0) idx = svlen - 1; else if (idx >= svlen) idx = 0;
     }
     return (uint32_t)h;
 }
 
-// right_homology(pos_tig, seq_tig, seq_sv)
-__device__ uint32_t right_hom(const SeqRef &t, int64_t pos, const SeqRef &sv, int64_t sv_pos, int64_t svlen) {
-    if (svlen <= 0) return 0;
-    const int64_t limit = (int64_t)t.len - pos;        // call.py:627
-    int64_t h = 0, idx = 0;                            // seq_sv[h % svlen]  (call.py:637)
-    while (h < limit) {
-        const uint32_t b = base(t, pos + h);
-        if (b > 3u) break;
-        if (base(sv, sv_pos + idx) != b) break;
-        ++h;
-        idx = idx + 1 == svlen ? 0 : idx + 1;
-    }
-    return (uint32_t)h;
+// left_homology(pos_tig, seq_tig, seq_sv)   call.py:542-592: walks upstream from pos while hom_len <= pos_tig
+__device__ __forceinline__ uint32_t left_hom(const SeqRef &t, int64_t pos, const SeqRef &sv, int64_t sv_pos, int64_t svlen) {
+    return hom_scan(t, pos, -1, pos + 1, sv, sv_pos, svlen);
+}
+
+// right_homology(pos_tig, seq_tig, seq_sv)  call.py:595-647: walks downstream while hom_len < len - pos_tig
+__device__ __forceinline__ uint32_t right_hom(const SeqRef &t, int64_t pos, const SeqRef &sv, int64_t sv_pos, int64_t svlen) {
+    return hom_scan(t, pos, +1, (int64_t)t.len - pos, sv, sv_pos, svlen);
 }
 
 // One lane per INS/DEL stub: left shift + four breakpoint homologies, then the final coordinates.
@@ -546,7 +619,7 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
     PAV_HIP(ctx, ctx->d_op_off.reserve(sizeof(uint64_t) * ((size_t)n_aln + 1)));
     PAV_LAUNCH(ctx, "tok_emit", tok_emit, n_tchunks, 256, 0, ctx->d_text.as<uint8_t>(), d_tpre, ctx->d_ops.as<uint32_t>(),
                d_tok_err);
-    PAV_LAUNCH(ctx, "row_ops", row_ops, (n_aln + 1 + 255) / 256, 256, 0, ctx->d_text.as<uint8_t>(),
+    PAV_LAUNCH(ctx, "row_ops", row_ops, (n_aln + 1 + 3) / 4, 256, 0, ctx->d_text.as<uint8_t>(),
                ctx->d_text_off.as<uint64_t>(), d_tpre, ctx->d_op_off.as<uint64_t>(), n_aln, d_tok_err);
 
     // --- walk: reduce, chunk scan, row bases -------------------------------------------------------------
