@@ -146,6 +146,71 @@ typedef struct {
 } pav_hom_query;
 int pav_homology(pav_ctx *ctx, uint32_t n, const pav_hom_query *q, uint32_t *out);
 
+/* ---- k-mer state + density scan (inversion caller) -------------------------------------------------------- *
+ * Replaces the subprocess `scripts/density.py` that pavlib.inv.scan_for_inv spawns once per scan iteration
+ * (pavlib/inv.py:246-288): pavlib.seq.ref_kmers (pavlib/seq.py:305-325), the low-complexity gate and
+ * orientation handling of scripts/density.py:508-545, get_smoothed_density (scripts/density.py:154-342:
+ * STATE_MER, compaction, scipy gaussian_kde x3, interpolate / fill, spike rule, arg-max STATE) and
+ * pavlib.density.rl_encoder (pavlib/density.py:330-361).  A batch of independent (reference region, contig
+ * region) jobs is processed per call; tables stay in HBM and are fetched only for regions that become calls.
+ * k <= 31.  Float columns follow scipy's arithmetic order (data ascending per evaluation point) with the
+ * device's exp(); they agree with the reference to ~1e-13 relative, STATE / STATE_MER / INDEX / runs exactly.
+ */
+typedef struct {
+    uint32_t ref_id, tig_id;        /* records in the REF / TIG stores                                      */
+    uint64_t ref_pos, ref_end;      /* region_ref  [pos, end)   (--refregion, BED coordinates)              */
+    uint64_t tig_pos, tig_end;      /* region_tig  [pos, end) on the stored contig (--tigregion)            */
+    uint32_t ref_rc;                /* -r true: reverse-complement the reference k-mer set (region_tig.is_rev) */
+    uint32_t state_run_smooth;      /* --staterunsmooth for this region (pavlib/inv.py:259 srs_tree lookup) */
+} pav_den_job;
+
+typedef struct {
+    int32_t k;                      /* -k               (31)     scripts/density.py:438                     */
+    uint32_t min_informative;       /* --mininf         (2000)   :449                                       */
+    uint32_t min_state_count;       /* --minstatecount  (20)     :462                                       */
+    double den_smooth;              /* --densmooth      (1)      :455                                       */
+    double state_run_delta;         /* --staterundelta  (0.005)  :476                                       */
+    uint32_t max_ref_kmer_count;    /* MAX_REF_KMER_COUNT (100)  :47                                        */
+    uint32_t pad;
+} pav_den_params;
+
+enum { PAV_DEN_OK = 0, PAV_DEN_UNFINALISED = 1, PAV_DEN_FAIL = 125 };   /* 125 = pavlib.constants.ERR_INV_FAIL */
+
+typedef struct {
+    int32_t status;                 /* PAV_DEN_OK: full table; PAV_DEN_UNFINALISED: < mininf rows, STATE = -1
+                                       (scripts/density.py:193-195); PAV_DEN_FAIL: soft failure                 */
+    int32_t fail_kind;              /* PAV_DEN_FAIL: 1 = no reference k-mers (:510-513), 2 = k-mer count (:516-527) */
+    uint32_t n_rows;                /* informative k-mers = table rows                                        */
+    uint32_t n_runs;                /* rl_encoder tuples                                                      */
+    uint32_t max_count;             /* largest reference k-mer count                                          */
+    uint32_t n_sample;              /* sampled sites                                                          */
+    uint64_t max_kmer;              /* fail_kind 2: first k-mer (insertion order) with max_count, kanapy encoding */
+    uint32_t state_count[3];        /* informative k-mers per STATE_MER after the min-state-count rule        */
+    uint32_t pad;
+    uint64_t n_eval;                /* density evaluation points computed (sampled + filled)                  */
+    double h[3];                    /* KDE bandwidth per state (scipy cho_cov)                                */
+} pav_den_result;
+
+typedef struct { int32_t state; uint32_t count; int64_t pos, end; } pav_run;   /* rl_encoder (state,count,pos,end) */
+
+int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, const pav_den_params *params,
+                      pav_den_result *results);
+/* rl_encoder tuples of one job of the last batch (results[job].n_runs entries). */
+int pav_density_runs(pav_ctx *ctx, uint32_t job, pav_run *runs);
+/* Density table of one job of the last batch, results[job].n_rows entries each; any pointer may be NULL.
+ * Columns: INDEX, STATE_MER, STATE, KERN_FWD, KERN_FWDREV, KERN_REV, KMER (scripts/density.py:341). */
+int pav_density_table(pav_ctx *ctx, uint32_t job, int64_t *index, int8_t *state_mer, int8_t *state, double *kern_fwd,
+                      double *kern_fwdrev, double *kern_rev, uint64_t *kmer);
+/* pavlib.inv.annotate_inv_dup_mers (pavlib/inv.py:457-561) on the resident table of one job:
+ * flank[i] 0 '' / 1 UP / 2 DN; match[i] 0 '' / 1 SAME / 2 OTHER / 3 NaN.  up_* / dn_* are the duplication
+ * regions on the reference record ref_id (BED) and on the contig; qry_index_base is added to INDEX (:519). */
+int pav_density_annotate(pav_ctx *ctx, uint32_t job, uint32_t ref_id, uint64_t ref_up_pos, uint64_t ref_up_end,
+                         uint64_t ref_dn_pos, uint64_t ref_dn_end, int64_t qry_index_base, int64_t tig_up_pos,
+                         int64_t tig_up_end, int64_t tig_dn_pos, int64_t tig_dn_end, uint8_t *flank, uint8_t *match);
+/* K-mer helpers in the (assumed) kanapy integer encoding: A0 C1 G2 T3, first base most significant. */
+uint64_t pav_kmer_rev_complement(uint64_t kmer, int k);
+uint64_t pav_kmer_canonical(uint64_t kmer, int k);
+
 /* ---- profiling ---------------------------------------------------------------------------------------- *
  * HIP-event timing of every kernel the library launches on its stream (bench.py's roofline leg).         */
 int pav_prof_enable(pav_ctx *ctx, int on);

@@ -120,3 +120,117 @@ def cigar_call(ref_arrays, tig_arrays, aln, cigar_text, cigar_off):
     finally:
         lib.orc_calls_free(h)
     return snv, indel, blob, err
+
+
+# ---------------------------------------------------------------------------------------------------------
+# k-mer state + density scan (oracle/pav_oracle_density.c)
+# ---------------------------------------------------------------------------------------------------------
+
+class DenParams(ctypes.Structure):
+    _fields_ = [('k', ctypes.c_int32), ('min_informative', ctypes.c_uint32), ('min_state_count', ctypes.c_uint32),
+                ('den_smooth', ctypes.c_double), ('state_run_smooth', ctypes.c_uint32),
+                ('state_run_delta', ctypes.c_double), ('max_ref_kmer_count', ctypes.c_uint32)]
+
+
+class DensityInfo(ctypes.Structure):
+    _fields_ = [('status', ctypes.c_int32), ('fail_kind', ctypes.c_int32), ('n', ctypes.c_uint32),
+                ('max_count', ctypes.c_uint32), ('max_kmer', ctypes.c_uint64), ('state_count', ctypes.c_uint32 * 3),
+                ('h', ctypes.c_double * 3), ('n_eval', ctypes.c_uint64)]
+
+
+RUN_DTYPE = np.dtype([('state', '<i4'), ('count', '<u4'), ('pos', '<i8'), ('end', '<i8')])
+
+
+def den_params(k=31, min_informative=2000, min_state_count=20, den_smooth=1.0, state_run_smooth=20,
+               state_run_delta=0.005, max_ref_kmer_count=100):
+    return DenParams(k, min_informative, min_state_count, den_smooth, state_run_smooth, state_run_delta,
+                     max_ref_kmer_count)
+
+
+def _den_protos(lib):
+    if getattr(lib, '_den_ready', False):
+        return
+    P = ctypes.c_void_p
+    lib.orc_density_run.restype = P
+    lib.orc_density_run.argtypes = [P, ctypes.c_uint64, P, ctypes.c_uint64, ctypes.c_int, P]
+    lib.orc_density_get_info.restype = ctypes.POINTER(DensityInfo)
+    lib.orc_density_get_info.argtypes = [P]
+    for name in ('orc_density_index', 'orc_density_state_mer', 'orc_density_state', 'orc_density_kmer',
+                 'orc_density_interp'):
+        getattr(lib, name).restype = P
+        getattr(lib, name).argtypes = [P]
+    lib.orc_density_kern.restype = P
+    lib.orc_density_kern.argtypes = [P, ctypes.c_int]
+    lib.orc_density_free.restype = None
+    lib.orc_density_free.argtypes = [P]
+    lib.orc_rl_encode.restype = ctypes.c_uint32
+    lib.orc_rl_encode.argtypes = [P, P, ctypes.c_uint32, P, ctypes.c_uint32]
+    lib.orc_annotate.restype = None
+    lib.orc_annotate.argtypes = [P, P, ctypes.c_uint32, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                 ctypes.c_int64, ctypes.c_int64, P, ctypes.c_uint64, P, ctypes.c_uint64, P, P]
+    lib.orc_kmer_rc.restype = ctypes.c_uint64
+    lib.orc_kmer_rc.argtypes = [ctypes.c_uint64, ctypes.c_int]
+    lib.orc_kmer_canonical.restype = ctypes.c_uint64
+    lib.orc_kmer_canonical.argtypes = [ctypes.c_uint64, ctypes.c_int]
+    lib._den_ready = True
+
+
+def _copy(ptr, n, dtype):
+    out = np.zeros(n, dtype=dtype)
+    if n:
+        ctypes.memmove(out.ctypes.data, ptr, n * np.dtype(dtype).itemsize)
+    return out
+
+
+def density(ref_seq, tig_seq, ref_rc, params=None):
+    """scripts/density.py on extracted region sequences (uint8 ASCII arrays).  Returns a dict of arrays + info."""
+    lib = load()
+    _den_protos(lib)
+    params = params or den_params()
+    ref_seq = np.ascontiguousarray(ref_seq, dtype=np.uint8)
+    tig_seq = np.ascontiguousarray(tig_seq, dtype=np.uint8)
+    h = lib.orc_density_run(ref_seq.ctypes.data, ref_seq.shape[0], tig_seq.ctypes.data, tig_seq.shape[0],
+                            1 if ref_rc else 0, ctypes.byref(params))
+    try:
+        info = lib.orc_density_get_info(h).contents
+        n = int(info.n)
+        out = {'status': int(info.status), 'fail_kind': int(info.fail_kind), 'n': n, 'max_count': int(info.max_count),
+               'max_kmer': int(info.max_kmer), 'state_count': [int(v) for v in info.state_count],
+               'h': [float(v) for v in info.h], 'n_eval': int(info.n_eval)}
+        if info.status != 125:
+            out['INDEX'] = _copy(lib.orc_density_index(h), n, np.int64)
+            out['STATE_MER'] = _copy(lib.orc_density_state_mer(h), n, np.int8)
+            out['STATE'] = _copy(lib.orc_density_state(h), n, np.int8)
+            out['KMER'] = _copy(lib.orc_density_kmer(h), n, np.uint64)
+            out['INTERP'] = _copy(lib.orc_density_interp(h), n, np.uint8)
+            for s, name in enumerate(('KERN_FWD', 'KERN_FWDREV', 'KERN_REV')):
+                out[name] = _copy(lib.orc_density_kern(h, s), n, np.float64)
+    finally:
+        lib.orc_density_free(h)
+    return out
+
+
+def rl_encode(state, index):
+    lib = load()
+    _den_protos(lib)
+    state = np.ascontiguousarray(state, dtype=np.int8)
+    index = np.ascontiguousarray(index, dtype=np.int64)
+    runs = np.zeros(max(1, state.shape[0]), dtype=RUN_DTYPE)
+    m = lib.orc_rl_encode(state.ctypes.data, index.ctypes.data, state.shape[0], runs.ctypes.data, runs.shape[0])
+    return [(int(r['state']), int(r['count']), int(r['pos']), int(r['end'])) for r in runs[:m]]
+
+
+def annotate(kmer, index, k, qry_index_base, up, dn, ref_up, ref_dn):
+    """pavlib/inv.py:457-561.  up / dn = (pos, end) of the contig duplication regions.  -> (flank, match) codes."""
+    lib = load()
+    _den_protos(lib)
+    kmer = np.ascontiguousarray(kmer, dtype=np.uint64)
+    index = np.ascontiguousarray(index, dtype=np.int64)
+    ref_up = np.ascontiguousarray(ref_up, dtype=np.uint8)
+    ref_dn = np.ascontiguousarray(ref_dn, dtype=np.uint8)
+    flank = np.zeros(kmer.shape[0], dtype=np.uint8)
+    match = np.zeros(kmer.shape[0], dtype=np.uint8)
+    lib.orc_annotate(kmer.ctypes.data, index.ctypes.data, kmer.shape[0], k, qry_index_base, up[0], up[1], dn[0], dn[1],
+                     ref_up.ctypes.data, ref_up.shape[0], ref_dn.ctypes.data, ref_dn.shape[0], flank.ctypes.data,
+                     match.ctypes.data)
+    return flank, match

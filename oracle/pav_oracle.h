@@ -90,6 +90,56 @@ const orc_indel *orc_calls_indel(const orc_calls *);
 const uint8_t *orc_calls_seq(const orc_calls *);
 void orc_calls_free(orc_calls *);
 
+/* ---- k-mer state + density scan ---------------------------------------------------------------------------- */
+typedef struct {
+    int32_t k;                      /* -k (31)                                    scripts/density.py:438          */
+    uint32_t min_informative;       /* --mininf (2000)                            :449                            */
+    uint32_t min_state_count;       /* --minstatecount (20)                       :462                            */
+    double den_smooth;              /* --densmooth (1)                            :455                            */
+    uint32_t state_run_smooth;      /* --staterunsmooth (20)                      :468                            */
+    double state_run_delta;         /* --staterundelta (0.005)                    :476                            */
+    uint32_t max_ref_kmer_count;    /* MAX_REF_KMER_COUNT (100)                   :47                             */
+} orc_den_params;
+
+typedef struct {
+    int32_t status;                 /* 0 finalised table; 1 un-finalised (< mininf rows, STATE = -1); 125 soft fail */
+    int32_t fail_kind;              /* status 125: 1 = no reference k-mers, 2 = k-mer count above the limit        */
+    uint32_t n;                     /* table rows                                                                   */
+    uint32_t max_count;             /* largest reference k-mer count                                                */
+    uint64_t max_kmer;              /* first-inserted k-mer with that count (fail_kind 2; message text)             */
+    uint32_t state_count[3];
+    double h[3];                    /* KDE bandwidth (cho_cov) per state                                            */
+    uint64_t n_eval;                /* evaluation points actually computed (sampled + filled)                       */
+} orc_density_info;
+
+typedef struct { int32_t state; uint32_t count; int64_t pos, end; } orc_run;   /* rl_encoder tuple */
+
+typedef struct orc_density orc_density;
+
+/* scripts/density.py main + get_smoothed_density on an already extracted reference / contig region (ASCII). */
+orc_density *orc_density_run(const uint8_t *ref_seq, uint64_t ref_len, const uint8_t *tig_seq, uint64_t tig_len,
+                             int ref_rc, const orc_den_params *pp);
+const orc_density_info *orc_density_get_info(const orc_density *);
+const int64_t *orc_density_index(const orc_density *);
+const int8_t *orc_density_state_mer(const orc_density *);
+const int8_t *orc_density_state(const orc_density *);
+const double *orc_density_kern(const orc_density *, int state);
+const uint64_t *orc_density_kmer(const orc_density *);
+const uint8_t *orc_density_interp(const orc_density *);
+void orc_density_free(orc_density *);
+
+/* pavlib/density.py:330-361; returns the number of runs (may exceed cap; only cap are written). */
+uint32_t orc_rl_encode(const int8_t *state, const int64_t *index, uint32_t n, orc_run *runs, uint32_t cap);
+
+/* pavlib/inv.py:457-561: flank 0 '' / 1 UP / 2 DN; match 0 '' / 1 SAME / 2 OTHER / 3 NaN. */
+void orc_annotate(const uint64_t *kmer, const int64_t *index, uint32_t n, int k, int64_t qry_index_base,
+                  int64_t up_pos, int64_t up_end, int64_t dn_pos, int64_t dn_end,
+                  const uint8_t *ref_up, uint64_t ref_up_len, const uint8_t *ref_dn, uint64_t ref_dn_len,
+                  uint8_t *flank, uint8_t *match);
+
+uint64_t orc_kmer_rc(uint64_t kmer, int k);
+uint64_t orc_kmer_canonical(uint64_t kmer, int k);
+
 #ifdef __cplusplus
 }
 #endif

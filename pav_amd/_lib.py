@@ -42,6 +42,29 @@ class CigarCounts(ctypes.Structure):
                 ('seq_bytes', ctypes.c_uint64), ('aligned_bases', ctypes.c_uint64)]
 
 
+class DenJob(ctypes.Structure):
+    _fields_ = [('ref_id', ctypes.c_uint32), ('tig_id', ctypes.c_uint32), ('ref_pos', ctypes.c_uint64),
+                ('ref_end', ctypes.c_uint64), ('tig_pos', ctypes.c_uint64), ('tig_end', ctypes.c_uint64),
+                ('ref_rc', ctypes.c_uint32), ('state_run_smooth', ctypes.c_uint32)]
+
+
+class DenParams(ctypes.Structure):
+    _fields_ = [('k', ctypes.c_int32), ('min_informative', ctypes.c_uint32), ('min_state_count', ctypes.c_uint32),
+                ('den_smooth', ctypes.c_double), ('state_run_delta', ctypes.c_double),
+                ('max_ref_kmer_count', ctypes.c_uint32), ('pad', ctypes.c_uint32)]
+
+
+class DenResult(ctypes.Structure):
+    _fields_ = [('status', ctypes.c_int32), ('fail_kind', ctypes.c_int32), ('n_rows', ctypes.c_uint32),
+                ('n_runs', ctypes.c_uint32), ('max_count', ctypes.c_uint32), ('n_sample', ctypes.c_uint32),
+                ('max_kmer', ctypes.c_uint64), ('state_count', ctypes.c_uint32 * 3), ('pad', ctypes.c_uint32),
+                ('n_eval', ctypes.c_uint64), ('h', ctypes.c_double * 3)]
+
+
+RUN_DTYPE = np.dtype([('state', '<i4'), ('count', '<u4'), ('pos', '<i8'), ('end', '<i8')])
+DEN_OK, DEN_UNFINALISED, DEN_FAIL = 0, 1, 125
+
+
 class CigarErr(ctypes.Structure):
     _fields_ = [('kind', ctypes.c_int32), ('aln', ctypes.c_uint32), ('op_index', ctypes.c_uint32),
                 ('op_char', ctypes.c_uint32), ('pos_ref', ctypes.c_uint32), ('pos_tig', ctypes.c_uint32)]
@@ -66,6 +89,14 @@ SYMBOLS = {
     'pav_cigar_fetch': (ctypes.c_int, [_P, _P, _P, _P]),
     'pav_cigar_fetch_ops': (ctypes.c_int, [_P, _P, _P]),
     'pav_homology': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P]),
+    'pav_density_batch': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P]),
+    'pav_density_runs': (ctypes.c_int, [_P, ctypes.c_uint32, _P]),
+    'pav_density_table': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P, _P, _P, _P, _P]),
+    'pav_density_annotate': (ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64,
+                                            ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64,
+                                            ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _P, _P]),
+    'pav_kmer_rev_complement': (ctypes.c_uint64, [ctypes.c_uint64, ctypes.c_int]),
+    'pav_kmer_canonical': (ctypes.c_uint64, [ctypes.c_uint64, ctypes.c_int]),
     'pav_prof_enable': (ctypes.c_int, [_P, ctypes.c_int]),
     'pav_prof_reset': (ctypes.c_int, [_P]),
     'pav_prof_count': (ctypes.c_int, [_P]),
@@ -223,6 +254,39 @@ class Context:
         out = np.zeros(q.shape[0], dtype=np.uint32)
         self._check(self.lib.pav_homology(self.handle, q.shape[0], _ptr(q), _ptr(out)), 'pav_homology')
         return out
+
+    # -- k-mer state + density scan --------------------------------------------------------------------------
+    def density_batch(self, jobs, params):
+        """``jobs``: list of DenJob; returns list of DenResult (tables / runs stay resident until the next batch)."""
+        n = len(jobs)
+        arr = (DenJob * max(n, 1))(*jobs)
+        res = (DenResult * max(n, 1))()
+        self._check(self.lib.pav_density_batch(self.handle, n, arr, ctypes.byref(params), res), 'pav_density_batch')
+        return [res[i] for i in range(n)]
+
+    def density_runs(self, job, n_runs):
+        runs = np.zeros(n_runs, dtype=RUN_DTYPE)
+        self._check(self.lib.pav_density_runs(self.handle, job, _ptr(runs)), 'pav_density_runs')
+        return [(int(r['state']), int(r['count']), int(r['pos']), int(r['end'])) for r in runs]
+
+    def density_table(self, job, n_rows):
+        cols = {'INDEX': np.zeros(n_rows, dtype=np.int64), 'STATE_MER': np.zeros(n_rows, dtype=np.int8),
+                'STATE': np.zeros(n_rows, dtype=np.int8), 'KERN_FWD': np.zeros(n_rows, dtype=np.float64),
+                'KERN_FWDREV': np.zeros(n_rows, dtype=np.float64), 'KERN_REV': np.zeros(n_rows, dtype=np.float64),
+                'KMER': np.zeros(n_rows, dtype=np.uint64)}
+        self._check(self.lib.pav_density_table(self.handle, job, _ptr(cols['INDEX']), _ptr(cols['STATE_MER']),
+                                               _ptr(cols['STATE']), _ptr(cols['KERN_FWD']), _ptr(cols['KERN_FWDREV']),
+                                               _ptr(cols['KERN_REV']), _ptr(cols['KMER'])), 'pav_density_table')
+        return cols
+
+    def density_annotate(self, job, n_rows, ref_id, ref_up, ref_dn, qry_index_base, tig_up, tig_dn):
+        flank = np.zeros(n_rows, dtype=np.uint8)
+        match = np.zeros(n_rows, dtype=np.uint8)
+        self._check(self.lib.pav_density_annotate(
+            self.handle, job, ref_id, ref_up[0], ref_up[1], ref_dn[0], ref_dn[1], qry_index_base, tig_up[0], tig_up[1],
+            tig_dn[0], tig_dn[1], _ptr(flank) or ctypes.c_void_p(flank.ctypes.data),
+            _ptr(match) or ctypes.c_void_p(match.ctypes.data)), 'pav_density_annotate')
+        return flank, match
 
     # -- profiling ----------------------------------------------------------------------------------------
     def prof_enable(self, on=True):

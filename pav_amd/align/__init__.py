@@ -1,0 +1,3 @@
+"""Alignment helpers on the host side of the hot path (mirror of the used parts of ``pavlib/align``)."""
+from .lift import AlignLift  # noqa: F401
+from .cigar import cigar_str_to_tuples, tokenize  # noqa: F401

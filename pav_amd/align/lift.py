@@ -1,0 +1,199 @@
+"""
+Alignment lift-over between reference and contig coordinates - host mirror of ``pavlib/align/lift.py``.
+
+The reference builds two interval trees per alignment record (pavlib/align/lift.py:380-476) and queries them with
+point lookups.  The CIGAR operations tile both coordinate axes, so the same answers come from sorted operation
+boundaries + binary search; the tables are built with numpy from a vectorised tokenizer.  All quirks are kept:
+intervals whose *target* span is 1 (length-1 match operations, insertions, deletions) lift to ``data[1]``
+(lift.py:163-181, 257-258), a query exactly at an alignment end matches the last interval (lift.py:122-138),
+reversed records translate through ``QRY_LEN - pos`` (lift.py:116, 260).
+"""
+
+import bisect
+import collections
+
+import numpy as np
+
+from .. import seq as pavseq
+from .cigar import tokenize
+
+
+class _Intervals:
+    """Disjoint half-open [begin, end) intervals with a (d0, d1) payload, sorted by begin."""
+
+    def __init__(self, begin, end, d0, d1):
+        self.begin, self.end, self.d0, self.d1 = begin, end, d0, d1
+        self._b = begin.tolist()
+
+    def at(self, pos):
+        """Index of the interval containing ``pos`` or -1."""
+        i = bisect.bisect_right(self._b, pos) - 1
+        if i >= 0 and pos < self.end[i]:
+            return i
+        return -1
+
+
+class AlignLift:
+    """Lift coordinates through alignment records (same constructor and methods as pavlib.align.AlignLift)."""
+
+    def __init__(self, df, df_fai, cache_align=10):
+        self.df = df
+        self.df_fai = df_fai
+        self.cache_align = cache_align
+        if len(set(df.index)) != df.shape[0]:
+            raise RuntimeError('Cannot create AlignLift object with duplicate index values')
+        # per subject / per query: list of (begin, end, index); lookups need "exactly one record contains pos"
+        self.ref_tree = collections.defaultdict(list)
+        self.tig_tree = collections.defaultdict(list)
+        for index, row in df.iterrows():
+            if row['END'] > row['POS']:
+                self.ref_tree[row['#CHROM']].append((row['POS'], row['END'], index))
+            if row['QRY_END'] > row['QRY_POS']:
+                self.tig_tree[row['QRY_ID']].append((row['QRY_POS'], row['QRY_END'], index))
+        self.cache_queue = collections.deque()
+        self.ref_cache = dict()
+        self.tig_cache = dict()
+
+    @staticmethod
+    def _containing(records, pos):
+        return [index for begin, end, index in records if begin <= pos < end]
+
+    # ---- query -> subject (lift.py:51-185) -------------------------------------------------------------
+    def lift_to_sub(self, query_id, coord, gap=False):
+        ret_list = issubclass(coord.__class__, (list, tuple))
+        if not ret_list:
+            coord = (coord,)
+        out = []
+        for pos in coord:
+            pos_org = pos
+            hits = self._containing(self.tig_tree.get(query_id, ()), pos)
+            if len(hits) == 1:
+                index = hits[0]
+            elif len(hits) == 0 and gap:
+                out.append(self._get_subject_gap(query_id, pos))
+                continue
+            else:
+                out.append(None)
+                continue
+            if index not in self.tig_cache:
+                self._add_align(index)
+            tree = self.tig_cache[index]
+            row = self.df.loc[index]
+            if row['REV']:
+                pos = self.df_fai[query_id] - pos
+            i = tree.at(pos)
+            if i < 0:
+                i = tree.at(pos - 1)                    # a query exactly at the alignment end (lift.py:122-138)
+                if i < 0 or tree.end[i] != pos:
+                    raise RuntimeError((
+                        'Found no matches in a lift-tree for a record within a '
+                        'global to-subject tree: {}:{} (index={}, gap={})'
+                    ).format(query_id, pos_org, index, gap))
+            d0, d1 = int(tree.d0[i]), int(tree.d1[i])
+            lift_pos = d0 + (int(pos) - int(tree.begin[i])) if d1 - d0 > 1 else d1
+            out.append((row['#CHROM'], lift_pos, row['REV'], lift_pos, lift_pos, (row['INDEX'],)))
+        return out if ret_list else out[0]
+
+    # ---- subject -> query (lift.py:187-272) ------------------------------------------------------------
+    def lift_to_qry(self, subject_id, coord):
+        ret_list = issubclass(coord.__class__, (list, tuple))
+        if not ret_list:
+            coord = (coord,)
+        out = []
+        for pos in coord:
+            hits = self._containing(self.ref_tree.get(subject_id, ()), pos)
+            if len(hits) != 1:
+                out.append(None)
+                continue
+            index = hits[0]
+            if index not in self.ref_cache:
+                self._add_align(index)
+            tree = self.ref_cache[index]
+            row = self.df.loc[index]
+            i = tree.at(pos)
+            if i < 0:
+                raise RuntimeError((
+                    'Program bug: Found no matches in a lift-tree for a record withing a '
+                    'global to-query tree: {}:{} (index={})'
+                ).format(subject_id, pos, index))
+            d0, d1 = int(tree.d0[i]), int(tree.d1[i])
+            qry_pos = d0 + (int(pos) - int(tree.begin[i])) if d1 - d0 > 1 else d1
+            if row['REV']:
+                qry_pos = self.df_fai[row['QRY_ID']] - qry_pos
+            out.append((row['QRY_ID'], qry_pos, row['REV'], qry_pos, qry_pos, (row['INDEX'],)))
+        return out if ret_list else out[0]
+
+    def lift_region_to_sub(self, region, gap=False):
+        """Query region -> subject region, or None (lift.py:274-302)."""
+        sub_pos, sub_end = self.lift_to_sub(region.chrom, (region.pos, region.end), gap)
+        if sub_pos is None or sub_end is None:
+            return None
+        if sub_pos[0] != sub_end[0] or (sub_pos[2] is not None and sub_end[2] is not None and sub_pos[2] != sub_end[2]):
+            return None
+        return pavseq.Region(sub_pos[0], sub_pos[1], sub_end[1], is_rev=False, pos_min=sub_pos[3], pos_max=sub_pos[4],
+                             end_min=sub_end[3], end_max=sub_end[4], pos_aln_index=(sub_pos[5],), end_aln_index=(sub_end[5],))
+
+    def lift_region_to_qry(self, region):
+        """Subject region -> query region, or None (lift.py:304-331)."""
+        query_pos, query_end = self.lift_to_qry(region.chrom, (region.pos, region.end))
+        if query_pos is None or query_end is None:
+            return None
+        if query_pos[0] != query_end[0] or query_pos[2] != query_end[2]:
+            return None
+        return pavseq.Region(query_pos[0], query_pos[1], query_end[1], is_rev=query_pos[2], pos_min=query_pos[3],
+                             pos_max=query_pos[4], end_min=query_end[3], end_max=query_end[4],
+                             pos_aln_index=(query_pos[5],), end_aln_index=(query_end[5],))
+
+    def _get_subject_gap(self, query_id, pos):
+        """Interpolate into the gap between two records of one contig (lift.py:333-378)."""
+        if pos is None:
+            return None
+        subdf = self.df.loc[self.df['QRY_ID'] == query_id]
+        if not np.any(subdf['QRY_END'] < pos) or not np.any(subdf['QRY_POS'] > pos):
+            return None
+        row_l = subdf.loc[subdf.loc[subdf['QRY_END'] < pos, 'QRY_END'].sort_values().index[-1]]
+        row_r = subdf.loc[subdf.loc[subdf['QRY_POS'] > pos, 'QRY_POS'].sort_values().index[0]]
+        if row_l['#CHROM'] != row_r['#CHROM']:
+            return None
+        return (row_l['#CHROM'], int((row_l['QRY_END'] + row_r['QRY_POS']) / 2),
+                row_l['REV'] if row_l['REV'] == row_r['REV'] else None, row_l['QRY_END'], row_r['QRY_POS'],
+                (row_l['INDEX'], row_r['INDEX']))
+
+    def _add_align(self, index):
+        """Build and cache the two operation tables of one record (lift.py:380-476)."""
+        if index in self.ref_cache:
+            while index in self.cache_queue:
+                self.cache_queue.remove(index)
+            self.cache_queue.appendleft(index)
+            return
+        self._check_and_clear()
+        row = self.df.loc[index]
+        lens, ops = tokenize(row['CIGAR'])
+        if np.any(lens == 0):
+            raise ValueError('IntervalTree: Null Interval objects not allowed in IntervalTree: zero-length CIGAR operation')
+        is_match = (ops == ord('=')) | (ops == ord('X')) | (ops == ord('M'))
+        is_ins, is_del = ops == ord('I'), ops == ord('D')
+        is_clip = (ops == ord('S')) | (ops == ord('H'))
+        other = ~(is_match | is_ins | is_del | is_clip)
+        if np.any(other):
+            raise RuntimeError('Unhandled CIGAR operation: {}: Alignment {}:{} ({})'.format(
+                chr(int(ops[np.flatnonzero(other)[0]])), row['#CHROM'], row['POS'], row['QRY_ID']))
+        sub_adv = np.where(is_match | is_del, lens, 0)
+        qry_adv = np.where(is_match | is_ins | is_clip, lens, 0)
+        sub_bp = int(row['POS']) + np.concatenate(([0], np.cumsum(sub_adv)[:-1]))
+        qry_bp = np.concatenate(([0], np.cumsum(qry_adv)[:-1]))
+        # reference axis: matches map to the query span, deletions to (qry_bp, qry_bp + 1)
+        r = is_match | is_del
+        self.ref_cache[index] = _Intervals(sub_bp[r], sub_bp[r] + lens[r], qry_bp[r],
+                                           np.where(is_match[r], qry_bp[r] + lens[r], qry_bp[r] + 1))
+        # query axis: matches map to the subject span, insertions to (sub_bp, sub_bp + 1)
+        q = is_match | is_ins
+        self.tig_cache[index] = _Intervals(qry_bp[q], qry_bp[q] + lens[q], sub_bp[q],
+                                           np.where(is_match[q], sub_bp[q] + lens[q], sub_bp[q] + 1))
+        self.cache_queue.appendleft(index)
+
+    def _check_and_clear(self):
+        while len(self.cache_queue) >= self.cache_align:
+            index = self.cache_queue.pop()
+            del self.ref_cache[index]
+            del self.tig_cache[index]

@@ -1,3 +1,850 @@
-// K-mer state + density scan (placeholder translation unit until the kernels land).
+// K-mer state + density scan on gfx950 (inversion caller): batched over independent (reference region, contig
+// region) jobs.  Replaces the `scripts/density.py` subprocess of pavlib.inv.scan_for_inv:
+//   pavlib/seq.py:305-325            ref_kmers                      -> k_ref_insert   (hash set with counts in HBM)
+//   scripts/density.py:510-539       low-complexity gate, -r        -> k_ref_insert / host gate
+//   scripts/density.py:165-203       STATE_MER, informative subset  -> k_tig_state, k_compact_*
+//   scripts/density.py:69-115,206-255  gaussian_kde at sampled sites -> k_kde_eval (mode 0)
+//   scripts/density.py:257-323       change test, np.interp / fill  -> k_windows, k_kde_eval (mode 1)
+//   scripts/density.py:329-338       spike rule, arg-max STATE      -> k_finalize
+//   pavlib/density.py:330-361        rl_encoder                     -> k_heads + host assembly
+//   pavlib/inv.py:457-561            annotate_inv_dup_mers          -> k_canon_insert, k_annotate
+// Integer work is exact.  The KDE is FP64 vector work (no MFMA: exp of a difference is not a contraction); every
+// evaluation point accumulates its data points in ascending order like scipy's gaussian_kernel_estimate, so the
+// only difference from the reference is the device exp() (<= 1 ulp per term).  Built with -ffp-contract=off.
 #include "common.h"
-extern "C" void pav_density_release(pav_ctx *ctx) { (void)ctx; }
+
+#include <algorithm>
+#include <cmath>
+
+namespace pav {
+
+constexpr int DTILE = 2048;               // positions per tile (256 lanes x 8); job arenas are tile aligned
+constexpr uint64_t EMPTY_KEY = ~0ull;
+
+struct JobDev {
+    uint64_t ref_abs;                     // arena position of the first base of region_ref
+    uint64_t tig_abs;                     // arena position of the first base of region_tig
+    uint32_t ref_len, tig_len;
+    uint32_t ref_rc, srs;
+    uint64_t ht_off;                      // first slot of this job's hash table
+    uint32_t ht_mask;                     // capacity - 1 (power of two)
+    uint32_t first_tile;                  // first tile of the job in the contig-position arena
+    uint64_t rpos_off;                    // job start in the reference-position arena
+    uint64_t tpos_off;                    // job start in the contig-position / row arena
+};
+
+struct JobStat {                          // written by kernels, zeroed per batch
+    uint32_t n_ref_valid, max_count;
+    uint32_t st_count[3];                 // STATE_MER counts before the min-state-count rule
+    uint32_t n_rows;
+    uint32_t m[3], fill_n;
+    unsigned long long s1[3], s2[3];      // sum / sum of squares of the row numbers of each state
+    unsigned long long max_key;           // packed (first position << 32 | slot) of the max-count k-mer (failure path)
+};
+
+struct JobKde {                           // host -> device after the first readback
+    uint32_t finalised, n, n_samp, srs;
+    uint32_t m[3], pad;
+    double inv_h[3], norm[3], w[3], cnt[3];
+};
+
+struct EvalTile { uint32_t job, first, count, mode; };   // mode 0: sampled sites, 1: fill list
+
+struct HeadEvent { uint32_t job, row; int32_t state; uint32_t index, prev_index; uint32_t pad; };
+
+struct DensityState {
+    DevBuf jobs, stat, kde, tile_job_r, tile_job_t, keys, cnt, first;
+    DevBuf st_tmp, tile_sum, tile_pre, index, state_mer, state, kmer, kern[3], list[3], pscaled[3], fill_list;
+    DevBuf tiles, events, ev_count, scratch;
+    std::vector<JobDev> h_jobs;
+    std::vector<JobKde> h_kde;
+    std::vector<pav_den_result> results;
+    std::vector<std::vector<pav_run>> runs;
+    pav_den_params params{};
+    uint32_t n_jobs = 0;
+    uint64_t arena_t = 0;
+    bool valid = false;
+    void release() {
+        DevBuf *all[] = {&jobs, &stat, &kde, &tile_job_r, &tile_job_t, &keys, &cnt, &first, &st_tmp, &tile_sum, &tile_pre,
+                         &index, &state_mer, &state, &kmer, &kern[0], &kern[1], &kern[2], &list[0], &list[1], &list[2],
+                         &pscaled[0], &pscaled[1], &pscaled[2], &fill_list, &tiles, &events, &ev_count, &scratch};
+        for (DevBuf *b : all) b->release();
+    }
+};
+
+// ---- k-mer access ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return x;
+}
+__device__ __forceinline__ uint64_t kmer_mask(int k) { return (1ull << (2 * k)) - 1ull; }   // k <= 31
+
+// Reverse the k 2-bit groups in the low 2k bits: window order (first base lowest) <-> kanapy order (first base highest)
+__device__ __forceinline__ uint64_t rev_groups(uint64_t x, int k) {
+    uint64_t r = __brevll(x) >> (64 - 2 * k);
+    return ((r & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((r & 0x5555555555555555ull) << 1);
+}
+
+// K-mer window starting at arena position a: x = bases in window order (base j at bits 2j); returns false when any of
+// the k bases is non-ACGT (kanapy's stream skips those windows).
+__device__ __forceinline__ bool kmer_window(const uint32_t *__restrict__ two, const uint32_t *__restrict__ mask, uint64_t a,
+                                            int k, uint64_t &x) {
+    const uint64_t *two64 = reinterpret_cast<const uint64_t *>(two);
+    const uint64_t *mask64 = reinterpret_cast<const uint64_t *>(mask);
+    const uint64_t w = a >> 5;
+    const int b = (int)(a & 31) * 2;
+    uint64_t v = two64[w] >> b;
+    if (b) v |= two64[w + 1] << (64 - b);
+    x = v & kmer_mask(k);
+    const uint64_t w2 = a >> 6;
+    const int b2 = (int)(a & 63);
+    uint64_t y = mask64[w2] >> b2;
+    if (b2) y |= mask64[w2 + 1] << (64 - b2);
+    return (y & ((1ull << k) - 1ull)) == 0;
+}
+// In kanapy order: kmer = rev_groups(x), reverse complement = x ^ mask (see DESIGN.md "k-mer encoding").
+
+__device__ __forceinline__ bool table_has(const unsigned long long *__restrict__ keys, uint64_t off, uint32_t hmask,
+                                          uint64_t key) {
+    uint32_t s = (uint32_t)mix64(key) & hmask;
+    while (true) {
+        const uint64_t cur = keys[off + s];
+        if (cur == key) return true;
+        if (cur == EMPTY_KEY) return false;
+        s = (s + 1) & hmask;
+    }
+}
+
+__device__ __forceinline__ uint32_t table_insert(unsigned long long *__restrict__ keys, uint64_t off, uint32_t hmask,
+                                                 uint64_t key) {
+    uint32_t s = (uint32_t)mix64(key) & hmask;
+    while (true) {
+        const unsigned long long old = atomicCAS(&keys[off + s], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+        if (old == EMPTY_KEY || old == key) return s;
+        s = (s + 1) & hmask;
+    }
+}
+
+// ---- reference k-mers -> hash set with counts (pavlib/seq.py:305-325; -r: scripts/density.py:538-539) ----------
+__global__ __launch_bounds__(256) void k_ref_insert(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
+                                                    SeqView R, int k, uint32_t limit, unsigned long long *__restrict__ keys,
+                                                    uint32_t *__restrict__ cnt, uint32_t *__restrict__ first,
+                                                    JobStat *__restrict__ stat) {
+    const uint64_t ap = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t j = tile_job[ap / DTILE];
+    const JobDev jd = jobs[j];
+    const uint64_t i = ap - jd.rpos_off;
+    bool valid = false;
+    if (i + (uint64_t)k <= jd.ref_len) {
+        uint64_t x;
+        valid = kmer_window(R.two, R.mask, jd.ref_abs + i, k, x);
+        if (valid) {
+            const uint64_t key = jd.ref_rc ? (x ^ kmer_mask(k)) : rev_groups(x, k);   // set of rc(kmer) when -r true
+            const uint32_t s = table_insert(keys, jd.ht_off, jd.ht_mask, key);
+            const uint32_t c = atomicAdd(&cnt[jd.ht_off + s], 1u) + 1u;
+            atomicMin(&first[jd.ht_off + s], (uint32_t)i);
+            if (c > limit) atomicMax(&stat[j].max_count, c);
+        }
+    }
+    const unsigned long long b = __ballot(valid);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&stat[j].n_ref_valid, (uint32_t)__popcll(b));
+}
+
+// Failure path only: first-inserted k-mer among those with the maximum count (message of scripts/density.py:519-526)
+__global__ void k_max_kmer(const JobDev *__restrict__ jobs, uint32_t j, const uint32_t *__restrict__ cnt,
+                           const uint32_t *__restrict__ first, JobStat *__restrict__ stat) {
+    const JobDev jd = jobs[j];
+    const uint32_t mx = stat[j].max_count;
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s <= jd.ht_mask; s += gridDim.x * blockDim.x)
+        if (cnt[jd.ht_off + s] == mx)
+            atomicMin(&stat[j].max_key, ((unsigned long long)first[jd.ht_off + s] << 32) | s);
+}
+
+// ---- contig k-mers -> STATE_MER (scripts/density.py:165-175) -------------------------------------------------
+__global__ __launch_bounds__(256) void k_tig_state(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
+                                                   SeqView T, int k, const unsigned long long *__restrict__ keys,
+                                                   int8_t *__restrict__ st_tmp, JobStat *__restrict__ stat) {
+    const uint64_t ap = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t j = tile_job[ap / DTILE];
+    const JobDev jd = jobs[j];
+    const uint64_t i = ap - jd.tpos_off;
+    int st = -1;
+    if (i + (uint64_t)k <= jd.tig_len) {
+        uint64_t x;
+        if (kmer_window(T.two, T.mask, jd.tig_abs + i, k, x)) {
+            const bool in_f = table_has(keys, jd.ht_off, jd.ht_mask, rev_groups(x, k));
+            const bool in_r = table_has(keys, jd.ht_off, jd.ht_mask, x ^ kmer_mask(k));
+            st = in_f ? (in_r ? 1 : 0) : (in_r ? 2 : -1);            // KMER_ORIENTATION_STATE, density.py:38-43
+        }
+    }
+    st_tmp[ap] = (int8_t)st;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const unsigned long long b = __ballot(st == s);
+        if ((threadIdx.x & 63) == 0 && b) atomicAdd(&stat[j].st_count[s], (uint32_t)__popcll(b));
+    }
+}
+
+// ---- compaction to informative rows (scripts/density.py:178-203) ----------------------------------------------
+// Scanned quantities per position: [0] row kept, [1..3] row of state 0/1/2 kept.
+__device__ __forceinline__ void block_scan4(uint32_t (&v)[4], uint32_t (&total)[4], uint32_t *lds /* 16 */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint32_t x = v[q];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(x, d); if (lane >= d) x += y; }
+        inc[q] = x;
+        if (lane == 63) lds[wave * 4 + q] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint32_t base = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { uint32_t s = lds[w * 4 + q]; if (w < wave) base += s; tot += s; }
+        total[q] = tot;
+        v[q] = base + inc[q] - v[q];
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ int keep_state(int st, const JobStat &js, uint32_t min_state_count) {
+    if (st < 0) return -1;
+    return js.st_count[st] >= min_state_count ? st : -1;               // low-count states are dropped (density.py:181-190)
+}
+
+__global__ __launch_bounds__(256) void k_compact_reduce(const uint32_t *__restrict__ tile_job, const JobStat *__restrict__ stat,
+                                                        const int8_t *__restrict__ st_tmp, uint32_t min_state_count,
+                                                        uint32_t *__restrict__ tile_sum /* [tiles][4] */) {
+    __shared__ uint32_t lds[16];
+    const uint32_t j = tile_job[blockIdx.x];
+    const JobStat js = stat[j];
+    const uint64_t base = (uint64_t)blockIdx.x * DTILE + (uint64_t)threadIdx.x * 8;
+    const uint64_t packed = *reinterpret_cast<const uint64_t *>(st_tmp + base);
+    uint32_t c[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int st = keep_state((int)(int8_t)(packed >> (8 * t)), js, min_state_count);
+        if (st >= 0) { c[0]++; c[1 + st]++; }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) c[q] += __shfl_xor(c[q], d);
+    }
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lds[(threadIdx.x >> 6) * 4 + q] = c[q];
+    __syncthreads();
+    if (threadIdx.x < 4)
+        tile_sum[(uint64_t)blockIdx.x * 4 + threadIdx.x] = lds[threadIdx.x] + lds[4 + threadIdx.x] + lds[8 + threadIdx.x] + lds[12 + threadIdx.x];
+}
+
+// Single workgroup: exclusive scan over tiles of the 4 counters.
+__global__ __launch_bounds__(256) void k_scan_tiles4(const uint32_t *__restrict__ tile_sum, unsigned long long *__restrict__ tile_pre,
+                                                     uint32_t n_tiles) {
+    __shared__ uint32_t lds[16];
+    __shared__ unsigned long long carry[4];
+    if (threadIdx.x < 4) carry[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_tiles; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        uint32_t v[4], tot[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = i < n_tiles ? tile_sum[(uint64_t)i * 4 + q] : 0;
+        block_scan4(v, tot, lds);
+        if (i < n_tiles)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tile_pre[(uint64_t)i * 4 + q] = carry[q] + v[q];
+        __syncthreads();
+        if (threadIdx.x == 0)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) carry[q] += tot[q];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) tile_pre[(uint64_t)n_tiles * 4 + threadIdx.x] = carry[threadIdx.x];
+}
+
+struct CompactArgs {
+    const JobDev *jobs; const uint32_t *tile_job; JobStat *stat; const int8_t *st_tmp;
+    const unsigned long long *tile_pre; SeqView T; int k; uint32_t min_state_count;
+    uint32_t *index; int8_t *state_mer; int8_t *state; unsigned long long *kmer; uint32_t *list[3];
+};
+
+__global__ __launch_bounds__(256) void k_compact_scatter(CompactArgs A) {
+    __shared__ uint32_t lds[16];
+    __shared__ unsigned long long red[4][7];
+    const uint32_t j = A.tile_job[blockIdx.x];
+    const JobDev jd = A.jobs[j];
+    const JobStat js = A.stat[j];
+    const uint64_t base = (uint64_t)blockIdx.x * DTILE + (uint64_t)threadIdx.x * 8;
+    const uint64_t packed = *reinterpret_cast<const uint64_t *>(A.st_tmp + base);
+    int st[8];
+    uint32_t c[4] = {0, 0, 0, 0}, tot[4];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        st[t] = keep_state((int)(int8_t)(packed >> (8 * t)), js, A.min_state_count);
+        if (st[t] >= 0) { c[0]++; c[1 + st[t]]++; }
+    }
+    block_scan4(c, tot, lds);
+    // job-relative bases: global tile prefix minus the prefix at the job's first tile
+    unsigned long long pre[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        pre[q] = A.tile_pre[(uint64_t)blockIdx.x * 4 + q] - A.tile_pre[(uint64_t)jd.first_tile * 4 + q] + c[q];
+    unsigned long long s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        if (st[t] < 0) continue;
+        const uint64_t i = base + t - jd.tpos_off;                     // k-mer offset in region_tig = INDEX
+        const uint64_t row = pre[0]++;
+        const uint64_t o = jd.tpos_off + row;
+        uint64_t x;
+        kmer_window(A.T.two, A.T.mask, jd.tig_abs + i, A.k, x);
+        A.index[o] = (uint32_t)i;
+        A.state_mer[o] = (int8_t)st[t];
+        A.state[o] = -1;                                               // df['STATE'] = -1 (density.py:163)
+        A.kmer[o] = rev_groups(x, A.k);
+        const uint64_t rank = pre[1 + st[t]]++;
+        A.list[st[t]][jd.tpos_off + rank] = (uint32_t)row;             // INDEX_DEN of the state's data points, ascending
+        s1[st[t]] += row; s2[st[t]] += row * row;
+    }
+    // block reduction of the per-state moments, one atomic per block and quantity
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { s1[s] += __shfl_xor(s1[s], d); s2[s] += __shfl_xor(s2[s], d); }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        for (int s = 0; s < 3; ++s) { red[w][s] = s1[s]; red[w][3 + s] = s2[s]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const unsigned long long v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (v) atomicAdd(threadIdx.x < 3 ? &A.stat[j].s1[threadIdx.x] : &A.stat[j].s2[threadIdx.x - 3], v);
+    }
+    if (threadIdx.x == 0) {
+        if (tot[0]) atomicAdd(&A.stat[j].n_rows, tot[0]);
+        for (int s = 0; s < 3; ++s) if (tot[1 + s]) atomicAdd(&A.stat[j].m[s], tot[1 + s]);
+    }
+}
+
+// ---- KDE -----------------------------------------------------------------------------------------------------
+// points_ = data * (1 / h): what scipy's solve_triangular computes for a 1x1 cho_cov.
+__global__ __launch_bounds__(256) void k_pscale(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
+                                                const JobKde *__restrict__ kde, const uint32_t *__restrict__ l0,
+                                                const uint32_t *__restrict__ l1, const uint32_t *__restrict__ l2,
+                                                double *__restrict__ p0, double *__restrict__ p1, double *__restrict__ p2) {
+    const uint64_t ap = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t j = tile_job[ap / DTILE];
+    const JobKde kd = kde[j];
+    if (!kd.finalised) return;
+    const uint64_t t = ap - jobs[j].tpos_off;
+    if (t < kd.m[0]) p0[ap] = (double)l0[ap] * kd.inv_h[0];
+    if (t < kd.m[1]) p1[ap] = (double)l1[ap] * kd.inv_h[1];
+    if (t < kd.m[2]) p2[ap] = (double)l2[ap] * kd.inv_h[2];
+}
+
+__device__ __forceinline__ int argmax3(double a, double b, double c) {   // np.argmax: first maximum wins
+    int m = 0; double v = a;
+    if (b > v) { v = b; m = 1; }
+    if (c > v) m = 2;
+    return m;
+}
+
+// gaussian_kernel_estimate (scipy/stats/_stats.pyx) for one state at one evaluation point; `ps` is wave-uniform so
+// the data stream goes through the scalar cache.  Accumulation order = data ascending, as in scipy.
+__device__ __forceinline__ double kde_state(const double *__restrict__ ps, uint32_t m, double xs, double norm, double w) {
+    double est = 0.0;
+    uint32_t i = 0;
+    for (; i + 4 <= m; i += 4) {
+        const double a0 = ps[i], a1 = ps[i + 1], a2 = ps[i + 2], a3 = ps[i + 3];
+        const double r0 = a0 - xs, r1 = a1 - xs, r2 = a2 - xs, r3 = a3 - xs;
+        est += w * (exp(-(r0 * r0) / 2) * norm);
+        est += w * (exp(-(r1 * r1) / 2) * norm);
+        est += w * (exp(-(r2 * r2) / 2) * norm);
+        est += w * (exp(-(r3 * r3) / 2) * norm);
+    }
+    for (; i < m; ++i) {
+        const double r = ps[i] - xs;
+        est += w * (exp(-(r * r) / 2) * norm);
+    }
+    return est;
+}
+
+struct KdeArgs {
+    const JobDev *jobs; const JobKde *kde; const EvalTile *tiles; const uint32_t *fill_list;
+    const double *ps[3]; double *kern[3]; int8_t *state;
+};
+
+// One wave per tile of 64 evaluation points of one job.
+__global__ __launch_bounds__(64) void k_kde_eval(KdeArgs A) {
+    const EvalTile t = A.tiles[blockIdx.x];
+    const JobKde kd = A.kde[t.job];
+    const uint64_t off = A.jobs[t.job].tpos_off;
+    if (threadIdx.x >= t.count) return;
+    uint32_t x;
+    if (t.mode == 0) {                                                 // sampled sites (density.py:211-214)
+        const uint64_t q = (uint64_t)t.first + threadIdx.x;
+        const uint64_t xx = q * kd.srs;
+        x = xx > kd.n - 1 ? kd.n - 1 : (uint32_t)xx;
+    } else {
+        x = A.fill_list[off + t.first + threadIdx.x];
+    }
+    double val[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        if (kd.m[s] == 0) { val[s] = 0.0; continue; }                  // density.py:84,92,100
+        const double est = kde_state(A.ps[s] + off, kd.m[s], (double)x * kd.inv_h[s], kd.norm[s], kd.w[s]);
+        val[s] = est * kd.cnt[s];                                      // density.py:110-115
+        A.kern[s][off + x] = val[s];
+    }
+    if (kd.m[0] == 0) A.kern[0][off + x] = 0.0;
+    if (kd.m[1] == 0) A.kern[1][off + x] = 0.0;
+    if (kd.m[2] == 0) A.kern[2][off + x] = 0.0;
+    if (t.mode == 0) A.state[off + x] = (int8_t)argmax3(val[0], val[1], val[2]);   // density.py:250-255
+}
+
+// One lane per window between consecutive sampled sites (scripts/density.py:257-323): linear interpolation when
+// neither the states nor the densities change, otherwise its inner sites are queued for full evaluation.
+__global__ __launch_bounds__(256) void k_windows(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
+                                                 const JobKde *__restrict__ kde, const int8_t *__restrict__ state_mer,
+                                                 const int8_t *__restrict__ state, double *__restrict__ k0,
+                                                 double *__restrict__ k1, double *__restrict__ k2, double delta,
+                                                 uint32_t *__restrict__ fill_list, JobStat *__restrict__ stat) {
+    const uint64_t ap = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t j = tile_job[ap / DTILE];
+    const JobKde kd = kde[j];
+    if (!kd.finalised) return;
+    const uint64_t off = jobs[j].tpos_off;
+    const uint64_t q = ap - off;
+    if (q + 1 >= kd.n_samp) return;
+    const uint64_t a = q * kd.srs;
+    uint64_t b = (q + 1) * kd.srs;
+    if (b > kd.n - 1) b = kd.n - 1;
+    if (b == a + 1) return;                                            // density.py:270-271
+    bool change = state[off + a] != state[off + b];
+    const int8_t sm = state_mer[off + a];
+    for (uint64_t i = a + 1; i <= b && !change; ++i) change = state_mer[off + i] != sm;      // :273-275
+    double *kk[3] = {k0, k1, k2};
+    double dmax = 0.0;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) { const double d = fabs(kk[s][off + a] - kk[s][off + b]); if (d > dmax) dmax = d; }
+    if (change || dmax > delta) {                                      // :277-283
+        const uint32_t cnt = (uint32_t)(b - a - 1);
+        const uint32_t at = atomicAdd(&stat[j].fill_n, cnt);
+        for (uint32_t t = 0; t < cnt; ++t) fill_list[off + at + t] = (uint32_t)(a + 1 + t);
+    } else {                                                           // np.interp: slope * (x - x0) + y0
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const double ya = kk[s][off + a], yb = kk[s][off + b];
+            const double slope = (yb - ya) / ((double)b - (double)a);
+            for (uint64_t x = a + 1; x < b; ++x) kk[s][off + x] = slope * ((double)x - (double)a) + ya;
+        }
+    }
+}
+
+// Spike penalty and arg-max (scripts/density.py:329-338)
+__global__ __launch_bounds__(256) void k_finalize(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
+                                                  const JobKde *__restrict__ kde, double *__restrict__ k0,
+                                                  double *__restrict__ k1, double *__restrict__ k2, int8_t *__restrict__ state) {
+    const uint64_t ap = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t j = tile_job[ap / DTILE];
+    const JobKde kd = kde[j];
+    if (!kd.finalised || ap - jobs[j].tpos_off >= kd.n) return;
+    double a = k0[ap], b = k1[ap], c = k2[ap];
+    if (a > 1.0) { a = 1 / a; k0[ap] = a; }
+    if (b > 1.0) { b = 1 / b; k1[ap] = b; }
+    if (c > 1.0) { c = 1 / c; k2[ap] = c; }
+    state[ap] = (int8_t)argmax3(a, b, c);
+}
+
+// Run heads for rl_encoder (pavlib/density.py:330-361): one event per row that starts a run, plus one end marker.
+__global__ __launch_bounds__(256) void k_heads(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
+                                               const JobStat *__restrict__ stat, const int8_t *__restrict__ state,
+                                               const uint32_t *__restrict__ index, HeadEvent *__restrict__ events,
+                                               uint32_t cap, uint32_t *__restrict__ ev_count) {
+    const uint64_t ap = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t j = tile_job[ap / DTILE];
+    const uint32_t n = stat[j].n_rows;
+    const uint64_t r = ap - jobs[j].tpos_off;
+    if (r >= n) return;
+    const bool head = r == 0 || state[ap] != state[ap - 1];
+    if (head) {
+        const uint32_t e = atomicAdd(ev_count, 1u);
+        if (e < cap) events[e] = HeadEvent{j, (uint32_t)r, (int32_t)state[ap], index[ap], r ? index[ap - 1] : 0u, 0u};
+    }
+    if (r == n - 1) {
+        const uint32_t e = atomicAdd(ev_count, 1u);
+        if (e < cap) events[e] = HeadEvent{j, n, -2, 0u, index[ap], 0u};
+    }
+}
+
+// ---- annotate_inv_dup_mers (pavlib/inv.py:457-561) --------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_canon_insert(SeqView R, uint64_t abs0, uint32_t len, int k,
+                                                      unsigned long long *__restrict__ keys, uint32_t hmask) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i + (uint64_t)k > len) return;
+    uint64_t x;
+    if (!kmer_window(R.two, R.mask, abs0 + i, k, x)) return;
+    const uint64_t f = rev_groups(x, k), r = x ^ kmer_mask(k);
+    table_insert(keys, 0, hmask, f <= r ? f : r);                      // canonical_complement = numeric min
+}
+
+__global__ __launch_bounds__(256) void k_annotate(const uint32_t *__restrict__ index, const unsigned long long *__restrict__ kmer,
+                                                  uint64_t off, uint32_t n, int k, int64_t base, int64_t up_pos, int64_t up_end,
+                                                  int64_t dn_pos, int64_t dn_end, const unsigned long long *__restrict__ keys_up,
+                                                  uint32_t mask_up, const unsigned long long *__restrict__ keys_dn,
+                                                  uint32_t mask_dn, uint8_t *__restrict__ flank, uint8_t *__restrict__ match) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t q = (int64_t)index[off + i] + base;                 // QRY_INDEX (inv.py:519)
+    uint8_t f = 0;
+    if (q >= up_pos && q < up_end - k) f = 1;                          // inv.py:524-527
+    if (q >= dn_pos && q < dn_end - k) f = 2;                          // inv.py:529-532
+    uint8_t m = 0;
+    if (f) {
+        const uint64_t km = kmer[off + i];                             // raw KMER against canonical sets (inv.py:537-553)
+        const bool in_up = table_has(keys_up, 0, mask_up, km), in_dn = table_has(keys_dn, 0, mask_dn, km);
+        const bool same = f == 1 ? in_up : in_dn, other = f == 1 ? in_dn : in_up;
+        m = same ? (other ? 3 : 1) : (other ? 2 : 3);                  // KMER_LOC_STATE: NA / OTHER / SAME / NA
+    }
+    flank[i] = f;
+    match[i] = m;
+}
+
+static uint32_t pow2_at_least(uint64_t n) {
+    uint64_t c = 64;
+    while (c < n) c <<= 1;
+    return (uint32_t)c;
+}
+
+static DensityState *dstate(pav_ctx *ctx) {
+    if (!ctx->density) ctx->density = new DensityState();
+    return static_cast<DensityState *>(ctx->density);
+}
+
+}  // namespace pav
+
+using namespace pav;
+
+extern "C" {
+
+void pav_density_release(pav_ctx *ctx) {
+    if (!ctx || !ctx->density) return;
+    DensityState *D = static_cast<DensityState *>(ctx->density);
+    D->release();
+    delete D;
+    ctx->density = nullptr;
+}
+
+uint64_t pav_kmer_rev_complement(uint64_t kmer, int k) {
+    uint64_t rc = 0;
+    for (int i = 0; i < k; ++i) { rc = (rc << 2) | ((kmer & 3ull) ^ 3ull); kmer >>= 2; }
+    return rc;
+}
+
+uint64_t pav_kmer_canonical(uint64_t kmer, int k) {
+    const uint64_t rc = pav_kmer_rev_complement(kmer, k);
+    return kmer <= rc ? kmer : rc;
+}
+
+int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, const pav_den_params *pp,
+                      pav_den_result *results) {
+    if (!ctx || !pp || (n_jobs && (!jobs || !results))) return fail(ctx, PAV_E_ARG, "pav_density_batch: null argument");
+    if (pp->k < 1 || pp->k > 31) return fail(ctx, PAV_E_LIMIT, "pav_density_batch: k = %d is outside 1..31", pp->k);
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    DensityState *D = dstate(ctx);
+    D->valid = false;
+    D->n_jobs = n_jobs;
+    D->params = *pp;
+    D->results.assign(n_jobs, pav_den_result{});
+    D->runs.assign(n_jobs, {});
+    if (n_jobs == 0) { D->valid = true; return PAV_OK; }
+    const SeqStore &RS = ctx->seq[PAV_ROLE_REF], &TS = ctx->seq[PAV_ROLE_TIG];
+    const int k = pp->k;
+
+    // ---- plan arenas --------------------------------------------------------------------------------------
+    D->h_jobs.assign(n_jobs, JobDev{});
+    uint64_t a_r = 0, a_t = 0, a_h = 0;
+    std::vector<uint32_t> tile_job_r, tile_job_t;
+    for (uint32_t j = 0; j < n_jobs; ++j) {
+        const pav_den_job &q = jobs[j];
+        if (q.ref_id >= RS.n || q.tig_id >= TS.n) return fail(ctx, PAV_E_ARG, "pav_density_batch: job %u references a sequence that is not loaded", j);
+        if (q.ref_end < q.ref_pos || q.ref_end > RS.len[q.ref_id] || q.tig_end < q.tig_pos || q.tig_end > TS.len[q.tig_id])
+            return fail(ctx, PAV_E_ARG, "pav_density_batch: job %u region outside its record", j);
+        if (q.state_run_smooth < 1) return fail(ctx, PAV_E_ARG, "pav_density_batch: job %u state_run_smooth must be >= 1", j);
+        JobDev &jd = D->h_jobs[j];
+        jd.ref_abs = RS.off[q.ref_id] + q.ref_pos;
+        jd.tig_abs = TS.off[q.tig_id] + q.tig_pos;
+        jd.ref_len = (uint32_t)(q.ref_end - q.ref_pos);
+        jd.tig_len = (uint32_t)(q.tig_end - q.tig_pos);
+        jd.ref_rc = q.ref_rc ? 1 : 0;
+        jd.srs = q.state_run_smooth;
+        const uint32_t cap = pow2_at_least(2ull * jd.ref_len + 2);
+        jd.ht_off = a_h; jd.ht_mask = cap - 1; a_h += cap;
+        jd.rpos_off = a_r; jd.tpos_off = a_t;
+        jd.first_tile = (uint32_t)(a_t / DTILE);
+        const uint64_t tr = (std::max<uint64_t>(jd.ref_len, 1) + DTILE - 1) / DTILE, tt = (std::max<uint64_t>(jd.tig_len, 1) + DTILE - 1) / DTILE;
+        tile_job_r.insert(tile_job_r.end(), tr, j);
+        tile_job_t.insert(tile_job_t.end(), tt, j);
+        a_r += tr * DTILE; a_t += tt * DTILE;
+    }
+    D->arena_t = a_t;
+    const uint32_t n_tiles_r = (uint32_t)tile_job_r.size(), n_tiles_t = (uint32_t)tile_job_t.size();
+
+    PAV_HIP(ctx, D->jobs.reserve(sizeof(JobDev) * n_jobs));
+    PAV_HIP(ctx, D->stat.reserve(sizeof(JobStat) * n_jobs));
+    PAV_HIP(ctx, D->kde.reserve(sizeof(JobKde) * n_jobs));
+    PAV_HIP(ctx, D->tile_job_r.reserve(4ull * n_tiles_r));
+    PAV_HIP(ctx, D->tile_job_t.reserve(4ull * n_tiles_t));
+    PAV_HIP(ctx, D->keys.reserve(8 * a_h));
+    PAV_HIP(ctx, D->cnt.reserve(4 * a_h));
+    PAV_HIP(ctx, D->first.reserve(4 * a_h));
+    PAV_HIP(ctx, D->st_tmp.reserve(a_t + 64));
+    PAV_HIP(ctx, D->tile_sum.reserve(16ull * n_tiles_t));
+    PAV_HIP(ctx, D->tile_pre.reserve(32ull * (n_tiles_t + 1)));
+    PAV_HIP(ctx, D->index.reserve(4 * a_t));
+    PAV_HIP(ctx, D->state_mer.reserve(a_t));
+    PAV_HIP(ctx, D->state.reserve(a_t));
+    PAV_HIP(ctx, D->kmer.reserve(8 * a_t));
+    PAV_HIP(ctx, D->fill_list.reserve(4 * a_t));
+    for (int s = 0; s < 3; ++s) {
+        PAV_HIP(ctx, D->kern[s].reserve(8 * a_t));
+        PAV_HIP(ctx, D->list[s].reserve(4 * a_t));
+        PAV_HIP(ctx, D->pscaled[s].reserve(8 * a_t));
+    }
+    hipStream_t st = ctx->stream;
+    PAV_HIP(ctx, hipMemcpyAsync(D->jobs.p, D->h_jobs.data(), sizeof(JobDev) * n_jobs, hipMemcpyHostToDevice, st));
+    PAV_HIP(ctx, hipMemcpyAsync(D->tile_job_r.p, tile_job_r.data(), 4ull * n_tiles_r, hipMemcpyHostToDevice, st));
+    PAV_HIP(ctx, hipMemcpyAsync(D->tile_job_t.p, tile_job_t.data(), 4ull * n_tiles_t, hipMemcpyHostToDevice, st));
+    PAV_HIP(ctx, hipMemsetAsync(D->stat.p, 0, sizeof(JobStat) * n_jobs, st));
+    PAV_HIP(ctx, hipMemsetAsync(D->keys.p, 0xFF, 8 * a_h, st));
+    PAV_HIP(ctx, hipMemsetAsync(D->cnt.p, 0, 4 * a_h, st));
+    PAV_HIP(ctx, hipMemsetAsync(D->first.p, 0xFF, 4 * a_h, st));
+
+    const JobDev *d_jobs = D->jobs.as<JobDev>();
+    JobStat *d_stat = D->stat.as<JobStat>();
+    const uint32_t *d_tjr = D->tile_job_r.as<uint32_t>(), *d_tjt = D->tile_job_t.as<uint32_t>();
+    unsigned long long *d_keys = D->keys.as<unsigned long long>();
+    const SeqView RV = RS.view(), TV = TS.view();
+
+    // ---- k-mer states and compaction -------------------------------------------------------------------------
+    PAV_LAUNCH(ctx, "k_ref_insert", k_ref_insert, (uint32_t)(a_r / 256), 256, 0, d_jobs, d_tjr, RV, k, pp->max_ref_kmer_count,
+               d_keys, D->cnt.as<uint32_t>(), D->first.as<uint32_t>(), d_stat);
+    PAV_LAUNCH(ctx, "k_tig_state", k_tig_state, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, TV, k, d_keys,
+               D->st_tmp.as<int8_t>(), d_stat);
+    PAV_LAUNCH(ctx, "k_compact_reduce", k_compact_reduce, n_tiles_t, 256, 0, d_tjt, d_stat, D->st_tmp.as<int8_t>(),
+               pp->min_state_count, D->tile_sum.as<uint32_t>());
+    PAV_LAUNCH(ctx, "k_scan_tiles4", k_scan_tiles4, 1, 256, 0, D->tile_sum.as<uint32_t>(), D->tile_pre.as<unsigned long long>(),
+               n_tiles_t);
+    CompactArgs CA;
+    CA.jobs = d_jobs; CA.tile_job = d_tjt; CA.stat = d_stat; CA.st_tmp = D->st_tmp.as<int8_t>();
+    CA.tile_pre = D->tile_pre.as<unsigned long long>(); CA.T = TV; CA.k = k; CA.min_state_count = pp->min_state_count;
+    CA.index = D->index.as<uint32_t>(); CA.state_mer = D->state_mer.as<int8_t>(); CA.state = D->state.as<int8_t>();
+    CA.kmer = D->kmer.as<unsigned long long>();
+    for (int s = 0; s < 3; ++s) CA.list[s] = D->list[s].as<uint32_t>();
+    PAV_LAUNCH(ctx, "k_compact_scatter", k_compact_scatter, n_tiles_t, 256, 0, CA);
+
+    // ---- readback 1: per-job counts and moments -> status, bandwidths (host, libm: same arithmetic as scipy) ----
+    std::vector<JobStat> hs(n_jobs);
+    PAV_HIP(ctx, hipMemcpyAsync(hs.data(), d_stat, sizeof(JobStat) * n_jobs, hipMemcpyDeviceToHost, st));
+    PAV_HIP(ctx, hipStreamSynchronize(st));
+    D->h_kde.assign(n_jobs, JobKde{});
+    std::vector<EvalTile> tiles;
+    for (uint32_t j = 0; j < n_jobs; ++j) {
+        pav_den_result &r = D->results[j];
+        JobKde &kd = D->h_kde[j];
+        const JobStat &s = hs[j];
+        r.n_rows = s.n_rows;
+        for (int q = 0; q < 3; ++q) r.state_count[q] = s.m[q];
+        r.max_count = s.max_count;
+        if (s.n_ref_valid == 0) { r.status = PAV_DEN_FAIL; r.fail_kind = 1; r.n_rows = 0; continue; }          // density.py:510-513
+        if (s.max_count > pp->max_ref_kmer_count) { r.status = PAV_DEN_FAIL; r.fail_kind = 2; r.n_rows = 0; continue; }   // :516-527
+        if (s.n_rows < pp->min_informative || s.n_rows == 0) { r.status = PAV_DEN_UNFINALISED; continue; }     // :193-195
+        r.status = PAV_DEN_OK;
+        const uint32_t n = s.n_rows;
+        kd.finalised = 1; kd.n = n; kd.srs = D->h_jobs[j].srs;
+        kd.n_samp = (n + kd.srs - 1) / kd.srs;
+        if ((uint64_t)(kd.n_samp - 1) * kd.srs != n - 1) kd.n_samp += 1;                                         // :213-214
+        r.n_sample = kd.n_samp;
+        const double bandwidth = std::pow((double)n, -1.0 / 5.0) * pp->den_smooth;                               // :198
+        for (int q = 0; q < 3; ++q) {
+            const uint64_t m = s.m[q];
+            kd.m[q] = (uint32_t)m;
+            kd.cnt[q] = (double)m;
+            if (m == 0) continue;
+            // unbiased variance of the integer row numbers, exact numerator (m*S2 - S1^2) / (m*(m-1))
+            const unsigned __int128 num = (unsigned __int128)m * s.s2[q] - (unsigned __int128)s.s1[q] * s.s1[q];
+            const double var = (double)num / ((double)m * (double)(m - 1));
+            const double h = std::sqrt(var) * bandwidth;                 // cho_cov = cholesky(cov) * factor
+            r.h[q] = h;
+            kd.inv_h[q] = 1.0 / h;
+            kd.norm[q] = std::pow(2 * 3.14159265358979323846, -0.5) / h;
+            kd.w[q] = 1.0 / (double)m;
+        }
+        for (uint32_t f = 0; f < kd.n_samp; f += 64) tiles.push_back(EvalTile{j, f, std::min<uint32_t>(64, kd.n_samp - f), 0});
+    }
+    // failure path: the k-mer named in the message of scripts/density.py:519-526
+    for (uint32_t j = 0; j < n_jobs; ++j) {
+        if (D->results[j].fail_kind != 2) continue;
+        PAV_HIP(ctx, hipMemsetAsync(&d_stat[j].max_key, 0xFF, sizeof(unsigned long long), st));
+        PAV_LAUNCH(ctx, "k_max_kmer", k_max_kmer, 64, 256, 0, d_jobs, j, D->cnt.as<uint32_t>(), D->first.as<uint32_t>(), d_stat);
+        unsigned long long packed = 0, key = 0;
+        PAV_HIP(ctx, hipMemcpyAsync(&packed, &d_stat[j].max_key, sizeof packed, hipMemcpyDeviceToHost, st));
+        PAV_HIP(ctx, hipStreamSynchronize(st));
+        PAV_HIP(ctx, hipMemcpy(&key, d_keys + D->h_jobs[j].ht_off + (packed & 0xFFFFFFFFull), sizeof key, hipMemcpyDeviceToHost));
+        // the set holds rc(k-mer) when -r is set; the counter in the reference is keyed by the forward k-mer
+        D->results[j].max_kmer = D->h_jobs[j].ref_rc ? pav_kmer_rev_complement(key, k) : key;
+    }
+    PAV_HIP(ctx, hipMemcpyAsync(D->kde.p, D->h_kde.data(), sizeof(JobKde) * n_jobs, hipMemcpyHostToDevice, st));
+    const JobKde *d_kde = D->kde.as<JobKde>();
+
+    KdeArgs KA;
+    KA.jobs = d_jobs; KA.kde = d_kde; KA.fill_list = D->fill_list.as<uint32_t>(); KA.state = D->state.as<int8_t>();
+    for (int s = 0; s < 3; ++s) { KA.ps[s] = D->pscaled[s].as<double>(); KA.kern[s] = D->kern[s].as<double>(); }
+
+    if (!tiles.empty()) {
+        PAV_LAUNCH(ctx, "k_pscale", k_pscale, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_kde, D->list[0].as<uint32_t>(),
+                   D->list[1].as<uint32_t>(), D->list[2].as<uint32_t>(), D->pscaled[0].as<double>(), D->pscaled[1].as<double>(),
+                   D->pscaled[2].as<double>());
+        PAV_HIP(ctx, D->tiles.reserve(sizeof(EvalTile) * tiles.size()));
+        PAV_HIP(ctx, hipMemcpyAsync(D->tiles.p, tiles.data(), sizeof(EvalTile) * tiles.size(), hipMemcpyHostToDevice, st));
+        KA.tiles = D->tiles.as<EvalTile>();
+        PAV_LAUNCH(ctx, "k_kde_eval", k_kde_eval, (uint32_t)tiles.size(), 64, 0, KA);
+        PAV_LAUNCH(ctx, "k_windows", k_windows, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_kde, D->state_mer.as<int8_t>(),
+                   D->state.as<int8_t>(), D->kern[0].as<double>(), D->kern[1].as<double>(), D->kern[2].as<double>(),
+                   pp->state_run_delta, D->fill_list.as<uint32_t>(), d_stat);
+        // ---- readback 2: how many inner sites need the full density --------------------------------------------
+        PAV_HIP(ctx, hipMemcpyAsync(hs.data(), d_stat, sizeof(JobStat) * n_jobs, hipMemcpyDeviceToHost, st));
+        PAV_HIP(ctx, hipStreamSynchronize(st));
+        std::vector<EvalTile> ftiles;
+        for (uint32_t j = 0; j < n_jobs; ++j) {
+            if (!D->h_kde[j].finalised) continue;
+            D->results[j].n_eval = (uint64_t)D->h_kde[j].n_samp + hs[j].fill_n;
+            for (uint32_t f = 0; f < hs[j].fill_n; f += 64) ftiles.push_back(EvalTile{j, f, std::min<uint32_t>(64, hs[j].fill_n - f), 1});
+        }
+        if (!ftiles.empty()) {
+            PAV_HIP(ctx, D->scratch.reserve(sizeof(EvalTile) * ftiles.size()));
+            PAV_HIP(ctx, hipMemcpyAsync(D->scratch.p, ftiles.data(), sizeof(EvalTile) * ftiles.size(), hipMemcpyHostToDevice, st));
+            KA.tiles = D->scratch.as<EvalTile>();
+            PAV_LAUNCH(ctx, "k_kde_eval", k_kde_eval, (uint32_t)ftiles.size(), 64, 0, KA);
+        }
+        PAV_LAUNCH(ctx, "k_finalize", k_finalize, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_kde, D->kern[0].as<double>(),
+                   D->kern[1].as<double>(), D->kern[2].as<double>(), D->state.as<int8_t>());
+    }
+
+    // ---- rl_encoder: run heads -> host assembly ------------------------------------------------------------------
+    uint64_t total_rows = 0;
+    for (uint32_t j = 0; j < n_jobs; ++j) total_rows += D->results[j].status == PAV_DEN_FAIL ? 0 : hs[j].n_rows;
+    uint32_t cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(65536, total_rows / 16 + 4ull * n_jobs), 0x7FFFFFFF);
+    std::vector<HeadEvent> ev;
+    while (true) {
+        PAV_HIP(ctx, D->events.reserve(sizeof(HeadEvent) * (size_t)cap));
+        PAV_HIP(ctx, D->ev_count.reserve(16));
+        PAV_HIP(ctx, hipMemsetAsync(D->ev_count.p, 0, 4, st));
+        PAV_LAUNCH(ctx, "k_heads", k_heads, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_stat, D->state.as<int8_t>(),
+                   D->index.as<uint32_t>(), D->events.as<HeadEvent>(), cap, D->ev_count.as<uint32_t>());
+        uint32_t n_ev = 0;
+        PAV_HIP(ctx, hipMemcpyAsync(&n_ev, D->ev_count.p, 4, hipMemcpyDeviceToHost, st));
+        PAV_HIP(ctx, hipStreamSynchronize(st));
+        if (n_ev > cap) { cap = n_ev + 1024; continue; }
+        ev.resize(n_ev);
+        if (n_ev) PAV_HIP(ctx, hipMemcpy(ev.data(), D->events.p, sizeof(HeadEvent) * n_ev, hipMemcpyDeviceToHost));
+        break;
+    }
+    std::sort(ev.begin(), ev.end(), [](const HeadEvent &a, const HeadEvent &b) { return a.job != b.job ? a.job < b.job : a.row < b.row; });
+    for (size_t e = 0; e < ev.size(); ++e) {
+        const HeadEvent &h = ev[e];
+        if (h.state == -2 || D->results[h.job].status == PAV_DEN_FAIL) continue;
+        const HeadEvent &nx = ev[e + 1];                               // next head or the end marker of the same job
+        D->runs[h.job].push_back(pav_run{h.state, nx.row - h.row, (int64_t)h.index, (int64_t)nx.prev_index});
+    }
+    for (uint32_t j = 0; j < n_jobs; ++j) {
+        D->results[j].n_runs = (uint32_t)D->runs[j].size();
+        results[j] = D->results[j];
+    }
+    D->valid = true;
+    return PAV_OK;
+}
+
+int pav_density_runs(pav_ctx *ctx, uint32_t job, pav_run *runs) {
+    if (!ctx) return PAV_E_ARG;
+    DensityState *D = dstate(ctx);
+    if (!D->valid || job >= D->n_jobs) return fail(ctx, PAV_E_STATE, "pav_density_runs: no such job in the last batch");
+    if (!D->runs[job].empty()) {
+        if (!runs) return PAV_E_ARG;
+        memcpy(runs, D->runs[job].data(), sizeof(pav_run) * D->runs[job].size());
+    }
+    return PAV_OK;
+}
+
+int pav_density_table(pav_ctx *ctx, uint32_t job, int64_t *index, int8_t *state_mer, int8_t *state, double *kern_fwd,
+                      double *kern_fwdrev, double *kern_rev, uint64_t *kmer) {
+    if (!ctx) return PAV_E_ARG;
+    DensityState *D = dstate(ctx);
+    if (!D->valid || job >= D->n_jobs) return fail(ctx, PAV_E_STATE, "pav_density_table: no such job in the last batch");
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = D->results[job].n_rows;
+    if (n == 0 || D->results[job].status == PAV_DEN_FAIL) return PAV_OK;
+    const uint64_t off = D->h_jobs[job].tpos_off;
+    hipStream_t st = ctx->stream;
+    std::vector<uint32_t> idx32;
+    if (index) {
+        idx32.resize(n);
+        PAV_HIP(ctx, hipMemcpyAsync(idx32.data(), D->index.as<uint32_t>() + off, 4ull * n, hipMemcpyDeviceToHost, st));
+    }
+    if (state_mer) PAV_HIP(ctx, hipMemcpyAsync(state_mer, D->state_mer.as<int8_t>() + off, n, hipMemcpyDeviceToHost, st));
+    if (state) PAV_HIP(ctx, hipMemcpyAsync(state, D->state.as<int8_t>() + off, n, hipMemcpyDeviceToHost, st));
+    if (kmer) PAV_HIP(ctx, hipMemcpyAsync(kmer, D->kmer.as<uint64_t>() + off, 8ull * n, hipMemcpyDeviceToHost, st));
+    double *outs[3] = {kern_fwd, kern_fwdrev, kern_rev};
+    const bool fin = D->results[job].status == PAV_DEN_OK;
+    for (int s = 0; s < 3; ++s)
+        if (outs[s] && fin) PAV_HIP(ctx, hipMemcpyAsync(outs[s], D->kern[s].as<double>() + off, 8ull * n, hipMemcpyDeviceToHost, st));
+    PAV_HIP(ctx, hipStreamSynchronize(st));
+    if (index) for (uint32_t i = 0; i < n; ++i) index[i] = idx32[i];
+    if (!fin) for (int s = 0; s < 3; ++s) if (outs[s]) for (uint32_t i = 0; i < n; ++i) outs[s][i] = NAN;
+    return PAV_OK;
+}
+
+int pav_density_annotate(pav_ctx *ctx, uint32_t job, uint32_t ref_id, uint64_t ref_up_pos, uint64_t ref_up_end,
+                         uint64_t ref_dn_pos, uint64_t ref_dn_end, int64_t qry_index_base, int64_t tig_up_pos,
+                         int64_t tig_up_end, int64_t tig_dn_pos, int64_t tig_dn_end, uint8_t *flank, uint8_t *match) {
+    if (!ctx || !flank || !match) return PAV_E_ARG;
+    DensityState *D = dstate(ctx);
+    if (!D->valid || job >= D->n_jobs) return fail(ctx, PAV_E_STATE, "pav_density_annotate: no such job in the last batch");
+    const SeqStore &RS = ctx->seq[PAV_ROLE_REF];
+    if (ref_id >= RS.n || ref_up_end > RS.len[ref_id] || ref_dn_end > RS.len[ref_id])
+        return fail(ctx, PAV_E_ARG, "pav_density_annotate: region outside the reference record");
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = D->results[job].n_rows;
+    if (n == 0) return PAV_OK;
+    const int k = D->params.k;
+    // Region(chrom, pos, end) swaps reversed coordinates (pavlib/seq.py:54-66); an empty region has no k-mers
+    if (ref_up_pos > ref_up_end) std::swap(ref_up_pos, ref_up_end);
+    if (ref_dn_pos > ref_dn_end) std::swap(ref_dn_pos, ref_dn_end);
+    const uint32_t up_len = (uint32_t)(ref_up_end - ref_up_pos), dn_len = (uint32_t)(ref_dn_end - ref_dn_pos);
+    const uint32_t cap_up = pow2_at_least(2ull * up_len + 2), cap_dn = pow2_at_least(2ull * dn_len + 2);
+    hipStream_t st = ctx->stream;
+    PAV_HIP(ctx, D->scratch.reserve(8ull * (cap_up + cap_dn) + 2ull * n + 64));
+    unsigned long long *k_up = D->scratch.as<unsigned long long>(), *k_dn = k_up + cap_up;
+    uint8_t *d_flank = reinterpret_cast<uint8_t *>(k_dn + cap_dn), *d_match = d_flank + n;
+    PAV_HIP(ctx, hipMemsetAsync(k_up, 0xFF, 8ull * (cap_up + cap_dn), st));
+    const SeqView RV = RS.view();
+    if (up_len >= (uint32_t)k)
+        PAV_LAUNCH(ctx, "k_canon_insert", k_canon_insert, (up_len + 255) / 256, 256, 0, RV, RS.off[ref_id] + ref_up_pos, up_len, k, k_up, cap_up - 1);
+    if (dn_len >= (uint32_t)k)
+        PAV_LAUNCH(ctx, "k_canon_insert", k_canon_insert, (dn_len + 255) / 256, 256, 0, RV, RS.off[ref_id] + ref_dn_pos, dn_len, k, k_dn, cap_dn - 1);
+    PAV_LAUNCH(ctx, "k_annotate", k_annotate, (n + 255) / 256, 256, 0, D->index.as<uint32_t>(), D->kmer.as<unsigned long long>(),
+               D->h_jobs[job].tpos_off, n, k, qry_index_base, tig_up_pos, tig_up_end, tig_dn_pos, tig_dn_end, k_up, cap_up - 1, k_dn,
+               cap_dn - 1, d_flank, d_match);
+    PAV_HIP(ctx, hipMemcpyAsync(flank, d_flank, n, hipMemcpyDeviceToHost, st));
+    PAV_HIP(ctx, hipMemcpyAsync(match, d_match, n, hipMemcpyDeviceToHost, st));
+    PAV_HIP(ctx, hipStreamSynchronize(st));
+    return PAV_OK;
+}
+
+}  // extern "C"

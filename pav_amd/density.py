@@ -1,0 +1,63 @@
+"""
+K-mer density for calling inversions - host mirror of ``pavlib/density.py`` (rl_encoder) and of the command-line
+contract of ``scripts/density.py``; the arithmetic runs on the GPU (csrc/density.hip).
+"""
+
+import numpy as np
+import pandas as pd
+
+from . import _lib
+
+# Defaults of scripts/density.py's command line (:438-477) and MAX_REF_KMER_COUNT (:47)
+DEFAULT_MIN_INFORMATIVE = 2000
+DEFAULT_MIN_STATE_COUNT = 20
+DEFAULT_DENSITY_SMOOTH = 1
+DEFAULT_STATE_RUN_SMOOTH = 20
+DEFAULT_STATE_RUN_DELTA = 0.005
+MAX_REF_KMER_COUNT = 100
+
+DENSITY_COLUMNS = ['INDEX', 'STATE_MER', 'STATE', 'KERN_FWD', 'KERN_FWDREV', 'KERN_REV', 'KMER']   # density.py:341
+
+
+def den_params(k=31, min_informative=DEFAULT_MIN_INFORMATIVE, min_state_count=DEFAULT_MIN_STATE_COUNT,
+               den_smooth=DEFAULT_DENSITY_SMOOTH, state_run_delta=DEFAULT_STATE_RUN_DELTA,
+               max_ref_kmer_count=MAX_REF_KMER_COUNT):
+    return _lib.DenParams(int(k), int(min_informative), int(min_state_count), float(den_smooth), float(state_run_delta),
+                          int(max_ref_kmer_count), 0)
+
+
+def table_frame(cols, finalised=True):
+    """Density table as the reference's DataFrame (scripts/density.py:340-342): indexed by INDEX; an un-finalised
+    table (fewer than --mininf informative k-mers) keeps the early column set of :157-163 with STATE = -1."""
+    if finalised:
+        df = pd.DataFrame({c: cols[c] for c in DENSITY_COLUMNS}, columns=DENSITY_COLUMNS)
+        df['INDEX'] = df['INDEX'].astype(np.int64)
+        df['STATE_MER'] = df['STATE_MER'].astype(np.int64)
+        df['STATE'] = df['STATE'].astype(np.int64)
+        df['KMER'] = [int(v) for v in cols['KMER']]                      # Python ints like kanapy k-mers
+    else:
+        df = pd.DataFrame({'KMER': [int(v) for v in cols['KMER']], 'INDEX': cols['INDEX'].astype(np.int64),
+                           'STATE': cols['STATE'].astype(np.int64), 'STATE_MER': cols['STATE_MER'].astype(np.int64)},
+                          columns=['KMER', 'INDEX', 'STATE', 'STATE_MER'])
+    df.set_index(df['INDEX'], inplace=True, drop=False)
+    return df
+
+
+def rl_encoder(df, state_col='STATE'):
+    """
+    Count consecutive states and track the INDEX range of each run (pavlib/density.py:330-361).
+
+    :param df: Dataframe of states with INDEX and the state column.
+    :param state_col: "STATE" (kernel-density max state) or "STATE_MER" (raw k-mer state).
+
+    :return: Iterator of (state, count, pos, end) tuples.
+    """
+    states = df[state_col].to_numpy()
+    index = df['INDEX'].to_numpy()
+    n = states.shape[0]
+    if n == 0:
+        return
+    heads = np.flatnonzero(np.concatenate(([True], states[1:] != states[:-1])))
+    ends = np.concatenate((heads[1:], [n])) - 1
+    for h, e in zip(heads.tolist(), ends.tolist()):
+        yield (int(states[h]), e - h + 1, int(index[h]), int(index[e]))

@@ -1,0 +1,396 @@
+"""
+Routines for calling inversions - host mirror of ``pavlib/inv.py`` for the MI355X path.
+
+``scan_for_inv`` keeps the reference's signature, return type, log lines and soft/hard failure behaviour
+(pavlib/inv.py:149-454); the per-iteration ``scripts/density.py`` subprocess is replaced by one call into
+``libpav_amd.so`` (k-mer states, compaction, Gaussian KDE, interpolation, arg-max, run-length encoding on the GPU).
+``scan_for_inv_batch`` runs many flagged regions in lock-step so that every scan iteration is one batched device
+call (regions are independent: SURVEY.md section 8(e)); its results are identical to calling ``scan_for_inv``
+region by region.
+"""
+
+import numpy as np
+
+from . import _lib, density, seq
+from .fasta import open_fasta, read_fai
+
+#
+# Constants (pavlib/inv.py:19-40)
+#
+
+INITIAL_EXPAND = 4000      # Expand the flagged region by this much before starting.
+EXPAND_FACTOR = 1.5        # Expand by this factor while searching
+MAX_REGION_SIZE = 1200000  # Maximum region size
+MIN_INFORMATIVE_KMERS = 2000
+MIN_KMER_STATE_COUNT = 20
+DENSITY_SMOOTH_FACTOR = 1
+MIN_INV_KMER_RUN = 100     # States must have a continuous run of this many strictly inverted k-mers
+MIN_QRY_REF_PROP = 0.6     # The contig and reference region sizes must be within this factor (reciprocal)
+DEFAULT_MIN_EXP_COUNT = 1
+DEFAULT_STATE_RUN_SMOOTH = 20
+CALL_SOURCE = 'FLAG-DEN'
+ERR_INV_FAIL = 125         # pavlib/constants.py:55
+
+# KMER_LOC_STATE[in-upstream, in-dnstream] (pavlib/inv.py:46-51) as the codes pav_density_annotate returns
+_MATCH_TEXT = np.array(['', 'SAME', 'OTHER', None], dtype=object)
+_FLANK_TEXT = np.array(['', 'UP', 'DN'], dtype=object)
+
+
+class InvCall:
+    """An inversion call with the data supporting it (same attributes as pavlib.inv.InvCall, inv.py:54-118)."""
+
+    def __init__(self, region_ref_outer, region_ref_inner, region_tig_outer, region_tig_inner, region_ref_discovery,
+                 region_tig_discovery, region_flag, df):
+        self.region_ref_outer = region_ref_outer
+        self.region_ref_inner = region_ref_inner
+        self.region_tig_outer = region_tig_outer
+        self.region_tig_inner = region_tig_inner
+        self.region_ref_discovery = region_ref_discovery
+        self.region_tig_discovery = region_tig_discovery
+        self.region_flag = region_flag
+        self.df = df
+        self.svlen = len(region_ref_outer)
+        self.id = '{}-{}-INV-{}'.format(region_ref_outer.chrom, region_ref_outer.pos + 1, self.svlen)
+
+    def __repr__(self):
+        return self.id
+
+
+class _Interval:
+    __slots__ = ('begin', 'end', 'data')
+
+    def __init__(self, begin, end, data):
+        self.begin, self.end, self.data = begin, end, data
+
+
+class SrsTree:
+    """Minimal interval lookup with the slice of the intervaltree interface scan_for_inv uses: ``tree[x]`` returns
+    the set of intervals containing ``x``; each has ``.data`` (pavlib/inv.py:259)."""
+
+    def __init__(self):
+        self.intervals = []
+
+    def add(self, begin, end, data):
+        self.intervals.append(_Interval(begin, end, data))
+
+    def __getitem__(self, point):
+        return {iv for iv in self.intervals if iv.begin <= point < iv.end}
+
+
+def get_srs_tree(srs_tuple_list):
+    """State-run-smooth limits -> lookup by region size (pavlib/inv.py:564-620; same checks and messages)."""
+    srs_tree = SrsTree()
+    if srs_tuple_list is None or len(srs_tuple_list) == 0:
+        srs_tree.add(0, np.inf, DEFAULT_STATE_RUN_SMOOTH)
+        return srs_tree
+    for srs_element in srs_tuple_list:
+        if len(srs_element) != 2:
+            raise RuntimeError('Element in "state run smooth" tuple list that is not length 2: ' + str(srs_element))
+    srs_tuple_list = sorted(srs_tuple_list)
+    last_inv_lim, last_smooth_factor = srs_tuple_list[0]
+    last_inv_lim = int(last_inv_lim)
+    last_smooth_factor = int(last_smooth_factor)
+    if last_inv_lim < 0:
+        raise RuntimeError('State run inversion size limits must be 0 or greater: {}'.format(last_inv_lim))
+    if last_smooth_factor < 4:
+        raise RuntimeError('Not tested with "state run smooth" factor less than 4: {}'.format(last_smooth_factor))
+    if last_inv_lim > 0:
+        srs_tree.add(0, last_inv_lim, np.min([last_inv_lim, 20]))
+    for inv_lim, smooth_factor in srs_tuple_list[1:]:
+        inv_lim = int(inv_lim)
+        smooth_factor = int(smooth_factor)
+        if smooth_factor < 20:
+            raise RuntimeError('Not tested with "state run smooth" factor less than 20: {}'.format(smooth_factor))
+        if inv_lim == last_inv_lim:
+            raise RuntimeError('Duplicate limit in state run limits: {}'.format(inv_lim))
+        srs_tree.add(last_inv_lim, inv_lim, last_smooth_factor)
+        last_inv_lim = inv_lim
+        last_smooth_factor = smooth_factor
+    srs_tree.add(last_inv_lim, np.inf, last_smooth_factor)
+    return srs_tree
+
+
+def _write_log(message, log):
+    if log is None:
+        return
+    log.write(message)
+    log.write('\n')
+    log.flush()
+
+
+class _Scan:
+    """One flagged region's scan as a state machine: ``next_job()`` gives the density job of the next iteration (or
+    None when the scan ended), ``feed()`` consumes the device result.  Control flow = pavlib/inv.py:203-454."""
+
+    def __init__(self, region_flag, ref_fa_name, tig_fa_name, align_lift, k_util, n_tree, max_region_size, log, srs_tree,
+                 min_exp_count, ref_index, tig_index):
+        self.region_flag = region_flag
+        self.ref_fa_name, self.tig_fa_name = ref_fa_name, tig_fa_name
+        self.align_lift, self.k_util, self.log = align_lift, k_util, log
+        self.min_exp_count = DEFAULT_MIN_EXP_COUNT if min_exp_count is None else min_exp_count
+        self.max_region_size = MAX_REGION_SIZE if max_region_size is None else max_region_size
+        self.ref_index, self.tig_index = ref_index, tig_index
+        self.done = False
+        self.result = None
+        self.error = None
+        self.pending = None            # set when the flanked region was found: needs table fetch + annotation
+        _write_log('Scanning for inversions in flagged region: {} (flagged region record id = {})'.format(
+            region_flag, region_flag.region_id()), log)
+        self.df_fai = read_fai(ref_fa_name + '.fai')
+        self.region_ref = region_flag.copy()
+        self.region_ref.expand(INITIAL_EXPAND, min_pos=0, max_end=self.df_fai, shift=True)
+        self.expansion_count = 0
+        self.n_tree_chrom = n_tree[self.region_ref.chrom] if n_tree is not None and self.region_ref.chrom in n_tree.keys() else None
+        self.srs_tree = get_srs_tree(None) if srs_tree is None else srs_tree
+        if not hasattr(self.srs_tree, '__getitem__'):
+            raise NotImplementedError('Custom state-run-smooth parameters are not currently implemented')
+        self.region_tig = None
+
+    def _finish(self, result=None):
+        self.done = True
+        self.result = result
+        return None
+
+    def next_job(self):
+        """Top of the ``while True`` loop (inv.py:223-260) up to the density call."""
+        region_ref = self.region_ref
+        if 0 < self.max_region_size < len(region_ref):
+            _write_log('Region size exceeds max: {} ({} > {})'.format(region_ref, len(region_ref), self.max_region_size), self.log)
+            return self._finish()
+        if self.n_tree_chrom is not None:
+            if len(self.n_tree_chrom[region_ref.pos:region_ref.end]) > 0:
+                _write_log('Region overlaps N bases: {}'.format(region_ref), self.log)
+        try:
+            region_tig = self.align_lift.lift_region_to_qry(region_ref)
+        except RuntimeError as ex:
+            self.error = ex
+            return self._finish()
+        if region_tig is None:
+            _write_log('Could not lift reference region onto contigs: {}'.format(region_ref), self.log)
+            return self._finish()
+        self.region_tig = region_tig
+        self.expansion_count += 1
+        _write_log('Scanning region: {}'.format(region_ref), self.log)
+        srs = int(list(self.srs_tree[len(region_tig)])[0].data)
+        if region_ref.chrom not in self.ref_index or region_tig.chrom not in self.tig_index:
+            self.error = RuntimeError('Sequence {} / {} is not loaded on the device'.format(region_ref.chrom, region_tig.chrom))
+            return self._finish()
+        return _lib.DenJob(self.ref_index[region_ref.chrom], self.tig_index[region_tig.chrom], region_ref.pos, region_ref.end,
+                           region_tig.pos, region_tig.end, 1 if region_tig.is_rev else 0, srs)
+
+    def feed(self, res, state_rl):
+        """After the density call (inv.py:268-351).  Returns True when the region is flanked by reference-oriented
+        k-mers and must be characterised (table needed)."""
+        region_ref, log = self.region_ref, self.log
+        if res.status == _lib.DEN_FAIL:
+            if res.fail_kind == 1:
+                stderr = ''                                            # message goes to stdout in density.py:511
+            else:
+                stderr = 'K-mer count exceeds max: {} > {} ({}): {}\n'.format(
+                    res.max_count, density.MAX_REF_KMER_COUNT, self.k_util.to_string(res.max_kmer), region_ref)
+            _write_log('Received return code {} from scripts/density.py for region {}:\n{}'.format(
+                ERR_INV_FAIL, str(region_ref), stderr), log)
+            self._finish()
+            return False
+        if res.n_rows == 0:
+            _write_log('No informative reference k-mers in forward or reverse orientation in region', log)
+            self._finish()
+            return False
+        self.state_rl = state_rl
+        condensed_states = [record[0] for record in state_rl]
+        if len(state_rl) == 1 and state_rl[0][0] in {0, -1} and self.expansion_count >= self.min_exp_count:
+            _write_log('Found no inverted k-mer states after {} expansion(s)'.format(self.expansion_count), log)
+            self._finish()
+            return False
+        if len(condensed_states) > 2 and condensed_states[0] == 0 and condensed_states[-1] == 0:
+            return True
+        # Expand (inv.py:309-342)
+        last_len = len(region_ref)
+        expand_bp = np.int32(len(region_ref) * EXPAND_FACTOR)
+        if len(condensed_states) > 2:
+            if condensed_states[0] == 0:
+                balance = 0.25
+            elif condensed_states[-1] == 0:
+                balance = 0.75
+            else:
+                balance = 0.5
+        else:
+            balance = 0.5
+        region_ref.expand(expand_bp, min_pos=0, max_end=self.df_fai, shift=True, balance=balance)
+        if len(region_ref) == last_len:
+            _write_log('Reached reference limits, cannot expand', log)
+            self._finish()
+        return False
+
+    def characterise(self, ctx, job):
+        """inv.py:353-454 with the flanked table resident on the device as ``job`` of the last batch."""
+        state_rl, log, k_util = self.state_rl, self.log, self.k_util
+        region_ref, region_tig = self.region_ref, self.region_tig
+        if not np.any([record[0] == 2 for record in state_rl]):
+            _write_log('No inverted states found', log)
+            return self._finish()
+        max_inv_run = np.max([record[1] for record in state_rl if record[0] == 2])
+        if max_inv_run < MIN_INV_KMER_RUN:
+            _write_log('Longest run of strictly inverted k-mers ({}) does not meet the minimum threshold ({})'.format(
+                max_inv_run, MIN_INV_KMER_RUN), log)
+            return self._finish()
+        if state_rl[0][0] != 0 or state_rl[-1][0] != 0:
+            self.error = RuntimeError('Found INV region not flanked by reference sequence (program bug): {}'.format(region_ref))
+            return self._finish()
+        state_rl_inv = [record for record in state_rl if record[0] == 2]
+        region_tig_outer = seq.Region(region_tig.chrom, state_rl[1][2] + region_tig.pos,
+                                      state_rl[-2][3] + region_tig.pos + k_util.k_size, is_rev=region_tig.is_rev)
+        region_tig_inner = seq.Region(region_tig.chrom, state_rl_inv[0][2] + region_tig.pos,
+                                      state_rl_inv[-1][3] + region_tig.pos + k_util.k_size, is_rev=region_tig.is_rev)
+        try:
+            region_ref_outer = self.align_lift.lift_region_to_sub(region_tig_outer)
+            if region_ref_outer is None:
+                _write_log('Failed lifting outer INV region to reference: {}'.format(region_tig_outer), log)
+                return self._finish()
+            region_ref_inner = self.align_lift.lift_region_to_sub(region_tig_inner, gap=True)
+        except RuntimeError as ex:
+            self.error = ex
+            return self._finish()
+        if region_ref_inner is None:
+            region_ref_inner = region_ref_outer
+        print('INV Found: outer={}, inner={} (ref outer={}, inner={})'.format(
+            region_tig_outer, region_tig_inner, region_ref_outer, region_ref_inner))
+        if len(region_ref_outer) < len(region_tig_outer) * MIN_QRY_REF_PROP:
+            _write_log('Reference region too short: Reference region length ({:,d}) is not within {:.2f}% of the contig region length ({:,d})'.format(
+                len(region_ref_outer), MIN_QRY_REF_PROP * 100, len(region_tig_outer)), log)
+            return self._finish()
+        if len(region_tig_outer) < len(region_ref_outer) * MIN_QRY_REF_PROP:
+            _write_log('Contig region too short: Contig region length ({:,d}) is not within {:.2f}% of the reference region length ({:,d})'.format(
+                len(region_tig_outer), MIN_QRY_REF_PROP * 100, len(region_ref_outer)), log)
+            return self._finish()
+        # density table + INV-DUP annotation (inv.py:440-442, 457-561)
+        res_rows = self.n_rows
+        cols = ctx.density_table(job, res_rows)
+        df = density.table_frame(cols, finalised=True)
+        df = annotate_inv_dup_mers(df, region_ref_outer, region_ref_inner, region_tig_outer, region_tig_inner, region_ref,
+                                   self.ref_fa_name, k_util, ctx=ctx, job=job, ref_index=self.ref_index)
+        inv_call = InvCall(region_ref_outer, region_ref_inner, region_tig_outer, region_tig_inner, region_ref, region_tig,
+                           self.region_flag, df)
+        _write_log('Found inversion: {}'.format(inv_call), log)
+        return self._finish(inv_call)
+
+
+def annotate_inv_dup_mers(df, region_ref_outer, region_ref_inner, region_tig_outer, region_tig_inner,
+                          region_tig_discovery, ref_fa, k_util, ctx=None, job=None, ref_index=None):
+    """
+    Annotate inverted duplications flanking an inversion: FLANK (UP / DN by contig index) and MATCH (SAME / OTHER /
+    NaN) columns (pavlib/inv.py:457-561).  Note the reference passes the *reference* discovery region as
+    ``region_tig_discovery`` (inv.py:440-442) and tests the raw KMER against canonical k-mer sets; both are kept.
+    Runs on the table resident on the device (``ctx``, ``job``).
+    """
+    if ctx is None or job is None:
+        raise _lib.PavDeviceError('annotate_inv_dup_mers needs the device context holding the density table')
+    region_dup_ref_up = seq.Region(region_ref_outer.chrom, region_ref_outer.pos, region_ref_inner.pos)
+    region_dup_ref_dn = seq.Region(region_ref_outer.chrom, region_ref_inner.end, region_ref_outer.end)
+    region_dup_tig_up = seq.Region(region_tig_outer.chrom, region_tig_outer.pos, region_tig_inner.pos)
+    region_dup_tig_dn = seq.Region(region_tig_outer.chrom, region_tig_inner.end, region_tig_outer.end)
+    flank, match = ctx.density_annotate(
+        job, df.shape[0], ref_index[region_ref_outer.chrom],
+        (region_dup_ref_up.pos, region_dup_ref_up.end), (region_dup_ref_dn.pos, region_dup_ref_dn.end),
+        int(region_tig_discovery.pos),
+        (region_dup_tig_up.pos, region_dup_tig_up.end), (region_dup_tig_dn.pos, region_dup_tig_dn.end))
+    df['FLANK'] = _FLANK_TEXT[flank]
+    m = _MATCH_TEXT[match]
+    df['MATCH'] = [np.nan if v is None else v for v in m]
+    return df
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Drivers
+# ---------------------------------------------------------------------------------------------------------
+
+def _seq_index(ctx):
+    return ({n: i for i, n in enumerate(ctx.seq_names(_lib.PAV_ROLE_REF))},
+            {n: i for i, n in enumerate(ctx.seq_names(_lib.PAV_ROLE_TIG))})
+
+
+def ensure_sequences(ctx, ref_fa_name, tig_fa_name):
+    """Upload both FASTA files once per context (records are addressed by name afterwards)."""
+    key = (str(ref_fa_name), str(tig_fa_name))
+    if getattr(ctx, '_inv_loaded', None) != key:
+        ref_fa, tig_fa = open_fasta(ref_fa_name), open_fasta(tig_fa_name)
+        ctx.seq_load(_lib.PAV_ROLE_REF, ref_fa.names, [ref_fa[n] for n in ref_fa.names])
+        ctx.seq_load(_lib.PAV_ROLE_TIG, tig_fa.names, [tig_fa[n] for n in tig_fa.names])
+        ctx._inv_loaded = key
+
+
+def _drive(ctx, scans, params, max_batch_bp=64_000_000):
+    """Run scan state machines in lock-step: every round is one batched device call over the live regions."""
+    live = list(scans)
+    while live:
+        jobs, owners = [], []
+        budget = 0
+        rest = []
+        for sc in live:
+            if budget > max_batch_bp and jobs:
+                rest.append(sc)
+                continue
+            job = sc.next_job()
+            if job is None:
+                continue
+            jobs.append(job)
+            owners.append(sc)
+            budget += (job.ref_end - job.ref_pos) + (job.tig_end - job.tig_pos)
+        if not jobs:
+            live = rest
+            continue
+        results = ctx.density_batch(jobs, params)
+        nxt = []
+        for j, (sc, res) in enumerate(zip(owners, results)):
+            runs = ctx.density_runs(j, res.n_runs) if res.status != _lib.DEN_FAIL and res.n_rows else []
+            sc.n_rows = res.n_rows
+            if sc.feed(res, runs):
+                sc.characterise(ctx, j)          # table of job j is still resident
+            elif not sc.done:
+                nxt.append(sc)
+        live = nxt + rest
+
+
+def scan_for_inv(region_flag, ref_fa_name, tig_fa_name, align_lift, k_util, n_tree=None, max_region_size=None, threads=1,
+                 log=None, srs_tree=None, min_exp_count=DEFAULT_MIN_EXP_COUNT, ctx=None, device_id=0):
+    """
+    Scan a flagged region for an inversion, expanding as necessary (same contract as pavlib/inv.py:149-185).
+
+    :return: An ``InvCall`` describing the inversion found or ``None``.  ``threads`` is accepted for compatibility.
+    """
+    own = ctx is None
+    if own:
+        ctx = _lib.Context(device_id)
+    try:
+        ensure_sequences(ctx, ref_fa_name, tig_fa_name)
+        ref_index, tig_index = _seq_index(ctx)
+        sc = _Scan(region_flag, ref_fa_name, tig_fa_name, align_lift, k_util, n_tree, max_region_size, log, srs_tree,
+                   min_exp_count, ref_index, tig_index)
+        _drive(ctx, [sc], density.den_params(k=k_util.k_size))
+    finally:
+        if own:
+            ctx.close()
+    if sc.error is not None:
+        raise sc.error
+    return sc.result
+
+
+def scan_for_inv_batch(region_flags, ref_fa_name, tig_fa_name, align_lift, k_util, n_tree=None, max_region_size=None,
+                       logs=None, srs_tree=None, min_exp_count=DEFAULT_MIN_EXP_COUNT, ctx=None, device_id=0):
+    """Scan many flagged regions; returns a list of ``InvCall`` / ``None`` / ``RuntimeError`` (one per region, the
+    error object where ``scan_for_inv`` would have raised).  ``logs``: one file-like object per region or None."""
+    own = ctx is None
+    if own:
+        ctx = _lib.Context(device_id)
+    try:
+        ensure_sequences(ctx, ref_fa_name, tig_fa_name)
+        ref_index, tig_index = _seq_index(ctx)
+        scans = []
+        for i, rf in enumerate(region_flags):
+            scans.append(_Scan(rf, ref_fa_name, tig_fa_name, align_lift, k_util, n_tree, max_region_size,
+                               None if logs is None else logs[i], srs_tree, min_exp_count, ref_index, tig_index))
+        _drive(ctx, scans, density.den_params(k=k_util.k_size))
+    finally:
+        if own:
+            ctx.close()
+    return [sc.error if sc.error is not None else sc.result for sc in scans]

@@ -64,3 +64,118 @@ def call_cigar_merge(bed_insdel_list, bed_snv_list, out_insdel=None, out_snv=Non
     if out_snv is not None:
         df_snv.to_csv(out_snv, sep='\t', index=False, compression='gzip')
     return df_snv, df_insdel
+
+
+# ---------------------------------------------------------------------------------------------------------
+# rule call_inv_batch (rules/call_inv.snakefile:115-311) and call_inv_batch_merge (:94-112)
+# ---------------------------------------------------------------------------------------------------------
+
+INV_BED_COLUMNS = ['#CHROM', 'POS', 'END', 'ID', 'SVTYPE', 'SVLEN', 'HAP', 'QRY_REGION', 'QRY_STRAND', 'CI',
+                   'RGN_REF_INNER', 'RGN_QRY_INNER', 'RGN_REF_DISC', 'RGN_QRY_DISC', 'FLAG_ID', 'FLAG_TYPE', 'ALIGN_INDEX',
+                   'CALL_SOURCE', 'FILTER', 'SEQ']                                   # call_inv.snakefile:270-282
+
+
+def collapse_to_set(items, to_type=None):
+    """Flatten nested tuples / lists into a set (pavlib/util.py:105-122)."""
+    stack, out = list(items), set()
+    while stack:
+        v = stack.pop()
+        if isinstance(v, (tuple, list)):
+            stack.extend(v)
+        else:
+            out.add(to_type(v) if to_type is not None else v)
+    return out
+
+
+def inv_bed_row(inv_call, hap, flag_type, tig_fa):
+    """One INV BED record as rule call_inv_batch builds it (call_inv.snakefile:203-282)."""
+    from . import inv as pavinv, seq as pavseq
+    seq = pavseq.region_seq_fasta(inv_call.region_tig_outer, tig_fa, rev_compl=inv_call.region_tig_outer.is_rev)
+    align_index = ','.join(sorted(collapse_to_set(
+        (inv_call.region_ref_outer.pos_aln_index, inv_call.region_ref_outer.end_aln_index,
+         inv_call.region_ref_inner.pos_aln_index, inv_call.region_ref_inner.end_aln_index), to_type=str)))
+    return pd.Series(
+        [inv_call.region_ref_outer.chrom, inv_call.region_ref_outer.pos, inv_call.region_ref_outer.end,
+         inv_call.id, 'INV', inv_call.svlen, hap,
+         inv_call.region_tig_outer.to_base1_string(), '-' if inv_call.region_tig_outer.is_rev else '+', 0,
+         inv_call.region_ref_inner.to_base1_string(), inv_call.region_tig_inner.to_base1_string(),
+         inv_call.region_ref_discovery.to_base1_string(), inv_call.region_tig_discovery.to_base1_string(),
+         inv_call.region_flag.region_id(), flag_type, align_index, pavinv.CALL_SOURCE, 'PASS', seq],
+        index=INV_BED_COLUMNS)
+
+
+def call_inv_batch(bed_flag, bed_aln, tig_fa, fai, ref_fa, hap, batch, bed_out=None, log_path=None,
+                   density_out_dir=None, k_size=31, inv_region_limit=None, inv_min_expand=None, srs_list=None, ctx=None,
+                   device_id=0):
+    """Body of rule call_inv_batch: scan every flagged region of ``batch``, write the INV BED, the per-call density
+    tables and the log.  All regions of the batch are scanned in lock-step on the GPU; logs are emitted in region
+    order, so the files equal those of the sequential reference loop."""
+    import gc
+    import io
+    import os
+    from . import _lib, inv as pavinv, seq as pavseq
+    from .align import AlignLift
+    from .fasta import read_fai
+    from .kmer import KmerUtil
+
+    batch = int(batch)
+    if density_out_dir is not None:
+        os.makedirs(density_out_dir, exist_ok=True)
+    srs_tree = pavinv.get_srs_tree(srs_list)
+    df_flag = pd.read_csv(bed_flag, sep='\t', header=0)
+    df_flag = df_flag.loc[df_flag['BATCH'] == batch]
+    empty_cols = [c for c in INV_BED_COLUMNS]
+    if df_flag.shape[0] == 0:
+        df_bed = pd.DataFrame([], columns=empty_cols)                                # :148-167
+    else:
+        k_util = KmerUtil(k_size)
+        align_lift = AlignLift(pd.read_csv(bed_aln, sep='\t'), read_fai(fai))
+        own = ctx is None
+        if own:
+            ctx = _lib.Context(device_id)
+        try:
+            regions = [pavseq.Region(row['#CHROM'], row['POS'], row['END']) for _, row in df_flag.iterrows()]
+            logs = [io.StringIO() for _ in regions]
+            results = pavinv.scan_for_inv_batch(regions, ref_fa, tig_fa, align_lift, k_util, max_region_size=inv_region_limit,
+                                                logs=logs, srs_tree=srs_tree, min_exp_count=inv_min_expand, ctx=ctx)
+        finally:
+            if own:
+                ctx.close()
+        id_set = set()
+        call_list = []
+        log_file = open(log_path, 'w') if log_path is not None else None
+        try:
+            for (_, row), res, lg in zip(df_flag.iterrows(), results, logs):
+                if log_file is not None:
+                    log_file.write(lg.getvalue())
+                if isinstance(res, RuntimeError):                                     # :198-200
+                    if log_file is not None:
+                        log_file.write('RuntimeError in scan_for_inv(): {}\n'.format(res))
+                    res = None
+                if res is not None and res.id not in id_set:                          # :203
+                    call_list.append(inv_bed_row(res, hap, row['TYPE'], tig_fa))
+                    id_set.add(res.id)
+                    if density_out_dir is not None:                                   # :287-291
+                        res.df.to_csv(os.path.join(density_out_dir, 'density_{}_{}.tsv.gz'.format(res.id, hap)),
+                                      sep='\t', index=False, compression='gzip')
+                    gc.collect()
+        finally:
+            if log_file is not None:
+                log_file.close()
+        if len(call_list) > 0:
+            df_bed = pd.concat(call_list, axis=1).T.sort_values(['#CHROM', 'POS', 'END', 'ID'])   # :297
+        else:
+            df_bed = pd.DataFrame([], columns=[c for c in INV_BED_COLUMNS if c != 'FILTER'])      # :300-308 (sic)
+    if bed_out is not None:
+        df_bed.to_csv(bed_out, sep='\t', index=False, compression='gzip')              # :311
+    return df_bed
+
+
+def call_inv_batch_merge(bed_list, bed_out=None):
+    """Body of rule call_inv_batch_merge (call_inv.snakefile:101-112)."""
+    df = pd.concat([pd.read_csv(f, sep='\t') for f in bed_list], axis=0)
+    df.drop_duplicates('ID', inplace=True)
+    df = df.sort_values(['#CHROM', 'POS', 'END', 'ID'])
+    if bed_out is not None:
+        df.to_csv(bed_out, sep='\t', index=False, compression='gzip')
+    return df

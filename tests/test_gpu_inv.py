@@ -1,0 +1,212 @@
+"""GPU parity tests of the inversion path: pav_amd.inv.scan_for_inv / the density kernels (through the C ABI) against
+the golden vectors produced by the reference (tests/golden/inv_*) and against the CPU oracle on seeded inputs."""
+import hashlib
+import io
+import json
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+import util
+from pav_amd import _lib, density as pavden, inv as pavinv, rules, seq as pavseq, synth
+from pav_amd.align import AlignLift
+from pav_amd.fasta import open_fasta, read_fai
+from pav_amd.kmer import KmerUtil
+
+pytestmark = pytest.mark.gpu
+GOLD = util.GOLD
+INV_CASES = ['inv_fwd', 'inv_rev', 'inv_small', 'inv_limits', 'inv_nolift']
+KERN = ('KERN_FWD', 'KERN_FWDREV', 'KERN_REV')
+RTOL = 1e-11      # KERN_* tolerance vs the reference: device exp() and np.cov's summation order
+
+
+def sha(a):
+    return hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def region_dict(r):
+    def aln(x):
+        return None if x is None else [[int(w) for w in v] if isinstance(v, (tuple, list)) else int(v) for v in x]
+    return {'chrom': r.chrom, 'pos': int(r.pos), 'end': int(r.end), 'is_rev': bool(r.is_rev),
+            'pos_aln_index': aln(r.pos_aln_index), 'end_aln_index': aln(r.end_aln_index)}
+
+
+def load_case(ctx, case):
+    d = os.path.join(GOLD, case)
+    ctx._inv_loaded = None
+    pavinv.ensure_sequences(ctx, os.path.join(d, 'ref.fa'), os.path.join(d, 'tig.fa'))
+    lift = AlignLift(pd.read_csv(os.path.join(d, 'align.tsv'), sep='\t'), read_fai(os.path.join(d, 'tig.fa.fai')))
+    with open(os.path.join(d, 'scans.json')) as fh:
+        scans = json.load(fh)
+    return d, lift, scans
+
+
+def check_call(d, rec, call):
+    g = rec['call']
+    assert call is not None and call.id == g['id'] and call.svlen == g['svlen']
+    for name in ('region_ref_outer', 'region_ref_inner', 'region_tig_outer', 'region_tig_inner', 'region_ref_discovery',
+                 'region_tig_discovery'):
+        assert region_dict(getattr(call, name)) == g[name], name
+    row = rules.inv_bed_row(call, 'h1', rec['flag']['type'], os.path.join(d, 'tig.fa'))
+    got = {k: (int(v) if isinstance(v, (int, np.integer)) else v) for k, v in row.items()}
+    assert got == g['bed_row']
+    t = np.load(os.path.join(d, 'density_%s.npz' % g['id']))
+    df = call.df
+    assert list(df.columns) == ['INDEX', 'STATE_MER', 'STATE', 'KERN_FWD', 'KERN_FWDREV', 'KERN_REV', 'KMER', 'FLANK', 'MATCH']
+    assert np.array_equal(df['INDEX'].to_numpy(), t['INDEX'])
+    assert np.array_equal(df['STATE_MER'].to_numpy(), t['STATE_MER'])
+    assert np.array_equal(df['STATE'].to_numpy(), t['STATE'])
+    assert np.array_equal(df['KMER'].to_numpy(dtype=np.uint64), t['KMER'])
+    assert np.array_equal(df['FLANK'].to_numpy(dtype=str), t['FLANK'])
+    assert np.array_equal(df['MATCH'].fillna('NA').to_numpy(dtype=str), t['MATCH'])
+    for c in KERN:
+        assert np.allclose(df[c].to_numpy(), t[c], rtol=RTOL, atol=1e-300), c
+    # text the rule writes: integer columns byte-identical; float columns printed by the same pandas formatter
+    buf = io.StringIO()
+    df.to_csv(buf, sep='\t', index=False)
+    head = buf.getvalue().splitlines()[:6]
+    assert head[0] == g['density_tsv_head'][0]
+    for a, b in zip(head[1:], g['density_tsv_head'][1:]):
+        fa, fb = a.split('\t'), b.split('\t')
+        assert [fa[i] for i in (0, 1, 2, 6, 7, 8)] == [fb[i] for i in (0, 1, 2, 6, 7, 8)]
+
+
+@pytest.mark.parametrize('case', INV_CASES)
+def test_scan_for_inv_vs_reference(built, gpu_ctx, case, capsys):
+    """Every flagged region of the golden cases: same log lines, same None / InvCall, same regions, BED row and table."""
+    d, lift, scans = load_case(gpu_ctx, case)
+    k_util = KmerUtil(31)
+    for rec in scans:
+        f = rec['flag']
+        log = io.StringIO()
+        call = pavinv.scan_for_inv(pavseq.Region(f['chrom'], f['pos'], f['end']), os.path.join(d, 'ref.fa'),
+                                   os.path.join(d, 'tig.fa'), lift, k_util, log=log, ctx=gpu_ctx, **rec['kwargs'])
+        assert log.getvalue().splitlines() == rec['log'], f
+        if rec['call'] is None:
+            assert call is None
+        else:
+            check_call(d, rec, call)
+
+
+@pytest.mark.parametrize('case', INV_CASES)
+def test_density_iterations_vs_reference(built, gpu_ctx, case):
+    """pav_density_batch on every (region_ref, region_tig) pair the reference scanned, all in one batch: row counts,
+    INDEX / STATE_MER / STATE digests and rl_encoder runs exact, density column sums to 1e-12."""
+    d, lift, scans = load_case(gpu_ctx, case)
+    ref_i = {n: i for i, n in enumerate(gpu_ctx.seq_names(_lib.PAV_ROLE_REF))}
+    tig_i = {n: i for i, n in enumerate(gpu_ctx.seq_names(_lib.PAV_ROLE_TIG))}
+    its = [it for rec in scans for it in rec['iterations'] if it['region_tig'] is not None]
+    jobs = [_lib.DenJob(ref_i[it['region_ref']['chrom']], tig_i[it['region_tig']['chrom']], it['region_ref']['pos'],
+                        it['region_ref']['end'], it['region_tig']['pos'], it['region_tig']['end'],
+                        1 if it['region_tig']['is_rev'] else 0, 20) for it in its]
+    if not jobs:
+        pytest.skip('no liftable iteration in this case')
+    res = gpu_ctx.density_batch(jobs, pavden.den_params())
+    for j, (it, r) in enumerate(zip(its, res)):
+        if 'n_rows' not in it:
+            assert r.status == _lib.DEN_FAIL
+            continue
+        assert r.status == (_lib.DEN_OK if it['finalised'] else _lib.DEN_UNFINALISED)
+        assert r.n_rows == it['n_rows']
+        cols = gpu_ctx.density_table(j, r.n_rows)
+        assert sha(cols['INDEX']) == it['index_sha1'] and sha(cols['STATE_MER']) == it['state_mer_sha1']
+        assert sha(cols['STATE']) == it['state_sha1']
+        assert [list(x) for x in gpu_ctx.density_runs(j, r.n_runs)] == it['state_rl']
+        if it['finalised']:
+            assert np.allclose([cols[c].sum() for c in KERN], it['kern_sum'], rtol=1e-12, atol=0)
+
+
+def test_batched_scan_equals_single(built, gpu_ctx):
+    d, lift, scans = load_case(gpu_ctx, 'inv_fwd')
+    k_util = KmerUtil(31)
+    recs = [r for r in scans if not r['kwargs']]
+    regions = [pavseq.Region(r['flag']['chrom'], r['flag']['pos'], r['flag']['end']) for r in recs]
+    logs = [io.StringIO() for _ in regions]
+    out = pavinv.scan_for_inv_batch(regions, os.path.join(d, 'ref.fa'), os.path.join(d, 'tig.fa'), lift, k_util, logs=logs,
+                                    ctx=gpu_ctx)
+    for rec, call, lg in zip(recs, out, logs):
+        assert lg.getvalue().splitlines() == rec['log']
+        if rec['call'] is None:
+            assert call is None
+        else:
+            check_call(d, rec, call)
+
+
+def test_rule_call_inv_batch_files(built, gpu_ctx, tmp_path):
+    """File contract of rule call_inv_batch: INV BED rows equal the reference rows; density tables are written."""
+    d, lift, scans = load_case(gpu_ctx, 'inv_fwd')
+    beds = []
+    for batch in (0, 1):
+        out = str(tmp_path / f'inv_call_{batch}.bed.gz')
+        rules.call_inv_batch(os.path.join(d, 'flag.tsv'), os.path.join(d, 'align.tsv'), os.path.join(d, 'tig.fa'),
+                             os.path.join(d, 'tig.fa.fai'), os.path.join(d, 'ref.fa'), 'h1', batch, bed_out=out,
+                             log_path=str(tmp_path / f'inv_call_{batch}.log'), density_out_dir=str(tmp_path / 'density'),
+                             ctx=gpu_ctx)
+        beds.append(out)
+    df = rules.call_inv_batch_merge(beds)
+    # flag.tsv holds every flagged region of the case; kwargs variants (region limit, min_exp_count) use defaults here
+    expect = {}
+    flag = pd.read_csv(os.path.join(d, 'flag.tsv'), sep='\t')
+    for rec in scans:
+        if rec['call'] is not None and not rec['kwargs']:
+            expect[rec['call']['id']] = rec['call']['bed_row']
+    got = {r['ID']: r for _, r in df.iterrows()}
+    for vid, row in expect.items():
+        assert vid in got
+        for k, v in row.items():
+            assert str(got[vid][k]) == str(v), (vid, k)
+        assert os.path.exists(tmp_path / 'density' / f'density_{vid}_h1.tsv.gz')
+    assert flag.shape[0] == len(scans)
+
+
+@pytest.mark.parametrize('seed', [31, 32])
+def test_density_vs_oracle_seeded(built, gpu_ctx, seed):
+    """Seeded haplotype with planted inversions, inverted repeats, N runs and reverse rows: the first scan iteration of
+    every flagged region as one device batch vs the scalar oracle - integer columns exact, KERN_* to 1e-11."""
+    from oracle import oracle
+    hap = synth.config2(seed=seed, scale=0.004, threads=4)
+    names = hap.ref.names
+    gpu_ctx._inv_loaded = None
+    gpu_ctx.seq_load(_lib.PAV_ROLE_REF, names, [hap.ref.seqs[n] for n in names])
+    gpu_ctx.seq_load(_lib.PAV_ROLE_TIG, hap.tig_names, [hap.tig_seqs[n] for n in hap.tig_names])
+    lift = AlignLift(hap.df_trim, hap.tig_lengths)
+    fai = pd.Series(hap.ref.lengths)
+    ref_i = {n: i for i, n in enumerate(names)}
+    tig_i = {n: i for i, n in enumerate(hap.tig_names)}
+    jobs, pairs = [], []
+    for _, row in hap.df_flag.iterrows():
+        r = pavseq.Region(row['#CHROM'], row['POS'], row['END'])
+        r.expand(4000, min_pos=0, max_end=fai, shift=True)
+        try:
+            t = lift.lift_region_to_qry(r)
+        except RuntimeError:
+            t = None
+        if t is None or len(r) > 60_000:
+            continue
+        jobs.append(_lib.DenJob(ref_i[r.chrom], tig_i[t.chrom], r.pos, r.end, t.pos, t.end, 1 if t.is_rev else 0, 20))
+        pairs.append((r, t))
+        if len(jobs) >= 24:
+            break
+    assert len(jobs) >= 8
+    res = gpu_ctx.density_batch(jobs, pavden.den_params())
+    n_final = 0
+    for j, ((r, t), g) in enumerate(zip(pairs, res)):
+        o = oracle.density(hap.ref.seqs[r.chrom][r.pos:r.end], hap.tig_seqs[t.chrom][t.pos:t.end], t.is_rev)
+        assert g.status == o['status'], (r, t)
+        if o['status'] == 125:
+            assert g.fail_kind == o['fail_kind']
+            continue
+        assert g.n_rows == o['n']
+        cols = gpu_ctx.density_table(j, g.n_rows)
+        for c in ('INDEX', 'STATE_MER', 'STATE', 'KMER'):
+            assert np.array_equal(cols[c], o[c]), c
+        assert gpu_ctx.density_runs(j, g.n_runs) == oracle.rl_encode(o['STATE'], o['INDEX'])
+        if o['status'] == 0:
+            n_final += 1
+            assert g.n_eval == o['n_eval']
+            assert np.allclose(list(g.h), o['h'], rtol=0, atol=0)          # bandwidths are computed identically
+            for c in KERN:
+                assert np.allclose(cols[c], o[c], rtol=RTOL, atol=1e-300), c
+    assert n_final >= 4
