@@ -1,0 +1,76 @@
+"""
+Multi-GPU sharding for the hot path: one process per GPU, no data-path collective.
+
+Units are independent at every level the reference already splits on:
+  * haplotypes (README.md:83-86)                       -> one haplotype per rank when there are enough of them
+  * ``CALL_BATCH`` alignment batches (cigarcall.py:21)  -> rules ``call_cigar`` jobs
+  * flagged-region ``BATCH``es (call_inv.snakefile:96)  -> rules ``call_inv_batch`` jobs
+Work is assigned longest-processing-time first on a cost estimate (CIGAR text length / region length); results are
+gathered as Python objects on rank 0 (``torch.distributed.gather_object``; gloo on CPU, RCCL-backed nccl groups can use
+the same call through a gloo side group) and merged exactly like ``call_cigar_merge`` / ``call_inv_batch_merge``.
+"""
+
+import numpy as np
+import pandas as pd
+
+
+def assign_lpt(costs, n_ranks):
+    """Greedy longest-processing-time assignment.  Returns ``n_ranks`` lists of item indices (deterministic)."""
+    costs = np.asarray(costs, dtype=np.float64)
+    order = np.argsort(-costs, kind='stable')
+    load = np.zeros(n_ranks, dtype=np.float64)
+    out = [[] for _ in range(n_ranks)]
+    for i in order.tolist():
+        r = int(np.argmin(load))
+        out[r].append(i)
+        load[r] += costs[i]
+    for lst in out:
+        lst.sort()
+    return out
+
+
+def shard_alignments(df_align, rank, world, by='row'):
+    """Rows of the alignment table this rank walks.  ``by='batch'`` keeps the reference's CALL_BATCH groups whole."""
+    if world <= 1:
+        return df_align
+    if by == 'batch':
+        batches = sorted(df_align['CALL_BATCH'].unique())
+        cost = [int(df_align.loc[df_align['CALL_BATCH'] == b, 'CIGAR'].str.len().sum()) for b in batches]
+        mine = {batches[i] for i in assign_lpt(cost, world)[rank]}
+        return df_align.loc[df_align['CALL_BATCH'].isin(mine)]
+    cost = df_align['CIGAR'].str.len().to_numpy()
+    return df_align.iloc[assign_lpt(cost, world)[rank]]
+
+
+def shard_regions(df_flag, rank, world):
+    """Flagged regions this rank scans (cost = region length + the initial 4 kb expansion)."""
+    if world <= 1:
+        return df_flag
+    cost = (df_flag['END'] - df_flag['POS']).to_numpy() + 4000
+    return df_flag.iloc[assign_lpt(cost, world)[rank]]
+
+
+def shard_haplotypes(n_haplotypes, rank, world, costs=None):
+    """Haplotype indices processed by this rank (config 4: 16 haplotypes over 8 GPUs, two waves)."""
+    costs = np.ones(n_haplotypes) if costs is None else costs
+    return assign_lpt(costs, world)[rank]
+
+
+def gather_frames(df_local, dst=0, group=None):
+    """Gather per-rank DataFrames on ``dst`` and concatenate (None on the other ranks).  No tensor collective: the
+    tables are host objects, exactly like the per-batch files the reference exchanges through the file system."""
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return df_local
+    rank = dist.get_rank(group)
+    buf = [None] * dist.get_world_size(group) if rank == dst else None
+    dist.gather_object(df_local, buf, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return pd.concat(buf, axis=0)
+
+
+def merge_cigar_tables(df_snv, df_insdel):
+    """Order of rule call_cigar_merge (rules/call.snakefile:763-786)."""
+    return (df_snv.reset_index(drop=True).sort_values(['#CHROM', 'POS']),
+            df_insdel.reset_index(drop=True).sort_values(['#CHROM', 'POS', 'END', 'ID']))
