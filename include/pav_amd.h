@@ -171,8 +171,17 @@ typedef struct {
     double den_smooth;              /* --densmooth      (1)      :455                                       */
     double state_run_delta;         /* --staterundelta  (0.005)  :476                                       */
     uint32_t max_ref_kmer_count;    /* MAX_REF_KMER_COUNT (100)  :47                                        */
-    uint32_t pad;
+    uint32_t kde_mode;              /* PAV_KDE_RUNS (default) or PAV_KDE_DIRECT, see below                  */
 } pav_den_params;
+
+/* Density evaluation.  Both give the reference's KERN_* to ~1e-13 relative and identical STATE on every test vector.
+ *   PAV_KDE_DIRECT  one exp() per (evaluation point, data point) pair, data accumulated in ascending order: the
+ *                   arithmetic order of scipy's gaussian_kernel_estimate.  O(N_eval x N_data).
+ *   PAV_KDE_RUNS    the data points of a state are runs of consecutive integers (INDEX_DEN = 0..n-1); the sum of the
+ *                   Gaussian over a run is evaluated in closed form (Euler-Maclaurin: erf/erfc integral + endpoint
+ *                   and odd-derivative corrections, remainder < 1e-15 for bandwidth >= 32; short runs and small
+ *                   bandwidths fall back to direct terms).  O(N_eval x N_runs). */
+enum { PAV_KDE_RUNS = 0, PAV_KDE_DIRECT = 1 };
 
 enum { PAV_DEN_OK = 0, PAV_DEN_UNFINALISED = 1, PAV_DEN_FAIL = 125 };   /* 125 = pavlib.constants.ERR_INV_FAIL */
 

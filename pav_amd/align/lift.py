@@ -45,18 +45,33 @@ class AlignLift:
         # per subject / per query: list of (begin, end, index); lookups need "exactly one record contains pos"
         self.ref_tree = collections.defaultdict(list)
         self.tig_tree = collections.defaultdict(list)
-        for index, row in df.iterrows():
+        self._rows = {}
+        cols = ['#CHROM', 'POS', 'END', 'INDEX', 'QRY_ID', 'QRY_POS', 'QRY_END', 'REV']
+        for index, vals in zip(df.index, zip(*[df[c].tolist() for c in cols])):
+            row = dict(zip(cols, vals))
+            self._rows[index] = row
             if row['END'] > row['POS']:
                 self.ref_tree[row['#CHROM']].append((row['POS'], row['END'], index))
             if row['QRY_END'] > row['QRY_POS']:
                 self.tig_tree[row['QRY_ID']].append((row['QRY_POS'], row['QRY_END'], index))
+        for tree in (self.ref_tree, self.tig_tree):
+            for key in tree:
+                tree[key].sort(key=lambda t: (t[0], t[1]))
+        self._starts = {id(tree): {k: [t[0] for t in v] for k, v in tree.items()} for tree in (self.ref_tree, self.tig_tree)}
+        self._maxlen = {id(tree): {k: max(t[1] - t[0] for t in v) for k, v in tree.items()} for tree in (self.ref_tree, self.tig_tree)}
         self.cache_queue = collections.deque()
         self.ref_cache = dict()
         self.tig_cache = dict()
 
-    @staticmethod
-    def _containing(records, pos):
-        return [index for begin, end, index in records if begin <= pos < end]
+    def _containing(self, tree, key, pos):
+        """Indexes of the records of ``key`` whose [begin, end) contains ``pos`` (sorted starts + bisect)."""
+        records = tree.get(key)
+        if not records:
+            return []
+        starts = self._starts[id(tree)][key]
+        hi = bisect.bisect_right(starts, pos)
+        lo = bisect.bisect_left(starts, pos - self._maxlen[id(tree)][key])
+        return [records[i][2] for i in range(lo, hi) if records[i][1] > pos]
 
     # ---- query -> subject (lift.py:51-185) -------------------------------------------------------------
     def lift_to_sub(self, query_id, coord, gap=False):
@@ -66,7 +81,7 @@ class AlignLift:
         out = []
         for pos in coord:
             pos_org = pos
-            hits = self._containing(self.tig_tree.get(query_id, ()), pos)
+            hits = self._containing(self.tig_tree, query_id, pos)
             if len(hits) == 1:
                 index = hits[0]
             elif len(hits) == 0 and gap:
@@ -78,7 +93,7 @@ class AlignLift:
             if index not in self.tig_cache:
                 self._add_align(index)
             tree = self.tig_cache[index]
-            row = self.df.loc[index]
+            row = self._rows[index]
             if row['REV']:
                 pos = self.df_fai[query_id] - pos
             i = tree.at(pos)
@@ -101,7 +116,7 @@ class AlignLift:
             coord = (coord,)
         out = []
         for pos in coord:
-            hits = self._containing(self.ref_tree.get(subject_id, ()), pos)
+            hits = self._containing(self.ref_tree, subject_id, pos)
             if len(hits) != 1:
                 out.append(None)
                 continue
@@ -109,7 +124,7 @@ class AlignLift:
             if index not in self.ref_cache:
                 self._add_align(index)
             tree = self.ref_cache[index]
-            row = self.df.loc[index]
+            row = self._rows[index]
             i = tree.at(pos)
             if i < 0:
                 raise RuntimeError((
@@ -193,7 +208,8 @@ class AlignLift:
         self.cache_queue.appendleft(index)
 
     def _check_and_clear(self):
-        while len(self.cache_queue) >= self.cache_align:
+        # The reference keeps 10 records (lift.py:20-49); eviction has no observable effect, so keep many more
+        while len(self.cache_queue) >= max(self.cache_align, 4096):
             index = self.cache_queue.pop()
             del self.ref_cache[index]
             del self.tig_cache[index]

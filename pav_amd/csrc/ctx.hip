@@ -73,26 +73,40 @@ __device__ __forceinline__ void pack4(uint32_t x, uint32_t &codes8, uint32_t &ba
     bad4 = (nz | (nz >> 7) | (nz >> 14) | (nz >> 21)) & 0xFu;
 }
 
+// Tuned on MI355X (tools/ubench/pack_variants.hip): four independent 16-byte loads in flight per lane, non-temporal
+// loads and stores (every byte is touched once), one 16 KiB tile per workgroup with an exact grid (a capped
+// grid-stride launch was 20 % slower): 6.0 TB/s of algorithmic traffic vs 4.5 TB/s for the first version.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int PACK_U = 4;
+
 __global__ __launch_bounds__(256) void pack_kernel(const uint4 *__restrict__ ascii, uint32_t *__restrict__ two,
                                                    uint32_t *__restrict__ mask, uint64_t n16) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
-        const uint4 v = ascii[i];
+    const uint64_t base = (uint64_t)blockIdx.x * (256 * PACK_U) + threadIdx.x;
+    u32x4 v[PACK_U];
+#pragma unroll
+    for (int u = 0; u < PACK_U; ++u) {
+        const uint64_t i = base + (uint64_t)u * 256;
+        if (i < n16) v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(ascii) + i);
+        else v[u] = u32x4{0x4e4e4e4eu, 0x4e4e4e4eu, 0x4e4e4e4eu, 0x4e4e4e4eu};
+    }
+#pragma unroll
+    for (int u = 0; u < PACK_U; ++u) {
+        const uint64_t i = base + (uint64_t)u * 256;
         uint32_t c0, c1, c2, c3, b0, b1, b2, b3;
-        pack4(v.x, c0, b0); pack4(v.y, c1, b1); pack4(v.z, c2, b2); pack4(v.w, c3, b3);
-        two[i] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+        pack4(v[u].x, c0, b0); pack4(v[u].y, c1, b1); pack4(v[u].z, c2, b2); pack4(v[u].w, c3, b3);
         const uint32_t m16 = b0 | (b1 << 4) | (b2 << 8) | (b3 << 12);
         const uint32_t other = __shfl_xor(m16, 1);                    // n16 is even: the partner always exists
-        if ((threadIdx.x & 1) == 0) mask[i >> 1] = m16 | (other << 16);
+        if (i < n16) {
+            __builtin_nontemporal_store(c0 | (c1 << 8) | (c2 << 16) | (c3 << 24), &two[i]);
+            if ((threadIdx.x & 1) == 0) __builtin_nontemporal_store(m16 | (other << 16), &mask[i >> 1]);
+        }
     }
 }
 
 static int run_pack(pav_ctx *ctx, SeqStore &s) {
     if (s.arena == 0) return PAV_OK;
     const uint64_t n16 = s.arena / 16;
-    uint64_t blocks = (n16 + 255) / 256;
-    const uint64_t cap = (uint64_t)ctx->n_cu * 8;
-    if (blocks > cap) blocks = cap;
+    const uint64_t blocks = (n16 + 256 * PACK_U - 1) / (256 * PACK_U);
     PAV_LAUNCH(ctx, "pack_kernel", pack_kernel, (uint32_t)blocks, 256, 0, s.d_ascii.as<uint4>(),
                s.d_two.as<uint32_t>(), s.d_mask.as<uint32_t>(), n16);
     return PAV_OK;

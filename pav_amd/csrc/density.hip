@@ -44,9 +44,15 @@ struct JobStat {                          // written by kernels, zeroed per batc
 
 struct JobKde {                           // host -> device after the first readback
     uint32_t finalised, n, n_samp, srs;
-    uint32_t m[3], pad;
-    double inv_h[3], norm[3], w[3], cnt[3];
+    uint32_t m[3], use_runs;              // use_runs: closed-form run sums (PAV_KDE_RUNS) for this job
+    uint32_t run_off[3], n_run[3];        // per-state slices of the run arena
+    double inv_h[3], norm[3], w[3], cnt[3], h[3];
 };
+
+struct RunDev { uint32_t a, b; };         // rows a..b (inclusive) are consecutive data points of one state
+
+constexpr double KDE_RUNS_MIN_H = 32.0;   // Euler-Maclaurin remainder < 1e-15 of the peak for h >= 32
+constexpr uint32_t KDE_RUNS_MAX = 1u << 16;   // jobs with more STATE_MER runs use the direct kernel
 
 struct EvalTile { uint32_t job, first, count, mode; };   // mode 0: sampled sites, 1: fill list
 
@@ -55,7 +61,7 @@ struct HeadEvent { uint32_t job, row; int32_t state; uint32_t index, prev_index;
 struct DensityState {
     DevBuf jobs, stat, kde, tile_job_r, tile_job_t, keys, cnt, first;
     DevBuf st_tmp, tile_sum, tile_pre, index, state_mer, state, kmer, kern[3], list[3], pscaled[3], fill_list;
-    DevBuf tiles, events, ev_count, scratch;
+    DevBuf tiles, events, ev_count, scratch, run_arena;
     std::vector<JobDev> h_jobs;
     std::vector<JobKde> h_kde;
     std::vector<pav_den_result> results;
@@ -67,7 +73,7 @@ struct DensityState {
     void release() {
         DevBuf *all[] = {&jobs, &stat, &kde, &tile_job_r, &tile_job_t, &keys, &cnt, &first, &st_tmp, &tile_sum, &tile_pre,
                          &index, &state_mer, &state, &kmer, &kern[0], &kern[1], &kern[2], &list[0], &list[1], &list[2],
-                         &pscaled[0], &pscaled[1], &pscaled[2], &fill_list, &tiles, &events, &ev_count, &scratch};
+                         &pscaled[0], &pscaled[1], &pscaled[2], &fill_list, &tiles, &events, &ev_count, &scratch, &run_arena};
         for (DevBuf *b : all) b->release();
     }
 };
@@ -375,9 +381,65 @@ __device__ __forceinline__ double kde_state(const double *__restrict__ ps, uint3
     return est;
 }
 
+// Sum of exp(-((i - x)/h)^2 / 2) over the consecutive integers i = a..b in closed form (Euler-Maclaurin):
+//   integral (erf / erfc difference, chosen so that tails keep their relative accuracy)
+//   + (f(a) + f(b)) / 2 + (f1(b) - f1(a)) / 12 - (f3(b) - f3(a)) / 720 + (f5(b) - f5(a)) / 30240,
+// where fm is the m-th derivative: fm(t) = (-1)^m He_m(u) f / h^m, u = (t - x)/h.  The next term is below
+// 27 / (1.2e6 h^7): < 1e-15 for h >= 32.
+__device__ __forceinline__ double run_sum_em(double da, double db, double h, double inv_h) {
+    const double ua = da * inv_h, ub = db * inv_h;
+    const double fa = exp(-(ua * ua) / 2), fb = exp(-(ub * ub) / 2);
+    const double s = 0.70710678118654752440;
+    double integ;
+    if (ua >= 0.0) integ = erfc(ua * s) - erfc(ub * s);
+    else if (ub <= 0.0) integ = erfc(-ub * s) - erfc(-ua * s);
+    else integ = erf(ub * s) - erf(ua * s);
+    integ *= h * 1.25331413731550025121;                               // sqrt(pi / 2)
+    const double ua2 = ua * ua, ub2 = ub * ub;
+    const double h3a = ua * (ua2 - 3.0), h3b = ub * (ub2 - 3.0);
+    const double h5a = ua * (ua2 * (ua2 - 10.0) + 15.0), h5b = ub * (ub2 * (ub2 - 10.0) + 15.0);
+    const double ih2 = inv_h * inv_h;
+    const double d1 = (ua * fa - ub * fb) * inv_h;                     // f1(b) - f1(a)
+    const double d3 = (h3a * fa - h3b * fb) * inv_h * ih2;             // f3(b) - f3(a)
+    const double d5 = (h5a * fa - h5b * fb) * inv_h * ih2 * ih2;       // f5(b) - f5(a)
+    return integ + 0.5 * (fa + fb) + d1 / 12.0 - d3 / 720.0 + d5 / 30240.0;
+}
+
+// Tail of a run seen from far away with a narrow kernel: consecutive terms fall by exp(-u/h) per step, so the sum is
+// its first few hundred terms at most (the Euler-Maclaurin series converges in u/h and is not used there).
+__device__ __forceinline__ double run_sum_tail(double d0, uint32_t len, double inv_h) {
+    double sum = 0.0;
+    for (uint32_t k = 0; k < len; ++k) {
+        const double u = (d0 + (double)k) * inv_h;
+        const double t = exp(-(u * u) / 2);
+        sum += t;
+        if (t < 1e-19 * sum) break;
+    }
+    return sum;
+}
+
+__device__ __forceinline__ double kde_state_runs(const RunDev *__restrict__ runs, uint32_t n_run, double x, double h,
+                                                 double inv_h, double norm, double w) {
+    const double short_len = fmax(16.0, h * 0.0625);                  // short runs: direct terms (also bounds the
+    double sum = 0.0;                                                  // cancellation in the erfc difference)
+    for (uint32_t r = 0; r < n_run; ++r) {
+        const RunDev rn = runs[r];
+        const double da = (double)rn.a - x, db = (double)rn.b - x;
+        const double near = da >= 0.0 ? da : (db <= 0.0 ? -db : 0.0);  // distance of the nearest run element
+        if ((double)(rn.b - rn.a) < short_len) {
+            for (uint32_t i = rn.a; i <= rn.b; ++i) { const double u = ((double)i - x) * inv_h; sum += exp(-(u * u) / 2); }
+        } else if (near * inv_h * inv_h > 0.1) {                       // u/h > 0.1: steep tail
+            sum += run_sum_tail(near, rn.b - rn.a + 1, inv_h);
+        } else {
+            sum += run_sum_em(da, db, h, inv_h);
+        }
+    }
+    return w * (sum * norm);
+}
+
 struct KdeArgs {
     const JobDev *jobs; const JobKde *kde; const EvalTile *tiles; const uint32_t *fill_list;
-    const double *ps[3]; double *kern[3]; int8_t *state;
+    const double *ps[3]; double *kern[3]; int8_t *state; const RunDev *runs;
 };
 
 // One wave per tile of 64 evaluation points of one job.
@@ -398,7 +460,9 @@ __global__ __launch_bounds__(64) void k_kde_eval(KdeArgs A) {
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         if (kd.m[s] == 0) { val[s] = 0.0; continue; }                  // density.py:84,92,100
-        const double est = kde_state(A.ps[s] + off, kd.m[s], (double)x * kd.inv_h[s], kd.norm[s], kd.w[s]);
+        const double est = (kd.use_runs && kd.h[s] >= KDE_RUNS_MIN_H)
+            ? kde_state_runs(A.runs + kd.run_off[s], kd.n_run[s], (double)x, kd.h[s], kd.inv_h[s], kd.norm[s], kd.w[s])
+            : kde_state(A.ps[s] + off, kd.m[s], (double)x * kd.inv_h[s], kd.norm[s], kd.w[s]);
         val[s] = est * kd.cnt[s];                                      // density.py:110-115
         A.kern[s][off + x] = val[s];
     }
@@ -653,6 +717,42 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     std::vector<JobStat> hs(n_jobs);
     PAV_HIP(ctx, hipMemcpyAsync(hs.data(), d_stat, sizeof(JobStat) * n_jobs, hipMemcpyDeviceToHost, st));
     PAV_HIP(ctx, hipStreamSynchronize(st));
+
+    // Run heads of a per-row state array (STATE_MER here, STATE for rl_encoder below): events sorted by (job, row).
+    auto collect_heads = [&](const int8_t *d_state, std::vector<HeadEvent> &ev, uint64_t hint) -> int {
+        uint32_t cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(65536, hint / 16 + 4ull * n_jobs), 0x7FFFFFFF);
+        while (true) {
+            PAV_HIP(ctx, D->events.reserve(sizeof(HeadEvent) * (size_t)cap));
+            PAV_HIP(ctx, D->ev_count.reserve(16));
+            PAV_HIP(ctx, hipMemsetAsync(D->ev_count.p, 0, 4, st));
+            PAV_LAUNCH(ctx, "k_heads", k_heads, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_stat, d_state,
+                       D->index.as<uint32_t>(), D->events.as<HeadEvent>(), cap, D->ev_count.as<uint32_t>());
+            uint32_t n_ev = 0;
+            PAV_HIP(ctx, hipMemcpyAsync(&n_ev, D->ev_count.p, 4, hipMemcpyDeviceToHost, st));
+            PAV_HIP(ctx, hipStreamSynchronize(st));
+            if (n_ev > cap) { cap = n_ev + 1024; continue; }
+            ev.resize(n_ev);
+            if (n_ev) PAV_HIP(ctx, hipMemcpy(ev.data(), D->events.p, sizeof(HeadEvent) * n_ev, hipMemcpyDeviceToHost));
+            break;
+        }
+        std::sort(ev.begin(), ev.end(), [](const HeadEvent &a, const HeadEvent &b) { return a.job != b.job ? a.job < b.job : a.row < b.row; });
+        return PAV_OK;
+    };
+    uint64_t total_rows = 0;
+    for (uint32_t j = 0; j < n_jobs; ++j) total_rows += hs[j].n_rows;
+    std::vector<std::vector<RunDev>> mer_runs;                         // [job * 3 + state]
+    const bool want_runs = pp->kde_mode != PAV_KDE_DIRECT;
+    if (want_runs) {
+        std::vector<HeadEvent> mev;
+        int rc = collect_heads(D->state_mer.as<int8_t>(), mev, total_rows);
+        if (rc != PAV_OK) return rc;
+        mer_runs.assign((size_t)n_jobs * 3, {});
+        for (size_t e = 0; e + 1 < mev.size(); ++e) {
+            const HeadEvent &h = mev[e];
+            if (h.state < 0 || h.state > 2) continue;                 // end markers
+            mer_runs[(size_t)h.job * 3 + h.state].push_back(RunDev{h.row, mev[e + 1].row - 1});
+        }
+    }
     D->h_kde.assign(n_jobs, JobKde{});
     std::vector<EvalTile> tiles;
     for (uint32_t j = 0; j < n_jobs; ++j) {
@@ -686,7 +786,28 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             kd.norm[q] = std::pow(2 * 3.14159265358979323846, -0.5) / h;
             kd.w[q] = 1.0 / (double)m;
         }
+        for (int q = 0; q < 3; ++q) kd.h[q] = r.h[q];
         for (uint32_t f = 0; f < kd.n_samp; f += 64) tiles.push_back(EvalTile{j, f, std::min<uint32_t>(64, kd.n_samp - f), 0});
+    }
+    // run arena for the closed-form evaluation
+    if (want_runs) {
+        std::vector<RunDev> arena;
+        for (uint32_t j = 0; j < n_jobs; ++j) {
+            JobKde &kd = D->h_kde[j];
+            if (!kd.finalised) continue;
+            const size_t nr = mer_runs[3 * j].size() + mer_runs[3 * j + 1].size() + mer_runs[3 * j + 2].size();
+            if (nr > KDE_RUNS_MAX) continue;                           // very fragmented region: direct kernel
+            kd.use_runs = 1;
+            for (int q = 0; q < 3; ++q) {
+                kd.run_off[q] = (uint32_t)arena.size();
+                kd.n_run[q] = (uint32_t)mer_runs[3 * j + q].size();
+                arena.insert(arena.end(), mer_runs[3 * j + q].begin(), mer_runs[3 * j + q].end());
+            }
+        }
+        PAV_HIP(ctx, D->run_arena.reserve(sizeof(RunDev) * (arena.size() + 1)));
+        if (!arena.empty())
+            PAV_HIP(ctx, hipMemcpyAsync(D->run_arena.p, arena.data(), sizeof(RunDev) * arena.size(), hipMemcpyHostToDevice, st));
+        PAV_HIP(ctx, hipStreamSynchronize(st));                        // `arena` is a local buffer
     }
     // failure path: the k-mer named in the message of scripts/density.py:519-526
     for (uint32_t j = 0; j < n_jobs; ++j) {
@@ -705,6 +826,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
 
     KdeArgs KA;
     KA.jobs = d_jobs; KA.kde = d_kde; KA.fill_list = D->fill_list.as<uint32_t>(); KA.state = D->state.as<int8_t>();
+    KA.runs = D->run_arena.as<RunDev>();
     for (int s = 0; s < 3; ++s) { KA.ps[s] = D->pscaled[s].as<double>(); KA.kern[s] = D->kern[s].as<double>(); }
 
     if (!tiles.empty()) {
@@ -738,25 +860,11 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     }
 
     // ---- rl_encoder: run heads -> host assembly ------------------------------------------------------------------
-    uint64_t total_rows = 0;
-    for (uint32_t j = 0; j < n_jobs; ++j) total_rows += D->results[j].status == PAV_DEN_FAIL ? 0 : hs[j].n_rows;
-    uint32_t cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(65536, total_rows / 16 + 4ull * n_jobs), 0x7FFFFFFF);
     std::vector<HeadEvent> ev;
-    while (true) {
-        PAV_HIP(ctx, D->events.reserve(sizeof(HeadEvent) * (size_t)cap));
-        PAV_HIP(ctx, D->ev_count.reserve(16));
-        PAV_HIP(ctx, hipMemsetAsync(D->ev_count.p, 0, 4, st));
-        PAV_LAUNCH(ctx, "k_heads", k_heads, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_stat, D->state.as<int8_t>(),
-                   D->index.as<uint32_t>(), D->events.as<HeadEvent>(), cap, D->ev_count.as<uint32_t>());
-        uint32_t n_ev = 0;
-        PAV_HIP(ctx, hipMemcpyAsync(&n_ev, D->ev_count.p, 4, hipMemcpyDeviceToHost, st));
-        PAV_HIP(ctx, hipStreamSynchronize(st));
-        if (n_ev > cap) { cap = n_ev + 1024; continue; }
-        ev.resize(n_ev);
-        if (n_ev) PAV_HIP(ctx, hipMemcpy(ev.data(), D->events.p, sizeof(HeadEvent) * n_ev, hipMemcpyDeviceToHost));
-        break;
+    {
+        int rc = collect_heads(D->state.as<int8_t>(), ev, total_rows);
+        if (rc != PAV_OK) return rc;
     }
-    std::sort(ev.begin(), ev.end(), [](const HeadEvent &a, const HeadEvent &b) { return a.job != b.job ? a.job < b.job : a.row < b.row; });
     for (size_t e = 0; e < ev.size(); ++e) {
         const HeadEvent &h = ev[e];
         if (h.state == -2 || D->results[h.job].status == PAV_DEN_FAIL) continue;

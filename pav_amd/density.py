@@ -21,9 +21,14 @@ DENSITY_COLUMNS = ['INDEX', 'STATE_MER', 'STATE', 'KERN_FWD', 'KERN_FWDREV', 'KE
 
 def den_params(k=31, min_informative=DEFAULT_MIN_INFORMATIVE, min_state_count=DEFAULT_MIN_STATE_COUNT,
                den_smooth=DEFAULT_DENSITY_SMOOTH, state_run_delta=DEFAULT_STATE_RUN_DELTA,
-               max_ref_kmer_count=MAX_REF_KMER_COUNT):
+               max_ref_kmer_count=MAX_REF_KMER_COUNT, kde_mode=None):
+    """``kde_mode``: ``_lib.KDE_RUNS`` (default; closed-form sums over runs of consecutive k-mers) or
+    ``_lib.KDE_DIRECT`` (one exp per pair in scipy's accumulation order).  Env ``PAV_KDE_MODE=direct`` forces the latter."""
+    if kde_mode is None:
+        import os
+        kde_mode = _lib.KDE_DIRECT if os.environ.get('PAV_KDE_MODE', '').lower() == 'direct' else _lib.KDE_RUNS
     return _lib.DenParams(int(k), int(min_informative), int(min_state_count), float(den_smooth), float(state_run_delta),
-                          int(max_ref_kmer_count), 0)
+                          int(max_ref_kmer_count), int(kde_mode))
 
 
 def table_frame(cols, finalised=True):
@@ -34,9 +39,9 @@ def table_frame(cols, finalised=True):
         df['INDEX'] = df['INDEX'].astype(np.int64)
         df['STATE_MER'] = df['STATE_MER'].astype(np.int64)
         df['STATE'] = df['STATE'].astype(np.int64)
-        df['KMER'] = [int(v) for v in cols['KMER']]                      # Python ints like kanapy k-mers
+        df['KMER'] = cols['KMER'].astype(np.int64)                      # k <= 31: fits int64 like the reference column
     else:
-        df = pd.DataFrame({'KMER': [int(v) for v in cols['KMER']], 'INDEX': cols['INDEX'].astype(np.int64),
+        df = pd.DataFrame({'KMER': cols['KMER'].astype(np.int64), 'INDEX': cols['INDEX'].astype(np.int64),
                            'STATE': cols['STATE'].astype(np.int64), 'STATE_MER': cols['STATE_MER'].astype(np.int64)},
                           columns=['KMER', 'INDEX', 'STATE', 'STATE_MER'])
     df.set_index(df['INDEX'], inplace=True, drop=False)

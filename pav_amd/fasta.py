@@ -76,9 +76,16 @@ def open_fasta(path, cache=True):
     return _CACHE[key]
 
 
+_FAI_CACHE = {}
+
+
 def read_fai(fai_file_name):
-    """``svpoplib.ref.get_df_fai`` contract (pavlib/inv.py:201): Series name -> length."""
+    """``svpoplib.ref.get_df_fai`` contract (pavlib/inv.py:201): Series name -> length (memoised per path + mtime)."""
     import pandas as pd
+    key = (os.path.abspath(str(fai_file_name)), os.path.getmtime(fai_file_name))
+    if key in _FAI_CACHE:
+        return _FAI_CACHE[key]
     df = pd.read_csv(fai_file_name, sep='\t', header=None, usecols=[0, 1], names=['CHROM', 'LEN'],
                      dtype={'CHROM': str, 'LEN': np.int64})
-    return df.set_index('CHROM')['LEN']
+    _FAI_CACHE[key] = df.set_index('CHROM')['LEN']
+    return _FAI_CACHE[key]

@@ -296,7 +296,8 @@ def annotate_inv_dup_mers(df, region_ref_outer, region_ref_inner, region_tig_out
         (region_dup_tig_up.pos, region_dup_tig_up.end), (region_dup_tig_dn.pos, region_dup_tig_dn.end))
     df['FLANK'] = _FLANK_TEXT[flank]
     m = _MATCH_TEXT[match]
-    df['MATCH'] = [np.nan if v is None else v for v in m]
+    m[match == 3] = np.nan                                             # 'NA' -> NaN (inv.py:555)
+    df['MATCH'] = m
     return df
 
 

@@ -90,8 +90,9 @@ def test_scan_for_inv_vs_reference(built, gpu_ctx, case, capsys):
             check_call(d, rec, call)
 
 
+@pytest.mark.parametrize('mode', [_lib.KDE_RUNS, _lib.KDE_DIRECT])
 @pytest.mark.parametrize('case', INV_CASES)
-def test_density_iterations_vs_reference(built, gpu_ctx, case):
+def test_density_iterations_vs_reference(built, gpu_ctx, case, mode):
     """pav_density_batch on every (region_ref, region_tig) pair the reference scanned, all in one batch: row counts,
     INDEX / STATE_MER / STATE digests and rl_encoder runs exact, density column sums to 1e-12."""
     d, lift, scans = load_case(gpu_ctx, case)
@@ -103,7 +104,7 @@ def test_density_iterations_vs_reference(built, gpu_ctx, case):
                         1 if it['region_tig']['is_rev'] else 0, 20) for it in its]
     if not jobs:
         pytest.skip('no liftable iteration in this case')
-    res = gpu_ctx.density_batch(jobs, pavden.den_params())
+    res = gpu_ctx.density_batch(jobs, pavden.den_params(kde_mode=mode))
     for j, (it, r) in enumerate(zip(its, res)):
         if 'n_rows' not in it:
             assert r.status == _lib.DEN_FAIL
@@ -161,8 +162,9 @@ def test_rule_call_inv_batch_files(built, gpu_ctx, tmp_path):
     assert flag.shape[0] == len(scans)
 
 
+@pytest.mark.parametrize('mode', [_lib.KDE_RUNS, _lib.KDE_DIRECT])
 @pytest.mark.parametrize('seed', [31, 32])
-def test_density_vs_oracle_seeded(built, gpu_ctx, seed):
+def test_density_vs_oracle_seeded(built, gpu_ctx, seed, mode):
     """Seeded haplotype with planted inversions, inverted repeats, N runs and reverse rows: the first scan iteration of
     every flagged region as one device batch vs the scalar oracle - integer columns exact, KERN_* to 1e-11."""
     from oracle import oracle
@@ -190,7 +192,7 @@ def test_density_vs_oracle_seeded(built, gpu_ctx, seed):
         if len(jobs) >= 24:
             break
     assert len(jobs) >= 8
-    res = gpu_ctx.density_batch(jobs, pavden.den_params())
+    res = gpu_ctx.density_batch(jobs, pavden.den_params(kde_mode=mode))
     n_final = 0
     for j, ((r, t), g) in enumerate(zip(pairs, res)):
         o = oracle.density(hap.ref.seqs[r.chrom][r.pos:r.end], hap.tig_seqs[t.chrom][t.pos:t.end], t.is_rev)
