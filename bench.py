@@ -42,6 +42,9 @@ def main():
                     help='reference span (bp) of the CPU-baseline sample; default = the whole haplotype (a few seconds of CPU)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--threads', type=int, default=0, help='host threads for the generator (0 = auto)')
+    ap.add_argument('--workload', choices=['cigar', 'cigar+inv'], default='cigar',
+                    help="'cigar' = BASELINE configs[1] (the metric's workload); 'cigar+inv' adds the k-mer inversion scan of "
+                         "every flagged region of the haplotype (configs[2] shape, one haplotype per GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -86,9 +89,38 @@ def main():
     t_h2d = time.time() - t0
     tig_bases = int(sum(hap.tig_seqs[n].shape[0] for n in hap.tig_names))
 
+    inv_state = {}
+    if args.workload == 'cigar+inv':
+        import io
+        import tempfile
+        from pav_amd import inv as pavinv, seq as pavseq
+        from pav_amd.align import AlignLift
+        from pav_amd.kmer import KmerUtil
+        tmpd = tempfile.mkdtemp(prefix='pav_bench_')
+        with open(os.path.join(tmpd, 'ref.fa.fai'), 'w') as fh:          # scan_for_inv reads "<ref>.fai" (inv.py:201)
+            for n in names:
+                fh.write(f'{n}\t{hap.ref.seqs[n].shape[0]}\t0\t0\t0\n')
+        ref_fa_name, tig_fa_name = os.path.join(tmpd, 'ref.fa'), os.path.join(tmpd, 'tig.fa')
+        ctx._inv_loaded = (ref_fa_name, tig_fa_name)                       # sequences are already resident
+        regions = [pavseq.Region(r['#CHROM'], r['POS'], r['END']) for _, r in hap.df_flag.iterrows()]
+        tig_len = hap.tig_lengths
+        k_util = KmerUtil(31)
+
+        def inv_step():
+            lift = AlignLift(hap.df_trim, tig_len, ctx=ctx)                # per job, like rule call_inv_batch; tables on the GPU
+            logs = [io.StringIO() for _ in regions]
+            out = pavinv.scan_for_inv_batch(regions, ref_fa_name, tig_fa_name, lift, k_util, logs=logs, ctx=ctx)
+            inv_state['out'], inv_state['logs'] = out, logs
+            return out
+
     def step():
         ctx.seq_pack(_lib.PAV_ROLE_TIG)
-        return ctx.cigar_call()
+        c = ctx.cigar_call()
+        if args.workload == 'cigar+inv':
+            import contextlib
+            with contextlib.redirect_stdout(io.StringIO()):                # scan_for_inv prints 'INV Found: ...' (inv.py:408)
+                inv_step()
+        return c
 
     def fence():
         if world > 1:
@@ -181,16 +213,37 @@ def main():
                              f'upper-casing and reverse complement, {c1:.1f} s wall',
                    'records_match_gpu': bool(ok)}
 
+        inv_report = None
+        if args.workload == 'cigar+inv':
+            from pav_amd import seq as pavseq2
+            out, logs = inv_state['out'], inv_state['logs']
+            scanned = iters = 0
+            for lg in logs:
+                for ln in lg.getvalue().splitlines():
+                    if ln.startswith('Scanning region: '):
+                        scanned += len(pavseq2.region_from_string(ln.split(': ')[1]))
+                        iters += 1
+            den = {k: v for k, v in kern.items() if k.startswith('k_')}
+            inv_report = {'flagged_regions': len(out), 'calls': sum(1 for o in out if o is not None and not isinstance(o, RuntimeError)),
+                          'planted': hap.stats['n_inv'], 'scan_iterations': iters, 'scanned_bp': scanned,
+                          'device_ms_per_step': round(sum(v['avg_ms'] * v['launches'] for v in den.values()) / args.steps, 3),
+                          'note': 'wall time of the step includes the Python scan control (lift-over, expansion logic, '
+                                  'DataFrame of every call); device_ms_per_step is the sum of the density kernels'}
+        metric = ('aligned Gbp/s through CIGAR-call (tokenise + walk + homology + SEQ gather + contig pack); bit-exact vs pavlib'
+                  if args.workload == 'cigar' else
+                  'aligned Gbp/s through CIGAR-call + k-mer inversion scan of all flagged regions; bit-exact calls vs pavlib')
         line = {
-            'metric': 'aligned Gbp/s through CIGAR-call (tokenise + walk + homology + SEQ gather + contig pack); bit-exact vs pavlib',
+            'metric': metric,
             'value': round(value, 2), 'unit': 'Gbp/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'u8/u32 (integer + byte)', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: one hg38-shaped haplotype, CIGAR-call only, one haplotype per GPU',
+            'config': {'workload': ('BASELINE configs[1]: one hg38-shaped haplotype, CIGAR-call only, one haplotype per GPU'
+                                    if args.workload == 'cigar' else
+                                    'BASELINE configs[2] shape: one hg38-shaped haplotype per GPU, CIGAR-call + k-mer inversion scan'),
                        'scale': args.scale, 'seed': args.seed, 'aligned_bp_per_gpu': int(counts.aligned_bases),
                        'n_aln': int(aln.shape[0]), 'n_ops': int(n_ops), 'n_snv': int(n_snv), 'n_indel': int(n_indel),
                        'parallelism': f'{world} x (1 haplotype / GPU), no collective'},
-            'roofline': roofline, 'cpu_baseline': cpu,
+            'roofline': roofline, 'cpu_baseline': cpu, 'inv_scan': inv_report,
             'host': {'generate_s': round(t_gen, 1), 'h2d_and_ref_pack_s': round(t_h2d, 2), 'd2h_records_s': round(t_d2h, 3),
                      'device': ctx.device_name},
         }

@@ -133,6 +133,16 @@ int pav_cigar_fetch(pav_ctx *ctx, pav_snv *snv, pav_indel *indel, uint8_t *seq_b
 /* Tokenised operations of the last pav_cigar_call: ops[i] = len << 4 | BAM opcode; op_off has n_aln + 1 entries. */
 int pav_cigar_fetch_ops(pav_ctx *ctx, uint32_t *ops, uint64_t *op_off);
 
+/* Lift-over tables for pavlib.align.AlignLift (pavlib/align/lift.py:380-476, `_add_align`): tokenises every row's
+ * CIGAR on the device and returns, per operation, the subject position where it starts (absolute, row POS included)
+ * and the query position where it starts (alignment orientation, clipping included).  Advance rules are AlignLift's:
+ * M / = / X move both axes, I / S / H the query, D the subject; N and P move nothing (the host raises on use).
+ * Two-call protocol: first with ops == NULL (tokenise, *n_ops_out = total operations; PAV_E_CIGAR + pav_cigar_error on a
+ * malformed row), then with buffers of n_ops_out entries (op_off: n_aln + 1) to copy the tables out. */
+int pav_align_index(pav_ctx *ctx, uint32_t n_aln, const uint32_t *row_pos, const uint8_t *cigar_text,
+                    const uint64_t *cigar_off, uint64_t *n_ops_out, uint32_t *ops, uint64_t *op_off, uint32_t *sub_begin,
+                    uint32_t *qry_begin);
+
 /* Direct entry to the device homology routines (unit parity tests against pavlib/call.py:542-647).
  * Sequence `seq_id` / `sv_seq_id` index the store of the given role; `rev` views that record reverse-
  * complemented (pavlib/cigarcall.py:69-70).  dir 0 = left_homology, 1 = right_homology. */

@@ -89,6 +89,7 @@ SYMBOLS = {
     'pav_cigar_error': (ctypes.c_int, [_P, _P]),
     'pav_cigar_fetch': (ctypes.c_int, [_P, _P, _P, _P]),
     'pav_cigar_fetch_ops': (ctypes.c_int, [_P, _P, _P]),
+    'pav_align_index': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P]),
     'pav_homology': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P]),
     'pav_density_batch': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P]),
     'pav_density_runs': (ctypes.c_int, [_P, ctypes.c_uint32, _P]),
@@ -249,6 +250,30 @@ class Context:
         self._check(self.lib.pav_cigar_fetch_ops(self.handle, _ptr(ops), ctypes.c_void_p(off.ctypes.data)),
                     'pav_cigar_fetch_ops')
         return ops, off
+
+    def align_index(self, row_pos, cigar_text, cigar_off):
+        """Device tokenizer + prefix scan for lift-over: -> (ops u32, op_off u64, sub_begin u32, qry_begin u32)."""
+        row_pos = np.ascontiguousarray(row_pos, dtype=np.uint32)
+        cigar_text = np.ascontiguousarray(cigar_text, dtype=np.uint8)
+        cigar_off = np.ascontiguousarray(cigar_off, dtype=np.uint64)
+        n = row_pos.shape[0]
+        n_ops = ctypes.c_uint64(0)
+        rc = self.lib.pav_align_index(self.handle, n, _ptr(row_pos), _ptr(cigar_text), ctypes.c_void_p(cigar_off.ctypes.data),
+                                      ctypes.byref(n_ops), None, None, None, None)
+        if rc == PAV_E_CIGAR:
+            e = CigarErr()
+            self.lib.pav_cigar_error(self.handle, ctypes.byref(e))
+            raise CigarDeviceError(self.lib.pav_last_error(self.handle).decode(), e)
+        self._check(rc, 'pav_align_index')
+        ops = np.empty(n_ops.value, dtype=np.uint32)
+        op_off = np.empty(n + 1, dtype=np.uint64)
+        sub_begin = np.empty(n_ops.value, dtype=np.uint32)
+        qry_begin = np.empty(n_ops.value, dtype=np.uint32)
+        dummy = np.zeros(1, dtype=np.uint32)
+        self._check(self.lib.pav_align_index(self.handle, n, _ptr(row_pos), _ptr(cigar_text), ctypes.c_void_p(cigar_off.ctypes.data),
+                                             ctypes.byref(n_ops), ctypes.c_void_p((ops if ops.size else dummy).ctypes.data),
+                                             ctypes.c_void_p(op_off.ctypes.data), _ptr(sub_begin), _ptr(qry_begin)), 'pav_align_index')
+        return ops, op_off, sub_begin, qry_begin
 
     def homology(self, queries):
         q = np.ascontiguousarray(queries, dtype=HOM_QUERY_DTYPE)

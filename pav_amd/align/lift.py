@@ -17,29 +17,74 @@ import numpy as np
 from .. import seq as pavseq
 from .cigar import tokenize
 
+_OP_TO_CODE = np.full(256, 15, dtype=np.int64)
+for _i, _c in enumerate(b'MIDNSHP=X'):
+    _OP_TO_CODE[_c] = _i
 
-class _Intervals:
-    """Disjoint half-open [begin, end) intervals with a (d0, d1) payload, sorted by begin."""
 
-    def __init__(self, begin, end, d0, d1):
-        self.begin, self.end, self.d0, self.d1 = begin, end, d0, d1
-        self._b = begin.tolist()
+_MATCH_CODES = np.zeros(16, dtype=bool)
+_MATCH_CODES[[0, 7, 8]] = True            # M, =, X
+
+
+class _OpTable:
+    """One alignment record's operations as parallel arrays (BAM codes, lengths, start on both axes) with the point
+    lookup the reference performs on its per-record interval trees.  ``axis`` 0 = subject, 1 = query."""
+
+    def __init__(self, ops, sub_begin, qry_begin):
+        self.code = (ops & 15).astype(np.int64)
+        self.len = (ops >> 4).astype(np.int64)
+        self.begin = (sub_begin.astype(np.int64), qry_begin.astype(np.int64))
+
+    def view(self, axis):
+        return _AxisView(self, axis)
+
+
+class _AxisView:
+    """Intervals of one axis: subject axis = M/=/X and D operations, query axis = M/=/X and I operations
+    (pavlib/align/lift.py:437-461).  Payload (d0, d1) = span on the other axis, or (x, x + 1) for I / D."""
+
+    def __init__(self, table, axis):
+        self.t, self.axis = table, axis
+        self.gap_code = 2 if axis == 0 else 1
 
     def at(self, pos):
-        """Index of the interval containing ``pos`` or -1."""
-        i = bisect.bisect_right(self._b, pos) - 1
-        if i >= 0 and pos < self.end[i]:
-            return i
-        return -1
+        """Index of the operation whose interval contains ``pos`` or -1."""
+        t = self.t
+        b = t.begin[self.axis]
+        k = int(np.searchsorted(b, pos, side='right')) - 1
+        if k < 0:
+            return -1
+        c = t.code[k]
+        if not (_MATCH_CODES[c] or c == self.gap_code):
+            return -1
+        return k if pos < b[k] + t.len[k] else -1
+
+    def interval(self, k):
+        """(begin, end, d0, d1) of operation k."""
+        t = self.t
+        begin = int(t.begin[self.axis][k])
+        ln = int(t.len[k])
+        o = int(t.begin[1 - self.axis][k])
+        return begin, begin + ln, o, (o + ln if _MATCH_CODES[t.code[k]] else o + 1)
 
 
 class AlignLift:
     """Lift coordinates through alignment records (same constructor and methods as pavlib.align.AlignLift)."""
 
-    def __init__(self, df, df_fai, cache_align=10):
+    def __init__(self, df, df_fai, cache_align=10, ctx=None):
+        """``ctx``: optional :class:`pav_amd._lib.Context`; the CIGARs of all rows are then tokenised and prefix-scanned
+        on the GPU in one call (``pav_align_index``) instead of per record on first use."""
         self.df = df
         self.df_fai = df_fai
         self.cache_align = cache_align
+        self._dev = None
+        if ctx is not None and df.shape[0]:
+            cig = [str(c).encode() for c in df['CIGAR']]
+            off = np.zeros(len(cig) + 1, dtype=np.uint64)
+            off[1:] = np.cumsum([len(c) for c in cig], dtype=np.uint64)
+            ops, op_off, sub_b, qry_b = ctx.align_index(df['POS'].to_numpy(dtype=np.uint32),
+                                                         np.frombuffer(b''.join(cig), dtype=np.uint8), off)
+            self._dev = (ops, op_off.astype(np.int64), sub_b, qry_b, {ix: i for i, ix in enumerate(df.index)})
         if len(set(df.index)) != df.shape[0]:
             raise RuntimeError('Cannot create AlignLift object with duplicate index values')
         # per subject / per query: list of (begin, end, index); lookups need "exactly one record contains pos"
@@ -99,13 +144,13 @@ class AlignLift:
             i = tree.at(pos)
             if i < 0:
                 i = tree.at(pos - 1)                    # a query exactly at the alignment end (lift.py:122-138)
-                if i < 0 or tree.end[i] != pos:
+                if i < 0 or tree.interval(i)[1] != pos:
                     raise RuntimeError((
                         'Found no matches in a lift-tree for a record within a '
                         'global to-subject tree: {}:{} (index={}, gap={})'
                     ).format(query_id, pos_org, index, gap))
-            d0, d1 = int(tree.d0[i]), int(tree.d1[i])
-            lift_pos = d0 + (int(pos) - int(tree.begin[i])) if d1 - d0 > 1 else d1
+            begin, _, d0, d1 = tree.interval(i)
+            lift_pos = d0 + (int(pos) - begin) if d1 - d0 > 1 else d1
             out.append((row['#CHROM'], lift_pos, row['REV'], lift_pos, lift_pos, (row['INDEX'],)))
         return out if ret_list else out[0]
 
@@ -131,8 +176,8 @@ class AlignLift:
                     'Program bug: Found no matches in a lift-tree for a record withing a '
                     'global to-query tree: {}:{} (index={})'
                 ).format(subject_id, pos, index))
-            d0, d1 = int(tree.d0[i]), int(tree.d1[i])
-            qry_pos = d0 + (int(pos) - int(tree.begin[i])) if d1 - d0 > 1 else d1
+            begin, _, d0, d1 = tree.interval(i)
+            qry_pos = d0 + (int(pos) - begin) if d1 - d0 > 1 else d1
             if row['REV']:
                 qry_pos = self.df_fai[row['QRY_ID']] - qry_pos
             out.append((row['QRY_ID'], qry_pos, row['REV'], qry_pos, qry_pos, (row['INDEX'],)))
@@ -182,29 +227,31 @@ class AlignLift:
             self.cache_queue.appendleft(index)
             return
         self._check_and_clear()
-        row = self.df.loc[index]
-        lens, ops = tokenize(row['CIGAR'])
-        if np.any(lens == 0):
-            raise ValueError('IntervalTree: Null Interval objects not allowed in IntervalTree: zero-length CIGAR operation')
-        is_match = (ops == ord('=')) | (ops == ord('X')) | (ops == ord('M'))
-        is_ins, is_del = ops == ord('I'), ops == ord('D')
-        is_clip = (ops == ord('S')) | (ops == ord('H'))
-        other = ~(is_match | is_ins | is_del | is_clip)
-        if np.any(other):
+        if self._dev is not None:
+            ops_all, op_off, sub_all, qry_all, where = self._dev
+            r = where[index]
+            sl = slice(int(op_off[r]), int(op_off[r + 1]))
+            ops, sub_b, qry_b = ops_all[sl], sub_all[sl], qry_all[sl]
+        else:                                           # host tokenizer (no GPU context given)
+            row = self.df.loc[index]
+            lens, opc = tokenize(row['CIGAR'])
+            code = _OP_TO_CODE[opc]
+            ops = (lens.astype(np.uint32) << 4) | code.astype(np.uint32)
+            match = _MATCH_CODES[code]
+            sub_adv = np.where(match | (code == 2), lens, 0)
+            qry_adv = np.where(match | (code == 1) | (code == 4) | (code == 5), lens, 0)
+            sub_b = int(row['POS']) + np.concatenate(([0], np.cumsum(sub_adv)[:-1]))
+            qry_b = np.concatenate(([0], np.cumsum(qry_adv)[:-1]))
+        table = _OpTable(ops, sub_b, qry_b)
+        bad = (table.code == 3) | (table.code == 6)
+        if np.any(bad):
+            row = self._rows[index]
             raise RuntimeError('Unhandled CIGAR operation: {}: Alignment {}:{} ({})'.format(
-                chr(int(ops[np.flatnonzero(other)[0]])), row['#CHROM'], row['POS'], row['QRY_ID']))
-        sub_adv = np.where(is_match | is_del, lens, 0)
-        qry_adv = np.where(is_match | is_ins | is_clip, lens, 0)
-        sub_bp = int(row['POS']) + np.concatenate(([0], np.cumsum(sub_adv)[:-1]))
-        qry_bp = np.concatenate(([0], np.cumsum(qry_adv)[:-1]))
-        # reference axis: matches map to the query span, deletions to (qry_bp, qry_bp + 1)
-        r = is_match | is_del
-        self.ref_cache[index] = _Intervals(sub_bp[r], sub_bp[r] + lens[r], qry_bp[r],
-                                           np.where(is_match[r], qry_bp[r] + lens[r], qry_bp[r] + 1))
-        # query axis: matches map to the subject span, insertions to (sub_bp, sub_bp + 1)
-        q = is_match | is_ins
-        self.tig_cache[index] = _Intervals(qry_bp[q], qry_bp[q] + lens[q], sub_bp[q],
-                                           np.where(is_match[q], sub_bp[q] + lens[q], sub_bp[q] + 1))
+                'NP'[int(table.code[np.flatnonzero(bad)[0]] == 6)], row['#CHROM'], row['POS'], row['QRY_ID']))
+        if np.any((table.len == 0) & (_MATCH_CODES[table.code] | (table.code == 1) | (table.code == 2))):
+            raise ValueError('IntervalTree: Null Interval objects not allowed in IntervalTree: zero-length CIGAR operation')
+        self.ref_cache[index] = table.view(0)
+        self.tig_cache[index] = table.view(1)
         self.cache_queue.appendleft(index)
 
     def _check_and_clear(self):

@@ -235,7 +235,10 @@ __global__ __launch_bounds__(256) void walk_chunks(const uint64_t *__restrict__ 
             for (int q = 0; q < NQ; ++q) carry[q] += tot[q];
         __syncthreads();
     }
-    if (threadIdx.x < NQ) totals[threadIdx.x] = carry[threadIdx.x];
+    if (threadIdx.x < NQ) {
+        totals[threadIdx.x] = carry[threadIdx.x];
+        chunk_pre[(uint64_t)n_chunks * NQ + threadIdx.x] = carry[threadIdx.x];   // read by rows that start at n_ops
+    }
 }
 
 // One wave per row: running (ref, tig) advance of all ops before the row's first op.
@@ -357,6 +360,101 @@ __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) run[q] += c[q];
         prev = o[j];
+    }
+}
+
+// ---- lift-over tables (pavlib/align/lift.py:380-476) ------------------------------------------------------------
+// Per operation: subject position where it starts (absolute) and query position where it starts (alignment
+// orientation, clips included).  Advance rules are AlignLift's: M, =, X move both axes, I / S / H the query,
+// D the subject.  Same flat scan as the variant walk, two quantities.
+__device__ __forceinline__ void lift_contrib(uint32_t op, uint64_t &sub, uint64_t &qry) {
+    const uint32_t code = op & 15u;
+    const uint64_t len = op >> 4;
+    const bool match = code == 7 || code == 8 || code == 0;
+    sub = (match || code == 2) ? len : 0;
+    qry = (match || code == 1 || code == 4 || code == 5) ? len : 0;
+}
+
+__global__ __launch_bounds__(256) void lift_reduce(const uint32_t *__restrict__ ops, uint64_t n_ops,
+                                                   uint64_t *__restrict__ chunk_sum /* [n_chunks][2] */) {
+    __shared__ uint64_t lds[8];
+    uint32_t o[OPS_PER_LANE];
+    load_ops(ops, n_ops, (uint64_t)blockIdx.x * WALK_CHUNK + (uint64_t)threadIdx.x * OPS_PER_LANE, o);
+    uint64_t a = 0, b = 0;
+#pragma unroll
+    for (int j = 0; j < OPS_PER_LANE; ++j) { uint64_t x, y; lift_contrib(o[j], x, y); a += x; b += y; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); }
+    if ((threadIdx.x & 63) == 0) { lds[(threadIdx.x >> 6) * 2] = a; lds[(threadIdx.x >> 6) * 2 + 1] = b; }
+    __syncthreads();
+    if (threadIdx.x < 2) chunk_sum[(uint64_t)blockIdx.x * 2 + threadIdx.x] = lds[threadIdx.x] + lds[2 + threadIdx.x] + lds[4 + threadIdx.x] + lds[6 + threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void lift_chunks(const uint64_t *__restrict__ chunk_sum, uint64_t *__restrict__ chunk_pre, uint32_t n_chunks) {
+    __shared__ uint64_t lds[8];
+    __shared__ uint64_t carry[2];
+    if (threadIdx.x < 2) carry[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_chunks; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        uint64_t v[2], tot[2];
+        v[0] = i < n_chunks ? chunk_sum[2ull * i] : 0; v[1] = i < n_chunks ? chunk_sum[2ull * i + 1] : 0;
+        block_excl_scan<2>(v, tot, lds);
+        if (i < n_chunks) { chunk_pre[2ull * i] = carry[0] + v[0]; chunk_pre[2ull * i + 1] = carry[1] + v[1]; }
+        __syncthreads();
+        if (threadIdx.x == 0) { carry[0] += tot[0]; carry[1] += tot[1]; }
+        __syncthreads();
+    }
+    if (threadIdx.x < 2) chunk_pre[2ull * n_chunks + threadIdx.x] = carry[threadIdx.x];   // rows starting at n_ops
+}
+
+__global__ __launch_bounds__(256) void lift_row_base(const uint32_t *__restrict__ ops, const uint64_t *__restrict__ op_off,
+                                                     const uint64_t *__restrict__ chunk_pre, uint64_t *__restrict__ rowbase, uint32_t n_aln) {
+    const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_aln) return;
+    const int lane = threadIdx.x & 63;
+    const uint64_t first = op_off[r];
+    const uint64_t c = first / WALK_CHUNK;
+    uint64_t a = 0, b = 0;
+    for (uint64_t i = c * WALK_CHUNK + lane; i < first; i += 64) { uint64_t x, y; lift_contrib(ops[i], x, y); a += x; b += y; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); }
+    if (lane == 0) {
+        const uint64_t n_chunks_guard = c;            // chunk_pre has one entry per chunk; first == n_ops only for empty tails
+        rowbase[2ull * r] = chunk_pre[2ull * n_chunks_guard] + a;
+        rowbase[2ull * r + 1] = chunk_pre[2ull * n_chunks_guard + 1] + b;
+    }
+}
+
+__global__ __launch_bounds__(256) void lift_positions(const uint32_t *__restrict__ ops, uint64_t n_ops,
+                                                      const uint64_t *__restrict__ op_off, const uint32_t *__restrict__ row_pos,
+                                                      uint32_t n_aln, const uint64_t *__restrict__ chunk_pre,
+                                                      const uint64_t *__restrict__ rowbase, uint32_t *__restrict__ sub_begin,
+                                                      uint32_t *__restrict__ qry_begin) {
+    __shared__ uint64_t lds[8];
+    const uint64_t first = (uint64_t)blockIdx.x * WALK_CHUNK + (uint64_t)threadIdx.x * OPS_PER_LANE;
+    uint32_t o[OPS_PER_LANE];
+    load_ops(ops, n_ops, first, o);
+    uint64_t run[2] = {0, 0}, tot[2];
+#pragma unroll
+    for (int j = 0; j < OPS_PER_LANE; ++j) { uint64_t x, y; lift_contrib(o[j], x, y); run[0] += x; run[1] += y; }
+    block_excl_scan<2>(run, tot, lds);
+    run[0] += chunk_pre[2ull * blockIdx.x]; run[1] += chunk_pre[2ull * blockIdx.x + 1];
+    if (first >= n_ops) return;
+    uint32_t lo = 0, hi = n_aln;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (op_off[mid] <= first) lo = mid; else hi = mid; }
+    uint32_t row = lo;
+    uint64_t row_end = op_off[row + 1];
+    uint64_t rb0 = rowbase[2ull * row], rb1 = rowbase[2ull * row + 1];
+    uint32_t pos0 = row_pos[row];
+#pragma unroll
+    for (int j = 0; j < OPS_PER_LANE; ++j) {
+        const uint64_t k = first + j;
+        if (k >= n_ops) break;
+        while (k >= row_end) { ++row; row_end = op_off[row + 1]; rb0 = rowbase[2ull * row]; rb1 = rowbase[2ull * row + 1]; pos0 = row_pos[row]; }
+        sub_begin[k] = pos0 + (uint32_t)(run[0] - rb0);
+        qry_begin[k] = (uint32_t)(run[1] - rb1);
+        uint64_t x, y; lift_contrib(o[j], x, y); run[0] += x; run[1] += y;
     }
 }
 
@@ -628,9 +726,9 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
     uint64_t errs[2] = {~0ull, ~0ull};
     uint64_t *d_csum = nullptr, *d_cpre = nullptr;
     if (n_wchunks) {
-        PAV_HIP(ctx, ctx->d_chunk2.reserve(2 * sizeof(uint64_t) * NQ * (size_t)n_wchunks));
+        PAV_HIP(ctx, ctx->d_chunk2.reserve(2 * sizeof(uint64_t) * NQ * ((size_t)n_wchunks + 1)));
         d_csum = ctx->d_chunk2.as<uint64_t>();
-        d_cpre = d_csum + (size_t)NQ * n_wchunks;
+        d_cpre = d_csum + (size_t)NQ * (n_wchunks + 1);
         PAV_HIP(ctx, ctx->d_rowbase.reserve(2 * sizeof(uint64_t) * ((size_t)n_aln + 1)));
         PAV_LAUNCH(ctx, "walk_reduce", walk_reduce, n_wchunks, 256, 0, ctx->d_ops.as<uint32_t>(), n_ops, d_csum);
         PAV_LAUNCH(ctx, "walk_chunks", walk_chunks, 1, 256, 0, d_csum, d_cpre, ctx->d_totals.as<uint64_t>(), n_wchunks);
@@ -760,6 +858,87 @@ int pav_cigar_fetch_ops(pav_ctx *ctx, uint32_t *ops, uint64_t *op_off) {
     if (op_off)
         PAV_HIP(ctx, hipMemcpyAsync(op_off, ctx->d_op_off.p, sizeof(uint64_t) * ((size_t)ctx->n_aln + 1), hipMemcpyDeviceToHost, ctx->stream));
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PAV_OK;
+}
+
+int pav_align_index(pav_ctx *ctx, uint32_t n_aln, const uint32_t *row_pos, const uint8_t *cigar_text, const uint64_t *cigar_off,
+                    uint64_t *n_ops_out, uint32_t *ops, uint64_t *op_off, uint32_t *sub_begin, uint32_t *qry_begin) {
+    if (!ctx || !n_ops_out) return PAV_E_ARG;
+    if (n_aln && (!row_pos || !cigar_off)) return fail(ctx, PAV_E_ARG, "pav_align_index: null input");
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint64_t T = n_aln ? cigar_off[n_aln] : 0;
+    const bool upload = ops == nullptr;                 // first call (ops == NULL): tokenise and return the op count
+    const uint64_t Tpad = round_up(T + 1, TOK_CHUNK);
+    const uint32_t n_tchunks = (uint32_t)(Tpad / TOK_CHUNK);
+    if (upload) {
+        memset(&ctx->cigar_err, 0, sizeof ctx->cigar_err);
+        PAV_HIP(ctx, ctx->ix_text.reserve(Tpad));
+        PAV_HIP(ctx, ctx->ix_off.reserve(sizeof(uint64_t) * ((size_t)n_aln + 1)));
+        PAV_HIP(ctx, ctx->ix_pos.reserve(sizeof(uint32_t) * ((size_t)n_aln + 1)));
+        PAV_HIP(ctx, ctx->ix_err.reserve(16));
+        PAV_HIP(ctx, hipMemsetAsync(ctx->ix_text.p, '0', Tpad, st));
+        PAV_HIP(ctx, hipMemsetAsync(ctx->ix_err.p, 0xFF, 16, st));
+        if (T) PAV_HIP(ctx, hipMemcpyAsync(ctx->ix_text.p, cigar_text, T, hipMemcpyHostToDevice, st));
+        uint64_t zero = 0;
+        PAV_HIP(ctx, hipMemcpyAsync(ctx->ix_off.p, n_aln ? cigar_off : &zero, sizeof(uint64_t) * ((size_t)n_aln + 1), hipMemcpyHostToDevice, st));
+        if (n_aln) PAV_HIP(ctx, hipMemcpyAsync(ctx->ix_pos.p, row_pos, sizeof(uint32_t) * n_aln, hipMemcpyHostToDevice, st));
+        PAV_HIP(ctx, ctx->ix_chunk.reserve(sizeof(uint32_t) * n_tchunks + sizeof(uint64_t) * ((size_t)n_tchunks + 1) + 64));
+        uint32_t *d_tcnt = ctx->ix_chunk.as<uint32_t>();
+        uint64_t *d_tpre = reinterpret_cast<uint64_t *>(ctx->ix_chunk.as<uint8_t>() + round_up(sizeof(uint32_t) * n_tchunks, 16));
+        unsigned long long *d_tok_err = ctx->ix_err.as<unsigned long long>();
+        PAV_LAUNCH(ctx, "tok_count", tok_count, n_tchunks, 256, 0, ctx->ix_text.as<uint4>(), d_tcnt);
+        PAV_LAUNCH(ctx, "scan_counts", scan_counts, 1, 256, 0, d_tcnt, d_tpre, n_tchunks);
+        uint64_t n_ops = 0;
+        PAV_HIP(ctx, hipMemcpyAsync(&n_ops, d_tpre + n_tchunks, sizeof n_ops, hipMemcpyDeviceToHost, st));
+        PAV_HIP(ctx, hipStreamSynchronize(st));
+        PAV_HIP(ctx, ctx->ix_ops.reserve(sizeof(uint32_t) * (n_ops + 16)));
+        PAV_HIP(ctx, ctx->ix_op_off.reserve(sizeof(uint64_t) * ((size_t)n_aln + 1)));
+        PAV_LAUNCH(ctx, "tok_emit", tok_emit, n_tchunks, 256, 0, ctx->ix_text.as<uint8_t>(), d_tpre, ctx->ix_ops.as<uint32_t>(), d_tok_err);
+        PAV_LAUNCH(ctx, "row_ops", row_ops, (n_aln + 1 + 3) / 4, 256, 0, ctx->ix_text.as<uint8_t>(), ctx->ix_off.as<uint64_t>(), d_tpre,
+                   ctx->ix_op_off.as<uint64_t>(), n_aln, d_tok_err);
+        const uint32_t n_wchunks = (uint32_t)((n_ops + WALK_CHUNK - 1) / WALK_CHUNK);
+        PAV_HIP(ctx, ctx->ix_begin.reserve(2 * sizeof(uint32_t) * (n_ops + 16)));
+        if (n_wchunks) {
+            PAV_HIP(ctx, ctx->ix_chunk2.reserve(4 * sizeof(uint64_t) * ((size_t)n_wchunks + 1)));
+            uint64_t *d_csum = ctx->ix_chunk2.as<uint64_t>(), *d_cpre = d_csum + 2ull * (n_wchunks + 1);
+            PAV_HIP(ctx, ctx->ix_rowbase.reserve(2 * sizeof(uint64_t) * ((size_t)n_aln + 1)));
+            PAV_LAUNCH(ctx, "lift_reduce", lift_reduce, n_wchunks, 256, 0, ctx->ix_ops.as<uint32_t>(), n_ops, d_csum);
+            PAV_LAUNCH(ctx, "lift_chunks", lift_chunks, 1, 256, 0, d_csum, d_cpre, n_wchunks);
+            PAV_LAUNCH(ctx, "lift_row_base", lift_row_base, (n_aln + 3) / 4, 256, 0, ctx->ix_ops.as<uint32_t>(), ctx->ix_op_off.as<uint64_t>(),
+                       d_cpre, ctx->ix_rowbase.as<uint64_t>(), n_aln);
+            PAV_LAUNCH(ctx, "lift_positions", lift_positions, n_wchunks, 256, 0, ctx->ix_ops.as<uint32_t>(), n_ops, ctx->ix_op_off.as<uint64_t>(),
+                       ctx->ix_pos.as<uint32_t>(), n_aln, d_cpre, ctx->ix_rowbase.as<uint64_t>(), ctx->ix_begin.as<uint32_t>(),
+                       ctx->ix_begin.as<uint32_t>() + n_ops);
+        }
+        uint64_t terr = ~0ull;
+        PAV_HIP(ctx, hipMemcpyAsync(&terr, ctx->ix_err.p, sizeof terr, hipMemcpyDeviceToHost, st));
+        PAV_HIP(ctx, hipStreamSynchronize(st));
+        *n_ops_out = n_ops;
+        ctx->ix_n_ops = n_ops; ctx->ix_n_aln = n_aln;
+        if (terr != ~0ull) {
+            const uint64_t bytepos = terr >> 3;
+            uint32_t lo = 0, hi = n_aln;
+            while (hi - lo > 1) { uint32_t mid = (lo + hi) / 2; if (cigar_off[mid] <= bytepos) lo = mid; else hi = mid; }
+            while (lo + 1 < n_aln && cigar_off[lo + 1] <= bytepos) ++lo;
+            ctx->cigar_err.kind = (int32_t)(terr & 7); ctx->cigar_err.aln = lo;
+            ctx->cigar_err.op_index = (uint32_t)(bytepos - cigar_off[lo]);
+            ctx->cigar_err.op_char = cigar_text[bytepos];
+            return fail(ctx, PAV_E_CIGAR, "CIGAR tokenizer error kind %d at alignment row %u", ctx->cigar_err.kind, lo);
+        }
+        return PAV_OK;
+    }
+    // second call: copy the tables out
+    if (ctx->ix_n_aln != n_aln) return fail(ctx, PAV_E_STATE, "pav_align_index: fetch does not match the indexed table");
+    const uint64_t n_ops = ctx->ix_n_ops;
+    *n_ops_out = n_ops;
+    if (n_ops) {
+        PAV_HIP(ctx, hipMemcpyAsync(ops, ctx->ix_ops.p, sizeof(uint32_t) * n_ops, hipMemcpyDeviceToHost, st));
+        if (sub_begin) PAV_HIP(ctx, hipMemcpyAsync(sub_begin, ctx->ix_begin.p, sizeof(uint32_t) * n_ops, hipMemcpyDeviceToHost, st));
+        if (qry_begin) PAV_HIP(ctx, hipMemcpyAsync(qry_begin, ctx->ix_begin.as<uint32_t>() + n_ops, sizeof(uint32_t) * n_ops, hipMemcpyDeviceToHost, st));
+    }
+    if (op_off) PAV_HIP(ctx, hipMemcpyAsync(op_off, ctx->ix_op_off.p, sizeof(uint64_t) * ((size_t)n_aln + 1), hipMemcpyDeviceToHost, st));
+    PAV_HIP(ctx, hipStreamSynchronize(st));
     return PAV_OK;
 }
 

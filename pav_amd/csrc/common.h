@@ -79,7 +79,9 @@ struct pav_ctx {
     pav_cigar_err cigar_err{};
     pav::DevBuf d_aln, d_text, d_text_off, d_ops, d_op_off, d_chunk, d_chunk2, d_rowbase, d_err, d_totals;
     pav::DevBuf d_snv, d_indel, d_seqblob, d_tmp;
+    pav::DevBuf ix_text, ix_off, ix_pos, ix_ops, ix_op_off, ix_chunk, ix_chunk2, ix_rowbase, ix_begin, ix_err;   // pav_align_index
     uint64_t n_ops = 0;
+    uint64_t ix_n_ops = 0; uint32_t ix_n_aln = 0;
 
     // density state lives in density.hip (opaque here)
     void *density = nullptr;

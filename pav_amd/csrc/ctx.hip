@@ -178,7 +178,8 @@ void pav_destroy(pav_ctx *ctx) {
     }
     DevBuf *bufs[] = {&ctx->d_aln, &ctx->d_text, &ctx->d_text_off, &ctx->d_ops, &ctx->d_op_off, &ctx->d_chunk,
                       &ctx->d_chunk2, &ctx->d_rowbase, &ctx->d_err, &ctx->d_totals, &ctx->d_snv, &ctx->d_indel,
-                      &ctx->d_seqblob, &ctx->d_tmp};
+                      &ctx->d_seqblob, &ctx->d_tmp, &ctx->ix_text, &ctx->ix_off, &ctx->ix_pos, &ctx->ix_ops, &ctx->ix_op_off,
+                      &ctx->ix_chunk, &ctx->ix_chunk2, &ctx->ix_rowbase, &ctx->ix_begin, &ctx->ix_err};
     for (DevBuf *b : bufs) b->release();
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -31,21 +31,21 @@ def den_params(k=31, min_informative=DEFAULT_MIN_INFORMATIVE, min_state_count=DE
                           int(max_ref_kmer_count), int(kde_mode))
 
 
-def table_frame(cols, finalised=True):
+def table_frame(cols, finalised=True, extra=None):
     """Density table as the reference's DataFrame (scripts/density.py:340-342): indexed by INDEX; an un-finalised
-    table (fewer than --mininf informative k-mers) keeps the early column set of :157-163 with STATE = -1."""
+    table (fewer than --mininf informative k-mers) keeps the early column set of :157-163 with STATE = -1.
+    ``extra``: further columns appended in order (FLANK / MATCH of pavlib/inv.py:522-555).  Built in one shot."""
+    index = cols['INDEX'].astype(np.int64)
     if finalised:
-        df = pd.DataFrame({c: cols[c] for c in DENSITY_COLUMNS}, columns=DENSITY_COLUMNS)
-        df['INDEX'] = df['INDEX'].astype(np.int64)
-        df['STATE_MER'] = df['STATE_MER'].astype(np.int64)
-        df['STATE'] = df['STATE'].astype(np.int64)
-        df['KMER'] = cols['KMER'].astype(np.int64)                      # k <= 31: fits int64 like the reference column
+        data = {'INDEX': index, 'STATE_MER': cols['STATE_MER'].astype(np.int64), 'STATE': cols['STATE'].astype(np.int64),
+                'KERN_FWD': cols['KERN_FWD'], 'KERN_FWDREV': cols['KERN_FWDREV'], 'KERN_REV': cols['KERN_REV'],
+                'KMER': cols['KMER'].astype(np.int64)}          # k <= 31: fits int64 like the reference column
     else:
-        df = pd.DataFrame({'KMER': cols['KMER'].astype(np.int64), 'INDEX': cols['INDEX'].astype(np.int64),
-                           'STATE': cols['STATE'].astype(np.int64), 'STATE_MER': cols['STATE_MER'].astype(np.int64)},
-                          columns=['KMER', 'INDEX', 'STATE', 'STATE_MER'])
-    df.set_index(df['INDEX'], inplace=True, drop=False)
-    return df
+        data = {'KMER': cols['KMER'].astype(np.int64), 'INDEX': index, 'STATE': cols['STATE'].astype(np.int64),
+                'STATE_MER': cols['STATE_MER'].astype(np.int64)}
+    if extra:
+        data.update(extra)
+    return pd.DataFrame(data, index=pd.Index(index, name='INDEX'), copy=False)
 
 
 def rl_encoder(df, state_col='STATE'):

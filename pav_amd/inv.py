@@ -266,13 +266,30 @@ class _Scan:
         # density table + INV-DUP annotation (inv.py:440-442, 457-561)
         res_rows = self.n_rows
         cols = ctx.density_table(job, res_rows)
-        df = density.table_frame(cols, finalised=True)
-        df = annotate_inv_dup_mers(df, region_ref_outer, region_ref_inner, region_tig_outer, region_tig_inner, region_ref,
-                                   self.ref_fa_name, k_util, ctx=ctx, job=job, ref_index=self.ref_index)
+        extra = _flank_match_columns(res_rows, region_ref_outer, region_ref_inner, region_tig_outer, region_tig_inner,
+                                     region_ref, ctx, job, self.ref_index)
+        df = density.table_frame(cols, finalised=True, extra=extra)
         inv_call = InvCall(region_ref_outer, region_ref_inner, region_tig_outer, region_tig_inner, region_ref, region_tig,
                            self.region_flag, df)
         _write_log('Found inversion: {}'.format(inv_call), log)
         return self._finish(inv_call)
+
+
+def _flank_match_columns(n_rows, region_ref_outer, region_ref_inner, region_tig_outer, region_tig_inner,
+                         region_tig_discovery, ctx, job, ref_index):
+    """FLANK / MATCH of pavlib/inv.py:480-555 for the table resident on the device as ``job``."""
+    region_dup_ref_up = seq.Region(region_ref_outer.chrom, region_ref_outer.pos, region_ref_inner.pos)
+    region_dup_ref_dn = seq.Region(region_ref_outer.chrom, region_ref_inner.end, region_ref_outer.end)
+    region_dup_tig_up = seq.Region(region_tig_outer.chrom, region_tig_outer.pos, region_tig_inner.pos)
+    region_dup_tig_dn = seq.Region(region_tig_outer.chrom, region_tig_inner.end, region_tig_outer.end)
+    flank, match = ctx.density_annotate(
+        job, n_rows, ref_index[region_ref_outer.chrom],
+        (region_dup_ref_up.pos, region_dup_ref_up.end), (region_dup_ref_dn.pos, region_dup_ref_dn.end),
+        int(region_tig_discovery.pos),
+        (region_dup_tig_up.pos, region_dup_tig_up.end), (region_dup_tig_dn.pos, region_dup_tig_dn.end))
+    m = _MATCH_TEXT[match]
+    m[match == 3] = np.nan                                             # 'NA' -> NaN (inv.py:555)
+    return {'FLANK': _FLANK_TEXT[flank], 'MATCH': m}
 
 
 def annotate_inv_dup_mers(df, region_ref_outer, region_ref_inner, region_tig_outer, region_tig_inner,
@@ -285,19 +302,10 @@ def annotate_inv_dup_mers(df, region_ref_outer, region_ref_inner, region_tig_out
     """
     if ctx is None or job is None:
         raise _lib.PavDeviceError('annotate_inv_dup_mers needs the device context holding the density table')
-    region_dup_ref_up = seq.Region(region_ref_outer.chrom, region_ref_outer.pos, region_ref_inner.pos)
-    region_dup_ref_dn = seq.Region(region_ref_outer.chrom, region_ref_inner.end, region_ref_outer.end)
-    region_dup_tig_up = seq.Region(region_tig_outer.chrom, region_tig_outer.pos, region_tig_inner.pos)
-    region_dup_tig_dn = seq.Region(region_tig_outer.chrom, region_tig_inner.end, region_tig_outer.end)
-    flank, match = ctx.density_annotate(
-        job, df.shape[0], ref_index[region_ref_outer.chrom],
-        (region_dup_ref_up.pos, region_dup_ref_up.end), (region_dup_ref_dn.pos, region_dup_ref_dn.end),
-        int(region_tig_discovery.pos),
-        (region_dup_tig_up.pos, region_dup_tig_up.end), (region_dup_tig_dn.pos, region_dup_tig_dn.end))
-    df['FLANK'] = _FLANK_TEXT[flank]
-    m = _MATCH_TEXT[match]
-    m[match == 3] = np.nan                                             # 'NA' -> NaN (inv.py:555)
-    df['MATCH'] = m
+    extra = _flank_match_columns(df.shape[0], region_ref_outer, region_ref_inner, region_tig_outer, region_tig_inner,
+                                 region_tig_discovery, ctx, job, ref_index)
+    df['FLANK'] = extra['FLANK']
+    df['MATCH'] = extra['MATCH']
     return df
 
 

@@ -129,11 +129,11 @@ def call_inv_batch(bed_flag, bed_aln, tig_fa, fai, ref_fa, hap, batch, bed_out=N
         df_bed = pd.DataFrame([], columns=empty_cols)                                # :148-167
     else:
         k_util = KmerUtil(k_size)
-        align_lift = AlignLift(pd.read_csv(bed_aln, sep='\t'), read_fai(fai))
         own = ctx is None
         if own:
             ctx = _lib.Context(device_id)
         try:
+            align_lift = AlignLift(pd.read_csv(bed_aln, sep='\t'), read_fai(fai), ctx=ctx)   # lift tables built on the GPU
             regions = [pavseq.Region(row['#CHROM'], row['POS'], row['END']) for _, row in df_flag.iterrows()]
             logs = [io.StringIO() for _ in regions]
             results = pavinv.scan_for_inv_batch(regions, ref_fa, tig_fa, align_lift, k_util, max_region_size=inv_region_limit,

@@ -119,6 +119,40 @@ def test_density_iterations_vs_reference(built, gpu_ctx, case, mode):
             assert np.allclose([cols[c].sum() for c in KERN], it['kern_sum'], rtol=1e-12, atol=0)
 
 
+def test_alignlift_device_tables(built, gpu_ctx):
+    """AlignLift with lift tables built by pav_align_index (device tokenizer + scan) against the reference's answers."""
+    with open(os.path.join(GOLD, 'lift_kat.json')) as fh:
+        kat = json.load(fh)
+    lifts = {}
+    for k in kat:
+        c = k['case']
+        if c not in lifts:
+            d = os.path.join(GOLD, c)
+            lifts[c] = AlignLift(pd.read_csv(os.path.join(d, 'align.tsv'), sep='\t'), read_fai(os.path.join(d, 'tig.fa.fai')),
+                                 ctx=gpu_ctx)
+        err = None
+        try:
+            out = lifts[c].lift_to_qry(k['id'], k['pos']) if k['dir'] == 'to_qry' else lifts[c].lift_to_sub(k['id'], k['pos'], k['gap'])
+        except RuntimeError as ex:
+            out, err = None, str(ex)
+        norm = None if out is None else [out[0], int(out[1]), None if out[2] is None else bool(out[2]), int(out[3]),
+                                         int(out[4]), [int(v) for v in out[5]]]
+        assert norm == k['out'], k
+        if k['dir'] == 'to_sub':
+            assert err == k.get('error'), k
+    # device tables == host tokenizer tables on a table with many rows, reverse rows, clips
+    hap = synth.config2(seed=41, scale=0.003, threads=2)
+    dev = AlignLift(hap.df_trim, hap.tig_lengths, ctx=gpu_ctx)
+    host = AlignLift(hap.df_trim, hap.tig_lengths)
+    for index in list(hap.df_trim.index)[:40]:
+        dev._add_align(index)
+        host._add_align(index)
+        for ax in (0, 1):
+            a, b = (dev.ref_cache[index], host.ref_cache[index]) if ax == 0 else (dev.tig_cache[index], host.tig_cache[index])
+            assert np.array_equal(a.t.code, b.t.code) and np.array_equal(a.t.len, b.t.len)
+            assert np.array_equal(a.t.begin[0], b.t.begin[0]) and np.array_equal(a.t.begin[1], b.t.begin[1])
+
+
 def test_batched_scan_equals_single(built, gpu_ctx):
     d, lift, scans = load_case(gpu_ctx, 'inv_fwd')
     k_util = KmerUtil(31)
