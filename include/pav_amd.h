@@ -56,7 +56,10 @@ int pav_sync(pav_ctx *ctx);                       /* hipStreamSynchronize on the
  * with str.upper().  Reverse-complemented contigs are never materialised; kernels index them in place.
  */
 int pav_seq_load(pav_ctx *ctx, int role, uint32_t n_seq, const uint8_t *const *ascii, const uint64_t *len);
-int pav_seq_pack(pav_ctx *ctx, int role);         /* re-run the pack kernel on the resident ASCII (bench)  */
+/* Re-run the pack kernel on the resident ASCII.  Asynchronous: it runs on a side stream and overlaps whatever the
+ * next calls queue that does not read the packed planes (CIGAR tokenizer, walk, SNV emission); kernels that do read
+ * them (homology, k-mer kernels) wait for it on the device.  pav_sync() waits for both streams. */
+int pav_seq_pack(pav_ctx *ctx, int role);
 int pav_seq_count(const pav_ctx *ctx, int role, uint32_t *n_seq, uint64_t *total_bases);
 
 /* ---- CIGAR variant calling ---------------------------------------------------------------------------- *

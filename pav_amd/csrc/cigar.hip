@@ -277,6 +277,7 @@ struct WalkArgs {
 // positions and its output slots, so the output order is exactly the reference's (row, op, base) order.
 __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
     __shared__ uint64_t lds[4 * NQ];
+    __shared__ uint32_t s_row0;
     const uint64_t first = (uint64_t)blockIdx.x * WALK_CHUNK + (uint64_t)threadIdx.x * OPS_PER_LANE;
     uint32_t o[OPS_PER_LANE];
     load_ops(A.ops, A.n_ops, first, o);
@@ -291,17 +292,22 @@ __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
     block_excl_scan<NQ>(run, tot, lds);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) run[q] += A.chunk_pre[(uint64_t)blockIdx.x * NQ + q];
-    if (first >= A.n_ops) return;
 
-    // row of this lane's first op: last r with op_off[r] <= first
-    uint32_t lo = 0, hi = A.n_aln;            // invariant: op_off[lo] <= first < op_off[hi]
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (A.op_off[mid] <= first) lo = mid; else hi = mid;
+    // row of this lane's first op: the workgroup's first row is found once (binary search by lane 0), lanes walk on
+    if (threadIdx.x == 0) {
+        const uint64_t f0 = (uint64_t)blockIdx.x * WALK_CHUNK;
+        uint32_t lo = 0, hi = A.n_aln;            // invariant: op_off[lo] <= f0 < op_off[hi]
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (A.op_off[mid] <= f0) lo = mid; else hi = mid;
+        }
+        s_row0 = lo;
     }
-    uint32_t row = lo;
+    __syncthreads();
+    if (first >= A.n_ops) return;
+    uint32_t row = s_row0;
     uint64_t row_end = A.op_off[row + 1];
-    while (row_end <= first && row + 1 < A.n_aln) { ++row; row_end = A.op_off[row + 1]; }   // skip empty rows
+    while (row_end <= first) { ++row; row_end = A.op_off[row + 1]; }      // rows without ops are skipped
     pav_aln al = A.aln[row];
     uint64_t rb_ref = A.rowbase[2ull * row], rb_tig = A.rowbase[2ull * row + 1];
 
@@ -320,8 +326,7 @@ __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
         const int64_t pos_tig = (int64_t)(run[1] - rb_tig);
         const int rev = al.rev != 0;
         if (code == 8) {                                                   // 'X'  cigarcall.py:95-139
-            const uint64_t roff = A.ref.off[al.ref_id], rlen = A.ref.len[al.ref_id];
-            const uint64_t toff = A.tig.off[al.tig_id], tlen = A.tig.len[al.tig_id];
+            const uint64_t tlen = A.tig.len[al.tig_id];
             pav_snv *out = A.snv + run[2];
             for (uint32_t i = 0; i < len; ++i) {
                 pav_snv s;
@@ -329,9 +334,7 @@ __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
                 s.pos = (uint32_t)(pos_ref + i);
                 const int64_t pt = pos_tig + i;
                 s.qry_pos = (uint32_t)(rev ? (int64_t)tlen - pt - 1 : pt);   // cigarcall.py:108-109
-                s.ref = ascii_at(A.ref.ascii, roff, rlen, 0, pos_ref + i);
-                s.alt = ascii_at(A.tig.ascii, toff, tlen, rev, pt);
-                s.pad = 0;
+                s.ref = 0; s.alt = 0; s.pad = 0;                             // bases: snv_bases kernel
                 out[i] = s;
             }
         } else if (code == 1 || code == 2) {                               // 'I' / 'D' stub
@@ -361,6 +364,21 @@ __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
         for (int q = 0; q < NQ; ++q) run[q] += c[q];
         prev = o[j];
     }
+}
+
+// REF / ALT of every SNV row (cigarcall.py:104-105): one lane per record, two independent scattered byte loads.
+// Kept apart from the walk so that no lane serialises a run of cache misses.
+__global__ __launch_bounds__(256) void snv_bases(pav_snv *__restrict__ snv, uint64_t n_snv, const pav_aln *__restrict__ aln,
+                                                 SeqView R, SeqView T) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_snv) return;
+    pav_snv s = snv[i];
+    const pav_aln al = aln[s.aln];
+    const uint8_t r = R.ascii[R.off[al.ref_id] + s.pos];
+    const uint8_t t = T.ascii[T.off[al.tig_id] + s.qry_pos];        // stored contig; complemented when the row is reversed
+    s.ref = r;
+    s.alt = al.rev ? comp_ascii(t) : t;
+    snv[i] = s;
 }
 
 // ---- lift-over tables (pavlib/align/lift.py:380-476) ------------------------------------------------------------
@@ -515,8 +533,10 @@ __device__ __forceinline__ int first_stop(uint64_t a, uint64_t b, uint32_t bad, 
 
 // Shared scan: t is walked from t_pos in direction dir for at most avail bases; seq_sv = sv[sv_pos, sv_pos+svlen)
 // is walked circularly from its last base backwards (dir < 0) or its first base forwards (dir > 0).
+// At most max_steps windows are examined; `done` tells whether the scan ended (mismatch, non-ACGT or edge).
 __device__ uint32_t hom_scan(const SeqRef &t, int64_t t_pos, int dir, int64_t avail, const SeqRef &sv, int64_t sv_pos,
-                             int64_t svlen) {
+                             int64_t svlen, int max_steps, bool &done) {
+    done = true;
     if (svlen <= 0 || avail <= 0) return 0;
     int64_t h = 0;
     if (svlen <= 32) {
@@ -526,7 +546,8 @@ __device__ uint32_t hom_scan(const SeqRef &t, int64_t t_pos, int dir, int64_t av
         const int reps = 32 / L, n = reps * L;
         uint64_t P = pc; uint32_t M = pm;
         for (int r = 1; r < reps; ++r) { P |= pc << (2 * L * r); M |= pm << (L * r); }
-        while (h < avail) {
+        for (int step = 0; h < avail; ++step) {
+            if (step == max_steps) { done = false; return (uint32_t)h; }
             const int m = (int)(avail - h < n ? avail - h : n);
             uint64_t tc; uint32_t tm;
             fetch_run(t, t_pos + dir * h, dir, m, tc, tm);
@@ -537,7 +558,8 @@ __device__ uint32_t hom_scan(const SeqRef &t, int64_t t_pos, int dir, int64_t av
         return (uint32_t)h;
     }
     int64_t idx = dir < 0 ? svlen - 1 : 0;
-    while (h < avail) {
+    for (int step = 0; h < avail; ++step) {
+        if (step == max_steps) { done = false; return (uint32_t)h; }
         const int64_t to_wrap = dir < 0 ? idx + 1 : svlen - idx;
         int64_t mm = avail - h < 32 ? avail - h : 32;
         if (to_wrap < mm) mm = to_wrap;
@@ -554,57 +576,138 @@ __device__ uint32_t hom_scan(const SeqRef &t, int64_t t_pos, int dir, int64_t av
     return (uint32_t)h;
 }
 
+__device__ __forceinline__ int64_t bcast64(int64_t v, int src) { return (int64_t)__shfl((long long)v, src); }
+
+// Wave-cooperative scan.  Every lane first walks its own scan for a few windows (most homologies are short); scans
+// still running (long tandem copies, kilobases) are then finished one at a time by the whole wave, lane c taking
+// the c-th window, so a 5 kb homology costs a handful of steps instead of ~160 dependent ones.
+// Must be called by all 64 lanes; `active` masks lanes without work.  `h0` resumes a scan known to match up to h0.
+__device__ uint32_t wave_hom_scan(bool active, const SeqRef &t, int64_t t_pos, int dir, int64_t avail, const SeqRef &sv,
+                                  int64_t sv_pos, int64_t svlen) {
+    const int lane = threadIdx.x & 63;
+    bool done = true;
+    uint32_t res = 0;
+    if (active) res = hom_scan(t, t_pos, dir, avail, sv, sv_pos, svlen, 3, done);
+    unsigned long long pending = __ballot(active && !done);
+    while (pending) {
+        const int src = __ffsll((long long)pending) - 1;
+        pending &= pending - 1;
+        SeqRef bt{t.two, t.mask, (uint64_t)bcast64((int64_t)t.off, src), (uint64_t)bcast64((int64_t)t.len, src), __shfl(t.rev, src)};
+        SeqRef bs{sv.two, sv.mask, (uint64_t)bcast64((int64_t)sv.off, src), (uint64_t)bcast64((int64_t)sv.len, src), __shfl(sv.rev, src)};
+        // the two planes differ between stores (reference / contig): broadcast the pointers as well
+        bt.two = (const uint32_t *)bcast64((int64_t)t.two, src); bt.mask = (const uint32_t *)bcast64((int64_t)t.mask, src);
+        bs.two = (const uint32_t *)bcast64((int64_t)sv.two, src); bs.mask = (const uint32_t *)bcast64((int64_t)sv.mask, src);
+        const int64_t b_pos = bcast64(t_pos, src), b_avail = bcast64(avail, src), b_svpos = bcast64(sv_pos, src),
+                      b_svlen = bcast64(svlen, src);
+        const int b_dir = __shfl(dir, src);
+        int64_t h = (int64_t)__shfl(res, src);
+        uint64_t P = 0; uint32_t M = 0;
+        int n = 32;
+        const bool periodic = b_svlen <= 32;
+        if (periodic) {
+            const int L = (int)b_svlen;
+            uint64_t pc; uint32_t pm;
+            fetch_run(bs, b_dir < 0 ? b_svpos + b_svlen - 1 : b_svpos, b_dir, L, pc, pm);
+            const int reps = 32 / L;
+            n = reps * L;
+            P = pc; M = pm;
+            for (int r = 1; r < reps; ++r) { P |= pc << (2 * L * r); M |= pm << (L * r); }
+        }
+        int64_t found_at = -1;
+        while (found_at < 0) {
+            const int64_t my_h = h + (int64_t)lane * n;
+            int64_t mm = b_avail - my_h;
+            if (mm > n) mm = n;
+            if (mm < 0) mm = 0;
+            const int m = (int)mm;
+            int st = m;
+            if (m > 0) {
+                uint64_t tc, sc; uint32_t tm, sm;
+                fetch_run(bt, b_pos + b_dir * my_h, b_dir, m, tc, tm);
+                if (periodic) { sc = P; sm = M; }
+                else {
+                    // h is a multiple of... nothing in general: index of the SV base matching scan offset my_h
+                    int64_t idx = b_dir < 0 ? (b_svlen - 1 - (my_h % b_svlen)) : (my_h % b_svlen);
+                    const int64_t to_wrap = b_dir < 0 ? idx + 1 : b_svlen - idx;
+                    const int m1 = (int)(to_wrap < m ? to_wrap : m);
+                    fetch_run(bs, b_svpos + idx, b_dir, m1, sc, sm);
+                    if (m1 < m) {
+                        uint64_t sc2; uint32_t sm2;
+                        fetch_run(bs, b_svpos + (b_dir < 0 ? b_svlen - 1 : 0), b_dir, m - m1, sc2, sm2);
+                        sc |= sc2 << (2 * m1); sm |= sm2 << m1;
+                    }
+                }
+                st = first_stop(tc, sc, tm | sm, m);
+            }
+            const bool stop_here = st < m || m < n;               // mismatch / non-ACGT in my window, or the edge is in it
+            const unsigned long long hit = __ballot(stop_here);
+            if (hit) {
+                const int first = __ffsll((long long)hit) - 1;
+                found_at = bcast64(my_h + st, first);
+            } else {
+                h += 64ll * n;
+            }
+        }
+        if (lane == src) res = (uint32_t)found_at;
+    }
+    return res;
+}
+
 // left_homology(pos_tig, seq_tig, seq_sv)   call.py:542-592: walks upstream from pos while hom_len <= pos_tig
 __device__ __forceinline__ uint32_t left_hom(const SeqRef &t, int64_t pos, const SeqRef &sv, int64_t sv_pos, int64_t svlen) {
-    return hom_scan(t, pos, -1, pos + 1, sv, sv_pos, svlen);
+    bool done;
+    return hom_scan(t, pos, -1, pos + 1, sv, sv_pos, svlen, 0x7FFFFFFF, done);
+}
+__device__ __forceinline__ uint32_t wave_left_hom(bool active, const SeqRef &t, int64_t pos, const SeqRef &sv, int64_t sv_pos, int64_t svlen) {
+    return wave_hom_scan(active, t, pos, -1, pos + 1, sv, sv_pos, svlen);
 }
 
 // right_homology(pos_tig, seq_tig, seq_sv)  call.py:595-647: walks downstream while hom_len < len - pos_tig
 __device__ __forceinline__ uint32_t right_hom(const SeqRef &t, int64_t pos, const SeqRef &sv, int64_t sv_pos, int64_t svlen) {
-    return hom_scan(t, pos, +1, (int64_t)t.len - pos, sv, sv_pos, svlen);
+    bool done;
+    return hom_scan(t, pos, +1, (int64_t)t.len - pos, sv, sv_pos, svlen, 0x7FFFFFFF, done);
+}
+__device__ __forceinline__ uint32_t wave_right_hom(bool active, const SeqRef &t, int64_t pos, const SeqRef &sv, int64_t sv_pos, int64_t svlen) {
+    return wave_hom_scan(active, t, pos, +1, (int64_t)t.len - pos, sv, sv_pos, svlen);
 }
 
-// One lane per INS/DEL stub: left shift + four breakpoint homologies, then the final coordinates.
+// One lane per INS/DEL stub: left shift + four breakpoint homologies, then the final coordinates.  The five scans are
+// wave-uniform calls (long scans are finished cooperatively), so no lane leaves early.
 __global__ __launch_bounds__(256) void homology_kernel(pav_indel *__restrict__ indel, uint64_t n_indel,
                                                        const pav_aln *__restrict__ aln, SeqView R, SeqView T) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_indel) return;
-    pav_indel r = indel[i];
+    const bool active = i < n_indel;
+    pav_indel r = indel[active ? i : 0];
     const pav_aln al = aln[r.aln];
     const int rev = al.rev != 0;
     const SeqRef ref{R.two, R.mask, R.off[al.ref_id], R.len[al.ref_id], 0};
     const SeqRef tig{T.two, T.mask, T.off[al.tig_id], T.len[al.tig_id], rev};
     const int64_t pos_ref = r.pos, pos_tig = r.qry_pos, oplen = r.svlen, tig_len = (int64_t)tig.len;
     const bool ins = r.svtype == 0;
-    const SeqRef &svs = ins ? tig : ref;               // seq = seq_tig[pos_tig:+oplen] / seq_ref[pos_ref:+oplen]
+    const SeqRef svs = ins ? tig : ref;                // seq = seq_tig[pos_tig:+oplen] / seq_ref[pos_ref:+oplen]
     int64_t sv_at = ins ? pos_tig : pos_ref;
-    int64_t shift = 0;
-    if (r.left_shift) {                                // last_op == '=' (cigarcall.py:149-155 / :225-231)
-        const int64_t h = left_hom(ref, pos_ref - 1, svs, sv_at, oplen);
-        shift = h < (int64_t)r.left_shift ? h : (int64_t)r.left_shift;
-    }
+    // last_op == '=' (cigarcall.py:149-155 / :225-231): shift = min(last_oplen, left_homology(pos_ref - 1, REF, SEQ))
+    const uint32_t hs = wave_left_hom(active && r.left_shift != 0, ref, pos_ref - 1, svs, sv_at, oplen);
+    const int64_t shift = r.left_shift ? ((int64_t)hs < (int64_t)r.left_shift ? (int64_t)hs : (int64_t)r.left_shift) : 0;
     const int64_t sv_pos_ref = pos_ref - shift, sv_pos_tig = pos_tig - shift;
+    if (ins && shift) sv_at = sv_pos_tig;              // INS: seq re-sliced at the shifted position (:162-163)
+    // INS: :178-182;  DEL: :247-251
+    const uint32_t h_rl = wave_left_hom(active, ref, sv_pos_ref - 1, svs, sv_at, oplen);
+    const uint32_t h_rr = wave_right_hom(active, ref, ins ? sv_pos_ref : sv_pos_ref + oplen, svs, sv_at, oplen);
+    const uint32_t h_tl = wave_left_hom(active, tig, sv_pos_tig - 1, svs, sv_at, oplen);
+    const uint32_t h_tr = wave_right_hom(active, tig, ins ? sv_pos_tig + oplen : sv_pos_tig, svs, sv_at, oplen);
+    if (!active) return;
+    r.hom_ref_l = h_rl; r.hom_ref_r = h_rr; r.hom_tig_l = h_tl; r.hom_tig_r = h_tr;
     if (ins) {
-        if (shift) sv_at = sv_pos_tig;                 // seq re-sliced at the shifted position (:162-163)
-        r.hom_ref_l = left_hom(ref, sv_pos_ref - 1, svs, sv_at, oplen);             // :178
-        r.hom_ref_r = right_hom(ref, sv_pos_ref, svs, sv_at, oplen);                // :179
-        r.hom_tig_l = left_hom(tig, sv_pos_tig - 1, svs, sv_at, oplen);             // :181
-        r.hom_tig_r = right_hom(tig, sv_pos_tig + oplen, svs, sv_at, oplen);        // :182
         r.pos = (uint32_t)sv_pos_ref; r.end = (uint32_t)(sv_pos_ref + 1);           // :157-158
         if (rev) { r.qry_end = (uint32_t)(tig_len - sv_pos_tig); r.qry_pos = r.qry_end - (uint32_t)oplen; }   // :167-169
         else { r.qry_pos = (uint32_t)sv_pos_tig; r.qry_end = (uint32_t)(sv_pos_tig + oplen); }                // :171-173
     } else {
-        r.hom_ref_l = left_hom(ref, sv_pos_ref - 1, svs, sv_at, oplen);             // :247
-        r.hom_ref_r = right_hom(ref, sv_pos_ref + oplen, svs, sv_at, oplen);        // :248
-        r.hom_tig_l = left_hom(tig, sv_pos_tig - 1, svs, sv_at, oplen);             // :250
-        r.hom_tig_r = right_hom(tig, sv_pos_tig, svs, sv_at, oplen);                // :251
         r.pos = (uint32_t)pos_ref; r.end = (uint32_t)(pos_ref + oplen);             // :258 (un-shifted)
         const int64_t q = rev ? tig_len - sv_pos_tig : sv_pos_tig;                  // :239-242
         r.qry_pos = (uint32_t)q; r.qry_end = (uint32_t)(q + 1);
     }
     r.left_shift = (uint32_t)shift;
-    // SEQ source for the gather kernel: oriented start of the slice (INS: shifted; DEL: un-shifted)
-    r.pad[0] = 0;
     indel[i] = r;
 }
 
@@ -758,7 +861,11 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
         A.snv = ctx->d_snv.as<pav_snv>(); A.indel = ctx->d_indel.as<pav_indel>();
         A.err_op = d_err_op;
         PAV_LAUNCH(ctx, "walk_emit", walk_emit, n_wchunks, 256, 0, A);
+        if (totals[2])
+            PAV_LAUNCH(ctx, "snv_bases", snv_bases, (uint32_t)((totals[2] + 255) / 256), 256, 0, ctx->d_snv.as<pav_snv>(), totals[2],
+                       ctx->d_aln.as<pav_aln>(), A.ref, A.tig);
         if (totals[3]) {
+            { int rcw = wait_planes(ctx); if (rcw != PAV_OK) return rcw; }   // the packed planes may still be in flight
             PAV_LAUNCH(ctx, "homology_kernel", homology_kernel, (uint32_t)((totals[3] + 255) / 256), 256, 0,
                        ctx->d_indel.as<pav_indel>(), totals[3], ctx->d_aln.as<pav_aln>(), A.ref, A.tig);
             if (totals[4])
@@ -956,6 +1063,7 @@ int pav_homology(pav_ctx *ctx, uint32_t n, const pav_hom_query *q, uint32_t *out
     pav_hom_query *dq = ctx->d_tmp.as<pav_hom_query>();
     uint32_t *dout = reinterpret_cast<uint32_t *>(dq + n);
     PAV_HIP(ctx, hipMemcpyAsync(dq, q, sizeof(pav_hom_query) * n, hipMemcpyHostToDevice, ctx->stream));
+    { int rcw = wait_planes(ctx); if (rcw != PAV_OK) return rcw; }
     PAV_LAUNCH(ctx, "homology_query_kernel", homology_query_kernel, (n + 255) / 256, 256, 0, dq, n,
                ctx->seq[PAV_ROLE_REF].view(), ctx->seq[PAV_ROLE_TIG].view(), dout);
     PAV_HIP(ctx, hipMemcpyAsync(out, dout, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, ctx->stream));

@@ -65,6 +65,9 @@ struct ProfPending { int entry; hipEvent_t a, b; };
 struct pav_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;        // side stream: contig re-pack overlaps the tokenizer / walk kernels
+    hipEvent_t pack_done[2] = {nullptr, nullptr};   // recorded after a pack on stream2; consumers of the planes wait on it
+    bool pack_pending[2] = {false, false};
     std::string err;
     char dev_name[256] = {0};
     int n_cu = 0;
@@ -108,9 +111,18 @@ int fail(pav_ctx *ctx, int code, const char *fmt, ...);
     } while (0)
 
 // Profiled launch: records a HIP event pair around the launch on ctx->stream when profiling is on.
-int prof_begin(pav_ctx *ctx, const char *name);
-void prof_end(pav_ctx *ctx, int token);
+int prof_begin(pav_ctx *ctx, const char *name, hipStream_t st = nullptr);
+void prof_end(pav_ctx *ctx, int token, hipStream_t st = nullptr);
+int wait_planes(pav_ctx *ctx);            // make ctx->stream wait for any pack still running on stream2
 int prof_flush(pav_ctx *ctx);
+
+#define PAV_LAUNCH_ON(ctx, st, name, kernel, grid, block, shmem, ...)                               \
+    do {                                                                                           \
+        int tok__ = pav::prof_begin((ctx), name, (st));                                            \
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (shmem), (st), __VA_ARGS__);           \
+        pav::prof_end((ctx), tok__, (st));                                                         \
+        PAV_HIP((ctx), hipGetLastError());                                                         \
+    } while (0)
 
 #define PAV_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                                      \
     do {                                                                                           \

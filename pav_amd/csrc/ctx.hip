@@ -18,7 +18,8 @@ int fail(pav_ctx *ctx, int code, const char *fmt, ...) {
 }
 
 // ---- profiling ------------------------------------------------------------------------------------------
-int prof_begin(pav_ctx *ctx, const char *name) {
+int prof_begin(pav_ctx *ctx, const char *name, hipStream_t st) {
+    if (!st) st = ctx->stream;
     if (!ctx->prof_on) return -1;
     int entry = -1;
     for (size_t i = 0; i < ctx->prof.size(); ++i)
@@ -32,18 +33,25 @@ int prof_begin(pav_ctx *ctx, const char *name) {
         if (hipEventCreate(&a) != hipSuccess) return -1;
         if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return -1; }
     }
-    (void)hipEventRecord(a, ctx->stream);
+    (void)hipEventRecord(a, st);
     ctx->prof_pending.push_back(ProfPending{entry, a, b});
     return (int)ctx->prof_pending.size() - 1;
 }
 
-void prof_end(pav_ctx *ctx, int token) {
+void prof_end(pav_ctx *ctx, int token, hipStream_t st) {
     if (token < 0) return;
-    (void)hipEventRecord(ctx->prof_pending[(size_t)token].b, ctx->stream);
+    (void)hipEventRecord(ctx->prof_pending[(size_t)token].b, st ? st : ctx->stream);
+}
+
+int wait_planes(pav_ctx *ctx) {
+    for (int r = 0; r < 2; ++r)
+        if (ctx->pack_pending[r]) { PAV_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->pack_done[r], 0)); ctx->pack_pending[r] = false; }
+    return PAV_OK;
 }
 
 int prof_flush(pav_ctx *ctx) {
     if (ctx->prof_pending.empty()) return PAV_OK;
+    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream2));
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (auto &p : ctx->prof_pending) {
         float ms = 0.f;
@@ -103,12 +111,12 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint4 *__restrict__ asc
     }
 }
 
-static int run_pack(pav_ctx *ctx, SeqStore &s) {
+static int run_pack(pav_ctx *ctx, SeqStore &s, hipStream_t st) {
     if (s.arena == 0) return PAV_OK;
     const uint64_t n16 = s.arena / 16;
     const uint64_t blocks = (n16 + 256 * PACK_U - 1) / (256 * PACK_U);
-    PAV_LAUNCH(ctx, "pack_kernel", pack_kernel, (uint32_t)blocks, 256, 0, s.d_ascii.as<uint4>(),
-               s.d_two.as<uint32_t>(), s.d_mask.as<uint32_t>(), n16);
+    PAV_LAUNCH_ON(ctx, st, "pack_kernel", pack_kernel, (uint32_t)blocks, 256, 0, s.d_ascii.as<uint4>(),
+                  s.d_two.as<uint32_t>(), s.d_mask.as<uint32_t>(), n16);
     return PAV_OK;
 }
 
@@ -155,7 +163,10 @@ pav_ctx *pav_create(int device_id) {
     ctx->n_cu = prop.multiProcessorCount;
     snprintf(ctx->dev_name, sizeof ctx->dev_name, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, ctx->n_cu);
     if ((e = hipSetDevice(device_id)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+        (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->pack_done[0], hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->pack_done[1], hipEventDisableTiming)) != hipSuccess) {
         fail(nullptr, PAV_E_HIP, "device init: %s", hipGetErrorString(e));
         delete ctx;
         return nullptr;
@@ -168,6 +179,7 @@ void pav_density_release(pav_ctx *ctx);   // density.hip
 void pav_destroy(pav_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream2);
     (void)hipStreamSynchronize(ctx->stream);
     pav_density_release(ctx);
     for (auto &p : ctx->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -182,6 +194,9 @@ void pav_destroy(pav_ctx *ctx) {
                       &ctx->ix_chunk, &ctx->ix_chunk2, &ctx->ix_rowbase, &ctx->ix_begin, &ctx->ix_err};
     for (DevBuf *b : bufs) b->release();
     (void)hipStreamDestroy(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream2);
+    (void)hipEventDestroy(ctx->pack_done[0]);
+    (void)hipEventDestroy(ctx->pack_done[1]);
     delete ctx;
 }
 
@@ -194,6 +209,7 @@ int pav_device_name(const pav_ctx *ctx, char *buf, int buf_len) {
 int pav_sync(pav_ctx *ctx) {
     if (!ctx) return PAV_E_ARG;
     PAV_HIP(ctx, hipSetDevice(ctx->device));
+    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream2));
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PAV_OK;
 }
@@ -202,6 +218,9 @@ int pav_seq_load(pav_ctx *ctx, int role, uint32_t n_seq, const uint8_t *const *a
     if (!ctx || (role != PAV_ROLE_REF && role != PAV_ROLE_TIG)) return fail(ctx, PAV_E_ARG, "pav_seq_load: bad role");
     if (n_seq && (!ascii || !len)) return fail(ctx, PAV_E_ARG, "pav_seq_load: null input");
     PAV_HIP(ctx, hipSetDevice(ctx->device));
+    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream2));   // a re-pack of the old arena may still be running
+    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pack_pending[role] = false;
     SeqStore &s = ctx->seq[role];
     s.n = n_seq;
     s.off.assign(n_seq, 0);
@@ -230,7 +249,7 @@ int pav_seq_load(pav_ctx *ctx, int role, uint32_t n_seq, const uint8_t *const *a
                                         ctx->stream));
     PAV_HIP(ctx, hipMemcpyAsync(s.d_off.p, s.off.data(), sizeof(uint64_t) * n_seq, hipMemcpyHostToDevice, ctx->stream));
     PAV_HIP(ctx, hipMemcpyAsync(s.d_len.p, s.len.data(), sizeof(uint64_t) * n_seq, hipMemcpyHostToDevice, ctx->stream));
-    int rc = run_pack(ctx, s);
+    int rc = run_pack(ctx, s, ctx->stream);
     if (rc != PAV_OK) return rc;
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));   // inputs are borrowed only for the duration of the call
     if (role == PAV_ROLE_TIG || role == PAV_ROLE_REF) { ctx->cigar_called = false; }
@@ -240,7 +259,16 @@ int pav_seq_load(pav_ctx *ctx, int role, uint32_t n_seq, const uint8_t *const *a
 int pav_seq_pack(pav_ctx *ctx, int role) {
     if (!ctx || (role != PAV_ROLE_REF && role != PAV_ROLE_TIG)) return fail(ctx, PAV_E_ARG, "pav_seq_pack: bad role");
     PAV_HIP(ctx, hipSetDevice(ctx->device));
-    return run_pack(ctx, ctx->seq[role]);
+    // Asynchronous on the side stream: everything queued so far on the main stream may still read the old planes, so
+    // the pack first waits for the main stream; consumers of the planes wait for pack_done (pav::wait_planes).
+    hipEvent_t *ev = &ctx->pack_done[role];
+    PAV_HIP(ctx, hipEventRecord(*ev, ctx->stream));
+    PAV_HIP(ctx, hipStreamWaitEvent(ctx->stream2, *ev, 0));
+    int rc = run_pack(ctx, ctx->seq[role], ctx->stream2);
+    if (rc != PAV_OK) return rc;
+    PAV_HIP(ctx, hipEventRecord(*ev, ctx->stream2));
+    ctx->pack_pending[role] = true;
+    return PAV_OK;
 }
 
 int pav_seq_count(const pav_ctx *ctx, int role, uint32_t *n_seq, uint64_t *total_bases) {

@@ -697,6 +697,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     const SeqView RV = RS.view(), TV = TS.view();
 
     // ---- k-mer states and compaction -------------------------------------------------------------------------
+    { int rcw = wait_planes(ctx); if (rcw != PAV_OK) return rcw; }
     PAV_LAUNCH(ctx, "k_ref_insert", k_ref_insert, (uint32_t)(a_r / 256), 256, 0, d_jobs, d_tjr, RV, k, pp->max_ref_kmer_count,
                d_keys, D->cnt.as<uint32_t>(), D->first.as<uint32_t>(), d_stat);
     PAV_LAUNCH(ctx, "k_tig_state", k_tig_state, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, TV, k, d_keys,
@@ -941,6 +942,7 @@ int pav_density_annotate(pav_ctx *ctx, uint32_t job, uint32_t ref_id, uint64_t r
     unsigned long long *k_up = D->scratch.as<unsigned long long>(), *k_dn = k_up + cap_up;
     uint8_t *d_flank = reinterpret_cast<uint8_t *>(k_dn + cap_dn), *d_match = d_flank + n;
     PAV_HIP(ctx, hipMemsetAsync(k_up, 0xFF, 8ull * (cap_up + cap_dn), st));
+    { int rcw = wait_planes(ctx); if (rcw != PAV_OK) return rcw; }
     const SeqView RV = RS.view();
     if (up_len >= (uint32_t)k)
         PAV_LAUNCH(ctx, "k_canon_insert", k_canon_insert, (up_len + 255) / 256, 256, 0, RV, RS.off[ref_id] + ref_up_pos, up_len, k, k_up, cap_up - 1);

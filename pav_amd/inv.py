@@ -48,9 +48,21 @@ class InvCall:
         self.region_ref_discovery = region_ref_discovery
         self.region_tig_discovery = region_tig_discovery
         self.region_flag = region_flag
-        self.df = df
+        self._df = df                       # DataFrame, or a zero-argument builder evaluated on first access
         self.svlen = len(region_ref_outer)
         self.id = '{}-{}-INV-{}'.format(region_ref_outer.chrom, region_ref_outer.pos + 1, self.svlen)
+
+    @property
+    def df(self):
+        """Density table (INDEX, STATE_MER, STATE, KERN_*, KMER, FLANK, MATCH).  The columns are copied off the device
+        when the call is made; the DataFrame itself is assembled on first access."""
+        if callable(self._df):
+            self._df = self._df()
+        return self._df
+
+    @df.setter
+    def df(self, value):
+        self._df = value
 
     def __repr__(self):
         return self.id
@@ -266,18 +278,30 @@ class _Scan:
         # density table + INV-DUP annotation (inv.py:440-442, 457-561)
         res_rows = self.n_rows
         cols = ctx.density_table(job, res_rows)
-        extra = _flank_match_columns(res_rows, region_ref_outer, region_ref_inner, region_tig_outer, region_tig_inner,
-                                     region_ref, ctx, job, self.ref_index)
-        df = density.table_frame(cols, finalised=True, extra=extra)
+        codes = _flank_match_codes(res_rows, region_ref_outer, region_ref_inner, region_tig_outer, region_tig_inner,
+                                   region_ref, ctx, job, self.ref_index)
+
+        def df():
+            return density.table_frame(cols, finalised=True, extra=_flank_match_text(*codes))
         inv_call = InvCall(region_ref_outer, region_ref_inner, region_tig_outer, region_tig_inner, region_ref, region_tig,
                            self.region_flag, df)
         _write_log('Found inversion: {}'.format(inv_call), log)
         return self._finish(inv_call)
 
 
-def _flank_match_columns(n_rows, region_ref_outer, region_ref_inner, region_tig_outer, region_tig_inner,
-                         region_tig_discovery, ctx, job, ref_index):
-    """FLANK / MATCH of pavlib/inv.py:480-555 for the table resident on the device as ``job``."""
+def _flank_match_text(flank, match):
+    m = _MATCH_TEXT[match]
+    m[match == 3] = np.nan                                             # 'NA' -> NaN (inv.py:555)
+    return {'FLANK': _FLANK_TEXT[flank], 'MATCH': m}
+
+
+def _flank_match_columns(*args):
+    return _flank_match_text(*_flank_match_codes(*args))
+
+
+def _flank_match_codes(n_rows, region_ref_outer, region_ref_inner, region_tig_outer, region_tig_inner,
+                       region_tig_discovery, ctx, job, ref_index):
+    """FLANK / MATCH codes of pavlib/inv.py:480-555 for the table resident on the device as ``job``."""
     region_dup_ref_up = seq.Region(region_ref_outer.chrom, region_ref_outer.pos, region_ref_inner.pos)
     region_dup_ref_dn = seq.Region(region_ref_outer.chrom, region_ref_inner.end, region_ref_outer.end)
     region_dup_tig_up = seq.Region(region_tig_outer.chrom, region_tig_outer.pos, region_tig_inner.pos)
@@ -287,9 +311,7 @@ def _flank_match_columns(n_rows, region_ref_outer, region_ref_inner, region_tig_
         (region_dup_ref_up.pos, region_dup_ref_up.end), (region_dup_ref_dn.pos, region_dup_ref_dn.end),
         int(region_tig_discovery.pos),
         (region_dup_tig_up.pos, region_dup_tig_up.end), (region_dup_tig_dn.pos, region_dup_tig_dn.end))
-    m = _MATCH_TEXT[match]
-    m[match == 3] = np.nan                                             # 'NA' -> NaN (inv.py:555)
-    return {'FLANK': _FLANK_TEXT[flank], 'MATCH': m}
+    return flank, match
 
 
 def annotate_inv_dup_mers(df, region_ref_outer, region_ref_inner, region_tig_outer, region_tig_inner,

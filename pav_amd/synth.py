@@ -185,7 +185,8 @@ def _plan_segments(rng, L, median, sigma, cap, zones=(), gap_min=1_000, gap_max=
 
 def make_haplotype(ref, seed, hap='h1', snv_rate=1.0e-3, indel_rate=2.0e-4, pareto_alpha=1.2, max_indel=5000,
                    tandem_frac=0.5, clip=100, seg_median=1_000_000, seg_sigma=1.4, seg_cap=150_000_000,
-                   rev_frac=0.5, decoys_per_inv=9, min_decoys=0, flag_batches=60, threads=8, segments=None):
+                   rev_frac=0.5, decoys_per_inv=9, min_decoys=0, flag_batches=60, threads=8, segments=None,
+                   zone_factor=3, zone_pad=20_000):
     """One haplotype: contigs, alignment BEDs (trim-none and trim-tigref) and flagged regions."""
     lib = _lib()
     rng = np.random.default_rng(seed)
@@ -196,8 +197,8 @@ def make_haplotype(ref, seed, hap='h1', snv_rate=1.0e-3, indel_rate=2.0e-4, pare
     for n in ref.names:
         L = ref.seqs[n].shape[0]
         invs = [v for v in ref.inversions if v.chrom == n]
-        zones = [(max(0, v.pos - 3 * (v.end - v.pos) - 20_000), min(L, v.end + 3 * (v.end - v.pos) + 20_000))
-                 for v in invs]
+        zones = [(max(0, v.pos - zone_factor * (v.end - v.pos) - zone_pad),
+                  min(L, v.end + zone_factor * (v.end - v.pos) + zone_pad)) for v in invs]
         segs = segments[n] if segments is not None and n in segments else \
             _plan_segments(rng, L, seg_median, seg_sigma, seg_cap, zones)
         for s, e in segs:

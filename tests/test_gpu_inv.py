@@ -17,7 +17,7 @@ from pav_amd.kmer import KmerUtil
 
 pytestmark = pytest.mark.gpu
 GOLD = util.GOLD
-INV_CASES = ['inv_fwd', 'inv_rev', 'inv_small', 'inv_limits', 'inv_nolift']
+INV_CASES = ['inv_fwd', 'inv_rev', 'inv_small', 'inv_limits', 'inv_nolift', 'inv_hap']
 KERN = ('KERN_FWD', 'KERN_FWDREV', 'KERN_REV')
 RTOL = 1e-11      # KERN_* tolerance vs the reference: device exp() and np.cov's summation order
 
@@ -167,6 +167,35 @@ def test_batched_scan_equals_single(built, gpu_ctx):
             assert call is None
         else:
             check_call(d, rec, call)
+
+
+def test_rule_call_inv_batch_haplotype(built, gpu_ctx, tmp_path):
+    """Multi-row haplotype (reverse rows, inverted repeats, N run, decoys) through the rule mirror in lock-step batches:
+    the merged INV BED equals the reference's rows and the log equals the sequential reference log."""
+    d, lift, scans = load_case(gpu_ctx, 'inv_hap')
+    beds, logs = [], []
+    for batch in (0, 1):
+        out, lg = str(tmp_path / f'inv_call_{batch}.bed.gz'), str(tmp_path / f'inv_call_{batch}.log')
+        rules.call_inv_batch(os.path.join(d, 'flag.tsv'), os.path.join(d, 'align.tsv'), os.path.join(d, 'tig.fa'),
+                             os.path.join(d, 'tig.fa.fai'), os.path.join(d, 'ref.fa'), 'h1', batch, bed_out=out, log_path=lg,
+                             density_out_dir=str(tmp_path / 'density'), ctx=gpu_ctx)
+        beds.append(out)
+        logs.append(lg)
+    df = rules.call_inv_batch_merge(beds)
+    expect = [rec['call']['bed_row'] for rec in scans if rec['call'] is not None]
+    assert sorted(df['ID']) == sorted(r['ID'] for r in expect)
+    got = {r['ID']: r for _, r in df.iterrows()}
+    for row in expect:
+        for k, v in row.items():
+            assert str(got[row['ID']][k]) == str(v), (row['ID'], k)
+    flag = pd.read_csv(os.path.join(d, 'flag.tsv'), sep='\t')
+    for batch in (0, 1):
+        want = []
+        for (_, f), rec in zip(flag.iterrows(), scans):
+            if f['BATCH'] == batch:
+                want.extend(rec['log'])
+        with open(logs[batch]) as fh:
+            assert fh.read().splitlines() == want
 
 
 def test_rule_call_inv_batch_files(built, gpu_ctx, tmp_path):

@@ -17,7 +17,7 @@ from pav_amd.fasta import open_fasta, read_fai
 from pav_amd.kmer import KmerUtil
 
 GOLD = util.GOLD
-INV_CASES = ['inv_fwd', 'inv_rev', 'inv_small', 'inv_limits', 'inv_nolift']
+INV_CASES = ['inv_fwd', 'inv_rev', 'inv_small', 'inv_limits', 'inv_nolift', 'inv_hap']
 
 
 def sha(a):

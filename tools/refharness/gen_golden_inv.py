@@ -327,5 +327,26 @@ def main():
     print('region_kat', len(rk))
 
 
+def hap_case():
+    """6. A small multi-chromosome haplotype (several alignment rows, reverse rows, inverted repeats, decoys):
+    every flagged region scanned by the reference - the batched-scan parity case."""
+    ref = synth.make_reference(77, {'chr1': 260_000, 'chr2': 200_000, 'chr10': 160_000}, n_every=0, inv_every=0, threads=1)
+    plan = [('chr1', 40_000, 52_000, 1_000), ('chr1', 150_000, 153_500, 0), ('chr2', 60_000, 95_000, 2_500),
+            ('chr10', 30_000, 36_000, 600), ('chr10', 100_000, 124_000, 0)]
+    for c, p, e, rep in plan:
+        s = ref.seqs[c]
+        if rep:
+            s[e - rep:e] = synth.revcomp(s[p:p + rep])
+        ref.inversions.append(synth.Inversion(c, p, e, rep))
+    ref.seqs['chr2'][150_000:153_000] = ord('N')
+    hap = synth.make_haplotype(ref, 77 * 64, 'h1', seg_median=70_000, seg_sigma=0.5, rev_frac=0.5, threads=1,
+                               decoys_per_inv=2, zone_factor=1, zone_pad=9_000)
+    flags = [(r['#CHROM'], int(r['POS']), int(r['END']), r['TYPE'], None) for _, r in hap.df_flag.iterrows()]
+    print('  inv_hap: rows', hap.df_align.shape[0], 'planted', hap.stats['n_inv'], 'flagged', len(flags))
+    run_case('inv_hap', ref, hap, flags)
+
+
 if __name__ == '__main__':
-    main()
+    if os.environ.get('PAV_GOLDEN_ONLY', '') != 'hap':
+        main()
+    hap_case()
