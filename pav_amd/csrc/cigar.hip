@@ -28,8 +28,8 @@ __device__ __forceinline__ int op_code_of(uint32_t c) {
 }
 
 // ---- block-wide exclusive scan of N u64 values per lane (256 lanes = 4 waves) ------------------------------
-template <int N>
-__device__ __forceinline__ void block_excl_scan(uint64_t (&v)[N], uint64_t (&total)[N], uint64_t *lds /* 4*N */) {
+template <int N, int NW = 4>
+__device__ __forceinline__ void block_excl_scan(uint64_t (&v)[N], uint64_t (&total)[N], uint64_t *lds /* NW*N */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t inc[N];
 #pragma unroll
@@ -48,7 +48,7 @@ __device__ __forceinline__ void block_excl_scan(uint64_t (&v)[N], uint64_t (&tot
     for (int q = 0; q < N; ++q) {
         uint64_t base = 0, tot = 0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < NW; ++w) {
             uint64_t s = lds[w * N + q];
             if (w < wave) base += s;
             tot += s;
@@ -101,35 +101,47 @@ __global__ __launch_bounds__(256) void scan_counts(const uint32_t *__restrict__ 
 __global__ __launch_bounds__(256) void tok_emit(const uint8_t *__restrict__ text, const uint64_t *__restrict__ chunk_pre,
                                                 uint32_t *__restrict__ ops, unsigned long long *__restrict__ tok_err) {
     __shared__ uint64_t lds[4];
-    const uint64_t p0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    __shared__ __attribute__((aligned(16))) uint8_t s_txt[32 + TOK_CHUNK];   // 32 B halo: digits of a token that starts
+    const uint64_t b0 = (uint64_t)blockIdx.x * TOK_CHUNK;                     // in the previous workgroup's text
+    const uint64_t p0 = b0 + (uint64_t)threadIdx.x * 16;
     const uint4 v = *reinterpret_cast<const uint4 *>(text + p0);
+    *reinterpret_cast<uint4 *>(s_txt + 32 + threadIdx.x * 16) = v;
+    if (threadIdx.x < 2) {
+        uint4 h = make_uint4(0x2a2a2a2a, 0x2a2a2a2a, 0x2a2a2a2a, 0x2a2a2a2a);     // '*': not a digit
+        if (blockIdx.x > 0) h = *reinterpret_cast<const uint4 *>(text + b0 - 32 + threadIdx.x * 16);
+        *reinterpret_cast<uint4 *>(s_txt + threadIdx.x * 16) = h;
+    }
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
     uint32_t flags = 0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) flags |= (uint32_t)!is_digit((w[j >> 2] >> (8 * (j & 3))) & 0xFFu) << j;
     uint64_t cnt[1] = {(uint64_t)__popc(flags)}, tot[1];
-    block_excl_scan<1>(cnt, tot, lds);
+    block_excl_scan<1>(cnt, tot, lds);                  // its barriers also publish s_txt
     uint64_t ord = chunk_pre[blockIdx.x] + cnt[0];
     while (flags) {
         const int j = __ffs((int)flags) - 1;
         flags &= flags - 1;
-        const uint64_t p = p0 + (uint64_t)j;
-        const uint32_t ch = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-        // digits in front of the op character (never more than 19 are read)
+        const int lp = 32 + (int)threadIdx.x * 16 + j;  // position of the op character in s_txt
+        const uint32_t ch = s_txt[lp];
+        // digits in front of the op character (never more than 19 contribute)
         uint64_t val = 0, mul = 1;
         int nd = 0;
         bool over = false;
-        int64_t q = (int64_t)p - 1;
-        while (q >= 0 && is_digit(text[q])) {
-            if (nd < 18) { val += (uint64_t)(text[q] - '0') * mul; mul *= 10; } else if (text[q] != '0') over = true;
+        int q = lp - 1;
+        while (q >= 0 && is_digit(s_txt[q])) {
+            if (nd < 18) { val += (uint64_t)(s_txt[q] - '0') * mul; mul *= 10; } else if (s_txt[q] != '0') over = true;
             ++nd; --q;
         }
+        int64_t g = (int64_t)b0 - 32 + q;               // global position of the first non-digit before the token
+        if (q < 0 && blockIdx.x > 0) {                  // more than 32 + j digits: keep walking in global memory
+            while (g >= 0 && is_digit(text[g])) { if (text[g] != '0') over = true; ++nd; --g; }
+        } else if (q < 0) g = -1;
         const int code = op_code_of(ch);
         int kind = 0;
         if (nd == 0) kind = PAV_CIGAR_ERR_MISSING_LEN;              // align.py:310 (checked before the op set)
         else if (code < 0) kind = PAV_CIGAR_ERR_UNKNOWN_OP;         // align.py:315
         else if (over || val >= (1ull << 28)) kind = PAV_CIGAR_ERR_LEN_OVERFLOW;
-        if (kind) atomicMin(tok_err, (unsigned long long)(((uint64_t)(q + 1)) << 3 | (uint64_t)kind));
+        if (kind) atomicMin(tok_err, (unsigned long long)(((uint64_t)(g + 1)) << 3 | (uint64_t)kind));
         ops[ord] = kind ? 0x7u /* 0= : harmless */ : ((uint32_t)val << 4 | (uint32_t)code);
         ++ord;
     }
@@ -711,7 +723,8 @@ __global__ __launch_bounds__(256) void homology_kernel(pav_indel *__restrict__ i
     indel[i] = r;
 }
 
-// SEQ blob: one lane per output byte; the owning record is found by binary search on seq_off.
+// SEQ blob (cigarcall.py:145,163,221): one lane per output byte (coalesced stores); the owning record is found by
+// binary search on seq_off.  (A lane-per-record variant with cooperative long copies measured 30 % slower.)
 __global__ __launch_bounds__(256) void seq_gather(const pav_indel *__restrict__ indel, uint64_t n_indel,
                                                   const pav_aln *__restrict__ aln, SeqView R, SeqView T,
                                                   uint8_t *__restrict__ blob, uint64_t n_bytes) {
@@ -726,12 +739,12 @@ __global__ __launch_bounds__(256) void seq_gather(const pav_indel *__restrict__ 
     const pav_aln al = aln[r.aln];
     const int64_t k = (int64_t)(b - r.seq_off);
     uint8_t c;
-    if (r.svtype == 0) {                               // INS: seq_tig[sv_pos_tig : +oplen]  (cigarcall.py:145,163)
+    if (r.svtype == 0) {                               // INS: seq_tig[sv_pos_tig : +oplen]
         const int rev = al.rev != 0;
         const uint64_t tlen = T.len[al.tig_id];
         const int64_t sv_pos_tig = rev ? (int64_t)tlen - (int64_t)r.qry_end : (int64_t)r.qry_pos;
         c = ascii_at(T.ascii, T.off[al.tig_id], tlen, rev, sv_pos_tig + k);
-    } else {                                           // DEL: seq_ref[pos_ref : +oplen]      (cigarcall.py:221)
+    } else {                                           // DEL: seq_ref[pos_ref : +oplen]
         c = R.ascii[R.off[al.ref_id] + r.pos + (uint64_t)k];
     }
     blob[b] = c;

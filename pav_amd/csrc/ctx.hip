@@ -162,9 +162,12 @@ pav_ctx *pav_create(int device_id) {
     ctx->device = device_id;
     ctx->n_cu = prop.multiProcessorCount;
     snprintf(ctx->dev_name, sizeof ctx->dev_name, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, ctx->n_cu);
+    int prio_lo = 0, prio_hi = 0;
     if ((e = hipSetDevice(device_id)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi)) != hipSuccess ||
+        // main stream = highest priority: its short dependent kernels must not queue behind the streaming pack
+        (e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_hi)) != hipSuccess ||
+        (e = hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_lo)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->pack_done[0], hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->pack_done[1], hipEventDisableTiming)) != hipSuccess) {
         fail(nullptr, PAV_E_HIP, "device init: %s", hipGetErrorString(e));
