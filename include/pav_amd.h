@@ -233,6 +233,75 @@ int pav_density_annotate(pav_ctx *ctx, uint32_t job, uint32_t ref_id, uint64_t r
 uint64_t pav_kmer_rev_complement(uint64_t kmer, int k);
 uint64_t pav_kmer_canonical(uint64_t kmer, int k);
 
+/* ---- batched inversion scan (native driver) ----------------------------------------------------------------- *
+ * Replaces the per-region loop of rule call_inv_batch (rules/call_inv.snakefile:185-200) around
+ * pavlib.inv.scan_for_inv (pavlib/inv.py:149-454): flagged regions advance in lock-step, every scan iteration is one
+ * pav_density_batch call; lift-over (pavlib/align/lift.py), region expansion (pavlib/seq.py:112-188), the stop /
+ * expand rules, breakpoint regions, size checks and annotate_inv_dup_mers are done inside the library.  Log lines
+ * and errors are the reference's, byte for byte.  pav_amd/inv.py holds the same state machine in Python (used when
+ * a foreign AlignLift object or an N-tree is passed); both are tested against the reference's golden vectors. */
+typedef struct {            /* one row of the trim-tigref alignment BED (AlignLift input, lift.py:20-49)            */
+    uint32_t ref_id, tig_id;
+    uint64_t pos, end;      /* POS, END                                                                            */
+    uint64_t qry_pos, qry_end;   /* QRY_POS, QRY_END                                                               */
+    uint32_t rev;           /* REV                                                                                 */
+    uint32_t pad;
+    int64_t index;          /* INDEX                                                                               */
+} pav_inv_aln;
+
+typedef struct { uint32_t ref_id; uint32_t pad; uint64_t pos, end; } pav_inv_region;   /* flagged region (BED)     */
+typedef struct { double begin, end; uint32_t value; uint32_t pad; } pav_srs;      /* state-run-smooth interval     */
+
+typedef struct {
+    int64_t max_region_size;        /* MAX_REGION_SIZE / inv_region_limit; 0 = unlimited (inv.py:226)               */
+    int32_t min_exp_count;          /* inv_min_expand / DEFAULT_MIN_EXP_COUNT (inv.py:297)                          */
+    uint32_t n_srs;                 /* get_srs_tree intervals (inv.py:564-620)                                      */
+    const pav_srs *srs;
+    pav_den_params den;
+} pav_inv_params;
+
+typedef struct {            /* pavlib.seq.Region as the scan reports it                                            */
+    uint32_t seq_id;        /* record in the REF store (ref_*) or the TIG store (tig_*)                            */
+    uint32_t is_rev;
+    uint64_t pos, end;
+    uint32_t n_aln[2];      /* entries of pos_aln_index / end_aln_index (1, or 2 after a gap lift)                 */
+    int64_t aln_index[2][2];
+} pav_inv_rgn;
+
+enum { PAV_INV_NONE = 0, PAV_INV_CALL = 1, PAV_INV_ERROR = 2 };   /* None / InvCall / RuntimeError               */
+
+typedef struct {
+    int32_t outcome;
+    uint32_t found;         /* 1 when 'INV Found: ...' is printed (inv.py:408), even if a size check then rejects  */
+    uint32_t iterations;
+    uint32_t n_rows;        /* density table rows of the call                                                      */
+    uint64_t svlen;
+    pav_inv_rgn ref_outer, ref_inner, tig_outer, tig_inner, ref_discovery, tig_discovery;
+    uint32_t log_bytes, error_bytes;
+} pav_inv_result;
+
+int pav_seq_set_names(pav_ctx *ctx, int role, uint32_t n, const char *const *names);   /* record names for log text */
+int pav_inv_load_alignments(pav_ctx *ctx, uint32_t n, const pav_inv_aln *aln, const uint8_t *cigar_text,
+                            const uint64_t *cigar_off);
+int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *regions, const pav_inv_params *params,
+                       pav_inv_result *results);
+/* what 0: the region's log lines (log_bytes + 1 buffer); what 1: the RuntimeError text (error_bytes + 1). */
+int pav_inv_text(pav_ctx *ctx, uint32_t region, int what, char *buf, uint32_t buf_len);
+/* Density table of a call incl. FLANK (0 '' / 1 UP / 2 DN) and MATCH (0 '' / 1 SAME / 2 OTHER / 3 NaN). */
+int pav_inv_table(pav_ctx *ctx, uint32_t region, int64_t *index, int8_t *state_mer, int8_t *state, double *kern_fwd,
+                  double *kern_fwdrev, double *kern_rev, uint64_t *kmer, uint8_t *flank, uint8_t *match);
+
+/* Zero-copy access: pointers to the library's pinned host copy of a call's table (INDEX as uint32).  Valid until the
+ * next pav_inv_scan_batch / pav_destroy on this context. */
+int pav_inv_table_view(pav_ctx *ctx, uint32_t region, uint32_t *n_rows, const uint32_t **index, const int8_t **state_mer,
+                       const int8_t **state, const double **kern_fwd, const double **kern_fwdrev, const double **kern_rev,
+                       const uint64_t **kmer, const uint8_t **flank, const uint8_t **match);
+/* All call tables of the last scan at once: rows of region i are written at row_off[i] of every column (regions without
+ * a call are skipped); the caller sizes the columns as the sum of n_rows. */
+int pav_inv_tables(pav_ctx *ctx, uint32_t n_regions, const uint64_t *row_off, int64_t *index, int8_t *state_mer,
+                   int8_t *state, double *kern_fwd, double *kern_fwdrev, double *kern_rev, uint64_t *kmer, uint8_t *flank,
+                   uint8_t *match);
+
 /* ---- profiling ---------------------------------------------------------------------------------------- *
  * HIP-event timing of every kernel the library launches on its stream (bench.py's roofline leg).         */
 int pav_prof_enable(pav_ctx *ctx, int on);

@@ -61,6 +61,41 @@ class DenResult(ctypes.Structure):
                 ('n_eval', ctypes.c_uint64), ('h', ctypes.c_double * 3)]
 
 
+class InvAln(ctypes.Structure):
+    _fields_ = [('ref_id', ctypes.c_uint32), ('tig_id', ctypes.c_uint32), ('pos', ctypes.c_uint64), ('end', ctypes.c_uint64),
+                ('qry_pos', ctypes.c_uint64), ('qry_end', ctypes.c_uint64), ('rev', ctypes.c_uint32), ('pad', ctypes.c_uint32),
+                ('index', ctypes.c_int64)]
+
+
+INV_ALN_DTYPE = np.dtype([('ref_id', '<u4'), ('tig_id', '<u4'), ('pos', '<u8'), ('end', '<u8'), ('qry_pos', '<u8'),
+                          ('qry_end', '<u8'), ('rev', '<u4'), ('pad', '<u4'), ('index', '<i8')])
+INV_REGION_DTYPE = np.dtype([('ref_id', '<u4'), ('pad', '<u4'), ('pos', '<u8'), ('end', '<u8')])
+assert INV_ALN_DTYPE.itemsize == 56 and INV_REGION_DTYPE.itemsize == 24
+
+
+class Srs(ctypes.Structure):
+    _fields_ = [('begin', ctypes.c_double), ('end', ctypes.c_double), ('value', ctypes.c_uint32), ('pad', ctypes.c_uint32)]
+
+
+class InvParams(ctypes.Structure):
+    _fields_ = [('max_region_size', ctypes.c_int64), ('min_exp_count', ctypes.c_int32), ('n_srs', ctypes.c_uint32),
+                ('srs', ctypes.POINTER(Srs)), ('den', DenParams)]
+
+
+class InvRgn(ctypes.Structure):
+    _fields_ = [('seq_id', ctypes.c_uint32), ('is_rev', ctypes.c_uint32), ('pos', ctypes.c_uint64), ('end', ctypes.c_uint64),
+                ('n_aln', ctypes.c_uint32 * 2), ('aln_index', (ctypes.c_int64 * 2) * 2)]
+
+
+class InvResult(ctypes.Structure):
+    _fields_ = [('outcome', ctypes.c_int32), ('found', ctypes.c_uint32), ('iterations', ctypes.c_uint32),
+                ('n_rows', ctypes.c_uint32), ('svlen', ctypes.c_uint64),
+                ('ref_outer', InvRgn), ('ref_inner', InvRgn), ('tig_outer', InvRgn), ('tig_inner', InvRgn),
+                ('ref_discovery', InvRgn), ('tig_discovery', InvRgn), ('log_bytes', ctypes.c_uint32),
+                ('error_bytes', ctypes.c_uint32)]
+
+
+INV_NONE, INV_CALL, INV_ERROR = 0, 1, 2
 RUN_DTYPE = np.dtype([('state', '<i4'), ('count', '<u4'), ('pos', '<i8'), ('end', '<i8')])
 DEN_OK, DEN_UNFINALISED, DEN_FAIL = 0, 1, 125
 KDE_RUNS, KDE_DIRECT = 0, 1
@@ -97,6 +132,13 @@ SYMBOLS = {
     'pav_density_annotate': (ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64,
                                             ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64,
                                             ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _P, _P]),
+    'pav_seq_set_names': (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_uint32, _P]),
+    'pav_inv_load_alignments': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P]),
+    'pav_inv_scan_batch': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P]),
+    'pav_inv_text': (ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_int, ctypes.c_char_p, ctypes.c_uint32]),
+    'pav_inv_table': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'pav_inv_table_view': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'pav_inv_tables': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'pav_kmer_rev_complement': (ctypes.c_uint64, [ctypes.c_uint64, ctypes.c_int]),
     'pav_kmer_canonical': (ctypes.c_uint64, [ctypes.c_uint64, ctypes.c_int]),
     'pav_prof_enable': (ctypes.c_int, [_P, ctypes.c_int]),
@@ -210,6 +252,8 @@ class Context:
         lens = (ctypes.c_uint64 * max(n, 1))(*[a.shape[0] for a in arrays])
         self._check(self.lib.pav_seq_load(self.handle, role, n, ptrs, lens), 'pav_seq_load')
         self._seq_names[role] = [str(x) for x in names]
+        cnames = (ctypes.c_char_p * max(n, 1))(*[x.encode() for x in self._seq_names[role]])
+        self._check(self.lib.pav_seq_set_names(self.handle, role, n, cnames), 'pav_seq_set_names')
 
     def seq_pack(self, role):
         self._check(self.lib.pav_seq_pack(self.handle, role), 'pav_seq_pack')
@@ -313,6 +357,80 @@ class Context:
             tig_dn[0], tig_dn[1], _ptr(flank) or ctypes.c_void_p(flank.ctypes.data),
             _ptr(match) or ctypes.c_void_p(match.ctypes.data)), 'pav_density_annotate')
         return flank, match
+
+    # -- native batched inversion scan -------------------------------------------------------------------------
+    def inv_load_alignments(self, aln, cigar_text, cigar_off):
+        aln = np.ascontiguousarray(aln, dtype=INV_ALN_DTYPE)
+        cigar_text = np.ascontiguousarray(cigar_text, dtype=np.uint8)
+        cigar_off = np.ascontiguousarray(cigar_off, dtype=np.uint64)
+        rc = self.lib.pav_inv_load_alignments(self.handle, aln.shape[0], _ptr(aln), _ptr(cigar_text),
+                                              ctypes.c_void_p(cigar_off.ctypes.data))
+        if rc == PAV_E_CIGAR:
+            e = CigarErr()
+            self.lib.pav_cigar_error(self.handle, ctypes.byref(e))
+            raise CigarDeviceError(self.lib.pav_last_error(self.handle).decode(), e)
+        self._check(rc, 'pav_inv_load_alignments')
+
+    def inv_scan_batch(self, regions, params):
+        regions = np.ascontiguousarray(regions, dtype=INV_REGION_DTYPE)
+        n = regions.shape[0]
+        res = (InvResult * max(n, 1))()
+        self._inv_generation = getattr(self, '_inv_generation', 0) + 1      # invalidates table views of earlier scans
+        self._check(self.lib.pav_inv_scan_batch(self.handle, n, _ptr(regions), ctypes.byref(params), res), 'pav_inv_scan_batch')
+        return res
+
+    def inv_table_view(self, region, generation):
+        """Zero-copy numpy views of a call's table in the library's pinned host memory (valid until the next scan)."""
+        if generation != getattr(self, '_inv_generation', 0) or not self.handle:
+            raise PavDeviceError('the density table of this InvCall is no longer resident: read InvCall.df before the next '
+                                 'scan on the same context, or scan with eager_tables=True')
+        n = ctypes.c_uint32(0)
+        ptrs = [ctypes.c_void_p() for _ in range(9)]
+        self._check(self.lib.pav_inv_table_view(self.handle, region, ctypes.byref(n), *[ctypes.byref(p) for p in ptrs]),
+                    'pav_inv_table_view')
+        n = int(n.value)
+        types = [ctypes.c_uint32, ctypes.c_int8, ctypes.c_int8, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_uint64,
+                 ctypes.c_uint8, ctypes.c_uint8]
+        arrs = [np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(t)), shape=(n,)) if n else np.zeros(0, dtype=t)
+                for p, t in zip(ptrs, types)]
+        cols = dict(zip(['INDEX', 'STATE_MER', 'STATE', 'KERN_FWD', 'KERN_FWDREV', 'KERN_REV', 'KMER'], arrs[:7]))
+        return cols, arrs[7], arrs[8]
+
+    def inv_text(self, region, what, n_bytes):
+        buf = ctypes.create_string_buffer(n_bytes + 1)
+        self._check(self.lib.pav_inv_text(self.handle, region, what, buf, n_bytes + 1), 'pav_inv_text')
+        return buf.value.decode()
+
+    def inv_table(self, region, n_rows):
+        cols = {'INDEX': np.zeros(n_rows, dtype=np.int64), 'STATE_MER': np.zeros(n_rows, dtype=np.int8),
+                'STATE': np.zeros(n_rows, dtype=np.int8), 'KERN_FWD': np.zeros(n_rows, dtype=np.float64),
+                'KERN_FWDREV': np.zeros(n_rows, dtype=np.float64), 'KERN_REV': np.zeros(n_rows, dtype=np.float64),
+                'KMER': np.zeros(n_rows, dtype=np.uint64)}
+        flank = np.zeros(n_rows, dtype=np.uint8)
+        match = np.zeros(n_rows, dtype=np.uint8)
+        self._check(self.lib.pav_inv_table(self.handle, region, _ptr(cols['INDEX']), _ptr(cols['STATE_MER']), _ptr(cols['STATE']),
+                                           _ptr(cols['KERN_FWD']), _ptr(cols['KERN_FWDREV']), _ptr(cols['KERN_REV']),
+                                           _ptr(cols['KMER']), _ptr(flank), _ptr(match)), 'pav_inv_table')
+        return cols, flank, match
+
+    def inv_tables(self, n_rows_per_region):
+        """All call tables of the last scan in one copy: -> (cols dict of concatenated columns, flank, match, row_off)."""
+        n_rows = np.asarray(n_rows_per_region, dtype=np.uint64)
+        off = np.zeros(n_rows.shape[0] + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(n_rows)
+        total = int(off[-1])
+        cols = {'INDEX': np.empty(total, dtype=np.int64), 'STATE_MER': np.empty(total, dtype=np.int8),
+                'STATE': np.empty(total, dtype=np.int8), 'KERN_FWD': np.empty(total, dtype=np.float64),
+                'KERN_FWDREV': np.empty(total, dtype=np.float64), 'KERN_REV': np.empty(total, dtype=np.float64),
+                'KMER': np.empty(total, dtype=np.uint64)}
+        flank = np.empty(total, dtype=np.uint8)
+        match = np.empty(total, dtype=np.uint8)
+        if total:
+            self._check(self.lib.pav_inv_tables(self.handle, n_rows.shape[0], ctypes.c_void_p(off.ctypes.data), _ptr(cols['INDEX']),
+                                                _ptr(cols['STATE_MER']), _ptr(cols['STATE']), _ptr(cols['KERN_FWD']),
+                                                _ptr(cols['KERN_FWDREV']), _ptr(cols['KERN_REV']), _ptr(cols['KMER']), _ptr(flank),
+                                                _ptr(match)), 'pav_inv_tables')
+        return cols, flank, match, off
 
     # -- profiling ----------------------------------------------------------------------------------------
     def prof_enable(self, on=True):

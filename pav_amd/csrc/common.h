@@ -88,6 +88,7 @@ struct pav_ctx {
 
     // density state lives in density.hip (opaque here)
     void *density = nullptr;
+    void *invscan = nullptr;              // native scan driver state (invscan.hip)
 
     // profiling
     bool prof_on = false;
@@ -131,6 +132,16 @@ int prof_flush(pav_ctx *ctx);
         pav::prof_end((ctx), tok__);                                                               \
         PAV_HIP((ctx), hipGetLastError());                                                         \
     } while (0)
+
+// ---- density.hip internals used by the native scan driver ---------------------------------------------------------
+struct CallFetch {              // one call of the batch still resident on the device
+    uint32_t job, n, ref_id;
+    uint64_t ref_up_pos, ref_up_end, ref_dn_pos, ref_dn_end;
+    int64_t base, tig_up_pos, tig_up_end, tig_dn_pos, tig_dn_end;
+    uint32_t *index; int8_t *state_mer, *state; double *kern[3]; uint64_t *kmer; uint8_t *flank, *match;   // pinned host
+};
+// Density tables + FLANK / MATCH of all calls of the last batch: everything is queued, one synchronisation.
+int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls);
 
 // ---- device helpers shared by kernels ---------------------------------------------------------------------
 

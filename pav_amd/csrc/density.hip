@@ -14,6 +14,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 
 namespace pav {
@@ -591,6 +592,125 @@ static DensityState *dstate(pav_ctx *ctx) {
     return static_cast<DensityState *>(ctx->density);
 }
 
+// Pack the table rows of all calls of a round into contiguous columns (one launch), so that the host copy is nine
+// large transfers instead of nine small ones per call.
+struct GatherCall { uint64_t src_off; uint32_t dst_off, n; };
+__global__ __launch_bounds__(256) void k_gather_calls(const GatherCall *__restrict__ calls, uint32_t n_calls, uint32_t total,
+                                                      const uint32_t *__restrict__ index, const int8_t *__restrict__ state_mer,
+                                                      const int8_t *__restrict__ state, const double *__restrict__ k0,
+                                                      const double *__restrict__ k1, const double *__restrict__ k2,
+                                                      const unsigned long long *__restrict__ kmer, uint32_t *__restrict__ o_index,
+                                                      int8_t *__restrict__ o_sm, int8_t *__restrict__ o_st, double *__restrict__ o_k0,
+                                                      double *__restrict__ o_k1, double *__restrict__ o_k2,
+                                                      unsigned long long *__restrict__ o_kmer) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    uint32_t lo = 0, hi = n_calls;                       // last call with dst_off <= t
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (calls[mid].dst_off <= t) lo = mid; else hi = mid; }
+    const uint64_t src = calls[lo].src_off + (t - calls[lo].dst_off);
+    o_index[t] = index[src]; o_sm[t] = state_mer[src]; o_st[t] = state[src];
+    o_k0[t] = k0[src]; o_k1[t] = k1[src]; o_k2[t] = k2[src]; o_kmer[t] = kmer[src];
+}
+
+int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls) {
+    if (calls.empty()) return PAV_OK;
+    DensityState *D = dstate(ctx);
+    if (!D->valid) return fail(ctx, PAV_E_STATE, "density_fetch_calls: no batch resident");
+    const SeqStore &RS = ctx->seq[PAV_ROLE_REF];
+    const SeqView RV = RS.view();
+    const int k = D->params.k;
+    hipStream_t st = ctx->stream;
+    struct Plan { uint64_t up_pos, dn_pos; uint32_t up_len, dn_len, cap_up, cap_dn; uint64_t key_off, fm_off; };
+    std::vector<Plan> plan(calls.size());
+    uint64_t keys = 0, bytes = 0;
+    for (size_t c = 0; c < calls.size(); ++c) {
+        const CallFetch &f = calls[c];
+        uint64_t a = f.ref_up_pos, b = f.ref_up_end, x = f.ref_dn_pos, y = f.ref_dn_end;
+        if (a > b) std::swap(a, b);                                   // Region() swaps reversed coordinates
+        if (x > y) std::swap(x, y);
+        if (f.ref_id >= RS.n || b > RS.len[f.ref_id] || y > RS.len[f.ref_id]) return fail(ctx, PAV_E_ARG, "density_fetch_calls: region outside the reference record");
+        Plan &p = plan[c];
+        p.up_pos = a; p.dn_pos = x; p.up_len = (uint32_t)(b - a); p.dn_len = (uint32_t)(y - x);
+        p.cap_up = pow2_at_least(2ull * p.up_len + 2); p.cap_dn = pow2_at_least(2ull * p.dn_len + 2);
+        p.key_off = keys; keys += (uint64_t)p.cap_up + p.cap_dn;
+        p.fm_off = bytes; bytes += (2ull * f.n + 15) / 16 * 16;
+    }
+    // device staging: [hash keys][flank/match per call][gathered columns]; the host blocks of the calls are contiguous
+    // (one pinned block per round, column-major per call), so the gathered columns are copied call by call only for
+    // the narrow ones; see the layout in invscan.hip.
+    uint64_t total = 0;
+    std::vector<GatherCall> gc(calls.size());
+    for (size_t c = 0; c < calls.size(); ++c) { gc[c] = GatherCall{D->h_jobs[calls[c].job].tpos_off, (uint32_t)total, calls[c].n}; total += calls[c].n; }
+    const uint64_t col_bytes = total * (4 + 1 + 1 + 8 * 4);
+    PAV_HIP(ctx, D->scratch.reserve(8ull * keys + bytes + col_bytes + sizeof(GatherCall) * calls.size() + 256));
+    unsigned long long *d_keys = D->scratch.as<unsigned long long>();
+    uint8_t *d_fm = reinterpret_cast<uint8_t *>(d_keys + keys);
+    uint8_t *d_cols = d_fm + (bytes + 63) / 64 * 64;
+    double *g_k0 = reinterpret_cast<double *>(d_cols), *g_k1 = g_k0 + total, *g_k2 = g_k1 + total;
+    unsigned long long *g_kmer = reinterpret_cast<unsigned long long *>(g_k2 + total);
+    uint32_t *g_index = reinterpret_cast<uint32_t *>(g_kmer + total);
+    int8_t *g_sm = reinterpret_cast<int8_t *>(g_index + total), *g_st = g_sm + total;
+    GatherCall *d_gc = reinterpret_cast<GatherCall *>(d_cols + (col_bytes + 63) / 64 * 64);
+    PAV_HIP(ctx, hipMemsetAsync(d_keys, 0xFF, 8ull * keys, st));
+    PAV_HIP(ctx, hipMemcpyAsync(d_gc, gc.data(), sizeof(GatherCall) * gc.size(), hipMemcpyHostToDevice, st));
+    { int rcw = wait_planes(ctx); if (rcw != PAV_OK) return rcw; }
+    PAV_LAUNCH(ctx, "k_gather_calls", k_gather_calls, (uint32_t)((total + 255) / 256), 256, 0, d_gc, (uint32_t)gc.size(), (uint32_t)total,
+               D->index.as<uint32_t>(), D->state_mer.as<int8_t>(), D->state.as<int8_t>(), D->kern[0].as<double>(), D->kern[1].as<double>(),
+               D->kern[2].as<double>(), D->kmer.as<unsigned long long>(), g_index, g_sm, g_st, g_k0, g_k1, g_k2, g_kmer);
+    for (size_t c = 0; c < calls.size(); ++c) {
+        const CallFetch &f = calls[c];
+        const Plan &p = plan[c];
+        const uint64_t off = D->h_jobs[f.job].tpos_off;
+        const uint32_t n = f.n;
+        unsigned long long *k_up = d_keys + p.key_off, *k_dn = k_up + p.cap_up;
+        uint8_t *d_flank = d_fm + p.fm_off, *d_match = d_flank + n;
+        if (p.up_len >= (uint32_t)k)
+            PAV_LAUNCH(ctx, "k_canon_insert", k_canon_insert, (p.up_len + 255) / 256, 256, 0, RV, RS.off[f.ref_id] + p.up_pos, p.up_len, k, k_up, p.cap_up - 1);
+        if (p.dn_len >= (uint32_t)k)
+            PAV_LAUNCH(ctx, "k_canon_insert", k_canon_insert, (p.dn_len + 255) / 256, 256, 0, RV, RS.off[f.ref_id] + p.dn_pos, p.dn_len, k, k_dn, p.cap_dn - 1);
+        PAV_LAUNCH(ctx, "k_annotate", k_annotate, (n + 255) / 256, 256, 0, D->index.as<uint32_t>(), D->kmer.as<unsigned long long>(), off, n, k,
+                   f.base, f.tig_up_pos, f.tig_up_end, f.tig_dn_pos, f.tig_dn_end, k_up, p.cap_up - 1, k_dn, p.cap_dn - 1, d_flank, d_match);
+    }
+    // Host side (invscan.hip): the round's block is laid out as whole-round columns when `calls[0].kern[0]` etc. are
+    // consecutive; detect that and use nine bulk copies, else copy call by call.
+    bool bulk = true;
+    for (size_t c = 0; c + 1 < calls.size() && bulk; ++c)
+        bulk = calls[c + 1].kern[0] == calls[c].kern[0] + calls[c].n && calls[c + 1].index == calls[c].index + calls[c].n &&
+               calls[c + 1].flank == calls[c].flank + calls[c].n;
+    if (bulk) {
+        const CallFetch &f0 = calls[0];
+        PAV_HIP(ctx, hipMemcpyAsync(f0.kern[0], g_k0, 8ull * total, hipMemcpyDeviceToHost, st));
+        PAV_HIP(ctx, hipMemcpyAsync(f0.kern[1], g_k1, 8ull * total, hipMemcpyDeviceToHost, st));
+        PAV_HIP(ctx, hipMemcpyAsync(f0.kern[2], g_k2, 8ull * total, hipMemcpyDeviceToHost, st));
+        PAV_HIP(ctx, hipMemcpyAsync(f0.kmer, g_kmer, 8ull * total, hipMemcpyDeviceToHost, st));
+        PAV_HIP(ctx, hipMemcpyAsync(f0.index, g_index, 4ull * total, hipMemcpyDeviceToHost, st));
+        PAV_HIP(ctx, hipMemcpyAsync(f0.state_mer, g_sm, total, hipMemcpyDeviceToHost, st));
+        PAV_HIP(ctx, hipMemcpyAsync(f0.state, g_st, total, hipMemcpyDeviceToHost, st));
+        // flank / match: per-call device slices are 16-byte padded; the host columns are dense
+        for (size_t c = 0; c < calls.size(); ++c) {
+            PAV_HIP(ctx, hipMemcpyAsync(calls[c].flank, d_fm + plan[c].fm_off, calls[c].n, hipMemcpyDeviceToHost, st));
+            PAV_HIP(ctx, hipMemcpyAsync(calls[c].match, d_fm + plan[c].fm_off + calls[c].n, calls[c].n, hipMemcpyDeviceToHost, st));
+        }
+    } else {
+        for (size_t c = 0; c < calls.size(); ++c) {
+            const CallFetch &f = calls[c];
+            const uint64_t o = gc[c].dst_off;
+            const uint32_t n = f.n;
+            PAV_HIP(ctx, hipMemcpyAsync(f.flank, d_fm + plan[c].fm_off, n, hipMemcpyDeviceToHost, st));
+            PAV_HIP(ctx, hipMemcpyAsync(f.match, d_fm + plan[c].fm_off + n, n, hipMemcpyDeviceToHost, st));
+            PAV_HIP(ctx, hipMemcpyAsync(f.index, g_index + o, 4ull * n, hipMemcpyDeviceToHost, st));
+            PAV_HIP(ctx, hipMemcpyAsync(f.state_mer, g_sm + o, n, hipMemcpyDeviceToHost, st));
+            PAV_HIP(ctx, hipMemcpyAsync(f.state, g_st + o, n, hipMemcpyDeviceToHost, st));
+            PAV_HIP(ctx, hipMemcpyAsync(f.kmer, g_kmer + o, 8ull * n, hipMemcpyDeviceToHost, st));
+            PAV_HIP(ctx, hipMemcpyAsync(f.kern[0], g_k0 + o, 8ull * n, hipMemcpyDeviceToHost, st));
+            PAV_HIP(ctx, hipMemcpyAsync(f.kern[1], g_k1 + o, 8ull * n, hipMemcpyDeviceToHost, st));
+            PAV_HIP(ctx, hipMemcpyAsync(f.kern[2], g_k2 + o, 8ull * n, hipMemcpyDeviceToHost, st));
+        }
+    }
+    PAV_HIP(ctx, hipStreamSynchronize(st));
+    return PAV_OK;
+}
+
 }  // namespace pav
 
 using namespace pav;
@@ -622,6 +742,11 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     if (pp->k < 1 || pp->k > 31) return fail(ctx, PAV_E_LIMIT, "pav_density_batch: k = %d is outside 1..31", pp->k);
     PAV_HIP(ctx, hipSetDevice(ctx->device));
     DensityState *D = dstate(ctx);
+    const bool timing = getenv("PAV_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    double t_mark = t_begin;
+    auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[pav timing]   density %-10s %.2f ms\n", what, (t - t_mark) * 1e3); t_mark = t; } };
     D->valid = false;
     D->n_jobs = n_jobs;
     D->params = *pp;
@@ -682,6 +807,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
         PAV_HIP(ctx, D->pscaled[s].reserve(8 * a_t));
     }
     hipStream_t st = ctx->stream;
+    lap("plan+alloc");
     PAV_HIP(ctx, hipMemcpyAsync(D->jobs.p, D->h_jobs.data(), sizeof(JobDev) * n_jobs, hipMemcpyHostToDevice, st));
     PAV_HIP(ctx, hipMemcpyAsync(D->tile_job_r.p, tile_job_r.data(), 4ull * n_tiles_r, hipMemcpyHostToDevice, st));
     PAV_HIP(ctx, hipMemcpyAsync(D->tile_job_t.p, tile_job_t.data(), 4ull * n_tiles_t, hipMemcpyHostToDevice, st));
@@ -718,6 +844,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     std::vector<JobStat> hs(n_jobs);
     PAV_HIP(ctx, hipMemcpyAsync(hs.data(), d_stat, sizeof(JobStat) * n_jobs, hipMemcpyDeviceToHost, st));
     PAV_HIP(ctx, hipStreamSynchronize(st));
+    lap("kmer+compact");
 
     // Run heads of a per-row state array (STATE_MER here, STATE for rl_encoder below): events sorted by (job, row).
     auto collect_heads = [&](const int8_t *d_state, std::vector<HeadEvent> &ev, uint64_t hint) -> int {
@@ -754,6 +881,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             mer_runs[(size_t)h.job * 3 + h.state].push_back(RunDev{h.row, mev[e + 1].row - 1});
         }
     }
+    lap("mer_runs");
     D->h_kde.assign(n_jobs, JobKde{});
     std::vector<EvalTile> tiles;
     for (uint32_t j = 0; j < n_jobs; ++j) {
@@ -860,6 +988,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
                    D->kern[1].as<double>(), D->kern[2].as<double>(), D->state.as<int8_t>());
     }
 
+    lap("kde");
     // ---- rl_encoder: run heads -> host assembly ------------------------------------------------------------------
     std::vector<HeadEvent> ev;
     {
@@ -876,6 +1005,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
         D->results[j].n_runs = (uint32_t)D->runs[j].size();
         results[j] = D->results[j];
     }
+    lap("rl");
     D->valid = true;
     return PAV_OK;
 }

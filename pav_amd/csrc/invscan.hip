@@ -1,0 +1,600 @@
+// Native batched driver for the inversion scan: the control flow of pavlib.inv.scan_for_inv (pavlib/inv.py:149-454)
+// for many flagged regions in lock-step, with lift-over (pavlib/align/lift.py) and region arithmetic
+// (pavlib/seq.py:112-188) on the host in C++ and every scan iteration one batched device call (density.hip).
+// The Python mirror (pav_amd/inv.py) implements the same state machine; this driver exists because at ~1k regions per
+// haplotype the interpreter, not the GPU, bounded throughput (bench.py --workload cigar+inv).  Log lines, soft / hard
+// failure behaviour and every coordinate are identical to the reference; tests compare both drivers with the golden
+// vectors the reference produced.
+#include "common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <chrono>
+#include <memory>
+
+namespace pav {
+
+struct LiftRow { uint32_t ref_id, tig_id; int64_t pos, end, qry_pos, qry_end; int rev; int64_t index; };
+
+struct InvTable {           // density table of one call: views into a pinned host block filled when the call is made
+    uint32_t n = 0;
+    uint32_t *index = nullptr; int8_t *state_mer = nullptr, *state = nullptr; double *kern[3] = {nullptr, nullptr, nullptr};
+    uint64_t *kmer = nullptr; uint8_t *flank = nullptr, *match = nullptr;
+};
+
+struct InvState {
+    // lift-over index (pav_inv_load_alignments)
+    std::vector<LiftRow> rows;
+    std::vector<uint32_t> ops, sub_begin, qry_begin;
+    std::vector<uint64_t> op_off;
+    std::vector<std::vector<uint32_t>> by_ref, by_tig;      // rows per reference / contig record, sorted by start
+    std::vector<int64_t> by_ref_maxlen, by_tig_maxlen;
+    std::vector<std::string> names[2];
+    mutable std::vector<int8_t> row_checked;                // 0 not yet, 1 usable, 2 has N / P operations
+    bool loaded = false;
+    // last scan
+    std::vector<pav_inv_result> results;
+    std::vector<std::string> logs;
+    std::vector<std::string> errors;
+    std::vector<std::unique_ptr<InvTable>> tables;
+    // Pinned host memory for the call tables: blocks persist across scans (pinning is expensive) and are bump-allocated;
+    // a new scan starts from the beginning again, so tables live until the next pav_inv_scan_batch.
+    struct PinBlock { void *p; size_t cap, used; };
+    std::vector<PinBlock> pinned;
+    void reset_pinned() { for (auto &b : pinned) b.used = 0; }
+    void free_pinned() { for (auto &b : pinned) (void)hipHostFree(b.p); pinned.clear(); }
+    void *pin_alloc(size_t bytes) {
+        for (auto &b : pinned) if (b.cap - b.used >= bytes) { void *r = static_cast<uint8_t *>(b.p) + b.used; b.used += bytes; return r; }
+        const size_t cap = std::max<size_t>(bytes + bytes / 4, (size_t)64 << 20);
+        void *p = nullptr;
+        if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+        pinned.push_back(PinBlock{p, cap, bytes});
+        return p;
+    }
+};
+
+static InvState *istate(pav_ctx *ctx) {
+    if (!ctx->invscan) ctx->invscan = new InvState();
+    return static_cast<InvState *>(ctx->invscan);
+}
+
+// ---- Python-compatible formatting --------------------------------------------------------------------------
+static std::string fmt_i(int64_t v) { return std::to_string(v); }
+static std::string fmt_commas(int64_t v) {                   // '{:,d}'
+    std::string s = std::to_string(v < 0 ? -v : v), out;
+    for (size_t i = 0; i < s.size(); ++i) { if (i && (s.size() - i) % 3 == 0) out += ','; out += s[i]; }
+    return v < 0 ? "-" + out : out;
+}
+static std::string fmt_f2(double v) { char b[64]; snprintf(b, sizeof b, "%.2f", v); return b; }   // '{:.2f}'
+
+struct Rgn {                                                  // pavlib.seq.Region (only what the scan uses)
+    int chrom = -1; int role = 0;
+    int64_t pos = 0, end = 0;
+    bool is_rev = false;
+    int64_t aln[2][2] = {{0, 0}, {0, 0}}; int n_aln[2] = {0, 0};   // pos_aln_index / end_aln_index (flattened)
+    int64_t len() const { return end - pos; }
+};
+
+struct Lifted { bool ok = false; int id = -1; int64_t pos = 0; int rev = 0; bool rev_none = false; int64_t idx[2] = {0, 0}; int n_idx = 0; };
+
+class Driver {
+public:
+    Driver(pav_ctx *c, InvState *s) : ctx(c), S(s) {}
+    pav_ctx *ctx; InvState *S;
+
+    std::string name(int role, int id) const {
+        if ((size_t)id < S->names[role].size() && !S->names[role][(size_t)id].empty()) return S->names[role][(size_t)id];
+        return (role == PAV_ROLE_REF ? "ref" : "tig") + std::to_string(id);
+    }
+    std::string base1(const Rgn &r) const { return name(r.role, r.chrom) + ":" + fmt_i(r.pos + 1) + "-" + fmt_i(r.end); }   // to_base1_string
+    std::string region_id(const Rgn &r) const { return name(r.role, r.chrom) + "-" + fmt_i(r.pos) + "-RGN-" + fmt_i(r.end - r.pos); }
+
+    // Region.expand(expand_bp, min_pos=0, max_end=fai, shift=True, balance)   pavlib/seq.py:112-188
+    void expand(Rgn &r, int64_t expand_bp, double balance) const {
+        const int64_t expand_pos = (int64_t)((double)expand_bp * balance);          // int(expand_bp * balance)
+        const int64_t expand_end = std::max<int64_t>(0, expand_bp - expand_pos);
+        int64_t new_pos = r.pos - expand_pos, new_end = r.end + expand_end;
+        const int64_t min_pos = 0;
+        if (new_pos < min_pos) { new_end += min_pos - new_pos; new_pos = min_pos; }
+        const int64_t max_end = (int64_t)ctx->seq[PAV_ROLE_REF].len[(size_t)r.chrom];
+        if (new_end > max_end) {
+            new_pos -= new_end - max_end;
+            if (new_pos < min_pos) new_pos = min_pos;
+            new_end = max_end;
+        }
+        if (new_end < new_pos) new_end = new_pos = (new_end + new_pos) / 2;       // over-contraction (negative expand)
+        r.pos = new_pos; r.end = new_end;
+    }
+
+    // records of one sequence whose [begin, end) contains pos
+    void containing(const std::vector<uint32_t> &recs, int64_t maxlen, bool ref_axis, int64_t pos, std::vector<uint32_t> &hits) const {
+        hits.clear();
+        auto begin_of = [&](uint32_t r) { return ref_axis ? S->rows[r].pos : S->rows[r].qry_pos; };
+        auto end_of = [&](uint32_t r) { return ref_axis ? S->rows[r].end : S->rows[r].qry_end; };
+        // recs sorted by begin: first candidate has begin >= pos - maxlen, last has begin <= pos
+        size_t lo = std::lower_bound(recs.begin(), recs.end(), pos - maxlen, [&](uint32_t r, int64_t v) { return begin_of(r) < v; }) - recs.begin();
+        for (size_t i = lo; i < recs.size() && begin_of(recs[i]) <= pos; ++i)
+            if (end_of(recs[i]) > pos) hits.push_back(recs[i]);
+    }
+
+    // point lookup in one record's operation table; axis 0 = subject, 1 = query.  Returns op index or -1.
+    int64_t op_at(uint32_t row, int axis, int64_t pos) const {
+        const uint64_t a = S->op_off[row], b = S->op_off[row + 1];
+        const uint32_t *beg = (axis == 0 ? S->sub_begin.data() : S->qry_begin.data());
+        const uint32_t *first = beg + a, *last = beg + b;
+        if (pos < 0) return -1;
+        const uint32_t *it = std::upper_bound(first, last, (uint32_t)std::min<int64_t>(pos, 0xFFFFFFFFll));
+        if (it == first) return -1;
+        const uint64_t k = (uint64_t)(it - beg) - 1;
+        const uint32_t code = S->ops[k] & 15u, len = S->ops[k] >> 4;
+        const bool match = code == 7 || code == 8 || code == 0;
+        if (!(match || code == (axis == 0 ? 2u : 1u))) return -1;
+        return pos < (int64_t)beg[k] + (int64_t)len ? (int64_t)k : -1;
+    }
+    // (begin, end, d0, d1) of operation k on `axis` (pavlib/align/lift.py:437-461)
+    void op_interval(uint64_t k, int axis, int64_t &begin, int64_t &end, int64_t &d0, int64_t &d1) const {
+        const uint32_t code = S->ops[k] & 15u; const int64_t len = S->ops[k] >> 4;
+        const bool match = code == 7 || code == 8 || code == 0;
+        begin = axis == 0 ? S->sub_begin[k] : S->qry_begin[k];
+        end = begin + len;
+        d0 = axis == 0 ? S->qry_begin[k] : S->sub_begin[k];
+        d1 = match ? d0 + len : d0 + 1;
+    }
+    bool check_row_ops(uint32_t row, std::string &err) const {       // errors _add_align raises (lift.py:463-471)
+        if (S->row_checked[row] == 1) return true;
+        S->row_checked[row] = 1;
+        for (uint64_t k = S->op_off[row]; k < S->op_off[row + 1]; ++k) {
+            const uint32_t code = S->ops[k] & 15u;
+            if (code == 3 || code == 6) {
+                err = std::string("Unhandled CIGAR operation: ") + (code == 3 ? "N" : "P") + ": Alignment " +
+                      name(PAV_ROLE_REF, (int)S->rows[row].ref_id) + ":" + fmt_i(S->rows[row].pos) + " (" + name(PAV_ROLE_TIG, (int)S->rows[row].tig_id) + ")";
+                S->row_checked[row] = 0;                          // raise again on the next use, like the reference
+                return false;
+            }
+        }
+        return true;
+    }
+
+    // AlignLift.lift_to_qry (lift.py:187-272).  false + err on RuntimeError.
+    bool lift_to_qry(int ref_id, int64_t pos, Lifted &out, std::string &err) const {
+        out = Lifted();
+        std::vector<uint32_t> hits;
+        if ((size_t)ref_id < S->by_ref.size()) containing(S->by_ref[(size_t)ref_id], S->by_ref_maxlen[(size_t)ref_id], true, pos, hits);
+        if (hits.size() != 1) return true;
+        const uint32_t row = hits[0];
+        if (!check_row_ops(row, err)) return false;
+        const int64_t k = op_at(row, 0, pos);
+        if (k < 0) {
+            err = "Program bug: Found no matches in a lift-tree for a record withing a global to-query tree: " + name(PAV_ROLE_REF, ref_id) + ":" +
+                  fmt_i(pos) + " (index=" + fmt_i(S->rows[row].index) + ")";
+            return false;
+        }
+        int64_t b, e, d0, d1;
+        op_interval((uint64_t)k, 0, b, e, d0, d1);
+        int64_t q = d1 - d0 > 1 ? d0 + (pos - b) : d1;
+        const LiftRow &r = S->rows[row];
+        if (r.rev) q = (int64_t)ctx->seq[PAV_ROLE_TIG].len[r.tig_id] - q;
+        out.ok = true; out.id = (int)r.tig_id; out.pos = q; out.rev = r.rev; out.idx[0] = r.index; out.n_idx = 1;
+        return true;
+    }
+
+    // AlignLift._get_subject_gap (lift.py:333-378)
+    void subject_gap(int tig_id, int64_t pos, Lifted &out) const {
+        out = Lifted();
+        if ((size_t)tig_id >= S->by_tig.size()) return;
+        const auto &recs = S->by_tig[(size_t)tig_id];
+        int64_t best_l = -1, best_r = -1; int64_t lv = 0, rv = 0;
+        // row_l: largest QRY_END < pos (ties: last in table order after a stable sort); row_r: smallest QRY_POS > pos (first)
+        std::vector<uint32_t> order(recs); std::sort(order.begin(), order.end());      // table order
+        for (uint32_t r : order) {
+            const LiftRow &x = S->rows[r];
+            if (x.qry_end < pos && (best_l < 0 || x.qry_end >= lv)) { best_l = r; lv = x.qry_end; }
+            if (x.qry_pos > pos && (best_r < 0 || x.qry_pos < rv)) { best_r = r; rv = x.qry_pos; }
+        }
+        if (best_l < 0 || best_r < 0) return;
+        const LiftRow &L = S->rows[(size_t)best_l], &R = S->rows[(size_t)best_r];
+        if (L.ref_id != R.ref_id) return;
+        out.ok = true; out.id = (int)L.ref_id;
+        out.pos = (int64_t)((double)(L.qry_end + R.qry_pos) / 2.0);                    // int((a + b) / 2)
+        out.rev = L.rev; out.rev_none = L.rev != R.rev;
+        out.idx[0] = L.index; out.idx[1] = R.index; out.n_idx = 2;
+    }
+
+    // AlignLift.lift_to_sub (lift.py:51-185)
+    bool lift_to_sub(int tig_id, int64_t pos, bool gap, Lifted &out, std::string &err) const {
+        out = Lifted();
+        const int64_t pos_org = pos;
+        std::vector<uint32_t> hits;
+        if ((size_t)tig_id < S->by_tig.size()) containing(S->by_tig[(size_t)tig_id], S->by_tig_maxlen[(size_t)tig_id], false, pos, hits);
+        if (hits.size() == 0 && gap) { subject_gap(tig_id, pos, out); return true; }
+        if (hits.size() != 1) return true;
+        const uint32_t row = hits[0];
+        if (!check_row_ops(row, err)) return false;
+        const LiftRow &r = S->rows[row];
+        if (r.rev) pos = (int64_t)ctx->seq[PAV_ROLE_TIG].len[r.tig_id] - pos;
+        int64_t k = op_at(row, 1, pos);
+        int64_t b, e, d0, d1;
+        if (k < 0) {
+            k = op_at(row, 1, pos - 1);
+            if (k >= 0) op_interval((uint64_t)k, 1, b, e, d0, d1);
+            if (k < 0 || e != pos) {
+                err = "Found no matches in a lift-tree for a record within a global to-subject tree: " + name(PAV_ROLE_TIG, tig_id) + ":" +
+                      fmt_i(pos_org) + " (index=" + fmt_i(r.index) + ", gap=" + (gap ? "True" : "False") + ")";
+                return false;
+            }
+        }
+        op_interval((uint64_t)k, 1, b, e, d0, d1);
+        const int64_t p = d1 - d0 > 1 ? d0 + (pos - b) : d1;
+        out.ok = true; out.id = (int)r.ref_id; out.pos = p; out.rev = r.rev; out.idx[0] = r.index; out.n_idx = 1;
+        return true;
+    }
+
+    // lift_region_to_qry (lift.py:304-331): ok=false => None
+    bool region_to_qry(const Rgn &r, Rgn &q, bool &ok, std::string &err) const {
+        Lifted a, b; ok = false;
+        if (!lift_to_qry(r.chrom, r.pos, a, err) || !lift_to_qry(r.chrom, r.end, b, err)) return false;
+        if (!a.ok || !b.ok || a.id != b.id || a.rev != b.rev) return true;
+        q = Rgn(); q.role = PAV_ROLE_TIG; q.chrom = a.id; q.pos = a.pos; q.end = b.pos; q.is_rev = a.rev != 0;
+        q.aln[0][0] = a.idx[0]; q.aln[1][0] = b.idx[0]; q.n_aln[0] = q.n_aln[1] = 1;
+        if (q.pos > q.end) { std::swap(q.pos, q.end); std::swap(q.aln[0], q.aln[1]); }   // Region swaps reversed coordinates
+        ok = true;
+        return true;
+    }
+    // lift_region_to_sub (lift.py:274-302)
+    bool region_to_sub(const Rgn &r, bool gap, Rgn &s, bool &ok, std::string &err) const {
+        Lifted a, b; ok = false;
+        if (!lift_to_sub(r.chrom, r.pos, gap, a, err) || !lift_to_sub(r.chrom, r.end, gap, b, err)) return false;
+        if (!a.ok || !b.ok) return true;
+        if (a.id != b.id || (!a.rev_none && !b.rev_none && a.rev != b.rev)) return true;
+        s = Rgn(); s.role = PAV_ROLE_REF; s.chrom = a.id; s.pos = a.pos; s.end = b.pos; s.is_rev = false;
+        for (int i = 0; i < a.n_idx; ++i) s.aln[0][i] = a.idx[i];
+        for (int i = 0; i < b.n_idx; ++i) s.aln[1][i] = b.idx[i];
+        s.n_aln[0] = a.n_idx; s.n_aln[1] = b.n_idx;
+        if (s.pos > s.end) { std::swap(s.pos, s.end); std::swap(s.aln[0], s.aln[1]); std::swap(s.n_aln[0], s.n_aln[1]); }
+        ok = true;
+        return true;
+    }
+};
+
+struct Scan {                       // per flagged region
+    Rgn flag, region_ref, region_tig;
+    int expansion_count = 0;
+    bool done = false;
+    std::vector<pav_run> state_rl;
+    uint32_t n_rows = 0;
+};
+
+}  // namespace pav
+
+using namespace pav;
+
+extern "C" {
+
+void pav_invscan_release(pav_ctx *ctx) {
+    if (!ctx || !ctx->invscan) return;
+    static_cast<InvState *>(ctx->invscan)->free_pinned();
+    delete static_cast<InvState *>(ctx->invscan);
+    ctx->invscan = nullptr;
+}
+
+int pav_seq_set_names(pav_ctx *ctx, int role, uint32_t n, const char *const *names) {
+    if (!ctx || (role != PAV_ROLE_REF && role != PAV_ROLE_TIG) || (n && !names)) return PAV_E_ARG;
+    InvState *S = istate(ctx);
+    S->names[role].assign(n, std::string());
+    for (uint32_t i = 0; i < n; ++i) S->names[role][i] = names[i] ? names[i] : "";
+    return PAV_OK;
+}
+
+int pav_inv_load_alignments(pav_ctx *ctx, uint32_t n, const pav_inv_aln *aln, const uint8_t *cigar_text, const uint64_t *cigar_off) {
+    if (!ctx || (n && (!aln || !cigar_off))) return fail(ctx, PAV_E_ARG, "pav_inv_load_alignments: null input");
+    InvState *S = istate(ctx);
+    S->loaded = false;
+    S->rows.resize(n);
+    std::vector<uint32_t> row_pos(n);
+    std::map<int64_t, int> seen;
+    for (uint32_t i = 0; i < n; ++i) {
+        const pav_inv_aln &a = aln[i];
+        if (a.ref_id >= ctx->seq[PAV_ROLE_REF].n || a.tig_id >= ctx->seq[PAV_ROLE_TIG].n)
+            return fail(ctx, PAV_E_ARG, "pav_inv_load_alignments: row %u references a sequence that is not loaded", i);
+        S->rows[i] = LiftRow{a.ref_id, a.tig_id, (int64_t)a.pos, (int64_t)a.end, (int64_t)a.qry_pos, (int64_t)a.qry_end, a.rev != 0, a.index};
+        row_pos[i] = (uint32_t)a.pos;
+    }
+    uint64_t n_ops = 0;
+    int rc = pav_align_index(ctx, n, row_pos.data(), cigar_text, cigar_off, &n_ops, nullptr, nullptr, nullptr, nullptr);
+    if (rc != PAV_OK) return rc;
+    S->ops.resize(n_ops + 1); S->sub_begin.resize(n_ops + 1); S->qry_begin.resize(n_ops + 1); S->op_off.resize((size_t)n + 1);
+    rc = pav_align_index(ctx, n, row_pos.data(), cigar_text, cigar_off, &n_ops, S->ops.data(), S->op_off.data(), S->sub_begin.data(), S->qry_begin.data());
+    if (rc != PAV_OK) return rc;
+    if (n == 0) S->op_off.assign(1, 0);
+    S->by_ref.assign(ctx->seq[PAV_ROLE_REF].n, {}); S->by_tig.assign(ctx->seq[PAV_ROLE_TIG].n, {});
+    S->by_ref_maxlen.assign(ctx->seq[PAV_ROLE_REF].n, 0); S->by_tig_maxlen.assign(ctx->seq[PAV_ROLE_TIG].n, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        const LiftRow &r = S->rows[i];
+        if (r.end > r.pos) { S->by_ref[r.ref_id].push_back(i); S->by_ref_maxlen[r.ref_id] = std::max(S->by_ref_maxlen[r.ref_id], r.end - r.pos); }
+        if (r.qry_end > r.qry_pos) { S->by_tig[r.tig_id].push_back(i); S->by_tig_maxlen[r.tig_id] = std::max(S->by_tig_maxlen[r.tig_id], r.qry_end - r.qry_pos); }
+    }
+    for (auto &v : S->by_ref) std::stable_sort(v.begin(), v.end(), [&](uint32_t a, uint32_t b) { return S->rows[a].pos < S->rows[b].pos; });
+    for (auto &v : S->by_tig) std::stable_sort(v.begin(), v.end(), [&](uint32_t a, uint32_t b) { return S->rows[a].qry_pos < S->rows[b].qry_pos; });
+    S->row_checked.assign(n, 0);
+    S->loaded = true;
+    return PAV_OK;
+}
+
+int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *regions, const pav_inv_params *pp,
+                       pav_inv_result *results) {
+    if (!ctx || !pp || (n_regions && (!regions || !results))) return fail(ctx, PAV_E_ARG, "pav_inv_scan_batch: null argument");
+    InvState *S = istate(ctx);
+    if (!S->loaded) return fail(ctx, PAV_E_STATE, "pav_inv_scan_batch: pav_inv_load_alignments has not been called");
+    Driver D(ctx, S);
+    const int k = pp->den.k;
+    const int64_t max_region_size = pp->max_region_size;
+    const int min_exp_count = pp->min_exp_count;
+    S->results.assign(n_regions, pav_inv_result{});
+    S->logs.assign(n_regions, std::string());
+    S->errors.assign(n_regions, std::string());
+    S->tables.clear(); S->tables.resize(n_regions);
+    S->reset_pinned();
+    std::vector<Scan> scans(n_regions);
+    auto log = [&](uint32_t i, const std::string &m) { S->logs[i] += m; S->logs[i] += '\n'; };
+    auto srs_of = [&](int64_t len) -> uint32_t {
+        for (uint32_t i = 0; i < pp->n_srs; ++i) if ((double)len >= pp->srs[i].begin && (double)len < pp->srs[i].end) return pp->srs[i].value;
+        return 20;
+    };
+    auto finish = [&](uint32_t i, int outcome) { scans[i].done = true; S->results[i].outcome = outcome; };
+    auto set_rgn = [&](pav_inv_rgn &o, const Rgn &r) {
+        o.seq_id = (uint32_t)r.chrom; o.pos = (uint64_t)r.pos; o.end = (uint64_t)r.end; o.is_rev = r.is_rev ? 1 : 0;
+        for (int e = 0; e < 2; ++e) { o.n_aln[e] = (uint32_t)r.n_aln[e]; for (int q = 0; q < 2; ++q) o.aln_index[e][q] = r.aln[e][q]; }
+    };
+
+    std::vector<uint32_t> live;
+    for (uint32_t i = 0; i < n_regions; ++i) {
+        Scan &sc = scans[i];
+        if (regions[i].ref_id >= ctx->seq[PAV_ROLE_REF].n) return fail(ctx, PAV_E_ARG, "pav_inv_scan_batch: region %u: unknown reference record", i);
+        sc.flag.role = PAV_ROLE_REF; sc.flag.chrom = (int)regions[i].ref_id; sc.flag.pos = (int64_t)regions[i].pos; sc.flag.end = (int64_t)regions[i].end;
+        if (sc.flag.pos > sc.flag.end) { std::swap(sc.flag.pos, sc.flag.end); sc.flag.is_rev = true; }
+        log(i, "Scanning for inversions in flagged region: " + D.base1(sc.flag) + " (flagged region record id = " + D.region_id(sc.flag) + ")");   // inv.py:194-199
+        sc.region_ref = sc.flag;
+        D.expand(sc.region_ref, 4000, 0.5);                                          // INITIAL_EXPAND, inv.py:203-204
+        live.push_back(i);
+    }
+
+    const uint64_t max_batch_bp = 64000000ull;
+    const bool timing = getenv("PAV_TIMING") != nullptr;
+    double t_batch = 0, t_table = 0, t_annot = 0, t_lift = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = now();
+    while (!live.empty()) {
+        std::vector<pav_den_job> jobs; std::vector<uint32_t> owners, rest;
+        uint64_t budget = 0;
+        for (uint32_t i : live) {
+            if (budget > max_batch_bp && !jobs.empty()) { rest.push_back(i); continue; }
+            Scan &sc = scans[i];
+            // top of the while-loop, inv.py:223-260
+            if (0 < max_region_size && max_region_size < sc.region_ref.len()) {
+                log(i, "Region size exceeds max: " + D.base1(sc.region_ref) + " (" + fmt_i(sc.region_ref.len()) + " > " + fmt_i(max_region_size) + ")");
+                finish(i, PAV_INV_NONE); continue;
+            }
+            bool ok = false; std::string err;
+            if (!D.region_to_qry(sc.region_ref, sc.region_tig, ok, err)) { S->errors[i] = err; finish(i, PAV_INV_ERROR); continue; }
+            if (!ok) { log(i, "Could not lift reference region onto contigs: " + D.base1(sc.region_ref)); finish(i, PAV_INV_NONE); continue; }
+            sc.expansion_count += 1;
+            log(i, "Scanning region: " + D.base1(sc.region_ref));
+            pav_den_job j{};
+            j.ref_id = (uint32_t)sc.region_ref.chrom; j.tig_id = (uint32_t)sc.region_tig.chrom;
+            j.ref_pos = (uint64_t)sc.region_ref.pos; j.ref_end = (uint64_t)sc.region_ref.end;
+            j.tig_pos = (uint64_t)sc.region_tig.pos; j.tig_end = (uint64_t)sc.region_tig.end;
+            j.ref_rc = sc.region_tig.is_rev ? 1 : 0; j.state_run_smooth = srs_of(sc.region_tig.len());
+            jobs.push_back(j); owners.push_back(i);
+            budget += (uint64_t)sc.region_ref.len() + (uint64_t)sc.region_tig.len();
+        }
+        if (jobs.empty()) { live.swap(rest); continue; }
+        std::vector<pav_den_result> res(jobs.size());
+        double t0 = now();
+        int rc = pav_density_batch(ctx, (uint32_t)jobs.size(), jobs.data(), &pp->den, res.data());
+        t_batch += now() - t0;
+        if (rc != PAV_OK) return rc;
+        std::vector<uint32_t> next;
+        std::vector<CallFetch> round_calls; std::vector<uint32_t> round_owner;
+        for (uint32_t j = 0; j < jobs.size(); ++j) {
+            const uint32_t i = owners[j];
+            Scan &sc = scans[i];
+            const pav_den_result &r = res[j];
+            S->results[i].iterations = (uint32_t)sc.expansion_count;
+            // after the density call, inv.py:268-351
+            if (r.status == PAV_DEN_FAIL) {
+                std::string stderr_text;
+                if (r.fail_kind == 2) {
+                    std::string kmer(k, 'A');
+                    for (int b = 0; b < k; ++b) kmer[(size_t)b] = "ACGT"[(r.max_kmer >> (2 * (k - 1 - b))) & 3];
+                    stderr_text = "K-mer count exceeds max: " + fmt_i(r.max_count) + " > " + fmt_i(pp->den.max_ref_kmer_count) + " (" + kmer + "): " +
+                                  D.base1(sc.region_ref) + "\n";
+                }
+                log(i, "Received return code 125 from scripts/density.py for region " + D.base1(sc.region_ref) + ":\n" + stderr_text);
+                finish(i, PAV_INV_NONE); continue;
+            }
+            if (r.n_rows == 0) { log(i, "No informative reference k-mers in forward or reverse orientation in region"); finish(i, PAV_INV_NONE); continue; }
+            sc.state_rl.resize(r.n_runs);
+            if (r.n_runs) { rc = pav_density_runs(ctx, j, sc.state_rl.data()); if (rc != PAV_OK) return rc; }
+            sc.n_rows = r.n_rows;
+            const auto &rl = sc.state_rl;
+            if (rl.size() == 1 && (rl[0].state == 0 || rl[0].state == -1) && sc.expansion_count >= min_exp_count) {
+                log(i, "Found no inverted k-mer states after " + fmt_i(sc.expansion_count) + " expansion(s)");
+                finish(i, PAV_INV_NONE); continue;
+            }
+            if (rl.size() > 2 && rl.front().state == 0 && rl.back().state == 0) {
+                // ---- characterise, inv.py:353-454 ----------------------------------------------------------
+                bool any_inv = false; uint32_t max_run = 0;
+                for (const auto &x : rl) if (x.state == 2) { any_inv = true; max_run = std::max(max_run, x.count); }
+                if (!any_inv) { log(i, "No inverted states found"); finish(i, PAV_INV_NONE); continue; }
+                if (max_run < 100) {                                                 // MIN_INV_KMER_RUN
+                    log(i, "Longest run of strictly inverted k-mers (" + fmt_i(max_run) + ") does not meet the minimum threshold (100)");
+                    finish(i, PAV_INV_NONE); continue;
+                }
+                const pav_run *inv_first = nullptr, *inv_last = nullptr;
+                for (const auto &x : rl) if (x.state == 2) { if (!inv_first) inv_first = &x; inv_last = &x; }
+                Rgn t_outer, t_inner;
+                t_outer.role = t_inner.role = PAV_ROLE_TIG; t_outer.chrom = t_inner.chrom = sc.region_tig.chrom;
+                t_outer.is_rev = t_inner.is_rev = sc.region_tig.is_rev;
+                t_outer.pos = rl[1].pos + sc.region_tig.pos; t_outer.end = rl[rl.size() - 2].end + sc.region_tig.pos + k;
+                t_inner.pos = inv_first->pos + sc.region_tig.pos; t_inner.end = inv_last->end + sc.region_tig.pos + k;
+                if (t_outer.pos > t_outer.end) std::swap(t_outer.pos, t_outer.end);
+                if (t_inner.pos > t_inner.end) std::swap(t_inner.pos, t_inner.end);
+                Rgn r_outer, r_inner; bool ok = false; std::string err;
+                if (!D.region_to_sub(t_outer, false, r_outer, ok, err)) { S->errors[i] = err; finish(i, PAV_INV_ERROR); continue; }
+                if (!ok) { log(i, "Failed lifting outer INV region to reference: " + D.base1(t_outer)); finish(i, PAV_INV_NONE); continue; }
+                bool ok2 = false;
+                if (!D.region_to_sub(t_inner, true, r_inner, ok2, err)) { S->errors[i] = err; finish(i, PAV_INV_ERROR); continue; }
+                if (!ok2) r_inner = r_outer;
+                pav_inv_result &out = S->results[i];
+                set_rgn(out.tig_outer, t_outer); set_rgn(out.tig_inner, t_inner); set_rgn(out.ref_outer, r_outer); set_rgn(out.ref_inner, r_inner);
+                set_rgn(out.ref_discovery, sc.region_ref); set_rgn(out.tig_discovery, sc.region_tig);
+                out.found = 1;                                                      // 'INV Found:' is printed by the caller (inv.py:408)
+                if ((double)r_outer.len() < (double)t_outer.len() * 0.6) {
+                    log(i, "Reference region too short: Reference region length (" + fmt_commas(r_outer.len()) + ") is not within " + fmt_f2(60.0) +
+                           "% of the contig region length (" + fmt_commas(t_outer.len()) + ")");
+                    finish(i, PAV_INV_NONE); continue;
+                }
+                if ((double)t_outer.len() < (double)r_outer.len() * 0.6) {
+                    log(i, "Contig region too short: Contig region length (" + fmt_commas(t_outer.len()) + ") is not within " + fmt_f2(60.0) +
+                           "% of the reference region length (" + fmt_commas(r_outer.len()) + ")");
+                    finish(i, PAV_INV_NONE); continue;
+                }
+                // density table + FLANK / MATCH (inv.py:440-442, 457-561): queued for the end of this round, while the batch
+                // is still resident.  The annotation receives the *reference* discovery start (inv.py:441).
+                const uint32_t n = r.n_rows;
+                CallFetch cf{};
+                cf.job = j; cf.n = n; cf.ref_id = (uint32_t)r_outer.chrom;
+                cf.ref_up_pos = (uint64_t)r_outer.pos; cf.ref_up_end = (uint64_t)r_inner.pos;
+                cf.ref_dn_pos = (uint64_t)r_inner.end; cf.ref_dn_end = (uint64_t)r_outer.end;
+                cf.base = sc.region_ref.pos;
+                cf.tig_up_pos = std::min(t_outer.pos, t_inner.pos); cf.tig_up_end = std::max(t_outer.pos, t_inner.pos);
+                cf.tig_dn_pos = std::min(t_inner.end, t_outer.end); cf.tig_dn_end = std::max(t_inner.end, t_outer.end);
+                round_calls.push_back(cf); round_owner.push_back(i);
+                out.n_rows = n;
+                out.svlen = (uint64_t)r_outer.len();
+                log(i, "Found inversion: " + D.name(PAV_ROLE_REF, r_outer.chrom) + "-" + fmt_i(r_outer.pos + 1) + "-INV-" + fmt_i(r_outer.len()));
+                finish(i, PAV_INV_CALL);
+                continue;
+            }
+            // Expand, inv.py:309-342
+            const int64_t last_len = sc.region_ref.len();
+            const int64_t expand_bp = (int64_t)(int32_t)((double)last_len * 1.5);        // np.int32(len * EXPAND_FACTOR)
+            double balance = 0.5;
+            if (rl.size() > 2) { if (rl.front().state == 0) balance = 0.25; else if (rl.back().state == 0) balance = 0.75; }
+            D.expand(sc.region_ref, expand_bp, balance);
+            if (sc.region_ref.len() == last_len) { log(i, "Reached reference limits, cannot expand"); finish(i, PAV_INV_NONE); continue; }
+            next.push_back(i);
+        }
+        if (!round_calls.empty()) {                                          // one pinned block, one synchronisation per round
+            double t0 = now();
+            // one pinned block per round, column-major over the whole round: K0 | K1 | K2 | KMER | INDEX | STATE_MER | STATE |
+            // FLANK | MATCH, each column holding the calls one after the other (nine bulk device-to-host copies)
+            size_t rows = 0;
+            for (const CallFetch &cf : round_calls) rows += cf.n;
+            const size_t total = rows * 40 + 64;
+            void *blk = S->pin_alloc(total);
+            if (!blk) return fail(ctx, PAV_E_HIP, "pav_inv_scan_batch: cannot pin %zu bytes of host memory", total);
+            double *c_k0 = static_cast<double *>(blk), *c_k1 = c_k0 + rows, *c_k2 = c_k1 + rows;
+            uint64_t *c_kmer = reinterpret_cast<uint64_t *>(c_k2 + rows);
+            uint32_t *c_index = reinterpret_cast<uint32_t *>(c_kmer + rows);
+            int8_t *c_sm = reinterpret_cast<int8_t *>(c_index + rows), *c_st = c_sm + rows;
+            uint8_t *c_fl = reinterpret_cast<uint8_t *>(c_st + rows), *c_ma = c_fl + rows;
+            size_t o = 0;
+            for (size_t c = 0; c < round_calls.size(); ++c) {
+                CallFetch &cf = round_calls[c];
+                auto tab = std::make_unique<InvTable>();
+                tab->n = cf.n;
+                tab->kern[0] = c_k0 + o; tab->kern[1] = c_k1 + o; tab->kern[2] = c_k2 + o; tab->kmer = c_kmer + o; tab->index = c_index + o;
+                tab->state_mer = c_sm + o; tab->state = c_st + o; tab->flank = c_fl + o; tab->match = c_ma + o;
+                cf.index = tab->index; cf.state_mer = tab->state_mer; cf.state = tab->state; cf.kmer = tab->kmer;
+                cf.flank = tab->flank; cf.match = tab->match;
+                for (int q = 0; q < 3; ++q) cf.kern[q] = tab->kern[q];
+                o += cf.n;
+                S->tables[round_owner[c]] = std::move(tab);
+            }
+            rc = density_fetch_calls(ctx, round_calls);
+            t_table += now() - t0;
+            if (rc != PAV_OK) return rc;
+        }
+        next.insert(next.end(), rest.begin(), rest.end());
+        live.swap(next);
+    }
+    (void)t_lift;
+    if (timing) fprintf(stderr, "[pav timing] inv_scan_batch %.1f ms: density_batch %.1f, tables %.1f, annotate %.1f\n",
+                        (now() - t_start) * 1e3, t_batch * 1e3, t_table * 1e3, t_annot * 1e3);
+    for (uint32_t i = 0; i < n_regions; ++i) {
+        S->results[i].log_bytes = (uint32_t)S->logs[i].size();
+        S->results[i].error_bytes = (uint32_t)S->errors[i].size();
+        results[i] = S->results[i];
+    }
+    return PAV_OK;
+}
+
+int pav_inv_text(pav_ctx *ctx, uint32_t region, int what, char *buf, uint32_t buf_len) {
+    if (!ctx || !buf) return PAV_E_ARG;
+    InvState *S = istate(ctx);
+    if (region >= S->logs.size()) return fail(ctx, PAV_E_STATE, "pav_inv_text: no such region in the last scan");
+    const std::string &s = what == 0 ? S->logs[region] : S->errors[region];
+    if (buf_len < s.size() + 1) return fail(ctx, PAV_E_ARG, "pav_inv_text: buffer too small");
+    memcpy(buf, s.data(), s.size());
+    buf[s.size()] = 0;
+    return PAV_OK;
+}
+
+int pav_inv_table(pav_ctx *ctx, uint32_t region, int64_t *index, int8_t *state_mer, int8_t *state, double *kern_fwd, double *kern_fwdrev,
+                  double *kern_rev, uint64_t *kmer, uint8_t *flank, uint8_t *match) {
+    if (!ctx) return PAV_E_ARG;
+    InvState *S = istate(ctx);
+    if (region >= S->tables.size() || !S->tables[region]) return fail(ctx, PAV_E_STATE, "pav_inv_table: region has no call in the last scan");
+    const InvTable &t = *S->tables[region];
+    const size_t n = t.n;
+    if (index) for (size_t i = 0; i < n; ++i) index[i] = t.index[i];
+    if (state_mer) memcpy(state_mer, t.state_mer, n);
+    if (state) memcpy(state, t.state, n);
+    if (kern_fwd) memcpy(kern_fwd, t.kern[0], 8 * n);
+    if (kern_fwdrev) memcpy(kern_fwdrev, t.kern[1], 8 * n);
+    if (kern_rev) memcpy(kern_rev, t.kern[2], 8 * n);
+    if (kmer) memcpy(kmer, t.kmer, 8 * n);
+    if (flank) memcpy(flank, t.flank, n);
+    if (match) memcpy(match, t.match, n);
+    return PAV_OK;
+}
+
+int pav_inv_table_view(pav_ctx *ctx, uint32_t region, uint32_t *n_rows, const uint32_t **index, const int8_t **state_mer,
+                       const int8_t **state, const double **kern_fwd, const double **kern_fwdrev, const double **kern_rev,
+                       const uint64_t **kmer, const uint8_t **flank, const uint8_t **match) {
+    if (!ctx || !n_rows) return PAV_E_ARG;
+    InvState *S = istate(ctx);
+    if (region >= S->tables.size() || !S->tables[region]) return fail(ctx, PAV_E_STATE, "pav_inv_table_view: region has no call in the last scan");
+    const InvTable &t = *S->tables[region];
+    *n_rows = t.n;
+    if (index) *index = t.index;
+    if (state_mer) *state_mer = t.state_mer;
+    if (state) *state = t.state;
+    if (kern_fwd) *kern_fwd = t.kern[0];
+    if (kern_fwdrev) *kern_fwdrev = t.kern[1];
+    if (kern_rev) *kern_rev = t.kern[2];
+    if (kmer) *kmer = t.kmer;
+    if (flank) *flank = t.flank;
+    if (match) *match = t.match;
+    return PAV_OK;
+}
+
+int pav_inv_tables(pav_ctx *ctx, uint32_t n_regions, const uint64_t *row_off, int64_t *index, int8_t *state_mer, int8_t *state,
+                   double *kern_fwd, double *kern_fwdrev, double *kern_rev, uint64_t *kmer, uint8_t *flank, uint8_t *match) {
+    if (!ctx || !row_off) return PAV_E_ARG;
+    InvState *S = istate(ctx);
+    if (n_regions != S->tables.size()) return fail(ctx, PAV_E_STATE, "pav_inv_tables: region count does not match the last scan");
+    for (uint32_t i = 0; i < n_regions; ++i) {
+        if (!S->tables[i]) continue;
+        const uint64_t o = row_off[i];
+        int rc = pav_inv_table(ctx, i, index ? index + o : nullptr, state_mer ? state_mer + o : nullptr, state ? state + o : nullptr,
+                               kern_fwd ? kern_fwd + o : nullptr, kern_fwdrev ? kern_fwdrev + o : nullptr, kern_rev ? kern_rev + o : nullptr,
+                               kmer ? kmer + o : nullptr, flank ? flank + o : nullptr, match ? match + o : nullptr);
+        if (rc != PAV_OK) return rc;
+    }
+    return PAV_OK;
+}
+
+}  // extern "C"

@@ -9,6 +9,8 @@ call (regions are independent: SURVEY.md section 8(e)); its results are identica
 region by region.
 """
 
+import os
+
 import numpy as np
 
 from . import _lib, density, seq
@@ -406,16 +408,121 @@ def scan_for_inv(region_flag, ref_fa_name, tig_fa_name, align_lift, k_util, n_tr
     return sc.result
 
 
+def _native_scan(ctx, region_flags, align_lift, k_util, max_region_size, logs, srs_tree, min_exp_count, ref_index, tig_index,
+                 eager_tables=True):
+    """All regions through the library's native driver (pav_inv_scan_batch, csrc/invscan.hip)."""
+    import ctypes
+    import time
+    _t = [time.perf_counter()]
+    _timing = bool(os.environ.get('PAV_TIMING'))
+
+    def _lap(what):
+        if _timing:
+            t = time.perf_counter()
+            print('[pav timing] _native_scan %-18s %.1f ms' % (what, (t - _t[0]) * 1e3), file=__import__('sys').stderr)
+            _t[0] = t
+    df = align_lift.df
+    n = df.shape[0]
+    if getattr(align_lift, '_native_loaded', None) is not ctx:
+        aln = np.zeros(n, dtype=_lib.INV_ALN_DTYPE)
+        if n:
+            aln['ref_id'] = [ref_index[str(c)] for c in df['#CHROM']]
+            aln['tig_id'] = [tig_index[str(c)] for c in df['QRY_ID']]
+            for col, name in (('pos', 'POS'), ('end', 'END'), ('qry_pos', 'QRY_POS'), ('qry_end', 'QRY_END'), ('index', 'INDEX')):
+                aln[col] = df[name].to_numpy(dtype=np.int64)
+            aln['rev'] = [1 if bool(v) else 0 for v in df['REV']]
+        cig = [str(c).encode() for c in df['CIGAR']] if n else []
+        off = np.zeros(n + 1, dtype=np.uint64)
+        if n:
+            off[1:] = np.cumsum([len(c) for c in cig], dtype=np.uint64)
+        text = np.frombuffer(b''.join(cig), dtype=np.uint8) if n else np.zeros(0, dtype=np.uint8)
+        _lap('marshal table')
+        ctx.inv_load_alignments(aln, text, off)
+        align_lift._native_loaded = ctx
+        _lap('load_alignments')
+    tree = get_srs_tree(None) if srs_tree is None else srs_tree
+    ivs = list(getattr(tree, 'intervals', None) or tree)            # SrsTree or a real intervaltree.IntervalTree
+    srs = (_lib.Srs * max(1, len(ivs)))(*[_lib.Srs(float(iv.begin), float(iv.end), int(iv.data), 0) for iv in ivs])
+    params = _lib.InvParams(int(MAX_REGION_SIZE if max_region_size is None else max_region_size),
+                            int(DEFAULT_MIN_EXP_COUNT if min_exp_count is None else min_exp_count), len(ivs),
+                            ctypes.cast(srs, ctypes.POINTER(_lib.Srs)), density.den_params(k=k_util.k_size))
+    regions = np.zeros(len(region_flags), dtype=_lib.INV_REGION_DTYPE)
+    for i, rf in enumerate(region_flags):
+        regions[i] = (ref_index[rf.chrom], 0, rf.pos, rf.end)
+    _lap('marshal regions')
+    res = ctx.inv_scan_batch(regions, params)
+    _lap('inv_scan_batch')
+    ref_names, tig_names = ctx.seq_names(_lib.PAV_ROLE_REF), ctx.seq_names(_lib.PAV_ROLE_TIG)
+
+    def rgn(r, names, with_rev):
+        aln_ix = [tuple(int(r.aln_index[e][q]) for q in range(r.n_aln[e])) for e in (0, 1)]
+        return seq.Region(names[r.seq_id], int(r.pos), int(r.end), is_rev=bool(r.is_rev) if with_rev else False,
+                          pos_aln_index=(aln_ix[0],) if r.n_aln[0] else None, end_aln_index=(aln_ix[1],) if r.n_aln[1] else None)
+
+    if eager_tables:
+        n_rows = [int(res[i].n_rows) if res[i].outcome == _lib.INV_CALL else 0 for i in range(len(region_flags))]
+        all_cols, all_flank, all_match, row_off = ctx.inv_tables(n_rows)
+    generation = ctx._inv_generation
+    _lap('inv_tables')
+    out = []
+    for i, rf in enumerate(region_flags):
+        r = res[i]
+        if logs is not None and logs[i] is not None and r.log_bytes:
+            logs[i].write(ctx.inv_text(i, 0, r.log_bytes))
+            logs[i].flush()
+        if r.found:
+            print('INV Found: outer={}, inner={} (ref outer={}, inner={})'.format(
+                rgn(r.tig_outer, tig_names, True), rgn(r.tig_inner, tig_names, True), rgn(r.ref_outer, ref_names, False),
+                rgn(r.ref_inner, ref_names, False)))
+        if r.outcome == _lib.INV_ERROR:
+            out.append(RuntimeError(ctx.inv_text(i, 1, r.error_bytes)))
+        elif r.outcome == _lib.INV_CALL:
+            if eager_tables:
+                sl = slice(int(row_off[i]), int(row_off[i + 1]))
+                cols = {name: arr[sl] for name, arr in all_cols.items()}
+                flank, match = all_flank[sl], all_match[sl]
+
+                def df(cols=cols, flank=flank, match=match):
+                    return density.table_frame(cols, finalised=True, extra=_flank_match_text(flank, match))
+            else:
+                def df(i=i):                    # views of the library's pinned host copy; valid until the next scan
+                    cols, flank, match = ctx.inv_table_view(i, generation)
+                    return density.table_frame(cols, finalised=True, extra=_flank_match_text(flank.copy(), match.copy()))
+            out.append(InvCall(rgn(r.ref_outer, ref_names, False), rgn(r.ref_inner, ref_names, False),
+                               rgn(r.tig_outer, tig_names, True), rgn(r.tig_inner, tig_names, True),
+                               rgn(r.ref_discovery, ref_names, False), rgn(r.tig_discovery, tig_names, True), rf, df))
+        else:
+            out.append(None)
+    _lap('results')
+    return out
+
+
 def scan_for_inv_batch(region_flags, ref_fa_name, tig_fa_name, align_lift, k_util, n_tree=None, max_region_size=None,
-                       logs=None, srs_tree=None, min_exp_count=DEFAULT_MIN_EXP_COUNT, ctx=None, device_id=0):
+                       logs=None, srs_tree=None, min_exp_count=DEFAULT_MIN_EXP_COUNT, ctx=None, device_id=0, native=None,
+                       eager_tables=True):
     """Scan many flagged regions; returns a list of ``InvCall`` / ``None`` / ``RuntimeError`` (one per region, the
-    error object where ``scan_for_inv`` would have raised).  ``logs``: one file-like object per region or None."""
+    error object where ``scan_for_inv`` would have raised).  ``logs``: one file-like object per region or None.
+
+    ``native``: run the whole scan loop inside the library (csrc/invscan.hip).  Default: yes when ``align_lift`` is a
+    :class:`pav_amd.align.AlignLift` and no N-tree is given; the Python state machine below is the same algorithm and
+    is used otherwise (e.g. for a ``pavlib.align.AlignLift`` object).
+
+    ``eager_tables`` (native driver): copy every call's density table into numpy arrays before returning (default).  With
+    ``False`` ``InvCall.df`` is assembled on first access from the library's host copy, which lives until the next scan
+    on the same context (reading it later raises); the rule mirror and bench.py use that."""
     own = ctx is None
     if own:
         ctx = _lib.Context(device_id)
     try:
         ensure_sequences(ctx, ref_fa_name, tig_fa_name)
         ref_index, tig_index = _seq_index(ctx)
+        from .align import AlignLift as _OurLift
+        if native is None:
+            native = isinstance(align_lift, _OurLift) and n_tree is None and \
+                os.environ.get('PAV_INV_DRIVER', '').lower() != 'python'
+        if native:
+            return _native_scan(ctx, region_flags, align_lift, k_util, max_region_size, logs, srs_tree, min_exp_count,
+                                ref_index, tig_index, eager_tables=eager_tables)
         scans = []
         for i, rf in enumerate(region_flags):
             scans.append(_Scan(rf, ref_fa_name, tig_fa_name, align_lift, k_util, n_tree, max_region_size,

@@ -137,7 +137,8 @@ def call_inv_batch(bed_flag, bed_aln, tig_fa, fai, ref_fa, hap, batch, bed_out=N
             regions = [pavseq.Region(row['#CHROM'], row['POS'], row['END']) for _, row in df_flag.iterrows()]
             logs = [io.StringIO() for _ in regions]
             results = pavinv.scan_for_inv_batch(regions, ref_fa, tig_fa, align_lift, k_util, max_region_size=inv_region_limit,
-                                                logs=logs, srs_tree=srs_tree, min_exp_count=inv_min_expand, ctx=ctx)
+                                                logs=logs, srs_tree=srs_tree, min_exp_count=inv_min_expand, ctx=ctx,
+                                                eager_tables=False)   # tables are consumed below, before any other scan
         finally:
             if own:
                 ctx.close()

@@ -153,20 +153,42 @@ def test_alignlift_device_tables(built, gpu_ctx):
             assert np.array_equal(a.t.begin[0], b.t.begin[0]) and np.array_equal(a.t.begin[1], b.t.begin[1])
 
 
-def test_batched_scan_equals_single(built, gpu_ctx):
-    d, lift, scans = load_case(gpu_ctx, 'inv_fwd')
+@pytest.mark.parametrize('native', [True, False])
+@pytest.mark.parametrize('case', INV_CASES)
+def test_batched_scan_vs_reference(built, gpu_ctx, case, native):
+    """scan_for_inv_batch (native C++ driver in the library, and the Python state machine) on every flagged region of
+    every golden case, grouped by keyword arguments: logs, None / InvCall, regions, BED rows and tables equal the
+    reference's sequential results."""
+    d, lift, scans = load_case(gpu_ctx, case)
     k_util = KmerUtil(31)
-    recs = [r for r in scans if not r['kwargs']]
-    regions = [pavseq.Region(r['flag']['chrom'], r['flag']['pos'], r['flag']['end']) for r in recs]
-    logs = [io.StringIO() for _ in regions]
-    out = pavinv.scan_for_inv_batch(regions, os.path.join(d, 'ref.fa'), os.path.join(d, 'tig.fa'), lift, k_util, logs=logs,
-                                    ctx=gpu_ctx)
-    for rec, call, lg in zip(recs, out, logs):
-        assert lg.getvalue().splitlines() == rec['log']
-        if rec['call'] is None:
-            assert call is None
-        else:
-            check_call(d, rec, call)
+    groups = {}
+    for rec in scans:
+        groups.setdefault(json.dumps(rec['kwargs'], sort_keys=True), []).append(rec)
+    for key, recs in groups.items():
+        kwargs = json.loads(key)
+        regions = [pavseq.Region(r['flag']['chrom'], r['flag']['pos'], r['flag']['end']) for r in recs]
+        logs = [io.StringIO() for _ in regions]
+        out = pavinv.scan_for_inv_batch(regions, os.path.join(d, 'ref.fa'), os.path.join(d, 'tig.fa'), lift, k_util, logs=logs,
+                                        ctx=gpu_ctx, native=native, eager_tables=(len(recs) % 2 == 0), **kwargs)
+        for rec, call, lg in zip(recs, out, logs):
+            assert lg.getvalue().splitlines() == rec['log'], (rec['flag'], native)
+            if rec['call'] is None:
+                assert call is None
+            else:
+                check_call(d, rec, call)
+
+
+def test_lazy_table_expires_with_the_next_scan(built, gpu_ctx):
+    d, lift, scans = load_case(gpu_ctx, 'inv_small')
+    k_util = KmerUtil(31)
+    rec = [r for r in scans if r['call'] is not None][0]
+    region = pavseq.Region(rec['flag']['chrom'], rec['flag']['pos'], rec['flag']['end'])
+    args = (os.path.join(d, 'ref.fa'), os.path.join(d, 'tig.fa'), lift, k_util)
+    first = pavinv.scan_for_inv_batch([region], *args, ctx=gpu_ctx, eager_tables=False)[0]
+    second = pavinv.scan_for_inv_batch([region], *args, ctx=gpu_ctx, eager_tables=False)[0]
+    check_call(d, rec, second)
+    with pytest.raises(_lib.PavDeviceError):
+        first.df
 
 
 def test_rule_call_inv_batch_haplotype(built, gpu_ctx, tmp_path):
