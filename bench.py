@@ -181,12 +181,26 @@ def main():
             'walk_reduce': 4.0 * n_ops,
             'walk_emit': 4.0 * n_ops + 16.0 * n_snv + 2.0 * n_snv + 64.0 * n_indel,
             'homology_kernel': 128.0 * n_indel,
+            'snv_bases': 18.0 * n_snv,
             'seq_gather': 2.0 * counts.seq_bytes,
         }
+        # HBM traffic of the dominant kernel from the committed PMC summary of the same workload (profiles/r01_pmc.json;
+        # separate rocprofv3 --pmc passes).  FETCH_SIZE is doubled for the streaming pack kernel as the guide prescribes.
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r01_pmc.json')) as fh:
+                pmc = json.load(fh)
+            if pmc['workload']['aligned_bp_per_gpu'] == int(counts.aligned_bases):
+                kmax = max(kern, key=lambda k: kern[k]['avg_ms'] * kern[k]['launches'])
+                if kmax in pmc['fetch_kib'] and kmax in pmc['write_kib']:
+                    fx = 2.0 if kmax == 'pack_kernel' else 1.0
+                    traffic = (pmc['fetch_kib'][kmax] * fx + pmc['write_kib'][kmax]) * 1024.0
+        except (OSError, KeyError, ValueError):
+            traffic = None
         a_bytes = alg_bytes.get(dom, 0.0)
         achieved = a_bytes / (kern[dom]['avg_ms'] * 1e-3) / 1e9 if kern[dom]['avg_ms'] > 0 else 0.0
         roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                     'avg_kernel_ms': round(kern[dom]['avg_ms'], 4), 'algorithmic_bytes_per_launch': a_bytes,
                     'kernels_ms': {k: round(v['avg_ms'], 4) for k, v in sorted(kern.items())}}
 
