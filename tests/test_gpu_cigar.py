@@ -99,6 +99,24 @@ def test_public_entry_point(built, gpu_ctx, tmp_path):
         util.frame_text(g_snv.sort_values(['#CHROM', 'POS', 'END', 'ID']))
 
 
+def test_rule_outputs_equal_the_reference_rules(built, gpu_ctx, tmp_path):
+    """rules.call_cigar x 10 batches + rules.call_cigar_merge vs the text the reference's own rule bodies wrote
+    (tests/golden/rule_call_cigar, produced by executing rules/call.snakefile:755-846 unmodified): byte-identical."""
+    import gzip
+    d, df_align, df_trim = util.golden_case('cigar_synth')
+    ins, snvs = [], []
+    for batch in range(10):
+        o1, o2 = str(tmp_path / f'insdel_{batch}.bed.gz'), str(tmp_path / f'snv_{batch}.bed.gz')
+        rules.call_cigar(f'{d}/align.tsv', f'{d}/trim.tsv', f'{d}/tig.fa', f'{d}/ref.fa', 'h1', batch, o1, o2, ctx=gpu_ctx)
+        ins.append(o1)
+        snvs.append(o2)
+    m1, m2 = str(tmp_path / 'insdel.bed.gz'), str(tmp_path / 'snv.bed.gz')
+    rules.call_cigar_merge(ins, snvs, m1, m2)
+    for got, want in ((m1, 'insdel_merged'), (m2, 'snv_merged')):
+        with gzip.open(got, 'rt') as fh:
+            assert fh.read() == util.golden_text('rule_call_cigar', want)
+
+
 def test_empty_table(built, gpu_ctx):
     d, df_align, _ = util.golden_case('cigar_empty')
     _load_case(gpu_ctx, d)

@@ -220,6 +220,39 @@ def test_rule_call_inv_batch_haplotype(built, gpu_ctx, tmp_path):
             assert fh.read().splitlines() == want
 
 
+def test_rule_outputs_equal_the_reference_rule(built, gpu_ctx, tmp_path):
+    """rules.call_inv_batch x 2 + call_inv_batch_merge vs the files the reference's own rule bodies wrote
+    (tests/golden/rule_call_inv_batch: rules/call_inv.snakefile:94-311 executed unmodified): merged INV BED and both
+    logs byte-identical; every density table file has the same rows / columns and identical non-float fields."""
+    import gzip
+    d, lift, scans = load_case(gpu_ctx, 'inv_hap')
+    g = os.path.join(GOLD, 'rule_call_inv_batch')
+    beds = []
+    for batch in (0, 1):
+        out, lg = str(tmp_path / f'inv_call_{batch}.bed.gz'), str(tmp_path / f'inv_call_{batch}.log')
+        rules.call_inv_batch(os.path.join(d, 'flag.tsv'), os.path.join(d, 'align.tsv'), os.path.join(d, 'tig.fa'),
+                             os.path.join(d, 'tig.fa.fai'), os.path.join(d, 'ref.fa'), 'h1', batch, bed_out=out, log_path=lg,
+                             density_out_dir=str(tmp_path / 'density'), ctx=gpu_ctx)
+        beds.append(out)
+        with open(lg) as fh, open(os.path.join(g, f'log_{batch}.txt')) as gh:
+            assert fh.read() == gh.read()
+    merged = str(tmp_path / 'sv_inv.bed.gz')
+    rules.call_inv_batch_merge(beds, merged)
+    with gzip.open(merged, 'rt') as fh, open(os.path.join(g, 'inv_merged.tsv')) as gh:
+        assert fh.read() == gh.read()
+    with open(os.path.join(g, 'density_index.json')) as fh:
+        index = json.load(fh)
+    assert sorted(os.listdir(tmp_path / 'density')) == sorted(index)
+    for name, meta in index.items():
+        with gzip.open(tmp_path / 'density' / name, 'rt') as fh:
+            lines = fh.read().splitlines()
+        assert len(lines) - 1 == meta['rows'] and lines[0].split('\t') == meta['columns']
+        for a, b in zip(lines[1:3], meta['head'][1:3]):
+            fa, fb = a.split('\t'), b.split('\t')
+            assert [fa[i] for i in (0, 1, 2, 6, 7, 8)] == [fb[i] for i in (0, 1, 2, 6, 7, 8)]
+            assert np.allclose([float(fa[i]) for i in (3, 4, 5)], [float(fb[i]) for i in (3, 4, 5)], rtol=RTOL, atol=1e-300)
+
+
 def test_rule_call_inv_batch_files(built, gpu_ctx, tmp_path):
     """File contract of rule call_inv_batch: INV BED rows equal the reference rows; density tables are written."""
     d, lift, scans = load_case(gpu_ctx, 'inv_fwd')

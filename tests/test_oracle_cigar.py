@@ -49,3 +49,22 @@ def test_error_cases(built):
             cigarcall._raise_reference_error(err, df)
         assert type(ei.value).__name__ == e['type'], e['label']
         assert str(ei.value) == e['message'], e['label']
+
+
+def test_rule_outputs_equal_the_reference_rules(built):
+    """Oracle tables, split into the 10 CALL_BATCH groups and merged like rule call_cigar_merge, against the text the
+    reference's own rule bodies wrote (tests/golden/rule_call_cigar): byte-identical."""
+    import io
+    import pandas as pd
+    d, df_align, df_trim = util.golden_case('cigar_synth')
+    parts_snv, parts_ins = [], []
+    for batch in range(10):
+        sub = df_align.loc[df_align['CALL_BATCH'] == batch]
+        df_snv, df_insdel = util.oracle_frames(d, sub, df_trim)
+        # the rule writes each batch to disk and the merge rule reads it back (dtypes are re-inferred by read_csv)
+        for frames, part in ((parts_snv, df_snv), (parts_ins, df_insdel)):
+            frames.append(pd.read_csv(io.StringIO(util.frame_text(part)), sep='\t', keep_default_na=False))
+    snv = pd.concat(parts_snv, axis=0).reset_index(drop=True).sort_values(['#CHROM', 'POS'])
+    ins = pd.concat(parts_ins, axis=0).reset_index(drop=True).sort_values(['#CHROM', 'POS', 'END', 'ID'])
+    assert util.frame_text(ins) == util.golden_text('rule_call_cigar', 'insdel_merged')
+    assert util.frame_text(snv) == util.golden_text('rule_call_cigar', 'snv_merged')
