@@ -136,6 +136,23 @@ int pav_cigar_fetch(pav_ctx *ctx, pav_snv *snv, pav_indel *indel, uint8_t *seq_b
 /* Tokenised operations of the last pav_cigar_call: ops[i] = len << 4 | BAM opcode; op_off has n_aln + 1 entries. */
 int pav_cigar_fetch_ops(pav_ctx *ctx, uint32_t *ops, uint64_t *op_off);
 
+/* Native writer of the two tables rule call_cigar produces (rules/call.snakefile:813-846), straight from the records of
+ * the last pav_cigar_call: FILTER (PASS iff POS > trim.POS and END < trim.END of the row's ALIGN_INDEX), the row order of
+ * sort_values(['#CHROM','POS','END','ID']) (pavlib/cigarcall.py:320,343; SNV rows are sorted on the device) and the TSV
+ * text DataFrame.to_csv(sep='\t', index=False) writes, byte for byte.  Names ending in ".gz" are written as concatenated
+ * gzip members compressed in parallel.  Needs pav_seq_set_names for both stores. */
+typedef struct {
+    const char *hap;              /* HAP column                                                                    */
+    const int64_t *align_index;   /* [n_aln] INDEX of every row of the table given to pav_cigar_load               */
+    const int64_t *trim_pos;      /* [n_aln] POS of that INDEX in the trim-tigref table, -1 when absent            */
+    const int64_t *trim_end;      /* [n_aln] END ...; both NULL: no FILTER column (the function-level tables)      */
+    const char *snv_path;         /* NULL = skip                                                                   */
+    const char *insdel_path;      /* NULL = skip                                                                   */
+    int32_t gzip_level;           /* 1..9, 0 = 6                                                                   */
+    int32_t threads;              /* formatting / compression threads, 0 = auto                                    */
+} pav_table_opts;
+int pav_cigar_write_tables(pav_ctx *ctx, const pav_table_opts *opts, uint64_t *n_snv_rows, uint64_t *n_insdel_rows);
+
 /* Lift-over tables for pavlib.align.AlignLift (pavlib/align/lift.py:380-476, `_add_align`): tokenises every row's
  * CIGAR on the device and returns, per operation, the subject position where it starts (absolute, row POS included)
  * and the query position where it starts (alignment orientation, clipping included).  Advance rules are AlignLift's:

@@ -101,6 +101,12 @@ DEN_OK, DEN_UNFINALISED, DEN_FAIL = 0, 1, 125
 KDE_RUNS, KDE_DIRECT = 0, 1
 
 
+class TableOpts(ctypes.Structure):
+    _fields_ = [('hap', ctypes.c_char_p), ('align_index', ctypes.c_void_p), ('trim_pos', ctypes.c_void_p),
+                ('trim_end', ctypes.c_void_p), ('snv_path', ctypes.c_char_p), ('insdel_path', ctypes.c_char_p),
+                ('gzip_level', ctypes.c_int32), ('threads', ctypes.c_int32)]
+
+
 class CigarErr(ctypes.Structure):
     _fields_ = [('kind', ctypes.c_int32), ('aln', ctypes.c_uint32), ('op_index', ctypes.c_uint32),
                 ('op_char', ctypes.c_uint32), ('pos_ref', ctypes.c_uint32), ('pos_tig', ctypes.c_uint32)]
@@ -124,6 +130,7 @@ SYMBOLS = {
     'pav_cigar_error': (ctypes.c_int, [_P, _P]),
     'pav_cigar_fetch': (ctypes.c_int, [_P, _P, _P, _P]),
     'pav_cigar_fetch_ops': (ctypes.c_int, [_P, _P, _P]),
+    'pav_cigar_write_tables': (ctypes.c_int, [_P, _P, _P, _P]),
     'pav_align_index': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P]),
     'pav_homology': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P]),
     'pav_density_batch': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P]),
@@ -287,6 +294,20 @@ class Context:
         blob = np.empty(counts.seq_bytes, dtype=np.uint8)
         self._check(self.lib.pav_cigar_fetch(self.handle, _ptr(snv), _ptr(indel), _ptr(blob)), 'pav_cigar_fetch')
         return snv, indel, blob
+
+    def cigar_write_tables(self, hap, align_index, trim_pos=None, trim_end=None, snv_path=None, insdel_path=None,
+                           gzip_level=0, threads=0):
+        """Write the SNV / INS-DEL tables of the last cigar_call natively (sorted, FILTER, pandas-identical text)."""
+        align_index = np.ascontiguousarray(align_index, dtype=np.int64)
+        tp = None if trim_pos is None else np.ascontiguousarray(trim_pos, dtype=np.int64)
+        te = None if trim_end is None else np.ascontiguousarray(trim_end, dtype=np.int64)
+        opts = TableOpts(str(hap).encode(), align_index.ctypes.data, None if tp is None else tp.ctypes.data,
+                         None if te is None else te.ctypes.data, None if snv_path is None else str(snv_path).encode(),
+                         None if insdel_path is None else str(insdel_path).encode(), int(gzip_level), int(threads))
+        n1, n2 = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._check(self.lib.pav_cigar_write_tables(self.handle, ctypes.byref(opts), ctypes.byref(n1), ctypes.byref(n2)),
+                    'pav_cigar_write_tables')
+        return int(n1.value), int(n2.value)
 
     def cigar_fetch_ops(self, n_ops, n_aln):
         ops = np.empty(n_ops, dtype=np.uint32)

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void tok_emit(const uint8_t *__restrict__ text
         else if (code < 0) kind = PAV_CIGAR_ERR_UNKNOWN_OP;         // align.py:315
         else if (over || val >= (1ull << 28)) kind = PAV_CIGAR_ERR_LEN_OVERFLOW;
         if (kind) atomicMin(tok_err, (unsigned long long)(((uint64_t)(g + 1)) << 3 | (uint64_t)kind));
-        ops[ord] = kind ? 0x7u /* 0= : harmless */ : ((uint32_t)val << 4 | (uint32_t)code);
+        ops[ord] = kind ? 0x7u /* a zero-length '=' keeps the stream well formed; the call fails anyway */ : ((uint32_t)val << 4 | (uint32_t)code);
         ++ord;
     }
 }
@@ -450,9 +450,8 @@ __global__ __launch_bounds__(256) void lift_row_base(const uint32_t *__restrict_
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); }
     if (lane == 0) {
-        const uint64_t n_chunks_guard = c;            // chunk_pre has one entry per chunk; first == n_ops only for empty tails
-        rowbase[2ull * r] = chunk_pre[2ull * n_chunks_guard] + a;
-        rowbase[2ull * r + 1] = chunk_pre[2ull * n_chunks_guard + 1] + b;
+        rowbase[2ull * r] = chunk_pre[2ull * c] + a;          // chunk_pre[n_chunks] = grand total: rows that start at n_ops
+        rowbase[2ull * r + 1] = chunk_pre[2ull * c + 1] + b;
     }
 }
 

@@ -257,6 +257,8 @@ public:
     }
 };
 
+const std::vector<std::string> &seq_names(pav_ctx *ctx, int role) { return istate(ctx)->names[role]; }
+
 struct Scan {                       // per flagged region
     Rgn flag, region_ref, region_tig;
     int expansion_count = 0;
@@ -361,7 +363,7 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
 
     const uint64_t max_batch_bp = 64000000ull;
     const bool timing = getenv("PAV_TIMING") != nullptr;
-    double t_batch = 0, t_table = 0, t_annot = 0, t_lift = 0;
+    double t_batch = 0, t_table = 0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_start = now();
     while (!live.empty()) {
@@ -520,9 +522,8 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
         next.insert(next.end(), rest.begin(), rest.end());
         live.swap(next);
     }
-    (void)t_lift;
-    if (timing) fprintf(stderr, "[pav timing] inv_scan_batch %.1f ms: density_batch %.1f, tables %.1f, annotate %.1f\n",
-                        (now() - t_start) * 1e3, t_batch * 1e3, t_table * 1e3, t_annot * 1e3);
+    if (timing) fprintf(stderr, "[pav timing] inv_scan_batch %.1f ms: density_batch %.1f, call tables + annotate %.1f\n",
+                        (now() - t_start) * 1e3, t_batch * 1e3, t_table * 1e3);
     for (uint32_t i = 0; i < n_regions; ++i) {
         S->results[i].log_bytes = (uint32_t)S->logs[i].size();
         S->results[i].error_bytes = (uint32_t)S->errors[i].size();

@@ -1,0 +1,260 @@
+// Native writer for the two tables rule call_cigar produces (rules/call.snakefile:813-846): FILTER, the
+// (#CHROM, POS, END, ID) order of pavlib/cigarcall.py:320,343 and the TSV text pandas.to_csv writes - straight from the
+// record streams resident in HBM.  The Python mirror (pav_amd/cigarcall.records_to_frames) builds all-object DataFrames
+// like the reference does, which costs ~13 us per row (~90 s per haplotype); this writer produces byte-identical text at
+// memory speed and gzips it in parallel as concatenated members.
+//   device : sort keys of the SNV rows, stable radix sort (rocPRIM primitive), gather + FILTER
+//   host   : INDEL order (stable sort; ID tie-break on TYPE then on the decimal *string* of SVLEN), text, gzip (zlib)
+#include "common.h"
+
+#include <rocprim/rocprim.hpp>
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <thread>
+
+namespace pav {
+
+struct SnvOut { uint32_t aln, pos, qry_pos; uint8_t ref, alt, pass, pad; };
+
+__device__ __forceinline__ uint8_t up8(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }
+
+// key = chrom rank | POS | REF.upper() | ALT.upper(): the order of (#CHROM, POS, END = POS + 1, ID) for SNV rows
+__global__ __launch_bounds__(256) void snv_sort_keys(const pav_snv *__restrict__ snv, uint64_t n, const pav_aln *__restrict__ aln,
+                                                     const uint16_t *__restrict__ chrom_rank, unsigned long long *__restrict__ keys,
+                                                     uint32_t *__restrict__ vals) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const pav_snv s = snv[i];
+    const uint64_t rank = chrom_rank[aln[s.aln].ref_id];
+    keys[i] = rank << 48 | (uint64_t)s.pos << 16 | (uint64_t)up8(s.ref) << 8 | up8(s.alt);
+    vals[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void snv_gather(const pav_snv *__restrict__ snv, const uint32_t *__restrict__ order, uint64_t n,
+                                                  const long long *__restrict__ trim_pos, const long long *__restrict__ trim_end,
+                                                  SnvOut *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const pav_snv s = snv[order[i]];
+    SnvOut o;
+    o.aln = s.aln; o.pos = s.pos; o.qry_pos = s.qry_pos; o.ref = s.ref; o.alt = s.alt; o.pad = 0;
+    o.pass = 1;
+    if (trim_pos) o.pass = ((long long)s.pos > trim_pos[s.aln] && (long long)s.pos + 1 < trim_end[s.aln]) ? 1 : 0;   // call.snakefile:826-828
+    out[i] = o;
+}
+
+// ---- text ---------------------------------------------------------------------------------------------------
+static inline void put_u64(std::string &s, uint64_t v) {
+    char b[24]; int n = 0;
+    do { b[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) s.push_back(b[--n]);
+}
+static inline void put_i64(std::string &s, int64_t v) { if (v < 0) { s.push_back('-'); put_u64(s, (uint64_t)(-v)); } else put_u64(s, (uint64_t)v); }
+// csv.QUOTE_MINIMAL with delimiter '\t' and quotechar '"' (what DataFrame.to_csv uses)
+static std::string csv_field(const std::string &f) {
+    if (f.find_first_of("\t\"\n\r") == std::string::npos) return f;
+    std::string q = "\"";
+    for (char c : f) { if (c == '"') q += '"'; q += c; }
+    return q + "\"";
+}
+
+static bool gz_member(const std::string &in, int level, std::string &out) {
+    z_stream zs; memset(&zs, 0, sizeof zs);
+    if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    out.resize(deflateBound(&zs, (uLong)in.size()) + 64);
+    zs.next_in = (Bytef *)in.data(); zs.avail_in = (uInt)in.size();
+    zs.next_out = (Bytef *)&out[0]; zs.avail_out = (uInt)out.size();
+    const int rc = deflate(&zs, Z_FINISH);
+    out.resize(zs.total_out);
+    deflateEnd(&zs);
+    return rc == Z_STREAM_END;
+}
+
+// Format `n_rows` rows in chunks on `threads` workers, compress each chunk as one gzip member when the name ends in
+// ".gz", and write the chunks in order.
+template <class RowFn>
+static int write_table(pav_ctx *ctx, const char *path, const std::string &header, uint64_t n_rows, int threads, int level, RowFn row) {
+    const std::string p(path);
+    const bool gz = p.size() > 3 && p.compare(p.size() - 3, 3, ".gz") == 0;
+    const uint64_t chunk_rows = 1 << 16;
+    const uint64_t n_chunks = std::max<uint64_t>(1, (n_rows + chunk_rows - 1) / chunk_rows);
+    std::vector<std::string> done(n_chunks);
+    std::atomic<uint64_t> next{0};
+    std::atomic<bool> ok{true};
+    auto work = [&]() {
+        std::string text;
+        for (uint64_t c; (c = next.fetch_add(1)) < n_chunks;) {
+            text.clear();
+            if (c == 0) text = header;
+            const uint64_t a = c * chunk_rows, b = std::min(n_rows, a + chunk_rows);
+            text.reserve((size_t)(b - a) * 160 + header.size());
+            for (uint64_t i = a; i < b; ++i) row(i, text);
+            if (gz) { if (!gz_member(text, level, done[c])) ok = false; } else done[c].swap(text);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    if (!ok) return fail(ctx, PAV_E_ARG, "pav_cigar_write_tables: zlib failed for %s", path);
+    FILE *fh = fopen(path, "wb");
+    if (!fh) return fail(ctx, PAV_E_ARG, "pav_cigar_write_tables: cannot open %s", path);
+    for (const std::string &s : done) if (!s.empty() && fwrite(s.data(), 1, s.size(), fh) != s.size()) { fclose(fh); return fail(ctx, PAV_E_ARG, "pav_cigar_write_tables: short write to %s", path); }
+    fclose(fh);
+    return PAV_OK;
+}
+
+const std::vector<std::string> &seq_names(pav_ctx *ctx, int role);   // invscan.hip
+
+}  // namespace pav
+
+using namespace pav;
+
+extern "C" int pav_cigar_write_tables(pav_ctx *ctx, const pav_table_opts *o, uint64_t *n_snv_rows, uint64_t *n_insdel_rows) {
+    if (!ctx || !o || !o->hap || !o->align_index) return fail(ctx, PAV_E_ARG, "pav_cigar_write_tables: null argument");
+    if (!ctx->cigar_called) return fail(ctx, PAV_E_STATE, "pav_cigar_write_tables: no successful pav_cigar_call to write");
+    if ((o->trim_pos == nullptr) != (o->trim_end == nullptr)) return fail(ctx, PAV_E_ARG, "pav_cigar_write_tables: trim_pos and trim_end go together");
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint32_t n_aln = ctx->n_aln;
+    const uint64_t n_snv = ctx->counts.n_snv, n_ind = ctx->counts.n_indel;
+    const std::vector<std::string> &rnames = seq_names(ctx, PAV_ROLE_REF), &tnames = seq_names(ctx, PAV_ROLE_TIG);
+    const uint32_t n_ref = ctx->seq[PAV_ROLE_REF].n, n_tig = ctx->seq[PAV_ROLE_TIG].n;
+    if (rnames.size() != n_ref || tnames.size() != n_tig) return fail(ctx, PAV_E_STATE, "pav_cigar_write_tables: pav_seq_set_names has not been called for both stores");
+    if (n_ref > 65535) return fail(ctx, PAV_E_LIMIT, "pav_cigar_write_tables: more than 65535 reference records");
+    const bool with_filter = o->trim_pos != nullptr;
+    int threads = o->threads > 0 ? o->threads : (int)std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
+    const int level = o->gzip_level > 0 ? o->gzip_level : 6;
+
+    // #CHROM compares as Python str: rank of each record name in byte order
+    std::vector<uint32_t> by_name(n_ref);
+    for (uint32_t i = 0; i < n_ref; ++i) by_name[i] = i;
+    std::sort(by_name.begin(), by_name.end(), [&](uint32_t a, uint32_t b) { return rnames[a] < rnames[b]; });
+    std::vector<uint16_t> rank(n_ref);
+    for (uint32_t i = 0; i < n_ref; ++i) rank[by_name[i]] = (uint16_t)(i && rnames[by_name[i]] == rnames[by_name[i - 1]] ? rank[by_name[i - 1]] : i);
+
+    std::vector<pav_aln> aln(n_aln);
+    if (n_aln) PAV_HIP(ctx, hipMemcpyAsync(aln.data(), ctx->d_aln.p, sizeof(pav_aln) * n_aln, hipMemcpyDeviceToHost, st));
+
+    // ---- SNV rows: device sort + gather + FILTER ------------------------------------------------------------
+    std::vector<SnvOut> snv(n_snv);
+    if (n_snv && o->snv_path) {
+        size_t tmp_bytes = 0;
+        unsigned long long *kin = nullptr, *kout = nullptr; uint32_t *vin = nullptr, *vout = nullptr;
+        PAV_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, kin, kout, vin, vout, (size_t)n_snv, 0, 64, st));
+        const size_t need = 2 * 8 * n_snv + 2 * 4 * n_snv + tmp_bytes + sizeof(SnvOut) * n_snv + 2 * n_ref + 16 * (size_t)n_aln + 1024;
+        PAV_HIP(ctx, ctx->d_tmp.reserve(need));
+        uint8_t *p = ctx->d_tmp.as<uint8_t>();
+        kin = reinterpret_cast<unsigned long long *>(p); p += 8 * n_snv;
+        kout = reinterpret_cast<unsigned long long *>(p); p += 8 * n_snv;
+        SnvOut *d_out = reinterpret_cast<SnvOut *>(p); p += sizeof(SnvOut) * n_snv;
+        long long *d_tp = reinterpret_cast<long long *>(p); p += 8 * (size_t)n_aln;
+        long long *d_te = reinterpret_cast<long long *>(p); p += 8 * (size_t)n_aln;
+        vin = reinterpret_cast<uint32_t *>(p); p += 4 * n_snv;
+        vout = reinterpret_cast<uint32_t *>(p); p += 4 * n_snv;
+        uint16_t *d_rank = reinterpret_cast<uint16_t *>(p); p += (2 * (size_t)n_ref + 15) / 16 * 16;
+        void *d_sort_tmp = p;
+        PAV_HIP(ctx, hipMemcpyAsync(d_rank, rank.data(), 2 * (size_t)n_ref, hipMemcpyHostToDevice, st));
+        if (with_filter) {
+            PAV_HIP(ctx, hipMemcpyAsync(d_tp, o->trim_pos, 8 * (size_t)n_aln, hipMemcpyHostToDevice, st));
+            PAV_HIP(ctx, hipMemcpyAsync(d_te, o->trim_end, 8 * (size_t)n_aln, hipMemcpyHostToDevice, st));
+        }
+        PAV_LAUNCH(ctx, "snv_sort_keys", snv_sort_keys, (uint32_t)((n_snv + 255) / 256), 256, 0, ctx->d_snv.as<pav_snv>(), n_snv,
+                   ctx->d_aln.as<pav_aln>(), d_rank, kin, vin);
+        {
+            int tok = prof_begin(ctx, "rocprim::radix_sort_pairs");
+            hipError_t e = rocprim::radix_sort_pairs(d_sort_tmp, tmp_bytes, kin, kout, vin, vout, (size_t)n_snv, 0, 64, st);
+            prof_end(ctx, tok);
+            PAV_HIP(ctx, e);
+        }
+        PAV_LAUNCH(ctx, "snv_gather", snv_gather, (uint32_t)((n_snv + 255) / 256), 256, 0, ctx->d_snv.as<pav_snv>(), vout, n_snv,
+                   with_filter ? d_tp : nullptr, with_filter ? d_te : nullptr, d_out);
+        PAV_HIP(ctx, hipMemcpyAsync(snv.data(), d_out, sizeof(SnvOut) * n_snv, hipMemcpyDeviceToHost, st));
+    }
+    // ---- INDEL rows: records + SEQ blob to the host, stable sort there ------------------------------------------
+    std::vector<pav_indel> ind(n_ind);
+    std::vector<uint8_t> blob(ctx->counts.seq_bytes + 1);
+    if (n_ind && o->insdel_path) {
+        PAV_HIP(ctx, hipMemcpyAsync(ind.data(), ctx->d_indel.p, sizeof(pav_indel) * n_ind, hipMemcpyDeviceToHost, st));
+        if (ctx->counts.seq_bytes) PAV_HIP(ctx, hipMemcpyAsync(blob.data(), ctx->d_seqblob.p, ctx->counts.seq_bytes, hipMemcpyDeviceToHost, st));
+    }
+    PAV_HIP(ctx, hipStreamSynchronize(st));
+
+    const std::string hap = csv_field(o->hap);
+    std::vector<std::string> chrom_f(n_ref), tig_f(n_tig);          // quoted forms are only needed when a name has odd characters
+    bool odd_names = false;
+    for (uint32_t i = 0; i < n_ref; ++i) { chrom_f[i] = csv_field(rnames[i]); odd_names |= chrom_f[i] != rnames[i]; }
+    for (uint32_t i = 0; i < n_tig; ++i) { tig_f[i] = csv_field(tnames[i]); odd_names |= tig_f[i] != tnames[i]; }
+    auto field = [&](std::string &s, const std::string &plain) { if (odd_names) s += csv_field(plain); else s += plain; };
+
+    int rc = PAV_OK;
+    if (o->snv_path) {
+        std::string header = "#CHROM\tPOS\tEND\tID\tSVTYPE\tSVLEN\tREF\tALT\tHAP\tQRY_REGION\tQRY_STRAND\tCI\tALIGN_INDEX\tCALL_SOURCE";
+        header += with_filter ? "\tFILTER\n" : "\n";
+        rc = write_table(ctx, o->snv_path, header, n_snv, threads, level, [&](uint64_t i, std::string &s) {
+            const SnvOut &r = snv[i];
+            const pav_aln &a = aln[r.aln];
+            const std::string &chrom = rnames[a.ref_id];
+            s += chrom_f[a.ref_id]; s += '\t'; put_u64(s, r.pos); s += '\t'; put_u64(s, (uint64_t)r.pos + 1); s += '\t';
+            std::string id = chrom; id += '-'; put_u64(id, (uint64_t)r.pos + 1); id += "-SNV-";
+            id += (char)((r.ref >= 'a' && r.ref <= 'z') ? r.ref - 32 : r.ref); id += (char)((r.alt >= 'a' && r.alt <= 'z') ? r.alt - 32 : r.alt);
+            field(s, id);
+            s += "\tSNV\t1\t"; s += (char)r.ref; s += '\t'; s += (char)r.alt; s += '\t'; s += hap; s += '\t';
+            std::string q = tnames[a.tig_id]; q += ':'; put_u64(q, (uint64_t)r.qry_pos + 1); q += '-'; put_u64(q, (uint64_t)r.qry_pos + 1);
+            field(s, q);
+            s += a.rev ? "\t-\t0\t" : "\t+\t0\t";
+            put_i64(s, o->align_index[r.aln]);
+            s += "\tCIGAR";
+            if (with_filter) s += r.pass ? "\tPASS" : "\tTRIM";
+            s += '\n';
+        });
+        if (rc != PAV_OK) return rc;
+    }
+    if (o->insdel_path) {
+        std::vector<uint32_t> order(n_ind);
+        for (uint64_t i = 0; i < n_ind; ++i) order[i] = (uint32_t)i;
+        auto dec = [](uint32_t v) { char b[16]; int n = snprintf(b, sizeof b, "%u", v); return std::string(b, (size_t)n); };
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+            const pav_indel &p = ind[x], &q = ind[y];
+            const uint16_t rp = rank[aln[p.aln].ref_id], rq = rank[aln[q.aln].ref_id];
+            if (rp != rq) return rp < rq;
+            if (p.pos != q.pos) return p.pos < q.pos;
+            if (p.end != q.end) return p.end < q.end;
+            if (p.svtype != q.svtype) return p.svtype > q.svtype;            // 'DEL' < 'INS' (svtype 1 = DEL)
+            if (p.svlen != q.svlen) return dec(p.svlen) < dec(q.svlen);      // ID compares the decimal strings
+            return false;
+        });
+        std::string header = "#CHROM\tPOS\tEND\tID\tSVTYPE\tSVLEN\tHAP\tQRY_REGION\tQRY_STRAND\tCI\tALIGN_INDEX\tLEFT_SHIFT\tHOM_REF\tHOM_TIG\tCALL_SOURCE\tSEQ";
+        header += with_filter ? "\tFILTER\n" : "\n";
+        rc = write_table(ctx, o->insdel_path, header, n_ind, threads, level, [&](uint64_t i, std::string &s) {
+            const pav_indel &r = ind[order[i]];
+            const pav_aln &a = aln[r.aln];
+            const std::string &chrom = rnames[a.ref_id];
+            const char *type = r.svtype == 0 ? "INS" : "DEL";
+            s += chrom_f[a.ref_id]; s += '\t'; put_u64(s, r.pos); s += '\t'; put_u64(s, r.end); s += '\t';
+            std::string id = chrom; id += '-'; put_u64(id, (uint64_t)r.pos + 1); id += '-'; id += type; id += '-'; put_u64(id, r.svlen);
+            field(s, id);
+            s += '\t'; s += type; s += '\t'; put_u64(s, r.svlen); s += '\t'; s += hap; s += '\t';
+            std::string q = tnames[a.tig_id]; q += ':'; put_u64(q, (uint64_t)r.qry_pos + 1); q += '-'; put_u64(q, r.qry_end);
+            field(s, q);
+            s += a.rev ? "\t-\t0\t" : "\t+\t0\t";
+            put_i64(s, o->align_index[r.aln]); s += '\t';
+            put_u64(s, r.left_shift); s += '\t';
+            put_u64(s, r.hom_ref_l); s += ','; put_u64(s, r.hom_ref_r); s += '\t';
+            put_u64(s, r.hom_tig_l); s += ','; put_u64(s, r.hom_tig_r);
+            s += "\tCIGAR\t";
+            s.append(reinterpret_cast<const char *>(blob.data()) + r.seq_off, r.svlen);
+            if (with_filter) {
+                const bool pass = (long long)r.pos > o->trim_pos[r.aln] && (long long)r.end < o->trim_end[r.aln];   // call.snakefile:838-840
+                s += pass ? "\tPASS" : "\tTRIM";
+            }
+            s += '\n';
+        });
+        if (rc != PAV_OK) return rc;
+    }
+    if (n_snv_rows) *n_snv_rows = n_snv;
+    if (n_insdel_rows) *n_insdel_rows = n_ind;
+    return PAV_OK;
+}

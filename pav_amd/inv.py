@@ -147,7 +147,6 @@ class _Scan:
         self.done = False
         self.result = None
         self.error = None
-        self.pending = None            # set when the flanked region was found: needs table fetch + annotation
         _write_log('Scanning for inversions in flagged region: {} (flagged region record id = {})'.format(
             region_flag, region_flag.region_id()), log)
         self.df_fai = read_fai(ref_fa_name + '.fai')

@@ -33,6 +33,38 @@ def read_trim_bed(path):
     return pd.read_csv(path, sep='\t', usecols=['POS', 'END', 'INDEX'], index_col='INDEX').astype(int)
 
 
+def call_cigar_files(bed, bed_trim, tig_fa_name, ref_fa_name, hap, batch, bed_insdel, bed_snv, ctx=None, device_id=0,
+                     threads=0):
+    """Body of rule call_cigar with the library's native table writer: same files as :func:`call_cigar` (gunzipped text
+    byte-identical) without building DataFrames - FILTER, the sort order and the TSV text are produced by
+    ``pav_cigar_write_tables``.  Returns ``(n_snv_rows, n_insdel_rows)``."""
+    from . import _lib
+    batch = int(batch)
+    df_align = read_align_bed(bed)
+    df_align = df_align.loc[df_align['CALL_BATCH'] == batch]
+    df_trim = read_trim_bed(bed_trim)
+    own = ctx is None
+    if own:
+        ctx = _lib.Context(device_id)
+    try:
+        ref_names, tig_names = cigarcall.load_sequences(ctx, ref_fa_name, tig_fa_name, df_align)
+        aln, text, off = cigarcall.pack_alignments(df_align, ref_names, tig_names)
+        ctx.cigar_load(aln, text, off)
+        try:
+            ctx.cigar_call()
+        except _lib.CigarDeviceError as ex:
+            if ex.detail is None:
+                raise
+            cigarcall._raise_reference_error(ex.detail, df_align)
+        index = df_align['INDEX'].to_numpy(dtype='int64')
+        trim = df_trim.reindex(list(index), fill_value=-1)                         # absent INDEX => -1 => TRIM (:818-822)
+        return ctx.cigar_write_tables(hap, index, trim['POS'].to_numpy(dtype='int64'), trim['END'].to_numpy(dtype='int64'),
+                                      snv_path=bed_snv, insdel_path=bed_insdel, threads=threads)
+    finally:
+        if own:
+            ctx.close()
+
+
 def call_cigar(bed, bed_trim, tig_fa_name, ref_fa_name, hap, batch, bed_insdel=None, bed_snv=None, ctx=None,
                device_id=0):
     """Body of rule call_cigar.  Writes the two batch tables when output names are given; returns the frames."""

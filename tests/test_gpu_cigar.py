@@ -117,6 +117,66 @@ def test_rule_outputs_equal_the_reference_rules(built, gpu_ctx, tmp_path):
             assert fh.read() == util.golden_text('rule_call_cigar', want)
 
 
+@pytest.mark.parametrize('case', ['cigar_synth', 'cigar_edge', 'cigar_empty'])
+def test_native_table_writer_vs_reference_text(built, gpu_ctx, tmp_path, case):
+    """pav_cigar_write_tables (device sort + FILTER, native TSV text, parallel gzip members) against the text the
+    reference wrote: byte-identical after gunzip, plain and gzip'd output."""
+    import gzip
+    d, df_align, df_trim = util.golden_case(case)
+    _load_case(gpu_ctx, d)
+    cigarcall.call_records(gpu_ctx, df_align)
+    index = df_align['INDEX'].to_numpy(dtype='int64') if df_align.shape[0] else np.zeros(0, dtype=np.int64)
+    trim = df_trim.reindex(list(index), fill_value=-1)
+    with_filter = case != 'cigar_empty'            # the empty golden holds the function-level frames (no FILTER column)
+    kw = dict(trim_pos=trim['POS'].to_numpy(dtype='int64'), trim_end=trim['END'].to_numpy(dtype='int64')) if with_filter else {}
+    for ext in ('.tsv', '.tsv.gz'):
+        p_snv, p_ins = str(tmp_path / ('snv' + ext)), str(tmp_path / ('insdel' + ext))
+        gpu_ctx.cigar_write_tables('h1', index, snv_path=p_snv, insdel_path=p_ins, threads=3, **kw)
+        opener = gzip.open if ext.endswith('.gz') else open
+        with opener(p_snv, 'rt') as fh:
+            assert fh.read() == util.golden_text(case, 'snv')
+        with opener(p_ins, 'rt') as fh:
+            assert fh.read() == util.golden_text(case, 'insdel')
+
+
+def test_native_rule_files_equal_the_reference_rules(built, gpu_ctx, tmp_path):
+    """rules.call_cigar_files x 10 batches -> call_cigar_merge vs the reference rules' merged output."""
+    import gzip
+    d, df_align, df_trim = util.golden_case('cigar_synth')
+    ins, snvs = [], []
+    for batch in range(10):
+        o1, o2 = str(tmp_path / f'insdel_{batch}.bed.gz'), str(tmp_path / f'snv_{batch}.bed.gz')
+        rules.call_cigar_files(f'{d}/align.tsv', f'{d}/trim.tsv', f'{d}/tig.fa', f'{d}/ref.fa', 'h1', batch, o1, o2, ctx=gpu_ctx)
+        ins.append(o1)
+        snvs.append(o2)
+    m1, m2 = str(tmp_path / 'insdel.bed.gz'), str(tmp_path / 'snv.bed.gz')
+    rules.call_cigar_merge(ins, snvs, m1, m2)
+    for got, want in ((m1, 'insdel_merged'), (m2, 'snv_merged')):
+        with gzip.open(got, 'rt') as fh:
+            assert fh.read() == util.golden_text('rule_call_cigar', want)
+
+
+def test_native_writer_large_random(built, gpu_ctx, tmp_path):
+    """Seeded haplotype with sort ties (overlapping rows, dense inversion SNV runs): native text == pandas mirror text."""
+    hap = synth.config2(seed=23, scale=0.01, threads=4)
+    names = hap.ref.names
+    gpu_ctx.seq_load(_lib.PAV_ROLE_REF, names, [hap.ref.seqs[n] for n in names])
+    gpu_ctx.seq_load(_lib.PAV_ROLE_TIG, hap.tig_names, [hap.tig_seqs[n] for n in hap.tig_names])
+    snv, indel, blob, counts = cigarcall.call_records(gpu_ctx, hap.df_align)
+    df_trim = hap.df_trim[['POS', 'END', 'INDEX']].set_index('INDEX').astype(int)
+    df_snv, df_insdel = cigarcall.records_to_frames(snv, indel, blob, hap.df_align, 'h1')
+    df_snv = rules.apply_trim_filter(df_snv, df_trim)
+    df_insdel = rules.apply_trim_filter(df_insdel, df_trim)
+    index = hap.df_align['INDEX'].to_numpy(dtype='int64')
+    trim = df_trim.reindex(list(index), fill_value=-1)
+    p_snv, p_ins = str(tmp_path / 'snv.tsv'), str(tmp_path / 'insdel.tsv')
+    gpu_ctx.cigar_write_tables('h1', index, trim['POS'].to_numpy(dtype='int64'), trim['END'].to_numpy(dtype='int64'), p_snv, p_ins)
+    with open(p_snv) as fh:
+        assert fh.read() == util.frame_text(df_snv)
+    with open(p_ins) as fh:
+        assert fh.read() == util.frame_text(df_insdel)
+
+
 def test_empty_table(built, gpu_ctx):
     d, df_align, _ = util.golden_case('cigar_empty')
     _load_case(gpu_ctx, d)
