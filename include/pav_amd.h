@@ -319,6 +319,76 @@ int pav_inv_tables(pav_ctx *ctx, uint32_t n_regions, const uint64_t *row_off, in
                    int8_t *state, double *kern_fwd, double *kern_fwdrev, double *kern_rev, uint64_t *kmer, uint8_t *flank,
                    uint8_t *match);
 
+/* ---- inversion-signature flagging --------------------------------------- *
+ * Replaces the run: bodies of rules call_inv_cluster (rules/call_inv.snakefile:603-692),
+ * call_inv_flag_insdel_cluster (:480-599) and call_inv_merge_flagged_loci (:321-474).  The per-variant sweeps (cluster
+ * boundaries over millions of SNV / indel rows, the INS-against-DEL interval queries) run on the device; the merges of
+ * the few thousand resulting regions run on the host inside the library.  #CHROM is passed as a rank: the position of
+ * the chromosome name in Python str order, so that (chrom, POS) order here is sort_values(['#CHROM', 'POS']) there.
+ * Result arrays are owned by the library and stay valid until the next pav_flag_* / pav_cigar_flag call on the context. */
+typedef struct {            /* one row of a flag table: cluster_{snv,indel} (count = COUNT) or insdel_{sv,indel} (0)  */
+    uint32_t chrom;
+    uint32_t pad;
+    int64_t pos, end;
+    int64_t count;
+} pav_flag_rgn;
+
+enum { PAV_FLAG_MATCH_SV = 1, PAV_FLAG_MATCH_INDEL = 2, PAV_FLAG_CLUSTER_INDEL = 4, PAV_FLAG_CLUSTER_SNV = 8 };   /* TYPE */
+enum { PAV_SIG_SVINDEL = 0, PAV_SIG_SV = 1, PAV_SIG_SINGLE_CLUSTER = 2, PAV_SIG_NONE = 3 };   /* inv_sig_filter (:337-355) */
+
+typedef struct {            /* one row of flagged_regions_{hap}.bed.gz (:409-420)                                     */
+    uint32_t chrom;
+    uint32_t type_mask;     /* TYPE: PAV_FLAG_* bits                                                                  */
+    int64_t pos, end;       /* SVLEN = end - pos (may be <= 0: END is the END of the last row merged, :397)          */
+    int64_t count_indel, count_snv;
+    int32_t try_inv;        /* TRY_INV (_call_inv_accept_flagged_region, :56-79)                                      */
+    int32_t batch;          /* BATCH: round-robin over accepted rows, -1 otherwise (:458-466)                         */
+} pav_flag_locus;
+
+typedef struct {            /* config keys with the reference's defaults                                              */
+    int64_t cluster_win;            /* inv_sig_cluster_win 200 (:609); also the minimum span: the rule reads          */
+                                    /* params.cluster_win for cluster_win_min (:619), inv_sig_cluster_win_min is dead */
+    int64_t cluster_min_snv;        /* inv_sig_cluster_snv_min 20 (:611)                                              */
+    int64_t cluster_min_indel;      /* inv_sig_cluster_indel_min 10 (:612)                                            */
+    int64_t insdel_flank_cluster;   /* inv_sig_insdel_cluster_flank 2 (:486)                                          */
+    int64_t insdel_flank_merge;     /* inv_sig_insdel_merge_flank 2000 (:487)                                         */
+    int64_t insdel_min_svlen;       /* inv_sig_cluster_svlen_min 4 (:488); the SV table always uses 50 (:497)         */
+    int64_t merge_flank;            /* inv_sig_merge_flank 500 (:332)                                                 */
+    int32_t batch_count;            /* inv_sig_batch_count 60 (:81, :333)                                             */
+    int32_t sig_filter;             /* inv_sig_filter: PAV_SIG_*                                                      */
+} pav_flag_params;
+void pav_flag_params_default(pav_flag_params *p);
+
+/* Cluster sweep of rule call_inv_cluster (:646-684) over n rows given in the rule's iteration order (FILTER == PASS
+ * rows, sort_values(['#CHROM','POS']) on the original POS): midpoint = (END + POS) // 2; a row joins the open cluster
+ * when chrom matches and midpoint < previous midpoint + win; clusters with count >= min_count and
+ * last midpoint - first midpoint >= win_min are reported in order. */
+int pav_flag_cluster(pav_ctx *ctx, uint64_t n, const uint32_t *chrom, const int64_t *pos, const int64_t *end, int64_t win,
+                     int64_t win_min, int64_t min_count, const pav_flag_rgn **out, uint64_t *n_out);
+/* Matched INS / DEL of rule call_inv_flag_insdel_cluster (:517-596): for every INS the DELs of its chromosome that
+ * overlap [POS - SVLEN * flank_cluster, POS + SVLEN * flank_cluster) give one (min DEL POS, max DEL END) interval; the
+ * intervals are sorted and merged with flank_merge exactly as the rule does (the interval still open at the end of the
+ * loop is not written, :575-583).  Rows in any order. */
+int pav_flag_insdel(pav_ctx *ctx, uint64_t n_ins, const uint32_t *ins_chrom, const int64_t *ins_pos, const int64_t *ins_svlen,
+                    uint64_t n_del, const uint32_t *del_chrom, const int64_t *del_pos, const int64_t *del_end,
+                    int64_t flank_cluster, int64_t flank_merge, const pav_flag_rgn **out, uint64_t *n_out);
+/* Rule call_inv_merge_flagged_loci (:357-466) over the four flag tables, in the rule's concat order: insdel_sv,
+ * insdel_indel, cluster_indel, cluster_snv.  Host only. */
+int pav_flag_merge_loci(pav_ctx *ctx, const pav_flag_rgn *const tables[4], const uint64_t n[4], int64_t flank,
+                        int32_t batch_count, int32_t sig_filter, const pav_flag_locus **out, uint64_t *n_out);
+
+/* All three rules at once, straight from the records of the last pav_cigar_call (no tables in between): FILTER from the
+ * trim table as in pav_table_opts, chromosome ranks from pav_seq_set_names.  tables[] order as pav_flag_merge_loci. */
+typedef struct {
+    const pav_flag_rgn *tables[4];
+    uint64_t n[4];
+    const pav_flag_locus *loci;
+    uint64_t n_loci;
+    uint64_t n_snv_pass, n_indel_pass;      /* rows with FILTER == PASS                                              */
+} pav_flag_result;
+int pav_cigar_flag(pav_ctx *ctx, const int64_t *trim_pos, const int64_t *trim_end, const pav_flag_params *params,
+                   pav_flag_result *result);
+
 /* ---- profiling ---------------------------------------------------------------------------------------- *
  * HIP-event timing of every kernel the library launches on its stream (bench.py's roofline leg).         */
 int pav_prof_enable(pav_ctx *ctx, int on);

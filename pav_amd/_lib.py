@@ -107,6 +107,27 @@ class TableOpts(ctypes.Structure):
                 ('gzip_level', ctypes.c_int32), ('threads', ctypes.c_int32)]
 
 
+FLAG_RGN_DTYPE = np.dtype([('chrom', '<u4'), ('pad', '<u4'), ('pos', '<i8'), ('end', '<i8'), ('count', '<i8')])
+FLAG_LOCUS_DTYPE = np.dtype([('chrom', '<u4'), ('type_mask', '<u4'), ('pos', '<i8'), ('end', '<i8'), ('count_indel', '<i8'),
+                             ('count_snv', '<i8'), ('try_inv', '<i4'), ('batch', '<i4')])
+assert FLAG_RGN_DTYPE.itemsize == 32 and FLAG_LOCUS_DTYPE.itemsize == 48
+FLAG_MATCH_SV, FLAG_MATCH_INDEL, FLAG_CLUSTER_INDEL, FLAG_CLUSTER_SNV = 1, 2, 4, 8
+SIG_SVINDEL, SIG_SV, SIG_SINGLE_CLUSTER, SIG_NONE = 0, 1, 2, 3
+FLAG_TABLES = ('insdel_sv', 'insdel_indel', 'cluster_indel', 'cluster_snv')          # order of pav_flag_merge_loci
+
+
+class FlagParams(ctypes.Structure):
+    _fields_ = [('cluster_win', ctypes.c_int64), ('cluster_min_snv', ctypes.c_int64), ('cluster_min_indel', ctypes.c_int64),
+                ('insdel_flank_cluster', ctypes.c_int64), ('insdel_flank_merge', ctypes.c_int64),
+                ('insdel_min_svlen', ctypes.c_int64), ('merge_flank', ctypes.c_int64), ('batch_count', ctypes.c_int32),
+                ('sig_filter', ctypes.c_int32)]
+
+
+class FlagResult(ctypes.Structure):
+    _fields_ = [('tables', ctypes.c_void_p * 4), ('n', ctypes.c_uint64 * 4), ('loci', ctypes.c_void_p), ('n_loci', ctypes.c_uint64),
+                ('n_snv_pass', ctypes.c_uint64), ('n_indel_pass', ctypes.c_uint64)]
+
+
 class CigarErr(ctypes.Structure):
     _fields_ = [('kind', ctypes.c_int32), ('aln', ctypes.c_uint32), ('op_index', ctypes.c_uint32),
                 ('op_char', ctypes.c_uint32), ('pos_ref', ctypes.c_uint32), ('pos_tig', ctypes.c_uint32)]
@@ -148,6 +169,12 @@ SYMBOLS = {
     'pav_inv_tables': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'pav_kmer_rev_complement': (ctypes.c_uint64, [ctypes.c_uint64, ctypes.c_int]),
     'pav_kmer_canonical': (ctypes.c_uint64, [ctypes.c_uint64, ctypes.c_int]),
+    'pav_flag_params_default': (None, [_P]),
+    'pav_flag_cluster': (ctypes.c_int, [_P, ctypes.c_uint64, _P, _P, _P, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _P, _P]),
+    'pav_flag_insdel': (ctypes.c_int, [_P, ctypes.c_uint64, _P, _P, _P, ctypes.c_uint64, _P, _P, _P, ctypes.c_int64,
+                                       ctypes.c_int64, _P, _P]),
+    'pav_flag_merge_loci': (ctypes.c_int, [_P, _P, _P, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _P, _P]),
+    'pav_cigar_flag': (ctypes.c_int, [_P, _P, _P, _P, _P]),
     'pav_prof_enable': (ctypes.c_int, [_P, ctypes.c_int]),
     'pav_prof_reset': (ctypes.c_int, [_P]),
     'pav_prof_count': (ctypes.c_int, [_P]),
@@ -308,6 +335,64 @@ class Context:
         self._check(self.lib.pav_cigar_write_tables(self.handle, ctypes.byref(opts), ctypes.byref(n1), ctypes.byref(n2)),
                     'pav_cigar_write_tables')
         return int(n1.value), int(n2.value)
+
+    # ---- inversion-signature flagging ---------------------------------------------------------------------------
+    @staticmethod
+    def _copy_out(ptr, n, dtype):
+        n = int(n)
+        if not n:
+            return np.empty(0, dtype=dtype)
+        buf = (ctypes.c_uint8 * (n * dtype.itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+    def flag_params(self, **kw):
+        p = FlagParams()
+        self.lib.pav_flag_params_default(ctypes.byref(p))
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise TypeError(f'unknown flag parameter {k}')
+            setattr(p, k, int(v))
+        return p
+
+    def flag_cluster(self, chrom, pos, end, win, win_min, min_count):
+        chrom = np.ascontiguousarray(chrom, dtype=np.uint32)
+        pos = np.ascontiguousarray(pos, dtype=np.int64)
+        end = np.ascontiguousarray(end, dtype=np.int64)
+        out, n = ctypes.c_void_p(0), ctypes.c_uint64(0)
+        self._check(self.lib.pav_flag_cluster(self.handle, len(chrom), _ptr(chrom), _ptr(pos), _ptr(end), int(win), int(win_min),
+                                              int(min_count), ctypes.byref(out), ctypes.byref(n)), 'pav_flag_cluster')
+        return self._copy_out(out.value, n.value, FLAG_RGN_DTYPE)
+
+    def flag_insdel(self, ins_chrom, ins_pos, ins_svlen, del_chrom, del_pos, del_end, flank_cluster, flank_merge):
+        a = [np.ascontiguousarray(ins_chrom, dtype=np.uint32), np.ascontiguousarray(ins_pos, dtype=np.int64),
+             np.ascontiguousarray(ins_svlen, dtype=np.int64), np.ascontiguousarray(del_chrom, dtype=np.uint32),
+             np.ascontiguousarray(del_pos, dtype=np.int64), np.ascontiguousarray(del_end, dtype=np.int64)]
+        out, n = ctypes.c_void_p(0), ctypes.c_uint64(0)
+        self._check(self.lib.pav_flag_insdel(self.handle, len(a[0]), _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), len(a[3]), _ptr(a[3]),
+                                             _ptr(a[4]), _ptr(a[5]), int(flank_cluster), int(flank_merge), ctypes.byref(out),
+                                             ctypes.byref(n)), 'pav_flag_insdel')
+        return self._copy_out(out.value, n.value, FLAG_RGN_DTYPE)
+
+    def flag_merge_loci(self, tables, flank, batch_count, sig_filter):
+        """tables: four FLAG_RGN_DTYPE arrays in FLAG_TABLES order."""
+        tabs = [np.ascontiguousarray(t, dtype=FLAG_RGN_DTYPE) for t in tables]
+        ptrs = (ctypes.c_void_p * 4)(*[t.ctypes.data if len(t) else None for t in tabs])
+        ns = (ctypes.c_uint64 * 4)(*[len(t) for t in tabs])
+        out, n = ctypes.c_void_p(0), ctypes.c_uint64(0)
+        self._check(self.lib.pav_flag_merge_loci(self.handle, ptrs, ns, int(flank), int(batch_count), int(sig_filter), ctypes.byref(out),
+                                                 ctypes.byref(n)), 'pav_flag_merge_loci')
+        return self._copy_out(out.value, n.value, FLAG_LOCUS_DTYPE)
+
+    def cigar_flag(self, trim_pos, trim_end, params=None):
+        """All flag tables + flagged loci from the records of the last cigar_call: -> (dict of tables, loci, counts)."""
+        tp = np.ascontiguousarray(trim_pos, dtype=np.int64)
+        te = np.ascontiguousarray(trim_end, dtype=np.int64)
+        params = params if params is not None else self.flag_params()
+        res = FlagResult()
+        self._check(self.lib.pav_cigar_flag(self.handle, _ptr(tp), _ptr(te), ctypes.byref(params), ctypes.byref(res)), 'pav_cigar_flag')
+        tables = {name: self._copy_out(res.tables[i], res.n[i], FLAG_RGN_DTYPE) for i, name in enumerate(FLAG_TABLES)}
+        loci = self._copy_out(res.loci, res.n_loci, FLAG_LOCUS_DTYPE)
+        return tables, loci, {'n_snv_pass': int(res.n_snv_pass), 'n_indel_pass': int(res.n_indel_pass)}
 
     def cigar_fetch_ops(self, n_ops, n_aln):
         ops = np.empty(n_ops, dtype=np.uint32)

@@ -89,6 +89,7 @@ struct pav_ctx {
     // density state lives in density.hip (opaque here)
     void *density = nullptr;
     void *invscan = nullptr;              // native scan driver state (invscan.hip)
+    void *flag = nullptr;                 // flagging scratch + results (flag.hip)
 
     // profiling
     bool prof_on = false;

@@ -1,0 +1,540 @@
+// Inversion-signature flagging: rules call_inv_cluster, call_inv_flag_insdel_cluster and
+// call_inv_merge_flagged_loci of rules/call_inv.snakefile:321-692.
+//
+// The reference walks every SNV / indel row with DataFrame.iterrows(); here the per-row work is data parallel:
+//   * cluster sweep: "does row j open a new cluster" depends only on rows j-1 and j (the open cluster's end is always the
+//     previous row's midpoint, :653-672), so every row that closes a cluster finds its opening row by a backward search
+//     (serial for short clusters, one wave per cluster for long ones) and reports the cluster if it qualifies;
+//   * INS / DEL matching: the interval-tree query of :517-534 becomes two binary searches over the DELs sorted by
+//     (chrom, POS) and a running maximum of END (the rank in the upper bits makes the maximum restart per chromosome).
+// The merges of the resulting few thousand intervals are sequential by definition and run on the host, quirks included.
+#include "common.h"
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+
+namespace pav {
+
+const std::vector<std::string> &seq_names(pav_ctx *ctx, int role);   // invscan.hip
+
+namespace {
+
+constexpr int CM_SHIFT = 40;                                  // cluster key = chrom rank << 40 | midpoint
+constexpr uint64_t CM_MID = (1ull << CM_SHIFT) - 1;
+constexpr int SERIAL_STEPS = 32;
+
+struct ClusterHit { uint64_t start; int64_t pos, end, count; uint32_t chrom, pad; };   // 40 B
+struct MatchHit { uint64_t key; int64_t end; };                                        // key = chrom << 32 | POS
+
+struct FlagState {
+    DevBuf a, b, c, d, tmp, hits, cnt, small;
+    std::vector<pav_flag_rgn> table[4];                       // insdel_sv, insdel_indel, cluster_indel, cluster_snv
+    std::vector<pav_flag_rgn> single;                         // result of the array-level entry points
+    std::vector<pav_flag_locus> loci;
+};
+
+FlagState *fstate(pav_ctx *ctx) {
+    if (!ctx->flag) ctx->flag = new FlagState();
+    return static_cast<FlagState *>(ctx->flag);
+}
+
+// ---- cluster sweep ---------------------------------------------------------------------------------------------------
+
+// True when row j (>= 1) does not join the cluster of row j - 1 (:653).
+__device__ __forceinline__ bool opens_cluster(const uint64_t *__restrict__ cm, uint64_t j, int64_t win) {
+    const uint64_t a = cm[j - 1], b = cm[j];
+    return (a >> CM_SHIFT) != (b >> CM_SHIFT) || (int64_t)(b & CM_MID) >= (int64_t)(a & CM_MID) + win;
+}
+
+__global__ __launch_bounds__(256) void k_cluster_sweep(const uint64_t *__restrict__ cm, uint64_t n, int64_t win, int64_t win_min,
+                                                       int64_t min_count, ClusterHit *__restrict__ hits,
+                                                       unsigned long long *__restrict__ n_hits, uint64_t cap) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const bool closes = i < n && (i + 1 == n || opens_cluster(cm, i + 1, win));
+    uint64_t j = i;
+    bool found = !closes;
+    if (closes) {
+        for (int s = 0; s < SERIAL_STEPS; ++s) {
+            if (j == 0 || opens_cluster(cm, j, win)) { found = true; break; }
+            --j;
+        }
+    }
+    // long clusters: the whole wave scans 64 rows per step for one lane at a time
+    unsigned long long pending = __ballot(!found);
+    while (pending) {
+        const int src = __ffsll((long long)pending) - 1;
+        unsigned long long jj = __shfl((unsigned long long)j, src);
+        unsigned long long start;
+        for (;;) {
+            bool hit = false;
+            if (jj >= (unsigned long long)lane) {
+                const uint64_t c = jj - lane;
+                hit = c == 0 || opens_cluster(cm, c, win);
+            }
+            const unsigned long long m = __ballot(hit);
+            if (m) { start = jj - (unsigned long long)(__ffsll((long long)m) - 1); break; }
+            jj -= WAVE;                                        // no hit => no lane saw row 0 => jj >= 64
+        }
+        if (lane == src) { j = start; found = true; }
+        pending &= pending - 1;
+    }
+    if (closes) {
+        const int64_t count = (int64_t)(i - j) + 1;
+        const int64_t pos = (int64_t)(cm[j] & CM_MID), end = (int64_t)(cm[i] & CM_MID);
+        if (count >= min_count && end - pos >= win_min) {
+            const unsigned long long slot = atomicAdd(n_hits, 1ull);
+            if (slot < cap) hits[slot] = ClusterHit{j, pos, end, count, (uint32_t)(cm[i] >> CM_SHIFT), 0};
+        }
+    }
+}
+
+// ---- keys from the device-resident call records ---------------------------------------------------------------------
+
+constexpr uint64_t SNV_SENTINEL = (1ull << 56) - 1;          // FILTER != PASS rows sort behind every chromosome
+constexpr uint64_t IND_SENTINEL = (1ull << 54) - 1;
+
+__device__ __forceinline__ void wave_count(bool flag, unsigned long long *counter) {
+    const unsigned long long m = __ballot(flag);
+    if (m && (threadIdx.x & (WAVE - 1)) == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(counter, (unsigned long long)__popcll(m));
+}
+
+// cluster key of every SNV row: rank << 40 | POS (the midpoint of [POS, POS + 1) is POS).
+__global__ __launch_bounds__(256) void k_snv_keys(const pav_snv *__restrict__ snv, uint64_t n, const pav_aln *__restrict__ aln,
+                                                  const uint16_t *__restrict__ rank, const long long *__restrict__ tpos,
+                                                  const long long *__restrict__ tend, unsigned long long *__restrict__ keys,
+                                                  unsigned long long *__restrict__ n_pass) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    bool pass = false;
+    if (i < n) {
+        const pav_snv s = snv[i];
+        pass = (long long)s.pos > tpos[s.aln] && (long long)s.pos + 1 < tend[s.aln];
+        keys[i] = pass ? ((unsigned long long)rank[aln[s.aln].ref_id] << CM_SHIFT | s.pos) : SNV_SENTINEL;
+    }
+    wave_count(pass, n_pass);
+}
+
+// cluster key of every indel row < 50 bp: rank << 38 | POS << 6 | (END - POS): the (#CHROM, POS, END) order of the table.
+__global__ __launch_bounds__(256) void k_indel_keys(const pav_indel *__restrict__ ind, uint64_t n, const pav_aln *__restrict__ aln,
+                                                    const uint16_t *__restrict__ rank, const long long *__restrict__ tpos,
+                                                    const long long *__restrict__ tend, unsigned long long *__restrict__ keys,
+                                                    unsigned long long *__restrict__ counters) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    bool pass = false, small = false;
+    if (i < n) {
+        const pav_indel v = ind[i];
+        pass = (long long)v.pos > tpos[v.aln] && (long long)v.end < tend[v.aln];
+        small = pass && v.svlen < 50;
+        keys[i] = small ? ((unsigned long long)rank[aln[v.aln].ref_id] << 38 | (unsigned long long)v.pos << 6 | (v.end - v.pos))
+                        : IND_SENTINEL;
+    }
+    wave_count(pass, counters);
+    wave_count(small, counters + 1);
+}
+
+__global__ __launch_bounds__(256) void k_indel_mid(unsigned long long *__restrict__ keys, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long k = keys[i];
+    const unsigned long long pos = (k >> 6) & 0xffffffffull, dlen = k & 63;
+    keys[i] = (k >> 38) << CM_SHIFT | ((2 * pos + dlen) >> 1);            // (END + POS) // 2, :643
+}
+
+// INS queries and DEL intervals of one vartype (svlen in [lo, hi)), FILTER == PASS.
+__global__ __launch_bounds__(256) void k_insdel_split(const pav_indel *__restrict__ ind, uint64_t n, const pav_aln *__restrict__ aln,
+                                                      const uint16_t *__restrict__ rank, const long long *__restrict__ tpos,
+                                                      const long long *__restrict__ tend, uint32_t svlen_lo, uint32_t svlen_hi,
+                                                      unsigned long long *__restrict__ del_key, unsigned long long *__restrict__ del_end,
+                                                      unsigned long long *__restrict__ ins_key, unsigned long long *__restrict__ ins_len,
+                                                      unsigned long long *__restrict__ counters) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const pav_indel v = ind[i];
+    if (!((long long)v.pos > tpos[v.aln] && (long long)v.end < tend[v.aln])) return;
+    if (v.svlen < svlen_lo || v.svlen >= svlen_hi) return;
+    const unsigned long long r = rank[aln[v.aln].ref_id];
+    if (v.svtype == 1) {
+        const unsigned long long s = atomicAdd(counters, 1ull);
+        del_key[s] = r << 32 | v.pos;
+        del_end[s] = r << 32 | v.end;
+    } else {
+        const unsigned long long s = atomicAdd(counters + 1, 1ull);
+        ins_key[s] = r << 32 | v.pos;
+        ins_len[s] = v.svlen;
+    }
+}
+
+// first index in [lo, hi) with a[i] >= x
+__device__ __forceinline__ uint64_t lower_bound_u64(const unsigned long long *__restrict__ a, uint64_t lo, uint64_t hi, unsigned long long x) {
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (a[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// del_key sorted; del_max[i] = max over rows <= i of (rank << 32 | END).  One INS per thread (:520-534).
+__global__ __launch_bounds__(256) void k_ins_match(const unsigned long long *__restrict__ ins_key, const unsigned long long *__restrict__ ins_len,
+                                                   uint64_t n_ins, const unsigned long long *__restrict__ del_key,
+                                                   const unsigned long long *__restrict__ del_max, uint64_t n_del, long long flank_cluster,
+                                                   MatchHit *__restrict__ hits, unsigned long long *__restrict__ n_hits) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_ins) return;
+    const unsigned long long r = ins_key[i] >> 32;
+    const long long pos = (long long)(ins_key[i] & 0xffffffffull), flank = (long long)ins_len[i] * flank_cluster;
+    const long long lo = pos - flank, hi = pos + flank;        // DEL overlaps when DEL.POS < hi and DEL.END > lo
+    if (hi <= lo || hi <= 0) return;
+    const uint64_t seg = lower_bound_u64(del_key, 0, n_del, r << 32);
+    const uint64_t j = hi > 0xffffffffll ? lower_bound_u64(del_key, seg, n_del, (r + 1) << 32)
+                                         : lower_bound_u64(del_key, seg, n_del, r << 32 | (unsigned long long)hi);
+    if (j == seg) return;
+    const long long max_end = (long long)(del_max[j - 1] & 0xffffffffull);
+    if (max_end <= lo) return;
+    uint64_t first = seg;
+    if (lo >= 0) first = lower_bound_u64(del_max, seg, j, (r << 32 | (unsigned long long)lo) + 1);   // first running max > lo
+    const unsigned long long s = atomicAdd(n_hits, 1ull);
+    hits[s] = MatchHit{r << 32 | (del_key[first] & 0xffffffffull), max_end};
+}
+
+// ---- host: the sequential merges ---------------------------------------------------------------------------------------
+
+// :538-596.  Sorted by (chrom, POS); the interval open when the loop ends is never appended.
+void merge_matches(std::vector<MatchHit> &m, int64_t flank_merge, std::vector<pav_flag_rgn> &out) {
+    out.clear();
+    std::sort(m.begin(), m.end(), [](const MatchHit &x, const MatchHit &y) { return x.key != y.key ? x.key < y.key : x.end < y.end; });
+    bool have = false;
+    uint32_t chrom = 0;
+    int64_t pos = 0, end = 0;
+    for (const MatchHit &h : m) {
+        const uint32_t c = (uint32_t)(h.key >> 32);
+        const int64_t p = (int64_t)(h.key & 0xffffffffull);
+        if (!have || chrom != c) {
+            if (have) out.push_back(pav_flag_rgn{chrom, 0, pos, end, 0});
+            have = true; chrom = c; pos = p; end = h.end;
+        }
+        if (p - flank_merge <= end) {
+            end = std::max(end, h.end);
+        } else {
+            out.push_back(pav_flag_rgn{chrom, 0, pos, end, 0});
+            pos = p; end = h.end;
+        }
+    }
+}
+
+// :357-466
+void merge_loci(const pav_flag_rgn *const tables[4], const uint64_t n[4], int64_t flank, int32_t batch_count, int32_t sig_filter,
+                std::vector<pav_flag_locus> &out) {
+    static const uint32_t type_of[4] = {PAV_FLAG_MATCH_SV, PAV_FLAG_MATCH_INDEL, PAV_FLAG_CLUSTER_INDEL, PAV_FLAG_CLUSTER_SNV};
+    struct Row { uint32_t chrom, type; int64_t pos, end, n_indel, n_snv; };
+    std::vector<Row> rows;
+    for (int t = 0; t < 4; ++t)
+        for (uint64_t i = 0; i < n[t]; ++i) {
+            const pav_flag_rgn &r = tables[t][i];
+            rows.push_back(Row{r.chrom, type_of[t], r.pos, r.end, t == 2 ? r.count : 0, t == 3 ? r.count : 0});
+        }
+    std::stable_sort(rows.begin(), rows.end(), [](const Row &x, const Row &y) { return x.chrom != y.chrom ? x.chrom < y.chrom : x.pos < y.pos; });
+    out.clear();
+    bool have_chrom = false;
+    uint32_t chrom = 0, type = 0;
+    int64_t pos = 0, end = 0, n_indel = 0, n_snv = 0;
+    auto flush = [&]() { if (type) out.push_back(pav_flag_locus{chrom, type, pos, end, n_indel, n_snv, 0, -1}); };
+    for (const Row &r : rows) {
+        if (r.pos < end + flank && have_chrom && r.chrom == chrom) {
+            type |= r.type;
+            end = r.end;                                       // not the maximum (:397)
+            n_indel += r.n_indel;
+            n_snv += r.n_snv;
+        } else {
+            flush();
+            type = r.type; pos = r.pos; end = r.end; chrom = r.chrom; have_chrom = true;
+            n_indel = r.n_indel; n_snv = r.n_snv;
+        }
+    }
+    flush();
+    // df_merged.sort_values(['#CHROM', 'POS']) (:449): already in that order, and stable
+    const bool allow_single = sig_filter == PAV_SIG_SINGLE_CLUSTER;
+    const uint32_t match_any = sig_filter == PAV_SIG_SVINDEL ? (PAV_FLAG_MATCH_SV | PAV_FLAG_MATCH_INDEL)
+                             : sig_filter == PAV_SIG_SV ? PAV_FLAG_MATCH_SV : 0u;
+    int32_t batch = 0;
+    for (pav_flag_locus &l : out) {
+        bool ok = true;
+        if (!allow_single && (l.type_mask == PAV_FLAG_CLUSTER_SNV || l.type_mask == PAV_FLAG_CLUSTER_INDEL)) ok = false;
+        if (ok && match_any && !(l.type_mask & match_any)) ok = false;
+        l.try_inv = ok;
+        if (ok) { l.batch = batch; batch = (batch + 1) % batch_count; }
+    }
+}
+
+// ---- device drivers ----------------------------------------------------------------------------------------------------
+
+int sort_keys(pav_ctx *ctx, FlagState *S, unsigned long long *in, unsigned long long *out, uint64_t n, unsigned end_bit) {
+    size_t bytes = 0;
+    PAV_HIP(ctx, rocprim::radix_sort_keys(nullptr, bytes, in, out, (size_t)n, 0, end_bit, ctx->stream));
+    PAV_HIP(ctx, S->tmp.reserve(bytes + 16));
+    const int tok = prof_begin(ctx, "rocprim::radix_sort_keys");
+    const hipError_t e = rocprim::radix_sort_keys(S->tmp.p, bytes, in, out, (size_t)n, 0, end_bit, ctx->stream);
+    prof_end(ctx, tok);
+    PAV_HIP(ctx, e);
+    return PAV_OK;
+}
+
+// Sweep over n device-resident cluster keys; result rows in sweep order.
+int run_sweep(pav_ctx *ctx, FlagState *S, const unsigned long long *d_cm, uint64_t n, int64_t win, int64_t win_min, int64_t min_count,
+              std::vector<pav_flag_rgn> &out) {
+    out.clear();
+    if (!n) return PAV_OK;
+    const uint64_t cap = n / (uint64_t)std::max<int64_t>(min_count, 1) + 1;
+    PAV_HIP(ctx, S->hits.reserve(sizeof(ClusterHit) * cap));
+    PAV_HIP(ctx, S->cnt.reserve(64));
+    PAV_HIP(ctx, hipMemsetAsync(S->cnt.p, 0, 64, ctx->stream));
+    PAV_LAUNCH(ctx, "k_cluster_sweep", k_cluster_sweep, (uint32_t)((n + 255) / 256), 256, 0, (const uint64_t *)d_cm, n, win, win_min, min_count,
+               S->hits.as<ClusterHit>(), S->cnt.as<unsigned long long>(), cap);
+    unsigned long long n_hits = 0;
+    PAV_HIP(ctx, hipMemcpyAsync(&n_hits, S->cnt.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_hits > cap) return fail(ctx, PAV_E_LIMIT, "flag: cluster output overflow (%llu > %llu)", n_hits, (unsigned long long)cap);
+    std::vector<ClusterHit> hits(n_hits);
+    if (n_hits) PAV_HIP(ctx, hipMemcpy(hits.data(), S->hits.p, sizeof(ClusterHit) * n_hits, hipMemcpyDeviceToHost));
+    std::sort(hits.begin(), hits.end(), [](const ClusterHit &x, const ClusterHit &y) { return x.start < y.start; });
+    out.reserve(n_hits);
+    for (const ClusterHit &h : hits) out.push_back(pav_flag_rgn{h.chrom, 0, h.pos, h.end, h.count});
+    return PAV_OK;
+}
+
+// DELs (unsorted keys / rank-tagged ENDs in S->a / S->b) against INS (S->c keys, S->d lengths); result merged on the host.
+int run_match(pav_ctx *ctx, FlagState *S, uint64_t n_del, uint64_t n_ins, int64_t flank_cluster, int64_t flank_merge,
+              std::vector<pav_flag_rgn> &out) {
+    out.clear();
+    if (!n_del || !n_ins) return PAV_OK;
+    hipStream_t st = ctx->stream;
+    // sort DELs by (chrom, POS), carrying END; then the running maximum of rank << 32 | END
+    unsigned long long *k_in = S->a.as<unsigned long long>(), *v_in = S->b.as<unsigned long long>();
+    unsigned long long *k_out = k_in + n_del, *v_out = v_in + n_del;          // the buffers were sized 2 x n
+    size_t bytes = 0, bytes2 = 0;
+    PAV_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, k_in, k_out, v_in, v_out, (size_t)n_del, 0, 48, st));
+    PAV_HIP(ctx, rocprim::inclusive_scan(nullptr, bytes2, v_out, v_in, (size_t)n_del, rocprim::maximum<unsigned long long>(), st));
+    PAV_HIP(ctx, S->tmp.reserve(std::max(bytes, bytes2) + 16));
+    {
+        const int tok = prof_begin(ctx, "rocprim::radix_sort_pairs");
+        const hipError_t e = rocprim::radix_sort_pairs(S->tmp.p, bytes, k_in, k_out, v_in, v_out, (size_t)n_del, 0, 48, st);
+        prof_end(ctx, tok);
+        PAV_HIP(ctx, e);
+    }
+    {
+        const int tok = prof_begin(ctx, "rocprim::inclusive_scan");
+        const hipError_t e = rocprim::inclusive_scan(S->tmp.p, bytes2, v_out, v_in, (size_t)n_del, rocprim::maximum<unsigned long long>(), st);
+        prof_end(ctx, tok);
+        PAV_HIP(ctx, e);
+    }
+    PAV_HIP(ctx, S->hits.reserve(sizeof(MatchHit) * n_ins));
+    PAV_HIP(ctx, S->cnt.reserve(64));
+    PAV_HIP(ctx, hipMemsetAsync(S->cnt.p, 0, 64, st));
+    PAV_LAUNCH(ctx, "k_ins_match", k_ins_match, (uint32_t)((n_ins + 255) / 256), 256, 0, S->c.as<unsigned long long>(),
+               S->d.as<unsigned long long>(), n_ins, k_out, v_in, n_del, (long long)flank_cluster, S->hits.as<MatchHit>(),
+               S->cnt.as<unsigned long long>());
+    unsigned long long n_hits = 0;
+    PAV_HIP(ctx, hipMemcpyAsync(&n_hits, S->cnt.p, 8, hipMemcpyDeviceToHost, st));
+    PAV_HIP(ctx, hipStreamSynchronize(st));
+    std::vector<MatchHit> hits(n_hits);
+    if (n_hits) PAV_HIP(ctx, hipMemcpy(hits.data(), S->hits.p, sizeof(MatchHit) * n_hits, hipMemcpyDeviceToHost));
+    merge_matches(hits, flank_merge, out);
+    return PAV_OK;
+}
+
+}  // namespace
+}  // namespace pav
+
+using namespace pav;
+
+extern "C" {
+
+void pav_flag_release(pav_ctx *ctx) {
+    if (!ctx || !ctx->flag) return;
+    FlagState *S = static_cast<FlagState *>(ctx->flag);
+    DevBuf *bufs[] = {&S->a, &S->b, &S->c, &S->d, &S->tmp, &S->hits, &S->cnt, &S->small};
+    for (DevBuf *b : bufs) b->release();
+    delete S;
+    ctx->flag = nullptr;
+}
+
+void pav_flag_params_default(pav_flag_params *p) {
+    if (!p) return;
+    p->cluster_win = 200;
+    p->cluster_min_snv = 20;
+    p->cluster_min_indel = 10;
+    p->insdel_flank_cluster = 2;
+    p->insdel_flank_merge = 2000;
+    p->insdel_min_svlen = 4;
+    p->merge_flank = 500;
+    p->batch_count = 60;
+    p->sig_filter = PAV_SIG_SVINDEL;
+}
+
+int pav_flag_cluster(pav_ctx *ctx, uint64_t n, const uint32_t *chrom, const int64_t *pos, const int64_t *end, int64_t win,
+                     int64_t win_min, int64_t min_count, const pav_flag_rgn **out, uint64_t *n_out) {
+    if (!ctx || !out || !n_out || (n && (!chrom || !pos || !end))) return PAV_E_ARG;
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    FlagState *S = fstate(ctx);
+    std::vector<unsigned long long> cm(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        const int64_t s = end[i] + pos[i];
+        const int64_t mid = s >= 0 ? s / 2 : -((-s + 1) / 2);                 // Python floor division
+        if (mid < 0 || (uint64_t)mid > CM_MID || chrom[i] >= (1u << 24))
+            return fail(ctx, PAV_E_LIMIT, "pav_flag_cluster: row %llu outside the supported coordinate range", (unsigned long long)i);
+        cm[i] = (unsigned long long)chrom[i] << CM_SHIFT | (unsigned long long)mid;
+    }
+    if (n) {
+        PAV_HIP(ctx, S->a.reserve(8 * n));
+        PAV_HIP(ctx, hipMemcpyAsync(S->a.p, cm.data(), 8 * n, hipMemcpyHostToDevice, ctx->stream));
+    }
+    const int rc = run_sweep(ctx, S, S->a.as<unsigned long long>(), n, win, win_min, min_count, S->single);
+    if (rc != PAV_OK) return rc;
+    if (prof_flush(ctx) != PAV_OK) return PAV_E_HIP;
+    *out = S->single.data();
+    *n_out = S->single.size();
+    return PAV_OK;
+}
+
+int pav_flag_insdel(pav_ctx *ctx, uint64_t n_ins, const uint32_t *ins_chrom, const int64_t *ins_pos, const int64_t *ins_svlen,
+                    uint64_t n_del, const uint32_t *del_chrom, const int64_t *del_pos, const int64_t *del_end,
+                    int64_t flank_cluster, int64_t flank_merge, const pav_flag_rgn **out, uint64_t *n_out) {
+    if (!ctx || !out || !n_out || (n_ins && (!ins_chrom || !ins_pos || !ins_svlen)) || (n_del && (!del_chrom || !del_pos || !del_end)))
+        return PAV_E_ARG;
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    FlagState *S = fstate(ctx);
+    const int64_t lim = 0xffffffffll;
+    std::vector<unsigned long long> dk(n_del), de(n_del), ik(n_ins), il(n_ins);
+    for (uint64_t i = 0; i < n_del; ++i) {
+        if (del_pos[i] < 0 || del_pos[i] > lim || del_end[i] < 0 || del_end[i] > lim)
+            return fail(ctx, PAV_E_LIMIT, "pav_flag_insdel: DEL row %llu outside the supported coordinate range", (unsigned long long)i);
+        dk[i] = (unsigned long long)del_chrom[i] << 32 | (unsigned long long)del_pos[i];
+        de[i] = (unsigned long long)del_chrom[i] << 32 | (unsigned long long)del_end[i];
+    }
+    for (uint64_t i = 0; i < n_ins; ++i) {
+        if (ins_pos[i] < 0 || ins_pos[i] > lim || ins_svlen[i] < 0 || ins_svlen[i] > lim)
+            return fail(ctx, PAV_E_LIMIT, "pav_flag_insdel: INS row %llu outside the supported coordinate range", (unsigned long long)i);
+        ik[i] = (unsigned long long)ins_chrom[i] << 32 | (unsigned long long)ins_pos[i];
+        il[i] = (unsigned long long)ins_svlen[i];
+    }
+    if (n_del && n_ins) {
+        PAV_HIP(ctx, S->a.reserve(16 * n_del)); PAV_HIP(ctx, S->b.reserve(16 * n_del));
+        PAV_HIP(ctx, S->c.reserve(8 * n_ins)); PAV_HIP(ctx, S->d.reserve(8 * n_ins));
+        PAV_HIP(ctx, hipMemcpyAsync(S->a.p, dk.data(), 8 * n_del, hipMemcpyHostToDevice, ctx->stream));
+        PAV_HIP(ctx, hipMemcpyAsync(S->b.p, de.data(), 8 * n_del, hipMemcpyHostToDevice, ctx->stream));
+        PAV_HIP(ctx, hipMemcpyAsync(S->c.p, ik.data(), 8 * n_ins, hipMemcpyHostToDevice, ctx->stream));
+        PAV_HIP(ctx, hipMemcpyAsync(S->d.p, il.data(), 8 * n_ins, hipMemcpyHostToDevice, ctx->stream));
+    }
+    const int rc = run_match(ctx, S, n_del, n_ins, flank_cluster, flank_merge, S->single);
+    if (rc != PAV_OK) return rc;
+    if (prof_flush(ctx) != PAV_OK) return PAV_E_HIP;
+    *out = S->single.data();
+    *n_out = S->single.size();
+    return PAV_OK;
+}
+
+int pav_flag_merge_loci(pav_ctx *ctx, const pav_flag_rgn *const tables[4], const uint64_t n[4], int64_t flank, int32_t batch_count,
+                        int32_t sig_filter, const pav_flag_locus **out, uint64_t *n_out) {
+    if (!ctx || !tables || !n || !out || !n_out) return PAV_E_ARG;
+    if (batch_count <= 0) return fail(ctx, PAV_E_ARG, "pav_flag_merge_loci: batch_count must be positive");
+    if (sig_filter < PAV_SIG_SVINDEL || sig_filter > PAV_SIG_NONE) return fail(ctx, PAV_E_ARG, "pav_flag_merge_loci: unknown sig_filter %d", sig_filter);
+    for (int t = 0; t < 4; ++t) if (n[t] && !tables[t]) return PAV_E_ARG;
+    FlagState *S = fstate(ctx);
+    merge_loci(tables, n, flank, batch_count, sig_filter, S->loci);
+    *out = S->loci.data();
+    *n_out = S->loci.size();
+    return PAV_OK;
+}
+
+int pav_cigar_flag(pav_ctx *ctx, const int64_t *trim_pos, const int64_t *trim_end, const pav_flag_params *P, pav_flag_result *res) {
+    if (!ctx || !P || !res) return PAV_E_ARG;
+    if (ctx->n_aln && (!trim_pos || !trim_end)) return PAV_E_ARG;
+    if (!ctx->cigar_called) return fail(ctx, PAV_E_STATE, "pav_cigar_flag: no pav_cigar_call results on this context");
+    if (P->batch_count <= 0 || P->sig_filter < PAV_SIG_SVINDEL || P->sig_filter > PAV_SIG_NONE) return fail(ctx, PAV_E_ARG, "pav_cigar_flag: bad parameters");
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    FlagState *S = fstate(ctx);
+    hipStream_t st = ctx->stream;
+    const uint32_t n_aln = ctx->n_aln, n_ref = ctx->seq[PAV_ROLE_REF].n;
+    const uint64_t n_snv = ctx->counts.n_snv, n_ind = ctx->counts.n_indel;
+    const std::vector<std::string> &rnames = seq_names(ctx, PAV_ROLE_REF);
+    if (rnames.size() != n_ref) return fail(ctx, PAV_E_STATE, "pav_cigar_flag: pav_seq_set_names has not been called for the reference store");
+    if (n_ref > 65535) return fail(ctx, PAV_E_LIMIT, "pav_cigar_flag: more than 65535 reference records");
+    memset(res, 0, sizeof(*res));
+    for (auto &t : S->table) t.clear();
+    S->loci.clear();
+
+    // #CHROM compares as Python str: rank of each record name in byte order
+    std::vector<uint32_t> by_name(n_ref);
+    for (uint32_t i = 0; i < n_ref; ++i) by_name[i] = i;
+    std::sort(by_name.begin(), by_name.end(), [&](uint32_t x, uint32_t y) { return rnames[x] < rnames[y]; });
+    std::vector<uint16_t> rank(n_ref);
+    for (uint32_t i = 0; i < n_ref; ++i)
+        rank[by_name[i]] = (uint16_t)(i && rnames[by_name[i]] == rnames[by_name[i - 1]] ? rank[by_name[i - 1]] : i);
+
+    // small inputs: counters, trim table, ranks
+    PAV_HIP(ctx, S->small.reserve(64 + 16 * (size_t)n_aln + 2 * (size_t)n_ref + 64));
+    unsigned long long *d_cnt = S->small.as<unsigned long long>();
+    long long *d_tp = reinterpret_cast<long long *>(S->small.as<uint8_t>() + 64), *d_te = d_tp + n_aln;
+    uint16_t *d_rank = reinterpret_cast<uint16_t *>(d_te + n_aln);
+    PAV_HIP(ctx, hipMemsetAsync(d_cnt, 0, 64, st));
+    if (n_aln) {
+        PAV_HIP(ctx, hipMemcpyAsync(d_tp, trim_pos, 8 * (size_t)n_aln, hipMemcpyHostToDevice, st));
+        PAV_HIP(ctx, hipMemcpyAsync(d_te, trim_end, 8 * (size_t)n_aln, hipMemcpyHostToDevice, st));
+    }
+    if (n_ref) PAV_HIP(ctx, hipMemcpyAsync(d_rank, rank.data(), 2 * (size_t)n_ref, hipMemcpyHostToDevice, st));
+    const pav_aln *d_aln = ctx->d_aln.as<pav_aln>();
+    unsigned long long cnt[8] = {0};
+    int rc;
+
+    // ---- keys of both cluster tables, sorted into the rules' iteration order --------------------------------------------
+    if (n_snv) {
+        PAV_HIP(ctx, S->a.reserve(8 * n_snv)); PAV_HIP(ctx, S->b.reserve(8 * n_snv));
+        PAV_LAUNCH(ctx, "k_snv_keys", k_snv_keys, (uint32_t)((n_snv + 255) / 256), 256, 0, ctx->d_snv.as<pav_snv>(), n_snv, d_aln, d_rank,
+                   d_tp, d_te, S->a.as<unsigned long long>(), d_cnt);
+        if ((rc = sort_keys(ctx, S, S->a.as<unsigned long long>(), S->b.as<unsigned long long>(), n_snv, 56)) != PAV_OK) return rc;
+    }
+    if (n_ind) {
+        PAV_HIP(ctx, S->c.reserve(8 * n_ind)); PAV_HIP(ctx, S->d.reserve(8 * n_ind));
+        PAV_LAUNCH(ctx, "k_indel_keys", k_indel_keys, (uint32_t)((n_ind + 255) / 256), 256, 0, ctx->d_indel.as<pav_indel>(), n_ind, d_aln, d_rank,
+                   d_tp, d_te, S->c.as<unsigned long long>(), d_cnt + 1);
+        if ((rc = sort_keys(ctx, S, S->c.as<unsigned long long>(), S->d.as<unsigned long long>(), n_ind, 54)) != PAV_OK) return rc;
+    }
+    PAV_HIP(ctx, hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
+    PAV_HIP(ctx, hipStreamSynchronize(st));
+    const uint64_t snv_pass = cnt[0], ind_pass = cnt[1], ind_small = cnt[2];
+    res->n_snv_pass = snv_pass;
+    res->n_indel_pass = ind_pass;
+
+    // ---- cluster_snv, cluster_indel (vartype 'snv' / 'indel' of rule call_inv_cluster) -----------------------------------
+    if ((rc = run_sweep(ctx, S, S->b.as<unsigned long long>(), snv_pass, P->cluster_win, P->cluster_win, P->cluster_min_snv, S->table[3])) != PAV_OK) return rc;
+    if (ind_small) PAV_LAUNCH(ctx, "k_indel_mid", k_indel_mid, (uint32_t)((ind_small + 255) / 256), 256, 0, S->d.as<unsigned long long>(), ind_small);
+    if ((rc = run_sweep(ctx, S, S->d.as<unsigned long long>(), ind_small, P->cluster_win, P->cluster_win, P->cluster_min_indel, S->table[2])) != PAV_OK) return rc;
+
+    // ---- insdel_sv, insdel_indel (rule call_inv_flag_insdel_cluster) ----------------------------------------------------
+    if (ind_pass) {
+        PAV_HIP(ctx, S->a.reserve(16 * n_ind)); PAV_HIP(ctx, S->b.reserve(16 * n_ind));
+        PAV_HIP(ctx, S->c.reserve(8 * n_ind)); PAV_HIP(ctx, S->d.reserve(8 * n_ind));
+        for (int t = 0; t < 2; ++t) {
+            const int64_t lo64 = t == 0 ? 50 : P->insdel_min_svlen;                   // :497
+            const uint32_t lo = (uint32_t)std::min<int64_t>(std::max<int64_t>(lo64, 0), 0xffffffffll);
+            const uint32_t hi = t == 0 ? 0xffffffffu : 50u;                           // :504-505 (svlen is below 2^28)
+            PAV_HIP(ctx, hipMemsetAsync(d_cnt, 0, 64, st));
+            PAV_LAUNCH(ctx, "k_insdel_split", k_insdel_split, (uint32_t)((n_ind + 255) / 256), 256, 0, ctx->d_indel.as<pav_indel>(), n_ind, d_aln,
+                       d_rank, d_tp, d_te, lo, hi, S->a.as<unsigned long long>(), S->b.as<unsigned long long>(), S->c.as<unsigned long long>(),
+                       S->d.as<unsigned long long>(), d_cnt);
+            PAV_HIP(ctx, hipMemcpyAsync(cnt, d_cnt, 16, hipMemcpyDeviceToHost, st));
+            PAV_HIP(ctx, hipStreamSynchronize(st));
+            if ((rc = run_match(ctx, S, cnt[0], cnt[1], P->insdel_flank_cluster, P->insdel_flank_merge, S->table[t])) != PAV_OK) return rc;
+        }
+    }
+
+    // ---- flagged regions (rule call_inv_merge_flagged_loci) ----------------------------------------------------------------
+    for (int t = 0; t < 4; ++t) { res->tables[t] = S->table[t].data(); res->n[t] = S->table[t].size(); }
+    merge_loci(res->tables, res->n, P->merge_flank, P->batch_count, P->sig_filter, S->loci);
+    res->loci = S->loci.data();
+    res->n_loci = S->loci.size();
+    if (prof_flush(ctx) != PAV_OK) return PAV_E_HIP;
+    return PAV_OK;
+}
+
+}  // extern "C"

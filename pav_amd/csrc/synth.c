@@ -88,6 +88,8 @@ typedef struct {
     uint32_t max_indel;
     double tandem_frac;   /* fraction of insertions that copy the upstream bases */
     uint32_t clip;        /* hard-clipped bases on each end of the contig */
+    double pair_frac;     /* fraction of indel events emitted as a matched DEL + INS of equal length (signature the
+                             inversion flagging of rules/call_inv.snakefile:476-600 looks for); 0 keeps older seeds' output */
 } pavsynth_params;
 
 typedef struct { char *p; uint64_t n, cap; int overflow; } sbuf;
@@ -181,6 +183,17 @@ int pavsynth_contig(uint64_t seed, const uint8_t *ref, uint64_t ref_len, const p
         double lf = floor(pow(up, -1.0 / pp->pareto_alpha));
         uint64_t len = lf > (double)pp->max_indel ? pp->max_indel : (uint64_t)lf;
         if (len < 1) len = 1;
+        if (pp->pair_frac > 0.0 && rng_unit(&r) < pp->pair_frac && p + len + 4 < stop) {   /* matched DEL + INS */
+            p += len; op_push(&o, 'D', len); n_del++;
+            const uint64_t gap = 1 + (rng_next(&r) & 1);
+            if (t + gap > tig_cap) return -1;
+            memcpy(tig + t, ref + p, (size_t)gap); t += gap; op_push(&o, '=', gap); n_aligned += gap; p += gap;
+            for (uint64_t k = 0; k < len; ++k) PUT(UP[rng_next(&r) & 3]);
+            op_push(&o, 'I', len); n_ins++;
+            force_match = 1;
+            if (next_evt <= p) next_evt = p + 1;
+            continue;
+        }
         if (rng_next(&r) & 1) {                           /* INS */
             uint64_t aligned_t = t - pp->clip;
             if (rng_unit(&r) < pp->tandem_frac && aligned_t >= len) {

@@ -212,3 +212,96 @@ def call_inv_batch_merge(bed_list, bed_out=None):
     if bed_out is not None:
         df.to_csv(bed_out, sep='\t', index=False, compression='gzip')
     return df
+
+
+# ---------------------------------------------------------------------------------------------------------
+# rules call_inv_cluster (:603-692), call_inv_flag_insdel_cluster (:480-599), call_inv_merge_flagged_loci (:321-474)
+# ---------------------------------------------------------------------------------------------------------
+
+def _with_ctx(ctx, device_id):
+    from . import _lib
+    return (ctx, False) if ctx is not None else (_lib.Context(device_id), True)
+
+
+def _write_bed(df, path):
+    if path is not None:
+        df.to_csv(path, sep='\t', index=False, compression='gzip')
+    return df
+
+
+def call_inv_cluster(bed_list, vartype, bed_out=None, ctx=None, device_id=0, cluster_win=200, cluster_min_snv=20,
+                     cluster_min_indel=10):
+    """Body of rule call_inv_cluster: ``bed_list`` is what _input_call_inv_cluster returns (call_inv.snakefile:32-54)."""
+    from . import flag
+    if vartype not in ('indel', 'snv'):
+        raise RuntimeError('Bad variant type {}: Expected "indel" or "snv"')           # :626
+    df = pd.concat([pd.read_csv(f, sep='\t', usecols=('#CHROM', 'POS', 'END', 'SVTYPE', 'SVLEN', 'FILTER'), low_memory=False,
+                                dtype={'#CHROM': str}) for f in bed_list], axis=0)     # :629-637
+    ctx, own = _with_ctx(ctx, device_id)
+    try:
+        return _write_bed(flag.cluster_table(ctx, df, vartype, cluster_win, cluster_min_snv, cluster_min_indel), bed_out)
+    finally:
+        if own:
+            ctx.close()
+
+
+def call_inv_flag_insdel_cluster(bed, vartype, bed_out=None, ctx=None, device_id=0, flank_cluster=2, flank_merge=2000,
+                                 cluster_min_svlen=4):
+    """Body of rule call_inv_flag_insdel_cluster."""
+    from . import flag
+    df = pd.read_csv(bed, sep='\t', header=0, low_memory=False)                       # :500
+    ctx, own = _with_ctx(ctx, device_id)
+    try:
+        return _write_bed(flag.insdel_table(ctx, df, vartype, flank_cluster, flank_merge, cluster_min_svlen), bed_out)
+    finally:
+        if own:
+            ctx.close()
+
+
+def call_inv_merge_flagged_loci(bed_insdel_sv, bed_insdel_indel, bed_cluster_indel, bed_cluster_snv, bed_out=None, ctx=None,
+                                device_id=0, flank=500, batch_count=60, inv_sig_filter='svindel'):
+    """Body of rule call_inv_merge_flagged_loci (config keys inv_sig_merge_flank / inv_sig_batch_count / inv_sig_filter)."""
+    from . import flag
+    frames = [pd.read_csv(f, sep='\t') for f in (bed_insdel_sv, bed_insdel_indel, bed_cluster_indel, bed_cluster_snv)]   # :358-361
+    ctx, own = _with_ctx(ctx, device_id)
+    try:
+        return _write_bed(flag.merge_flagged(ctx, *frames, flank=flank, batch_count=batch_count, inv_sig_filter=inv_sig_filter),
+                          bed_out)
+    finally:
+        if own:
+            ctx.close()
+
+
+FLAG_OUTPUTS = ('insdel_sv', 'insdel_indel', 'cluster_indel', 'cluster_snv', 'flagged_regions')
+
+
+def call_inv_flag(bed, bed_trim, tig_fa_name, ref_fa_name, out=None, ctx=None, device_id=0, inv_sig_filter='svindel', **config):
+    """The three flag rules for one haplotype without the intermediate variant tables: CIGAR calls of *all* alignment rows
+    (every CALL_BATCH) are made on the device and flagged in place (``pav_cigar_flag``).  ``out`` maps FLAG_OUTPUTS names
+    to file names (any subset).  The tables equal those of the rule chain call_cigar x10 -> call_cigar_merge ->
+    call_inv_cluster x2 / call_inv_flag_insdel_cluster x2 -> call_inv_merge_flagged_loci."""
+    from . import _lib, flag
+    df_align = read_align_bed(bed)
+    df_trim = read_trim_bed(bed_trim)
+    ctx, own = _with_ctx(ctx, device_id)
+    try:
+        ref_names, tig_names = cigarcall.load_sequences(ctx, ref_fa_name, tig_fa_name, df_align)
+        aln, text, off = cigarcall.pack_alignments(df_align, ref_names, tig_names)
+        ctx.cigar_load(aln, text, off)
+        try:
+            ctx.cigar_call()
+        except _lib.CigarDeviceError as ex:
+            if ex.detail is None:
+                raise
+            cigarcall._raise_reference_error(ex.detail, df_align)
+        trim = df_trim.reindex(list(df_align['INDEX'].to_numpy(dtype='int64')), fill_value=-1)
+        res = flag.flag_from_calls(ctx, trim['POS'].to_numpy(dtype='int64'), trim['END'].to_numpy(dtype='int64'),
+                                   inv_sig_filter=inv_sig_filter, **config)
+    finally:
+        if own:
+            ctx.close()
+    for name, path in (out or {}).items():
+        if name not in FLAG_OUTPUTS:
+            raise KeyError(name)
+        _write_bed(res[name], path)
+    return res

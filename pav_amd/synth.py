@@ -48,7 +48,7 @@ def _lib():
 class _Params(ctypes.Structure):
     _fields_ = [('snv_rate', ctypes.c_double), ('indel_rate', ctypes.c_double),
                 ('pareto_alpha', ctypes.c_double), ('max_indel', ctypes.c_uint32),
-                ('tandem_frac', ctypes.c_double), ('clip', ctypes.c_uint32)]
+                ('tandem_frac', ctypes.c_double), ('clip', ctypes.c_uint32), ('pair_frac', ctypes.c_double)]
 
 
 # hg38 no-ALT primary assembly lengths (chr1..22, X, Y); T2T-CHM13v2.0 lengths.
@@ -186,11 +186,11 @@ def _plan_segments(rng, L, median, sigma, cap, zones=(), gap_min=1_000, gap_max=
 def make_haplotype(ref, seed, hap='h1', snv_rate=1.0e-3, indel_rate=2.0e-4, pareto_alpha=1.2, max_indel=5000,
                    tandem_frac=0.5, clip=100, seg_median=1_000_000, seg_sigma=1.4, seg_cap=150_000_000,
                    rev_frac=0.5, decoys_per_inv=9, min_decoys=0, flag_batches=60, threads=8, segments=None,
-                   zone_factor=3, zone_pad=20_000):
+                   zone_factor=3, zone_pad=20_000, pair_frac=0.0):
     """One haplotype: contigs, alignment BEDs (trim-none and trim-tigref) and flagged regions."""
     lib = _lib()
     rng = np.random.default_rng(seed)
-    params = _Params(snv_rate, indel_rate, pareto_alpha, max_indel, tandem_frac, clip)
+    params = _Params(snv_rate, indel_rate, pareto_alpha, max_indel, tandem_frac, clip, pair_frac)
 
     # Plan alignment rows: (chrom, pos, end, rev, inversions inside)
     plan = []

@@ -46,6 +46,19 @@ def rule_body(snakefile, rule_name):
     return textwrap.dedent('\n'.join(body))
 
 
+def top_level_def(snakefile, name, namespace=None):
+    """Evaluate one top-level ``def`` of the reference snakefile (read at harness time) and return the function."""
+    with open(snakefile) as fh:
+        lines = fh.read().split('\n')
+    start = next(i for i, ln in enumerate(lines) if re.match(r'^def\s+%s\s*\(' % re.escape(name), ln))
+    stop = start + 1
+    while stop < len(lines) and (not lines[stop].strip() or lines[stop].startswith((' ', '\t'))):
+        stop += 1
+    ns = dict(namespace or {})
+    exec(compile('\n'.join(lines[start:stop]), f'{snakefile}:{name}', 'exec'), ns)
+    return ns[name]
+
+
 def exec_rule(snakefile, rule_name, namespace):
     """Run the rule body; ``namespace`` supplies globals (modules, REF_FA, get_config, ...) and the rule objects."""
     src = 'def __run__():\n' + textwrap.indent(rule_body(snakefile, rule_name), '    ') + '\n__run__()\n'
