@@ -120,6 +120,11 @@ def main():
         ref_fa_name, tig_fa_name = os.path.join(tmpd, 'ref.fa'), os.path.join(tmpd, 'tig.fa')
         ctx._inv_loaded = (ref_fa_name, tig_fa_name)                       # sequences are already resident
         regions = [pavseq.Region(r['#CHROM'], r['POS'], r['END']) for _, r in hap.df_flag.iterrows()]
+        # FILTER inputs of the flagging pass (rules call_inv_cluster / call_inv_flag_insdel_cluster / call_inv_merge_flagged_loci)
+        _index = hap.df_align['INDEX'].to_numpy(dtype='int64')
+        _trim = hap.df_trim[['POS', 'END', 'INDEX']].set_index('INDEX').astype(int).reindex(list(_index), fill_value=-1)
+        flag_tp, flag_te = _trim['POS'].to_numpy(dtype='int64'), _trim['END'].to_numpy(dtype='int64')
+        flag_params = ctx.flag_params()
         tig_len = tig_len_series
         k_util = KmerUtil(31)
 
@@ -140,6 +145,7 @@ def main():
         c = ctx.cigar_call()
         if args.workload == 'cigar+inv':
             import contextlib
+            inv_state['flag'] = ctx.cigar_flag(flag_tp, flag_te, flag_params)   # signature flagging of the fresh calls
             with contextlib.redirect_stdout(io.StringIO()):                # scan_for_inv prints 'INV Found: ...' (inv.py:408)
                 inv_step()
         return c
@@ -283,8 +289,25 @@ def main():
                     if ln.startswith('Scanning region: '):
                         scanned += len(pavseq2.region_from_string(ln.split(': ')[1]))
                         iters += 1
-            den = {k: v for k, v in kern.items() if k.startswith('k_')}
-            inv_report = {'flagged_regions': len(out), 'calls': sum(1 for o in out if o is not None and not isinstance(o, RuntimeError)),
+            flag_kernels = ('k_snv_keys', 'k_indel_keys', 'k_indel_mid', 'k_cluster_sweep', 'k_insdel_split', 'k_ins_match',
+                            'rocprim::radix_sort_keys', 'rocprim::radix_sort_pairs', 'rocprim::inclusive_scan')
+            den = {k: v for k, v in kern.items() if k.startswith('k_') and k not in flag_kernels}
+            f_tables, f_loci, f_counts = inv_state['flag']
+            # every planted inversion that is aligned through shows up as a CLUSTER_SNV locus: count the overlaps
+            rank_of = {n: i for i, n in enumerate(sorted(names))}
+            hit = 0
+            for iv in hap.ref.inversions:
+                sel = f_loci[(f_loci['chrom'] == rank_of[iv.chrom]) & (f_loci['pos'] < iv.end) & (f_loci['end'] > iv.pos)]
+                hit += bool(len(sel))
+            flag_report = {'loci': int(len(f_loci)), 'try_inv': int(f_loci['try_inv'].sum()),
+                           'tables': {k: int(len(v)) for k, v in f_tables.items()}, **f_counts,
+                           'planted_inversions_flagged': hit,
+                           'device_ms_per_step': round(sum(kern[k]['avg_ms'] * kern[k]['launches'] for k in flag_kernels if k in kern) / args.steps, 3),
+                           'note': 'pav_cigar_flag inside the timed step: FILTER + sort + cluster sweeps + INS/DEL matching on the '
+                                   'device, interval merges on the host (rules call_inv_cluster, call_inv_flag_insdel_cluster, '
+                                   'call_inv_merge_flagged_loci); the scan below runs on the generator\'s flagged regions '
+                                   '(planted inversions + decoys), a superset of what the default inv_sig_filter would try'}
+            inv_report = {'flagging': flag_report, 'flagged_regions': len(out), 'calls': sum(1 for o in out if o is not None and not isinstance(o, RuntimeError)),
                           'planted': hap.stats['n_inv'], 'scan_iterations': iters, 'scanned_bp': scanned,
                           'device_ms_per_step': round(sum(v['avg_ms'] * v['launches'] for v in den.values()) / args.steps, 3),
                           'host_ms_last_step': {'align_table': round(inv_state['t_lift_ms'], 1), 'scan_for_inv_batch': round(inv_state['t_scan_ms'], 1)},

@@ -95,9 +95,10 @@ __global__ __launch_bounds__(256) void k_cluster_sweep(const uint64_t *__restric
 constexpr uint64_t SNV_SENTINEL = (1ull << 56) - 1;          // FILTER != PASS rows sort behind every chromosome
 constexpr uint64_t IND_SENTINEL = (1ull << 54) - 1;
 
-__device__ __forceinline__ void wave_count(bool flag, unsigned long long *counter) {
-    const unsigned long long m = __ballot(flag);
-    if (m && (threadIdx.x & (WAVE - 1)) == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(counter, (unsigned long long)__popcll(m));
+// One atomic per wave for a per-thread partial count (the kernels below are grid-stride: a few thousand atomics in all).
+__device__ __forceinline__ void wave_add(unsigned long long v, unsigned long long *counter) {
+    for (int o = WAVE / 2; o; o >>= 1) v += __shfl_down(v, o);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && v) atomicAdd(counter, v);
 }
 
 // cluster key of every SNV row: rank << 40 | POS (the midpoint of [POS, POS + 1) is POS).
@@ -105,14 +106,14 @@ __global__ __launch_bounds__(256) void k_snv_keys(const pav_snv *__restrict__ sn
                                                   const uint16_t *__restrict__ rank, const long long *__restrict__ tpos,
                                                   const long long *__restrict__ tend, unsigned long long *__restrict__ keys,
                                                   unsigned long long *__restrict__ n_pass) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    bool pass = false;
-    if (i < n) {
+    unsigned long long mine = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
         const pav_snv s = snv[i];
-        pass = (long long)s.pos > tpos[s.aln] && (long long)s.pos + 1 < tend[s.aln];
+        const bool pass = (long long)s.pos > tpos[s.aln] && (long long)s.pos + 1 < tend[s.aln];
         keys[i] = pass ? ((unsigned long long)rank[aln[s.aln].ref_id] << CM_SHIFT | s.pos) : SNV_SENTINEL;
+        mine += pass;
     }
-    wave_count(pass, n_pass);
+    wave_add(mine, n_pass);
 }
 
 // cluster key of every indel row < 50 bp: rank << 38 | POS << 6 | (END - POS): the (#CHROM, POS, END) order of the table.
@@ -120,17 +121,18 @@ __global__ __launch_bounds__(256) void k_indel_keys(const pav_indel *__restrict_
                                                     const uint16_t *__restrict__ rank, const long long *__restrict__ tpos,
                                                     const long long *__restrict__ tend, unsigned long long *__restrict__ keys,
                                                     unsigned long long *__restrict__ counters) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    bool pass = false, small = false;
-    if (i < n) {
+    unsigned long long n_pass = 0, n_small = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
         const pav_indel v = ind[i];
-        pass = (long long)v.pos > tpos[v.aln] && (long long)v.end < tend[v.aln];
-        small = pass && v.svlen < 50;
+        const bool pass = (long long)v.pos > tpos[v.aln] && (long long)v.end < tend[v.aln];
+        const bool small = pass && v.svlen < 50;
         keys[i] = small ? ((unsigned long long)rank[aln[v.aln].ref_id] << 38 | (unsigned long long)v.pos << 6 | (v.end - v.pos))
                         : IND_SENTINEL;
+        n_pass += pass;
+        n_small += small;
     }
-    wave_count(pass, counters);
-    wave_count(small, counters + 1);
+    wave_add(n_pass, counters);
+    wave_add(n_small, counters + 1);
 }
 
 __global__ __launch_bounds__(256) void k_indel_mid(unsigned long long *__restrict__ keys, uint64_t n) {
@@ -149,19 +151,27 @@ __global__ __launch_bounds__(256) void k_insdel_split(const pav_indel *__restric
                                                       unsigned long long *__restrict__ ins_key, unsigned long long *__restrict__ ins_len,
                                                       unsigned long long *__restrict__ counters) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const pav_indel v = ind[i];
-    if (!((long long)v.pos > tpos[v.aln] && (long long)v.end < tend[v.aln])) return;
-    if (v.svlen < svlen_lo || v.svlen >= svlen_hi) return;
-    const unsigned long long r = rank[aln[v.aln].ref_id];
-    if (v.svtype == 1) {
-        const unsigned long long s = atomicAdd(counters, 1ull);
-        del_key[s] = r << 32 | v.pos;
-        del_end[s] = r << 32 | v.end;
-    } else {
-        const unsigned long long s = atomicAdd(counters + 1, 1ull);
-        ins_key[s] = r << 32 | v.pos;
-        ins_len[s] = v.svlen;
+    const int lane = threadIdx.x & (WAVE - 1);
+    pav_indel v{};
+    bool keep = false;
+    if (i < n) {
+        v = ind[i];
+        keep = (long long)v.pos > tpos[v.aln] && (long long)v.end < tend[v.aln] && v.svlen >= svlen_lo && v.svlen < svlen_hi;
+    }
+    const unsigned long long r = keep ? rank[aln[v.aln].ref_id] : 0;
+    // wave-aggregated append (the DEL rows are sorted afterwards and the INS order does not matter)
+    for (int t = 0; t < 2; ++t) {
+        const bool mine = keep && v.svtype == (t == 0 ? 1 : 0);
+        const unsigned long long m = __ballot(mine);
+        if (!m) continue;
+        const int leader = __ffsll((long long)m) - 1;
+        unsigned long long base = 0;
+        if (lane == leader) base = atomicAdd(counters + t, (unsigned long long)__popcll(m));
+        base = __shfl(base, leader);
+        if (!mine) continue;
+        const unsigned long long s = base + __popcll(m & ((1ull << lane) - 1));
+        if (t == 0) { del_key[s] = r << 32 | v.pos; del_end[s] = r << 32 | v.end; }
+        else { ins_key[s] = r << 32 | v.pos; ins_len[s] = v.svlen; }
     }
 }
 
@@ -489,13 +499,13 @@ int pav_cigar_flag(pav_ctx *ctx, const int64_t *trim_pos, const int64_t *trim_en
     // ---- keys of both cluster tables, sorted into the rules' iteration order --------------------------------------------
     if (n_snv) {
         PAV_HIP(ctx, S->a.reserve(8 * n_snv)); PAV_HIP(ctx, S->b.reserve(8 * n_snv));
-        PAV_LAUNCH(ctx, "k_snv_keys", k_snv_keys, (uint32_t)((n_snv + 255) / 256), 256, 0, ctx->d_snv.as<pav_snv>(), n_snv, d_aln, d_rank,
+        PAV_LAUNCH(ctx, "k_snv_keys", k_snv_keys, (uint32_t)std::min<uint64_t>((n_snv + 255) / 256, 8u * (uint32_t)ctx->n_cu), 256, 0, ctx->d_snv.as<pav_snv>(), n_snv, d_aln, d_rank,
                    d_tp, d_te, S->a.as<unsigned long long>(), d_cnt);
         if ((rc = sort_keys(ctx, S, S->a.as<unsigned long long>(), S->b.as<unsigned long long>(), n_snv, 56)) != PAV_OK) return rc;
     }
     if (n_ind) {
         PAV_HIP(ctx, S->c.reserve(8 * n_ind)); PAV_HIP(ctx, S->d.reserve(8 * n_ind));
-        PAV_LAUNCH(ctx, "k_indel_keys", k_indel_keys, (uint32_t)((n_ind + 255) / 256), 256, 0, ctx->d_indel.as<pav_indel>(), n_ind, d_aln, d_rank,
+        PAV_LAUNCH(ctx, "k_indel_keys", k_indel_keys, (uint32_t)std::min<uint64_t>((n_ind + 255) / 256, 8u * (uint32_t)ctx->n_cu), 256, 0, ctx->d_indel.as<pav_indel>(), n_ind, d_aln, d_rank,
                    d_tp, d_te, S->c.as<unsigned long long>(), d_cnt + 1);
         if ((rc = sort_keys(ctx, S, S->c.as<unsigned long long>(), S->d.as<unsigned long long>(), n_ind, 54)) != PAV_OK) return rc;
     }

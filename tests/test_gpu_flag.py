@@ -95,7 +95,7 @@ def test_long_clusters_and_ties(gpu_ctx):
         for _ in range(40):
             run = int(rng.choice([1, 3, 31, 32, 33, 64, 65, 700, 5000]))
             for _ in range(run):
-                p += int(rng.integers(0, 199))
+                p += int(rng.integers(0, 150))
                 chrom.append(c); pos.append(p); end.append(p + int(rng.integers(1, 50)))
             p += 200 + 50 + int(rng.integers(0, 300))
     chrom, pos, end = np.array(chrom, dtype=np.uint32), np.array(pos), np.array(end)
