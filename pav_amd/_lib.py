@@ -96,6 +96,13 @@ class InvResult(ctypes.Structure):
 
 
 INV_NONE, INV_CALL, INV_ERROR = 0, 1, 2
+_INV_RGN_DTYPE = np.dtype([('seq_id', '<u4'), ('is_rev', '<u4'), ('pos', '<u8'), ('end', '<u8'), ('n_aln', '<u4', (2,)),
+                           ('aln_index', '<i8', (2, 2))])
+INV_RESULT_DTYPE = np.dtype([('outcome', '<i4'), ('found', '<u4'), ('iterations', '<u4'), ('n_rows', '<u4'), ('svlen', '<u8'),
+                             ('ref_outer', _INV_RGN_DTYPE), ('ref_inner', _INV_RGN_DTYPE), ('tig_outer', _INV_RGN_DTYPE),
+                             ('tig_inner', _INV_RGN_DTYPE), ('ref_discovery', _INV_RGN_DTYPE), ('tig_discovery', _INV_RGN_DTYPE),
+                             ('log_bytes', '<u4'), ('error_bytes', '<u4')])
+assert INV_RESULT_DTYPE.itemsize == ctypes.sizeof(InvResult)
 RUN_DTYPE = np.dtype([('state', '<i4'), ('count', '<u4'), ('pos', '<i8'), ('end', '<i8')])
 DEN_OK, DEN_UNFINALISED, DEN_FAIL = 0, 1, 125
 KDE_RUNS, KDE_DIRECT = 0, 1
@@ -164,6 +171,7 @@ SYMBOLS = {
     'pav_inv_load_alignments': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P]),
     'pav_inv_scan_batch': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P]),
     'pav_inv_text': (ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_int, ctypes.c_char_p, ctypes.c_uint32]),
+    'pav_inv_texts': (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_char_p, ctypes.c_uint64, _P]),
     'pav_inv_table': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'pav_inv_table_view': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'pav_inv_tables': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -506,6 +514,14 @@ class Context:
         buf = ctypes.create_string_buffer(n_bytes + 1)
         self._check(self.lib.pav_inv_text(self.handle, region, what, buf, n_bytes + 1), 'pav_inv_text')
         return buf.value.decode()
+
+    def inv_texts(self, what, n_regions, total_bytes):
+        """Log (what 0) or error (what 1) text of every region of the last scan: list of str."""
+        buf = ctypes.create_string_buffer(int(total_bytes) + 1)
+        off = np.zeros(n_regions + 1, dtype=np.uint64)
+        self._check(self.lib.pav_inv_texts(self.handle, what, buf, int(total_bytes), _ptr(off)), 'pav_inv_texts')
+        raw = buf.raw
+        return [raw[int(off[i]):int(off[i + 1])].decode() for i in range(n_regions)]
 
     def inv_table(self, region, n_rows):
         cols = {'INDEX': np.zeros(n_rows, dtype=np.int64), 'STATE_MER': np.zeros(n_rows, dtype=np.int8),

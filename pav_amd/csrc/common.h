@@ -66,6 +66,9 @@ struct pav_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;        // side stream: contig re-pack overlaps the tokenizer / walk kernels
+    hipStream_t stream3 = nullptr;        // copy stream: call tables of the inversion scan travel to the host behind the scan
+    hipEvent_t tables_done = nullptr;     // recorded on stream3 after the last queued table copy
+    bool tables_pending = false;
     hipEvent_t pack_done[2] = {nullptr, nullptr};   // recorded after a pack on stream2; consumers of the planes wait on it
     bool pack_pending[2] = {false, false};
     std::string err;
@@ -115,6 +118,7 @@ int fail(pav_ctx *ctx, int code, const char *fmt, ...);
 // Profiled launch: records a HIP event pair around the launch on ctx->stream when profiling is on.
 int prof_begin(pav_ctx *ctx, const char *name, hipStream_t st = nullptr);
 void prof_end(pav_ctx *ctx, int token, hipStream_t st = nullptr);
+int wait_tables(pav_ctx *ctx);            // host waits until every queued call-table copy has landed
 int wait_planes(pav_ctx *ctx);            // make ctx->stream wait for any pack still running on stream2
 int prof_flush(pav_ctx *ctx);
 

@@ -49,6 +49,13 @@ int wait_planes(pav_ctx *ctx) {
     return PAV_OK;
 }
 
+int wait_tables(pav_ctx *ctx) {
+    if (!ctx->tables_pending) return PAV_OK;
+    PAV_HIP(ctx, hipEventSynchronize(ctx->tables_done));
+    ctx->tables_pending = false;
+    return PAV_OK;
+}
+
 int prof_flush(pav_ctx *ctx) {
     if (ctx->prof_pending.empty()) return PAV_OK;
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream2));
@@ -168,6 +175,8 @@ pav_ctx *pav_create(int device_id) {
         // main stream = highest priority: its short dependent kernels must not queue behind the streaming pack
         (e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_hi)) != hipSuccess ||
         (e = hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_lo)) != hipSuccess ||
+        (e = hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, prio_lo)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->tables_done, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->pack_done[0], hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->pack_done[1], hipEventDisableTiming)) != hipSuccess) {
         fail(nullptr, PAV_E_HIP, "device init: %s", hipGetErrorString(e));
@@ -184,6 +193,7 @@ void pav_flag_release(pav_ctx *ctx);      // flag.hip
 void pav_destroy(pav_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream3);
     (void)hipStreamSynchronize(ctx->stream2);
     (void)hipStreamSynchronize(ctx->stream);
     pav_density_release(ctx);
@@ -202,6 +212,8 @@ void pav_destroy(pav_ctx *ctx) {
     for (DevBuf *b : bufs) b->release();
     (void)hipStreamDestroy(ctx->stream);
     (void)hipStreamDestroy(ctx->stream2);
+    (void)hipStreamDestroy(ctx->stream3);
+    (void)hipEventDestroy(ctx->tables_done);
     (void)hipEventDestroy(ctx->pack_done[0]);
     (void)hipEventDestroy(ctx->pack_done[1]);
     delete ctx;
@@ -218,6 +230,8 @@ int pav_sync(pav_ctx *ctx) {
     PAV_HIP(ctx, hipSetDevice(ctx->device));
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream2));
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream3));
+    ctx->tables_pending = false;
     return PAV_OK;
 }
 

@@ -65,6 +65,11 @@ struct DensityState {
     DevBuf tiles, events, ev_count, scratch, run_arena;
     std::vector<JobDev> h_jobs;
     std::vector<JobKde> h_kde;
+    std::vector<uint8_t> desc_host2[2];   // descriptor uploads of density_fetch_calls (one per staging buffer)
+    DevBuf call_stage[2];                 // packed call tables of a round; two, so that a round never waits for the copy
+    hipEvent_t stage_copied[2] = {nullptr, nullptr};   // of the round before it (recorded on the copy stream)
+    hipEvent_t gathered = nullptr;
+    int stage_turn = 0;
     std::vector<pav_den_result> results;
     std::vector<std::vector<pav_run>> runs;
     pav_den_params params{};
@@ -76,6 +81,9 @@ struct DensityState {
                          &index, &state_mer, &state, &kmer, &kern[0], &kern[1], &kern[2], &list[0], &list[1], &list[2],
                          &pscaled[0], &pscaled[1], &pscaled[2], &fill_list, &tiles, &events, &ev_count, &scratch, &run_arena};
         for (DevBuf *b : all) b->release();
+        call_stage[0].release(); call_stage[1].release();
+        for (hipEvent_t &e : stage_copied) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        if (gathered) { (void)hipEventDestroy(gathered); gathered = nullptr; }
     }
 };
 
@@ -592,24 +600,60 @@ static DensityState *dstate(pav_ctx *ctx) {
     return static_cast<DensityState *>(ctx->density);
 }
 
-// Pack the table rows of all calls of a round into contiguous columns (one launch), so that the host copy is nine
-// large transfers instead of nine small ones per call.
-struct GatherCall { uint64_t src_off; uint32_t dst_off, n; };
-__global__ __launch_bounds__(256) void k_gather_calls(const GatherCall *__restrict__ calls, uint32_t n_calls, uint32_t total,
+// ---- call tables of a round: flank k-mer sets, FLANK / MATCH and the packed columns, three launches in all -------------
+struct CanonJob { uint64_t abs0, key_off; uint32_t len, hmask, tile0, pad; };      // one flank of one call
+__global__ __launch_bounds__(256) void k_canon_insert_batch(SeqView R, const CanonJob *__restrict__ jobs, uint32_t n_jobs, int k,
+                                                            unsigned long long *__restrict__ keys) {
+    uint32_t lo = 0, hi = n_jobs;                        // last job with tile0 <= blockIdx.x
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (jobs[mid].tile0 <= blockIdx.x) lo = mid; else hi = mid; }
+    const CanonJob j = jobs[lo];
+    const uint64_t i = (uint64_t)(blockIdx.x - j.tile0) * 256 + threadIdx.x;
+    if (i + (uint64_t)k > j.len) return;
+    uint64_t x;
+    if (!kmer_window(R.two, R.mask, j.abs0 + i, k, x)) return;
+    const uint64_t f = rev_groups(x, k), r = x ^ kmer_mask(k);
+    table_insert(keys + j.key_off, 0, j.hmask, f <= r ? f : r);
+}
+
+// Pack the table rows of all calls of a round into contiguous columns and annotate them (annotate_inv_dup_mers,
+// pavlib/inv.py:457-561), so that the host copy is one large transfer per round.
+struct GatherCall {
+    uint64_t src_off, key_up, key_dn;
+    int64_t base, up_pos, up_end, dn_pos, dn_end;
+    uint32_t dst_off, n, mask_up, mask_dn;
+};
+__global__ __launch_bounds__(256) void k_gather_calls(const GatherCall *__restrict__ calls, uint32_t n_calls, uint32_t total, int k,
                                                       const uint32_t *__restrict__ index, const int8_t *__restrict__ state_mer,
                                                       const int8_t *__restrict__ state, const double *__restrict__ k0,
                                                       const double *__restrict__ k1, const double *__restrict__ k2,
-                                                      const unsigned long long *__restrict__ kmer, uint32_t *__restrict__ o_index,
+                                                      const unsigned long long *__restrict__ kmer,
+                                                      const unsigned long long *__restrict__ keys, uint32_t *__restrict__ o_index,
                                                       int8_t *__restrict__ o_sm, int8_t *__restrict__ o_st, double *__restrict__ o_k0,
                                                       double *__restrict__ o_k1, double *__restrict__ o_k2,
-                                                      unsigned long long *__restrict__ o_kmer) {
+                                                      unsigned long long *__restrict__ o_kmer, uint8_t *__restrict__ o_flank,
+                                                      uint8_t *__restrict__ o_match) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
     uint32_t lo = 0, hi = n_calls;                       // last call with dst_off <= t
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (calls[mid].dst_off <= t) lo = mid; else hi = mid; }
-    const uint64_t src = calls[lo].src_off + (t - calls[lo].dst_off);
-    o_index[t] = index[src]; o_sm[t] = state_mer[src]; o_st[t] = state[src];
-    o_k0[t] = k0[src]; o_k1[t] = k1[src]; o_k2[t] = k2[src]; o_kmer[t] = kmer[src];
+    const GatherCall c = calls[lo];
+    const uint64_t src = c.src_off + (t - c.dst_off);
+    const uint32_t ix = index[src];
+    const unsigned long long km = kmer[src];
+    o_index[t] = ix; o_sm[t] = state_mer[src]; o_st[t] = state[src];
+    o_k0[t] = k0[src]; o_k1[t] = k1[src]; o_k2[t] = k2[src]; o_kmer[t] = km;
+    const int64_t q = (int64_t)ix + c.base;                            // QRY_INDEX (inv.py:519)
+    uint8_t f = 0;
+    if (q >= c.up_pos && q < c.up_end - k) f = 1;                      // inv.py:524-527
+    if (q >= c.dn_pos && q < c.dn_end - k) f = 2;                      // inv.py:529-532
+    uint8_t m = 0;
+    if (f) {                                                           // raw KMER against canonical sets (inv.py:537-553)
+        const bool in_up = table_has(keys + c.key_up, 0, c.mask_up, km), in_dn = table_has(keys + c.key_dn, 0, c.mask_dn, km);
+        const bool same = f == 1 ? in_up : in_dn, other = f == 1 ? in_dn : in_up;
+        m = same ? (other ? 3 : 1) : (other ? 2 : 3);                  // KMER_LOC_STATE: NA / OTHER / SAME / NA
+    }
+    o_flank[t] = f;
+    o_match[t] = m;
 }
 
 int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls) {
@@ -620,84 +664,86 @@ int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls) {
     const SeqView RV = RS.view();
     const int k = D->params.k;
     hipStream_t st = ctx->stream;
-    struct Plan { uint64_t up_pos, dn_pos; uint32_t up_len, dn_len, cap_up, cap_dn; uint64_t key_off, fm_off; };
-    std::vector<Plan> plan(calls.size());
-    uint64_t keys = 0, bytes = 0;
+    std::vector<GatherCall> gc(calls.size());
+    std::vector<CanonJob> cj;
+    uint64_t keys = 0, total = 0;
+    uint32_t tiles = 0;
     for (size_t c = 0; c < calls.size(); ++c) {
         const CallFetch &f = calls[c];
         uint64_t a = f.ref_up_pos, b = f.ref_up_end, x = f.ref_dn_pos, y = f.ref_dn_end;
         if (a > b) std::swap(a, b);                                   // Region() swaps reversed coordinates
         if (x > y) std::swap(x, y);
         if (f.ref_id >= RS.n || b > RS.len[f.ref_id] || y > RS.len[f.ref_id]) return fail(ctx, PAV_E_ARG, "density_fetch_calls: region outside the reference record");
-        Plan &p = plan[c];
-        p.up_pos = a; p.dn_pos = x; p.up_len = (uint32_t)(b - a); p.dn_len = (uint32_t)(y - x);
-        p.cap_up = pow2_at_least(2ull * p.up_len + 2); p.cap_dn = pow2_at_least(2ull * p.dn_len + 2);
-        p.key_off = keys; keys += (uint64_t)p.cap_up + p.cap_dn;
-        p.fm_off = bytes; bytes += (2ull * f.n + 15) / 16 * 16;
+        const uint32_t up_len = (uint32_t)(b - a), dn_len = (uint32_t)(y - x);
+        const uint32_t cap_up = pow2_at_least(2ull * up_len + 2), cap_dn = pow2_at_least(2ull * dn_len + 2);
+        GatherCall &g = gc[c];
+        g.src_off = D->h_jobs[f.job].tpos_off; g.dst_off = (uint32_t)total; g.n = f.n;
+        g.base = f.base; g.up_pos = f.tig_up_pos; g.up_end = f.tig_up_end; g.dn_pos = f.tig_dn_pos; g.dn_end = f.tig_dn_end;
+        g.key_up = keys; g.key_dn = keys + cap_up; g.mask_up = cap_up - 1; g.mask_dn = cap_dn - 1;
+        if (up_len >= (uint32_t)k) { cj.push_back(CanonJob{RS.off[f.ref_id] + a, g.key_up, up_len, g.mask_up, tiles, 0}); tiles += (up_len + 255) / 256; }
+        if (dn_len >= (uint32_t)k) { cj.push_back(CanonJob{RS.off[f.ref_id] + x, g.key_dn, dn_len, g.mask_dn, tiles, 0}); tiles += (dn_len + 255) / 256; }
+        keys += (uint64_t)cap_up + cap_dn;
+        total += f.n;
     }
-    // device staging: [hash keys][flank/match per call][gathered columns]; the host blocks of the calls are contiguous
-    // (one pinned block per round, column-major per call), so the gathered columns are copied call by call only for
-    // the narrow ones; see the layout in invscan.hip.
-    uint64_t total = 0;
-    std::vector<GatherCall> gc(calls.size());
-    for (size_t c = 0; c < calls.size(); ++c) { gc[c] = GatherCall{D->h_jobs[calls[c].job].tpos_off, (uint32_t)total, calls[c].n}; total += calls[c].n; }
-    const uint64_t col_bytes = total * (4 + 1 + 1 + 8 * 4);
-    PAV_HIP(ctx, D->scratch.reserve(8ull * keys + bytes + col_bytes + sizeof(GatherCall) * calls.size() + 256));
-    unsigned long long *d_keys = D->scratch.as<unsigned long long>();
-    uint8_t *d_fm = reinterpret_cast<uint8_t *>(d_keys + keys);
-    uint8_t *d_cols = d_fm + (bytes + 63) / 64 * 64;
+    // device staging: [hash keys][packed columns in the host block's order][descriptors]
+    const uint64_t col_bytes = total * 40;
+    const uint64_t desc_bytes = sizeof(GatherCall) * gc.size() + sizeof(CanonJob) * cj.size();
+    const int turn = D->stage_turn;
+    D->stage_turn ^= 1;
+    if (!D->gathered) PAV_HIP(ctx, hipEventCreateWithFlags(&D->gathered, hipEventDisableTiming));
+    if (!D->stage_copied[turn]) PAV_HIP(ctx, hipEventCreateWithFlags(&D->stage_copied[turn], hipEventDisableTiming));
+    else PAV_HIP(ctx, hipEventSynchronize(D->stage_copied[turn]));      // copy of two rounds ago: long finished
+    DevBuf &stage = D->call_stage[turn];
+    PAV_HIP(ctx, stage.reserve(8ull * keys + col_bytes + desc_bytes + 512));
+    unsigned long long *d_keys = stage.as<unsigned long long>();
+    uint8_t *d_cols = reinterpret_cast<uint8_t *>(d_keys + keys);
     double *g_k0 = reinterpret_cast<double *>(d_cols), *g_k1 = g_k0 + total, *g_k2 = g_k1 + total;
     unsigned long long *g_kmer = reinterpret_cast<unsigned long long *>(g_k2 + total);
     uint32_t *g_index = reinterpret_cast<uint32_t *>(g_kmer + total);
     int8_t *g_sm = reinterpret_cast<int8_t *>(g_index + total), *g_st = g_sm + total;
+    uint8_t *g_fl = reinterpret_cast<uint8_t *>(g_st + total), *g_ma = g_fl + total;
     GatherCall *d_gc = reinterpret_cast<GatherCall *>(d_cols + (col_bytes + 63) / 64 * 64);
+    CanonJob *d_cj = reinterpret_cast<CanonJob *>(d_gc + gc.size());
+    std::vector<uint8_t> &desc_host = D->desc_host2[turn];             // stays alive until the copy has run
+    desc_host.resize(desc_bytes);
+    memcpy(desc_host.data(), gc.data(), sizeof(GatherCall) * gc.size());
+    if (!cj.empty()) memcpy(desc_host.data() + sizeof(GatherCall) * gc.size(), cj.data(), sizeof(CanonJob) * cj.size());
     PAV_HIP(ctx, hipMemsetAsync(d_keys, 0xFF, 8ull * keys, st));
-    PAV_HIP(ctx, hipMemcpyAsync(d_gc, gc.data(), sizeof(GatherCall) * gc.size(), hipMemcpyHostToDevice, st));
+    PAV_HIP(ctx, hipMemcpyAsync(d_gc, desc_host.data(), desc_bytes, hipMemcpyHostToDevice, st));
     { int rcw = wait_planes(ctx); if (rcw != PAV_OK) return rcw; }
-    PAV_LAUNCH(ctx, "k_gather_calls", k_gather_calls, (uint32_t)((total + 255) / 256), 256, 0, d_gc, (uint32_t)gc.size(), (uint32_t)total,
+    if (tiles) PAV_LAUNCH(ctx, "k_canon_insert", k_canon_insert_batch, tiles, 256, 0, RV, d_cj, (uint32_t)cj.size(), k, d_keys);
+    PAV_LAUNCH(ctx, "k_gather_calls", k_gather_calls, (uint32_t)((total + 255) / 256), 256, 0, d_gc, (uint32_t)gc.size(), (uint32_t)total, k,
                D->index.as<uint32_t>(), D->state_mer.as<int8_t>(), D->state.as<int8_t>(), D->kern[0].as<double>(), D->kern[1].as<double>(),
-               D->kern[2].as<double>(), D->kmer.as<unsigned long long>(), g_index, g_sm, g_st, g_k0, g_k1, g_k2, g_kmer);
-    for (size_t c = 0; c < calls.size(); ++c) {
-        const CallFetch &f = calls[c];
-        const Plan &p = plan[c];
-        const uint64_t off = D->h_jobs[f.job].tpos_off;
-        const uint32_t n = f.n;
-        unsigned long long *k_up = d_keys + p.key_off, *k_dn = k_up + p.cap_up;
-        uint8_t *d_flank = d_fm + p.fm_off, *d_match = d_flank + n;
-        if (p.up_len >= (uint32_t)k)
-            PAV_LAUNCH(ctx, "k_canon_insert", k_canon_insert, (p.up_len + 255) / 256, 256, 0, RV, RS.off[f.ref_id] + p.up_pos, p.up_len, k, k_up, p.cap_up - 1);
-        if (p.dn_len >= (uint32_t)k)
-            PAV_LAUNCH(ctx, "k_canon_insert", k_canon_insert, (p.dn_len + 255) / 256, 256, 0, RV, RS.off[f.ref_id] + p.dn_pos, p.dn_len, k, k_dn, p.cap_dn - 1);
-        PAV_LAUNCH(ctx, "k_annotate", k_annotate, (n + 255) / 256, 256, 0, D->index.as<uint32_t>(), D->kmer.as<unsigned long long>(), off, n, k,
-                   f.base, f.tig_up_pos, f.tig_up_end, f.tig_dn_pos, f.tig_dn_end, k_up, p.cap_up - 1, k_dn, p.cap_dn - 1, d_flank, d_match);
-    }
-    // Host side (invscan.hip): the round's block is laid out as whole-round columns when `calls[0].kern[0]` etc. are
-    // consecutive; detect that and use nine bulk copies, else copy call by call.
+               D->kern[2].as<double>(), D->kmer.as<unsigned long long>(), d_keys, g_index, g_sm, g_st, g_k0, g_k1, g_k2, g_kmer, g_fl, g_ma);
+    // Host side (invscan.hip): the round's block is laid out as whole-round columns, K0 | K1 | K2 | KMER | INDEX | STATE_MER |
+    // STATE | FLANK | MATCH, exactly like the packed device columns: one copy.  Any other layout is copied call by call.
     bool bulk = true;
     for (size_t c = 0; c + 1 < calls.size() && bulk; ++c)
-        bulk = calls[c + 1].kern[0] == calls[c].kern[0] + calls[c].n && calls[c + 1].index == calls[c].index + calls[c].n &&
-               calls[c + 1].flank == calls[c].flank + calls[c].n;
+        bulk = calls[c + 1].kern[0] == calls[c].kern[0] + calls[c].n;
+    const CallFetch &f0 = calls[0];
+    bulk = bulk && f0.kern[1] == f0.kern[0] + total && f0.kern[2] == f0.kern[1] + total &&
+           reinterpret_cast<uint8_t *>(f0.kmer) == reinterpret_cast<uint8_t *>(f0.kern[2] + total) &&
+           reinterpret_cast<uint8_t *>(f0.index) == reinterpret_cast<uint8_t *>(f0.kmer + total) &&
+           reinterpret_cast<uint8_t *>(f0.state_mer) == reinterpret_cast<uint8_t *>(f0.index + total) &&
+           f0.state == f0.state_mer + total && f0.flank == reinterpret_cast<uint8_t *>(f0.state + total) && f0.match == f0.flank + total;
     if (bulk) {
-        const CallFetch &f0 = calls[0];
-        PAV_HIP(ctx, hipMemcpyAsync(f0.kern[0], g_k0, 8ull * total, hipMemcpyDeviceToHost, st));
-        PAV_HIP(ctx, hipMemcpyAsync(f0.kern[1], g_k1, 8ull * total, hipMemcpyDeviceToHost, st));
-        PAV_HIP(ctx, hipMemcpyAsync(f0.kern[2], g_k2, 8ull * total, hipMemcpyDeviceToHost, st));
-        PAV_HIP(ctx, hipMemcpyAsync(f0.kmer, g_kmer, 8ull * total, hipMemcpyDeviceToHost, st));
-        PAV_HIP(ctx, hipMemcpyAsync(f0.index, g_index, 4ull * total, hipMemcpyDeviceToHost, st));
-        PAV_HIP(ctx, hipMemcpyAsync(f0.state_mer, g_sm, total, hipMemcpyDeviceToHost, st));
-        PAV_HIP(ctx, hipMemcpyAsync(f0.state, g_st, total, hipMemcpyDeviceToHost, st));
-        // flank / match: per-call device slices are 16-byte padded; the host columns are dense
-        for (size_t c = 0; c < calls.size(); ++c) {
-            PAV_HIP(ctx, hipMemcpyAsync(calls[c].flank, d_fm + plan[c].fm_off, calls[c].n, hipMemcpyDeviceToHost, st));
-            PAV_HIP(ctx, hipMemcpyAsync(calls[c].match, d_fm + plan[c].fm_off + calls[c].n, calls[c].n, hipMemcpyDeviceToHost, st));
-        }
+        // the copy runs on the copy stream behind the scan (wait_tables() before the host reads the block)
+        PAV_HIP(ctx, hipEventRecord(D->gathered, st));
+        PAV_HIP(ctx, hipStreamWaitEvent(ctx->stream3, D->gathered, 0));
+        PAV_HIP(ctx, hipMemcpyAsync(f0.kern[0], d_cols, col_bytes, hipMemcpyDeviceToHost, ctx->stream3));
+        PAV_HIP(ctx, hipEventRecord(D->stage_copied[turn], ctx->stream3));
+        PAV_HIP(ctx, hipEventRecord(ctx->tables_done, ctx->stream3));
+        ctx->tables_pending = true;
+        if (getenv("PAV_TIMING")) fprintf(stderr, "[pav timing]   call tables: %zu calls, %llu rows (%.1f MB to the host), %llu hash slots, %u insert tiles\n",
+                                          calls.size(), (unsigned long long)total, col_bytes / 1e6, (unsigned long long)keys, tiles);
+        return PAV_OK;
     } else {
         for (size_t c = 0; c < calls.size(); ++c) {
             const CallFetch &f = calls[c];
             const uint64_t o = gc[c].dst_off;
             const uint32_t n = f.n;
-            PAV_HIP(ctx, hipMemcpyAsync(f.flank, d_fm + plan[c].fm_off, n, hipMemcpyDeviceToHost, st));
-            PAV_HIP(ctx, hipMemcpyAsync(f.match, d_fm + plan[c].fm_off + n, n, hipMemcpyDeviceToHost, st));
+            PAV_HIP(ctx, hipMemcpyAsync(f.flank, g_fl + o, n, hipMemcpyDeviceToHost, st));
+            PAV_HIP(ctx, hipMemcpyAsync(f.match, g_ma + o, n, hipMemcpyDeviceToHost, st));
             PAV_HIP(ctx, hipMemcpyAsync(f.index, g_index + o, 4ull * n, hipMemcpyDeviceToHost, st));
             PAV_HIP(ctx, hipMemcpyAsync(f.state_mer, g_sm + o, n, hipMemcpyDeviceToHost, st));
             PAV_HIP(ctx, hipMemcpyAsync(f.state, g_st + o, n, hipMemcpyDeviceToHost, st));
@@ -708,6 +754,7 @@ int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls) {
         }
     }
     PAV_HIP(ctx, hipStreamSynchronize(st));
+    PAV_HIP(ctx, hipEventRecord(D->stage_copied[turn], st));
     return PAV_OK;
 }
 

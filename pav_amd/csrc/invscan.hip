@@ -335,6 +335,7 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
     S->results.assign(n_regions, pav_inv_result{});
     S->logs.assign(n_regions, std::string());
     S->errors.assign(n_regions, std::string());
+    { const int rcw = wait_tables(ctx); if (rcw != PAV_OK) return rcw; }   // the pinned arena is about to be reused
     S->tables.clear(); S->tables.resize(n_regions);
     S->reset_pinned();
     std::vector<Scan> scans(n_regions);
@@ -543,11 +544,27 @@ int pav_inv_text(pav_ctx *ctx, uint32_t region, int what, char *buf, uint32_t bu
     return PAV_OK;
 }
 
+int pav_inv_texts(pav_ctx *ctx, int what, char *buf, uint64_t buf_len, uint64_t *off) {
+    if (!ctx || !off || (what != 0 && what != 1)) return PAV_E_ARG;
+    InvState *S = istate(ctx);
+    const std::vector<std::string> &src = what == 0 ? S->logs : S->errors;
+    uint64_t at = 0;
+    for (size_t i = 0; i < src.size(); ++i) {
+        off[i] = at;
+        if (at + src[i].size() > buf_len || (src[i].size() && !buf)) return fail(ctx, PAV_E_ARG, "pav_inv_texts: buffer too small");
+        if (!src[i].empty()) memcpy(buf + at, src[i].data(), src[i].size());
+        at += src[i].size();
+    }
+    off[src.size()] = at;
+    return PAV_OK;
+}
+
 int pav_inv_table(pav_ctx *ctx, uint32_t region, int64_t *index, int8_t *state_mer, int8_t *state, double *kern_fwd, double *kern_fwdrev,
                   double *kern_rev, uint64_t *kmer, uint8_t *flank, uint8_t *match) {
     if (!ctx) return PAV_E_ARG;
     InvState *S = istate(ctx);
     if (region >= S->tables.size() || !S->tables[region]) return fail(ctx, PAV_E_STATE, "pav_inv_table: region has no call in the last scan");
+    { const int rcw = wait_tables(ctx); if (rcw != PAV_OK) return rcw; }
     const InvTable &t = *S->tables[region];
     const size_t n = t.n;
     if (index) for (size_t i = 0; i < n; ++i) index[i] = t.index[i];
@@ -568,6 +585,7 @@ int pav_inv_table_view(pav_ctx *ctx, uint32_t region, uint32_t *n_rows, const ui
     if (!ctx || !n_rows) return PAV_E_ARG;
     InvState *S = istate(ctx);
     if (region >= S->tables.size() || !S->tables[region]) return fail(ctx, PAV_E_STATE, "pav_inv_table_view: region has no call in the last scan");
+    { const int rcw = wait_tables(ctx); if (rcw != PAV_OK) return rcw; }
     const InvTable &t = *S->tables[region];
     *n_rows = t.n;
     if (index) *index = t.index;
@@ -587,6 +605,7 @@ int pav_inv_tables(pav_ctx *ctx, uint32_t n_regions, const uint64_t *row_off, in
     if (!ctx || !row_off) return PAV_E_ARG;
     InvState *S = istate(ctx);
     if (n_regions != S->tables.size()) return fail(ctx, PAV_E_STATE, "pav_inv_tables: region count does not match the last scan");
+    { const int rcw = wait_tables(ctx); if (rcw != PAV_OK) return rcw; }
     for (uint32_t i = 0; i < n_regions; ++i) {
         if (!S->tables[i]) continue;
         const uint64_t o = row_off[i];

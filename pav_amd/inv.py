@@ -446,8 +446,10 @@ def _native_scan(ctx, region_flags, align_lift, k_util, max_region_size, logs, s
                             int(DEFAULT_MIN_EXP_COUNT if min_exp_count is None else min_exp_count), len(ivs),
                             ctypes.cast(srs, ctypes.POINTER(_lib.Srs)), density.den_params(k=k_util.k_size))
     regions = np.zeros(len(region_flags), dtype=_lib.INV_REGION_DTYPE)
-    for i, rf in enumerate(region_flags):
-        regions[i] = (ref_index[rf.chrom], 0, rf.pos, rf.end)
+    if len(region_flags):
+        regions['ref_id'] = [ref_index[rf.chrom] for rf in region_flags]
+        regions['pos'] = [rf.pos for rf in region_flags]
+        regions['end'] = [rf.end for rf in region_flags]
     _lap('marshal regions')
     res = ctx.inv_scan_batch(regions, params)
     _lap('inv_scan_batch')
@@ -463,18 +465,26 @@ def _native_scan(ctx, region_flags, align_lift, k_util, max_region_size, logs, s
         all_cols, all_flank, all_match, row_off = ctx.inv_tables(n_rows)
     generation = ctx._inv_generation
     _lap('inv_tables')
-    out = []
-    for i, rf in enumerate(region_flags):
-        r = res[i]
-        if logs is not None and logs[i] is not None and r.log_bytes:
-            logs[i].write(ctx.inv_text(i, 0, r.log_bytes))
-            logs[i].flush()
+    n_rgn = len(region_flags)
+    resv = np.frombuffer(res, dtype=_lib.INV_RESULT_DTYPE, count=n_rgn) if n_rgn else np.zeros(0, dtype=_lib.INV_RESULT_DTYPE)
+    outcome, found = resv['outcome'], resv['found']
+    if logs is not None and n_rgn:
+        texts = ctx.inv_texts(0, n_rgn, int(resv['log_bytes'].sum(dtype=np.int64)))
+        for lg, text in zip(logs, texts):
+            if lg is not None and text:
+                lg.write(text)
+                lg.flush()
+    errors = ctx.inv_texts(1, n_rgn, int(resv['error_bytes'].sum(dtype=np.int64))) if (outcome == _lib.INV_ERROR).any() else None
+    out = [None] * n_rgn
+    for i in np.flatnonzero((found != 0) | (outcome != _lib.INV_NONE)):
+        i = int(i)
+        r, rf = res[i], region_flags[i]
         if r.found:
             print('INV Found: outer={}, inner={} (ref outer={}, inner={})'.format(
                 rgn(r.tig_outer, tig_names, True), rgn(r.tig_inner, tig_names, True), rgn(r.ref_outer, ref_names, False),
                 rgn(r.ref_inner, ref_names, False)))
         if r.outcome == _lib.INV_ERROR:
-            out.append(RuntimeError(ctx.inv_text(i, 1, r.error_bytes)))
+            out[i] = RuntimeError(errors[i])
         elif r.outcome == _lib.INV_CALL:
             if eager_tables:
                 sl = slice(int(row_off[i]), int(row_off[i + 1]))
@@ -487,11 +497,9 @@ def _native_scan(ctx, region_flags, align_lift, k_util, max_region_size, logs, s
                 def df(i=i):                    # views of the library's pinned host copy; valid until the next scan
                     cols, flank, match = ctx.inv_table_view(i, generation)
                     return density.table_frame(cols, finalised=True, extra=_flank_match_text(flank.copy(), match.copy()))
-            out.append(InvCall(rgn(r.ref_outer, ref_names, False), rgn(r.ref_inner, ref_names, False),
-                               rgn(r.tig_outer, tig_names, True), rgn(r.tig_inner, tig_names, True),
-                               rgn(r.ref_discovery, ref_names, False), rgn(r.tig_discovery, tig_names, True), rf, df))
-        else:
-            out.append(None)
+            out[i] = InvCall(rgn(r.ref_outer, ref_names, False), rgn(r.ref_inner, ref_names, False),
+                             rgn(r.tig_outer, tig_names, True), rgn(r.tig_inner, tig_names, True),
+                             rgn(r.ref_discovery, ref_names, False), rgn(r.tig_discovery, tig_names, True), rf, df)
     _lap('results')
     return out
 
