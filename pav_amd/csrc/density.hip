@@ -60,7 +60,7 @@ struct EvalTile { uint32_t job, first, count, mode; };   // mode 0: sampled site
 struct HeadEvent { uint32_t job, row; int32_t state; uint32_t index, prev_index; uint32_t pad; };
 
 struct DensityState {
-    DevBuf jobs, stat, kde, tile_job_r, tile_job_t, keys, cnt, first;
+    DevBuf jobs, stat, kde, tile_job_r, tile_job_t, keys, cnt;
     DevBuf st_tmp, tile_sum, tile_pre, index, state_mer, state, kmer, kern[3], list[3], pscaled[3], fill_list;
     DevBuf tiles, events, ev_count, scratch, run_arena;
     std::vector<JobDev> h_jobs;
@@ -77,7 +77,7 @@ struct DensityState {
     uint64_t arena_t = 0;
     bool valid = false;
     void release() {
-        DevBuf *all[] = {&jobs, &stat, &kde, &tile_job_r, &tile_job_t, &keys, &cnt, &first, &st_tmp, &tile_sum, &tile_pre,
+        DevBuf *all[] = {&jobs, &stat, &kde, &tile_job_r, &tile_job_t, &keys, &cnt, &st_tmp, &tile_sum, &tile_pre,
                          &index, &state_mer, &state, &kmer, &kern[0], &kern[1], &kern[2], &list[0], &list[1], &list[2],
                          &pscaled[0], &pscaled[1], &pscaled[2], &fill_list, &tiles, &events, &ev_count, &scratch, &run_arena};
         for (DevBuf *b : all) b->release();
@@ -140,11 +140,29 @@ __device__ __forceinline__ uint32_t table_insert(unsigned long long *__restrict_
     }
 }
 
+// Insert; `dup` tells whether the key was already there.
+__device__ __forceinline__ uint32_t table_insert_dup(unsigned long long *__restrict__ keys, uint64_t off, uint32_t hmask,
+                                                     uint64_t key, bool &dup) {
+    uint32_t s = (uint32_t)mix64(key) & hmask;
+    while (true) {
+        const unsigned long long old = atomicCAS(&keys[off + s], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+        if (old == EMPTY_KEY) { dup = false; return s; }
+        if (old == key) { dup = true; return s; }
+        s = (s + 1) & hmask;
+    }
+}
+
+__device__ __forceinline__ uint32_t table_slot(const unsigned long long *__restrict__ keys, uint64_t off, uint32_t hmask, uint64_t key) {
+    uint32_t s = (uint32_t)mix64(key) & hmask;
+    while (keys[off + s] != key) s = (s + 1) & hmask;                  // the key is known to be present
+    return s;
+}
+
 // ---- reference k-mers -> hash set with counts (pavlib/seq.py:305-325; -r: scripts/density.py:538-539) ----------
+// One atomic per k-mer in the common case: cnt[] holds (occurrences - 1) and is only touched by repeats.
 __global__ __launch_bounds__(256) void k_ref_insert(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
                                                     SeqView R, int k, uint32_t limit, unsigned long long *__restrict__ keys,
-                                                    uint32_t *__restrict__ cnt, uint32_t *__restrict__ first,
-                                                    JobStat *__restrict__ stat) {
+                                                    uint32_t *__restrict__ cnt, JobStat *__restrict__ stat) {
     const uint64_t ap = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint32_t j = tile_job[ap / DTILE];
     const JobDev jd = jobs[j];
@@ -155,9 +173,9 @@ __global__ __launch_bounds__(256) void k_ref_insert(const JobDev *__restrict__ j
         valid = kmer_window(R.two, R.mask, jd.ref_abs + i, k, x);
         if (valid) {
             const uint64_t key = jd.ref_rc ? (x ^ kmer_mask(k)) : rev_groups(x, k);   // set of rc(kmer) when -r true
-            const uint32_t s = table_insert(keys, jd.ht_off, jd.ht_mask, key);
-            const uint32_t c = atomicAdd(&cnt[jd.ht_off + s], 1u) + 1u;
-            atomicMin(&first[jd.ht_off + s], (uint32_t)i);
+            bool dup;
+            const uint32_t s = table_insert_dup(keys, jd.ht_off, jd.ht_mask, key, dup);
+            const uint32_t c = dup ? atomicAdd(&cnt[jd.ht_off + s], 1u) + 2u : 1u;
             if (c > limit) atomicMax(&stat[j].max_count, c);
         }
     }
@@ -165,14 +183,19 @@ __global__ __launch_bounds__(256) void k_ref_insert(const JobDev *__restrict__ j
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(&stat[j].n_ref_valid, (uint32_t)__popcll(b));
 }
 
-// Failure path only: first-inserted k-mer among those with the maximum count (message of scripts/density.py:519-526)
-__global__ void k_max_kmer(const JobDev *__restrict__ jobs, uint32_t j, const uint32_t *__restrict__ cnt,
-                           const uint32_t *__restrict__ first, JobStat *__restrict__ stat) {
+// Failure path only: first-inserted k-mer among those with the maximum count (message of scripts/density.py:519-526):
+// the smallest reference position whose k-mer reached the maximum.
+__global__ void k_max_kmer(const JobDev *__restrict__ jobs, uint32_t j, SeqView R, int k, const unsigned long long *__restrict__ keys,
+                           const uint32_t *__restrict__ cnt, JobStat *__restrict__ stat) {
     const JobDev jd = jobs[j];
     const uint32_t mx = stat[j].max_count;
-    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s <= jd.ht_mask; s += gridDim.x * blockDim.x)
-        if (cnt[jd.ht_off + s] == mx)
-            atomicMin(&stat[j].max_key, ((unsigned long long)first[jd.ht_off + s] << 32) | s);
+    for (uint64_t i = blockIdx.x * blockDim.x + threadIdx.x; i + (uint64_t)k <= jd.ref_len; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t x;
+        if (!kmer_window(R.two, R.mask, jd.ref_abs + i, k, x)) continue;
+        const uint64_t key = jd.ref_rc ? (x ^ kmer_mask(k)) : rev_groups(x, k);
+        const uint32_t s = table_slot(keys, jd.ht_off, jd.ht_mask, key);
+        if (cnt[jd.ht_off + s] + 1u == mx) atomicMin(&stat[j].max_key, ((unsigned long long)i << 32) | s);
+    }
 }
 
 // ---- contig k-mers -> STATE_MER (scripts/density.py:165-175) -------------------------------------------------
@@ -839,7 +862,6 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     PAV_HIP(ctx, D->tile_job_t.reserve(4ull * n_tiles_t));
     PAV_HIP(ctx, D->keys.reserve(8 * a_h));
     PAV_HIP(ctx, D->cnt.reserve(4 * a_h));
-    PAV_HIP(ctx, D->first.reserve(4 * a_h));
     PAV_HIP(ctx, D->st_tmp.reserve(a_t + 64));
     PAV_HIP(ctx, D->tile_sum.reserve(16ull * n_tiles_t));
     PAV_HIP(ctx, D->tile_pre.reserve(32ull * (n_tiles_t + 1)));
@@ -861,7 +883,6 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     PAV_HIP(ctx, hipMemsetAsync(D->stat.p, 0, sizeof(JobStat) * n_jobs, st));
     PAV_HIP(ctx, hipMemsetAsync(D->keys.p, 0xFF, 8 * a_h, st));
     PAV_HIP(ctx, hipMemsetAsync(D->cnt.p, 0, 4 * a_h, st));
-    PAV_HIP(ctx, hipMemsetAsync(D->first.p, 0xFF, 4 * a_h, st));
 
     const JobDev *d_jobs = D->jobs.as<JobDev>();
     JobStat *d_stat = D->stat.as<JobStat>();
@@ -872,7 +893,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     // ---- k-mer states and compaction -------------------------------------------------------------------------
     { int rcw = wait_planes(ctx); if (rcw != PAV_OK) return rcw; }
     PAV_LAUNCH(ctx, "k_ref_insert", k_ref_insert, (uint32_t)(a_r / 256), 256, 0, d_jobs, d_tjr, RV, k, pp->max_ref_kmer_count,
-               d_keys, D->cnt.as<uint32_t>(), D->first.as<uint32_t>(), d_stat);
+               d_keys, D->cnt.as<uint32_t>(), d_stat);
     PAV_LAUNCH(ctx, "k_tig_state", k_tig_state, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, TV, k, d_keys,
                D->st_tmp.as<int8_t>(), d_stat);
     PAV_LAUNCH(ctx, "k_compact_reduce", k_compact_reduce, n_tiles_t, 256, 0, d_tjt, d_stat, D->st_tmp.as<int8_t>(),
@@ -989,7 +1010,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     for (uint32_t j = 0; j < n_jobs; ++j) {
         if (D->results[j].fail_kind != 2) continue;
         PAV_HIP(ctx, hipMemsetAsync(&d_stat[j].max_key, 0xFF, sizeof(unsigned long long), st));
-        PAV_LAUNCH(ctx, "k_max_kmer", k_max_kmer, 64, 256, 0, d_jobs, j, D->cnt.as<uint32_t>(), D->first.as<uint32_t>(), d_stat);
+        PAV_LAUNCH(ctx, "k_max_kmer", k_max_kmer, 64, 256, 0, d_jobs, j, RV, k, d_keys, D->cnt.as<uint32_t>(), d_stat);
         unsigned long long packed = 0, key = 0;
         PAV_HIP(ctx, hipMemcpyAsync(&packed, &d_stat[j].max_key, sizeof packed, hipMemcpyDeviceToHost, st));
         PAV_HIP(ctx, hipStreamSynchronize(st));
