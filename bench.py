@@ -236,6 +236,20 @@ def main():
             'snv_bases': 18.0 * n_snv,
             'seq_gather': 2.0 * counts.seq_bytes,
         }
+        if args.workload == 'cigar+inv':
+            # k-mer kernels: per scanned base 0.375 B of packed planes, 8 B per key inserted,
+            # 2 x 8 B per contig k-mer probed + 1 B of state; `scanned` = region bases over all scan iterations of a step,
+            # spread over the launches of a step (one per lock-step round)
+            import re as _re
+            scanned_bp = 0
+            for lg in inv_state['logs']:
+                for ln in lg.getvalue().splitlines():
+                    if ln.startswith('Scanning region: '):
+                        m = _re.search(r':(\d+)-(\d+)', ln.split(': ')[1])
+                        scanned_bp += int(m.group(2)) - int(m.group(1)) + 1
+            for kname, per_base in (('k_ref_insert', 8.375), ('k_tig_state', 17.375)):
+                if kname in kern and kern[kname]['launches']:
+                    alg_bytes[kname] = per_base * scanned_bp * args.steps / kern[kname]['launches']
         # HBM traffic of the dominant kernel from the committed PMC summary of the same workload (profiles/r01_pmc.json;
         # separate rocprofv3 --pmc passes).  FETCH_SIZE is doubled for the streaming pack kernel as the guide prescribes.
         traffic = None

@@ -9,6 +9,12 @@ import sys
 
 
 def short(name):
+    import re
+    name = name.replace('(anonymous namespace)::', '')
+    m = re.search(r'rocprim::\w+::detail::(?:trampoline_kernel<rocprim::\w+::detail::wrapped_)?(\w+?)(?:_config)?<', name)
+    if m:
+        vals = 'pairs' if re.search(r'unsigned long long, unsigned (int|long long)>', name) else 'keys'
+        return 'rocprim::' + m.group(1) + ('/' + vals if 'sort' in m.group(1) else '')
     name = name.split('(')[0]
     return name.replace('pav::', '')
 
@@ -18,12 +24,21 @@ def stats(db, out):
     rows = cur.execute(
         "select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels "
         "group by name order by sum(duration) desc").fetchall()
+    merged = {}
+    for n, c, t, a, mn, mx in rows:                       # template instances of one library kernel are listed together
+        k = short(n)
+        if k in merged:
+            m = merged[k]
+            merged[k] = (k, m[1] + c, m[2] + t, (m[2] + t) / (m[1] + c), min(m[4], mn), max(m[5], mx))
+        else:
+            merged[k] = (k, c, t, a, mn, mx)
+    rows = sorted(merged.values(), key=lambda r: -r[2])
     tot = sum(r[2] for r in rows) or 1
     with open(out, 'w') as fh:
         fh.write(f'# rocprofv3 --kernel-trace --stats  ({db})\n')
         fh.write(f'{"kernel":34s} {"calls":>6s} {"total_us":>12s} {"avg_us":>10s} {"min_us":>10s} {"max_us":>10s} {"pct":>6s}\n')
         for n, c, t, a, mn, mx in rows:
-            fh.write(f'{short(n):34s} {c:6d} {t / 1e3:12.1f} {a / 1e3:10.2f} {mn / 1e3:10.2f} {mx / 1e3:10.2f} {100 * t / tot:6.2f}\n')
+            fh.write(f'{n:34s} {c:6d} {t / 1e3:12.1f} {a / 1e3:10.2f} {mn / 1e3:10.2f} {mx / 1e3:10.2f} {100 * t / tot:6.2f}\n')
     print(open(out).read())
 
 
