@@ -32,7 +32,8 @@ enum {
     PAV_E_NODEV = -3,      /* no usable gfx950 device                                                  */
     PAV_E_CIGAR = -4,      /* illegal / malformed CIGAR: details via pav_cigar_error()                 */
     PAV_E_STATE = -5,      /* call order violated (e.g. call before load)                              */
-    PAV_E_LIMIT = -6       /* a documented size limit was exceeded                                     */
+    PAV_E_LIMIT = -6,      /* a documented size limit was exceeded                                     */
+    PAV_E_TRIM = -7        /* alignment trimming would have raised: details via pav_trim_error()      */
 };
 
 enum { PAV_ROLE_REF = 0, PAV_ROLE_TIG = 1 };
@@ -321,6 +322,69 @@ int pav_inv_table_view(pav_ctx *ctx, uint32_t region, uint32_t *n_rows, const ui
 int pav_inv_tables(pav_ctx *ctx, uint32_t n_regions, const uint64_t *row_off, int64_t *index, int8_t *state_mer,
                    int8_t *state, double *kern_fwd, double *kern_fwdrev, double *kern_rev, uint64_t *kmer, uint8_t *flank,
                    uint8_t *match);
+
+/* ---- alignment trimming ------------------------------------------------ *
+ * Replaces pavlib.align.trim_alignments and its helpers trim_alignment_record, find_cut_sites, trace_cigar_to_zero
+ * (pavlib/align/trim.py:11-917; rules align_trim_tig / align_trim_tigref, rules/align.snakefile:54-97).  Every CIGAR is
+ * tokenised once on the device; a record's CIGAR is then a window into that operation array plus the clipping trimming
+ * adds, so a pair of overlapping records costs the operations inside the overlap.  The host mirror keeps the DataFrame,
+ * does the reference's sorts and calls one pass per mode with the iteration order. */
+typedef struct {            /* one alignment row: what the trimming loops read and write                            */
+    uint32_t chrom;         /* #CHROM, compared for equality only                                                  */
+    uint32_t qry_id;        /* QRY_ID, compared for equality only                                                  */
+    int64_t pos, end, qry_pos, qry_end;
+    int64_t index;          /* INDEX; set to -1 when the record is dropped (contained / shorter than the minimum)  */
+    int32_t rev;            /* REV                                                                                 */
+    int32_t modified;       /* out: the CIGAR string changed                                                       */
+    int64_t trim_ref_l, trim_ref_r, trim_qry_l, trim_qry_r;    /* TRIM_REF_L ... (rules/align.snakefile:166-169)    */
+} pav_trim_row;
+
+enum { PAV_TRIM_QUERY = 0, PAV_TRIM_SUBJECT = 1 };             /* match_coord 'query' / 'subject'                  */
+enum {                                                         /* pav_trim_err.kind: the RuntimeError of ...       */
+    PAV_TRIM_ERR_NONE = 0,
+    PAV_TRIM_ERR_NEGATIVE = 1,       /* 'Cannot trim to negative distance'        trim.py:428-434, 445-451        */
+    PAV_TRIM_ERR_ORDER = 2,          /* 'Contigs are incorrectly ordered in subject space'  trim.py:436-441       */
+    PAV_TRIM_ERR_ILLEGAL_OP = 3,     /* 'Illegal operation in contig alignment while trimming'  trim.py:880-883   */
+    PAV_TRIM_ERR_NO_CUT = 4          /* 'Program bug: Found no cut-sites'          trim.py:465-470                 */
+};
+typedef struct {
+    int32_t kind;
+    uint32_t row_l, row_r;  /* record_l / record_r of the failing trim_alignment_record call (loaded row numbers)   */
+    uint32_t op_index;      /* kind 3: operation index in trimming orientation ('CIGAR operation #')               */
+    uint32_t op_char;       /* kind 3                                                                              */
+    int32_t side;           /* kind 3: 0 = the operation is in record_l, 1 = record_r                              */
+    int64_t diff_bp;        /* kind 1                                                                              */
+    uint64_t op_len;        /* kind 3                                                                              */
+} pav_trim_err;
+
+enum {                      /* pav_trim_count.err_kind: the RuntimeError count_cigar raises (align.py:560-664)       */
+    PAV_TRIM_CHECK_OK = 0, PAV_TRIM_CHECK_DUP_S_L = 1, PAV_TRIM_CHECK_DUP_H_L = 2, PAV_TRIM_CHECK_S_BEFORE_H_L = 3,
+    PAV_TRIM_CHECK_CLIP_INSIDE = 4, PAV_TRIM_CHECK_DUP_S_R = 5, PAV_TRIM_CHECK_H_BEFORE_S_R = 6, PAV_TRIM_CHECK_DUP_H_R = 7,
+    PAV_TRIM_CHECK_M = 8, PAV_TRIM_CHECK_BAD_OP = 9
+};
+typedef struct {            /* count_cigar of a record's current CIGAR (input of check_record, align.py:364-509)      */
+    int64_t ref_bp, tig_bp, clip_h_l, clip_s_l, clip_h_r, clip_s_r;
+    int32_t err_kind;
+    uint32_t err_op;        /* operation index of the failure                                                      */
+    uint64_t err_len;
+    uint32_t err_char;
+    uint32_t pad;
+} pav_trim_count;
+
+/* Upload the table and tokenise the CIGAR strings (PAV_E_CIGAR + pav_cigar_error on a malformed string). */
+int pav_trim_load(pav_ctx *ctx, uint32_t n, const pav_trim_row *rows, const uint8_t *cigar_text, const uint64_t *cigar_off);
+/* One pass of the pair loop over the rows listed in `order` (loaded row numbers in the reference's iteration order:
+ * QRY_ID / QRY_LEN descending for PAV_TRIM_QUERY, trim.py:64-66; #CHROM / END - POS descending for PAV_TRIM_SUBJECT,
+ * trim.py:267-274).  PAV_E_TRIM + pav_trim_error when the reference would have raised. */
+int pav_trim_pass(pav_ctx *ctx, uint32_t n_order, const uint32_t *order, int mode, int64_t min_trim_tig_len, int match_tig);
+/* trim_alignment_record (trim.py:357-599) on two loaded rows: record_l = row_l, record_r = row_r, rev_l / rev_r as in
+ * the reference (trim that record from its downstream end).  Both rows are replaced by their trimmed versions. */
+int pav_trim_pair(pav_ctx *ctx, uint32_t row_l, uint32_t row_r, int mode, int rev_l, int rev_r);
+int pav_trim_error(const pav_ctx *ctx, pav_trim_err *err);
+/* Current state of every loaded row, count_cigar of its CIGAR, and the total size of the CIGAR strings (any pointer may
+ * be NULL); then the strings themselves: row i = text[off[i] .. off[i + 1]). */
+int pav_trim_fetch(pav_ctx *ctx, pav_trim_row *rows, pav_trim_count *counts, uint64_t *cigar_bytes);
+int pav_trim_fetch_cigar(pav_ctx *ctx, uint8_t *text, uint64_t *off);
 
 /* ---- inversion-signature flagging --------------------------------------- *
  * Replaces the run: bodies of rules call_inv_cluster (rules/call_inv.snakefile:603-692),

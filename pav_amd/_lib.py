@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libpav_amd.so')
 
 PAV_ROLE_REF, PAV_ROLE_TIG = 0, 1
-PAV_OK, PAV_E_ARG, PAV_E_HIP, PAV_E_NODEV, PAV_E_CIGAR, PAV_E_STATE, PAV_E_LIMIT = 0, -1, -2, -3, -4, -5, -6
+PAV_OK, PAV_E_ARG, PAV_E_HIP, PAV_E_NODEV, PAV_E_CIGAR, PAV_E_STATE, PAV_E_LIMIT, PAV_E_TRIM = 0, -1, -2, -3, -4, -5, -6, -7
 
 
 class PavDeviceError(RuntimeError):
@@ -123,6 +123,21 @@ SIG_SVINDEL, SIG_SV, SIG_SINGLE_CLUSTER, SIG_NONE = 0, 1, 2, 3
 FLAG_TABLES = ('insdel_sv', 'insdel_indel', 'cluster_indel', 'cluster_snv')          # order of pav_flag_merge_loci
 
 
+TRIM_ROW_DTYPE = np.dtype([('chrom', '<u4'), ('qry_id', '<u4'), ('pos', '<i8'), ('end', '<i8'), ('qry_pos', '<i8'), ('qry_end', '<i8'),
+                           ('index', '<i8'), ('rev', '<i4'), ('modified', '<i4'), ('trim_ref_l', '<i8'), ('trim_ref_r', '<i8'),
+                           ('trim_qry_l', '<i8'), ('trim_qry_r', '<i8')])
+TRIM_COUNT_DTYPE = np.dtype([('ref_bp', '<i8'), ('tig_bp', '<i8'), ('clip_h_l', '<i8'), ('clip_s_l', '<i8'), ('clip_h_r', '<i8'),
+                             ('clip_s_r', '<i8'), ('err_kind', '<i4'), ('err_op', '<u4'), ('err_len', '<u8'), ('err_char', '<u4'),
+                             ('pad', '<u4')])
+assert TRIM_ROW_DTYPE.itemsize == 88 and TRIM_COUNT_DTYPE.itemsize == 72
+TRIM_QUERY, TRIM_SUBJECT = 0, 1
+
+
+class TrimErr(ctypes.Structure):
+    _fields_ = [('kind', ctypes.c_int32), ('row_l', ctypes.c_uint32), ('row_r', ctypes.c_uint32), ('op_index', ctypes.c_uint32),
+                ('op_char', ctypes.c_uint32), ('side', ctypes.c_int32), ('diff_bp', ctypes.c_int64), ('op_len', ctypes.c_uint64)]
+
+
 class FlagParams(ctypes.Structure):
     _fields_ = [('cluster_win', ctypes.c_int64), ('cluster_min_snv', ctypes.c_int64), ('cluster_min_indel', ctypes.c_int64),
                 ('insdel_flank_cluster', ctypes.c_int64), ('insdel_flank_merge', ctypes.c_int64),
@@ -177,6 +192,12 @@ SYMBOLS = {
     'pav_inv_tables': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'pav_kmer_rev_complement': (ctypes.c_uint64, [ctypes.c_uint64, ctypes.c_int]),
     'pav_kmer_canonical': (ctypes.c_uint64, [ctypes.c_uint64, ctypes.c_int]),
+    'pav_trim_load': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P]),
+    'pav_trim_pass': (ctypes.c_int, [_P, ctypes.c_uint32, _P, ctypes.c_int, ctypes.c_int64, ctypes.c_int]),
+    'pav_trim_pair': (ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    'pav_trim_error': (ctypes.c_int, [_P, _P]),
+    'pav_trim_fetch': (ctypes.c_int, [_P, _P, _P, _P]),
+    'pav_trim_fetch_cigar': (ctypes.c_int, [_P, _P, _P]),
     'pav_flag_params_default': (None, [_P]),
     'pav_flag_cluster': (ctypes.c_int, [_P, ctypes.c_uint64, _P, _P, _P, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _P, _P]),
     'pav_flag_insdel': (ctypes.c_int, [_P, ctypes.c_uint64, _P, _P, _P, ctypes.c_uint64, _P, _P, _P, ctypes.c_int64,
@@ -343,6 +364,52 @@ class Context:
         self._check(self.lib.pav_cigar_write_tables(self.handle, ctypes.byref(opts), ctypes.byref(n1), ctypes.byref(n2)),
                     'pav_cigar_write_tables')
         return int(n1.value), int(n2.value)
+
+    # ---- alignment trimming ---------------------------------------------------------------------------------------
+    def trim_load(self, rows, cigar_text, cigar_off):
+        rows = np.ascontiguousarray(rows, dtype=TRIM_ROW_DTYPE)
+        cigar_text = np.ascontiguousarray(cigar_text, dtype=np.uint8)
+        cigar_off = np.ascontiguousarray(cigar_off, dtype=np.uint64)
+        rc = self.lib.pav_trim_load(self.handle, rows.shape[0], _ptr(rows), _ptr(cigar_text), ctypes.c_void_p(cigar_off.ctypes.data))
+        if rc == PAV_E_CIGAR:
+            err = CigarErr()
+            self.lib.pav_cigar_error(self.handle, ctypes.byref(err))
+            raise CigarDeviceError(self.lib.pav_last_error(self.handle).decode(), err)
+        self._check(rc, 'pav_trim_load')
+        self._trim_n = rows.shape[0]
+
+    def trim_pass(self, order, mode, min_trim_tig_len, match_tig=False):
+        """One pair-loop pass; raises TrimDeviceError (with the pav_trim_err detail) where the reference would raise."""
+        order = np.ascontiguousarray(order, dtype=np.uint32)
+        rc = self.lib.pav_trim_pass(self.handle, order.shape[0], _ptr(order), int(mode), int(min_trim_tig_len), int(bool(match_tig)))
+        if rc == PAV_E_TRIM:
+            err = TrimErr()
+            self.lib.pav_trim_error(self.handle, ctypes.byref(err))
+            raise TrimDeviceError(self.lib.pav_last_error(self.handle).decode(), err)
+        self._check(rc, 'pav_trim_pass')
+
+    def trim_pair(self, row_l, row_r, mode, rev_l, rev_r):
+        rc = self.lib.pav_trim_pair(self.handle, int(row_l), int(row_r), int(mode), int(bool(rev_l)), int(bool(rev_r)))
+        if rc == PAV_E_TRIM:
+            err = TrimErr()
+            self.lib.pav_trim_error(self.handle, ctypes.byref(err))
+            raise TrimDeviceError(self.lib.pav_last_error(self.handle).decode(), err)
+        self._check(rc, 'pav_trim_pair')
+
+    def trim_fetch(self, with_cigar=True):
+        """-> (rows, count_cigar records, list of CIGAR strings or None) for every loaded row."""
+        n = self._trim_n
+        rows = np.zeros(n, dtype=TRIM_ROW_DTYPE)
+        counts = np.zeros(n, dtype=TRIM_COUNT_DTYPE)
+        nbytes = ctypes.c_uint64(0)
+        self._check(self.lib.pav_trim_fetch(self.handle, _ptr(rows), _ptr(counts), ctypes.byref(nbytes)), 'pav_trim_fetch')
+        if not with_cigar:
+            return rows, counts, None
+        text = np.zeros(int(nbytes.value), dtype=np.uint8)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        self._check(self.lib.pav_trim_fetch_cigar(self.handle, _ptr(text), ctypes.c_void_p(off.ctypes.data)), 'pav_trim_fetch_cigar')
+        raw = text.tobytes()
+        return rows, counts, [raw[int(off[i]):int(off[i + 1])].decode() for i in range(n)]
 
     # ---- inversion-signature flagging ---------------------------------------------------------------------------
     @staticmethod
@@ -575,6 +642,14 @@ class Context:
                         'pav_prof_get')
             out[name.value.decode()] = (int(launches.value), float(ms.value))
         return out
+
+
+class TrimDeviceError(RuntimeError):
+    """pav_trim_pass returned PAV_E_TRIM; ``detail`` is the TrimErr record the host mirror turns into the reference's message."""
+
+    def __init__(self, message, detail=None):
+        super().__init__(message)
+        self.detail = detail
 
 
 class CigarDeviceError(RuntimeError):

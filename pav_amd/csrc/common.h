@@ -93,6 +93,7 @@ struct pav_ctx {
     void *density = nullptr;
     void *invscan = nullptr;              // native scan driver state (invscan.hip)
     void *flag = nullptr;                 // flagging scratch + results (flag.hip)
+    void *trim = nullptr;                 // alignment trimming state (trim.hip)
 
     // profiling
     bool prof_on = false;

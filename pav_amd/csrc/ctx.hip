@@ -189,6 +189,7 @@ pav_ctx *pav_create(int device_id) {
 void pav_density_release(pav_ctx *ctx);   // density.hip
 void pav_invscan_release(pav_ctx *ctx);   // invscan.hip
 void pav_flag_release(pav_ctx *ctx);      // flag.hip
+void pav_trim_release(pav_ctx *ctx);      // trim.hip
 
 void pav_destroy(pav_ctx *ctx) {
     if (!ctx) return;
@@ -199,6 +200,7 @@ void pav_destroy(pav_ctx *ctx) {
     pav_density_release(ctx);
     pav_invscan_release(ctx);
     pav_flag_release(ctx);
+    pav_trim_release(ctx);
     for (auto &p : ctx->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto ev : ctx->ev_pool) (void)hipEventDestroy(ev);
     for (int r = 0; r < 2; ++r) {

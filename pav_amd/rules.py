@@ -305,3 +305,18 @@ def call_inv_flag(bed, bed_trim, tig_fa_name, ref_fa_name, out=None, ctx=None, d
             raise KeyError(name)
         _write_bed(res[name], path)
     return res
+
+
+# ---------------------------------------------------------------------------------------------------------
+# rules align_trim_tig / align_trim_tigref (rules/align.snakefile:54-97)
+# ---------------------------------------------------------------------------------------------------------
+
+def align_trim(bed, tig_fai, mode, bed_out=None, min_trim_tig_len=1000, redundant_callset=False, ctx=None, device_id=0):
+    """Body of rule align_trim_tig (``mode='tig'``, input = trim-none table) or align_trim_tigref (``mode='ref'``, input =
+    trim-tig table; ``redundant_callset`` -> match_tig)."""
+    from .align import trim_alignments
+    df = trim_alignments(pd.read_csv(bed, sep='\t', dtype={'#CHROM': str}), int(min_trim_tig_len), tig_fai,
+                         match_tig=bool(redundant_callset) if mode == 'ref' else False, mode=mode, ctx=ctx, device_id=device_id)
+    if bed_out is not None:
+        df.to_csv(bed_out, sep='\t', index=False, compression='gzip')
+    return df

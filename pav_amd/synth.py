@@ -340,3 +340,119 @@ def config2(seed=1002, scale=1.0, hap_index=0, ref=None, lengths=None, threads=8
                              inv_every=int(25_000_000 * max(scale, 0.02)) if scale < 1 else 25_000_000)
     med = max(20_000, int(1_000_000 * min(1.0, scale * 10)))
     return make_haplotype(ref, seed * 64 + hap_index, f'h{hap_index + 1}', seg_median=med, threads=threads, **kw)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Untrimmed alignment tables with overlapping records (input of the trimming rules, rules/align.snakefile:54-97).
+# Trimming reads coordinates and CIGAR strings only, so no sequence is generated.
+# ---------------------------------------------------------------------------------------------------------
+
+def _random_cigar_ops(rng, qry_len, snv_rate, indel_rate, max_indel, ragged):
+    """CIGAR operations (len, op) consuming exactly ``qry_len`` query bases; returns (ops, ref_bp)."""
+    ops, q, ref = [], 0, 0
+    first = True
+    while q < qry_len:
+        left = qry_len - q
+        run = int(min(left, rng.geometric(min(0.5, snv_rate + indel_rate))))
+        if first and ragged and rng.random() < 0.5:
+            run = 0                                                   # alignment starts on a variant
+        first = False
+        if run:
+            ops.append((run, '='))
+            q += run
+            ref += run
+        left = qry_len - q
+        if not left:
+            break
+        u = rng.random() * (snv_rate + indel_rate)
+        if u < snv_rate:
+            n = int(min(left, 1 + rng.integers(0, 3)))
+            ops.append((n, 'X'))
+            q += n
+            ref += n
+        elif rng.random() < 0.5:
+            n = int(min(left, 1 + rng.integers(0, max_indel)))
+            ops.append((n, 'I'))
+            q += n
+        else:
+            n = int(1 + rng.integers(0, max_indel))
+            ops.append((n, 'D'))
+            ref += n
+    while not ragged and ops and ops[-1][1] in 'ID' and len(ops) > 1:    # aligners do not end on an indel
+        n, op = ops.pop()
+        if op == 'I':
+            ops.append((n, '='))
+            ref += n
+        else:
+            ref -= n
+    merged = []
+    for n, op in ops:
+        if merged and merged[-1][1] == op:
+            merged[-1] = (merged[-1][0] + n, op)
+        else:
+            merged.append((n, op))
+    return merged, ref
+
+
+def make_overlap_table(seed, n_tigs=40, chroms=('chr1', 'chr10', 'chr2'), tig_len=(40_000, 200_000), snv_rate=2e-3,
+                       indel_rate=1e-3, max_indel=60, max_overlap=4_000, short_frac=0.08, soft_frac=0.15, hap='h1'):
+    """Alignment table (trim-none schema + TRIM_* = 0, rules/align.snakefile:166-169) whose records overlap in query and in
+    reference space the way split alignments around SVs do: neighbouring records of a contig share up to ``max_overlap``
+    query bases (same or different chromosome / strand, sometimes one inside the other), records of different contigs pile
+    up on the same reference intervals, some records are shorter than the minimum aligned length.  Returns
+    ``(DataFrame, Series of contig lengths)``."""
+    import pandas as pd
+    rng = np.random.default_rng(seed)
+    rows, tig_lens = [], {}
+    placed = []                                                        # (chrom, pos, end) of earlier records
+    index = 0
+    for t in range(n_tigs):
+        tig = 'tig%06d' % t
+        L = int(rng.integers(tig_len[0], tig_len[1]))
+        tig_lens[tig] = L
+        k = int(rng.integers(1, 6))
+        edge = sorted(int(x) for x in rng.integers(200, L - 200, size=k - 1)) if k > 1 else []
+        cuts = [int(rng.integers(0, 150))] + edge + [L - int(rng.integers(0, 150))]
+        prev = None
+        for s in range(k):
+            qs, qe = cuts[s], cuts[s + 1]
+            if qe - qs < 50:
+                continue
+            ov_l = int(rng.integers(0, max_overlap)) if s > 0 and rng.random() < 0.8 else 0
+            ov_r = int(rng.integers(0, max_overlap)) if s + 1 < k and rng.random() < 0.8 else 0
+            if rng.random() < 0.1:
+                ov_l *= 8                                              # may swallow the neighbour (containment)
+            qs, qe = max(0, qs - ov_l), min(L, qe + ov_r)
+            if rng.random() < short_frac:
+                qe = min(qe, qs + int(rng.integers(60, 990)))
+            ragged = rng.random() < 0.25
+            ops, ref_bp = _random_cigar_ops(rng, qe - qs, snv_rate, indel_rate, max_indel, ragged)
+            mode = rng.random()
+            if prev is not None and mode < 0.45:                       # same chromosome and strand, next to the previous record
+                chrom, rev = prev['#CHROM'], prev['REV']
+                shift = int(rng.integers(-max_overlap, max_overlap))
+                pos = (prev['END'] + shift) if not rev else (prev['POS'] - ref_bp - shift)
+            elif prev is not None and mode < 0.6:                      # same chromosome, other strand
+                chrom, rev = prev['#CHROM'], not prev['REV']
+                pos = prev['POS'] + int(rng.integers(-20_000, 20_000))
+            elif placed and mode < 0.8:                                # on top of a record of another contig
+                chrom, p0, p1 = placed[int(rng.integers(0, len(placed)))]
+                rev = bool(rng.integers(0, 2))
+                pos = p0 + int(rng.integers(-ref_bp // 2, max(1, (p1 - p0) // 2 + 1)))
+            else:
+                chrom, rev = chroms[int(rng.integers(0, len(chroms)))], bool(rng.integers(0, 2))
+                pos = int(rng.integers(0, 5_000_000))
+            pos = max(0, int(pos))
+            lead, trail = (L - qe, qs) if rev else (qs, L - qe)
+            clip = 'S' if rng.random() < soft_frac else 'H'
+            cigar = ('%d%s' % (lead, clip) if lead else '') + ''.join('%d%s' % o for o in ops) + ('%d%s' % (trail, clip) if trail else '')
+            row = {'#CHROM': chrom, 'POS': pos, 'END': pos + ref_bp, 'INDEX': index, 'QRY_ID': tig, 'QRY_POS': qs, 'QRY_END': qe,
+                   'QRY_LEN': L, 'RG': 'NA', 'AO': 'NA', 'MAPQ': 60, 'REV': bool(rev), 'FLAGS': '0x0000' if s == 0 else '0x0800',
+                   'HAP': hap, 'CIGAR': cigar, 'CALL_BATCH': t % 10, 'TRIM_REF_L': 0, 'TRIM_REF_R': 0, 'TRIM_QRY_L': 0, 'TRIM_QRY_R': 0}
+            rows.append(row)
+            placed.append((chrom, pos, pos + ref_bp))
+            prev = row
+            index += 1
+    df = pd.DataFrame(rows)
+    df = df.sort_values(['#CHROM', 'POS']).reset_index(drop=True)      # get_align_bed order (align.py:280)
+    return df, pd.Series(tig_lens, name='LEN')

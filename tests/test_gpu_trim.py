@@ -1,0 +1,75 @@
+"""GPU-side parity of alignment trimming against tables produced by the reference's own rule bodies and function
+(tests/golden/trim_*; generator tools/refharness/gen_golden_trim.py)."""
+import gzip
+import io
+import json
+import os
+
+import pandas as pd
+import pytest
+
+from pav_amd import rules
+from pav_amd.align import trim_alignment_record, trim_alignments
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+CASES = [('trim_overlap', 1000), ('trim_dense', 1500)]
+
+
+def gz_text(path):
+    with gzip.open(path, 'rt') as fh:
+        return fh.read()
+
+
+def as_text(df):
+    buf = io.StringIO()
+    df.to_csv(buf, sep='\t', index=False)
+    return buf.getvalue()
+
+
+@pytest.mark.parametrize('case,min_len', CASES)
+def test_rule_align_trim_tig(gpu_ctx, case, min_len, tmp_path):
+    d = os.path.join(GOLD, case)
+    out = tmp_path / 'trim_tig.bed.gz'
+    rules.align_trim(os.path.join(d, 'align_none.tsv.gz'), os.path.join(d, 'tig.fa.fai'), 'tig', bed_out=str(out), min_trim_tig_len=min_len,
+                     ctx=gpu_ctx)
+    assert gz_text(out) == gz_text(os.path.join(d, 'trim_tig.tsv.gz'))
+
+
+@pytest.mark.parametrize('case,min_len', CASES)
+@pytest.mark.parametrize('redundant', [False, True])
+def test_rule_align_trim_tigref(gpu_ctx, case, min_len, redundant, tmp_path):
+    d = os.path.join(GOLD, case)
+    out = tmp_path / 'trim_tigref.bed.gz'
+    rules.align_trim(os.path.join(d, 'trim_tig.tsv.gz'), os.path.join(d, 'tig.fa.fai'), 'ref', bed_out=str(out), min_trim_tig_len=min_len,
+                     redundant_callset=redundant, ctx=gpu_ctx)
+    assert gz_text(out) == gz_text(os.path.join(d, 'trim_tigref_redundant.tsv.gz' if redundant else 'trim_tigref.tsv.gz'))
+
+
+@pytest.mark.parametrize('case,min_len', CASES)
+def test_trim_alignments_both(gpu_ctx, case, min_len):
+    d = os.path.join(GOLD, case)
+    df = trim_alignments(pd.read_csv(os.path.join(d, 'align_none.tsv.gz'), sep='\t', dtype={'#CHROM': str}), min_len,
+                         os.path.join(d, 'tig.fa.fai'), mode='both', ctx=gpu_ctx)
+    assert as_text(df) == gz_text(os.path.join(d, 'trim_both.tsv.gz'))
+    with pytest.raises(RuntimeError, match='Unrecognized trimming mode'):
+        trim_alignments(df, min_len, os.path.join(d, 'tig.fa.fai'), mode='sideways', ctx=gpu_ctx)
+
+
+def test_trim_alignment_record_known_answers(gpu_ctx):
+    with open(os.path.join(GOLD, 'trim_kat.json')) as fh:
+        items = json.load(fh)
+    n_err = 0
+    for it in items:
+        l, r = pd.Series(it['l']), pd.Series(it['r'])
+        if 'error' in it:
+            n_err += 1
+            with pytest.raises(RuntimeError) as ei:
+                trim_alignment_record(l, r, it['match_coord'], rev_l=it['rev_l'], rev_r=it['rev_r'], ctx=gpu_ctx)
+            assert str(ei.value) == it['error'][1]
+            continue
+        a, b = trim_alignment_record(l, r, it['match_coord'], rev_l=it['rev_l'], rev_r=it['rev_r'], ctx=gpu_ctx)
+        assert json.loads(a.to_json()) == it['out_l']
+        assert json.loads(b.to_json()) == it['out_r']
+    assert n_err == 5
