@@ -381,8 +381,9 @@ int pav_trim_pass(pav_ctx *ctx, uint32_t n_order, const uint32_t *order, int mod
  * the reference (trim that record from its downstream end).  Both rows are replaced by their trimmed versions. */
 int pav_trim_pair(pav_ctx *ctx, uint32_t row_l, uint32_t row_r, int mode, int rev_l, int rev_r);
 int pav_trim_error(const pav_ctx *ctx, pav_trim_err *err);
-/* Current state of every loaded row, count_cigar of its CIGAR, and the total size of the CIGAR strings (any pointer may
- * be NULL); then the strings themselves: row i = text[off[i] .. off[i + 1]). */
+/* Current state of every loaded row, count_cigar of its CIGAR, and the total size of the CIGAR strings of the rows whose
+ * `modified` flag is set (any pointer may be NULL: that part is skipped); then the strings themselves: row i =
+ * text[off[i] .. off[i + 1]), empty for unmodified rows (their CIGAR is the input string). */
 int pav_trim_fetch(pav_ctx *ctx, pav_trim_row *rows, pav_trim_count *counts, uint64_t *cigar_bytes);
 int pav_trim_fetch_cigar(pav_ctx *ctx, uint8_t *text, uint64_t *off);
 

@@ -396,20 +396,21 @@ class Context:
             raise TrimDeviceError(self.lib.pav_last_error(self.handle).decode(), err)
         self._check(rc, 'pav_trim_pair')
 
-    def trim_fetch(self, with_cigar=True):
-        """-> (rows, count_cigar records, list of CIGAR strings or None) for every loaded row."""
+    def trim_fetch(self, with_cigar=True, with_counts=True):
+        """-> (rows, count_cigar records or None, CIGAR strings of the modified rows (None elsewhere) or None)."""
         n = self._trim_n
         rows = np.zeros(n, dtype=TRIM_ROW_DTYPE)
-        counts = np.zeros(n, dtype=TRIM_COUNT_DTYPE)
+        counts = np.zeros(n, dtype=TRIM_COUNT_DTYPE) if with_counts else None
         nbytes = ctypes.c_uint64(0)
-        self._check(self.lib.pav_trim_fetch(self.handle, _ptr(rows), _ptr(counts), ctypes.byref(nbytes)), 'pav_trim_fetch')
+        self._check(self.lib.pav_trim_fetch(self.handle, _ptr(rows), _ptr(counts) if with_counts else None,
+                                            ctypes.byref(nbytes) if with_cigar else None), 'pav_trim_fetch')
         if not with_cigar:
             return rows, counts, None
         text = np.zeros(int(nbytes.value), dtype=np.uint8)
         off = np.zeros(n + 1, dtype=np.uint64)
         self._check(self.lib.pav_trim_fetch_cigar(self.handle, _ptr(text), ctypes.c_void_p(off.ctypes.data)), 'pav_trim_fetch_cigar')
         raw = text.tobytes()
-        return rows, counts, [raw[int(off[i]):int(off[i + 1])].decode() for i in range(n)]
+        return rows, counts, [raw[int(off[i]):int(off[i + 1])].decode() if rows['modified'][i] else None for i in range(n)]
 
     # ---- inversion-signature flagging ---------------------------------------------------------------------------
     @staticmethod

@@ -87,7 +87,7 @@ def _run_pass(ctx, df, order, mode, min_trim_tig_len, match_tig):
     except _lib.TrimDeviceError as ex:
         if ex.detail is None:
             raise
-        rows, _, _ = ctx.trim_fetch(with_cigar=False)                 # positions as they were when the pair failed
+        rows, _, _ = ctx.trim_fetch(with_cigar=False, with_counts=False)   # positions as they were when the pair failed
         cur = df.copy()
         for f, c in _TRIM_COLS:
             cur[c] = rows[f]
@@ -110,7 +110,7 @@ def trim_alignment_record(record_l, record_r, match_coord, rev_l=True, rev_r=Fal
             if ex.detail is None:
                 raise
             _raise_trim_error(ex.detail, df, match_coord)
-        rows, _, cigars = ctx.trim_fetch()
+        rows, _, cigars = ctx.trim_fetch(with_counts=False)
     finally:
         if own:
             ctx.close()
@@ -119,7 +119,8 @@ def trim_alignment_record(record_l, record_r, match_coord, rev_l=True, rev_r=Fal
         rec = rec.copy()
         for f, c in _TRIM_COLS:
             rec[c] = int(rows[f][i])
-        rec['CIGAR'] = cigars[i]
+        if cigars[i] is not None:
+            rec['CIGAR'] = cigars[i]
         out.append(rec)
     return out[0], out[1]
 
@@ -189,7 +190,7 @@ def trim_alignments(df, min_trim_tig_len, tig_fai, match_tig=False, mode='both',
             df.reset_index(inplace=True, drop=True)
             _load(ctx, df)
             _run_pass(ctx, df, np.arange(df.shape[0], dtype=np.uint32), _lib.TRIM_QUERY, min_trim_tig_len, False)
-            rows, _, cigars = ctx.trim_fetch()
+            rows, _, cigars = ctx.trim_fetch(with_counts=False)
             df = _store(df, rows, cigars)
             df = df.loc[df['INDEX'] >= 0].copy()                                              # :253
         if do_trim_ref:
@@ -198,7 +199,7 @@ def trim_alignments(df, min_trim_tig_len, tig_fai, match_tig=False, mode='both',
             ].reset_index(drop=True)                                                          # :267-274
             _load(ctx, df)
             _run_pass(ctx, df, np.arange(df.shape[0], dtype=np.uint32), _lib.TRIM_SUBJECT, min_trim_tig_len, match_tig)
-            rows, _, cigars = ctx.trim_fetch()
+            rows, _, cigars = ctx.trim_fetch(with_counts=False)
             df = _store(df, rows, cigars)
             df = df.loc[df['INDEX'] >= 0].copy()                                              # :333
 

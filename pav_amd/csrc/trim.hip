@@ -10,7 +10,9 @@
 #include "common.h"
 
 #include <algorithm>
+#include <atomic>
 #include <string>
+#include <thread>
 
 namespace pav {
 namespace {
@@ -316,6 +318,51 @@ void put_dec(std::string &s, uint64_t v) {
     while (n) s += buf[--n];
 }
 
+// count_cigar (pavlib/align/align.py:534-664) of one record: spans, clipping and the structural checks, first failure wins.
+pav_trim_count count_cigar(const TrimState &S, const Cigar &c) {
+    pav_trim_count cnt{};
+    const size_t n = c.size();
+    bool lead = true;
+    for (size_t k = 0; k < n && !cnt.err_kind; ++k) {
+        const Op o = cigar_get(S, c, k);
+        auto bad = [&](int kind) { cnt.err_kind = kind; cnt.err_op = (uint32_t)k; cnt.err_len = o.len; cnt.err_char = (uint32_t)OP_CHARS[o.code]; };
+        if (lead && (o.code == OP_S || o.code == OP_H)) {
+            if (o.code == OP_S) { if (cnt.clip_s_l > 0) bad(PAV_TRIM_CHECK_DUP_S_L); else cnt.clip_s_l = (int64_t)o.len; }
+            else if (cnt.clip_h_l > 0) bad(PAV_TRIM_CHECK_DUP_H_L);
+            else if (cnt.clip_s_l > 0) bad(PAV_TRIM_CHECK_S_BEFORE_H_L);
+            else cnt.clip_h_l = (int64_t)o.len;
+            continue;
+        }
+        lead = false;
+        const bool clipped = cnt.clip_s_r > 0 || cnt.clip_h_r > 0;
+        switch (o.code) {
+            case OP_EQ: case OP_X: if (clipped) bad(PAV_TRIM_CHECK_CLIP_INSIDE); else { cnt.ref_bp += (int64_t)o.len; cnt.tig_bp += (int64_t)o.len; } break;
+            case OP_I: if (clipped) bad(PAV_TRIM_CHECK_CLIP_INSIDE); else cnt.tig_bp += (int64_t)o.len; break;
+            case OP_D: if (clipped) bad(PAV_TRIM_CHECK_CLIP_INSIDE); else cnt.ref_bp += (int64_t)o.len; break;
+            case OP_S:
+                if (cnt.clip_s_r > 0) bad(PAV_TRIM_CHECK_DUP_S_R);
+                else if (cnt.clip_h_r > 0) bad(PAV_TRIM_CHECK_H_BEFORE_S_R);
+                else cnt.clip_s_r = (int64_t)o.len;
+                break;
+            case OP_H: if (cnt.clip_h_r > 0) bad(PAV_TRIM_CHECK_DUP_H_R); else cnt.clip_h_r = (int64_t)o.len; break;
+            case OP_M: bad(PAV_TRIM_CHECK_M); break;
+            default: bad(PAV_TRIM_CHECK_BAD_OP); break;
+        }
+    }
+    return cnt;
+}
+
+template <class F> void parallel_rows(size_t n, F &&fn) {
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const size_t nt = std::min<size_t>(hw, (n + 63) / 64);
+    if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < nt; ++t)
+        pool.emplace_back([&] { for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); });
+    for (auto &th : pool) th.join();
+}
+
 }  // namespace
 }  // namespace pav
 
@@ -389,59 +436,36 @@ int pav_trim_error(const pav_ctx *ctx, pav_trim_err *err) {
 int pav_trim_fetch(pav_ctx *ctx, pav_trim_row *rows, pav_trim_count *counts, uint64_t *cigar_bytes) {
     if (!ctx) return PAV_E_ARG;
     TrimState *S = tstate(ctx);
-    S->text.clear();
-    S->text_off.assign(S->rows.size() + 1, 0);
-    for (size_t i = 0; i < S->rows.size(); ++i) {
-        const Row &r = S->rows[i];
-        S->text_off[i] = S->text.size();
-        const size_t n = r.c.size();
-        pav_trim_count cnt{};
-        // count_cigar (pavlib/align/align.py:534-664): spans, clipping and the structural checks, first failure wins
-        size_t k = 0;
-        auto bad = [&](int kind, size_t at) { if (!cnt.err_kind) { cnt.err_kind = kind; cnt.err_op = (uint32_t)at; } };
-        bool lead = true;
-        for (; k < n; ++k) {
-            const Op o = cigar_get(*S, r.c, k);
-            put_dec(S->text, o.len);
-            S->text += OP_CHARS[o.code];
-            if (cnt.err_kind) continue;
-            if (lead && (o.code == OP_S || o.code == OP_H)) {
-                if (o.code == OP_S) { if (cnt.clip_s_l > 0) { bad(PAV_TRIM_CHECK_DUP_S_L, k); continue; } cnt.clip_s_l = (int64_t)o.len; }
-                else {
-                    if (cnt.clip_h_l > 0) { bad(PAV_TRIM_CHECK_DUP_H_L, k); continue; }
-                    if (cnt.clip_s_l > 0) { bad(PAV_TRIM_CHECK_S_BEFORE_H_L, k); continue; }
-                    cnt.clip_h_l = (int64_t)o.len;
-                }
-                continue;
-            }
-            lead = false;
-            const bool clipped = cnt.clip_s_r > 0 || cnt.clip_h_r > 0;
-            switch (o.code) {
-                case OP_EQ: case OP_X: if (clipped) { bad(PAV_TRIM_CHECK_CLIP_INSIDE, k); break; } cnt.ref_bp += (int64_t)o.len; cnt.tig_bp += (int64_t)o.len; break;
-                case OP_I: if (clipped) { bad(PAV_TRIM_CHECK_CLIP_INSIDE, k); break; } cnt.tig_bp += (int64_t)o.len; break;
-                case OP_D: if (clipped) { bad(PAV_TRIM_CHECK_CLIP_INSIDE, k); break; } cnt.ref_bp += (int64_t)o.len; break;
-                case OP_S:
-                    if (cnt.clip_s_r > 0) { bad(PAV_TRIM_CHECK_DUP_S_R, k); break; }
-                    if (cnt.clip_h_r > 0) { bad(PAV_TRIM_CHECK_H_BEFORE_S_R, k); break; }
-                    cnt.clip_s_r = (int64_t)o.len; break;
-                case OP_H: if (cnt.clip_h_r > 0) { bad(PAV_TRIM_CHECK_DUP_H_R, k); break; } cnt.clip_h_r = (int64_t)o.len; break;
-                case OP_M: bad(PAV_TRIM_CHECK_M, k); break;
-                default: bad(PAV_TRIM_CHECK_BAD_OP, k); break;
-            }
-            if (cnt.err_kind) { cnt.err_len = o.len; cnt.err_char = (uint32_t)OP_CHARS[o.code]; }
-        }
-        if (rows) { rows[i] = r.f; rows[i].modified = r.c.modified ? 1 : 0; }
-        if (counts) counts[i] = cnt;
+    const size_t n = S->rows.size();
+    if (rows) for (size_t i = 0; i < n; ++i) { rows[i] = S->rows[i].f; rows[i].modified = S->rows[i].c.modified ? 1 : 0; }
+    if (counts) parallel_rows(n, [&](size_t i) { counts[i] = count_cigar(*S, S->rows[i].c); });
+    if (cigar_bytes) {
+        // CIGAR strings of the records trimming changed (the others kept their input string: empty here)
+        std::vector<std::string> parts(n);
+        parallel_rows(n, [&](size_t i) {
+            const Cigar &c = S->rows[i].c;
+            if (!c.modified) return;
+            std::string &t = parts[i];
+            const size_t m = c.size();
+            t.reserve(m * 5 + 16);
+            for (size_t k = 0; k < m; ++k) { const Op o = cigar_get(*S, c, k); put_dec(t, o.len); t += OP_CHARS[o.code]; }
+        });
+        S->text.clear();
+        S->text_off.assign(n + 1, 0);
+        size_t total = 0;
+        for (size_t i = 0; i < n; ++i) { S->text_off[i] = total; total += parts[i].size(); }
+        S->text_off[n] = total;
+        S->text.resize(total);
+        parallel_rows(n, [&](size_t i) { if (!parts[i].empty()) memcpy(&S->text[S->text_off[i]], parts[i].data(), parts[i].size()); });
+        *cigar_bytes = total;
     }
-    S->text_off[S->rows.size()] = S->text.size();
-    if (cigar_bytes) *cigar_bytes = S->text.size();
     return PAV_OK;
 }
 
 int pav_trim_fetch_cigar(pav_ctx *ctx, uint8_t *text, uint64_t *off) {
     if (!ctx || !off) return PAV_E_ARG;
     TrimState *S = tstate(ctx);
-    if (S->text_off.size() != S->rows.size() + 1) return fail(ctx, PAV_E_STATE, "pav_trim_fetch_cigar: call pav_trim_fetch first");
+    if (S->text_off.size() != S->rows.size() + 1) return fail(ctx, PAV_E_STATE, "pav_trim_fetch_cigar: call pav_trim_fetch with cigar_bytes first");
     if (!S->text.empty()) { if (!text) return PAV_E_ARG; memcpy(text, S->text.data(), S->text.size()); }
     memcpy(off, S->text_off.data(), sizeof(uint64_t) * S->text_off.size());
     return PAV_OK;

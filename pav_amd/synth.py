@@ -456,3 +456,61 @@ def make_overlap_table(seed, n_tigs=40, chroms=('chr1', 'chr10', 'chr2'), tig_le
     df = pd.DataFrame(rows)
     df = df.sort_values(['#CHROM', 'POS']).reset_index(drop=True)      # get_align_bed order (align.py:280)
     return df, pd.Series(tig_lens, name='LEN')
+
+
+def split_overlaps(df_align, seed, max_overlap_ops=60, pieces=(2, 4)):
+    """Untrimmed-looking table from a clean one: every record is cut into 2..4 consecutive records whose CIGARs share up to
+    ``max_overlap_ops`` operations (the aligner's view of a repeat-mediated breakpoint: same chromosome and strand,
+    overlapping in contig *and* reference space - the "try both trim orders" branch, trim.py:128-197).  Works on the CIGAR
+    text (numpy), so it scales to the bench haplotype.  Adds TRIM_* = 0; INDEX is renumbered."""
+    import pandas as pd
+    from .align.cigar import tokenize
+    rng = np.random.default_rng(seed)
+    out = []
+    for _, row in df_align.iterrows():
+        text = row['CIGAR']
+        b = np.frombuffer(text.encode(), dtype=np.uint8)
+        lens, ops = tokenize(text)
+        op_end = np.flatnonzero((b < 48) | (b > 57)) + 1                # byte offset one past each operation
+        op_start = np.concatenate(([0], op_end[:-1]))
+        q_adv = np.where(np.isin(ops, np.frombuffer(b'=XIM', dtype=np.uint8)), lens, 0)
+        r_adv = np.where(np.isin(ops, np.frombuffer(b'=XDM', dtype=np.uint8)), lens, 0)
+        clip = np.isin(ops, np.frombuffer(b'SH', dtype=np.uint8))
+        body = np.flatnonzero(~clip)
+        lo, hi = int(body[0]), int(body[-1]) + 1                       # operations [lo, hi) are the aligned part
+        lead = int(lens[:lo].sum())
+        trail = int(lens[hi:].sum())
+        qc = np.concatenate(([0], np.cumsum(q_adv[lo:hi])))           # query / reference consumed before body op i
+        rc = np.concatenate(([0], np.cumsum(r_adv[lo:hi])))
+        nb = hi - lo
+        k = int(rng.integers(pieces[0], pieces[1] + 1))
+        if nb < 40 * k:
+            k = 1
+        cuts = sorted(int(x) for x in rng.integers(10, nb - 10, size=k - 1)) if k > 1 else []
+        bounds = [0] + cuts + [nb]
+        is_match = ops[lo:hi] == ord('=')
+        for p in range(k):
+            a, e = bounds[p], bounds[p + 1]
+            if p > 0:
+                a = max(1, a - int(rng.integers(0, max_overlap_ops // 2 + 1)))
+            if p + 1 < k:
+                e = min(nb - 1, e + int(rng.integers(0, max_overlap_ops // 2 + 1)))
+            while a > 0 and not is_match[a]:                            # records start and end on '=' like the aligner's
+                a -= 1
+            while e < nb and not is_match[e - 1]:
+                e += 1
+            q0, q1, r0, r1 = int(qc[a]), int(qc[e]), int(rc[a]), int(rc[e])
+            new = row.copy()
+            h_lead, h_trail = lead + q0, trail + int(qc[nb]) - q1
+            new['CIGAR'] = ('%dH' % h_lead if h_lead else '') + text[int(op_start[lo + a]):int(op_end[lo + e - 1])] + ('%dH' % h_trail if h_trail else '')
+            new['POS'], new['END'] = int(row['POS']) + r0, int(row['POS']) + r1
+            if bool(row['REV']):
+                new['QRY_POS'], new['QRY_END'] = int(row['QRY_END']) - q1, int(row['QRY_END']) - q0
+            else:
+                new['QRY_POS'], new['QRY_END'] = int(row['QRY_POS']) + q0, int(row['QRY_POS']) + q1
+            out.append(new)
+    df = pd.DataFrame(out).reset_index(drop=True)
+    df['INDEX'] = np.arange(df.shape[0])
+    for c in ('TRIM_REF_L', 'TRIM_REF_R', 'TRIM_QRY_L', 'TRIM_QRY_R'):
+        df[c] = 0
+    return df.sort_values(['#CHROM', 'POS']).reset_index(drop=True)

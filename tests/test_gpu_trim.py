@@ -14,7 +14,7 @@ from pav_amd.align import trim_alignment_record, trim_alignments
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(__file__), 'golden')
-CASES = [('trim_overlap', 1000), ('trim_dense', 1500)]
+CASES = [('trim_overlap', 1000), ('trim_dense', 1500), ('trim_split', 1000)]
 
 
 def gz_text(path):
@@ -73,3 +73,22 @@ def test_trim_alignment_record_known_answers(gpu_ctx):
         assert json.loads(a.to_json()) == it['out_l']
         assert json.loads(b.to_json()) == it['out_r']
     assert n_err == 5
+
+
+def test_trimmed_table_has_no_overlaps(gpu_ctx):
+    """Size-independent property on a larger table than the fixtures: after mode='both' no two records of a contig share
+    contig bases and no two records share reference bases; spans still match the CIGARs (check_record ran)."""
+    from pav_amd import synth
+    hap = synth.config2(seed=77, scale=0.02, threads=4)
+    df0 = synth.split_overlaps(hap.df_align, 77)
+    df = trim_alignments(df0, 1000, hap.tig_lengths, mode='both', ctx=gpu_ctx)
+    assert 0 < df.shape[0] <= df0.shape[0]
+    for key, a, b in (('QRY_ID', 'QRY_POS', 'QRY_END'), ('#CHROM', 'POS', 'END')):
+        for _, g in df.groupby(key):
+            g = g.sort_values(a)
+            assert (g[a].to_numpy()[1:] >= g[b].to_numpy()[:-1]).all(), key
+    trimmed = df[['TRIM_QRY_L', 'TRIM_QRY_R']].to_numpy().sum()
+    assert trimmed > 0
+    # idempotence: a trimmed table is a fixed point
+    again = trim_alignments(df, 1000, hap.tig_lengths, mode='both', ctx=gpu_ctx)
+    assert as_text(again) == as_text(df)

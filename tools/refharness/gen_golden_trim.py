@@ -46,10 +46,14 @@ def regz(src, dst):
         out.write(data)
 
 
-def case(name, seed, min_trim_tig_len=1000, **kw):
+def case(name, seed, min_trim_tig_len=1000, split_scale=None, **kw):
     out = os.path.join(GOLD, name)
     os.makedirs(out, exist_ok=True)
-    df, fai = synth.make_overlap_table(seed, **kw)
+    if split_scale is None:
+        df, fai = synth.make_overlap_table(seed, **kw)
+    else:                                      # the bench haplotype in small: clean records cut into overlapping pieces
+        hap = synth.config2(seed=seed, scale=split_scale, threads=2)
+        df, fai = synth.split_overlaps(hap.df_align, seed, **kw), hap.tig_lengths
     df.to_csv(os.path.join(out, 'align_none.tsv.gz'), sep='\t', index=False, compression=GZ)
     fai_path = os.path.join(out, 'tig.fa.fai')
     with open(fai_path, 'w') as fh:
@@ -151,6 +155,7 @@ def kat():
 def main():
     case('trim_overlap', 21)
     case('trim_dense', 22, n_tigs=25, max_overlap=9_000, snv_rate=6e-3, indel_rate=4e-3, short_frac=0.15, min_trim_tig_len=1500)
+    case('trim_split', 1002, split_scale=0.004)
     kat()
 
 
