@@ -91,6 +91,26 @@ class SrsTree:
         return {iv for iv in self.intervals if iv.begin <= point < iv.end}
 
 
+class IntervalSet:
+    """The slice of ``intervaltree.IntervalTree`` the N-gap trees of the rules use (call_lg.snakefile:76-81,
+    pavlib/inv.py:214-219): ``tree[a:b] = data`` adds an interval, ``tree[a:b]`` returns the intervals overlapping
+    ``[a, b)``, ``tree[x]`` those containing ``x``."""
+
+    def __init__(self):
+        self.intervals = []
+
+    def __setitem__(self, key, data):
+        self.intervals.append(_Interval(key.start, key.stop, data))
+
+    def __getitem__(self, key):
+        if isinstance(key, slice):
+            return {iv for iv in self.intervals if iv.begin < key.stop and iv.end > key.start}
+        return {iv for iv in self.intervals if iv.begin <= key < iv.end}
+
+    def __len__(self):
+        return len(self.intervals)
+
+
 def get_srs_tree(srs_tuple_list):
     """State-run-smooth limits -> lookup by region size (pavlib/inv.py:564-620; same checks and messages)."""
     srs_tree = SrsTree()

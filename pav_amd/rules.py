@@ -320,3 +320,54 @@ def align_trim(bed, tig_fai, mode, bed_out=None, min_trim_tig_len=1000, redundan
     if bed_out is not None:
         df.to_csv(bed_out, sep='\t', index=False, compression='gzip')
     return df
+
+
+# ---------------------------------------------------------------------------------------------------------
+# rules call_lg_split / call_lg_discover (rules/call_lg.snakefile:40-139)
+# ---------------------------------------------------------------------------------------------------------
+
+def call_lg_split(bed, tsv_out=None, batch_count=10):
+    """Body of rule call_lg_split: (CHROM, TIG, BATCH) of every chromosome / contig pair with several alignment records."""
+    import collections
+    df = pd.read_csv(bed, sep='\t')
+    tig_map_count = collections.Counter(df[['#CHROM', 'QRY_ID']].apply(tuple, axis=1)) if df.shape[0] else {}
+    rows = [pd.Series([chrom, tig, index % batch_count], index=['CHROM', 'TIG', 'BATCH'])
+            for index, (chrom, tig) in enumerate([k for k, count in tig_map_count.items() if count > 1])]
+    df_group = pd.concat(rows, axis=1).T if rows else pd.DataFrame([], columns=['CHROM', 'TIG', 'BATCH'])
+    if tsv_out is not None:
+        df_group.to_csv(tsv_out, sep='\t', index=False, compression='gzip')
+    return df_group
+
+
+def call_lg_discover(bed, tsv_group, fa, fai, bed_n, ref_fa, hap, batch, bed_ins=None, bed_del=None, bed_inv=None, log_path=None,
+                     density_out_dir=None, k_size=31, inv_region_limit=None, srs_list=None, threads=1, ctx=None, device_id=0):
+    """Body of rule call_lg_discover: alignment-truncating INS / DEL / INV of one batch of (chromosome, contig) pairs."""
+    import collections
+    import os
+    import sys
+    from . import fasta, inv as pavinv, lgsv
+    srs_tree = pavinv.get_srs_tree(srs_list)
+    df = pd.read_csv(bed, sep='\t', dtype={'#CHROM': str, 'QRY_ID': str})
+    df_tig_fai = fasta.read_fai(fai)
+    df_group = pd.read_csv(tsv_group, sep='\t', dtype={'CHROM': str, 'TIG': str})
+    df_group = df_group.loc[df_group['BATCH'] == int(batch)]
+    group_set = set(df_group[['CHROM', 'TIG']].apply(tuple, axis=1)) if df_group.shape[0] else set()
+    if df.shape[0] > 0:
+        df = df.loc[df.apply(lambda row: (row['#CHROM'], row['QRY_ID']) in group_set, axis=1)]
+    n_tree = collections.defaultdict(pavinv.IntervalSet)
+    for _, row in pd.read_csv(bed_n, sep='\t', dtype={'#CHROM': str}).iterrows():
+        n_tree[row['#CHROM']][row['POS']:row['END']] = True
+    if density_out_dir is not None:
+        os.makedirs(density_out_dir, exist_ok=True)
+    log_file = open(log_path, 'wt') if log_path is not None else sys.stdout
+    try:
+        df_ins, df_del, df_inv = lgsv.scan_for_events(df, df_tig_fai, hap, ref_fa, fa, k_size=k_size, n_tree=n_tree, srs_tree=srs_tree,
+                                                      threads=threads, log=log_file, density_out_dir=density_out_dir,
+                                                      max_region_size=inv_region_limit, version_id=False, ctx=ctx, device_id=device_id)
+    finally:
+        if log_path is not None:
+            log_file.close()
+    for frame, path in ((df_ins, bed_ins), (df_del, bed_del), (df_inv, bed_inv)):
+        if path is not None:
+            frame.to_csv(path, sep='\t', index=False, compression='gzip')
+    return df_ins, df_del, df_inv

@@ -514,3 +514,119 @@ def split_overlaps(df_align, seed, max_overlap_ops=60, pieces=(2, 4)):
     for c in ('TRIM_REF_L', 'TRIM_REF_R', 'TRIM_QRY_L', 'TRIM_QRY_R'):
         df[c] = 0
     return df.sort_values(['#CHROM', 'POS']).reset_index(drop=True)
+
+
+def make_truncating_table(hap, seed, sv_split_prob=0.7, low_mapq_frac=0.1):
+    """Alignment table in which large events truncate alignments, the input of the large-SV caller
+    (pavlib/lgsv.py:31-642): every record of ``hap.df_align`` is broken at some of its >= 50 bp insertions / deletions
+    (the aligner's split around a large SV: reference gap = deletion, contig gap = insertion) and around planted
+    inversions (+,-,+ triples with the middle record on the other strand, or just the two flanks).  Pure Python on the
+    operation lists: meant for test-sized haplotypes."""
+    import pandas as pd
+    from .align.cigar import tokenize
+    rng = np.random.default_rng(seed)
+    inv_by_chrom = {}
+    for iv in hap.ref.inversions:
+        inv_by_chrom.setdefault(iv.chrom, []).append(iv)
+    out = []
+
+    def emit(row, ops, r0, q0, q1, rev, qlen, total_q, lead, trail, mapq=None):
+        """One record from body operations ``ops`` that start r0 reference / q0 query bases into the parent's body."""
+        r_len = sum(n for n, o in ops if o in '=XD')
+        new = row.copy()
+        h_lead, h_trail = lead + q0, trail + total_q - q1
+        new['CIGAR'] = ('%dH' % h_lead if h_lead else '') + ''.join('%d%s' % o for o in ops) + ('%dH' % h_trail if h_trail else '')
+        new['POS'], new['END'] = int(row['POS']) + r0, int(row['POS']) + r0 + r_len
+        if rev:
+            new['QRY_POS'], new['QRY_END'] = int(row['QRY_END']) - q1, int(row['QRY_END']) - q0
+        else:
+            new['QRY_POS'], new['QRY_END'] = int(row['QRY_POS']) + q0, int(row['QRY_POS']) + q1
+        if mapq is not None:
+            new['MAPQ'] = mapq
+        out.append(new)
+
+    for _, row in hap.df_align.iterrows():
+        lens, codes = tokenize(row['CIGAR'])
+        ops = [(int(n), chr(c)) for n, c in zip(lens, codes)]
+        lead = sum(n for n, o in ops[:1] if o in 'SH')
+        trail = sum(n for n, o in ops[-1:] if o in 'SH') if len(ops) > 1 else 0
+        body = [o for o in ops if o[1] not in 'SH']
+        rev, qlen = bool(row['REV']), int(row['QRY_LEN'])
+        total_q = sum(n for n, o in body if o in '=XI')
+        # cut points: (body op index, kind); inversion zones are split at reference offsets first
+        zones = []
+        for iv in inv_by_chrom.get(row['#CHROM'], []):
+            if iv.pos - 200 >= int(row['POS']) and iv.end + 200 <= int(row['END']):
+                zones.append((iv.pos - int(row['POS']), iv.end - int(row['POS']), float(rng.random())))
+        zones.sort()
+        pieces, cur, r, q = [], [], 0, 0                           # pieces: (ops, r0, q0, kind)
+        r_start, q_start = 0, 0
+        zi = 0
+        in_zone = False
+        stack = list(reversed(body))
+        while stack:
+            n, o = stack.pop()
+            r_adv, q_adv = (n if o in '=XD' else 0), (n if o in '=XI' else 0)
+            bound = None
+            if zi < len(zones):
+                bound = zones[zi][1] if in_zone else zones[zi][0]
+            if bound is not None and o in '=X' and r < bound < r + n:        # split the operation at the zone boundary
+                stack.append((r + n - bound, o))
+                n = bound - r
+                r_adv = q_adv = n
+            if bound is not None and r == bound and (cur or in_zone):
+                pieces.append((cur, r_start, q_start, 'zone' if in_zone else 'flank'))
+                if in_zone:
+                    zi += 1
+                in_zone = not in_zone
+                cur, r_start, q_start = [], r, q
+            big = o in 'ID' and n >= 50 and not in_zone and cur and stack and rng.random() < sv_split_prob
+            if big:
+                pieces.append((cur, r_start, q_start, 'flank'))
+                r += r_adv
+                q += q_adv
+                cur, r_start, q_start = [], r, q
+                continue
+            cur.append((n, o))
+            r += r_adv
+            q += q_adv
+        if cur:
+            pieces.append((cur, r_start, q_start, 'zone' if in_zone else 'flank'))
+        zone_rank = iter(z[2] for z in zones)
+        for p_ops, r0, q0, kind in pieces:
+            while p_ops and p_ops[0][1] in 'ID':                  # records do not start / end on an indel
+                n, o = p_ops.pop(0)
+                r0 += n if o == 'D' else 0
+                q0 += n if o == 'I' else 0
+            while p_ops and p_ops[-1][1] in 'ID':
+                p_ops.pop()
+            if not p_ops:
+                continue
+            q1 = q0 + sum(n for n, o in p_ops if o in '=XI')
+            mapq = 20 if rng.random() < low_mapq_frac else None
+            if kind == 'flank':
+                emit(row, p_ops, r0, q0, q1, rev, qlen, total_q, lead, trail, mapq)
+                continue
+            u = next(zone_rank)
+            if u < 0.25:                                          # left aligned through, as the generator made it
+                emit(row, p_ops, r0, q0, q1, rev, qlen, total_q, lead, trail, mapq)
+            elif u < 0.5:                                         # the aligner dropped the inverted part: two flanks only
+                continue
+            else:                                                 # +,-,+: the middle record on the other strand
+                mid = row.copy()
+                span = q1 - q0
+                if rev:
+                    qa, qb = int(row['QRY_END']) - q1, int(row['QRY_END']) - q0
+                else:
+                    qa, qb = int(row['QRY_POS']) + q0, int(row['QRY_POS']) + q1
+                m_rev = not rev
+                h_lead, h_trail = (qlen - qb, qa) if m_rev else (qa, qlen - qb)
+                mid['CIGAR'] = ('%dH' % h_lead if h_lead else '') + '%d=' % span + ('%dH' % h_trail if h_trail else '')
+                mid['POS'], mid['END'] = int(row['POS']) + r0, int(row['POS']) + r0 + span
+                mid['QRY_POS'], mid['QRY_END'], mid['REV'] = qa, qb, m_rev
+                out.append(mid)
+    df = pd.DataFrame(out).reset_index(drop=True)
+    df['INDEX'] = np.arange(df.shape[0])
+    for c in ('TRIM_REF_L', 'TRIM_REF_R', 'TRIM_QRY_L', 'TRIM_QRY_R'):
+        df[c] = 0
+    return df.sort_values(['#CHROM', 'POS']).reset_index(drop=True)
