@@ -1,0 +1,107 @@
+"""CPU-side checks of the host layers of the trimming / flagging / large-SV rows: generators, table builders, error texts.
+(The device paths are covered by tests/test_gpu_{trim,flag,lgsv}.py.)"""
+import collections
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from pav_amd import _lib, flag, lgsv, synth
+from pav_amd.align import trim as ptrim
+from pav_amd.align.cigar import tokenize
+from pav_amd.inv import IntervalSet
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def spans(cigar):
+    lens, ops = tokenize(cigar)
+    q = int(lens[np.isin(ops, np.frombuffer(b'=XI', dtype=np.uint8))].sum())
+    r = int(lens[np.isin(ops, np.frombuffer(b'=XD', dtype=np.uint8))].sum())
+    total = int(lens[np.isin(ops, np.frombuffer(b'=XISH', dtype=np.uint8))].sum())
+    return q, r, total
+
+
+def consistent(df):
+    for _, row in df.iterrows():
+        q, r, total = spans(row['CIGAR'])
+        assert row['QRY_POS'] + q == row['QRY_END'] and row['POS'] + r == row['END'] and total == row['QRY_LEN'], row['INDEX']
+
+
+def test_overlap_table_generator_is_consistent_and_deterministic():
+    df, fai = synth.make_overlap_table(21)
+    consistent(df)
+    assert (df['QRY_LEN'] == df['QRY_ID'].map(fai)).all()
+    golden = pd.read_csv(os.path.join(GOLD, 'trim_overlap', 'align_none.tsv.gz'), sep='\t', dtype={'#CHROM': str}, keep_default_na=False)
+    assert golden['CIGAR'].tolist() == df['CIGAR'].tolist()            # the committed fixture is this seed's table
+    overlaps = 0
+    for _, g in df.groupby('QRY_ID'):
+        g = g.sort_values('QRY_POS')
+        overlaps += int((g['QRY_POS'].to_numpy()[1:] < g['QRY_END'].to_numpy()[:-1]).sum())
+    assert overlaps > 20
+
+
+def test_split_and_truncating_generators():
+    hap = synth.config2(seed=41, scale=0.004, threads=2)
+    split = synth.split_overlaps(hap.df_align, 3)
+    consistent(split)
+    assert split.shape[0] > hap.df_align.shape[0]
+    trunc = synth.make_truncating_table(hap, 5)
+    consistent(trunc)
+    pairs = collections.Counter(trunc[['#CHROM', 'QRY_ID']].apply(tuple, axis=1))
+    assert sum(1 for v in pairs.values() if v > 1) >= 5
+    for _, g in trunc.groupby('QRY_ID'):                                # truncated records never share contig bases
+        g = g.sort_values('QRY_POS')
+        assert (g['QRY_POS'].to_numpy()[1:] >= g['QRY_END'].to_numpy()[:-1]).all()
+
+
+def test_flag_host_helpers():
+    names, (a, b) = flag.chrom_ranks(np.array(['chr2', 'chr10', 'chr1'], dtype=object), np.array(['chr10'], dtype=object))
+    assert list(names) == ['chr1', 'chr10', 'chr2'] and list(a) == [2, 1, 0] and list(b) == [1]      # Python str order
+    names, (a,) = flag.chrom_ranks(np.array([3, 1, 2]))
+    assert list(names) == [1, 2, 3] and list(a) == [2, 0, 1]
+    with pytest.raises(TypeError):
+        flag.chrom_ranks(np.array(['x'], dtype=object), np.array([1]))
+    assert flag.sig_filter_code('svindel') == _lib.SIG_SVINDEL and flag.sig_filter_code(None) == _lib.SIG_NONE
+    with pytest.raises(RuntimeError, match='Unrecognized region filter: both'):
+        flag.sig_filter_code('both')
+    loci = np.zeros(2, dtype=_lib.FLAG_LOCUS_DTYPE)
+    loci['chrom'], loci['pos'], loci['end'] = [0, 1], [10, 500], [60, 450]
+    loci['type_mask'] = [_lib.FLAG_MATCH_SV | _lib.FLAG_CLUSTER_SNV, _lib.FLAG_CLUSTER_INDEL]
+    loci['count_snv'], loci['count_indel'], loci['try_inv'], loci['batch'] = [25, 0], [0, 12], [1, 0], [0, -1]
+    df = flag._locus_frame(np.array(['chrA', 'chrB'], dtype=object), loci)
+    assert df.to_csv(sep='\t', index=False) == (
+        '#CHROM\tPOS\tEND\tID\tSVTYPE\tSVLEN\tTYPE\tCOUNT_INDEL\tCOUNT_SNV\tTRY_INV\tBATCH\n'
+        'chrA\t10\t60\tchrA-10-RGN-50\tRGN\t50\tCLUSTER_SNV,MATCH_SV\t0\t25\tTrue\t0\n'
+        'chrB\t500\t450\tchrB-500-RGN--50\tRGN\t-50\tCLUSTER_INDEL\t12\t0\tFalse\t-1\n')
+    empty = flag._locus_frame(np.empty(0, dtype=object), np.zeros(0, dtype=_lib.FLAG_LOCUS_DTYPE))
+    assert empty.to_csv(sep='\t', index=False) == '\t'.join(flag.LOCUS_COLUMNS) + '\n'
+
+
+def test_check_record_messages():
+    row = pd.Series({'INDEX': 7, 'QRY_ID': 'tigA', 'QRY_POS': 10, 'QRY_END': 110, 'QRY_LEN': 500, '#CHROM': 'chr1', 'POS': 1000, 'END': 1100})
+    fai = pd.Series({'tigA': 500})
+    cnt = np.zeros(1, dtype=_lib.TRIM_COUNT_DTYPE)[0]
+    cnt['ref_bp'], cnt['tig_bp'] = 100, 100
+    ptrim.check_record(row, cnt, fai)
+    where = '(INDEX=7, QRY=tigA:10-110, REF=chr1:1000-1100)'
+    cnt['ref_bp'] = 99
+    with pytest.raises(RuntimeError) as ei:
+        ptrim.check_record(row, cnt, fai)
+    assert str(ei.value) == 'END mismatch: POS + ref_bp != END (1099 != 1100) ' + where
+    cnt['ref_bp'], cnt['err_kind'], cnt['err_op'], cnt['err_len'], cnt['err_char'] = 100, 4, 3, 25, ord('I')
+    with pytest.raises(RuntimeError) as ei:
+        ptrim.check_record(row, cnt, fai)
+    assert str(ei.value) == ('CIGAR parsing error: Found clipped bases before last non-clipped CIGAR operation at operation 3 (25I) ' + where)
+    with pytest.raises(RuntimeError, match='QRY_LEN != length from FAI \\(500 != 400\\)'):
+        cnt['err_kind'] = 0
+        ptrim.check_record(row, cnt, pd.Series({'tigA': 400}))
+
+
+def test_interval_set_and_lgsv_constants():
+    t = IntervalSet()
+    t[100:200] = True
+    assert len(t[150:160]) == 1 and len(t[200:300]) == 0 and len(t[50:101]) == 1 and len(t[199]) == 1 and len(t[200]) == 0
+    assert lgsv.match_bp({'CIGAR': '10='}, False) == 0
+    assert lgsv.INSDEL_COLUMNS[11:14] == ['LEFT_SHIFT', 'HOM_REF', 'HOM_TIG'] and len(lgsv.INV_COLUMNS) == 20
