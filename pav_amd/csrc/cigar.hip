@@ -811,12 +811,15 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
     const uint64_t Tpad = round_up(T + 1, TOK_CHUNK);
     const uint32_t n_tchunks = (uint32_t)(Tpad / TOK_CHUNK);
 
-    // d_err: [0] tokenizer error key, [1] illegal-op ordinal; d_totals: NQ walk totals
-    PAV_HIP(ctx, ctx->d_err.reserve(2 * sizeof(uint64_t)));
-    PAV_HIP(ctx, hipMemsetAsync(ctx->d_err.p, 0xFF, 2 * sizeof(uint64_t), ctx->stream));
-    PAV_HIP(ctx, ctx->d_totals.reserve(NQ * sizeof(uint64_t)));
-    unsigned long long *d_tok_err = ctx->d_err.as<unsigned long long>();
+    // one status block on the device, d_totals: [0, NQ) walk totals, [NQ] tokenizer error key, [NQ + 1] illegal-op ordinal.
+    // It comes back with a single copy into pinned host memory (h_status): several small copies into pageable memory
+    // cost hundreds of microseconds each under the concurrent pack.
+    PAV_HIP(ctx, ctx->d_totals.reserve((NQ + 2) * sizeof(uint64_t)));
+    PAV_HIP(ctx, hipMemsetAsync(ctx->d_totals.p, 0, NQ * sizeof(uint64_t), ctx->stream));
+    PAV_HIP(ctx, hipMemsetAsync(ctx->d_totals.as<uint64_t>() + NQ, 0xFF, 2 * sizeof(uint64_t), ctx->stream));
+    unsigned long long *d_tok_err = ctx->d_totals.as<unsigned long long>() + NQ;
     unsigned long long *d_err_op = d_tok_err + 1;
+    uint64_t *h_status = ctx->h_status;
 
     // --- tokenise -------------------------------------------------------------------------------------
     PAV_HIP(ctx, ctx->d_chunk.reserve(sizeof(uint32_t) * n_tchunks + sizeof(uint64_t) * ((size_t)n_tchunks + 1) + 64));
@@ -824,9 +827,9 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
     uint64_t *d_tpre = reinterpret_cast<uint64_t *>(ctx->d_chunk.as<uint8_t>() + round_up(sizeof(uint32_t) * n_tchunks, 16));
     PAV_LAUNCH(ctx, "tok_count", tok_count, n_tchunks, 256, 0, ctx->d_text.as<uint4>(), d_tcnt);
     PAV_LAUNCH(ctx, "scan_counts", scan_counts, 1, 256, 0, d_tcnt, d_tpre, n_tchunks);
-    uint64_t n_ops = 0;
-    PAV_HIP(ctx, hipMemcpyAsync(&n_ops, d_tpre + n_tchunks, sizeof n_ops, hipMemcpyDeviceToHost, ctx->stream));
+    PAV_HIP(ctx, hipMemcpyAsync(h_status, d_tpre + n_tchunks, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t n_ops = h_status[0];
     ctx->n_ops = n_ops;
     PAV_HIP(ctx, ctx->d_ops.reserve(sizeof(uint32_t) * (n_ops + 16)));
     PAV_HIP(ctx, ctx->d_op_off.reserve(sizeof(uint64_t) * ((size_t)n_aln + 1)));
@@ -849,10 +852,11 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
         PAV_LAUNCH(ctx, "walk_chunks", walk_chunks, 1, 256, 0, d_csum, d_cpre, ctx->d_totals.as<uint64_t>(), n_wchunks);
         PAV_LAUNCH(ctx, "row_base", row_base, (n_aln + 3) / 4, 256, 0, ctx->d_ops.as<uint32_t>(),
                    ctx->d_op_off.as<uint64_t>(), d_cpre, ctx->d_rowbase.as<uint64_t>(), n_aln);
-        PAV_HIP(ctx, hipMemcpyAsync(totals, ctx->d_totals.p, sizeof totals, hipMemcpyDeviceToHost, ctx->stream));
     }
-    PAV_HIP(ctx, hipMemcpyAsync(errs, ctx->d_err.p, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    PAV_HIP(ctx, hipMemcpyAsync(h_status, ctx->d_totals.p, (NQ + 2) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int q = 0; q < NQ; ++q) totals[q] = h_status[q];
+    errs[0] = h_status[NQ];
 
     ctx->counts.n_ops = n_ops;
     ctx->counts.n_snv = totals[2];
@@ -885,8 +889,10 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
                            ctx->d_indel.as<pav_indel>(), totals[3], ctx->d_aln.as<pav_aln>(), A.ref, A.tig,
                            ctx->d_seqblob.as<uint8_t>(), totals[4]);
         }
-        PAV_HIP(ctx, hipMemcpyAsync(errs, ctx->d_err.p, sizeof errs, hipMemcpyDeviceToHost, ctx->stream));
+        PAV_HIP(ctx, hipMemcpyAsync(h_status, d_tok_err, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        errs[0] = h_status[0];
+        errs[1] = h_status[1];
     }
     if (counts) *counts = ctx->counts;
     ctx->cigar_called = true;

@@ -83,7 +83,8 @@ struct pav_ctx {
     bool cigar_loaded = false, cigar_called = false;
     pav_cigar_counts counts{};
     pav_cigar_err cigar_err{};
-    pav::DevBuf d_aln, d_text, d_text_off, d_ops, d_op_off, d_chunk, d_chunk2, d_rowbase, d_err, d_totals;
+    uint64_t *h_status = nullptr;         // pinned host words for the small device-to-host readbacks of pav_cigar_call
+    pav::DevBuf d_aln, d_text, d_text_off, d_ops, d_op_off, d_chunk, d_chunk2, d_rowbase, d_totals;
     pav::DevBuf d_snv, d_indel, d_seqblob, d_tmp;
     pav::DevBuf ix_text, ix_off, ix_pos, ix_ops, ix_op_off, ix_chunk, ix_chunk2, ix_rowbase, ix_begin, ix_err;   // pav_align_index
     uint64_t n_ops = 0;

@@ -58,6 +58,7 @@ int wait_tables(pav_ctx *ctx) {
 
 int prof_flush(pav_ctx *ctx) {
     if (ctx->prof_pending.empty()) return PAV_OK;
+    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream3));
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream2));
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (auto &p : ctx->prof_pending) {
@@ -177,6 +178,7 @@ pav_ctx *pav_create(int device_id) {
         (e = hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_lo)) != hipSuccess ||
         (e = hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, prio_lo)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->tables_done, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_status), 256, hipHostMallocDefault)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->pack_done[0], hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->pack_done[1], hipEventDisableTiming)) != hipSuccess) {
         fail(nullptr, PAV_E_HIP, "device init: %s", hipGetErrorString(e));
@@ -208,7 +210,7 @@ void pav_destroy(pav_ctx *ctx) {
         s.d_ascii.release(); s.d_two.release(); s.d_mask.release(); s.d_off.release(); s.d_len.release();
     }
     DevBuf *bufs[] = {&ctx->d_aln, &ctx->d_text, &ctx->d_text_off, &ctx->d_ops, &ctx->d_op_off, &ctx->d_chunk,
-                      &ctx->d_chunk2, &ctx->d_rowbase, &ctx->d_err, &ctx->d_totals, &ctx->d_snv, &ctx->d_indel,
+                      &ctx->d_chunk2, &ctx->d_rowbase, &ctx->d_totals, &ctx->d_snv, &ctx->d_indel,
                       &ctx->d_seqblob, &ctx->d_tmp, &ctx->ix_text, &ctx->ix_off, &ctx->ix_pos, &ctx->ix_ops, &ctx->ix_op_off,
                       &ctx->ix_chunk, &ctx->ix_chunk2, &ctx->ix_rowbase, &ctx->ix_begin, &ctx->ix_err};
     for (DevBuf *b : bufs) b->release();
@@ -216,6 +218,7 @@ void pav_destroy(pav_ctx *ctx) {
     (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream3);
     (void)hipEventDestroy(ctx->tables_done);
+    if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     (void)hipEventDestroy(ctx->pack_done[0]);
     (void)hipEventDestroy(ctx->pack_done[1]);
     delete ctx;

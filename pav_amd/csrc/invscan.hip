@@ -495,7 +495,7 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
             // FLANK | MATCH, each column holding the calls one after the other (nine bulk device-to-host copies)
             size_t rows = 0;
             for (const CallFetch &cf : round_calls) rows += cf.n;
-            const size_t total = rows * 40 + 64;
+            const size_t total = (rows * 40 + 64 + 63) / 64 * 64;           // blocks stay 64-byte aligned (vector stores from the device)
             void *blk = S->pin_alloc(total);
             if (!blk) return fail(ctx, PAV_E_HIP, "pav_inv_scan_batch: cannot pin %zu bytes of host memory", total);
             double *c_k0 = static_cast<double *>(blk), *c_k1 = c_k0 + rows, *c_k2 = c_k1 + rows;
