@@ -251,3 +251,28 @@ def test_full_size_properties(built, gpu_ctx):
     assert int((indel['svtype'] == 0).sum()) == st['n_ins']
     snv2, indel2, blob2, _ = cigarcall.call_records(gpu_ctx, hap.df_align)
     assert snv.tobytes() == snv2.tobytes() and indel.tobytes() == indel2.tobytes() and blob.tobytes() == blob2.tobytes()
+
+
+def test_cohort_haplotypes_share_one_resident_reference(built, gpu_ctx):
+    """BASELINE configs[3] / configs[4] shape in small: a T2T-CHM13-shaped reference is uploaded and packed once, several
+    haplotypes (two samples x two haplotypes, different seeds) are called one after the other on the same context with
+    only the contigs and the alignment table replaced; every haplotype is bit-exact vs the oracle, and calling the first one
+    again gives the same bytes (no state leaks between haplotypes)."""
+    ref = synth.make_reference(515, synth.scaled_lengths(synth.CHM13_LENGTHS, 0.002), threads=4, n_every=0, inv_every=2_000_000)
+    names = ref.names
+    gpu_ctx.seq_load(_lib.PAV_ROLE_REF, names, [ref.seqs[n] for n in names])
+    first = None
+    haps = [synth.config2(seed=515 + s, scale=0.002, hap_index=h, ref=ref, threads=4) for s in range(2) for h in range(2)]
+    for hap in haps + haps[:1]:
+        gpu_ctx.seq_load(_lib.PAV_ROLE_TIG, hap.tig_names, [hap.tig_seqs[n] for n in hap.tig_names])
+        snv, indel, blob, counts = cigarcall.call_records(gpu_ctx, hap.df_align)
+        o_snv, o_indel, o_blob, err = util.oracle_records(names, [ref.seqs[n] for n in names], hap.tig_names,
+                                                          [hap.tig_seqs[n] for n in hap.tig_names], hap.df_align)
+        assert err.kind == 0 and counts.aligned_bases == hap.stats['aligned_bp']
+        util.assert_records_equal(snv, o_snv, 'snv')
+        util.assert_records_equal(indel, o_indel, 'indel')
+        assert blob.tobytes() == o_blob.tobytes()
+        if first is None:
+            first = (snv.tobytes(), indel.tobytes(), blob.tobytes())
+    assert first == (snv.tobytes(), indel.tobytes(), blob.tobytes())
+    assert len({h.stats['n_snv'] for h in haps}) > 1                 # the haplotypes really differ
