@@ -45,6 +45,9 @@ def main():
     ap.add_argument('--workload', choices=['cigar', 'cigar+inv'], default='cigar',
                     help="'cigar' = BASELINE configs[1] (the metric's workload); 'cigar+inv' adds the k-mer inversion scan of "
                          "every flagged region of the haplotype (configs[2] shape, one haplotype per GPU)")
+    ap.add_argument('--backend', default='nccl', help="process-group backend for N > 1 ('nccl' = RCCL; tests use 'gloo')")
+    ap.add_argument('--share-gpu', action='store_true',
+                    help='tests only: every rank uses GPU 0 (exercises the N > 1 code path on a one-GPU box; needs --backend gloo)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -57,10 +60,16 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (no CPU fallback exists)')
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    comm_device = 'cuda' if args.backend == 'nccl' else 'cpu'
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     import numpy as np
     import __graft_entry__ as g
@@ -173,10 +182,10 @@ def main():
     t_local = time.perf_counter() - t0
     fence()
     if world > 1:
-        tt = torch.tensor([t_local], dtype=torch.float64, device='cuda')
+        tt = torch.tensor([t_local], dtype=torch.float64, device=comm_device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_max = float(tt.item())
-        ab = torch.tensor([float(counts.aligned_bases)], dtype=torch.float64, device='cuda')
+        ab = torch.tensor([float(counts.aligned_bases)], dtype=torch.float64, device=comm_device)
         dist.all_reduce(ab, op=dist.ReduceOp.SUM)
         aligned_total = float(ab.item())
     else:

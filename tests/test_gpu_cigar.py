@@ -276,3 +276,30 @@ def test_cohort_haplotypes_share_one_resident_reference(built, gpu_ctx):
             first = (snv.tobytes(), indel.tobytes(), blob.tobytes())
     assert first == (snv.tobytes(), indel.tobytes(), blob.tobytes())
     assert len({h.stats['n_snv'] for h in haps}) > 1                 # the haplotypes really differ
+
+
+def test_bench_two_ranks_on_one_gpu(built):
+    """The N > 1 path of bench.py (staggered prepare, barrier, max-over-ranks time, summed aligned bases) on a one-GPU box:
+    two ranks share GPU 0 over gloo.  The driver's real runs use one GPU per rank over RCCL; the rank logic is the same."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--scale', '0.01',
+           '--backend', 'gloo', '--share-gpu', '--no-cpu-baseline']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['value'] > 0 and line['steps'] == 2
+    one = synth.config2(seed=1002, scale=0.01, hap_index=0, threads=2).stats['aligned_bp']
+    two = synth.config2(seed=1002, scale=0.01, hap_index=1, threads=2).stats['aligned_bp']
+    got = line['value'] * 1e9 * line['ms_per_step'] * 1e-3               # aligned bases per step over both ranks
+    assert abs(got - (one + two)) / (one + two) < 0.02                    # value and ms_per_step are rounded in the line
