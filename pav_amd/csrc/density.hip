@@ -62,7 +62,7 @@ struct HeadEvent { uint32_t job, row; int32_t state; uint32_t index, prev_index;
 struct DensityState {
     DevBuf jobs, stat, kde, tile_job_r, tile_job_t, keys, cnt;
     DevBuf st_tmp, tile_sum, tile_pre, index, state_mer, state, kmer, kern[3], list[3], pscaled[3], fill_list;
-    DevBuf tiles, events, ev_count, scratch, run_arena;
+    DevBuf tiles, events, ev_count, scratch, run_arena, win_fill;
     std::vector<JobDev> h_jobs;
     std::vector<JobKde> h_kde;
     std::vector<uint8_t> desc_host2[2];   // descriptor uploads of density_fetch_calls (one per staging buffer)
@@ -79,7 +79,7 @@ struct DensityState {
     void release() {
         DevBuf *all[] = {&jobs, &stat, &kde, &tile_job_r, &tile_job_t, &keys, &cnt, &st_tmp, &tile_sum, &tile_pre,
                          &index, &state_mer, &state, &kmer, &kern[0], &kern[1], &kern[2], &list[0], &list[1], &list[2],
-                         &pscaled[0], &pscaled[1], &pscaled[2], &fill_list, &tiles, &events, &ev_count, &scratch, &run_arena};
+                         &pscaled[0], &pscaled[1], &pscaled[2], &fill_list, &tiles, &events, &ev_count, &scratch, &run_arena, &win_fill};
         for (DevBuf *b : all) b->release();
         call_stage[0].release(); call_stage[1].release();
         for (hipEvent_t &e : stage_copied) if (e) { (void)hipEventDestroy(e); e = nullptr; }
@@ -504,13 +504,16 @@ __global__ __launch_bounds__(64) void k_kde_eval(KdeArgs A) {
     if (t.mode == 0) A.state[off + x] = (int8_t)argmax3(val[0], val[1], val[2]);   // density.py:250-255
 }
 
-// One lane per window between consecutive sampled sites (scripts/density.py:257-323): linear interpolation when
-// neither the states nor the densities change, otherwise its inner sites are queued for full evaluation.
+// Windows between consecutive sampled sites (scripts/density.py:257-323), two launches.  k_windows: one lane per window
+// decides whether the states or the densities change inside it; if so its inner sites are queued for full evaluation.
+// k_interp: one lane per row fills the inner sites of the quiet windows by linear interpolation (coalesced stores; with one
+// lane per window the 3 x 19 strided stores per lane made this the second most expensive kernel of the scan).
 __global__ __launch_bounds__(256) void k_windows(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
                                                  const JobKde *__restrict__ kde, const int8_t *__restrict__ state_mer,
-                                                 const int8_t *__restrict__ state, double *__restrict__ k0,
-                                                 double *__restrict__ k1, double *__restrict__ k2, double delta,
-                                                 uint32_t *__restrict__ fill_list, JobStat *__restrict__ stat) {
+                                                 const int8_t *__restrict__ state, const double *__restrict__ k0,
+                                                 const double *__restrict__ k1, const double *__restrict__ k2, double delta,
+                                                 uint32_t *__restrict__ fill_list, uint8_t *__restrict__ win_fill,
+                                                 JobStat *__restrict__ stat) {
     const uint64_t ap = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint32_t j = tile_job[ap / DTILE];
     const JobKde kd = kde[j];
@@ -521,25 +524,45 @@ __global__ __launch_bounds__(256) void k_windows(const JobDev *__restrict__ jobs
     const uint64_t a = q * kd.srs;
     uint64_t b = (q + 1) * kd.srs;
     if (b > kd.n - 1) b = kd.n - 1;
-    if (b == a + 1) return;                                            // density.py:270-271
+    if (b == a + 1) { win_fill[ap] = 1; return; }                      // density.py:270-271: nothing in between
     bool change = state[off + a] != state[off + b];
     const int8_t sm = state_mer[off + a];
     for (uint64_t i = a + 1; i <= b && !change; ++i) change = state_mer[off + i] != sm;      // :273-275
-    double *kk[3] = {k0, k1, k2};
+    const double *kk[3] = {k0, k1, k2};
     double dmax = 0.0;
 #pragma unroll
     for (int s = 0; s < 3; ++s) { const double d = fabs(kk[s][off + a] - kk[s][off + b]); if (d > dmax) dmax = d; }
-    if (change || dmax > delta) {                                      // :277-283
+    const bool fill = change || dmax > delta;                          // :277-283
+    win_fill[ap] = fill ? 1 : 0;
+    if (fill) {
         const uint32_t cnt = (uint32_t)(b - a - 1);
         const uint32_t at = atomicAdd(&stat[j].fill_n, cnt);
         for (uint32_t t = 0; t < cnt; ++t) fill_list[off + at + t] = (uint32_t)(a + 1 + t);
-    } else {                                                           // np.interp: slope * (x - x0) + y0
+    }
+}
+
+__global__ __launch_bounds__(256) void k_interp(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
+                                                const JobKde *__restrict__ kde, const uint8_t *__restrict__ win_fill,
+                                                double *__restrict__ k0, double *__restrict__ k1, double *__restrict__ k2) {
+    const uint64_t ap = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t j = tile_job[ap / DTILE];
+    const JobKde kd = kde[j];
+    if (!kd.finalised) return;
+    const uint64_t off = jobs[j].tpos_off;
+    const uint64_t x = ap - off;
+    if (x >= kd.n) return;
+    const uint64_t q = x / kd.srs;
+    const uint64_t a = q * kd.srs;
+    if (x == a || q + 1 >= kd.n_samp) return;                          // a sampled site, or past the last window
+    uint64_t b = (q + 1) * kd.srs;
+    if (b > kd.n - 1) b = kd.n - 1;
+    if (x >= b || win_fill[off + q]) return;
+    double *kk[3] = {k0, k1, k2};
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const double ya = kk[s][off + a], yb = kk[s][off + b];
-            const double slope = (yb - ya) / ((double)b - (double)a);
-            for (uint64_t x = a + 1; x < b; ++x) kk[s][off + x] = slope * ((double)x - (double)a) + ya;
-        }
+    for (int s = 0; s < 3; ++s) {                                      // np.interp: slope * (x - x0) + y0
+        const double ya = kk[s][off + a], yb = kk[s][off + b];
+        const double slope = (yb - ya) / ((double)b - (double)a);
+        kk[s][ap] = slope * ((double)x - (double)a) + ya;
     }
 }
 
@@ -872,6 +895,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     PAV_HIP(ctx, D->state.reserve(a_t));
     PAV_HIP(ctx, D->kmer.reserve(8 * a_t));
     PAV_HIP(ctx, D->fill_list.reserve(4 * a_t));
+    PAV_HIP(ctx, D->win_fill.reserve(a_t));
     for (int s = 0; s < 3; ++s) {
         PAV_HIP(ctx, D->kern[s].reserve(8 * a_t));
         PAV_HIP(ctx, D->list[s].reserve(4 * a_t));
@@ -1038,7 +1062,9 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
         PAV_LAUNCH(ctx, "k_kde_eval", k_kde_eval, (uint32_t)tiles.size(), 64, 0, KA);
         PAV_LAUNCH(ctx, "k_windows", k_windows, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_kde, D->state_mer.as<int8_t>(),
                    D->state.as<int8_t>(), D->kern[0].as<double>(), D->kern[1].as<double>(), D->kern[2].as<double>(),
-                   pp->state_run_delta, D->fill_list.as<uint32_t>(), d_stat);
+                   pp->state_run_delta, D->fill_list.as<uint32_t>(), D->win_fill.as<uint8_t>(), d_stat);
+        PAV_LAUNCH(ctx, "k_interp", k_interp, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_kde, D->win_fill.as<uint8_t>(),
+                   D->kern[0].as<double>(), D->kern[1].as<double>(), D->kern[2].as<double>());
         // ---- readback 2: how many inner sites need the full density --------------------------------------------
         PAV_HIP(ctx, hipMemcpyAsync(hs.data(), d_stat, sizeof(JobStat) * n_jobs, hipMemcpyDeviceToHost, st));
         PAV_HIP(ctx, hipStreamSynchronize(st));
