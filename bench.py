@@ -221,7 +221,23 @@ def main():
             t0 = time.perf_counter()
             ctx.cigar_write_tables(hap.hap, index, tp, te, os.path.join(tmp_out, 'snv.bed'), os.path.join(tmp_out, 'insdel.bed'))
             t_plain = time.perf_counter() - t0
+            # reader half: the alignment table as PAV stores it (gzip TSV incl. CIGAR), parsed by the library and handed to the
+            # caller without pandas (pav_bed_open + pav_cigar_load_bed); writing the input file is not timed
+            bed_path = os.path.join(tmp_out, 'aligned_tig.bed.gz')
+            hap.df_align.to_csv(bed_path, sep='\t', index=False, compression={'method': 'gzip', 'compresslevel': 1})
+            t0 = time.perf_counter()
+            table = _lib.BedTable(bed_path)
+            t_parse = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            loaded_index = ctx.cigar_load_bed(table, -1)
+            ctx.sync()
+            t_load = time.perf_counter() - t0
+            table.close()
+            assert loaded_index.shape[0] == aln.shape[0]
+            ctx.cigar_load(aln, text, off)                             # back to the arrays the timed steps used
             e2e = {'rows': n1 + n2, 'write_tables_gzip_s': round(t_gz, 3), 'write_tables_plain_s': round(t_plain, 3),
+                   'read_align_table_s': {'parse_gzip_tsv': round(t_parse, 3), 'load_to_device': round(t_load, 3),
+                                          'bytes': os.path.getsize(bed_path)},
                    'text_bytes': os.path.getsize(os.path.join(tmp_out, 'snv.bed')) + os.path.getsize(os.path.join(tmp_out, 'insdel.bed')),
                    'note': 'pav_cigar_write_tables: device sort + FILTER, native TSV text (byte-identical to pandas), parallel gzip '
                            'members; the pandas mirror needs ~13 us per row, the reference ~410 us per row (BASELINE.md)'}

@@ -323,6 +323,34 @@ int pav_inv_tables(pav_ctx *ctx, uint32_t n_regions, const uint64_t *row_off, in
                    int8_t *state, double *kern_fwd, double *kern_fwdrev, double *kern_rev, uint64_t *kmer, uint8_t *flank,
                    uint8_t *match);
 
+/* ---- alignment tables: native reader (reader half) -------------------------- *
+ * The tables of results/{asm}/align/trim-{none,tig,tigref}/aligned_tig_{hap}.bed.gz (API_ALIGN.md:31-64) as rule call_cigar
+ * reads them with pandas (rules/call.snakefile:805, 813-816): gzip or plain TSV with a header line; columns are found by
+ * name, unknown columns are skipped.  Parsing needs no GPU and no context.  Fields are taken verbatim (no quoting rules:
+ * PAV writes none for these tables); REV is the text True / False. */
+typedef struct pav_bed pav_bed;
+typedef struct {
+    uint64_t n_rows, cigar_bytes;
+    uint32_t n_chrom, n_qry;        /* distinct #CHROM / QRY_ID values, numbered in order of first appearance                */
+    uint32_t columns;               /* bit i set: column i of (#CHROM, POS, END, INDEX, QRY_ID, QRY_POS, QRY_END, QRY_LEN,    */
+    uint32_t pad;                   /* MAPQ, REV, CIGAR, CALL_BATCH) is present                                              */
+} pav_bed_info_t;
+typedef struct {                    /* destinations, n_rows entries each (cigar_off: n_rows + 1); NULL = not wanted         */
+    uint32_t *chrom_id, *qry_id;
+    int64_t *pos, *end, *index, *qry_pos, *qry_end, *qry_len, *mapq, *call_batch;
+    uint8_t *rev;
+    uint8_t *cigar_text;
+    uint64_t *cigar_off;
+} pav_bed_cols;
+int pav_bed_open(const char *path, int with_cigar, pav_bed **out);      /* message via pav_last_error(NULL)                  */
+void pav_bed_close(pav_bed *bed);
+int pav_bed_info(const pav_bed *bed, pav_bed_info_t *info);
+int pav_bed_fetch(const pav_bed *bed, const pav_bed_cols *cols);
+const char *pav_bed_name(const pav_bed *bed, int which /* 0 #CHROM, 1 QRY_ID */, uint32_t id);
+/* pav_cigar_load straight from a parsed table: the rows with CALL_BATCH == call_batch (all rows when negative), names mapped
+ * to the stores through pav_seq_set_names.  index_out (n_rows of the table is an upper bound) receives their INDEX. */
+int pav_cigar_load_bed(pav_ctx *ctx, const pav_bed *bed, int64_t call_batch, uint32_t *n_rows, int64_t *index_out);
+
 /* ---- alignment trimming ------------------------------------------------ *
  * Replaces pavlib.align.trim_alignments and its helpers trim_alignment_record, find_cut_sites, trace_cigar_to_zero
  * (pavlib/align/trim.py:11-917; rules align_trim_tig / align_trim_tigref, rules/align.snakefile:54-97).  Every CIGAR is

@@ -133,6 +133,19 @@ assert TRIM_ROW_DTYPE.itemsize == 88 and TRIM_COUNT_DTYPE.itemsize == 72
 TRIM_QUERY, TRIM_SUBJECT = 0, 1
 
 
+class BedInfo(ctypes.Structure):
+    _fields_ = [('n_rows', ctypes.c_uint64), ('cigar_bytes', ctypes.c_uint64), ('n_chrom', ctypes.c_uint32), ('n_qry', ctypes.c_uint32),
+                ('columns', ctypes.c_uint32), ('pad', ctypes.c_uint32)]
+
+
+class BedCols(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ('chrom_id', 'qry_id', 'pos', 'end', 'index', 'qry_pos', 'qry_end', 'qry_len', 'mapq',
+                                               'call_batch', 'rev', 'cigar_text', 'cigar_off')]
+
+
+BED_COLUMNS = ('#CHROM', 'POS', 'END', 'INDEX', 'QRY_ID', 'QRY_POS', 'QRY_END', 'QRY_LEN', 'MAPQ', 'REV', 'CIGAR', 'CALL_BATCH')
+
+
 class TrimErr(ctypes.Structure):
     _fields_ = [('kind', ctypes.c_int32), ('row_l', ctypes.c_uint32), ('row_r', ctypes.c_uint32), ('op_index', ctypes.c_uint32),
                 ('op_char', ctypes.c_uint32), ('side', ctypes.c_int32), ('diff_bp', ctypes.c_int64), ('op_len', ctypes.c_uint64)]
@@ -192,6 +205,12 @@ SYMBOLS = {
     'pav_inv_tables': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'pav_kmer_rev_complement': (ctypes.c_uint64, [ctypes.c_uint64, ctypes.c_int]),
     'pav_kmer_canonical': (ctypes.c_uint64, [ctypes.c_uint64, ctypes.c_int]),
+    'pav_bed_open': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, _P]),
+    'pav_bed_close': (None, [_P]),
+    'pav_bed_info': (ctypes.c_int, [_P, _P]),
+    'pav_bed_fetch': (ctypes.c_int, [_P, _P]),
+    'pav_bed_name': (ctypes.c_char_p, [_P, ctypes.c_int, ctypes.c_uint32]),
+    'pav_cigar_load_bed': (ctypes.c_int, [_P, _P, ctypes.c_int64, _P, _P]),
     'pav_trim_load': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P]),
     'pav_trim_pass': (ctypes.c_int, [_P, ctypes.c_uint32, _P, ctypes.c_int, ctypes.c_int64, ctypes.c_int]),
     'pav_trim_pair': (ctypes.c_int, [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
@@ -333,6 +352,14 @@ class Context:
             raise ValueError('cigar_off must have n_aln + 1 entries')
         self._check(self.lib.pav_cigar_load(self.handle, aln.shape[0], _ptr(aln), _ptr(cigar_text),
                                             ctypes.c_void_p(cigar_off.ctypes.data)), 'pav_cigar_load')
+
+    def cigar_load_bed(self, bed, call_batch=-1):
+        """pav_cigar_load from a parsed table (rows of one CALL_BATCH, all when negative): -> INDEX of the loaded rows."""
+        n = ctypes.c_uint32(0)
+        index = np.zeros(max(1, bed.n_rows), dtype=np.int64)
+        self._check(self.lib.pav_cigar_load_bed(self.handle, bed.handle, int(call_batch), ctypes.byref(n), _ptr(index)),
+                    'pav_cigar_load_bed')
+        return index[:int(n.value)].copy()
 
     def cigar_call(self):
         c = CigarCounts()
@@ -642,6 +669,70 @@ class Context:
             self._check(self.lib.pav_prof_get(self.handle, i, name, 128, ctypes.byref(launches), ctypes.byref(ms)),
                         'pav_prof_get')
             out[name.value.decode()] = (int(launches.value), float(ms.value))
+        return out
+
+
+class BedTable:
+    """An alignment table parsed by the library (``pav_bed_open``): numeric columns as numpy arrays, names, CIGAR text."""
+
+    _NUMERIC = {'POS': 'pos', 'END': 'end', 'INDEX': 'index', 'QRY_POS': 'qry_pos', 'QRY_END': 'qry_end', 'QRY_LEN': 'qry_len',
+                'MAPQ': 'mapq', 'CALL_BATCH': 'call_batch'}
+
+    def __init__(self, path, with_cigar=True):
+        self.lib = load()
+        h = ctypes.c_void_p(0)
+        rc = self.lib.pav_bed_open(str(path).encode(), 1 if with_cigar else 0, ctypes.byref(h))
+        if rc != PAV_OK:
+            raise PavDeviceError('pav_bed_open failed ({}): {}'.format(rc, (self.lib.pav_last_error(None) or b'').decode()))
+        self.handle = h
+        info = BedInfo()
+        self.lib.pav_bed_info(self.handle, ctypes.byref(info))
+        self.n_rows, self.cigar_bytes = int(info.n_rows), int(info.cigar_bytes)
+        self.columns = [c for i, c in enumerate(BED_COLUMNS) if info.columns >> i & 1]
+        self.chrom_names = [self.lib.pav_bed_name(self.handle, 0, i).decode() for i in range(info.n_chrom)]
+        self.qry_names = [self.lib.pav_bed_name(self.handle, 1, i).decode() for i in range(info.n_qry)]
+        self._cols = None
+
+    def close(self):
+        if self.handle:
+            self.lib.pav_bed_close(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def fetch(self):
+        """dict: column name -> numpy array (ids for #CHROM / QRY_ID, bool for REV), plus 'CIGAR_TEXT' / 'CIGAR_OFF'."""
+        if self._cols is not None:
+            return self._cols
+        n = self.n_rows
+        out, c = {}, BedCols()
+        for name, field in self._NUMERIC.items():
+            if name in self.columns:
+                out[name] = np.zeros(n, dtype=np.int64)
+                setattr(c, field, out[name].ctypes.data)
+        if '#CHROM' in self.columns:
+            out['#CHROM'] = np.zeros(n, dtype=np.uint32)
+            c.chrom_id = out['#CHROM'].ctypes.data
+        if 'QRY_ID' in self.columns:
+            out['QRY_ID'] = np.zeros(n, dtype=np.uint32)
+            c.qry_id = out['QRY_ID'].ctypes.data
+        if 'REV' in self.columns:
+            out['REV'] = np.zeros(n, dtype=np.uint8)
+            c.rev = out['REV'].ctypes.data
+        if 'CIGAR' in self.columns and self.cigar_bytes:
+            out['CIGAR_TEXT'] = np.zeros(self.cigar_bytes, dtype=np.uint8)
+            out['CIGAR_OFF'] = np.zeros(n + 1, dtype=np.uint64)
+            c.cigar_text, c.cigar_off = out['CIGAR_TEXT'].ctypes.data, out['CIGAR_OFF'].ctypes.data
+        rc = self.lib.pav_bed_fetch(self.handle, ctypes.byref(c))
+        if rc != PAV_OK:
+            raise PavDeviceError(f'pav_bed_fetch failed ({rc})')
+        if 'REV' in out:
+            out['REV'] = out['REV'].astype(bool)
+        self._cols = out
         return out
 
 

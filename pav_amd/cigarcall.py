@@ -55,13 +55,17 @@ def pack_alignments(df_align, ref_names, tig_names):
     return aln, text, off
 
 
-def load_sequences(ctx, ref_fa_name, tig_fa_name, df_align=None):
-    """Upload the records the alignment table touches (all records when ``df_align`` is None)."""
+def load_sequences(ctx, ref_fa_name, tig_fa_name, df_align=None, names=None):
+    """Upload the records the alignment table touches (all records when ``df_align`` is None); ``names`` gives the two
+    sets of record names directly."""
     ref_fa = open_fasta(ref_fa_name)
     tig_fa = open_fasta(tig_fa_name)
-    if df_align is not None and df_align.shape[0]:
-        want_ref = {str(c) for c in df_align['#CHROM']}
-        want_tig = {str(c) for c in df_align['QRY_ID']}
+    if names is not None or (df_align is not None and df_align.shape[0]):
+        if names is not None:
+            want_ref, want_tig = {str(c) for c in names[0]}, {str(c) for c in names[1]}
+        else:
+            want_ref = {str(c) for c in df_align['#CHROM']}
+            want_tig = {str(c) for c in df_align['QRY_ID']}
         ref_names = [n for n in ref_fa.names if n in want_ref]
         tig_names = [n for n in tig_fa.names if n in want_tig]
         missing = (want_ref - set(ref_names)) | (want_tig - set(tig_names))

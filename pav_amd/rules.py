@@ -35,32 +35,46 @@ def read_trim_bed(path):
 
 def call_cigar_files(bed, bed_trim, tig_fa_name, ref_fa_name, hap, batch, bed_insdel, bed_snv, ctx=None, device_id=0,
                      threads=0):
-    """Body of rule call_cigar with the library's native table writer: same files as :func:`call_cigar` (gunzipped text
-    byte-identical) without building DataFrames - FILTER, the sort order and the TSV text are produced by
-    ``pav_cigar_write_tables``.  Returns ``(n_snv_rows, n_insdel_rows)``."""
+    """Body of rule call_cigar without pandas: the alignment tables are parsed by the library (``pav_bed_open``), the rows of
+    ``batch`` go straight to the caller (``pav_cigar_load_bed``), FILTER, the sort order and the TSV text are produced by
+    ``pav_cigar_write_tables``.  Same files as :func:`call_cigar` (gunzipped text byte-identical).  Returns
+    ``(n_snv_rows, n_insdel_rows)``."""
+    import numpy as np
     from . import _lib
     batch = int(batch)
-    df_align = read_align_bed(bed)
-    df_align = df_align.loc[df_align['CALL_BATCH'] == batch]
-    df_trim = read_trim_bed(bed_trim)
+    table = _lib.BedTable(bed, with_cigar=True)                                     # :805
+    trim_table = _lib.BedTable(bed_trim, with_cigar=False)                          # :813-816 (POS, END, INDEX)
     own = ctx is None
     if own:
         ctx = _lib.Context(device_id)
     try:
-        ref_names, tig_names = cigarcall.load_sequences(ctx, ref_fa_name, tig_fa_name, df_align)
-        aln, text, off = cigarcall.pack_alignments(df_align, ref_names, tig_names)
-        ctx.cigar_load(aln, text, off)
+        cols = table.fetch()
+        sel = cols['CALL_BATCH'] == batch if table.n_rows else np.zeros(0, dtype=bool)    # :807
+        want_ref = [table.chrom_names[i] for i in np.unique(cols['#CHROM'][sel])] if table.n_rows else []
+        want_tig = [table.qry_names[i] for i in np.unique(cols['QRY_ID'][sel])] if table.n_rows else []
+        if sel.any():
+            cigarcall.load_sequences(ctx, ref_fa_name, tig_fa_name, names=(want_ref, want_tig))
+        else:
+            ctx.seq_load(_lib.PAV_ROLE_REF, [], [])
+            ctx.seq_load(_lib.PAV_ROLE_TIG, [], [])
+        index = ctx.cigar_load_bed(table, batch)
         try:
             ctx.cigar_call()
         except _lib.CigarDeviceError as ex:
             if ex.detail is None:
                 raise
-            cigarcall._raise_reference_error(ex.detail, df_align)
-        index = df_align['INDEX'].to_numpy(dtype='int64')
-        trim = df_trim.reindex(list(index), fill_value=-1)                         # absent INDEX => -1 => TRIM (:818-822)
+            rows = np.flatnonzero(sel)                                               # the reference's message names the row
+            df_err = pd.DataFrame({'#CHROM': [table.chrom_names[i] for i in cols['#CHROM'][rows]], 'POS': cols['POS'][rows],
+                                   'QRY_ID': [table.qry_names[i] for i in cols['QRY_ID'][rows]], 'INDEX': cols['INDEX'][rows]})
+            cigarcall._raise_reference_error(ex.detail, df_err)
+        tc = trim_table.fetch()
+        trim = pd.DataFrame({'POS': tc['POS'], 'END': tc['END']}, index=tc['INDEX']).astype(int)
+        trim = trim.reindex(list(index), fill_value=-1)                             # absent INDEX => -1 => TRIM (:818-822)
         return ctx.cigar_write_tables(hap, index, trim['POS'].to_numpy(dtype='int64'), trim['END'].to_numpy(dtype='int64'),
                                       snv_path=bed_snv, insdel_path=bed_insdel, threads=threads)
     finally:
+        table.close()
+        trim_table.close()
         if own:
             ctx.close()
 

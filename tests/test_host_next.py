@@ -105,3 +105,46 @@ def test_interval_set_and_lgsv_constants():
     assert len(t[150:160]) == 1 and len(t[200:300]) == 0 and len(t[50:101]) == 1 and len(t[199]) == 1 and len(t[200]) == 0
     assert lgsv.match_bp({'CIGAR': '10='}, False) == 0
     assert lgsv.INSDEL_COLUMNS[11:14] == ['LEFT_SHIFT', 'HOM_REF', 'HOM_TIG'] and len(lgsv.INV_COLUMNS) == 20
+
+
+@pytest.mark.parametrize('rel', ['cigar_synth/align.tsv', 'cigar_synth/trim.tsv', 'inv_hap/align.tsv', 'trim_overlap/align_none.tsv.gz', 'trim_split/trim_tigref.tsv.gz', 'flag_hap/align.tsv',
+                                 'lgsv_hap/align.tsv.gz'])
+def test_native_alignment_table_reader_equals_pandas(built, rel, tmp_path):
+    """pav_bed_open (no GPU needed) against pandas.read_csv on committed alignment tables, gzip and plain."""
+    path = os.path.join(GOLD, rel)
+    if os.path.isdir(path):
+        cand = [f for f in sorted(os.listdir(path)) if 'align' in f and (f.endswith('.tsv') or f.endswith('.gz') or f.endswith('.bed'))]
+        assert cand, os.listdir(path)
+        path = os.path.join(path, cand[0])
+    df = pd.read_csv(path, sep='\t', dtype={'#CHROM': str, 'QRY_ID': str}, keep_default_na=False, low_memory=False)
+    t = _lib.BedTable(path)
+    cols = t.fetch()
+    assert t.n_rows == df.shape[0]
+    for c in ('POS', 'END', 'INDEX', 'QRY_POS', 'QRY_END', 'QRY_LEN', 'MAPQ', 'CALL_BATCH'):
+        if c in df.columns:
+            assert np.array_equal(cols[c], df[c].to_numpy(dtype=np.int64)), c
+    assert [t.chrom_names[i] for i in cols['#CHROM']] == df['#CHROM'].tolist()
+    assert [t.qry_names[i] for i in cols['QRY_ID']] == df['QRY_ID'].tolist()
+    assert cols['REV'].tolist() == [bool(v) for v in df['REV']]
+    text = cols['CIGAR_TEXT'].tobytes().decode()
+    off = cols['CIGAR_OFF']
+    assert [text[int(off[i]):int(off[i + 1])] for i in range(t.n_rows)] == df['CIGAR'].tolist()
+    t.close()
+    plain = tmp_path / 'plain.tsv'                                     # the same table uncompressed, CRLF line ends
+    with open(plain, 'w', newline='') as fh:
+        fh.write(df.to_csv(sep='\t', index=False).replace('\n', '\r\n'))
+    t2 = _lib.BedTable(str(plain), with_cigar=False)
+    assert t2.n_rows == df.shape[0] and 'CIGAR_TEXT' not in t2.fetch() and np.array_equal(t2.fetch()['POS'], cols['POS'])
+    t2.close()
+
+
+def test_native_reader_errors(built, tmp_path):
+    p = tmp_path / 'bad.tsv'
+    p.write_text('#CHROM\tPOS\tEND\tREV\tCIGAR\nchr1\t10\tx20\tTrue\t5=\n')
+    with pytest.raises(_lib.PavDeviceError, match="cannot parse 'x20' in column END"):
+        _lib.BedTable(str(p))
+    p.write_text('#CHROM\tPOS\nchr1\t10\t99\n')
+    with pytest.raises(_lib.PavDeviceError, match='has no CIGAR column'):
+        _lib.BedTable(str(p))
+    with pytest.raises(_lib.PavDeviceError, match='cannot open'):
+        _lib.BedTable(str(tmp_path / 'missing.tsv.gz'))
