@@ -203,6 +203,8 @@ typedef struct {
     double state_run_delta;         /* --staterundelta  (0.005)  :476                                       */
     uint32_t max_ref_kmer_count;    /* MAX_REF_KMER_COUNT (100)  :47                                        */
     uint32_t kde_mode;              /* PAV_KDE_RUNS (default) or PAV_KDE_DIRECT, see below                  */
+    uint32_t kmer_mode;             /* PAV_KMER_LDS (default) or PAV_KMER_HBM, see below                    */
+    uint32_t reserved;
 } pav_den_params;
 
 /* Density evaluation.  Both give the reference's KERN_* to ~1e-13 relative and identical STATE on every test vector.
@@ -213,6 +215,12 @@ typedef struct {
  *                   and odd-derivative corrections, remainder < 1e-15 for bandwidth >= 32; short runs and small
  *                   bandwidths fall back to direct terms).  O(N_eval x N_runs). */
 enum { PAV_KDE_RUNS = 0, PAV_KDE_DIRECT = 1 };
+
+/* Where the reference k-mer set of a region lives while STATE_MER is computed (identical results):
+ *   PAV_KMER_LDS    partitioned by hash, one workgroup builds each partition in a 128 KiB LDS table and answers the
+ *                   contig k-mers that hash to it (regions up to ~7 Mbp; larger ones use HBM tables).
+ *   PAV_KMER_HBM    one open-addressing table per region in HBM, device-scope atomics. */
+enum { PAV_KMER_LDS = 0, PAV_KMER_HBM = 1 };
 
 enum { PAV_DEN_OK = 0, PAV_DEN_UNFINALISED = 1, PAV_DEN_FAIL = 125 };   /* 125 = pavlib.constants.ERR_INV_FAIL */
 

@@ -51,7 +51,8 @@ class DenJob(ctypes.Structure):
 class DenParams(ctypes.Structure):
     _fields_ = [('k', ctypes.c_int32), ('min_informative', ctypes.c_uint32), ('min_state_count', ctypes.c_uint32),
                 ('den_smooth', ctypes.c_double), ('state_run_delta', ctypes.c_double),
-                ('max_ref_kmer_count', ctypes.c_uint32), ('kde_mode', ctypes.c_uint32)]
+                ('max_ref_kmer_count', ctypes.c_uint32), ('kde_mode', ctypes.c_uint32), ('kmer_mode', ctypes.c_uint32),
+                ('reserved', ctypes.c_uint32)]
 
 
 class DenResult(ctypes.Structure):
@@ -106,6 +107,7 @@ assert INV_RESULT_DTYPE.itemsize == ctypes.sizeof(InvResult)
 RUN_DTYPE = np.dtype([('state', '<i4'), ('count', '<u4'), ('pos', '<i8'), ('end', '<i8')])
 DEN_OK, DEN_UNFINALISED, DEN_FAIL = 0, 1, 125
 KDE_RUNS, KDE_DIRECT = 0, 1
+KMER_LDS, KMER_HBM = 0, 1
 
 
 class TableOpts(ctypes.Structure):

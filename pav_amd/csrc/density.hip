@@ -32,6 +32,10 @@ struct JobDev {
     uint32_t first_tile;                  // first tile of the job in the contig-position arena
     uint64_t rpos_off;                    // job start in the reference-position arena
     uint64_t tpos_off;                    // job start in the contig-position / row arena
+    uint32_t n_parts;                     // > 0: LDS-resident k-mer set split into n_parts partitions; 0: hash table in HBM
+    uint32_t bucket_off;                  // first of the job's 3 x n_parts list counters (reference, forward, reverse complement)
+    uint64_t list_off_r, list_off_t;      // first entry of the job's reference lists / of its 2 x n_parts contig lists
+    uint32_t cap_r, cap_t;                // entries per list
 };
 
 struct JobStat {                          // written by kernels, zeroed per batch
@@ -39,6 +43,7 @@ struct JobStat {                          // written by kernels, zeroed per batc
     uint32_t st_count[3];                 // STATE_MER counts before the min-state-count rule
     uint32_t n_rows;
     uint32_t m[3], fill_n;
+    uint32_t lds_flags, pad;              // k_kmer_lds: LDS_EXCEED (a count passed the limit), LDS_OVERFLOW (partition table full)
     unsigned long long s1[3], s2[3];      // sum / sum of squares of the row numbers of each state
     unsigned long long max_key;           // packed (first position << 32 | slot) of the max-count k-mer (failure path)
 };
@@ -60,7 +65,7 @@ struct EvalTile { uint32_t job, first, count, mode; };   // mode 0: sampled site
 struct HeadEvent { uint32_t job, row; int32_t state; uint32_t index, prev_index; uint32_t pad; };
 
 struct DensityState {
-    DevBuf jobs, stat, kde, tile_job_r, tile_job_t, keys, cnt;
+    DevBuf jobs, stat, kde, tile_job_r, tile_job_t, keys, cnt, keys_x, cnt_x, lists, bcount, ans_f, ans_c, items;
     DevBuf st_tmp, tile_sum, tile_pre, index, state_mer, state, kmer, kern[3], list[3], pscaled[3], fill_list;
     DevBuf tiles, events, ev_count, scratch, run_arena, win_fill;
     std::vector<JobDev> h_jobs;
@@ -77,7 +82,7 @@ struct DensityState {
     uint64_t arena_t = 0;
     bool valid = false;
     void release() {
-        DevBuf *all[] = {&jobs, &stat, &kde, &tile_job_r, &tile_job_t, &keys, &cnt, &st_tmp, &tile_sum, &tile_pre,
+        DevBuf *all[] = {&jobs, &stat, &kde, &tile_job_r, &tile_job_t, &keys, &cnt, &keys_x, &cnt_x, &lists, &bcount, &ans_f, &ans_c, &items, &st_tmp, &tile_sum, &tile_pre,
                          &index, &state_mer, &state, &kmer, &kern[0], &kern[1], &kern[2], &list[0], &list[1], &list[2],
                          &pscaled[0], &pscaled[1], &pscaled[2], &fill_list, &tiles, &events, &ev_count, &scratch, &run_arena, &win_fill};
         for (DevBuf *b : all) b->release();
@@ -162,10 +167,12 @@ __device__ __forceinline__ uint32_t table_slot(const unsigned long long *__restr
 // One atomic per k-mer in the common case: cnt[] holds (occurrences - 1) and is only touched by repeats.
 __global__ __launch_bounds__(256) void k_ref_insert(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
                                                     SeqView R, int k, uint32_t limit, unsigned long long *__restrict__ keys,
-                                                    uint32_t *__restrict__ cnt, JobStat *__restrict__ stat) {
-    const uint64_t ap = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+                                                    uint32_t *__restrict__ cnt, JobStat *__restrict__ stat, uint32_t block0,
+                                                    int force) {
+    const uint64_t ap = ((uint64_t)blockIdx.x + block0) * 256 + threadIdx.x;
     const uint32_t j = tile_job[ap / DTILE];
     const JobDev jd = jobs[j];
+    if (jd.n_parts && !force) return;                                  // this job's set lives in LDS (k_kmer_lds)
     const uint64_t i = ap - jd.rpos_off;
     bool valid = false;
     if (i + (uint64_t)k <= jd.ref_len) {
@@ -205,6 +212,7 @@ __global__ __launch_bounds__(256) void k_tig_state(const JobDev *__restrict__ jo
     const uint64_t ap = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint32_t j = tile_job[ap / DTILE];
     const JobDev jd = jobs[j];
+    if (jd.n_parts) return;                                            // k_kmer_lds + k_state_combine
     const uint64_t i = ap - jd.tpos_off;
     int st = -1;
     if (i + (uint64_t)k <= jd.tig_len) {
@@ -220,6 +228,232 @@ __global__ __launch_bounds__(256) void k_tig_state(const JobDev *__restrict__ jo
     for (int s = 0; s < 3; ++s) {
         const unsigned long long b = __ballot(st == s);
         if ((threadIdx.x & 63) == 0 && b) atomicAdd(&stat[j].st_count[s], (uint32_t)__popcll(b));
+    }
+}
+
+// ---- LDS-resident k-mer sets ------------------------------------------------------------------------------------
+// The reference k-mers of a region are split by a hash into n_parts partitions of ~7 k k-mers; one workgroup owns one
+// (job, partition): it builds that partition's set in a 128 KiB LDS table (gfx950 has 160 KiB per CU) and answers the
+// membership questions of the contig k-mers that hash to it - no table atomic ever leaves the CU.
+//   k_bucket_ref / k_bucket_tig  one workgroup per 2048-position tile: every k-mer is hashed once and its position is
+//                                appended to the list of its partition (ranks from an LDS histogram, one global atomic
+//                                per (tile, partition) to reserve the slots); a contig k-mer goes to two lists, one for
+//                                its forward key and one for its reverse-complement key
+//   k_kmer_lds                   reads its three lists densely: inserts, then probes and writes one answer byte per question
+//   k_state_combine              STATE_MER from the two answers per position (+ per-state counts)
+// Counts (scripts/density.py:516-527) are bytes holding occurrences - 1; a count that passes the limit only raises a flag
+// and the exact maximum and its k-mer come from the HBM-table kernels on that failure path.
+constexpr int LDS_SLOTS = 16384;
+constexpr int LDS_THREADS = 1024;
+constexpr uint32_t LDS_FILL = 7168;                  // k-mers per partition aimed at (load factor 0.44)
+constexpr uint32_t LDS_MAX_PARTS = 1024;             // histogram size of the bucket kernels (regions up to 7.3 Mbp)
+constexpr uint32_t LDS_MAX_LIMIT = 250;              // byte counts: the limit must stay below the wrap
+constexpr uint32_t ANS_ABSENT = 0, ANS_PRESENT = 1, ANS_INVALID = 0xFF;
+constexpr uint32_t LDS_EXCEED = 1, LDS_OVERFLOW = 2;
+
+struct PartItem { uint32_t job, part; };
+
+__device__ __forceinline__ uint32_t khash(uint64_t key) {
+    uint32_t h = (uint32_t)key * 0x9E3779B1u ^ (uint32_t)(key >> 32) * 0x85EBCA77u;
+    h ^= h >> 15; h *= 0xC2B2AE3Du; h ^= h >> 13;
+    return h;
+}
+__device__ __forceinline__ uint32_t kpart(uint32_t h, uint32_t n_parts) { return ((h >> 16) * n_parts) >> 16; }
+
+// List capacity per (job, partition): the mean plus 25 % (> 20 sigma at 7 k entries) plus slack for small means.
+static uint32_t bucket_cap(uint64_t n_pos, uint32_t n_parts) {
+    if (n_parts <= 1) return (uint32_t)std::max<uint64_t>(n_pos, 1);
+    return (uint32_t)(n_pos / n_parts + n_pos / n_parts / 4 + 256);
+}
+
+__global__ __launch_bounds__(256) void k_bucket_ref(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
+                                                    SeqView R, int k, uint32_t *__restrict__ lists, uint32_t *__restrict__ bcount,
+                                                    JobStat *__restrict__ stat) {
+    __shared__ uint32_t hist[LDS_MAX_PARTS], base[LDS_MAX_PARTS];
+    const uint32_t j = tile_job[blockIdx.x];
+    const JobDev jd = jobs[j];
+    const uint32_t P = jd.n_parts;
+    if (!P) return;
+    for (uint32_t p = threadIdx.x; p < P; p += 256) hist[p] = 0;
+    __syncthreads();
+    const uint64_t i0 = (uint64_t)blockIdx.x * DTILE - jd.rpos_off;
+    uint32_t pid[8], rank[8];
+    bool any = false;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const uint64_t i = i0 + t * 256 + threadIdx.x;
+        uint64_t x;
+        pid[t] = ~0u;
+        if (i + (uint64_t)k <= jd.ref_len && kmer_window(R.two, R.mask, jd.ref_abs + i, k, x)) {
+            pid[t] = kpart(khash(jd.ref_rc ? (x ^ kmer_mask(k)) : rev_groups(x, k)), P);
+            rank[t] = atomicAdd(&hist[pid[t]], 1u);
+            any = true;
+        }
+    }
+    const int block_any = __syncthreads_or(any);
+    for (uint32_t p = threadIdx.x; p < P; p += 256)
+        if (hist[p]) base[p] = atomicAdd(&bcount[jd.bucket_off + p], hist[p]);
+    __syncthreads();
+    bool over = false;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        if (pid[t] == ~0u) continue;
+        const uint32_t slot = base[pid[t]] + rank[t];
+        if (slot < jd.cap_r) lists[jd.list_off_r + (uint64_t)pid[t] * jd.cap_r + slot] = (uint32_t)(i0 + t * 256 + threadIdx.x);
+        else over = true;
+    }
+    if (over) atomicOr(&stat[j].lds_flags, LDS_OVERFLOW);
+    if (block_any && threadIdx.x == 0) stat[j].n_ref_valid = 1;       // only "any" matters (scripts/density.py:510-513)
+}
+
+__global__ __launch_bounds__(256) void k_bucket_tig(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
+                                                    SeqView T, int k, uint32_t *__restrict__ lists, uint32_t *__restrict__ bcount,
+                                                    uint8_t *__restrict__ ans_f, JobStat *__restrict__ stat) {
+    __shared__ uint32_t hist[2 * LDS_MAX_PARTS], base[2 * LDS_MAX_PARTS];
+    const uint32_t j = tile_job[blockIdx.x];
+    const JobDev jd = jobs[j];
+    const uint32_t P = jd.n_parts;
+    if (!P) return;
+    for (uint32_t p = threadIdx.x; p < 2 * P; p += 256) hist[p] = 0;
+    __syncthreads();
+    const uint64_t i0 = (uint64_t)blockIdx.x * DTILE - jd.tpos_off;
+    uint32_t pf[8], pc[8], rf[8], rc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const uint64_t i = i0 + t * 256 + threadIdx.x;
+        uint64_t x;
+        pf[t] = ~0u;
+        if (i + (uint64_t)k <= jd.tig_len && kmer_window(T.two, T.mask, jd.tig_abs + i, k, x)) {
+            pf[t] = kpart(khash(rev_groups(x, k)), P);
+            pc[t] = P + kpart(khash(x ^ kmer_mask(k)), P);
+            rf[t] = atomicAdd(&hist[pf[t]], 1u);
+            rc[t] = atomicAdd(&hist[pc[t]], 1u);
+        }
+        ans_f[(uint64_t)blockIdx.x * DTILE + t * 256 + threadIdx.x] = pf[t] == ~0u ? (uint8_t)ANS_INVALID : (uint8_t)ANS_ABSENT;
+    }
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < 2 * P; p += 256)
+        if (hist[p]) base[p] = atomicAdd(&bcount[jd.bucket_off + P + p], hist[p]);
+    __syncthreads();
+    bool over = false;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        if (pf[t] == ~0u) continue;
+        const uint32_t pos = (uint32_t)(i0 + t * 256 + threadIdx.x);
+        const uint32_t sf = base[pf[t]] + rf[t], sc = base[pc[t]] + rc[t];
+        if (sf < jd.cap_t) lists[jd.list_off_t + (uint64_t)pf[t] * jd.cap_t + sf] = pos; else over = true;
+        if (sc < jd.cap_t) lists[jd.list_off_t + (uint64_t)pc[t] * jd.cap_t + sc] = pos; else over = true;
+    }
+    if (over) atomicOr(&stat[j].lds_flags, LDS_OVERFLOW);
+}
+
+__global__ __launch_bounds__(LDS_THREADS) void k_kmer_lds(const PartItem *__restrict__ items, const JobDev *__restrict__ jobs,
+                                                          SeqView R, SeqView T, int k, uint32_t limit,
+                                                          const uint32_t *__restrict__ lists, const uint32_t *__restrict__ bcount,
+                                                          uint8_t *__restrict__ ans_f, uint8_t *__restrict__ ans_c,
+                                                          JobStat *__restrict__ stat) {
+    __shared__ unsigned long long keys[LDS_SLOTS];
+    __shared__ uint32_t cnt4[LDS_SLOTS / 4];
+    __shared__ uint32_t flags;
+    const PartItem it = items[blockIdx.x];
+    const JobDev jd = jobs[it.job];
+    const uint32_t P = jd.n_parts;
+    for (int s = threadIdx.x; s < LDS_SLOTS; s += LDS_THREADS) keys[s] = EMPTY_KEY;
+    for (int s = threadIdx.x; s < LDS_SLOTS / 4; s += LDS_THREADS) cnt4[s] = 0;
+    if (threadIdx.x == 0) flags = 0;
+    __syncthreads();
+
+    // reference k-mers of this partition -> LDS set with byte counts
+    {
+        const uint32_t n = min(bcount[jd.bucket_off + it.part], jd.cap_r);
+        const uint32_t *list = lists + jd.list_off_r + (uint64_t)it.part * jd.cap_r;
+        uint32_t my_flags = 0;
+        for (uint32_t e = threadIdx.x; e < n; e += LDS_THREADS) {
+            uint64_t x;
+            kmer_window(R.two, R.mask, jd.ref_abs + list[e], k, x);
+            const uint64_t key = jd.ref_rc ? (x ^ kmer_mask(k)) : rev_groups(x, k);
+            uint32_t s = khash(key) & (LDS_SLOTS - 1);
+            int probes = 0;
+            while (true) {
+                const unsigned long long old = atomicCAS(&keys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+                if (old == EMPTY_KEY) break;
+                if (old == key) {
+                    const uint32_t sh = 8 * (s & 3);
+                    const uint32_t prev = (atomicAdd(&cnt4[s >> 2], 1u << sh) >> sh) & 0xFFu;     // occurrences - 2
+                    if (prev + 2 > limit) my_flags |= LDS_EXCEED;
+                    break;
+                }
+                s = (s + 1) & (LDS_SLOTS - 1);
+                if (++probes >= LDS_SLOTS) { my_flags |= LDS_OVERFLOW; break; }
+            }
+        }
+        if (my_flags) atomicOr(&flags, my_flags);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && flags) atomicOr(&stat[it.job].lds_flags, flags);
+
+    // contig k-mers: the forward key and the reverse-complement key are two independent questions, each answered by the
+    // partition its key hashes to
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const uint32_t b = (1 + side) * P + it.part;
+        const uint32_t n = min(bcount[jd.bucket_off + b], jd.cap_t);
+        const uint32_t *list = lists + jd.list_off_t + (uint64_t)(side * P + it.part) * jd.cap_t;
+        uint8_t *ans = side ? ans_c : ans_f;
+        for (uint32_t e = threadIdx.x; e < n; e += LDS_THREADS) {
+            const uint32_t pos = list[e];
+            uint64_t x;
+            kmer_window(T.two, T.mask, jd.tig_abs + pos, k, x);
+            const uint64_t key = side ? (x ^ kmer_mask(k)) : rev_groups(x, k);
+            uint32_t s = khash(key) & (LDS_SLOTS - 1);
+            uint32_t a = ANS_ABSENT;
+            for (int probes = 0; probes < LDS_SLOTS; ++probes) {
+                const unsigned long long cur = keys[s];
+                if (cur == key) { a = ANS_PRESENT; break; }
+                if (cur == EMPTY_KEY) break;
+                s = (s + 1) & (LDS_SLOTS - 1);
+            }
+            ans[jd.tpos_off + pos] = (uint8_t)a;
+        }
+    }
+}
+
+// STATE_MER from the two membership answers (scripts/density.py:38-43,165-175), one workgroup per tile, 8 positions per lane;
+// jobs with HBM tables were done by k_tig_state.
+__global__ __launch_bounds__(256) void k_state_combine(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
+                                                       const uint8_t *__restrict__ ans_f, const uint8_t *__restrict__ ans_c,
+                                                       int8_t *__restrict__ st_tmp, JobStat *__restrict__ stat) {
+    __shared__ uint32_t red[4][3];
+    const uint32_t j = tile_job[blockIdx.x];
+    if (!jobs[j].n_parts) return;
+    const uint64_t at = (uint64_t)blockIdx.x * DTILE + (uint64_t)threadIdx.x * 8;
+    const uint64_t f8 = *reinterpret_cast<const uint64_t *>(ans_f + at), c8 = *reinterpret_cast<const uint64_t *>(ans_c + at);
+    uint64_t out = 0;
+    uint32_t n[3] = {0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const uint32_t f = (uint32_t)(f8 >> (8 * t)) & 0xFFu, c = (uint32_t)(c8 >> (8 * t)) & 0xFFu;
+        int st = -1;
+        if (f != ANS_INVALID) {
+            const bool in_f = f == ANS_PRESENT, in_r = c == ANS_PRESENT;
+            st = in_f ? (in_r ? 1 : 0) : (in_r ? 2 : -1);            // KMER_ORIENTATION_STATE
+        }
+        if (st >= 0) n[st]++;
+        out |= (uint64_t)(uint8_t)(int8_t)st << (8 * t);
+    }
+    *reinterpret_cast<uint64_t *>(st_tmp + at) = out;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) n[s] += __shfl_xor(n[s], d);
+    }
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) red[threadIdx.x >> 6][s] = n[s];
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const uint32_t v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (v) atomicAdd(&stat[j].st_count[threadIdx.x], v);
     }
 }
 
@@ -831,8 +1065,8 @@ uint64_t pav_kmer_canonical(uint64_t kmer, int k) {
     return kmer <= rc ? kmer : rc;
 }
 
-int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, const pav_den_params *pp,
-                      pav_den_result *results) {
+static int density_batch_impl(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, const pav_den_params *pp,
+                              pav_den_result *results, bool hbm_tables_only) {
     if (!ctx || !pp || (n_jobs && (!jobs || !results))) return fail(ctx, PAV_E_ARG, "pav_density_batch: null argument");
     if (pp->k < 1 || pp->k > 31) return fail(ctx, PAV_E_LIMIT, "pav_density_batch: k = %d is outside 1..31", pp->k);
     PAV_HIP(ctx, hipSetDevice(ctx->device));
@@ -855,6 +1089,13 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     D->h_jobs.assign(n_jobs, JobDev{});
     uint64_t a_r = 0, a_t = 0, a_h = 0;
     std::vector<uint32_t> tile_job_r, tile_job_t;
+    // k-mer sets in LDS unless asked otherwise (params, env), the count limit does not fit a byte, or a region needs
+    // more partitions than the bucket kernels' histograms hold (> 7 Mbp; the reference's MAX_REGION_SIZE is 1.2 Mbp)
+    const bool lds_sets = !hbm_tables_only && pp->kmer_mode != PAV_KMER_HBM && pp->max_ref_kmer_count <= LDS_MAX_LIMIT &&
+                          getenv("PAV_KMER_HBM") == nullptr;
+    std::vector<PartItem> items;
+    uint32_t n_hbm_jobs = 0;
+    uint64_t n_lists = 0, n_bcount = 0;
     for (uint32_t j = 0; j < n_jobs; ++j) {
         const pav_den_job &q = jobs[j];
         if (q.ref_id >= RS.n || q.tig_id >= TS.n) return fail(ctx, PAV_E_ARG, "pav_density_batch: job %u references a sequence that is not loaded", j);
@@ -868,8 +1109,20 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
         jd.tig_len = (uint32_t)(q.tig_end - q.tig_pos);
         jd.ref_rc = q.ref_rc ? 1 : 0;
         jd.srs = q.state_run_smooth;
-        const uint32_t cap = pow2_at_least(2ull * jd.ref_len + 2);
-        jd.ht_off = a_h; jd.ht_mask = cap - 1; a_h += cap;
+        const uint64_t n_ref_kmers = jd.ref_len >= (uint32_t)k ? (uint64_t)jd.ref_len - k + 1 : 0;
+        const uint64_t parts = std::max<uint64_t>(1, (n_ref_kmers + LDS_FILL - 1) / LDS_FILL);
+        if (lds_sets && parts <= LDS_MAX_PARTS) {
+            jd.n_parts = (uint32_t)parts;
+            jd.bucket_off = (uint32_t)n_bcount; n_bcount += 3 * parts;
+            jd.cap_r = bucket_cap(jd.ref_len, jd.n_parts);
+            jd.cap_t = bucket_cap(jd.tig_len, jd.n_parts);
+            jd.list_off_r = n_lists; n_lists += parts * jd.cap_r;
+            jd.list_off_t = n_lists; n_lists += 2 * parts * jd.cap_t;
+        } else {
+            const uint32_t cap = pow2_at_least(2ull * jd.ref_len + 2);
+            jd.ht_off = a_h; jd.ht_mask = cap - 1; a_h += cap;
+            ++n_hbm_jobs;
+        }
         jd.rpos_off = a_r; jd.tpos_off = a_t;
         jd.first_tile = (uint32_t)(a_t / DTILE);
         const uint64_t tr = (std::max<uint64_t>(jd.ref_len, 1) + DTILE - 1) / DTILE, tt = (std::max<uint64_t>(jd.tig_len, 1) + DTILE - 1) / DTILE;
@@ -879,6 +1132,14 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     }
     D->arena_t = a_t;
     const uint32_t n_tiles_r = (uint32_t)tile_job_r.size(), n_tiles_t = (uint32_t)tile_job_t.size();
+    {   // one workgroup per (job, partition); the long scans first
+        std::vector<uint32_t> order;
+        for (uint32_t j = 0; j < n_jobs; ++j) if (D->h_jobs[j].n_parts) order.push_back(j);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+            return (uint64_t)D->h_jobs[a].ref_len + D->h_jobs[a].tig_len > (uint64_t)D->h_jobs[b].ref_len + D->h_jobs[b].tig_len; });
+        for (uint32_t j : order)
+            for (uint32_t p = 0; p < D->h_jobs[j].n_parts; ++p) items.push_back(PartItem{j, p});
+    }
 
     PAV_HIP(ctx, D->jobs.reserve(sizeof(JobDev) * n_jobs));
     PAV_HIP(ctx, D->stat.reserve(sizeof(JobStat) * n_jobs));
@@ -887,6 +1148,14 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     PAV_HIP(ctx, D->tile_job_t.reserve(4ull * n_tiles_t));
     PAV_HIP(ctx, D->keys.reserve(8 * a_h));
     PAV_HIP(ctx, D->cnt.reserve(4 * a_h));
+    if (!items.empty()) {
+        if (n_bcount > 0xFFFFFFFFull) return fail(ctx, PAV_E_LIMIT, "pav_density_batch: too many k-mer partitions in one batch");
+        PAV_HIP(ctx, D->lists.reserve(4 * n_lists));
+        PAV_HIP(ctx, D->bcount.reserve(4 * n_bcount));
+        PAV_HIP(ctx, D->ans_f.reserve(a_t));
+        PAV_HIP(ctx, D->ans_c.reserve(a_t));
+        PAV_HIP(ctx, D->items.reserve(sizeof(PartItem) * items.size()));
+    }
     PAV_HIP(ctx, D->st_tmp.reserve(a_t + 64));
     PAV_HIP(ctx, D->tile_sum.reserve(16ull * n_tiles_t));
     PAV_HIP(ctx, D->tile_pre.reserve(32ull * (n_tiles_t + 1)));
@@ -907,21 +1176,40 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     PAV_HIP(ctx, hipMemcpyAsync(D->tile_job_r.p, tile_job_r.data(), 4ull * n_tiles_r, hipMemcpyHostToDevice, st));
     PAV_HIP(ctx, hipMemcpyAsync(D->tile_job_t.p, tile_job_t.data(), 4ull * n_tiles_t, hipMemcpyHostToDevice, st));
     PAV_HIP(ctx, hipMemsetAsync(D->stat.p, 0, sizeof(JobStat) * n_jobs, st));
-    PAV_HIP(ctx, hipMemsetAsync(D->keys.p, 0xFF, 8 * a_h, st));
-    PAV_HIP(ctx, hipMemsetAsync(D->cnt.p, 0, 4 * a_h, st));
+    if (a_h) {
+        PAV_HIP(ctx, hipMemsetAsync(D->keys.p, 0xFF, 8 * a_h, st));
+        PAV_HIP(ctx, hipMemsetAsync(D->cnt.p, 0, 4 * a_h, st));
+    }
+    if (!items.empty()) {
+        PAV_HIP(ctx, hipMemcpyAsync(D->items.p, items.data(), sizeof(PartItem) * items.size(), hipMemcpyHostToDevice, st));
+        PAV_HIP(ctx, hipMemsetAsync(D->bcount.p, 0, 4 * n_bcount, st));
+    }
 
     const JobDev *d_jobs = D->jobs.as<JobDev>();
     JobStat *d_stat = D->stat.as<JobStat>();
     const uint32_t *d_tjr = D->tile_job_r.as<uint32_t>(), *d_tjt = D->tile_job_t.as<uint32_t>();
-    unsigned long long *d_keys = D->keys.as<unsigned long long>();
+    unsigned long long *const d_keys = D->keys.as<unsigned long long>();      // HBM tables (jobs without LDS sets, failure path)
     const SeqView RV = RS.view(), TV = TS.view();
 
     // ---- k-mer states and compaction -------------------------------------------------------------------------
     { int rcw = wait_planes(ctx); if (rcw != PAV_OK) return rcw; }
-    PAV_LAUNCH(ctx, "k_ref_insert", k_ref_insert, (uint32_t)(a_r / 256), 256, 0, d_jobs, d_tjr, RV, k, pp->max_ref_kmer_count,
-               d_keys, D->cnt.as<uint32_t>(), d_stat);
-    PAV_LAUNCH(ctx, "k_tig_state", k_tig_state, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, TV, k, d_keys,
-               D->st_tmp.as<int8_t>(), d_stat);
+    if (!items.empty()) {
+        PAV_LAUNCH(ctx, "k_bucket_ref", k_bucket_ref, n_tiles_r, 256, 0, d_jobs, d_tjr, RV, k, D->lists.as<uint32_t>(),
+                   D->bcount.as<uint32_t>(), d_stat);
+        PAV_LAUNCH(ctx, "k_bucket_tig", k_bucket_tig, n_tiles_t, 256, 0, d_jobs, d_tjt, TV, k, D->lists.as<uint32_t>(),
+                   D->bcount.as<uint32_t>(), D->ans_f.as<uint8_t>(), d_stat);
+        PAV_LAUNCH(ctx, "k_kmer_lds", k_kmer_lds, (uint32_t)items.size(), LDS_THREADS, 0, D->items.as<PartItem>(), d_jobs, RV, TV, k,
+                   pp->max_ref_kmer_count, D->lists.as<uint32_t>(), D->bcount.as<uint32_t>(), D->ans_f.as<uint8_t>(),
+                   D->ans_c.as<uint8_t>(), d_stat);
+        PAV_LAUNCH(ctx, "k_state_combine", k_state_combine, n_tiles_t, 256, 0, d_jobs, d_tjt, D->ans_f.as<uint8_t>(),
+                   D->ans_c.as<uint8_t>(), D->st_tmp.as<int8_t>(), d_stat);
+    }
+    if (n_hbm_jobs) {
+        PAV_LAUNCH(ctx, "k_ref_insert", k_ref_insert, (uint32_t)(a_r / 256), 256, 0, d_jobs, d_tjr, RV, k, pp->max_ref_kmer_count,
+                   d_keys, D->cnt.as<uint32_t>(), d_stat, 0u, 0);
+        PAV_LAUNCH(ctx, "k_tig_state", k_tig_state, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, TV, k, d_keys,
+                   D->st_tmp.as<int8_t>(), d_stat);
+    }
     PAV_LAUNCH(ctx, "k_compact_reduce", k_compact_reduce, n_tiles_t, 256, 0, d_tjt, d_stat, D->st_tmp.as<int8_t>(),
                pp->min_state_count, D->tile_sum.as<uint32_t>());
     PAV_LAUNCH(ctx, "k_scan_tiles4", k_scan_tiles4, 1, 256, 0, D->tile_sum.as<uint32_t>(), D->tile_pre.as<unsigned long long>(),
@@ -939,6 +1227,39 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     PAV_HIP(ctx, hipMemcpyAsync(hs.data(), d_stat, sizeof(JobStat) * n_jobs, hipMemcpyDeviceToHost, st));
     PAV_HIP(ctx, hipStreamSynchronize(st));
     lap("kmer+compact");
+    {
+        bool overflow = false;
+        std::vector<uint32_t> exceed;
+        for (uint32_t j = 0; j < n_jobs; ++j) {
+            if (hs[j].lds_flags & LDS_OVERFLOW) overflow = true;
+            else if (hs[j].lds_flags & LDS_EXCEED) exceed.push_back(j);
+        }
+        if (overflow)                                                  // a partition outgrew its LDS table (hash imbalance far
+            return density_batch_impl(ctx, n_jobs, jobs, pp, results, true);   // beyond the 0.44 load aimed at): HBM tables
+        if (!exceed.empty()) {
+            // failure path (scripts/density.py:516-527): the exact largest count comes from an HBM table of the region
+            uint64_t extra = 0;
+            for (uint32_t j : exceed) {
+                JobDev &jd = D->h_jobs[j];
+                const uint32_t cap = pow2_at_least(2ull * jd.ref_len + 2);
+                jd.ht_off = extra; jd.ht_mask = cap - 1; extra += cap;
+            }
+            PAV_HIP(ctx, D->keys_x.reserve(8 * extra));
+            PAV_HIP(ctx, D->cnt_x.reserve(4 * extra));
+            PAV_HIP(ctx, hipMemsetAsync(D->keys_x.p, 0xFF, 8 * extra, st));
+            PAV_HIP(ctx, hipMemsetAsync(D->cnt_x.p, 0, 4 * extra, st));
+            PAV_HIP(ctx, hipMemcpyAsync(D->jobs.p, D->h_jobs.data(), sizeof(JobDev) * n_jobs, hipMemcpyHostToDevice, st));
+            for (uint32_t j : exceed) {
+                const JobDev &jd = D->h_jobs[j];
+                PAV_HIP(ctx, hipMemsetAsync(&d_stat[j].n_ref_valid, 0, 4, st));     // counted again by the insert below
+                PAV_LAUNCH(ctx, "k_ref_insert", k_ref_insert, (uint32_t)((std::max<uint64_t>(jd.ref_len, 1) + DTILE - 1) / DTILE * (DTILE / 256)),
+                           256, 0, d_jobs, d_tjr, RV, k, pp->max_ref_kmer_count, D->keys_x.as<unsigned long long>(),
+                           D->cnt_x.as<uint32_t>(), d_stat, (uint32_t)(jd.rpos_off / 256), 1);
+            }
+            PAV_HIP(ctx, hipMemcpyAsync(hs.data(), d_stat, sizeof(JobStat) * n_jobs, hipMemcpyDeviceToHost, st));
+            PAV_HIP(ctx, hipStreamSynchronize(st));
+        }
+    }
 
     // Run heads of a per-row state array (STATE_MER here, STATE for rl_encoder below): events sorted by (job, row).
     auto collect_heads = [&](const int8_t *d_state, std::vector<HeadEvent> &ev, uint64_t hint) -> int {
@@ -1036,11 +1357,14 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     for (uint32_t j = 0; j < n_jobs; ++j) {
         if (D->results[j].fail_kind != 2) continue;
         PAV_HIP(ctx, hipMemsetAsync(&d_stat[j].max_key, 0xFF, sizeof(unsigned long long), st));
-        PAV_LAUNCH(ctx, "k_max_kmer", k_max_kmer, 64, 256, 0, d_jobs, j, RV, k, d_keys, D->cnt.as<uint32_t>(), d_stat);
+        // regions with LDS sets got their HBM table on the failure path above (keys_x / cnt_x)
+        const unsigned long long *jk = D->h_jobs[j].n_parts ? D->keys_x.as<unsigned long long>() : d_keys;
+        const uint32_t *jc = D->h_jobs[j].n_parts ? D->cnt_x.as<uint32_t>() : D->cnt.as<uint32_t>();
+        PAV_LAUNCH(ctx, "k_max_kmer", k_max_kmer, 64, 256, 0, d_jobs, j, RV, k, jk, jc, d_stat);
         unsigned long long packed = 0, key = 0;
         PAV_HIP(ctx, hipMemcpyAsync(&packed, &d_stat[j].max_key, sizeof packed, hipMemcpyDeviceToHost, st));
         PAV_HIP(ctx, hipStreamSynchronize(st));
-        PAV_HIP(ctx, hipMemcpy(&key, d_keys + D->h_jobs[j].ht_off + (packed & 0xFFFFFFFFull), sizeof key, hipMemcpyDeviceToHost));
+        PAV_HIP(ctx, hipMemcpy(&key, jk + D->h_jobs[j].ht_off + (packed & 0xFFFFFFFFull), sizeof key, hipMemcpyDeviceToHost));
         // the set holds rc(k-mer) when -r is set; the counter in the reference is keyed by the forward k-mer
         D->results[j].max_kmer = D->h_jobs[j].ref_rc ? pav_kmer_rev_complement(key, k) : key;
     }
@@ -1104,6 +1428,11 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     lap("rl");
     D->valid = true;
     return PAV_OK;
+}
+
+int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, const pav_den_params *pp,
+                      pav_den_result *results) {
+    return density_batch_impl(ctx, n_jobs, jobs, pp, results, false);
 }
 
 int pav_density_runs(pav_ctx *ctx, uint32_t job, pav_run *runs) {

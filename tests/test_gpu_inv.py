@@ -90,9 +90,13 @@ def test_scan_for_inv_vs_reference(built, gpu_ctx, case, capsys):
             check_call(d, rec, call)
 
 
-@pytest.mark.parametrize('mode', [_lib.KDE_RUNS, _lib.KDE_DIRECT])
+MODES = [(_lib.KDE_RUNS, _lib.KMER_LDS), (_lib.KDE_DIRECT, _lib.KMER_LDS), (_lib.KDE_RUNS, _lib.KMER_HBM)]
+MODE_IDS = ['runs-lds', 'direct-lds', 'runs-hbm']
+
+
+@pytest.mark.parametrize('mode,kmer', MODES, ids=MODE_IDS)
 @pytest.mark.parametrize('case', INV_CASES)
-def test_density_iterations_vs_reference(built, gpu_ctx, case, mode):
+def test_density_iterations_vs_reference(built, gpu_ctx, case, mode, kmer):
     """pav_density_batch on every (region_ref, region_tig) pair the reference scanned, all in one batch: row counts,
     INDEX / STATE_MER / STATE digests and rl_encoder runs exact, density column sums to 1e-12."""
     d, lift, scans = load_case(gpu_ctx, case)
@@ -104,7 +108,7 @@ def test_density_iterations_vs_reference(built, gpu_ctx, case, mode):
                         1 if it['region_tig']['is_rev'] else 0, 20) for it in its]
     if not jobs:
         pytest.skip('no liftable iteration in this case')
-    res = gpu_ctx.density_batch(jobs, pavden.den_params(kde_mode=mode))
+    res = gpu_ctx.density_batch(jobs, pavden.den_params(kde_mode=mode, kmer_mode=kmer))
     for j, (it, r) in enumerate(zip(its, res)):
         if 'n_rows' not in it:
             assert r.status == _lib.DEN_FAIL
@@ -151,6 +155,65 @@ def test_alignlift_device_tables(built, gpu_ctx):
             a, b = (dev.ref_cache[index], host.ref_cache[index]) if ax == 0 else (dev.tig_cache[index], host.tig_cache[index])
             assert np.array_equal(a.t.code, b.t.code) and np.array_equal(a.t.len, b.t.len)
             assert np.array_equal(a.t.begin[0], b.t.begin[0]) and np.array_equal(a.t.begin[1], b.t.begin[1])
+
+
+def test_scan_with_hbm_tables_vs_reference(built, gpu_ctx, monkeypatch):
+    """The whole scan with the k-mer sets forced into HBM tables (PAV_KMER_HBM): same logs (incl. the 'K-mer count exceeds
+    max' failure, whose count and k-mer come from the HBM table in both modes) and calls as the reference."""
+    monkeypatch.setenv('PAV_KMER_HBM', '1')
+    d, lift, scans = load_case(gpu_ctx, 'inv_small')
+    k_util = KmerUtil(31)
+    assert any('K-mer count exceeds max' in ln for rec in scans for ln in rec['log'])
+    for rec in scans:
+        f = rec['flag']
+        log = io.StringIO()
+        call = pavinv.scan_for_inv(pavseq.Region(f['chrom'], f['pos'], f['end']), os.path.join(d, 'ref.fa'),
+                                   os.path.join(d, 'tig.fa'), lift, k_util, log=log, ctx=gpu_ctx, **rec['kwargs'])
+        assert log.getvalue().splitlines() == rec['log'], f
+        if rec['call'] is None:
+            assert call is None
+        else:
+            check_call(d, rec, call)
+
+
+def test_kmer_sets_lds_equal_hbm_on_large_regions(built, gpu_ctx):
+    """Regions of 60 kbp - 1.2 Mbp (9 - 170 LDS partitions per region), forward and reverse, with an inverted segment, a
+    tandem array above the count limit and N runs: the LDS-partitioned sets and the HBM tables give identical tables."""
+    rng = np.random.default_rng(77)
+    n = 2_600_000
+    ref = rng.integers(0, 4, n, dtype=np.uint8)
+    acgt = np.frombuffer(b'ACGT', dtype=np.uint8)
+    tig = ref.copy()
+    snv = rng.random(n) < 0.002
+    tig[snv] = (tig[snv] + rng.integers(1, 4, int(snv.sum()), dtype=np.uint8)) & 3
+    tig[400_000:520_000] = 3 - tig[400_000:520_000][::-1]                      # inversion
+    ref_a, tig_a = acgt[ref].copy(), acgt[tig].copy()
+    ref_a[2_000_000:2_000_500] = ord('N')
+    tig_a[700_000:700_040] = ord('n')
+    unit = acgt[rng.integers(0, 4, 37, dtype=np.uint8)]
+    ref_a[2_300_000:2_300_000 + 37 * 160] = np.tile(unit, 160)                  # 160 copies > MAX_REF_KMER_COUNT
+    gpu_ctx._inv_loaded = None
+    gpu_ctx.seq_load(_lib.PAV_ROLE_REF, ['chrL'], [ref_a])
+    gpu_ctx.seq_load(_lib.PAV_ROLE_TIG, ['tigL'], [tig_a])
+    spans = [(300_000, 360_000, 0), (350_000, 650_000, 0), (0, 1_200_000, 0), (380_000, 540_000, 1),
+             (1_900_000, 2_100_000, 0), (2_250_000, 2_350_000, 0), (690_000, 710_000, 0)]
+    jobs = [_lib.DenJob(0, 0, a, b, a, b, rc, 20) for a, b, rc in spans]
+    out = {}
+    for kmer in (_lib.KMER_LDS, _lib.KMER_HBM):
+        res = gpu_ctx.density_batch(jobs, pavden.den_params(kmer_mode=kmer))
+        out[kmer] = [(r.status, r.fail_kind, r.n_rows, r.max_count, r.max_kmer, list(r.state_count),
+                      gpu_ctx.density_table(j, r.n_rows) if r.status != _lib.DEN_FAIL else None,
+                      gpu_ctx.density_runs(j, r.n_runs) if r.status != _lib.DEN_FAIL else None) for j, r in enumerate(res)]
+    statuses = [o[0] for o in out[_lib.KMER_LDS]]
+    assert statuses.count(_lib.DEN_OK) >= 5 and statuses[5] == _lib.DEN_FAIL and out[_lib.KMER_LDS][5][3] == 160
+    for a, b in zip(out[_lib.KMER_LDS], out[_lib.KMER_HBM]):
+        assert a[:6] == b[:6]
+        if a[6] is not None:
+            assert a[7] == b[7]
+            for c in a[6]:
+                assert np.array_equal(a[6][c], b[6][c]), c
+    inv_rows = out[_lib.KMER_LDS][1][6]
+    assert (inv_rows['STATE_MER'] == 2).sum() > 100_000                           # the inverted segment shows up as REV
 
 
 @pytest.mark.parametrize('native', [True, False])
@@ -280,9 +343,9 @@ def test_rule_call_inv_batch_files(built, gpu_ctx, tmp_path):
     assert flag.shape[0] == len(scans)
 
 
-@pytest.mark.parametrize('mode', [_lib.KDE_RUNS, _lib.KDE_DIRECT])
+@pytest.mark.parametrize('mode,kmer', MODES, ids=MODE_IDS)
 @pytest.mark.parametrize('seed', [31, 32])
-def test_density_vs_oracle_seeded(built, gpu_ctx, seed, mode):
+def test_density_vs_oracle_seeded(built, gpu_ctx, seed, mode, kmer):
     """Seeded haplotype with planted inversions, inverted repeats, N runs and reverse rows: the first scan iteration of
     every flagged region as one device batch vs the scalar oracle - integer columns exact, KERN_* to 1e-11."""
     from oracle import oracle
@@ -310,7 +373,7 @@ def test_density_vs_oracle_seeded(built, gpu_ctx, seed, mode):
         if len(jobs) >= 24:
             break
     assert len(jobs) >= 8
-    res = gpu_ctx.density_batch(jobs, pavden.den_params(kde_mode=mode))
+    res = gpu_ctx.density_batch(jobs, pavden.den_params(kde_mode=mode, kmer_mode=kmer))
     n_final = 0
     for j, ((r, t), g) in enumerate(zip(pairs, res)):
         o = oracle.density(hap.ref.seqs[r.chrom][r.pos:r.end], hap.tig_seqs[t.chrom][t.pos:t.end], t.is_rev)
