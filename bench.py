@@ -152,14 +152,26 @@ def main():
             inv_state['t_scan_ms'] = (time.perf_counter() - t_b) * 1e3
             return out
 
+    phase_timing = bool(os.environ.get('PAV_TIMING'))
+
     def step():
+        t_p = [time.perf_counter()]
+
+        def lap(what):
+            if phase_timing:
+                t = time.perf_counter()
+                print('[pav timing] step %-12s %.2f ms' % (what, (t - t_p[0]) * 1e3), file=sys.stderr)
+                t_p[0] = t
         ctx.seq_pack(_lib.PAV_ROLE_TIG)
         c = ctx.cigar_call()
+        lap('cigar_call')
         if args.workload == 'cigar+inv':
             import contextlib
             inv_state['flag'] = ctx.cigar_flag(flag_tp, flag_te, flag_params)   # signature flagging of the fresh calls
+            lap('cigar_flag')
             with contextlib.redirect_stdout(io.StringIO()):                # scan_for_inv prints 'INV Found: ...' (inv.py:408)
                 inv_step()
+            lap('inv_step')
         return c
 
     def fence():

@@ -618,7 +618,11 @@ class Context:
         off = np.zeros(n_regions + 1, dtype=np.uint64)
         self._check(self.lib.pav_inv_texts(self.handle, what, buf, int(total_bytes), _ptr(off)), 'pav_inv_texts')
         raw = buf.raw
-        return [raw[int(off[i]):int(off[i + 1])].decode() for i in range(n_regions)]
+        o = off.tolist()
+        text = raw.decode()
+        if len(text) == len(raw):                                   # ASCII: byte offsets are character offsets
+            return [text[o[i]:o[i + 1]] for i in range(n_regions)]
+        return [raw[o[i]:o[i + 1]].decode() for i in range(n_regions)]
 
     def inv_table(self, region, n_rows):
         cols = {'INDEX': np.zeros(n_rows, dtype=np.int64), 'STATE_MER': np.zeros(n_rows, dtype=np.int8),

@@ -548,6 +548,10 @@ struct CompactArgs {
 __global__ __launch_bounds__(256) void k_compact_scatter(CompactArgs A) {
     __shared__ uint32_t lds[16];
     __shared__ unsigned long long red[4][7];
+    // the tile's kept rows are staged in LDS in row order and leave with coalesced stores
+    __shared__ unsigned long long s_kmer[DTILE];
+    __shared__ uint32_t s_index[DTILE], s_list[3][DTILE];
+    __shared__ int8_t s_mer[DTILE];
     const uint32_t j = A.tile_job[blockIdx.x];
     const JobDev jd = A.jobs[j];
     const JobStat js = A.stat[j];
@@ -560,29 +564,38 @@ __global__ __launch_bounds__(256) void k_compact_scatter(CompactArgs A) {
         st[t] = keep_state((int)(int8_t)(packed >> (8 * t)), js, A.min_state_count);
         if (st[t] >= 0) { c[0]++; c[1 + st[t]]++; }
     }
-    block_scan4(c, tot, lds);
-    // job-relative bases: global tile prefix minus the prefix at the job's first tile
-    unsigned long long pre[4];
+    block_scan4(c, tot, lds);                                          // c[] = exclusive prefixes inside the tile
+    // job-relative bases of the tile: global tile prefix minus the prefix at the job's first tile
+    unsigned long long tile0[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-        pre[q] = A.tile_pre[(uint64_t)blockIdx.x * 4 + q] - A.tile_pre[(uint64_t)jd.first_tile * 4 + q] + c[q];
+        tile0[q] = A.tile_pre[(uint64_t)blockIdx.x * 4 + q] - A.tile_pre[(uint64_t)jd.first_tile * 4 + q];
     unsigned long long s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0};
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         if (st[t] < 0) continue;
         const uint64_t i = base + t - jd.tpos_off;                     // k-mer offset in region_tig = INDEX
-        const uint64_t row = pre[0]++;
-        const uint64_t o = jd.tpos_off + row;
+        const uint32_t lr = c[0]++;                                    // row inside the tile
+        const uint64_t row = tile0[0] + lr;
         uint64_t x;
         kmer_window(A.T.two, A.T.mask, jd.tig_abs + i, A.k, x);
-        A.index[o] = (uint32_t)i;
-        A.state_mer[o] = (int8_t)st[t];
-        A.state[o] = -1;                                               // df['STATE'] = -1 (density.py:163)
-        A.kmer[o] = rev_groups(x, A.k);
-        const uint64_t rank = pre[1 + st[t]]++;
-        A.list[st[t]][jd.tpos_off + rank] = (uint32_t)row;             // INDEX_DEN of the state's data points, ascending
+        s_index[lr] = (uint32_t)i;
+        s_mer[lr] = (int8_t)st[t];
+        s_kmer[lr] = rev_groups(x, A.k);
+        s_list[st[t]][c[1 + st[t]]++] = (uint32_t)row;                 // INDEX_DEN of the state's data points, ascending
         s1[st[t]] += row; s2[st[t]] += row * row;
     }
+    __syncthreads();
+    const uint64_t o0 = jd.tpos_off + tile0[0];
+    for (uint32_t r = threadIdx.x; r < tot[0]; r += 256) {
+        A.index[o0 + r] = s_index[r];
+        A.state_mer[o0 + r] = s_mer[r];
+        A.state[o0 + r] = -1;                                          // df['STATE'] = -1 (density.py:163)
+        A.kmer[o0 + r] = s_kmer[r];
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+        for (uint32_t r = threadIdx.x; r < tot[1 + s]; r += 256) A.list[s][jd.tpos_off + tile0[1 + s] + r] = s_list[s][r];
     // block reduction of the per-state moments, one atomic per block and quantity
 #pragma unroll
     for (int s = 0; s < 3; ++s) {

@@ -475,19 +475,13 @@ def _native_scan(ctx, region_flags, align_lift, k_util, max_region_size, logs, s
     _lap('inv_scan_batch')
     ref_names, tig_names = ctx.seq_names(_lib.PAV_ROLE_REF), ctx.seq_names(_lib.PAV_ROLE_TIG)
 
-    def rgn(r, names, with_rev):
-        aln_ix = [tuple(int(r.aln_index[e][q]) for q in range(r.n_aln[e])) for e in (0, 1)]
-        return seq.Region(names[r.seq_id], int(r.pos), int(r.end), is_rev=bool(r.is_rev) if with_rev else False,
-                          pos_aln_index=(aln_ix[0],) if r.n_aln[0] else None, end_aln_index=(aln_ix[1],) if r.n_aln[1] else None)
-
-    if eager_tables:
-        n_rows = [int(res[i].n_rows) if res[i].outcome == _lib.INV_CALL else 0 for i in range(len(region_flags))]
-        all_cols, all_flank, all_match, row_off = ctx.inv_tables(n_rows)
-    generation = ctx._inv_generation
-    _lap('inv_tables')
     n_rgn = len(region_flags)
     resv = np.frombuffer(res, dtype=_lib.INV_RESULT_DTYPE, count=n_rgn) if n_rgn else np.zeros(0, dtype=_lib.INV_RESULT_DTYPE)
     outcome, found = resv['outcome'], resv['found']
+    if eager_tables:
+        all_cols, all_flank, all_match, row_off = ctx.inv_tables(np.where(outcome == _lib.INV_CALL, resv['n_rows'], 0))
+    generation = ctx._inv_generation
+    _lap('inv_tables')
     if logs is not None and n_rgn:
         texts = ctx.inv_texts(0, n_rgn, int(resv['log_bytes'].sum(dtype=np.int64)))
         for lg, text in zip(logs, texts):
@@ -496,16 +490,35 @@ def _native_scan(ctx, region_flags, align_lift, k_util, max_region_size, logs, s
                 lg.flush()
     errors = ctx.inv_texts(1, n_rgn, int(resv['error_bytes'].sum(dtype=np.int64))) if (outcome == _lib.INV_ERROR).any() else None
     out = [None] * n_rgn
-    for i in np.flatnonzero((found != 0) | (outcome != _lib.INV_NONE)):
-        i = int(i)
-        r, rf = res[i], region_flags[i]
-        if r.found:
-            print('INV Found: outer={}, inner={} (ref outer={}, inner={})'.format(
-                rgn(r.tig_outer, tig_names, True), rgn(r.tig_inner, tig_names, True), rgn(r.ref_outer, ref_names, False),
-                rgn(r.ref_inner, ref_names, False)))
-        if r.outcome == _lib.INV_ERROR:
+    hit = np.flatnonzero((found != 0) | (outcome != _lib.INV_NONE))
+    sub = resv[hit]                                                   # the few regions with something to report, as plain lists
+
+    def rgn_lists(field, names, with_rev):
+        g = sub[field]
+        seq_id, pos, end, is_rev = g['seq_id'].tolist(), g['pos'].tolist(), g['end'].tolist(), g['is_rev'].tolist()
+        n_aln, aln = g['n_aln'].tolist(), g['aln_index'].tolist()
+        regions = []
+        for q in range(len(hit)):
+            pa = (tuple(aln[q][0][:n_aln[q][0]]),) if n_aln[q][0] else None
+            ea = (tuple(aln[q][1][:n_aln[q][1]]),) if n_aln[q][1] else None
+            regions.append(seq.Region(names[seq_id[q]], pos[q], end[q], is_rev=bool(is_rev[q]) if with_rev else False,
+                                      pos_aln_index=pa, end_aln_index=ea))
+        return regions
+
+    r_ref_outer, r_ref_inner = rgn_lists('ref_outer', ref_names, False), rgn_lists('ref_inner', ref_names, False)
+    r_tig_outer, r_tig_inner = rgn_lists('tig_outer', tig_names, True), rgn_lists('tig_inner', tig_names, True)
+    is_call = (sub['outcome'] == _lib.INV_CALL).tolist()
+    r_ref_disc = rgn_lists('ref_discovery', ref_names, False) if any(is_call) else None
+    r_tig_disc = rgn_lists('tig_discovery', tig_names, True) if any(is_call) else None
+    sub_found, sub_outcome = sub['found'].tolist(), sub['outcome'].tolist()
+    found_lines = []
+    for q, i in enumerate(hit.tolist()):
+        if sub_found[q]:
+            found_lines.append('INV Found: outer={}, inner={} (ref outer={}, inner={})'.format(
+                r_tig_outer[q], r_tig_inner[q], r_ref_outer[q], r_ref_inner[q]))
+        if sub_outcome[q] == _lib.INV_ERROR:
             out[i] = RuntimeError(errors[i])
-        elif r.outcome == _lib.INV_CALL:
+        elif sub_outcome[q] == _lib.INV_CALL:
             if eager_tables:
                 sl = slice(int(row_off[i]), int(row_off[i + 1]))
                 cols = {name: arr[sl] for name, arr in all_cols.items()}
@@ -517,9 +530,10 @@ def _native_scan(ctx, region_flags, align_lift, k_util, max_region_size, logs, s
                 def df(i=i):                    # views of the library's pinned host copy; valid until the next scan
                     cols, flank, match = ctx.inv_table_view(i, generation)
                     return density.table_frame(cols, finalised=True, extra=_flank_match_text(flank.copy(), match.copy()))
-            out[i] = InvCall(rgn(r.ref_outer, ref_names, False), rgn(r.ref_inner, ref_names, False),
-                             rgn(r.tig_outer, tig_names, True), rgn(r.tig_inner, tig_names, True),
-                             rgn(r.ref_discovery, ref_names, False), rgn(r.tig_discovery, tig_names, True), rf, df)
+            out[i] = InvCall(r_ref_outer[q], r_ref_inner[q], r_tig_outer[q], r_tig_inner[q], r_ref_disc[q], r_tig_disc[q],
+                             region_flags[i], df)
+    if found_lines:
+        print('\n'.join(found_lines))                                   # inv.py:408, one line per region in region order
     _lap('results')
     return out
 

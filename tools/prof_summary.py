@@ -3,6 +3,8 @@
 
   python tools/prof_summary.py stats <db> <out.txt>            per-kernel calls / total / avg / min / max (us)
   python tools/prof_summary.py pmc   <db> <out.txt>            per-kernel average counter value per launch
+  python tools/prof_summary.py timeline <db> <out.txt> [ms]    kernels (and copies) of the last [ms] of the trace in start order,
+                                                               with the idle gap in front of each (us)
 """
 import sqlite3
 import sys
@@ -55,5 +57,28 @@ def pmc(db, out):
     print(open(out).read())
 
 
+def timeline(db, out, last_ms=30.0):
+    cur = sqlite3.connect(db).cursor()
+    ev = [(s, e, short(n)) for n, s, e in cur.execute('select name, start, end from kernels')]
+    try:
+        ev += [(s, e, 'copy:%s:%d' % (n, b)) for n, s, e, b in cur.execute('select name, start, end, size from memory_copies')]
+    except sqlite3.Error:
+        pass
+    ev.sort()
+    t_end = max(e for _, e, _ in ev)
+    ev = [x for x in ev if x[0] >= t_end - last_ms * 1e6]
+    t0, busy_end = ev[0][0], ev[0][0]
+    with open(out, 'w') as fh:
+        fh.write(f'# kernels of the last {last_ms} ms of {db}: start offset, duration, idle gap before (us)\n')
+        for s, e, n in ev:
+            gap = max(0, s - busy_end)
+            fh.write(f'{(s - t0) / 1e3:10.1f} {(e - s) / 1e3:9.1f} {gap / 1e3:8.1f}  {n}\n')
+            busy_end = max(busy_end, e)
+    print(open(out).read())
+
+
 if __name__ == '__main__':
-    {'stats': stats, 'pmc': pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])
+    if sys.argv[1] == 'timeline':
+        timeline(sys.argv[2], sys.argv[3], float(sys.argv[4]) if len(sys.argv) > 4 else 30.0)
+    else:
+        {'stats': stats, 'pmc': pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])
