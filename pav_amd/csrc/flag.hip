@@ -22,13 +22,12 @@ namespace {
 
 constexpr int CM_SHIFT = 40;                                  // cluster key = chrom rank << 40 | midpoint
 constexpr uint64_t CM_MID = (1ull << CM_SHIFT) - 1;
-constexpr int SERIAL_STEPS = 32;
 
 struct ClusterHit { uint64_t start; int64_t pos, end, count; uint32_t chrom, pad; };   // 40 B
 struct MatchHit { uint64_t key; int64_t end; };                                        // key = chrom << 32 | POS
 
 struct FlagState {
-    DevBuf a, b, c, d, tmp, hits, cnt, small;
+    DevBuf a, b, c, d, tmp, hits, cnt, small, start;
     std::vector<pav_flag_rgn> table[4];                       // insdel_sv, insdel_indel, cluster_indel, cluster_snv
     std::vector<pav_flag_rgn> single;                         // result of the array-level entry points
     std::vector<pav_flag_locus> loci;
@@ -47,46 +46,25 @@ __device__ __forceinline__ bool opens_cluster(const uint64_t *__restrict__ cm, u
     return (a >> CM_SHIFT) != (b >> CM_SHIFT) || (int64_t)(b & CM_MID) >= (int64_t)(a & CM_MID) + win;
 }
 
-__global__ __launch_bounds__(256) void k_cluster_sweep(const uint64_t *__restrict__ cm, uint64_t n, int64_t win, int64_t win_min,
-                                                       int64_t min_count, ClusterHit *__restrict__ hits,
-                                                       unsigned long long *__restrict__ n_hits, uint64_t cap) {
+// The cluster a row belongs to opens at the last row <= it that does not join its predecessor: an inclusive maximum
+// scan over (row opens a cluster ? row : 0).  The reference's sequential loop (:646-684) in two data-parallel passes.
+struct OpenRow {
+    const uint64_t *cm;
+    int64_t win;
+    __device__ unsigned long long operator()(unsigned long long i) const { return (i == 0 || opens_cluster(cm, i, win)) ? i : 0ull; }
+};
+
+__global__ __launch_bounds__(256) void k_cluster_emit(const uint64_t *__restrict__ cm, const unsigned long long *__restrict__ start,
+                                                      uint64_t n, int64_t win, int64_t win_min, int64_t min_count,
+                                                      ClusterHit *__restrict__ hits, unsigned long long *__restrict__ n_hits, uint64_t cap) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & (WAVE - 1);
-    const bool closes = i < n && (i + 1 == n || opens_cluster(cm, i + 1, win));
-    uint64_t j = i;
-    bool found = !closes;
-    if (closes) {
-        for (int s = 0; s < SERIAL_STEPS; ++s) {
-            if (j == 0 || opens_cluster(cm, j, win)) { found = true; break; }
-            --j;
-        }
-    }
-    // long clusters: the whole wave scans 64 rows per step for one lane at a time
-    unsigned long long pending = __ballot(!found);
-    while (pending) {
-        const int src = __ffsll((long long)pending) - 1;
-        unsigned long long jj = __shfl((unsigned long long)j, src);
-        unsigned long long start;
-        for (;;) {
-            bool hit = false;
-            if (jj >= (unsigned long long)lane) {
-                const uint64_t c = jj - lane;
-                hit = c == 0 || opens_cluster(cm, c, win);
-            }
-            const unsigned long long m = __ballot(hit);
-            if (m) { start = jj - (unsigned long long)(__ffsll((long long)m) - 1); break; }
-            jj -= WAVE;                                        // no hit => no lane saw row 0 => jj >= 64
-        }
-        if (lane == src) { j = start; found = true; }
-        pending &= pending - 1;
-    }
-    if (closes) {
-        const int64_t count = (int64_t)(i - j) + 1;
-        const int64_t pos = (int64_t)(cm[j] & CM_MID), end = (int64_t)(cm[i] & CM_MID);
-        if (count >= min_count && end - pos >= win_min) {
-            const unsigned long long slot = atomicAdd(n_hits, 1ull);
-            if (slot < cap) hits[slot] = ClusterHit{j, pos, end, count, (uint32_t)(cm[i] >> CM_SHIFT), 0};
-        }
+    if (i >= n || !(i + 1 == n || opens_cluster(cm, i + 1, win))) return;       // only the last row of a cluster reports
+    const uint64_t j = start[i];
+    const int64_t count = (int64_t)(i - j) + 1;
+    const int64_t pos = (int64_t)(cm[j] & CM_MID), end = (int64_t)(cm[i] & CM_MID);
+    if (count >= min_count && end - pos >= win_min) {
+        const unsigned long long slot = atomicAdd(n_hits, 1ull);
+        if (slot < cap) hits[slot] = ClusterHit{j, pos, end, count, (uint32_t)(cm[i] >> CM_SHIFT), 0};
     }
 }
 
@@ -298,8 +276,22 @@ int run_sweep(pav_ctx *ctx, FlagState *S, const unsigned long long *d_cm, uint64
     PAV_HIP(ctx, S->hits.reserve(sizeof(ClusterHit) * cap));
     PAV_HIP(ctx, S->cnt.reserve(64));
     PAV_HIP(ctx, hipMemsetAsync(S->cnt.p, 0, 64, ctx->stream));
-    PAV_LAUNCH(ctx, "k_cluster_sweep", k_cluster_sweep, (uint32_t)((n + 255) / 256), 256, 0, (const uint64_t *)d_cm, n, win, win_min, min_count,
-               S->hits.as<ClusterHit>(), S->cnt.as<unsigned long long>(), cap);
+    {
+        PAV_HIP(ctx, S->start.reserve(8 * n));
+        auto opens = rocprim::make_transform_iterator(rocprim::counting_iterator<unsigned long long>(0),
+                                                      OpenRow{(const uint64_t *)d_cm, win});
+        size_t bytes = 0;
+        PAV_HIP(ctx, rocprim::inclusive_scan(nullptr, bytes, opens, S->start.as<unsigned long long>(), (size_t)n,
+                                             rocprim::maximum<unsigned long long>(), ctx->stream));
+        PAV_HIP(ctx, S->tmp.reserve(bytes + 16));
+        const int tok = prof_begin(ctx, "rocprim::inclusive_scan");
+        const hipError_t e = rocprim::inclusive_scan(S->tmp.p, bytes, opens, S->start.as<unsigned long long>(), (size_t)n,
+                                                     rocprim::maximum<unsigned long long>(), ctx->stream);
+        prof_end(ctx, tok);
+        PAV_HIP(ctx, e);
+    }
+    PAV_LAUNCH(ctx, "k_cluster_emit", k_cluster_emit, (uint32_t)((n + 255) / 256), 256, 0, (const uint64_t *)d_cm,
+               S->start.as<unsigned long long>(), n, win, win_min, min_count, S->hits.as<ClusterHit>(), S->cnt.as<unsigned long long>(), cap);
     unsigned long long n_hits = 0;
     PAV_HIP(ctx, hipMemcpyAsync(&n_hits, S->cnt.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -362,7 +354,7 @@ extern "C" {
 void pav_flag_release(pav_ctx *ctx) {
     if (!ctx || !ctx->flag) return;
     FlagState *S = static_cast<FlagState *>(ctx->flag);
-    DevBuf *bufs[] = {&S->a, &S->b, &S->c, &S->d, &S->tmp, &S->hits, &S->cnt, &S->small};
+    DevBuf *bufs[] = {&S->a, &S->b, &S->c, &S->d, &S->tmp, &S->hits, &S->cnt, &S->small, &S->start};
     for (DevBuf *b : bufs) b->release();
     delete S;
     ctx->flag = nullptr;
