@@ -57,6 +57,22 @@ int pav_sync(pav_ctx *ctx);                       /* hipStreamSynchronize on the
  * with str.upper().  Reverse-complemented contigs are never materialised; kernels index them in place.
  */
 int pav_seq_load(pav_ctx *ctx, int role, uint32_t n_seq, const uint8_t *const *ascii, const uint64_t *len);
+
+/* Native FASTA reader (host only; no context needed).  Replaces pysam.FastaFile(path).fetch(name) of the reference
+ * (pavlib/cigarcall.py:59-66, pavlib/seq.py:339-351) for whole records: plain, gzip and BGZF files (PAV bgzips its
+ * FASTA files, rules/align.snakefile:32-50; BGZF blocks are inflated in parallel).  Records are contiguous ASCII byte
+ * arrays with the line breaks removed and the case kept; names are the first word of the header line, as in faidx.
+ * threads <= 0: one per host core (at most 32).  Errors: PAV_E_ARG, message via pav_last_error(NULL). */
+typedef struct pav_fasta pav_fasta;
+int pav_fasta_open(const char *path, int threads, pav_fasta **out);
+void pav_fasta_close(pav_fasta *fa);
+uint32_t pav_fasta_count(const pav_fasta *fa);
+const char *pav_fasta_name(const pav_fasta *fa, uint32_t record);
+uint64_t pav_fasta_length(const pav_fasta *fa, uint32_t record);
+const uint8_t *pav_fasta_seq(const pav_fasta *fa, uint32_t record);     /* valid until pav_fasta_close              */
+int pav_fasta_kind(const pav_fasta *fa);                                 /* 0 plain text, 1 gzip stream, 2 BGZF      */
+/* pav_seq_load + pav_seq_set_names of the chosen records, in the order given. */
+int pav_seq_load_fasta(pav_ctx *ctx, int role, const pav_fasta *fa, uint32_t n_records, const uint32_t *records);
 /* Re-run the pack kernel on the resident ASCII.  Asynchronous: it runs on a side stream and overlaps whatever the
  * next calls queue that does not read the packed planes (CIGAR tokenizer, walk, SNV emission); kernels that do read
  * them (homology, k-mer kernels) wait for it on the device.  pav_sync() waits for both streams. */
@@ -330,6 +346,15 @@ int pav_inv_table_view(pav_ctx *ctx, uint32_t region, uint32_t *n_rows, const ui
 int pav_inv_tables(pav_ctx *ctx, uint32_t n_regions, const uint64_t *row_off, int64_t *index, int8_t *state_mer,
                    int8_t *state, double *kern_fwd, double *kern_fwdrev, double *kern_rev, uint64_t *kmer, uint8_t *flank,
                    uint8_t *match);
+/* Density tables of rule call_inv_batch (rules/call_inv.snakefile:287-291: call.df.to_csv(path, sep='\t', index=False,
+ * compression='gzip')) for calls of the last scan, written from the library's host copies: the text pandas writes (float
+ * columns as repr(), NaN as empty), names ending in ".gz" as concatenated gzip members compressed in parallel.
+ * threads <= 0: up to 16 host threads; gzip_level <= 0: 6. */
+int pav_inv_write_tables(pav_ctx *ctx, uint32_t n, const uint32_t *regions, const char *const *paths, int threads,
+                         int gzip_level);
+/* repr() of a float64 as DataFrame.to_csv writes it (shortest round-trip digits, Python's positional / exponent rule);
+ * returns the length, out is NUL-terminated.  Text helper of the writers, exposed for unit tests. */
+int pav_repr_f64(double value, char *out, int out_len);
 
 /* ---- alignment tables: native reader (reader half) -------------------------- *
  * The tables of results/{asm}/align/trim-{none,tig,tigref}/aligned_tig_{hap}.bed.gz (API_ALIGN.md:31-64) as rule call_cigar

@@ -205,8 +205,18 @@ SYMBOLS = {
     'pav_inv_table': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'pav_inv_table_view': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'pav_inv_tables': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'pav_inv_write_tables': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, ctypes.c_int, ctypes.c_int]),
+    'pav_repr_f64': (ctypes.c_int, [ctypes.c_double, ctypes.c_char_p, ctypes.c_int]),
     'pav_kmer_rev_complement': (ctypes.c_uint64, [ctypes.c_uint64, ctypes.c_int]),
     'pav_kmer_canonical': (ctypes.c_uint64, [ctypes.c_uint64, ctypes.c_int]),
+    'pav_fasta_open': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, _P]),
+    'pav_fasta_close': (None, [_P]),
+    'pav_fasta_count': (ctypes.c_uint32, [_P]),
+    'pav_fasta_name': (ctypes.c_char_p, [_P, ctypes.c_uint32]),
+    'pav_fasta_length': (ctypes.c_uint64, [_P, ctypes.c_uint32]),
+    'pav_fasta_seq': (_P, [_P, ctypes.c_uint32]),
+    'pav_fasta_kind': (ctypes.c_int, [_P]),
+    'pav_seq_load_fasta': (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_uint32, _P]),
     'pav_bed_open': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, _P]),
     'pav_bed_close': (None, [_P]),
     'pav_bed_info': (ctypes.c_int, [_P, _P]),
@@ -338,6 +348,12 @@ class Context:
         self._seq_names[role] = [str(x) for x in names]
         cnames = (ctypes.c_char_p * max(n, 1))(*[x.encode() for x in self._seq_names[role]])
         self._check(self.lib.pav_seq_set_names(self.handle, role, n, cnames), 'pav_seq_set_names')
+
+    def seq_load_fasta(self, role, fasta, records):
+        """Upload records (indexes into ``fasta``, a :class:`FastaFile`) straight from the library's parse buffers."""
+        rec = np.ascontiguousarray(records, dtype=np.uint32)
+        self._check(self.lib.pav_seq_load_fasta(self.handle, role, fasta.handle, rec.shape[0], _ptr(rec)), 'pav_seq_load_fasta')
+        self._seq_names[role] = [fasta.names[int(i)] for i in rec]
 
     def seq_pack(self, role):
         self._check(self.lib.pav_seq_pack(self.handle, role), 'pav_seq_pack')
@@ -624,6 +640,13 @@ class Context:
             return [text[o[i]:o[i + 1]] for i in range(n_regions)]
         return [raw[o[i]:o[i + 1]].decode() for i in range(n_regions)]
 
+    def inv_write_tables(self, regions, paths, threads=0, gzip_level=0):
+        """Write the density tables of calls of the last scan (region numbers of that scan) to ``paths`` as TSV / TSV.gz."""
+        rg = np.ascontiguousarray(regions, dtype=np.uint32)
+        cp = (ctypes.c_char_p * max(1, rg.shape[0]))(*[str(p).encode() for p in paths])
+        self._check(self.lib.pav_inv_write_tables(self.handle, rg.shape[0], _ptr(rg), cp, int(threads), int(gzip_level)),
+                    'pav_inv_write_tables')
+
     def inv_table(self, region, n_rows):
         cols = {'INDEX': np.zeros(n_rows, dtype=np.int64), 'STATE_MER': np.zeros(n_rows, dtype=np.int8),
                 'STATE': np.zeros(n_rows, dtype=np.int8), 'KERN_FWD': np.zeros(n_rows, dtype=np.float64),
@@ -676,6 +699,47 @@ class Context:
                         'pav_prof_get')
             out[name.value.decode()] = (int(launches.value), float(ms.value))
         return out
+
+
+class FastaFile:
+    """A FASTA file parsed by the library (``pav_fasta_open``: plain, gzip or BGZF with parallel inflate).  ``seq(i)`` is a
+    zero-copy ``uint8`` view of record i in the library's memory; it stays valid while this object is alive."""
+
+    KINDS = ('plain', 'gzip', 'bgzf')
+
+    def __init__(self, path, threads=0):
+        self.lib = load()
+        h = ctypes.c_void_p(0)
+        rc = self.lib.pav_fasta_open(str(path).encode(), int(threads), ctypes.byref(h))
+        if rc != PAV_OK:
+            raise PavDeviceError('pav_fasta_open failed ({}): {}'.format(rc, (self.lib.pav_last_error(None) or b'').decode()))
+        self.handle = h
+        n = int(self.lib.pav_fasta_count(h))
+        self.names = [self.lib.pav_fasta_name(h, i).decode() for i in range(n)]
+        self.lengths = [int(self.lib.pav_fasta_length(h, i)) for i in range(n)]
+        self.kind = self.KINDS[self.lib.pav_fasta_kind(h)]
+
+    def seq(self, i):
+        n = self.lengths[i]
+        if n == 0:
+            return np.zeros(0, dtype=np.uint8)
+        buf = (ctypes.c_uint8 * n).from_address(self.lib.pav_fasta_seq(self.handle, i))
+        a = np.frombuffer(buf, dtype=np.uint8)
+        a.flags.writeable = False
+        self._keep = getattr(self, '_keep', [])
+        self._keep.append(buf)
+        return a
+
+    def close(self):
+        if self.handle:
+            self.lib.pav_fasta_close(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 class BedTable:

@@ -73,8 +73,8 @@ def load_sequences(ctx, ref_fa_name, tig_fa_name, df_align=None, names=None):
             raise KeyError(f'sequence(s) {sorted(missing)} of the alignment table are not in the FASTA files')
     else:
         ref_names, tig_names = list(ref_fa.names), list(tig_fa.names)
-    ctx.seq_load(_lib.PAV_ROLE_REF, ref_names, [ref_fa[n] for n in ref_names])
-    ctx.seq_load(_lib.PAV_ROLE_TIG, tig_names, [tig_fa[n] for n in tig_names])
+    ctx.seq_load_fasta(_lib.PAV_ROLE_REF, ref_fa.native, ref_fa.record_numbers(ref_names))   # straight from the reader's buffers
+    ctx.seq_load_fasta(_lib.PAV_ROLE_TIG, tig_fa.native, tig_fa.record_numbers(tig_names))
     return ref_names, tig_names
 
 

@@ -6,6 +6,7 @@
 // failure behaviour and every coordinate are identical to the reference; tests compare both drivers with the golden
 // vectors the reference produced.
 #include "common.h"
+#include "textio.h"
 
 #include <algorithm>
 #include <cmath>
@@ -598,6 +599,91 @@ int pav_inv_table_view(pav_ctx *ctx, uint32_t region, uint32_t *n_rows, const ui
     if (flank) *flank = t.flank;
     if (match) *match = t.match;
     return PAV_OK;
+}
+
+// Density tables of rule call_inv_batch (rules/call_inv.snakefile:287-291: call.df.to_csv(path, sep='\t', index=False,
+// compression='gzip')) written straight from the host copies of the last scan: same text as pandas, formatted on host
+// threads, ".gz" names as concatenated gzip members compressed in parallel.
+int pav_inv_write_tables(pav_ctx *ctx, uint32_t n, const uint32_t *regions, const char *const *paths, int threads, int gzip_level) {
+    if (!ctx || (n && (!regions || !paths))) return fail(ctx, PAV_E_ARG, "pav_inv_write_tables: null argument");
+    InvState *S = istate(ctx);
+    { const int rcw = wait_tables(ctx); if (rcw != PAV_OK) return rcw; }
+    if (threads <= 0) threads = (int)std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
+    const int level = gzip_level > 0 ? gzip_level : 6;
+    static const char *FLANK_TEXT[3] = {"", "UP", "DN"};
+    static const char *MATCH_TEXT[4] = {"", "SAME", "OTHER", ""};      // 3 = NaN, written as the empty na_rep
+    const std::string header = "INDEX\tSTATE_MER\tSTATE\tKERN_FWD\tKERN_FWDREV\tKERN_REV\tKMER\tFLANK\tMATCH\n";
+    // one pool over the (table, chunk of rows) pairs of all tables: calls range from 10^4 to 10^6 rows
+    const std::string gz_suffix = ".gz";
+    constexpr uint64_t CHUNK_ROWS = 1 << 15;
+    struct Task { uint32_t q; uint64_t a, b; };
+    std::vector<Task> tasks;
+    std::vector<uint32_t> first_task(n + 1, 0);
+    for (uint32_t q = 0; q < n; ++q) {
+        const uint32_t region = regions[q];
+        if (region >= S->tables.size() || !S->tables[region])
+            return fail(ctx, PAV_E_STATE, "pav_inv_write_tables: region %u has no call in the last scan", region);
+        if (!paths[q]) return fail(ctx, PAV_E_ARG, "pav_inv_write_tables: null path");
+        const uint64_t rows = S->tables[region]->n;
+        first_task[q] = (uint32_t)tasks.size();
+        for (uint64_t a = 0; a < rows || a == 0; a += CHUNK_ROWS) { tasks.push_back(Task{q, a, std::min(rows, a + CHUNK_ROWS)}); if (a + CHUNK_ROWS >= rows) break; }
+    }
+    first_task[n] = (uint32_t)tasks.size();
+    std::vector<std::string> done(tasks.size());
+    std::atomic<size_t> next{0};
+    std::atomic<bool> ok{true};
+    auto work = [&]() {
+        std::string text;
+        for (size_t k; (k = next.fetch_add(1)) < tasks.size();) {
+            const Task &tk = tasks[k];
+            const InvTable &t = *S->tables[regions[tk.q]];
+            const std::string p(paths[tk.q]);
+            const bool gz = p.size() > 3 && p.compare(p.size() - 3, 3, gz_suffix) == 0;
+            text.clear();
+            text.reserve((size_t)(tk.b - tk.a) * 110 + header.size());
+            if (tk.a == 0) text = header;
+            for (uint64_t i = tk.a; i < tk.b; ++i) {
+                put_u64(text, t.index[i]); text.push_back('\t');
+                put_i64(text, t.state_mer[i]); text.push_back('\t');
+                put_i64(text, t.state[i]); text.push_back('\t');
+                put_f64_repr(text, t.kern[0][i]); text.push_back('\t');
+                put_f64_repr(text, t.kern[1][i]); text.push_back('\t');
+                put_f64_repr(text, t.kern[2][i]); text.push_back('\t');
+                put_u64(text, t.kmer[i]); text.push_back('\t');
+                text += FLANK_TEXT[t.flank[i] < 3 ? t.flank[i] : 0]; text.push_back('\t');
+                text += MATCH_TEXT[t.match[i] & 3]; text.push_back('\n');
+            }
+            if (gz) { if (!gz_member(text, level, done[k])) ok = false; } else done[k].swap(text);
+        }
+    };
+    {
+        std::vector<std::thread> pool;
+        for (int w = 1; w < threads; ++w) pool.emplace_back(work);
+        work();
+        for (auto &th : pool) th.join();
+    }
+    if (!ok) return fail(ctx, PAV_E_ARG, "pav_inv_write_tables: zlib failed");
+    for (uint32_t q = 0; q < n; ++q) {
+        FILE *fh = fopen(paths[q], "wb");
+        if (!fh) return fail(ctx, PAV_E_ARG, "pav_inv_write_tables: cannot open %s", paths[q]);
+        for (uint32_t k = first_task[q]; k < first_task[q + 1]; ++k)
+            if (!done[k].empty() && fwrite(done[k].data(), 1, done[k].size(), fh) != done[k].size()) {
+                fclose(fh);
+                return fail(ctx, PAV_E_ARG, "pav_inv_write_tables: short write to %s", paths[q]);
+            }
+        fclose(fh);
+        for (uint32_t k = first_task[q]; k < first_task[q + 1]; ++k) std::string().swap(done[k]);
+    }
+    return PAV_OK;
+}
+
+// repr() of a float64 as DataFrame.to_csv writes it (text helper of the writers; exposed for the unit tests).
+int pav_repr_f64(double value, char *out, int out_len) {
+    std::string s;
+    put_f64_repr(s, value);
+    if (!out || out_len <= (int)s.size()) return PAV_E_ARG;
+    memcpy(out, s.c_str(), s.size() + 1);
+    return (int)s.size();
 }
 
 int pav_inv_tables(pav_ctx *ctx, uint32_t n_regions, const uint64_t *row_off, int64_t *index, int8_t *state_mer, int8_t *state,

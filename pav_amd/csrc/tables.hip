@@ -6,6 +6,7 @@
 //   device : sort keys of the SNV rows, stable radix sort (rocPRIM primitive), gather + FILTER
 //   host   : INDEL order (stable sort; ID tie-break on TYPE then on the decimal *string* of SVLEN), text, gzip (zlib)
 #include "common.h"
+#include "textio.h"
 
 #include <rocprim/rocprim.hpp>
 #include <zlib.h>
@@ -43,67 +44,6 @@ __global__ __launch_bounds__(256) void snv_gather(const pav_snv *__restrict__ sn
     o.pass = 1;
     if (trim_pos) o.pass = ((long long)s.pos > trim_pos[s.aln] && (long long)s.pos + 1 < trim_end[s.aln]) ? 1 : 0;   // call.snakefile:826-828
     out[i] = o;
-}
-
-// ---- text ---------------------------------------------------------------------------------------------------
-static inline void put_u64(std::string &s, uint64_t v) {
-    char b[24]; int n = 0;
-    do { b[n++] = (char)('0' + v % 10); v /= 10; } while (v);
-    while (n) s.push_back(b[--n]);
-}
-static inline void put_i64(std::string &s, int64_t v) { if (v < 0) { s.push_back('-'); put_u64(s, (uint64_t)(-v)); } else put_u64(s, (uint64_t)v); }
-// csv.QUOTE_MINIMAL with delimiter '\t' and quotechar '"' (what DataFrame.to_csv uses)
-static std::string csv_field(const std::string &f) {
-    if (f.find_first_of("\t\"\n\r") == std::string::npos) return f;
-    std::string q = "\"";
-    for (char c : f) { if (c == '"') q += '"'; q += c; }
-    return q + "\"";
-}
-
-static bool gz_member(const std::string &in, int level, std::string &out) {
-    z_stream zs; memset(&zs, 0, sizeof zs);
-    if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
-    out.resize(deflateBound(&zs, (uLong)in.size()) + 64);
-    zs.next_in = (Bytef *)in.data(); zs.avail_in = (uInt)in.size();
-    zs.next_out = (Bytef *)&out[0]; zs.avail_out = (uInt)out.size();
-    const int rc = deflate(&zs, Z_FINISH);
-    out.resize(zs.total_out);
-    deflateEnd(&zs);
-    return rc == Z_STREAM_END;
-}
-
-// Format `n_rows` rows in chunks on `threads` workers, compress each chunk as one gzip member when the name ends in
-// ".gz", and write the chunks in order.
-template <class RowFn>
-static int write_table(pav_ctx *ctx, const char *path, const std::string &header, uint64_t n_rows, int threads, int level, RowFn row) {
-    const std::string p(path);
-    const bool gz = p.size() > 3 && p.compare(p.size() - 3, 3, ".gz") == 0;
-    const uint64_t chunk_rows = 1 << 16;
-    const uint64_t n_chunks = std::max<uint64_t>(1, (n_rows + chunk_rows - 1) / chunk_rows);
-    std::vector<std::string> done(n_chunks);
-    std::atomic<uint64_t> next{0};
-    std::atomic<bool> ok{true};
-    auto work = [&]() {
-        std::string text;
-        for (uint64_t c; (c = next.fetch_add(1)) < n_chunks;) {
-            text.clear();
-            if (c == 0) text = header;
-            const uint64_t a = c * chunk_rows, b = std::min(n_rows, a + chunk_rows);
-            text.reserve((size_t)(b - a) * 160 + header.size());
-            for (uint64_t i = a; i < b; ++i) row(i, text);
-            if (gz) { if (!gz_member(text, level, done[c])) ok = false; } else done[c].swap(text);
-        }
-    };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < threads; ++t) pool.emplace_back(work);
-    work();
-    for (auto &t : pool) t.join();
-    if (!ok) return fail(ctx, PAV_E_ARG, "pav_cigar_write_tables: zlib failed for %s", path);
-    FILE *fh = fopen(path, "wb");
-    if (!fh) return fail(ctx, PAV_E_ARG, "pav_cigar_write_tables: cannot open %s", path);
-    for (const std::string &s : done) if (!s.empty() && fwrite(s.data(), 1, s.size(), fh) != s.size()) { fclose(fh); return fail(ctx, PAV_E_ARG, "pav_cigar_write_tables: short write to %s", path); }
-    fclose(fh);
-    return PAV_OK;
 }
 
 const std::vector<std::string> &seq_names(pav_ctx *ctx, int role);   // invscan.hip

@@ -1,16 +1,18 @@
 """
-Minimal FASTA access for the host side of the hot path.
+FASTA access for the host side of the hot path.
 
 Replaces the two ``pysam.FastaFile(...).fetch(...)`` uses on the path (pavlib/cigarcall.py:59-66,
 pavlib/seq.py:339-351) without pysam: whole records are held as ``numpy.uint8`` ASCII arrays exactly as they
-appear in the file (case preserved), because the device library takes plain byte pointers.
-Plain and gzip/bgzip FASTA are both accepted.
+appear in the file (case preserved), because the device library takes plain byte pointers.  The file is read by the
+library's native reader (``pav_fasta_open``, csrc/fastaio.hip): plain, gzip and BGZF (blocks inflated in parallel);
+the arrays are zero-copy views of its buffers.
 """
 
-import gzip
 import os
 
 import numpy as np
+
+from . import _lib
 
 _CACHE = {}
 
@@ -22,31 +24,21 @@ class Fasta:
         self.path = str(path)
         self.names = []
         self.seqs = {}
+        self._record = {}                              # name -> record number in the native reader
         self._load()
 
+    def record_numbers(self, names):
+        """Record numbers of ``names`` for ``Context.seq_load_fasta``."""
+        return [self._record[str(n)] for n in names]
+
     def _load(self):
-        opener = gzip.open if self.path.endswith('.gz') else open
-        with opener(self.path, 'rb') as fh:
-            data = np.frombuffer(fh.read(), dtype=np.uint8)
-        if data.size == 0:
-            return
-        # record starts: '>' at offset 0 or right after a newline
-        gt = np.flatnonzero(data == ord('>'))
-        gt = gt[(gt == 0) | (data[np.maximum(gt, 1) - 1] == ord('\n'))]
-        nl = np.flatnonzero(data == ord('\n'))
-        for i, s in enumerate(gt):
-            e = gt[i + 1] if i + 1 < gt.size else data.size
-            k = np.searchsorted(nl, s)
-            hdr_end = nl[k] if k < nl.size and nl[k] < e else e
-            name = data[s + 1:hdr_end].tobytes().decode().split()[0] if hdr_end > s + 1 else ''
-            body = data[min(hdr_end + 1, e):e]
-            n_nl = int(np.count_nonzero(body == ord('\n'))) if body.size else 0
-            if n_nl == 1 and body[-1] == ord('\n') and not np.any(body == ord('\r')):
-                body = body[:-1]
-            elif n_nl > 0 or (body.size and np.any(body == ord('\r'))):
-                body = body[(body != ord('\n')) & (body != ord('\r'))]
+        self.native = _lib.FastaFile(self.path)
+        self.kind = self.native.kind
+        for i, name in enumerate(self.native.names):
             self.names.append(name)
-            self.seqs[name] = np.ascontiguousarray(body)
+            if name not in self.seqs:                  # a repeated name keeps its first record (dict of faidx names)
+                self.seqs[name] = self.native.seq(i)
+                self._record[name] = i
 
     def __contains__(self, name):
         return str(name) in self.seqs

@@ -51,6 +51,7 @@ class InvCall:
         self.region_tig_discovery = region_tig_discovery
         self.region_flag = region_flag
         self._df = df                       # DataFrame, or a zero-argument builder evaluated on first access
+        self.native_table = None            # (context, region number, scan generation) when the native driver made the call
         self.svlen = len(region_ref_outer)
         self.id = '{}-{}-INV-{}'.format(region_ref_outer.chrom, region_ref_outer.pos + 1, self.svlen)
 
@@ -366,8 +367,8 @@ def ensure_sequences(ctx, ref_fa_name, tig_fa_name):
     key = (str(ref_fa_name), str(tig_fa_name))
     if getattr(ctx, '_inv_loaded', None) != key:
         ref_fa, tig_fa = open_fasta(ref_fa_name), open_fasta(tig_fa_name)
-        ctx.seq_load(_lib.PAV_ROLE_REF, ref_fa.names, [ref_fa[n] for n in ref_fa.names])
-        ctx.seq_load(_lib.PAV_ROLE_TIG, tig_fa.names, [tig_fa[n] for n in tig_fa.names])
+        ctx.seq_load_fasta(_lib.PAV_ROLE_REF, ref_fa.native, ref_fa.record_numbers(ref_fa.names))
+        ctx.seq_load_fasta(_lib.PAV_ROLE_TIG, tig_fa.native, tig_fa.record_numbers(tig_fa.names))
         ctx._inv_loaded = key
 
 
@@ -532,6 +533,7 @@ def _native_scan(ctx, region_flags, align_lift, k_util, max_region_size, logs, s
                     return density.table_frame(cols, finalised=True, extra=_flank_match_text(flank.copy(), match.copy()))
             out[i] = InvCall(r_ref_outer[q], r_ref_inner[q], r_tig_outer[q], r_tig_inner[q], r_ref_disc[q], r_tig_disc[q],
                              region_flags[i], df)
+            out[i].native_table = (ctx, i, generation)   # the library's host copy: Context.inv_write_tables writes it as text
     if found_lines:
         print('\n'.join(found_lines))                                   # inv.py:408, one line per region in region order
     _lap('results')

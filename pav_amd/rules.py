@@ -185,30 +185,36 @@ def call_inv_batch(bed_flag, bed_aln, tig_fa, fai, ref_fa, hap, batch, bed_out=N
             results = pavinv.scan_for_inv_batch(regions, ref_fa, tig_fa, align_lift, k_util, max_region_size=inv_region_limit,
                                                 logs=logs, srs_tree=srs_tree, min_exp_count=inv_min_expand, ctx=ctx,
                                                 eager_tables=False)   # tables are consumed below, before any other scan
+            id_set = set()
+            call_list = []
+            native_tables = []                                                        # (region number, path): one library call
+            log_file = open(log_path, 'w') if log_path is not None else None
+            try:
+                for (_, row), res, lg in zip(df_flag.iterrows(), results, logs):
+                    if log_file is not None:
+                        log_file.write(lg.getvalue())
+                    if isinstance(res, RuntimeError):                                 # :198-200
+                        if log_file is not None:
+                            log_file.write('RuntimeError in scan_for_inv(): {}\n'.format(res))
+                        res = None
+                    if res is not None and res.id not in id_set:                      # :203
+                        call_list.append(inv_bed_row(res, hap, row['TYPE'], tig_fa))
+                        id_set.add(res.id)
+                        if density_out_dir is not None:                               # :287-291
+                            path = os.path.join(density_out_dir, 'density_{}_{}.tsv.gz'.format(res.id, hap))
+                            nt = res.native_table
+                            if nt is not None and nt[0] is ctx and nt[2] == ctx._inv_generation and callable(res._df):
+                                native_tables.append((nt[1], path))                   # text from the library's host copy
+                            else:
+                                res.df.to_csv(path, sep='\t', index=False, compression='gzip')
+                if native_tables:
+                    ctx.inv_write_tables([r for r, _ in native_tables], [p for _, p in native_tables])
+            finally:
+                if log_file is not None:
+                    log_file.close()
         finally:
             if own:
                 ctx.close()
-        id_set = set()
-        call_list = []
-        log_file = open(log_path, 'w') if log_path is not None else None
-        try:
-            for (_, row), res, lg in zip(df_flag.iterrows(), results, logs):
-                if log_file is not None:
-                    log_file.write(lg.getvalue())
-                if isinstance(res, RuntimeError):                                     # :198-200
-                    if log_file is not None:
-                        log_file.write('RuntimeError in scan_for_inv(): {}\n'.format(res))
-                    res = None
-                if res is not None and res.id not in id_set:                          # :203
-                    call_list.append(inv_bed_row(res, hap, row['TYPE'], tig_fa))
-                    id_set.add(res.id)
-                    if density_out_dir is not None:                                   # :287-291
-                        res.df.to_csv(os.path.join(density_out_dir, 'density_{}_{}.tsv.gz'.format(res.id, hap)),
-                                      sep='\t', index=False, compression='gzip')
-                    gc.collect()
-        finally:
-            if log_file is not None:
-                log_file.close()
         if len(call_list) > 0:
             df_bed = pd.concat(call_list, axis=1).T.sort_values(['#CHROM', 'POS', 'END', 'ID'])   # :297
         else:

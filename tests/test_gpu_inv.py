@@ -316,6 +316,33 @@ def test_rule_outputs_equal_the_reference_rule(built, gpu_ctx, tmp_path):
             assert np.allclose([float(fa[i]) for i in (3, 4, 5)], [float(fb[i]) for i in (3, 4, 5)], rtol=RTOL, atol=1e-300)
 
 
+def test_native_density_tables_equal_pandas_text(built, gpu_ctx, tmp_path):
+    """pav_inv_write_tables (what rule call_inv_batch's density_*.tsv.gz files are written with) against
+    call.df.to_csv(sep='\\t', index=False) of the same calls: identical text, plain and gzip, one and many threads."""
+    import gzip
+    d, lift, scans = load_case(gpu_ctx, 'inv_hap')
+    regions = [pavseq.Region(r['flag']['chrom'], r['flag']['pos'], r['flag']['end']) for r in scans]
+    out = pavinv.scan_for_inv_batch(regions, os.path.join(d, 'ref.fa'), os.path.join(d, 'tig.fa'), lift, KmerUtil(31), ctx=gpu_ctx,
+                                    eager_tables=False)
+    calls = [(i, c) for i, c in enumerate(out) if c is not None and not isinstance(c, RuntimeError)]
+    assert len(calls) >= 3 and all(c.native_table[1] == i for i, c in calls)
+    plain = [str(tmp_path / f'{c.id}.tsv') for _, c in calls]
+    gz = [str(tmp_path / f'{c.id}.tsv.gz') for _, c in calls]
+    gpu_ctx.inv_write_tables([i for i, _ in calls], plain, threads=1)
+    gpu_ctx.inv_write_tables([i for i, _ in calls], gz, threads=5, gzip_level=1)
+    for (i, c), p, g in zip(calls, plain, gz):
+        want = c.df.to_csv(sep='\t', index=False)
+        with open(p) as fh:
+            assert fh.read() == want, c.id
+        with gzip.open(g, 'rt') as fh:
+            assert fh.read() == want, c.id
+    flank = pd.concat([c.df['FLANK'] for _, c in calls])
+    match = pd.concat([c.df['MATCH'] for _, c in calls])
+    assert {'', 'UP', 'DN'} <= set(flank) and (match == 'OTHER').any() and match.isna().any()     # every text form occurs
+    with pytest.raises(_lib.PavDeviceError, match='no call'):
+        gpu_ctx.inv_write_tables([next(i for i, c in enumerate(out) if c is None)], [str(tmp_path / 'none.tsv')])
+
+
 def test_rule_call_inv_batch_files(built, gpu_ctx, tmp_path):
     """File contract of rule call_inv_batch: INV BED rows equal the reference rows; density tables are written."""
     d, lift, scans = load_case(gpu_ctx, 'inv_fwd')

@@ -148,3 +148,30 @@ def test_native_reader_errors(built, tmp_path):
         _lib.BedTable(str(p))
     with pytest.raises(_lib.PavDeviceError, match='cannot open'):
         _lib.BedTable(str(tmp_path / 'missing.tsv.gz'))
+
+
+def test_float_text_of_the_table_writers_equals_pandas(built):
+    """pav_repr_f64 (float columns of pav_inv_write_tables) against DataFrame.to_csv and repr(): magnitudes from denormal to
+    1e308, exact powers of ten around the positional / exponent switch, negative zero, NaN (empty na_rep), infinities."""
+    import ctypes
+    import io
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(64)
+    rng = np.random.default_rng(9)
+    vals = np.concatenate([
+        [0.0, -0.0, 1.0, -1.5, 1e15, 1e16, 1e17, 1e-4, 1e-5, 9.999999999999999e-05, 5e-324, 1.7976931348623157e308,
+         2.2250738585072014e-308, 0.1, 1 / 3, 1e22, 1e23, 9007199254740993.0, 99999999999999.98, np.nan, np.inf, -np.inf],
+        rng.random(20000), rng.random(20000) * 1e-7, np.exp(rng.uniform(-700, 700, 20000)),
+        rng.integers(0, 2 ** 63, 20000, dtype=np.uint64).view(np.float64)])
+    want = pd.DataFrame({'x': vals}).to_csv(io.StringIO(), sep='\t', index=False, header=False)
+    text = io.StringIO()
+    pd.DataFrame({'x': vals}).to_csv(text, sep='\t', index=False, header=False)
+    want = text.getvalue().split('\n')[:-1]
+    got = []
+    for v in vals:
+        n = lib.pav_repr_f64(float(v), buf, 64)
+        assert n >= 0
+        got.append(buf.value.decode())
+    bad = [(float(v), g, w) for v, g, w in zip(vals, got, want) if g != w and not (w == '""' and g == '')]
+    assert not bad, bad[:5]
+    assert got[0] == '0.0' and got[1] == '-0.0' and got[5] == '1e+16' and got[4] == '1000000000000000.0' and got[8] == '1e-05'
