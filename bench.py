@@ -362,7 +362,11 @@ def main():
                            'traffic': traffic, 'avg_kernel_ms': round(kern_[dom]['avg_ms'], 4),
                            'launches_per_step': round(kern_[dom]['launches'] / args.steps, 2),
                            'algorithmic_bytes_per_launch': a_bytes,
-                           'kernels_ms': {k: round(v['avg_ms'], 4) for k, v in sorted(kern_.items())}}
+                           'kernels_ms': {k: round(v['avg_ms'], 4) for k, v in sorted(kern_.items())},
+                           # every kernel with a byte model: achieved GB/s of algorithmic bytes; the
+                           # latency-bound ones (scattered line fetches, dependent launches) sit far below the HBM roof by nature
+                           'modelled_kernels_gbs': {k: round(alg_bytes[k] / (kern_[k]['avg_ms'] * 1e-3) / 1e9, 1)
+                                                    for k in sorted(alg_bytes) if k in kern_ and kern_[k]['avg_ms'] > 0}}
 
         kern, roofline = make_roofline(prof)
         cigar_only = None

@@ -3,6 +3,8 @@
 
   python tools/prof_summary.py stats <db> <out.txt>            per-kernel calls / total / avg / min / max (us)
   python tools/prof_summary.py pmc   <db> <out.txt>            per-kernel average counter value per launch
+  python tools/prof_summary.py pmcjson <fetch.db> <write.db> <bench.json> <out.json>   per-kernel FETCH_SIZE / WRITE_SIZE averages
+                                                               (KiB per dispatch) keyed to the workload of the bench line
   python tools/prof_summary.py timeline <db> <out.txt> [ms]    kernels (and copies) of the last [ms] of the trace in start order,
                                                                with the idle gap in front of each (us)
 """
@@ -57,6 +59,31 @@ def pmc(db, out):
     print(open(out).read())
 
 
+def pmcjson(fetch_db, write_db, bench_json, out):
+    import json
+
+    def per_kernel(db, counter):
+        cur = sqlite3.connect(db).cursor()
+        acc = {}
+        for n, v in cur.execute('select kernel_name, value from counters_collection where counter_name = ?', (counter,)):
+            a = acc.setdefault(short(n), [0.0, 0])
+            a[0] += v
+            a[1] += 1
+        return {k: round(t / c, 1) for k, (t, c) in sorted(acc.items(), key=lambda kv: -kv[1][0] / kv[1][1])}
+    with open(bench_json) as fh:
+        line = json.loads(fh.read().strip().splitlines()[-1])
+    doc = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) around bench.py, MI355X; values are KiB per '
+                     'dispatch, averaged over the dispatches of a kernel (tools/prof_summary.py pmcjson)',
+           'workload': {'seed': line['config']['seed'], 'scale': line['config']['scale'],
+                        'aligned_bp_per_gpu': line['config']['aligned_bp_per_gpu'], 'name': line['config']['workload']},
+           'gfx950_note': 'FETCH_SIZE counts 128 B requests as 64 B for 16 B/lane streaming reads: x2 for pack_kernel (calibrated '
+                          'against the 3.08 GB ASCII arena); other kernels are reported raw',
+           'fetch_kib': per_kernel(fetch_db, 'FETCH_SIZE'), 'write_kib': per_kernel(write_db, 'WRITE_SIZE')}
+    with open(out, 'w') as fh:
+        json.dump(doc, fh, indent=1)
+    print(open(out).read())
+
+
 def timeline(db, out, last_ms=30.0):
     cur = sqlite3.connect(db).cursor()
     ev = [(s, e, short(n)) for n, s, e in cur.execute('select name, start, end from kernels')]
@@ -78,7 +105,9 @@ def timeline(db, out, last_ms=30.0):
 
 
 if __name__ == '__main__':
-    if sys.argv[1] == 'timeline':
+    if sys.argv[1] == 'pmcjson':
+        pmcjson(*sys.argv[2:6])
+    elif sys.argv[1] == 'timeline':
         timeline(sys.argv[2], sys.argv[3], float(sys.argv[4]) if len(sys.argv) > 4 else 30.0)
     else:
         {'stats': stats, 'pmc': pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])

@@ -1,13 +1,27 @@
+# Round profile on the GPU box:  gpurun -- 'bash tools/scripts/profile_round.sh r01'
+# Kernel stats (rocprofv3 --kernel-trace --stats) of both workloads, PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, no
+# tracing domains next to --pmc) and the plain bench lines; summaries land in profiles/<round>_* through tools/prof_summary.py.
 set -x
+ROUND=${1:-r01}
 R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/$ROUND
+mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_cigar -o cigar -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/prof_cigar_bench.json 2> $R/gpurun_out/prof_cigar.err
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_inv -o inv -- python3 $R/bench.py --workload cigar+inv --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_inv_bench.json 2> $R/gpurun_out/prof_inv.err
-rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch -o f -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2> $R/gpurun_out/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write -o w -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2> $R/gpurun_out/pmc_write.err
+rocprofv3 --kernel-trace --stats -d $O/prof_full -o full -- python3 $R/bench.py --no-cpu-baseline > $O/full_bench_under_rocprof.json 2> $O/prof_full.err
+rocprofv3 --kernel-trace --stats -d $O/prof_cigar -o cigar -- python3 $R/bench.py --workload cigar --no-cpu-baseline > $O/cigar_bench_under_rocprof.json 2> $O/prof_cigar.err
+rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o f -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $O/pmc_bench.json 2> $O/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o w -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2> $O/pmc_write.err
 cd $R
-python3 bench.py > gpurun_out/bench_cigar.json 2> gpurun_out/bench_cigar.err
-python3 bench.py --workload cigar+inv > gpurun_out/bench_inv.json 2> gpurun_out/bench_inv.err
-find gpurun_out -name "*.db" | head; ls -la gpurun_out/prof_cigar gpurun_out/prof_inv | head -30
-for d in prof_cigar prof_inv pmc_fetch pmc_write; do find gpurun_out/$d -name "*.db" -size +60M -delete; done
-du -sh gpurun_out
+P=$O/profiles
+mkdir -p $P
+python3 tools/prof_summary.py stats $(ls $O/prof_full/*.db | head -1) $P/${ROUND}_full_path_kernel_stats.txt > /dev/null
+python3 tools/prof_summary.py stats $(ls $O/prof_cigar/*.db | head -1) $P/${ROUND}_cigar_only_kernel_stats.txt > /dev/null
+python3 tools/prof_summary.py pmc $(ls $O/pmc_fetch/*.db | head -1) $P/${ROUND}_full_path_pmc_fetch.txt > /dev/null
+python3 tools/prof_summary.py pmc $(ls $O/pmc_write/*.db | head -1) $P/${ROUND}_full_path_pmc_write.txt > /dev/null
+python3 tools/prof_summary.py pmcjson $(ls $O/pmc_fetch/*.db | head -1) $(ls $O/pmc_write/*.db | head -1) $O/pmc_bench.json $P/${ROUND}_pmc.json > /dev/null
+cp $O/full_bench_under_rocprof.json $P/${ROUND}_full_path_bench_under_rocprof.json
+cp $O/cigar_bench_under_rocprof.json $P/${ROUND}_cigar_only_bench_under_rocprof.json
+python3 bench.py > $P/${ROUND}_full_path_bench.json 2> $O/bench_full.err
+python3 bench.py --workload cigar > $P/${ROUND}_cigar_only_bench.json 2> $O/bench_cigar.err
+find $O -name "*.db" -delete
+ls -la $P; du -sh $O
