@@ -67,8 +67,10 @@ struct pav_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;        // side stream: contig re-pack overlaps the tokenizer / walk kernels
     hipStream_t stream3 = nullptr;        // copy stream: call tables of the inversion scan travel to the host behind the scan
-    hipEvent_t tables_done = nullptr;     // recorded on stream3 after the last queued table copy
+    hipEvent_t tables_done = nullptr;     // recorded on stream3 after the last queued table copy of the current scan
     bool tables_pending = false;
+    hipEvent_t tables_done_prev = nullptr;   // same for the scan before it: its tables live in the other pinned arena, so a new
+    bool tables_pending_prev = false;        // scan does not wait for them (the two are swapped when a scan starts)
     hipEvent_t pack_done[2] = {nullptr, nullptr};   // recorded after a pack on stream2; consumers of the planes wait on it
     bool pack_pending[2] = {false, false};
     std::string err;

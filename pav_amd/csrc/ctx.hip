@@ -178,6 +178,7 @@ pav_ctx *pav_create(int device_id) {
         (e = hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_lo)) != hipSuccess ||
         (e = hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, prio_lo)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->tables_done, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->tables_done_prev, hipEventDisableTiming)) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_status), 256, hipHostMallocDefault)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->pack_done[0], hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->pack_done[1], hipEventDisableTiming)) != hipSuccess) {
@@ -218,6 +219,7 @@ void pav_destroy(pav_ctx *ctx) {
     (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream3);
     (void)hipEventDestroy(ctx->tables_done);
+    (void)hipEventDestroy(ctx->tables_done_prev);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     (void)hipEventDestroy(ctx->pack_done[0]);
     (void)hipEventDestroy(ctx->pack_done[1]);
@@ -237,6 +239,7 @@ int pav_sync(pav_ctx *ctx) {
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream3));
     ctx->tables_pending = false;
+    ctx->tables_pending_prev = false;
     return PAV_OK;
 }
 

@@ -10,6 +10,8 @@
 // The merges of the resulting few thousand intervals are sequential by definition and run on the host, quirks included.
 #include "common.h"
 
+#include <chrono>
+
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
@@ -28,6 +30,8 @@ struct MatchHit { uint64_t key; int64_t end; };                                 
 
 struct FlagState {
     DevBuf a, b, c, d, tmp, hits, cnt, small, start;
+    DevBuf split[2][4];                                       // pav_cigar_flag: DEL keys / ENDs, INS keys / lengths of the two vartypes
+    DevBuf hits_b[4];                                         // pav_cigar_flag: hits of the four branches (snv / indel sweep, two matches)
     std::vector<pav_flag_rgn> table[4];                       // insdel_sv, insdel_indel, cluster_indel, cluster_snv
     std::vector<pav_flag_rgn> single;                         // result of the array-level entry points
     std::vector<pav_flag_locus> loci;
@@ -267,23 +271,20 @@ int sort_keys(pav_ctx *ctx, FlagState *S, unsigned long long *in, unsigned long 
     return PAV_OK;
 }
 
-// Sweep over n device-resident cluster keys; result rows in sweep order.
-int run_sweep(pav_ctx *ctx, FlagState *S, const unsigned long long *d_cm, uint64_t n, int64_t win, int64_t win_min, int64_t min_count,
-              std::vector<pav_flag_rgn> &out) {
-    out.clear();
+// Sweep over n device-resident cluster keys, queued on the stream: qualifying clusters are appended to d_hits (capacity
+// sweep_cap), their number to *d_n_hits (zeroed by the caller).
+uint64_t sweep_cap(uint64_t n, int64_t min_count) { return n / (uint64_t)std::max<int64_t>(min_count, 1) + 1; }
+
+int sweep_launch(pav_ctx *ctx, FlagState *S, const unsigned long long *d_cm, uint64_t n, int64_t win, int64_t win_min, int64_t min_count,
+                 ClusterHit *d_hits, unsigned long long *d_n_hits) {
     if (!n) return PAV_OK;
-    const uint64_t cap = n / (uint64_t)std::max<int64_t>(min_count, 1) + 1;
-    PAV_HIP(ctx, S->hits.reserve(sizeof(ClusterHit) * cap));
-    PAV_HIP(ctx, S->cnt.reserve(64));
-    PAV_HIP(ctx, hipMemsetAsync(S->cnt.p, 0, 64, ctx->stream));
+    PAV_HIP(ctx, S->start.reserve(8 * n));
+    auto opens = rocprim::make_transform_iterator(rocprim::counting_iterator<unsigned long long>(0), OpenRow{(const uint64_t *)d_cm, win});
+    size_t bytes = 0;
+    PAV_HIP(ctx, rocprim::inclusive_scan(nullptr, bytes, opens, S->start.as<unsigned long long>(), (size_t)n,
+                                         rocprim::maximum<unsigned long long>(), ctx->stream));
+    PAV_HIP(ctx, S->tmp.reserve(bytes + 16));
     {
-        PAV_HIP(ctx, S->start.reserve(8 * n));
-        auto opens = rocprim::make_transform_iterator(rocprim::counting_iterator<unsigned long long>(0),
-                                                      OpenRow{(const uint64_t *)d_cm, win});
-        size_t bytes = 0;
-        PAV_HIP(ctx, rocprim::inclusive_scan(nullptr, bytes, opens, S->start.as<unsigned long long>(), (size_t)n,
-                                             rocprim::maximum<unsigned long long>(), ctx->stream));
-        PAV_HIP(ctx, S->tmp.reserve(bytes + 16));
         const int tok = prof_begin(ctx, "rocprim::inclusive_scan");
         const hipError_t e = rocprim::inclusive_scan(S->tmp.p, bytes, opens, S->start.as<unsigned long long>(), (size_t)n,
                                                      rocprim::maximum<unsigned long long>(), ctx->stream);
@@ -291,28 +292,47 @@ int run_sweep(pav_ctx *ctx, FlagState *S, const unsigned long long *d_cm, uint64
         PAV_HIP(ctx, e);
     }
     PAV_LAUNCH(ctx, "k_cluster_emit", k_cluster_emit, (uint32_t)((n + 255) / 256), 256, 0, (const uint64_t *)d_cm,
-               S->start.as<unsigned long long>(), n, win, win_min, min_count, S->hits.as<ClusterHit>(), S->cnt.as<unsigned long long>(), cap);
+               S->start.as<unsigned long long>(), n, win, win_min, min_count, d_hits, d_n_hits, sweep_cap(n, min_count));
+    return PAV_OK;
+}
+
+// Hits copied off the device -> result rows in sweep order.
+void sweep_collect(std::vector<ClusterHit> &hits, std::vector<pav_flag_rgn> &out) {
+    std::sort(hits.begin(), hits.end(), [](const ClusterHit &x, const ClusterHit &y) { return x.start < y.start; });
+    out.clear();
+    out.reserve(hits.size());
+    for (const ClusterHit &h : hits) out.push_back(pav_flag_rgn{h.chrom, 0, h.pos, h.end, h.count});
+}
+
+int run_sweep(pav_ctx *ctx, FlagState *S, const unsigned long long *d_cm, uint64_t n, int64_t win, int64_t win_min, int64_t min_count,
+              std::vector<pav_flag_rgn> &out) {
+    out.clear();
+    if (!n) return PAV_OK;
+    const uint64_t cap = sweep_cap(n, min_count);
+    PAV_HIP(ctx, S->hits.reserve(sizeof(ClusterHit) * cap));
+    PAV_HIP(ctx, S->cnt.reserve(64));
+    PAV_HIP(ctx, hipMemsetAsync(S->cnt.p, 0, 64, ctx->stream));
+    const int rc = sweep_launch(ctx, S, d_cm, n, win, win_min, min_count, S->hits.as<ClusterHit>(), S->cnt.as<unsigned long long>());
+    if (rc != PAV_OK) return rc;
     unsigned long long n_hits = 0;
     PAV_HIP(ctx, hipMemcpyAsync(&n_hits, S->cnt.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (n_hits > cap) return fail(ctx, PAV_E_LIMIT, "flag: cluster output overflow (%llu > %llu)", n_hits, (unsigned long long)cap);
     std::vector<ClusterHit> hits(n_hits);
     if (n_hits) PAV_HIP(ctx, hipMemcpy(hits.data(), S->hits.p, sizeof(ClusterHit) * n_hits, hipMemcpyDeviceToHost));
-    std::sort(hits.begin(), hits.end(), [](const ClusterHit &x, const ClusterHit &y) { return x.start < y.start; });
-    out.reserve(n_hits);
-    for (const ClusterHit &h : hits) out.push_back(pav_flag_rgn{h.chrom, 0, h.pos, h.end, h.count});
+    sweep_collect(hits, out);
     return PAV_OK;
 }
 
-// DELs (unsorted keys / rank-tagged ENDs in S->a / S->b) against INS (S->c keys, S->d lengths); result merged on the host.
-int run_match(pav_ctx *ctx, FlagState *S, uint64_t n_del, uint64_t n_ins, int64_t flank_cluster, int64_t flank_merge,
-              std::vector<pav_flag_rgn> &out) {
-    out.clear();
+// DELs (unsorted keys / rank-tagged ENDs in k_in / v_in, buffers sized 2 x n_del) against INS (keys, lengths), queued on the
+// stream: hits are appended to d_hits (capacity n_ins), their number to *d_n_hits (zeroed by the caller).
+int match_launch(pav_ctx *ctx, FlagState *S, unsigned long long *k_in, unsigned long long *v_in, const unsigned long long *ins_key,
+                 const unsigned long long *ins_len, uint64_t n_del, uint64_t n_ins, int64_t flank_cluster, MatchHit *d_hits,
+                 unsigned long long *d_n_hits) {
     if (!n_del || !n_ins) return PAV_OK;
     hipStream_t st = ctx->stream;
     // sort DELs by (chrom, POS), carrying END; then the running maximum of rank << 32 | END
-    unsigned long long *k_in = S->a.as<unsigned long long>(), *v_in = S->b.as<unsigned long long>();
-    unsigned long long *k_out = k_in + n_del, *v_out = v_in + n_del;          // the buffers were sized 2 x n
+    unsigned long long *k_out = k_in + n_del, *v_out = v_in + n_del;
     size_t bytes = 0, bytes2 = 0;
     PAV_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, k_in, k_out, v_in, v_out, (size_t)n_del, 0, 48, st));
     PAV_HIP(ctx, rocprim::inclusive_scan(nullptr, bytes2, v_out, v_in, (size_t)n_del, rocprim::maximum<unsigned long long>(), st));
@@ -329,12 +349,24 @@ int run_match(pav_ctx *ctx, FlagState *S, uint64_t n_del, uint64_t n_ins, int64_
         prof_end(ctx, tok);
         PAV_HIP(ctx, e);
     }
+    PAV_LAUNCH(ctx, "k_ins_match", k_ins_match, (uint32_t)((n_ins + 255) / 256), 256, 0, ins_key, ins_len, n_ins, k_out, v_in, n_del,
+               (long long)flank_cluster, d_hits, d_n_hits);
+    return PAV_OK;
+}
+
+// DELs (S->a / S->b) against INS (S->c keys, S->d lengths); result merged on the host.
+int run_match(pav_ctx *ctx, FlagState *S, uint64_t n_del, uint64_t n_ins, int64_t flank_cluster, int64_t flank_merge,
+              std::vector<pav_flag_rgn> &out) {
+    out.clear();
+    if (!n_del || !n_ins) return PAV_OK;
+    hipStream_t st = ctx->stream;
     PAV_HIP(ctx, S->hits.reserve(sizeof(MatchHit) * n_ins));
     PAV_HIP(ctx, S->cnt.reserve(64));
     PAV_HIP(ctx, hipMemsetAsync(S->cnt.p, 0, 64, st));
-    PAV_LAUNCH(ctx, "k_ins_match", k_ins_match, (uint32_t)((n_ins + 255) / 256), 256, 0, S->c.as<unsigned long long>(),
-               S->d.as<unsigned long long>(), n_ins, k_out, v_in, n_del, (long long)flank_cluster, S->hits.as<MatchHit>(),
-               S->cnt.as<unsigned long long>());
+    const int rc = match_launch(ctx, S, S->a.as<unsigned long long>(), S->b.as<unsigned long long>(), S->c.as<unsigned long long>(),
+                                S->d.as<unsigned long long>(), n_del, n_ins, flank_cluster, S->hits.as<MatchHit>(),
+                                S->cnt.as<unsigned long long>());
+    if (rc != PAV_OK) return rc;
     unsigned long long n_hits = 0;
     PAV_HIP(ctx, hipMemcpyAsync(&n_hits, S->cnt.p, 8, hipMemcpyDeviceToHost, st));
     PAV_HIP(ctx, hipStreamSynchronize(st));
@@ -354,7 +386,9 @@ extern "C" {
 void pav_flag_release(pav_ctx *ctx) {
     if (!ctx || !ctx->flag) return;
     FlagState *S = static_cast<FlagState *>(ctx->flag);
-    DevBuf *bufs[] = {&S->a, &S->b, &S->c, &S->d, &S->tmp, &S->hits, &S->cnt, &S->small, &S->start};
+    DevBuf *bufs[] = {&S->a, &S->b, &S->c, &S->d, &S->tmp, &S->hits, &S->cnt, &S->small, &S->start,
+                      &S->split[0][0], &S->split[0][1], &S->split[0][2], &S->split[0][3], &S->split[1][0], &S->split[1][1],
+                      &S->split[1][2], &S->split[1][3], &S->hits_b[0], &S->hits_b[1], &S->hits_b[2], &S->hits_b[3]};
     for (DevBuf *b : bufs) b->release();
     delete S;
     ctx->flag = nullptr;
@@ -450,6 +484,10 @@ int pav_flag_merge_loci(pav_ctx *ctx, const pav_flag_rgn *const tables[4], const
 
 int pav_cigar_flag(pav_ctx *ctx, const int64_t *trim_pos, const int64_t *trim_end, const pav_flag_params *P, pav_flag_result *res) {
     if (!ctx || !P || !res) return PAV_E_ARG;
+    const bool timing = getenv("PAV_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_mark = now();
+    auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[pav timing]   flag %-14s %.2f ms\n", what, (t - t_mark) * 1e3); t_mark = t; } };
     if (ctx->n_aln && (!trim_pos || !trim_end)) return PAV_E_ARG;
     if (!ctx->cigar_called) return fail(ctx, PAV_E_STATE, "pav_cigar_flag: no pav_cigar_call results on this context");
     if (P->batch_count <= 0 || P->sig_filter < PAV_SIG_SVINDEL || P->sig_filter > PAV_SIG_NONE) return fail(ctx, PAV_E_ARG, "pav_cigar_flag: bad parameters");
@@ -474,11 +512,11 @@ int pav_cigar_flag(pav_ctx *ctx, const int64_t *trim_pos, const int64_t *trim_en
         rank[by_name[i]] = (uint16_t)(i && rnames[by_name[i]] == rnames[by_name[i - 1]] ? rank[by_name[i - 1]] : i);
 
     // small inputs: counters, trim table, ranks
-    PAV_HIP(ctx, S->small.reserve(64 + 16 * (size_t)n_aln + 2 * (size_t)n_ref + 64));
+    PAV_HIP(ctx, S->small.reserve(128 + 16 * (size_t)n_aln + 2 * (size_t)n_ref + 64));
     unsigned long long *d_cnt = S->small.as<unsigned long long>();
-    long long *d_tp = reinterpret_cast<long long *>(S->small.as<uint8_t>() + 64), *d_te = d_tp + n_aln;
+    long long *d_tp = reinterpret_cast<long long *>(S->small.as<uint8_t>() + 128), *d_te = d_tp + n_aln;
     uint16_t *d_rank = reinterpret_cast<uint16_t *>(d_te + n_aln);
-    PAV_HIP(ctx, hipMemsetAsync(d_cnt, 0, 64, st));
+    PAV_HIP(ctx, hipMemsetAsync(d_cnt, 0, 128, st));
     if (n_aln) {
         PAV_HIP(ctx, hipMemcpyAsync(d_tp, trim_pos, 8 * (size_t)n_aln, hipMemcpyHostToDevice, st));
         PAV_HIP(ctx, hipMemcpyAsync(d_te, trim_end, 8 * (size_t)n_aln, hipMemcpyHostToDevice, st));
@@ -503,32 +541,71 @@ int pav_cigar_flag(pav_ctx *ctx, const int64_t *trim_pos, const int64_t *trim_en
     }
     PAV_HIP(ctx, hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
     PAV_HIP(ctx, hipStreamSynchronize(st));
+    lap("keys+sort");
     const uint64_t snv_pass = cnt[0], ind_pass = cnt[1], ind_small = cnt[2];
     res->n_snv_pass = snv_pass;
     res->n_indel_pass = ind_pass;
 
-    // ---- cluster_snv, cluster_indel (vartype 'snv' / 'indel' of rule call_inv_cluster) -----------------------------------
-    if ((rc = run_sweep(ctx, S, S->b.as<unsigned long long>(), snv_pass, P->cluster_win, P->cluster_win, P->cluster_min_snv, S->table[3])) != PAV_OK) return rc;
+    // ---- the four tables: everything that only needs the counts above is queued behind one another, then read back together:
+    //      cluster_snv, cluster_indel (rule call_inv_cluster), the INS / DEL split of both vartypes (rule
+    //      call_inv_flag_insdel_cluster); the two matches follow once the split sizes are known.  Four readbacks in all.
+    // d_cnt words: 4 / 5 sweep hits (snv, indel); 8,9 / 10,11 DEL and INS rows of vartype sv / indel; 12 / 13 match hits
+    const uint64_t cap_snv = sweep_cap(snv_pass, P->cluster_min_snv), cap_ind = sweep_cap(ind_small, P->cluster_min_indel);
+    if (snv_pass) PAV_HIP(ctx, S->hits_b[0].reserve(sizeof(ClusterHit) * cap_snv));
+    if (ind_small) PAV_HIP(ctx, S->hits_b[1].reserve(sizeof(ClusterHit) * cap_ind));
+    PAV_HIP(ctx, hipMemsetAsync(d_cnt, 0, 128, st));
+    if ((rc = sweep_launch(ctx, S, S->b.as<unsigned long long>(), snv_pass, P->cluster_win, P->cluster_win, P->cluster_min_snv,
+                           S->hits_b[0].as<ClusterHit>(), d_cnt + 4)) != PAV_OK) return rc;
     if (ind_small) PAV_LAUNCH(ctx, "k_indel_mid", k_indel_mid, (uint32_t)((ind_small + 255) / 256), 256, 0, S->d.as<unsigned long long>(), ind_small);
-    if ((rc = run_sweep(ctx, S, S->d.as<unsigned long long>(), ind_small, P->cluster_win, P->cluster_win, P->cluster_min_indel, S->table[2])) != PAV_OK) return rc;
-
-    // ---- insdel_sv, insdel_indel (rule call_inv_flag_insdel_cluster) ----------------------------------------------------
+    if ((rc = sweep_launch(ctx, S, S->d.as<unsigned long long>(), ind_small, P->cluster_win, P->cluster_win, P->cluster_min_indel,
+                           S->hits_b[1].as<ClusterHit>(), d_cnt + 5)) != PAV_OK) return rc;
     if (ind_pass) {
-        PAV_HIP(ctx, S->a.reserve(16 * n_ind)); PAV_HIP(ctx, S->b.reserve(16 * n_ind));
-        PAV_HIP(ctx, S->c.reserve(8 * n_ind)); PAV_HIP(ctx, S->d.reserve(8 * n_ind));
         for (int t = 0; t < 2; ++t) {
             const int64_t lo64 = t == 0 ? 50 : P->insdel_min_svlen;                   // :497
             const uint32_t lo = (uint32_t)std::min<int64_t>(std::max<int64_t>(lo64, 0), 0xffffffffll);
             const uint32_t hi = t == 0 ? 0xffffffffu : 50u;                           // :504-505 (svlen is below 2^28)
-            PAV_HIP(ctx, hipMemsetAsync(d_cnt, 0, 64, st));
+            PAV_HIP(ctx, S->split[t][0].reserve(16 * n_ind)); PAV_HIP(ctx, S->split[t][1].reserve(16 * n_ind));
+            PAV_HIP(ctx, S->split[t][2].reserve(8 * n_ind)); PAV_HIP(ctx, S->split[t][3].reserve(8 * n_ind));
             PAV_LAUNCH(ctx, "k_insdel_split", k_insdel_split, (uint32_t)((n_ind + 255) / 256), 256, 0, ctx->d_indel.as<pav_indel>(), n_ind, d_aln,
-                       d_rank, d_tp, d_te, lo, hi, S->a.as<unsigned long long>(), S->b.as<unsigned long long>(), S->c.as<unsigned long long>(),
-                       S->d.as<unsigned long long>(), d_cnt);
-            PAV_HIP(ctx, hipMemcpyAsync(cnt, d_cnt, 16, hipMemcpyDeviceToHost, st));
-            PAV_HIP(ctx, hipStreamSynchronize(st));
-            if ((rc = run_match(ctx, S, cnt[0], cnt[1], P->insdel_flank_cluster, P->insdel_flank_merge, S->table[t])) != PAV_OK) return rc;
+                       d_rank, d_tp, d_te, lo, hi, S->split[t][0].as<unsigned long long>(), S->split[t][1].as<unsigned long long>(),
+                       S->split[t][2].as<unsigned long long>(), S->split[t][3].as<unsigned long long>(), d_cnt + 8 + 2 * t);
         }
     }
+    unsigned long long c2[16] = {0};
+    PAV_HIP(ctx, hipMemcpyAsync(c2, d_cnt, 128, hipMemcpyDeviceToHost, st));
+    lap("queue 2");
+    PAV_HIP(ctx, hipStreamSynchronize(st));                                             // readback 2
+    lap("sweeps+split");
+    if (c2[4] > cap_snv || c2[5] > cap_ind)
+        return fail(ctx, PAV_E_LIMIT, "flag: cluster output overflow (%llu / %llu hits)", c2[4], c2[5]);
+    std::vector<ClusterHit> sweep_hits[2];
+    sweep_hits[0].resize(c2[4]); sweep_hits[1].resize(c2[5]);
+    for (int q = 0; q < 2; ++q)
+        if (!sweep_hits[q].empty())
+            PAV_HIP(ctx, hipMemcpyAsync(sweep_hits[q].data(), S->hits_b[q].p, sizeof(ClusterHit) * sweep_hits[q].size(), hipMemcpyDeviceToHost, st));
+    for (int t = 0; t < 2; ++t) {
+        const uint64_t n_del = c2[8 + 2 * t], n_ins = c2[9 + 2 * t];
+        if (!n_del || !n_ins) continue;
+        PAV_HIP(ctx, S->hits_b[2 + t].reserve(sizeof(MatchHit) * n_ins));
+        if ((rc = match_launch(ctx, S, S->split[t][0].as<unsigned long long>(), S->split[t][1].as<unsigned long long>(),
+                               S->split[t][2].as<unsigned long long>(), S->split[t][3].as<unsigned long long>(), n_del, n_ins,
+                               P->insdel_flank_cluster, S->hits_b[2 + t].as<MatchHit>(), d_cnt + 12 + t)) != PAV_OK) return rc;
+    }
+    unsigned long long c3[2] = {0, 0};
+    PAV_HIP(ctx, hipMemcpyAsync(c3, d_cnt + 12, 16, hipMemcpyDeviceToHost, st));
+    lap("queue 3");
+    PAV_HIP(ctx, hipStreamSynchronize(st));                                             // readback 3 (sweep hits have landed too)
+    lap("matches");
+    sweep_collect(sweep_hits[0], S->table[3]);
+    sweep_collect(sweep_hits[1], S->table[2]);
+    std::vector<MatchHit> match_hits[2];
+    for (int t = 0; t < 2; ++t) {
+        match_hits[t].resize(c3[t]);
+        if (c3[t]) PAV_HIP(ctx, hipMemcpyAsync(match_hits[t].data(), S->hits_b[2 + t].p, sizeof(MatchHit) * c3[t], hipMemcpyDeviceToHost, st));
+    }
+    if (c3[0] || c3[1]) PAV_HIP(ctx, hipStreamSynchronize(st));                         // readback 4
+    for (int t = 0; t < 2; ++t) merge_matches(match_hits[t], P->insdel_flank_merge, S->table[t]);
+    lap("hits+merge");
 
     // ---- flagged regions (rule call_inv_merge_flagged_loci) ----------------------------------------------------------------
     for (int t = 0; t < 4; ++t) { res->tables[t] = S->table[t].data(); res->n[t] = S->table[t].size(); }
@@ -536,6 +613,7 @@ int pav_cigar_flag(pav_ctx *ctx, const int64_t *trim_pos, const int64_t *trim_en
     res->loci = S->loci.data();
     res->n_loci = S->loci.size();
     if (prof_flush(ctx) != PAV_OK) return PAV_E_HIP;
+    lap("loci");
     return PAV_OK;
 }
 

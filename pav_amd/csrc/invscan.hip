@@ -39,13 +39,16 @@ struct InvState {
     std::vector<std::string> logs;
     std::vector<std::string> errors;
     std::vector<std::unique_ptr<InvTable>> tables;
-    // Pinned host memory for the call tables: blocks persist across scans (pinning is expensive) and are bump-allocated;
-    // a new scan starts from the beginning again, so tables live until the next pav_inv_scan_batch.
+    // Pinned host memory for the call tables: blocks persist across scans (pinning is expensive) and are bump-allocated.
+    // Two arenas alternate between scans: the tables of a scan live until the next pav_inv_scan_batch, and that next scan
+    // fills the other arena, so it never waits for copies of the scan before it that are still crossing PCIe.
     struct PinBlock { void *p; size_t cap, used; };
-    std::vector<PinBlock> pinned;
-    void reset_pinned() { for (auto &b : pinned) b.used = 0; }
-    void free_pinned() { for (auto &b : pinned) (void)hipHostFree(b.p); pinned.clear(); }
+    std::vector<PinBlock> pinned_sets[2];
+    int cur_set = 0;
+    void next_pinned() { cur_set ^= 1; for (auto &b : pinned_sets[cur_set]) b.used = 0; }
+    void free_pinned() { for (auto &set : pinned_sets) { for (auto &b : set) (void)hipHostFree(b.p); set.clear(); } }
     void *pin_alloc(size_t bytes) {
+        auto &pinned = pinned_sets[cur_set];
         for (auto &b : pinned) if (b.cap - b.used >= bytes) { void *r = static_cast<uint8_t *>(b.p) + b.used; b.used += bytes; return r; }
         const size_t cap = std::max<size_t>(bytes + bytes / 4, (size_t)64 << 20);
         void *p = nullptr;
@@ -336,9 +339,13 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
     S->results.assign(n_regions, pav_inv_result{});
     S->logs.assign(n_regions, std::string());
     S->errors.assign(n_regions, std::string());
-    { const int rcw = wait_tables(ctx); if (rcw != PAV_OK) return rcw; }   // the pinned arena is about to be reused
+    // this scan fills the arena of the scan before the last one: only *its* copies must have landed (they have, long ago);
+    // the copies of the last scan may still be travelling into the other arena
+    std::swap(ctx->tables_done, ctx->tables_done_prev);
+    std::swap(ctx->tables_pending, ctx->tables_pending_prev);
+    { const int rcw = wait_tables(ctx); if (rcw != PAV_OK) return rcw; }
     S->tables.clear(); S->tables.resize(n_regions);
-    S->reset_pinned();
+    S->next_pinned();
     std::vector<Scan> scans(n_regions);
     auto log = [&](uint32_t i, const std::string &m) { S->logs[i] += m; S->logs[i] += '\n'; };
     auto srs_of = [&](int64_t len) -> uint32_t {
