@@ -151,11 +151,11 @@ def main():
         inv_state['t_lift_ms'] = (time.perf_counter() - t_a) * 1e3
 
         def inv_step():
-            logs = [io.StringIO() for _ in regions]
+            log = io.StringIO()                                   # one log for the batch, as rule call_inv_batch keeps it
             t_b = time.perf_counter()
-            out = pavinv.scan_for_inv_batch(regions, ref_fa_name, tig_fa_name, lift, k_util, logs=logs, ctx=ctx,
+            out = pavinv.scan_for_inv_batch(regions, ref_fa_name, tig_fa_name, lift, k_util, log=log, ctx=ctx,
                                             eager_tables=False)   # call tables stay in the library's pinned host copy
-            inv_state['out'], inv_state['logs'] = out, logs
+            inv_state['out'], inv_state['log'] = out, log
             inv_state['t_scan_ms'] = (time.perf_counter() - t_b) * 1e3
             return out
 
@@ -312,11 +312,10 @@ def main():
         scanned_bp = 0
         if args.workload == 'cigar+inv':
             import re as _re
-            for lg in inv_state['logs']:
-                for ln in lg.getvalue().splitlines():
-                    if ln.startswith('Scanning region: '):
-                        m = _re.search(r':(\d+)-(\d+)', ln.split(': ')[1])
-                        scanned_bp += int(m.group(2)) - int(m.group(1)) + 1
+            for ln in inv_state['log'].getvalue().splitlines():
+                if ln.startswith('Scanning region: '):
+                    m = _re.search(r':(\d+)-(\d+)', ln.split(': ')[1])
+                    scanned_bp += int(m.group(2)) - int(m.group(1)) + 1
         try:
             with open(os.path.join(ROOT, 'profiles', 'r01_pmc.json')) as fh:
                 pmc = json.load(fh)
@@ -451,13 +450,12 @@ def main():
         inv_report = None
         if args.workload == 'cigar+inv':
             from pav_amd import seq as pavseq2
-            out, logs = inv_state['out'], inv_state['logs']
+            out = inv_state['out']
             scanned = iters = 0
-            for lg in logs:
-                for ln in lg.getvalue().splitlines():
-                    if ln.startswith('Scanning region: '):
-                        scanned += len(pavseq2.region_from_string(ln.split(': ')[1]))
-                        iters += 1
+            for ln in inv_state['log'].getvalue().splitlines():
+                if ln.startswith('Scanning region: '):
+                    scanned += len(pavseq2.region_from_string(ln.split(': ')[1]))
+                    iters += 1
             flag_kernels = ('k_snv_keys', 'k_indel_keys', 'k_indel_mid', 'k_cluster_emit', 'k_insdel_split', 'k_ins_match',
                             'rocprim::radix_sort_keys', 'rocprim::radix_sort_pairs', 'rocprim::inclusive_scan')
             den = {k: v for k, v in kern.items() if k.startswith('k_') and k not in flag_kernels}

@@ -628,12 +628,15 @@ class Context:
         self._check(self.lib.pav_inv_text(self.handle, region, what, buf, n_bytes + 1), 'pav_inv_text')
         return buf.value.decode()
 
-    def inv_texts(self, what, n_regions, total_bytes):
-        """Log (what 0) or error (what 1) text of every region of the last scan: list of str."""
+    def inv_texts(self, what, n_regions, total_bytes, joined=False):
+        """Log (what 0) or error (what 1) text of every region of the last scan: list of str (``joined``: one string, the
+        texts in region order)."""
         buf = ctypes.create_string_buffer(int(total_bytes) + 1)
         off = np.zeros(n_regions + 1, dtype=np.uint64)
         self._check(self.lib.pav_inv_texts(self.handle, what, buf, int(total_bytes), _ptr(off)), 'pav_inv_texts')
         raw = buf.raw
+        if joined:
+            return [raw[:int(off[n_regions])].decode()]
         o = off.tolist()
         text = raw.decode()
         if len(text) == len(raw):                                   # ASCII: byte offsets are character offsets

@@ -429,7 +429,7 @@ def scan_for_inv(region_flag, ref_fa_name, tig_fa_name, align_lift, k_util, n_tr
 
 
 def _native_scan(ctx, region_flags, align_lift, k_util, max_region_size, logs, srs_tree, min_exp_count, ref_index, tig_index,
-                 eager_tables=True):
+                 eager_tables=True, log=None):
     """All regions through the library's native driver (pav_inv_scan_batch, csrc/invscan.hip)."""
     import ctypes
     import time
@@ -483,6 +483,9 @@ def _native_scan(ctx, region_flags, align_lift, k_util, max_region_size, logs, s
         all_cols, all_flank, all_match, row_off = ctx.inv_tables(np.where(outcome == _lib.INV_CALL, resv['n_rows'], 0))
     generation = ctx._inv_generation
     _lap('inv_tables')
+    if log is not None and n_rgn:                                      # one sink for the batch: the texts in region order
+        log.write(''.join(ctx.inv_texts(0, n_rgn, int(resv['log_bytes'].sum(dtype=np.int64)), joined=True)))
+        log.flush()
     if logs is not None and n_rgn:
         texts = ctx.inv_texts(0, n_rgn, int(resv['log_bytes'].sum(dtype=np.int64)))
         for lg, text in zip(logs, texts):
@@ -542,9 +545,11 @@ def _native_scan(ctx, region_flags, align_lift, k_util, max_region_size, logs, s
 
 def scan_for_inv_batch(region_flags, ref_fa_name, tig_fa_name, align_lift, k_util, n_tree=None, max_region_size=None,
                        logs=None, srs_tree=None, min_exp_count=DEFAULT_MIN_EXP_COUNT, ctx=None, device_id=0, native=None,
-                       eager_tables=True):
+                       eager_tables=True, log=None):
     """Scan many flagged regions; returns a list of ``InvCall`` / ``None`` / ``RuntimeError`` (one per region, the
     error object where ``scan_for_inv`` would have raised).  ``logs``: one file-like object per region or None.
+    ``log``: one file-like object for the whole batch - what rule call_inv_batch passes to every ``scan_for_inv`` call
+    (rules/call_inv.snakefile:172,191-196); it receives the log text of all regions in region order.
 
     ``native``: run the whole scan loop inside the library (csrc/invscan.hip).  Default: yes when ``align_lift`` is a
     :class:`pav_amd.align.AlignLift` and no N-tree is given; the Python state machine below is the same algorithm and
@@ -565,12 +570,21 @@ def scan_for_inv_batch(region_flags, ref_fa_name, tig_fa_name, align_lift, k_uti
                 os.environ.get('PAV_INV_DRIVER', '').lower() != 'python'
         if native:
             return _native_scan(ctx, region_flags, align_lift, k_util, max_region_size, logs, srs_tree, min_exp_count,
-                                ref_index, tig_index, eager_tables=eager_tables)
+                                ref_index, tig_index, eager_tables=eager_tables, log=log)
         scans = []
+        if log is not None and logs is None:                           # lock-step scans: per-region buffers, joined in region order
+            import io
+            joined = [io.StringIO() for _ in region_flags]
+        else:
+            joined = None
         for i, rf in enumerate(region_flags):
+            sink = joined[i] if joined is not None else (None if logs is None else logs[i])
             scans.append(_Scan(rf, ref_fa_name, tig_fa_name, align_lift, k_util, n_tree, max_region_size,
-                               None if logs is None else logs[i], srs_tree, min_exp_count, ref_index, tig_index))
+                               sink, srs_tree, min_exp_count, ref_index, tig_index))
         _drive(ctx, scans, density.den_params(k=k_util.k_size))
+        if log is not None:
+            log.write(''.join(b.getvalue() for b in (joined if joined is not None else logs)))
+            log.flush()
     finally:
         if own:
             ctx.close()

@@ -241,6 +241,20 @@ def test_batched_scan_vs_reference(built, gpu_ctx, case, native):
                 check_call(d, rec, call)
 
 
+@pytest.mark.parametrize('native', [True, False])
+def test_batch_log_sink_equals_the_sequential_log(built, gpu_ctx, native):
+    """``log=``: one file-like object for the whole batch, as rule call_inv_batch hands its log file to every scan_for_inv
+    call (rules/call_inv.snakefile:172-196): the text is the reference's per-region logs in region order."""
+    d, lift, scans = load_case(gpu_ctx, 'inv_hap')
+    recs = [r for r in scans if not r['kwargs']]
+    regions = [pavseq.Region(r['flag']['chrom'], r['flag']['pos'], r['flag']['end']) for r in recs]
+    log = io.StringIO()
+    out = pavinv.scan_for_inv_batch(regions, os.path.join(d, 'ref.fa'), os.path.join(d, 'tig.fa'), lift, KmerUtil(31), log=log,
+                                    ctx=gpu_ctx, native=native)
+    assert log.getvalue().splitlines() == [ln for r in recs for ln in r['log']]
+    assert [o is not None for o in out] == [r['call'] is not None for r in recs]
+
+
 def test_lazy_table_expires_with_the_next_scan(built, gpu_ctx):
     d, lift, scans = load_case(gpu_ctx, 'inv_small')
     k_util = KmerUtil(31)
