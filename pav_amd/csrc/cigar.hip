@@ -877,9 +877,18 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
         A.snv = ctx->d_snv.as<pav_snv>(); A.indel = ctx->d_indel.as<pav_indel>();
         A.err_op = d_err_op;
         PAV_LAUNCH(ctx, "walk_emit", walk_emit, n_wchunks, 256, 0, A);
-        if (totals[2])
+        // REF / ALT bytes of the SNV rows (ASCII plane only) on the side stream, next to the homology scans (packed planes)
+        const bool side_snv = totals[2] && totals[3];
+        if (side_snv) {
+            PAV_HIP(ctx, hipEventRecord(ctx->emit_done, ctx->stream));
+            PAV_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->emit_done, 0));
+            PAV_LAUNCH_ON(ctx, ctx->stream2, "snv_bases", snv_bases, (uint32_t)((totals[2] + 255) / 256), 256, 0, ctx->d_snv.as<pav_snv>(),
+                          totals[2], ctx->d_aln.as<pav_aln>(), A.ref, A.tig);
+            PAV_HIP(ctx, hipEventRecord(ctx->snv_done, ctx->stream2));
+        } else if (totals[2]) {
             PAV_LAUNCH(ctx, "snv_bases", snv_bases, (uint32_t)((totals[2] + 255) / 256), 256, 0, ctx->d_snv.as<pav_snv>(), totals[2],
                        ctx->d_aln.as<pav_aln>(), A.ref, A.tig);
+        }
         if (totals[3]) {
             { int rcw = wait_planes(ctx); if (rcw != PAV_OK) return rcw; }   // the packed planes may still be in flight
             PAV_LAUNCH(ctx, "homology_kernel", homology_kernel, (uint32_t)((totals[3] + 255) / 256), 256, 0,
@@ -889,6 +898,7 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
                            ctx->d_indel.as<pav_indel>(), totals[3], ctx->d_aln.as<pav_aln>(), A.ref, A.tig,
                            ctx->d_seqblob.as<uint8_t>(), totals[4]);
         }
+        if (side_snv) PAV_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->snv_done, 0));   // later readers of the SNV rows use this stream
         PAV_HIP(ctx, hipMemcpyAsync(h_status, d_tok_err, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
         errs[0] = h_status[0];
