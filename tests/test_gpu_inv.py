@@ -215,6 +215,27 @@ def test_kmer_sets_lds_equal_hbm_on_large_regions(built, gpu_ctx):
     inv_rows = out[_lib.KMER_LDS][1][6]
     assert (inv_rows['STATE_MER'] == 2).sum() > 100_000                           # the inverted segment shows up as REV
 
+    # Low-complexity sequence sends far more k-mers to one partition than its list holds: the batch is redone with HBM
+    # tables (same answers).  Job 0: 20 kbp of poly-A on the contig only; job 1: on the reference too (count gate fails).
+    ref_b, tig_b = ref_a.copy(), tig_a.copy()
+    tig_b[1_300_000:1_320_000] = ord('A')
+    ref_b[1_500_000:1_520_000] = ord('a')
+    tig_b[1_500_000:1_520_000] = ord('A')
+    gpu_ctx.seq_load(_lib.PAV_ROLE_REF, ['chrL'], [ref_b])
+    gpu_ctx.seq_load(_lib.PAV_ROLE_TIG, ['tigL'], [tig_b])
+    jobs = [_lib.DenJob(0, 0, 1_280_000, 1_340_000, 1_280_000, 1_340_000, 0, 20),
+            _lib.DenJob(0, 0, 1_480_000, 1_540_000, 1_480_000, 1_540_000, 0, 20),
+            _lib.DenJob(0, 0, 300_000, 360_000, 300_000, 360_000, 0, 20)]
+    got = {}
+    for kmer in (_lib.KMER_LDS, _lib.KMER_HBM):
+        res = gpu_ctx.density_batch(jobs, pavden.den_params(kmer_mode=kmer))
+        got[kmer] = [(r.status, r.fail_kind, r.n_rows, r.max_count, r.max_kmer,
+                      gpu_ctx.density_table(j, r.n_rows)['STATE_MER'].tobytes() if r.status != _lib.DEN_FAIL else None)
+                     for j, r in enumerate(res)]
+    assert got[_lib.KMER_LDS] == got[_lib.KMER_HBM]
+    assert got[_lib.KMER_LDS][0][0] == _lib.DEN_OK and got[_lib.KMER_LDS][2][0] == _lib.DEN_OK
+    assert got[_lib.KMER_LDS][1][:2] == (_lib.DEN_FAIL, 2) and 19_970 <= got[_lib.KMER_LDS][1][3] < 19_990 and got[_lib.KMER_LDS][1][4] == 0
+
 
 @pytest.mark.parametrize('native', [True, False])
 @pytest.mark.parametrize('case', INV_CASES)
