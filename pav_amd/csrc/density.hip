@@ -208,8 +208,8 @@ __global__ void k_max_kmer(const JobDev *__restrict__ jobs, uint32_t j, SeqView 
 // ---- contig k-mers -> STATE_MER (scripts/density.py:165-175) -------------------------------------------------
 __global__ __launch_bounds__(256) void k_tig_state(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
                                                    SeqView T, int k, const unsigned long long *__restrict__ keys,
-                                                   int8_t *__restrict__ st_tmp, JobStat *__restrict__ stat) {
-    const uint64_t ap = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+                                                   int8_t *__restrict__ st_tmp, JobStat *__restrict__ stat, uint32_t block0) {
+    const uint64_t ap = ((uint64_t)blockIdx.x + block0) * 256 + threadIdx.x;
     const uint32_t j = tile_job[ap / DTILE];
     const JobDev jd = jobs[j];
     if (jd.n_parts) return;                                            // k_kmer_lds + k_state_combine
@@ -1078,8 +1078,8 @@ uint64_t pav_kmer_canonical(uint64_t kmer, int k) {
     return kmer <= rc ? kmer : rc;
 }
 
-static int density_batch_impl(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, const pav_den_params *pp,
-                              pav_den_result *results, bool hbm_tables_only) {
+int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, const pav_den_params *pp,
+                      pav_den_result *results) {
     if (!ctx || !pp || (n_jobs && (!jobs || !results))) return fail(ctx, PAV_E_ARG, "pav_density_batch: null argument");
     if (pp->k < 1 || pp->k > 31) return fail(ctx, PAV_E_LIMIT, "pav_density_batch: k = %d is outside 1..31", pp->k);
     PAV_HIP(ctx, hipSetDevice(ctx->device));
@@ -1104,7 +1104,7 @@ static int density_batch_impl(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *
     std::vector<uint32_t> tile_job_r, tile_job_t;
     // k-mer sets in LDS unless asked otherwise (params, env), the count limit does not fit a byte, or a region needs
     // more partitions than the bucket kernels' histograms hold (> 7 Mbp; the reference's MAX_REGION_SIZE is 1.2 Mbp)
-    const bool lds_sets = !hbm_tables_only && pp->kmer_mode != PAV_KMER_HBM && pp->max_ref_kmer_count <= LDS_MAX_LIMIT &&
+    const bool lds_sets = pp->kmer_mode != PAV_KMER_HBM && pp->max_ref_kmer_count <= LDS_MAX_LIMIT &&
                           getenv("PAV_KMER_HBM") == nullptr;
     std::vector<PartItem> items;
     uint32_t n_hbm_jobs = 0;
@@ -1221,56 +1221,86 @@ static int density_batch_impl(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *
         PAV_LAUNCH(ctx, "k_ref_insert", k_ref_insert, (uint32_t)(a_r / 256), 256, 0, d_jobs, d_tjr, RV, k, pp->max_ref_kmer_count,
                    d_keys, D->cnt.as<uint32_t>(), d_stat, 0u, 0);
         PAV_LAUNCH(ctx, "k_tig_state", k_tig_state, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, TV, k, d_keys,
-                   D->st_tmp.as<int8_t>(), d_stat);
+                   D->st_tmp.as<int8_t>(), d_stat, 0u);
     }
-    PAV_LAUNCH(ctx, "k_compact_reduce", k_compact_reduce, n_tiles_t, 256, 0, d_tjt, d_stat, D->st_tmp.as<int8_t>(),
-               pp->min_state_count, D->tile_sum.as<uint32_t>());
-    PAV_LAUNCH(ctx, "k_scan_tiles4", k_scan_tiles4, 1, 256, 0, D->tile_sum.as<uint32_t>(), D->tile_pre.as<unsigned long long>(),
-               n_tiles_t);
     CompactArgs CA;
     CA.jobs = d_jobs; CA.tile_job = d_tjt; CA.stat = d_stat; CA.st_tmp = D->st_tmp.as<int8_t>();
     CA.tile_pre = D->tile_pre.as<unsigned long long>(); CA.T = TV; CA.k = k; CA.min_state_count = pp->min_state_count;
     CA.index = D->index.as<uint32_t>(); CA.state_mer = D->state_mer.as<int8_t>(); CA.state = D->state.as<int8_t>();
     CA.kmer = D->kmer.as<unsigned long long>();
     for (int s = 0; s < 3; ++s) CA.list[s] = D->list[s].as<uint32_t>();
-    PAV_LAUNCH(ctx, "k_compact_scatter", k_compact_scatter, n_tiles_t, 256, 0, CA);
-
-    // ---- readback 1: per-job counts and moments -> status, bandwidths (host, libm: same arithmetic as scipy) ----
     std::vector<JobStat> hs(n_jobs);
-    PAV_HIP(ctx, hipMemcpyAsync(hs.data(), d_stat, sizeof(JobStat) * n_jobs, hipMemcpyDeviceToHost, st));
-    PAV_HIP(ctx, hipStreamSynchronize(st));
+    // compaction to the informative rows, then readback 1: per-job counts and moments -> status, bandwidths (host, libm:
+    // same arithmetic as scipy)
+    auto compact_and_read = [&]() -> int {
+        PAV_LAUNCH(ctx, "k_compact_reduce", k_compact_reduce, n_tiles_t, 256, 0, d_tjt, d_stat, D->st_tmp.as<int8_t>(),
+                   pp->min_state_count, D->tile_sum.as<uint32_t>());
+        PAV_LAUNCH(ctx, "k_scan_tiles4", k_scan_tiles4, 1, 256, 0, D->tile_sum.as<uint32_t>(), D->tile_pre.as<unsigned long long>(),
+                   n_tiles_t);
+        PAV_LAUNCH(ctx, "k_compact_scatter", k_compact_scatter, n_tiles_t, 256, 0, CA);
+        PAV_HIP(ctx, hipMemcpyAsync(hs.data(), d_stat, sizeof(JobStat) * n_jobs, hipMemcpyDeviceToHost, st));
+        PAV_HIP(ctx, hipStreamSynchronize(st));
+        return PAV_OK;
+    };
+    { const int rcc = compact_and_read(); if (rcc != PAV_OK) return rcc; }
     lap("kmer+compact");
+    std::vector<uint8_t> in_x(n_jobs, 0);                              // the job's HBM table lives in keys_x / cnt_x
     {
-        bool overflow = false;
-        std::vector<uint32_t> exceed;
+        std::vector<uint32_t> overflow, exceed;
         for (uint32_t j = 0; j < n_jobs; ++j) {
-            if (hs[j].lds_flags & LDS_OVERFLOW) overflow = true;
+            if (hs[j].lds_flags & LDS_OVERFLOW) overflow.push_back(j);
             else if (hs[j].lds_flags & LDS_EXCEED) exceed.push_back(j);
         }
-        if (overflow)                                                  // a partition outgrew its LDS table (hash imbalance far
-            return density_batch_impl(ctx, n_jobs, jobs, pp, results, true);   // beyond the 0.44 load aimed at): HBM tables
-        if (!exceed.empty()) {
-            // failure path (scripts/density.py:516-527): the exact largest count comes from an HBM table of the region
+        if (!overflow.empty() || !exceed.empty()) {
+            // Both sets get an HBM table of their region (keys_x / cnt_x):
+            //  * overflow - a partition list or LDS table of the region overflowed: low-complexity sequence sends thousands of
+            //    copies of one k-mer to one partition (or, in theory, a hash imbalance far beyond the 0.44 load aimed at).
+            //    These regions alone are redone with the HBM-table kernels; every other region keeps its rows.
+            //  * exceed - failure path (scripts/density.py:516-527): the exact largest count and its k-mer.
             uint64_t extra = 0;
-            for (uint32_t j : exceed) {
-                JobDev &jd = D->h_jobs[j];
-                const uint32_t cap = pow2_at_least(2ull * jd.ref_len + 2);
-                jd.ht_off = extra; jd.ht_mask = cap - 1; extra += cap;
-            }
+            for (const std::vector<uint32_t> *set : {&overflow, &exceed})
+                for (uint32_t j : *set) {
+                    JobDev &jd = D->h_jobs[j];
+                    const uint32_t cap = pow2_at_least(2ull * jd.ref_len + 2);
+                    jd.ht_off = extra; jd.ht_mask = cap - 1; extra += cap;
+                    in_x[j] = 1;
+                }
+            for (uint32_t j : overflow) D->h_jobs[j].n_parts = 0;
             PAV_HIP(ctx, D->keys_x.reserve(8 * extra));
             PAV_HIP(ctx, D->cnt_x.reserve(4 * extra));
             PAV_HIP(ctx, hipMemsetAsync(D->keys_x.p, 0xFF, 8 * extra, st));
             PAV_HIP(ctx, hipMemsetAsync(D->cnt_x.p, 0, 4 * extra, st));
             PAV_HIP(ctx, hipMemcpyAsync(D->jobs.p, D->h_jobs.data(), sizeof(JobDev) * n_jobs, hipMemcpyHostToDevice, st));
-            for (uint32_t j : exceed) {
-                const JobDev &jd = D->h_jobs[j];
-                PAV_HIP(ctx, hipMemsetAsync(&d_stat[j].n_ref_valid, 0, 4, st));     // counted again by the insert below
-                PAV_LAUNCH(ctx, "k_ref_insert", k_ref_insert, (uint32_t)((std::max<uint64_t>(jd.ref_len, 1) + DTILE - 1) / DTILE * (DTILE / 256)),
-                           256, 0, d_jobs, d_tjr, RV, k, pp->max_ref_kmer_count, D->keys_x.as<unsigned long long>(),
-                           D->cnt_x.as<uint32_t>(), d_stat, (uint32_t)(jd.rpos_off / 256), 1);
+            if (!overflow.empty()) {
+                // statistics: the overflowed regions start from zero, the compaction results of all regions are recomputed
+                for (uint32_t j : overflow) hs[j] = JobStat{};
+                for (uint32_t j = 0; j < n_jobs; ++j) {
+                    JobStat &q = hs[j];
+                    q.n_rows = 0; q.fill_n = 0;
+                    for (int t = 0; t < 3; ++t) { q.m[t] = 0; q.s1[t] = 0; q.s2[t] = 0; }
+                }
+                PAV_HIP(ctx, hipMemcpyAsync(d_stat, hs.data(), sizeof(JobStat) * n_jobs, hipMemcpyHostToDevice, st));
             }
-            PAV_HIP(ctx, hipMemcpyAsync(hs.data(), d_stat, sizeof(JobStat) * n_jobs, hipMemcpyDeviceToHost, st));
-            PAV_HIP(ctx, hipStreamSynchronize(st));
+            for (const std::vector<uint32_t> *set : {&overflow, &exceed})
+                for (uint32_t j : *set) {
+                    const JobDev &jd = D->h_jobs[j];
+                    const uint32_t blocks_r = (uint32_t)((std::max<uint64_t>(jd.ref_len, 1) + DTILE - 1) / DTILE * (DTILE / 256));
+                    if (set == &exceed) PAV_HIP(ctx, hipMemsetAsync(&d_stat[j].n_ref_valid, 0, 4, st));     // counted again by the insert
+                    PAV_LAUNCH(ctx, "k_ref_insert", k_ref_insert, blocks_r, 256, 0, d_jobs, d_tjr, RV, k, pp->max_ref_kmer_count,
+                               D->keys_x.as<unsigned long long>(), D->cnt_x.as<uint32_t>(), d_stat, (uint32_t)(jd.rpos_off / 256), 1);
+                    if (set == &overflow) {
+                        const uint32_t blocks_t = (uint32_t)((std::max<uint64_t>(jd.tig_len, 1) + DTILE - 1) / DTILE * (DTILE / 256));
+                        PAV_LAUNCH(ctx, "k_tig_state", k_tig_state, blocks_t, 256, 0, d_jobs, d_tjt, TV, k,
+                                   D->keys_x.as<unsigned long long>(), D->st_tmp.as<int8_t>(), d_stat, (uint32_t)(jd.tpos_off / 256));
+                    }
+                }
+            if (!overflow.empty()) {
+                const int rcc = compact_and_read();
+                if (rcc != PAV_OK) return rcc;
+            } else {
+                PAV_HIP(ctx, hipMemcpyAsync(hs.data(), d_stat, sizeof(JobStat) * n_jobs, hipMemcpyDeviceToHost, st));
+                PAV_HIP(ctx, hipStreamSynchronize(st));
+            }
         }
     }
 
@@ -1370,9 +1400,9 @@ static int density_batch_impl(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *
     for (uint32_t j = 0; j < n_jobs; ++j) {
         if (D->results[j].fail_kind != 2) continue;
         PAV_HIP(ctx, hipMemsetAsync(&d_stat[j].max_key, 0xFF, sizeof(unsigned long long), st));
-        // regions with LDS sets got their HBM table on the failure path above (keys_x / cnt_x)
-        const unsigned long long *jk = D->h_jobs[j].n_parts ? D->keys_x.as<unsigned long long>() : d_keys;
-        const uint32_t *jc = D->h_jobs[j].n_parts ? D->cnt_x.as<uint32_t>() : D->cnt.as<uint32_t>();
+        // regions with LDS sets got their HBM table above (keys_x / cnt_x)
+        const unsigned long long *jk = in_x[j] ? D->keys_x.as<unsigned long long>() : d_keys;
+        const uint32_t *jc = in_x[j] ? D->cnt_x.as<uint32_t>() : D->cnt.as<uint32_t>();
         PAV_LAUNCH(ctx, "k_max_kmer", k_max_kmer, 64, 256, 0, d_jobs, j, RV, k, jk, jc, d_stat);
         unsigned long long packed = 0, key = 0;
         PAV_HIP(ctx, hipMemcpyAsync(&packed, &d_stat[j].max_key, sizeof packed, hipMemcpyDeviceToHost, st));
@@ -1441,11 +1471,6 @@ static int density_batch_impl(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *
     lap("rl");
     D->valid = true;
     return PAV_OK;
-}
-
-int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, const pav_den_params *pp,
-                      pav_den_result *results) {
-    return density_batch_impl(ctx, n_jobs, jobs, pp, results, false);
 }
 
 int pav_density_runs(pav_ctx *ctx, uint32_t job, pav_run *runs) {
