@@ -358,6 +358,44 @@ int pav_inv_write_tables(pav_ctx *ctx, uint32_t n, const uint32_t *regions, cons
  * returns the length, out is NUL-terminated.  Text helper of the writers, exposed for unit tests. */
 int pav_repr_f64(double value, char *out, int out_len);
 
+/* ---- alignment ingest: SAM -> alignment table ----------------------------- *
+ * The record loop of pavlib.align.get_align_bed (pavlib/align/align.py:666-794; rule align_get_read_bed,
+ * rules/align.snakefile:101-171) without pysam: SAM text (plain, gzip, BGZF) is parsed on host threads into the quantities
+ * that function reads from pysam's AlignedSegment (restated from the SAM specification / htslib: reference_start = POS - 1,
+ * reference_end = start + max(1, M+D+N+=+X), query_alignment_start / _end from the soft clips, flags), the CIGAR with
+ * soft clipping folded into hard clipping (clip_soft_to_hard, align.py:797-831) and count_cigar of that CIGAR
+ * (align.py:534-663; err_kind as pav_trim_count).  Records that are unmapped, below min_mapq or without CIGAR are
+ * dropped but counted: INDEX is the ordinal of the alignment line in the file (align.py:692).  Host only. */
+typedef struct pav_sam pav_sam;
+typedef struct {
+    uint64_t n_records;             /* alignment lines in the file                                            */
+    uint64_t n_rows;                /* records kept                                                           */
+    uint32_t n_ref, n_qry;          /* distinct RNAME / QNAME among them                                      */
+    uint64_t cigar_bytes, tag_bytes, header_bytes;
+} pav_sam_info_t;
+typedef struct {                    /* caller-allocated, n_rows entries (offset arrays n_rows + 1); any may be NULL */
+    int64_t *index, *pos, *end;
+    uint32_t *chrom_id, *qry_id;
+    int64_t *query_alignment_start, *query_alignment_end;
+    int64_t *clip_h;                /* leading H of the SAM CIGAR (align.py:708-711)                          */
+    int64_t *tig_map_pos;           /* leading clipping of the transformed CIGAR (:715)                       */
+    int32_t *mapq, *flag;
+    uint8_t *has_m;                 /* an M operation is present (:725-729)                                   */
+    uint8_t *status;                /* 0 ok; 1 clipping order pysam rejects; 2 clipping operations only       */
+    int64_t *ref_bp, *tig_bp;       /* count_cigar of the transformed CIGAR                                   */
+    uint32_t *err_kind, *err_op, *err_len, *err_char;
+    uint8_t *cigar_text; uint64_t *cigar_off;
+    uint8_t *tag_text;              /* RG value at [rg_off[i], ao_off[i]), AO value at [ao_off[i], rg_off[i + 1]) */
+    uint64_t *rg_off, *ao_off;
+    uint8_t *rg_kind, *ao_kind;     /* 0 absent, 1 integer (type i), 2 text, 3 float                          */
+} pav_sam_cols;
+int pav_sam_open(const char *path, int min_mapq, int threads, pav_sam **out);   /* message via pav_last_error(NULL) */
+void pav_sam_close(pav_sam *sam);
+int pav_sam_info(const pav_sam *sam, pav_sam_info_t *info);
+int pav_sam_fetch(const pav_sam *sam, const pav_sam_cols *cols);
+const char *pav_sam_name(const pav_sam *sam, int which /* 0 RNAME, 1 QNAME */, uint32_t id);
+int pav_sam_header(const pav_sam *sam, uint8_t *buf /* header_bytes: the leading '@' lines */);
+
 /* ---- alignment tables: native reader (reader half) -------------------------- *
  * The tables of results/{asm}/align/trim-{none,tig,tigref}/aligned_tig_{hap}.bed.gz (API_ALIGN.md:31-64) as rule call_cigar
  * reads them with pandas (rules/call.snakefile:805, 813-816): gzip or plain TSV with a header line; columns are found by

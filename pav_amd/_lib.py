@@ -217,6 +217,12 @@ SYMBOLS = {
     'pav_fasta_seq': (_P, [_P, ctypes.c_uint32]),
     'pav_fasta_kind': (ctypes.c_int, [_P]),
     'pav_seq_load_fasta': (ctypes.c_int, [_P, ctypes.c_int, _P, ctypes.c_uint32, _P]),
+    'pav_sam_open': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, _P]),
+    'pav_sam_close': (None, [_P]),
+    'pav_sam_info': (ctypes.c_int, [_P, _P]),
+    'pav_sam_fetch': (ctypes.c_int, [_P, _P]),
+    'pav_sam_name': (ctypes.c_char_p, [_P, ctypes.c_int, ctypes.c_uint32]),
+    'pav_sam_header': (ctypes.c_int, [_P, _P]),
     'pav_bed_open': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, _P]),
     'pav_bed_close': (None, [_P]),
     'pav_bed_info': (ctypes.c_int, [_P, _P]),
@@ -743,6 +749,66 @@ class FastaFile:
             self.close()
         except Exception:  # noqa: BLE001
             pass
+
+
+class SamInfo(ctypes.Structure):
+    _fields_ = [('n_records', ctypes.c_uint64), ('n_rows', ctypes.c_uint64), ('n_ref', ctypes.c_uint32), ('n_qry', ctypes.c_uint32),
+                ('cigar_bytes', ctypes.c_uint64), ('tag_bytes', ctypes.c_uint64), ('header_bytes', ctypes.c_uint64)]
+
+
+_SAM_COLS = [('index', np.int64), ('pos', np.int64), ('end', np.int64), ('chrom_id', np.uint32), ('qry_id', np.uint32),
+             ('query_alignment_start', np.int64), ('query_alignment_end', np.int64), ('clip_h', np.int64), ('tig_map_pos', np.int64),
+             ('mapq', np.int32), ('flag', np.int32), ('has_m', np.uint8), ('status', np.uint8), ('ref_bp', np.int64), ('tig_bp', np.int64),
+             ('err_kind', np.uint32), ('err_op', np.uint32), ('err_len', np.uint32), ('err_char', np.uint32),
+             ('cigar_text', None), ('cigar_off', None), ('tag_text', None), ('rg_off', None), ('ao_off', None),
+             ('rg_kind', np.uint8), ('ao_kind', np.uint8)]
+
+
+class SamCols(ctypes.Structure):
+    _fields_ = [(name, ctypes.c_void_p) for name, _ in _SAM_COLS]
+
+
+class SamFile:
+    """A SAM file parsed by the library (``pav_sam_open``): what ``pavlib.align.get_align_bed`` reads from pysam, per kept record,
+    plus the transformed CIGAR strings.  ``cols`` maps field name -> numpy array; ``cigars`` / ``rg`` / ``ao`` are Python lists."""
+
+    def __init__(self, path, min_mapq=0, threads=0):
+        self.lib = load()
+        h = ctypes.c_void_p(0)
+        rc = self.lib.pav_sam_open(str(path).encode(), int(min_mapq), int(threads), ctypes.byref(h))
+        if rc != PAV_OK:
+            raise PavDeviceError('pav_sam_open failed ({}): {}'.format(rc, (self.lib.pav_last_error(None) or b'').decode()))
+        self.handle = h
+        try:
+            info = SamInfo()
+            self.lib.pav_sam_info(h, ctypes.byref(info))
+            n = self.n_rows = int(info.n_rows)
+            self.n_records = int(info.n_records)
+            self.ref_names = [self.lib.pav_sam_name(h, 0, i).decode() for i in range(info.n_ref)]
+            self.qry_names = [self.lib.pav_sam_name(h, 1, i).decode() for i in range(info.n_qry)]
+            head = ctypes.create_string_buffer(max(1, int(info.header_bytes)))
+            self.lib.pav_sam_header(h, head)
+            self.header = head.raw[:int(info.header_bytes)]
+            cols = {name: np.zeros(max(n, 1), dtype=dt) for name, dt in _SAM_COLS if dt is not None}
+            cols['cigar_text'] = np.zeros(max(1, int(info.cigar_bytes)), dtype=np.uint8)
+            cols['tag_text'] = np.zeros(max(1, int(info.tag_bytes)), dtype=np.uint8)
+            for name in ('cigar_off', 'rg_off', 'ao_off'):
+                cols[name] = np.zeros(n + 1, dtype=np.uint64)
+            c = SamCols(**{name: cols[name].ctypes.data for name, _ in _SAM_COLS})
+            rc = self.lib.pav_sam_fetch(h, ctypes.byref(c))
+            if rc != PAV_OK:
+                raise PavDeviceError('pav_sam_fetch failed ({})'.format(rc))
+            self.cols = {name: (a[:n] if name not in ('cigar_off', 'rg_off', 'ao_off', 'cigar_text', 'tag_text') else a) for name, a in cols.items()}
+            text = cols['cigar_text'].tobytes()
+            off = cols['cigar_off'].tolist()
+            self.cigars = [text[off[i]:off[i + 1]].decode() for i in range(n)]
+            tags = cols['tag_text'].tobytes()
+            ro, ao = cols['rg_off'].tolist(), cols['ao_off'].tolist()
+            self.rg = [tags[ro[i]:ao[i]].decode() for i in range(n)]
+            self.ao = [tags[ao[i]:ro[i + 1]].decode() for i in range(n)]
+        finally:
+            self.lib.pav_sam_close(h)
+            self.handle = None
 
 
 class BedTable:

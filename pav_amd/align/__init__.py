@@ -2,3 +2,4 @@
 from .lift import AlignLift  # noqa: F401
 from .cigar import cigar_str_to_tuples, tokenize  # noqa: F401
 from .trim import trim_alignments, trim_alignment_record  # noqa: F401
+from .ingest import get_align_bed  # noqa: F401

@@ -6,15 +6,7 @@
 // pav_seq_load takes - and can be handed to a context directly (pav_seq_load_fasta).  Host code; no GPU needed to parse.
 #include "common.h"
 
-#include <fcntl.h>
-#include <sys/mman.h>
-#include <sys/stat.h>
-#include <unistd.h>
-#include <zlib.h>
-
-#include <algorithm>
-#include <atomic>
-#include <thread>
+#include "fileio.h"
 
 struct pav_fasta {
     std::vector<std::string> names;
@@ -25,80 +17,6 @@ struct pav_fasta {
     ~pav_fasta() { free(seq); }
 };
 
-namespace pav {
-namespace {
-
-struct Mapped {
-    const uint8_t *p = nullptr;
-    size_t n = 0;
-    int fd = -1;
-    ~Mapped() { if (p && n) munmap(const_cast<uint8_t *>(p), n); if (fd >= 0) close(fd); }
-};
-
-struct Block { uint64_t in_off, in_len, out_off, out_len; };   // deflate payload of one BGZF block, its place in the text
-
-// BGZF block header (SAM specification 4.1): gzip member with FEXTRA carrying subfield 'B','C' = total block size - 1.
-bool bgzf_block(const uint8_t *p, size_t avail, uint64_t &bsize, uint64_t &hdr) {
-    if (avail < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return false;
-    const uint32_t xlen = p[10] | (uint32_t)p[11] << 8;
-    if (avail < 12ull + xlen) return false;
-    for (uint32_t x = 0; x + 4 <= xlen;) {
-        const uint8_t *f = p + 12 + x;
-        const uint32_t slen = f[2] | (uint32_t)f[3] << 8;
-        if (f[0] == 'B' && f[1] == 'C' && slen == 2 && x + 6 <= xlen) {
-            bsize = (uint64_t)(f[4] | (uint32_t)f[5] << 8) + 1;
-            hdr = 12ull + xlen;
-            return bsize >= hdr + 8 && bsize <= avail;
-        }
-        x += 4 + slen;
-    }
-    return false;
-}
-
-template <class F> void parallel_for(size_t n, int threads, F &&body) {
-    threads = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, n));
-    if (threads == 1) { for (size_t i = 0; i < n; ++i) body(i); return; }
-    std::atomic<size_t> next{0};
-    std::vector<std::thread> pool;
-    for (int t = 0; t < threads; ++t)
-        pool.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < n;) body(i); });
-    for (auto &th : pool) th.join();
-}
-
-// One gzip stream, possibly several concatenated members (what `gzip` and `cat a.gz b.gz` produce).
-bool inflate_stream(const uint8_t *in, size_t n, std::vector<uint8_t> &out, std::string &err) {
-    z_stream z{};
-    if (inflateInit2(&z, 15 + 16) != Z_OK) { err = "inflateInit2 failed"; return false; }
-    out.resize(std::max<size_t>(n * 4, 1 << 20));
-    size_t produced = 0;
-    z.next_in = const_cast<Bytef *>(in);
-    size_t left = n;
-    for (;;) {
-        z.avail_in = (uInt)std::min<size_t>(left, 1u << 30);
-        const size_t fed = z.avail_in;
-        if (out.size() - produced < (1u << 20)) out.resize(out.size() * 2);
-        z.next_out = out.data() + produced;
-        z.avail_out = (uInt)std::min<size_t>(out.size() - produced, 1u << 30);
-        const size_t room = z.avail_out;
-        const int rc = inflate(&z, Z_NO_FLUSH);
-        left -= fed - z.avail_in;
-        produced += room - z.avail_out;
-        if (rc == Z_STREAM_END) {
-            if (left == 0) break;
-            if (inflateReset(&z) != Z_OK) { err = "inflateReset failed"; inflateEnd(&z); return false; }
-            continue;
-        }
-        if (rc != Z_OK && rc != Z_BUF_ERROR) { err = std::string("inflate: ") + (z.msg ? z.msg : "corrupt data"); inflateEnd(&z); return false; }
-        if (rc == Z_BUF_ERROR && left == 0 && z.avail_out != 0) { err = "truncated gzip stream"; inflateEnd(&z); return false; }
-    }
-    inflateEnd(&z);
-    out.resize(produced);
-    return true;
-}
-
-}  // namespace
-}  // namespace pav
-
 using namespace pav;
 
 extern "C" {
@@ -106,65 +24,14 @@ extern "C" {
 int pav_fasta_open(const char *path, int threads, pav_fasta **out) {
     if (!path || !out) return PAV_E_ARG;
     *out = nullptr;
-    if (threads <= 0) threads = (int)std::min<unsigned>(std::max<unsigned>(std::thread::hardware_concurrency(), 1), 32);
-    Mapped m;
-    m.fd = open(path, O_RDONLY);
-    if (m.fd < 0) return fail(nullptr, PAV_E_ARG, "pav_fasta_open: cannot open %s", path);
-    struct stat sb;
-    if (fstat(m.fd, &sb) != 0) return fail(nullptr, PAV_E_ARG, "pav_fasta_open: cannot stat %s", path);
-    m.n = (size_t)sb.st_size;
-    if (m.n) {
-        void *p = mmap(nullptr, m.n, PROT_READ, MAP_PRIVATE, m.fd, 0);
-        if (p == MAP_FAILED) { m.n = 0; return fail(nullptr, PAV_E_ARG, "pav_fasta_open: cannot map %s", path); }
-        m.p = static_cast<const uint8_t *>(p);
-    }
+    if (threads <= 0) threads = default_host_threads();
+    FileText ft;
+    std::string err;
+    if (!read_file_text(path, threads, ft, err)) return fail(nullptr, PAV_E_ARG, "pav_fasta_open: %s", err.c_str());
     auto fa = new pav_fasta();
-
-    // ---- text of the file ------------------------------------------------------------------------------------
-    const uint8_t *text = m.p;
-    uint64_t n_text = m.n;
-    std::vector<uint8_t> inflated;
-    uint8_t *bg_text = nullptr;
-    if (m.n >= 2 && m.p[0] == 0x1f && m.p[1] == 0x8b) {
-        std::vector<Block> blocks;
-        uint64_t at = 0, total = 0, bsize = 0, hdr = 0;
-        bool bgzf = true;
-        while (at < m.n) {
-            if (!bgzf_block(m.p + at, m.n - at, bsize, hdr)) { bgzf = false; break; }
-            const uint8_t *tail = m.p + at + bsize - 4;
-            const uint64_t isize = tail[0] | (uint64_t)tail[1] << 8 | (uint64_t)tail[2] << 16 | (uint64_t)tail[3] << 24;
-            blocks.push_back(Block{at + hdr, bsize - hdr - 8, total, isize});
-            total += isize;
-            at += bsize;
-        }
-        if (bgzf) {
-            fa->kind = 2;
-            bg_text = static_cast<uint8_t *>(malloc(std::max<uint64_t>(total, 1)));
-            if (!bg_text) { delete fa; return fail(nullptr, PAV_E_ARG, "pav_fasta_open: out of memory (%llu bytes of text)", (unsigned long long)total); }
-            std::atomic<int> bad{0};
-            constexpr size_t STRIPE = 64;                        // blocks per work item
-            parallel_for((blocks.size() + STRIPE - 1) / STRIPE, threads, [&](size_t s) {
-                z_stream z{};
-                if (inflateInit2(&z, -15) != Z_OK) { bad = 1; return; }
-                for (size_t b = s * STRIPE; b < std::min(blocks.size(), (s + 1) * STRIPE); ++b) {
-                    const Block &k = blocks[b];
-                    z.next_in = const_cast<Bytef *>(m.p + k.in_off); z.avail_in = (uInt)k.in_len;
-                    z.next_out = bg_text + k.out_off; z.avail_out = (uInt)k.out_len;
-                    const int rc = k.out_len || k.in_len > 2 ? inflate(&z, Z_FINISH) : Z_STREAM_END;
-                    if (rc != Z_STREAM_END || z.avail_out != 0) bad = 1;
-                    inflateReset(&z);
-                }
-                inflateEnd(&z);
-            });
-            if (bad) { free(bg_text); delete fa; return fail(nullptr, PAV_E_ARG, "pav_fasta_open: corrupt BGZF block in %s", path); }
-            text = bg_text; n_text = total;
-        } else {
-            fa->kind = 1;
-            std::string err;
-            if (!inflate_stream(m.p, m.n, inflated, err)) { delete fa; return fail(nullptr, PAV_E_ARG, "pav_fasta_open: %s: %s", path, err.c_str()); }
-            text = inflated.data(); n_text = inflated.size();
-        }
-    }
+    fa->kind = ft.kind;
+    const uint8_t *text = ft.text;
+    const uint64_t n_text = ft.n;
 
     // ---- records: '>' at the start of a line -------------------------------------------------------------------
     struct Rec { uint64_t body, body_end; };
@@ -213,7 +80,7 @@ int pav_fasta_open(const char *path, int threads, pav_fasta **out) {
     }
     fa->bytes = total;
     fa->seq = static_cast<uint8_t *>(aligned_alloc(64, (std::max<uint64_t>(total, 1) + 63) & ~63ull));
-    if (!fa->seq) { free(bg_text); delete fa; return fail(nullptr, PAV_E_ARG, "pav_fasta_open: out of memory (%llu sequence bytes)", (unsigned long long)total); }
+    if (!fa->seq) { delete fa; return fail(nullptr, PAV_E_ARG, "pav_fasta_open: out of memory (%llu sequence bytes)", (unsigned long long)total); }
     parallel_for(pieces.size(), threads, [&](size_t i) {
         const Piece &pc = pieces[i];
         uint8_t *o = fa->seq + pc.out;
@@ -232,7 +99,6 @@ int pav_fasta_open(const char *path, int threads, pav_fasta **out) {
             q = e + 1;
         }
     });
-    free(bg_text);
     *out = fa;
     return PAV_OK;
 }

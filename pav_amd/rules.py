@@ -238,6 +238,44 @@ def call_inv_batch_merge(bed_list, bed_out=None):
 # rules call_inv_cluster (:603-692), call_inv_flag_insdel_cluster (:480-599), call_inv_merge_flagged_loci (:321-474)
 # ---------------------------------------------------------------------------------------------------------
 
+# ---------------------------------------------------------------------------------------------------------
+# rule align_get_read_bed (rules/align.snakefile:101-171)
+# ---------------------------------------------------------------------------------------------------------
+
+CALL_CIGAR_BATCH_COUNT = 10                                             # pavlib/cigarcall.py:21
+
+
+def align_get_read_bed(sam, tig_fai, hap, bed_out=None, align_head_out=None):
+    """Body of rule align_get_read_bed: SAM -> trim-none alignment table (+ the SAM header lines).  No GPU involved."""
+    import gzip
+    import os
+    from .align import get_align_bed
+    from .fasta import read_fai
+    if os.stat(sam).st_size == 0:                                       # :111-132 (sic: QRY_MAPPED, no QRY_LEN)
+        df = pd.DataFrame([], columns=['#CHROM', 'POS', 'END', 'INDEX', 'QRY_ID', 'QRY_POS', 'QRY_END', 'QRY_MAPPED', 'RG', 'AO',
+                                       'MAPQ', 'REV', 'FLAGS', 'HAP', 'CIGAR'])
+        if bed_out is not None:
+            df.to_csv(bed_out, sep='\t', index=False, compression='gzip')
+        if align_head_out is not None:
+            with open(align_head_out, 'w'):
+                pass
+        return df
+    df_tig_fai = read_fai(tig_fai).copy()
+    df_tig_fai.index = df_tig_fai.index.astype(str)                     # :135-136
+    df = get_align_bed(sam, df_tig_fai, hap)                            # :139
+    if align_head_out is not None:                                      # :142-161
+        with gzip.open(align_head_out, 'wb') as out_file:
+            out_file.write(df.attrs['sam_header'])
+    df['CALL_BATCH'] = df['INDEX'].apply(lambda val: val % CALL_CIGAR_BATCH_COUNT)   # :164
+    df['TRIM_REF_L'] = 0                                                # :167-170
+    df['TRIM_REF_R'] = 0
+    df['TRIM_QRY_L'] = 0
+    df['TRIM_QRY_R'] = 0
+    if bed_out is not None:
+        df.to_csv(bed_out, sep='\t', index=False, compression='gzip')   # :173
+    return df
+
+
 def _with_ctx(ctx, device_id):
     from . import _lib
     return (ctx, False) if ctx is not None else (_lib.Context(device_id), True)
