@@ -167,6 +167,12 @@ typedef struct {
     const char *insdel_path;      /* NULL = skip                                                                   */
     int32_t gzip_level;           /* 1..9, 0 = 6                                                                   */
     int32_t threads;              /* formatting / compression threads, 0 = auto                                    */
+    const int64_t *call_batch;    /* NULL: the tables of one call_cigar job.  [n_aln] CALL_BATCH of every row (0..15): the
+                                     *merged* tables of rule call_cigar_merge (rules/call.snakefile:755-786) when all rows of
+                                     a haplotype were called at once - the batch files are concatenated in batch order and
+                                     stable-sorted by (#CHROM, POS, END, ID) (INS / DEL) resp. (#CHROM, POS) only (SNV), so
+                                     equal keys keep batch order; needs <= 4096 reference records with non-numeric names
+                                     (pandas would re-read numeric names as integers and order them numerically)         */
 } pav_table_opts;
 int pav_cigar_write_tables(pav_ctx *ctx, const pav_table_opts *opts, uint64_t *n_snv_rows, uint64_t *n_insdel_rows);
 

@@ -113,7 +113,7 @@ KMER_LDS, KMER_HBM = 0, 1
 class TableOpts(ctypes.Structure):
     _fields_ = [('hap', ctypes.c_char_p), ('align_index', ctypes.c_void_p), ('trim_pos', ctypes.c_void_p),
                 ('trim_end', ctypes.c_void_p), ('snv_path', ctypes.c_char_p), ('insdel_path', ctypes.c_char_p),
-                ('gzip_level', ctypes.c_int32), ('threads', ctypes.c_int32)]
+                ('gzip_level', ctypes.c_int32), ('threads', ctypes.c_int32), ('call_batch', ctypes.c_void_p)]
 
 
 FLAG_RGN_DTYPE = np.dtype([('chrom', '<u4'), ('pad', '<u4'), ('pos', '<i8'), ('end', '<i8'), ('count', '<i8')])
@@ -403,14 +403,17 @@ class Context:
         return snv, indel, blob
 
     def cigar_write_tables(self, hap, align_index, trim_pos=None, trim_end=None, snv_path=None, insdel_path=None,
-                           gzip_level=0, threads=0):
-        """Write the SNV / INS-DEL tables of the last cigar_call natively (sorted, FILTER, pandas-identical text)."""
+                           gzip_level=0, threads=0, call_batch=None):
+        """Write the SNV / INS-DEL tables of the last cigar_call natively (sorted, FILTER, pandas-identical text).
+        ``call_batch`` (CALL_BATCH of every alignment row): write the merged tables of rule call_cigar_merge instead."""
+        cb = None if call_batch is None else np.ascontiguousarray(call_batch, dtype=np.int64)
         align_index = np.ascontiguousarray(align_index, dtype=np.int64)
         tp = None if trim_pos is None else np.ascontiguousarray(trim_pos, dtype=np.int64)
         te = None if trim_end is None else np.ascontiguousarray(trim_end, dtype=np.int64)
         opts = TableOpts(str(hap).encode(), align_index.ctypes.data, None if tp is None else tp.ctypes.data,
                          None if te is None else te.ctypes.data, None if snv_path is None else str(snv_path).encode(),
-                         None if insdel_path is None else str(insdel_path).encode(), int(gzip_level), int(threads))
+                         None if insdel_path is None else str(insdel_path).encode(), int(gzip_level), int(threads),
+                         None if cb is None else cb.ctypes.data)
         n1, n2 = ctypes.c_uint64(0), ctypes.c_uint64(0)
         self._check(self.lib.pav_cigar_write_tables(self.handle, ctypes.byref(opts), ctypes.byref(n1), ctypes.byref(n2)),
                     'pav_cigar_write_tables')

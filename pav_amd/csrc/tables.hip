@@ -22,14 +22,17 @@ struct SnvOut { uint32_t aln, pos, qry_pos; uint8_t ref, alt, pass, pad; };
 __device__ __forceinline__ uint8_t up8(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }
 
 // key = chrom rank | POS | REF.upper() | ALT.upper(): the order of (#CHROM, POS, END = POS + 1, ID) for SNV rows
+// merged tables (call_batch given): chrom rank (12 bits) | POS | CALL_BATCH (4 bits) | REF.upper() | ALT.upper() - the batch
+// files concatenated in batch order and stable-sorted by (#CHROM, POS) (rules/call.snakefile:777-786)
 __global__ __launch_bounds__(256) void snv_sort_keys(const pav_snv *__restrict__ snv, uint64_t n, const pav_aln *__restrict__ aln,
-                                                     const uint16_t *__restrict__ chrom_rank, unsigned long long *__restrict__ keys,
-                                                     uint32_t *__restrict__ vals) {
+                                                     const uint16_t *__restrict__ chrom_rank, const uint8_t *__restrict__ batch,
+                                                     unsigned long long *__restrict__ keys, uint32_t *__restrict__ vals) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const pav_snv s = snv[i];
     const uint64_t rank = chrom_rank[aln[s.aln].ref_id];
-    keys[i] = rank << 48 | (uint64_t)s.pos << 16 | (uint64_t)up8(s.ref) << 8 | up8(s.alt);
+    if (batch) keys[i] = rank << 52 | (uint64_t)s.pos << 20 | (uint64_t)batch[s.aln] << 16 | (uint64_t)up8(s.ref) << 8 | up8(s.alt);
+    else keys[i] = rank << 48 | (uint64_t)s.pos << 16 | (uint64_t)up8(s.ref) << 8 | up8(s.alt);
     vals[i] = (uint32_t)i;
 }
 
@@ -65,6 +68,22 @@ extern "C" int pav_cigar_write_tables(pav_ctx *ctx, const pav_table_opts *o, uin
     if (rnames.size() != n_ref || tnames.size() != n_tig) return fail(ctx, PAV_E_STATE, "pav_cigar_write_tables: pav_seq_set_names has not been called for both stores");
     if (n_ref > 65535) return fail(ctx, PAV_E_LIMIT, "pav_cigar_write_tables: more than 65535 reference records");
     const bool with_filter = o->trim_pos != nullptr;
+    const bool merged = o->call_batch != nullptr;
+    std::vector<uint8_t> batch8(merged ? n_aln : 0);
+    if (merged) {
+        if (n_ref > 4096) return fail(ctx, PAV_E_LIMIT, "pav_cigar_write_tables: merged tables need <= 4096 reference records");
+        for (uint32_t i = 0; i < n_aln; ++i) {
+            if (o->call_batch[i] < 0 || o->call_batch[i] > 15) return fail(ctx, PAV_E_LIMIT, "pav_cigar_write_tables: CALL_BATCH %lld of row %u is outside 0..15", (long long)o->call_batch[i], i);
+            batch8[i] = (uint8_t)o->call_batch[i];
+        }
+        for (uint32_t i = 0; i < n_ref; ++i) {
+            char *e = nullptr;
+            (void)strtod(rnames[i].c_str(), &e);
+            if (!rnames[i].empty() && e && *e == 0)
+                return fail(ctx, PAV_E_LIMIT, "pav_cigar_write_tables: reference name '%s' reads as a number: rule call_cigar_merge re-reads its "
+                            "inputs without a string dtype and would order such names numerically", rnames[i].c_str());
+        }
+    }
     int threads = o->threads > 0 ? o->threads : (int)std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
     const int level = o->gzip_level > 0 ? o->gzip_level : 6;
 
@@ -84,7 +103,7 @@ extern "C" int pav_cigar_write_tables(pav_ctx *ctx, const pav_table_opts *o, uin
         size_t tmp_bytes = 0;
         unsigned long long *kin = nullptr, *kout = nullptr; uint32_t *vin = nullptr, *vout = nullptr;
         PAV_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, kin, kout, vin, vout, (size_t)n_snv, 0, 64, st));
-        const size_t need = 2 * 8 * n_snv + 2 * 4 * n_snv + tmp_bytes + sizeof(SnvOut) * n_snv + 2 * n_ref + 16 * (size_t)n_aln + 1024;
+        const size_t need = 2 * 8 * n_snv + 2 * 4 * n_snv + tmp_bytes + sizeof(SnvOut) * n_snv + 2 * n_ref + 17 * (size_t)n_aln + 1024;
         PAV_HIP(ctx, ctx->d_tmp.reserve(need));
         uint8_t *p = ctx->d_tmp.as<uint8_t>();
         kin = reinterpret_cast<unsigned long long *>(p); p += 8 * n_snv;
@@ -95,14 +114,16 @@ extern "C" int pav_cigar_write_tables(pav_ctx *ctx, const pav_table_opts *o, uin
         vin = reinterpret_cast<uint32_t *>(p); p += 4 * n_snv;
         vout = reinterpret_cast<uint32_t *>(p); p += 4 * n_snv;
         uint16_t *d_rank = reinterpret_cast<uint16_t *>(p); p += (2 * (size_t)n_ref + 15) / 16 * 16;
+        uint8_t *d_batch = p; p += ((size_t)n_aln + 15) / 16 * 16;
         void *d_sort_tmp = p;
+        if (merged && n_aln) PAV_HIP(ctx, hipMemcpyAsync(d_batch, batch8.data(), n_aln, hipMemcpyHostToDevice, st));
         PAV_HIP(ctx, hipMemcpyAsync(d_rank, rank.data(), 2 * (size_t)n_ref, hipMemcpyHostToDevice, st));
         if (with_filter) {
             PAV_HIP(ctx, hipMemcpyAsync(d_tp, o->trim_pos, 8 * (size_t)n_aln, hipMemcpyHostToDevice, st));
             PAV_HIP(ctx, hipMemcpyAsync(d_te, o->trim_end, 8 * (size_t)n_aln, hipMemcpyHostToDevice, st));
         }
         PAV_LAUNCH(ctx, "snv_sort_keys", snv_sort_keys, (uint32_t)((n_snv + 255) / 256), 256, 0, ctx->d_snv.as<pav_snv>(), n_snv,
-                   ctx->d_aln.as<pav_aln>(), d_rank, kin, vin);
+                   ctx->d_aln.as<pav_aln>(), d_rank, merged ? d_batch : nullptr, kin, vin);
         {
             int tok = prof_begin(ctx, "rocprim::radix_sort_pairs");
             hipError_t e = rocprim::radix_sort_pairs(d_sort_tmp, tmp_bytes, kin, kout, vin, vout, (size_t)n_snv, 0, 64, st);
@@ -164,6 +185,7 @@ extern "C" int pav_cigar_write_tables(pav_ctx *ctx, const pav_table_opts *o, uin
             if (p.end != q.end) return p.end < q.end;
             if (p.svtype != q.svtype) return p.svtype > q.svtype;            // 'DEL' < 'INS' (svtype 1 = DEL)
             if (p.svlen != q.svlen) return dec(p.svlen) < dec(q.svlen);      // ID compares the decimal strings
+            if (merged && batch8[p.aln] != batch8[q.aln]) return batch8[p.aln] < batch8[q.aln];   // equal keys keep concat order
             return false;
         });
         std::string header = "#CHROM\tPOS\tEND\tID\tSVTYPE\tSVLEN\tHAP\tQRY_REGION\tQRY_STRAND\tCI\tALIGN_INDEX\tLEFT_SHIFT\tHOM_REF\tHOM_TIG\tCALL_SOURCE\tSEQ";

@@ -97,6 +97,46 @@ def call_cigar(bed, bed_trim, tig_fa_name, ref_fa_name, hap, batch, bed_insdel=N
     return df_snv, df_insdel
 
 
+def call_cigar_merged_files(bed, bed_trim, tig_fa_name, ref_fa_name, hap, bed_insdel, bed_snv, ctx=None, device_id=0, threads=0):
+    """Rules call_cigar (all CALL_BATCH values) + call_cigar_merge in one pass: every alignment row of the haplotype is called at
+    once and ``pav_cigar_write_tables`` writes the *merged* tables (rules/call.snakefile:755-786) - the row order of the batch
+    files concatenated in batch order and stable-sorted, which the writer reproduces from CALL_BATCH.  Same text as
+    :func:`call_cigar_files` x 10 -> :func:`call_cigar_merge`.  Returns ``(n_snv_rows, n_insdel_rows)``."""
+    import numpy as np
+    from . import _lib
+    table = _lib.BedTable(bed, with_cigar=True)
+    trim_table = _lib.BedTable(bed_trim, with_cigar=False)
+    own = ctx is None
+    if own:
+        ctx = _lib.Context(device_id)
+    try:
+        cols = table.fetch()
+        if table.n_rows:
+            cigarcall.load_sequences(ctx, ref_fa_name, tig_fa_name, names=(table.chrom_names, table.qry_names))
+        else:
+            ctx.seq_load(_lib.PAV_ROLE_REF, [], [])
+            ctx.seq_load(_lib.PAV_ROLE_TIG, [], [])
+        index = ctx.cigar_load_bed(table, -1)                                        # every row, table order
+        try:
+            ctx.cigar_call()
+        except _lib.CigarDeviceError as ex:
+            if ex.detail is None:
+                raise
+            df_err = pd.DataFrame({'#CHROM': [table.chrom_names[i] for i in cols['#CHROM']], 'POS': cols['POS'],
+                                   'QRY_ID': [table.qry_names[i] for i in cols['QRY_ID']], 'INDEX': cols['INDEX']})
+            cigarcall._raise_reference_error(ex.detail, df_err)
+        tc = trim_table.fetch()
+        trim = pd.DataFrame({'POS': tc['POS'], 'END': tc['END']}, index=tc['INDEX']).astype(int).reindex(list(index), fill_value=-1)
+        batch = cols['CALL_BATCH'] if table.n_rows else np.zeros(0, dtype=np.int64)
+        return ctx.cigar_write_tables(hap, index, trim['POS'].to_numpy(dtype='int64'), trim['END'].to_numpy(dtype='int64'),
+                                      snv_path=bed_snv, insdel_path=bed_insdel, threads=threads, call_batch=batch)
+    finally:
+        table.close()
+        trim_table.close()
+        if own:
+            ctx.close()
+
+
 def call_cigar_merge(bed_insdel_list, bed_snv_list, out_insdel=None, out_snv=None):
     """Body of rule call_cigar_merge (rules/call.snakefile:763-786)."""
     df_insdel = pd.concat(

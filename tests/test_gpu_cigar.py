@@ -156,6 +156,54 @@ def test_native_rule_files_equal_the_reference_rules(built, gpu_ctx, tmp_path):
             assert fh.read() == util.golden_text('rule_call_cigar', want)
 
 
+def test_merged_tables_in_one_pass_equal_the_reference_rules(built, gpu_ctx, tmp_path):
+    """rules.call_cigar_merged_files: all rows called at once, merged tables written from CALL_BATCH - vs the text of the
+    reference's call_cigar x 10 -> call_cigar_merge (tests/golden/rule_call_cigar): byte-identical."""
+    import gzip
+    d, df_align, df_trim = util.golden_case('cigar_synth')
+    assert df_align['CALL_BATCH'].nunique() > 3
+    m1, m2 = str(tmp_path / 'insdel.bed.gz'), str(tmp_path / 'snv.bed.gz')
+    n_snv, n_ins = rules.call_cigar_merged_files(f'{d}/align.tsv', f'{d}/trim.tsv', f'{d}/tig.fa', f'{d}/ref.fa', 'h1', m1, m2, ctx=gpu_ctx)
+    assert n_snv > 0 and n_ins > 0
+    for got, want in ((m1, 'insdel_merged'), (m2, 'snv_merged')):
+        with gzip.open(got, 'rt') as fh:
+            assert fh.read() == util.golden_text('rule_call_cigar', want)
+
+
+def test_merged_tables_keep_batch_order_on_ties(built, gpu_ctx, tmp_path):
+    """Seeded haplotype with overlapping alignment rows (the same SNV / indel called from several rows, in different batches):
+    the one-pass merged tables equal call_cigar_files x 10 -> the pandas merge of rule call_cigar_merge."""
+    import gzip
+    hap = synth.config2(seed=91, scale=0.003, threads=2)
+    df = synth.split_overlaps(hap.df_align, 7) if hasattr(synth, 'split_overlaps') else hap.df_align
+    df = df.copy()
+    df['CALL_BATCH'] = df['INDEX'] % 10
+    bed, trim = str(tmp_path / 'align.bed.gz'), str(tmp_path / 'trim.bed.gz')
+    df.to_csv(bed, sep='\t', index=False, compression='gzip')
+    df.iloc[::2].to_csv(trim, sep='\t', index=False, compression='gzip')        # half of the rows survive trimming
+    ref_fa, tig_fa = str(tmp_path / 'ref.fa'), str(tmp_path / 'tig.fa')
+    with open(ref_fa, 'wb') as fh:
+        for n in hap.ref.names:
+            fh.write(b'>' + n.encode() + b'\n' + hap.ref.seqs[n].tobytes() + b'\n')
+    with open(tig_fa, 'wb') as fh:
+        for n in hap.tig_names:
+            fh.write(b'>' + n.encode() + b'\n' + hap.tig_seqs[n].tobytes() + b'\n')
+    ins, snvs = [], []
+    for batch in range(10):
+        o1, o2 = str(tmp_path / f'insdel_{batch}.bed.gz'), str(tmp_path / f'snv_{batch}.bed.gz')
+        rules.call_cigar_files(bed, trim, tig_fa, ref_fa, 'h2', batch, o1, o2, ctx=gpu_ctx)
+        ins.append(o1)
+        snvs.append(o2)
+    w1, w2 = str(tmp_path / 'want_insdel.bed.gz'), str(tmp_path / 'want_snv.bed.gz')
+    df_snv, _ = rules.call_cigar_merge(ins, snvs, w1, w2)
+    assert df_snv.duplicated(['#CHROM', 'POS']).sum() > 10                      # ties exist: batch order decides
+    m1, m2 = str(tmp_path / 'insdel.bed.gz'), str(tmp_path / 'snv.bed.gz')
+    rules.call_cigar_merged_files(bed, trim, tig_fa, ref_fa, 'h2', m1, m2, ctx=gpu_ctx)
+    for got, want in ((m1, w1), (m2, w2)):
+        with gzip.open(got, 'rb') as a, gzip.open(want, 'rb') as b:
+            assert a.read() == b.read()
+
+
 def test_native_writer_large_random(built, gpu_ctx, tmp_path):
     """Seeded haplotype with sort ties (overlapping rows, dense inversion SNV runs): native text == pandas mirror text."""
     hap = synth.config2(seed=23, scale=0.01, threads=4)
