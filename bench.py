@@ -39,8 +39,8 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_M
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--scale', type=float, default=1.0, help='shrink every sequence length (tests only; 1.0 = the named workload)')
     ap.add_argument('--seed', type=int, default=1002)
     ap.add_argument('--cpu-sample-bp', type=float, default=4e9,

@@ -77,10 +77,15 @@ __global__ __launch_bounds__(256) void k_cluster_emit(const uint64_t *__restrict
 constexpr uint64_t SNV_SENTINEL = (1ull << 56) - 1;          // FILTER != PASS rows sort behind every chromosome
 constexpr uint64_t IND_SENTINEL = (1ull << 54) - 1;
 
-// One atomic per wave for a per-thread partial count (the kernels below are grid-stride: a few thousand atomics in all).
-__device__ __forceinline__ void wave_add(unsigned long long v, unsigned long long *counter) {
+// One atomic per workgroup for a per-thread partial count: thousands of waves adding to one word serialise at ~11 ns each
+// (k_indel_keys spent 0.18 of its 0.20 ms there with one atomic per wave).  All 256 threads of the block must call it.
+__device__ __forceinline__ void block_add(unsigned long long v, unsigned long long *counter) {
+    __shared__ unsigned long long part[4];
     for (int o = WAVE / 2; o; o >>= 1) v += __shfl_down(v, o);
-    if ((threadIdx.x & (WAVE - 1)) == 0 && v) atomicAdd(counter, v);
+    __syncthreads();                                                    // `part` may still be read from a previous call
+    if ((threadIdx.x & (WAVE - 1)) == 0) part[threadIdx.x / WAVE] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { const unsigned long long t = part[0] + part[1] + part[2] + part[3]; if (t) atomicAdd(counter, t); }
 }
 
 // cluster key of every SNV row: rank << 40 | POS (the midpoint of [POS, POS + 1) is POS).
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(256) void k_snv_keys(const pav_snv *__restrict__ sn
         keys[i] = pass ? ((unsigned long long)rank[aln[s.aln].ref_id] << CM_SHIFT | s.pos) : SNV_SENTINEL;
         mine += pass;
     }
-    wave_add(mine, n_pass);
+    block_add(mine, n_pass);
 }
 
 // cluster key of every indel row < 50 bp: rank << 38 | POS << 6 | (END - POS): the (#CHROM, POS, END) order of the table.
@@ -113,8 +118,8 @@ __global__ __launch_bounds__(256) void k_indel_keys(const pav_indel *__restrict_
         n_pass += pass;
         n_small += small;
     }
-    wave_add(n_pass, counters);
-    wave_add(n_small, counters + 1);
+    block_add(n_pass, counters);
+    block_add(n_small, counters + 1);
 }
 
 __global__ __launch_bounds__(256) void k_indel_mid(unsigned long long *__restrict__ keys, uint64_t n) {
@@ -141,17 +146,29 @@ __global__ __launch_bounds__(256) void k_insdel_split(const pav_indel *__restric
         keep = (long long)v.pos > tpos[v.aln] && (long long)v.end < tend[v.aln] && v.svlen >= svlen_lo && v.svlen < svlen_hi;
     }
     const unsigned long long r = keep ? rank[aln[v.aln].ref_id] : 0;
-    // wave-aggregated append (the DEL rows are sorted afterwards and the INS order does not matter)
+    // block-aggregated append (the DEL rows are sorted afterwards and the INS order does not matter): ranks inside the block
+    // from wave ballots + the waves' totals in LDS, one returning atomic per block and kind
+    __shared__ uint32_t wtot[2][4];
+    __shared__ unsigned long long base[2];
+    const int wave = threadIdx.x / WAVE;
+    unsigned long long m[2];
     for (int t = 0; t < 2; ++t) {
         const bool mine = keep && v.svtype == (t == 0 ? 1 : 0);
-        const unsigned long long m = __ballot(mine);
-        if (!m) continue;
-        const int leader = __ffsll((long long)m) - 1;
-        unsigned long long base = 0;
-        if (lane == leader) base = atomicAdd(counters + t, (unsigned long long)__popcll(m));
-        base = __shfl(base, leader);
+        m[t] = __ballot(mine);
+        if (lane == 0) wtot[t][wave] = (uint32_t)__popcll(m[t]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const uint32_t tot = wtot[threadIdx.x][0] + wtot[threadIdx.x][1] + wtot[threadIdx.x][2] + wtot[threadIdx.x][3];
+        base[threadIdx.x] = tot ? atomicAdd(counters + threadIdx.x, (unsigned long long)tot) : 0ull;
+    }
+    __syncthreads();
+    for (int t = 0; t < 2; ++t) {
+        const bool mine = keep && v.svtype == (t == 0 ? 1 : 0);
         if (!mine) continue;
-        const unsigned long long s = base + __popcll(m & ((1ull << lane) - 1));
+        uint32_t before = 0;
+        for (int w = 0; w < wave; ++w) before += wtot[t][w];
+        const unsigned long long s = base[t] + before + __popcll(m[t] & ((1ull << lane) - 1));
         if (t == 0) { del_key[s] = r << 32 | v.pos; del_end[s] = r << 32 | v.end; }
         else { ins_key[s] = r << 32 | v.pos; ins_len[s] = v.svlen; }
     }
@@ -529,13 +546,13 @@ int pav_cigar_flag(pav_ctx *ctx, const int64_t *trim_pos, const int64_t *trim_en
     // ---- keys of both cluster tables, sorted into the rules' iteration order --------------------------------------------
     if (n_snv) {
         PAV_HIP(ctx, S->a.reserve(8 * n_snv)); PAV_HIP(ctx, S->b.reserve(8 * n_snv));
-        PAV_LAUNCH(ctx, "k_snv_keys", k_snv_keys, (uint32_t)std::min<uint64_t>((n_snv + 255) / 256, 8u * (uint32_t)ctx->n_cu), 256, 0, ctx->d_snv.as<pav_snv>(), n_snv, d_aln, d_rank,
+        PAV_LAUNCH(ctx, "k_snv_keys", k_snv_keys, (uint32_t)std::min<uint64_t>((n_snv + 255) / 256, 4u * (uint32_t)ctx->n_cu), 256, 0, ctx->d_snv.as<pav_snv>(), n_snv, d_aln, d_rank,
                    d_tp, d_te, S->a.as<unsigned long long>(), d_cnt);
         if ((rc = sort_keys(ctx, S, S->a.as<unsigned long long>(), S->b.as<unsigned long long>(), n_snv, 56)) != PAV_OK) return rc;
     }
     if (n_ind) {
         PAV_HIP(ctx, S->c.reserve(8 * n_ind)); PAV_HIP(ctx, S->d.reserve(8 * n_ind));
-        PAV_LAUNCH(ctx, "k_indel_keys", k_indel_keys, (uint32_t)std::min<uint64_t>((n_ind + 255) / 256, 8u * (uint32_t)ctx->n_cu), 256, 0, ctx->d_indel.as<pav_indel>(), n_ind, d_aln, d_rank,
+        PAV_LAUNCH(ctx, "k_indel_keys", k_indel_keys, (uint32_t)std::min<uint64_t>((n_ind + 255) / 256, 4u * (uint32_t)ctx->n_cu), 256, 0, ctx->d_indel.as<pav_indel>(), n_ind, d_aln, d_rank,
                    d_tp, d_te, S->c.as<unsigned long long>(), d_cnt + 1);
         if ((rc = sort_keys(ctx, S, S->c.as<unsigned long long>(), S->d.as<unsigned long long>(), n_ind, 54)) != PAV_OK) return rc;
     }
