@@ -172,6 +172,8 @@ def main():
         ctx.seq_pack(_lib.PAV_ROLE_TIG)
         c = ctx.cigar_call()
         lap('cigar_call')
+        if workload == 'cigar+verify':
+            inv_state['verify'] = ctx.cigar_verify()
         if workload == 'cigar+inv':
             import contextlib
             inv_state['flag'] = ctx.cigar_flag(flag_tp, flag_te, flag_params)   # signature flagging of the fresh calls
@@ -219,28 +221,33 @@ def main():
     ctx.prof_enable(False)
 
     # ---- configs[1] in the same run: K steps of CIGAR-call only, timed and event-profiled the same way ----------------
-    cigar_leg = None
-    if args.workload == 'cigar+inv':
+    def side_leg(workload):
         for _ in range(max(1, args.warmup)):
-            step('cigar')
+            step(workload)
         fence()
-        t0 = time.perf_counter()
+        t_a = time.perf_counter()
         for _ in range(args.steps):
-            step('cigar')
+            step(workload)
         ctx.sync()
         torch.cuda.synchronize()
-        t_c = time.perf_counter() - t0
+        t_c = time.perf_counter() - t_a
         fence()
         if world > 1:
-            tt = torch.tensor([t_c], dtype=torch.float64, device=comm_device)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            t_c = float(tt.item())
+            tt_ = torch.tensor([t_c], dtype=torch.float64, device=comm_device)
+            dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+            t_c = float(tt_.item())
         ctx.prof_reset()
         ctx.prof_enable(True)
         for _ in range(args.steps):
-            step('cigar')
-        cigar_leg = {'t': t_c, 'prof': ctx.prof_read()}
+            step(workload)
+        leg = {'t': t_c, 'prof': ctx.prof_read()}
         ctx.prof_enable(False)
+        return leg
+
+    cigar_leg = side_leg('cigar') if args.workload == 'cigar+inv' else None
+    # ---- verify mode (second line): CIGAR-call + a pass over both packed sequences that checks every
+    #      '=' / 'X' base against the CIGAR; never mixed into `value` ------------------------------------------------------
+    verify_leg = side_leg('cigar+verify')
 
     # D2H of the record streams (reported, never part of `value`)
     t0 = time.perf_counter()
@@ -324,12 +331,13 @@ def main():
         except (OSError, KeyError, ValueError):
             pmc = None
 
-        def make_roofline(prof_):
+        def make_roofline(prof_, want=None):
             """Dominant kernel (largest total time in the profiled steps) against the HBM roofline: algorithmic bytes per
             launch / average launch duration from HIP events on the library's streams."""
             kern_ = {k: {'launches': v[0], 'avg_ms': v[1] / max(1, v[0])} for k, v in prof_.items()}
-            dom = max(kern_, key=lambda k: kern_[k]['avg_ms'] * kern_[k]['launches'])
+            dom = want or max(kern_, key=lambda k: kern_[k]['avg_ms'] * kern_[k]['launches'])
             alg_bytes = {
+                'verify_kernel': 0.75 * float(counts.aligned_bases),          # 0.375 B of packed planes per base, both sequences
                 'pack_kernel': tig_bases * (1.0 + 0.25 + 0.125),
                 'tok_count': float(text.shape[0]),
                 'tok_emit': float(text.shape[0]) + 4.0 * n_ops,
@@ -368,6 +376,14 @@ def main():
                                                     for k in sorted(alg_bytes) if k in kern_ and kern_[k]['avg_ms'] > 0}}
 
         kern, roofline = make_roofline(prof)
+        _, roof_v = make_roofline(verify_leg['prof'], want='verify_kernel')
+        vres = inv_state['verify']
+        verify_mode = {'workload': 'CIGAR-call + verify: the packed reference and contig are streamed along every = / X operation and '
+                                   'every base is checked against the CIGAR (pav_cigar_verify; the reference never looks at = runs)',
+                       'value': round(aligned_total * args.steps / verify_leg['t'] / 1e9, 2), 'unit': 'Gbp/s',
+                       'ms_per_step': round(verify_leg['t'] / args.steps * 1e3, 4), 'steps': args.steps,
+                       'bases_checked': vres['eq_bases'] + vres['x_bases'], 'bases_contradicting_the_cigar': vres['eq_mismatch'] + vres['x_match'],
+                       'roofline': roof_v}
         cigar_only = None
         if cigar_leg is not None:
             _, roof_c = make_roofline(cigar_leg['prof'])
@@ -495,7 +511,7 @@ def main():
                        'scale': args.scale, 'seed': args.seed, 'aligned_bp_per_gpu': int(counts.aligned_bases),
                        'n_aln': int(aln.shape[0]), 'n_ops': int(n_ops), 'n_snv': int(n_snv), 'n_indel': int(n_indel),
                        'parallelism': f'{world} x (1 haplotype / GPU), no collective'},
-            'roofline': roofline, 'cpu_baseline': cpu, 'cigar_only': cigar_only, 'inv_scan': inv_report,
+            'roofline': roofline, 'cpu_baseline': cpu, 'cigar_only': cigar_only, 'verify_mode': verify_mode, 'inv_scan': inv_report,
             'end_to_end': e2e,
             'host': {'generate_s': round(t_gen, 1), 'h2d_and_ref_pack_s': round(t_h2d, 2), 'd2h_records_s': round(t_d2h, 3),
                      'device': ctx.device_name},

@@ -150,6 +150,14 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts);
 int pav_cigar_error(const pav_ctx *ctx, pav_cigar_err *err);
 /* Copy results to caller buffers sized from pav_cigar_counts (any pointer may be NULL to skip it). */
 int pav_cigar_fetch(pav_ctx *ctx, pav_snv *snv, pav_indel *indel, uint8_t *seq_blob);
+/* Verify mode: stream the packed reference and contig along every '=' / 'X' operation of the
+ * last pav_cigar_call and count the bases that contradict the CIGAR - the reference trusts the aligner and never looks
+ * at '=' runs (pavlib/cigarcall.py:91-93).  A base of an '=' run is wrong when the two codes differ or exactly one side
+ * is non-ACGT; a base of an 'X' run is wrong when both sides are the same ACGT base or both are non-ACGT (case is folded,
+ * contigs of reverse rows are read reverse-complemented).  first_bad_op: smallest global operation ordinal with a wrong
+ * base (see pav_cigar_fetch_ops), ~0 when none.  One HBM-bound kernel: 0.75 B of packed planes per aligned base. */
+typedef struct { uint64_t eq_bases, eq_mismatch, x_bases, x_match, first_bad_op; } pav_verify_counts;
+int pav_cigar_verify(pav_ctx *ctx, pav_verify_counts *counts);
 /* Tokenised operations of the last pav_cigar_call: ops[i] = len << 4 | BAM opcode; op_off has n_aln + 1 entries. */
 int pav_cigar_fetch_ops(pav_ctx *ctx, uint32_t *ops, uint64_t *op_off);
 

@@ -180,6 +180,7 @@ SYMBOLS = {
     'pav_last_error': (ctypes.c_char_p, [_P]),
     'pav_device_name': (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int]),
     'pav_sync': (ctypes.c_int, [_P]),
+    'pav_cigar_verify': (ctypes.c_int, [_P, _P]),
     'pav_seq_load': (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_uint32, _P, _P]),
     'pav_seq_pack': (ctypes.c_int, [_P, ctypes.c_int]),
     'pav_seq_count': (ctypes.c_int, [_P, ctypes.c_int, _P, _P]),
@@ -523,6 +524,14 @@ class Context:
         tables = {name: self._copy_out(res.tables[i], res.n[i], FLAG_RGN_DTYPE) for i, name in enumerate(FLAG_TABLES)}
         loci = self._copy_out(res.loci, res.n_loci, FLAG_LOCUS_DTYPE)
         return tables, loci, {'n_snv_pass': int(res.n_snv_pass), 'n_indel_pass': int(res.n_indel_pass)}
+
+    def cigar_verify(self):
+        """Verify mode: -> dict(eq_bases, eq_mismatch, x_bases, x_match, first_bad_op) for the last cigar_call."""
+        c = (ctypes.c_uint64 * 5)()
+        self._check(self.lib.pav_cigar_verify(self.handle, c), 'pav_cigar_verify')
+        first = int(c[4])
+        return {'eq_bases': int(c[0]), 'eq_mismatch': int(c[1]), 'x_bases': int(c[2]), 'x_match': int(c[3]),
+                'first_bad_op': None if first == 0xFFFFFFFFFFFFFFFF else first}
 
     def cigar_fetch_ops(self, n_ops, n_aln):
         ops = np.empty(n_ops, dtype=np.uint32)

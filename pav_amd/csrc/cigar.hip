@@ -393,6 +393,213 @@ __global__ __launch_bounds__(256) void snv_bases(pav_snv *__restrict__ snv, uint
     snv[i] = s;
 }
 
+// ---- verify mode ----------------------------------------------------------------------------------------------------------
+// Streams both packed sequences along every '=' and 'X' operation and checks what the aligner claimed: every base of an '='
+// run equal, every base of an 'X' run different (SURVEY.md section 8(d) "verify mode"; the reference trusts the CIGAR -
+// pavlib/cigarcall.py:91-93 skips '=' runs without looking at them).  The HBM-bound member of the call path: 0.375 B of packed
+// planes per reference base + 0.375 B per contig base.  Operation positions come from the same block scan as walk_emit; the
+// workgroup then cuts its runs into 64-base pieces, one lane per piece (one unaligned 128-bit window of each 2-bit plane,
+// reversed and complemented for reverse-strand rows).
+struct VerifyArgs {
+    const uint32_t *ops; uint64_t n_ops;
+    const uint64_t *op_off; const pav_aln *aln; uint32_t n_aln;
+    const uint64_t *chunk_pre; const uint64_t *rowbase;
+    SeqView ref, tig;
+    unsigned long long *cnt;             // [0] '=' bases, [1] of them different, [2] 'X' bases, [3] of them equal, [4] first bad op
+};
+
+typedef unsigned __int128 u128;
+constexpr uint32_t VPIECE = 64;                                        // bases per lane and step
+
+__device__ __forceinline__ u128 window128(const uint32_t *__restrict__ two, uint64_t a) {            // 64 bases from position a
+    const uint64_t *two64 = reinterpret_cast<const uint64_t *>(two);
+    const uint64_t w = a >> 5;
+    const int b = (int)(a & 31) * 2;
+    const uint64_t v0 = two64[w], v1 = two64[w + 1], v2 = two64[w + 2];
+    const uint64_t lo = b ? (v0 >> b | v1 << (64 - b)) : v0, hi = b ? (v1 >> b | v2 << (64 - b)) : v1;
+    return (u128)hi << 64 | lo;
+}
+__device__ __forceinline__ uint64_t window64(const uint32_t *__restrict__ mask, uint64_t a) {         // 64 mask bits from position a
+    const uint64_t *m64 = reinterpret_cast<const uint64_t *>(mask);
+    const uint64_t w = a >> 6;
+    const int b = (int)(a & 63);
+    const uint64_t v0 = m64[w], v1 = m64[w + 1];
+    return b ? (v0 >> b | v1 << (64 - b)) : v0;
+}
+__device__ __forceinline__ uint64_t spread32(uint32_t x32) {                                          // bit i -> bit 2i
+    uint64_t x = x32;
+    x = (x | x << 16) & 0x0000FFFF0000FFFFull; x = (x | x << 8) & 0x00FF00FF00FF00FFull; x = (x | x << 4) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | x << 2) & 0x3333333333333333ull; x = (x | x << 1) & 0x5555555555555555ull;
+    return x;
+}
+__device__ __forceinline__ u128 spread64(uint64_t m) { return (u128)spread32((uint32_t)(m >> 32)) << 64 | spread32((uint32_t)m); }
+__device__ __forceinline__ u128 brev128(u128 x) { return (u128)__brevll((uint64_t)x) << 64 | __brevll((uint64_t)(x >> 64)); }
+__device__ __forceinline__ int popc128(u128 x) { return __popcll((uint64_t)x) + __popcll((uint64_t)(x >> 64)); }
+
+__global__ __launch_bounds__(256) void verify_kernel(VerifyArgs A) {
+    __shared__ uint64_t lds[4 * NQ];
+    __shared__ uint32_t s_row0;
+    __shared__ uint64_t d_ref[WALK_CHUNK], d_tig[WALK_CHUNK];
+    __shared__ uint32_t d_len[WALK_CHUNK];                               // len << 2 | rev << 1 | is 'X'; 0 = nothing to check
+    const uint64_t first = (uint64_t)blockIdx.x * WALK_CHUNK + (uint64_t)threadIdx.x * OPS_PER_LANE;
+    uint32_t o[OPS_PER_LANE];
+    load_ops(A.ops, A.n_ops, first, o);
+    uint64_t run[NQ] = {0, 0, 0, 0, 0, 0}, tot[NQ];
+#pragma unroll
+    for (int j = 0; j < OPS_PER_LANE; ++j) {
+        uint64_t c[NQ];
+        op_contrib(o[j], c);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) run[q] += c[q];
+    }
+    block_excl_scan<NQ>(run, tot, lds);
+    run[0] += A.chunk_pre[(uint64_t)blockIdx.x * NQ + 0];
+    run[1] += A.chunk_pre[(uint64_t)blockIdx.x * NQ + 1];
+    if (threadIdx.x == 0) {
+        const uint64_t f0 = (uint64_t)blockIdx.x * WALK_CHUNK;
+        uint32_t lo = 0, hi = A.n_aln;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (A.op_off[mid] <= f0) lo = mid; else hi = mid; }
+        s_row0 = lo;
+    }
+#pragma unroll
+    for (int j = 0; j < OPS_PER_LANE; ++j) d_len[threadIdx.x * OPS_PER_LANE + j] = 0;
+    __syncthreads();
+    if (first < A.n_ops) {
+        uint32_t row = s_row0;
+        uint64_t row_end = A.op_off[row + 1];
+        while (row_end <= first) { ++row; row_end = A.op_off[row + 1]; }
+        pav_aln al = A.aln[row];
+        uint64_t rb_ref = A.rowbase[2ull * row], rb_tig = A.rowbase[2ull * row + 1];
+#pragma unroll
+        for (int j = 0; j < OPS_PER_LANE; ++j) {
+            const uint64_t k = first + j;
+            if (k >= A.n_ops) break;
+            while (k >= row_end) {
+                ++row; row_end = A.op_off[row + 1];
+                al = A.aln[row];
+                rb_ref = A.rowbase[2ull * row]; rb_tig = A.rowbase[2ull * row + 1];
+            }
+            const uint32_t code = o[j] & 15u, len = o[j] >> 4;
+            if ((code == 7 || code == 8) && len) {
+                const uint64_t pos_ref = (uint64_t)al.pos + (run[0] - rb_ref), pos_tig = run[1] - rb_tig;
+                const uint64_t tlen = A.tig.len[al.tig_id];
+                const int slot = threadIdx.x * OPS_PER_LANE + j;
+                d_ref[slot] = A.ref.off[al.ref_id] + pos_ref;
+                // forward rows: first base of the run; reverse rows: the stored base that is oriented base 0 (runs downwards)
+                d_tig[slot] = A.tig.off[al.tig_id] + (al.rev ? tlen - 1 - pos_tig : pos_tig);
+                d_len[slot] = len << 2 | (al.rev ? 2u : 0u) | (code == 8 ? 1u : 0u);
+            }
+            uint64_t c[NQ];
+            op_contrib(o[j], c);
+            run[0] += c[0]; run[1] += c[1];
+        }
+    }
+    __syncthreads();
+    // The runs are cut into 64-base pieces (one lane, one window of each plane); a block scan numbers the pieces of the chunk
+    // and every lane takes pieces t, t + 256, ... - an 'X' of one base costs one lane, not one wave; consecutive lanes read
+    // consecutive windows of the same run.
+    __shared__ uint32_t s_pre[WALK_CHUNK + 1];
+    {
+        uint64_t mine[1] = {0}, all[1];
+        uint32_t np[OPS_PER_LANE];
+#pragma unroll
+        for (int j = 0; j < OPS_PER_LANE; ++j) { np[j] = ((d_len[threadIdx.x * OPS_PER_LANE + j] >> 2) + VPIECE - 1) / VPIECE; mine[0] += np[j]; }
+        block_excl_scan<1>(mine, all, lds);
+        uint32_t at = (uint32_t)mine[0];
+#pragma unroll
+        for (int j = 0; j < OPS_PER_LANE; ++j) { s_pre[threadIdx.x * OPS_PER_LANE + j] = at; at += np[j]; }
+        if (threadIdx.x == 255) s_pre[WALK_CHUNK] = (uint32_t)all[0];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long n_eq = 0, bad_eq = 0, n_x = 0, bad_x = 0, first_bad = ~0ull;
+    const uint32_t n_pieces = s_pre[WALK_CHUNK];
+    // coarse index: the slot that owns piece 256 m, so that a lane only searches the few slots its group of 256 pieces spans
+    constexpr uint32_t TBL = 1024;
+    __shared__ uint16_t tbl[TBL + 1];
+    const uint32_t n_grp = (n_pieces + 255) / 256;
+    const bool use_tbl = n_grp <= TBL;
+    if (use_tbl) {
+#pragma unroll
+        for (int j = 0; j < OPS_PER_LANE; ++j) {
+            const uint32_t q = threadIdx.x * OPS_PER_LANE + j, s0 = s_pre[q], e0 = s_pre[q + 1];
+            for (uint32_t m = (s0 + 255) / 256; m * 256 < e0; ++m) tbl[m] = (uint16_t)q;
+        }
+        if (threadIdx.x == 0) tbl[n_grp] = WALK_CHUNK - 1;
+    }
+    __syncthreads();
+    constexpr int UNROLL = 2;                                            // pieces in flight per lane: the loads of both are
+    for (uint32_t g0 = 0; g0 < n_grp; g0 += UNROLL) {                    // issued before the first compare
+        uint32_t q[UNROLL], n[UNROLL];
+        u128 xr[UNROLL], xt[UNROLL];
+        uint64_t mr[UNROLL], mt[UNROLL];
+        bool live[UNROLL], rev[UNROLL], is_x[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const uint32_t g = g0 + u, piece = g * 256 + threadIdx.x;
+            live[u] = g < n_grp && piece < n_pieces;
+            q[u] = 0; n[u] = 0; xr[u] = xt[u] = 0; mr[u] = mt[u] = 0; rev[u] = is_x[u] = false;
+            if (!live[u]) continue;
+            uint32_t lo = use_tbl ? tbl[g] : 0u, hi = (use_tbl ? (uint32_t)tbl[g + 1] : (uint32_t)WALK_CHUNK - 1) + 1;
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_pre[mid] <= piece) lo = mid; else hi = mid; }
+            // (slots without pieces share their prefix with the slot after them, so the largest such slot is the owner of the piece)
+            q[u] = lo;
+            const uint32_t dl = d_len[lo], len = dl >> 2;
+            rev[u] = dl & 2u; is_x[u] = dl & 1u;
+            const uint64_t ra = d_ref[lo], ta = d_tig[lo];
+            const uint32_t b = (piece - s_pre[lo]) * VPIECE;
+            n[u] = min(VPIECE, len - b);
+            xr[u] = window128(A.ref.two, ra + b);
+            mr[u] = window64(A.ref.mask, ra + b);
+            const uint64_t s0 = rev[u] ? ta - b - (n[u] - 1) : ta + b;   // reverse rows: lowest stored base of this window
+            xt[u] = window128(A.tig.two, s0);
+            mt[u] = window64(A.tig.mask, s0);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            if (!live[u]) continue;
+            const uint64_t keep = n[u] == 64 ? ~0ull : (1ull << n[u]) - 1ull;
+            u128 t2 = xt[u];
+            uint64_t tm = mt[u] & keep;
+            if (rev[u]) {
+                u128 r = brev128(xt[u] << (2 * (64 - n[u])));           // groups reversed, bits inside a group swapped
+                const u128 odd = (u128)0xAAAAAAAAAAAAAAAAull << 64 | 0xAAAAAAAAAAAAAAAAull;
+                r = ((r & odd) >> 1) | ((r & (odd >> 1)) << 1);
+                t2 = ~r;                                                // complement
+                tm = __brevll(mt[u] << (64 - n[u])) & keep;
+            }
+            const uint64_t rm = mr[u] & keep;
+            const u128 even = (u128)0x5555555555555555ull << 64 | 0x5555555555555555ull;
+            const u128 kmask = spread64(keep);
+            const u128 d = xr[u] ^ t2;
+            const u128 neq = (d | d >> 1) & even & kmask;                                  // bit 2i: base i differs
+            const u128 one_n = spread64(rm ^ tm), both_n = spread64(rm & tm);               // non-ACGT on one / on both sides
+            // '=' : wrong when the codes differ (unless both are non-ACGT) or exactly one side is non-ACGT
+            // 'X' : wrong when both are ACGT and equal, or both are non-ACGT (the planes cannot tell N from N)
+            const u128 wrong = is_x[u] ? ((~neq & kmask & ~one_n) | both_n) : ((neq & ~both_n) | one_n);
+            const uint32_t bad = (uint32_t)popc128(wrong);
+            if (is_x[u]) { n_x += n[u]; bad_x += bad; } else { n_eq += n[u]; bad_eq += bad; }
+            if (bad) first_bad = min(first_bad, (unsigned long long)blockIdx.x * WALK_CHUNK + (unsigned long long)q[u]);
+        }
+    }
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) {
+        n_eq += __shfl_xor(n_eq, dd); bad_eq += __shfl_xor(bad_eq, dd); n_x += __shfl_xor(n_x, dd); bad_x += __shfl_xor(bad_x, dd);
+        first_bad = min(first_bad, (unsigned long long)__shfl_xor(first_bad, dd));
+    }
+    // one atomic per workgroup and counter
+    __shared__ unsigned long long part[4][5];
+    if (lane == 0) { part[wave][0] = n_eq; part[wave][1] = bad_eq; part[wave][2] = n_x; part[wave][3] = bad_x; part[wave][4] = first_bad; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const unsigned long long v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        if (v) atomicAdd(&A.cnt[threadIdx.x], v);
+    } else if (threadIdx.x == 4) {
+        const unsigned long long v = min(min(part[0][4], part[1][4]), min(part[2][4], part[3][4]));
+        if (v != ~0ull) atomicMin(&A.cnt[4], v);
+    }
+}
+
 // ---- lift-over tables (pavlib/align/lift.py:380-476) ------------------------------------------------------------
 // Per operation: subject position where it starts (absolute) and query position where it starts (alignment
 // orientation, clips included).  Advance rules are AlignLift's: M, =, X move both axes, I / S / H the query,
@@ -981,6 +1188,35 @@ int pav_cigar_fetch(pav_ctx *ctx, pav_snv *snv, pav_indel *indel, uint8_t *seq_b
     if (seq_blob && ctx->counts.seq_bytes)
         PAV_HIP(ctx, hipMemcpyAsync(seq_blob, ctx->d_seqblob.p, ctx->counts.seq_bytes, hipMemcpyDeviceToHost, ctx->stream));
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PAV_OK;
+}
+
+int pav_cigar_verify(pav_ctx *ctx, pav_verify_counts *out) {
+    if (!ctx || !out) return PAV_E_ARG;
+    if (!ctx->cigar_called) return fail(ctx, PAV_E_STATE, "pav_cigar_verify: pav_cigar_call has not been called");
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    memset(out, 0, sizeof *out);
+    out->first_bad_op = ~0ull;
+    const uint64_t n_ops = ctx->n_ops;
+    const uint32_t n_wchunks = (uint32_t)((n_ops + WALK_CHUNK - 1) / WALK_CHUNK);
+    if (!n_wchunks) return PAV_OK;
+    PAV_HIP(ctx, ctx->d_tmp.reserve(64));
+    unsigned long long *d_cnt = ctx->d_tmp.as<unsigned long long>();
+    PAV_HIP(ctx, hipMemsetAsync(d_cnt, 0, 32, ctx->stream));
+    PAV_HIP(ctx, hipMemsetAsync(d_cnt + 4, 0xFF, 8, ctx->stream));
+    { int rcw = wait_planes(ctx); if (rcw != PAV_OK) return rcw; }
+    VerifyArgs A;
+    A.ops = ctx->d_ops.as<uint32_t>(); A.n_ops = n_ops;
+    A.op_off = ctx->d_op_off.as<uint64_t>(); A.aln = ctx->d_aln.as<pav_aln>(); A.n_aln = ctx->n_aln;
+    A.chunk_pre = ctx->d_chunk2.as<uint64_t>() + (size_t)NQ * (n_wchunks + 1); A.rowbase = ctx->d_rowbase.as<uint64_t>();
+    A.ref = ctx->seq[PAV_ROLE_REF].view(); A.tig = ctx->seq[PAV_ROLE_TIG].view();
+    A.cnt = d_cnt;
+    PAV_LAUNCH(ctx, "verify_kernel", verify_kernel, n_wchunks, 256, 0, A);
+    unsigned long long h[5];
+    PAV_HIP(ctx, hipMemcpyAsync(h, d_cnt, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out->eq_bases = h[0]; out->eq_mismatch = h[1]; out->x_bases = h[2]; out->x_match = h[3]; out->first_bad_op = h[4];
+    if (prof_flush(ctx) != PAV_OK) return PAV_E_HIP;
     return PAV_OK;
 }
 

@@ -351,3 +351,90 @@ def test_bench_two_ranks_on_one_gpu(built):
     two = synth.config2(seed=1002, scale=0.01, hap_index=1, threads=2).stats['aligned_bp']
     got = line['value'] * 1e9 * line['ms_per_step'] * 1e-3               # aligned bases per step over both ranks
     assert abs(got - (one + two)) / (one + two) < 0.02                    # value and ms_per_step are rounded in the line
+
+
+def _verify_numpy(hap_ref, tig_seqs, tig_names, names, aln, ops, op_off):
+    """Plain restatement of pav_cigar_verify on the ASCII sequences (upper-cased; reverse rows reverse-complemented)."""
+    comp = np.arange(256, dtype=np.uint8)
+    for a, b in zip(b'ACGTacgt', b'TGCAtgca'):
+        comp[a] = b
+    cls = np.full(256, 4, dtype=np.uint8)
+    for i, c in enumerate(b'ACGT'):
+        cls[c] = i
+        cls[c + 32] = i
+    out = dict(eq_bases=0, eq_mismatch=0, x_bases=0, x_match=0, first_bad_op=None)
+    for r in range(aln.shape[0]):
+        ref = cls[hap_ref[names[aln['ref_id'][r]]]]
+        tig = tig_seqs[tig_names[aln['tig_id'][r]]]
+        tig = cls[comp[tig[::-1]]] if aln['rev'][r] else cls[tig]
+        pr, pt = int(aln['pos'][r]), 0
+        for k in range(int(op_off[r]), int(op_off[r + 1])):
+            code, n = int(ops[k]) & 15, int(ops[k]) >> 4
+            if code in (7, 8):
+                a, b = ref[pr:pr + n], tig[pt:pt + n]
+                one_n, both_n = (a == 4) != (b == 4), (a == 4) & (b == 4)
+                if code == 7:
+                    wrong = int((((a != b) & ~both_n) | one_n).sum())
+                    out['eq_bases'] += n
+                    out['eq_mismatch'] += wrong
+                else:
+                    wrong = int((((a == b) & ~one_n) | both_n).sum())
+                    out['x_bases'] += n
+                    out['x_match'] += wrong
+                if wrong and out['first_bad_op'] is None:
+                    out['first_bad_op'] = k
+            if code in (7, 8, 2):
+                pr += n
+            if code in (7, 8, 1, 4, 5):
+                pt += n
+    return out
+
+
+def test_verify_mode_counts_bases_that_contradict_the_cigar(built, gpu_ctx):
+    """pav_cigar_verify: clean synthetic alignments verify with zero wrong bases; after corrupting contig and reference bases
+    (substitutions, N on one side, N on both sides, inside '=' and 'X' runs, forward and reverse rows) the counters and the
+    first offending operation equal a numpy restatement on the ASCII sequences."""
+    hap = synth.config2(seed=77, scale=0.003, threads=2)
+    names = hap.ref.names
+    aln, text, off = cigarcall.pack_alignments(hap.df_align, names, hap.tig_names)
+
+    def run(ref_seqs, tig_seqs):
+        gpu_ctx._inv_loaded = None
+        gpu_ctx.seq_load(_lib.PAV_ROLE_REF, names, [ref_seqs[n] for n in names])
+        gpu_ctx.seq_load(_lib.PAV_ROLE_TIG, hap.tig_names, [tig_seqs[n] for n in hap.tig_names])
+        gpu_ctx.cigar_load(aln, text, off)
+        counts = gpu_ctx.cigar_call()
+        ops, op_off = gpu_ctx.cigar_fetch_ops(counts.n_ops, aln.shape[0])
+        return counts, gpu_ctx.cigar_verify(), ops, op_off
+
+    counts, v, ops, op_off = run(hap.ref.seqs, hap.tig_seqs)
+    assert v['eq_mismatch'] == 0 and v['x_match'] == 0 and v['first_bad_op'] is None
+    assert v['eq_bases'] + v['x_bases'] == counts.aligned_bases and v['x_bases'] == counts.n_snv
+    assert aln['rev'].any() and not aln['rev'].all()
+
+    rng = np.random.default_rng(5)
+    ref2 = {n: a.copy() for n, a in hap.ref.seqs.items()}
+    tig2 = {n: a.copy() for n, a in hap.tig_seqs.items()}
+    for n in hap.tig_names:                                   # substitutions and N runs on the contigs
+        a = tig2[n]
+        idx = rng.integers(0, a.shape[0], max(4, a.shape[0] // 5000))
+        a[idx] = np.frombuffer(b'ACGTacgtN', dtype=np.uint8)[rng.integers(0, 9, idx.shape[0])]
+        s = int(rng.integers(0, max(1, a.shape[0] - 200)))
+        a[s:s + 150] = ord('N')
+    for n in names:                                           # N runs on the reference, some of them facing contig N runs
+        a = ref2[n]
+        for _ in range(3):
+            s = int(rng.integers(0, max(1, a.shape[0] - 100)))
+            a[s:s + 70] = ord('n')
+    row = hap.df_align.iloc[0]                                # an N run on both sides of one forward-or-reverse row's first '=' run
+    ref2[row['#CHROM']][int(row['POS']):int(row['POS']) + 40] = ord('N')
+    t = tig2[row['QRY_ID']]
+    q0 = int(row['QRY_POS'])
+    if row['REV']:
+        t[t.shape[0] - q0 - 40:t.shape[0] - q0] = ord('N')
+    else:
+        t[q0:q0 + 40] = ord('N')
+    _, v2, ops2, op_off2 = run(ref2, tig2)
+    want = _verify_numpy(ref2, tig2, hap.tig_names, names, aln, ops2, op_off2)
+    assert want['eq_mismatch'] > 100 and want['x_match'] > 0
+    assert v2 == want
