@@ -248,6 +248,14 @@ def main():
     # ---- verify mode (second line): CIGAR-call + a pass over both packed sequences that checks every
     #      '=' / 'X' base against the CIGAR; never mixed into `value` ------------------------------------------------------
     verify_leg = side_leg('cigar+verify')
+    # the dominant kernel with nothing beside it: K packs of the resident contigs, each waited for (HIP events as above)
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    for _ in range(args.steps):
+        ctx.seq_pack(_lib.PAV_ROLE_TIG)
+        ctx.sync()
+    pack_alone = ctx.prof_read().get('pack_kernel')
+    ctx.prof_enable(False)
 
     # D2H of the record streams (reported, never part of `value`)
     t0 = time.perf_counter()
@@ -376,6 +384,15 @@ def main():
                                                     for k in sorted(alg_bytes) if k in kern_ and kern_[k]['avg_ms'] > 0}}
 
         kern, roofline = make_roofline(prof)
+
+        def add_alone(roof):
+            if pack_alone and pack_alone[0] and roof['kernel'] == 'pack_kernel':
+                ms_alone = pack_alone[1] / pack_alone[0]
+                gbs = roof['algorithmic_bytes_per_launch'] / (ms_alone * 1e-3) / 1e9
+                roof['alone'] = {'avg_kernel_ms': round(ms_alone, 4), 'achieved': round(gbs, 1), 'frac': round(gbs / HBM_PEAK_GBS, 4),
+                                 'note': 'the same launch with no other kernel resident (inside a step the tokenizer / walk kernels and, '
+                                         'in the whole path, the previous step\'s table copy run beside it)'}
+        add_alone(roofline)
         _, roof_v = make_roofline(verify_leg['prof'], want='verify_kernel')
         vres = inv_state['verify']
         verify_mode = {'workload': 'CIGAR-call + verify: the packed reference and contig are streamed along every = / X operation and '
@@ -387,6 +404,7 @@ def main():
         cigar_only = None
         if cigar_leg is not None:
             _, roof_c = make_roofline(cigar_leg['prof'])
+            add_alone(roof_c)
             cigar_only = {'workload': 'BASELINE configs[1]: the same haplotype, CIGAR-call only (pack + tokenise + walk + homology + '
                                       'SEQ gather), measured in this run after the headline region',
                           'value': round(aligned_total * args.steps / cigar_leg['t'] / 1e9, 2), 'unit': 'Gbp/s',
