@@ -411,11 +411,16 @@ struct VerifyArgs {
 typedef unsigned __int128 u128;
 constexpr uint32_t VPIECE = 64;                                        // bases per lane and step
 
+// Two aligned 16-byte loads cover the three 64-bit words an unaligned 64-base window touches (16 B per lane is the widest and
+// cheapest global load; three 8-byte loads per window made the kernel load-instruction bound).
 __device__ __forceinline__ u128 window128(const uint32_t *__restrict__ two, uint64_t a) {            // 64 bases from position a
-    const uint64_t *two64 = reinterpret_cast<const uint64_t *>(two);
-    const uint64_t w = a >> 5;
+    const uint64_t w = a >> 5;                                          // first 64-bit word
+    const uint4 *p = reinterpret_cast<const uint4 *>(two) + (w >> 1);
+    const uint4 q0 = p[0], q1 = p[1];
+    const uint64_t v[4] = {(uint64_t)q0.y << 32 | q0.x, (uint64_t)q0.w << 32 | q0.z, (uint64_t)q1.y << 32 | q1.x, (uint64_t)q1.w << 32 | q1.z};
+    const int o = (int)(w & 1);
+    const uint64_t v0 = o ? v[1] : v[0], v1 = o ? v[2] : v[1], v2 = o ? v[3] : v[2];
     const int b = (int)(a & 31) * 2;
-    const uint64_t v0 = two64[w], v1 = two64[w + 1], v2 = two64[w + 2];
     const uint64_t lo = b ? (v0 >> b | v1 << (64 - b)) : v0, hi = b ? (v1 >> b | v2 << (64 - b)) : v1;
     return (u128)hi << 64 | lo;
 }
