@@ -20,8 +20,10 @@ A "step" is one pass of the hot path over one haplotype with inputs already resi
     ->  per flagged region: lift-over, k-mer sets, STATE_MER, KDE, STATE runs, expansion rounds, inversion calls
         (the density tables of all calls are copied to pinned host memory inside the timed region).
 
-Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed on the library's stream) and
-"cpu_baseline" (oracle/ scalar C port timed on a bounded sample of the same workload, rank 0, N = 1 only).
+Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed on the library's stream; "alone" = the same
+launch with nothing beside it), "cpu_baseline" (oracle/ scalar C port timed on a bounded sample of the same workload, rank 0,
+N = 1 only), "cigar_only" (BASELINE configs[1]), "verify_mode" (CIGAR-call + a pass over both packed sequences that checks
+every = / X base; SURVEY.md section 8(d), never mixed into `value`), "inv_scan" and "end_to_end" (writers / readers).
 """
 
 import argparse
@@ -365,10 +367,10 @@ def main():
                 if kname in kern_ and kern_[kname]['launches'] and scanned_bp:
                     alg_bytes[kname] = per_base * scanned_bp * args.steps / kern_[kname]['launches']
             # HBM traffic of the dominant kernel from the committed PMC summary of the same workload (profiles/r01_pmc.json;
-            # separate rocprofv3 --pmc passes).  FETCH_SIZE is doubled for the streaming pack kernel as the guide prescribes.
+            # separate rocprofv3 --pmc passes).  FETCH_SIZE is doubled for the 16 B/lane streaming kernels as the guide prescribes.
             traffic = None
             if pmc and dom in pmc.get('fetch_kib', {}) and dom in pmc.get('write_kib', {}):
-                fx = 2.0 if dom == 'pack_kernel' else 1.0
+                fx = 2.0 if dom in ('pack_kernel', 'verify_kernel') else 1.0          # 16 B/lane streams (verify: its 2-bit windows)
                 traffic = (pmc['fetch_kib'][dom] * fx + pmc['write_kib'][dom]) * 1024.0
             a_bytes = alg_bytes.get(dom)
             achieved = a_bytes / (kern_[dom]['avg_ms'] * 1e-3) / 1e9 if a_bytes and kern_[dom]['avg_ms'] > 0 else None

@@ -77,7 +77,8 @@ def pmcjson(fetch_db, write_db, bench_json, out):
            'workload': {'seed': line['config']['seed'], 'scale': line['config']['scale'],
                         'aligned_bp_per_gpu': line['config']['aligned_bp_per_gpu'], 'name': line['config']['workload']},
            'gfx950_note': 'FETCH_SIZE counts 128 B requests as 64 B for 16 B/lane streaming reads: x2 for pack_kernel (calibrated '
-                          'against the 3.08 GB ASCII arena); other kernels are reported raw',
+                          'against the 3.08 GB ASCII arena) and verify_kernel (16 B/lane windows of the 2-bit planes); '
+                          'other kernels are reported raw',
            'fetch_kib': per_kernel(fetch_db, 'FETCH_SIZE'), 'write_kib': per_kernel(write_db, 'WRITE_SIZE')}
     with open(out, 'w') as fh:
         json.dump(doc, fh, indent=1)
