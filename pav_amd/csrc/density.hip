@@ -70,6 +70,15 @@ struct DensityState {
     DevBuf tiles, events, ev_count, scratch, run_arena, win_fill;
     std::vector<JobDev> h_jobs;
     std::vector<JobKde> h_kde;
+    void *pin = nullptr; size_t pin_cap = 0;                  // pinned host scratch for the small readbacks (pageable targets are
+    void *pinned(size_t bytes) {                              // staged by the runtime and cost tens of microseconds each)
+        if (bytes <= pin_cap) return pin;
+        if (pin) (void)hipHostFree(pin);
+        pin = nullptr; pin_cap = 0;
+        if (hipHostMalloc(&pin, bytes + bytes / 2 + 4096, hipHostMallocDefault) != hipSuccess) { pin = nullptr; return nullptr; }
+        pin_cap = bytes + bytes / 2 + 4096;
+        return pin;
+    }
     std::vector<uint8_t> desc_host2[2];   // descriptor uploads of density_fetch_calls (one per staging buffer)
     DevBuf call_stage[2];                 // packed call tables of a round; two, so that a round never waits for the copy
     hipEvent_t stage_copied[2] = {nullptr, nullptr};   // of the round before it (recorded on the copy stream)
@@ -87,6 +96,7 @@ struct DensityState {
                          &pscaled[0], &pscaled[1], &pscaled[2], &fill_list, &tiles, &events, &ev_count, &scratch, &run_arena, &win_fill};
         for (DevBuf *b : all) b->release();
         call_stage[0].release(); call_stage[1].release();
+        if (pin) { (void)hipHostFree(pin); pin = nullptr; pin_cap = 0; }
         for (hipEvent_t &e : stage_copied) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (gathered) { (void)hipEventDestroy(gathered); gathered = nullptr; }
     }
@@ -1230,6 +1240,15 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     CA.kmer = D->kmer.as<unsigned long long>();
     for (int s = 0; s < 3; ++s) CA.list[s] = D->list[s].as<uint32_t>();
     std::vector<JobStat> hs(n_jobs);
+    constexpr uint32_t EV_PREFETCH = 4096;                             // head events copied together with their count
+    uint8_t *h_pin = static_cast<uint8_t *>(D->pinned(std::max(sizeof(JobStat) * (size_t)n_jobs, sizeof(HeadEvent) * (size_t)EV_PREFETCH + 64)));
+    if (!h_pin) return fail(ctx, PAV_E_HIP, "pav_density_batch: cannot pin host memory for the readbacks");
+    auto read_stats = [&]() -> int {
+        PAV_HIP(ctx, hipMemcpyAsync(h_pin, d_stat, sizeof(JobStat) * n_jobs, hipMemcpyDeviceToHost, st));
+        PAV_HIP(ctx, hipStreamSynchronize(st));
+        memcpy(hs.data(), h_pin, sizeof(JobStat) * n_jobs);
+        return PAV_OK;
+    };
     // compaction to the informative rows, then readback 1: per-job counts and moments -> status, bandwidths (host, libm:
     // same arithmetic as scipy)
     auto compact_and_read = [&]() -> int {
@@ -1238,9 +1257,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
         PAV_LAUNCH(ctx, "k_scan_tiles4", k_scan_tiles4, 1, 256, 0, D->tile_sum.as<uint32_t>(), D->tile_pre.as<unsigned long long>(),
                    n_tiles_t);
         PAV_LAUNCH(ctx, "k_compact_scatter", k_compact_scatter, n_tiles_t, 256, 0, CA);
-        PAV_HIP(ctx, hipMemcpyAsync(hs.data(), d_stat, sizeof(JobStat) * n_jobs, hipMemcpyDeviceToHost, st));
-        PAV_HIP(ctx, hipStreamSynchronize(st));
-        return PAV_OK;
+        return read_stats();
     };
     { const int rcc = compact_and_read(); if (rcc != PAV_OK) return rcc; }
     lap("kmer+compact");
@@ -1298,8 +1315,8 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
                 const int rcc = compact_and_read();
                 if (rcc != PAV_OK) return rcc;
             } else {
-                PAV_HIP(ctx, hipMemcpyAsync(hs.data(), d_stat, sizeof(JobStat) * n_jobs, hipMemcpyDeviceToHost, st));
-                PAV_HIP(ctx, hipStreamSynchronize(st));
+                const int rcs = read_stats();
+                if (rcs != PAV_OK) return rcs;
             }
         }
     }
@@ -1313,12 +1330,18 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             PAV_HIP(ctx, hipMemsetAsync(D->ev_count.p, 0, 4, st));
             PAV_LAUNCH(ctx, "k_heads", k_heads, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_stat, d_state,
                        D->index.as<uint32_t>(), D->events.as<HeadEvent>(), cap, D->ev_count.as<uint32_t>());
-            uint32_t n_ev = 0;
-            PAV_HIP(ctx, hipMemcpyAsync(&n_ev, D->ev_count.p, 4, hipMemcpyDeviceToHost, st));
+            // the count and the first EV_PREFETCH events come back together (a batch of 1 000 regions has ~2 000 heads)
+            const uint32_t pre = std::min(cap, EV_PREFETCH);
+            PAV_HIP(ctx, hipMemcpyAsync(h_pin, D->ev_count.p, 4, hipMemcpyDeviceToHost, st));
+            PAV_HIP(ctx, hipMemcpyAsync(h_pin + 64, D->events.p, sizeof(HeadEvent) * pre, hipMemcpyDeviceToHost, st));
             PAV_HIP(ctx, hipStreamSynchronize(st));
+            uint32_t n_ev = 0;
+            memcpy(&n_ev, h_pin, 4);
             if (n_ev > cap) { cap = n_ev + 1024; continue; }
             ev.resize(n_ev);
-            if (n_ev) PAV_HIP(ctx, hipMemcpy(ev.data(), D->events.p, sizeof(HeadEvent) * n_ev, hipMemcpyDeviceToHost));
+            if (n_ev) memcpy(ev.data(), h_pin + 64, sizeof(HeadEvent) * std::min(n_ev, pre));
+            if (n_ev > pre)
+                PAV_HIP(ctx, hipMemcpy(ev.data() + pre, D->events.as<HeadEvent>() + pre, sizeof(HeadEvent) * (n_ev - pre), hipMemcpyDeviceToHost));
             break;
         }
         std::sort(ev.begin(), ev.end(), [](const HeadEvent &a, const HeadEvent &b) { return a.job != b.job ? a.job < b.job : a.row < b.row; });
@@ -1433,8 +1456,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
         PAV_LAUNCH(ctx, "k_interp", k_interp, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_kde, D->win_fill.as<uint8_t>(),
                    D->kern[0].as<double>(), D->kern[1].as<double>(), D->kern[2].as<double>());
         // ---- readback 2: how many inner sites need the full density --------------------------------------------
-        PAV_HIP(ctx, hipMemcpyAsync(hs.data(), d_stat, sizeof(JobStat) * n_jobs, hipMemcpyDeviceToHost, st));
-        PAV_HIP(ctx, hipStreamSynchronize(st));
+        { const int rcs = read_stats(); if (rcs != PAV_OK) return rcs; }
         std::vector<EvalTile> ftiles;
         for (uint32_t j = 0; j < n_jobs; ++j) {
             if (!D->h_kde[j].finalised) continue;
