@@ -1419,6 +1419,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             PAV_HIP(ctx, hipMemcpyAsync(D->run_arena.p, arena.data(), sizeof(RunDev) * arena.size(), hipMemcpyHostToDevice, st));
         PAV_HIP(ctx, hipStreamSynchronize(st));                        // `arena` is a local buffer
     }
+    lap("kde host");
     // failure path: the k-mer named in the message of scripts/density.py:519-526
     for (uint32_t j = 0; j < n_jobs; ++j) {
         if (D->results[j].fail_kind != 2) continue;
@@ -1455,8 +1456,10 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
                    pp->state_run_delta, D->fill_list.as<uint32_t>(), D->win_fill.as<uint8_t>(), d_stat);
         PAV_LAUNCH(ctx, "k_interp", k_interp, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_kde, D->win_fill.as<uint8_t>(),
                    D->kern[0].as<double>(), D->kern[1].as<double>(), D->kern[2].as<double>());
+        lap("kde queue 1");
         // ---- readback 2: how many inner sites need the full density --------------------------------------------
         { const int rcs = read_stats(); if (rcs != PAV_OK) return rcs; }
+        lap("kde eval 1");
         std::vector<EvalTile> ftiles;
         for (uint32_t j = 0; j < n_jobs; ++j) {
             if (!D->h_kde[j].finalised) continue;
