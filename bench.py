@@ -439,6 +439,29 @@ def main():
                              f'{o_snv.shape[0]} SNV, {o_indel.shape[0]} INDEL), oracle/ scalar C walk incl. per-contig '
                              f'upper-casing and reverse complement, {c1:.1f} s wall',
                    'records_match_gpu': bool(ok)}
+            # the same port on all host cores: the alignment rows are independent, so the haplotype is cut into row groups of
+            # equal CIGAR text and every group walks on its own thread (ctypes releases the GIL); reported beside the 1-core figure
+            from concurrent.futures import ThreadPoolExecutor
+            n_thr = max(1, min(os.cpu_count() or 1, 64))
+            t_all = None
+            if n_thr > 1 and sub.shape[0] >= 2:
+                # consecutive rows stay together (the table is sorted by chromosome, and every group upper-cases the sequences
+                # its rows touch once): cut where the cumulative CIGAR text crosses multiples of total / groups
+                cum = np.cumsum(sub['CIGAR'].str.len().to_numpy(dtype=np.int64))
+                n_grp = min(sub.shape[0], 2 * n_thr)
+                cuts = np.unique(np.concatenate(([0], np.searchsorted(cum, cum[-1] * np.arange(1, n_grp) / n_grp) + 1, [sub.shape[0]])))
+                groups = [np.arange(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+                n_grp = len(groups)
+                packs = [cigarcall.pack_alignments(sub.iloc[g], names, hap.tig_names) for g in groups]
+                refs, tigs = [hap.ref.seqs[n] for n in names], [hap.tig_seqs[n] for n in hap.tig_names]
+                c0 = time.perf_counter()
+                with ThreadPoolExecutor(n_thr) as pool:
+                    parts = list(pool.map(lambda pk: oracle.cigar_call(refs, tigs, *pk)[0].shape[0], packs))
+                t_all = time.perf_counter() - c0
+                cpu['all_cores'] = {'cigar_call_only': round(sample_bp / t_all / 1e9, 3), 'unit': 'Gbp/s', 'cores': n_thr,
+                                    'snv_records': int(sum(parts)), 'wall_s': round(t_all, 2),
+                                    'note': f'{n_grp} groups of consecutive rows on {n_thr} threads; every group upper-cases the chromosomes '
+                                            'and contigs its rows touch (the reference does so per row, cigarcall.py:74-75)'}
             if args.workload == 'cigar+inv' and scanned_bp:
                 # k-mer density scan on the CPU: the first scan iteration of the first liftable flagged regions through the
                 # oracle (scalar C: hash set, STATE_MER, scipy-order KDE, change test, STATE), extrapolated by scanned bases
@@ -482,6 +505,16 @@ def main():
                                   f'({den_bp} region bp, {t_den:.1f} s wall) extrapolated to the {scanned_bp} bp scanned per haplotype '
                                   f'({t_scan_cpu:.0f} s); value = aligned bp / (CIGAR walk + extrapolated scan); flagging not included',
                         'density_tables_match_gpu': bool(den_ok)})
+                    if t_all is not None and len(pairs) >= 2:
+                        c0 = time.perf_counter()
+                        with ThreadPoolExecutor(n_thr) as pool:
+                            list(pool.map(lambda rt: oracle.density(hap.ref.seqs[rt[0].chrom][rt[0].pos:rt[0].end],
+                                                                    hap.tig_seqs[rt[1].chrom][rt[1].pos:rt[1].end], rt[1].is_rev)['status'], pairs))
+                        t_den_all = time.perf_counter() - c0
+                        t_scan_all = t_den_all * scanned_bp / den_bp
+                        t_cigar_all = t_all * float(counts.aligned_bases) / sample_bp
+                        cpu['all_cores'].update({'value': round(float(counts.aligned_bases) / (t_cigar_all + t_scan_all) / 1e9, 4),
+                                                 'density_scan_bp_per_s': round(den_bp / t_den_all, 1)})
 
         inv_report = None
         if args.workload == 'cigar+inv':
