@@ -51,6 +51,7 @@ struct JobStat {                          // written by kernels, zeroed per batc
 struct JobKde {                           // host -> device after the first readback
     uint32_t finalised, n, n_samp, srs;
     uint32_t m[3], use_runs;              // use_runs: closed-form run sums (PAV_KDE_RUNS) for this job
+    uint32_t samp_off, pad;               // first entry of the job in the compact arrays of sampled sites (ks / ss)
     uint32_t run_off[3], n_run[3];        // per-state slices of the run arena
     double inv_h[3], norm[3], w[3], cnt[3], h[3];
 };
@@ -67,7 +68,7 @@ struct HeadEvent { uint32_t job, row; int32_t state; uint32_t index, prev_index;
 struct DensityState {
     DevBuf jobs, stat, kde, tile_job_r, tile_job_t, keys, cnt, keys_x, cnt_x, lists, bcount, ans_f, ans_c, items;
     DevBuf st_tmp, tile_sum, tile_pre, index, state_mer, state, kmer, kern[3], list[3], pscaled[3], fill_list;
-    DevBuf tiles, events, ev_count, scratch, run_arena, win_fill;
+    DevBuf tiles, events, ev_count, scratch, run_arena, win_fill, ks[3], ss;
     std::vector<JobDev> h_jobs;
     std::vector<JobKde> h_kde;
     void *pin = nullptr; size_t pin_cap = 0;                  // pinned host scratch for the small readbacks (pageable targets are
@@ -93,7 +94,7 @@ struct DensityState {
     void release() {
         DevBuf *all[] = {&jobs, &stat, &kde, &tile_job_r, &tile_job_t, &keys, &cnt, &keys_x, &cnt_x, &lists, &bcount, &ans_f, &ans_c, &items, &st_tmp, &tile_sum, &tile_pre,
                          &index, &state_mer, &state, &kmer, &kern[0], &kern[1], &kern[2], &list[0], &list[1], &list[2],
-                         &pscaled[0], &pscaled[1], &pscaled[2], &fill_list, &tiles, &events, &ev_count, &scratch, &run_arena, &win_fill};
+                         &pscaled[0], &pscaled[1], &pscaled[2], &fill_list, &tiles, &events, &ev_count, &scratch, &run_arena, &win_fill, &ks[0], &ks[1], &ks[2], &ss};
         for (DevBuf *b : all) b->release();
         call_stage[0].release(); call_stage[1].release();
         if (pin) { (void)hipHostFree(pin); pin = nullptr; pin_cap = 0; }
@@ -729,6 +730,7 @@ __device__ __forceinline__ double kde_state_runs(const RunDev *__restrict__ runs
 struct KdeArgs {
     const JobDev *jobs; const JobKde *kde; const EvalTile *tiles; const uint32_t *fill_list;
     const double *ps[3]; double *kern[3]; int8_t *state; const RunDev *runs;
+    double *ks[3]; int8_t *ss;            // sampled sites, compact: entry samp_off + q of job j = row min(q * srs, n - 1)
 };
 
 // One wave per tile of 64 evaluation points of one job.
@@ -753,12 +755,17 @@ __global__ __launch_bounds__(64) void k_kde_eval(KdeArgs A) {
             ? kde_state_runs(A.runs + kd.run_off[s], kd.n_run[s], (double)x, kd.h[s], kd.inv_h[s], kd.norm[s], kd.w[s])
             : kde_state(A.ps[s] + off, kd.m[s], (double)x * kd.inv_h[s], kd.norm[s], kd.w[s]);
         val[s] = est * kd.cnt[s];                                      // density.py:110-115
-        A.kern[s][off + x] = val[s];
     }
-    if (kd.m[0] == 0) A.kern[0][off + x] = 0.0;
-    if (kd.m[1] == 0) A.kern[1][off + x] = 0.0;
-    if (kd.m[2] == 0) A.kern[2][off + x] = 0.0;
-    if (t.mode == 0) A.state[off + x] = (int8_t)argmax3(val[0], val[1], val[2]);   // density.py:250-255
+    if (t.mode == 0) {
+        // sampled sites go to compact arrays (coalesced here and in k_windows / k_interp, which puts them into the table rows)
+        const uint64_t so = (uint64_t)kd.samp_off + t.first + threadIdx.x;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) A.ks[s][so] = val[s];
+        A.ss[so] = (int8_t)argmax3(val[0], val[1], val[2]);            // density.py:250-255
+    } else {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) A.kern[s][off + x] = val[s];
+    }
 }
 
 // Windows between consecutive sampled sites (scripts/density.py:257-323), two launches.  k_windows: one lane per window
@@ -767,8 +774,8 @@ __global__ __launch_bounds__(64) void k_kde_eval(KdeArgs A) {
 // lane per window the 3 x 19 strided stores per lane made this the second most expensive kernel of the scan).
 __global__ __launch_bounds__(256) void k_windows(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
                                                  const JobKde *__restrict__ kde, const int8_t *__restrict__ state_mer,
-                                                 const int8_t *__restrict__ state, const double *__restrict__ k0,
-                                                 const double *__restrict__ k1, const double *__restrict__ k2, double delta,
+                                                 const int8_t *__restrict__ ss, const double *__restrict__ s0,
+                                                 const double *__restrict__ s1, const double *__restrict__ s2, double delta,
                                                  uint32_t *__restrict__ fill_list, uint8_t *__restrict__ win_fill,
                                                  JobStat *__restrict__ stat) {
     const uint64_t ap = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -782,13 +789,14 @@ __global__ __launch_bounds__(256) void k_windows(const JobDev *__restrict__ jobs
     uint64_t b = (q + 1) * kd.srs;
     if (b > kd.n - 1) b = kd.n - 1;
     if (b == a + 1) { win_fill[ap] = 1; return; }                      // density.py:270-271: nothing in between
-    bool change = state[off + a] != state[off + b];
+    const uint64_t so = (uint64_t)kd.samp_off + q;                     // the two sampled sites of the window, compact arrays
+    bool change = ss[so] != ss[so + 1];
     const int8_t sm = state_mer[off + a];
     for (uint64_t i = a + 1; i <= b && !change; ++i) change = state_mer[off + i] != sm;      // :273-275
-    const double *kk[3] = {k0, k1, k2};
+    const double *kk[3] = {s0, s1, s2};
     double dmax = 0.0;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) { const double d = fabs(kk[s][off + a] - kk[s][off + b]); if (d > dmax) dmax = d; }
+    for (int s = 0; s < 3; ++s) { const double d = fabs(kk[s][so] - kk[s][so + 1]); if (d > dmax) dmax = d; }
     const bool fill = change || dmax > delta;                          // :277-283
     win_fill[ap] = fill ? 1 : 0;
     if (fill) {
@@ -798,9 +806,13 @@ __global__ __launch_bounds__(256) void k_windows(const JobDev *__restrict__ jobs
     }
 }
 
+// One lane per table row: sampled sites are copied from the compact arrays, the inner sites of quiet windows are interpolated
+// (np.interp: slope * (x - x0) + y0); the inner sites of the other windows are written by k_kde_eval (mode 1).
 __global__ __launch_bounds__(256) void k_interp(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
                                                 const JobKde *__restrict__ kde, const uint8_t *__restrict__ win_fill,
-                                                double *__restrict__ k0, double *__restrict__ k1, double *__restrict__ k2) {
+                                                const double *__restrict__ s0, const double *__restrict__ s1,
+                                                const double *__restrict__ s2, double *__restrict__ k0, double *__restrict__ k1,
+                                                double *__restrict__ k2) {
     const uint64_t ap = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint32_t j = tile_job[ap / DTILE];
     const JobKde kd = kde[j];
@@ -810,14 +822,25 @@ __global__ __launch_bounds__(256) void k_interp(const JobDev *__restrict__ jobs,
     if (x >= kd.n) return;
     const uint64_t q = x / kd.srs;
     const uint64_t a = q * kd.srs;
-    if (x == a || q + 1 >= kd.n_samp) return;                          // a sampled site, or past the last window
-    uint64_t b = (q + 1) * kd.srs;
-    if (b > kd.n - 1) b = kd.n - 1;
-    if (x >= b || win_fill[off + q]) return;
+    const uint64_t so = (uint64_t)kd.samp_off + q;
+    const double *sk[3] = {s0, s1, s2};
     double *kk[3] = {k0, k1, k2};
+    if (x == a) {                                                      // a sampled site
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {                                      // np.interp: slope * (x - x0) + y0
-        const double ya = kk[s][off + a], yb = kk[s][off + b];
+        for (int s = 0; s < 3; ++s) kk[s][ap] = sk[s][so];
+        return;
+    }
+    uint64_t b = (q + 1) * kd.srs;                                     // x > a, so the window has an end: q + 1 < n_samp
+    if (b > kd.n - 1) b = kd.n - 1;
+    if (x == b) {                                                      // the last sampled site (n - 1, not a multiple of srs)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) kk[s][ap] = sk[s][so + 1];
+        return;
+    }
+    if (win_fill[off + q]) return;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const double ya = sk[s][so], yb = sk[s][so + 1];
         const double slope = (yb - ya) / ((double)b - (double)a);
         kk[s][ap] = slope * ((double)x - (double)a) + ya;
     }
@@ -1365,6 +1388,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     lap("mer_runs");
     D->h_kde.assign(n_jobs, JobKde{});
     std::vector<EvalTile> tiles;
+    uint64_t total_samp = 0;
     for (uint32_t j = 0; j < n_jobs; ++j) {
         pav_den_result &r = D->results[j];
         JobKde &kd = D->h_kde[j];
@@ -1381,6 +1405,8 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
         kd.n_samp = (n + kd.srs - 1) / kd.srs;
         if ((uint64_t)(kd.n_samp - 1) * kd.srs != n - 1) kd.n_samp += 1;                                         // :213-214
         r.n_sample = kd.n_samp;
+        kd.samp_off = (uint32_t)total_samp;
+        total_samp += kd.n_samp;
         const double bandwidth = std::pow((double)n, -1.0 / 5.0) * pp->den_smooth;                               // :198
         for (int q = 0; q < 3; ++q) {
             const uint64_t m = s.m[q];
@@ -1441,7 +1467,11 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     KdeArgs KA;
     KA.jobs = d_jobs; KA.kde = d_kde; KA.fill_list = D->fill_list.as<uint32_t>(); KA.state = D->state.as<int8_t>();
     KA.runs = D->run_arena.as<RunDev>();
-    for (int s = 0; s < 3; ++s) { KA.ps[s] = D->pscaled[s].as<double>(); KA.kern[s] = D->kern[s].as<double>(); }
+    if (total_samp > 0xFFFFFFFFull) return fail(ctx, PAV_E_LIMIT, "pav_density_batch: too many sampled sites in one batch");
+    for (int s = 0; s < 3; ++s) PAV_HIP(ctx, D->ks[s].reserve(8 * (total_samp + 1)));
+    PAV_HIP(ctx, D->ss.reserve(total_samp + 1));
+    for (int s = 0; s < 3; ++s) { KA.ps[s] = D->pscaled[s].as<double>(); KA.kern[s] = D->kern[s].as<double>(); KA.ks[s] = D->ks[s].as<double>(); }
+    KA.ss = D->ss.as<int8_t>();
 
     if (!tiles.empty()) {
         PAV_LAUNCH(ctx, "k_pscale", k_pscale, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_kde, D->list[0].as<uint32_t>(),
@@ -1452,10 +1482,11 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
         KA.tiles = D->tiles.as<EvalTile>();
         PAV_LAUNCH(ctx, "k_kde_eval", k_kde_eval, (uint32_t)tiles.size(), 64, 0, KA);
         PAV_LAUNCH(ctx, "k_windows", k_windows, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_kde, D->state_mer.as<int8_t>(),
-                   D->state.as<int8_t>(), D->kern[0].as<double>(), D->kern[1].as<double>(), D->kern[2].as<double>(),
+                   D->ss.as<int8_t>(), D->ks[0].as<double>(), D->ks[1].as<double>(), D->ks[2].as<double>(),
                    pp->state_run_delta, D->fill_list.as<uint32_t>(), D->win_fill.as<uint8_t>(), d_stat);
         PAV_LAUNCH(ctx, "k_interp", k_interp, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_kde, D->win_fill.as<uint8_t>(),
-                   D->kern[0].as<double>(), D->kern[1].as<double>(), D->kern[2].as<double>());
+                   D->ks[0].as<double>(), D->ks[1].as<double>(), D->ks[2].as<double>(), D->kern[0].as<double>(),
+                   D->kern[1].as<double>(), D->kern[2].as<double>());
         lap("kde queue 1");
         // ---- readback 2: how many inner sites need the full density --------------------------------------------
         { const int rcs = read_stats(); if (rcs != PAV_OK) return rcs; }
