@@ -772,18 +772,19 @@ __global__ __launch_bounds__(64) void k_kde_eval(KdeArgs A) {
 // decides whether the states or the densities change inside it; if so its inner sites are queued for full evaluation.
 // k_interp: one lane per row fills the inner sites of the quiet windows by linear interpolation (coalesced stores; with one
 // lane per window the 3 x 19 strided stores per lane made this the second most expensive kernel of the scan).
-__global__ __launch_bounds__(256) void k_windows(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
-                                                 const JobKde *__restrict__ kde, const int8_t *__restrict__ state_mer,
-                                                 const int8_t *__restrict__ ss, const double *__restrict__ s0,
-                                                 const double *__restrict__ s1, const double *__restrict__ s2, double delta,
-                                                 uint32_t *__restrict__ fill_list, uint8_t *__restrict__ win_fill,
-                                                 JobStat *__restrict__ stat) {
-    const uint64_t ap = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint32_t j = tile_job[ap / DTILE];
+__global__ __launch_bounds__(64) void k_windows(const JobDev *__restrict__ jobs, const EvalTile *__restrict__ tiles,
+                                                const JobKde *__restrict__ kde, const int8_t *__restrict__ state_mer,
+                                                const int8_t *__restrict__ ss, const double *__restrict__ s0,
+                                                const double *__restrict__ s1, const double *__restrict__ s2, double delta,
+                                                uint32_t *__restrict__ fill_list, uint8_t *__restrict__ win_fill,
+                                                JobStat *__restrict__ stat) {
+    const EvalTile t = tiles[blockIdx.x];                              // the tiles of the sampled sites: one wave per 64 windows
+    if (threadIdx.x >= t.count) return;
+    const uint32_t j = t.job;
     const JobKde kd = kde[j];
-    if (!kd.finalised) return;
     const uint64_t off = jobs[j].tpos_off;
-    const uint64_t q = ap - off;
+    const uint64_t q = (uint64_t)t.first + threadIdx.x;
+    const uint64_t ap = off + q;
     if (q + 1 >= kd.n_samp) return;
     const uint64_t a = q * kd.srs;
     uint64_t b = (q + 1) * kd.srs;
@@ -1481,7 +1482,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
         PAV_HIP(ctx, hipMemcpyAsync(D->tiles.p, tiles.data(), sizeof(EvalTile) * tiles.size(), hipMemcpyHostToDevice, st));
         KA.tiles = D->tiles.as<EvalTile>();
         PAV_LAUNCH(ctx, "k_kde_eval", k_kde_eval, (uint32_t)tiles.size(), 64, 0, KA);
-        PAV_LAUNCH(ctx, "k_windows", k_windows, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_kde, D->state_mer.as<int8_t>(),
+        PAV_LAUNCH(ctx, "k_windows", k_windows, (uint32_t)tiles.size(), 64, 0, d_jobs, D->tiles.as<EvalTile>(), d_kde, D->state_mer.as<int8_t>(),
                    D->ss.as<int8_t>(), D->ks[0].as<double>(), D->ks[1].as<double>(), D->ks[2].as<double>(),
                    pp->state_run_delta, D->fill_list.as<uint32_t>(), D->win_fill.as<uint8_t>(), d_stat);
         PAV_LAUNCH(ctx, "k_interp", k_interp, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_kde, D->win_fill.as<uint8_t>(),
