@@ -71,6 +71,38 @@ class InvCall:
         return self.id
 
 
+class _NativeInvCall(InvCall):
+    """InvCall made by the native driver: ``id`` / ``svlen`` are set at once, the six regions are decoded from the driver's
+    result record on first access (a batch of a thousand regions yields a hundred calls with six regions each; building
+    them eagerly was most of the Python time of a scan)."""
+
+    _FIELDS = {'region_ref_outer': ('ref_outer', 0, False), 'region_ref_inner': ('ref_inner', 0, False),
+               'region_tig_outer': ('tig_outer', 1, True), 'region_tig_inner': ('tig_inner', 1, True),
+               'region_ref_discovery': ('ref_discovery', 0, False), 'region_tig_discovery': ('tig_discovery', 1, True)}
+
+    def __init__(self, record, names, region_flag, df):     # noqa: super().__init__ not called: the regions stay lazy
+        self._record, self._names = record, names
+        self.region_flag = region_flag
+        self._df = df
+        self.native_table = None
+        ro = record['ref_outer']
+        self.svlen = int(ro['end']) - int(ro['pos'])
+        self.id = '{}-{}-INV-{}'.format(names[0][int(ro['seq_id'])], int(ro['pos']) + 1, self.svlen)
+
+    def __getattr__(self, name):                             # reached only while the attribute has not been built yet
+        spec = _NativeInvCall._FIELDS.get(name)
+        if spec is None:
+            raise AttributeError(name)
+        g = self._record[spec[0]]
+        n_aln, aln = g['n_aln'].tolist(), g['aln_index'].tolist()
+        region = seq.Region(self._names[spec[1]][int(g['seq_id'])], int(g['pos']), int(g['end']),
+                            is_rev=bool(g['is_rev']) if spec[2] else False,
+                            pos_aln_index=(tuple(aln[0][:n_aln[0]]),) if n_aln[0] else None,
+                            end_aln_index=(tuple(aln[1][:n_aln[1]]),) if n_aln[1] else None)
+        setattr(self, name, region)
+        return region
+
+
 class _Interval:
     __slots__ = ('begin', 'end', 'data')
 
@@ -497,29 +529,20 @@ def _native_scan(ctx, region_flags, align_lift, k_util, max_region_size, logs, s
     hit = np.flatnonzero((found != 0) | (outcome != _lib.INV_NONE))
     sub = resv[hit]                                                   # the few regions with something to report, as plain lists
 
-    def rgn_lists(field, names, with_rev):
-        g = sub[field]
-        seq_id, pos, end, is_rev = g['seq_id'].tolist(), g['pos'].tolist(), g['end'].tolist(), g['is_rev'].tolist()
-        n_aln, aln = g['n_aln'].tolist(), g['aln_index'].tolist()
-        regions = []
-        for q in range(len(hit)):
-            pa = (tuple(aln[q][0][:n_aln[q][0]]),) if n_aln[q][0] else None
-            ea = (tuple(aln[q][1][:n_aln[q][1]]),) if n_aln[q][1] else None
-            regions.append(seq.Region(names[seq_id[q]], pos[q], end[q], is_rev=bool(is_rev[q]) if with_rev else False,
-                                      pos_aln_index=pa, end_aln_index=ea))
-        return regions
+    names = (ref_names, tig_names)
 
-    r_ref_outer, r_ref_inner = rgn_lists('ref_outer', ref_names, False), rgn_lists('ref_inner', ref_names, False)
-    r_tig_outer, r_tig_inner = rgn_lists('tig_outer', tig_names, True), rgn_lists('tig_inner', tig_names, True)
-    is_call = (sub['outcome'] == _lib.INV_CALL).tolist()
-    r_ref_disc = rgn_lists('ref_discovery', ref_names, False) if any(is_call) else None
-    r_tig_disc = rgn_lists('tig_discovery', tig_names, True) if any(is_call) else None
+    def base1(field, which):                                           # Region.to_base1_string of one result field, all hits
+        g = sub[field]
+        nm = names[which]
+        return ['{}:{}-{}'.format(nm[c], p + 1, e) for c, p, e in zip(g['seq_id'].tolist(), g['pos'].tolist(), g['end'].tolist())]
+
     sub_found, sub_outcome = sub['found'].tolist(), sub['outcome'].tolist()
     found_lines = []
+    if any(sub_found):
+        t_out, t_in, r_out, r_in = base1('tig_outer', 1), base1('tig_inner', 1), base1('ref_outer', 0), base1('ref_inner', 0)
     for q, i in enumerate(hit.tolist()):
         if sub_found[q]:
-            found_lines.append('INV Found: outer={}, inner={} (ref outer={}, inner={})'.format(
-                r_tig_outer[q], r_tig_inner[q], r_ref_outer[q], r_ref_inner[q]))
+            found_lines.append('INV Found: outer={}, inner={} (ref outer={}, inner={})'.format(t_out[q], t_in[q], r_out[q], r_in[q]))
         if sub_outcome[q] == _lib.INV_ERROR:
             out[i] = RuntimeError(errors[i])
         elif sub_outcome[q] == _lib.INV_CALL:
@@ -534,8 +557,7 @@ def _native_scan(ctx, region_flags, align_lift, k_util, max_region_size, logs, s
                 def df(i=i):                    # views of the library's pinned host copy; valid until the next scan
                     cols, flank, match = ctx.inv_table_view(i, generation)
                     return density.table_frame(cols, finalised=True, extra=_flank_match_text(flank.copy(), match.copy()))
-            out[i] = InvCall(r_ref_outer[q], r_ref_inner[q], r_tig_outer[q], r_tig_inner[q], r_ref_disc[q], r_tig_disc[q],
-                             region_flags[i], df)
+            out[i] = _NativeInvCall(sub[q], names, region_flags[i], df)
             out[i].native_table = (ctx, i, generation)   # the library's host copy: Context.inv_write_tables writes it as text
     if found_lines:
         print('\n'.join(found_lines))                                   # inv.py:408, one line per region in region order
