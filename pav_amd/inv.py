@@ -390,8 +390,13 @@ def annotate_inv_dup_mers(df, region_ref_outer, region_ref_inner, region_tig_out
 # ---------------------------------------------------------------------------------------------------------
 
 def _seq_index(ctx):
-    return ({n: i for i, n in enumerate(ctx.seq_names(_lib.PAV_ROLE_REF))},
-            {n: i for i, n in enumerate(ctx.seq_names(_lib.PAV_ROLE_TIG))})
+    """name -> record number for both stores (rebuilt only when a store was loaded again)."""
+    r, t = ctx.seq_names(_lib.PAV_ROLE_REF), ctx.seq_names(_lib.PAV_ROLE_TIG)
+    cache = getattr(ctx, '_seq_index_cache', None)
+    if cache is None or cache[0] is not r or cache[1] is not t:
+        cache = (r, t, {n: i for i, n in enumerate(r)}, {n: i for i, n in enumerate(t)})
+        ctx._seq_index_cache = cache
+    return cache[2], cache[3]
 
 
 def ensure_sequences(ctx, ref_fa_name, tig_fa_name):
