@@ -51,7 +51,8 @@ struct JobStat {                          // written by kernels, zeroed per batc
 struct JobKde {                           // host -> device after the first readback
     uint32_t finalised, n, n_samp, srs;
     uint32_t m[3], use_runs;              // use_runs: closed-form run sums (PAV_KDE_RUNS) for this job
-    uint32_t samp_off, pad;               // first entry of the job in the compact arrays of sampled sites (ks / ss)
+    uint32_t samp_off, ps_mask;           // first entry of the job in the compact arrays of sampled sites (ks / ss); states
+                                          // whose density is summed term by term and therefore need the scaled positions
     uint32_t run_off[3], n_run[3];        // per-state slices of the run arena
     double inv_h[3], norm[3], w[3], cnt[3], h[3];
 };
@@ -639,9 +640,9 @@ __global__ __launch_bounds__(256) void k_pscale(const JobDev *__restrict__ jobs,
     const JobKde kd = kde[j];
     if (!kd.finalised) return;
     const uint64_t t = ap - jobs[j].tpos_off;
-    if (t < kd.m[0]) p0[ap] = (double)l0[ap] * kd.inv_h[0];
-    if (t < kd.m[1]) p1[ap] = (double)l1[ap] * kd.inv_h[1];
-    if (t < kd.m[2]) p2[ap] = (double)l2[ap] * kd.inv_h[2];
+    if ((kd.ps_mask & 1u) && t < kd.m[0]) p0[ap] = (double)l0[ap] * kd.inv_h[0];
+    if ((kd.ps_mask & 2u) && t < kd.m[1]) p1[ap] = (double)l1[ap] * kd.inv_h[1];
+    if ((kd.ps_mask & 4u) && t < kd.m[2]) p2[ap] = (double)l2[ap] * kd.inv_h[2];
 }
 
 __device__ __forceinline__ int argmax3(double a, double b, double c) {   // np.argmax: first maximum wins
@@ -1446,6 +1447,14 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             PAV_HIP(ctx, hipMemcpyAsync(D->run_arena.p, arena.data(), sizeof(RunDev) * arena.size(), hipMemcpyHostToDevice, st));
         PAV_HIP(ctx, hipStreamSynchronize(st));                        // `arena` is a local buffer
     }
+    bool any_ps = false;
+    for (uint32_t j = 0; j < n_jobs; ++j) {                            // same choice as k_kde_eval makes per state
+        JobKde &kd = D->h_kde[j];
+        if (!kd.finalised) continue;
+        for (int q = 0; q < 3; ++q)
+            if (kd.m[q] && !(kd.use_runs && kd.h[q] >= KDE_RUNS_MIN_H)) kd.ps_mask |= 1u << q;
+        any_ps = any_ps || kd.ps_mask;
+    }
     lap("kde host");
     // failure path: the k-mer named in the message of scripts/density.py:519-526
     for (uint32_t j = 0; j < n_jobs; ++j) {
@@ -1475,9 +1484,10 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     KA.ss = D->ss.as<int8_t>();
 
     if (!tiles.empty()) {
-        PAV_LAUNCH(ctx, "k_pscale", k_pscale, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_kde, D->list[0].as<uint32_t>(),
-                   D->list[1].as<uint32_t>(), D->list[2].as<uint32_t>(), D->pscaled[0].as<double>(), D->pscaled[1].as<double>(),
-                   D->pscaled[2].as<double>());
+        if (any_ps)
+            PAV_LAUNCH(ctx, "k_pscale", k_pscale, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_kde, D->list[0].as<uint32_t>(),
+                       D->list[1].as<uint32_t>(), D->list[2].as<uint32_t>(), D->pscaled[0].as<double>(), D->pscaled[1].as<double>(),
+                       D->pscaled[2].as<double>());
         PAV_HIP(ctx, D->tiles.reserve(sizeof(EvalTile) * tiles.size()));
         PAV_HIP(ctx, hipMemcpyAsync(D->tiles.p, tiles.data(), sizeof(EvalTile) * tiles.size(), hipMemcpyHostToDevice, st));
         KA.tiles = D->tiles.as<EvalTile>();

@@ -372,12 +372,13 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
 
     const uint64_t max_batch_bp = 64000000ull;
     const bool timing = getenv("PAV_TIMING") != nullptr;
-    double t_batch = 0, t_table = 0;
+    double t_batch = 0, t_table = 0, t_pre = 0, t_post = 0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_start = now();
     while (!live.empty()) {
         std::vector<pav_den_job> jobs; std::vector<uint32_t> owners, rest;
         uint64_t budget = 0;
+        const double t_p0 = now();
         for (uint32_t i : live) {
             if (budget > max_batch_bp && !jobs.empty()) { rest.push_back(i); continue; }
             Scan &sc = scans[i];
@@ -402,9 +403,11 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
         if (jobs.empty()) { live.swap(rest); continue; }
         std::vector<pav_den_result> res(jobs.size());
         double t0 = now();
+        t_pre += t0 - t_p0;
         int rc = pav_density_batch(ctx, (uint32_t)jobs.size(), jobs.data(), &pp->den, res.data());
         t_batch += now() - t0;
         if (rc != PAV_OK) return rc;
+        const double t_q0 = now();
         std::vector<uint32_t> next;
         std::vector<CallFetch> round_calls; std::vector<uint32_t> round_owner;
         for (uint32_t j = 0; j < jobs.size(); ++j) {
@@ -497,6 +500,7 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
             if (sc.region_ref.len() == last_len) { log(i, "Reached reference limits, cannot expand"); finish(i, PAV_INV_NONE); continue; }
             next.push_back(i);
         }
+        t_post += now() - t_q0;
         if (!round_calls.empty()) {                                          // one pinned block, one synchronisation per round
             double t0 = now();
             // one pinned block per round, column-major over the whole round: K0 | K1 | K2 | KMER | INDEX | STATE_MER | STATE |
@@ -531,8 +535,8 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
         next.insert(next.end(), rest.begin(), rest.end());
         live.swap(next);
     }
-    if (timing) fprintf(stderr, "[pav timing] inv_scan_batch %.1f ms: density_batch %.1f, call tables + annotate %.1f\n",
-                        (now() - t_start) * 1e3, t_batch * 1e3, t_table * 1e3);
+    if (timing) fprintf(stderr, "[pav timing] inv_scan_batch %.1f ms: density_batch %.1f, call tables + annotate %.1f, lift + jobs %.2f, decisions %.2f\n",
+                        (now() - t_start) * 1e3, t_batch * 1e3, t_table * 1e3, t_pre * 1e3, t_post * 1e3);
     for (uint32_t i = 0; i < n_regions; ++i) {
         S->results[i].log_bytes = (uint32_t)S->logs[i].size();
         S->results[i].error_bytes = (uint32_t)S->errors[i].size();
