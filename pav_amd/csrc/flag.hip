@@ -74,8 +74,6 @@ __global__ __launch_bounds__(256) void k_cluster_emit(const uint64_t *__restrict
 
 // ---- keys from the device-resident call records ---------------------------------------------------------------------
 
-constexpr uint64_t SNV_SENTINEL = (1ull << 56) - 1;          // FILTER != PASS rows sort behind every chromosome
-constexpr uint64_t IND_SENTINEL = (1ull << 54) - 1;
 
 // One atomic per workgroup for a per-thread partial count: thousands of waves adding to one word serialise at ~11 ns each
 // (k_indel_keys spent 0.18 of its 0.20 ms there with one atomic per wave).  All 256 threads of the block must call it.
@@ -92,12 +90,12 @@ __device__ __forceinline__ void block_add(unsigned long long v, unsigned long lo
 __global__ __launch_bounds__(256) void k_snv_keys(const pav_snv *__restrict__ snv, uint64_t n, const pav_aln *__restrict__ aln,
                                                   const uint16_t *__restrict__ rank, const long long *__restrict__ tpos,
                                                   const long long *__restrict__ tend, unsigned long long *__restrict__ keys,
-                                                  unsigned long long *__restrict__ n_pass) {
+                                                  unsigned long long *__restrict__ n_pass, unsigned long long sentinel) {
     unsigned long long mine = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
         const pav_snv s = snv[i];
         const bool pass = (long long)s.pos > tpos[s.aln] && (long long)s.pos + 1 < tend[s.aln];
-        keys[i] = pass ? ((unsigned long long)rank[aln[s.aln].ref_id] << CM_SHIFT | s.pos) : SNV_SENTINEL;
+        keys[i] = pass ? ((unsigned long long)rank[aln[s.aln].ref_id] << CM_SHIFT | s.pos) : sentinel;
         mine += pass;
     }
     block_add(mine, n_pass);
@@ -107,14 +105,15 @@ __global__ __launch_bounds__(256) void k_snv_keys(const pav_snv *__restrict__ sn
 __global__ __launch_bounds__(256) void k_indel_keys(const pav_indel *__restrict__ ind, uint64_t n, const pav_aln *__restrict__ aln,
                                                     const uint16_t *__restrict__ rank, const long long *__restrict__ tpos,
                                                     const long long *__restrict__ tend, unsigned long long *__restrict__ keys,
-                                                    unsigned long long *__restrict__ counters) {
+                                                    unsigned long long *__restrict__ counters, unsigned long long tag,
+                                                    unsigned long long sentinel) {
     unsigned long long n_pass = 0, n_small = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
         const pav_indel v = ind[i];
         const bool pass = (long long)v.pos > tpos[v.aln] && (long long)v.end < tend[v.aln];
         const bool small = pass && v.svlen < 50;
-        keys[i] = small ? ((unsigned long long)rank[aln[v.aln].ref_id] << 38 | (unsigned long long)v.pos << 6 | (v.end - v.pos))
-                        : IND_SENTINEL;
+        keys[i] = small ? (tag | (unsigned long long)rank[aln[v.aln].ref_id] << 38 | (unsigned long long)v.pos << 6 | (v.end - v.pos))
+                        : sentinel;
         n_pass += pass;
         n_small += small;
     }
@@ -122,10 +121,10 @@ __global__ __launch_bounds__(256) void k_indel_keys(const pav_indel *__restrict_
     block_add(n_small, counters + 1);
 }
 
-__global__ __launch_bounds__(256) void k_indel_mid(unsigned long long *__restrict__ keys, uint64_t n) {
+__global__ __launch_bounds__(256) void k_indel_mid(unsigned long long *__restrict__ keys, uint64_t n, unsigned long long tag) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const unsigned long long k = keys[i];
+    const unsigned long long k = keys[i] & ~tag;
     const unsigned long long pos = (k >> 6) & 0xffffffffull, dlen = k & 63;
     keys[i] = (k >> 38) << CM_SHIFT | ((2 * pos + dlen) >> 1);            // (END + POS) // 2, :643
 }
@@ -548,17 +547,22 @@ int pav_cigar_flag(pav_ctx *ctx, const int64_t *trim_pos, const int64_t *trim_en
     // real rank - 24 chromosomes: 45 instead of 56 bits, six radix passes instead of seven
     unsigned rank_bits = 1;
     while ((1ull << rank_bits) < (uint64_t)n_ref + 1) ++rank_bits;
-    if (n_snv) {
-        PAV_HIP(ctx, S->a.reserve(8 * n_snv)); PAV_HIP(ctx, S->b.reserve(8 * n_snv));
-        PAV_LAUNCH(ctx, "k_snv_keys", k_snv_keys, (uint32_t)std::min<uint64_t>((n_snv + 255) / 256, 4u * (uint32_t)ctx->n_cu), 256, 0, ctx->d_snv.as<pav_snv>(), n_snv, d_aln, d_rank,
-                   d_tp, d_te, S->a.as<unsigned long long>(), d_cnt);
-        if ((rc = sort_keys(ctx, S, S->a.as<unsigned long long>(), S->b.as<unsigned long long>(), n_snv, CM_SHIFT + rank_bits)) != PAV_OK) return rc;
-    }
-    if (n_ind) {
-        PAV_HIP(ctx, S->c.reserve(8 * n_ind)); PAV_HIP(ctx, S->d.reserve(8 * n_ind));
-        PAV_LAUNCH(ctx, "k_indel_keys", k_indel_keys, (uint32_t)std::min<uint64_t>((n_ind + 255) / 256, 4u * (uint32_t)ctx->n_cu), 256, 0, ctx->d_indel.as<pav_indel>(), n_ind, d_aln, d_rank,
-                   d_tp, d_te, S->c.as<unsigned long long>(), d_cnt + 1);
-        if ((rc = sort_keys(ctx, S, S->c.as<unsigned long long>(), S->d.as<unsigned long long>(), n_ind, 38 + rank_bits)) != PAV_OK) return rc;
+    // One radix sort for both tables: the indel keys carry a tag bit above the widest key, so the sorted array holds the SNV keys
+    // (their sentinels last) and behind them the indel keys (a separate sort of the 0.6 M indel keys went through rocPRIM's merge
+    // sort: twenty small launches, 0.15 ms).
+    const unsigned long long tag = 1ull << (CM_SHIFT + rank_bits);
+    const uint64_t n_keys = n_snv + n_ind;
+    unsigned long long *k_in = nullptr, *k_sorted = nullptr;
+    if (n_keys) {
+        PAV_HIP(ctx, S->a.reserve(8 * n_keys)); PAV_HIP(ctx, S->b.reserve(8 * n_keys));
+        k_in = S->a.as<unsigned long long>(); k_sorted = S->b.as<unsigned long long>();
+        if (n_snv)
+            PAV_LAUNCH(ctx, "k_snv_keys", k_snv_keys, (uint32_t)std::min<uint64_t>((n_snv + 255) / 256, 4u * (uint32_t)ctx->n_cu), 256, 0, ctx->d_snv.as<pav_snv>(), n_snv, d_aln, d_rank,
+                       d_tp, d_te, k_in, d_cnt, tag - 1);
+        if (n_ind)
+            PAV_LAUNCH(ctx, "k_indel_keys", k_indel_keys, (uint32_t)std::min<uint64_t>((n_ind + 255) / 256, 4u * (uint32_t)ctx->n_cu), 256, 0, ctx->d_indel.as<pav_indel>(), n_ind, d_aln, d_rank,
+                       d_tp, d_te, k_in + n_snv, d_cnt + 1, tag, tag | (tag - 1));
+        if ((rc = sort_keys(ctx, S, k_in, k_sorted, n_keys, CM_SHIFT + rank_bits + 1)) != PAV_OK) return rc;
     }
     PAV_HIP(ctx, hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
     PAV_HIP(ctx, hipStreamSynchronize(st));
@@ -575,10 +579,10 @@ int pav_cigar_flag(pav_ctx *ctx, const int64_t *trim_pos, const int64_t *trim_en
     if (snv_pass) PAV_HIP(ctx, S->hits_b[0].reserve(sizeof(ClusterHit) * cap_snv));
     if (ind_small) PAV_HIP(ctx, S->hits_b[1].reserve(sizeof(ClusterHit) * cap_ind));
     PAV_HIP(ctx, hipMemsetAsync(d_cnt, 0, 128, st));
-    if ((rc = sweep_launch(ctx, S, S->b.as<unsigned long long>(), snv_pass, P->cluster_win, P->cluster_win, P->cluster_min_snv,
+    if ((rc = sweep_launch(ctx, S, k_sorted, snv_pass, P->cluster_win, P->cluster_win, P->cluster_min_snv,
                            S->hits_b[0].as<ClusterHit>(), d_cnt + 4)) != PAV_OK) return rc;
-    if (ind_small) PAV_LAUNCH(ctx, "k_indel_mid", k_indel_mid, (uint32_t)((ind_small + 255) / 256), 256, 0, S->d.as<unsigned long long>(), ind_small);
-    if ((rc = sweep_launch(ctx, S, S->d.as<unsigned long long>(), ind_small, P->cluster_win, P->cluster_win, P->cluster_min_indel,
+    if (ind_small) PAV_LAUNCH(ctx, "k_indel_mid", k_indel_mid, (uint32_t)((ind_small + 255) / 256), 256, 0, k_sorted + n_snv, ind_small, tag);
+    if ((rc = sweep_launch(ctx, S, k_sorted + n_snv, ind_small, P->cluster_win, P->cluster_win, P->cluster_min_indel,
                            S->hits_b[1].as<ClusterHit>(), d_cnt + 5)) != PAV_OK) return rc;
     if (ind_pass) {
         for (int t = 0; t < 2; ++t) {
