@@ -257,6 +257,7 @@ __global__ __launch_bounds__(256) void k_tig_state(const JobDev *__restrict__ jo
 // and the exact maximum and its k-mer come from the HBM-table kernels on that failure path.
 constexpr int LDS_SLOTS = 16384;
 constexpr int LDS_THREADS = 1024;
+constexpr int KU = 4;                                 // list entries a lane of k_kmer_lds has in flight
 constexpr uint32_t LDS_FILL = 7168;                  // k-mers per partition aimed at (load factor 0.44)
 constexpr uint32_t LDS_MAX_PARTS = 1024;             // histogram size of the bucket kernels (regions up to 7.3 Mbp)
 constexpr uint32_t LDS_MAX_LIMIT = 250;              // byte counts: the limit must stay below the wrap
@@ -380,23 +381,32 @@ __global__ __launch_bounds__(LDS_THREADS) void k_kmer_lds(const PartItem *__rest
         const uint32_t n = min(bcount[jd.bucket_off + it.part], jd.cap_r);
         const uint32_t *list = lists + jd.list_off_r + (uint64_t)it.part * jd.cap_r;
         uint32_t my_flags = 0;
-        for (uint32_t e = threadIdx.x; e < n; e += LDS_THREADS) {
-            uint64_t x;
-            kmer_window(R.two, R.mask, jd.ref_abs + list[e], k, x);
-            const uint64_t key = jd.ref_rc ? (x ^ kmer_mask(k)) : rev_groups(x, k);
-            uint32_t s = khash(key) & (LDS_SLOTS - 1);
-            int probes = 0;
-            while (true) {
-                const unsigned long long old = atomicCAS(&keys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
-                if (old == EMPTY_KEY) break;
-                if (old == key) {
-                    const uint32_t sh = 8 * (s & 3);
-                    const uint32_t prev = (atomicAdd(&cnt4[s >> 2], 1u << sh) >> sh) & 0xFFu;     // occurrences - 2
-                    if (prev + 2 > limit) my_flags |= LDS_EXCEED;
-                    break;
+        // KU list entries per lane and step: their positions, then their windows are fetched before the first insert, so
+        // that a lane has several global loads in flight (the kernel is latency-bound: 16 waves per CU, dependent loads)
+        for (uint32_t e0 = threadIdx.x; e0 < n; e0 += KU * LDS_THREADS) {
+            uint32_t pos[KU]; uint64_t x[KU]; bool ok[KU];
+#pragma unroll
+            for (int u = 0; u < KU; ++u) { const uint32_t e = e0 + u * LDS_THREADS; ok[u] = e < n; pos[u] = ok[u] ? list[e] : 0u; }
+#pragma unroll
+            for (int u = 0; u < KU; ++u) { x[u] = 0; if (ok[u]) kmer_window(R.two, R.mask, jd.ref_abs + pos[u], k, x[u]); }
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                if (!ok[u]) continue;
+                const uint64_t key = jd.ref_rc ? (x[u] ^ kmer_mask(k)) : rev_groups(x[u], k);
+                uint32_t s = khash(key) & (LDS_SLOTS - 1);
+                int probes = 0;
+                while (true) {
+                    const unsigned long long old = atomicCAS(&keys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+                    if (old == EMPTY_KEY) break;
+                    if (old == key) {
+                        const uint32_t sh = 8 * (s & 3);
+                        const uint32_t prev = (atomicAdd(&cnt4[s >> 2], 1u << sh) >> sh) & 0xFFu;     // occurrences - 2
+                        if (prev + 2 > limit) my_flags |= LDS_EXCEED;
+                        break;
+                    }
+                    s = (s + 1) & (LDS_SLOTS - 1);
+                    if (++probes >= LDS_SLOTS) { my_flags |= LDS_OVERFLOW; break; }
                 }
-                s = (s + 1) & (LDS_SLOTS - 1);
-                if (++probes >= LDS_SLOTS) { my_flags |= LDS_OVERFLOW; break; }
             }
         }
         if (my_flags) atomicOr(&flags, my_flags);
@@ -412,20 +422,26 @@ __global__ __launch_bounds__(LDS_THREADS) void k_kmer_lds(const PartItem *__rest
         const uint32_t n = min(bcount[jd.bucket_off + b], jd.cap_t);
         const uint32_t *list = lists + jd.list_off_t + (uint64_t)(side * P + it.part) * jd.cap_t;
         uint8_t *ans = side ? ans_c : ans_f;
-        for (uint32_t e = threadIdx.x; e < n; e += LDS_THREADS) {
-            const uint32_t pos = list[e];
-            uint64_t x;
-            kmer_window(T.two, T.mask, jd.tig_abs + pos, k, x);
-            const uint64_t key = side ? (x ^ kmer_mask(k)) : rev_groups(x, k);
-            uint32_t s = khash(key) & (LDS_SLOTS - 1);
-            uint32_t a = ANS_ABSENT;
-            for (int probes = 0; probes < LDS_SLOTS; ++probes) {
-                const unsigned long long cur = keys[s];
-                if (cur == key) { a = ANS_PRESENT; break; }
-                if (cur == EMPTY_KEY) break;
-                s = (s + 1) & (LDS_SLOTS - 1);
+        for (uint32_t e0 = threadIdx.x; e0 < n; e0 += KU * LDS_THREADS) {
+            uint32_t pos[KU]; uint64_t x[KU]; bool ok[KU];
+#pragma unroll
+            for (int u = 0; u < KU; ++u) { const uint32_t e = e0 + u * LDS_THREADS; ok[u] = e < n; pos[u] = ok[u] ? list[e] : 0u; }
+#pragma unroll
+            for (int u = 0; u < KU; ++u) { x[u] = 0; if (ok[u]) kmer_window(T.two, T.mask, jd.tig_abs + pos[u], k, x[u]); }
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                if (!ok[u]) continue;
+                const uint64_t key = side ? (x[u] ^ kmer_mask(k)) : rev_groups(x[u], k);
+                uint32_t s = khash(key) & (LDS_SLOTS - 1);
+                uint32_t a = ANS_ABSENT;
+                for (int probes = 0; probes < LDS_SLOTS; ++probes) {
+                    const unsigned long long cur = keys[s];
+                    if (cur == key) { a = ANS_PRESENT; break; }
+                    if (cur == EMPTY_KEY) break;
+                    s = (s + 1) & (LDS_SLOTS - 1);
+                }
+                ans[jd.tpos_off + pos[u]] = (uint8_t)a;
             }
-            ans[jd.tpos_off + pos] = (uint8_t)a;
         }
     }
 }
