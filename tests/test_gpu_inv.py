@@ -455,3 +455,30 @@ def test_density_vs_oracle_seeded(built, gpu_ctx, seed, mode, kmer):
             for c in KERN:
                 assert np.allclose(cols[c], o[c], rtol=RTOL, atol=1e-300), c
     assert n_final >= 4
+
+
+def test_files_to_files_tool(built, tmp_path):
+    """tools/bench_e2e.py at a small scale: FASTA + alignment tables in, every output file of the rule chain out (merged
+    SNV / INS-DEL tables, five flag tables, INV BED, density tables, log), through the native readers and writers."""
+    import gzip
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / 'e2e'
+    p = subprocess.run([sys.executable, os.path.join(root, 'tools', 'bench_e2e.py'), '--scale', '0.02', '--inv-sig-filter', 'single_cluster',
+                        '--out', str(out)], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line['snv_rows'] > 1000 and line['insdel_rows'] > 100 and line['aligned_bp'] > 10_000_000
+    assert line['scanned_regions'] == line['flagged_regions'] > 0
+    for name in ('snv_snv_h1.bed.gz', 'svindel_insdel_h1.bed.gz', 'flag_flagged_regions_h1.bed.gz', 'inv_call_h1.log'):
+        assert (out / name).exists(), name
+    with gzip.open(out / 'snv_snv_h1.bed.gz', 'rt') as fh:
+        snv = pd.read_csv(fh, sep='\t')
+    assert snv.shape[0] == line['snv_rows'] and list(snv.columns[:4]) == ['#CHROM', 'POS', 'END', 'ID']
+    key = list(zip(snv['#CHROM'], snv['POS']))
+    assert key == sorted(key)                                                    # merged order of rule call_cigar_merge
+    if line['inv_calls']:
+        inv = pd.read_csv(out / 'sv_inv_h1.bed.gz', sep='\t')
+        assert inv.shape[0] == line['inv_calls']
+        assert len(os.listdir(out / 'density_table')) == line['inv_calls']
