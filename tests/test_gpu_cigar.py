@@ -438,3 +438,25 @@ def test_verify_mode_counts_bases_that_contradict_the_cigar(built, gpu_ctx):
     want = _verify_numpy(ref2, tig2, hap.tig_names, names, aln, ops2, op_off2)
     assert want['eq_mismatch'] > 100 and want['x_match'] > 0
     assert v2 == want
+
+
+def test_merged_tables_of_an_empty_alignment_table(built, gpu_ctx, tmp_path):
+    """No alignment rows: call_cigar_merged_files writes the two header-only tables the rule chain writes
+    (call_cigar_files x 10 -> call_cigar_merge on the same empty input)."""
+    import gzip
+    d, df_align, df_trim = util.golden_case('cigar_empty')
+    assert df_align.shape[0] == 0
+    ins, snvs = [], []
+    for batch in range(10):
+        o1, o2 = str(tmp_path / f'insdel_{batch}.bed.gz'), str(tmp_path / f'snv_{batch}.bed.gz')
+        rules.call_cigar_files(f'{d}/align.tsv', f'{d}/trim.tsv', f'{d}/tig.fa', f'{d}/ref.fa', 'h1', batch, o1, o2, ctx=gpu_ctx)
+        ins.append(o1)
+        snvs.append(o2)
+    w1, w2 = str(tmp_path / 'want_insdel.bed.gz'), str(tmp_path / 'want_snv.bed.gz')
+    rules.call_cigar_merge(ins, snvs, w1, w2)
+    m1, m2 = str(tmp_path / 'insdel.bed.gz'), str(tmp_path / 'snv.bed.gz')
+    assert rules.call_cigar_merged_files(f'{d}/align.tsv', f'{d}/trim.tsv', f'{d}/tig.fa', f'{d}/ref.fa', 'h1', m1, m2, ctx=gpu_ctx) == (0, 0)
+    for got, want in ((m1, w1), (m2, w2)):
+        with gzip.open(got, 'rb') as a, gzip.open(want, 'rb') as b:
+            text = a.read()
+            assert text == b.read() and text.count(b'\n') == 1
