@@ -5,6 +5,8 @@
   python tools/prof_summary.py pmc   <db> <out.txt>            per-kernel average counter value per launch
   python tools/prof_summary.py pmcjson <fetch.db> <write.db> <bench.json> <out.json>   per-kernel FETCH_SIZE / WRITE_SIZE averages
                                                                (KiB per dispatch) keyed to the workload of the bench line
+  python tools/prof_summary.py sq    <db> <out.txt>            per-kernel SQ counters of one --pmc pass as fractions of the wave cycles
+                                                               (issuing / parked / issue-stalled) and of the LDS-array cycles
   python tools/prof_summary.py timeline <db> <out.txt> [ms]    kernels (and copies) of the last [ms] of the trace in start order,
                                                                with the idle gap in front of each (us)
 """
@@ -85,6 +87,30 @@ def pmcjson(fetch_db, write_db, bench_json, out):
     print(open(out).read())
 
 
+def sq(db, out):
+    cur = sqlite3.connect(db).cursor()
+    per = {}
+    for n, c, k, a in cur.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
+                                  "group by kernel_name, counter_name"):
+        per.setdefault(short(n), {})[c] = (k, a)
+    cols = ['SQ_ACTIVE_INST_ANY', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_WAIT_INST_LDS']
+    rows = sorted(per.items(), key=lambda kv: -kv[1].get('SQ_WAVE_CYCLES', (0, 0))[1])
+    with open(out, 'w') as fh:
+        fh.write(f'# rocprofv3 --pmc (one SQ pass, {db}); averages per launch.  wave_cyc = SQ_WAVE_CYCLES (quad-cycles summed over\n'
+                 '# the waves); issue / parked / stall / stall_lds = SQ_ACTIVE_INST_ANY / SQ_WAIT_ANY (s_waitcnt, barrier) /\n'
+                 '# SQ_WAIT_INST_ANY / SQ_WAIT_INST_LDS as fractions of wave_cyc; lds_cyc = SQ_LDS_IDX_ACTIVE (LDS-array cycles),\n'
+                 '# conflict = SQ_LDS_BANK_CONFLICT / lds_cyc, unaligned = SQ_LDS_UNALIGNED_STALL / lds_cyc.\n')
+        fh.write(f'{"kernel":34s} {"launches":>8s} {"wave_cyc":>14s} {"issue":>7s} {"parked":>7s} {"stall":>7s} {"stall_lds":>9s} '
+                 f'{"lds_cyc":>14s} {"conflict":>8s} {"unaligned":>9s}\n')
+        for n, c in rows:
+            k, wc = c.get('SQ_WAVE_CYCLES', (0, 0.0))
+            lds = c.get('SQ_LDS_IDX_ACTIVE', (0, 0.0))[1]
+            fr = ['%7.3f' % (c.get(x, (0, 0.0))[1] / wc) if wc else '%7s' % '-' for x in cols]
+            lf = ['%8.3f' % (c.get(x, (0, 0.0))[1] / lds) if lds else '%8s' % '-' for x in ('SQ_LDS_BANK_CONFLICT', 'SQ_LDS_UNALIGNED_STALL')]
+            fh.write(f'{n:34s} {k:8d} {wc:14.0f} {fr[0]} {fr[1]} {fr[2]} {fr[3]:>9s} {lds:14.0f} {lf[0]} {lf[1]:>9s}\n')
+    print(open(out).read())
+
+
 def timeline(db, out, last_ms=30.0):
     cur = sqlite3.connect(db).cursor()
     ev = [(s, e, short(n)) for n, s, e in cur.execute('select name, start, end from kernels')]
@@ -111,4 +137,4 @@ if __name__ == '__main__':
     elif sys.argv[1] == 'timeline':
         timeline(sys.argv[2], sys.argv[3], float(sys.argv[4]) if len(sys.argv) > 4 else 30.0)
     else:
-        {'stats': stats, 'pmc': pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])
+        {'stats': stats, 'pmc': pmc, 'sq': sq}[sys.argv[1]](sys.argv[2], sys.argv[3])
