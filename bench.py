@@ -347,7 +347,7 @@ def main():
             kern_ = {k: {'launches': v[0], 'avg_ms': v[1] / max(1, v[0])} for k, v in prof_.items()}
             dom = want or max(kern_, key=lambda k: kern_[k]['avg_ms'] * kern_[k]['launches'])
             alg_bytes = {
-                'verify_kernel': 0.75 * float(counts.aligned_bases),          # 0.375 B of packed planes per base, both sequences
+                'verify_kernel': 0.5 * float(counts.aligned_bases),           # the two 2-bit planes; masks only where marked dirty
                 'pack_kernel': tig_bases * (1.0 + 0.25 + 0.125),
                 'tok_count': float(text.shape[0]),
                 'tok_emit': float(text.shape[0]) + 4.0 * n_ops,

@@ -155,7 +155,8 @@ int pav_cigar_fetch(pav_ctx *ctx, pav_snv *snv, pav_indel *indel, uint8_t *seq_b
  * at '=' runs (pavlib/cigarcall.py:91-93).  A base of an '=' run is wrong when the two codes differ or exactly one side
  * is non-ACGT; a base of an 'X' run is wrong when both sides are the same ACGT base or both are non-ACGT (case is folded,
  * contigs of reverse rows are read reverse-complemented).  first_bad_op: smallest global operation ordinal with a wrong
- * base (see pav_cigar_fetch_ops), ~0 when none.  One HBM-bound kernel: 0.75 B of packed planes per aligned base. */
+ * base (see pav_cigar_fetch_ops), ~0 when none.  One streaming kernel: 0.5 B of 2-bit planes per aligned base
+ * (the non-ACGT planes are read only where the pack's per-1024-base summary marks a block). */
 typedef struct { uint64_t eq_bases, eq_mismatch, x_bases, x_match, first_bad_op; } pav_verify_counts;
 int pav_cigar_verify(pav_ctx *ctx, pav_verify_counts *counts);
 /* Tokenised operations of the last pav_cigar_call: ops[i] = len << 4 | BAM opcode; op_off has n_aln + 1 entries. */

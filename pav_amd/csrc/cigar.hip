@@ -227,7 +227,8 @@ __global__ __launch_bounds__(256) void walk_reduce(const uint32_t *__restrict__ 
 
 // Single workgroup: exclusive scan of the per-chunk sums; totals[NQ] = grand totals.
 __global__ __launch_bounds__(256) void walk_chunks(const uint64_t *__restrict__ chunk_sum, uint64_t *__restrict__ chunk_pre,
-                                                   uint64_t *__restrict__ totals, uint32_t n_chunks) {
+                                                   uint64_t *__restrict__ totals, uint32_t n_chunks,
+                                                   volatile uint64_t *host_status) {
     __shared__ uint64_t lds[4 * NQ];
     __shared__ uint64_t carry[NQ];
     if (threadIdx.x < NQ) carry[threadIdx.x] = 0;
@@ -251,17 +252,26 @@ __global__ __launch_bounds__(256) void walk_chunks(const uint64_t *__restrict__ 
         totals[threadIdx.x] = carry[threadIdx.x];
         chunk_pre[(uint64_t)n_chunks * NQ + threadIdx.x] = carry[threadIdx.x];   // read by rows that start at n_ops
     }
+    // the status block goes straight into the host's pinned words (mapped into the device's address space): the runtime's
+    // copy kernel for a device-to-host copy issued here does not retire until the concurrent pack has drained (~0.3 ms)
+    if (host_status) {
+        if (threadIdx.x < NQ) host_status[threadIdx.x] = carry[threadIdx.x];
+        else if (threadIdx.x == NQ) host_status[NQ] = totals[NQ];           // tokenizer error key (tok_emit / row_ops ran before us)
+    }
 }
 
-// One wave per row: running (ref, tig) advance of all ops before the row's first op.
+// One wave per row: running (ref, tig) advance of all ops before the row's first op; and for every 2048-operation chunk that
+// starts inside the row, the row (chunk_row: the walk / verify workgroups start from it instead of searching op_off with
+// ten dependent loads each).
 __global__ __launch_bounds__(256) void row_base(const uint32_t *__restrict__ ops, const uint64_t *__restrict__ op_off,
                                                 const uint64_t *__restrict__ chunk_pre, uint64_t *__restrict__ rowbase,
-                                                uint32_t n_aln) {
+                                                uint32_t *__restrict__ chunk_row, uint32_t n_aln) {
     const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_aln) return;
     const int lane = threadIdx.x & 63;
-    const uint64_t first = op_off[r];
+    const uint64_t first = op_off[r], next = op_off[r + 1];
     const uint64_t c = first / WALK_CHUNK;
+    for (uint64_t cc = (first + WALK_CHUNK - 1) / WALK_CHUNK + lane; cc * WALK_CHUNK < next; cc += 64) chunk_row[cc] = r;
     uint64_t a = 0, b = 0;
     for (uint64_t i = c * WALK_CHUNK + lane; i < first; i += 64) {
         uint64_t q[NQ];
@@ -279,7 +289,7 @@ __global__ __launch_bounds__(256) void row_base(const uint32_t *__restrict__ ops
 struct WalkArgs {
     const uint32_t *ops; uint64_t n_ops;
     const uint64_t *op_off; const pav_aln *aln; uint32_t n_aln;
-    const uint64_t *chunk_pre; const uint64_t *rowbase;
+    const uint64_t *chunk_pre; const uint64_t *rowbase; const uint32_t *chunk_row;
     SeqView ref, tig;
     pav_snv *snv; pav_indel *indel;
     unsigned long long *err_op;          // smallest global ordinal of an illegal op (M, N, P)
@@ -289,7 +299,6 @@ struct WalkArgs {
 // positions and its output slots, so the output order is exactly the reference's (row, op, base) order.
 __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
     __shared__ uint64_t lds[4 * NQ];
-    __shared__ uint32_t s_row0;
     const uint64_t first = (uint64_t)blockIdx.x * WALK_CHUNK + (uint64_t)threadIdx.x * OPS_PER_LANE;
     uint32_t o[OPS_PER_LANE];
     load_ops(A.ops, A.n_ops, first, o);
@@ -305,19 +314,9 @@ __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) run[q] += A.chunk_pre[(uint64_t)blockIdx.x * NQ + q];
 
-    // row of this lane's first op: the workgroup's first row is found once (binary search by lane 0), lanes walk on
-    if (threadIdx.x == 0) {
-        const uint64_t f0 = (uint64_t)blockIdx.x * WALK_CHUNK;
-        uint32_t lo = 0, hi = A.n_aln;            // invariant: op_off[lo] <= f0 < op_off[hi]
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (A.op_off[mid] <= f0) lo = mid; else hi = mid;
-        }
-        s_row0 = lo;
-    }
-    __syncthreads();
+    // row of this lane's first op: the row of the chunk's first op comes from row_base (chunk_row), lanes walk on
     if (first >= A.n_ops) return;
-    uint32_t row = s_row0;
+    uint32_t row = A.chunk_row[blockIdx.x];
     uint64_t row_end = A.op_off[row + 1];
     while (row_end <= first) { ++row; row_end = A.op_off[row + 1]; }      // rows without ops are skipped
     pav_aln al = A.aln[row];
@@ -396,14 +395,14 @@ __global__ __launch_bounds__(256) void snv_bases(pav_snv *__restrict__ snv, uint
 // ---- verify mode ----------------------------------------------------------------------------------------------------------
 // Streams both packed sequences along every '=' and 'X' operation and checks what the aligner claimed: every base of an '='
 // run equal, every base of an 'X' run different (SURVEY.md section 8(d) "verify mode"; the reference trusts the CIGAR -
-// pavlib/cigarcall.py:91-93 skips '=' runs without looking at them).  The HBM-bound member of the call path: 0.375 B of packed
-// planes per reference base + 0.375 B per contig base.  Operation positions come from the same block scan as walk_emit; the
-// workgroup then cuts its runs into 64-base pieces, one lane per piece (one unaligned 128-bit window of each 2-bit plane,
+// pavlib/cigarcall.py:91-93 skips '=' runs without looking at them).  The streaming member of the call path: 0.25 B of 2-bit
+// plane per reference base + 0.25 B per contig base (non-ACGT planes only where SeqView::dirty marks a block).  Operation positions come from the same block scan as walk_emit; the
+// workgroup then cuts its runs into 64-base pieces, one lane per piece (one unaligned 64-base window of each 2-bit plane,
 // reversed and complemented for reverse-strand rows).
 struct VerifyArgs {
     const uint32_t *ops; uint64_t n_ops;
     const uint64_t *op_off; const pav_aln *aln; uint32_t n_aln;
-    const uint64_t *chunk_pre; const uint64_t *rowbase;
+    const uint64_t *chunk_pre; const uint64_t *rowbase; const uint32_t *chunk_row;
     SeqView ref, tig;
     unsigned long long *cnt;             // [0] '=' bases, [1] of them different, [2] 'X' bases, [3] of them equal, [4] first bad op
 };
@@ -412,18 +411,18 @@ typedef unsigned __int128 u128;
 constexpr uint32_t VPIECE = 64;                                        // bases per lane and step
 constexpr int VSPLIT = 2;                                              // workgroups per 2048-operation chunk
 
-// Two aligned 16-byte loads cover the three 64-bit words an unaligned 64-base window touches (16 B per lane is the widest and
-// cheapest global load; three 8-byte loads per window made the kernel load-instruction bound).
-__device__ __forceinline__ u128 window128(const uint32_t *__restrict__ two, uint64_t a) {            // 64 bases from position a
-    const uint64_t w = a >> 5;                                          // first 64-bit word
-    const uint4 *p = reinterpret_cast<const uint4 *>(two) + (w >> 1);
-    const uint4 q0 = p[0], q1 = p[1];
-    const uint64_t v[4] = {(uint64_t)q0.y << 32 | q0.x, (uint64_t)q0.w << 32 | q0.z, (uint64_t)q1.y << 32 | q1.x, (uint64_t)q1.w << 32 | q1.z};
-    const int o = (int)(w & 1);
-    const uint64_t v0 = o ? v[1] : v[0], v1 = o ? v[2] : v[1], v2 = o ? v[3] : v[2];
-    const int b = (int)(a & 31) * 2;
-    const uint64_t lo = b ? (v0 >> b | v1 << (64 - b)) : v0, hi = b ? (v1 >> b | v2 << (64 - b)) : v1;
-    return (u128)hi << 64 | lo;
+// Five dwords from the dword that holds base a (4-byte aligned 16-byte load + 1 dword): the 64-base window is bits [2 (a & 15), + 128).
+struct W5 { uint32_t w[5]; };
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ W5 window_dw(const uint32_t *__restrict__ two, uint64_t a) {
+    const uint32_t *p = two + (a >> 4);
+    const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(p);
+    return W5{{v.x, v.y, v.z, v.w, p[4]}};
+}
+__device__ __forceinline__ void align_dw(const W5 &x, uint64_t a, uint32_t (&out)[4]) {
+    const uint32_t sh = ((uint32_t)a & 15u) * 2u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = __builtin_amdgcn_alignbit(x.w[i + 1], x.w[i], sh);
 }
 __device__ __forceinline__ uint64_t window64(const uint32_t *__restrict__ mask, uint64_t a) {         // 64 mask bits from position a
     const uint64_t *m64 = reinterpret_cast<const uint64_t *>(mask);
@@ -432,6 +431,13 @@ __device__ __forceinline__ uint64_t window64(const uint32_t *__restrict__ mask, 
     const uint64_t v0 = m64[w], v1 = m64[w + 1];
     return b ? (v0 >> b | v1 << (64 - b)) : v0;
 }
+__device__ __forceinline__ uint64_t low_bits(uint32_t n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
+__device__ __forceinline__ bool dirty_span(const uint8_t *__restrict__ dirty, uint64_t a) {              // any non-ACGT in [a, a + 64)?
+    const uint64_t d0 = a >> DIRTY_SHIFT, d1 = (a + 63) >> DIRTY_SHIFT;
+    uint32_t d = dirty[d0];
+    if (d1 != d0) d |= dirty[d1];
+    return d != 0;
+}
 __device__ __forceinline__ uint64_t spread32(uint32_t x32) {                                          // bit i -> bit 2i
     uint64_t x = x32;
     x = (x | x << 16) & 0x0000FFFF0000FFFFull; x = (x | x << 8) & 0x00FF00FF00FF00FFull; x = (x | x << 4) & 0x0F0F0F0F0F0F0F0Full;
@@ -439,14 +445,12 @@ __device__ __forceinline__ uint64_t spread32(uint32_t x32) {                    
     return x;
 }
 __device__ __forceinline__ u128 spread64(uint64_t m) { return (u128)spread32((uint32_t)(m >> 32)) << 64 | spread32((uint32_t)m); }
-__device__ __forceinline__ u128 brev128(u128 x) { return (u128)__brevll((uint64_t)x) << 64 | __brevll((uint64_t)(x >> 64)); }
 __device__ __forceinline__ int popc128(u128 x) { return __popcll((uint64_t)x) + __popcll((uint64_t)(x >> 64)); }
 
 __global__ __launch_bounds__(256) void verify_kernel(VerifyArgs A) {
     __shared__ uint64_t lds[4 * NQ];
-    __shared__ uint32_t s_row0;
     // VSPLIT workgroups share a 2048-operation chunk: all repeat its (cheap) scan, each keeps the descriptors of one part - a
-    // fraction of the LDS per workgroup, more waves per CU for the latency-bound gather below (1: 0.94 ms, 2: 0.74 ms, 4: 0.82 ms per haplotype).
+    // fraction of the LDS per workgroup, more waves per CU for the latency-bound gather below (1: 0.46 ms, 2: 0.38 ms, 4: 0.41 ms per haplotype).
     constexpr int VSLOTS = WALK_CHUNK / VSPLIT;
     __shared__ uint64_t d_ref[VSLOTS], d_tig[VSLOTS];
     __shared__ uint32_t d_len[VSLOTS];                                   // len << 2 | rev << 1 | is 'X'; 0 = nothing to check
@@ -465,12 +469,6 @@ __global__ __launch_bounds__(256) void verify_kernel(VerifyArgs A) {
     block_excl_scan<NQ>(run, tot, lds);
     run[0] += A.chunk_pre[(uint64_t)chunk * NQ + 0];
     run[1] += A.chunk_pre[(uint64_t)chunk * NQ + 1];
-    if (threadIdx.x == 0) {
-        const uint64_t f0 = (uint64_t)chunk * WALK_CHUNK;
-        uint32_t lo = 0, hi = A.n_aln;
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (A.op_off[mid] <= f0) lo = mid; else hi = mid; }
-        s_row0 = lo;
-    }
     const bool mine_half = threadIdx.x * OPS_PER_LANE >= slot0 && threadIdx.x * OPS_PER_LANE < slot0 + VSLOTS;
     const uint32_t my0 = threadIdx.x * OPS_PER_LANE - slot0;             // this lane's first descriptor slot (its 8 ops lie in one half)
     if (mine_half)
@@ -478,7 +476,7 @@ __global__ __launch_bounds__(256) void verify_kernel(VerifyArgs A) {
         for (int j = 0; j < OPS_PER_LANE; ++j) d_len[my0 + j] = 0;
     __syncthreads();
     if (first < A.n_ops) {
-        uint32_t row = s_row0;
+        uint32_t row = A.chunk_row[chunk];
         uint64_t row_end = A.op_off[row + 1];
         while (row_end <= first) { ++row; row_end = A.op_off[row + 1]; }
         pav_aln al = A.aln[row];
@@ -543,57 +541,100 @@ __global__ __launch_bounds__(256) void verify_kernel(VerifyArgs A) {
         if (threadIdx.x == 0) tbl[n_grp] = VSLOTS - 1;
     }
     __syncthreads();
+    // The loop is bound by instruction issue, not by HBM (SQ counters: one wave per SIMD issuing at any time), so the data
+    // path works on dwords: an unaligned 64-base window = one 4-byte-aligned 16-byte load + one dword, put in place with four
+    // v_alignbit; reverse-strand windows are loaded so that they END at the piece's first base (bit reversal alone then puts
+    // the bases in scan order); the non-ACGT planes are read only where the pack's summary marks a block (SeqView::dirty).
     constexpr int UNROLL = 2;                                            // pieces in flight per lane: the loads of both are
-    for (uint32_t g0 = 0; g0 < n_grp; g0 += UNROLL) {                    // issued before the first compare
-        uint32_t q[UNROLL], n[UNROLL];
-        u128 xr[UNROLL], xt[UNROLL];
-        uint64_t mr[UNROLL], mt[UNROLL];
-        bool live[UNROLL], rev[UNROLL], is_x[UNROLL];
+    constexpr uint32_t EVEN = 0x55555555u;                               // issued before the first compare
+    for (uint32_t g0 = 0; g0 < n_grp; g0 += UNROLL) {
+        uint32_t q[UNROLL], n[UNROLL], flags[UNROLL], lsh[UNROLL];
+        uint8_t dr[UNROLL][2], dt[UNROLL][2];                            // summary bytes of the blocks a window touches (used after all loads are out)
+        uint64_t pr[UNROLL], pt[UNROLL];
+        W5 xr[UNROLL], xt[UNROLL];
+        bool live[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
-            const uint32_t g = g0 + u, piece = g * 256 + threadIdx.x;
-            live[u] = g < n_grp && piece < n_pieces;
-            q[u] = 0; n[u] = 0; xr[u] = xt[u] = 0; mr[u] = mt[u] = 0; rev[u] = is_x[u] = false;
-            if (!live[u]) continue;
+            // lanes past the last piece repeat it with n = 0: no branch around the loads, so nothing of piece u has to be
+            // waited for before the loads of piece u + 1 are issued (a skipped block made the compiler merge, and wait)
+            const uint32_t want = (g0 + u) * 256 + threadIdx.x;
+            live[u] = want < n_pieces;
+            const uint32_t piece = live[u] ? want : n_pieces - 1, g = piece >> 8;
             uint32_t lo = use_tbl ? tbl[g] : 0u, hi = (use_tbl ? (uint32_t)tbl[g + 1] : (uint32_t)VSLOTS - 1) + 1;
             while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_pre[mid] <= piece) lo = mid; else hi = mid; }
             // (slots without pieces share their prefix with the slot after them, so the largest such slot is the owner of the piece)
             q[u] = lo;
             const uint32_t dl = d_len[lo], len = dl >> 2;
-            rev[u] = dl & 2u; is_x[u] = dl & 1u;
+            flags[u] = dl & 3u;                                          // bit 1 reverse row, bit 0 'X'
             const uint64_t ra = d_ref[lo], ta = d_tig[lo];
             const uint32_t b = (piece - s_pre[lo]) * VPIECE;
-            n[u] = min(VPIECE, len - b);
-            xr[u] = window128(A.ref.two, ra + b);
-            mr[u] = window64(A.ref.mask, ra + b);
-            const uint64_t s0 = rev[u] ? ta - b - (n[u] - 1) : ta + b;   // reverse rows: lowest stored base of this window
-            xt[u] = window128(A.tig.two, s0);
-            mt[u] = window64(A.tig.mask, s0);
+            n[u] = live[u] ? min(VPIECE, len - b) : 0u;
+            pr[u] = ra + b;
+            // forward rows: the window starts at the piece's first base.  Reverse rows: it ends there (stored bases ta-b-63 .. ta-b);
+            // at the very start of the arena it starts at 0 and the reversed window is moved down by the missing bases (lsh)
+            uint64_t s0 = ta + b;
+            if (flags[u] & 2u) {
+                const uint64_t e = ta - b;
+                lsh[u] = e < 63 ? (uint32_t)(63 - e) : 0u;
+                s0 = e < 63 ? 0ull : e - 63;
+            }
+            pt[u] = s0;
+            dr[u][0] = A.ref.dirty[pr[u] >> DIRTY_SHIFT]; dr[u][1] = A.ref.dirty[(pr[u] + 63) >> DIRTY_SHIFT];
+            dt[u][0] = A.tig.dirty[s0 >> DIRTY_SHIFT]; dt[u][1] = A.tig.dirty[(s0 + 63) >> DIRTY_SHIFT];
+            xr[u] = window_dw(A.ref.two, pr[u]);
+            xt[u] = window_dw(A.tig.two, s0);
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
-            if (!live[u]) continue;
-            const uint64_t keep = n[u] == 64 ? ~0ull : (1ull << n[u]) - 1ull;
-            u128 t2 = xt[u];
-            uint64_t tm = mt[u] & keep;
-            if (rev[u]) {
-                u128 r = brev128(xt[u] << (2 * (64 - n[u])));           // groups reversed, bits inside a group swapped
-                const u128 odd = (u128)0xAAAAAAAAAAAAAAAAull << 64 | 0xAAAAAAAAAAAAAAAAull;
-                r = ((r & odd) >> 1) | ((r & (odd >> 1)) << 1);
-                t2 = ~r;                                                // complement
-                tm = __brevll(mt[u] << (64 - n[u])) & keep;
+            uint32_t r[4], t[4];
+            align_dw(xr[u], pr[u], r);
+            align_dw(xt[u], pt[u], t);
+            uint64_t rm = 0, tm = 0;
+            if (dr[u][0] | dr[u][1] | dt[u][0] | dt[u][1]) {             // rare: a non-ACGT base somewhere near
+                const uint64_t keep = n[u] == 64 ? ~0ull : (1ull << n[u]) - 1ull;
+                rm = window64(A.ref.mask, pr[u]) & keep;
+                tm = window64(A.tig.mask, pt[u]);
+                if (flags[u] & 2u) tm = __brevll(tm) >> lsh[u];
+                tm &= keep;
             }
-            const uint64_t rm = mr[u] & keep;
-            const u128 even = (u128)0x5555555555555555ull << 64 | 0x5555555555555555ull;
-            const u128 kmask = spread64(keep);
-            const u128 d = xr[u] ^ t2;
-            const u128 neq = (d | d >> 1) & even & kmask;                                  // bit 2i: base i differs
-            const u128 one_n = spread64(rm ^ tm), both_n = spread64(rm & tm);               // non-ACGT on one / on both sides
-            // '=' : wrong when the codes differ (unless both are non-ACGT) or exactly one side is non-ACGT
-            // 'X' : wrong when both are ACGT and equal, or both are non-ACGT (the planes cannot tell N from N)
-            const u128 wrong = is_x[u] ? ((~neq & kmask & ~one_n) | both_n) : ((neq & ~both_n) | one_n);
-            const uint32_t bad = (uint32_t)popc128(wrong);
-            if (is_x[u]) { n_x += n[u]; bad_x += bad; } else { n_eq += n[u]; bad_eq += bad; }
+            if (flags[u] & 2u) {
+                // bit reversal: bases in scan order with the two bits of every base swapped; swap them back and complement
+                uint32_t v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t x = __brev(t[3 - i]);
+                    v[i] = ~(((x & ~EVEN) >> 1) | ((x & EVEN) << 1));
+                }
+                if (lsh[u]) {                                            // window clipped at arena position 0 (first bases of record 0)
+                    u128 w = (u128)v[3] << 96 | (u128)v[2] << 64 | (u128)v[1] << 32 | v[0];
+                    w >>= 2 * lsh[u];
+                    v[0] = (uint32_t)w; v[1] = (uint32_t)(w >> 32); v[2] = (uint32_t)(w >> 64); v[3] = (uint32_t)(w >> 96);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t[i] = v[i];
+            }
+            // bit 2j of dword i: base 16 i + j differs; km keeps the n bases of the piece; 'X' pieces count the equal ones
+            const uint32_t xm = (flags[u] & 1u) ? EVEN : 0u;
+            uint32_t bad = 0;
+            uint32_t neq[4], km[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int have = (int)n[u] - 16 * i;                     // bases of the piece in this dword
+                km[i] = have >= 16 ? EVEN : (have <= 0 ? 0u : EVEN & ((1u << (2 * have)) - 1u));
+                const uint32_t d = r[i] ^ t[i];
+                neq[i] = (d | d >> 1) & km[i];
+                bad += __popc((neq[i] ^ xm) & km[i]);
+            }
+            if (rm | tm) {
+                const u128 nq = (u128)neq[3] << 96 | (u128)neq[2] << 64 | (u128)neq[1] << 32 | neq[0];
+                const u128 kmask = (u128)km[3] << 96 | (u128)km[2] << 64 | (u128)km[1] << 32 | km[0];
+                const u128 one_n = spread64(rm ^ tm), both_n = spread64(rm & tm);           // non-ACGT on one / on both sides
+                // '=' : wrong when the codes differ (unless both are non-ACGT) or exactly one side is non-ACGT
+                // 'X' : wrong when both are ACGT and equal, or both are non-ACGT (the planes cannot tell N from N)
+                const u128 wrong = (flags[u] & 1u) ? ((~nq & kmask & ~one_n) | both_n) : ((nq & ~both_n) | one_n);
+                bad = (uint32_t)popc128(wrong);
+            }
+            if (flags[u] & 1u) { n_x += n[u]; bad_x += bad; } else { n_eq += n[u]; bad_eq += bad; }
             if (bad) first_bad = min(first_bad, (unsigned long long)chunk * WALK_CHUNK + slot0 + (unsigned long long)q[u]);
         }
     }
@@ -717,6 +758,7 @@ __global__ __launch_bounds__(256) void lift_positions(const uint32_t *__restrict
 // starts at phase 0; longer SVs are compared window by window up to the wrap point.
 struct SeqRef {                 // one oriented record of a store
     const uint32_t *two, *mask;
+    const uint8_t *dirty;
     uint64_t off, len;
     int rev;
 };
@@ -741,11 +783,18 @@ __device__ __forceinline__ void fetch_run(const SeqRef &s, int64_t p, int dir, i
     const int b = (int)(abs & 31) * 2;
     uint64_t x = two64[w] >> b;
     if (b) x |= two64[w + 1] << (64 - b);
-    const uint64_t w2 = abs >> 6;
-    const int b2 = (int)(abs & 63);
-    uint64_t y = mask64[w2] >> b2;
-    if (b2) y |= mask64[w2 + 1] << (64 - b2);
-    uint32_t m = (uint32_t)y;
+    // non-ACGT bits: only blocks the summary marks hold any (SeqView::dirty)
+    const uint64_t d0 = abs >> DIRTY_SHIFT, d1 = (abs + (uint64_t)(n - 1)) >> DIRTY_SHIFT;
+    uint32_t dirty = s.dirty[d0];
+    if (d1 != d0) dirty |= s.dirty[d1];
+    uint32_t m = 0;
+    if (dirty) {
+        const uint64_t w2 = abs >> 6;
+        const int b2 = (int)(abs & 63);
+        uint64_t y = mask64[w2] >> b2;
+        if (b2) y |= mask64[w2 + 1] << (64 - b2);
+        m = (uint32_t)y;
+    }
     if (n < 32) { x &= low_bits64(2 * n); m &= (1u << n) - 1u; }
     if (sdir < 0) { x = reverse_groups(x, n); m = __brev(m) >> (32 - n); }
     if (s.rev) x ^= low_bits64(2 * n);                                // complement every base
@@ -825,11 +874,12 @@ __device__ uint32_t wave_hom_scan(bool active, const SeqRef &t, int64_t t_pos, i
     while (pending) {
         const int src = __ffsll((long long)pending) - 1;
         pending &= pending - 1;
-        SeqRef bt{t.two, t.mask, (uint64_t)bcast64((int64_t)t.off, src), (uint64_t)bcast64((int64_t)t.len, src), __shfl(t.rev, src)};
-        SeqRef bs{sv.two, sv.mask, (uint64_t)bcast64((int64_t)sv.off, src), (uint64_t)bcast64((int64_t)sv.len, src), __shfl(sv.rev, src)};
+        SeqRef bt{t.two, t.mask, t.dirty, (uint64_t)bcast64((int64_t)t.off, src), (uint64_t)bcast64((int64_t)t.len, src), __shfl(t.rev, src)};
+        SeqRef bs{sv.two, sv.mask, sv.dirty, (uint64_t)bcast64((int64_t)sv.off, src), (uint64_t)bcast64((int64_t)sv.len, src), __shfl(sv.rev, src)};
         // the two planes differ between stores (reference / contig): broadcast the pointers as well
         bt.two = (const uint32_t *)bcast64((int64_t)t.two, src); bt.mask = (const uint32_t *)bcast64((int64_t)t.mask, src);
         bs.two = (const uint32_t *)bcast64((int64_t)sv.two, src); bs.mask = (const uint32_t *)bcast64((int64_t)sv.mask, src);
+        bt.dirty = (const uint8_t *)bcast64((int64_t)t.dirty, src); bs.dirty = (const uint8_t *)bcast64((int64_t)sv.dirty, src);
         const int64_t b_pos = bcast64(t_pos, src), b_avail = bcast64(avail, src), b_svpos = bcast64(sv_pos, src),
                       b_svlen = bcast64(svlen, src);
         const int b_dir = __shfl(dir, src);
@@ -886,6 +936,124 @@ __device__ uint32_t wave_hom_scan(bool active, const SeqRef &t, int64_t t_pos, i
     return res;
 }
 
+// The four breakpoint scans of one INS / DEL (cigarcall.py:178-182, 247-251) share seq_sv and are independent of each other:
+// they advance in lockstep, so that a lane has the windows of all its unfinished scans in flight at once instead of one
+// dependent load chain per scan (the kernel is latency-bound: 88 % of its wave cycles are spent parked in s_waitcnt).
+// Scan s walks t[s] from t_pos[s] in direction dir[s] (-1 left_homology / +1 right_homology) for at most avail[s] bases.
+// Up to three windows per scan and lane; scans still running are finished by the whole wave as in wave_hom_scan.
+struct ScanSide { SeqRef t; int64_t t_pos, avail; int dir; };
+
+__device__ void wave_hom_scan4(bool active, const ScanSide (&sc)[4], const SeqRef &sv, int64_t sv_pos, int64_t svlen, uint32_t (&res)[4]) {
+    const int lane = threadIdx.x & 63;
+    int64_t h[4] = {0, 0, 0, 0};
+    bool done[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) done[s] = !active || svlen <= 0 || sc[s].avail <= 0;
+    const bool periodic = svlen <= 32;
+    // one period of seq_sv in either scan order, replicated to a whole number of periods (phase 0 at every window start)
+    uint64_t P[2] = {0, 0}; uint32_t M[2] = {0, 0};
+    int n = 32;
+    if (active && periodic && svlen > 0) {
+        const int L = (int)svlen;
+        uint64_t pc[2]; uint32_t pm[2];
+        fetch_run(sv, sv_pos + svlen - 1, -1, L, pc[0], pm[0]);
+        fetch_run(sv, sv_pos, +1, L, pc[1], pm[1]);
+        const int reps = 32 / L;
+        n = reps * L;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            uint64_t x = pc[d]; uint32_t y = pm[d];
+            for (int have = 1; have < reps; ) {                    // doubling: have periods -> min(2 have, reps)
+                const int add = have < reps - have ? have : reps - have;
+                x |= (x & low_bits64(2 * L * add)) << (2 * L * have);
+                y |= (y & (uint32_t)low_bits64(L * add)) << (L * have);
+                have += add;
+            }
+            P[d] = x; M[d] = y;
+        }
+    }
+    for (int step = 0; step < 3; ++step) {
+        int m[4]; uint64_t tc[4], pc[4]; uint32_t tm[4], pm[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {                               // every load of this step is issued before any is used
+            m[s] = 0;
+            if (done[s]) continue;
+            const int dir = sc[s].dir;
+            int64_t mm = sc[s].avail - h[s] < n ? sc[s].avail - h[s] : n;
+            if (periodic) { pc[s] = P[dir > 0]; pm[s] = M[dir > 0]; }
+            else {
+                const int64_t idx = dir < 0 ? svlen - 1 - (h[s] % svlen) : h[s] % svlen;
+                const int64_t to_wrap = dir < 0 ? idx + 1 : svlen - idx;
+                if (to_wrap < mm) mm = to_wrap;
+                fetch_run(sv, sv_pos + idx, dir, (int)mm, pc[s], pm[s]);
+            }
+            m[s] = (int)mm;
+            fetch_run(sc[s].t, sc[s].t_pos + dir * h[s], dir, m[s], tc[s], tm[s]);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (done[s]) continue;
+            const int st = first_stop(tc[s], pc[s], tm[s] | pm[s], m[s]);
+            h[s] += st;
+            if (st < m[s] || h[s] >= sc[s].avail) done[s] = true;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        res[s] = (uint32_t)h[s];
+        unsigned long long pending = __ballot(!done[s]);
+        while (pending) {                                           // long scan: lane c takes the c-th window from h on
+            const int src = __ffsll((long long)pending) - 1;
+            pending &= pending - 1;
+            SeqRef bt, bs;
+            bt.two = (const uint32_t *)bcast64((int64_t)sc[s].t.two, src); bt.mask = (const uint32_t *)bcast64((int64_t)sc[s].t.mask, src);
+            bt.off = (uint64_t)bcast64((int64_t)sc[s].t.off, src); bt.len = (uint64_t)bcast64((int64_t)sc[s].t.len, src); bt.rev = __shfl(sc[s].t.rev, src);
+            bs.two = (const uint32_t *)bcast64((int64_t)sv.two, src); bs.mask = (const uint32_t *)bcast64((int64_t)sv.mask, src);
+            bt.dirty = (const uint8_t *)bcast64((int64_t)sc[s].t.dirty, src); bs.dirty = (const uint8_t *)bcast64((int64_t)sv.dirty, src);
+            bs.off = (uint64_t)bcast64((int64_t)sv.off, src); bs.len = (uint64_t)bcast64((int64_t)sv.len, src); bs.rev = __shfl(sv.rev, src);
+            const int64_t b_pos = bcast64(sc[s].t_pos, src), b_avail = bcast64(sc[s].avail, src), b_svpos = bcast64(sv_pos, src),
+                          b_svlen = bcast64(svlen, src);
+            const int b_dir = sc[s].dir;                            // the direction of scan s is the same in every lane
+            const bool b_periodic = b_svlen <= 32;
+            const int b_n = __shfl(n, src);
+            const uint64_t bP = (uint64_t)bcast64((int64_t)P[b_dir > 0], src);
+            const uint32_t bM = (uint32_t)__shfl((int)M[b_dir > 0], src);
+            int64_t hh = bcast64(h[s], src);
+            int64_t found_at = -1;
+            while (found_at < 0) {
+                const int64_t my_h = hh + (int64_t)lane * b_n;
+                int64_t mm = b_avail - my_h;
+                if (mm > b_n) mm = b_n;
+                if (mm < 0) mm = 0;
+                const int mw = (int)mm;
+                int st = mw;
+                if (mw > 0) {
+                    uint64_t tcw, scw; uint32_t tmw, smw;
+                    fetch_run(bt, b_pos + b_dir * my_h, b_dir, mw, tcw, tmw);
+                    if (b_periodic) { scw = bP; smw = bM; }
+                    else {
+                        const int64_t idx = b_dir < 0 ? (b_svlen - 1 - (my_h % b_svlen)) : (my_h % b_svlen);
+                        const int64_t to_wrap = b_dir < 0 ? idx + 1 : b_svlen - idx;
+                        const int m1 = (int)(to_wrap < mw ? to_wrap : mw);
+                        fetch_run(bs, b_svpos + idx, b_dir, m1, scw, smw);
+                        if (m1 < mw) {
+                            uint64_t sc2; uint32_t sm2;
+                            fetch_run(bs, b_svpos + (b_dir < 0 ? b_svlen - 1 : 0), b_dir, mw - m1, sc2, sm2);
+                            scw |= sc2 << (2 * m1); smw |= sm2 << m1;
+                        }
+                    }
+                    st = first_stop(tcw, scw, tmw | smw, mw);
+                }
+                const bool stop_here = st < mw || mw < b_n;
+                const unsigned long long hit = __ballot(stop_here);
+                if (hit) found_at = bcast64(my_h + st, __ffsll((long long)hit) - 1);
+                else hh += 64ll * b_n;
+            }
+            if (lane == src) res[s] = (uint32_t)found_at;
+        }
+    }
+}
+
 // left_homology(pos_tig, seq_tig, seq_sv)   call.py:542-592: walks upstream from pos while hom_len <= pos_tig
 __device__ __forceinline__ uint32_t left_hom(const SeqRef &t, int64_t pos, const SeqRef &sv, int64_t sv_pos, int64_t svlen) {
     bool done;
@@ -900,12 +1068,9 @@ __device__ __forceinline__ uint32_t right_hom(const SeqRef &t, int64_t pos, cons
     bool done;
     return hom_scan(t, pos, +1, (int64_t)t.len - pos, sv, sv_pos, svlen, 0x7FFFFFFF, done);
 }
-__device__ __forceinline__ uint32_t wave_right_hom(bool active, const SeqRef &t, int64_t pos, const SeqRef &sv, int64_t sv_pos, int64_t svlen) {
-    return wave_hom_scan(active, t, pos, +1, (int64_t)t.len - pos, sv, sv_pos, svlen);
-}
 
-// One lane per INS/DEL stub: left shift + four breakpoint homologies, then the final coordinates.  The five scans are
-// wave-uniform calls (long scans are finished cooperatively), so no lane leaves early.
+// One lane per INS/DEL stub: left shift, then the four breakpoint homologies in lockstep (wave_hom_scan4), then the final
+// coordinates.  The scans are wave-uniform calls (long scans are finished cooperatively), so no lane leaves early.
 __global__ __launch_bounds__(256) void homology_kernel(pav_indel *__restrict__ indel, uint64_t n_indel,
                                                        const pav_aln *__restrict__ aln, SeqView R, SeqView T) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -913,8 +1078,8 @@ __global__ __launch_bounds__(256) void homology_kernel(pav_indel *__restrict__ i
     pav_indel r = indel[active ? i : 0];
     const pav_aln al = aln[r.aln];
     const int rev = al.rev != 0;
-    const SeqRef ref{R.two, R.mask, R.off[al.ref_id], R.len[al.ref_id], 0};
-    const SeqRef tig{T.two, T.mask, T.off[al.tig_id], T.len[al.tig_id], rev};
+    const SeqRef ref{R.two, R.mask, R.dirty, R.off[al.ref_id], R.len[al.ref_id], 0};
+    const SeqRef tig{T.two, T.mask, T.dirty, T.off[al.tig_id], T.len[al.tig_id], rev};
     const int64_t pos_ref = r.pos, pos_tig = r.qry_pos, oplen = r.svlen, tig_len = (int64_t)tig.len;
     const bool ins = r.svtype == 0;
     const SeqRef svs = ins ? tig : ref;                // seq = seq_tig[pos_tig:+oplen] / seq_ref[pos_ref:+oplen]
@@ -925,12 +1090,13 @@ __global__ __launch_bounds__(256) void homology_kernel(pav_indel *__restrict__ i
     const int64_t sv_pos_ref = pos_ref - shift, sv_pos_tig = pos_tig - shift;
     if (ins && shift) sv_at = sv_pos_tig;              // INS: seq re-sliced at the shifted position (:162-163)
     // INS: :178-182;  DEL: :247-251
-    const uint32_t h_rl = wave_left_hom(active, ref, sv_pos_ref - 1, svs, sv_at, oplen);
-    const uint32_t h_rr = wave_right_hom(active, ref, ins ? sv_pos_ref : sv_pos_ref + oplen, svs, sv_at, oplen);
-    const uint32_t h_tl = wave_left_hom(active, tig, sv_pos_tig - 1, svs, sv_at, oplen);
-    const uint32_t h_tr = wave_right_hom(active, tig, ins ? sv_pos_tig + oplen : sv_pos_tig, svs, sv_at, oplen);
+    const int64_t p_rr = ins ? sv_pos_ref : sv_pos_ref + oplen, p_tr = ins ? sv_pos_tig + oplen : sv_pos_tig;
+    const ScanSide sides[4] = {{ref, sv_pos_ref - 1, sv_pos_ref, -1}, {ref, p_rr, (int64_t)ref.len - p_rr, +1},
+                               {tig, sv_pos_tig - 1, sv_pos_tig, -1}, {tig, p_tr, tig_len - p_tr, +1}};
+    uint32_t hom[4];
+    wave_hom_scan4(active, sides, svs, sv_at, oplen, hom);
     if (!active) return;
-    r.hom_ref_l = h_rl; r.hom_ref_r = h_rr; r.hom_tig_l = h_tl; r.hom_tig_r = h_tr;
+    r.hom_ref_l = hom[0]; r.hom_ref_r = hom[1]; r.hom_tig_l = hom[2]; r.hom_tig_r = hom[3];
     if (ins) {
         r.pos = (uint32_t)sv_pos_ref; r.end = (uint32_t)(sv_pos_ref + 1);           // :157-158
         if (rev) { r.qry_end = (uint32_t)(tig_len - sv_pos_tig); r.qry_pos = r.qry_end - (uint32_t)oplen; }   // :167-169
@@ -978,8 +1144,8 @@ __global__ void homology_query_kernel(const pav_hom_query *__restrict__ q, uint3
     const pav_hom_query h = q[i];
     const SeqView &a = h.role == PAV_ROLE_REF ? R : T;
     const SeqView &b = h.sv_role == PAV_ROLE_REF ? R : T;
-    const SeqRef t{a.two, a.mask, a.off[h.seq_id], a.len[h.seq_id], h.rev != 0};
-    const SeqRef sv{b.two, b.mask, b.off[h.sv_seq_id], b.len[h.sv_seq_id], h.sv_rev != 0};
+    const SeqRef t{a.two, a.mask, a.dirty, a.off[h.seq_id], a.len[h.seq_id], h.rev != 0};
+    const SeqRef sv{b.two, b.mask, b.dirty, b.off[h.sv_seq_id], b.len[h.sv_seq_id], h.sv_rev != 0};
     out[i] = h.dir == 0 ? left_hom(t, h.pos, sv, h.sv_pos, h.svlen) : right_hom(t, h.pos, sv, h.sv_pos, h.svlen);
 }
 
@@ -1069,13 +1235,15 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
         PAV_HIP(ctx, ctx->d_chunk2.reserve(2 * sizeof(uint64_t) * NQ * ((size_t)n_wchunks + 1)));
         d_csum = ctx->d_chunk2.as<uint64_t>();
         d_cpre = d_csum + (size_t)NQ * (n_wchunks + 1);
-        PAV_HIP(ctx, ctx->d_rowbase.reserve(2 * sizeof(uint64_t) * ((size_t)n_aln + 1)));
+        PAV_HIP(ctx, ctx->d_rowbase.reserve(2 * sizeof(uint64_t) * ((size_t)n_aln + 1) + sizeof(uint32_t) * ((size_t)n_wchunks + 1)));
         PAV_LAUNCH(ctx, "walk_reduce", walk_reduce, n_wchunks, 256, 0, ctx->d_ops.as<uint32_t>(), n_ops, d_csum);
-        PAV_LAUNCH(ctx, "walk_chunks", walk_chunks, 1, 256, 0, d_csum, d_cpre, ctx->d_totals.as<uint64_t>(), n_wchunks);
+        PAV_LAUNCH(ctx, "walk_chunks", walk_chunks, 1, 256, 0, d_csum, d_cpre, ctx->d_totals.as<uint64_t>(), n_wchunks, h_status);
         PAV_LAUNCH(ctx, "row_base", row_base, (n_aln + 3) / 4, 256, 0, ctx->d_ops.as<uint32_t>(),
-                   ctx->d_op_off.as<uint64_t>(), d_cpre, ctx->d_rowbase.as<uint64_t>(), n_aln);
+                   ctx->d_op_off.as<uint64_t>(), d_cpre, ctx->d_rowbase.as<uint64_t>(),
+                   reinterpret_cast<uint32_t *>(ctx->d_rowbase.as<uint64_t>() + 2 * ((size_t)n_aln + 1)), n_aln);
+    } else {
+        PAV_HIP(ctx, hipMemcpyAsync(h_status, ctx->d_totals.p, (NQ + 2) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     }
-    PAV_HIP(ctx, hipMemcpyAsync(h_status, ctx->d_totals.p, (NQ + 2) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int q = 0; q < NQ; ++q) totals[q] = h_status[q];
     errs[0] = h_status[NQ];
@@ -1095,6 +1263,7 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
         A.ops = ctx->d_ops.as<uint32_t>(); A.n_ops = n_ops;
         A.op_off = ctx->d_op_off.as<uint64_t>(); A.aln = ctx->d_aln.as<pav_aln>(); A.n_aln = n_aln;
         A.chunk_pre = d_cpre; A.rowbase = ctx->d_rowbase.as<uint64_t>();
+        A.chunk_row = reinterpret_cast<const uint32_t *>(A.rowbase + 2 * ((size_t)n_aln + 1));
         A.ref = ctx->seq[PAV_ROLE_REF].view(); A.tig = ctx->seq[PAV_ROLE_TIG].view();
         A.snv = ctx->d_snv.as<pav_snv>(); A.indel = ctx->d_indel.as<pav_indel>();
         A.err_op = d_err_op;
@@ -1224,6 +1393,7 @@ int pav_cigar_verify(pav_ctx *ctx, pav_verify_counts *out) {
     A.ops = ctx->d_ops.as<uint32_t>(); A.n_ops = n_ops;
     A.op_off = ctx->d_op_off.as<uint64_t>(); A.aln = ctx->d_aln.as<pav_aln>(); A.n_aln = ctx->n_aln;
     A.chunk_pre = ctx->d_chunk2.as<uint64_t>() + (size_t)NQ * (n_wchunks + 1); A.rowbase = ctx->d_rowbase.as<uint64_t>();
+    A.chunk_row = reinterpret_cast<const uint32_t *>(A.rowbase + 2 * ((size_t)ctx->n_aln + 1));
     A.ref = ctx->seq[PAV_ROLE_REF].view(); A.tig = ctx->seq[PAV_ROLE_TIG].view();
     A.cnt = d_cnt;
     PAV_LAUNCH(ctx, "verify_kernel", verify_kernel, VSPLIT * n_wchunks, 256, 0, A);

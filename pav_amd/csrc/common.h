@@ -15,6 +15,7 @@
 namespace pav {
 
 constexpr int WAVE = 64;                 // CDNA wavefront
+constexpr int DIRTY_SHIFT = 10;          // granularity of SeqView::dirty (1024 bases = what one wave packs per load)
 constexpr uint64_t SEQ_ALIGN = 256;      // every record starts on a 256-base boundary of the arena
 
 // ---- grow-only device buffer ------------------------------------------------------------------------------
@@ -39,6 +40,7 @@ struct SeqView {                          // passed by value to kernels
     const uint8_t *ascii;                 // arena bytes
     const uint32_t *two;                  // 2-bit plane, 16 bases / word, base i at bits 2*(i&15)
     const uint32_t *mask;                 // non-ACGT plane, 32 bases / word, base i at bit (i&31)
+    const uint8_t *dirty;                 // one byte per 2^DIRTY_SHIFT bases: non-zero when the block holds a non-ACGT base
     const uint64_t *off;                  // per record: first base in the arena (multiple of SEQ_ALIGN)
     const uint64_t *len;                  // per record: length
     uint32_t n;
@@ -49,9 +51,9 @@ struct SeqStore {
     uint64_t arena = 0;                   // bases incl. padding
     uint64_t total = 0;                   // bases excl. padding
     std::vector<uint64_t> off, len;
-    DevBuf d_ascii, d_two, d_mask, d_off, d_len;
+    DevBuf d_ascii, d_two, d_mask, d_dirty, d_off, d_len;
     SeqView view() const {
-        return SeqView{d_ascii.as<uint8_t>(), d_two.as<uint32_t>(), d_mask.as<uint32_t>(),
+        return SeqView{d_ascii.as<uint8_t>(), d_two.as<uint32_t>(), d_mask.as<uint32_t>(), d_dirty.as<uint8_t>(),
                        d_off.as<uint64_t>(), d_len.as<uint64_t>(), n};
     }
 };

@@ -92,11 +92,14 @@ __device__ __forceinline__ void pack4(uint32_t x, uint32_t &codes8, uint32_t &ba
 // Tuned on MI355X (tools/ubench/pack_variants.hip): four independent 16-byte loads in flight per lane, non-temporal
 // loads and stores (every byte is touched once), one 16 KiB tile per workgroup with an exact grid (a capped
 // grid-stride launch was 20 % slower): 6.0 TB/s of algorithmic traffic vs 4.5 TB/s for the first version.
+// A wave also writes one summary byte per 1024 bases (dirty: the block holds a non-ACGT base).  Non-ACGT bases are rare, so
+// the random-access readers (breakpoint homology, verify mode) look at the summary - a few MB that stay in L2 - and fetch a
+// line of the mask plane only for dirty blocks: half of their cache-line fetches otherwise.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int PACK_U = 4;
 
 __global__ __launch_bounds__(256) void pack_kernel(const uint4 *__restrict__ ascii, uint32_t *__restrict__ two,
-                                                   uint32_t *__restrict__ mask, uint64_t n16) {
+                                                   uint32_t *__restrict__ mask, uint8_t *__restrict__ dirty, uint64_t n16) {
     const uint64_t base = (uint64_t)blockIdx.x * (256 * PACK_U) + threadIdx.x;
     u32x4 v[PACK_U];
 #pragma unroll
@@ -112,6 +115,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint4 *__restrict__ asc
         pack4(v[u].x, c0, b0); pack4(v[u].y, c1, b1); pack4(v[u].z, c2, b2); pack4(v[u].w, c3, b3);
         const uint32_t m16 = b0 | (b1 << 4) | (b2 << 8) | (b3 << 12);
         const uint32_t other = __shfl_xor(m16, 1);                    // n16 is even: the partner always exists
+        const unsigned long long any_bad = __ballot(m16 != 0);
+        if ((threadIdx.x & 63) == 0) dirty[(uint64_t)blockIdx.x * 16 + u * 4 + (threadIdx.x >> 6)] = any_bad != 0;
         if (i < n16) {
             __builtin_nontemporal_store(c0 | (c1 << 8) | (c2 << 16) | (c3 << 24), &two[i]);
             if ((threadIdx.x & 1) == 0) __builtin_nontemporal_store(m16 | (other << 16), &mask[i >> 1]);
@@ -124,7 +129,7 @@ static int run_pack(pav_ctx *ctx, SeqStore &s, hipStream_t st) {
     const uint64_t n16 = s.arena / 16;
     const uint64_t blocks = (n16 + 256 * PACK_U - 1) / (256 * PACK_U);
     PAV_LAUNCH_ON(ctx, st, "pack_kernel", pack_kernel, (uint32_t)blocks, 256, 0, s.d_ascii.as<uint4>(),
-                  s.d_two.as<uint32_t>(), s.d_mask.as<uint32_t>(), n16);
+                  s.d_two.as<uint32_t>(), s.d_mask.as<uint32_t>(), s.d_dirty.as<uint8_t>(), n16);
     return PAV_OK;
 }
 
@@ -210,7 +215,7 @@ void pav_destroy(pav_ctx *ctx) {
     for (auto ev : ctx->ev_pool) (void)hipEventDestroy(ev);
     for (int r = 0; r < 2; ++r) {
         SeqStore &s = ctx->seq[r];
-        s.d_ascii.release(); s.d_two.release(); s.d_mask.release(); s.d_off.release(); s.d_len.release();
+        s.d_ascii.release(); s.d_two.release(); s.d_mask.release(); s.d_dirty.release(); s.d_off.release(); s.d_len.release();
     }
     DevBuf *bufs[] = {&ctx->d_aln, &ctx->d_text, &ctx->d_text_off, &ctx->d_ops, &ctx->d_op_off, &ctx->d_chunk,
                       &ctx->d_chunk2, &ctx->d_rowbase, &ctx->d_totals, &ctx->d_snv, &ctx->d_indel,
@@ -273,6 +278,7 @@ int pav_seq_load(pav_ctx *ctx, int role, uint32_t n_seq, const uint8_t *const *a
     PAV_HIP(ctx, s.d_ascii.reserve(a));
     PAV_HIP(ctx, s.d_two.reserve(a / 4));
     PAV_HIP(ctx, s.d_mask.reserve(a / 8));
+    PAV_HIP(ctx, s.d_dirty.reserve((a / 16 + 256 * PACK_U - 1) / (256 * PACK_U) * 16));   // 16 summary bytes per pack workgroup
     PAV_HIP(ctx, s.d_off.reserve(sizeof(uint64_t) * n_seq));
     PAV_HIP(ctx, s.d_len.reserve(sizeof(uint64_t) * n_seq));
     PAV_HIP(ctx, hipMemsetAsync(s.d_ascii.p, 'N', a, ctx->stream));          // padding reads as non-ACGT

@@ -440,6 +440,61 @@ def test_verify_mode_counts_bases_that_contradict_the_cigar(built, gpu_ctx):
     assert v2 == want
 
 
+def test_verify_mode_window_edges(built, gpu_ctx):
+    """pav_cigar_verify on rows without clipping: reverse rows that reach the first stored bases of the first contig (the
+    kernel's window would start before arena position 0), runs whose length sits on the 16 / 32 / 64-base boundaries of the
+    dword data path, mismatches and N at the first and last base of a run, and runs next to non-ACGT blocks."""
+    import pandas as pd
+    rng = np.random.default_rng(9)
+    acgt = np.frombuffer(b'ACGT', dtype=np.uint8)
+    comp = np.arange(256, dtype=np.uint8)
+    for a, b in zip(b'ACGTN', b'TGCAN'):
+        comp[a] = b
+    ref = acgt[rng.integers(0, 4, 6000)].copy()
+    rows, tigs = [], {}
+    pos = 7
+    lengths = [49, 1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 63, 64, 65, 79, 80, 81, 127, 128, 129, 191, 200, 300]
+    for i, ln in enumerate(lengths):
+        seg = ref[pos:pos + ln].copy()
+        rev = i % 2 == 0                                                  # row 0 (the first contig of the arena) is reverse
+        bad = []
+        if ln >= 3 and i % 3 == 0:
+            bad = [0, ln - 1]                                              # wrong first and last base of the run
+        for j in bad:
+            seg[j] = acgt[(np.searchsorted(acgt, seg[j]) + 1) % 4]
+        if i % 5 == 4:
+            seg[ln // 2] = ord('N')                                        # N on the contig only
+        if i % 7 == 6:
+            seg[ln // 3] = ord('N'); ref[pos + ln // 3] = ord('N')         # N on both sides
+        name = f'tig{i}'
+        tigs[name] = comp[seg[::-1]].copy() if rev else seg
+        rows.append({'#CHROM': 'chrT', 'POS': pos, 'QRY_ID': name, 'REV': rev, 'CIGAR': f'{ln}='})
+        pos += ln + 11
+    # an 'X' run of 40 bases that is right (every base differs) and one that is wrong in two places, reverse and forward
+    for i, rev in enumerate((True, False)):
+        seg = ref[pos:pos + 40].copy()
+        seg = acgt[(np.searchsorted(acgt, seg) + 1 + i) % 4]
+        if i == 1:
+            seg[[0, 39]] = ref[[pos, pos + 39]]
+        name = f'x{i}'
+        tigs[name] = comp[seg[::-1]].copy() if rev else seg
+        rows.append({'#CHROM': 'chrT', 'POS': pos, 'QRY_ID': name, 'REV': rev, 'CIGAR': '40X'})
+        pos += 51
+    df = pd.DataFrame(rows)
+    names, tig_names = ['chrT'], list(tigs)
+    aln, text, off = cigarcall.pack_alignments(df, names, tig_names)
+    gpu_ctx._inv_loaded = None
+    gpu_ctx.seq_load(_lib.PAV_ROLE_REF, names, [ref])
+    gpu_ctx.seq_load(_lib.PAV_ROLE_TIG, tig_names, [tigs[n] for n in tig_names])
+    gpu_ctx.cigar_load(aln, text, off)
+    counts = gpu_ctx.cigar_call()
+    ops, op_off = gpu_ctx.cigar_fetch_ops(counts.n_ops, aln.shape[0])
+    got = gpu_ctx.cigar_verify()
+    want = _verify_numpy({'chrT': ref}, tigs, tig_names, names, aln, ops, op_off)
+    assert want['eq_mismatch'] >= 16 and want['x_match'] == 2 and want['first_bad_op'] == 0
+    assert got == want
+
+
 def test_merged_tables_of_an_empty_alignment_table(built, gpu_ctx, tmp_path):
     """No alignment rows: call_cigar_merged_files writes the two header-only tables the rule chain writes
     (call_cigar_files x 10 -> call_cigar_merge on the same empty input)."""
