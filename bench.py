@@ -257,6 +257,14 @@ def main():
         ctx.seq_pack(_lib.PAV_ROLE_TIG)
         ctx.sync()
     pack_alone = ctx.prof_read().get('pack_kernel')
+    # ... and the call kernels with the planes already packed and no pack beside them
+    ctx.prof_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.cigar_call()
+    ctx.sync()
+    call_alone = {'ms_per_call': round((time.perf_counter() - t0) / args.steps * 1e3, 4),
+                  'kernels_ms': {k: round(v[1] / max(1, v[0]), 4) for k, v in sorted(ctx.prof_read().items())}}
     ctx.prof_enable(False)
 
     # D2H of the record streams (reported, never part of `value`)
@@ -393,7 +401,8 @@ def main():
                 gbs = roof['algorithmic_bytes_per_launch'] / (ms_alone * 1e-3) / 1e9
                 roof['alone'] = {'avg_kernel_ms': round(ms_alone, 4), 'achieved': round(gbs, 1), 'frac': round(gbs / HBM_PEAK_GBS, 4),
                                  'note': 'the same launch with no other kernel resident (inside a step the tokenizer / walk kernels and, '
-                                         'in the whole path, the previous step\'s table copy run beside it)'}
+                                         'in the whole path, the previous step\'s table copy run beside it)',
+                                 'cigar_call_without_pack': call_alone}
         add_alone(roofline)
         _, roof_v = make_roofline(verify_leg['prof'], want='verify_kernel')
         vres = inv_state['verify']

@@ -76,23 +76,41 @@ __global__ __launch_bounds__(256) void tok_count(const uint4 *__restrict__ text,
     if (threadIdx.x == 0) chunk_cnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
-// Single-workgroup exclusive scan of u32 counts into u64 prefixes; out[n] = total.
+// Single-workgroup exclusive scan of u32 counts into u64 prefixes; out[n] = total.  The scans sit on the critical path of a
+// step between two kernels, beside the HBM-saturating pack: what they cost is dependent round trips to memory.  A tile of 8192
+// counts is fetched with 32 independent coalesced loads per lane into LDS, every lane then owns 32 consecutive counts (one
+// block scan per tile instead of one per 256 counts: 43 -> ~8 us for the 6.4 k counts of a haplotype).  256 lanes on purpose:
+// a 1024-lane workgroup is not scheduled before the pack drains (it needs four free wave slots on every SIMD of one CU).
+constexpr int SCAN_PER = 32;
 __global__ __launch_bounds__(256) void scan_counts(const uint32_t *__restrict__ in, uint64_t *__restrict__ out,
-                                                   uint32_t n) {
+                                                   uint32_t n, volatile uint64_t *host_total) {
     __shared__ uint64_t lds[4];
-    __shared__ uint64_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n; base += 256) {
-        const uint32_t i = base + threadIdx.x;
-        uint64_t v[1] = {i < n ? (uint64_t)in[i] : 0}, tot[1];
+    __shared__ uint32_t tile[256 * (SCAN_PER + 1)];                       // + 1: a lane's run starts in its own bank
+    uint64_t carry = 0;
+    for (uint32_t base = 0; base < n; base += 256 * SCAN_PER) {
+        uint32_t c[SCAN_PER];
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; ++k) { const uint32_t i = base + k * 256 + threadIdx.x; c[k] = i < n ? in[i] : 0u; }
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; ++k) { const uint32_t j = k * 256 + threadIdx.x; tile[j + j / SCAN_PER] = c[k]; }
+        __syncthreads();
+        uint64_t v[1] = {0}, tot[1];
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; ++k) { c[k] = tile[threadIdx.x * (SCAN_PER + 1) + k]; v[0] += c[k]; }
         block_excl_scan<1>(v, tot, lds);
-        if (i < n) out[i] = carry + v[0];
-        __syncthreads();
-        if (threadIdx.x == 0) carry += tot[0];
-        __syncthreads();
+        uint64_t run = carry + v[0];
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; ++k) {
+            const uint32_t i = base + threadIdx.x * SCAN_PER + k;
+            if (i < n) out[i] = run;
+            run += c[k];
+        }
+        carry += tot[0];
     }
-    if (threadIdx.x == 0) out[n] = carry;
+    if (threadIdx.x == 0) {
+        out[n] = carry;
+        if (host_total) *host_total = carry;     // straight into the host's pinned word: see walk_chunks
+    }
 }
 
 // Each op character parses the digits in front of it and writes ops[ordinal] = len << 4 | code.
@@ -225,39 +243,56 @@ __global__ __launch_bounds__(256) void walk_reduce(const uint32_t *__restrict__ 
             lds[threadIdx.x] + lds[NQ + threadIdx.x] + lds[2 * NQ + threadIdx.x] + lds[3 * NQ + threadIdx.x];
 }
 
-// Single workgroup: exclusive scan of the per-chunk sums; totals[NQ] = grand totals.
+// Single workgroup: exclusive scan of the per-chunk sums; totals[NQ] = grand totals.  Tiles of 1024 chunks through LDS, four
+// consecutive chunks per lane (see scan_counts): 63 -> ~20 us for the 4.4 k chunks of a haplotype.
 __global__ __launch_bounds__(256) void walk_chunks(const uint64_t *__restrict__ chunk_sum, uint64_t *__restrict__ chunk_pre,
                                                    uint64_t *__restrict__ totals, uint32_t n_chunks,
                                                    volatile uint64_t *host_status) {
+    constexpr int PER = 4, WORDS = PER * NQ;                              // u64 words per lane and tile
     __shared__ uint64_t lds[4 * NQ];
-    __shared__ uint64_t carry[NQ];
-    if (threadIdx.x < NQ) carry[threadIdx.x] = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n_chunks; base += 256) {
-        const uint32_t i = base + threadIdx.x;
+    __shared__ uint64_t tile[256 * WORDS];
+    uint64_t carry[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) carry[q] = 0;
+    const uint64_t n_words = (uint64_t)n_chunks * NQ;
+    for (uint32_t base = 0; base < n_chunks; base += 256 * PER) {
+        uint64_t w[WORDS];
+#pragma unroll
+        for (int k = 0; k < WORDS; ++k) {
+            const uint64_t i = (uint64_t)base * NQ + (uint64_t)k * 256 + threadIdx.x;
+            w[k] = i < n_words ? chunk_sum[i] : 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < WORDS; ++k) tile[k * 256 + threadIdx.x] = w[k];
+        __syncthreads();
         uint64_t v[NQ], tot[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) v[q] = i < n_chunks ? chunk_sum[(uint64_t)i * NQ + q] : 0;
+        for (int q = 0; q < NQ; ++q) v[q] = 0;
+#pragma unroll
+        for (int k = 0; k < WORDS; ++k) { w[k] = tile[threadIdx.x * WORDS + k]; v[k % NQ] += w[k]; }
         block_excl_scan<NQ>(v, tot, lds);
-        if (i < n_chunks)
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) chunk_pre[(uint64_t)i * NQ + q] = carry[q] + v[q];
-        __syncthreads();
-        if (threadIdx.x == 0)
+        for (int j = 0; j < PER; ++j) {
+            const uint32_t i = base + threadIdx.x * PER + j;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) carry[q] += tot[q];
-        __syncthreads();
+            for (int q = 0; q < NQ; ++q) {
+                if (i < n_chunks) chunk_pre[(uint64_t)i * NQ + q] = carry[q] + v[q];
+                v[q] += w[j * NQ + q];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) carry[q] += tot[q];
     }
     if (threadIdx.x < NQ) {
-        totals[threadIdx.x] = carry[threadIdx.x];
-        chunk_pre[(uint64_t)n_chunks * NQ + threadIdx.x] = carry[threadIdx.x];   // read by rows that start at n_ops
-    }
+        uint64_t mine = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) if ((int)threadIdx.x == q) mine = carry[q];
+        totals[threadIdx.x] = mine;
+        chunk_pre[(uint64_t)n_chunks * NQ + threadIdx.x] = mine;           // read by rows that start at n_ops
+        if (host_status) host_status[threadIdx.x] = mine;
+    } else if (threadIdx.x == NQ && host_status) host_status[NQ] = totals[NQ];   // tokenizer error key (tok_emit / row_ops ran before us)
     // the status block goes straight into the host's pinned words (mapped into the device's address space): the runtime's
     // copy kernel for a device-to-host copy issued here does not retire until the concurrent pack has drained (~0.3 ms)
-    if (host_status) {
-        if (threadIdx.x < NQ) host_status[threadIdx.x] = carry[threadIdx.x];
-        else if (threadIdx.x == NQ) host_status[NQ] = totals[NQ];           // tokenizer error key (tok_emit / row_ops ran before us)
-    }
 }
 
 // One wave per row: running (ref, tig) advance of all ops before the row's first op; and for every 2048-operation chunk that
@@ -295,10 +330,17 @@ struct WalkArgs {
     unsigned long long *err_op;          // smallest global ordinal of an illegal op (M, N, P)
 };
 
-// Emit SNV rows and INDEL stubs.  Each lane owns 8 consecutive ops; the block scan gives every op its running
-// positions and its output slots, so the output order is exactly the reference's (row, op, base) order.
+// Emit SNV rows and INDEL stubs.  Each lane owns 8 consecutive ops; the block scan gives every op its running positions and
+// its output slots, so the output order is exactly the reference's (row, op, base) order.  INDEL stubs (one per I / D op) are
+// written where they are met.  SNV rows are written flat: every op leaves its first output slot and positions in LDS, then
+// lane t of the workgroup builds rows t, t + 256, ... of the chunk (binary search for the owning 'X' run) - complete rows with
+// REF / ALT read from the ASCII planes (cigarcall.py:104-105), stored 16 B per lane to consecutive addresses.  (First version:
+// each lane wrote the rows of its own ops, 64 scattered 16-byte stores per instruction and 209 VGPRs, and a second kernel
+// re-read every row to add the bases; beside the HBM-saturating pack that walk took 0.49 ms.)
 __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
     __shared__ uint64_t lds[4 * NQ];
+    __shared__ uint32_t s_pre[WALK_CHUNK + 1];          // first SNV row of the op, relative to the chunk's first row
+    __shared__ uint32_t d_pos[WALK_CHUNK], d_q0[WALK_CHUNK], d_row[WALK_CHUNK];   // 'X' ops: POS, stored contig position of base 0, row | rev << 31
     const uint64_t first = (uint64_t)blockIdx.x * WALK_CHUNK + (uint64_t)threadIdx.x * OPS_PER_LANE;
     uint32_t o[OPS_PER_LANE];
     load_ops(A.ops, A.n_ops, first, o);
@@ -311,85 +353,118 @@ __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
         for (int q = 0; q < NQ; ++q) run[q] += c[q];
     }
     block_excl_scan<NQ>(run, tot, lds);
+    const uint64_t snv_base = A.chunk_pre[(uint64_t)blockIdx.x * NQ + 2];
+    const uint32_t n_rows = (uint32_t)tot[2];            // SNV rows of this chunk
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) run[q] += A.chunk_pre[(uint64_t)blockIdx.x * NQ + q];
+    for (int q = 0; q < NQ; ++q) if (q != 2) run[q] += A.chunk_pre[(uint64_t)blockIdx.x * NQ + q];
 
     // row of this lane's first op: the row of the chunk's first op comes from row_base (chunk_row), lanes walk on
-    if (first >= A.n_ops) return;
-    uint32_t row = A.chunk_row[blockIdx.x];
-    uint64_t row_end = A.op_off[row + 1];
-    while (row_end <= first) { ++row; row_end = A.op_off[row + 1]; }      // rows without ops are skipped
-    pav_aln al = A.aln[row];
-    uint64_t rb_ref = A.rowbase[2ull * row], rb_tig = A.rowbase[2ull * row + 1];
-
-    uint32_t prev = first > 0 ? A.ops[first - 1] : 0x5u;   // last_op / last_oplen carried across lanes
+    const uint32_t row0 = A.chunk_row[blockIdx.x];
+    const pav_aln al0 = A.aln[row0];
+    const uint64_t roff0 = A.ref.off[al0.ref_id], toff0 = A.tig.off[al0.tig_id];
+    const uint32_t slot0 = threadIdx.x * OPS_PER_LANE;
+    if (first >= A.n_ops) {
 #pragma unroll
-    for (int j = 0; j < OPS_PER_LANE; ++j) {
-        const uint64_t k = first + j;
-        if (k >= A.n_ops) break;
-        while (k >= row_end) {                 // next row (rows without ops are skipped)
-            ++row; row_end = A.op_off[row + 1];
+        for (int j = 0; j < OPS_PER_LANE; ++j) s_pre[slot0 + j] = n_rows;
+    } else {
+        uint32_t row = row0;
+        uint64_t row_end = A.op_off[row + 1];
+        pav_aln al = al0;
+        if (row_end <= first) {
+            do { ++row; row_end = A.op_off[row + 1]; } while (row_end <= first);      // rows without ops are skipped
             al = A.aln[row];
-            rb_ref = A.rowbase[2ull * row]; rb_tig = A.rowbase[2ull * row + 1];
         }
-        const uint32_t code = o[j] & 15u, len = o[j] >> 4;
-        const int64_t pos_ref = (int64_t)al.pos + (int64_t)(run[0] - rb_ref);
-        const int64_t pos_tig = (int64_t)(run[1] - rb_tig);
-        const int rev = al.rev != 0;
-        if (code == 8) {                                                   // 'X'  cigarcall.py:95-139
-            const uint64_t tlen = A.tig.len[al.tig_id];
-            pav_snv *out = A.snv + run[2];
-            for (uint32_t i = 0; i < len; ++i) {
-                pav_snv s;
-                s.aln = row;
-                s.pos = (uint32_t)(pos_ref + i);
-                const int64_t pt = pos_tig + i;
-                s.qry_pos = (uint32_t)(rev ? (int64_t)tlen - pt - 1 : pt);   // cigarcall.py:108-109
-                s.ref = 0; s.alt = 0; s.pad = 0;                             // bases: snv_bases kernel
-                out[i] = s;
+        uint64_t rb_ref = A.rowbase[2ull * row], rb_tig = A.rowbase[2ull * row + 1];
+        uint64_t tlen = A.tig.len[al.tig_id];
+        uint32_t prev = first > 0 ? A.ops[first - 1] : 0x5u;   // last_op / last_oplen carried across lanes
+#pragma unroll
+        for (int j = 0; j < OPS_PER_LANE; ++j) {
+            const uint64_t k = first + j;
+            s_pre[slot0 + j] = (uint32_t)run[2];
+            if (k >= A.n_ops) continue;                // (the padding ops contribute nothing: run[2] stays at the total)
+            while (k >= row_end) {                     // next row (rows without ops are skipped)
+                ++row; row_end = A.op_off[row + 1];
+                al = A.aln[row];
+                rb_ref = A.rowbase[2ull * row]; rb_tig = A.rowbase[2ull * row + 1];
+                tlen = A.tig.len[al.tig_id];
             }
-        } else if (code == 1 || code == 2) {                               // 'I' / 'D' stub
-            pav_indel r;
-            r.aln = row;
-            r.op_index = (uint32_t)(k - A.op_off[row]) + 1;                // cigar_index, cigarcall.py:89
-            r.pos = (uint32_t)pos_ref;                                     // un-shifted; finalised by homology_kernel
-            r.end = 0;
-            r.svlen = len;
-            r.qry_pos = (uint32_t)pos_tig;                                 // oriented, un-shifted
-            r.qry_end = 0;
-            // last_op / last_oplen (cigarcall.py:149-151,310-311): previous op of the same row
-            const bool has_prev = k > A.op_off[row];                       // first op of a row: last_op is None
-            r.left_shift = (has_prev && (prev & 15u) == 7u) ? (prev >> 4) : 0u;   // shift cap; 0 when last_op != '='
-            r.hom_ref_l = r.hom_ref_r = r.hom_tig_l = r.hom_tig_r = 0;
-            r.seq_off = run[4];
-            r.svtype = code == 1 ? 0 : 1;
+            const uint32_t code = o[j] & 15u, len = o[j] >> 4;
+            const int64_t pos_ref = (int64_t)al.pos + (int64_t)(run[0] - rb_ref);
+            const int64_t pos_tig = (int64_t)(run[1] - rb_tig);
+            const int rev = al.rev != 0;
+            if (code == 8) {                                                   // 'X'  cigarcall.py:95-139
+                d_pos[slot0 + j] = (uint32_t)pos_ref;
+                d_q0[slot0 + j] = (uint32_t)(rev ? (int64_t)tlen - pos_tig - 1 : pos_tig);   // cigarcall.py:108-109; base i: -i / +i
+                d_row[slot0 + j] = row | (rev ? 0x80000000u : 0u);
+            } else if (code == 1 || code == 2) {                               // 'I' / 'D' stub
+                pav_indel r;
+                r.aln = row;
+                r.op_index = (uint32_t)(k - A.op_off[row]) + 1;                // cigar_index, cigarcall.py:89
+                r.pos = (uint32_t)pos_ref;                                     // un-shifted; finalised by homology_kernel
+                r.end = 0;
+                r.svlen = len;
+                r.qry_pos = (uint32_t)pos_tig;                                 // oriented, un-shifted
+                r.qry_end = 0;
+                // last_op / last_oplen (cigarcall.py:149-151,310-311): previous op of the same row
+                const bool has_prev = k > A.op_off[row];                       // first op of a row: last_op is None
+                r.left_shift = (has_prev && (prev & 15u) == 7u) ? (prev >> 4) : 0u;   // shift cap; 0 when last_op != '='
+                r.hom_ref_l = r.hom_ref_r = r.hom_tig_l = r.hom_tig_r = 0;
+                r.seq_off = run[4];
+                r.svtype = code == 1 ? 0 : 1;
 #pragma unroll
-            for (int b = 0; b < 7; ++b) r.pad[b] = 0;
-            A.indel[run[3]] = r;
-        } else if (code != 7 && code != 4 && code != 5) {                  // M, N, P: cigarcall.py:289-307
-            atomicMin(A.err_op, (unsigned long long)k);               // first one in walk order wins
+                for (int b = 0; b < 7; ++b) r.pad[b] = 0;
+                A.indel[run[3]] = r;
+            } else if (code != 7 && code != 4 && code != 5) {                  // M, N, P: cigarcall.py:289-307
+                atomicMin(A.err_op, (unsigned long long)k);               // first one in walk order wins
+            }
+            uint64_t c[NQ];
+            op_contrib(o[j], c);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) run[q] += c[q];
+            prev = o[j];
         }
-        uint64_t c[NQ];
-        op_contrib(o[j], c);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) run[q] += c[q];
-        prev = o[j];
     }
-}
+    if (threadIdx.x == 0) s_pre[WALK_CHUNK] = n_rows;
+    __syncthreads();
 
-// REF / ALT of every SNV row (cigarcall.py:104-105): one lane per record, two independent scattered byte loads.
-// Kept apart from the walk so that no lane serialises a run of cache misses.
-__global__ __launch_bounds__(256) void snv_bases(pav_snv *__restrict__ snv, uint64_t n_snv, const pav_aln *__restrict__ aln,
-                                                 SeqView R, SeqView T) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_snv) return;
-    pav_snv s = snv[i];
-    const pav_aln al = aln[s.aln];
-    const uint8_t r = R.ascii[R.off[al.ref_id] + s.pos];
-    const uint8_t t = T.ascii[T.off[al.tig_id] + s.qry_pos];        // stored contig; complemented when the row is reversed
-    s.ref = r;
-    s.alt = al.rev ? comp_ascii(t) : t;
-    snv[i] = s;
+    // flat SNV rows: two rows per lane in flight; lanes past the last row repeat it and do not store (no branch around the loads)
+    constexpr int EMIT_U = 2;
+    uint4 *out = reinterpret_cast<uint4 *>(A.snv + snv_base);              // pav_snv = {aln, pos, qry_pos, ref | alt << 8 | pad << 16}
+    static_assert(sizeof(pav_snv) == sizeof(uint4), "pav_snv is stored as one 16-byte vector");
+    for (uint32_t s0 = 0; s0 < n_rows; s0 += 256 * EMIT_U) {
+        uint32_t at[EMIT_U], rw[EMIT_U], pos[EMIT_U], qp[EMIT_U];
+        uint64_t roff[EMIT_U], toff[EMIT_U];
+        uint8_t br[EMIT_U], bt[EMIT_U];
+        bool live[EMIT_U];
+#pragma unroll
+        for (int u = 0; u < EMIT_U; ++u) {
+            const uint32_t want = s0 + u * 256 + threadIdx.x;
+            live[u] = want < n_rows;
+            const uint32_t s = live[u] ? want : n_rows - 1;
+            at[u] = s;
+            uint32_t lo = 0, hi = WALK_CHUNK;               // largest op with s_pre <= s: the 'X' run that owns row s
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_pre[mid] <= s) lo = mid; else hi = mid; }
+            const uint32_t i = s - s_pre[lo];
+            rw[u] = d_row[lo];
+            pos[u] = d_pos[lo] + i;
+            qp[u] = (rw[u] >> 31) ? d_q0[lo] - i : d_q0[lo] + i;
+            roff[u] = roff0; toff[u] = toff0;
+            if ((rw[u] & 0x7FFFFFFFu) != row0) {            // chunk that crosses into another row
+                const pav_aln al = A.aln[rw[u] & 0x7FFFFFFFu];
+                roff[u] = A.ref.off[al.ref_id]; toff[u] = A.tig.off[al.tig_id];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < EMIT_U; ++u) {
+            br[u] = A.ref.ascii[roff[u] + pos[u]];
+            bt[u] = A.tig.ascii[toff[u] + qp[u]];            // stored contig; complemented when the row is reversed
+        }
+#pragma unroll
+        for (int u = 0; u < EMIT_U; ++u) {
+            const uint32_t alt = (rw[u] >> 31) ? comp_ascii(bt[u]) : bt[u];
+            if (live[u]) out[at[u]] = make_uint4(rw[u] & 0x7FFFFFFFu, pos[u], qp[u], (uint32_t)br[u] | alt << 8);
+        }
+    }
 }
 
 // ---- verify mode ----------------------------------------------------------------------------------------------------------
@@ -684,21 +759,34 @@ __global__ __launch_bounds__(256) void lift_reduce(const uint32_t *__restrict__ 
 }
 
 __global__ __launch_bounds__(256) void lift_chunks(const uint64_t *__restrict__ chunk_sum, uint64_t *__restrict__ chunk_pre, uint32_t n_chunks) {
+    constexpr int PER = 8, WORDS = PER * 2;                               // tiles of 2048 chunks through LDS, see scan_counts
     __shared__ uint64_t lds[8];
-    __shared__ uint64_t carry[2];
-    if (threadIdx.x < 2) carry[threadIdx.x] = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n_chunks; base += 256) {
-        const uint32_t i = base + threadIdx.x;
-        uint64_t v[2], tot[2];
-        v[0] = i < n_chunks ? chunk_sum[2ull * i] : 0; v[1] = i < n_chunks ? chunk_sum[2ull * i + 1] : 0;
+    __shared__ uint64_t tile[256 * WORDS];
+    uint64_t carry[2] = {0, 0};
+    const uint64_t n_words = 2ull * n_chunks;
+    for (uint32_t base = 0; base < n_chunks; base += 256 * PER) {
+        uint64_t w[WORDS];
+#pragma unroll
+        for (int k = 0; k < WORDS; ++k) {
+            const uint64_t i = 2ull * base + (uint64_t)k * 256 + threadIdx.x;
+            w[k] = i < n_words ? chunk_sum[i] : 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < WORDS; ++k) tile[k * 256 + threadIdx.x] = w[k];
+        __syncthreads();
+        uint64_t v[2] = {0, 0}, tot[2];
+#pragma unroll
+        for (int k = 0; k < WORDS; ++k) { w[k] = tile[threadIdx.x * WORDS + k]; v[k & 1] += w[k]; }
         block_excl_scan<2>(v, tot, lds);
-        if (i < n_chunks) { chunk_pre[2ull * i] = carry[0] + v[0]; chunk_pre[2ull * i + 1] = carry[1] + v[1]; }
-        __syncthreads();
-        if (threadIdx.x == 0) { carry[0] += tot[0]; carry[1] += tot[1]; }
-        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const uint32_t i = base + threadIdx.x * PER + j;
+            if (i < n_chunks) { chunk_pre[2ull * i] = carry[0] + v[0]; chunk_pre[2ull * i + 1] = carry[1] + v[1]; }
+            v[0] += w[2 * j]; v[1] += w[2 * j + 1];
+        }
+        carry[0] += tot[0]; carry[1] += tot[1];
     }
-    if (threadIdx.x < 2) chunk_pre[2ull * n_chunks + threadIdx.x] = carry[threadIdx.x];   // rows starting at n_ops
+    if (threadIdx.x < 2) chunk_pre[2ull * n_chunks + threadIdx.x] = threadIdx.x ? carry[1] : carry[0];   // rows starting at n_ops
 }
 
 __global__ __launch_bounds__(256) void lift_row_base(const uint32_t *__restrict__ ops, const uint64_t *__restrict__ op_off,
@@ -1214,8 +1302,7 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
     uint32_t *d_tcnt = ctx->d_chunk.as<uint32_t>();
     uint64_t *d_tpre = reinterpret_cast<uint64_t *>(ctx->d_chunk.as<uint8_t>() + round_up(sizeof(uint32_t) * n_tchunks, 16));
     PAV_LAUNCH(ctx, "tok_count", tok_count, n_tchunks, 256, 0, ctx->d_text.as<uint4>(), d_tcnt);
-    PAV_LAUNCH(ctx, "scan_counts", scan_counts, 1, 256, 0, d_tcnt, d_tpre, n_tchunks);
-    PAV_HIP(ctx, hipMemcpyAsync(h_status, d_tpre + n_tchunks, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    PAV_LAUNCH(ctx, "scan_counts", scan_counts, 1, 256, 0, d_tcnt, d_tpre, n_tchunks, h_status);
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint64_t n_ops = h_status[0];
     ctx->n_ops = n_ops;
@@ -1268,18 +1355,6 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
         A.snv = ctx->d_snv.as<pav_snv>(); A.indel = ctx->d_indel.as<pav_indel>();
         A.err_op = d_err_op;
         PAV_LAUNCH(ctx, "walk_emit", walk_emit, n_wchunks, 256, 0, A);
-        // REF / ALT bytes of the SNV rows (ASCII plane only) on the side stream, next to the homology scans (packed planes)
-        const bool side_snv = totals[2] && totals[3];
-        if (side_snv) {
-            PAV_HIP(ctx, hipEventRecord(ctx->emit_done, ctx->stream));
-            PAV_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->emit_done, 0));
-            PAV_LAUNCH_ON(ctx, ctx->stream2, "snv_bases", snv_bases, (uint32_t)((totals[2] + 255) / 256), 256, 0, ctx->d_snv.as<pav_snv>(),
-                          totals[2], ctx->d_aln.as<pav_aln>(), A.ref, A.tig);
-            PAV_HIP(ctx, hipEventRecord(ctx->snv_done, ctx->stream2));
-        } else if (totals[2]) {
-            PAV_LAUNCH(ctx, "snv_bases", snv_bases, (uint32_t)((totals[2] + 255) / 256), 256, 0, ctx->d_snv.as<pav_snv>(), totals[2],
-                       ctx->d_aln.as<pav_aln>(), A.ref, A.tig);
-        }
         if (totals[3]) {
             { int rcw = wait_planes(ctx); if (rcw != PAV_OK) return rcw; }   // the packed planes may still be in flight
             PAV_LAUNCH(ctx, "homology_kernel", homology_kernel, (uint32_t)((totals[3] + 255) / 256), 256, 0,
@@ -1289,7 +1364,6 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
                            ctx->d_indel.as<pav_indel>(), totals[3], ctx->d_aln.as<pav_aln>(), A.ref, A.tig,
                            ctx->d_seqblob.as<uint8_t>(), totals[4]);
         }
-        if (side_snv) PAV_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->snv_done, 0));   // later readers of the SNV rows use this stream
         PAV_HIP(ctx, hipMemcpyAsync(h_status, d_tok_err, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
         errs[0] = h_status[0];
@@ -1444,7 +1518,7 @@ int pav_align_index(pav_ctx *ctx, uint32_t n_aln, const uint32_t *row_pos, const
         uint64_t *d_tpre = reinterpret_cast<uint64_t *>(ctx->ix_chunk.as<uint8_t>() + round_up(sizeof(uint32_t) * n_tchunks, 16));
         unsigned long long *d_tok_err = ctx->ix_err.as<unsigned long long>();
         PAV_LAUNCH(ctx, "tok_count", tok_count, n_tchunks, 256, 0, ctx->ix_text.as<uint4>(), d_tcnt);
-        PAV_LAUNCH(ctx, "scan_counts", scan_counts, 1, 256, 0, d_tcnt, d_tpre, n_tchunks);
+        PAV_LAUNCH(ctx, "scan_counts", scan_counts, 1, 256, 0, d_tcnt, d_tpre, n_tchunks, (volatile uint64_t *)nullptr);
         uint64_t n_ops = 0;
         PAV_HIP(ctx, hipMemcpyAsync(&n_ops, d_tpre + n_tchunks, sizeof n_ops, hipMemcpyDeviceToHost, st));
         PAV_HIP(ctx, hipStreamSynchronize(st));
