@@ -360,9 +360,9 @@ def main():
                 'tok_count': float(text.shape[0]),
                 'tok_emit': float(text.shape[0]) + 4.0 * n_ops,
                 'walk_reduce': 4.0 * n_ops,
-                'walk_emit': 4.0 * n_ops + 16.0 * n_snv + 2.0 * n_snv + 64.0 * n_indel,
+                'walk_snv': 4.0 * n_ops + 16.0 * n_snv + 2.0 * n_snv,          # ops, SNV rows out, REF / ALT bytes in
+                'walk_indel': 4.0 * n_ops + 64.0 * n_indel,
                 'homology_kernel': 128.0 * n_indel,
-                'snv_bases': 18.0 * n_snv,
                 'seq_gather': 2.0 * counts.seq_bytes,
                 'rocprim::radix_sort_keys': 7 * 16.0 * n_snv,               # 56 key bits = 7 passes over 8 B keys, in + out
                 'k_snv_keys': 24.0 * n_snv, 'k_indel_keys': 72.0 * n_indel,

@@ -337,10 +337,16 @@ struct WalkArgs {
 // REF / ALT read from the ASCII planes (cigarcall.py:104-105), stored 16 B per lane to consecutive addresses.  (First version:
 // each lane wrote the rows of its own ops, 64 scattered 16-byte stores per instruction and 209 VGPRs, and a second kernel
 // re-read every row to add the bases; beside the HBM-saturating pack that walk took 0.49 ms.)
+// Two instances of the same walk: WALK_INDEL writes the stubs (and reports illegal ops) - little traffic, it runs beside the
+// contig pack; WALK_SNV writes the SNV rows - 0.4 GB of scattered byte fetches - behind the pack on the side stream, beside the
+// homology scans, so that the pack keeps HBM to itself (one kernel doing both beside the pack stretched it from 0.70 to 0.85 ms).
+constexpr int WALK_INDEL = 1, WALK_SNV = 2;
+template <int MODE>
 __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
     __shared__ uint64_t lds[4 * NQ];
-    __shared__ uint32_t s_pre[WALK_CHUNK + 1];          // first SNV row of the op, relative to the chunk's first row
-    __shared__ uint32_t d_pos[WALK_CHUNK], d_q0[WALK_CHUNK], d_row[WALK_CHUNK];   // 'X' ops: POS, stored contig position of base 0, row | rev << 31
+    constexpr int NSLOT = MODE == WALK_SNV ? WALK_CHUNK : 1;
+    __shared__ uint32_t s_pre[NSLOT + 1];               // first SNV row of the op, relative to the chunk's first row
+    __shared__ uint32_t d_pos[NSLOT], d_q0[NSLOT], d_row[NSLOT];   // 'X' ops: POS, stored contig position of base 0, row | rev << 31
     const uint64_t first = (uint64_t)blockIdx.x * WALK_CHUNK + (uint64_t)threadIdx.x * OPS_PER_LANE;
     uint32_t o[OPS_PER_LANE];
     load_ops(A.ops, A.n_ops, first, o);
@@ -364,8 +370,10 @@ __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
     const uint64_t roff0 = A.ref.off[al0.ref_id], toff0 = A.tig.off[al0.tig_id];
     const uint32_t slot0 = threadIdx.x * OPS_PER_LANE;
     if (first >= A.n_ops) {
+        if constexpr (MODE == WALK_SNV) {
 #pragma unroll
-        for (int j = 0; j < OPS_PER_LANE; ++j) s_pre[slot0 + j] = n_rows;
+            for (int j = 0; j < OPS_PER_LANE; ++j) s_pre[slot0 + j] = n_rows;
+        }
     } else {
         uint32_t row = row0;
         uint64_t row_end = A.op_off[row + 1];
@@ -376,14 +384,15 @@ __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
         }
         uint64_t rb_ref = A.rowbase[2ull * row], rb_tig = A.rowbase[2ull * row + 1];
         uint64_t tlen = A.tig.len[al.tig_id];
+        uint64_t row_begin = A.op_off[row];                    // kept in a register: no load inside the per-op branches below
         uint32_t prev = first > 0 ? A.ops[first - 1] : 0x5u;   // last_op / last_oplen carried across lanes
 #pragma unroll
         for (int j = 0; j < OPS_PER_LANE; ++j) {
             const uint64_t k = first + j;
-            s_pre[slot0 + j] = (uint32_t)run[2];
+            if constexpr (MODE == WALK_SNV) s_pre[slot0 + j] = (uint32_t)run[2];
             if (k >= A.n_ops) continue;                // (the padding ops contribute nothing: run[2] stays at the total)
             while (k >= row_end) {                     // next row (rows without ops are skipped)
-                ++row; row_end = A.op_off[row + 1];
+                ++row; row_begin = row_end; row_end = A.op_off[row + 1];
                 al = A.aln[row];
                 rb_ref = A.rowbase[2ull * row]; rb_tig = A.rowbase[2ull * row + 1];
                 tlen = A.tig.len[al.tig_id];
@@ -393,20 +402,23 @@ __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
             const int64_t pos_tig = (int64_t)(run[1] - rb_tig);
             const int rev = al.rev != 0;
             if (code == 8) {                                                   // 'X'  cigarcall.py:95-139
+                if constexpr (MODE == WALK_SNV) {
                 d_pos[slot0 + j] = (uint32_t)pos_ref;
                 d_q0[slot0 + j] = (uint32_t)(rev ? (int64_t)tlen - pos_tig - 1 : pos_tig);   // cigarcall.py:108-109; base i: -i / +i
                 d_row[slot0 + j] = row | (rev ? 0x80000000u : 0u);
+                }
             } else if (code == 1 || code == 2) {                               // 'I' / 'D' stub
+                if constexpr (MODE == WALK_INDEL) {
                 pav_indel r;
                 r.aln = row;
-                r.op_index = (uint32_t)(k - A.op_off[row]) + 1;                // cigar_index, cigarcall.py:89
+                r.op_index = (uint32_t)(k - row_begin) + 1;                    // cigar_index, cigarcall.py:89
                 r.pos = (uint32_t)pos_ref;                                     // un-shifted; finalised by homology_kernel
                 r.end = 0;
                 r.svlen = len;
                 r.qry_pos = (uint32_t)pos_tig;                                 // oriented, un-shifted
                 r.qry_end = 0;
                 // last_op / last_oplen (cigarcall.py:149-151,310-311): previous op of the same row
-                const bool has_prev = k > A.op_off[row];                       // first op of a row: last_op is None
+                const bool has_prev = k > row_begin;                           // first op of a row: last_op is None
                 r.left_shift = (has_prev && (prev & 15u) == 7u) ? (prev >> 4) : 0u;   // shift cap; 0 when last_op != '='
                 r.hom_ref_l = r.hom_ref_r = r.hom_tig_l = r.hom_tig_r = 0;
                 r.seq_off = run[4];
@@ -414,8 +426,9 @@ __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
 #pragma unroll
                 for (int b = 0; b < 7; ++b) r.pad[b] = 0;
                 A.indel[run[3]] = r;
+                }
             } else if (code != 7 && code != 4 && code != 5) {                  // M, N, P: cigarcall.py:289-307
-                atomicMin(A.err_op, (unsigned long long)k);               // first one in walk order wins
+                if constexpr (MODE == WALK_INDEL) atomicMin(A.err_op, (unsigned long long)k);   // first one in walk order wins
             }
             uint64_t c[NQ];
             op_contrib(o[j], c);
@@ -424,7 +437,8 @@ __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
             prev = o[j];
         }
     }
-    if (threadIdx.x == 0) s_pre[WALK_CHUNK] = n_rows;
+    if constexpr (MODE == WALK_INDEL) return;
+    if (threadIdx.x == 0) s_pre[NSLOT] = n_rows;
     __syncthreads();
 
     // flat SNV rows: two rows per lane in flight; lanes past the last row repeat it and do not store (no branch around the loads)
@@ -1160,7 +1174,8 @@ __device__ __forceinline__ uint32_t right_hom(const SeqRef &t, int64_t pos, cons
 // One lane per INS/DEL stub: left shift, then the four breakpoint homologies in lockstep (wave_hom_scan4), then the final
 // coordinates.  The scans are wave-uniform calls (long scans are finished cooperatively), so no lane leaves early.
 __global__ __launch_bounds__(256) void homology_kernel(pav_indel *__restrict__ indel, uint64_t n_indel,
-                                                       const pav_aln *__restrict__ aln, SeqView R, SeqView T) {
+                                                       const pav_aln *__restrict__ aln, SeqView R, SeqView T,
+                                                       uint32_t *__restrict__ seq_blk) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = i < n_indel;
     pav_indel r = indel[active ? i : 0];
@@ -1196,21 +1211,31 @@ __global__ __launch_bounds__(256) void homology_kernel(pav_indel *__restrict__ i
     }
     r.left_shift = (uint32_t)shift;
     indel[i] = r;
+    // seq_gather: this record owns the first byte of every 256-byte block of the SEQ blob that starts inside its sequence
+    for (uint64_t blk = (r.seq_off + 255) >> 8; (blk << 8) < r.seq_off + (uint64_t)oplen; ++blk) seq_blk[blk] = (uint32_t)i;
 }
 
-// SEQ blob (cigarcall.py:145,163,221): one lane per output byte (coalesced stores); the owning record is found by
-// binary search on seq_off.  (A lane-per-record variant with cooperative long copies measured 30 % slower.)
+// SEQ blob (cigarcall.py:145,163,221): one lane per output byte (coalesced stores).  The record that owns the first byte of a
+// 256-byte block comes from homology_kernel (seq_blk); the offsets of the 257 records from there on are staged in LDS and
+// searched there - a lane used to search all of indel[] in global memory, twenty dependent loads per byte.
+// (A lane-per-record variant with cooperative long copies measured 30 % slower.)
 __global__ __launch_bounds__(256) void seq_gather(const pav_indel *__restrict__ indel, uint64_t n_indel,
                                                   const pav_aln *__restrict__ aln, SeqView R, SeqView T,
-                                                  uint8_t *__restrict__ blob, uint64_t n_bytes) {
+                                                  uint8_t *__restrict__ blob, uint64_t n_bytes, const uint32_t *__restrict__ seq_blk) {
+    __shared__ uint64_t s_off[257];
     const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t lo0 = seq_blk[blockIdx.x];
+    for (uint32_t t = threadIdx.x; t < 257; t += 256) s_off[t] = lo0 + t < n_indel ? indel[lo0 + t].seq_off : ~0ull;
+    __syncthreads();
     if (b >= n_bytes) return;
-    uint64_t lo = 0, hi = n_indel;                     // last record with seq_off <= b
+    uint64_t lo = 0, hi = 257;                         // last record with seq_off <= b
+    if (s_off[256] <= b) { lo = 256; hi = n_indel - lo0; }   // only with records of length 0 in between: search on in global memory
     while (hi - lo > 1) {
         const uint64_t mid = (lo + hi) >> 1;
-        if (indel[mid].seq_off <= b) lo = mid; else hi = mid;
+        const uint64_t v = mid <= 256 ? s_off[mid] : indel[lo0 + mid].seq_off;
+        if (v <= b) lo = mid; else hi = mid;
     }
-    const pav_indel r = indel[lo];
+    const pav_indel r = indel[lo0 + lo];
     const pav_aln al = aln[r.aln];
     const int64_t k = (int64_t)(b - r.seq_off);
     uint8_t c;
@@ -1345,7 +1370,9 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
     if (n_wchunks) {
         PAV_HIP(ctx, ctx->d_snv.reserve(sizeof(pav_snv) * (totals[2] + 1)));
         PAV_HIP(ctx, ctx->d_indel.reserve(sizeof(pav_indel) * (totals[3] + 1)));
-        PAV_HIP(ctx, ctx->d_seqblob.reserve(totals[4] + 16));
+        const uint64_t blob_bytes = round_up(totals[4] + 16, 16);                 // SEQ bytes, then seq_gather's block index
+        PAV_HIP(ctx, ctx->d_seqblob.reserve(blob_bytes + sizeof(uint32_t) * (totals[4] / 256 + 2)));
+        uint32_t *d_seq_blk = reinterpret_cast<uint32_t *>(ctx->d_seqblob.as<uint8_t>() + blob_bytes);
         WalkArgs A;
         A.ops = ctx->d_ops.as<uint32_t>(); A.n_ops = n_ops;
         A.op_off = ctx->d_op_off.as<uint64_t>(); A.aln = ctx->d_aln.as<pav_aln>(); A.n_aln = n_aln;
@@ -1354,16 +1381,25 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
         A.ref = ctx->seq[PAV_ROLE_REF].view(); A.tig = ctx->seq[PAV_ROLE_TIG].view();
         A.snv = ctx->d_snv.as<pav_snv>(); A.indel = ctx->d_indel.as<pav_indel>();
         A.err_op = d_err_op;
-        PAV_LAUNCH(ctx, "walk_emit", walk_emit, n_wchunks, 256, 0, A);
+        // SNV rows: on the side stream, i.e. behind the contig pack when one is in flight (it is the HBM-bound kernel of the step
+        // and the rows cost 0.4 GB of scattered fetches), next to the homology scans of the main stream
+        if (totals[2]) {
+            PAV_HIP(ctx, hipEventRecord(ctx->snv_ready, ctx->stream));
+            PAV_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->snv_ready, 0));
+            PAV_LAUNCH_ON(ctx, ctx->stream2, "walk_snv", walk_emit<WALK_SNV>, n_wchunks, 256, 0, A);
+            PAV_HIP(ctx, hipEventRecord(ctx->snv_done, ctx->stream2));
+        }
+        PAV_LAUNCH(ctx, "walk_indel", walk_emit<WALK_INDEL>, n_wchunks, 256, 0, A);
         if (totals[3]) {
             { int rcw = wait_planes(ctx); if (rcw != PAV_OK) return rcw; }   // the packed planes may still be in flight
             PAV_LAUNCH(ctx, "homology_kernel", homology_kernel, (uint32_t)((totals[3] + 255) / 256), 256, 0,
-                       ctx->d_indel.as<pav_indel>(), totals[3], ctx->d_aln.as<pav_aln>(), A.ref, A.tig);
+                       ctx->d_indel.as<pav_indel>(), totals[3], ctx->d_aln.as<pav_aln>(), A.ref, A.tig, d_seq_blk);
             if (totals[4])
                 PAV_LAUNCH(ctx, "seq_gather", seq_gather, (uint32_t)((totals[4] + 255) / 256), 256, 0,
                            ctx->d_indel.as<pav_indel>(), totals[3], ctx->d_aln.as<pav_aln>(), A.ref, A.tig,
-                           ctx->d_seqblob.as<uint8_t>(), totals[4]);
+                           ctx->d_seqblob.as<uint8_t>(), totals[4], d_seq_blk);
         }
+        if (totals[2]) PAV_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->snv_done, 0));   // later readers of the SNV rows use this stream
         PAV_HIP(ctx, hipMemcpyAsync(h_status, d_tok_err, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
         errs[0] = h_status[0];

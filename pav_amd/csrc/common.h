@@ -73,6 +73,8 @@ struct pav_ctx {
     bool tables_pending = false;
     hipEvent_t tables_done_prev = nullptr;   // same for the scan before it: its tables live in the other pinned arena, so a new
     bool tables_pending_prev = false;        // scan does not wait for them (the two are swapped when a scan starts)
+    hipEvent_t snv_ready = nullptr, snv_done = nullptr;   // pav_cigar_call: the SNV rows are written on stream2 (behind the pack),
+                                                          // next to the homology scans of the main stream
     hipEvent_t pack_done[2] = {nullptr, nullptr};   // recorded after a pack on stream2; consumers of the planes wait on it
     bool pack_pending[2] = {false, false};
     std::string err;

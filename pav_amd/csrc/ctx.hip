@@ -184,6 +184,8 @@ pav_ctx *pav_create(int device_id) {
         (e = hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, prio_lo)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->tables_done, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->tables_done_prev, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->snv_ready, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->snv_done, hipEventDisableTiming)) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_status), 256, hipHostMallocDefault)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->pack_done[0], hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->pack_done[1], hipEventDisableTiming)) != hipSuccess) {
@@ -225,6 +227,8 @@ void pav_destroy(pav_ctx *ctx) {
     (void)hipStreamDestroy(ctx->stream3);
     (void)hipEventDestroy(ctx->tables_done);
     (void)hipEventDestroy(ctx->tables_done_prev);
+    (void)hipEventDestroy(ctx->snv_ready);
+    (void)hipEventDestroy(ctx->snv_done);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     (void)hipEventDestroy(ctx->pack_done[0]);
     (void)hipEventDestroy(ctx->pack_done[1]);
