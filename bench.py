@@ -52,7 +52,7 @@ def main():
     ap.add_argument('--workload', choices=['cigar+inv', 'cigar'], default='cigar+inv',
                     help="'cigar+inv' = the whole path of the metric: CIGAR-call + flagging + k-mer inversion scan of every flagged "
                          "region (configs[2] shape, one haplotype per GPU); 'cigar' = BASELINE configs[1], CIGAR-call only")
-    ap.add_argument('--cpu-sample-regions', type=int, default=100,
+    ap.add_argument('--cpu-sample-regions', type=int, default=300,
                     help='flagged regions whose k-mer density scan the CPU baseline times (oracle, one core)')
     ap.add_argument('--backend', default='nccl', help="process-group backend for N > 1 ('nccl' = RCCL; tests use 'gloo')")
     ap.add_argument('--share-gpu', action='store_true',
