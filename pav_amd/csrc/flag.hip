@@ -274,6 +274,22 @@ void merge_loci(const pav_flag_rgn *const tables[4], const uint64_t n[4], int64_
     }
 }
 
+// Keys in table order are already in the rules' iteration order when the alignment table is what get_align_bed writes
+// (sorted by #CHROM as str, then POS - pavlib/align/align.py:280) and its rows do not overlap on the reference (trim-tigref):
+// the walk emits the records of a row by rising position.  Then the sort is a stable compaction of the real keys.
+struct RealKey {
+    unsigned long long low;                  // tag - 1: every sentinel has all of these bits set, no real key has
+    __device__ bool operator()(unsigned long long k) const { return (k & low) != low; }
+};
+// *unsorted |= the first *n_ptr keys do not rise
+__global__ __launch_bounds__(256) void k_check_sorted(const unsigned long long *__restrict__ keys, const unsigned long long *__restrict__ n_ptr,
+                                                      unsigned long long *__restrict__ unsorted) {
+    const unsigned long long n = *n_ptr;
+    bool bad = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i + 1 < n; i += (uint64_t)gridDim.x * 256) bad |= keys[i] > keys[i + 1];
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) *unsorted = 1;
+}
+
 // ---- device drivers ----------------------------------------------------------------------------------------------------
 
 int sort_keys(pav_ctx *ctx, FlagState *S, unsigned long long *in, unsigned long long *out, uint64_t n, unsigned end_bit) {
@@ -562,10 +578,28 @@ int pav_cigar_flag(pav_ctx *ctx, const int64_t *trim_pos, const int64_t *trim_en
         if (n_ind)
             PAV_LAUNCH(ctx, "k_indel_keys", k_indel_keys, (uint32_t)std::min<uint64_t>((n_ind + 255) / 256, 4u * (uint32_t)ctx->n_cu), 256, 0, ctx->d_indel.as<pav_indel>(), n_ind, d_aln, d_rank,
                        d_tp, d_te, k_in + n_snv, d_cnt + 1, tag, tag | (tag - 1));
-        if ((rc = sort_keys(ctx, S, k_in, k_sorted, n_keys, CM_SHIFT + rank_bits + 1)) != PAV_OK) return rc;
+        // the common case first: compact the real keys of both tables in table order and look whether they rise (d_cnt[3])
+        const RealKey real{tag - 1};
+        unsigned long long *d_sel = d_cnt + 6;                      // select's own counts (= d_cnt[0], d_cnt[2])
+        for (int t = 0; t < 2; ++t) {
+            const uint64_t n_t = t == 0 ? n_snv : n_ind, at = t == 0 ? 0 : n_snv;
+            if (!n_t) continue;
+            size_t bytes = 0;
+            PAV_HIP(ctx, rocprim::select(nullptr, bytes, k_in + at, k_sorted + at, d_sel + t, (size_t)n_t, real, st));
+            PAV_HIP(ctx, S->tmp.reserve(bytes + 16));
+            const int tok = prof_begin(ctx, "rocprim::select");
+            const hipError_t e = rocprim::select(S->tmp.p, bytes, k_in + at, k_sorted + at, d_sel + t, (size_t)n_t, real, st);
+            prof_end(ctx, tok);
+            PAV_HIP(ctx, e);
+            PAV_LAUNCH(ctx, "k_check_sorted", k_check_sorted, (uint32_t)std::min<uint64_t>((n_t + 255) / 256, 4u * (uint32_t)ctx->n_cu), 256, 0,
+                       k_sorted + at, d_cnt + (t == 0 ? 0 : 2), d_cnt + 3);
+        }
     }
     PAV_HIP(ctx, hipMemcpyAsync(cnt, d_cnt, 64, hipMemcpyDeviceToHost, st));
     PAV_HIP(ctx, hipStreamSynchronize(st));
+    if (cnt[3] && n_keys) {                                         // a table in another order: the general path, one radix sort
+        if ((rc = sort_keys(ctx, S, k_in, k_sorted, n_keys, CM_SHIFT + rank_bits + 1)) != PAV_OK) return rc;
+    }
     lap("keys+sort");
     const uint64_t snv_pass = cnt[0], ind_pass = cnt[1], ind_small = cnt[2];
     res->n_snv_pass = snv_pass;

@@ -86,6 +86,19 @@ def test_fused_from_device_calls(gpu_ctx, case, tmp_path):
     assert res['n_snv_pass'] == int((snv['FILTER'] == 'PASS').sum())
 
 
+def test_fused_with_alignment_rows_in_another_order(gpu_ctx, tmp_path):
+    """The cluster keys of a get_align_bed table arrive in the rules' order and are only compacted; with the rows of the table
+    reversed they do not, and the general path (one radix sort) must give the same tables."""
+    d = os.path.join(GOLD, 'flag_hap')
+    df = pd.read_csv(os.path.join(d, 'align.tsv'), sep='\t', dtype=str, keep_default_na=False)
+    assert df.shape[0] > 3
+    shuffled = str(tmp_path / 'align_reversed.tsv')
+    df.iloc[::-1].to_csv(shuffled, sep='\t', index=False)
+    res = rules.call_inv_flag(shuffled, os.path.join(d, 'trim.tsv'), os.path.join(d, 'tig.fa'), os.path.join(d, 'ref.fa'), ctx=gpu_ctx)
+    for n in rules.FLAG_OUTPUTS:
+        assert as_text(res[n]) == golden_text('flag_hap', n), n
+
+
 def test_long_clusters_and_ties(gpu_ctx):
     """Clusters far longer than the serial search (wave path), chromosome switches inside a wave, decreasing midpoints."""
     rng = np.random.default_rng(5)
