@@ -547,15 +547,14 @@ __global__ __launch_bounds__(256) void verify_kernel(VerifyArgs A) {
     const uint64_t first = (uint64_t)chunk * WALK_CHUNK + (uint64_t)threadIdx.x * OPS_PER_LANE;
     uint32_t o[OPS_PER_LANE];
     load_ops(A.ops, A.n_ops, first, o);
-    uint64_t run[NQ] = {0, 0, 0, 0, 0, 0}, tot[NQ];
+    uint64_t run[2] = {0, 0}, tot[2];                                    // only the two positions are scanned here
 #pragma unroll
     for (int j = 0; j < OPS_PER_LANE; ++j) {
         uint64_t c[NQ];
         op_contrib(o[j], c);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) run[q] += c[q];
+        run[0] += c[0]; run[1] += c[1];
     }
-    block_excl_scan<NQ>(run, tot, lds);
+    block_excl_scan<2>(run, tot, lds);
     run[0] += A.chunk_pre[(uint64_t)chunk * NQ + 0];
     run[1] += A.chunk_pre[(uint64_t)chunk * NQ + 1];
     const bool mine_half = threadIdx.x * OPS_PER_LANE >= slot0 && threadIdx.x * OPS_PER_LANE < slot0 + VSLOTS;
