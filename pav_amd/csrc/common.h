@@ -154,7 +154,9 @@ struct CallFetch {              // one call of the batch still resident on the d
     uint32_t *index; int8_t *state_mer, *state; double *kern[3]; uint64_t *kmer; uint8_t *flank, *match;   // pinned host
 };
 // Density tables + FLANK / MATCH of all calls of the last batch: everything is queued, one synchronisation.
-int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls);
+// k1_rows: rows of the leading calls whose KERN_FWDREV column is wanted; the column of the calls behind them (no FWDREV
+// k-mers: all zeros, scripts/density.py:313-323) is not sent over PCIe.  = all rows to copy everything.
+int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls, uint64_t k1_rows);
 
 // ---- device helpers shared by kernels ---------------------------------------------------------------------
 

@@ -1000,7 +1000,7 @@ __global__ __launch_bounds__(256) void k_gather_calls(const GatherCall *__restri
     o_match[t] = m;
 }
 
-int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls) {
+int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls, uint64_t k1_rows) {
     if (calls.empty()) return PAV_OK;
     DensityState *D = dstate(ctx);
     if (!D->valid) return fail(ctx, PAV_E_STATE, "density_fetch_calls: no batch resident");
@@ -1076,12 +1076,17 @@ int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls) {
         PAV_HIP(ctx, hipStreamWaitEvent(ctx->stream3, D->gathered, 0));
         // (a hand-rolled 64-workgroup copy kernel was tried instead of the runtime's copy to keep the chip free for the next
         // step: 16.6 ms per step against 13.9 ms, the runtime's copy is the better one)
-        PAV_HIP(ctx, hipMemcpyAsync(f0.kern[0], d_cols, col_bytes, hipMemcpyDeviceToHost, ctx->stream3));
+        if (k1_rows >= total) {
+            PAV_HIP(ctx, hipMemcpyAsync(f0.kern[0], d_cols, col_bytes, hipMemcpyDeviceToHost, ctx->stream3));
+        } else {                                                    // K0 | leading part of K1, then K2 | ... | MATCH
+            PAV_HIP(ctx, hipMemcpyAsync(f0.kern[0], d_cols, 8ull * (total + k1_rows), hipMemcpyDeviceToHost, ctx->stream3));
+            PAV_HIP(ctx, hipMemcpyAsync(f0.kern[2], g_k2, col_bytes - 16ull * total, hipMemcpyDeviceToHost, ctx->stream3));
+        }
         PAV_HIP(ctx, hipEventRecord(D->stage_copied[turn], ctx->stream3));
         PAV_HIP(ctx, hipEventRecord(ctx->tables_done, ctx->stream3));
         ctx->tables_pending = true;
         if (getenv("PAV_TIMING")) fprintf(stderr, "[pav timing]   call tables: %zu calls, %llu rows (%.1f MB to the host), %llu hash slots, %u insert tiles\n",
-                                          calls.size(), (unsigned long long)total, col_bytes / 1e6, (unsigned long long)keys, tiles);
+                                          calls.size(), (unsigned long long)total, (col_bytes - 8.0 * (double)(total - std::min<uint64_t>(k1_rows, total))) / 1e6, (unsigned long long)keys, tiles);
         return PAV_OK;
     } else {
         for (size_t c = 0; c < calls.size(); ++c) {

@@ -46,6 +46,16 @@ struct InvState {
     struct PinBlock { void *p; size_t cap, used; };
     std::vector<PinBlock> pinned_sets[2];
     int cur_set = 0;
+    // KERN column of a state without k-mers: every table points at a shared block of zeros instead of receiving 8 B per row
+    std::vector<std::unique_ptr<double[]>> zero_blocks;
+    size_t zero_rows = 0;
+    const double *zeros(size_t n) {
+        if (n > zero_rows) {                                  // older blocks stay alive: earlier tables point into them
+            zero_rows = std::max(n, 2 * zero_rows);
+            zero_blocks.emplace_back(new double[zero_rows]());
+        }
+        return zero_blocks.back().get();
+    }
     void next_pinned() { cur_set ^= 1; for (auto &b : pinned_sets[cur_set]) b.used = 0; }
     void free_pinned() { for (auto &set : pinned_sets) { for (auto &b : set) (void)hipHostFree(b.p); set.clear(); } }
     void *pin_alloc(size_t bytes) {
@@ -425,7 +435,7 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
         if (rc != PAV_OK) return rc;
         const double t_q0 = now();
         std::vector<uint32_t> next;
-        std::vector<CallFetch> round_calls; std::vector<uint32_t> round_owner;
+        std::vector<CallFetch> round_calls; std::vector<uint32_t> round_owner; std::vector<uint8_t> round_k1;   // round_k1: the call has FWDREV k-mers
         for (uint32_t j = 0; j < jobs.size(); ++j) {
             const uint32_t i = owners[j];
             Scan &sc = scans[i];
@@ -500,7 +510,7 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
                 cf.base = sc.region_ref.pos;
                 cf.tig_up_pos = std::min(t_outer.pos, t_inner.pos); cf.tig_up_end = std::max(t_outer.pos, t_inner.pos);
                 cf.tig_dn_pos = std::min(t_inner.end, t_outer.end); cf.tig_dn_end = std::max(t_inner.end, t_outer.end);
-                round_calls.push_back(cf); round_owner.push_back(i);
+                round_calls.push_back(cf); round_owner.push_back(i); round_k1.push_back(r.state_count[1] != 0);
                 out.n_rows = n;
                 out.svlen = (uint64_t)r_outer.len();
                 log(i, "Found inversion: " + D.name(PAV_ROLE_REF, r_outer.chrom) + "-" + fmt_i(r_outer.pos + 1) + "-INV-" + fmt_i(r_outer.len()));
@@ -521,8 +531,17 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
             double t0 = now();
             // one pinned block per round, column-major over the whole round: K0 | K1 | K2 | KMER | INDEX | STATE_MER | STATE |
             // FLANK | MATCH, each column holding the calls one after the other (nine bulk device-to-host copies)
-            size_t rows = 0;
-            for (const CallFetch &cf : round_calls) rows += cf.n;
+            // calls without FWDREV k-mers (KERN_FWDREV all zeros) go last: their part of that column stays on the device
+            {
+                std::vector<size_t> order(round_calls.size());
+                for (size_t c = 0; c < order.size(); ++c) order[c] = c;
+                std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return round_k1[a] > round_k1[b]; });
+                std::vector<CallFetch> rc2; std::vector<uint32_t> ro2; std::vector<uint8_t> rk2;
+                for (size_t c : order) { rc2.push_back(round_calls[c]); ro2.push_back(round_owner[c]); rk2.push_back(round_k1[c]); }
+                round_calls.swap(rc2); round_owner.swap(ro2); round_k1.swap(rk2);
+            }
+            size_t rows = 0, k1_rows = 0;
+            for (size_t c = 0; c < round_calls.size(); ++c) { rows += round_calls[c].n; if (round_k1[c]) k1_rows += round_calls[c].n; }
             const size_t total = (rows * 40 + 64 + 63) / 64 * 64;           // blocks stay 64-byte aligned (vector stores from the device)
             void *blk = S->pin_alloc(total);
             if (!blk) return fail(ctx, PAV_E_HIP, "pav_inv_scan_batch: cannot pin %zu bytes of host memory", total);
@@ -541,10 +560,11 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
                 cf.index = tab->index; cf.state_mer = tab->state_mer; cf.state = tab->state; cf.kmer = tab->kmer;
                 cf.flank = tab->flank; cf.match = tab->match;
                 for (int q = 0; q < 3; ++q) cf.kern[q] = tab->kern[q];
+                if (!round_k1[c]) tab->kern[1] = const_cast<double *>(S->zeros(cf.n));   // (read-only for every consumer of the table)
                 o += cf.n;
                 S->tables[round_owner[c]] = std::move(tab);
             }
-            rc = density_fetch_calls(ctx, round_calls);
+            rc = density_fetch_calls(ctx, round_calls, k1_rows);
             t_table += now() - t0;
             if (rc != PAV_OK) return rc;
         }
