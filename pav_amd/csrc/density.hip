@@ -599,14 +599,27 @@ __global__ __launch_bounds__(256) void k_compact_scatter(CompactArgs A) {
     for (int q = 0; q < 4; ++q)
         tile0[q] = A.tile_pre[(uint64_t)blockIdx.x * 4 + q] - A.tile_pre[(uint64_t)jd.first_tile * 4 + q];
     unsigned long long s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0};
+    // the lane's eight k-mers start at consecutive bases: one 64-base window of the 2-bit plane (a 4-byte-aligned 16-byte load +
+    // one dword), fetched before the loop - a window per kept k-mer inside the branch cost eight dependent rounds of loads, and
+    // the non-ACGT plane is not needed (a kept k-mer is a valid one)
+    const uint64_t i0 = base - jd.tpos_off;
+    uint64_t w_lo, w_hi;
+    {
+        const uint64_t a0 = jd.tig_abs + (i0 < jd.tig_len ? i0 : jd.tig_len);      // past the region: stay inside the record's pad block
+        const uint32_t *p = A.T.two + (a0 >> 4);
+        typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+        const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(p);
+        const uint32_t v4 = p[4], sh = ((uint32_t)a0 & 15u) * 2u;
+        w_lo = (uint64_t)__builtin_amdgcn_alignbit(v.z, v.y, sh) << 32 | __builtin_amdgcn_alignbit(v.y, v.x, sh);
+        w_hi = (uint64_t)__builtin_amdgcn_alignbit(v4, v.w, sh) << 32 | __builtin_amdgcn_alignbit(v.w, v.z, sh);
+    }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         if (st[t] < 0) continue;
-        const uint64_t i = base + t - jd.tpos_off;                     // k-mer offset in region_tig = INDEX
+        const uint64_t i = i0 + t;                                     // k-mer offset in region_tig = INDEX
         const uint32_t lr = c[0]++;                                    // row inside the tile
         const uint64_t row = tile0[0] + lr;
-        uint64_t x;
-        kmer_window(A.T.two, A.T.mask, jd.tig_abs + i, A.k, x);
+        const uint64_t x = (t ? (w_lo >> (2 * t) | w_hi << (64 - 2 * t)) : w_lo) & kmer_mask(A.k);
         s_index[lr] = (uint32_t)i;
         s_mer[lr] = (int8_t)st[t];
         s_kmer[lr] = rev_groups(x, A.k);
