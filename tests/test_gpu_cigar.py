@@ -67,6 +67,38 @@ def test_homology_reverse_view(built, gpu_ctx):
     assert [int(x) for x in out] == expect
 
 
+def test_homology_across_non_acgt_summary_blocks(built, gpu_ctx):
+    """The scans read the non-ACGT plane only where the pack's per-1024-base summary marks a block: long matching runs that
+    start in a clean block and reach an N just before / at / after a block boundary, forward and reverse-complemented views."""
+    from oracle import oracle
+    rng = np.random.default_rng(17)
+    unit = 'ACGGTCA'
+    seqs = []
+    for r in range(6):
+        s = list((unit * 1200)[:8192 - 7 * r])                     # a tandem array: homology runs for kilobases
+        for p in (1023, 1024, 1025, 2047, 3072, 5000)[r % 3::3] + (6143 + r,):
+            s[p] = 'N'
+        seqs.append(''.join(s))
+    comp = str.maketrans('ACGTN', 'TGCAN')
+    gpu_ctx.seq_load(_lib.PAV_ROLE_TIG, [str(i) for i in range(len(seqs))], [np.frombuffer(s.encode(), np.uint8) for s in seqs])
+    q = np.zeros(600, dtype=_lib.HOM_QUERY_DTYPE)
+    expect = []
+    for i in range(600):
+        a, ra = int(rng.integers(0, len(seqs))), int(rng.integers(0, 2))
+        sa = seqs[a].translate(comp)[::-1] if ra else seqs[a]
+        svlen = int(rng.choice([7, 14, 21, 35, 70]))                 # whole periods: the scan runs until an N or the edge
+        sv_pos = int(rng.integers(0, 100)) * 7 + (0 if not ra else (len(sa) % 7))
+        sv_pos = min(sv_pos, len(sa) - svlen)
+        pos = int(rng.integers(0, len(sa)))
+        d = int(rng.integers(0, 2))
+        q[i] = (1, a, ra, 0, pos, 1, a, ra, 0, sv_pos, svlen, d)
+        f = oracle.left_homology if d == 0 else oracle.right_homology
+        expect.append(f(pos, sa, sa[sv_pos:sv_pos + svlen]))
+    out = gpu_ctx.homology(q)
+    assert [int(x) for x in out] == expect
+    assert max(expect) > 1024 and sum(1 for e in expect if e > 64) > 50
+
+
 @pytest.mark.parametrize('case', ['cigar_synth', 'cigar_edge'])
 def test_tables_byte_exact_vs_reference(built, gpu_ctx, case):
     """Device output formatted by the host mirror == the TSV text the reference rule wrote."""
