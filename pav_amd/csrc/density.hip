@@ -135,6 +135,28 @@ __device__ __forceinline__ bool kmer_window(const uint32_t *__restrict__ two, co
     return (y & ((1ull << k) - 1ull)) == 0;
 }
 // In kanapy order: kmer = rev_groups(x), reverse complement = x ^ mask (see DESIGN.md "k-mer encoding").
+// The same window in two steps, for loops that want the loads of several windows in flight: kmer_words() only loads (no branch,
+// no use of the data - a window fetched inside an `if` is waited for before the next one is issued), kmer_from_words() shifts.
+struct KmerWords { uint64_t v0, v1; };
+__device__ __forceinline__ KmerWords kmer_words(const uint32_t *__restrict__ two, uint64_t a) {
+    const uint64_t *two64 = reinterpret_cast<const uint64_t *>(two);
+    const uint64_t w = a >> 5;
+    return KmerWords{two64[w], two64[w + 1]};                       // the word after the last base of a record is padding
+}
+// all k bases from a are ACGT (the rare second step of a window whose summary bytes mark a non-ACGT base nearby)
+__device__ __forceinline__ bool kmer_clean(const uint32_t *__restrict__ mask, uint64_t a, int k) {
+    const uint64_t *mask64 = reinterpret_cast<const uint64_t *>(mask);
+    const uint64_t w2 = a >> 6;
+    const int b2 = (int)(a & 63);
+    uint64_t y = mask64[w2] >> b2;
+    if (b2) y |= mask64[w2 + 1] << (64 - b2);
+    return (y & ((1ull << k) - 1ull)) == 0;
+}
+__device__ __forceinline__ uint64_t kmer_from_words(const KmerWords &kw, uint64_t a, int k) {
+    const int b = (int)(a & 31) * 2;
+    return (b ? (kw.v0 >> b | kw.v1 << (64 - b)) : kw.v0) & kmer_mask(k);
+}
+
 
 __device__ __forceinline__ bool table_has(const unsigned long long *__restrict__ keys, uint64_t off, uint32_t hmask,
                                           uint64_t key) {
@@ -292,12 +314,22 @@ __global__ __launch_bounds__(256) void k_bucket_ref(const JobDev *__restrict__ j
     const uint64_t i0 = (uint64_t)blockIdx.x * DTILE - jd.rpos_off;
     uint32_t pid[8], rank[8];
     bool any = false;
+    // the eight windows of a lane and the summary bytes of their blocks are fetched before any is used (no load inside a branch);
+    // the non-ACGT plane itself only where a summary byte is set
+    KmerWords kw[8]; uint64_t at[8]; uint32_t dirt[8]; bool inside[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         const uint64_t i = i0 + t * 256 + threadIdx.x;
-        uint64_t x;
+        inside[t] = i + (uint64_t)k <= jd.ref_len;
+        at[t] = jd.ref_abs + (inside[t] ? i : 0);
+        kw[t] = kmer_words(R.two, at[t]);
+        dirt[t] = (uint32_t)R.dirty[at[t] >> DIRTY_SHIFT] | R.dirty[(at[t] + (uint64_t)k - 1) >> DIRTY_SHIFT];
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const uint64_t x = kmer_from_words(kw[t], at[t], k);
         pid[t] = ~0u;
-        if (i + (uint64_t)k <= jd.ref_len && kmer_window(R.two, R.mask, jd.ref_abs + i, k, x)) {
+        if (inside[t] && (!dirt[t] || kmer_clean(R.mask, at[t], k))) {
             pid[t] = kpart(khash(jd.ref_rc ? (x ^ kmer_mask(k)) : rev_groups(x, k)), P);
             rank[t] = atomicAdd(&hist[pid[t]], 1u);
             any = true;
@@ -331,12 +363,20 @@ __global__ __launch_bounds__(256) void k_bucket_tig(const JobDev *__restrict__ j
     __syncthreads();
     const uint64_t i0 = (uint64_t)blockIdx.x * DTILE - jd.tpos_off;
     uint32_t pf[8], pc[8], rf[8], rc[8];
+    KmerWords kw[8]; uint64_t at[8]; uint32_t dirt[8]; bool inside[8];          // as in k_bucket_ref
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         const uint64_t i = i0 + t * 256 + threadIdx.x;
-        uint64_t x;
+        inside[t] = i + (uint64_t)k <= jd.tig_len;
+        at[t] = jd.tig_abs + (inside[t] ? i : 0);
+        kw[t] = kmer_words(T.two, at[t]);
+        dirt[t] = (uint32_t)T.dirty[at[t] >> DIRTY_SHIFT] | T.dirty[(at[t] + (uint64_t)k - 1) >> DIRTY_SHIFT];
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const uint64_t x = kmer_from_words(kw[t], at[t], k);
         pf[t] = ~0u;
-        if (i + (uint64_t)k <= jd.tig_len && kmer_window(T.two, T.mask, jd.tig_abs + i, k, x)) {
+        if (inside[t] && (!dirt[t] || kmer_clean(T.mask, at[t], k))) {
             pf[t] = kpart(khash(rev_groups(x, k)), P);
             pc[t] = P + kpart(khash(x ^ kmer_mask(k)), P);
             rf[t] = atomicAdd(&hist[pf[t]], 1u);
@@ -386,9 +426,12 @@ __global__ __launch_bounds__(LDS_THREADS) void k_kmer_lds(const PartItem *__rest
         for (uint32_t e0 = threadIdx.x; e0 < n; e0 += KU * LDS_THREADS) {
             uint32_t pos[KU]; uint64_t x[KU]; bool ok[KU];
 #pragma unroll
-            for (int u = 0; u < KU; ++u) { const uint32_t e = e0 + u * LDS_THREADS; ok[u] = e < n; pos[u] = ok[u] ? list[e] : 0u; }
+            for (int u = 0; u < KU; ++u) { const uint32_t e = e0 + u * LDS_THREADS; ok[u] = e < n; pos[u] = list[ok[u] ? e : n - 1]; }
+            KmerWords kw[KU];
 #pragma unroll
-            for (int u = 0; u < KU; ++u) { x[u] = 0; if (ok[u]) kmer_window(R.two, R.mask, jd.ref_abs + pos[u], k, x[u]); }
+            for (int u = 0; u < KU; ++u) kw[u] = kmer_words(R.two, jd.ref_abs + pos[u]);
+#pragma unroll
+            for (int u = 0; u < KU; ++u) x[u] = kmer_from_words(kw[u], jd.ref_abs + pos[u], k);
 #pragma unroll
             for (int u = 0; u < KU; ++u) {
                 if (!ok[u]) continue;
@@ -425,9 +468,12 @@ __global__ __launch_bounds__(LDS_THREADS) void k_kmer_lds(const PartItem *__rest
         for (uint32_t e0 = threadIdx.x; e0 < n; e0 += KU * LDS_THREADS) {
             uint32_t pos[KU]; uint64_t x[KU]; bool ok[KU];
 #pragma unroll
-            for (int u = 0; u < KU; ++u) { const uint32_t e = e0 + u * LDS_THREADS; ok[u] = e < n; pos[u] = ok[u] ? list[e] : 0u; }
+            for (int u = 0; u < KU; ++u) { const uint32_t e = e0 + u * LDS_THREADS; ok[u] = e < n; pos[u] = list[ok[u] ? e : n - 1]; }
+            KmerWords kw[KU];
 #pragma unroll
-            for (int u = 0; u < KU; ++u) { x[u] = 0; if (ok[u]) kmer_window(T.two, T.mask, jd.tig_abs + pos[u], k, x[u]); }
+            for (int u = 0; u < KU; ++u) kw[u] = kmer_words(T.two, jd.tig_abs + pos[u]);
+#pragma unroll
+            for (int u = 0; u < KU; ++u) x[u] = kmer_from_words(kw[u], jd.tig_abs + pos[u], k);
 #pragma unroll
             for (int u = 0; u < KU; ++u) {
                 if (!ok[u]) continue;
