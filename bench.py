@@ -88,7 +88,8 @@ def main():
         dist.barrier()
     from pav_amd import _lib, cigarcall, synth
 
-    threads = args.threads or max(1, (os.cpu_count() or 8) // max(1, world))
+    from pav_amd.shard import effective_cpus
+    threads = args.threads or max(1, effective_cpus() // max(1, world))
     threads = min(threads, 16)
 
     # ---- synthetic inputs (host) -> HBM -----------------------------------------------------------------------
@@ -451,7 +452,8 @@ def main():
             # the same port on all host cores: the alignment rows are independent, so the haplotype is cut into row groups of
             # equal CIGAR text and every group walks on its own thread (ctypes releases the GIL); reported beside the 1-core figure
             from concurrent.futures import ThreadPoolExecutor
-            n_thr = max(1, min(os.cpu_count() or 1, 64))
+            from pav_amd.shard import effective_cpus
+            n_thr = max(1, min(effective_cpus(), 64))          # cgroup quota / affinity, not the host's core count
             t_all = None
             if n_thr > 1 and sub.shape[0] >= 2:
                 # consecutive rows stay together (the table is sorted by chromosome, and every group upper-cases the sequences
@@ -469,7 +471,9 @@ def main():
                 t_all = time.perf_counter() - c0
                 cpu['all_cores'] = {'cigar_call_only': round(sample_bp / t_all / 1e9, 3), 'unit': 'Gbp/s', 'cores': n_thr,
                                     'snv_records': int(sum(parts)), 'wall_s': round(t_all, 2),
-                                    'note': f'{n_grp} groups of consecutive rows on {n_thr} threads; every group upper-cases the chromosomes '
+                                    'host_cpus': os.cpu_count(),
+                                    'note': f'{n_grp} groups of consecutive rows on {n_thr} threads (= the CPUs this process may use: '
+                                            f'affinity and cgroup quota; the host has {os.cpu_count()}); every group upper-cases the chromosomes '
                                             'and contigs its rows touch (the reference does so per row, cigarcall.py:74-75)'}
             if args.workload == 'cigar+inv' and scanned_bp:
                 # k-mer density scan on the CPU: the first scan iteration of the first liftable flagged regions through the

@@ -14,6 +14,31 @@ import numpy as np
 import pandas as pd
 
 
+def effective_cpus():
+    """CPUs this process can really use: the affinity mask, capped by the cgroup CPU quota (containers report the host's core
+    count in os.cpu_count() while cpu.max allows a fraction of it)."""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ('/sys/fs/cgroup/cpu.max',):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != 'max' and int(period) > 0:
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    try:                                                                   # cgroup v1
+        q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        if q > 0 and per > 0:
+            n = min(n, max(1, q // per))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def assign_lpt(costs, n_ranks):
     """Greedy longest-processing-time assignment.  Returns ``n_ranks`` lists of item indices (deterministic)."""
     costs = np.asarray(costs, dtype=np.float64)

@@ -24,6 +24,8 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+from pav_amd.shard import effective_cpus  # noqa: E402
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -32,6 +34,8 @@ def main():
     ap.add_argument('--out', default=None)
     ap.add_argument('--fasta-line', type=int, default=80)
     ap.add_argument('--inv-sig-filter', default='svindel', help="config inv_sig_filter (reference default 'svindel')")
+    ap.add_argument('--threads', type=int, default=min(64, effective_cpus()),
+                    help='host threads of the native table writers (text + gzip members; the library default is 16)')
     args = ap.parse_args()
     import torch  # noqa: F401  first: one HIP runtime per process (pav_amd/_lib.py)
     import __graft_entry__ as g
@@ -46,7 +50,7 @@ def main():
     work = args.out or tempfile.mkdtemp(prefix='pav_e2e_')
     os.makedirs(work, exist_ok=True)
     t0 = time.time()
-    hap = synth.config2(seed=args.seed, scale=args.scale, threads=min(16, os.cpu_count() or 8))
+    hap = synth.config2(seed=args.seed, scale=args.scale, threads=min(16, effective_cpus()))
     ref_fa, tig_fa = os.path.join(work, 'ref.fa'), os.path.join(work, 'contigs_h1.fa')
     synth.write_fasta(ref_fa, hap.ref.names, hap.ref.seqs, line=args.fasta_line)
     synth.write_fasta(tig_fa, hap.tig_names, hap.tig_seqs, line=args.fasta_line)
@@ -86,7 +90,8 @@ def main():
         stage('call: read tables + CIGAR-call', t)
         t = time.time()
         n_snv, n_ins = ctx.cigar_write_tables('h1', index, tp, te, snv_path=os.path.join(work, 'snv_snv_h1.bed.gz'),
-                                              insdel_path=os.path.join(work, 'svindel_insdel_h1.bed.gz'), call_batch=cols['CALL_BATCH'])
+                                              insdel_path=os.path.join(work, 'svindel_insdel_h1.bed.gz'), call_batch=cols['CALL_BATCH'],
+                                              threads=args.threads)
         stage('call: merged tables (sort, text, gzip)', t)
         # ---- flag ----------------------------------------------------------------------------------------------------------
         t = time.time()
@@ -112,21 +117,24 @@ def main():
         calls = [(i, c) for i, c in enumerate(out) if c is not None and not isinstance(c, RuntimeError)]
         den_dir = os.path.join(work, 'density_table')
         os.makedirs(den_dir, exist_ok=True)
-        ctx.inv_write_tables([i for i, _ in calls], [os.path.join(den_dir, f'density_{c.id}_h1.tsv.gz') for _, c in calls])
+        ctx.inv_write_tables([i for i, _ in calls], [os.path.join(den_dir, f'density_{c.id}_h1.tsv.gz') for _, c in calls],
+                             threads=args.threads)
+        stage('scan: density tables (text, gzip)', t)
+        t = time.time()
         rows = [rules.inv_bed_row(c, 'h1', df_try.iloc[i]['TYPE'] if 'TYPE' in df_try else 'NA', tig_fa) for i, c in calls]
         if rows:
             pd.concat(rows, axis=1).T.sort_values(['#CHROM', 'POS', 'END', 'ID']).to_csv(os.path.join(work, 'sv_inv_h1.bed.gz'), sep='\t',
                                                                                         index=False, compression='gzip')
         with open(os.path.join(work, 'inv_call_h1.log'), 'w') as fh:
             fh.write(log.getvalue())
-        stage('scan: INV BED + density tables + log', t)
+        stage('scan: INV BED + log', t)
     total = round(sum(stages.values()), 3)
     sizes = {f: os.path.getsize(os.path.join(work, f)) for f in sorted(os.listdir(work)) if os.path.isfile(os.path.join(work, f))}
     print(json.dumps({'workload': f'one synthetic hg38-shaped haplotype, seed {args.seed}, scale {args.scale}', 'aligned_bp': aligned_bp,
                       'snv_rows': n_snv, 'insdel_rows': n_ins, 'flagged_regions': int(df_flag.shape[0]), 'scanned_regions': len(regions),
                       'inv_calls': len(calls), 'stages_s': stages, 'total_s': total,
-                      'end_to_end_Gbp_per_s': round(aligned_bp / total / 1e9, 3), 'inputs_written_s': round(t_inputs, 1),
-                      'host_cores': os.cpu_count(), 'file_bytes': sizes}), flush=True)
+                      'end_to_end_Gbp_per_s': round(aligned_bp / total / 1e9, 3), 'writer_threads': args.threads, 'inputs_written_s': round(t_inputs, 1),
+                      'host_cores': os.cpu_count(), 'usable_cores': effective_cpus(), 'file_bytes': sizes}), flush=True)
     if args.out is None:
         shutil.rmtree(work, ignore_errors=True)
 
