@@ -28,7 +28,21 @@ template <class F> static void parallel_for(size_t n, int threads, F &&body) {
     for (auto &th : pool) th.join();
 }
 
-static inline int default_host_threads() { return (int)std::min<unsigned>(std::max<unsigned>(std::thread::hardware_concurrency(), 1), 32); }
+// Host threads for the parallel readers / writers: the CPUs this process may really use - hardware_concurrency() reports the
+// host's cores inside a container whose cgroup quota (cpu.max) allows a fraction of them - at most 32.
+static inline int default_host_threads() {
+    unsigned n = std::max<unsigned>(std::thread::hardware_concurrency(), 1);
+    if (FILE *fh = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32] = {0};
+        long long period = 0;
+        if (fscanf(fh, "%31s %lld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0) {
+            const long long q = atoll(quota) / period;
+            if (q >= 1) n = std::min<unsigned>(n, (unsigned)q);
+        }
+        fclose(fh);
+    }
+    return (int)std::min<unsigned>(n, 32);
+}
 
 struct FileText {
     const uint8_t *text = nullptr;           // the decoded bytes of the file
