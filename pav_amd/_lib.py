@@ -638,6 +638,8 @@ class Context:
                  ctypes.c_uint8, ctypes.c_uint8]
         arrs = [np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(t)), shape=(n,)) if n else np.zeros(0, dtype=t)
                 for p, t in zip(ptrs, types)]
+        for a in arrs:                                  # library memory (a column of zeros is shared between calls): read-only
+            a.flags.writeable = False
         cols = dict(zip(['INDEX', 'STATE_MER', 'STATE', 'KERN_FWD', 'KERN_FWDREV', 'KERN_REV', 'KMER'], arrs[:7]))
         return cols, arrs[7], arrs[8]
 
