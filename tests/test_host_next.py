@@ -175,3 +175,17 @@ def test_float_text_of_the_table_writers_equals_pandas(built):
     bad = [(float(v), g, w) for v, g, w in zip(vals, got, want) if g != w and not (w == '""' and g == '')]
     assert not bad, bad[:5]
     assert got[0] == '0.0' and got[1] == '-0.0' and got[5] == '1e+16' and got[4] == '1000000000000000.0' and got[8] == '1e-05'
+
+
+def test_effective_cpus_is_bounded_by_the_host_and_the_cgroup_quota():
+    """pav_amd.shard.effective_cpus: what bench.py / tools size their host thread pools with."""
+    import os
+    from pav_amd.shard import effective_cpus
+    n = effective_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            assert n <= max(1, int(quota) // int(period))
+    except (OSError, ValueError):
+        pass
