@@ -1380,15 +1380,16 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
         A.ref = ctx->seq[PAV_ROLE_REF].view(); A.tig = ctx->seq[PAV_ROLE_TIG].view();
         A.snv = ctx->d_snv.as<pav_snv>(); A.indel = ctx->d_indel.as<pav_indel>();
         A.err_op = d_err_op;
+        PAV_LAUNCH(ctx, "walk_indel", walk_emit<WALK_INDEL>, n_wchunks, 256, 0, A);
         // SNV rows: on the side stream, i.e. behind the contig pack when one is in flight (it is the HBM-bound kernel of the step
-        // and the rows cost 0.4 GB of scattered fetches), next to the homology scans of the main stream
+        // and the rows cost 0.4 GB of scattered fetches), and behind the stubs: next to the homology scans of the main stream
+        // (beside walk_indel the two walks slowed each other down, and the stubs are on the critical path)
         if (totals[2]) {
             PAV_HIP(ctx, hipEventRecord(ctx->snv_ready, ctx->stream));
             PAV_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->snv_ready, 0));
             PAV_LAUNCH_ON(ctx, ctx->stream2, "walk_snv", walk_emit<WALK_SNV>, n_wchunks, 256, 0, A);
             PAV_HIP(ctx, hipEventRecord(ctx->snv_done, ctx->stream2));
         }
-        PAV_LAUNCH(ctx, "walk_indel", walk_emit<WALK_INDEL>, n_wchunks, 256, 0, A);
         if (totals[3]) {
             { int rcw = wait_planes(ctx); if (rcw != PAV_OK) return rcw; }   // the packed planes may still be in flight
             PAV_LAUNCH(ctx, "homology_kernel", homology_kernel, (uint32_t)((totals[3] + 255) / 256), 256, 0,
