@@ -291,8 +291,8 @@ __global__ __launch_bounds__(256) void walk_chunks(const uint64_t *__restrict__ 
         chunk_pre[(uint64_t)n_chunks * NQ + threadIdx.x] = mine;           // read by rows that start at n_ops
         if (host_status) host_status[threadIdx.x] = mine;
     } else if (threadIdx.x == NQ && host_status) host_status[NQ] = totals[NQ];   // tokenizer error key (tok_emit / row_ops ran before us)
-    // the status block goes straight into the host's pinned words (mapped into the device's address space): the runtime's
-    // copy kernel for a device-to-host copy issued here does not retire until the concurrent pack has drained (~0.3 ms)
+    // the status block goes straight into the host's pinned words (mapped into the device's address space): one copy fewer per
+    // call (and under rocprofv3, where copies run as shader kernels, such a copy did not retire before the concurrent pack)
 }
 
 // One wave per row: running (ref, tig) advance of all ops before the row's first op; and for every 2048-operation chunk that
