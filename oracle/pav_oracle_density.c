@@ -179,7 +179,7 @@ orc_density *orc_density_run(const uint8_t *ref_seq, uint64_t ref_len, const uin
     uint64_t n_samp = (n + srs - 1) / srs;
     uint64_t *samp = malloc(8 * (n_samp + 2));
     for (uint64_t q = 0; q < n_samp; ++q) samp[q] = q * srs;
-    if (samp[n_samp - 1] != n - 1) samp[n_samp++] = n - 1;
+    if (n_samp == 0 || samp[n_samp - 1] != n - 1) samp[n_samp++] = n - 1;
     uint64_t n_eval = 0;
     for (uint64_t q = 0; q < n_samp; ++q) {
         const uint64_t x = samp[q];
