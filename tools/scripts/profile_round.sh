@@ -19,6 +19,9 @@ python3 tools/prof_summary.py stats $(ls $O/prof_cigar/*.db | head -1) $P/${ROUN
 python3 tools/prof_summary.py pmc $(ls $O/pmc_fetch/*.db | head -1) $P/${ROUND}_full_path_pmc_fetch.txt > /dev/null
 python3 tools/prof_summary.py pmc $(ls $O/pmc_write/*.db | head -1) $P/${ROUND}_full_path_pmc_write.txt > /dev/null
 python3 tools/prof_summary.py pmcjson $(ls $O/pmc_fetch/*.db | head -1) $(ls $O/pmc_write/*.db | head -1) $O/pmc_bench.json $P/${ROUND}_pmc.json > /dev/null
+# command headers (the per-run figures quoted in the committed copies are added by hand)
+sed -i "1i # Command: rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline   (tools/scripts/profile_round.sh; whole path + the cigar_only,\n# verify_mode, pack-alone and call-without-pack legs).  Under rocprofv3 the runtime copies with shader kernels instead of the SDMA\n# engines: the call-table copy of a step then runs on the CUs beside the next step's pack (same figures as a plain run with\n# HSA_ENABLE_SDMA=0); compare pack_kernel through the cigar_only pair of files." $P/${ROUND}_full_path_kernel_stats.txt
+sed -i "1i # Command: rocprofv3 --kernel-trace --stats -- python3 bench.py --workload cigar --no-cpu-baseline   (tools/scripts/profile_round.sh)\n# Launches of the timed / profiled steps, of the verify leg, of the pack alone and of the call kernels without a pack." $P/${ROUND}_cigar_only_kernel_stats.txt
 cp $O/full_bench_under_rocprof.json $P/${ROUND}_full_path_bench_under_rocprof.json
 cp $O/cigar_bench_under_rocprof.json $P/${ROUND}_cigar_only_bench_under_rocprof.json
 python3 bench.py > $P/${ROUND}_full_path_bench.json 2> $O/bench_full.err
