@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PAV_ABI_VERSION 1
+#define PAV_ABI_VERSION 2
 
 enum {
     PAV_OK = 0,
@@ -235,7 +235,10 @@ typedef struct {
     uint32_t max_ref_kmer_count;    /* MAX_REF_KMER_COUNT (100)  :47                                        */
     uint32_t kde_mode;              /* PAV_KDE_RUNS (default) or PAV_KDE_DIRECT, see below                  */
     uint32_t kmer_mode;             /* PAV_KMER_LDS (default) or PAV_KMER_HBM, see below                    */
-    uint32_t reserved;
+    uint32_t guard_cap;             /* near-tie guard: entries of the re-evaluation list (0 = 1 << 20); when more sites
+                                       are flagged the whole batch is evaluated again in PAV_KDE_DIRECT order           */
+    double guard_rel;               /* near-tie guard: relative margin below which a float decision is re-evaluated in
+                                       scipy's accumulation order; 0 = default 1e-9, < 0 = guard off (see below)        */
 } pav_den_params;
 
 /* Density evaluation.  Both give the reference's KERN_* to ~1e-13 relative and identical STATE on every test vector.
@@ -246,6 +249,22 @@ typedef struct {
  *                   and odd-derivative corrections, remainder < 1e-15 for bandwidth >= 32; short runs and small
  *                   bandwidths fall back to direct terms).  O(N_eval x N_runs). */
 enum { PAV_KDE_RUNS = 0, PAV_KDE_DIRECT = 1 };
+
+/* Near-tie guard (hard part 2).  Three decisions of scripts/density.py depend on float64 densities:
+ *   (a) the arg-max at the sampled sites (:250-255), which feeds `state_change` of the windows (:273-276);
+ *   (b) `density_change`: max |delta KERN| > --staterundelta between two sampled sites (:277-281);
+ *   (c) the final arg-max STATE of every row (:335-338), taken after the spike rule KERN > 1.0 -> 1 / KERN (:330-332).
+ * The closed-form run sums of PAV_KDE_RUNS agree with scipy to ~1e-12 relative, so a decision whose margin is smaller than
+ * guard_rel - (max - second) / max for an arg-max, | max|delta| - delta | / delta for (b) - is not trusted: the sampled sites
+ * (and, for rows of evaluated windows, the rows) it depends on are evaluated again with one exp() per (site, data point)
+ * pair accumulated in ascending data order - scipy's gaussian_kernel_estimate order - and everything downstream (windows,
+ * interpolation, fill, spike rule, arg-max, runs) is redone from those values, until no new site is flagged.
+ * The spike rule itself is continuous (|1/v - v| <= 2 |v - 1|: a row the reference inverts and we do not, or the reverse,
+ * differs by at most twice its distance from 1.0), so rows with |KERN - 1| < guard_rel are only counted (n_spike_near: in
+ * the interior of a long run KERN = 1.0 to the last bit and the branch is decided by rounding in the reference as well);
+ * its discrete consequence, the arg-max taken afterwards, is covered by (c).
+ * After re-evaluation the only differences from scipy left are the last bit of exp() and of np.cov's BLAS dot product
+ * (machine dependent in the reference itself); decisions still within 1e-13 are reported as n_unresolved. */
 
 /* Where the reference k-mer set of a region lives while STATE_MER is computed (identical results):
  *   PAV_KMER_LDS    partitioned by hash, one workgroup builds each partition in a 128 KiB LDS table and answers the
@@ -267,9 +286,13 @@ typedef struct {
     uint32_t n_sample;              /* sampled sites                                                          */
     uint64_t max_kmer;              /* fail_kind 2: first k-mer (insertion order) with max_count, kanapy encoding */
     uint32_t state_count[3];        /* informative k-mers per STATE_MER after the min-state-count rule        */
-    uint32_t pad;
+    uint32_t n_near_tie;            /* float decisions (a)-(c) whose margin was below guard_rel               */
     uint64_t n_eval;                /* density evaluation points computed (sampled + filled)                  */
     double h[3];                    /* KDE bandwidth per state (scipy cho_cov)                                */
+    uint32_t n_reeval;              /* sites evaluated again in scipy's accumulation order because of them    */
+    uint32_t n_unresolved;          /* decisions still within 1e-13 after that: ambiguous in the reference too */
+    uint32_t n_spike_near;          /* table values with |KERN - 1.0| < guard_rel (continuous branch, counted only) */
+    uint32_t guard_fallback;        /* 1: the re-evaluation list overflowed, the batch was redone in PAV_KDE_DIRECT */
 } pav_den_result;
 
 typedef struct { int32_t state; uint32_t count; int64_t pos, end; } pav_run;   /* rl_encoder (state,count,pos,end) */
@@ -337,6 +360,7 @@ typedef struct {
     uint64_t svlen;
     pav_inv_rgn ref_outer, ref_inner, tig_outer, tig_inner, ref_discovery, tig_discovery;
     uint32_t log_bytes, error_bytes;
+    uint32_t n_near_tie, n_unresolved;   /* near-tie guard, summed over the region's scan iterations (pav_den_result)       */
 } pav_inv_result;
 
 int pav_seq_set_names(pav_ctx *ctx, int role, uint32_t n, const char *const *names);   /* record names for log text */

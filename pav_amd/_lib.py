@@ -52,14 +52,15 @@ class DenParams(ctypes.Structure):
     _fields_ = [('k', ctypes.c_int32), ('min_informative', ctypes.c_uint32), ('min_state_count', ctypes.c_uint32),
                 ('den_smooth', ctypes.c_double), ('state_run_delta', ctypes.c_double),
                 ('max_ref_kmer_count', ctypes.c_uint32), ('kde_mode', ctypes.c_uint32), ('kmer_mode', ctypes.c_uint32),
-                ('reserved', ctypes.c_uint32)]
+                ('guard_cap', ctypes.c_uint32), ('guard_rel', ctypes.c_double)]
 
 
 class DenResult(ctypes.Structure):
     _fields_ = [('status', ctypes.c_int32), ('fail_kind', ctypes.c_int32), ('n_rows', ctypes.c_uint32),
                 ('n_runs', ctypes.c_uint32), ('max_count', ctypes.c_uint32), ('n_sample', ctypes.c_uint32),
-                ('max_kmer', ctypes.c_uint64), ('state_count', ctypes.c_uint32 * 3), ('pad', ctypes.c_uint32),
-                ('n_eval', ctypes.c_uint64), ('h', ctypes.c_double * 3)]
+                ('max_kmer', ctypes.c_uint64), ('state_count', ctypes.c_uint32 * 3), ('n_near_tie', ctypes.c_uint32),
+                ('n_eval', ctypes.c_uint64), ('h', ctypes.c_double * 3), ('n_reeval', ctypes.c_uint32),
+                ('n_unresolved', ctypes.c_uint32), ('n_spike_near', ctypes.c_uint32), ('guard_fallback', ctypes.c_uint32)]
 
 
 class InvAln(ctypes.Structure):
@@ -93,7 +94,7 @@ class InvResult(ctypes.Structure):
                 ('n_rows', ctypes.c_uint32), ('svlen', ctypes.c_uint64),
                 ('ref_outer', InvRgn), ('ref_inner', InvRgn), ('tig_outer', InvRgn), ('tig_inner', InvRgn),
                 ('ref_discovery', InvRgn), ('tig_discovery', InvRgn), ('log_bytes', ctypes.c_uint32),
-                ('error_bytes', ctypes.c_uint32)]
+                ('error_bytes', ctypes.c_uint32), ('n_near_tie', ctypes.c_uint32), ('n_unresolved', ctypes.c_uint32)]
 
 
 INV_NONE, INV_CALL, INV_ERROR = 0, 1, 2
@@ -102,7 +103,7 @@ _INV_RGN_DTYPE = np.dtype([('seq_id', '<u4'), ('is_rev', '<u4'), ('pos', '<u8'),
 INV_RESULT_DTYPE = np.dtype([('outcome', '<i4'), ('found', '<u4'), ('iterations', '<u4'), ('n_rows', '<u4'), ('svlen', '<u8'),
                              ('ref_outer', _INV_RGN_DTYPE), ('ref_inner', _INV_RGN_DTYPE), ('tig_outer', _INV_RGN_DTYPE),
                              ('tig_inner', _INV_RGN_DTYPE), ('ref_discovery', _INV_RGN_DTYPE), ('tig_discovery', _INV_RGN_DTYPE),
-                             ('log_bytes', '<u4'), ('error_bytes', '<u4')])
+                             ('log_bytes', '<u4'), ('error_bytes', '<u4'), ('n_near_tie', '<u4'), ('n_unresolved', '<u4')])
 assert INV_RESULT_DTYPE.itemsize == ctypes.sizeof(InvResult)
 RUN_DTYPE = np.dtype([('state', '<i4'), ('count', '<u4'), ('pos', '<i8'), ('end', '<i8')])
 DEN_OK, DEN_UNFINALISED, DEN_FAIL = 0, 1, 125

@@ -44,6 +44,7 @@ struct JobStat {                          // written by kernels, zeroed per batc
     uint32_t n_rows;
     uint32_t m[3], fill_n;
     uint32_t lds_flags, pad;              // k_kmer_lds: LDS_EXCEED (a count passed the limit), LDS_OVERFLOW (partition table full)
+    uint32_t n_near, n_reeval, n_unres, n_spike;   // near-tie guard (include/pav_amd.h)
     unsigned long long s1[3], s2[3];      // sum / sum of squares of the row numbers of each state
     unsigned long long max_key;           // packed (first position << 32 | slot) of the max-count k-mer (failure path)
 };
@@ -53,6 +54,7 @@ struct JobKde {                           // host -> device after the first read
     uint32_t m[3], use_runs;              // use_runs: closed-form run sums (PAV_KDE_RUNS) for this job
     uint32_t samp_off, ps_mask;           // first entry of the job in the compact arrays of sampled sites (ks / ss); states
                                           // whose density is summed term by term and therefore need the scaled positions
+    uint32_t all_direct, pad;             // every present state is summed term by term in ascending order: scipy's order
     uint32_t run_off[3], n_run[3];        // per-state slices of the run arena
     double inv_h[3], norm[3], w[3], cnt[3], h[3];
 };
@@ -70,6 +72,7 @@ struct DensityState {
     DevBuf jobs, stat, kde, tile_job_r, tile_job_t, keys, cnt, keys_x, cnt_x, lists, bcount, ans_f, ans_c, items;
     DevBuf st_tmp, tile_sum, tile_pre, index, state_mer, state, kmer, kern[3], list[3], pscaled[3], fill_list;
     DevBuf tiles, events, ev_count, scratch, run_arena, win_fill, ks[3], ss;
+    DevBuf guard, guard_entries, samp_flag, row_flag, ftiles; // near-tie guard; evaluation tiles of the fill list
     std::vector<JobDev> h_jobs;
     std::vector<JobKde> h_kde;
     void *pin = nullptr; size_t pin_cap = 0;                  // pinned host scratch for the small readbacks (pageable targets are
@@ -95,7 +98,8 @@ struct DensityState {
     void release() {
         DevBuf *all[] = {&jobs, &stat, &kde, &tile_job_r, &tile_job_t, &keys, &cnt, &keys_x, &cnt_x, &lists, &bcount, &ans_f, &ans_c, &items, &st_tmp, &tile_sum, &tile_pre,
                          &index, &state_mer, &state, &kmer, &kern[0], &kern[1], &kern[2], &list[0], &list[1], &list[2],
-                         &pscaled[0], &pscaled[1], &pscaled[2], &fill_list, &tiles, &events, &ev_count, &scratch, &run_arena, &win_fill, &ks[0], &ks[1], &ks[2], &ss};
+                         &pscaled[0], &pscaled[1], &pscaled[2], &fill_list, &tiles, &events, &ev_count, &scratch, &run_arena, &win_fill, &ks[0], &ks[1], &ks[2], &ss,
+                         &guard, &guard_entries, &samp_flag, &row_flag, &ftiles};
         for (DevBuf *b : all) b->release();
         call_stage[0].release(); call_stage[1].release();
         if (pin) { (void)hipHostFree(pin); pin = nullptr; pin_cap = 0; }
@@ -727,6 +731,52 @@ __device__ __forceinline__ int argmax3(double a, double b, double c) {   // np.a
     return m;
 }
 
+
+// ---- near-tie guard (include/pav_amd.h; SURVEY.md section 7, hard part 2) -----------------------------------------
+// Float decisions of scripts/density.py - arg-max at the sampled sites (:250-255), density_change (:277-281), final arg-max
+// (:335-338) - whose margin is below G.rel are not trusted when they rest on closed-form run sums: the kernels that take
+// the decisions append the sites they depend on to a list; k_redo evaluates those in scipy's accumulation order and the
+// host redoes everything downstream (pav_density_batch).  Decisions that are still within G.unres afterwards are counted.
+constexpr double GUARD_REL_DEFAULT = 1e-9;
+constexpr double GUARD_UNRESOLVED = 1e-13;
+constexpr uint32_t GUARD_CAP_DEFAULT = 1u << 20;
+constexpr uint32_t SF_EXACT = 1, SF_PENDING = 2, SF_WIN_COUNTED = 4;  // samp_flag[]: one word per sampled site
+constexpr uint8_t RF_EXACT = 1, RF_PENDING = 2, RF_COUNTED = 4;       // row_flag[]: one byte per table row
+constexpr unsigned long long GE_ROW = 0x80000000ull;                  // list entry: job << 32 | GE_ROW? | sampled site / row
+
+struct GuardDev { uint32_t n_entries, overflow, pad[2]; };
+struct GuardArgs {
+    double rel, unres;                    // rel <= 0: guard off
+    uint32_t pass, cap;                   // pass 0: the regular evaluation; >= 1: redone from re-evaluated sites
+    uint32_t *samp_flag; uint8_t *row_flag;
+    GuardDev *g; unsigned long long *entries;
+    JobStat *stat;
+};
+
+// (max - second) / max < rel.  All zero (absent states, underflow): no tie to resolve, np.argmax takes the first.
+__device__ __forceinline__ bool near_argmax(double a, double b, double c, double rel) {
+    const int m = argmax3(a, b, c);
+    const double mx = m == 0 ? a : (m == 1 ? b : c);
+    if (!(mx > 0.0)) return false;
+    const double second = m == 0 ? fmax(b, c) : (m == 1 ? fmax(a, c) : fmax(a, b));
+    return mx - second < rel * mx;
+}
+
+__device__ __forceinline__ void guard_append(const GuardArgs &G, unsigned long long entry) {
+    const uint32_t e = atomicAdd(&G.g->n_entries, 1u);
+    if (e < G.cap) G.entries[e] = entry; else G.g->overflow = 1;
+}
+__device__ __forceinline__ void guard_flag_sample(const GuardArgs &G, uint32_t job, uint32_t q, uint64_t so) {
+    const uint32_t old = atomicOr(&G.samp_flag[so], SF_PENDING);
+    if (!(old & (SF_PENDING | SF_EXACT))) guard_append(G, (unsigned long long)job << 32 | q);
+}
+__device__ __forceinline__ void guard_flag_row(const GuardArgs &G, uint32_t job, uint32_t row, uint64_t ap) {
+    const uint8_t old = G.row_flag[ap];                                // only the row's own lane (k_finalize) gets here
+    if (old & (RF_PENDING | RF_EXACT)) return;
+    G.row_flag[ap] = old | RF_PENDING;
+    guard_append(G, (unsigned long long)job << 32 | GE_ROW | row);
+}
+
 // gaussian_kernel_estimate (scipy/stats/_stats.pyx) for one state at one evaluation point; `ps` is wave-uniform so
 // the data stream goes through the scalar cache.  Accumulation order = data ascending, as in scipy.
 __device__ __forceinline__ double kde_state(const double *__restrict__ ps, uint32_t m, double xs, double norm, double w) {
@@ -752,8 +802,7 @@ __device__ __forceinline__ double kde_state(const double *__restrict__ ps, uint3
 //   + (f(a) + f(b)) / 2 + (f1(b) - f1(a)) / 12 - (f3(b) - f3(a)) / 720 + (f5(b) - f5(a)) / 30240,
 // where fm is the m-th derivative: fm(t) = (-1)^m He_m(u) f / h^m, u = (t - x)/h.  The next term is below
 // 27 / (1.2e6 h^7): < 1e-15 for h >= 32.
-__device__ __forceinline__ double run_sum_em(double da, double db, double h, double inv_h) {
-    const double ua = da * inv_h, ub = db * inv_h;
+__device__ __forceinline__ double run_sum_em(double ua, double ub, double h, double inv_h) {
     const double fa = exp(-(ua * ua) / 2), fb = exp(-(ub * ub) / 2);
     const double s = 0.70710678118654752440;
     double integ;
@@ -773,10 +822,11 @@ __device__ __forceinline__ double run_sum_em(double da, double db, double h, dou
 
 // Tail of a run seen from far away with a narrow kernel: consecutive terms fall by exp(-u/h) per step, so the sum is
 // its first few hundred terms at most (the Euler-Maclaurin series converges in u/h and is not used there).
-__device__ __forceinline__ double run_sum_tail(double d0, uint32_t len, double inv_h) {
+// Terms as scipy forms them: fl(i / h) - fl(x / h).  first / step: nearest element of the run and the direction away from x.
+__device__ __forceinline__ double run_sum_tail(uint32_t first, int step, uint32_t len, double inv_h, double xs) {
     double sum = 0.0;
     for (uint32_t k = 0; k < len; ++k) {
-        const double u = (d0 + (double)k) * inv_h;
+        const double u = (double)(first + (uint32_t)(step * (int)k)) * inv_h - xs;
         const double t = exp(-(u * u) / 2);
         sum += t;
         if (t < 1e-19 * sum) break;
@@ -784,20 +834,24 @@ __device__ __forceinline__ double run_sum_tail(double d0, uint32_t len, double i
     return sum;
 }
 
-__device__ __forceinline__ double kde_state_runs(const RunDev *__restrict__ runs, uint32_t n_run, double x, double h,
+// scipy subtracts the scaled positions, fl(i / h) - fl(x / h) (gaussian_kernel_estimate: points_[i] - xi_[j]); the rounding of
+// x / h is common to every term of an evaluation point and shifts a far, concentrated state's density by up to 1e-11
+// relative, so the closed form takes its arguments relative to the same rounded xs: u = fma(i, 1 / h, -xs).
+__device__ __forceinline__ double kde_state_runs(const RunDev *__restrict__ runs, uint32_t n_run, uint32_t xi, double h,
                                                  double inv_h, double norm, double w) {
     const double short_len = fmax(16.0, h * 0.0625);                  // short runs: direct terms (also bounds the
-    double sum = 0.0;                                                  // cancellation in the erfc difference)
+    const double x = (double)xi, xs = x * inv_h;                       // cancellation in the erfc difference)
+    double sum = 0.0;
     for (uint32_t r = 0; r < n_run; ++r) {
         const RunDev rn = runs[r];
         const double da = (double)rn.a - x, db = (double)rn.b - x;
         const double near = da >= 0.0 ? da : (db <= 0.0 ? -db : 0.0);  // distance of the nearest run element
         if ((double)(rn.b - rn.a) < short_len) {
-            for (uint32_t i = rn.a; i <= rn.b; ++i) { const double u = ((double)i - x) * inv_h; sum += exp(-(u * u) / 2); }
+            for (uint32_t i = rn.a; i <= rn.b; ++i) { const double u = (double)i * inv_h - xs; sum += exp(-(u * u) / 2); }
         } else if (near * inv_h * inv_h > 0.1) {                       // u/h > 0.1: steep tail
-            sum += run_sum_tail(near, rn.b - rn.a + 1, inv_h);
+            sum += da >= 0.0 ? run_sum_tail(rn.a, 1, rn.b - rn.a + 1, inv_h, xs) : run_sum_tail(rn.b, -1, rn.b - rn.a + 1, inv_h, xs);
         } else {
-            sum += run_sum_em(da, db, h, inv_h);
+            sum += run_sum_em(fma((double)rn.a, inv_h, -xs), fma((double)rn.b, inv_h, -xs), h, inv_h);
         }
     }
     return w * (sum * norm);
@@ -807,6 +861,7 @@ struct KdeArgs {
     const JobDev *jobs; const JobKde *kde; const EvalTile *tiles; const uint32_t *fill_list;
     const double *ps[3]; double *kern[3]; int8_t *state; const RunDev *runs;
     double *ks[3]; int8_t *ss;            // sampled sites, compact: entry samp_off + q of job j = row min(q * srs, n - 1)
+    GuardArgs G;
 };
 
 // One wave per tile of 64 evaluation points of one job.
@@ -828,7 +883,7 @@ __global__ __launch_bounds__(64) void k_kde_eval(KdeArgs A) {
     for (int s = 0; s < 3; ++s) {
         if (kd.m[s] == 0) { val[s] = 0.0; continue; }                  // density.py:84,92,100
         const double est = (kd.use_runs && kd.h[s] >= KDE_RUNS_MIN_H)
-            ? kde_state_runs(A.runs + kd.run_off[s], kd.n_run[s], (double)x, kd.h[s], kd.inv_h[s], kd.norm[s], kd.w[s])
+            ? kde_state_runs(A.runs + kd.run_off[s], kd.n_run[s], x, kd.h[s], kd.inv_h[s], kd.norm[s], kd.w[s])
             : kde_state(A.ps[s] + off, kd.m[s], (double)x * kd.inv_h[s], kd.norm[s], kd.w[s]);
         val[s] = est * kd.cnt[s];                                      // density.py:110-115
     }
@@ -838,6 +893,11 @@ __global__ __launch_bounds__(64) void k_kde_eval(KdeArgs A) {
 #pragma unroll
         for (int s = 0; s < 3; ++s) A.ks[s][so] = val[s];
         A.ss[so] = (int8_t)argmax3(val[0], val[1], val[2]);            // density.py:250-255
+        if (A.G.rel > 0.0 && near_argmax(val[0], val[1], val[2], A.G.rel)) {
+            atomicAdd(&A.G.stat[t.job].n_near, 1u);                    // sampled sites are evaluated here in pass 0 only
+            if (!kd.all_direct) guard_flag_sample(A.G, t.job, t.first + threadIdx.x, so);
+            else if (near_argmax(val[0], val[1], val[2], A.G.unres)) atomicAdd(&A.G.stat[t.job].n_unres, 1u);
+        }
     } else {
 #pragma unroll
         for (int s = 0; s < 3; ++s) A.kern[s][off + x] = val[s];
@@ -853,7 +913,7 @@ __global__ __launch_bounds__(64) void k_windows(const JobDev *__restrict__ jobs,
                                                 const int8_t *__restrict__ ss, const double *__restrict__ s0,
                                                 const double *__restrict__ s1, const double *__restrict__ s2, double delta,
                                                 uint32_t *__restrict__ fill_list, uint8_t *__restrict__ win_fill,
-                                                JobStat *__restrict__ stat) {
+                                                JobStat *__restrict__ stat, GuardArgs G) {
     const EvalTile t = tiles[blockIdx.x];                              // the tiles of the sampled sites: one wave per 64 windows
     if (threadIdx.x >= t.count) return;
     const uint32_t j = t.job;
@@ -875,6 +935,14 @@ __global__ __launch_bounds__(64) void k_windows(const JobDev *__restrict__ jobs,
 #pragma unroll
     for (int s = 0; s < 3; ++s) { const double d = fabs(kk[s][so] - kk[s][so + 1]); if (d > dmax) dmax = d; }
     const bool fill = change || dmax > delta;                          // :277-283
+    if (G.rel > 0.0 && !change && fabs(dmax - delta) < G.rel * delta) {          // density_change decided by a hair
+        if (G.pass == 0) atomicAdd(&stat[j].n_near, 1u);
+        const bool e0 = kd.all_direct || (G.samp_flag[so] & SF_EXACT), e1 = kd.all_direct || (G.samp_flag[so + 1] & SF_EXACT);
+        if (!e0) guard_flag_sample(G, j, (uint32_t)q, so);
+        if (!e1) guard_flag_sample(G, j, (uint32_t)q + 1, so + 1);
+        if (e0 && e1 && !(atomicOr(&G.samp_flag[so], SF_WIN_COUNTED) & SF_WIN_COUNTED) && fabs(dmax - delta) < G.unres * delta)
+            atomicAdd(&stat[j].n_unres, 1u);
+    }
     win_fill[ap] = fill ? 1 : 0;
     if (fill) {
         const uint32_t cnt = (uint32_t)(b - a - 1);
@@ -923,19 +991,152 @@ __global__ __launch_bounds__(256) void k_interp(const JobDev *__restrict__ jobs,
     }
 }
 
-// Spike penalty and arg-max (scripts/density.py:329-338)
+// Spike penalty and arg-max (scripts/density.py:329-338).  Near-tie guard of the arg-max: the sites a doubtful row rests on -
+// itself when it is a sampled site or a row of an evaluated window, the two ends of its window when it was interpolated -
+// are queued for evaluation in scipy's order unless they already are.  blk_spike: rows of the block with a value within
+// G.rel of the spike threshold 1.0 (counted only: the branch is continuous, see include/pav_amd.h).
 __global__ __launch_bounds__(256) void k_finalize(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
                                                   const JobKde *__restrict__ kde, double *__restrict__ k0,
-                                                  double *__restrict__ k1, double *__restrict__ k2, int8_t *__restrict__ state) {
+                                                  double *__restrict__ k1, double *__restrict__ k2, int8_t *__restrict__ state,
+                                                  const uint8_t *__restrict__ win_fill, GuardArgs G,
+                                                  uint32_t *__restrict__ blk_spike) {
+    __shared__ uint32_t s_spike[4];
     const uint64_t ap = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint32_t j = tile_job[ap / DTILE];
     const JobKde kd = kde[j];
-    if (!kd.finalised || ap - jobs[j].tpos_off >= kd.n) return;
-    double a = k0[ap], b = k1[ap], c = k2[ap];
-    if (a > 1.0) { a = 1 / a; k0[ap] = a; }
-    if (b > 1.0) { b = 1 / b; k1[ap] = b; }
-    if (c > 1.0) { c = 1 / c; k2[ap] = c; }
-    state[ap] = (int8_t)argmax3(a, b, c);
+    const uint64_t off = jobs[j].tpos_off;
+    bool spike_near = false;
+    if (kd.finalised && ap - off < kd.n) {
+        double a = k0[ap], b = k1[ap], c = k2[ap];
+        if (G.rel > 0.0) spike_near = fabs(a - 1.0) < G.rel || fabs(b - 1.0) < G.rel || fabs(c - 1.0) < G.rel;
+        if (a > 1.0) { a = 1 / a; k0[ap] = a; }
+        if (b > 1.0) { b = 1 / b; k1[ap] = b; }
+        if (c > 1.0) { c = 1 / c; k2[ap] = c; }
+        state[ap] = (int8_t)argmax3(a, b, c);
+        if (G.rel > 0.0 && near_argmax(a, b, c, G.rel)) {
+            if (G.pass == 0) atomicAdd(&G.stat[j].n_near, 1u);
+            const uint32_t x = (uint32_t)(ap - off), q = x / kd.srs;
+            bool exact;
+            if (x == q * kd.srs || x == kd.n - 1) {                    // a sampled site (n - 1 is site q + 1 unless a multiple of srs)
+                const uint32_t qs = x == q * kd.srs ? q : q + 1;
+                const uint64_t so = (uint64_t)kd.samp_off + qs;
+                exact = kd.all_direct || (G.samp_flag[so] & SF_EXACT);
+                if (!exact) guard_flag_sample(G, j, qs, so);
+            } else if (win_fill[off + q]) {                            // evaluated row
+                exact = kd.all_direct || (G.row_flag[ap] & RF_EXACT);
+                if (!exact) guard_flag_row(G, j, x, ap);
+            } else {                                                   // interpolated between the ends of window q
+                const uint64_t so = (uint64_t)kd.samp_off + q;
+                const bool e0 = kd.all_direct || (G.samp_flag[so] & SF_EXACT), e1 = kd.all_direct || (G.samp_flag[so + 1] & SF_EXACT);
+                if (!e0) guard_flag_sample(G, j, q, so);
+                if (!e1) guard_flag_sample(G, j, q + 1, so + 1);
+                exact = e0 && e1;
+            }
+            if (exact && !(G.row_flag[ap] & RF_COUNTED)) {
+                G.row_flag[ap] |= RF_COUNTED;
+                if (near_argmax(a, b, c, G.unres)) atomicAdd(&G.stat[j].n_unres, 1u);
+            }
+        }
+    }
+    if (blk_spike) {
+        const unsigned long long bal = __ballot(spike_near);
+        if ((threadIdx.x & 63) == 0) s_spike[threadIdx.x >> 6] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        if (threadIdx.x == 0) blk_spike[blockIdx.x] = s_spike[0] + s_spike[1] + s_spike[2] + s_spike[3];
+    }
+}
+
+// Per job: sum of its blocks' spike counts (a plain store: the same value whenever k_finalize is repeated).
+__global__ __launch_bounds__(256) void k_spike_sum(const JobDev *__restrict__ jobs, const JobKde *__restrict__ kde,
+                                                   const uint32_t *__restrict__ blk_spike, JobStat *__restrict__ stat) {
+    __shared__ uint32_t red[4];
+    const uint32_t j = blockIdx.x;
+    const JobKde kd = kde[j];
+    uint32_t v = 0;
+    if (kd.finalised) {
+        const uint64_t b0 = jobs[j].tpos_off / 256, nb = ((uint64_t)kd.n + 255) / 256;
+        for (uint64_t b = threadIdx.x; b < nb; b += 256) v += blk_spike[b0 + b];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) stat[j].n_spike = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void k_reset_fill(JobStat *__restrict__ stat, uint32_t n_jobs) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n_jobs) stat[j].fill_n = 0;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// One wave per queued site: its three densities with one exp() per data point, accumulated in ascending data order like
+// scipy's gaussian_kernel_estimate (the lanes compute 64 terms at a time, the sum takes them one after the other: the same
+// additions in the same order as kde_state()).  kinds: bit 0 sampled sites of the list slice, bit 1 rows.
+struct RedoArgs {
+    const JobDev *jobs; const JobKde *kde; const uint32_t *list[3]; double *ks[3]; int8_t *ss; double *kern[3];
+    const uint8_t *win_fill; GuardArgs G; uint32_t first, kinds;
+};
+__global__ __launch_bounds__(64) void k_redo(RedoArgs A) {
+    const unsigned long long e = A.G.entries[A.first + blockIdx.x];
+    const uint32_t j = (uint32_t)(e >> 32), idx = (uint32_t)(e & 0x7FFFFFFFull);
+    const bool is_row = (e & GE_ROW) != 0;
+    if (!((A.kinds >> (is_row ? 1 : 0)) & 1u)) return;
+    const JobKde kd = A.kde[j];
+    const uint64_t off = A.jobs[j].tpos_off;
+    uint32_t x;
+    uint64_t so = 0;
+    if (is_row) {
+        x = idx;
+        if (!A.win_fill[off + x / kd.srs]) return;                    // interpolated now: k_finalize looks at the window's ends
+    } else {
+        so = (uint64_t)kd.samp_off + idx;
+        if (A.G.samp_flag[so] & SF_EXACT) return;
+        const uint64_t xx = (uint64_t)idx * kd.srs;
+        x = xx > kd.n - 1 ? kd.n - 1 : (uint32_t)xx;
+    }
+    const int lane = threadIdx.x;
+    double val[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const uint32_t m = kd.m[s];
+        if (m == 0) { val[s] = 0.0; continue; }
+        const double inv_h = kd.inv_h[s], norm = kd.norm[s], w = kd.w[s];
+        const double xs = (double)x * inv_h;
+        const uint32_t *ls = A.list[s] + off;
+        double est = 0.0;
+        for (uint32_t i0 = 0; i0 < m; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            double t = 0.0;
+            if (i < m) {
+                const double r = (double)ls[i] * inv_h - xs;          // points_[i] - xi_[j], points_ = data * (1 / h)
+                t = w * (exp(-(r * r) / 2) * norm);
+            }
+            const int cnt = (int)min(64u, m - i0);
+            for (int l = 0; l < cnt; ++l) est += readlane_f64(t, l);
+        }
+        val[s] = est * kd.cnt[s];
+    }
+    if (lane != 0) return;
+    if (is_row) {
+        const uint64_t ap = off + x;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) A.kern[s][ap] = val[s];
+        const uint8_t old = A.G.row_flag[ap];
+        if (!(old & RF_EXACT)) atomicAdd(&A.G.stat[j].n_reeval, 1u);
+        A.G.row_flag[ap] = (uint8_t)((old & ~RF_PENDING) | RF_EXACT);
+    } else {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) A.ks[s][so] = val[s];
+        A.ss[so] = (int8_t)argmax3(val[0], val[1], val[2]);
+        A.G.samp_flag[so] = (A.G.samp_flag[so] & ~SF_PENDING) | SF_EXACT;
+        atomicAdd(&A.G.stat[j].n_reeval, 1u);
+        if (near_argmax(val[0], val[1], val[2], A.G.unres)) atomicAdd(&A.G.stat[j].n_unres, 1u);
+    }
 }
 
 // Run heads for rl_encoder (pavlib/density.py:330-361): one event per row that starts a run, plus one end marker.
@@ -1346,7 +1547,8 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     for (int s = 0; s < 3; ++s) CA.list[s] = D->list[s].as<uint32_t>();
     std::vector<JobStat> hs(n_jobs);
     constexpr uint32_t EV_PREFETCH = 4096;                             // head events copied together with their count
-    uint8_t *h_pin = static_cast<uint8_t *>(D->pinned(std::max(sizeof(JobStat) * (size_t)n_jobs, sizeof(HeadEvent) * (size_t)EV_PREFETCH + 64)));
+    const size_t pin_guard_off = (std::max(sizeof(JobStat) * (size_t)n_jobs, sizeof(HeadEvent) * (size_t)EV_PREFETCH + 64) + 63) / 64 * 64;
+    uint8_t *h_pin = static_cast<uint8_t *>(D->pinned(pin_guard_off + 64));
     if (!h_pin) return fail(ctx, PAV_E_HIP, "pav_density_batch: cannot pin host memory for the readbacks");
     auto read_stats = [&]() -> int {
         PAV_HIP(ctx, hipMemcpyAsync(h_pin, d_stat, sizeof(JobStat) * n_jobs, hipMemcpyDeviceToHost, st));
@@ -1527,15 +1729,6 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             PAV_HIP(ctx, hipMemcpyAsync(D->run_arena.p, arena.data(), sizeof(RunDev) * arena.size(), hipMemcpyHostToDevice, st));
         PAV_HIP(ctx, hipStreamSynchronize(st));                        // `arena` is a local buffer
     }
-    bool any_ps = false;
-    for (uint32_t j = 0; j < n_jobs; ++j) {                            // same choice as k_kde_eval makes per state
-        JobKde &kd = D->h_kde[j];
-        if (!kd.finalised) continue;
-        for (int q = 0; q < 3; ++q)
-            if (kd.m[q] && !(kd.use_runs && kd.h[q] >= KDE_RUNS_MIN_H)) kd.ps_mask |= 1u << q;
-        any_ps = any_ps || kd.ps_mask;
-    }
-    lap("kde host");
     // failure path: the k-mer named in the message of scripts/density.py:519-526
     for (uint32_t j = 0; j < n_jobs; ++j) {
         if (D->results[j].fail_kind != 2) continue;
@@ -1551,59 +1744,152 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
         // the set holds rc(k-mer) when -r is set; the counter in the reference is keyed by the forward k-mer
         D->results[j].max_kmer = D->h_jobs[j].ref_rc ? pav_kmer_rev_complement(key, k) : key;
     }
-    PAV_HIP(ctx, hipMemcpyAsync(D->kde.p, D->h_kde.data(), sizeof(JobKde) * n_jobs, hipMemcpyHostToDevice, st));
     const JobKde *d_kde = D->kde.as<JobKde>();
+    if (total_samp > 0xFFFFFFFFull) return fail(ctx, PAV_E_LIMIT, "pav_density_batch: too many sampled sites in one batch");
+    for (int s = 0; s < 3; ++s) PAV_HIP(ctx, D->ks[s].reserve(8 * (total_samp + 1)));
+    PAV_HIP(ctx, D->ss.reserve(total_samp + 1));
+
+    // near-tie guard (include/pav_amd.h): flags per sampled site / table row, the list of sites to evaluate again
+    GuardArgs G{};
+    G.rel = pp->guard_rel == 0.0 ? GUARD_REL_DEFAULT : pp->guard_rel;
+    G.unres = GUARD_UNRESOLVED;
+    G.cap = pp->guard_cap ? pp->guard_cap : GUARD_CAP_DEFAULT;
+    G.stat = d_stat;
+    if (G.rel > 0.0 && !tiles.empty()) {
+        PAV_HIP(ctx, D->guard.reserve(sizeof(GuardDev)));
+        PAV_HIP(ctx, D->guard_entries.reserve(8ull * G.cap));
+        PAV_HIP(ctx, D->samp_flag.reserve(4 * (total_samp + 2)));
+        PAV_HIP(ctx, D->row_flag.reserve(a_t));
+        G.g = D->guard.as<GuardDev>(); G.entries = D->guard_entries.as<unsigned long long>();
+        G.samp_flag = D->samp_flag.as<uint32_t>(); G.row_flag = D->row_flag.as<uint8_t>();
+    }
+    PAV_HIP(ctx, D->scratch.reserve(4ull * (a_t / 256 + 1)));         // spike counts per block of k_finalize
+    GuardDev h_guard{};
+    auto read_guard = [&](uint8_t *dst) -> int {                        // queued in front of a synchronisation that follows
+        if (G.rel > 0.0 && G.g) PAV_HIP(ctx, hipMemcpyAsync(dst, G.g, sizeof(GuardDev), hipMemcpyDeviceToHost, st));
+        return PAV_OK;
+    };
+    uint8_t *h_guard_pin = h_pin + pin_guard_off;
 
     KdeArgs KA;
     KA.jobs = d_jobs; KA.kde = d_kde; KA.fill_list = D->fill_list.as<uint32_t>(); KA.state = D->state.as<int8_t>();
     KA.runs = D->run_arena.as<RunDev>();
-    if (total_samp > 0xFFFFFFFFull) return fail(ctx, PAV_E_LIMIT, "pav_density_batch: too many sampled sites in one batch");
-    for (int s = 0; s < 3; ++s) PAV_HIP(ctx, D->ks[s].reserve(8 * (total_samp + 1)));
-    PAV_HIP(ctx, D->ss.reserve(total_samp + 1));
     for (int s = 0; s < 3; ++s) { KA.ps[s] = D->pscaled[s].as<double>(); KA.kern[s] = D->kern[s].as<double>(); KA.ks[s] = D->ks[s].as<double>(); }
     KA.ss = D->ss.as<int8_t>();
+    RedoArgs RA;
+    RA.jobs = d_jobs; RA.kde = d_kde; RA.ss = D->ss.as<int8_t>(); RA.win_fill = D->win_fill.as<uint8_t>();
+    for (int s = 0; s < 3; ++s) { RA.list[s] = D->list[s].as<uint32_t>(); RA.ks[s] = D->ks[s].as<double>(); RA.kern[s] = D->kern[s].as<double>(); }
 
+    std::vector<HeadEvent> ev;
+    std::vector<EvalTile> ftiles;                                      // alive until the synchronisation of collect_heads
     if (!tiles.empty()) {
+        PAV_HIP(ctx, D->tiles.reserve(sizeof(EvalTile) * tiles.size()));
+        PAV_HIP(ctx, hipMemcpyAsync(D->tiles.p, tiles.data(), sizeof(EvalTile) * tiles.size(), hipMemcpyHostToDevice, st));
+    }
+    // The density stage runs once in the regular case.  It is repeated with every job summed term by term (force_direct) only
+    // when the guard's list overflowed.
+    bool fallback = false;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const bool force_direct = attempt == 1;
+        bool any_ps = false;
+        for (uint32_t j = 0; j < n_jobs; ++j) {                        // same choice as k_kde_eval makes per state
+            JobKde &kd = D->h_kde[j];
+            if (!kd.finalised) continue;
+            if (force_direct) kd.use_runs = 0;
+            kd.ps_mask = 0; kd.all_direct = 1;
+            for (int q = 0; q < 3; ++q) {
+                if (!kd.m[q]) continue;
+                if (kd.use_runs && kd.h[q] >= KDE_RUNS_MIN_H) kd.all_direct = 0; else kd.ps_mask |= 1u << q;
+            }
+            any_ps = any_ps || kd.ps_mask;
+        }
+        if (attempt == 0) lap("kde host");
+        PAV_HIP(ctx, hipMemcpyAsync(D->kde.p, D->h_kde.data(), sizeof(JobKde) * n_jobs, hipMemcpyHostToDevice, st));
+        if (tiles.empty()) break;
+        if (G.g) {
+            PAV_HIP(ctx, hipMemsetAsync(G.g, 0, sizeof(GuardDev), st));
+            PAV_HIP(ctx, hipMemsetAsync(G.samp_flag, 0, 4 * (total_samp + 2), st));
+            PAV_HIP(ctx, hipMemsetAsync(G.row_flag, 0, a_t, st));
+        }
+        if (force_direct) {                                            // counters of the abandoned attempt
+            for (uint32_t j = 0; j < n_jobs; ++j) { JobStat &q = hs[j]; q.fill_n = 0; q.n_near = q.n_reeval = q.n_unres = q.n_spike = 0; }
+            PAV_HIP(ctx, hipMemcpyAsync(d_stat, hs.data(), sizeof(JobStat) * n_jobs, hipMemcpyHostToDevice, st));
+        }
         if (any_ps)
             PAV_LAUNCH(ctx, "k_pscale", k_pscale, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_kde, D->list[0].as<uint32_t>(),
                        D->list[1].as<uint32_t>(), D->list[2].as<uint32_t>(), D->pscaled[0].as<double>(), D->pscaled[1].as<double>(),
                        D->pscaled[2].as<double>());
-        PAV_HIP(ctx, D->tiles.reserve(sizeof(EvalTile) * tiles.size()));
-        PAV_HIP(ctx, hipMemcpyAsync(D->tiles.p, tiles.data(), sizeof(EvalTile) * tiles.size(), hipMemcpyHostToDevice, st));
+        G.pass = 0;
+        KA.G = G;
         KA.tiles = D->tiles.as<EvalTile>();
         PAV_LAUNCH(ctx, "k_kde_eval", k_kde_eval, (uint32_t)tiles.size(), 64, 0, KA);
-        PAV_LAUNCH(ctx, "k_windows", k_windows, (uint32_t)tiles.size(), 64, 0, d_jobs, D->tiles.as<EvalTile>(), d_kde, D->state_mer.as<int8_t>(),
-                   D->ss.as<int8_t>(), D->ks[0].as<double>(), D->ks[1].as<double>(), D->ks[2].as<double>(),
-                   pp->state_run_delta, D->fill_list.as<uint32_t>(), D->win_fill.as<uint8_t>(), d_stat);
-        PAV_LAUNCH(ctx, "k_interp", k_interp, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_kde, D->win_fill.as<uint8_t>(),
-                   D->ks[0].as<double>(), D->ks[1].as<double>(), D->ks[2].as<double>(), D->kern[0].as<double>(),
-                   D->kern[1].as<double>(), D->kern[2].as<double>());
-        lap("kde queue 1");
-        // ---- readback 2: how many inner sites need the full density --------------------------------------------
-        { const int rcs = read_stats(); if (rcs != PAV_OK) return rcs; }
-        lap("kde eval 1");
-        std::vector<EvalTile> ftiles;
-        for (uint32_t j = 0; j < n_jobs; ++j) {
-            if (!D->h_kde[j].finalised) continue;
-            D->results[j].n_eval = (uint64_t)D->h_kde[j].n_samp + hs[j].fill_n;
-            for (uint32_t f = 0; f < hs[j].fill_n; f += 64) ftiles.push_back(EvalTile{j, f, std::min<uint32_t>(64, hs[j].fill_n - f), 1});
+        uint32_t processed = 0;                                        // list entries whose sampled sites have been evaluated again
+        bool overflow = false;
+        for (uint32_t pass = 0; ; ++pass) {
+            if (pass > 64) return fail(ctx, PAV_E_STATE, "pav_density_batch: the near-tie guard did not settle");
+            G.pass = pass;
+            KA.G = G; RA.G = G;
+            // ---- windows between sampled sites: interpolate or queue for evaluation (readback 2: fill counts) ----------
+            if (pass) PAV_LAUNCH(ctx, "k_reset_fill", k_reset_fill, (n_jobs + 255) / 256, 256, 0, d_stat, n_jobs);
+            PAV_LAUNCH(ctx, "k_windows", k_windows, (uint32_t)tiles.size(), 64, 0, d_jobs, D->tiles.as<EvalTile>(), d_kde, D->state_mer.as<int8_t>(),
+                       D->ss.as<int8_t>(), D->ks[0].as<double>(), D->ks[1].as<double>(), D->ks[2].as<double>(),
+                       pp->state_run_delta, D->fill_list.as<uint32_t>(), D->win_fill.as<uint8_t>(), d_stat, G);
+            PAV_LAUNCH(ctx, "k_interp", k_interp, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_kde, D->win_fill.as<uint8_t>(),
+                       D->ks[0].as<double>(), D->ks[1].as<double>(), D->ks[2].as<double>(), D->kern[0].as<double>(),
+                       D->kern[1].as<double>(), D->kern[2].as<double>());
+            if (pass == 0) lap("kde queue 1");
+            { const int rcs = read_stats(); if (rcs != PAV_OK) return rcs; }
+            if (pass == 0) lap("kde eval 1");
+            ftiles.clear();
+            for (uint32_t j = 0; j < n_jobs; ++j) {
+                if (!D->h_kde[j].finalised) continue;
+                D->results[j].n_eval = (uint64_t)D->h_kde[j].n_samp + hs[j].fill_n;
+                for (uint32_t f = 0; f < hs[j].fill_n; f += 64) ftiles.push_back(EvalTile{j, f, std::min<uint32_t>(64, hs[j].fill_n - f), 1});
+            }
+            if (!ftiles.empty()) {
+                PAV_HIP(ctx, D->ftiles.reserve(sizeof(EvalTile) * ftiles.size()));
+                PAV_HIP(ctx, hipMemcpyAsync(D->ftiles.p, ftiles.data(), sizeof(EvalTile) * ftiles.size(), hipMemcpyHostToDevice, st));
+                KA.tiles = D->ftiles.as<EvalTile>();
+                PAV_LAUNCH(ctx, "k_kde_eval", k_kde_eval, (uint32_t)ftiles.size(), 64, 0, KA);
+            }
+            if (processed) {                                           // rows queued earlier: scipy's order overrides the run sums
+                RA.first = 0; RA.kinds = 2;
+                PAV_LAUNCH(ctx, "k_redo", k_redo, processed, 64, 0, RA);
+            }
+            PAV_LAUNCH(ctx, "k_finalize", k_finalize, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_kde, D->kern[0].as<double>(),
+                       D->kern[1].as<double>(), D->kern[2].as<double>(), D->state.as<int8_t>(), D->win_fill.as<uint8_t>(), G,
+                       G.rel > 0.0 ? D->scratch.as<uint32_t>() : nullptr);
+            if (G.rel > 0.0)
+                PAV_LAUNCH(ctx, "k_spike_sum", k_spike_sum, n_jobs, 256, 0, d_jobs, d_kde, D->scratch.as<uint32_t>(), d_stat);
+            if (pass == 0) lap("kde");
+            // ---- rl_encoder: run heads -> host (readback 3, with the guard's counters) -----------------------------------
+            { const int rcg = read_guard(h_guard_pin); if (rcg != PAV_OK) return rcg; }
+            { const int rch = collect_heads(D->state.as<int8_t>(), ev, total_rows); if (rch != PAV_OK) return rch; }
+            if (!G.g) break;
+            memcpy(&h_guard, h_guard_pin, sizeof h_guard);
+            if (h_guard.overflow || h_guard.n_entries > G.cap) { overflow = true; break; }
+            if (h_guard.n_entries == processed) break;                 // nothing new was flagged: settled
+            // sampled sites flagged in this pass are evaluated in scipy's order; rows are applied behind the fill evaluation
+            RA.first = processed; RA.kinds = 1;
+            PAV_LAUNCH(ctx, "k_redo", k_redo, h_guard.n_entries - processed, 64, 0, RA);
+            processed = h_guard.n_entries;
         }
-        if (!ftiles.empty()) {
-            PAV_HIP(ctx, D->scratch.reserve(sizeof(EvalTile) * ftiles.size()));
-            PAV_HIP(ctx, hipMemcpyAsync(D->scratch.p, ftiles.data(), sizeof(EvalTile) * ftiles.size(), hipMemcpyHostToDevice, st));
-            KA.tiles = D->scratch.as<EvalTile>();
-            PAV_LAUNCH(ctx, "k_kde_eval", k_kde_eval, (uint32_t)ftiles.size(), 64, 0, KA);
-        }
-        PAV_LAUNCH(ctx, "k_finalize", k_finalize, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_kde, D->kern[0].as<double>(),
-                   D->kern[1].as<double>(), D->kern[2].as<double>(), D->state.as<int8_t>());
+        if (!overflow) break;
+        if (force_direct) return fail(ctx, PAV_E_STATE, "pav_density_batch: guard list overflow in direct mode");
+        fallback = true;
     }
-
-    lap("kde");
-    // ---- rl_encoder: run heads -> host assembly ------------------------------------------------------------------
-    std::vector<HeadEvent> ev;
-    {
-        int rc = collect_heads(D->state.as<int8_t>(), ev, total_rows);
-        if (rc != PAV_OK) return rc;
+    if (G.g) {                                                         // guard counters of every job
+        const int rcs = read_stats();
+        if (rcs != PAV_OK) return rcs;
+        for (uint32_t j = 0; j < n_jobs; ++j) {
+            pav_den_result &r = D->results[j];
+            r.n_near_tie = hs[j].n_near; r.n_reeval = hs[j].n_reeval; r.n_unresolved = hs[j].n_unres; r.n_spike_near = hs[j].n_spike;
+            r.guard_fallback = fallback ? 1 : 0;
+        }
+    }
+    if (tiles.empty()) {
+        const int rch = collect_heads(D->state.as<int8_t>(), ev, total_rows);
+        if (rch != PAV_OK) return rch;
     }
     for (size_t e = 0; e < ev.size(); ++e) {
         const HeadEvent &h = ev[e];

@@ -441,6 +441,7 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
             Scan &sc = scans[i];
             const pav_den_result &r = res[j];
             S->results[i].iterations = (uint32_t)sc.expansion_count;
+            S->results[i].n_near_tie += r.n_near_tie; S->results[i].n_unresolved += r.n_unresolved;
             // after the density call, inv.py:268-351
             if (r.status == PAV_DEN_FAIL) {
                 std::string stderr_text;

@@ -21,18 +21,20 @@ DENSITY_COLUMNS = ['INDEX', 'STATE_MER', 'STATE', 'KERN_FWD', 'KERN_FWDREV', 'KE
 
 def den_params(k=31, min_informative=DEFAULT_MIN_INFORMATIVE, min_state_count=DEFAULT_MIN_STATE_COUNT,
                den_smooth=DEFAULT_DENSITY_SMOOTH, state_run_delta=DEFAULT_STATE_RUN_DELTA,
-               max_ref_kmer_count=MAX_REF_KMER_COUNT, kde_mode=None, kmer_mode=None):
+               max_ref_kmer_count=MAX_REF_KMER_COUNT, kde_mode=None, kmer_mode=None, guard_rel=0.0, guard_cap=0):
     """``kde_mode``: ``_lib.KDE_RUNS`` (default; closed-form sums over runs of consecutive k-mers) or
     ``_lib.KDE_DIRECT`` (one exp per pair in scipy's accumulation order).  Env ``PAV_KDE_MODE=direct`` forces the latter.
     ``kmer_mode``: ``_lib.KMER_LDS`` (default; reference k-mer sets partitioned into LDS tables) or ``_lib.KMER_HBM``
-    (one hash table per region in HBM); same results.  Env ``PAV_KMER_HBM=1`` forces the latter inside the library."""
+    (one hash table per region in HBM); same results.  Env ``PAV_KMER_HBM=1`` forces the latter inside the library.
+    ``guard_rel``: near-tie guard of the float decisions (include/pav_amd.h): 0 = the default margin 1e-9, negative = off;
+    ``guard_cap``: capacity of its re-evaluation list (0 = default)."""
     if kde_mode is None:
         import os
         kde_mode = _lib.KDE_DIRECT if os.environ.get('PAV_KDE_MODE', '').lower() == 'direct' else _lib.KDE_RUNS
     if kmer_mode is None:
         kmer_mode = _lib.KMER_LDS
     return _lib.DenParams(int(k), int(min_informative), int(min_state_count), float(den_smooth), float(state_run_delta),
-                          int(max_ref_kmer_count), int(kde_mode), int(kmer_mode), 0)
+                          int(max_ref_kmer_count), int(kde_mode), int(kmer_mode), int(guard_cap), float(guard_rel))
 
 
 def table_frame(cols, finalised=True, extra=None):

@@ -1,15 +1,23 @@
 """
-Large alignment-truncating variants: mirror of ``pavlib.lgsv.scan_for_events`` (pavlib/lgsv.py:31-642; rule
-``call_lg_discover``, rules/call_lg.snakefile:40-104).
+Large alignment-truncating variants - the interface of ``pavlib.lgsv.scan_for_events`` (pavlib/lgsv.py:31-642; rule
+``call_lg_discover``, rules/call_lg.snakefile:40-104) for this package.
 
-The control flow over (chromosome, contig) pairs with several alignment records is the reference's; what ran as Python
-per-base loops and subprocesses runs on the GPU: the breakpoint homology of every INS / DEL (``pav_homology``, one batched
-call for all events of the table: the event list does not depend on the homology values, see ``match_bp`` below) and the
-inversion scans (``pav_amd.inv.scan_for_inv``).  Sequences are uploaded once per context instead of the reference's
-per-call whole-chromosome ``SeqCache`` reloads (lgsv.py:645-695).
+How it is organised here
+  * the alignment table is split once into per-(chromosome, contig) column arrays (``_Group``); the partner search of every
+    record walks those arrays instead of re-indexing the DataFrame per step;
+  * a candidate pair is described by a ``_Gap`` (the unaligned interval between two same-strand records on both axes) which
+    classifies itself as DEL / INS / INV-candidate / nothing;
+  * INS / DEL rows are collected column-wise by ``_Events`` together with four breakpoint-homology queries each, and all
+    queries of the table go to the GPU in ONE ``pav_homology`` call after the walk - possible because the event list does
+    not depend on the homology values (``match_bp`` below);
+  * inversion candidates go through ``pav_amd.inv.scan_for_inv`` (k-mer density scan on the GPU); sequences are resident
+    once per context instead of the reference's whole-chromosome ``SeqCache`` (pavlib/lgsv.py:645-695).
+
+What must stay as the reference has it (tests/golden/lgsv_hap is the reference's own output): the order in which partners are
+tried, including the step of two after a same-strand pair that yields nothing (pavlib/lgsv.py:434-437 and :556-557 both
+advance), the distance-proportion filter (:160-170), the three RuntimeError texts, the log lines, the columns.
 """
 
-import collections
 import os
 import sys
 
@@ -23,6 +31,7 @@ from .kmer import KmerUtil
 MAX_QRY_DIST_PROP = 1       # lgsv.py:18
 MAX_REF_DIST_PROP = 3       # lgsv.py:19
 DIST_PROP_LEN_MAPQ = (20000, 40)   # lgsv.py:21
+MIN_SV = 50                 # both axes: a gap of at least this many bases is an event (lgsv.py:173, 261, 351)
 CALL_SOURCE = 'ALNTRUNC'
 CALL_SOURCE_INV_DENSITY = 'ALNTRUNC-DEN'
 CALL_SOURCE_INV_NO_DENSITY = 'ALNTRUNC-NODEN'
@@ -31,6 +40,9 @@ INSDEL_COLUMNS = ['#CHROM', 'POS', 'END', 'ID', 'SVTYPE', 'SVLEN', 'HAP', 'QRY_R
                   'HOM_REF', 'HOM_TIG', 'CALL_SOURCE', 'FILTER', 'SEQ']
 INV_COLUMNS = ['#CHROM', 'POS', 'END', 'ID', 'SVTYPE', 'SVLEN', 'HAP', 'QRY_REGION', 'QRY_STRAND', 'CI', 'RGN_REF_INNER', 'RGN_QRY_INNER',
                'RGN_REF_DISC', 'RGN_QRY_DISC', 'FLAG_ID', 'FLAG_TYPE', 'ALIGN_INDEX', 'CALL_SOURCE', 'FILTER', 'SEQ']
+_HOM_COL, _HOM_TIG_COL = INSDEL_COLUMNS.index('HOM_REF'), INSDEL_COLUMNS.index('HOM_TIG')
+_REF, _TIG = _lib.PAV_ROLE_REF, _lib.PAV_ROLE_TIG
+_LEFT, _RIGHT = 0, 1        # pav_hom_query.dir
 
 
 def match_bp(record, right_end):
@@ -41,21 +53,157 @@ def match_bp(record, right_end):
     return 0
 
 
-def _overlap_error(row1, row2):
-    return RuntimeError(
-        'Contig ranges overlap for two alignment records (should not occur after alignment trimming): '
-        f'Index {row1["INDEX"]} ({row1["QRY_ID"]}:{row1["QRY_POS"]}-{row1["QRY_END"]}) and '
-        f'Index {row2["INDEX"]} ({row2["QRY_ID"]}:{row2["QRY_POS"]}-{row2["QRY_END"]})')
+class _Group:
+    """The records of one (chromosome, contig) pair in table order, as column arrays."""
+
+    def __init__(self, df, rows, chrom, tig_id):
+        self.chrom, self.tig_id, self.n = chrom, tig_id, len(rows)
+        take = lambda col: df[col].to_numpy()[rows]            # noqa: E731
+        self.pos, self.end = take('POS'), take('END')
+        self.qpos, self.qend = take('QRY_POS'), take('QRY_END')
+        self.rev, self.mapq, self.index = take('REV'), take('MAPQ'), take('INDEX')
+        self.span = self.end - self.pos                        # what the reference keeps in its QRY_LEN column (lgsv.py:70)
+
+    def label(self, i):
+        return f'Index {self.index[i]} ({self.tig_id}:{self.qpos[i]}-{self.qend[i]})'
+
+    def index_list(self, *members):
+        return ','.join(str(self.index[i]) for i in members)
 
 
-def _inv_series(inv_call, hap, is_rev, align_index, call_source, tig_fa_name):
-    seq_str = seq.region_seq_fasta(inv_call.region_tig_outer, tig_fa_name, rev_compl=is_rev)
-    return pd.Series([
-        inv_call.region_ref_outer.chrom, inv_call.region_ref_outer.pos, inv_call.region_ref_outer.end, inv_call.id, 'INV', inv_call.svlen,
-        hap, inv_call.region_tig_outer.to_base1_string(), '-' if is_rev else '+', 0,
-        inv_call.region_ref_inner.to_base1_string(), inv_call.region_tig_inner.to_base1_string(),
-        inv_call.region_ref_discovery.to_base1_string(), inv_call.region_tig_discovery.to_base1_string(),
-        inv_call.region_flag.region_id(), 'ALNTRUNC', align_index, call_source, 'PASS', seq_str], index=INV_COLUMNS)
+def _groups(df):
+    """(chromosome, contig) pairs with more than one record, in order of first appearance (lgsv.py:89-90)."""
+    if df.shape[0] == 0:
+        return
+    by_pair = df.groupby(['#CHROM', 'QRY_ID'], sort=False).indices
+    for (chrom, tig_id), rows in by_pair.items():
+        if len(rows) > 1:
+            yield _Group(df, np.sort(rows), chrom, tig_id)
+
+
+class _Gap:
+    """What lies between record ``a`` and a later record ``b`` of the same strand: ``[q0, q1)`` on the contig (whichever of
+    the two comes first there), ``dist_ref`` bases on the reference."""
+
+    def __init__(self, g, a, b):
+        first, second = (a, b) if g.qpos[a] < g.qpos[b] else (b, a)
+        if g.qpos[second] < g.qend[first]:
+            raise RuntimeError('Contig ranges overlap for two alignment records (should not occur after alignment trimming): '
+                               f'{g.label(a)} and {g.label(b)}')
+        self.q0, self.q1 = g.qend[first], g.qpos[second]
+        self.dist_tig = self.q1 - self.q0
+        self.dist_ref = g.pos[b] - g.end[a]
+        if self.dist_tig < 0:
+            raise RuntimeError('Contig query positions are out of order (program bug): Contig distance is negative '
+                               f'({self.dist_tig}): {g.label(a)} and {g.label(b)}')
+        self.shortest = np.min([g.span[a], g.span[b]])
+        self.weakest = np.min([g.mapq[a], g.mapq[b]])
+
+    def too_far(self, max_tig_prop, max_ref_prop):
+        """Short or poorly mapped flanks do not support a gap that is large relative to them (lgsv.py:160-170)."""
+        if self.shortest >= DIST_PROP_LEN_MAPQ[0] and self.weakest >= DIST_PROP_LEN_MAPQ[1]:
+            return False
+        return bool(np.abs(self.dist_tig) / self.shortest > max_tig_prop or np.abs(self.dist_ref) / self.shortest > max_ref_prop)
+
+    def kind(self):
+        big_ref, big_tig = bool(self.dist_ref >= MIN_SV), bool(self.dist_tig >= MIN_SV)
+        return {(True, False): 'DEL', (False, True): 'INS', (True, True): 'INV'}.get((big_ref, big_tig))
+
+
+class _Events:
+    """INS / DEL rows (their two homology columns are filled in by ``resolve``) and INV rows of one table."""
+
+    def __init__(self, ctx, hap, log, ref_fa_name, tig_fa_name, density_out_dir):
+        self.ctx, self.hap, self.log = ctx, hap, log
+        self.ref_fa_name, self.tig_fa_name, self.density_out_dir = ref_fa_name, tig_fa_name, density_out_dir
+        self.ref_id, self.tig_id = inv._seq_index(ctx)
+        self.rows = {'INS': [], 'DEL': []}
+        self.order = []                                        # (svtype, row) per event, the order of their homology queries
+        self.queries = []
+        self.inv_rows = []
+        self.inv_seen = set()                                  # the same inversion can be reached from several gaps
+
+    def say(self, what, item):
+        self.log.write(f'{what}: {item}\n')
+        self.log.flush()
+
+    def _query(self, where, pos, sv, direction):
+        """Scan ``where`` = (role, record, oriented reverse?) from ``pos`` against the SV sequence ``sv`` = (role, record,
+        oriented reverse?, start on the oriented record, length)."""
+        ids = (self.ref_id, self.tig_id)
+        self.queries.append((where[0], ids[where[0]][where[1]], int(bool(where[2])), 0, int(pos),
+                             sv[0], ids[sv[0]][sv[1]], int(bool(sv[2])), 0, int(sv[3]), int(sv[4]), direction))
+
+    def _indel(self, svtype, g, a, b, fields, ref_scan, tig_scan, sv):
+        self.say(svtype, fields[3])
+        on_ref, on_tig = (_REF, g.chrom, False), (_TIG, g.tig_id, g.rev[a])
+        self._query(on_ref, ref_scan[0], sv, _LEFT)
+        self._query(on_ref, ref_scan[1], sv, _RIGHT)
+        self._query(on_tig, tig_scan[0], sv, _LEFT)            # contig coordinates as given, on the oriented contig
+        self._query(on_tig, tig_scan[1], sv, _RIGHT)           # (pavlib/lgsv.py:237-238, 309-310)
+        self.order.append(svtype)
+        self.rows[svtype].append(fields)
+
+    def deletion(self, g, a, b, gap):
+        start, stop, at = g.end[a], g.pos[b], gap.q0
+        shift = np.min([match_bp(None, True), 0])              # always 0: nothing is moved (see match_bp)
+        bases = seq.region_seq_fasta(seq.Region(g.chrom, start, stop), self.ref_fa_name)
+        fields = [g.chrom, start, stop, f'{g.chrom}-{start}-DEL-{gap.dist_ref}', 'DEL', gap.dist_ref, self.hap,
+                  f'{g.tig_id}:{at + 1}-{at + 1}', '-' if g.rev[a] else '+', gap.dist_tig, g.index_list(a, b), shift, None, None,
+                  CALL_SOURCE, 'PASS', bases]
+        self._indel('DEL', g, a, b, fields, (start - 1, stop), (at - 1, at), (_REF, g.chrom, False, start, gap.dist_ref))
+
+    def insertion(self, g, a, b, gap, tig_len):
+        at = g.end[a]
+        rev = g.rev[a]
+        where = seq.Region(g.tig_id, gap.q0, gap.q1, is_rev=rev)
+        shift = np.min([match_bp(None, True), 0])
+        bases = seq.region_seq_fasta(where, self.tig_fa_name, rev_compl=rev)
+        fields = [g.chrom, at, at + 1, f'{g.chrom}-{at}-INS-{gap.dist_tig}', 'INS', gap.dist_tig, self.hap, where.to_base1_string(),
+                  '-' if rev else '+', gap.dist_ref, g.index_list(a, b), shift, None, None, CALL_SOURCE, 'PASS', bases]
+        # the inserted bases in alignment orientation: contig[q0:q1], read from the other end when the record is reverse
+        sv_start = tig_len - int(gap.q1) if rev else int(gap.q0)
+        self._indel('INS', g, a, b, fields, (at - 1, at), (gap.q0 - 1, gap.q1), (_TIG, g.tig_id, bool(rev), sv_start, gap.dist_tig))
+
+    def inversion(self, label, call, g, members, source):
+        """Record ``call`` unless it was seen before.  Returns True when it was recorded."""
+        if call is None or call.id in self.inv_seen:
+            return False
+        self.inv_seen.add(call.id)
+        self.say(label, call)
+        rev = g.rev[members[0]]
+        outer = call.region_tig_outer
+        self.inv_rows.append([
+            call.region_ref_outer.chrom, call.region_ref_outer.pos, call.region_ref_outer.end, call.id, 'INV', call.svlen, self.hap,
+            outer.to_base1_string(), '-' if rev else '+', 0, call.region_ref_inner.to_base1_string(),
+            call.region_tig_inner.to_base1_string(), call.region_ref_discovery.to_base1_string(),
+            call.region_tig_discovery.to_base1_string(), call.region_flag.region_id(), 'ALNTRUNC', g.index_list(*members), source,
+            'PASS', seq.region_seq_fasta(outer, self.tig_fa_name, rev_compl=rev)])
+        if self.density_out_dir is not None and call.df is not None:
+            call.df.to_csv(os.path.join(self.density_out_dir, f'density_{call.id}_{self.hap}.tsv.gz'), sep='\t', index=False,
+                           compression='gzip')
+        return True
+
+    def resolve(self):
+        """One device call for the breakpoint homology of every INS / DEL, then the three tables."""
+        if self.queries:
+            q = np.array(self.queries, dtype=_lib.HOM_QUERY_DTYPE)
+            hom = self.ctx.homology(q).reshape(-1, 4)
+            cursor = {'INS': 0, 'DEL': 0}
+            for svtype, (ref_l, ref_r, tig_l, tig_r) in zip(self.order, hom):
+                row = self.rows[svtype][cursor[svtype]]
+                cursor[svtype] += 1
+                row[_HOM_COL], row[_HOM_TIG_COL] = f'{int(ref_l)},{int(ref_r)}', f'{int(tig_l)},{int(tig_r)}'
+        return _table(self.rows['INS'], INSDEL_COLUMNS), _table(self.rows['DEL'], INSDEL_COLUMNS), _table(self.inv_rows, INV_COLUMNS)
+
+
+def _table(rows, columns):
+    """All-object frame in the reference's sort order (pd.concat(...).T of Series gives object columns, lgsv.py:561-636)."""
+    if not rows:
+        return pd.DataFrame([], columns=columns)
+    out = pd.DataFrame({c: pd.Series([r[i] for r in rows], dtype=object) for i, c in enumerate(columns)}, columns=columns)
+    out.sort_values(['#CHROM', 'POS', 'END', 'ID'], inplace=True)
+    return out
 
 
 def scan_for_events(df, df_tig_fai, hap, ref_fa_name, tig_fa_name, k_size, n_tree=None, threads=1, log=sys.stdout,
@@ -65,192 +213,72 @@ def scan_for_events(df, df_tig_fai, hap, ref_fa_name, tig_fa_name, k_size, n_tre
     if version_id:
         raise NotImplementedError('version_id=True needs svpoplib.variant.version_id (un-vendored submodule); '
                                   'rule call_lg_discover passes version_id=False (call_lg.snakefile:98)')
-    max_tig_dist_prop = max_tig_dist_prop if max_tig_dist_prop is not None else MAX_QRY_DIST_PROP
-    max_ref_dist_prop = max_ref_dist_prop if max_ref_dist_prop is not None else MAX_REF_DIST_PROP
-
-    df = df.copy()
-    df['QRY_LEN'] = df['END'] - df['POS']                                 # lgsv.py:70 (the column is reused for the reference span)
+    if max_tig_dist_prop is None:
+        max_tig_dist_prop = MAX_QRY_DIST_PROP
+    if max_ref_dist_prop is None:
+        max_ref_dist_prop = MAX_REF_DIST_PROP
 
     own = ctx is None
     if own:
         ctx = _lib.Context(device_id)
     try:
         inv.ensure_sequences(ctx, ref_fa_name, tig_fa_name)
-        ref_index, tig_index = inv._seq_index(ctx)
-        align_lift = AlignLift(df, df_tig_fai)
+        lift_table = df.assign(QRY_LEN=df['END'] - df['POS'])      # the table AlignLift sees in the reference (lgsv.py:70-73)
+        align_lift = AlignLift(lift_table, df_tig_fai)
         k_util = KmerUtil(k_size)
+        events = _Events(ctx, hap, log, ref_fa_name, tig_fa_name, density_out_dir)
 
-        events = []                    # INS / DEL: dict of row fields; homology filled in after the loop
-        queries = []                   # four pav_hom_query per event
-        inv_list = []
-        inv_id_set = set()
+        def try_inversion(g, left, right):
+            flagged = seq.Region(g.chrom, g.end[left], g.pos[right], is_rev=g.rev[left])
+            return inv.scan_for_inv(flagged, ref_fa_name, tig_fa_name, align_lift, k_util, max_region_size=max_region_size,
+                                    threads=threads, n_tree=n_tree, srs_tree=srs_tree, log=log, min_exp_count=1, ctx=ctx)
 
-        def hom(role, name, rev, pos, sv_role, sv_name, sv_rev, sv_pos, svlen, direction):
-            names = ref_index if role == _lib.PAV_ROLE_REF else tig_index
-            sv_names = ref_index if sv_role == _lib.PAV_ROLE_REF else tig_index
-            queries.append((role, names[name], 1 if rev else 0, 0, pos, sv_role, sv_names[sv_name], 1 if sv_rev else 0, 0, sv_pos, svlen, direction))
+        def same_strand(g, a, b):
+            """Returns how far the partner index moves on; 0 = record ``a`` is done."""
+            gap = _Gap(g, a, b)
+            if gap.too_far(max_tig_dist_prop, max_ref_dist_prop):
+                return 1
+            kind = gap.kind()
+            if kind == 'DEL':
+                events.deletion(g, a, b, gap)
+                return 0
+            if kind == 'INS':
+                events.insertion(g, a, b, gap, int(df_tig_fai[g.tig_id]))
+                return 0
+            if kind == 'INV' and events.inversion('INV (2-tig)', try_inversion(g, a, b), g, (a, b), CALL_SOURCE_INV_DENSITY):
+                return 0
+            return 2                                               # nothing called: the reference advances twice here
 
-        tig_map_count = collections.Counter(df[['#CHROM', 'QRY_ID']].apply(tuple, axis=1)) if df.shape[0] else {}
-        tig_map_count = [(chrom, tig_id) for (chrom, tig_id), count in tig_map_count.items() if count > 1]
+        def flanked(g, a, b, c):
+            """``b`` is on the other strand: an inversion if ``c`` continues ``a`` and ``b`` lies between them on the contig."""
+            if g.rev[c] != g.rev[a]:
+                return 1
+            mid = (g.qpos[b] + g.qend[b]) // 2
+            between = (g.qpos[c] < mid < g.qend[a]) if g.rev[a] else (g.qend[a] < mid < g.qpos[c])
+            if not between:
+                return 1
+            call, source = try_inversion(g, a, c), CALL_SOURCE_INV_DENSITY
+            if call is None and (b, c) == (a + 1, a + 2):
+                # three consecutive records and no density support: the middle record itself is the call (lgsv.py:478-497)
+                on_ref = seq.Region(g.chrom, g.pos[b], g.end[b])
+                on_tig = seq.Region(g.tig_id, g.qpos[b], g.qend[b])
+                call, source = inv.InvCall(on_ref, on_ref, on_tig, on_tig, on_ref, on_tig, on_ref, None), CALL_SOURCE_INV_NO_DENSITY
+            return 0 if events.inversion('INV (3-tig)', call, g, (a, b, c), source) else 1
 
-        for chrom, tig_id in tig_map_count:
-            tig_index_list = list(df.loc[(df['#CHROM'] == chrom) & (df['QRY_ID'] == tig_id)].index)
-            tig_index_list_len = len(tig_index_list)
-            tig_len = int(df_tig_fai[tig_id])
-
-            for subindex1 in range(len(tig_index_list) - 1):
-                subindex2 = subindex1 + 1
-                row1 = df.loc[tig_index_list[subindex1]]
-                is_rev = row1['REV']
-
-                while subindex2 < tig_index_list_len:
-                    row2 = df.loc[tig_index_list[subindex2]]
-
-                    if row2['REV'] == is_rev:
-                        # INS / DEL / 2-record INV (lgsv.py:116-437)
-                        if row1['QRY_POS'] < row2['QRY_POS']:
-                            if row2['QRY_POS'] < row1['QRY_END']:
-                                raise _overlap_error(row1, row2)
-                            query_pos, query_end = row1['QRY_END'], row2['QRY_POS']
-                        else:
-                            if row1['QRY_POS'] < row2['QRY_END']:
-                                raise _overlap_error(row1, row2)
-                            query_pos, query_end = row2['QRY_END'], row1['QRY_POS']
-
-                        dist_tig = query_end - query_pos
-                        dist_ref = row2['POS'] - row1['END']
-                        if dist_tig < 0:
-                            raise RuntimeError(
-                                f'Contig query positions are out of order (program bug): Contig distance is negative ({dist_tig}): '
-                                f'Index {row1["INDEX"]} ({row1["QRY_ID"]}:{row1["QRY_POS"]}-{row1["QRY_END"]}) and '
-                                f'Index {row2["INDEX"]} ({row2["QRY_ID"]}:{row2["QRY_POS"]}-{row2["QRY_END"]})')
-
-                        min_aln_len = np.min([row1['QRY_LEN'], row2['QRY_LEN']])
-                        min_mapq = np.min([row1['MAPQ'], row2['MAPQ']])
-                        if min_aln_len < DIST_PROP_LEN_MAPQ[0] or min_mapq < DIST_PROP_LEN_MAPQ[1]:
-                            if (np.abs(dist_tig) / min_aln_len > max_tig_dist_prop) or (np.abs(dist_ref) / min_aln_len > max_ref_dist_prop):
-                                subindex2 += 1
-                                continue
-
-                        if dist_ref >= 50 and dist_tig < 50:
-                            # DEL (lgsv.py:173-258)
-                            svlen = dist_ref
-                            pos_ref, end_ref = row1['END'], row2['POS']
-                            pos_tig = query_pos
-                            end_tig = pos_tig + 1
-                            left_shift = np.min([match_bp(row1, True), 0])          # see match_bp: always 0, nothing moves
-                            seq_str = seq.region_seq_fasta(seq.Region(chrom, pos_ref, end_ref), ref_fa_name)
-                            sv_id = '{}-{}-DEL-{}'.format(chrom, pos_ref, svlen)
-                            log.write('DEL: {}\n'.format(sv_id))
-                            log.flush()
-                            R, T = _lib.PAV_ROLE_REF, _lib.PAV_ROLE_TIG
-                            sv = (R, chrom, False, int(pos_ref), int(svlen))
-                            hom(R, chrom, False, int(pos_ref) - 1, *sv, 0)
-                            hom(R, chrom, False, int(end_ref), *sv, 1)
-                            hom(T, tig_id, is_rev, int(pos_tig) - 1, *sv, 0)
-                            hom(T, tig_id, is_rev, int(pos_tig), *sv, 1)
-                            events.append(('DEL', [chrom, pos_ref, end_ref, sv_id, 'DEL', svlen, hap, f'{tig_id}:{pos_tig + 1}-{end_tig}',
-                                                   '-' if row1['REV'] else '+', dist_tig, '{},{}'.format(row1['INDEX'], row2['INDEX']),
-                                                   left_shift, None, None, CALL_SOURCE, 'PASS', seq_str]))
-                            break
-
-                        elif dist_ref < 50 and dist_tig >= 50:
-                            # INS (lgsv.py:261-348)
-                            pos_ref = row1['END']
-                            end_ref = pos_ref + 1
-                            pos_tig, end_tig = query_pos, query_end
-                            svlen = dist_tig
-                            tig_region = seq.Region(tig_id, pos_tig, end_tig, is_rev=is_rev)
-                            seq_str = seq.region_seq_fasta(tig_region, tig_fa_name, rev_compl=is_rev)
-                            left_shift = np.min([match_bp(row1, True), 0])
-                            sv_id = '{}-{}-INS-{}'.format(chrom, pos_ref, svlen)
-                            log.write('INS: {}\n'.format(sv_id))
-                            log.flush()
-                            R, T = _lib.PAV_ROLE_REF, _lib.PAV_ROLE_TIG
-                            # the SV sequence is contig[pos_tig:end_tig], reverse-complemented with the alignment
-                            sv = (T, tig_id, bool(is_rev), (tig_len - int(end_tig)) if is_rev else int(pos_tig), int(svlen))
-                            hom(R, chrom, False, int(pos_ref) - 1, *sv, 0)
-                            hom(R, chrom, False, int(pos_ref), *sv, 1)
-                            hom(T, tig_id, is_rev, int(pos_tig) - 1, *sv, 0)       # contig coordinates on the oriented contig, as lgsv.py:309-310
-                            hom(T, tig_id, is_rev, int(end_tig), *sv, 1)
-                            events.append(('INS', [chrom, pos_ref, end_ref, sv_id, 'INS', svlen, hap, tig_region.to_base1_string(),
-                                                   '-' if is_rev else '+', dist_ref, '{},{}'.format(row1['INDEX'], row2['INDEX']),
-                                                   left_shift, None, None, CALL_SOURCE, 'PASS', seq_str]))
-                            break
-
-                        elif dist_ref >= 50 and dist_tig >= 50:
-                            # INV from two records (lgsv.py:351-434)
-                            region_flag = seq.Region(chrom, row1['END'], row2['POS'], is_rev=row1['REV'])
-                            inv_call = inv.scan_for_inv(region_flag, ref_fa_name, tig_fa_name, align_lift, k_util,
-                                                        max_region_size=max_region_size, threads=threads, n_tree=n_tree, srs_tree=srs_tree,
-                                                        log=log, min_exp_count=1, ctx=ctx)
-                            if inv_call is not None and inv_call.id not in inv_id_set:
-                                log.write('INV (2-tig): {}\n'.format(inv_call))
-                                log.flush()
-                                inv_list.append(_inv_series(inv_call, hap, is_rev, '{},{}'.format(row1['INDEX'], row2['INDEX']),
-                                                            CALL_SOURCE_INV_DENSITY, tig_fa_name))
-                                inv_id_set.add(inv_call.id)
-                                if density_out_dir is not None:
-                                    inv_call.df.to_csv(os.path.join(density_out_dir, 'density_{}_{}.tsv.gz'.format(inv_call.id, hap)),
-                                                       sep='\t', index=False, compression='gzip')
-                                break
-
-                        subindex2 += 1
-
-                    elif subindex2 + 1 < tig_index_list_len:
-                        # INV from three records, middle one on the other strand (lgsv.py:440-558)
-                        subindex3 = subindex2 + 1
-                        row3 = df.loc[tig_index_list[subindex3]]
-                        mid = (row2['QRY_POS'] + row2['QRY_END']) // 2
-                        if (row3['REV'] == row1['REV']) and (
-                            (not row1['REV'] and (row1['QRY_END'] < mid < row3['QRY_POS'])) or
-                            (row1['REV'] and (row3['QRY_POS'] < mid < row1['QRY_END']))
-                        ):
-                            region_flag = seq.Region(chrom, row1['END'], row3['POS'], is_rev=row1['REV'])
-                            inv_call = inv.scan_for_inv(region_flag, ref_fa_name, tig_fa_name, align_lift, k_util,
-                                                        max_region_size=max_region_size, threads=threads, n_tree=n_tree, srs_tree=srs_tree,
-                                                        log=log, min_exp_count=1, ctx=ctx)
-                            if inv_call is None and subindex2 == subindex1 + 1 and subindex3 == subindex1 + 2:
-                                region_ref = seq.Region(chrom, row2['POS'], row2['END'])
-                                region_tig = seq.Region(row2['QRY_ID'], row2['QRY_POS'], row2['QRY_END'])
-                                inv_call = inv.InvCall(region_ref, region_ref, region_tig, region_tig, region_ref, region_tig, region_ref, None)
-                                call_source = CALL_SOURCE_INV_NO_DENSITY
-                            else:
-                                call_source = CALL_SOURCE_INV_DENSITY
-                            if inv_call is not None and inv_call.id not in inv_id_set:
-                                log.write('INV (3-tig): {}\n'.format(inv_call))
-                                log.flush()
-                                inv_list.append(_inv_series(inv_call, hap, is_rev,
-                                                            '{},{},{}'.format(row1['INDEX'], row2['INDEX'], row3['INDEX']), call_source,
-                                                            tig_fa_name))
-                                inv_id_set.add(inv_call.id)
-                                if density_out_dir is not None and inv_call.df is not None:
-                                    inv_call.df.to_csv(os.path.join(density_out_dir, 'density_{}_{}.tsv.gz'.format(inv_call.id, hap)),
-                                                       sep='\t', index=False, compression='gzip')
-                                break
-
-                    subindex2 += 1
-
-        # breakpoint homology of all INS / DEL in one device call
-        if queries:
-            q = np.zeros(len(queries), dtype=_lib.HOM_QUERY_DTYPE)
-            for i, rec in enumerate(queries):
-                q[i] = rec
-            h = ctx.homology(q)
-        ins_list, del_list = [], []
-        for e, (kind, fields) in enumerate(events):
-            fields[12] = '{},{}'.format(int(h[4 * e]), int(h[4 * e + 1]))
-            fields[13] = '{},{}'.format(int(h[4 * e + 2]), int(h[4 * e + 3]))
-            (ins_list if kind == 'INS' else del_list).append(pd.Series(fields, index=INSDEL_COLUMNS))
+        for g in _groups(df):
+            for a in range(g.n - 1):
+                b = a + 1
+                while b < g.n:
+                    if g.rev[b] == g.rev[a]:
+                        step = same_strand(g, a, b)
+                    elif b + 1 < g.n:
+                        step = flanked(g, a, b, b + 1)
+                    else:
+                        step = 1
+                    if not step:
+                        break
+                    b += step
+        return events.resolve()
     finally:
         if own:
             ctx.close()
-
-    def table(rows, columns):
-        if len(rows) > 0:
-            out = pd.concat(rows, axis=1).T
-            out.sort_values(['#CHROM', 'POS', 'END', 'ID'], inplace=True)
-            return out
-        return pd.DataFrame([], columns=columns)
-
-    return table(ins_list, INSDEL_COLUMNS), table(del_list, INSDEL_COLUMNS), table(inv_list, INV_COLUMNS)

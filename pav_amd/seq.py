@@ -1,8 +1,15 @@
 """
-Regions and FASTA region access - host mirror of the parts of ``pavlib/seq.py`` the inversion path calls
-(``Region`` :20-258, ``region_from_string`` :260-285, ``region_from_id`` :288-302, ``region_seq_fasta`` :328-360).
-Same coordinates, same string forms, same quirks (``region_id()`` is 0-based while ``region_from_id()`` assumes a
-1-based ID: pavlib/seq.py:110,302).
+Regions and FASTA region access on the host - the interface of the parts of ``pavlib/seq.py`` the inversion path calls
+(``Region`` :20-258, ``region_from_string`` :260-285, ``region_from_id`` :288-302, ``region_seq_fasta`` :328-360), written
+for this package: coordinates are plain Python integers, expansion is interval arithmetic on a (lo, hi) pair, sequences are
+byte arrays from the native FASTA reader.
+
+Behaviour that callers (and the golden vectors, tests/golden/region_kat.json) depend on and that is therefore kept:
+  * a region given with pos > end is stored swapped, marked reverse, and its uncertainty bounds end up crossed
+    (pavlib/seq.py:54-66);
+  * ``expand`` only honours ``max_end`` when it is a pandas Series holding the chromosome (pavlib/seq.py:157-162);
+  * ``region_id()`` prints the 0-based start while ``region_from_id()`` reads the number as 1-based (:110, :302);
+  * ``to_bed_string()`` prints ``pos + 1`` (:92-96).
 """
 
 import re
@@ -12,133 +19,145 @@ import pandas as pd
 
 from .fasta import open_fasta
 
+# IUPAC complement table for byte arrays (Bio.Seq.reverse_complement semantics: case kept, U -> A, others unchanged)
 _COMP = np.arange(256, dtype=np.uint8)
-for _a, _b in zip(b'ACGTRYSWKMBDHVNUacgtryswkmbdhvnu', b'TGCAYRSWMKVHDBNAtgcayrswmkvhdbna'):
-    _COMP[_a] = _b
+_COMP[list(b'ACGTRYSWKMBDHVNUacgtryswkmbdhvnu')] = list(b'TGCAYRSWMKVHDBNAtgcayrswmkvhdbna')
+
+_REGION_TEXT = re.compile(r'(?P<chrom>[^:]+):(?P<first>\d+)-(?P<last>\d+)$')
+_ITEM_KEYS = ('chrom', 'pos', 'pos1', 'end')
+
+
+def _bound(value, default):
+    return default if value is None else int(value)
 
 
 class Region:
-    """0-based half-open region (BED) with orientation flag and optional alignment-record indexes."""
+    """Half-open interval ``[pos, end)`` on ``chrom`` (BED coordinates) with an orientation flag, optional
+    uncertainty bounds for both ends, and the alignment-record indexes the ends were lifted through."""
 
     def __init__(self, chrom, pos, end, is_rev=None, pos_min=None, pos_max=None, end_min=None, end_max=None,
                  pos_aln_index=None, end_aln_index=None):
+        lo, hi = int(pos), int(end)
+        flipped = lo > hi
+        if flipped:
+            # Stored in ascending order.  The bounds follow the reference's bookkeeping: each end's bounds come from the
+            # arguments of the *other* end and default to the other end's coordinate.
+            lo, hi = hi, lo
+            pos_min, pos_max, end_min, end_max = end_min, end_max, pos_min, pos_max
+            pos_aln_index, end_aln_index = end_aln_index, pos_aln_index
         self.chrom = str(chrom)
-        self.pos = int(pos)
-        self.end = int(end)
-        self.pos_min = self.pos if pos_min is None else int(pos_min)
-        self.pos_max = self.pos if pos_max is None else int(pos_max)
-        self.end_min = self.end if end_min is None else int(end_min)
-        self.end_max = self.end if end_max is None else int(end_max)
-        self.pos_aln_index = pos_aln_index
-        self.end_aln_index = end_aln_index
-        if self.pos > self.end:                       # reversed coordinates: swap and mark reverse (seq.py:54-70)
-            self.pos, self.end = self.end, self.pos
-            self.end_min = self.pos if pos_min is None else int(pos_min)
-            self.end_max = self.pos if pos_max is None else int(pos_max)
-            self.pos_min = self.end if end_min is None else int(end_min)
-            self.pos_max = self.end if end_max is None else int(end_max)
-            self.pos_aln_index, self.end_aln_index = self.end_aln_index, self.pos_aln_index
-            if is_rev is None:
-                is_rev = True
-        self.is_rev = False if is_rev is None else is_rev
+        self.pos, self.end = lo, hi
+        near, far = (hi, lo) if flipped else (lo, hi)
+        self.pos_min, self.pos_max = _bound(pos_min, near), _bound(pos_max, near)
+        self.end_min, self.end_max = _bound(end_min, far), _bound(end_max, far)
+        self.pos_aln_index, self.end_aln_index = pos_aln_index, end_aln_index
+        self.is_rev = flipped if is_rev is None else is_rev
 
-    def __repr__(self):
-        return self.to_base1_string()
-
+    # ---- text forms -----------------------------------------------------------------------------------------
     def to_base1_string(self):
-        return '{}:{}-{}'.format(self.chrom, self.pos + 1, self.end)
+        """``chrom:first-last``, 1-based closed (samtools / browser notation)."""
+        return f'{self.chrom}:{self.pos + 1}-{self.end}'
+
+    __repr__ = to_base1_string
 
     def to_bed_string(self):
-        return '{}\t{}\t{}'.format(self.chrom, self.pos + 1, self.end)     # sic (seq.py:92-96)
+        return '\t'.join((self.chrom, str(self.pos + 1), str(self.end)))
 
+    def region_id(self):
+        return f'{self.chrom}-{self.pos}-RGN-{len(self)}'
+
+    # ---- container protocol ---------------------------------------------------------------------------------
     def __len__(self):
         return self.end - self.pos
 
-    def region_id(self):
-        return '{}-{}-RGN-{}'.format(self.chrom, self.pos, self.end - self.pos)
+    def __getitem__(self, key):
+        if key not in _ITEM_KEYS:
+            raise IndexError('No key in Region: {}'.format(key))
+        return self.pos + 1 if key == 'pos1' else getattr(self, key)
 
+    def _key(self):
+        return self.chrom, self.pos, self.end
+
+    def __eq__(self, other):
+        return self._key() == (other.chrom, other.pos, other.end)
+
+    def __lt__(self, other):
+        return self._key() < (other.chrom, other.pos, other.end)
+
+    __hash__ = None
+
+    def copy(self):
+        return Region(*self._key(), self.is_rev, self.pos_min, self.pos_max, self.end_min, self.end_max)
+
+    # ---- expansion --------------------------------------------------------------------------------------------
     def expand(self, expand_bp, min_pos=0, max_end=None, shift=True, balance=0.5):
-        """Grow by ``expand_bp`` split ``balance`` / ``1 - balance`` between the two ends, clipped to
-        ``[min_pos, max_end[chrom]]`` and shifted to keep the size when ``shift`` (seq.py:112-188)."""
+        """Grow the interval by ``expand_bp`` bases, ``int(expand_bp * balance)`` of them on the left.
+
+        The result never leaves ``[min_pos, max_end[chrom]]``; with ``shift`` the part that would have crossed one limit
+        is given to the other end (which is then clipped as well).  An interval that would turn inside out collapses to
+        its midpoint.  Uncertainty bounds are reset to the new ends."""
         if balance is None:
             balance = 0.5
         try:
-            if not (0 <= balance <= 1):
-                raise RuntimeError('balance must be in range [0, 1]: {}'.format(balance))
+            in_range = 0 <= balance <= 1
         except ValueError:
             raise RuntimeError('balance is not numeric: {}'.format(balance))
-        expand_pos = int(expand_bp * balance)
-        expand_end = np.max([0, expand_bp - expand_pos])
-        new_pos = int(self.pos - expand_pos)
-        new_end = int(self.end + expand_end)
-        if min_pos is not None and new_pos < min_pos:
+        if not in_range:
+            raise RuntimeError('balance must be in range [0, 1]: {}'.format(balance))
+        left = int(expand_bp * balance)
+        right = max(0, int(expand_bp - left))
+        lo, hi = self.pos - left, self.end + right
+
+        ceiling = None                                   # only a per-chromosome table is honoured
+        if isinstance(max_end, pd.Series) and self.chrom in max_end.index:
+            ceiling = max_end[self.chrom]
+
+        if min_pos is not None and lo < min_pos:
+            hi += (min_pos - lo) if shift else 0
+            lo = min_pos
+        if ceiling is not None and hi > ceiling:
             if shift:
-                new_end += min_pos - new_pos
-            new_pos = min_pos
-        if max_end is not None:
-            if max_end.__class__ == pd.core.series.Series and self.chrom in max_end.index:
-                max_end = max_end[self.chrom]
-            else:
-                max_end = None
-        if max_end is not None and new_end > max_end:
-            if shift:
-                new_pos -= new_end - max_end
-                if new_pos < min_pos:
-                    new_pos = min_pos
-            new_end = max_end
-        if new_end < new_pos:
-            new_end = new_pos = (new_end + new_pos) // 2
-        self.pos = new_pos
-        self.end = new_end
-        self.pos_min = self.pos_max = self.pos
-        self.end_min = self.end_max = self.end
+                lo -= hi - ceiling
+                if min_pos is not None:
+                    lo = max(lo, min_pos)
+            hi = ceiling
+        if hi < lo:
+            lo = hi = (lo + hi) // 2
 
-    def __getitem__(self, key):
-        if key not in {'chrom', 'pos', 'pos1', 'end'}:
-            raise IndexError('No key in Region: {}'.format(key))
-        return self.pos + 1 if key == 'pos1' else self.__dict__[key]
-
-    def __eq__(self, other):
-        return self.chrom == other.chrom and self.pos == other.pos and self.end == other.end
-
-    def __lt__(self, other):
-        return (self.chrom, self.pos, self.end) < (other.chrom, other.pos, other.end)
-
-    def copy(self):
-        return Region(self.chrom, self.pos, self.end, self.is_rev, self.pos_min, self.pos_max, self.end_min, self.end_max)
+        self.pos = self.pos_min = self.pos_max = int(lo)
+        self.end = self.end_min = self.end_max = int(hi)
 
 
 def region_from_string(rgn_str, is_rev=None, base0half=False):
-    """"chrom:pos-end" (1-based closed unless ``base0half``) -> Region (seq.py:260-285)."""
-    match_obj = re.match(r'^([^:]+):(\d+)-(\d+)$', rgn_str.replace(',', ''))
-    if match_obj is None:
+    """Parse ``chrom:pos-end`` (thousands separators allowed).  The numbers are 1-based closed unless ``base0half``."""
+    found = _REGION_TEXT.match(rgn_str.replace(',', ''))
+    if found is None:
         raise RuntimeError('Region is not in expected format (chrom:pos-end): {}'.format(rgn_str))
-    pos = int(match_obj[2])
-    end = int(match_obj[3])
-    if not base0half:
-        pos -= 1
-    return Region(match_obj[1], pos, end, is_rev=is_rev)
+    first, last = int(found['first']), int(found['last'])
+    return Region(found['chrom'], first if base0half else first - 1, last, is_rev=is_rev)
 
 
 def region_from_id(region_id):
-    """CHROM-POS-SVTYPE-LEN -> Region, POS taken as 1-based (seq.py:288-302)."""
-    tok = region_id.split('-')
-    if len(tok) != 4:
+    """``CHROM-POS-SVTYPE-LEN`` (e.g. an "RGN" ID) to a Region; POS is read as 1-based."""
+    fields = region_id.split('-')
+    if len(fields) != 4:
         raise RuntimeError('Unrecognized region ID: {}'.format(region_id))
-    return Region(tok[0], int(tok[1]) - 1, int(tok[1]) - 1 + int(tok[3]))
+    chrom, start1, _, length = fields
+    start = int(start1) - 1
+    return Region(chrom, start, start + int(length))
 
 
 def region_seq_fasta(region, fa_file_name, rev_compl=None):
-    """Sequence of a Region (or of a whole record when ``region`` is a str); reverse-complemented when
-    ``rev_compl`` or, if that is None, when ``region.is_rev`` (seq.py:328-360)."""
-    fa = open_fasta(fa_file_name)
-    if region.__class__ == str:
-        arr, is_region = fa[region], False
-    elif region.__class__ == Region:
-        arr, is_region = fa[region.chrom][region.pos:region.end], True
+    """Bases of a Region - or of the whole record named by a str - as text.  Reverse-complemented when ``rev_compl`` is
+    true, or, when it is None, for a Region with ``is_rev`` set."""
+    records = open_fasta(fa_file_name)
+    if type(region) is str:
+        bases, flip = records[region], bool(rev_compl)
+    elif type(region) is Region:
+        bases = records[region.chrom][region.pos:region.end]
+        flip = bool(region.is_rev if rev_compl is None else rev_compl)
     else:
-        raise RuntimeError('Unrecognized region type: {}: Expected Region (pavlib.seq) or str'.format(str(region.__class__.__name__)))
-    do_rc = (is_region and region.is_rev) if rev_compl is None else bool(rev_compl)
-    if do_rc:
-        arr = _COMP[arr[::-1]]
-    return arr.tobytes().decode()
+        raise RuntimeError('Unrecognized region type: {}: Expected Region (pavlib.seq) or str'.format(type(region).__name__))
+    if flip:
+        bases = _COMP[bases[::-1]]
+    return bases.tobytes().decode()

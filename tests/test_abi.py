@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol(built):
     for name in declared:
         assert hasattr(lib, name), f'{name} is declared in include/pav_amd.h but not exported'
     assert sorted(_lib.SYMBOLS) == declared, 'pav_amd/_lib.py prototypes out of sync with include/pav_amd.h'
-    assert lib.pav_abi_version() == 1
+    assert lib.pav_abi_version() == 2
 
 
 def test_struct_sizes_match_header():

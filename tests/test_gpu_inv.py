@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 GOLD = util.GOLD
 INV_CASES = ['inv_fwd', 'inv_rev', 'inv_small', 'inv_limits', 'inv_nolift', 'inv_hap']
 KERN = ('KERN_FWD', 'KERN_FWDREV', 'KERN_REV')
-RTOL = 1e-11      # KERN_* tolerance vs the reference: device exp() and np.cov's summation order
+RTOL = 1e-12      # KERN_* tolerance vs the reference: device exp() and np.cov's summation order
 
 
 def sha(a):
@@ -409,7 +409,7 @@ def test_rule_call_inv_batch_files(built, gpu_ctx, tmp_path):
 @pytest.mark.parametrize('seed', [31, 32])
 def test_density_vs_oracle_seeded(built, gpu_ctx, seed, mode, kmer):
     """Seeded haplotype with planted inversions, inverted repeats, N runs and reverse rows: the first scan iteration of
-    every flagged region as one device batch vs the scalar oracle - integer columns exact, KERN_* to 1e-11."""
+    every flagged region as one device batch vs the scalar oracle - integer columns exact, KERN_* to 1e-12."""
     from oracle import oracle
     hap = synth.config2(seed=seed, scale=0.004, threads=4)
     names = hap.ref.names
@@ -455,6 +455,120 @@ def test_density_vs_oracle_seeded(built, gpu_ctx, seed, mode, kmer):
             for c in KERN:
                 assert np.allclose(cols[c], o[c], rtol=RTOL, atol=1e-300), c
     assert n_final >= 4
+
+
+NEARTIE = ['argmax_search', 'argmax_mirror', 'delta_above', 'delta_below']
+
+
+def run_neartie(ctx, case, **kw):
+    g = np.load(os.path.join(GOLD, 'den_neartie', case + '.npz'))
+    p = json.loads(str(g['params']))
+    ctx._inv_loaded = None
+    ctx.seq_load(_lib.PAV_ROLE_REF, ['chrN'], [g['ref']])
+    ctx.seq_load(_lib.PAV_ROLE_TIG, ['tigN'], [g['tig']])
+    job = _lib.DenJob(0, 0, 0, g['ref'].shape[0], 0, g['tig'].shape[0], 0, p['staterunsmooth'])
+    res = ctx.density_batch([job], pavden.den_params(k=p['k'], state_run_delta=p['staterundelta'], **kw))[0]
+    assert res.status == _lib.DEN_OK and res.n_rows == g['INDEX'].shape[0]
+    return g, p, res, ctx.density_table(0, res.n_rows)
+
+
+@pytest.mark.parametrize('mode', [_lib.KDE_RUNS, _lib.KDE_DIRECT], ids=['runs', 'direct'])
+@pytest.mark.parametrize('case', NEARTIE)
+def test_constructed_near_ties_vs_reference(built, gpu_ctx, case, mode):
+    """Inputs built so that scripts/density.py takes a float decision by a hair (tools/refharness/gen_golden_neartie.py; the
+    tables are the reference's own): the arg-max of a row with a margin of 2e-11, an exact tie (1e-15: rounding decides in
+    the reference too), and density_change of one window 1e-10 above / below --staterundelta.  The guard must see each of
+    them, evaluate the sites they rest on in scipy's order and reproduce the reference's decision; only the exact tie is
+    allowed to go either way, and is reported as unresolved."""
+    g, p, res, cols = run_neartie(gpu_ctx, case, kde_mode=mode)
+    assert np.array_equal(cols['INDEX'], g['INDEX']) and np.array_equal(cols['STATE_MER'], g['STATE_MER'])
+    for c in KERN:
+        assert np.allclose(cols[c], g[c], rtol=RTOL, atol=1e-300), c
+    diff = np.flatnonzero(cols['STATE'] != g['STATE'])
+    assert res.n_near_tie >= 1 and res.guard_fallback == 0
+    assert res.n_spike_near > 100                    # KERN = 1.0 to the last bits inside a long run: counted, continuous
+    if mode == _lib.KDE_RUNS:
+        assert res.n_reeval >= (2 if case.startswith('delta') else 1)
+    else:
+        assert res.n_reeval == 0                     # every sum is in scipy's order already
+    if case == 'argmax_mirror':
+        assert set(diff) <= {p['row']} and cols['STATE'][p['row']] in (0, 2)
+        assert res.n_unresolved >= 1
+    else:
+        assert diff.size == 0 and res.n_unresolved == 0
+    if case.startswith('delta'):
+        a, b = p['window']
+        x = np.arange(a + 1, b)
+        chord = cols['KERN_FWD'][a] + (cols['KERN_FWD'][b] - cols['KERN_FWD'][a]) / (b - a) * (x - a)
+        assert np.allclose(cols['KERN_FWD'][a + 1:b], chord, rtol=1e-13, atol=0) == (case == 'delta_above')
+
+
+def test_near_tie_sites_are_evaluated_in_scipy_order(built, gpu_ctx):
+    """The re-evaluated densities are the PAV_KDE_DIRECT ones bit for bit: at the doubtful row of argmax_search the guarded
+    run-sum table equals the direct table exactly, while the unguarded run sums differ from it in the last digits (that
+    difference, 1e-13 relative, is of the order of the margin the decision hangs on)."""
+    g, p, r_dir, direct = run_neartie(gpu_ctx, 'argmax_search', kde_mode=_lib.KDE_DIRECT)
+    _, _, r_on, guarded = run_neartie(gpu_ctx, 'argmax_search', kde_mode=_lib.KDE_RUNS)
+    _, _, r_off, raw = run_neartie(gpu_ctx, 'argmax_search', kde_mode=_lib.KDE_RUNS, guard_rel=-1.0)
+    row = p['row']
+    assert r_off.n_near_tie == 0 and r_off.n_reeval == 0 and r_on.n_reeval >= 1
+    for c in ('KERN_FWD', 'KERN_REV'):
+        assert guarded[c][row] == direct[c][row]
+        assert np.isclose(raw[c][row], direct[c][row], rtol=1e-11, atol=0)
+    assert guarded['STATE'][row] == direct['STATE'][row] == g['STATE'][row]
+
+
+@pytest.mark.parametrize('cap', [0, 300], ids=['list', 'overflow'])
+def test_guard_on_everything_equals_direct_mode(built, gpu_ctx, cap):
+    """guard_rel = 2 makes every decision doubtful: all sampled sites and all evaluated rows are summed again in scipy's
+    order and everything downstream is redone from them, so the run-sum table must come out bit-identical to the
+    PAV_KDE_DIRECT table (KERN_* included).  With a list of 300 entries the list overflows and the library falls back to
+    PAV_KDE_DIRECT for the batch: same tables, guard_fallback set."""
+    hap = synth.config2(seed=31, scale=0.004, threads=4)
+    names = hap.ref.names
+    gpu_ctx._inv_loaded = None
+    gpu_ctx.seq_load(_lib.PAV_ROLE_REF, names, [hap.ref.seqs[n] for n in names])
+    gpu_ctx.seq_load(_lib.PAV_ROLE_TIG, hap.tig_names, [hap.tig_seqs[n] for n in hap.tig_names])
+    lift = AlignLift(hap.df_trim, hap.tig_lengths)
+    fai = pd.Series(hap.ref.lengths)
+    ref_i = {n: i for i, n in enumerate(names)}
+    tig_i = {n: i for i, n in enumerate(hap.tig_names)}
+    jobs = []
+    for _, row in hap.df_flag.iterrows():
+        r = pavseq.Region(row['#CHROM'], row['POS'], row['END'])
+        r.expand(4000, min_pos=0, max_end=fai, shift=True)
+        try:
+            t = lift.lift_region_to_qry(r)
+        except RuntimeError:
+            t = None
+        if t is None or len(r) > 40_000:
+            continue
+        jobs.append(_lib.DenJob(ref_i[r.chrom], tig_i[t.chrom], r.pos, r.end, t.pos, t.end, 1 if t.is_rev else 0, 20))
+        if len(jobs) >= 10:
+            break
+    assert len(jobs) >= 6
+
+    def tables(**kw):
+        res = gpu_ctx.density_batch(jobs, pavden.den_params(**kw))
+        return res, [gpu_ctx.density_table(j, r.n_rows) if r.status != _lib.DEN_FAIL else None for j, r in enumerate(res)], \
+            [gpu_ctx.density_runs(j, r.n_runs) if r.status != _lib.DEN_FAIL else None for j, r in enumerate(res)]
+    r_d, t_d, runs_d = tables(kde_mode=_lib.KDE_DIRECT)
+    r_g, t_g, runs_g = tables(kde_mode=_lib.KDE_RUNS, guard_rel=2.0, guard_cap=cap)
+    n_ok = 0
+    for a, b, ta, tb, ra, rb in zip(r_d, r_g, t_d, t_g, runs_d, runs_g):
+        assert (a.status, a.n_rows, a.n_eval) == (b.status, b.n_rows, b.n_eval)
+        if a.status == _lib.DEN_FAIL:
+            continue
+        assert ra == rb
+        for c in ('INDEX', 'STATE_MER', 'STATE'):
+            assert np.array_equal(ta[c], tb[c]), c
+        if a.status == _lib.DEN_OK:
+            n_ok += 1
+            for c in KERN:
+                assert np.array_equal(ta[c], tb[c]), c
+            assert b.guard_fallback == (1 if cap else 0)
+            assert b.n_near_tie > 0 and (cap or b.n_reeval >= b.n_sample)
+    assert n_ok >= 4
 
 
 def test_files_to_files_tool(built, tmp_path):

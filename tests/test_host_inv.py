@@ -97,7 +97,7 @@ def test_rl_encoder_matches_golden_runs():
 @pytest.mark.parametrize('case', INV_CASES)
 def test_oracle_density_matches_reference(built, case):
     """oracle/pav_oracle_density.c vs every scan iteration the reference executed: row count, INDEX, STATE_MER, STATE,
-    rl_encoder runs exact; KERN_* within 1e-11 relative (np.cov's summation order is not reproducible, exp is libm's)."""
+    rl_encoder runs exact; KERN_* within 1e-12 relative (np.cov's summation order is not reproducible, exp is libm's)."""
     from oracle import oracle
     d = os.path.join(GOLD, case)
     ref, tig = open_fasta(os.path.join(d, 'ref.fa')), open_fasta(os.path.join(d, 'tig.fa'))
@@ -124,7 +124,7 @@ def test_oracle_density_matches_reference(built, case):
         if rec['call'] is not None:
             g = np.load(os.path.join(d, 'density_%s.npz' % rec['call']['id']))
             for c in ('KERN_FWD', 'KERN_FWDREV', 'KERN_REV'):
-                assert np.allclose(o[c], g[c], rtol=1e-11, atol=1e-300), c
+                assert np.allclose(o[c], g[c], rtol=1e-12, atol=1e-300), c
             assert np.array_equal(o['KMER'], g['KMER'])
             # FLANK / MATCH (pavlib/inv.py:457-561)
             call = rec['call']
@@ -135,3 +135,46 @@ def test_oracle_density_matches_reference(built, case):
                                            chrom[ro['pos']:ri['pos']], chrom[ri['end']:ro['end']])
             assert np.array_equal(np.array(['', 'UP', 'DN'])[flank], g['FLANK'])
             assert np.array_equal(np.array(['', 'SAME', 'OTHER', 'NA'])[match], g['MATCH'])
+
+
+NEARTIE = ['argmax_search', 'argmax_mirror', 'delta_above', 'delta_below']
+
+
+def load_neartie(case):
+    g = np.load(os.path.join(GOLD, 'den_neartie', case + '.npz'))
+    return g, json.loads(str(g['params']))
+
+
+@pytest.mark.parametrize('case', NEARTIE)
+def test_oracle_density_on_constructed_near_ties(built, case):
+    """tests/golden/den_neartie (tools/refharness/gen_golden_neartie.py): inputs on which scripts/density.py takes a float
+    decision by a hair - the arg-max of one row with a margin of 2e-11 (argmax_search) / of 1e-15, an exact tie up to rounding
+    (argmax_mirror), and density_change of one window 1e-10 above / below --staterundelta.  The scalar oracle follows scipy's
+    order, so it reproduces the reference's table; only the exact tie may go either way."""
+    from oracle import oracle
+    g, p = load_neartie(case)
+    o = oracle.density(g['ref'], g['tig'], False, oracle.den_params(k=p['k'], state_run_smooth=p['staterunsmooth'],
+                                                                    state_run_delta=p['staterundelta']))
+    assert o['status'] == 0 and np.array_equal(o['INDEX'], g['INDEX']) and np.array_equal(o['STATE_MER'], g['STATE_MER'])
+    for c in ('KERN_FWD', 'KERN_FWDREV', 'KERN_REV'):
+        assert np.allclose(o[c], g[c], rtol=1e-12, atol=1e-300), c
+    diff = np.flatnonzero(o['STATE'] != g['STATE'])
+    if case == 'argmax_mirror':
+        assert set(diff) <= {p['row']} and g['STATE'][p['row']] in (0, 2)
+        kk = np.array([g[c][p['row']] for c in ('KERN_FWD', 'KERN_REV')])
+        assert abs(kk[0] - kk[1]) < 1e-13 * kk.max()
+    else:
+        assert diff.size == 0
+    if case == 'argmax_search':
+        r = p['row']
+        m = abs(g['KERN_FWD'][r] - g['KERN_REV'][r]) / max(g['KERN_FWD'][r], g['KERN_REV'][r])
+        assert 1e-12 < m < 1e-9 and g['KERN_FWDREV'][r] == 0.0
+    if case.startswith('delta'):
+        a, b = p['window']
+        d = max(abs(g[c][a] - g[c][b]) for c in ('KERN_FWD', 'KERN_FWDREV', 'KERN_REV'))
+        assert abs(d - p['staterundelta']) < 2e-10 * d and (d > p['staterundelta']) == (case == 'delta_below')
+        # the decision shows in the table: interpolated rows lie on the chord, evaluated rows do not
+        x = np.arange(a + 1, b)
+        chord = g['KERN_FWD'][a] + (g['KERN_FWD'][b] - g['KERN_FWD'][a]) / (b - a) * (x - a)
+        on_chord = np.allclose(g['KERN_FWD'][a + 1:b], chord, rtol=1e-13, atol=0)
+        assert on_chord == (case == 'delta_above')
