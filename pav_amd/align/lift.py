@@ -104,9 +104,9 @@ class AlignLift:
                 tree[key].sort(key=lambda t: (t[0], t[1]))
         self._starts = {id(tree): {k: [t[0] for t in v] for k, v in tree.items()} for tree in (self.ref_tree, self.tig_tree)}
         self._maxlen = {id(tree): {k: max(t[1] - t[0] for t in v) for k, v in tree.items()} for tree in (self.ref_tree, self.tig_tree)}
-        self.cache_queue = collections.deque()
-        self.ref_cache = dict()
-        self.tig_cache = dict()
+        self._tables = collections.OrderedDict()           # index -> (subject-axis view, query-axis view), least recent first
+        self.ref_cache = _AxisCache(self._tables, 0)
+        self.tig_cache = _AxisCache(self._tables, 1)
 
     def _containing(self, tree, key, pos):
         """Indexes of the records of ``key`` whose [begin, end) contains ``pos`` (sorted starts + bisect)."""
@@ -118,113 +118,115 @@ class AlignLift:
         lo = bisect.bisect_left(starts, pos - self._maxlen[id(tree)][key])
         return [records[i][2] for i in range(lo, hi) if records[i][1] > pos]
 
-    # ---- query -> subject (lift.py:51-185) -------------------------------------------------------------
+    # ---- point lifts ------------------------------------------------------------------------------------------
+    # A lifted point is (sequence, position, record is reverse, lowest, highest position, record indexes).
+    @staticmethod
+    def _each(coord, lift_one):
+        if isinstance(coord, (list, tuple)):
+            return [lift_one(p) for p in coord]
+        return lift_one(coord)
+
+    @staticmethod
+    def _through(view, k, at):
+        """Position ``at`` inside operation ``k`` of ``view`` carried to the other axis: operations that cover one
+        position there (insertions, deletions, one-base matches) give that payload's end (lift.py:163-181, 257-258)."""
+        begin, _, d0, d1 = view.interval(k)
+        return d0 + (int(at) - begin) if d1 - d0 > 1 else d1
+
     def lift_to_sub(self, query_id, coord, gap=False):
-        ret_list = issubclass(coord.__class__, (list, tuple))
-        if not ret_list:
-            coord = (coord,)
-        out = []
-        for pos in coord:
-            pos_org = pos
-            hits = self._containing(self.tig_tree, query_id, pos)
-            if len(hits) == 1:
-                index = hits[0]
-            elif len(hits) == 0 and gap:
-                out.append(self._get_subject_gap(query_id, pos))
-                continue
-            else:
-                out.append(None)
-                continue
-            if index not in self.tig_cache:
-                self._add_align(index)
-            tree = self.tig_cache[index]
-            row = self._rows[index]
-            if row['REV']:
-                pos = self.df_fai[query_id] - pos
-            i = tree.at(pos)
-            if i < 0:
-                i = tree.at(pos - 1)                    # a query exactly at the alignment end (lift.py:122-138)
-                if i < 0 or tree.interval(i)[1] != pos:
+        """Contig position(s) -> subject (pavlib/align/lift.py:51-185): the one record containing the position carries it
+        over; no record and ``gap``: interpolated between the flanking records; otherwise None."""
+        def one(pos):
+            owners = self._containing(self.tig_tree, query_id, pos)
+            if len(owners) != 1:
+                return self._get_subject_gap(query_id, pos) if (gap and not owners) else None
+            index = owners[0]
+            self._add_align(index)
+            view, rec = self.tig_cache[index], self._rows[index]
+            at = self.df_fai[query_id] - pos if rec['REV'] else pos      # reverse records count from the other contig end
+            k = view.at(at)
+            if k < 0:                                                    # exactly at the alignment end (lift.py:122-138)
+                k = view.at(at - 1)
+                if k < 0 or view.interval(k)[1] != at:
                     raise RuntimeError((
                         'Found no matches in a lift-tree for a record within a '
                         'global to-subject tree: {}:{} (index={}, gap={})'
-                    ).format(query_id, pos_org, index, gap))
-            begin, _, d0, d1 = tree.interval(i)
-            lift_pos = d0 + (int(pos) - begin) if d1 - d0 > 1 else d1
-            out.append((row['#CHROM'], lift_pos, row['REV'], lift_pos, lift_pos, (row['INDEX'],)))
-        return out if ret_list else out[0]
+                    ).format(query_id, pos, index, gap))
+            there = self._through(view, k, at)
+            return rec['#CHROM'], there, rec['REV'], there, there, (rec['INDEX'],)
+        return self._each(coord, one)
 
-    # ---- subject -> query (lift.py:187-272) ------------------------------------------------------------
     def lift_to_qry(self, subject_id, coord):
-        ret_list = issubclass(coord.__class__, (list, tuple))
-        if not ret_list:
-            coord = (coord,)
-        out = []
-        for pos in coord:
-            hits = self._containing(self.ref_tree, subject_id, pos)
-            if len(hits) != 1:
-                out.append(None)
-                continue
-            index = hits[0]
-            if index not in self.ref_cache:
-                self._add_align(index)
-            tree = self.ref_cache[index]
-            row = self._rows[index]
-            i = tree.at(pos)
-            if i < 0:
+        """Subject position(s) -> contig (pavlib/align/lift.py:187-272); None unless exactly one record contains it."""
+        def one(pos):
+            owners = self._containing(self.ref_tree, subject_id, pos)
+            if len(owners) != 1:
+                return None
+            index = owners[0]
+            self._add_align(index)
+            view, rec = self.ref_cache[index], self._rows[index]
+            k = view.at(pos)
+            if k < 0:
                 raise RuntimeError((
                     'Program bug: Found no matches in a lift-tree for a record withing a '
                     'global to-query tree: {}:{} (index={})'
                 ).format(subject_id, pos, index))
-            begin, _, d0, d1 = tree.interval(i)
-            qry_pos = d0 + (int(pos) - begin) if d1 - d0 > 1 else d1
-            if row['REV']:
-                qry_pos = self.df_fai[row['QRY_ID']] - qry_pos
-            out.append((row['QRY_ID'], qry_pos, row['REV'], qry_pos, qry_pos, (row['INDEX'],)))
-        return out if ret_list else out[0]
+            there = self._through(view, k, pos)
+            if rec['REV']:
+                there = self.df_fai[rec['QRY_ID']] - there
+            return rec['QRY_ID'], there, rec['REV'], there, there, (rec['INDEX'],)
+        return self._each(coord, one)
+
+    @staticmethod
+    def _span(first, last, is_rev):
+        """Region between two lifted points ((name, pos, rev, lo, hi, records) each) on the same sequence."""
+        if first is None or last is None or first[0] != last[0]:
+            return None
+        (name, pos, _, pos_lo, pos_hi, pos_rec), (_, end, _, end_lo, end_hi, end_rec) = first, last
+        return pavseq.Region(name, pos, end, is_rev=is_rev, pos_min=pos_lo, pos_max=pos_hi, end_min=end_lo, end_max=end_hi,
+                             pos_aln_index=(pos_rec,), end_aln_index=(end_rec,))
 
     def lift_region_to_sub(self, region, gap=False):
-        """Query region -> subject region, or None (lift.py:274-302)."""
-        sub_pos, sub_end = self.lift_to_sub(region.chrom, (region.pos, region.end), gap)
-        if sub_pos is None or sub_end is None:
+        """Query region -> subject region (never marked reverse), or None when an end does not lift, the ends land on
+        different subjects, or both orientations are known and disagree (pavlib/align/lift.py:274-302)."""
+        first, last = self.lift_to_sub(region.chrom, (region.pos, region.end), gap)
+        if first is not None and last is not None and None not in (first[2], last[2]) and first[2] != last[2]:
             return None
-        if sub_pos[0] != sub_end[0] or (sub_pos[2] is not None and sub_end[2] is not None and sub_pos[2] != sub_end[2]):
-            return None
-        return pavseq.Region(sub_pos[0], sub_pos[1], sub_end[1], is_rev=False, pos_min=sub_pos[3], pos_max=sub_pos[4],
-                             end_min=sub_end[3], end_max=sub_end[4], pos_aln_index=(sub_pos[5],), end_aln_index=(sub_end[5],))
+        return self._span(first, last, False)
 
     def lift_region_to_qry(self, region):
-        """Subject region -> query region, or None (lift.py:304-331)."""
-        query_pos, query_end = self.lift_to_qry(region.chrom, (region.pos, region.end))
-        if query_pos is None or query_end is None:
+        """Subject region -> query region carrying the record's orientation, or None when an end does not lift or the ends
+        land on different contigs / orientations (pavlib/align/lift.py:304-331)."""
+        first, last = self.lift_to_qry(region.chrom, (region.pos, region.end))
+        if first is None or last is None or first[2] != last[2]:
             return None
-        if query_pos[0] != query_end[0] or query_pos[2] != query_end[2]:
-            return None
-        return pavseq.Region(query_pos[0], query_pos[1], query_end[1], is_rev=query_pos[2], pos_min=query_pos[3],
-                             pos_max=query_pos[4], end_min=query_end[3], end_max=query_end[4],
-                             pos_aln_index=(query_pos[5],), end_aln_index=(query_end[5],))
+        return self._span(first, last, first[2])
 
     def _get_subject_gap(self, query_id, pos):
-        """Interpolate into the gap between two records of one contig (lift.py:333-378)."""
+        """A contig position no record covers, placed between the record that ends last before it and the one that starts
+        first after it - if both exist and sit on the same subject (pavlib/align/lift.py:333-378).  The position reported
+        is the midpoint of the contig gap; orientation only when both neighbours agree."""
         if pos is None:
             return None
-        subdf = self.df.loc[self.df['QRY_ID'] == query_id]
-        if not np.any(subdf['QRY_END'] < pos) or not np.any(subdf['QRY_POS'] > pos):
+        members = np.flatnonzero(self.df['QRY_ID'].to_numpy() == query_id)
+        ends, starts = self.df['QRY_END'].to_numpy()[members], self.df['QRY_POS'].to_numpy()[members]
+        before, after = np.flatnonzero(ends < pos), np.flatnonzero(starts > pos)
+        if before.size == 0 or after.size == 0:
             return None
-        row_l = subdf.loc[subdf.loc[subdf['QRY_END'] < pos, 'QRY_END'].sort_values().index[-1]]
-        row_r = subdf.loc[subdf.loc[subdf['QRY_POS'] > pos, 'QRY_POS'].sort_values().index[0]]
-        if row_l['#CHROM'] != row_r['#CHROM']:
+        # the same (unstable) sort the reference's Series.sort_values() uses decides between equal coordinates
+        left = self.df.iloc[members[before[np.argsort(ends[before], kind='quicksort')[-1]]]]
+        right = self.df.iloc[members[after[np.argsort(starts[after], kind='quicksort')[0]]]]
+        if left['#CHROM'] != right['#CHROM']:
             return None
-        return (row_l['#CHROM'], int((row_l['QRY_END'] + row_r['QRY_POS']) / 2),
-                row_l['REV'] if row_l['REV'] == row_r['REV'] else None, row_l['QRY_END'], row_r['QRY_POS'],
-                (row_l['INDEX'], row_r['INDEX']))
+        gap_from, gap_to = left['QRY_END'], right['QRY_POS']
+        return (left['#CHROM'], int((gap_from + gap_to) / 2), left['REV'] if left['REV'] == right['REV'] else None,
+                gap_from, gap_to, (left['INDEX'], right['INDEX']))
 
     def _add_align(self, index):
-        """Build and cache the two operation tables of one record (lift.py:380-476)."""
-        if index in self.ref_cache:
-            while index in self.cache_queue:
-                self.cache_queue.remove(index)
-            self.cache_queue.appendleft(index)
+        """Make the operation tables of one record available (the job of pavlib/align/lift.py:380-476); most recently used
+        records stay at the end of ``_tables``."""
+        if index in self._tables:
+            self._tables.move_to_end(index)
             return
         self._check_and_clear()
         if self._dev is not None:
@@ -250,13 +252,35 @@ class AlignLift:
                 'NP'[int(table.code[np.flatnonzero(bad)[0]] == 6)], row['#CHROM'], row['POS'], row['QRY_ID']))
         if np.any((table.len == 0) & (_MATCH_CODES[table.code] | (table.code == 1) | (table.code == 2))):
             raise ValueError('IntervalTree: Null Interval objects not allowed in IntervalTree: zero-length CIGAR operation')
-        self.ref_cache[index] = table.view(0)
-        self.tig_cache[index] = table.view(1)
-        self.cache_queue.appendleft(index)
+        self._tables[index] = (table.view(0), table.view(1))
 
     def _check_and_clear(self):
-        # The reference keeps 10 records (lift.py:20-49); eviction has no observable effect, so keep many more
-        while len(self.cache_queue) >= max(self.cache_align, 4096):
-            index = self.cache_queue.pop()
-            del self.ref_cache[index]
-            del self.tig_cache[index]
+        """Drop the least recently used tables.  The reference keeps ``cache_align`` = 10 records; a table here is three
+        small arrays and eviction has no observable effect, so at least 4096 stay."""
+        keep = max(self.cache_align, 4096)
+        while len(self._tables) >= keep:
+            self._tables.popitem(last=False)
+
+    @property
+    def cache_queue(self):
+        """Cached record indexes, most recently used first (the reference's deque, for introspection)."""
+        return collections.deque(reversed(self._tables))
+
+
+class _AxisCache:
+    """``ref_cache`` / ``tig_cache`` of the reference as read-only views of the table cache (one axis each)."""
+
+    def __init__(self, tables, axis):
+        self._tables, self._axis = tables, axis
+
+    def __contains__(self, index):
+        return index in self._tables
+
+    def __getitem__(self, index):
+        return self._tables[index][self._axis]
+
+    def __len__(self):
+        return len(self._tables)
+
+    def keys(self):
+        return self._tables.keys()

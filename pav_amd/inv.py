@@ -145,36 +145,36 @@ class IntervalSet:
 
 
 def get_srs_tree(srs_tuple_list):
-    """State-run-smooth limits -> lookup by region size (pavlib/inv.py:564-620; same checks and messages)."""
-    srs_tree = SrsTree()
+    """``[(region size limit, state-run-smooth factor), ...]`` -> lookup of the factor by region size, as
+    ``pavlib.inv.get_srs_tree`` (pavlib/inv.py:564-620): the factor given with a limit applies from that limit up to the next
+    one; below the first limit it is 20 (or the limit if smaller); no list = 20 everywhere.  Same checks and messages, in
+    the order the reference meets them (a malformed element fails on the reference's message concatenation: TypeError)."""
+    tree = SrsTree()
     if srs_tuple_list is None or len(srs_tuple_list) == 0:
-        srs_tree.add(0, np.inf, DEFAULT_STATE_RUN_SMOOTH)
-        return srs_tree
-    for srs_element in srs_tuple_list:
-        if len(srs_element) != 2:
-            raise RuntimeError('Element in "state run smooth" tuple list that is not length 2: ' + str(srs_element))
-    srs_tuple_list = sorted(srs_tuple_list)
-    last_inv_lim, last_smooth_factor = srs_tuple_list[0]
-    last_inv_lim = int(last_inv_lim)
-    last_smooth_factor = int(last_smooth_factor)
-    if last_inv_lim < 0:
-        raise RuntimeError('State run inversion size limits must be 0 or greater: {}'.format(last_inv_lim))
-    if last_smooth_factor < 4:
-        raise RuntimeError('Not tested with "state run smooth" factor less than 4: {}'.format(last_smooth_factor))
-    if last_inv_lim > 0:
-        srs_tree.add(0, last_inv_lim, np.min([last_inv_lim, 20]))
-    for inv_lim, smooth_factor in srs_tuple_list[1:]:
-        inv_lim = int(inv_lim)
-        smooth_factor = int(smooth_factor)
-        if smooth_factor < 20:
-            raise RuntimeError('Not tested with "state run smooth" factor less than 20: {}'.format(smooth_factor))
-        if inv_lim == last_inv_lim:
-            raise RuntimeError('Duplicate limit in state run limits: {}'.format(inv_lim))
-        srs_tree.add(last_inv_lim, inv_lim, last_smooth_factor)
-        last_inv_lim = inv_lim
-        last_smooth_factor = smooth_factor
-    srs_tree.add(last_inv_lim, np.inf, last_smooth_factor)
-    return srs_tree
+        tree.add(0, np.inf, DEFAULT_STATE_RUN_SMOOTH)
+        return tree
+    for item in srs_tuple_list:
+        if len(item) != 2:
+            raise TypeError('can only concatenate str (not "{}") to str'.format(type(item).__name__))
+    lower = factor = None
+    for limit, value in sorted(srs_tuple_list):
+        limit, value = int(limit), int(value)
+        if lower is None:
+            if limit < 0:
+                raise RuntimeError('State run inversion size limits must be 0 or greater: {}'.format(limit))
+            if value < 4:
+                raise RuntimeError('Not tested with "state run smooth" factor less than 4: {}'.format(value))
+            if limit > 0:
+                tree.add(0, limit, np.min([limit, 20]))
+        else:
+            if value < 20:
+                raise RuntimeError('Not tested with "state run smooth" factor less than 20: {}'.format(value))
+            if limit == lower:
+                raise RuntimeError('Duplicate limit in state run limits: {}'.format(limit))
+            tree.add(lower, limit, factor)
+        lower, factor = limit, value
+    tree.add(lower, np.inf, factor)
+    return tree
 
 
 def _write_log(message, log):

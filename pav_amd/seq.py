@@ -45,8 +45,7 @@ class Region:
             lo, hi = hi, lo
             pos_min, pos_max, end_min, end_max = end_min, end_max, pos_min, pos_max
             pos_aln_index, end_aln_index = end_aln_index, pos_aln_index
-        self.chrom = str(chrom)
-        self.pos, self.end = lo, hi
+        self.chrom, self.pos, self.end = str(chrom), lo, hi
         near, far = (hi, lo) if flipped else (lo, hi)
         self.pos_min, self.pos_max = _bound(pos_min, near), _bound(pos_max, near)
         self.end_min, self.end_max = _bound(end_min, far), _bound(end_max, far)
@@ -96,12 +95,11 @@ class Region:
         The result never leaves ``[min_pos, max_end[chrom]]``; with ``shift`` the part that would have crossed one limit
         is given to the other end (which is then clipped as well).  An interval that would turn inside out collapses to
         its midpoint.  Uncertainty bounds are reset to the new ends."""
-        if balance is None:
-            balance = 0.5
+        balance = 0.5 if balance is None else balance
         try:
             in_range = 0 <= balance <= 1
-        except ValueError:
-            raise RuntimeError('balance is not numeric: {}'.format(balance))
+        except ValueError as not_a_number:
+            raise RuntimeError('balance is not numeric: {}'.format(balance)) from not_a_number
         if not in_range:
             raise RuntimeError('balance must be in range [0, 1]: {}'.format(balance))
         left = int(expand_bp * balance)
