@@ -38,11 +38,21 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+PAIR_FRAC = 0.009          # matched DEL + INS events of the generator: ~1 k MATCH_INDEL loci per haplotype (~1 k flagged regions)
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=4)
     ap.add_argument('--scale', type=float, default=1.0, help='shrink every sequence length (tests only; 1.0 = the named workload)')
     ap.add_argument('--seed', type=int, default=1002)
     ap.add_argument('--cpu-sample-bp', type=float, default=4e9,
@@ -51,19 +61,41 @@ def main():
     ap.add_argument('--threads', type=int, default=0, help='host threads for the generator (0 = auto)')
     ap.add_argument('--workload', choices=['cigar+inv', 'cigar'], default='cigar+inv',
                     help="'cigar+inv' = the whole path of the metric: CIGAR-call + flagging + k-mer inversion scan of every flagged "
-                         "region (configs[2] shape, one haplotype per GPU); 'cigar' = BASELINE configs[1], CIGAR-call only")
+                         "locus (configs[2]: both haplotypes of a diploid sample per GPU); 'cigar' = BASELINE configs[1], CIGAR-call only")
+    ap.add_argument('--lanes', type=int, default=2,
+                    help='haplotypes resident per GPU, one context + host thread each, sharing one resident reference; the K steps '
+                         'alternate between them (default 2 = h1 + h2 of the diploid sample of configs[2]; 1 = one haplotype)')
+    ap.add_argument('--pair-frac', type=float, default=PAIR_FRAC, help='generator: fraction of indel events emitted as a matched DEL + INS')
+    ap.add_argument('--eager-tables', action='store_true',
+                    help='copy the density tables of every inversion call to pinned host memory inside the timed region (round-1 '
+                         'behaviour); default: they stay in HBM like the SNV / INDEL records, their D2H time is reported in `host`')
     ap.add_argument('--cpu-sample-regions', type=int, default=300,
-                    help='flagged regions whose k-mer density scan the CPU baseline times (oracle, one core)')
+                    help='flagged loci whose k-mer density scan the CPU baseline times (oracle, one core)')
     ap.add_argument('--backend', default='nccl', help="process-group backend for N > 1 ('nccl' = RCCL; tests use 'gloo')")
     ap.add_argument('--share-gpu', action='store_true',
                     help='tests only: every rank uses GPU 0 (exercises the N > 1 code path on a one-GPU box; needs --backend gloo)')
+    ap.add_argument('--no-build', action='store_true', help='do not (re)build the libraries: the profile scripts build first, outside the profiler')
     args = ap.parse_args()
 
+    # ---- before anything touches the GPU: the N-rank launch and the build ------------------------------------------------
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks as a child job and hand its exit code on (this
+        # process has not initialised the GPU; it never measures one GPU and calls it N)
+        import subprocess
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    import __graft_entry__ as g
+    if not args.no_build:
+        import fcntl
+        with open(os.path.join(ROOT, '.build.lock'), 'w') as lock:       # ranks take turns; all but the first find everything built
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            g.build_cpu_side()
 
     import torch  # first: its bundled HIP runtime becomes the process-wide one (pav_amd/_lib.py docstring)
     import torch.distributed as dist
@@ -80,56 +112,73 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    import io
+    import threading
     import numpy as np
-    import __graft_entry__ as g
-    if rank == 0:
-        g.build_cpu_side()
-    if world > 1:
-        dist.barrier()
     from pav_amd import _lib, cigarcall, synth
 
     from pav_amd.shard import effective_cpus
     threads = args.threads or max(1, effective_cpus() // max(1, world))
     threads = min(threads, 16)
+    n_lanes = max(1, args.lanes)
+    gen_kw = {'pair_frac': args.pair_frac} if args.workload == 'cigar+inv' and args.pair_frac > 0 else {}
 
     # ---- synthetic inputs (host) -> HBM -----------------------------------------------------------------------
-    # With several ranks on one node the ranks take turns (generate -> upload -> free the host copies), so the node
-    # never holds more than one rank's 6 GB of host sequence at a time; the timed region starts after all are resident.
-    def prepare():
-        t0 = time.time()
-        hap_ = synth.config2(seed=args.seed, scale=args.scale, hap_index=rank, threads=threads)
-        t_gen_ = time.time() - t0
-        ctx_ = _lib.Context(local_rank)
-        t0 = time.time()
-        names_ = hap_.ref.names
-        ctx_.seq_load(_lib.PAV_ROLE_REF, names_, [hap_.ref.seqs[n] for n in names_])
-        ctx_.seq_load(_lib.PAV_ROLE_TIG, hap_.tig_names, [hap_.tig_seqs[n] for n in hap_.tig_names])
-        aln_, text_, off_ = cigarcall.pack_alignments(hap_.df_align, names_, hap_.tig_names)
-        ctx_.cigar_load(aln_, text_, off_)
-        ctx_.sync()
-        return hap_, ctx_, aln_, text_, off_, t_gen_, time.time() - t0
+    # One lane = one haplotype resident on the GPU: its own context (streams, contigs, alignment tables, results) sharing the
+    # reference planes of lane 0 (pav_seq_share).  With several ranks on one node the ranks take turns (generate -> upload ->
+    # free the host copies), so the node never holds more than one rank's host sequence at a time.
+    class Lane:
+        pass
 
-    hap = ctx = None
+    def prepare():
+        lanes_ = []
+        ref_ = None
+        for li in range(n_lanes):
+            ln = Lane()
+            ln.idx = li
+            t0 = time.time()
+            ln.hap = synth.config2(seed=args.seed, scale=args.scale, hap_index=rank * n_lanes + li, ref=ref_, threads=threads, **gen_kw)
+            ref_ = ln.hap.ref
+            ln.t_gen = time.time() - t0
+            ln.ctx = _lib.Context(local_rank)
+            t0 = time.time()
+            names_ = ref_.names
+            if li == 0:
+                ln.ctx.seq_load(_lib.PAV_ROLE_REF, names_, [ref_.seqs[n] for n in names_])
+            else:
+                ln.ctx.seq_share(lanes_[0].ctx, _lib.PAV_ROLE_REF)
+            ln.ctx.seq_load(_lib.PAV_ROLE_TIG, ln.hap.tig_names, [ln.hap.tig_seqs[n] for n in ln.hap.tig_names])
+            ln.aln, ln.text, ln.off = cigarcall.pack_alignments(ln.hap.df_align, names_, ln.hap.tig_names)
+            ln.ctx.cigar_load(ln.aln, ln.text, ln.off)
+            ln.ctx.sync()
+            ln.t_h2d = time.time() - t0
+            ln.tig_bases = int(sum(ln.hap.tig_seqs[n].shape[0] for n in ln.hap.tig_names))
+            ln.tig_len = ln.hap.tig_lengths
+            if world > 1 or li > 0:                          # host copies are only needed for the N = 1 CPU baseline (lane 0)
+                ln.hap.tig_seqs.clear()
+            lanes_.append(ln)
+        return lanes_
+
+    lanes = None
     for turn in range(world):
         if turn == rank:
-            hap, ctx, aln, text, off, t_gen, t_h2d = prepare()
-            tig_bases = int(sum(hap.tig_seqs[n].shape[0] for n in hap.tig_names))
-            ref_lengths = {n: int(hap.ref.seqs[n].shape[0]) for n in hap.ref.names}
-            tig_len_series = hap.tig_lengths
-            if world > 1:                                   # host copies are only needed for the N = 1 CPU baseline
-                hap.ref.seqs.clear()
-                hap.tig_seqs.clear()
+            lanes = prepare()
+            ref_lengths = {n: int(lanes[0].hap.ref.seqs[n].shape[0]) for n in lanes[0].hap.ref.names}
+            if world > 1:
+                lanes[0].hap.ref.seqs.clear()
                 import gc
                 gc.collect()
         if world > 1:
             dist.barrier()
+    hap, ctx = lanes[0].hap, lanes[0].ctx                    # lane 0 = h1: the side legs, the CPU baseline, the reports
+    aln, text, off = lanes[0].aln, lanes[0].text, lanes[0].off
+    tig_bases = lanes[0].tig_bases
+    t_gen, t_h2d = sum(ln.t_gen for ln in lanes), sum(ln.t_h2d for ln in lanes)
     names = hap.ref.names
 
-    inv_state = {}
     if args.workload == 'cigar+inv':
-        import io
         import tempfile
-        from pav_amd import inv as pavinv, seq as pavseq
+        from pav_amd import inv as pavinv
         from pav_amd.align import AlignLift
         from pav_amd.kmer import KmerUtil
         tmpd = tempfile.mkdtemp(prefix='pav_bench_')
@@ -137,112 +186,142 @@ def main():
             for n in names:
                 fh.write(f'{n}\t{ref_lengths[n]}\t0\t0\t0\n')
         ref_fa_name, tig_fa_name = os.path.join(tmpd, 'ref.fa'), os.path.join(tmpd, 'tig.fa')
-        ctx._inv_loaded = (ref_fa_name, tig_fa_name)                       # sequences are already resident
-        regions = [pavseq.Region(r['#CHROM'], r['POS'], r['END']) for _, r in hap.df_flag.iterrows()]
-        # FILTER inputs of the flagging pass (rules call_inv_cluster / call_inv_flag_insdel_cluster / call_inv_merge_flagged_loci)
-        _index = hap.df_align['INDEX'].to_numpy(dtype='int64')
-        _trim = hap.df_trim[['POS', 'END', 'INDEX']].set_index('INDEX').astype(int).reindex(list(_index), fill_value=-1)
-        flag_tp, flag_te = _trim['POS'].to_numpy(dtype='int64'), _trim['END'].to_numpy(dtype='int64')
-        flag_params = ctx.flag_params()
-        tig_len = tig_len_series
         k_util = KmerUtil(31)
+        for ln in lanes:
+            ln.ctx._inv_loaded = (ref_fa_name, tig_fa_name)               # sequences are already resident
+            # FILTER inputs of the flagging pass (rules call_inv_cluster / call_inv_flag_insdel_cluster / call_inv_merge_flagged_loci)
+            index_ = ln.hap.df_align['INDEX'].to_numpy(dtype='int64')
+            trim_ = ln.hap.df_trim[['POS', 'END', 'INDEX']].set_index('INDEX').astype(int).reindex(list(index_), fill_value=-1)
+            ln.flag_tp, ln.flag_te = trim_['POS'].to_numpy(dtype='int64'), trim_['END'].to_numpy(dtype='int64')
+            # inv_sig_filter = single_cluster (CONFIG.md: try loci that only show a cluster of SNVs / indels): the planted inversions
+            # are aligned through, which is what such a cluster is; the default filter would leave them to the large-SV caller
+            ln.flag_params = ln.ctx.flag_params(sig_filter=_lib.SIG_SINGLE_CLUSTER)
+            # The trimmed alignment table is an input of the job like the sequences and the CIGAR strings of the call path:
+            # it is tokenised into the lift-over index on the device once, before the timed region.
+            t_a = time.perf_counter()
+            ln.lift = AlignLift(ln.hap.df_trim, ln.tig_len)
+            ln.t_lift_ms = (time.perf_counter() - t_a) * 1e3
+            ln.found = io.StringIO()
 
-        # The trimmed alignment table is an input of the job like the sequences and the CIGAR strings of the call path:
-        # it is tokenised into the lift-over index on the device once, before the timed region.
-        t_a = time.perf_counter()
-        lift = AlignLift(hap.df_trim, tig_len)
-        inv_state['t_lift_ms'] = (time.perf_counter() - t_a) * 1e3
-
-        def inv_step():
-            log = io.StringIO()                                   # one log for the batch, as rule call_inv_batch keeps it
-            t_b = time.perf_counter()
-            out = pavinv.scan_for_inv_batch(regions, ref_fa_name, tig_fa_name, lift, k_util, log=log, ctx=ctx,
-                                            eager_tables=False)   # call tables stay in the library's pinned host copy
-            inv_state['out'], inv_state['log'] = out, log
-            inv_state['t_scan_ms'] = (time.perf_counter() - t_b) * 1e3
-            return out
+    def inv_step(ln):
+        """Flagged loci of the fresh calls -> scan of every locus with TRY_INV (rules/call_inv.snakefile:145-196)."""
+        ln.flag = ln.ctx.cigar_flag(ln.flag_tp, ln.flag_te, ln.flag_params)
+        regions = pavinv.loci_regions(ln.ctx, ln.flag[1])
+        log = io.StringIO()                                   # one log for the batch, as rule call_inv_batch keeps it
+        t_b = time.perf_counter()
+        ln.found.seek(0)
+        ln.found.truncate()
+        ln.out = pavinv.scan_for_inv_batch(regions, ref_fa_name, tig_fa_name, ln.lift, k_util, log=log, ctx=ln.ctx,
+                                           eager_tables=args.eager_tables, found_out=ln.found)
+        ln.log, ln.regions = log, regions
+        ln.t_scan_ms = (time.perf_counter() - t_b) * 1e3
 
     phase_timing = bool(os.environ.get('PAV_TIMING'))
 
-    def step(workload=args.workload):
+    def step(ln, workload=args.workload):
         t_p = [time.perf_counter()]
 
         def lap(what):
             if phase_timing:
                 t = time.perf_counter()
-                print('[pav timing] step %-12s %.2f ms' % (what, (t - t_p[0]) * 1e3), file=sys.stderr)
+                print('[pav timing] lane %d step %-12s %.2f ms' % (ln.idx, what, (t - t_p[0]) * 1e3), file=sys.stderr)
                 t_p[0] = t
-        ctx.seq_pack(_lib.PAV_ROLE_TIG)
-        c = ctx.cigar_call()
+        ln.ctx.seq_pack(_lib.PAV_ROLE_TIG)
+        ln.counts = ln.ctx.cigar_call()
         lap('cigar_call')
         if workload == 'cigar+verify':
-            inv_state['verify'] = ctx.cigar_verify()
+            ln.verify = ln.ctx.cigar_verify()
         if workload == 'cigar+inv':
-            import contextlib
-            inv_state['flag'] = ctx.cigar_flag(flag_tp, flag_te, flag_params)   # signature flagging of the fresh calls
-            lap('cigar_flag')
-            with contextlib.redirect_stdout(io.StringIO()):                # scan_for_inv prints 'INV Found: ...' (inv.py:408)
-                inv_step()
-            lap('inv_step')
-        return c
+            inv_step(ln)
+            lap('flag + scan')
+
+    def run_steps(n, workload=args.workload, only=None):
+        """n passes of the hot path, one haplotype each: step s goes to lane s mod L; the lanes run on their own host threads
+        (the library releases the GIL inside its calls), so one haplotype's kernels fill the gaps of the other's host work."""
+        use = lanes if only is None else [only]
+        if len(use) == 1:
+            for _ in range(n):
+                step(use[0], workload)
+            return
+        err = []
+
+        def worker(ln):
+            try:
+                for _ in range(ln.idx, n, len(use)):
+                    step(ln, workload)
+            except BaseException as ex:      # noqa: BLE001 - re-raised on the main thread
+                err.append(ex)
+        ths = [threading.Thread(target=worker, args=(ln,)) for ln in use]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if err:
+            raise err[0]
 
     def fence():
-        ctx.sync()                       # the library's three streams, incl. call-table copies still travelling to the host
+        for ln in lanes:
+            ln.ctx.sync()                # the library's three streams, incl. call-table copies still travelling to the host
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        counts = step()
-    counts = step() if args.warmup == 0 else counts
-
-    # ---- timed region: exactly K steps, profiling off ---------------------------------------------------
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        counts = step()
-    ctx.sync()
-    torch.cuda.synchronize()
-    t_local = time.perf_counter() - t0
-    fence()
-    if world > 1:
-        tt = torch.tensor([t_local], dtype=torch.float64, device=comm_device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t_max = float(tt.item())
-        ab = torch.tensor([float(counts.aligned_bases)], dtype=torch.float64, device=comm_device)
-        dist.all_reduce(ab, op=dist.ReduceOp.SUM)
-        aligned_total = float(ab.item())
-    else:
-        t_max, aligned_total = t_local, float(counts.aligned_bases)
-
-    # ---- same K steps again with HIP events around every kernel (roofline leg) ---------------------------
-    ctx.prof_reset()
-    ctx.prof_enable(True)
-    for _ in range(args.steps):
-        step()
-    prof = ctx.prof_read()
-    ctx.prof_enable(False)
-
-    # ---- configs[1] in the same run: K steps of CIGAR-call only, timed and event-profiled the same way ----------------
-    def side_leg(workload):
-        for _ in range(max(1, args.warmup)):
-            step(workload)
+    def timed(n, workload=args.workload):
         fence()
         t_a = time.perf_counter()
-        for _ in range(args.steps):
-            step(workload)
-        ctx.sync()
+        run_steps(n, workload)
+        for ln in lanes:
+            ln.ctx.sync()
         torch.cuda.synchronize()
         t_c = time.perf_counter() - t_a
         fence()
         if world > 1:
             tt_ = torch.tensor([t_c], dtype=torch.float64, device=comm_device)
             dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
-            t_c = float(tt_.item())
+            return t_c, float(tt_.item())
+        return t_c, t_c
+
+    run_steps(max(args.warmup, n_lanes))                     # every lane at least once: buffers sized, tables known
+
+    # ---- timed region: exactly K steps, profiling off ---------------------------------------------------
+    t_local, t_max = timed(args.steps)
+    counts = lanes[0].counts
+    aligned_steps = float(sum(lanes[s % n_lanes].counts.aligned_bases for s in range(args.steps)))   # bp of the K passes of this rank
+    if world > 1:
+        ab = torch.tensor([aligned_steps], dtype=torch.float64, device=comm_device)
+        dist.all_reduce(ab, op=dist.ReduceOp.SUM)
+        aligned_total = float(ab.item())
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {'rank': rank, 'ms_per_step': round(t_local / args.steps * 1e3, 4),
+                                          'aligned_bp': aligned_steps / args.steps,
+                                          'cigar_text_bytes': int(sum(ln.text.shape[0] for ln in lanes))})
+    else:
+        aligned_total = aligned_steps
+        per_rank = [{'rank': 0, 'ms_per_step': round(t_local / args.steps * 1e3, 4), 'aligned_bp': aligned_steps / args.steps,
+                     'cigar_text_bytes': int(sum(ln.text.shape[0] for ln in lanes))}]
+
+    # ---- the same steps on ONE lane with HIP events around every kernel (roofline leg): nothing of another haplotype
+    #      beside them, so the sum of the kernel times is the device work of a step ---------------------------------------
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    run_steps(args.steps, only=lanes[0])
+    prof = ctx.prof_read()
+    ctx.prof_enable(False)
+    t_single = None
+    if n_lanes > 1:                                           # and timed without the events: what one lane alone achieves
+        fence()
+        t_a = time.perf_counter()
+        run_steps(args.steps, only=lanes[0])
+        ctx.sync()
+        t_single = time.perf_counter() - t_a
+
+    # ---- configs[1] in the same run: K steps of CIGAR-call only, timed and event-profiled the same way ----------------
+    def side_leg(workload):
+        run_steps(max(1, args.warmup), workload)
+        _, t_c = timed(args.steps, workload)
         ctx.prof_reset()
         ctx.prof_enable(True)
-        for _ in range(args.steps):
-            step(workload)
+        run_steps(args.steps, workload, only=lanes[0])
         leg = {'t': t_c, 'prof': ctx.prof_read()}
         ctx.prof_enable(False)
         return leg
@@ -272,6 +351,15 @@ def main():
     t0 = time.perf_counter()
     snv, indel, blob = ctx.cigar_fetch(counts)
     t_d2h = time.perf_counter() - t0
+    # ... and of the density tables of the inversion calls of lane 0's last scan (they stay packed in HBM unless --eager-tables)
+    t_d2h_tables = tables_mb = None
+    if args.workload == 'cigar+inv':
+        calls0 = [(i, c) for i, c in enumerate(lanes[0].out) if c is not None and not isinstance(c, RuntimeError)]
+        if calls0:
+            t0 = time.perf_counter()
+            views = [ctx.inv_table_view(i, c.native_table[2]) for i, c in calls0]      # the first one brings every round's block over
+            t_d2h_tables = time.perf_counter() - t0
+            tables_mb = sum(v[0]['INDEX'].shape[0] for v in views) * 40 / 1e6
 
     # End-to-end leg (N = 1 only, reported separately, never part of `value`): the two call_cigar tables of the whole
     # haplotype - FILTER, sort, TSV text, gzip - through the native writer, into a scratch directory.
@@ -307,7 +395,7 @@ def main():
             inv_tables = None
             if args.workload == 'cigar+inv':
                 # density tables of every inversion call as rule call_inv_batch writes them (density_{ID}_{hap}.tsv.gz)
-                calls = [(i, c) for i, c in enumerate(inv_state['out']) if c is not None and not isinstance(c, RuntimeError)]
+                calls = [(i, c) for i, c in enumerate(lanes[0].out) if c is not None and not isinstance(c, RuntimeError)]
                 den_dir = os.path.join(tmp_out, 'density')
                 os.makedirs(den_dir)
                 t0 = time.perf_counter()
@@ -333,22 +421,26 @@ def main():
 
     if rank == 0:
         ms_per_step = t_max / args.steps * 1e3
-        value = aligned_total * args.steps / t_max / 1e9
+        value = aligned_total / t_max / 1e9                 # bp of the K passes (all ranks) / slowest rank's wall time
         n_ops, n_snv, n_indel = counts.n_ops, counts.n_snv, counts.n_indel
         scanned_bp = 0
         if args.workload == 'cigar+inv':
             import re as _re
-            for ln in inv_state['log'].getvalue().splitlines():
+            for ln in lanes[0].log.getvalue().splitlines():
                 if ln.startswith('Scanning region: '):
                     m = _re.search(r':(\d+)-(\d+)', ln.split(': ')[1])
                     scanned_bp += int(m.group(2)) - int(m.group(1)) + 1
-        try:
-            with open(os.path.join(ROOT, 'profiles', 'r01_pmc.json')) as fh:
-                pmc = json.load(fh)
-            if pmc['workload']['aligned_bp_per_gpu'] != int(counts.aligned_bases):
-                pmc = None
-        except (OSError, KeyError, ValueError):
-            pmc = None
+        pmc = None                                            # committed PMC summary of this workload, newest round first
+        for pmc_name in ('r02_pmc.json', 'r01_pmc.json'):
+            try:
+                with open(os.path.join(ROOT, 'profiles', pmc_name)) as fh:
+                    cand = json.load(fh)
+                if cand['workload']['aligned_bp_per_gpu'] == int(counts.aligned_bases):
+                    pmc = cand
+                    pmc['file'] = 'profiles/' + pmc_name
+                    break
+            except (OSError, KeyError, ValueError):
+                pass
 
         def make_roofline(prof_, want=None):
             """Dominant kernel (largest total time in the profiled steps) against the HBM roofline: algorithmic bytes per
@@ -395,6 +487,39 @@ def main():
                                                     for k in sorted(alg_bytes) if k in kern_ and kern_[k]['avg_ms'] > 0}}
 
         kern, roofline = make_roofline(prof)
+        # ---- the honest roofline of the PATH (SURVEY.md section 8(d) byte model; the pack above is pre-processing the model
+        #      has no term for): algorithmic bytes of one step / step time.  CIGAR-call: 4 B / op + 64 B / row + 16 B / SNV +
+        #      40 B / indel + 2-bit SV bases + 0.5 B per scanned homology base (window bound: 128 B / indel) + 0.5 B per X base;
+        #      k-mer scan: 80 B per scanned region base.
+        path_bytes = (4.0 * n_ops + 64.0 * aln.shape[0] + 16.0 * n_snv + 40.0 * n_indel + 0.5 * counts.seq_bytes + 64.0 * n_indel +
+                      0.5 * n_snv)
+        scan_bytes = 80.0 * scanned_bp
+        sum_kernel_ms = sum(v['avg_ms'] * v['launches'] for v in kern.values()) / args.steps
+        roofline['path'] = {
+            'bound': 'hbm', 'unit': 'GB/s', 'peak': HBM_PEAK_GBS,
+            'algorithmic_bytes_per_step': {'cigar_call': round(path_bytes), 'kmer_scan': round(scan_bytes),
+                                           'contig_pack_not_in_the_model': round(tig_bases * 1.375)},
+            'achieved': round((path_bytes + scan_bytes) / (ms_per_step * 1e-3) / 1e9, 1),
+            'frac': round((path_bytes + scan_bytes) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            'frac_with_pack_counted': round((path_bytes + scan_bytes + tig_bases * 1.375) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            'sum_kernel_ms_per_step': round(sum_kernel_ms, 3),
+            'ms_per_step_over_sum_kernel_ms': round(ms_per_step / sum_kernel_ms, 3) if sum_kernel_ms else None,
+            'single_lane_ms_per_step': None if t_single is None else round(t_single / args.steps * 1e3, 4),
+            'note': 'SURVEY 8(d) bytes of one pass / ms_per_step: the path is bound by scattered 64 B sector fetches, dependent '
+                    'launches and host control, not by streamed bytes (DESIGN.md section 3); sum_kernel_ms_per_step = HIP-event '
+                    'time of every kernel of one pass, measured with one lane running alone'}
+        if pmc:
+            # measured HBM traffic over modelled bytes per launch, for every kernel that has both (committed PMC summary)
+            ratios = {}
+            model = make_roofline(prof)[1]
+            for k_, gbs in model['modelled_kernels_gbs'].items():
+                if k_ in pmc.get('fetch_kib', {}) and k_ in pmc.get('write_kib', {}) and kern[k_]['avg_ms'] > 0:
+                    fx = 2.0 if k_ in ('pack_kernel', 'verify_kernel') else 1.0
+                    tr = (pmc['fetch_kib'][k_] * fx + pmc['write_kib'][k_]) * 1024.0
+                    ab = gbs * 1e9 * kern[k_]['avg_ms'] * 1e-3
+                    if ab > 0:
+                        ratios[k_] = round(tr / ab, 2)
+            roofline['traffic_over_algorithmic'] = {'source': pmc.get('file'), 'ratio': ratios}
 
         def add_alone(roof):
             if pack_alone and pack_alone[0] and roof['kernel'] == 'pack_kernel':
@@ -406,10 +531,10 @@ def main():
                                  'cigar_call_without_pack': call_alone}
         add_alone(roofline)
         _, roof_v = make_roofline(verify_leg['prof'], want='verify_kernel')
-        vres = inv_state['verify']
+        vres = lanes[0].verify
         verify_mode = {'workload': 'CIGAR-call + verify: the packed reference and contig are streamed along every = / X operation and '
                                    'every base is checked against the CIGAR (pav_cigar_verify; the reference never looks at = runs)',
-                       'value': round(aligned_total * args.steps / verify_leg['t'] / 1e9, 2), 'unit': 'Gbp/s',
+                       'value': round(aligned_total / verify_leg['t'] / 1e9, 2), 'unit': 'Gbp/s',
                        'ms_per_step': round(verify_leg['t'] / args.steps * 1e3, 4), 'steps': args.steps,
                        'bases_checked': vres['eq_bases'] + vres['x_bases'], 'bases_contradicting_the_cigar': vres['eq_mismatch'] + vres['x_match'],
                        'roofline': roof_v}
@@ -419,7 +544,7 @@ def main():
             add_alone(roof_c)
             cigar_only = {'workload': 'BASELINE configs[1]: the same haplotype, CIGAR-call only (pack + tokenise + walk + homology + '
                                       'SEQ gather), measured in this run after the headline region',
-                          'value': round(aligned_total * args.steps / cigar_leg['t'] / 1e9, 2), 'unit': 'Gbp/s',
+                          'value': round(aligned_total / cigar_leg['t'] / 1e9, 2), 'unit': 'Gbp/s',
                           'ms_per_step': round(cigar_leg['t'] / args.steps * 1e3, 4), 'steps': args.steps, 'roofline': roof_c}
 
         cpu = None
@@ -445,6 +570,12 @@ def main():
                 if f != 'pad':
                     ok = ok and bool(np.array_equal(indel[f][:o_indel.shape[0]], o_indel[f]))
             cpu = {'value': round(sample_bp / c1 / 1e9, 4), 'unit': 'Gbp/s', 'cores': 1, 'kind': 'port',
+                   'reference_python': {'cigar_call_Mbp_per_s': 2.1, 'density_scan_kbp_per_s': 2.5, 'cores': 1,
+                                        'hardware': 'survey sandbox: 8 host cores (1 used), Python 3.10.12, numpy 2.2.6, pandas 2.3.3, '
+                                                    'scipy 1.15.3; pavlib 2.4.6 imported unmodified with shims for the absent modules',
+                                        'source': 'BASELINE.md section 2 (make_insdel_snv_calls on a 1 Mb contig: 0.48 s; scripts/density.py '
+                                                  'on a 25 kb region: 9.8 s); the reference Python never travels to the GPU box, so it '
+                                                  'cannot be re-timed here'},
                    'sample': f'first {sub.shape[0]} alignment rows of the same haplotype ({sample_bp / 1e9:.3f} Gbp aligned, '
                              f'{o_snv.shape[0]} SNV, {o_indel.shape[0]} INDEL), oracle/ scalar C walk incl. per-contig '
                              f'upper-casing and reverse complement, {c1:.1f} s wall',
@@ -483,11 +614,10 @@ def main():
                 fai = pd.Series(ref_lengths)
                 ref_i, tig_i = {n: i for i, n in enumerate(names)}, {n: i for i, n in enumerate(hap.tig_names)}
                 jobs, pairs = [], []
-                for _, row in hap.df_flag.iterrows():
-                    r = pavseq3.Region(row['#CHROM'], row['POS'], row['END'])
+                for r in lanes[0].regions:                  # the loci this haplotype's flagging produced and the step scanned
                     r.expand(4000, min_pos=0, max_end=fai, shift=True)
                     try:
-                        t = lift.lift_region_to_qry(r)
+                        t = lanes[0].lift.lift_region_to_qry(r)
                     except RuntimeError:
                         t = None
                     if t is None or len(r) > 60_000:
@@ -532,16 +662,16 @@ def main():
         inv_report = None
         if args.workload == 'cigar+inv':
             from pav_amd import seq as pavseq2
-            out = inv_state['out']
+            out = lanes[0].out
             scanned = iters = 0
-            for ln in inv_state['log'].getvalue().splitlines():
+            for ln in lanes[0].log.getvalue().splitlines():
                 if ln.startswith('Scanning region: '):
                     scanned += len(pavseq2.region_from_string(ln.split(': ')[1]))
                     iters += 1
             flag_kernels = ('k_snv_keys', 'k_indel_keys', 'k_indel_mid', 'k_cluster_emit', 'k_insdel_split', 'k_ins_match',
                             'rocprim::radix_sort_keys', 'rocprim::radix_sort_pairs', 'rocprim::inclusive_scan')
             den = {k: v for k, v in kern.items() if k.startswith('k_') and k not in flag_kernels}
-            f_tables, f_loci, f_counts = inv_state['flag']
+            f_tables, f_loci, f_counts = lanes[0].flag
             # every planted inversion that is aligned through shows up as a CLUSTER_SNV locus: count the overlaps
             rank_of = {n: i for i, n in enumerate(sorted(names))}
             hit = 0
@@ -554,12 +684,15 @@ def main():
                            'device_ms_per_step': round(sum(kern[k]['avg_ms'] * kern[k]['launches'] for k in flag_kernels if k in kern) / args.steps, 3),
                            'note': 'pav_cigar_flag inside the timed step: FILTER + sort + cluster sweeps + INS/DEL matching on the '
                                    'device, interval merges on the host (rules call_inv_cluster, call_inv_flag_insdel_cluster, '
-                                   'call_inv_merge_flagged_loci); the scan below runs on the generator\'s flagged regions '
-                                   '(planted inversions + decoys), a superset of what the default inv_sig_filter would try'}
-            inv_report = {'flagging': flag_report, 'flagged_regions': len(out), 'calls': sum(1 for o in out if o is not None and not isinstance(o, RuntimeError)),
+                                   'call_inv_merge_flagged_loci), inv_sig_filter = single_cluster; the scan below runs on exactly the '
+                                   'loci with TRY_INV this call produced (planted inversions: SNV clusters; generator-planted matched '
+                                   'DEL + INS pairs: MATCH_INDEL)'}
+            inv_report = {'flagging': flag_report, 'scanned_loci': len(out),
+                          'near_tie_guard': {'n_near_tie': int(sum(getattr(o, 'n_near_tie', 0) for o in out if o is not None and not isinstance(o, RuntimeError))),
+                                             'note': 'float decisions of the calls\' scans within 1e-9 (re-evaluated in scipy\'s order)'}, 'calls': sum(1 for o in out if o is not None and not isinstance(o, RuntimeError)),
                           'planted': hap.stats['n_inv'], 'scan_iterations': iters, 'scanned_bp': scanned,
                           'device_ms_per_step': round(sum(v['avg_ms'] * v['launches'] for v in den.values()) / args.steps, 3),
-                          'host_ms': {'align_table_once': round(inv_state['t_lift_ms'], 1), 'scan_for_inv_batch_last_step': round(inv_state['t_scan_ms'], 1)},
+                          'host_ms': {'align_table_once': round(lanes[0].t_lift_ms, 1), 'scan_for_inv_batch_last_step': round(lanes[0].t_scan_ms, 1)},
                           'note': 'wall time of the step includes the Python scan control (lift-over, expansion logic, '
                                   'DataFrame of every call); device_ms_per_step is the sum of the density kernels'}
         metric = ('aligned Gbp/s through CIGAR-call only (tokenise + walk + homology + SEQ gather + contig pack); bit-exact vs pavlib'
@@ -572,18 +705,32 @@ def main():
             'dtype': 'u8/u32 (integer + byte)', 'data': 'synthetic',
             'config': {'workload': ('BASELINE configs[1]: one hg38-shaped haplotype, CIGAR-call only, one haplotype per GPU'
                                     if args.workload == 'cigar' else
-                                    'BASELINE configs[2] at one haplotype per GPU: hg38-shaped haplotype, CIGAR-call + signature flagging '
-                                    '+ k-mer inversion density scan of all flagged regions (configs[1] = CIGAR-call only: see cigar_only)'),
+                                    f'BASELINE configs[2]: phased diploid sample (h1 + h2, hg38-shaped), {n_lanes} haplotype(s) resident per GPU '
+                                    'against one resident reference; a step = one haplotype through CIGAR-call + signature flagging + '
+                                    'k-mer inversion density scan of every locus the flagging marks TRY_INV; steps alternate between the '
+                                    'haplotypes (configs[1] = CIGAR-call only: see cigar_only)'),
                        'scale': args.scale, 'seed': args.seed, 'aligned_bp_per_gpu': int(counts.aligned_bases),
                        'n_aln': int(aln.shape[0]), 'n_ops': int(n_ops), 'n_snv': int(n_snv), 'n_indel': int(n_indel),
-                       'parallelism': f'{world} x (1 haplotype / GPU), no collective'},
+                       'lanes_per_gpu': n_lanes, 'pair_frac': args.pair_frac if gen_kw else 0.0,
+                       'call_tables': 'copied to pinned host memory inside the step' if args.eager_tables else 'resident in HBM (D2H in host.d2h_density_tables_s)',
+                       'parallelism': f'{world} GPU(s) x {n_lanes} resident haplotype(s), one host thread each; no collective'},
+            'per_rank': per_rank,
+            'load_balance': {'max_over_mean_ms': round(max(r['ms_per_step'] for r in per_rank) / (sum(r['ms_per_step'] for r in per_rank) / len(per_rank)), 4),
+                             'max_over_mean_cigar_text': round(max(r['cigar_text_bytes'] for r in per_rank) /
+                                                               (sum(r['cigar_text_bytes'] for r in per_rank) / len(per_rank)), 4),
+                             'note': 'haplotype -> GPU; every rank holds whole haplotypes (weak scaling), so the balance is the '
+                                     'haplotypes\' own size spread'},
             'roofline': roofline, 'cpu_baseline': cpu, 'cigar_only': cigar_only, 'verify_mode': verify_mode, 'inv_scan': inv_report,
             'end_to_end': e2e,
             'host': {'generate_s': round(t_gen, 1), 'h2d_and_ref_pack_s': round(t_h2d, 2), 'd2h_records_s': round(t_d2h, 3),
+                     'd2h_density_tables_s': None if t_d2h_tables is None else round(t_d2h_tables, 4),
+                     'density_tables_mb': None if tables_mb is None else round(tables_mb, 1),
+                     'cpu_baseline_cores_all': None if not cpu or 'all_cores' not in cpu else cpu['all_cores'].get('cores'),
                      'device': ctx.device_name},
         }
         print(json.dumps(line), flush=True)
-    ctx.close()
+    for ln in lanes[::-1]:
+        ln.ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -48,6 +48,7 @@ void pav_destroy(pav_ctx *ctx);
 const char *pav_last_error(const pav_ctx *ctx);
 int pav_device_name(const pav_ctx *ctx, char *buf, int buf_len);
 int pav_sync(pav_ctx *ctx);                       /* hipStreamSynchronize on the context's stream          */
+int pav_mem_info(pav_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);   /* HBM of the context's GPU (hipMemGetInfo) */
 
 /* ---- sequence store ----------------------------------------------------------------------------------- *
  * Replaces: pysam.FastaFile.fetch of whole records + str.upper() of the whole chromosome / contig per
@@ -57,6 +58,14 @@ int pav_sync(pav_ctx *ctx);                       /* hipStreamSynchronize on the
  * with str.upper().  Reverse-complemented contigs are never materialised; kernels index them in place.
  */
 int pav_seq_load(pav_ctx *ctx, int role, uint32_t n_seq, const uint8_t *const *ascii, const uint64_t *len);
+/* Use the store `from` holds for `role` (no copy: both contexts read the same planes in HBM; they must be on the same GPU).
+ * This is how several haplotypes are kept resident against ONE reference (BASELINE.json configs[3], [4]; the reference
+ * treats haplotypes as independent jobs, README.md:83-86, rules/call.snakefile:755-786): one context per haplotype - each
+ * with its own streams, contigs, alignment tables and results, drivable from its own host thread - all sharing the
+ * reference context's PAV_ROLE_REF store.  The planes are freed with their last user.  A later pav_seq_load for that
+ * role gives the context a store of its own again; re-packing a shared store (pav_seq_pack) while others use it is
+ * the caller's race.  Record names (pav_seq_set_names) are per context and are not copied. */
+int pav_seq_share(pav_ctx *ctx, const pav_ctx *from, int role);
 
 /* Native FASTA reader (host only; no context needed).  Replaces pysam.FastaFile(path).fetch(name) of the reference
  * (pavlib/cigarcall.py:59-66, pavlib/seq.py:339-351) for whole records: plain, gzip and BGZF files (PAV bgzips its
@@ -128,7 +137,11 @@ enum {                    /* pav_cigar_err.kind                                 
     PAV_CIGAR_ERR_MISSING_LEN = 3,   /* pavlib/align/align.py:310-313                                       */
     PAV_CIGAR_ERR_UNKNOWN_OP = 4,    /* pavlib/align/align.py:315-318                                       */
     PAV_CIGAR_ERR_TRUNCATED = 5,     /* text ends inside a length: IndexError at align.py:307               */
-    PAV_CIGAR_ERR_LEN_OVERFLOW = 6   /* operation length >= 2^28 (not representable in BAM either)          */
+    PAV_CIGAR_ERR_LEN_OVERFLOW = 6,  /* operation length >= 2^28 (not representable in BAM either)          */
+    PAV_CIGAR_ERR_RANGE = 7          /* the row (POS + its = / X / D lengths, or its query lengths) does not fit the
+                                        reference record / contig it names: pavlib indexes Python strings and raises
+                                        IndexError at the first X base past the end (pavlib/cigarcall.py:104-105); here
+                                        the whole row is refused before any kernel reads past a record; aln = the row   */
 };
 
 typedef struct {
@@ -340,6 +353,11 @@ typedef struct {
     uint32_t n_srs;                 /* get_srs_tree intervals (inv.py:564-620)                                      */
     const pav_srs *srs;
     pav_den_params den;
+    uint32_t lazy_tables;           /* 0: the density tables of the calls are copied to the library's pinned host memory
+                                       behind the scan (copy stream).  1: they stay packed in HBM; the first pav_inv_table* /
+                                       pav_inv_write_tables call that needs them brings them over (like the SNV / INDEL
+                                       records of pav_cigar_call, which stay in HBM until pav_cigar_fetch)              */
+    uint32_t reserved;
 } pav_inv_params;
 
 typedef struct {            /* pavlib.seq.Region as the scan reports it                                            */

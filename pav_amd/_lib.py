@@ -81,7 +81,7 @@ class Srs(ctypes.Structure):
 
 class InvParams(ctypes.Structure):
     _fields_ = [('max_region_size', ctypes.c_int64), ('min_exp_count', ctypes.c_int32), ('n_srs', ctypes.c_uint32),
-                ('srs', ctypes.POINTER(Srs)), ('den', DenParams)]
+                ('srs', ctypes.POINTER(Srs)), ('den', DenParams), ('lazy_tables', ctypes.c_uint32), ('reserved', ctypes.c_uint32)]
 
 
 class InvRgn(ctypes.Structure):
@@ -181,8 +181,10 @@ SYMBOLS = {
     'pav_last_error': (ctypes.c_char_p, [_P]),
     'pav_device_name': (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int]),
     'pav_sync': (ctypes.c_int, [_P]),
+    'pav_mem_info': (ctypes.c_int, [_P, _P, _P]),
     'pav_cigar_verify': (ctypes.c_int, [_P, _P]),
     'pav_seq_load': (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_uint32, _P, _P]),
+    'pav_seq_share': (ctypes.c_int, [_P, _P, ctypes.c_int]),
     'pav_seq_pack': (ctypes.c_int, [_P, ctypes.c_int]),
     'pav_seq_count': (ctypes.c_int, [_P, ctypes.c_int, _P, _P]),
     'pav_cigar_load': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P]),
@@ -345,6 +347,12 @@ class Context:
     def sync(self):
         self._check(self.lib.pav_sync(self.handle), 'pav_sync')
 
+    def mem_info(self):
+        """(free, total) bytes of HBM on the context's GPU."""
+        f, t = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._check(self.lib.pav_mem_info(self.handle, ctypes.byref(f), ctypes.byref(t)), 'pav_mem_info')
+        return int(f.value), int(t.value)
+
     # -- sequences ----------------------------------------------------------------------------------------
     def seq_load(self, role, names, arrays):
         """Upload and pack all records of one role.  ``arrays``: list of contiguous uint8 ASCII arrays."""
@@ -354,6 +362,15 @@ class Context:
         lens = (ctypes.c_uint64 * max(n, 1))(*[a.shape[0] for a in arrays])
         self._check(self.lib.pav_seq_load(self.handle, role, n, ptrs, lens), 'pav_seq_load')
         self._seq_names[role] = [str(x) for x in names]
+        cnames = (ctypes.c_char_p * max(n, 1))(*[x.encode() for x in self._seq_names[role]])
+        self._check(self.lib.pav_seq_set_names(self.handle, role, n, cnames), 'pav_seq_set_names')
+
+    def seq_share(self, other, role=PAV_ROLE_REF):
+        """Read ``other``'s resident records of ``role`` (same GPU) instead of holding a copy: one context per haplotype, one
+        reference for all of them (``pav_seq_share``)."""
+        self._check(self.lib.pav_seq_share(self.handle, other.handle, role), 'pav_seq_share')
+        self._seq_names[role] = list(other._seq_names[role])
+        n = len(self._seq_names[role])
         cnames = (ctypes.c_char_p * max(n, 1))(*[x.encode() for x in self._seq_names[role]])
         self._check(self.lib.pav_seq_set_names(self.handle, role, n, cnames), 'pav_seq_set_names')
 

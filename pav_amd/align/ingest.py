@@ -2,7 +2,7 @@
 Alignment ingest: SAM -> the alignment table the rest of PAV works on.
 
 Mirror of ``pavlib.align.get_align_bed`` (pavlib/align/align.py:666-794) without pysam: the SAM text is parsed by the library
-(``pav_sam_open``, csrc/samio.hip - record fields, soft clipping folded into hard clipping, ``count_cigar``), this module
+(``pav_sam_open``, csrc/samio.cpp - record fields, soft clipping folded into hard clipping, ``count_cigar``), this module
 applies the reference's per-record rules, raises its errors and builds its all-object DataFrame, sorted with the reference's
 own ``sort_values`` call.
 """

@@ -4,7 +4,7 @@ Alignment trimming: mirror of ``pavlib.align.trim_alignments`` and ``trim_alignm
 
 The DataFrame, the reference's sorts and the error texts live here; the pair loops (``trim_alignment_record``,
 ``trace_cigar_to_zero``, ``find_cut_sites``) run inside the library on CIGARs tokenised once on the device
-(``pav_trim_load`` / ``pav_trim_pass`` / ``pav_trim_fetch``, csrc/trim.hip).
+(``pav_trim_load`` / ``pav_trim_pass`` / ``pav_trim_fetch``, csrc/trim.cpp).
 """
 
 import numpy as np

@@ -45,7 +45,10 @@ def pack_alignments(df_align, ref_names, tig_names):
             aln['tig_id'] = [tig_index[str(q)] for q in df_align['QRY_ID']]
         except KeyError as ex:
             raise KeyError(f'sequence {ex} of the alignment table is not in the FASTA') from ex
-        aln['pos'] = df_align['POS'].to_numpy(dtype=np.int64)
+        pos = df_align['POS'].to_numpy(dtype=np.int64)
+        if pos.min() < 0 or pos.max() >= 0xFFFFFF00:
+            raise ValueError('POS of the alignment table must be in [0, 2^32 - 256): got {} .. {}'.format(pos.min(), pos.max()))
+        aln['pos'] = pos
         aln['rev'] = [1 if bool(v) else 0 for v in df_align['REV']]
     cigars = [str(c).encode() for c in df_align['CIGAR']] if n else []
     off = np.zeros(n + 1, dtype=np.uint64)
@@ -110,6 +113,8 @@ def _raise_reference_error(detail, df_align):
     if kind == 6:
         raise RuntimeError('CIGAR operation length >= 2^28 for contig {} alignment starting at {}:{}: CIGAR index {}'.format(
             row['QRY_ID'], row['#CHROM'], row['POS'], detail.op_index))
+    if kind == 7:      # the alignment row does not fit the sequences: ``seq_ref[pos_ref + i]`` past the end, cigarcall.py:104-105
+        raise IndexError('string index out of range')
     raise RuntimeError(f'unknown CIGAR error kind {kind}')
 
 

@@ -22,7 +22,7 @@ struct pav_bed {
 
 namespace pav {
 
-const std::vector<std::string> &seq_names(pav_ctx *ctx, int role);   // invscan.hip
+const std::vector<std::string> &seq_names(pav_ctx *ctx, int role);   // invscan.cpp
 
 namespace {
 

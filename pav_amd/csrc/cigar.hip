@@ -217,17 +217,27 @@ __device__ __forceinline__ void load_ops(const uint32_t *__restrict__ ops, uint6
 }
 
 __global__ __launch_bounds__(256) void walk_reduce(const uint32_t *__restrict__ ops, uint64_t n_ops,
-                                                   uint64_t *__restrict__ chunk_sum /* [n_chunks][NQ] */) {
+                                                   uint64_t *__restrict__ chunk_sum /* [n_chunks][NQ] */,
+                                                   unsigned long long *__restrict__ err_op) {
     __shared__ uint64_t lds[4 * NQ];
     uint32_t o[OPS_PER_LANE];
-    load_ops(ops, n_ops, (uint64_t)blockIdx.x * WALK_CHUNK + (uint64_t)threadIdx.x * OPS_PER_LANE, o);
+    const uint64_t first = (uint64_t)blockIdx.x * WALK_CHUNK + (uint64_t)threadIdx.x * OPS_PER_LANE;
+    load_ops(ops, n_ops, first, o);
     uint64_t s[NQ] = {0, 0, 0, 0, 0, 0};
+    unsigned long long bad = ~0ull;                                    // first M / N / P op of the lane (cigarcall.py:289-307)
 #pragma unroll
     for (int j = 0; j < OPS_PER_LANE; ++j) {
         uint64_t c[NQ];
         op_contrib(o[j], c);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) s[q] += c[q];
+        const uint32_t code = o[j] & 15u;
+        if ((code == 0u || code == 3u || code == 6u || code > 8u) && bad == ~0ull) bad = first + j;
+    }
+    if (__ballot(bad != ~0ull)) {                                      // rare: the first one in walk order wins
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const unsigned long long y = __shfl_xor(bad, d); bad = y < bad ? y : bad; }
+        if ((threadIdx.x & 63) == 0 && bad != ~0ull) atomicMin(err_op, bad);
     }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -290,7 +300,8 @@ __global__ __launch_bounds__(256) void walk_chunks(const uint64_t *__restrict__ 
         totals[threadIdx.x] = mine;
         chunk_pre[(uint64_t)n_chunks * NQ + threadIdx.x] = mine;           // read by rows that start at n_ops
         if (host_status) host_status[threadIdx.x] = mine;
-    } else if (threadIdx.x == NQ && host_status) host_status[NQ] = totals[NQ];   // tokenizer error key (tok_emit / row_ops ran before us)
+    } else if (threadIdx.x <= NQ + 1 && host_status) host_status[threadIdx.x] = totals[threadIdx.x];   // tokenizer error key (tok_emit /
+                                                                       // row_ops ran before us), illegal-op ordinal (walk_reduce)
     // the status block goes straight into the host's pinned words (mapped into the device's address space): one copy fewer per
     // call (and under rocprofv3, where copies run as shader kernels, such a copy did not retire before the concurrent pack)
 }
@@ -318,6 +329,30 @@ __global__ __launch_bounds__(256) void row_base(const uint32_t *__restrict__ ops
     if (lane == 0) {
         rowbase[2ull * r] = chunk_pre[c * NQ + 0] + a;
         rowbase[2ull * r + 1] = chunk_pre[c * NQ + 1] + b;
+    }
+}
+
+// Single workgroup: every row's span against the records it names - POS + reference advance must fit the reference record, the
+// query advance the contig (pavlib indexes Python strings: an X base past the end raises IndexError, cigarcall.py:104-105;
+// here any row that does not fit is refused before a kernel reads past a record).  host_status[NQ + 2] = first such row or ~0.
+__global__ __launch_bounds__(256) void row_check(const pav_aln *__restrict__ aln, const uint64_t *__restrict__ rowbase,
+                                                 const uint64_t *__restrict__ totals, SeqView ref, SeqView tig, uint32_t n_aln,
+                                                 volatile uint64_t *host_status) {
+    __shared__ unsigned long long red[4];
+    unsigned long long bad = ~0ull;
+    for (uint32_t r = threadIdx.x; r < n_aln; r += 256) {
+        const uint64_t ra = (r + 1 < n_aln ? rowbase[2ull * (r + 1)] : totals[0]) - rowbase[2ull * r];
+        const uint64_t ta = (r + 1 < n_aln ? rowbase[2ull * (r + 1) + 1] : totals[1]) - rowbase[2ull * r + 1];
+        const pav_aln a = aln[r];
+        if ((uint64_t)a.pos + ra > ref.len[a.ref_id] || ta > tig.len[a.tig_id]) { if (r < bad) bad = r; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const unsigned long long y = __shfl_xor(bad, d); bad = y < bad ? y : bad; }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = bad;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) bad = red[w] < bad ? red[w] : bad;
+        host_status[NQ + 2] = bad;
     }
 }
 
@@ -428,7 +463,7 @@ __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
                 A.indel[run[3]] = r;
                 }
             } else if (code != 7 && code != 4 && code != 5) {                  // M, N, P: cigarcall.py:289-307
-                if constexpr (MODE == WALK_INDEL) atomicMin(A.err_op, (unsigned long long)k);   // first one in walk order wins
+                // reported by walk_reduce (before any row is emitted); nothing to write for it
             }
             uint64_t c[NQ];
             op_contrib(o[j], c);
@@ -1347,17 +1382,25 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
         d_csum = ctx->d_chunk2.as<uint64_t>();
         d_cpre = d_csum + (size_t)NQ * (n_wchunks + 1);
         PAV_HIP(ctx, ctx->d_rowbase.reserve(2 * sizeof(uint64_t) * ((size_t)n_aln + 1) + sizeof(uint32_t) * ((size_t)n_wchunks + 1)));
-        PAV_LAUNCH(ctx, "walk_reduce", walk_reduce, n_wchunks, 256, 0, ctx->d_ops.as<uint32_t>(), n_ops, d_csum);
+        PAV_LAUNCH(ctx, "walk_reduce", walk_reduce, n_wchunks, 256, 0, ctx->d_ops.as<uint32_t>(), n_ops, d_csum, d_err_op);
         PAV_LAUNCH(ctx, "walk_chunks", walk_chunks, 1, 256, 0, d_csum, d_cpre, ctx->d_totals.as<uint64_t>(), n_wchunks, h_status);
         PAV_LAUNCH(ctx, "row_base", row_base, (n_aln + 3) / 4, 256, 0, ctx->d_ops.as<uint32_t>(),
                    ctx->d_op_off.as<uint64_t>(), d_cpre, ctx->d_rowbase.as<uint64_t>(),
                    reinterpret_cast<uint32_t *>(ctx->d_rowbase.as<uint64_t>() + 2 * ((size_t)n_aln + 1)), n_aln);
+        PAV_LAUNCH(ctx, "row_check", row_check, 1, 256, 0, ctx->d_aln.as<pav_aln>(), ctx->d_rowbase.as<uint64_t>(),
+                   ctx->d_totals.as<uint64_t>(), ctx->seq[PAV_ROLE_REF].view(), ctx->seq[PAV_ROLE_TIG].view(), n_aln, h_status);
     } else {
+        h_status[NQ + 2] = ~0ull;
         PAV_HIP(ctx, hipMemcpyAsync(h_status, ctx->d_totals.p, (NQ + 2) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     }
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int q = 0; q < NQ; ++q) totals[q] = h_status[q];
     errs[0] = h_status[NQ];
+    errs[1] = h_status[NQ + 1];
+    const uint64_t range_row = h_status[NQ + 2];
+    // Any error is known by now (malformed token, illegal operation, a row that does not fit its records): nothing is emitted,
+    // the kernels below would walk garbage or read past a record.
+    const bool refuse = errs[0] != ~0ull || errs[1] != ~0ull || range_row != ~0ull;
 
     ctx->counts.n_ops = n_ops;
     ctx->counts.n_snv = totals[2];
@@ -1366,7 +1409,7 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
     ctx->counts.aligned_bases = totals[5];
 
     // --- emit + homology + SEQ gather ---------------------------------------------------------------------
-    if (n_wchunks) {
+    if (n_wchunks && !refuse) {
         PAV_HIP(ctx, ctx->d_snv.reserve(sizeof(pav_snv) * (totals[2] + 1)));
         PAV_HIP(ctx, ctx->d_indel.reserve(sizeof(pav_indel) * (totals[3] + 1)));
         const uint64_t blob_bytes = round_up(totals[4] + 16, 16);                 // SEQ bytes, then seq_gather's block index
@@ -1400,16 +1443,12 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
                            ctx->d_seqblob.as<uint8_t>(), totals[4], d_seq_blk);
         }
         if (totals[2]) PAV_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->snv_done, 0));   // later readers of the SNV rows use this stream
-        PAV_HIP(ctx, hipMemcpyAsync(h_status, d_tok_err, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-        PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        errs[0] = h_status[0];
-        errs[1] = h_status[1];
     }
     if (counts) *counts = ctx->counts;
     ctx->cigar_called = true;
 
     // --- errors: the first one the sequential walk would have hit ------------------------------------------
-    if (errs[0] != ~0ull || errs[1] != ~0ull) {
+    if (refuse) {
         // Resolve on the host (error path only): fetch op offsets and, for an illegal op, the row's ops.
         std::vector<uint64_t> op_off((size_t)n_aln + 1), text_off((size_t)n_aln + 1);
         PAV_HIP(ctx, hipMemcpy(op_off.data(), ctx->d_op_off.p, sizeof(uint64_t) * op_off.size(), hipMemcpyDeviceToHost));
@@ -1459,6 +1498,14 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
             ill_ord = ((uint64_t)ill.aln << 32) | (uint64_t)ill.op_index;
         }
         ctx->cigar_err = (ill_ord < tok_ord) ? ill : tok;
+        // a row that does not fit its records is reported unless a token / operation error comes first in walk order (same
+        // row included: the reference meets those while it still walks inside the sequence)
+        if (range_row != ~0ull && (std::min(ill_ord, tok_ord) >> 32) > range_row) {
+            pav_cigar_err rg{};
+            rg.kind = PAV_CIGAR_ERR_RANGE;
+            rg.aln = (uint32_t)range_row;
+            ctx->cigar_err = rg;
+        }
         ctx->cigar_called = false;
         return fail(ctx, PAV_E_CIGAR, "CIGAR error kind %d at alignment row %u", ctx->cigar_err.kind, ctx->cigar_err.aln);
     }

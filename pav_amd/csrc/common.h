@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -52,10 +53,25 @@ struct SeqStore {
     uint64_t total = 0;                   // bases excl. padding
     std::vector<uint64_t> off, len;
     DevBuf d_ascii, d_two, d_mask, d_dirty, d_off, d_len;
+    int device = -1;                      // where the planes live (shared stores: all users sit on this device)
     SeqView view() const {
         return SeqView{d_ascii.as<uint8_t>(), d_two.as<uint32_t>(), d_mask.as<uint32_t>(), d_dirty.as<uint8_t>(),
                        d_off.as<uint64_t>(), d_len.as<uint64_t>(), n};
     }
+    void release() { for (DevBuf *b : {&d_ascii, &d_two, &d_mask, &d_dirty, &d_off, &d_len}) b->release(); n = 0; arena = total = 0; }
+    SeqStore() = default;
+    SeqStore(const SeqStore &) = delete;
+    SeqStore &operator=(const SeqStore &) = delete;
+    ~SeqStore() { if (device >= 0) (void)hipSetDevice(device); release(); }
+};
+
+// The two stores of a context.  A store can be shared between contexts on the same GPU (pav_seq_share): a cohort's
+// haplotypes - one context each, driven from their own host threads - read ONE resident reference.
+struct SeqSlots {
+    std::shared_ptr<SeqStore> p[2];
+    SeqSlots() { p[0] = std::make_shared<SeqStore>(); p[1] = std::make_shared<SeqStore>(); }
+    SeqStore &operator[](int role) { return *p[role]; }
+    const SeqStore &operator[](int role) const { return *p[role]; }
 };
 
 // ---- profiling --------------------------------------------------------------------------------------------
@@ -81,7 +97,7 @@ struct pav_ctx {
     char dev_name[256] = {0};
     int n_cu = 0;
 
-    pav::SeqStore seq[2];
+    pav::SeqSlots seq;
 
     // CIGAR state
     uint32_t n_aln = 0;
@@ -98,9 +114,9 @@ struct pav_ctx {
 
     // density state lives in density.hip (opaque here)
     void *density = nullptr;
-    void *invscan = nullptr;              // native scan driver state (invscan.hip)
+    void *invscan = nullptr;              // native scan driver state (invscan.cpp)
     void *flag = nullptr;                 // flagging scratch + results (flag.hip)
-    void *trim = nullptr;                 // alignment trimming state (trim.hip)
+    void *trim = nullptr;                 // alignment trimming state (trim.cpp)
 
     // profiling
     bool prof_on = false;
@@ -153,10 +169,22 @@ struct CallFetch {              // one call of the batch still resident on the d
     int64_t base, tig_up_pos, tig_up_end, tig_dn_pos, tig_dn_end;
     uint32_t *index; int8_t *state_mer, *state; double *kern[3]; uint64_t *kmer; uint8_t *flank, *match;   // pinned host
 };
-// Density tables + FLANK / MATCH of all calls of the last batch: everything is queued, one synchronisation.
+// The packed call tables of one scan round on the device (+ the flank k-mer sets and descriptors in front of / behind them)
+// and the copies that bring them to the host block of the round.
+struct CallStage {
+    DevBuf buf;
+    std::vector<uint8_t> desc_host;
+    struct Copy { const void *src; void *dst; size_t bytes; };
+    Copy copies[2];
+    int n_copies = 0;
+};
+// Density tables + FLANK / MATCH of all calls of the last batch, packed into `stage` in the host block's column order.
 // k1_rows: rows of the leading calls whose KERN_FWDREV column is wanted; the column of the calls behind them (no FWDREV
 // k-mers: all zeros, scripts/density.py:313-323) is not sent over PCIe.  = all rows to copy everything.
-int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls, uint64_t k1_rows);
+// copy_now: queue the device-to-host copies on the copy stream at once; otherwise they are left in stage.copies for
+// stage_copy() - the tables stay in HBM until a reader asks for them.
+int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls, uint64_t k1_rows, CallStage &stage, bool copy_now);
+int stage_copy(pav_ctx *ctx, CallStage &stage);
 
 // ---- device helpers shared by kernels ---------------------------------------------------------------------
 

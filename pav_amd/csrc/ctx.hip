@@ -201,9 +201,9 @@ pav_ctx *pav_create(int device_id) {
 }
 
 void pav_density_release(pav_ctx *ctx);   // density.hip
-void pav_invscan_release(pav_ctx *ctx);   // invscan.hip
+void pav_invscan_release(pav_ctx *ctx);   // invscan.cpp
 void pav_flag_release(pav_ctx *ctx);      // flag.hip
-void pav_trim_release(pav_ctx *ctx);      // trim.hip
+void pav_trim_release(pav_ctx *ctx);      // trim.cpp
 
 void pav_destroy(pav_ctx *ctx) {
     if (!ctx) return;
@@ -217,10 +217,7 @@ void pav_destroy(pav_ctx *ctx) {
     pav_trim_release(ctx);
     for (auto &p : ctx->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto ev : ctx->ev_pool) (void)hipEventDestroy(ev);
-    for (int r = 0; r < 2; ++r) {
-        SeqStore &s = ctx->seq[r];
-        s.d_ascii.release(); s.d_two.release(); s.d_mask.release(); s.d_dirty.release(); s.d_off.release(); s.d_len.release();
-    }
+    for (int r = 0; r < 2; ++r) ctx->seq.p[r].reset();              // the planes go with their last user
     DevBuf *bufs[] = {&ctx->d_aln, &ctx->d_text, &ctx->d_text_off, &ctx->d_ops, &ctx->d_op_off, &ctx->d_chunk,
                       &ctx->d_chunk2, &ctx->d_rowbase, &ctx->d_totals, &ctx->d_snv, &ctx->d_indel,
                       &ctx->d_seqblob, &ctx->d_tmp, &ctx->ix_text, &ctx->ix_off, &ctx->ix_pos, &ctx->ix_ops, &ctx->ix_op_off,
@@ -259,26 +256,34 @@ int pav_sync(pav_ctx *ctx) {
 int pav_seq_load(pav_ctx *ctx, int role, uint32_t n_seq, const uint8_t *const *ascii, const uint64_t *len) {
     if (!ctx || (role != PAV_ROLE_REF && role != PAV_ROLE_TIG)) return fail(ctx, PAV_E_ARG, "pav_seq_load: bad role");
     if (n_seq && (!ascii || !len)) return fail(ctx, PAV_E_ARG, "pav_seq_load: null input");
-    PAV_HIP(ctx, hipSetDevice(ctx->device));
-    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream2));   // a re-pack of the old arena may still be running
-    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->pack_pending[role] = false;
-    SeqStore &s = ctx->seq[role];
-    s.n = n_seq;
-    s.off.assign(n_seq, 0);
-    s.len.assign(len, len + n_seq);
+    // lengths are checked and the layout is planned before the store is touched: a refused call leaves it as it was
+    std::vector<uint64_t> off(n_seq, 0);
     uint64_t a = 0, total = 0;
     for (uint32_t i = 0; i < n_seq; ++i) {
         if (len[i] >= 0xFFFFFF00ull)
             return fail(ctx, PAV_E_LIMIT, "pav_seq_load: record %u has %llu bases (limit 2^32 - 256)", i,
                         (unsigned long long)len[i]);
-        s.off[i] = a;
+        off[i] = a;
         a += (len[i] + SEQ_ALIGN - 1) / SEQ_ALIGN * SEQ_ALIGN + SEQ_ALIGN;   // one pad block between records
         total += len[i];
     }
-    s.arena = a;
-    s.total = total;
-    if (a == 0) return PAV_OK;
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream2));   // a re-pack of the old arena may still be running
+    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pack_pending[role] = false;
+    if (ctx->seq.p[role].use_count() > 1) ctx->seq.p[role] = std::make_shared<SeqStore>();   // other contexts keep the shared one
+    SeqStore &s = ctx->seq[role];
+    s.device = ctx->device;
+    // from here on the old content is gone: results and tables that refer to it are invalid, and so is the store until the
+    // uploads and the pack have succeeded
+    ctx->cigar_called = false;
+    s.n = 0; s.arena = s.total = 0;
+    s.off.clear(); s.len.clear();
+    struct Guard {                                   // any early return below leaves an empty store and no loaded table
+        pav_ctx *c; bool armed = true;
+        ~Guard() { if (armed) c->cigar_loaded = false; }
+    } guard{ctx};
+    if (a == 0) { guard.armed = false; s.n = n_seq; s.off = off; s.len.assign(len, len + n_seq); return PAV_OK; }
     PAV_HIP(ctx, s.d_ascii.reserve(a));
     PAV_HIP(ctx, s.d_two.reserve(a / 4));
     PAV_HIP(ctx, s.d_mask.reserve(a / 8));
@@ -288,14 +293,29 @@ int pav_seq_load(pav_ctx *ctx, int role, uint32_t n_seq, const uint8_t *const *a
     PAV_HIP(ctx, hipMemsetAsync(s.d_ascii.p, 'N', a, ctx->stream));          // padding reads as non-ACGT
     for (uint32_t i = 0; i < n_seq; ++i)
         if (len[i])
-            PAV_HIP(ctx, hipMemcpyAsync(s.d_ascii.as<uint8_t>() + s.off[i], ascii[i], len[i], hipMemcpyHostToDevice,
+            PAV_HIP(ctx, hipMemcpyAsync(s.d_ascii.as<uint8_t>() + off[i], ascii[i], len[i], hipMemcpyHostToDevice,
                                         ctx->stream));
-    PAV_HIP(ctx, hipMemcpyAsync(s.d_off.p, s.off.data(), sizeof(uint64_t) * n_seq, hipMemcpyHostToDevice, ctx->stream));
-    PAV_HIP(ctx, hipMemcpyAsync(s.d_len.p, s.len.data(), sizeof(uint64_t) * n_seq, hipMemcpyHostToDevice, ctx->stream));
+    PAV_HIP(ctx, hipMemcpyAsync(s.d_off.p, off.data(), sizeof(uint64_t) * n_seq, hipMemcpyHostToDevice, ctx->stream));
+    PAV_HIP(ctx, hipMemcpyAsync(s.d_len.p, len, sizeof(uint64_t) * n_seq, hipMemcpyHostToDevice, ctx->stream));
+    s.n = n_seq; s.arena = a; s.total = total;                               // run_pack reads the layout from the store
+    s.off = off; s.len.assign(len, len + n_seq);
     int rc = run_pack(ctx, s, ctx->stream);
-    if (rc != PAV_OK) return rc;
-    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));   // inputs are borrowed only for the duration of the call
-    if (role == PAV_ROLE_TIG || role == PAV_ROLE_REF) { ctx->cigar_called = false; }
+    if (rc == PAV_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)     // inputs are borrowed only for the duration of the call
+        rc = fail(ctx, PAV_E_HIP, "pav_seq_load: upload / pack failed");
+    if (rc != PAV_OK) { s.n = 0; s.arena = s.total = 0; s.off.clear(); s.len.clear(); return rc; }
+    guard.armed = false;
+    return PAV_OK;
+}
+
+int pav_seq_share(pav_ctx *ctx, const pav_ctx *from, int role) {
+    if (!ctx || !from || (role != PAV_ROLE_REF && role != PAV_ROLE_TIG)) return fail(ctx, PAV_E_ARG, "pav_seq_share: bad argument");
+    if (ctx->device != from->device) return fail(ctx, PAV_E_ARG, "pav_seq_share: the two contexts are on different devices");
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream2));
+    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pack_pending[role] = false;
+    ctx->cigar_loaded = ctx->cigar_called = false;
+    ctx->seq.p[role] = from->seq.p[role];
     return PAV_OK;
 }
 
@@ -311,6 +331,16 @@ int pav_seq_pack(pav_ctx *ctx, int role) {
     if (rc != PAV_OK) return rc;
     PAV_HIP(ctx, hipEventRecord(*ev, ctx->stream2));
     ctx->pack_pending[role] = true;
+    return PAV_OK;
+}
+
+int pav_mem_info(pav_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes) {
+    if (!ctx) return PAV_E_ARG;
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    size_t f = 0, t = 0;
+    PAV_HIP(ctx, hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
     return PAV_OK;
 }
 

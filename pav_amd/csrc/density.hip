@@ -84,11 +84,7 @@ struct DensityState {
         pin_cap = bytes + bytes / 2 + 4096;
         return pin;
     }
-    std::vector<uint8_t> desc_host2[2];   // descriptor uploads of density_fetch_calls (one per staging buffer)
-    DevBuf call_stage[2];                 // packed call tables of a round; two, so that a round never waits for the copy
-    hipEvent_t stage_copied[2] = {nullptr, nullptr};   // of the round before it (recorded on the copy stream)
-    hipEvent_t gathered = nullptr;
-    int stage_turn = 0;
+    hipEvent_t gathered = nullptr;        // the packed call tables of a round are complete (main stream)
     std::vector<pav_den_result> results;
     std::vector<std::vector<pav_run>> runs;
     pav_den_params params{};
@@ -101,9 +97,7 @@ struct DensityState {
                          &pscaled[0], &pscaled[1], &pscaled[2], &fill_list, &tiles, &events, &ev_count, &scratch, &run_arena, &win_fill, &ks[0], &ks[1], &ks[2], &ss,
                          &guard, &guard_entries, &samp_flag, &row_flag, &ftiles};
         for (DevBuf *b : all) b->release();
-        call_stage[0].release(); call_stage[1].release();
         if (pin) { (void)hipHostFree(pin); pin = nullptr; pin_cap = 0; }
-        for (hipEvent_t &e : stage_copied) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (gathered) { (void)hipEventDestroy(gathered); gathered = nullptr; }
     }
 };
@@ -837,12 +831,13 @@ __device__ __forceinline__ double run_sum_tail(uint32_t first, int step, uint32_
 // scipy subtracts the scaled positions, fl(i / h) - fl(x / h) (gaussian_kernel_estimate: points_[i] - xi_[j]); the rounding of
 // x / h is common to every term of an evaluation point and shifts a far, concentrated state's density by up to 1e-11
 // relative, so the closed form takes its arguments relative to the same rounded xs: u = fma(i, 1 / h, -xs).
-__device__ __forceinline__ double kde_state_runs(const RunDev *__restrict__ runs, uint32_t n_run, uint32_t xi, double h,
-                                                 double inv_h, double norm, double w) {
+// Partial sum over the runs first, first + stride, ...: the waves of a workgroup share the runs of an evaluation point.
+__device__ __forceinline__ double kde_state_runs(const RunDev *__restrict__ runs, uint32_t n_run, uint32_t first, uint32_t stride,
+                                                 uint32_t xi, double h, double inv_h) {
     const double short_len = fmax(16.0, h * 0.0625);                  // short runs: direct terms (also bounds the
     const double x = (double)xi, xs = x * inv_h;                       // cancellation in the erfc difference)
     double sum = 0.0;
-    for (uint32_t r = 0; r < n_run; ++r) {
+    for (uint32_t r = first; r < n_run; r += stride) {
         const RunDev rn = runs[r];
         const double da = (double)rn.a - x, db = (double)rn.b - x;
         const double near = da >= 0.0 ? da : (db <= 0.0 ? -db : 0.0);  // distance of the nearest run element
@@ -854,7 +849,7 @@ __device__ __forceinline__ double kde_state_runs(const RunDev *__restrict__ runs
             sum += run_sum_em(fma((double)rn.a, inv_h, -xs), fma((double)rn.b, inv_h, -xs), h, inv_h);
         }
     }
-    return w * (sum * norm);
+    return sum;
 }
 
 struct KdeArgs {
@@ -864,38 +859,62 @@ struct KdeArgs {
     GuardArgs G;
 };
 
-// One wave per tile of 64 evaluation points of one job.
-__global__ __launch_bounds__(64) void k_kde_eval(KdeArgs A) {
+// One workgroup per tile of 64 evaluation points of one job.  Lane l of every wave stands for point l; the waves share the
+// runs of a state (wave w takes runs w, w + KDE_WAVES, ...) and wave 0 adds their partial sums in wave order - a fixed order,
+// so the result does not depend on scheduling.  With one wave per tile the expansion rounds of the scan - a handful of
+// regions of 10^5 rows whose states alternate thousands of times - took 0.7 - 1.1 ms per launch, all of it the latency of one
+// lane walking 10^4 runs; the chip was idle.  States summed term by term (scipy's order) stay on wave 0.
+constexpr int KDE_WAVES = 8;
+__global__ __launch_bounds__(64 * KDE_WAVES) void k_kde_eval(KdeArgs A) {
+    __shared__ double part[KDE_WAVES][3][64];
     const EvalTile t = A.tiles[blockIdx.x];
     const JobKde kd = A.kde[t.job];
     const uint64_t off = A.jobs[t.job].tpos_off;
-    if (threadIdx.x >= t.count) return;
-    uint32_t x;
-    if (t.mode == 0) {                                                 // sampled sites (density.py:211-214)
-        const uint64_t q = (uint64_t)t.first + threadIdx.x;
-        const uint64_t xx = q * kd.srs;
-        x = xx > kd.n - 1 ? kd.n - 1 : (uint32_t)xx;
-    } else {
-        x = A.fill_list[off + t.first + threadIdx.x];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool active = lane < t.count;
+    uint32_t x = 0;
+    if (active) {
+        if (t.mode == 0) {                                             // sampled sites (density.py:211-214)
+            const uint64_t xx = ((uint64_t)t.first + lane) * kd.srs;
+            x = xx > kd.n - 1 ? kd.n - 1 : (uint32_t)xx;
+        } else {
+            x = A.fill_list[off + t.first + lane];
+        }
     }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        double v = 0.0;
+        if (active && kd.m[s]) {
+            if (kd.use_runs && kd.h[s] >= KDE_RUNS_MIN_H)
+                v = kde_state_runs(A.runs + kd.run_off[s], kd.n_run[s], wave, KDE_WAVES, x, kd.h[s], kd.inv_h[s]);
+            else if (wave == 0)
+                v = kde_state(A.ps[s] + off, kd.m[s], (double)x * kd.inv_h[s], kd.norm[s], kd.w[s]);
+        }
+        part[wave][s][lane] = v;
+    }
+    __syncthreads();
+    if (wave != 0 || !active) return;
     double val[3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         if (kd.m[s] == 0) { val[s] = 0.0; continue; }                  // density.py:84,92,100
-        const double est = (kd.use_runs && kd.h[s] >= KDE_RUNS_MIN_H)
-            ? kde_state_runs(A.runs + kd.run_off[s], kd.n_run[s], x, kd.h[s], kd.inv_h[s], kd.norm[s], kd.w[s])
-            : kde_state(A.ps[s] + off, kd.m[s], (double)x * kd.inv_h[s], kd.norm[s], kd.w[s]);
+        double est = part[0][s][lane];
+        if (kd.use_runs && kd.h[s] >= KDE_RUNS_MIN_H) {
+#pragma unroll
+            for (int w = 1; w < KDE_WAVES; ++w) est += part[w][s][lane];
+            est = kd.w[s] * (est * kd.norm[s]);
+        }
         val[s] = est * kd.cnt[s];                                      // density.py:110-115
     }
     if (t.mode == 0) {
         // sampled sites go to compact arrays (coalesced here and in k_windows / k_interp, which puts them into the table rows)
-        const uint64_t so = (uint64_t)kd.samp_off + t.first + threadIdx.x;
+        const uint64_t so = (uint64_t)kd.samp_off + t.first + lane;
 #pragma unroll
         for (int s = 0; s < 3; ++s) A.ks[s][so] = val[s];
         A.ss[so] = (int8_t)argmax3(val[0], val[1], val[2]);            // density.py:250-255
         if (A.G.rel > 0.0 && near_argmax(val[0], val[1], val[2], A.G.rel)) {
             atomicAdd(&A.G.stat[t.job].n_near, 1u);                    // sampled sites are evaluated here in pass 0 only
-            if (!kd.all_direct) guard_flag_sample(A.G, t.job, t.first + threadIdx.x, so);
+            if (!kd.all_direct) guard_flag_sample(A.G, t.job, t.first + lane, so);
             else if (near_argmax(val[0], val[1], val[2], A.G.unres)) atomicAdd(&A.G.stat[t.job].n_unres, 1u);
         }
     } else {
@@ -1260,7 +1279,8 @@ __global__ __launch_bounds__(256) void k_gather_calls(const GatherCall *__restri
     o_match[t] = m;
 }
 
-int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls, uint64_t k1_rows) {
+int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls, uint64_t k1_rows, CallStage &stage, bool copy_now) {
+    stage.n_copies = 0;
     if (calls.empty()) return PAV_OK;
     DensityState *D = dstate(ctx);
     if (!D->valid) return fail(ctx, PAV_E_STATE, "density_fetch_calls: no batch resident");
@@ -1289,17 +1309,13 @@ int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls, uint6
         keys += (uint64_t)cap_up + cap_dn;
         total += f.n;
     }
-    // device staging: [hash keys][packed columns in the host block's order][descriptors]
+    // device staging, owned by the caller for as long as the tables may be asked for:
+    // [hash keys][packed columns in the host block's order][descriptors]
     const uint64_t col_bytes = total * 40;
     const uint64_t desc_bytes = sizeof(GatherCall) * gc.size() + sizeof(CanonJob) * cj.size();
-    const int turn = D->stage_turn;
-    D->stage_turn ^= 1;
     if (!D->gathered) PAV_HIP(ctx, hipEventCreateWithFlags(&D->gathered, hipEventDisableTiming));
-    if (!D->stage_copied[turn]) PAV_HIP(ctx, hipEventCreateWithFlags(&D->stage_copied[turn], hipEventDisableTiming));
-    else PAV_HIP(ctx, hipEventSynchronize(D->stage_copied[turn]));      // copy of two rounds ago: long finished
-    DevBuf &stage = D->call_stage[turn];
-    PAV_HIP(ctx, stage.reserve(8ull * keys + col_bytes + desc_bytes + 512));
-    unsigned long long *d_keys = stage.as<unsigned long long>();
+    PAV_HIP(ctx, stage.buf.reserve(8ull * keys + col_bytes + desc_bytes + 512));
+    unsigned long long *d_keys = stage.buf.as<unsigned long long>();
     uint8_t *d_cols = reinterpret_cast<uint8_t *>(d_keys + keys);
     double *g_k0 = reinterpret_cast<double *>(d_cols), *g_k1 = g_k0 + total, *g_k2 = g_k1 + total;
     unsigned long long *g_kmer = reinterpret_cast<unsigned long long *>(g_k2 + total);
@@ -1308,7 +1324,7 @@ int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls, uint6
     uint8_t *g_fl = reinterpret_cast<uint8_t *>(g_st + total), *g_ma = g_fl + total;
     GatherCall *d_gc = reinterpret_cast<GatherCall *>(d_cols + (col_bytes + 63) / 64 * 64);
     CanonJob *d_cj = reinterpret_cast<CanonJob *>(d_gc + gc.size());
-    std::vector<uint8_t> &desc_host = D->desc_host2[turn];             // stays alive until the copy has run
+    std::vector<uint8_t> &desc_host = stage.desc_host;                 // stays alive until the upload has run
     desc_host.resize(desc_bytes);
     memcpy(desc_host.data(), gc.data(), sizeof(GatherCall) * gc.size());
     if (!cj.empty()) memcpy(desc_host.data() + sizeof(GatherCall) * gc.size(), cj.data(), sizeof(CanonJob) * cj.size());
@@ -1319,8 +1335,8 @@ int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls, uint6
     PAV_LAUNCH(ctx, "k_gather_calls", k_gather_calls, (uint32_t)((total + 255) / 256), 256, 0, d_gc, (uint32_t)gc.size(), (uint32_t)total, k,
                D->index.as<uint32_t>(), D->state_mer.as<int8_t>(), D->state.as<int8_t>(), D->kern[0].as<double>(), D->kern[1].as<double>(),
                D->kern[2].as<double>(), D->kmer.as<unsigned long long>(), d_keys, g_index, g_sm, g_st, g_k0, g_k1, g_k2, g_kmer, g_fl, g_ma);
-    // Host side (invscan.hip): the round's block is laid out as whole-round columns, K0 | K1 | K2 | KMER | INDEX | STATE_MER |
-    // STATE | FLANK | MATCH, exactly like the packed device columns: one copy.  Any other layout is copied call by call.
+    // Host side (invscan.cpp): the round's block is laid out as whole-round columns, K0 | K1 | K2 | KMER | INDEX | STATE_MER |
+    // STATE | FLANK | MATCH, exactly like the packed device columns: one copy (two when the tail of K1 stays behind).
     bool bulk = true;
     for (size_t c = 0; c + 1 < calls.size() && bulk; ++c)
         bulk = calls[c + 1].kern[0] == calls[c].kern[0] + calls[c].n;
@@ -1330,42 +1346,34 @@ int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls, uint6
            reinterpret_cast<uint8_t *>(f0.index) == reinterpret_cast<uint8_t *>(f0.kmer + total) &&
            reinterpret_cast<uint8_t *>(f0.state_mer) == reinterpret_cast<uint8_t *>(f0.index + total) &&
            f0.state == f0.state_mer + total && f0.flank == reinterpret_cast<uint8_t *>(f0.state + total) && f0.match == f0.flank + total;
-    if (bulk) {
-        // the copy runs on the copy stream behind the scan (wait_tables() before the host reads the block)
-        PAV_HIP(ctx, hipEventRecord(D->gathered, st));
-        PAV_HIP(ctx, hipStreamWaitEvent(ctx->stream3, D->gathered, 0));
-        // (a hand-rolled 64-workgroup copy kernel was tried instead of the runtime's copy to keep the chip free for the next
-        // step: 16.6 ms per step against 13.9 ms, the runtime's copy is the better one)
-        if (k1_rows >= total) {
-            PAV_HIP(ctx, hipMemcpyAsync(f0.kern[0], d_cols, col_bytes, hipMemcpyDeviceToHost, ctx->stream3));
-        } else {                                                    // K0 | leading part of K1, then K2 | ... | MATCH
-            PAV_HIP(ctx, hipMemcpyAsync(f0.kern[0], d_cols, 8ull * (total + k1_rows), hipMemcpyDeviceToHost, ctx->stream3));
-            PAV_HIP(ctx, hipMemcpyAsync(f0.kern[2], g_k2, col_bytes - 16ull * total, hipMemcpyDeviceToHost, ctx->stream3));
-        }
-        PAV_HIP(ctx, hipEventRecord(D->stage_copied[turn], ctx->stream3));
+    if (!bulk) return fail(ctx, PAV_E_ARG, "density_fetch_calls: the host block of a round must be laid out as whole-round columns");
+    if (k1_rows >= total) {
+        stage.copies[stage.n_copies++] = CallStage::Copy{d_cols, f0.kern[0], col_bytes};
+    } else {                                                        // K0 | leading part of K1, then K2 | ... | MATCH
+        stage.copies[stage.n_copies++] = CallStage::Copy{d_cols, f0.kern[0], 8ull * (total + k1_rows)};
+        stage.copies[stage.n_copies++] = CallStage::Copy{g_k2, f0.kern[2], col_bytes - 16ull * total};
+    }
+    if (getenv("PAV_TIMING")) fprintf(stderr, "[pav timing]   call tables: %zu calls, %llu rows (%.1f MB %s), %llu hash slots, %u insert tiles\n",
+                                      calls.size(), (unsigned long long)total, (col_bytes - 8.0 * (double)(total - std::min<uint64_t>(k1_rows, total))) / 1e6,
+                                      copy_now ? "to the host" : "packed, resident", (unsigned long long)keys, tiles);
+    if (!copy_now) return PAV_OK;                                   // the tables stay in HBM until somebody asks (stage_copy)
+    // the copy runs on the copy stream behind the scan (wait_tables() before the host reads the block)
+    // (a hand-rolled 64-workgroup copy kernel was tried instead of the runtime's copy to keep the chip free for the next
+    // step: 16.6 ms per step against 13.9 ms, the runtime's copy is the better one)
+    PAV_HIP(ctx, hipEventRecord(D->gathered, st));
+    PAV_HIP(ctx, hipStreamWaitEvent(ctx->stream3, D->gathered, 0));
+    return stage_copy(ctx, stage);
+}
+
+// Queue the device-to-host copies of a packed round on the copy stream (the caller has made that stream wait for the gather).
+int stage_copy(pav_ctx *ctx, CallStage &stage) {
+    for (int c = 0; c < stage.n_copies; ++c)
+        PAV_HIP(ctx, hipMemcpyAsync(stage.copies[c].dst, stage.copies[c].src, stage.copies[c].bytes, hipMemcpyDeviceToHost, ctx->stream3));
+    if (stage.n_copies) {
         PAV_HIP(ctx, hipEventRecord(ctx->tables_done, ctx->stream3));
         ctx->tables_pending = true;
-        if (getenv("PAV_TIMING")) fprintf(stderr, "[pav timing]   call tables: %zu calls, %llu rows (%.1f MB to the host), %llu hash slots, %u insert tiles\n",
-                                          calls.size(), (unsigned long long)total, (col_bytes - 8.0 * (double)(total - std::min<uint64_t>(k1_rows, total))) / 1e6, (unsigned long long)keys, tiles);
-        return PAV_OK;
-    } else {
-        for (size_t c = 0; c < calls.size(); ++c) {
-            const CallFetch &f = calls[c];
-            const uint64_t o = gc[c].dst_off;
-            const uint32_t n = f.n;
-            PAV_HIP(ctx, hipMemcpyAsync(f.flank, g_fl + o, n, hipMemcpyDeviceToHost, st));
-            PAV_HIP(ctx, hipMemcpyAsync(f.match, g_ma + o, n, hipMemcpyDeviceToHost, st));
-            PAV_HIP(ctx, hipMemcpyAsync(f.index, g_index + o, 4ull * n, hipMemcpyDeviceToHost, st));
-            PAV_HIP(ctx, hipMemcpyAsync(f.state_mer, g_sm + o, n, hipMemcpyDeviceToHost, st));
-            PAV_HIP(ctx, hipMemcpyAsync(f.state, g_st + o, n, hipMemcpyDeviceToHost, st));
-            PAV_HIP(ctx, hipMemcpyAsync(f.kmer, g_kmer + o, 8ull * n, hipMemcpyDeviceToHost, st));
-            PAV_HIP(ctx, hipMemcpyAsync(f.kern[0], g_k0 + o, 8ull * n, hipMemcpyDeviceToHost, st));
-            PAV_HIP(ctx, hipMemcpyAsync(f.kern[1], g_k1 + o, 8ull * n, hipMemcpyDeviceToHost, st));
-            PAV_HIP(ctx, hipMemcpyAsync(f.kern[2], g_k2 + o, 8ull * n, hipMemcpyDeviceToHost, st));
-        }
     }
-    PAV_HIP(ctx, hipStreamSynchronize(st));
-    PAV_HIP(ctx, hipEventRecord(D->stage_copied[turn], st));
+    stage.n_copies = 0;
     return PAV_OK;
 }
 
@@ -1822,7 +1830,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
         G.pass = 0;
         KA.G = G;
         KA.tiles = D->tiles.as<EvalTile>();
-        PAV_LAUNCH(ctx, "k_kde_eval", k_kde_eval, (uint32_t)tiles.size(), 64, 0, KA);
+        PAV_LAUNCH(ctx, "k_kde_eval", k_kde_eval, (uint32_t)tiles.size(), 64 * KDE_WAVES, 0, KA);
         uint32_t processed = 0;                                        // list entries whose sampled sites have been evaluated again
         bool overflow = false;
         for (uint32_t pass = 0; ; ++pass) {
@@ -1850,7 +1858,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
                 PAV_HIP(ctx, D->ftiles.reserve(sizeof(EvalTile) * ftiles.size()));
                 PAV_HIP(ctx, hipMemcpyAsync(D->ftiles.p, ftiles.data(), sizeof(EvalTile) * ftiles.size(), hipMemcpyHostToDevice, st));
                 KA.tiles = D->ftiles.as<EvalTile>();
-                PAV_LAUNCH(ctx, "k_kde_eval", k_kde_eval, (uint32_t)ftiles.size(), 64, 0, KA);
+                PAV_LAUNCH(ctx, "k_kde_eval", k_kde_eval, (uint32_t)ftiles.size(), 64 * KDE_WAVES, 0, KA);
             }
             if (processed) {                                           // rows queued earlier: scipy's order overrides the run sums
                 RA.first = 0; RA.kinds = 2;

@@ -1,4 +1,4 @@
-// Whole-file text loading shared by the host-side readers (fastaio.hip, samio.hip): plain files are mapped, gzip streams are
+// Whole-file text loading shared by the host-side readers (fastaio.cpp, samio.cpp): plain files are mapped, gzip streams are
 // inflated, BGZF files (a series of independent <= 64 KiB gzip members, SAM specification 4.1) are inflated block-parallel.
 #pragma once
 

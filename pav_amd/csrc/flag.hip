@@ -18,7 +18,7 @@
 
 namespace pav {
 
-const std::vector<std::string> &seq_names(pav_ctx *ctx, int role);   // invscan.hip
+const std::vector<std::string> &seq_names(pav_ctx *ctx, int role);   // invscan.cpp
 
 namespace {
 

@@ -56,8 +56,21 @@ struct InvState {
         }
         return zero_blocks.back().get();
     }
-    void next_pinned() { cur_set ^= 1; for (auto &b : pinned_sets[cur_set]) b.used = 0; }
-    void free_pinned() { for (auto &set : pinned_sets) { for (auto &b : set) (void)hipHostFree(b.p); set.clear(); } }
+    // Device side of the same tables: one packed block per scan round, in the set of the current scan.  With lazy tables
+    // (pav_inv_params.lazy_tables) nothing crosses PCIe during the scan; the first reader of a table of this scan brings the
+    // blocks over (materialise).
+    std::vector<std::unique_ptr<CallStage>> stage_sets[2];
+    size_t stage_used = 0;
+    CallStage &next_stage() {
+        auto &set = stage_sets[cur_set];
+        if (stage_used == set.size()) set.emplace_back(new CallStage());
+        return *set[stage_used++];
+    }
+    void next_pinned() { cur_set ^= 1; for (auto &b : pinned_sets[cur_set]) b.used = 0; stage_used = 0; }
+    void free_pinned() {
+        for (auto &set : pinned_sets) { for (auto &b : set) (void)hipHostFree(b.p); set.clear(); }
+        for (auto &set : stage_sets) { for (auto &st : set) st->buf.release(); set.clear(); }
+    }
     void *pin_alloc(size_t bytes) {
         auto &pinned = pinned_sets[cur_set];
         for (auto &b : pinned) if (b.cap - b.used >= bytes) { void *r = static_cast<uint8_t *>(b.p) + b.used; b.used += bytes; return r; }
@@ -280,6 +293,21 @@ public:
 };
 
 const std::vector<std::string> &seq_names(pav_ctx *ctx, int role) { return istate(ctx)->names[role]; }
+
+// Host copies of the call tables of the last scan: queue whatever a lazy scan left in HBM, then wait for the copy stream.
+static int tables_on_host(pav_ctx *ctx, InvState *S) {
+    bool any = false;
+    for (size_t r = 0; r < S->stage_used; ++r) any = any || S->stage_sets[S->cur_set][r]->n_copies > 0;
+    if (any) {
+        PAV_HIP(ctx, hipSetDevice(ctx->device));
+        PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));              // the gather kernels of the scan
+        for (size_t r = 0; r < S->stage_used; ++r) {
+            const int rc = stage_copy(ctx, *S->stage_sets[S->cur_set][r]);
+            if (rc != PAV_OK) return rc;
+        }
+    }
+    return wait_tables(ctx);
+}
 
 struct Scan {                       // per flagged region
     Rgn flag, region_ref, region_tig;
@@ -565,7 +593,7 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
                 o += cf.n;
                 S->tables[round_owner[c]] = std::move(tab);
             }
-            rc = density_fetch_calls(ctx, round_calls, k1_rows);
+            rc = density_fetch_calls(ctx, round_calls, k1_rows, S->next_stage(), pp->lazy_tables == 0);
             t_table += now() - t0;
             if (rc != PAV_OK) return rc;
         }
@@ -613,7 +641,7 @@ int pav_inv_table(pav_ctx *ctx, uint32_t region, int64_t *index, int8_t *state_m
     if (!ctx) return PAV_E_ARG;
     InvState *S = istate(ctx);
     if (region >= S->tables.size() || !S->tables[region]) return fail(ctx, PAV_E_STATE, "pav_inv_table: region has no call in the last scan");
-    { const int rcw = wait_tables(ctx); if (rcw != PAV_OK) return rcw; }
+    { const int rcw = tables_on_host(ctx, S); if (rcw != PAV_OK) return rcw; }
     const InvTable &t = *S->tables[region];
     const size_t n = t.n;
     if (index) for (size_t i = 0; i < n; ++i) index[i] = t.index[i];
@@ -634,7 +662,7 @@ int pav_inv_table_view(pav_ctx *ctx, uint32_t region, uint32_t *n_rows, const ui
     if (!ctx || !n_rows) return PAV_E_ARG;
     InvState *S = istate(ctx);
     if (region >= S->tables.size() || !S->tables[region]) return fail(ctx, PAV_E_STATE, "pav_inv_table_view: region has no call in the last scan");
-    { const int rcw = wait_tables(ctx); if (rcw != PAV_OK) return rcw; }
+    { const int rcw = tables_on_host(ctx, S); if (rcw != PAV_OK) return rcw; }
     const InvTable &t = *S->tables[region];
     *n_rows = t.n;
     if (index) *index = t.index;
@@ -655,7 +683,7 @@ int pav_inv_table_view(pav_ctx *ctx, uint32_t region, uint32_t *n_rows, const ui
 int pav_inv_write_tables(pav_ctx *ctx, uint32_t n, const uint32_t *regions, const char *const *paths, int threads, int gzip_level) {
     if (!ctx || (n && (!regions || !paths))) return fail(ctx, PAV_E_ARG, "pav_inv_write_tables: null argument");
     InvState *S = istate(ctx);
-    { const int rcw = wait_tables(ctx); if (rcw != PAV_OK) return rcw; }
+    { const int rcw = tables_on_host(ctx, S); if (rcw != PAV_OK) return rcw; }
     if (threads <= 0) threads = (int)std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
     const int level = gzip_level > 0 ? gzip_level : 6;
     static const char *FLANK_TEXT[3] = {"", "UP", "DN"};
@@ -739,7 +767,7 @@ int pav_inv_tables(pav_ctx *ctx, uint32_t n_regions, const uint64_t *row_off, in
     if (!ctx || !row_off) return PAV_E_ARG;
     InvState *S = istate(ctx);
     if (n_regions != S->tables.size()) return fail(ctx, PAV_E_STATE, "pav_inv_tables: region count does not match the last scan");
-    { const int rcw = wait_tables(ctx); if (rcw != PAV_OK) return rcw; }
+    { const int rcw = tables_on_host(ctx, S); if (rcw != PAV_OK) return rcw; }
     for (uint32_t i = 0; i < n_regions; ++i) {
         if (!S->tables[i]) continue;
         const uint64_t o = row_off[i];

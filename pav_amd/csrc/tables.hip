@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void snv_gather(const pav_snv *__restrict__ sn
     out[i] = o;
 }
 
-const std::vector<std::string> &seq_names(pav_ctx *ctx, int role);   // invscan.hip
+const std::vector<std::string> &seq_names(pav_ctx *ctx, int role);   // invscan.cpp
 
 }  // namespace pav
 

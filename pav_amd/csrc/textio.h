@@ -1,4 +1,4 @@
-// Text / gzip helpers shared by the table writers (tables.hip: rule call_cigar; invscan.hip: density tables of rule
+// Text / gzip helpers shared by the table writers (tables.hip: rule call_cigar; invscan.cpp: density tables of rule
 // call_inv_batch).  Everything here reproduces what pandas.DataFrame.to_csv(sep='\t', index=False) writes.
 #pragma once
 

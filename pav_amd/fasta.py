@@ -4,7 +4,7 @@ FASTA access for the host side of the hot path.
 Replaces the two ``pysam.FastaFile(...).fetch(...)`` uses on the path (pavlib/cigarcall.py:59-66,
 pavlib/seq.py:339-351) without pysam: whole records are held as ``numpy.uint8`` ASCII arrays exactly as they
 appear in the file (case preserved), because the device library takes plain byte pointers.  The file is read by the
-library's native reader (``pav_fasta_open``, csrc/fastaio.hip): plain, gzip and BGZF (blocks inflated in parallel);
+library's native reader (``pav_fasta_open``, csrc/fastaio.cpp): plain, gzip and BGZF (blocks inflated in parallel);
 the arrays are zero-copy views of its buffers.
 """
 

@@ -86,6 +86,7 @@ class _NativeInvCall(InvCall):
         self._df = df
         self.native_table = None
         ro = record['ref_outer']
+        self.n_near_tie, self.n_unresolved = int(record['n_near_tie']), int(record['n_unresolved'])   # near-tie guard (pav_amd.h)
         self.svlen = int(ro['end']) - int(ro['pos'])
         self.id = '{}-{}-INV-{}'.format(names[0][int(ro['seq_id'])], int(ro['pos']) + 1, self.svlen)
 
@@ -466,8 +467,8 @@ def scan_for_inv(region_flag, ref_fa_name, tig_fa_name, align_lift, k_util, n_tr
 
 
 def _native_scan(ctx, region_flags, align_lift, k_util, max_region_size, logs, srs_tree, min_exp_count, ref_index, tig_index,
-                 eager_tables=True, log=None):
-    """All regions through the library's native driver (pav_inv_scan_batch, csrc/invscan.hip)."""
+                 eager_tables=True, log=None, found_out=None):
+    """All regions through the library's native driver (pav_inv_scan_batch, csrc/invscan.cpp)."""
     import ctypes
     import time
     _t = [time.perf_counter()]
@@ -502,9 +503,12 @@ def _native_scan(ctx, region_flags, align_lift, k_util, max_region_size, logs, s
     srs = (_lib.Srs * max(1, len(ivs)))(*[_lib.Srs(float(iv.begin), float(iv.end), int(iv.data), 0) for iv in ivs])
     params = _lib.InvParams(int(MAX_REGION_SIZE if max_region_size is None else max_region_size),
                             int(DEFAULT_MIN_EXP_COUNT if min_exp_count is None else min_exp_count), len(ivs),
-                            ctypes.cast(srs, ctypes.POINTER(_lib.Srs)), density.den_params(k=k_util.k_size))
+                            ctypes.cast(srs, ctypes.POINTER(_lib.Srs)), density.den_params(k=k_util.k_size),
+                            0 if eager_tables else 1, 0)
     regions = np.zeros(len(region_flags), dtype=_lib.INV_REGION_DTYPE)
-    if len(region_flags):
+    if isinstance(region_flags, RegionColumns):
+        regions['ref_id'], regions['pos'], regions['end'] = region_flags.ref_id, region_flags.pos, region_flags.end
+    elif len(region_flags):
         regions['ref_id'] = [ref_index[rf.chrom] for rf in region_flags]
         regions['pos'] = [rf.pos for rf in region_flags]
         regions['end'] = [rf.end for rf in region_flags]
@@ -565,26 +569,60 @@ def _native_scan(ctx, region_flags, align_lift, k_util, max_region_size, logs, s
             out[i] = _NativeInvCall(sub[q], names, region_flags[i], df)
             out[i].native_table = (ctx, i, generation)   # the library's host copy: Context.inv_write_tables writes it as text
     if found_lines:
-        print('\n'.join(found_lines))                                   # inv.py:408, one line per region in region order
+        print('\n'.join(found_lines), file=found_out)                   # inv.py:408, one line per region in region order
     _lap('results')
     return out
 
 
+class RegionColumns:
+    """Flagged regions as three columns - record number in the context's reference store, POS, END - for batches that never
+    existed as Python objects (the loci ``pav_cigar_flag`` has just produced).  Behaves like a list of Regions."""
+
+    def __init__(self, ref_id, pos, end, names):
+        self.ref_id = np.ascontiguousarray(ref_id, dtype=np.uint32)
+        self.pos = np.ascontiguousarray(pos, dtype=np.int64)
+        self.end = np.ascontiguousarray(end, dtype=np.int64)
+        self.names = names
+
+    def __len__(self):
+        return self.ref_id.shape[0]
+
+    def __getitem__(self, i):
+        return seq.Region(self.names[int(self.ref_id[i])], int(self.pos[i]), int(self.end[i]))
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
+def loci_regions(ctx, loci, only_try_inv=True):
+    """``pav_flag_locus`` records (``Context.cigar_flag`` / ``flag_merge_loci``; their ``chrom`` is the rank of the
+    chromosome name in str order, as the flag tables sort) -> :class:`RegionColumns` of the loci rule call_inv_batch would
+    hand to ``scan_for_inv``: those with TRY_INV (rules/call_inv.snakefile:145-146, 185-196)."""
+    names = ctx.seq_names(_lib.PAV_ROLE_REF)
+    by_rank = np.array(sorted(range(len(names)), key=lambda i: names[i]), dtype=np.uint32)
+    sel = loci[loci['try_inv'] != 0] if only_try_inv else loci
+    return RegionColumns(by_rank[sel['chrom']] if sel.shape[0] else np.zeros(0, np.uint32), sel['pos'], sel['end'], names)
+
+
 def scan_for_inv_batch(region_flags, ref_fa_name, tig_fa_name, align_lift, k_util, n_tree=None, max_region_size=None,
                        logs=None, srs_tree=None, min_exp_count=DEFAULT_MIN_EXP_COUNT, ctx=None, device_id=0, native=None,
-                       eager_tables=True, log=None):
+                       eager_tables=True, log=None, found_out=None):
     """Scan many flagged regions; returns a list of ``InvCall`` / ``None`` / ``RuntimeError`` (one per region, the
     error object where ``scan_for_inv`` would have raised).  ``logs``: one file-like object per region or None.
     ``log``: one file-like object for the whole batch - what rule call_inv_batch passes to every ``scan_for_inv`` call
     (rules/call_inv.snakefile:172,191-196); it receives the log text of all regions in region order.
 
-    ``native``: run the whole scan loop inside the library (csrc/invscan.hip).  Default: yes when ``align_lift`` is a
+    ``native``: run the whole scan loop inside the library (csrc/invscan.cpp).  Default: yes when ``align_lift`` is a
     :class:`pav_amd.align.AlignLift` and no N-tree is given; the Python state machine below is the same algorithm and
     is used otherwise (e.g. for a ``pavlib.align.AlignLift`` object).
 
     ``eager_tables`` (native driver): copy every call's density table into numpy arrays before returning (default).  With
     ``False`` ``InvCall.df`` is assembled on first access from the library's host copy, which lives until the next scan
-    on the same context (reading it later raises); the rule mirror and bench.py use that."""
+    on the same context (reading it later raises); the rule mirror and bench.py use that.  The tables then stay packed in
+    HBM during the scan and cross PCIe when the first of them is read.
+
+    ``found_out``: where the 'INV Found: ...' lines the reference prints (pavlib/inv.py:408) go (native driver; default
+    ``sys.stdout``) - callers that scan from several threads give each its own sink."""
     own = ctx is None
     if own:
         ctx = _lib.Context(device_id)
@@ -596,21 +634,23 @@ def scan_for_inv_batch(region_flags, ref_fa_name, tig_fa_name, align_lift, k_uti
             native = isinstance(align_lift, _OurLift) and n_tree is None and \
                 os.environ.get('PAV_INV_DRIVER', '').lower() != 'python'
         if native:
+            # a context that is closed on return cannot serve lazy tables: they are copied out before it goes
             return _native_scan(ctx, region_flags, align_lift, k_util, max_region_size, logs, srs_tree, min_exp_count,
-                                ref_index, tig_index, eager_tables=eager_tables, log=log)
-        scans = []
-        if log is not None and logs is None:                           # lock-step scans: per-region buffers, joined in region order
-            import io
-            joined = [io.StringIO() for _ in region_flags]
-        else:
-            joined = None
-        for i, rf in enumerate(region_flags):
-            sink = joined[i] if joined is not None else (None if logs is None else logs[i])
-            scans.append(_Scan(rf, ref_fa_name, tig_fa_name, align_lift, k_util, n_tree, max_region_size,
-                               sink, srs_tree, min_exp_count, ref_index, tig_index))
+                                ref_index, tig_index, eager_tables=eager_tables or own, log=log, found_out=found_out)
+        # lock-step scans write into private buffers; the text goes to the caller's sinks afterwards, in region order
+        import io
+        want_text = log is not None or logs is not None
+        private = [io.StringIO() if want_text else None for _ in region_flags]
+        scans = [_Scan(rf, ref_fa_name, tig_fa_name, align_lift, k_util, n_tree, max_region_size, private[i], srs_tree,
+                       min_exp_count, ref_index, tig_index) for i, rf in enumerate(region_flags)]
         _drive(ctx, scans, density.den_params(k=k_util.k_size))
+        if logs is not None:
+            for sink, buf in zip(logs, private):
+                if sink is not None and buf.getvalue():
+                    sink.write(buf.getvalue())
+                    sink.flush()
         if log is not None:
-            log.write(''.join(b.getvalue() for b in (joined if joined is not None else logs)))
+            log.write(''.join(buf.getvalue() for buf in private))
             log.flush()
     finally:
         if own:

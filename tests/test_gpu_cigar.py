@@ -280,6 +280,39 @@ def test_error_cases(built, gpu_ctx):
         assert str(ei.value) == e['message'], e['label']
 
 
+def test_rows_that_do_not_fit_their_records_are_refused(built, gpu_ctx):
+    """An alignment table that does not belong to the FASTA (POS + the row's =/X/D lengths past the end of the chromosome,
+    or more query bases than the contig has): pavlib raises IndexError when it indexes the strings (cigarcall.py:104-105);
+    here the row is refused before any kernel reads past a record - no neighbouring record's bases end up in REF / ALT / SEQ.
+    An illegal operation earlier in walk order still wins, as in the sequential walk."""
+    d, df_align, _ = util.golden_case('cigar_edge')
+    _load_case(gpu_ctx, d)
+    cigarcall.call_records(gpu_ctx, df_align)                         # the table itself is fine
+    ref_fa, _ = util.seq_arrays(d, df_align)
+    ref_len = {n: len(ref_fa[n]) for n in ref_fa.names}
+    last = (df_align['END'] - df_align['POS']).idxmax()                # a row that really walks some reference
+    df = df_align.copy()
+    df.loc[last, 'POS'] = ref_len[df.loc[last, '#CHROM']] - 10       # the row now runs off the chromosome
+    with pytest.raises(IndexError, match='string index out of range'):
+        cigarcall.call_records(gpu_ctx, df)
+    df = df_align.copy()
+    df.loc[last, 'CIGAR'] = df.loc[last, 'CIGAR'] + '200000000='         # more query (and reference) bases than exist
+    with pytest.raises(IndexError, match='string index out of range'):
+        cigarcall.call_records(gpu_ctx, df)
+    df = df_align.copy()
+    df.loc[last, 'POS'] = ref_len[df.loc[last, '#CHROM']] - 10
+    first = df_align.index[0]
+    df.loc[first, 'CIGAR'] = '5M' + df.loc[first, 'CIGAR']
+    with pytest.raises(RuntimeError, match='not M'):
+        cigarcall.call_records(gpu_ctx, df)
+    with pytest.raises(ValueError, match='POS'):
+        bad = df_align.copy()
+        bad.loc[last, 'POS'] = -5
+        cigarcall.call_records(gpu_ctx, bad)
+    snv, indel, blob, counts = cigarcall.call_records(gpu_ctx, df_align)   # the context is still usable
+    assert counts.n_snv == snv.shape[0] > 0
+
+
 def test_tokenizer_matches_oracle(built, gpu_ctx):
     d, df_align, _ = util.golden_case('cigar_synth')
     _load_case(gpu_ctx, d)
@@ -358,6 +391,58 @@ def test_cohort_haplotypes_share_one_resident_reference(built, gpu_ctx):
     assert len({h.stats['n_snv'] for h in haps}) > 1                 # the haplotypes really differ
 
 
+def test_eight_haplotypes_resident_against_one_reference(built, gpu_ctx):
+    """BASELINE configs[4] shape (T2T-CHM13-shaped reference, haplotypes batched 8 per GPU) in small: the reference is
+    uploaded and packed ONCE; eight haplotypes (four samples x h1 / h2, different seeds) are resident at the same time, one
+    context each sharing the reference's planes (pav_seq_share), and are called from four host threads at once.  Every
+    haplotype's records are bit-exact vs the oracle, a second concurrent pass gives the same bytes, and the HBM the eight
+    haplotypes add is what their contigs and tables need - not eight references."""
+    from concurrent.futures import ThreadPoolExecutor
+    ref = synth.make_reference(616, synth.scaled_lengths(synth.CHM13_LENGTHS, 0.003), threads=4, n_every=0, inv_every=3_000_000)
+    names = ref.names
+    gpu_ctx.seq_load(_lib.PAV_ROLE_REF, names, [ref.seqs[n] for n in names])
+    free_ref, total = gpu_ctx.mem_info()
+    ref_bytes = 1.375 * sum(ref.seqs[n].shape[0] for n in names)         # ASCII + 2-bit + non-ACGT planes
+    haps = [synth.config2(seed=616 + s, scale=0.003, hap_index=h, ref=ref, threads=4) for s in range(4) for h in range(2)]
+    lanes = []
+    try:
+        for hap in haps:
+            c = _lib.Context(0)
+            lanes.append(c)
+            before, _ = c.mem_info()
+            c.seq_share(gpu_ctx, _lib.PAV_ROLE_REF)
+            assert before - c.mem_info()[0] < 0.1 * ref_bytes                # no second copy of the reference planes
+            c.seq_load(_lib.PAV_ROLE_TIG, hap.tig_names, [hap.tig_seqs[n] for n in hap.tig_names])
+            aln, text, off = cigarcall.pack_alignments(hap.df_align, names, hap.tig_names)
+            c.cigar_load(aln, text, off)
+        free_all, _ = gpu_ctx.mem_info()
+
+        def one(i):
+            counts = lanes[i].cigar_call()
+            return counts, lanes[i].cigar_fetch(counts)
+        with ThreadPoolExecutor(4) as pool:
+            first = list(pool.map(one, range(len(haps))))
+            again = list(pool.map(one, range(len(haps))))
+        free_end, _ = gpu_ctx.mem_info()
+        for hap, (counts, (snv, indel, blob)), (_, (snv2, indel2, blob2)) in zip(haps, first, again):
+            o_snv, o_indel, o_blob, err = util.oracle_records(names, [ref.seqs[n] for n in names], hap.tig_names,
+                                                              [hap.tig_seqs[n] for n in hap.tig_names], hap.df_align)
+            assert err.kind == 0 and counts.aligned_bases == hap.stats['aligned_bp']
+            util.assert_records_equal(snv, o_snv, 'snv')
+            util.assert_records_equal(indel, o_indel, 'indel')
+            assert blob.tobytes() == o_blob.tobytes()
+            assert (snv.tobytes(), indel.tobytes(), blob.tobytes()) == (snv2.tobytes(), indel2.tobytes(), blob2.tobytes())
+        per_hap = (free_ref - free_end) / len(haps)
+        tig_bases = sum(h.tig_seqs[n].shape[0] for h in haps for n in h.tig_names) / len(haps)
+        print(f'HBM: reference planes {ref_bytes / 1e6:.1f} MB once; {per_hap / 1e6:.1f} MB per resident haplotype incl. call records '
+              f'({tig_bases / 1e6:.1f} Mbp of contigs = {1.375 * tig_bases / 1e6:.1f} MB of planes); {total / 1e9:.0f} GB on the device')
+        assert free_all <= free_ref
+        assert len({h.stats['n_snv'] for h in haps}) == len(haps)
+    finally:
+        for c in lanes:
+            c.close()
+
+
 def test_bench_two_ranks_on_one_gpu(built):
     """The N > 1 path of bench.py (staggered prepare, barrier, max-over-ranks time, summed aligned bases) on a one-GPU box:
     two ranks share GPU 0 over gloo.  The driver's real runs use one GPU per rank over RCCL; the rank logic is the same."""
@@ -379,6 +464,7 @@ def test_bench_two_ranks_on_one_gpu(built):
     assert len(lines) == 1
     line = json.loads(lines[0])
     assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['value'] > 0 and line['steps'] == 2
+    assert [r['rank'] for r in line['per_rank']] == [0, 1] and line['load_balance']['max_over_mean_ms'] >= 1.0
     one = synth.config2(seed=1002, scale=0.01, hap_index=0, threads=2).stats['aligned_bp']
     two = synth.config2(seed=1002, scale=0.01, hap_index=1, threads=2).stats['aligned_bp']
     got = line['value'] * 1e9 * line['ms_per_step'] * 1e-3               # aligned bases per step over both ranks
@@ -547,3 +633,33 @@ def test_merged_tables_of_an_empty_alignment_table(built, gpu_ctx, tmp_path):
         with gzip.open(got, 'rb') as a, gzip.open(want, 'rb') as b:
             text = a.read()
             assert text == b.read() and text.count(b'\n') == 1
+
+
+def _device_count():
+    import torch
+    return torch.cuda.device_count()        # counting devices does not initialise the GPU
+
+
+@pytest.mark.skipif(_device_count() < 2, reason='needs two GPUs: one rank per GPU over RCCL')
+def test_bench_ranks_over_rccl(built):
+    """bench.py --gpus N as the driver launches it: one rank per GPU, RCCL (backend nccl) for the barrier and the max-over-ranks /
+    sum-over-ranks reductions, no data-path collective.  Also the launcher-less form `python bench.py --gpus N`, which must
+    start the N ranks itself instead of measuring one GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = min(_device_count(), 8)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(n), '--steps', '4', '--warmup', '2', '--scale', '0.01',
+                          '--no-cpu-baseline'], capture_output=True, text=True, timeout=1800, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == n and line['scaling'] == 'weak' and len(line['per_rank']) == n
+    assert {r['rank'] for r in line['per_rank']} == set(range(n))
+    assert abs(line['value'] - sum(r['aligned_bp'] for r in line['per_rank']) / (line['ms_per_step'] * 1e-3) / 1e9) < 0.02 * line['value']

@@ -1,4 +1,4 @@
-"""Native FASTA reader (pav_fasta_open, csrc/fastaio.hip) against a plain-Python reading of the same files: plain text, gzip
+"""Native FASTA reader (pav_fasta_open, csrc/fastaio.cpp) against a plain-Python reading of the same files: plain text, gzip
 (one and several members), BGZF with parallel inflate, CRLF, missing final newline, empty records, '>' inside lines.
 No GPU needed: the reader is host code of the library.  Semantics = what pysam.FastaFile(...).fetch(name) returns for whole
 records (pavlib/cigarcall.py:59-66): name = first word of the header, sequence = the lines joined, case kept."""
