@@ -823,7 +823,7 @@ __device__ __forceinline__ double run_sum_tail(uint32_t first, int step, uint32_
         const double u = (double)(first + (uint32_t)(step * (int)k)) * inv_h - xs;
         const double t = exp(-(u * u) / 2);
         sum += t;
-        if (t < 1e-19 * sum) break;
+        if (t <= 1e-19 * sum) break;                                   // also when everything so far underflowed to zero
     }
     return sum;
 }
@@ -841,6 +841,8 @@ __device__ __forceinline__ double kde_state_runs(const RunDev *__restrict__ runs
         const RunDev rn = runs[r];
         const double da = (double)rn.a - x, db = (double)rn.b - x;
         const double near = da >= 0.0 ? da : (db <= 0.0 ? -db : 0.0);  // distance of the nearest run element
+        if (near * inv_h > 38.8) continue;                             // exp(-u^2 / 2) is exactly 0.0 from u = 38.6 on: every term of
+                                                                       // the run is zero in scipy's sum as well
         if ((double)(rn.b - rn.a) < short_len) {
             for (uint32_t i = rn.a; i <= rn.b; ++i) { const double u = (double)i * inv_h - xs; sum += exp(-(u * u) / 2); }
         } else if (near * inv_h * inv_h > 0.1) {                       // u/h > 0.1: steep tail
