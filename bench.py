@@ -62,9 +62,10 @@ def main():
     ap.add_argument('--workload', choices=['cigar+inv', 'cigar'], default='cigar+inv',
                     help="'cigar+inv' = the whole path of the metric: CIGAR-call + flagging + k-mer inversion scan of every flagged "
                          "locus (configs[2]: both haplotypes of a diploid sample per GPU); 'cigar' = BASELINE configs[1], CIGAR-call only")
-    ap.add_argument('--lanes', type=int, default=2,
+    ap.add_argument('--lanes', type=int, default=4,
                     help='haplotypes resident per GPU, one context + host thread each, sharing one resident reference; the K steps '
-                         'alternate between them (default 2 = h1 + h2 of the diploid sample of configs[2]; 1 = one haplotype)')
+                         'go round them (default 4 = h1 + h2 of two phased diploid samples, the per-GPU share of configs[2] / [3]; '
+                         '1 = one haplotype, no overlap)')
     ap.add_argument('--pair-frac', type=float, default=PAIR_FRAC, help='generator: fraction of indel events emitted as a matched DEL + INS')
     ap.add_argument('--eager-tables', action='store_true',
                     help='copy the density tables of every inversion call to pinned host memory inside the timed region (round-1 '
@@ -281,7 +282,10 @@ def main():
             return t_c, float(tt_.item())
         return t_c, t_c
 
-    run_steps(max(args.warmup, n_lanes))                     # every lane at least once: buffers sized, tables known
+    # Untimed warm-up: W steps as asked, but at least two per lane - a lane's buffers are sized by its first pass and the two
+    # alternating table arenas of its scan by its first two
+    warmup_run = max(args.warmup, 2 * n_lanes)
+    run_steps(warmup_run)
 
     # ---- timed region: exactly K steps, profiling off ---------------------------------------------------
     t_local, t_max = timed(args.steps)
@@ -317,7 +321,7 @@ def main():
 
     # ---- configs[1] in the same run: K steps of CIGAR-call only, timed and event-profiled the same way ----------------
     def side_leg(workload):
-        run_steps(max(1, args.warmup), workload)
+        run_steps(max(1, args.warmup, n_lanes), workload)
         _, t_c = timed(args.steps, workload)
         ctx.prof_reset()
         ctx.prof_enable(True)
@@ -705,13 +709,13 @@ def main():
             'dtype': 'u8/u32 (integer + byte)', 'data': 'synthetic',
             'config': {'workload': ('BASELINE configs[1]: one hg38-shaped haplotype, CIGAR-call only, one haplotype per GPU'
                                     if args.workload == 'cigar' else
-                                    f'BASELINE configs[2]: phased diploid sample (h1 + h2, hg38-shaped), {n_lanes} haplotype(s) resident per GPU '
-                                    'against one resident reference; a step = one haplotype through CIGAR-call + signature flagging + '
-                                    'k-mer inversion density scan of every locus the flagging marks TRY_INV; steps alternate between the '
-                                    'haplotypes (configs[1] = CIGAR-call only: see cigar_only)'),
+                                    f'BASELINE configs[2] / [3] per-GPU share: {n_lanes} hg38-shaped haplotype(s) (h1 + h2 of phased diploid samples) '
+                                    'resident per GPU against one resident reference; a step = one haplotype through CIGAR-call + '
+                                    'signature flagging + k-mer inversion density scan of every locus the flagging marks TRY_INV; the '
+                                    'steps go round the haplotypes (configs[1] = CIGAR-call only: see cigar_only)'),
                        'scale': args.scale, 'seed': args.seed, 'aligned_bp_per_gpu': int(counts.aligned_bases),
                        'n_aln': int(aln.shape[0]), 'n_ops': int(n_ops), 'n_snv': int(n_snv), 'n_indel': int(n_indel),
-                       'lanes_per_gpu': n_lanes, 'pair_frac': args.pair_frac if gen_kw else 0.0,
+                       'lanes_per_gpu': n_lanes, 'pair_frac': args.pair_frac if gen_kw else 0.0, 'warmup_steps_run': warmup_run,
                        'call_tables': 'copied to pinned host memory inside the step' if args.eager_tables else 'resident in HBM (D2H in host.d2h_density_tables_s)',
                        'parallelism': f'{world} GPU(s) x {n_lanes} resident haplotype(s), one host thread each; no collective'},
             'per_rank': per_rank,

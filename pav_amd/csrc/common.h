@@ -167,22 +167,26 @@ struct CallFetch {              // one call of the batch still resident on the d
     uint32_t job, n, ref_id;
     uint64_t ref_up_pos, ref_up_end, ref_dn_pos, ref_dn_end;
     int64_t base, tig_up_pos, tig_up_end, tig_dn_pos, tig_dn_end;
-    uint32_t *index; int8_t *state_mer, *state; double *kern[3]; uint64_t *kmer; uint8_t *flank, *match;   // pinned host
 };
 // The packed call tables of one scan round on the device (+ the flank k-mer sets and descriptors in front of / behind them)
 // and the copies that bring them to the host block of the round.
 struct CallStage {
     DevBuf buf;
     std::vector<uint8_t> desc_host;
-    struct Copy { const void *src; void *dst; size_t bytes; };
+    struct Copy { const void *src; size_t dst_off; size_t bytes; };   // dst_off: into the round's host block
     Copy copies[2];
     int n_copies = 0;
+    uint64_t rows = 0;                    // table rows of the round; host block = whole-round columns K0 | K1 | K2 | KMER | INDEX |
+    void *host = nullptr;                 // STATE_MER | STATE | FLANK | MATCH (40 bytes per row), bound by the caller before stage_copy
+    struct Entry { uint32_t owner; uint32_t n; uint64_t row0; bool has_k1; };   // the calls of the round in block order
+    std::vector<Entry> entries;
 };
 // Density tables + FLANK / MATCH of all calls of the last batch, packed into `stage` in the host block's column order.
 // k1_rows: rows of the leading calls whose KERN_FWDREV column is wanted; the column of the calls behind them (no FWDREV
 // k-mers: all zeros, scripts/density.py:313-323) is not sent over PCIe.  = all rows to copy everything.
-// copy_now: queue the device-to-host copies on the copy stream at once; otherwise they are left in stage.copies for
-// stage_copy() - the tables stay in HBM until a reader asks for them.
+// The copies that bring the block to stage.host are left in stage.copies for stage_copy(); with copy_now the copy stream is
+// made to wait for the gather and they are queued at once (stage.host must be bound), otherwise the tables stay in HBM until
+// a reader asks for them.
 int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls, uint64_t k1_rows, CallStage &stage, bool copy_now);
 int stage_copy(pav_ctx *ctx, CallStage &stage);
 

@@ -149,6 +149,27 @@ int pav_device_count(void) {
 
 const char *pav_last_error(const pav_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
+// The side stream (contig pack, SNV rows).  PAV_PACK_CUS = n (experiment): restrict it to n compute units with a CU mask, so
+// that the short kernels of the main stream always find a free CU next to the HBM-saturating pack; priorities cannot be
+// combined with a mask, the stream then has the default one.
+static hipError_t create_side_stream(hipStream_t *st, int prio, int n_cu) {
+    const char *env = getenv("PAV_PACK_CUS");
+    const int want = env ? atoi(env) : 0;
+    if (want <= 0 || want >= n_cu) return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio);
+    std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32, 0u);
+    const char *mode = getenv("PAV_PACK_CU_SPREAD");
+    for (int i = 0; i < n_cu; ++i) {
+        // spread: leave every (n_cu / (n_cu - want))-th unit free; otherwise the low `want` units
+        const bool on = mode ? ((long long)(i + 1) * (n_cu - want) / n_cu == (long long)i * (n_cu - want) / n_cu) : i < want;
+        if (on) mask[(size_t)i / 32] |= 1u << (i % 32);
+    }
+    return hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data());
+}
+
+// PAV_PRIO = main | equal (experiment): which of the two streams gets the high priority (default: the side stream).
+static int main_prio(int lo, int hi) { const char *e = getenv("PAV_PRIO"); return e && !strcmp(e, "main") ? hi : lo; }
+static int side_prio(int lo, int hi) { const char *e = getenv("PAV_PRIO"); return e && (!strcmp(e, "main") || !strcmp(e, "equal")) ? lo : hi; }
+
 pav_ctx *pav_create(int device_id) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -183,8 +204,8 @@ pav_ctx *pav_create(int device_id) {
         // that way (0.68 ms = 0.78 of the HBM peak inside the step; 0.78 ms = 0.68 with the priorities the other way round).
         // The whole path runs at the same rate either way (the step is bound by the call tables' PCIe time); a CIGAR-call-only
         // step costs 1.31 instead of 1.19 ms, because its chain now waits for the pack more often.
-        (e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_lo)) != hipSuccess ||
-        (e = hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_hi)) != hipSuccess ||
+        (e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, main_prio(prio_lo, prio_hi))) != hipSuccess ||
+        (e = create_side_stream(&ctx->stream2, side_prio(prio_lo, prio_hi), ctx->n_cu)) != hipSuccess ||
         (e = hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, prio_lo)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->tables_done, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->tables_done_prev, hipEventDisableTiming)) != hipSuccess ||

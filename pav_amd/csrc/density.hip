@@ -1339,21 +1339,12 @@ int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls, uint6
                D->kern[2].as<double>(), D->kmer.as<unsigned long long>(), d_keys, g_index, g_sm, g_st, g_k0, g_k1, g_k2, g_kmer, g_fl, g_ma);
     // Host side (invscan.cpp): the round's block is laid out as whole-round columns, K0 | K1 | K2 | KMER | INDEX | STATE_MER |
     // STATE | FLANK | MATCH, exactly like the packed device columns: one copy (two when the tail of K1 stays behind).
-    bool bulk = true;
-    for (size_t c = 0; c + 1 < calls.size() && bulk; ++c)
-        bulk = calls[c + 1].kern[0] == calls[c].kern[0] + calls[c].n;
-    const CallFetch &f0 = calls[0];
-    bulk = bulk && f0.kern[1] == f0.kern[0] + total && f0.kern[2] == f0.kern[1] + total &&
-           reinterpret_cast<uint8_t *>(f0.kmer) == reinterpret_cast<uint8_t *>(f0.kern[2] + total) &&
-           reinterpret_cast<uint8_t *>(f0.index) == reinterpret_cast<uint8_t *>(f0.kmer + total) &&
-           reinterpret_cast<uint8_t *>(f0.state_mer) == reinterpret_cast<uint8_t *>(f0.index + total) &&
-           f0.state == f0.state_mer + total && f0.flank == reinterpret_cast<uint8_t *>(f0.state + total) && f0.match == f0.flank + total;
-    if (!bulk) return fail(ctx, PAV_E_ARG, "density_fetch_calls: the host block of a round must be laid out as whole-round columns");
+    stage.rows = total;
     if (k1_rows >= total) {
-        stage.copies[stage.n_copies++] = CallStage::Copy{d_cols, f0.kern[0], col_bytes};
+        stage.copies[stage.n_copies++] = CallStage::Copy{d_cols, 0, col_bytes};
     } else {                                                        // K0 | leading part of K1, then K2 | ... | MATCH
-        stage.copies[stage.n_copies++] = CallStage::Copy{d_cols, f0.kern[0], 8ull * (total + k1_rows)};
-        stage.copies[stage.n_copies++] = CallStage::Copy{g_k2, f0.kern[2], col_bytes - 16ull * total};
+        stage.copies[stage.n_copies++] = CallStage::Copy{d_cols, 0, 8ull * (total + k1_rows)};
+        stage.copies[stage.n_copies++] = CallStage::Copy{g_k2, 16ull * total, col_bytes - 16ull * total};
     }
     if (getenv("PAV_TIMING")) fprintf(stderr, "[pav timing]   call tables: %zu calls, %llu rows (%.1f MB %s), %llu hash slots, %u insert tiles\n",
                                       calls.size(), (unsigned long long)total, (col_bytes - 8.0 * (double)(total - std::min<uint64_t>(k1_rows, total))) / 1e6,
@@ -1369,8 +1360,10 @@ int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls, uint6
 
 // Queue the device-to-host copies of a packed round on the copy stream (the caller has made that stream wait for the gather).
 int stage_copy(pav_ctx *ctx, CallStage &stage) {
+    if (stage.n_copies && !stage.host) return fail(ctx, PAV_E_STATE, "stage_copy: the round has no host block");
     for (int c = 0; c < stage.n_copies; ++c)
-        PAV_HIP(ctx, hipMemcpyAsync(stage.copies[c].dst, stage.copies[c].src, stage.copies[c].bytes, hipMemcpyDeviceToHost, ctx->stream3));
+        PAV_HIP(ctx, hipMemcpyAsync(static_cast<uint8_t *>(stage.host) + stage.copies[c].dst_off, stage.copies[c].src, stage.copies[c].bytes,
+                                    hipMemcpyDeviceToHost, ctx->stream3));
     if (stage.n_copies) {
         PAV_HIP(ctx, hipEventRecord(ctx->tables_done, ctx->stream3));
         ctx->tables_pending = true;

@@ -294,7 +294,34 @@ public:
 
 const std::vector<std::string> &seq_names(pav_ctx *ctx, int role) { return istate(ctx)->names[role]; }
 
-// Host copies of the call tables of the last scan: queue whatever a lazy scan left in HBM, then wait for the copy stream.
+// Give a round its pinned host block (whole-round columns: K0 | K1 | K2 | KMER | INDEX | STATE_MER | STATE | FLANK | MATCH, each
+// holding the calls one after the other) and point the tables of its calls into it.
+static int bind_round(pav_ctx *ctx, InvState *S, CallStage &stg) {
+    if (stg.host || stg.rows == 0) return PAV_OK;
+    const size_t rows = stg.rows;
+    const size_t total = (rows * 40 + 64 + 63) / 64 * 64;             // blocks stay 64-byte aligned
+    void *blk = S->pin_alloc(total);
+    if (!blk) return fail(ctx, PAV_E_HIP, "pav_inv_scan_batch: cannot pin %zu bytes of host memory", total);
+    stg.host = blk;
+    double *c_k0 = static_cast<double *>(blk), *c_k1 = c_k0 + rows, *c_k2 = c_k1 + rows;
+    uint64_t *c_kmer = reinterpret_cast<uint64_t *>(c_k2 + rows);
+    uint32_t *c_index = reinterpret_cast<uint32_t *>(c_kmer + rows);
+    int8_t *c_sm = reinterpret_cast<int8_t *>(c_index + rows), *c_st = c_sm + rows;
+    uint8_t *c_fl = reinterpret_cast<uint8_t *>(c_st + rows), *c_ma = c_fl + rows;
+    for (const CallStage::Entry &e : stg.entries) {
+        InvTable *tab = S->tables[e.owner].get();
+        if (!tab) continue;
+        const size_t o = e.row0;
+        tab->kern[0] = c_k0 + o; tab->kern[1] = c_k1 + o; tab->kern[2] = c_k2 + o; tab->kmer = c_kmer + o; tab->index = c_index + o;
+        tab->state_mer = c_sm + o; tab->state = c_st + o; tab->flank = c_fl + o; tab->match = c_ma + o;
+        // a call without FWDREV k-mers has a KERN_FWDREV column of zeros (scripts/density.py:313-323): it is not copied, the
+        // table reads a shared block of zeros (read-only for every consumer)
+        if (!e.has_k1) tab->kern[1] = const_cast<double *>(S->zeros(e.n));
+    }
+    return PAV_OK;
+}
+
+// Host copies of the call tables of the last scan: bind and queue whatever a lazy scan left in HBM, then wait for the copy stream.
 static int tables_on_host(pav_ctx *ctx, InvState *S) {
     bool any = false;
     for (size_t r = 0; r < S->stage_used; ++r) any = any || S->stage_sets[S->cur_set][r]->n_copies > 0;
@@ -302,7 +329,9 @@ static int tables_on_host(pav_ctx *ctx, InvState *S) {
         PAV_HIP(ctx, hipSetDevice(ctx->device));
         PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));              // the gather kernels of the scan
         for (size_t r = 0; r < S->stage_used; ++r) {
-            const int rc = stage_copy(ctx, *S->stage_sets[S->cur_set][r]);
+            CallStage &stg = *S->stage_sets[S->cur_set][r];
+            int rc = bind_round(ctx, S, stg);
+            if (rc == PAV_OK) rc = stage_copy(ctx, stg);
             if (rc != PAV_OK) return rc;
         }
     }
@@ -571,29 +600,20 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
             }
             size_t rows = 0, k1_rows = 0;
             for (size_t c = 0; c < round_calls.size(); ++c) { rows += round_calls[c].n; if (round_k1[c]) k1_rows += round_calls[c].n; }
-            const size_t total = (rows * 40 + 64 + 63) / 64 * 64;           // blocks stay 64-byte aligned (vector stores from the device)
-            void *blk = S->pin_alloc(total);
-            if (!blk) return fail(ctx, PAV_E_HIP, "pav_inv_scan_batch: cannot pin %zu bytes of host memory", total);
-            double *c_k0 = static_cast<double *>(blk), *c_k1 = c_k0 + rows, *c_k2 = c_k1 + rows;
-            uint64_t *c_kmer = reinterpret_cast<uint64_t *>(c_k2 + rows);
-            uint32_t *c_index = reinterpret_cast<uint32_t *>(c_kmer + rows);
-            int8_t *c_sm = reinterpret_cast<int8_t *>(c_index + rows), *c_st = c_sm + rows;
-            uint8_t *c_fl = reinterpret_cast<uint8_t *>(c_st + rows), *c_ma = c_fl + rows;
+            CallStage &stg = S->next_stage();
+            stg.entries.clear();
+            stg.host = nullptr;
             size_t o = 0;
             for (size_t c = 0; c < round_calls.size(); ++c) {
-                CallFetch &cf = round_calls[c];
-                auto tab = std::make_unique<InvTable>();
-                tab->n = cf.n;
-                tab->kern[0] = c_k0 + o; tab->kern[1] = c_k1 + o; tab->kern[2] = c_k2 + o; tab->kmer = c_kmer + o; tab->index = c_index + o;
-                tab->state_mer = c_sm + o; tab->state = c_st + o; tab->flank = c_fl + o; tab->match = c_ma + o;
-                cf.index = tab->index; cf.state_mer = tab->state_mer; cf.state = tab->state; cf.kmer = tab->kmer;
-                cf.flank = tab->flank; cf.match = tab->match;
-                for (int q = 0; q < 3; ++q) cf.kern[q] = tab->kern[q];
-                if (!round_k1[c]) tab->kern[1] = const_cast<double *>(S->zeros(cf.n));   // (read-only for every consumer of the table)
-                o += cf.n;
+                stg.entries.push_back(CallStage::Entry{round_owner[c], round_calls[c].n, o, round_k1[c] != 0});
+                auto tab = std::make_unique<InvTable>();            // rows known now; the columns are bound with the host block
+                tab->n = round_calls[c].n;
                 S->tables[round_owner[c]] = std::move(tab);
+                o += round_calls[c].n;
             }
-            rc = density_fetch_calls(ctx, round_calls, k1_rows, S->next_stage(), pp->lazy_tables == 0);
+            stg.rows = rows;
+            if (!pp->lazy_tables) { const int rcb = bind_round(ctx, S, stg); if (rcb != PAV_OK) return rcb; }
+            rc = density_fetch_calls(ctx, round_calls, k1_rows, stg, pp->lazy_tables == 0);
             t_table += now() - t0;
             if (rc != PAV_OK) return rc;
         }

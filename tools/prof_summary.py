@@ -9,6 +9,11 @@
                                                                (issuing / parked / issue-stalled) and of the LDS-array cycles
   python tools/prof_summary.py timeline <db> <out.txt> [ms]    kernels (and copies) of the last [ms] of the trace in start order,
                                                                with the idle gap in front of each (us)
+  python tools/prof_summary.py busy <db> <out.txt> <t0_ms> <t1_ms>   device occupancy of the window [t0, t1) ms after the first
+                                                               kernel: wall time, time with at least one kernel running, sum of
+                                                               kernel durations, per-kernel totals; windows are found with
+                                                               `busy <db> <out> scan <width_ms> [kernel]` (the window of that width
+                                                               with the most launches of `kernel`, default k_kmer_lds: the two-lane region)
 """
 import sqlite3
 import sys
@@ -132,8 +137,50 @@ def timeline(db, out, last_ms=30.0):
     print(open(out).read())
 
 
+def busy(db, out, a, b, mark='k_kmer_lds'):
+    cur = sqlite3.connect(db).cursor()
+    ev = sorted((s, e, short(n)) for n, s, e in cur.execute('select name, start, end from kernels'))
+    t_first = ev[0][0]
+    if a == 'scan':                                         # the window of width b with the most launches of walk_snv: steady state
+        width = float(b) * 1e6
+        marks = [s for s, _, n in ev if n == mark]
+        best, lo = (0, marks[0]), 0
+        for hi in range(len(marks)):
+            while marks[hi] - marks[lo] > width:
+                lo += 1
+            if hi - lo + 1 > best[0]:
+                best = (hi - lo + 1, marks[lo])
+        w0, w1 = best[1], best[1] + width
+    else:
+        w0, w1 = t_first + float(a) * 1e6, t_first + float(b) * 1e6
+    sel = [(max(s, w0), min(e, w1), n) for s, e, n in ev if e > w0 and s < w1]
+    union, end = 0.0, w0
+    for s, e, _ in sel:
+        if e > end:
+            union += e - max(s, end)
+            end = e
+    per = {}
+    for s, e, n in sel:
+        t = per.setdefault(n, [0, 0.0])
+        t[0] += 1
+        t[1] += e - s
+    total = sum(v[1] for v in per.values())
+    packs = per.get('pack_kernel', [0, 0.0])[0]
+    with open(out, 'w') as fh:
+        fh.write(f'# device occupancy, window of {(w1 - w0) / 1e6:.2f} ms starting {(w0 - t_first) / 1e6:.2f} ms after the first kernel ({db})\n')
+        fh.write(f'# passes in the window (pack_kernel launches): {packs}  ->  {(w1 - w0) / 1e6 / max(1, packs):.3f} ms of wall time per pass\n')
+        fh.write(f'wall_ms {(w1 - w0) / 1e6:.3f}   busy_ms (>= 1 kernel running) {union / 1e6:.3f} = {union / (w1 - w0):.3f} of wall   '
+                 f'sum_of_kernel_ms {total / 1e6:.3f} = {total / (w1 - w0):.3f} of wall (kernels of the two lanes overlap)\n')
+        fh.write(f'{"kernel":34s} {"launches":>8s} {"total_ms":>10s} {"per_pass_ms":>12s}\n')
+        for n, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+            fh.write(f'{n:34s} {c:8d} {t / 1e6:10.3f} {t / 1e6 / max(1, packs):12.4f}\n')
+    print(open(out).read())
+
+
 if __name__ == '__main__':
-    if sys.argv[1] == 'pmcjson':
+    if sys.argv[1] == 'busy':
+        busy(*sys.argv[2:7])
+    elif sys.argv[1] == 'pmcjson':
         pmcjson(*sys.argv[2:6])
     elif sys.argv[1] == 'timeline':
         timeline(sys.argv[2], sys.argv[3], float(sys.argv[4]) if len(sys.argv) > 4 else 30.0)
