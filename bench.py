@@ -460,7 +460,7 @@ def main():
                 'walk_snv': 4.0 * n_ops + 16.0 * n_snv + 2.0 * n_snv,          # ops, SNV rows out, REF / ALT bytes in
                 'walk_indel': 4.0 * n_ops + 64.0 * n_indel,
                 'homology_kernel': 128.0 * n_indel,
-                'seq_gather': 2.0 * counts.seq_bytes,
+                'seq_gather': 2.0 * counts.seq_bytes + 64.0 * n_indel,          # SEQ bytes in and out + every INS / DEL record (where to copy from)
                 'rocprim::radix_sort_keys': 7 * 16.0 * n_snv,               # 56 key bits = 7 passes over 8 B keys, in + out
                 'k_snv_keys': 24.0 * n_snv, 'k_indel_keys': 72.0 * n_indel,
             }
@@ -523,7 +523,14 @@ def main():
                     ab = gbs * 1e9 * kern[k_]['avg_ms'] * 1e-3
                     if ab > 0:
                         ratios[k_] = round(tr / ab, 2)
-            roofline['traffic_over_algorithmic'] = {'source': pmc.get('file'), 'ratio': ratios}
+            # walk_snv reads ONE byte per SNV from each ASCII plane; SNVs lie ~470 bases apart, so every byte costs a 32 B sector
+            # of its own (tools/ubench/gather_rate.hip, profiles/r02_gather_rate.txt): its traffic against that granularity
+            sector = None
+            if 'walk_snv' in pmc.get('fetch_kib', {}) and 'walk_snv' in pmc.get('write_kib', {}):
+                sector = round((pmc['fetch_kib']['walk_snv'] + pmc['write_kib']['walk_snv']) * 1024.0 /
+                               (4.0 * n_ops + 16.0 * n_snv + 2 * 32.0 * n_snv), 2)
+            roofline['traffic_over_algorithmic'] = {'source': pmc.get('file'), 'ratio': ratios,
+                                                    'walk_snv_over_sector_granular_model': sector}
 
         def add_alone(roof):
             if pack_alone and pack_alone[0] and roof['kernel'] == 'pack_kernel':

@@ -909,7 +909,7 @@ __global__ __launch_bounds__(64 * KDE_WAVES) void k_kde_eval(KdeArgs A) {
         val[s] = est * kd.cnt[s];                                      // density.py:110-115
     }
     if (t.mode == 0) {
-        // sampled sites go to compact arrays (coalesced here and in k_windows / k_interp, which puts them into the table rows)
+        // sampled sites go to compact arrays (coalesced here and in k_windows; k_finalize puts them into the table rows)
         const uint64_t so = (uint64_t)kd.samp_off + t.first + lane;
 #pragma unroll
         for (int s = 0; s < 3; ++s) A.ks[s][so] = val[s];
@@ -927,8 +927,7 @@ __global__ __launch_bounds__(64 * KDE_WAVES) void k_kde_eval(KdeArgs A) {
 
 // Windows between consecutive sampled sites (scripts/density.py:257-323), two launches.  k_windows: one lane per window
 // decides whether the states or the densities change inside it; if so its inner sites are queued for full evaluation.
-// k_interp: one lane per row fills the inner sites of the quiet windows by linear interpolation (coalesced stores; with one
-// lane per window the 3 x 19 strided stores per lane made this the second most expensive kernel of the scan).
+// The inner sites of the quiet windows are interpolated by k_finalize (one lane per row, coalesced stores).
 __global__ __launch_bounds__(64) void k_windows(const JobDev *__restrict__ jobs, const EvalTile *__restrict__ tiles,
                                                 const JobKde *__restrict__ kde, const int8_t *__restrict__ state_mer,
                                                 const int8_t *__restrict__ ss, const double *__restrict__ s0,
@@ -972,78 +971,89 @@ __global__ __launch_bounds__(64) void k_windows(const JobDev *__restrict__ jobs,
     }
 }
 
-// One lane per table row: sampled sites are copied from the compact arrays, the inner sites of quiet windows are interpolated
-// (np.interp: slope * (x - x0) + y0); the inner sites of the other windows are written by k_kde_eval (mode 1).
-__global__ __launch_bounds__(256) void k_interp(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
-                                                const JobKde *__restrict__ kde, const uint8_t *__restrict__ win_fill,
-                                                const double *__restrict__ s0, const double *__restrict__ s1,
-                                                const double *__restrict__ s2, double *__restrict__ k0, double *__restrict__ k1,
-                                                double *__restrict__ k2) {
-    const uint64_t ap = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint32_t j = tile_job[ap / DTILE];
-    const JobKde kd = kde[j];
-    if (!kd.finalised) return;
-    const uint64_t off = jobs[j].tpos_off;
-    const uint64_t x = ap - off;
-    if (x >= kd.n) return;
-    const uint64_t q = x / kd.srs;
-    const uint64_t a = q * kd.srs;
+// ---- one pass over the table rows: interpolation, spike rule, arg-max, run heads (scripts/density.py:289-338, pavlib/density.py:330-361)
+struct FinArgs {
+    const JobDev *jobs; const uint32_t *tile_job; const JobKde *kde; const JobStat *stat;
+    const uint8_t *win_fill; const double *ks[3]; double *kern[3]; int8_t *state; const uint32_t *index;
+    HeadEvent *events; uint32_t ev_cap; uint32_t *ev_count;
+    GuardArgs G; uint32_t *blk_spike;
+};
+
+// Densities of row x of a finalised job before the spike rule: a sampled site comes from the compact arrays, a row of an
+// evaluated window from the table (k_kde_eval mode 1 / k_redo wrote it), a row of a quiet window is interpolated between the
+// two sampled sites around it (np.interp: slope * (x - x0) + y0).
+__device__ __forceinline__ void row_raw(const FinArgs &A, const JobKde &kd, uint64_t off, uint32_t x, double (&v)[3]) {
+    const uint32_t q = x / kd.srs, a = q * kd.srs;
     const uint64_t so = (uint64_t)kd.samp_off + q;
-    const double *sk[3] = {s0, s1, s2};
-    double *kk[3] = {k0, k1, k2};
-    if (x == a) {                                                      // a sampled site
+    if (x == a) {
 #pragma unroll
-        for (int s = 0; s < 3; ++s) kk[s][ap] = sk[s][so];
+        for (int s = 0; s < 3; ++s) v[s] = A.ks[s][so];
         return;
     }
-    uint64_t b = (q + 1) * kd.srs;                                     // x > a, so the window has an end: q + 1 < n_samp
+    uint32_t b = a + kd.srs;                                           // x > a, so the window has an end: q + 1 < n_samp
     if (b > kd.n - 1) b = kd.n - 1;
     if (x == b) {                                                      // the last sampled site (n - 1, not a multiple of srs)
 #pragma unroll
-        for (int s = 0; s < 3; ++s) kk[s][ap] = sk[s][so + 1];
+        for (int s = 0; s < 3; ++s) v[s] = A.ks[s][so + 1];
         return;
     }
-    if (win_fill[off + q]) return;
+    if (A.win_fill[off + q]) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) v[s] = A.kern[s][off + x];
+        return;
+    }
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-        const double ya = sk[s][so], yb = sk[s][so + 1];
+        const double ya = A.ks[s][so], yb = A.ks[s][so + 1];
         const double slope = (yb - ya) / ((double)b - (double)a);
-        kk[s][ap] = slope * ((double)x - (double)a) + ya;
+        v[s] = slope * ((double)x - (double)a) + ya;
     }
 }
+__device__ __forceinline__ int spike_argmax(double (&v)[3]) {         // KERN > 1.0 -> 1 / KERN, then np.argmax (:329-338)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) if (v[s] > 1.0) v[s] = 1 / v[s];
+    return argmax3(v[0], v[1], v[2]);
+}
 
-// Spike penalty and arg-max (scripts/density.py:329-338).  Near-tie guard of the arg-max: the sites a doubtful row rests on -
-// itself when it is a sampled site or a row of an evaluated window, the two ends of its window when it was interpolated -
-// are queued for evaluation in scipy's order unless they already are.  blk_spike: rows of the block with a value within
-// G.rel of the spike threshold 1.0 (counted only: the branch is continuous, see include/pav_amd.h).
-__global__ __launch_bounds__(256) void k_finalize(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
-                                                  const JobKde *__restrict__ kde, double *__restrict__ k0,
-                                                  double *__restrict__ k1, double *__restrict__ k2, int8_t *__restrict__ state,
-                                                  const uint8_t *__restrict__ win_fill, GuardArgs G,
-                                                  uint32_t *__restrict__ blk_spike) {
+// One lane per table row.  Finalised jobs: the row's densities (row_raw), spike rule, arg-max, the three KERN columns and
+// STATE written once; near-tie guard of the arg-max - the sites a doubtful row rests on (itself when it is a sampled site or
+// a row of an evaluated window, the two ends of its window when it was interpolated) are queued for evaluation in scipy's
+// order unless they already are; blk_spike: rows of the block with a value within G.rel of the spike threshold 1.0 (counted
+// only: the branch is continuous, see include/pav_amd.h).  Every job (un-finalised tables have STATE = -1 throughout): one
+// event per row that starts a run of equal STATE and one end marker - the input of rl_encoder; the state of the row in front
+// of a block comes from re-deriving that row (its own lane may be rewriting its spiked value meanwhile: v and 1 / v give the
+// same state).  Failed jobs have no rows.
+__global__ __launch_bounds__(256) void k_finalize(FinArgs A) {
     __shared__ uint32_t s_spike[4];
+    __shared__ int8_t s_state[256];
+    const GuardArgs &G = A.G;
     const uint64_t ap = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint32_t j = tile_job[ap / DTILE];
-    const JobKde kd = kde[j];
-    const uint64_t off = jobs[j].tpos_off;
+    const uint32_t j = A.tile_job[ap / DTILE];
+    const JobKde kd = A.kde[j];
+    const uint64_t off = A.jobs[j].tpos_off;
+    const uint32_t n = kd.finalised ? kd.n : A.stat[j].n_rows;
+    const uint32_t x = (uint32_t)(ap - off);
+    const bool live = ap - off < n;
     bool spike_near = false;
-    if (kd.finalised && ap - off < kd.n) {
-        double a = k0[ap], b = k1[ap], c = k2[ap];
-        if (G.rel > 0.0) spike_near = fabs(a - 1.0) < G.rel || fabs(b - 1.0) < G.rel || fabs(c - 1.0) < G.rel;
-        if (a > 1.0) { a = 1 / a; k0[ap] = a; }
-        if (b > 1.0) { b = 1 / b; k1[ap] = b; }
-        if (c > 1.0) { c = 1 / c; k2[ap] = c; }
-        state[ap] = (int8_t)argmax3(a, b, c);
-        if (G.rel > 0.0 && near_argmax(a, b, c, G.rel)) {
+    int st = -1;
+    if (live && kd.finalised) {
+        double v[3];
+        row_raw(A, kd, off, x, v);
+        if (G.rel > 0.0) spike_near = fabs(v[0] - 1.0) < G.rel || fabs(v[1] - 1.0) < G.rel || fabs(v[2] - 1.0) < G.rel;
+        st = spike_argmax(v);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) A.kern[s][ap] = v[s];
+        A.state[ap] = (int8_t)st;
+        if (G.rel > 0.0 && near_argmax(v[0], v[1], v[2], G.rel)) {
             if (G.pass == 0) atomicAdd(&G.stat[j].n_near, 1u);
-            const uint32_t x = (uint32_t)(ap - off), q = x / kd.srs;
+            const uint32_t q = x / kd.srs;
             bool exact;
             if (x == q * kd.srs || x == kd.n - 1) {                    // a sampled site (n - 1 is site q + 1 unless a multiple of srs)
                 const uint32_t qs = x == q * kd.srs ? q : q + 1;
                 const uint64_t so = (uint64_t)kd.samp_off + qs;
                 exact = kd.all_direct || (G.samp_flag[so] & SF_EXACT);
                 if (!exact) guard_flag_sample(G, j, qs, so);
-            } else if (win_fill[off + q]) {                            // evaluated row
+            } else if (A.win_fill[off + q]) {                          // evaluated row
                 exact = kd.all_direct || (G.row_flag[ap] & RF_EXACT);
                 if (!exact) guard_flag_row(G, j, x, ap);
             } else {                                                   // interpolated between the ends of window q
@@ -1055,15 +1065,32 @@ __global__ __launch_bounds__(256) void k_finalize(const JobDev *__restrict__ job
             }
             if (exact && !(G.row_flag[ap] & RF_COUNTED)) {
                 G.row_flag[ap] |= RF_COUNTED;
-                if (near_argmax(a, b, c, G.unres)) atomicAdd(&G.stat[j].n_unres, 1u);
+                if (near_argmax(v[0], v[1], v[2], G.unres)) atomicAdd(&G.stat[j].n_unres, 1u);
             }
         }
     }
-    if (blk_spike) {
-        const unsigned long long bal = __ballot(spike_near);
-        if ((threadIdx.x & 63) == 0) s_spike[threadIdx.x >> 6] = (uint32_t)__popcll(bal);
-        __syncthreads();
-        if (threadIdx.x == 0) blk_spike[blockIdx.x] = s_spike[0] + s_spike[1] + s_spike[2] + s_spike[3];
+    s_state[threadIdx.x] = (int8_t)st;
+    const unsigned long long bal = __ballot(spike_near);
+    if ((threadIdx.x & 63) == 0) s_spike[threadIdx.x >> 6] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    if (A.blk_spike && threadIdx.x == 0) A.blk_spike[blockIdx.x] = s_spike[0] + s_spike[1] + s_spike[2] + s_spike[3];
+    if (!live) return;
+    // run heads
+    bool head = x == 0;
+    if (!head) {
+        int prev;
+        if (threadIdx.x > 0) prev = s_state[threadIdx.x - 1];
+        else if (!kd.finalised) prev = -1;
+        else { double pv[3]; row_raw(A, kd, off, x - 1, pv); prev = spike_argmax(pv); }
+        head = prev != st;
+    }
+    if (head) {
+        const uint32_t e = atomicAdd(A.ev_count, 1u);
+        if (e < A.ev_cap) A.events[e] = HeadEvent{j, x, (int32_t)st, A.index[ap], x ? A.index[ap - 1] : 0u, 0u};
+    }
+    if (x == n - 1) {
+        const uint32_t e = atomicAdd(A.ev_count, 1u);
+        if (e < A.ev_cap) A.events[e] = HeadEvent{j, n, -2, 0u, A.index[ap], 0u};
     }
 }
 
@@ -1550,13 +1577,21 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     for (int s = 0; s < 3; ++s) CA.list[s] = D->list[s].as<uint32_t>();
     std::vector<JobStat> hs(n_jobs);
     constexpr uint32_t EV_PREFETCH = 4096;                             // head events copied together with their count
-    const size_t pin_guard_off = (std::max(sizeof(JobStat) * (size_t)n_jobs, sizeof(HeadEvent) * (size_t)EV_PREFETCH + 64) + 63) / 64 * 64;
+    // pinned readback area: [event count | first events] [per-job statistics] [guard counters]
+    const size_t pin_stat_off = (sizeof(HeadEvent) * (size_t)EV_PREFETCH + 64 + 63) / 64 * 64;
+    const size_t pin_guard_off = pin_stat_off + (sizeof(JobStat) * (size_t)n_jobs + 63) / 64 * 64;
     uint8_t *h_pin = static_cast<uint8_t *>(D->pinned(pin_guard_off + 64));
     if (!h_pin) return fail(ctx, PAV_E_HIP, "pav_density_batch: cannot pin host memory for the readbacks");
+    auto queue_stats = [&]() -> int {                                  // in front of a synchronisation that follows
+        PAV_HIP(ctx, hipMemcpyAsync(h_pin + pin_stat_off, d_stat, sizeof(JobStat) * n_jobs, hipMemcpyDeviceToHost, st));
+        return PAV_OK;
+    };
+    auto take_stats = [&]() { memcpy(hs.data(), h_pin + pin_stat_off, sizeof(JobStat) * n_jobs); };
     auto read_stats = [&]() -> int {
-        PAV_HIP(ctx, hipMemcpyAsync(h_pin, d_stat, sizeof(JobStat) * n_jobs, hipMemcpyDeviceToHost, st));
+        const int rcq = queue_stats();
+        if (rcq != PAV_OK) return rcq;
         PAV_HIP(ctx, hipStreamSynchronize(st));
-        memcpy(hs.data(), h_pin, sizeof(JobStat) * n_jobs);
+        take_stats();
         return PAV_OK;
     };
     // compaction to the informative rows, then readback 1: per-job counts and moments -> status, bandwidths (host, libm:
@@ -1631,23 +1666,38 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
         }
     }
 
-    // Run heads of a per-row state array (STATE_MER here, STATE for rl_encoder below): events sorted by (job, row).
-    auto collect_heads = [&](const int8_t *d_state, std::vector<HeadEvent> &ev, uint64_t hint) -> int {
-        uint32_t cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(65536, hint / 16 + 4ull * n_jobs), 0x7FFFFFFF);
+    // Run heads of a per-row state array: events sorted by (job, row).  STATE_MER: k_heads; STATE (rl_encoder): k_finalize
+    // writes the events itself, k_heads only repeats the work when the event buffer was too small.
+    uint32_t ev_cap = 0;
+    auto prepare_events = [&](uint64_t hint) -> int {
+        ev_cap = std::max(ev_cap, (uint32_t)std::min<uint64_t>(std::max<uint64_t>(65536, hint / 16 + 4ull * n_jobs), 0x7FFFFFFF));
+        PAV_HIP(ctx, D->events.reserve(sizeof(HeadEvent) * (size_t)ev_cap));
+        PAV_HIP(ctx, D->ev_count.reserve(16));
+        PAV_HIP(ctx, hipMemsetAsync(D->ev_count.p, 0, 4, st));
+        return PAV_OK;
+    };
+    auto launch_heads = [&](const int8_t *d_state) -> int {
+        PAV_LAUNCH(ctx, "k_heads", k_heads, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_stat, d_state,
+                   D->index.as<uint32_t>(), D->events.as<HeadEvent>(), ev_cap, D->ev_count.as<uint32_t>());
+        return PAV_OK;
+    };
+    // d_state: the array k_heads walks again should the events not fit
+    auto read_events = [&](const int8_t *d_state, std::vector<HeadEvent> &ev) -> int {
         while (true) {
-            PAV_HIP(ctx, D->events.reserve(sizeof(HeadEvent) * (size_t)cap));
-            PAV_HIP(ctx, D->ev_count.reserve(16));
-            PAV_HIP(ctx, hipMemsetAsync(D->ev_count.p, 0, 4, st));
-            PAV_LAUNCH(ctx, "k_heads", k_heads, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_stat, d_state,
-                       D->index.as<uint32_t>(), D->events.as<HeadEvent>(), cap, D->ev_count.as<uint32_t>());
             // the count and the first EV_PREFETCH events come back together (a batch of 1 000 regions has ~2 000 heads)
-            const uint32_t pre = std::min(cap, EV_PREFETCH);
+            const uint32_t pre = std::min(ev_cap, EV_PREFETCH);
             PAV_HIP(ctx, hipMemcpyAsync(h_pin, D->ev_count.p, 4, hipMemcpyDeviceToHost, st));
             PAV_HIP(ctx, hipMemcpyAsync(h_pin + 64, D->events.p, sizeof(HeadEvent) * pre, hipMemcpyDeviceToHost, st));
             PAV_HIP(ctx, hipStreamSynchronize(st));
             uint32_t n_ev = 0;
             memcpy(&n_ev, h_pin, 4);
-            if (n_ev > cap) { cap = n_ev + 1024; continue; }
+            if (n_ev > ev_cap) {
+                ev_cap = n_ev + 1024;
+                int rc = prepare_events(0);
+                if (rc == PAV_OK) rc = launch_heads(d_state);
+                if (rc != PAV_OK) return rc;
+                continue;
+            }
             ev.resize(n_ev);
             if (n_ev) memcpy(ev.data(), h_pin + 64, sizeof(HeadEvent) * std::min(n_ev, pre));
             if (n_ev > pre)
@@ -1656,6 +1706,12 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
         }
         std::sort(ev.begin(), ev.end(), [](const HeadEvent &a, const HeadEvent &b) { return a.job != b.job ? a.job < b.job : a.row < b.row; });
         return PAV_OK;
+    };
+    auto collect_heads = [&](const int8_t *d_state, std::vector<HeadEvent> &ev, uint64_t hint) -> int {
+        int rc = prepare_events(hint);
+        if (rc == PAV_OK) rc = launch_heads(d_state);
+        if (rc == PAV_OK) rc = read_events(d_state, ev);
+        return rc;
     };
     uint64_t total_rows = 0;
     for (uint32_t j = 0; j < n_jobs; ++j) total_rows += hs[j].n_rows;
@@ -1783,6 +1839,10 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     RA.jobs = d_jobs; RA.kde = d_kde; RA.ss = D->ss.as<int8_t>(); RA.win_fill = D->win_fill.as<uint8_t>();
     for (int s = 0; s < 3; ++s) { RA.list[s] = D->list[s].as<uint32_t>(); RA.ks[s] = D->ks[s].as<double>(); RA.kern[s] = D->kern[s].as<double>(); }
 
+    FinArgs FA;
+    FA.jobs = d_jobs; FA.tile_job = d_tjt; FA.kde = d_kde; FA.stat = d_stat; FA.win_fill = D->win_fill.as<uint8_t>();
+    FA.state = D->state.as<int8_t>(); FA.index = D->index.as<uint32_t>();
+    for (int s = 0; s < 3; ++s) { FA.ks[s] = D->ks[s].as<double>(); FA.kern[s] = D->kern[s].as<double>(); }
     std::vector<HeadEvent> ev;
     std::vector<EvalTile> ftiles;                                      // alive until the synchronisation of collect_heads
     if (!tiles.empty()) {
@@ -1837,9 +1897,6 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             PAV_LAUNCH(ctx, "k_windows", k_windows, (uint32_t)tiles.size(), 64, 0, d_jobs, D->tiles.as<EvalTile>(), d_kde, D->state_mer.as<int8_t>(),
                        D->ss.as<int8_t>(), D->ks[0].as<double>(), D->ks[1].as<double>(), D->ks[2].as<double>(),
                        pp->state_run_delta, D->fill_list.as<uint32_t>(), D->win_fill.as<uint8_t>(), d_stat, G);
-            PAV_LAUNCH(ctx, "k_interp", k_interp, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_kde, D->win_fill.as<uint8_t>(),
-                       D->ks[0].as<double>(), D->ks[1].as<double>(), D->ks[2].as<double>(), D->kern[0].as<double>(),
-                       D->kern[1].as<double>(), D->kern[2].as<double>());
             if (pass == 0) lap("kde queue 1");
             { const int rcs = read_stats(); if (rcs != PAV_OK) return rcs; }
             if (pass == 0) lap("kde eval 1");
@@ -1859,15 +1916,18 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
                 RA.first = 0; RA.kinds = 2;
                 PAV_LAUNCH(ctx, "k_redo", k_redo, processed, 64, 0, RA);
             }
-            PAV_LAUNCH(ctx, "k_finalize", k_finalize, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_kde, D->kern[0].as<double>(),
-                       D->kern[1].as<double>(), D->kern[2].as<double>(), D->state.as<int8_t>(), D->win_fill.as<uint8_t>(), G,
-                       G.rel > 0.0 ? D->scratch.as<uint32_t>() : nullptr);
+            { const int rce = prepare_events(total_rows); if (rce != PAV_OK) return rce; }
+            FA.G = G; FA.ev_cap = ev_cap; FA.events = D->events.as<HeadEvent>(); FA.ev_count = D->ev_count.as<uint32_t>();
+            FA.blk_spike = G.rel > 0.0 ? D->scratch.as<uint32_t>() : nullptr;
+            PAV_LAUNCH(ctx, "k_finalize", k_finalize, (uint32_t)(a_t / 256), 256, 0, FA);
             if (G.rel > 0.0)
                 PAV_LAUNCH(ctx, "k_spike_sum", k_spike_sum, n_jobs, 256, 0, d_jobs, d_kde, D->scratch.as<uint32_t>(), d_stat);
             if (pass == 0) lap("kde");
             // ---- rl_encoder: run heads -> host (readback 3, with the guard's counters) -----------------------------------
             { const int rcg = read_guard(h_guard_pin); if (rcg != PAV_OK) return rcg; }
-            { const int rch = collect_heads(D->state.as<int8_t>(), ev, total_rows); if (rch != PAV_OK) return rch; }
+            { const int rcq = queue_stats(); if (rcq != PAV_OK) return rcq; }      // guard counters of every job ride along
+            { const int rch = read_events(D->state.as<int8_t>(), ev); if (rch != PAV_OK) return rch; }
+            take_stats();
             if (!G.g) break;
             memcpy(&h_guard, h_guard_pin, sizeof h_guard);
             if (h_guard.overflow || h_guard.n_entries > G.cap) { overflow = true; break; }
@@ -1881,9 +1941,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
         if (force_direct) return fail(ctx, PAV_E_STATE, "pav_density_batch: guard list overflow in direct mode");
         fallback = true;
     }
-    if (G.g) {                                                         // guard counters of every job
-        const int rcs = read_stats();
-        if (rcs != PAV_OK) return rcs;
+    if (G.g) {                                                         // guard counters of every job (read with the run heads)
         for (uint32_t j = 0; j < n_jobs; ++j) {
             pav_den_result &r = D->results[j];
             r.n_near_tie = hs[j].n_near; r.n_reeval = hs[j].n_reeval; r.n_unresolved = hs[j].n_unres; r.n_spike_near = hs[j].n_spike;
