@@ -615,6 +615,7 @@ struct CompactArgs {
     const JobDev *jobs; const uint32_t *tile_job; JobStat *stat; const int8_t *st_tmp;
     const unsigned long long *tile_pre; SeqView T; int k; uint32_t min_state_count;
     uint32_t *index; int8_t *state_mer; int8_t *state; unsigned long long *kmer; uint32_t *list[3];
+    HeadEvent *events; uint32_t ev_cap; uint32_t *ev_count;   // run heads of STATE_MER (closed-form run sums); null: not wanted
 };
 
 __global__ __launch_bounds__(256) void k_compact_scatter(CompactArgs A) {
@@ -677,6 +678,12 @@ __global__ __launch_bounds__(256) void k_compact_scatter(CompactArgs A) {
         A.state_mer[o0 + r] = s_mer[r];
         A.state[o0 + r] = -1;                                          // df['STATE'] = -1 (density.py:163)
         A.kmer[o0 + r] = s_kmer[r];
+        // runs of equal STATE_MER: every change inside the tile is a head; the tile's first row is reported as well (pad = 1)
+        // and the host drops it when the run merely continues from the tile before
+        if (A.events && (r == 0 || s_mer[r] != s_mer[r - 1])) {
+            const uint32_t e = atomicAdd(A.ev_count, 1u);
+            if (e < A.ev_cap) A.events[e] = HeadEvent{j, (uint32_t)(tile0[0] + r), (int32_t)s_mer[r], 0u, 0u, r == 0 ? 1u : 0u};
+        }
     }
 #pragma unroll
     for (int s = 0; s < 3; ++s)
@@ -1576,7 +1583,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     CA.kmer = D->kmer.as<unsigned long long>();
     for (int s = 0; s < 3; ++s) CA.list[s] = D->list[s].as<uint32_t>();
     std::vector<JobStat> hs(n_jobs);
-    constexpr uint32_t EV_PREFETCH = 4096;                             // head events copied together with their count
+    constexpr uint32_t EV_PREFETCH = 16384;                            // head events copied together with their count
     // pinned readback area: [event count | first events] [per-job statistics] [guard counters]
     const size_t pin_stat_off = (sizeof(HeadEvent) * (size_t)EV_PREFETCH + 64 + 63) / 64 * 64;
     const size_t pin_guard_off = pin_stat_off + (sizeof(JobStat) * (size_t)n_jobs + 63) / 64 * 64;
@@ -1594,15 +1601,78 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
         take_stats();
         return PAV_OK;
     };
+    // Run heads of a per-row state array: events sorted by (job, row).  The kernels that produce the arrays write the events
+    // themselves (STATE_MER: k_compact_scatter, STATE: k_finalize); k_heads only repeats the work when the event buffer was too small.
+    uint32_t ev_cap = 0;
+    auto prepare_events = [&](uint64_t hint) -> int {
+        ev_cap = std::max(ev_cap, (uint32_t)std::min<uint64_t>(std::max<uint64_t>(65536, hint / 16 + 4ull * n_jobs), 0x7FFFFFFF));
+        PAV_HIP(ctx, D->events.reserve(sizeof(HeadEvent) * (size_t)ev_cap));
+        PAV_HIP(ctx, D->ev_count.reserve(16));
+        PAV_HIP(ctx, hipMemsetAsync(D->ev_count.p, 0, 4, st));
+        return PAV_OK;
+    };
+    auto launch_heads = [&](const int8_t *d_state) -> int {
+        PAV_LAUNCH(ctx, "k_heads", k_heads, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_stat, d_state,
+                   D->index.as<uint32_t>(), D->events.as<HeadEvent>(), ev_cap, D->ev_count.as<uint32_t>());
+        return PAV_OK;
+    };
+    // d_state: the array k_heads walks again should the events not fit
+    bool ev_overflow = false;                                          // read_events(nullptr, ...): too many events, nothing was read
+    auto read_events = [&](const int8_t *d_state, std::vector<HeadEvent> &ev) -> int {
+        ev_overflow = false;
+        while (true) {
+            // the count and the first EV_PREFETCH events come back together (a batch of 1 000 regions has ~2 000 heads)
+            const uint32_t pre = std::min(ev_cap, EV_PREFETCH);
+            PAV_HIP(ctx, hipMemcpyAsync(h_pin, D->ev_count.p, 4, hipMemcpyDeviceToHost, st));
+            PAV_HIP(ctx, hipMemcpyAsync(h_pin + 64, D->events.p, sizeof(HeadEvent) * pre, hipMemcpyDeviceToHost, st));
+            PAV_HIP(ctx, hipStreamSynchronize(st));
+            uint32_t n_ev = 0;
+            memcpy(&n_ev, h_pin, 4);
+            if (n_ev > ev_cap && !d_state) { ev_overflow = true; ev.clear(); return PAV_OK; }
+            if (n_ev > ev_cap) {
+                ev_cap = n_ev + 1024;
+                int rc = prepare_events(0);
+                if (rc == PAV_OK) rc = launch_heads(d_state);
+                if (rc != PAV_OK) return rc;
+                continue;
+            }
+            ev.resize(n_ev);
+            if (n_ev) memcpy(ev.data(), h_pin + 64, sizeof(HeadEvent) * std::min(n_ev, pre));
+            if (n_ev > pre)
+                PAV_HIP(ctx, hipMemcpy(ev.data() + pre, D->events.as<HeadEvent>() + pre, sizeof(HeadEvent) * (n_ev - pre), hipMemcpyDeviceToHost));
+            break;
+        }
+        std::sort(ev.begin(), ev.end(), [](const HeadEvent &a, const HeadEvent &b) { return a.job != b.job ? a.job < b.job : a.row < b.row; });
+        return PAV_OK;
+    };
+    auto collect_heads = [&](const int8_t *d_state, std::vector<HeadEvent> &ev, uint64_t hint) -> int {
+        int rc = prepare_events(hint);
+        if (rc == PAV_OK) rc = launch_heads(d_state);
+        if (rc == PAV_OK) rc = read_events(d_state, ev);
+        return rc;
+    };
     // compaction to the informative rows, then readback 1: per-job counts and moments -> status, bandwidths (host, libm:
     // same arithmetic as scipy)
+    const bool want_runs = pp->kde_mode != PAV_KDE_DIRECT;
+    std::vector<HeadEvent> mev;                                        // run heads of STATE_MER (closed-form run sums)
     auto compact_and_read = [&]() -> int {
+        CA.events = nullptr; CA.ev_cap = 0; CA.ev_count = nullptr;
+        if (want_runs) {                                               // every change of STATE_MER + one event per tile
+            const int rce = prepare_events(a_t + 16ull * n_tiles_t);
+            if (rce != PAV_OK) return rce;
+            CA.events = D->events.as<HeadEvent>(); CA.ev_cap = ev_cap; CA.ev_count = D->ev_count.as<uint32_t>();
+        }
         PAV_LAUNCH(ctx, "k_compact_reduce", k_compact_reduce, n_tiles_t, 256, 0, d_tjt, d_stat, D->st_tmp.as<int8_t>(),
                    pp->min_state_count, D->tile_sum.as<uint32_t>());
         PAV_LAUNCH(ctx, "k_scan_tiles4", k_scan_tiles4, 1, 256, 0, D->tile_sum.as<uint32_t>(), D->tile_pre.as<unsigned long long>(),
                    n_tiles_t);
         PAV_LAUNCH(ctx, "k_compact_scatter", k_compact_scatter, n_tiles_t, 256, 0, CA);
-        return read_stats();
+        if (!want_runs) return read_stats();
+        const int rcq = queue_stats();                                 // one synchronisation for the statistics and the events
+        if (rcq != PAV_OK) return rcq;
+        const int rcv = read_events(nullptr, mev);
+        take_stats();
+        return rcv;
     };
     { const int rcc = compact_and_read(); if (rcc != PAV_OK) return rcc; }
     lap("kmer+compact");
@@ -1666,61 +1736,28 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
         }
     }
 
-    // Run heads of a per-row state array: events sorted by (job, row).  STATE_MER: k_heads; STATE (rl_encoder): k_finalize
-    // writes the events itself, k_heads only repeats the work when the event buffer was too small.
-    uint32_t ev_cap = 0;
-    auto prepare_events = [&](uint64_t hint) -> int {
-        ev_cap = std::max(ev_cap, (uint32_t)std::min<uint64_t>(std::max<uint64_t>(65536, hint / 16 + 4ull * n_jobs), 0x7FFFFFFF));
-        PAV_HIP(ctx, D->events.reserve(sizeof(HeadEvent) * (size_t)ev_cap));
-        PAV_HIP(ctx, D->ev_count.reserve(16));
-        PAV_HIP(ctx, hipMemsetAsync(D->ev_count.p, 0, 4, st));
-        return PAV_OK;
-    };
-    auto launch_heads = [&](const int8_t *d_state) -> int {
-        PAV_LAUNCH(ctx, "k_heads", k_heads, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_stat, d_state,
-                   D->index.as<uint32_t>(), D->events.as<HeadEvent>(), ev_cap, D->ev_count.as<uint32_t>());
-        return PAV_OK;
-    };
-    // d_state: the array k_heads walks again should the events not fit
-    auto read_events = [&](const int8_t *d_state, std::vector<HeadEvent> &ev) -> int {
-        while (true) {
-            // the count and the first EV_PREFETCH events come back together (a batch of 1 000 regions has ~2 000 heads)
-            const uint32_t pre = std::min(ev_cap, EV_PREFETCH);
-            PAV_HIP(ctx, hipMemcpyAsync(h_pin, D->ev_count.p, 4, hipMemcpyDeviceToHost, st));
-            PAV_HIP(ctx, hipMemcpyAsync(h_pin + 64, D->events.p, sizeof(HeadEvent) * pre, hipMemcpyDeviceToHost, st));
-            PAV_HIP(ctx, hipStreamSynchronize(st));
-            uint32_t n_ev = 0;
-            memcpy(&n_ev, h_pin, 4);
-            if (n_ev > ev_cap) {
-                ev_cap = n_ev + 1024;
-                int rc = prepare_events(0);
-                if (rc == PAV_OK) rc = launch_heads(d_state);
-                if (rc != PAV_OK) return rc;
-                continue;
-            }
-            ev.resize(n_ev);
-            if (n_ev) memcpy(ev.data(), h_pin + 64, sizeof(HeadEvent) * std::min(n_ev, pre));
-            if (n_ev > pre)
-                PAV_HIP(ctx, hipMemcpy(ev.data() + pre, D->events.as<HeadEvent>() + pre, sizeof(HeadEvent) * (n_ev - pre), hipMemcpyDeviceToHost));
-            break;
-        }
-        std::sort(ev.begin(), ev.end(), [](const HeadEvent &a, const HeadEvent &b) { return a.job != b.job ? a.job < b.job : a.row < b.row; });
-        return PAV_OK;
-    };
-    auto collect_heads = [&](const int8_t *d_state, std::vector<HeadEvent> &ev, uint64_t hint) -> int {
-        int rc = prepare_events(hint);
-        if (rc == PAV_OK) rc = launch_heads(d_state);
-        if (rc == PAV_OK) rc = read_events(d_state, ev);
-        return rc;
-    };
     uint64_t total_rows = 0;
     for (uint32_t j = 0; j < n_jobs; ++j) total_rows += hs[j].n_rows;
     std::vector<std::vector<RunDev>> mer_runs;                         // [job * 3 + state]
-    const bool want_runs = pp->kde_mode != PAV_KDE_DIRECT;
     if (want_runs) {
-        std::vector<HeadEvent> mev;
-        int rc = collect_heads(D->state_mer.as<int8_t>(), mev, total_rows);
-        if (rc != PAV_OK) return rc;
+        if (ev_overflow) {                                             // more events than the buffer held: walk the column again
+            int rc = collect_heads(D->state_mer.as<int8_t>(), mev, total_rows);
+            if (rc != PAV_OK) return rc;
+        } else {
+            // k_compact_scatter's events: a tile's first row is a head only when the state really changes there; every job's
+            // events end with a marker at its row count (what k_heads writes)
+            std::vector<HeadEvent> kept;
+            kept.reserve(mev.size() + n_jobs);
+            for (size_t e = 0; e < mev.size(); ++e) {
+                const HeadEvent &h = mev[e];
+                const bool same_job = !kept.empty() && kept.back().job == h.job;
+                if (!kept.empty() && !same_job) kept.push_back(HeadEvent{kept.back().job, hs[kept.back().job].n_rows, -2, 0u, 0u, 0u});
+                if (same_job && kept.back().state == h.state) continue;
+                kept.push_back(h);
+            }
+            if (!kept.empty()) kept.push_back(HeadEvent{kept.back().job, hs[kept.back().job].n_rows, -2, 0u, 0u, 0u});
+            mev.swap(kept);
+        }
         mer_runs.assign((size_t)n_jobs * 3, {});
         for (size_t e = 0; e + 1 < mev.size(); ++e) {
             const HeadEvent &h = mev[e];
