@@ -280,8 +280,8 @@ enum { PAV_KDE_RUNS = 0, PAV_KDE_DIRECT = 1 };
  * (machine dependent in the reference itself); decisions still within 1e-13 are reported as n_unresolved. */
 
 /* Where the reference k-mer set of a region lives while STATE_MER is computed (identical results):
- *   PAV_KMER_LDS    partitioned by hash, one workgroup builds each partition in a 128 KiB LDS table and answers the
- *                   contig k-mers that hash to it (regions up to ~7 Mbp; larger ones use HBM tables).
+ *   PAV_KMER_LDS    partitioned by hash, one workgroup builds each partition in a 32 KiB LDS table and answers the
+ *                   contig k-mers that hash to it (regions up to ~1.8 Mbp; larger ones use HBM tables).
  *   PAV_KMER_HBM    one open-addressing table per region in HBM, device-scope atomics.  Also used per region when a
  *                   partition overflows (kilobases of one repeated k-mer) and for the exact count of the count-limit
  *                   failure.  The environment variable PAV_KMER_HBM (any value) forces this mode for every call. */

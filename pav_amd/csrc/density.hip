@@ -13,6 +13,11 @@
 // only difference from the reference is the device exp() (<= 1 ulp per term).  Built with -ffp-contract=off.
 #include "common.h"
 
+#ifndef PAV_LDS_SLOTS                 // slots / threads of a k_kmer_lds workgroup (tuning builds override them)
+#define PAV_LDS_SLOTS 4096
+#define PAV_LDS_THREADS 512
+#endif
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -264,9 +269,11 @@ __global__ __launch_bounds__(256) void k_tig_state(const JobDev *__restrict__ jo
 }
 
 // ---- LDS-resident k-mer sets ------------------------------------------------------------------------------------
-// The reference k-mers of a region are split by a hash into n_parts partitions of ~7 k k-mers; one workgroup owns one
-// (job, partition): it builds that partition's set in a 128 KiB LDS table (gfx950 has 160 KiB per CU) and answers the
-// membership questions of the contig k-mers that hash to it - no table atomic ever leaves the CU.
+// The reference k-mers of a region are split by a hash into n_parts partitions of ~1.8 k k-mers; one workgroup owns one
+// (job, partition): it builds that partition's set in a 32 KiB LDS table and answers the membership questions of the contig
+// k-mers that hash to it - no table atomic ever leaves the CU.  (Table size: with the GPU to itself a 128 KiB table - one
+// 1024-lane workgroup per CU - and a 32 KiB one run the same, 0.146 / 0.118 ms per launch; beside the kernels of three other
+// resident haplotypes the big workgroup waits for a whole free CU, and the step went from 3.85 to 3.55 ms with the small one.)
 //   k_bucket_ref / k_bucket_tig  one workgroup per 2048-position tile: every k-mer is hashed once and its position is
 //                                appended to the list of its partition (ranks from an LDS histogram, one global atomic
 //                                per (tile, partition) to reserve the slots); a contig k-mer goes to two lists, one for
@@ -275,11 +282,11 @@ __global__ __launch_bounds__(256) void k_tig_state(const JobDev *__restrict__ jo
 //   k_state_combine              STATE_MER from the two answers per position (+ per-state counts)
 // Counts (scripts/density.py:516-527) are bytes holding occurrences - 1; a count that passes the limit only raises a flag
 // and the exact maximum and its k-mer come from the HBM-table kernels on that failure path.
-constexpr int LDS_SLOTS = 16384;
-constexpr int LDS_THREADS = 1024;
+constexpr int LDS_SLOTS = PAV_LDS_SLOTS;
+constexpr int LDS_THREADS = PAV_LDS_THREADS;
 constexpr int KU = 4;                                 // list entries a lane of k_kmer_lds has in flight
-constexpr uint32_t LDS_FILL = 7168;                  // k-mers per partition aimed at (load factor 0.44)
-constexpr uint32_t LDS_MAX_PARTS = 1024;             // histogram size of the bucket kernels (regions up to 7.3 Mbp)
+constexpr uint32_t LDS_FILL = LDS_SLOTS * 7 / 16;   // k-mers per partition aimed at (load factor 0.44)
+constexpr uint32_t LDS_MAX_PARTS = 1024;             // histogram size of the bucket kernels (regions up to 1.8 Mbp; MAX_REGION_SIZE is 1.2 Mbp)
 constexpr uint32_t LDS_MAX_LIMIT = 250;              // byte counts: the limit must stay below the wrap
 constexpr uint32_t ANS_ABSENT = 0, ANS_PRESENT = 1, ANS_INVALID = 0xFF;
 constexpr uint32_t LDS_EXCEED = 1, LDS_OVERFLOW = 2;
@@ -778,12 +785,28 @@ __device__ __forceinline__ void guard_flag_row(const GuardArgs &G, uint32_t job,
     guard_append(G, (unsigned long long)job << 32 | GE_ROW | row);
 }
 
+// exp(-r^2 / 2) is exactly 0.0 in float64 from |r| = 38.61 on (r^2 / 2 > 745.2 = -log of half the smallest subnormal), so a data
+// point further than this from an evaluation point adds +0.0 to scipy's sum: leaving it out changes no bit of the result.
+constexpr double KDE_ZERO_R = 38.7;
+
+__device__ __forceinline__ double uniform_f64(double v) {          // the first lane's value, in scalar registers
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+// First index i in [0, m) with ps[i] >= v (ps ascending; wave-uniform arguments: scalar loads).
+__device__ __forceinline__ uint32_t ps_lower_bound(const double *__restrict__ ps, uint32_t m, double v) {
+    uint32_t lo = 0, hi = m;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (ps[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
 // gaussian_kernel_estimate (scipy/stats/_stats.pyx) for one state at one evaluation point; `ps` is wave-uniform so
-// the data stream goes through the scalar cache.  Accumulation order = data ascending, as in scipy.
-__device__ __forceinline__ double kde_state(const double *__restrict__ ps, uint32_t m, double xs, double norm, double w) {
+// the data stream goes through the scalar cache.  Accumulation order = data ascending, as in scipy.  [lo, hi): the data
+// points that can contribute to any point of the wave (everything outside adds exact zeros).
+__device__ __forceinline__ double kde_state(const double *__restrict__ ps, uint32_t lo, uint32_t hi, double xs, double norm, double w) {
     double est = 0.0;
-    uint32_t i = 0;
-    for (; i + 4 <= m; i += 4) {
+    uint32_t i = lo;
+    for (; i + 4 <= hi; i += 4) {
         const double a0 = ps[i], a1 = ps[i + 1], a2 = ps[i + 2], a3 = ps[i + 3];
         const double r0 = a0 - xs, r1 = a1 - xs, r2 = a2 - xs, r3 = a3 - xs;
         est += w * (exp(-(r0 * r0) / 2) * norm);
@@ -791,7 +814,7 @@ __device__ __forceinline__ double kde_state(const double *__restrict__ ps, uint3
         est += w * (exp(-(r2 * r2) / 2) * norm);
         est += w * (exp(-(r3 * r3) / 2) * norm);
     }
-    for (; i < m; ++i) {
+    for (; i < hi; ++i) {
         const double r = ps[i] - xs;
         est += w * (exp(-(r * r) / 2) * norm);
     }
@@ -893,11 +916,20 @@ __global__ __launch_bounds__(64 * KDE_WAVES) void k_kde_eval(KdeArgs A) {
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         double v = 0.0;
-        if (active && kd.m[s]) {
-            if (kd.use_runs && kd.h[s] >= KDE_RUNS_MIN_H)
-                v = kde_state_runs(A.runs + kd.run_off[s], kd.n_run[s], wave, KDE_WAVES, x, kd.h[s], kd.inv_h[s]);
-            else if (wave == 0)
-                v = kde_state(A.ps[s] + off, kd.m[s], (double)x * kd.inv_h[s], kd.norm[s], kd.w[s]);
+        const bool by_runs = kd.use_runs && kd.h[s] >= KDE_RUNS_MIN_H;                     // (uniform over the workgroup)
+        if (kd.m[s] && by_runs) {
+            if (active) v = kde_state_runs(A.runs + kd.run_off[s], kd.n_run[s], wave, KDE_WAVES, x, kd.h[s], kd.inv_h[s]);
+        } else if (kd.m[s] && wave == 0) {
+            // term by term (scipy's order), over the data points within KDE_ZERO_R of any point of the wave: bounds from the
+            // smallest / largest scaled position among the wave's points
+            const double xs = (double)x * kd.inv_h[s];
+            double xlo = active ? xs : INFINITY, xhi = active ? xs : -INFINITY;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { xlo = fmin(xlo, __shfl_xor(xlo, d)); xhi = fmax(xhi, __shfl_xor(xhi, d)); }
+            const double *ps = A.ps[s] + off;
+            const uint32_t lo = __builtin_amdgcn_readfirstlane(ps_lower_bound(ps, kd.m[s], uniform_f64(xlo) - KDE_ZERO_R));
+            const uint32_t hi = __builtin_amdgcn_readfirstlane(ps_lower_bound(ps, kd.m[s], uniform_f64(xhi) + KDE_ZERO_R));
+            if (active) v = kde_state(ps, lo, hi, xs, kd.norm[s], kd.w[s]);
         }
         part[wave][s][lane] = v;
     }
@@ -1164,14 +1196,23 @@ __global__ __launch_bounds__(64) void k_redo(RedoArgs A) {
         const double xs = (double)x * inv_h;
         const uint32_t *ls = A.list[s] + off;
         double est = 0.0;
-        for (uint32_t i0 = 0; i0 < m; i0 += 64) {
+        // data points further than KDE_ZERO_R add exact zeros: start at the first one that can contribute, stop behind the last
+        uint32_t lo = 0, hi = m;
+        {
+            uint32_t a = 0, b = m;
+            while (a < b) { const uint32_t mid = (a + b) >> 1; if ((double)ls[mid] * inv_h < xs - KDE_ZERO_R) a = mid + 1; else b = mid; }
+            lo = a; b = m;
+            while (a < b) { const uint32_t mid = (a + b) >> 1; if ((double)ls[mid] * inv_h <= xs + KDE_ZERO_R) a = mid + 1; else b = mid; }
+            hi = a;
+        }
+        for (uint32_t i0 = lo; i0 < hi; i0 += 64) {
             const uint32_t i = i0 + lane;
             double t = 0.0;
-            if (i < m) {
+            if (i < hi) {
                 const double r = (double)ls[i] * inv_h - xs;          // points_[i] - xi_[j], points_ = data * (1 / h)
                 t = w * (exp(-(r * r) / 2) * norm);
             }
-            const int cnt = (int)min(64u, m - i0);
+            const int cnt = (int)min(64u, hi - i0);
             for (int l = 0; l < cnt; ++l) est += readlane_f64(t, l);
         }
         val[s] = est * kd.cnt[s];
@@ -1456,7 +1497,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     uint64_t a_r = 0, a_t = 0, a_h = 0;
     std::vector<uint32_t> tile_job_r, tile_job_t;
     // k-mer sets in LDS unless asked otherwise (params, env), the count limit does not fit a byte, or a region needs
-    // more partitions than the bucket kernels' histograms hold (> 7 Mbp; the reference's MAX_REGION_SIZE is 1.2 Mbp)
+    // more partitions than the bucket kernels' histograms hold (> 1.8 Mbp; the reference's MAX_REGION_SIZE is 1.2 Mbp)
     const bool lds_sets = pp->kmer_mode != PAV_KMER_HBM && pp->max_ref_kmer_count <= LDS_MAX_LIMIT &&
                           getenv("PAV_KMER_HBM") == nullptr;
     std::vector<PartItem> items;
@@ -1942,6 +1983,18 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
                 if (!D->h_kde[j].finalised) continue;
                 D->results[j].n_eval = (uint64_t)D->h_kde[j].n_samp + hs[j].fill_n;
                 for (uint32_t f = 0; f < hs[j].fill_n; f += 64) ftiles.push_back(EvalTile{j, f, std::min<uint32_t>(64, hs[j].fill_n - f), 1});
+            }
+            if (timing && pass == 0) {
+                double pairs = 0, points = 0, big = 0;
+                for (uint32_t j = 0; j < n_jobs; ++j) {
+                    const JobKde &kd = D->h_kde[j];
+                    if (!kd.finalised) continue;
+                    const double pts = (double)kd.n_samp + hs[j].fill_n, runs = (double)kd.n_run[0] + kd.n_run[1] + kd.n_run[2];
+                    points += pts; pairs += pts * runs;
+                    if (runs > 256) big += pts * runs;
+                }
+                fprintf(stderr, "[pav timing]   kde work: %.3g evaluation points, %.3g (point, run) pairs (%.1f runs per point; %.0f %% of the pairs in jobs with > 256 runs)\n",
+                        points, pairs, points ? pairs / points : 0.0, pairs ? 100.0 * big / pairs : 0.0);
             }
             if (!ftiles.empty()) {
                 PAV_HIP(ctx, D->ftiles.reserve(sizeof(EvalTile) * ftiles.size()));
