@@ -571,6 +571,71 @@ def test_guard_on_everything_equals_direct_mode(built, gpu_ctx, cap):
     assert n_ok >= 4
 
 
+def test_concurrent_haplotype_lanes_equal_sequential_runs(built, gpu_ctx):
+    """bench.py's lanes in small: four haplotypes resident at once - one context each, sharing the reference planes - run
+    the whole chain (CIGAR-call -> flagging -> scan of the flagged loci with lazy tables) from four host threads at the same
+    time, twice.  Every lane's loci, calls and density tables equal what the same haplotype gives alone on one context."""
+    import threading
+    haps = [synth.config2(seed=717, scale=0.01, hap_index=0, threads=4, pair_frac=0.01)]
+    ref = haps[0].ref
+    names = ref.names
+    haps += [synth.config2(seed=717, scale=0.01, hap_index=h, ref=ref, threads=4, pair_frac=0.01) for h in range(1, 4)]
+    k_util = KmerUtil(31)
+
+    def chain(ctx, hap, lift):
+        from pav_amd import cigarcall
+        index = hap.df_align['INDEX'].to_numpy(dtype='int64')
+        trim = hap.df_trim[['POS', 'END', 'INDEX']].set_index('INDEX').astype(int).reindex(list(index), fill_value=-1)
+        ctx.seq_pack(_lib.PAV_ROLE_TIG)
+        counts = ctx.cigar_call()
+        _, loci, _ = ctx.cigar_flag(trim['POS'].to_numpy(dtype='int64'), trim['END'].to_numpy(dtype='int64'),
+                                    ctx.flag_params(sig_filter=_lib.SIG_SINGLE_CLUSTER))
+        regions = pavinv.loci_regions(ctx, loci)
+        log, found = io.StringIO(), io.StringIO()
+        out = pavinv.scan_for_inv_batch(regions, 'ref.fa', 'tig.fa', lift, k_util, log=log, ctx=ctx, eager_tables=False, found_out=found)
+        tables = {c.id: sha(np.concatenate([c.df[k].to_numpy().astype(np.float64) for k in ('INDEX', 'STATE', 'KERN_FWD', 'KERN_REV')]))
+                  for c in out if c is not None and not isinstance(c, RuntimeError)}
+        return counts.n_snv, loci.tobytes(), log.getvalue(), found.getvalue(), tables
+
+    def setup(ctx, hap):
+        from pav_amd import cigarcall
+        ctx.seq_load(_lib.PAV_ROLE_TIG, hap.tig_names, [hap.tig_seqs[n] for n in hap.tig_names])
+        ctx.cigar_load(*cigarcall.pack_alignments(hap.df_align, names, hap.tig_names))
+        ctx._inv_loaded = ('ref.fa', 'tig.fa')
+        return AlignLift(hap.df_trim, hap.tig_lengths)
+
+    gpu_ctx._inv_loaded = None
+    gpu_ctx.seq_load(_lib.PAV_ROLE_REF, names, [ref.seqs[n] for n in names])
+    alone = []
+    for hap in haps:
+        alone.append(chain(gpu_ctx, hap, setup(gpu_ctx, hap)))
+    assert sum(len(a[4]) for a in alone) >= 4 and len({a[0] for a in alone}) == 4
+    lanes = [_lib.Context(0) for _ in haps]
+    try:
+        lifts = []
+        for c, hap in zip(lanes, haps):
+            c.seq_share(gpu_ctx, _lib.PAV_ROLE_REF)
+            lifts.append(setup(c, hap))
+        for _ in range(2):
+            got, errs = [None] * len(haps), []
+
+            def work(i):
+                try:
+                    got[i] = chain(lanes[i], haps[i], lifts[i])
+                except BaseException as ex:      # noqa: BLE001
+                    errs.append(ex)
+            ths = [threading.Thread(target=work, args=(i,)) for i in range(len(haps))]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            assert not errs, errs
+            assert got == alone
+    finally:
+        for c in lanes:
+            c.close()
+
+
 def test_files_to_files_tool(built, tmp_path):
     """tools/bench_e2e.py at a small scale: FASTA + alignment tables in, every output file of the rule chain out (merged
     SNV / INS-DEL tables, five flag tables, INV BED, density tables, log), through the native readers and writers."""
