@@ -62,10 +62,11 @@ def main():
     ap.add_argument('--workload', choices=['cigar+inv', 'cigar'], default='cigar+inv',
                     help="'cigar+inv' = the whole path of the metric: CIGAR-call + flagging + k-mer inversion scan of every flagged "
                          "locus (configs[2]: both haplotypes of a diploid sample per GPU); 'cigar' = BASELINE configs[1], CIGAR-call only")
-    ap.add_argument('--lanes', type=int, default=4,
+    ap.add_argument('--lanes', type=int, default=0,
                     help='haplotypes resident per GPU, one context + host thread each, sharing one resident reference; the K steps '
-                         'go round them (default 4 = h1 + h2 of two phased diploid samples, the per-GPU share of configs[2] / [3]; '
-                         '1 = one haplotype, no overlap)')
+                         'go round them (default 0 = auto: 4 = h1 + h2 of two phased diploid samples, the per-GPU share of '
+                         'configs[2] / [3], when the process may use >= 6 CPUs per rank - every lane is a host thread that polls its '
+                         'stream - else 2, else 1; 1 = one haplotype, no overlap)')
     ap.add_argument('--pair-frac', type=float, default=PAIR_FRAC, help='generator: fraction of indel events emitted as a matched DEL + INS')
     ap.add_argument('--eager-tables', action='store_true',
                     help='copy the density tables of every inversion call to pinned host memory inside the timed region (round-1 '
@@ -121,7 +122,8 @@ def main():
     from pav_amd.shard import effective_cpus
     threads = args.threads or max(1, effective_cpus() // max(1, world))
     threads = min(threads, 16)
-    n_lanes = max(1, args.lanes)
+    cpus_per_rank = effective_cpus() / max(1, world)
+    n_lanes = args.lanes if args.lanes > 0 else (4 if cpus_per_rank >= 6 else (2 if cpus_per_rank >= 3 else 1))
     gen_kw = {'pair_frac': args.pair_frac} if args.workload == 'cigar+inv' and args.pair_frac > 0 else {}
 
     # ---- synthetic inputs (host) -> HBM -----------------------------------------------------------------------

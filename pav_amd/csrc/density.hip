@@ -893,10 +893,12 @@ struct KdeArgs {
 
 // One workgroup per tile of 64 evaluation points of one job.  Lane l of every wave stands for point l; the waves share the
 // runs of a state (wave w takes runs w, w + KDE_WAVES, ...) and wave 0 adds their partial sums in wave order - a fixed order,
-// so the result does not depend on scheduling.  With one wave per tile the expansion rounds of the scan - a handful of
-// regions of 10^5 rows whose states alternate thousands of times - took 0.7 - 1.1 ms per launch, all of it the latency of one
-// lane walking 10^4 runs; the chip was idle.  States summed term by term (scipy's order) stay on wave 0.
-constexpr int KDE_WAVES = 8;
+// so the result does not depend on scheduling; a region whose states alternate thousands of times does not hang on one lane.
+// States summed term by term in scipy's order (PAV_KDE_DIRECT) stay on wave 0.
+#ifndef PAV_KDE_WAVES                 // waves per evaluation tile (tuning builds override it): 1 / 2 / 4 / 8 waves gave
+#define PAV_KDE_WAVES 2               // 0.104 / 0.097 / 0.111 / 0.148 ms per launch - a tile's lifetime is a chain of dependent loads,
+#endif                                // and small workgroups let more tiles hide each other's latency
+constexpr int KDE_WAVES = PAV_KDE_WAVES;
 __global__ __launch_bounds__(64 * KDE_WAVES) void k_kde_eval(KdeArgs A) {
     __shared__ double part[KDE_WAVES][3][64];
     const EvalTile t = A.tiles[blockIdx.x];
@@ -919,16 +921,24 @@ __global__ __launch_bounds__(64 * KDE_WAVES) void k_kde_eval(KdeArgs A) {
         const bool by_runs = kd.use_runs && kd.h[s] >= KDE_RUNS_MIN_H;                     // (uniform over the workgroup)
         if (kd.m[s] && by_runs) {
             if (active) v = kde_state_runs(A.runs + kd.run_off[s], kd.n_run[s], wave, KDE_WAVES, x, kd.h[s], kd.inv_h[s]);
-        } else if (kd.m[s] && wave == 0) {
-            // term by term (scipy's order), over the data points within KDE_ZERO_R of any point of the wave: bounds from the
-            // smallest / largest scaled position among the wave's points
+        } else if (kd.m[s] && (wave == 0 || kd.use_runs)) {
+            // term by term over the data points within KDE_ZERO_R of any point of the wave (bounds from the smallest / largest
+            // scaled position among the wave's points).  PAV_KDE_DIRECT (use_runs == 0): wave 0 alone, strictly ascending -
+            // scipy's order.  A narrow-bandwidth state of a run-sum job: the eight waves take consecutive slices of the window
+            // (the sum is then not in scipy's order; the near-tie guard treats it like a run sum).  One wave walking up to
+            // 77 bandwidths + the tile's span of data points (~4 k exp) was the longest workgroup of every launch.
             const double xs = (double)x * kd.inv_h[s];
             double xlo = active ? xs : INFINITY, xhi = active ? xs : -INFINITY;
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) { xlo = fmin(xlo, __shfl_xor(xlo, d)); xhi = fmax(xhi, __shfl_xor(xhi, d)); }
             const double *ps = A.ps[s] + off;
-            const uint32_t lo = __builtin_amdgcn_readfirstlane(ps_lower_bound(ps, kd.m[s], uniform_f64(xlo) - KDE_ZERO_R));
-            const uint32_t hi = __builtin_amdgcn_readfirstlane(ps_lower_bound(ps, kd.m[s], uniform_f64(xhi) + KDE_ZERO_R));
+            uint32_t lo = __builtin_amdgcn_readfirstlane(ps_lower_bound(ps, kd.m[s], uniform_f64(xlo) - KDE_ZERO_R));
+            uint32_t hi = __builtin_amdgcn_readfirstlane(ps_lower_bound(ps, kd.m[s], uniform_f64(xhi) + KDE_ZERO_R));
+            if (kd.use_runs) {
+                const uint32_t len = hi - lo, w0 = __builtin_amdgcn_readfirstlane(wave);
+                hi = lo + (uint32_t)((uint64_t)len * (w0 + 1) / KDE_WAVES);
+                lo = lo + (uint32_t)((uint64_t)len * w0 / KDE_WAVES);
+            }
             if (active) v = kde_state(ps, lo, hi, xs, kd.norm[s], kd.w[s]);
         }
         part[wave][s][lane] = v;
@@ -940,10 +950,10 @@ __global__ __launch_bounds__(64 * KDE_WAVES) void k_kde_eval(KdeArgs A) {
     for (int s = 0; s < 3; ++s) {
         if (kd.m[s] == 0) { val[s] = 0.0; continue; }                  // density.py:84,92,100
         double est = part[0][s][lane];
-        if (kd.use_runs && kd.h[s] >= KDE_RUNS_MIN_H) {
+        if (kd.use_runs) {                                             // partial sums of the eight waves, in wave order
 #pragma unroll
             for (int w = 1; w < KDE_WAVES; ++w) est += part[w][s][lane];
-            est = kd.w[s] * (est * kd.norm[s]);
+            if (kd.h[s] >= KDE_RUNS_MIN_H) est = kd.w[s] * (est * kd.norm[s]);
         }
         val[s] = est * kd.cnt[s];                                      // density.py:110-115
     }
@@ -1937,10 +1947,10 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             JobKde &kd = D->h_kde[j];
             if (!kd.finalised) continue;
             if (force_direct) kd.use_runs = 0;
-            kd.ps_mask = 0; kd.all_direct = 1;
+            kd.ps_mask = 0; kd.all_direct = kd.use_runs ? 0 : 1;       // scipy's order throughout: only without run sums
             for (int q = 0; q < 3; ++q) {
                 if (!kd.m[q]) continue;
-                if (kd.use_runs && kd.h[q] >= KDE_RUNS_MIN_H) kd.all_direct = 0; else kd.ps_mask |= 1u << q;
+                if (!(kd.use_runs && kd.h[q] >= KDE_RUNS_MIN_H)) kd.ps_mask |= 1u << q;
             }
             any_ps = any_ps || kd.ps_mask;
         }
