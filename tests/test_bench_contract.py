@@ -14,7 +14,8 @@ def load(name):
         return json.loads(fh.read().strip().splitlines()[-1])
 
 
-@pytest.mark.parametrize('name', ['r01_full_path_bench.json', 'r01_cigar_only_bench.json'])
+@pytest.mark.parametrize('name', ['r01_full_path_bench.json', 'r01_cigar_only_bench.json', 'r02_full_path_bench.json',
+                                  'r02_cigar_only_bench.json'])
 def test_bench_line_has_the_contract_fields(name):
     line = load(name)
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
@@ -22,7 +23,9 @@ def test_bench_line_has_the_contract_fields(name):
         assert key in line, key
     assert line['unit'] == 'Gbp/s' and line['higher_is_better'] is True and line['scaling'] == 'weak' and line['vs_baseline'] is None
     assert line['data'] == 'synthetic' and 'workload' in line['config'] and 'model' not in line['config']
-    assert abs(line['value'] - line['config']['aligned_bp_per_gpu'] * line['n_gpus'] / (line['ms_per_step'] * 1e-3) / 1e9) < 0.01 * line['value']
+    # value = aligned bp of the timed passes (all ranks) / slowest rank's time; round 2 lists every rank's bp per pass
+    per_pass = sum(r['aligned_bp'] for r in line['per_rank']) if 'per_rank' in line else line['config']['aligned_bp_per_gpu'] * line['n_gpus']
+    assert abs(line['value'] - per_pass / (line['ms_per_step'] * 1e-3) / 1e9) < 0.01 * line['value']
     r = line['roofline']
     assert r['bound'] in ('hbm', 'mfma') and r['unit'] == 'GB/s' and r['peak'] == 8000.0
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
@@ -33,10 +36,28 @@ def test_bench_line_has_the_contract_fields(name):
     assert c['records_match_gpu'] is True
 
 
-def test_headline_is_the_whole_metric_path():
+def test_round2_line_carries_the_path_roofline_and_the_reference_figures():
+    line = load('r02_full_path_bench.json')
+    p = line['roofline']['path']
+    total = p['algorithmic_bytes_per_step']['cigar_call'] + p['algorithmic_bytes_per_step']['kmer_scan']
+    assert abs(p['achieved'] - total / (line['ms_per_step'] * 1e-3) / 1e9) < 0.01 * p['achieved']
+    assert abs(p['frac'] - p['achieved'] / 8000.0) < 1e-3 and p['frac'] < 0.2           # the path is not byte-bound, and says so
+    assert p['ms_per_step_over_sum_kernel_ms'] <= 1.15                                  # the step is device-bound
+    ratios = line['roofline']['traffic_over_algorithmic']
+    assert ratios['source'] == 'profiles/r02_pmc.json' and abs(ratios['ratio']['pack_kernel'] - 1.0) < 0.05
+    assert 0.8 < ratios['walk_snv_over_sector_granular_model'] < 1.2                     # walk_snv: one sector per isolated byte
+    ref = line['cpu_baseline']['reference_python']
+    assert ref['cigar_call_Mbp_per_s'] == 2.1 and ref['density_scan_kbp_per_s'] == 2.5 and 'hardware' in ref
+    assert line['host']['cpu_baseline_cores_all'] == line['cpu_baseline']['all_cores']['cores']
+    assert line['config']['lanes_per_gpu'] >= 1 and line['config']['call_tables'].startswith('resident in HBM')
+    assert line['value'] > 1.5 * load('r01_full_path_bench.json')['value']
+
+
+@pytest.mark.parametrize('name', ['r01_full_path_bench.json', 'r02_full_path_bench.json'])
+def test_headline_is_the_whole_metric_path(name):
     with open(BASELINE) as fh:
         base = json.load(fh)
-    line = load('r01_full_path_bench.json')
+    line = load(name)
     assert line['metric'] == base['metric']
     assert line['inv_scan']['calls'] > 0 and line['inv_scan']['flagging']['planted_inversions_flagged'] > 0
     assert line['cpu_baseline']['density_tables_match_gpu'] is True

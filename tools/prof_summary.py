@@ -170,7 +170,7 @@ def busy(db, out, a, b, mark='k_kmer_lds'):
         fh.write(f'# device occupancy, window of {(w1 - w0) / 1e6:.2f} ms starting {(w0 - t_first) / 1e6:.2f} ms after the first kernel ({db})\n')
         fh.write(f'# passes in the window (pack_kernel launches): {packs}  ->  {(w1 - w0) / 1e6 / max(1, packs):.3f} ms of wall time per pass\n')
         fh.write(f'wall_ms {(w1 - w0) / 1e6:.3f}   busy_ms (>= 1 kernel running) {union / 1e6:.3f} = {union / (w1 - w0):.3f} of wall   '
-                 f'sum_of_kernel_ms {total / 1e6:.3f} = {total / (w1 - w0):.3f} of wall (kernels of the two lanes overlap)\n')
+                 f'sum_of_kernel_ms {total / 1e6:.3f} = {total / (w1 - w0):.3f} of wall (kernels of the lanes overlap)\n')
         fh.write(f'{"kernel":34s} {"launches":>8s} {"total_ms":>10s} {"per_pass_ms":>12s}\n')
         for n, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1]):
             fh.write(f'{n:34s} {c:8d} {t / 1e6:10.3f} {t / 1e6 / max(1, packs):12.4f}\n')
