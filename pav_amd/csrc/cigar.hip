@@ -571,57 +571,118 @@ __device__ __forceinline__ uint64_t spread32(uint32_t x32) {                    
 __device__ __forceinline__ u128 spread64(uint64_t m) { return (u128)spread32((uint32_t)(m >> 32)) << 64 | spread32((uint32_t)m); }
 __device__ __forceinline__ int popc128(u128 x) { return __popcll((uint64_t)x) + __popcll((uint64_t)(x >> 64)); }
 
+// Positions are arena offsets in bases.  Arenas below 2^32 bases (a human genome is 3.1 G) run the kernel on 32-bit
+// positions: half the descriptor bytes in LDS, and every address is a scalar base + a 32-bit lane offset (one VALU op
+// instead of 64-bit shifts and adds).  WIDE keeps the high words beside them.
+// Where the time goes (bench haplotype, 0.30 ms, SQ counters in DESIGN.md section 5): 111 M vector instructions = 0.18 ms of
+// issue on 1024 SIMDs, 1.63 GB of HBM = 0.25 ms at the streaming rate of pack_kernel; the two overlap to 0.30 ms.  With the
+// loads of the loop compiled out the kernel still takes 0.255 ms, with the loop compiled out 0.07 ms (the scan + descriptors).
+// Tried and dropped: 5 waves / SIMD via amdgpu_waves_per_eu (96 VGPRs: +5 %), one unaligned 2-byte load of the dirty pair
+// (+5 %), non-temporal window loads (no change), one or four pieces per lane and step, one workgroup per chunk (no change).
+template <bool WIDE> struct VPos { typedef uint32_t type; };
+template <> struct VPos<true> { typedef uint64_t type; };
+
+template <typename P>
+__device__ __forceinline__ W5 window_at(const uint32_t *__restrict__ two, P a) {
+    // byte offset of the dword that holds base a; for 32-bit positions it stays a 32-bit lane offset on a scalar base
+    const P byte = (a >> 4) << 2;
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(two) + byte);
+    const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(p);
+    return W5{{v.x, v.y, v.z, v.w, p[4]}};
+}
+
+template <bool WIDE>
 __global__ __launch_bounds__(256) void verify_kernel(VerifyArgs A) {
-    __shared__ uint64_t lds[4 * NQ];
+    typedef typename VPos<WIDE>::type pos_t;
+    __shared__ uint64_t lds[4 * 3];
     // VSPLIT workgroups share a 2048-operation chunk: all repeat its (cheap) scan, each keeps the descriptors of one part - a
-    // fraction of the LDS per workgroup, more waves per CU for the latency-bound gather below (1: 0.46 ms, 2: 0.38 ms, 4: 0.41 ms per haplotype).
+    // fraction of the LDS per workgroup, more waves per CU for the gather below.
     constexpr int VSLOTS = WALK_CHUNK / VSPLIT;
-    __shared__ uint64_t d_ref[VSLOTS], d_tig[VSLOTS];
-    __shared__ uint32_t d_len[VSLOTS];                                   // len << 2 | rev << 1 | is 'X'; 0 = nothing to check
+    // One descriptor per '=' / 'X' run of this part, in operation order, runs without bases left out ("compact slots"):
+    // ref position, contig position, len << 2 | rev << 1 | is 'X', first piece; slot n_slots is a sentinel of length 0.
+    __shared__ uint32_t d_ref[VSLOTS + 1], d_tig[VSLOTS + 1], d_len[VSLOTS + 1], s_pre[VSLOTS + 1];
+    __shared__ uint2 d_hi[WIDE ? VSLOTS + 1 : 1];                        // high words of the two positions
+    __shared__ uint16_t d_op[VSLOTS + 1];                                // slot -> operation of the part (first_bad_op)
+    constexpr int VU = 2;                                                // pieces per lane and step
+    __shared__ uint8_t mark[4][VU * VPIECE];                              // per wave: which of the 128 pieces of a step start a run
+    __shared__ uint4 km_tbl[VPIECE + 1];                                 // n bases -> compare mask of the four dwords
+    constexpr uint32_t EVEN = 0x55555555u;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t chunk = blockIdx.x / VSPLIT, slot0 = (blockIdx.x % VSPLIT) * VSLOTS;
     const uint64_t first = (uint64_t)chunk * WALK_CHUNK + (uint64_t)threadIdx.x * OPS_PER_LANE;
     uint32_t o[OPS_PER_LANE];
     load_ops(A.ops, A.n_ops, first, o);
-    uint64_t run[2] = {0, 0}, tot[2];                                    // only the two positions are scanned here
+    const bool mine_half = threadIdx.x * OPS_PER_LANE >= slot0 && threadIdx.x * OPS_PER_LANE < slot0 + VSLOTS;
+    const uint32_t my0 = threadIdx.x * OPS_PER_LANE - slot0;             // this lane's first operation within the part (its 8 ops lie in one part)
+    // one block scan: the two positions, and (runs | pieces) of this part packed in one word.  The runs are cut into 64-base
+    // pieces (one lane, one window of each plane) - an 'X' of one base costs one lane, not one wave.
+    constexpr int PK_SHIFT = 44;                                         // pieces below, runs above (<= 1024 runs, < 2^38 / 64 pieces)
+    uint64_t run[3] = {0, 0, 0}, tot[3];
+    uint32_t np[OPS_PER_LANE], len_eq = 0, len_x = 0;
 #pragma unroll
     for (int j = 0; j < OPS_PER_LANE; ++j) {
         uint64_t c[NQ];
         op_contrib(o[j], c);
         run[0] += c[0]; run[1] += c[1];
+        const uint32_t code = o[j] & 15u, len = o[j] >> 4;
+        np[j] = (mine_half && (code == 7 || code == 8)) ? (len + VPIECE - 1) / VPIECE : 0u;
+        if (np[j]) run[2] += (1ull << PK_SHIFT) + np[j];
+        if (np[j]) { if (code == 8) len_x += len; else len_eq += len; }    // the bases checked are counted here, not per piece
     }
-    block_excl_scan<2>(run, tot, lds);
+    block_excl_scan<3>(run, tot, lds);
     run[0] += A.chunk_pre[(uint64_t)chunk * NQ + 0];
     run[1] += A.chunk_pre[(uint64_t)chunk * NQ + 1];
-    const bool mine_half = threadIdx.x * OPS_PER_LANE >= slot0 && threadIdx.x * OPS_PER_LANE < slot0 + VSLOTS;
-    const uint32_t my0 = threadIdx.x * OPS_PER_LANE - slot0;             // this lane's first descriptor slot (its 8 ops lie in one half)
-    if (mine_half)
+    const uint32_t n_slots = (uint32_t)(tot[2] >> PK_SHIFT), n_pieces = (uint32_t)(tot[2] & ((1ull << PK_SHIFT) - 1));
+    if (threadIdx.x <= VPIECE) {
+        uint32_t m[4];
 #pragma unroll
-        for (int j = 0; j < OPS_PER_LANE; ++j) d_len[my0 + j] = 0;
-    __syncthreads();
-    if (first < A.n_ops) {
+        for (int i = 0; i < 4; ++i) {
+            const int have = (int)threadIdx.x - 16 * i;                  // bases of the piece in dword i
+            m[i] = have >= 16 ? EVEN : (have <= 0 ? 0u : EVEN & ((1u << (2 * have)) - 1u));
+        }
+        km_tbl[threadIdx.x] = make_uint4(m[0], m[1], m[2], m[3]);
+    }
+#pragma unroll
+    for (int u = 0; u < VU; ++u) mark[wave][u * VPIECE + lane] = 0;
+    if (threadIdx.x == 0) {
+        d_ref[n_slots] = 0; d_tig[n_slots] = 0; d_len[n_slots] = 0; s_pre[n_slots] = n_pieces;
+        if (WIDE) d_hi[n_slots] = make_uint2(0u, 0u);
+        d_op[n_slots] = 0;
+    }
+    if (first < A.n_ops && mine_half) {
         uint32_t row = A.chunk_row[chunk];
         uint64_t row_end = A.op_off[row + 1];
         while (row_end <= first) { ++row; row_end = A.op_off[row + 1]; }
-        pav_aln al = A.aln[row];
-        uint64_t rb_ref = A.rowbase[2ull * row], rb_tig = A.rowbase[2ull * row + 1];
+        // per row: ra = r0 + (reference bases before the op), ta = t0 +/- (contig bases before the op).  Forward rows: first
+        // base of the run; reverse rows: the stored base that is oriented base 0 of the run (the run goes downwards)
+        uint64_t r0, t0;
+        bool rev;
+        auto enter_row = [&](uint32_t rw) {
+            const pav_aln al = A.aln[rw];
+            const uint64_t rb_ref = A.rowbase[2ull * rw], rb_tig = A.rowbase[2ull * rw + 1];
+            rev = al.rev != 0;
+            r0 = A.ref.off[al.ref_id] + (uint64_t)al.pos - rb_ref;
+            t0 = rev ? A.tig.off[al.tig_id] + A.tig.len[al.tig_id] - 1 + rb_tig : A.tig.off[al.tig_id] - rb_tig;
+        };
+        enter_row(row);
+        uint32_t slot = (uint32_t)(run[2] >> PK_SHIFT), at = (uint32_t)(run[2] & ((1ull << PK_SHIFT) - 1));
 #pragma unroll
         for (int j = 0; j < OPS_PER_LANE; ++j) {
             const uint64_t k = first + j;
             if (k >= A.n_ops) break;
-            while (k >= row_end) {
-                ++row; row_end = A.op_off[row + 1];
-                al = A.aln[row];
-                rb_ref = A.rowbase[2ull * row]; rb_tig = A.rowbase[2ull * row + 1];
+            if (k >= row_end) {
+                do { ++row; row_end = A.op_off[row + 1]; } while (k >= row_end);
+                enter_row(row);
             }
             const uint32_t code = o[j] & 15u, len = o[j] >> 4;
-            if (mine_half && (code == 7 || code == 8) && len) {
-                const uint64_t pos_ref = (uint64_t)al.pos + (run[0] - rb_ref), pos_tig = run[1] - rb_tig;
-                const uint64_t tlen = A.tig.len[al.tig_id];
-                const int slot = (int)my0 + j;
-                d_ref[slot] = A.ref.off[al.ref_id] + pos_ref;
-                // forward rows: first base of the run; reverse rows: the stored base that is oriented base 0 (runs downwards)
-                d_tig[slot] = A.tig.off[al.tig_id] + (al.rev ? tlen - 1 - pos_tig : pos_tig);
-                d_len[slot] = len << 2 | (al.rev ? 2u : 0u) | (code == 8 ? 1u : 0u);
+            if (np[j]) {
+                const uint64_t ra = r0 + run[0], ta = rev ? t0 - run[1] : t0 + run[1];
+                d_ref[slot] = (uint32_t)ra; d_tig[slot] = (uint32_t)ta;
+                d_len[slot] = len << 2 | (rev ? 2u : 0u) | (code == 8 ? 1u : 0u);
+                if (WIDE) d_hi[slot] = make_uint2((uint32_t)(ra >> 32), (uint32_t)(ta >> 32));
+                s_pre[slot] = at;
+                d_op[slot] = (uint16_t)(my0 + j);
+                ++slot; at += np[j];
             }
             uint64_t c[NQ];
             op_contrib(o[j], c);
@@ -629,94 +690,85 @@ __global__ __launch_bounds__(256) void verify_kernel(VerifyArgs A) {
         }
     }
     __syncthreads();
-    // The runs are cut into 64-base pieces (one lane, one window of each plane); a block scan numbers the pieces of the chunk
-    // and every lane takes pieces t, t + 256, ... - an 'X' of one base costs one lane, not one wave; consecutive lanes read
-    // consecutive windows of the same run.
-    __shared__ uint32_t s_pre[VSLOTS + 1];
-    {
-        uint64_t mine[1] = {0}, all[1];
-        uint32_t np[OPS_PER_LANE];
-#pragma unroll
-        for (int j = 0; j < OPS_PER_LANE; ++j) { np[j] = mine_half ? ((d_len[my0 + j] >> 2) + VPIECE - 1) / VPIECE : 0u; mine[0] += np[j]; }
-        block_excl_scan<1>(mine, all, lds);
-        uint32_t at = (uint32_t)mine[0];
-        if (mine_half)
-#pragma unroll
-            for (int j = 0; j < OPS_PER_LANE; ++j) { s_pre[my0 + j] = at; at += np[j]; }
-        if (threadIdx.x == 255) s_pre[VSLOTS] = (uint32_t)all[0];
+    // Every wave takes one contiguous quarter of the pieces, 128 per step (two per lane, the loads of both issued before the
+    // first compare); consecutive lanes read consecutive windows of the same run.  The run that owns a piece is not searched
+    // for: c0 = run of the step's first piece; the lanes look at the first pieces of the 128 runs after c0 (more cannot
+    // start within 128 pieces), mark the pieces of this step that start a run, and a lane's run = c0 + the marks at or
+    // before its piece (ballot + mbcnt).
+    uint32_t bad_tot = 0, bad_x = 0, bad_slot = ~0u;
+    const uint32_t per_wave = ((n_pieces + 4 * VU * VPIECE - 1) / (4 * VU * VPIECE)) * VU * VPIECE;
+    // (wave id, piece range, c0 in scalar registers: the loop control and the owner arithmetic stay off the vector ALU)
+    const uint32_t swave = __builtin_amdgcn_readfirstlane((uint32_t)wave);
+    const uint32_t p0 = swave * per_wave, p1 = min(p0 + per_wave, n_pieces);
+    uint32_t c0 = 0;
+    if (p0 < p1) {                                                       // last run that starts at or before piece p0
+        uint32_t hi = n_slots;
+        while (hi - c0 > 1) {
+            const uint32_t mid = (c0 + hi) >> 1;
+            if ((uint32_t)__builtin_amdgcn_readfirstlane(s_pre[mid]) <= p0) c0 = mid; else hi = mid;
+        }
     }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long n_eq = 0, bad_eq = 0, n_x = 0, bad_x = 0, first_bad = ~0ull;
-    const uint32_t n_pieces = s_pre[VSLOTS];
-    // coarse index: the slot that owns piece 256 m, so that a lane only searches the few slots its group of 256 pieces spans
-    constexpr uint32_t TBL = 1024;
-    __shared__ uint16_t tbl[TBL + 1];
-    const uint32_t n_grp = (n_pieces + 255) / 256;
-    const bool use_tbl = n_grp <= TBL;
-    if (use_tbl) {
-        if (mine_half)
+    for (uint32_t base = p0; base < p1; base += VU * VPIECE) {
 #pragma unroll
-            for (int j = 0; j < OPS_PER_LANE; ++j) {
-                const uint32_t q = my0 + j, s0 = s_pre[q], e0 = s_pre[q + 1];
-                for (uint32_t m = (s0 + 255) / 256; m * 256 < e0; ++m) tbl[m] = (uint16_t)q;
-            }
-        if (threadIdx.x == 0) tbl[n_grp] = VSLOTS - 1;
-    }
-    __syncthreads();
-    // The loop is bound by instruction issue, not by HBM (SQ counters: one wave per SIMD issuing at any time), so the data
-    // path works on dwords: an unaligned 64-base window = one 4-byte-aligned 16-byte load + one dword, put in place with four
-    // v_alignbit; reverse-strand windows are loaded so that they END at the piece's first base (bit reversal alone then puts
-    // the bases in scan order); the non-ACGT planes are read only where the pack's summary marks a block (SeqView::dirty).
-    constexpr int UNROLL = 2;                                            // pieces in flight per lane: the loads of both are
-    constexpr uint32_t EVEN = 0x55555555u;                               // issued before the first compare
-    for (uint32_t g0 = 0; g0 < n_grp; g0 += UNROLL) {
-        uint32_t q[UNROLL], n[UNROLL], flags[UNROLL], lsh[UNROLL];
-        uint8_t dr[UNROLL][2], dt[UNROLL][2];                            // summary bytes of the blocks a window touches (used after all loads are out)
-        uint64_t pr[UNROLL], pt[UNROLL];
-        W5 xr[UNROLL], xt[UNROLL];
-        bool live[UNROLL];
+        for (int u = 0; u < VU; ++u) {                                   // run c0 + 1 + i starts at piece base + 1 + s
+            const uint32_t s = s_pre[min(c0 + 1 + (uint32_t)u * VPIECE + (uint32_t)lane, n_slots)] - base - 1;
+            if (s < VU * VPIECE) mark[wave][s] = 1;
+        }
+        // mark[i]: a run starts at piece base + 1 + i; piece base + l belongs to run c0 + (marks below l)
+        uint32_t q[VU];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            // lanes past the last piece repeat it with n = 0: no branch around the loads, so nothing of piece u has to be
-            // waited for before the loads of piece u + 1 are issued (a skipped block made the compiler merge, and wait)
-            const uint32_t want = (g0 + u) * 256 + threadIdx.x;
-            live[u] = want < n_pieces;
-            const uint32_t piece = live[u] ? want : n_pieces - 1, g = piece >> 8;
-            uint32_t lo = use_tbl ? tbl[g] : 0u, hi = (use_tbl ? (uint32_t)tbl[g + 1] : (uint32_t)VSLOTS - 1) + 1;
-            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_pre[mid] <= piece) lo = mid; else hi = mid; }
-            // (slots without pieces share their prefix with the slot after them, so the largest such slot is the owner of the piece)
-            q[u] = lo;
-            const uint32_t dl = d_len[lo], len = dl >> 2;
+        for (int u = 0; u < VU; ++u) {
+            const uint32_t m = mark[wave][u * VPIECE + lane];
+            mark[wave][u * VPIECE + lane] = 0;
+            const uint64_t M = __ballot(m != 0);
+            q[u] = __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, c0));
+            c0 += (uint32_t)__popcll(M);
+        }
+
+        uint32_t n[VU], flags[VU], lsh[VU];
+        uint8_t dr[VU], dt[VU];                                             // summary bytes of the blocks a window touches (used after all loads are out)
+        pos_t pr[VU], pt[VU];
+        W5 xr[VU], xt[VU];
+#pragma unroll
+        for (int u = 0; u < VU; ++u) {
+            // lanes past the last piece sit on the sentinel (length 0, position 0): no branch around the loads, so nothing of
+            // piece u has to be waited for before the loads of piece u + 1 are issued
+            const uint32_t piece = base + (uint32_t)u * VPIECE + (uint32_t)lane;
+            const bool live = piece < n_pieces;
+            pos_t ra = d_ref[q[u]], ta = d_tig[q[u]];
+            if (WIDE) { const uint2 H = d_hi[q[u]]; ra |= (pos_t)((uint64_t)H.x << 32); ta |= (pos_t)((uint64_t)H.y << 32); }
+            const uint32_t dl = d_len[q[u]], len = dl >> 2;
             flags[u] = dl & 3u;                                          // bit 1 reverse row, bit 0 'X'
-            const uint64_t ra = d_ref[lo], ta = d_tig[lo];
-            const uint32_t b = (piece - s_pre[lo]) * VPIECE;
-            n[u] = live[u] ? min(VPIECE, len - b) : 0u;
+            const uint32_t first_piece = s_pre[q[u]];
+            const uint32_t b = live ? (piece - first_piece) * VPIECE : 0u;
+            n[u] = live ? min(VPIECE, len - b) : 0u;
             pr[u] = ra + b;
             // forward rows: the window starts at the piece's first base.  Reverse rows: it ends there (stored bases ta-b-63 .. ta-b);
             // at the very start of the arena it starts at 0 and the reversed window is moved down by the missing bases (lsh)
-            uint64_t s0 = ta + b;
+            pos_t s0 = ta + b;
+            lsh[u] = 0;
             if (flags[u] & 2u) {
-                const uint64_t e = ta - b;
+                const pos_t e = ta - b;
                 lsh[u] = e < 63 ? (uint32_t)(63 - e) : 0u;
-                s0 = e < 63 ? 0ull : e - 63;
+                s0 = e < 63 ? (pos_t)0 : e - 63;
             }
             pt[u] = s0;
-            dr[u][0] = A.ref.dirty[pr[u] >> DIRTY_SHIFT]; dr[u][1] = A.ref.dirty[(pr[u] + 63) >> DIRTY_SHIFT];
-            dt[u][0] = A.tig.dirty[s0 >> DIRTY_SHIFT]; dt[u][1] = A.tig.dirty[(s0 + 63) >> DIRTY_SHIFT];
-            xr[u] = window_dw(A.ref.two, pr[u]);
-            xt[u] = window_dw(A.tig.two, s0);
+            // (two byte loads per plane: one unaligned 2-byte load of the block and its neighbour measured 5 % slower)
+            dr[u] = A.ref.dirty[pr[u] >> DIRTY_SHIFT] | A.ref.dirty[(pr[u] + 63) >> DIRTY_SHIFT];
+            dt[u] = A.tig.dirty[s0 >> DIRTY_SHIFT] | A.tig.dirty[(s0 + 63) >> DIRTY_SHIFT];
+            xr[u] = window_at<pos_t>(A.ref.two, pr[u]);
+            xt[u] = window_at<pos_t>(A.tig.two, s0);
         }
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
+        for (int u = 0; u < VU; ++u) {
             uint32_t r[4], t[4];
-            align_dw(xr[u], pr[u], r);
-            align_dw(xt[u], pt[u], t);
+            align_dw(xr[u], (uint64_t)pr[u], r);
+            align_dw(xt[u], (uint64_t)pt[u], t);
             uint64_t rm = 0, tm = 0;
-            if (dr[u][0] | dr[u][1] | dt[u][0] | dt[u][1]) {             // rare: a non-ACGT base somewhere near
+            if (dr[u] | dt[u]) {                                         // rare: a non-ACGT base somewhere near
                 const uint64_t keep = n[u] == 64 ? ~0ull : (1ull << n[u]) - 1ull;
-                rm = window64(A.ref.mask, pr[u]) & keep;
-                tm = window64(A.tig.mask, pt[u]);
+                rm = window64(A.ref.mask, (uint64_t)pr[u]) & keep;
+                tm = window64(A.tig.mask, (uint64_t)pt[u]);
                 if (flags[u] & 2u) tm = __brevll(tm) >> lsh[u];
                 tm &= keep;
             }
@@ -738,12 +790,12 @@ __global__ __launch_bounds__(256) void verify_kernel(VerifyArgs A) {
             }
             // bit 2j of dword i: base 16 i + j differs; km keeps the n bases of the piece; 'X' pieces count the equal ones
             const uint32_t xm = (flags[u] & 1u) ? EVEN : 0u;
+            const uint4 K = km_tbl[n[u]];
+            const uint32_t km[4] = {K.x, K.y, K.z, K.w};
             uint32_t bad = 0;
-            uint32_t neq[4], km[4];
+            uint32_t neq[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int have = (int)n[u] - 16 * i;                     // bases of the piece in this dword
-                km[i] = have >= 16 ? EVEN : (have <= 0 ? 0u : EVEN & ((1u << (2 * have)) - 1u));
                 const uint32_t d = r[i] ^ t[i];
                 neq[i] = (d | d >> 1) & km[i];
                 bad += __popc((neq[i] ^ xm) & km[i]);
@@ -757,18 +809,21 @@ __global__ __launch_bounds__(256) void verify_kernel(VerifyArgs A) {
                 const u128 wrong = (flags[u] & 1u) ? ((~nq & kmask & ~one_n) | both_n) : ((nq & ~both_n) | one_n);
                 bad = (uint32_t)popc128(wrong);
             }
-            if (flags[u] & 1u) { n_x += n[u]; bad_x += bad; } else { n_eq += n[u]; bad_eq += bad; }
-            if (bad) first_bad = min(first_bad, (unsigned long long)chunk * WALK_CHUNK + slot0 + (unsigned long long)q[u]);
+            bad_tot += bad;                                              // 32-bit counters: < 2^38 / 256 bases per lane; '=' = all - 'X'
+            if (flags[u] & 1u) bad_x += bad;
+            if (bad) bad_slot = min(bad_slot, q[u]);
         }
     }
+    unsigned long long n_eq = len_eq, bad_eq = bad_tot - bad_x, nx = len_x, bx = bad_x;
+    unsigned long long first_bad = bad_slot == ~0u ? ~0ull : (unsigned long long)chunk * WALK_CHUNK + slot0 + (unsigned long long)d_op[bad_slot];
 #pragma unroll
     for (int dd = 32; dd >= 1; dd >>= 1) {
-        n_eq += __shfl_xor(n_eq, dd); bad_eq += __shfl_xor(bad_eq, dd); n_x += __shfl_xor(n_x, dd); bad_x += __shfl_xor(bad_x, dd);
+        n_eq += __shfl_xor(n_eq, dd); bad_eq += __shfl_xor(bad_eq, dd); nx += __shfl_xor(nx, dd); bx += __shfl_xor(bx, dd);
         first_bad = min(first_bad, (unsigned long long)__shfl_xor(first_bad, dd));
     }
     // one atomic per workgroup and counter
     __shared__ unsigned long long part[4][5];
-    if (lane == 0) { part[wave][0] = n_eq; part[wave][1] = bad_eq; part[wave][2] = n_x; part[wave][3] = bad_x; part[wave][4] = first_bad; }
+    if (lane == 0) { part[wave][0] = n_eq; part[wave][1] = bad_eq; part[wave][2] = nx; part[wave][3] = bx; part[wave][4] = first_bad; }
     __syncthreads();
     if (threadIdx.x < 4) {
         const unsigned long long v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
@@ -1553,7 +1608,12 @@ int pav_cigar_verify(pav_ctx *ctx, pav_verify_counts *out) {
     A.chunk_row = reinterpret_cast<const uint32_t *>(A.rowbase + 2 * ((size_t)ctx->n_aln + 1));
     A.ref = ctx->seq[PAV_ROLE_REF].view(); A.tig = ctx->seq[PAV_ROLE_TIG].view();
     A.cnt = d_cnt;
-    PAV_LAUNCH(ctx, "verify_kernel", verify_kernel, VSPLIT * n_wchunks, 256, 0, A);
+    // 32-bit positions when both arenas (padding included) stay below 2^32 bases; PAV_VERIFY_WIDE=1 forces the 64-bit kernel (tests)
+    const char *force_wide = getenv("PAV_VERIFY_WIDE");
+    const bool wide = (force_wide && *force_wide == '1') || ctx->seq[PAV_ROLE_REF].arena + 128 >= (1ull << 32) ||
+                      ctx->seq[PAV_ROLE_TIG].arena + 128 >= (1ull << 32);
+    if (wide) PAV_LAUNCH(ctx, "verify_kernel", verify_kernel<true>, VSPLIT * n_wchunks, 256, 0, A);
+    else      PAV_LAUNCH(ctx, "verify_kernel", verify_kernel<false>, VSPLIT * n_wchunks, 256, 0, A);
     unsigned long long h[5];
     PAV_HIP(ctx, hipMemcpyAsync(h, d_cnt, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));

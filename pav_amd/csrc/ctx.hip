@@ -308,7 +308,7 @@ int pav_seq_load(pav_ctx *ctx, int role, uint32_t n_seq, const uint8_t *const *a
     PAV_HIP(ctx, s.d_ascii.reserve(a));
     PAV_HIP(ctx, s.d_two.reserve(a / 4));
     PAV_HIP(ctx, s.d_mask.reserve(a / 8));
-    PAV_HIP(ctx, s.d_dirty.reserve((a / 16 + 256 * PACK_U - 1) / (256 * PACK_U) * 16));   // 16 summary bytes per pack workgroup
+    PAV_HIP(ctx, s.d_dirty.reserve((a / 16 + 256 * PACK_U - 1) / (256 * PACK_U) * 16 + 16));   // 16 summary bytes per pack workgroup (+ slack: verify_kernel reads pairs)
     PAV_HIP(ctx, s.d_off.reserve(sizeof(uint64_t) * n_seq));
     PAV_HIP(ctx, s.d_len.reserve(sizeof(uint64_t) * n_seq));
     PAV_HIP(ctx, hipMemsetAsync(s.d_ascii.p, 'N', a, ctx->stream));          // padding reads as non-ACGT

@@ -613,6 +613,58 @@ def test_verify_mode_window_edges(built, gpu_ctx):
     assert got == want
 
 
+@pytest.mark.parametrize('wide', [False, True], ids=['pos32', 'pos64'])
+def test_verify_mode_long_runs_and_step_boundaries(built, gpu_ctx, monkeypatch, wide):
+    """pav_cigar_verify where one run spans many 128-piece steps of a wave, runs start and end exactly on the step and piece
+    boundaries, and thousands of short runs follow each other (every lane of a step owns a different run); both the 32-bit
+    and the 64-bit position kernels (PAV_VERIFY_WIDE=1 forces the one that arenas of 2^32 bases and more get)."""
+    import pandas as pd
+    monkeypatch.setenv('PAV_VERIFY_WIDE', '1' if wide else '0')
+    rng = np.random.default_rng(31)
+    acgt = np.frombuffer(b'ACGT', dtype=np.uint8)
+    comp = np.arange(256, dtype=np.uint8)
+    for a, b in zip(b'ACGTN', b'TGCAN'):
+        comp[a] = b
+    ref = acgt[rng.integers(0, 4, 1_500_000)].copy()
+    special = [1, 63, 64, 65, 127, 128, 129, 8191, 8192, 8193, 16384, 40000]
+    rows, tigs = [], {}
+    pos = 3
+    for r, rev in enumerate((False, True, False)):
+        lens = [int(x) for x in rng.permutation(np.repeat(special, 3))]
+        if r == 2:                                                        # 3000 runs of 1-3 bases: a new run in almost every lane
+            lens = [int(x) for x in rng.integers(1, 4, 3000)]
+        codes = ['=' if i % 2 == 0 else 'X' for i in range(len(lens))]
+        if r != 2:
+            lens = [n if c == '=' else min(n, 70) for n, c in zip(lens, codes)]
+        seg = ref[pos:pos + sum(lens)].copy()
+        at = 0
+        for n, c in zip(lens, codes):
+            if c == 'X':
+                seg[at:at + n] = acgt[(np.searchsorted(acgt, seg[at:at + n]) + 1 + rng.integers(0, 3, n)) % 4]
+            at += n
+        hit = rng.integers(0, seg.shape[0], 60)                           # contradictions: '=' bases changed, 'X' bases made equal
+        seg[hit] = np.where(rng.random(60) < 0.5, ref[pos + hit], acgt[(np.searchsorted(acgt, seg[hit]) + 1) % 4])
+        seg[[0, seg.shape[0] - 1]] = ord('N')
+        name = f'tig{r}'
+        tigs[name] = comp[seg[::-1]].copy() if rev else seg
+        rows.append({'#CHROM': 'chrT', 'POS': pos, 'QRY_ID': name, 'REV': rev, 'CIGAR': ''.join(f'{n}{c}' for n, c in zip(lens, codes))})
+        pos += sum(lens) + 5
+    assert pos < ref.shape[0]
+    df = pd.DataFrame(rows)
+    names, tig_names = ['chrT'], list(tigs)
+    aln, text, off = cigarcall.pack_alignments(df, names, tig_names)
+    gpu_ctx._inv_loaded = None
+    gpu_ctx.seq_load(_lib.PAV_ROLE_REF, names, [ref])
+    gpu_ctx.seq_load(_lib.PAV_ROLE_TIG, tig_names, [tigs[n] for n in tig_names])
+    gpu_ctx.cigar_load(aln, text, off)
+    counts = gpu_ctx.cigar_call()
+    ops, op_off = gpu_ctx.cigar_fetch_ops(counts.n_ops, aln.shape[0])
+    got = gpu_ctx.cigar_verify()
+    want = _verify_numpy({'chrT': ref}, tigs, tig_names, names, aln, ops, op_off)
+    assert want['eq_mismatch'] > 20 and want['x_match'] > 5 and want['first_bad_op'] == 0
+    assert got == want
+
+
 def test_merged_tables_of_an_empty_alignment_table(built, gpu_ctx, tmp_path):
     """No alignment rows: call_cigar_merged_files writes the two header-only tables the rule chain writes
     (call_cigar_files x 10 -> call_cigar_merge on the same empty input)."""
