@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # half of the guide's 157.3 TFLOP/s FP32 vector peak (256 CUs x 4 SIMD-32 x FMA x 2.4 GHz); the KDE has no MFMA form
 
 
 PAIR_FRAC = 0.009          # matched DEL + INS events of the generator: ~1 k MATCH_INDEL loci per haplotype (~1 k flagged regions)
@@ -76,6 +77,8 @@ def main():
     ap.add_argument('--backend', default='nccl', help="process-group backend for N > 1 ('nccl' = RCCL; tests use 'gloo')")
     ap.add_argument('--share-gpu', action='store_true',
                     help='tests only: every rank uses GPU 0 (exercises the N > 1 code path on a one-GPU box; needs --backend gloo)')
+    ap.add_argument('--eager-pack', action='store_true',
+                    help='pack the whole contig arena at the start of every pass (PAV_EAGER_PACK=1: the round-1 behaviour) instead of on demand')
     ap.add_argument('--no-build', action='store_true', help='do not (re)build the libraries: the profile scripts build first, outside the profiler')
     args = ap.parse_args()
 
@@ -87,6 +90,9 @@ def main():
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
                '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.run(cmd).returncode)
+    if args.eager_pack:
+        os.environ['PAV_EAGER_PACK'] = '1'
+    eager_pack = os.environ.get('PAV_EAGER_PACK') == '1'
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -310,8 +316,10 @@ def main():
     #      beside them, so the sum of the kernel times is the device work of a step ---------------------------------------
     ctx.prof_reset()
     ctx.prof_enable(True)
+    kde0 = ctx.kde_work()
     run_steps(args.steps, only=lanes[0])
     prof = ctx.prof_read()
+    kde_leg = tuple(b - a for a, b in zip(kde0, ctx.kde_work()))       # evaluation points, (point, run) pairs, (point, data point) pairs
     ctx.prof_enable(False)
     t_single = None
     if n_lanes > 1:                                           # and timed without the events: what one lane alone achieves
@@ -337,12 +345,20 @@ def main():
     #      '=' / 'X' base against the CIGAR; never mixed into `value` ------------------------------------------------------
     verify_leg = side_leg('cigar+verify')
     # the dominant kernel with nothing beside it: K packs of the resident contigs, each waited for (HIP events as above)
+    # (the contig planes are packed on demand since round 2 - DESIGN.md section 3.1: the full streaming pack runs in verify
+    #  mode and with PAV_EAGER_PACK=1; it is timed here with that switch, nothing beside it)
     ctx.prof_reset()
     ctx.prof_enable(True)
+    eager_before = os.environ.get('PAV_EAGER_PACK')
+    os.environ['PAV_EAGER_PACK'] = '1'
     for _ in range(args.steps):
         ctx.seq_pack(_lib.PAV_ROLE_TIG)
         ctx.sync()
     pack_alone = ctx.prof_read().get('pack_kernel')
+    if eager_before is None:
+        del os.environ['PAV_EAGER_PACK']
+    else:
+        os.environ['PAV_EAGER_PACK'] = eager_before
     # ... and the call kernels with the planes already packed and no pack beside them
     ctx.prof_reset()
     t0 = time.perf_counter()
@@ -448,7 +464,7 @@ def main():
             except (OSError, KeyError, ValueError):
                 pass
 
-        def make_roofline(prof_, want=None):
+        def make_roofline(prof_, want=None, kde=None):
             """Dominant kernel (largest total time in the profiled steps) against the HBM roofline: algorithmic bytes per
             launch / average launch duration from HIP events on the library's streams."""
             kern_ = {k: {'launches': v[0], 'avg_ms': v[1] / max(1, v[0])} for k, v in prof_.items()}
@@ -483,18 +499,35 @@ def main():
                 traffic = (pmc['fetch_kib'][dom] * fx + pmc['write_kib'][dom]) * 1024.0
             a_bytes = alg_bytes.get(dom)
             achieved = a_bytes / (kern_[dom]['avg_ms'] * 1e-3) / 1e9 if a_bytes and kern_[dom]['avg_ms'] > 0 else None
-            return kern_, {'kernel': dom, 'bound': 'hbm', 'achieved': None if achieved is None else round(achieved, 1),
-                           'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
-                           'traffic': traffic, 'avg_kernel_ms': round(kern_[dom]['avg_ms'], 4),
-                           'launches_per_step': round(kern_[dom]['launches'] / args.steps, 2),
-                           'algorithmic_bytes_per_launch': a_bytes,
+            head = {'kernel': dom, 'bound': 'hbm', 'achieved': None if achieved is None else round(achieved, 1),
+                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
+                    'traffic': traffic, 'algorithmic_bytes_per_launch': a_bytes}
+            if dom == 'k_kde_eval' and kde and kern_[dom]['launches'] and kern_[dom]['avg_ms'] > 0:
+                # the kernel densities: FP64 exp work, no bytes to speak of.  Algorithmic flops = SURVEY 8(d): 25 per (evaluation
+                # point, data point) pair of scipy's double loop.  The kernel does not run that loop - a run of consecutive
+                # INDEX values is summed in closed form - so the figure can exceed the FP64 vector peak;
+                # `executed` prices the (point, run) pairs it does go over at ~150 flop (two exp, two erfc, the polynomial terms)
+                flops = 25.0 * kde[2] / kern_[dom]['launches']
+                tf = flops / (kern_[dom]['avg_ms'] * 1e-3) / 1e12
+                ex = 150.0 * kde[1] / kern_[dom]['launches'] / (kern_[dom]['avg_ms'] * 1e-3) / 1e12
+                head = {'kernel': dom, 'bound': 'mfma', 'bound_detail': 'FP64 vector ALU (exp / erfc): the sum of Gaussians has no MFMA form '
+                                                                        '(SURVEY 8(d)); peak = FP64 vector peak, not a matrix peak',
+                        'achieved': round(tf, 2), 'peak': FP64_VECTOR_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(tf / FP64_VECTOR_PEAK_TFLOPS, 4), 'traffic': None, 'algorithmic_flops_per_launch': flops,
+                        'evaluation_points_per_launch': kde[0] / kern_[dom]['launches'],
+                        'point_run_pairs_per_launch': kde[1] / kern_[dom]['launches'],
+                        'point_data_pairs_per_launch': kde[2] / kern_[dom]['launches'],
+                        'executed': {'tflops': round(ex, 2), 'frac': round(ex / FP64_VECTOR_PEAK_TFLOPS, 4),
+                                     'model': '150 flop per (point, run) pair'}}
+            head.update({'avg_kernel_ms': round(kern_[dom]['avg_ms'], 4), 'launches_per_step': round(kern_[dom]['launches'] / args.steps, 2)})
+            return kern_, {**head,
                            'kernels_ms': {k: round(v['avg_ms'], 4) for k, v in sorted(kern_.items())},
                            # every kernel with a byte model: achieved GB/s of algorithmic bytes; the
                            # latency-bound ones (scattered line fetches, dependent launches) sit far below the HBM roof by nature
                            'modelled_kernels_gbs': {k: round(alg_bytes[k] / (kern_[k]['avg_ms'] * 1e-3) / 1e9, 1)
                                                     for k in sorted(alg_bytes) if k in kern_ and kern_[k]['avg_ms'] > 0}}
 
-        kern, roofline = make_roofline(prof)
+        kern, roofline = make_roofline(prof, kde=kde_leg)
         # ---- the honest roofline of the PATH (SURVEY.md section 8(d) byte model; the pack above is pre-processing the model
         #      has no term for): algorithmic bytes of one step / step time.  CIGAR-call: 4 B / op + 64 B / row + 16 B / SNV +
         #      40 B / indel + 2-bit SV bases + 0.5 B per scanned homology base (window bound: 128 B / indel) + 0.5 B per X base;
@@ -506,10 +539,13 @@ def main():
         roofline['path'] = {
             'bound': 'hbm', 'unit': 'GB/s', 'peak': HBM_PEAK_GBS,
             'algorithmic_bytes_per_step': {'cigar_call': round(path_bytes), 'kmer_scan': round(scan_bytes),
-                                           'contig_pack_not_in_the_model': round(tig_bases * 1.375)},
+                                           'contig_pack_not_in_the_model': round(tig_bases * 1.375) if eager_pack else 0},
             'achieved': round((path_bytes + scan_bytes) / (ms_per_step * 1e-3) / 1e9, 1),
             'frac': round((path_bytes + scan_bytes) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            'frac_with_pack_counted': round((path_bytes + scan_bytes + tig_bases * 1.375) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            'frac_with_pack_counted': round((path_bytes + scan_bytes + (tig_bases * 1.375 if eager_pack else 0.0)) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            'contig_pack': ('whole arena at the start of every pass (PAV_EAGER_PACK=1)' if eager_pack else
+                            'on demand: homology windows decode the ASCII arena, the k-mer scans pack the 1024-base blocks under their '
+                            'regions (pack_spans_kernel), verify mode packs everything (DESIGN.md section 3.1)'),
             'sum_kernel_ms_per_step': round(sum_kernel_ms, 3),
             'ms_per_step_over_sum_kernel_ms': round(ms_per_step / sum_kernel_ms, 3) if sum_kernel_ms else None,
             'single_lane_ms_per_step': None if t_single is None else round(t_single / args.steps * 1e3, 4),
@@ -557,7 +593,7 @@ def main():
         if cigar_leg is not None:
             _, roof_c = make_roofline(cigar_leg['prof'])
             add_alone(roof_c)
-            cigar_only = {'workload': 'BASELINE configs[1]: the same haplotype, CIGAR-call only (pack + tokenise + walk + homology + '
+            cigar_only = {'workload': 'BASELINE configs[1]: the same haplotype, CIGAR-call only (tokenise + walk + homology + '
                                       'SEQ gather), measured in this run after the headline region',
                           'value': round(aligned_total / cigar_leg['t'] / 1e9, 2), 'unit': 'Gbp/s',
                           'ms_per_step': round(cigar_leg['t'] / args.steps * 1e3, 4), 'steps': args.steps, 'roofline': roof_c}
@@ -737,6 +773,13 @@ def main():
                                      'haplotypes\' own size spread'},
             'roofline': roofline, 'cpu_baseline': cpu, 'cigar_only': cigar_only, 'verify_mode': verify_mode, 'inv_scan': inv_report,
             'end_to_end': e2e,
+            # the streaming pack of the whole contig arena (verify mode, PAV_EAGER_PACK=1): timed with nothing beside it
+            'contig_pack_alone': None if not (pack_alone and pack_alone[0]) else {
+                'kernel': 'pack_kernel', 'avg_kernel_ms': round(pack_alone[1] / pack_alone[0], 4),
+                'algorithmic_bytes_per_launch': tig_bases * 1.375,
+                'achieved': round(tig_bases * 1.375 / (pack_alone[1] / pack_alone[0] * 1e-3) / 1e9, 1), 'unit': 'GB/s', 'peak': HBM_PEAK_GBS,
+                'frac': round(tig_bases * 1.375 / (pack_alone[1] / pack_alone[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                'in_the_path': bool(eager_pack)},
             'host': {'generate_s': round(t_gen, 1), 'h2d_and_ref_pack_s': round(t_h2d, 2), 'd2h_records_s': round(t_d2h, 3),
                      'd2h_density_tables_s': None if t_d2h_tables is None else round(t_d2h_tables, 4),
                      'density_tables_mb': None if tables_mb is None else round(tables_mb, 1),

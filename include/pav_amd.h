@@ -49,6 +49,10 @@ const char *pav_last_error(const pav_ctx *ctx);
 int pav_device_name(const pav_ctx *ctx, char *buf, int buf_len);
 int pav_sync(pav_ctx *ctx);                       /* hipStreamSynchronize on the context's stream          */
 int pav_mem_info(pav_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);   /* HBM of the context's GPU (hipMemGetInfo) */
+/* Density work done by the context since it was created (for roofline accounting, bench.py): out[0] evaluation points of
+ * the kernel densities (sampled + filled), out[1] (point, run of consecutive INDEX values) pairs the closed-form sums went
+ * over, out[2] (point, data point) pairs - what scipy's double loop would have gone over (~25 flop each). */
+int pav_kde_work(const pav_ctx *ctx, double out[3]);
 
 /* ---- sequence store ----------------------------------------------------------------------------------- *
  * Replaces: pysam.FastaFile.fetch of whole records + str.upper() of the whole chromosome / contig per

@@ -182,6 +182,7 @@ SYMBOLS = {
     'pav_device_name': (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int]),
     'pav_sync': (ctypes.c_int, [_P]),
     'pav_mem_info': (ctypes.c_int, [_P, _P, _P]),
+    'pav_kde_work': (ctypes.c_int, [_P, _P]),
     'pav_cigar_verify': (ctypes.c_int, [_P, _P]),
     'pav_seq_load': (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_uint32, _P, _P]),
     'pav_seq_share': (ctypes.c_int, [_P, _P, ctypes.c_int]),
@@ -352,6 +353,12 @@ class Context:
         f, t = ctypes.c_uint64(0), ctypes.c_uint64(0)
         self._check(self.lib.pav_mem_info(self.handle, ctypes.byref(f), ctypes.byref(t)), 'pav_mem_info')
         return int(f.value), int(t.value)
+
+    def kde_work(self):
+        """Cumulative density work of the context: (evaluation points, (point, run) pairs, (point, data point) pairs)."""
+        out = (ctypes.c_double * 3)()
+        self._check(self.lib.pav_kde_work(self.handle, out), 'pav_kde_work')
+        return float(out[0]), float(out[1]), float(out[2])
 
     # -- sequences ----------------------------------------------------------------------------------------
     def seq_load(self, role, names, arrays):

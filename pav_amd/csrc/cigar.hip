@@ -948,11 +948,15 @@ __global__ __launch_bounds__(256) void lift_positions(const uint32_t *__restrict
 // becomes a periodic pattern: for svlen <= 32 one period is fetched once and replicated so that every step
 // starts at phase 0; longer SVs are compared window by window up to the wrap point.
 struct SeqRef {                 // one oriented record of a store
-    const uint32_t *two, *mask;
-    const uint8_t *dirty;
+    const uint32_t *two, *mask; // planes of a packed store; of a store whose planes are packed on demand (contigs, ctx.hip
+    const uint8_t *dirty;       // "lazy contig pack"): two = nullptr, dirty = the ASCII arena - fetch_run decodes the bytes
     uint64_t off, len;
     int rev;
 };
+__device__ __forceinline__ SeqRef seq_ref(const SeqView &v, uint32_t id, int rev) {
+    if (v.packed) return SeqRef{v.two, v.mask, v.dirty, v.off[id], v.len[id], rev};
+    return SeqRef{nullptr, nullptr, v.ascii, v.off[id], v.len[id], rev};
+}
 
 __device__ __forceinline__ uint64_t low_bits64(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
 
@@ -968,23 +972,41 @@ __device__ __forceinline__ void fetch_run(const SeqRef &s, int64_t p, int dir, i
     const int64_t st = s.rev ? (int64_t)s.len - 1 - p : p;          // stored position of the first scanned base
     const int sdir = s.rev ? -dir : dir;                              // direction in stored coordinates
     const uint64_t abs = s.off + (uint64_t)(sdir > 0 ? st : st - (n - 1));
-    const uint64_t *two64 = reinterpret_cast<const uint64_t *>(s.two);
-    const uint64_t *mask64 = reinterpret_cast<const uint64_t *>(s.mask);
-    const uint64_t w = abs >> 5;
-    const int b = (int)(abs & 31) * 2;
-    uint64_t x = two64[w] >> b;
-    if (b) x |= two64[w + 1] << (64 - b);
-    // non-ACGT bits: only blocks the summary marks hold any (SeqView::dirty)
-    const uint64_t d0 = abs >> DIRTY_SHIFT, d1 = (abs + (uint64_t)(n - 1)) >> DIRTY_SHIFT;
-    uint32_t dirty = s.dirty[d0];
-    if (d1 != d0) dirty |= s.dirty[d1];
+    uint64_t x;
     uint32_t m = 0;
-    if (dirty) {
-        const uint64_t w2 = abs >> 6;
-        const int b2 = (int)(abs & 63);
-        uint64_t y = mask64[w2] >> b2;
-        if (b2) y |= mask64[w2 + 1] << (64 - b2);
-        m = (uint32_t)y;
+    if (!s.two) {
+        // ASCII arena: nine dwords from the dword that holds byte abs, moved into place with v_alignbyte, four bases per
+        // dword through the pack's own conversion (pad blocks and anything that is not ACGT / acgt come out as non-ACGT bits)
+        const uint32_t *a4 = reinterpret_cast<const uint32_t *>(s.dirty + (abs & ~3ull));
+        const u32x4_a4 v0 = *reinterpret_cast<const u32x4_a4 *>(a4), v1 = *reinterpret_cast<const u32x4_a4 *>(a4 + 4);
+        const uint32_t w[9] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, a4[8]};
+        const uint32_t sh = (uint32_t)abs & 3u;
+        x = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            uint32_t c8, b4;
+            pack4(__builtin_amdgcn_alignbyte(w[i + 1], w[i], sh), c8, b4);
+            x |= (uint64_t)c8 << (8 * i);
+            m |= b4 << (4 * i);
+        }
+    } else {
+        const uint64_t *two64 = reinterpret_cast<const uint64_t *>(s.two);
+        const uint64_t *mask64 = reinterpret_cast<const uint64_t *>(s.mask);
+        const uint64_t w = abs >> 5;
+        const int b = (int)(abs & 31) * 2;
+        x = two64[w] >> b;
+        if (b) x |= two64[w + 1] << (64 - b);
+        // non-ACGT bits: only blocks the summary marks hold any (SeqView::dirty)
+        const uint64_t d0 = abs >> DIRTY_SHIFT, d1 = (abs + (uint64_t)(n - 1)) >> DIRTY_SHIFT;
+        uint32_t dirty = s.dirty[d0];
+        if (d1 != d0) dirty |= s.dirty[d1];
+        if (dirty) {
+            const uint64_t w2 = abs >> 6;
+            const int b2 = (int)(abs & 63);
+            uint64_t y = mask64[w2] >> b2;
+            if (b2) y |= mask64[w2 + 1] << (64 - b2);
+            m = (uint32_t)y;
+        }
     }
     if (n < 32) { x &= low_bits64(2 * n); m &= (1u << n) - 1u; }
     if (sdir < 0) { x = reverse_groups(x, n); m = __brev(m) >> (32 - n); }
@@ -1270,8 +1292,7 @@ __global__ __launch_bounds__(256) void homology_kernel(pav_indel *__restrict__ i
     pav_indel r = indel[active ? i : 0];
     const pav_aln al = aln[r.aln];
     const int rev = al.rev != 0;
-    const SeqRef ref{R.two, R.mask, R.dirty, R.off[al.ref_id], R.len[al.ref_id], 0};
-    const SeqRef tig{T.two, T.mask, T.dirty, T.off[al.tig_id], T.len[al.tig_id], rev};
+    const SeqRef ref = seq_ref(R, al.ref_id, 0), tig = seq_ref(T, al.tig_id, rev);
     const int64_t pos_ref = r.pos, pos_tig = r.qry_pos, oplen = r.svlen, tig_len = (int64_t)tig.len;
     const bool ins = r.svtype == 0;
     const SeqRef svs = ins ? tig : ref;                // seq = seq_tig[pos_tig:+oplen] / seq_ref[pos_ref:+oplen]
@@ -1346,8 +1367,7 @@ __global__ void homology_query_kernel(const pav_hom_query *__restrict__ q, uint3
     const pav_hom_query h = q[i];
     const SeqView &a = h.role == PAV_ROLE_REF ? R : T;
     const SeqView &b = h.sv_role == PAV_ROLE_REF ? R : T;
-    const SeqRef t{a.two, a.mask, a.dirty, a.off[h.seq_id], a.len[h.seq_id], h.rev != 0};
-    const SeqRef sv{b.two, b.mask, b.dirty, b.off[h.sv_seq_id], b.len[h.sv_seq_id], h.sv_rev != 0};
+    const SeqRef t = seq_ref(a, (uint32_t)h.seq_id, h.rev != 0), sv = seq_ref(b, (uint32_t)h.sv_seq_id, h.sv_rev != 0);
     out[i] = h.dir == 0 ? left_hom(t, h.pos, sv, h.sv_pos, h.svlen) : right_hom(t, h.pos, sv, h.sv_pos, h.svlen);
 }
 
@@ -1600,7 +1620,7 @@ int pav_cigar_verify(pav_ctx *ctx, pav_verify_counts *out) {
     unsigned long long *d_cnt = ctx->d_tmp.as<unsigned long long>();
     PAV_HIP(ctx, hipMemsetAsync(d_cnt, 0, 32, ctx->stream));
     PAV_HIP(ctx, hipMemsetAsync(d_cnt + 4, 0xFF, 8, ctx->stream));
-    { int rcw = wait_planes(ctx); if (rcw != PAV_OK) return rcw; }
+    { int rcw = need_planes_full(ctx, PAV_ROLE_TIG); if (rcw != PAV_OK) return rcw; }   // verify streams both arenas: the contig planes are packed here if they are not
     VerifyArgs A;
     A.ops = ctx->d_ops.as<uint32_t>(); A.n_ops = n_ops;
     A.op_off = ctx->d_op_off.as<uint64_t>(); A.aln = ctx->d_aln.as<pav_aln>(); A.n_aln = ctx->n_aln;

@@ -36,6 +36,18 @@ struct DevBuf {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// Four ASCII bases (one dword) -> 8 bits of 2-bit codes (base 0 lowest) and 4 non-ACGT bits.
+__device__ __forceinline__ void pack4(uint32_t x, uint32_t &codes8, uint32_t &bad4) {
+    const uint32_t t = ((x >> 1) ^ (x >> 2)) & 0x03030303u;          // A0 C1 G2 T3, either case
+    uint32_t c = t | (t >> 6);
+    codes8 = (c | (c >> 12)) & 0xFFu;
+    const uint32_t lo = t & 0x01010101u, hi = (t >> 1) & 0x01010101u, both = lo & hi;
+    const uint32_t expect = 0x41414141u + lo * 2u + hi * 6u + both * 11u;   // 'A','C','G','T' for the code
+    const uint32_t d = (x & 0xDFDFDFDFu) ^ expect;                    // non-zero byte <=> not ACGT/acgt
+    uint32_t nz = ((((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u) >> 7;
+    bad4 = (nz | (nz >> 7) | (nz >> 14) | (nz >> 21)) & 0xFu;
+}
+
 // ---- sequence store (one per role) ------------------------------------------------------------------------
 struct SeqView {                          // passed by value to kernels
     const uint8_t *ascii;                 // arena bytes
@@ -45,7 +57,8 @@ struct SeqView {                          // passed by value to kernels
     const uint64_t *off;                  // per record: first base in the arena (multiple of SEQ_ALIGN)
     const uint64_t *len;                  // per record: length
     uint32_t n;
-};
+    uint32_t packed;                      // 1: the three planes hold the whole arena; 0: only the spans packed on demand
+};                                        //    (contigs, pav_seq_pack / pav_seq_load) - scattered readers then decode the ASCII
 
 struct SeqStore {
     uint32_t n = 0;
@@ -54,11 +67,12 @@ struct SeqStore {
     std::vector<uint64_t> off, len;
     DevBuf d_ascii, d_two, d_mask, d_dirty, d_off, d_len;
     int device = -1;                      // where the planes live (shared stores: all users sit on this device)
+    bool planes_full = false;             // pack_kernel has run over the whole arena since the ASCII last changed
     SeqView view() const {
         return SeqView{d_ascii.as<uint8_t>(), d_two.as<uint32_t>(), d_mask.as<uint32_t>(), d_dirty.as<uint8_t>(),
-                       d_off.as<uint64_t>(), d_len.as<uint64_t>(), n};
+                       d_off.as<uint64_t>(), d_len.as<uint64_t>(), n, planes_full ? 1u : 0u};
     }
-    void release() { for (DevBuf *b : {&d_ascii, &d_two, &d_mask, &d_dirty, &d_off, &d_len}) b->release(); n = 0; arena = total = 0; }
+    void release() { for (DevBuf *b : {&d_ascii, &d_two, &d_mask, &d_dirty, &d_off, &d_len}) b->release(); n = 0; arena = total = 0; planes_full = false; }
     SeqStore() = default;
     SeqStore(const SeqStore &) = delete;
     SeqStore &operator=(const SeqStore &) = delete;
@@ -108,6 +122,9 @@ struct pav_ctx {
     uint64_t *h_status = nullptr;         // pinned host words for the small device-to-host readbacks of pav_cigar_call
     pav::DevBuf d_aln, d_text, d_text_off, d_ops, d_op_off, d_chunk, d_chunk2, d_rowbase, d_totals;
     pav::DevBuf d_snv, d_indel, d_seqblob, d_tmp;
+    double kde_work[3] = {0, 0, 0};       // pav_kde_work: evaluation points, (point, run) pairs, (point, data point) pairs
+    pav::DevBuf d_spans;                  // need_planes_spans: block runs of the spans being packed
+    std::vector<uint8_t> span_host;       // ... and their host copy (alive until the upload has run)
     pav::DevBuf ix_text, ix_off, ix_pos, ix_ops, ix_op_off, ix_chunk, ix_chunk2, ix_rowbase, ix_begin, ix_err;   // pav_align_index
     uint64_t n_ops = 0;
     uint64_t ix_n_ops = 0; uint32_t ix_n_aln = 0;
@@ -144,6 +161,12 @@ int prof_begin(pav_ctx *ctx, const char *name, hipStream_t st = nullptr);
 void prof_end(pav_ctx *ctx, int token, hipStream_t st = nullptr);
 int wait_tables(pav_ctx *ctx);            // host waits until every queued call-table copy has landed
 int wait_planes(pav_ctx *ctx);            // make ctx->stream wait for any pack still running on stream2
+// Contig planes are packed on demand (ctx.hip "lazy contig pack"): a consumer that streams the whole arena calls
+// need_planes_full, one that reads spans [abs, abs + len) calls need_planes_spans; both order the pack before what the caller
+// launches next on ctx->stream.  The reference store is always packed in full.
+int need_planes_full(pav_ctx *ctx, int role);
+struct PlaneSpan { uint64_t abs, len; };
+int need_planes_spans(pav_ctx *ctx, int role, const std::vector<PlaneSpan> &spans);
 int prof_flush(pav_ctx *ctx);
 
 #define PAV_LAUNCH_ON(ctx, st, name, kernel, grid, block, shmem, ...)                               \

@@ -1,6 +1,7 @@
 // Context, sequence store (ASCII arena -> 2-bit + non-ACGT planes) and HIP-event profiling.
 // gfx950 only; public ABI in include/pav_amd.h.
 #include "common.h"
+#include <algorithm>
 
 namespace pav {
 
@@ -78,17 +79,6 @@ int prof_flush(pav_ctx *ctx) {
 // One lane packs 16 bases (one 16-byte load): a u32 of 2-bit codes and 16 non-ACGT bits; lane pairs merge
 // their halves of the 32-base mask word with one cross-lane move.  Pure streaming: 1 B/base in,
 // 0.25 + 0.125 B/base out; HBM-bound.
-__device__ __forceinline__ void pack4(uint32_t x, uint32_t &codes8, uint32_t &bad4) {
-    const uint32_t t = ((x >> 1) ^ (x >> 2)) & 0x03030303u;          // A0 C1 G2 T3, either case
-    uint32_t c = t | (t >> 6);
-    codes8 = (c | (c >> 12)) & 0xFFu;
-    const uint32_t lo = t & 0x01010101u, hi = (t >> 1) & 0x01010101u, both = lo & hi;
-    const uint32_t expect = 0x41414141u + lo * 2u + hi * 6u + both * 11u;   // 'A','C','G','T' for the code
-    const uint32_t d = (x & 0xDFDFDFDFu) ^ expect;                    // non-zero byte <=> not ACGT/acgt
-    uint32_t nz = ((((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u) >> 7;
-    bad4 = (nz | (nz >> 7) | (nz >> 14) | (nz >> 21)) & 0xFu;
-}
-
 // Tuned on MI355X (tools/ubench/pack_variants.hip): four independent 16-byte loads in flight per lane, non-temporal
 // loads and stores (every byte is touched once), one 16 KiB tile per workgroup with an exact grid (a capped
 // grid-stride launch was 20 % slower): 6.0 TB/s of algorithmic traffic vs 4.5 TB/s for the first version.
@@ -125,12 +115,90 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint4 *__restrict__ asc
 }
 
 static int run_pack(pav_ctx *ctx, SeqStore &s, hipStream_t st) {
+    s.planes_full = true;
     if (s.arena == 0) return PAV_OK;
     const uint64_t n16 = s.arena / 16;
     const uint64_t blocks = (n16 + 256 * PACK_U - 1) / (256 * PACK_U);
     PAV_LAUNCH_ON(ctx, st, "pack_kernel", pack_kernel, (uint32_t)blocks, 256, 0, s.d_ascii.as<uint4>(),
                   s.d_two.as<uint32_t>(), s.d_mask.as<uint32_t>(), s.d_dirty.as<uint8_t>(), n16);
     return PAV_OK;
+}
+
+// ---- lazy contig pack -------------------------------------------------------------------------------------
+// The contig planes have three readers: the breakpoint-homology scans (windows of <= 32 bases at ~0.6 M scattered places),
+// the k-mer scans of the flagged regions (a few % of the contigs) and verify mode (everything).  Packing the whole arena for
+// them was the largest kernel of a pass (4.2 of the ~5.7 GB it moved).  So pav_seq_load / pav_seq_pack of the contig role
+// only mark the planes stale; the homology scans decode their windows from the ASCII arena (cigar.hip fetch_run), the k-mer
+// scans pack the 1024-base blocks of their regions first (pack_spans_kernel: the body of pack_kernel, one wave per block),
+// verify mode packs everything.  PAV_EAGER_PACK=1 restores the full pack at load time (A/B measurements, tests).
+// The reference is packed once, in full, when it is loaded.
+struct SpanDev { uint32_t first_block, pre; };                          // 1024-base blocks of a span; blocks of the spans before it
+
+__global__ __launch_bounds__(256) void pack_spans_kernel(const uint4 *__restrict__ ascii, uint32_t *__restrict__ two,
+                                                         uint32_t *__restrict__ mask, uint8_t *__restrict__ dirty,
+                                                         const SpanDev *__restrict__ spans, uint32_t n_spans, uint32_t n_blocks,
+                                                         uint64_t n16) {
+    const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);              // one wave, one block of 1024 bases
+    if (w >= n_blocks) return;
+    uint32_t lo = 0, hi = n_spans;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (spans[mid].pre <= w) lo = mid; else hi = mid; }
+    const uint64_t blk = (uint64_t)spans[lo].first_block + (w - spans[lo].pre);
+    const uint64_t i = blk * 64 + (threadIdx.x & 63);                    // the lane's 16 bases
+    u32x4 v = u32x4{0x4e4e4e4eu, 0x4e4e4e4eu, 0x4e4e4e4eu, 0x4e4e4e4eu};   // past the arena (its last block may be partial): 'N'
+    if (i < n16) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(ascii) + i);
+    uint32_t c0, c1, c2, c3, b0, b1, b2, b3;
+    pack4(v.x, c0, b0); pack4(v.y, c1, b1); pack4(v.z, c2, b2); pack4(v.w, c3, b3);
+    const uint32_t m16 = b0 | (b1 << 4) | (b2 << 8) | (b3 << 12);
+    const uint32_t other = __shfl_xor(m16, 1);                           // n16 is even: the partner always exists
+    const unsigned long long any_bad = __ballot(m16 != 0);
+    if ((threadIdx.x & 63) == 0) dirty[blk] = any_bad != 0;
+    if (i < n16) {
+        two[i] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+        if ((threadIdx.x & 1) == 0) mask[i >> 1] = m16 | (other << 16);
+    }
+}
+
+static bool eager_pack() { const char *e = getenv("PAV_EAGER_PACK"); return e && *e == '1'; }   // read per load / pack call
+
+int need_planes_full(pav_ctx *ctx, int role) {
+    SeqStore &s = ctx->seq[role];
+    if (!s.planes_full) { const int rc = run_pack(ctx, s, ctx->stream); if (rc != PAV_OK) return rc; }
+    return wait_planes(ctx);
+}
+
+int need_planes_spans(pav_ctx *ctx, int role, const std::vector<PlaneSpan> &spans) {
+    SeqStore &s = ctx->seq[role];
+    if (s.planes_full || s.arena == 0) return wait_planes(ctx);
+    // spans -> runs of 1024-base blocks (pack_kernel's tile per wave; the arena is a multiple of 256 bases, its planes and
+    // the ASCII buffer are allocated in whole pack tiles of 16384)
+    const uint64_t arena_blocks = (s.arena + 1023) >> DIRTY_SHIFT;
+    std::vector<std::pair<uint64_t, uint64_t>> runs;                     // [first block, last block]
+    runs.reserve(spans.size());
+    for (const PlaneSpan &sp : spans) {
+        if (sp.len == 0 || (sp.abs >> DIRTY_SHIFT) >= arena_blocks) continue;
+        const uint64_t b1 = (sp.abs + sp.len - 1) >> DIRTY_SHIFT;
+        runs.emplace_back(sp.abs >> DIRTY_SHIFT, b1 < arena_blocks ? b1 : arena_blocks - 1);
+    }
+    std::sort(runs.begin(), runs.end());
+    std::vector<SpanDev> sd;
+    uint64_t total = 0;
+    for (size_t i = 0; i < runs.size();) {                               // overlapping / adjacent runs become one
+        uint64_t b0 = runs[i].first, b1 = runs[i].second;
+        for (++i; i < runs.size() && runs[i].first <= b1 + 1; ++i) b1 = runs[i].second > b1 ? runs[i].second : b1;
+        sd.push_back(SpanDev{(uint32_t)b0, (uint32_t)total});
+        total += b1 - b0 + 1;
+    }
+    if (total == 0) return wait_planes(ctx);
+    if (total >= 0xFFFFFFFFull) return need_planes_full(ctx, role);
+    // more than a third of the arena asked for: the streaming kernel is cheaper than scattered blocks
+    if (3 * total > arena_blocks) return need_planes_full(ctx, role);
+    ctx->span_host.assign(reinterpret_cast<const uint8_t *>(sd.data()), reinterpret_cast<const uint8_t *>(sd.data()) + sizeof(SpanDev) * sd.size());
+    PAV_HIP(ctx, ctx->d_spans.reserve(sizeof(SpanDev) * sd.size()));
+    PAV_HIP(ctx, hipMemcpyAsync(ctx->d_spans.p, ctx->span_host.data(), sizeof(SpanDev) * sd.size(), hipMemcpyHostToDevice, ctx->stream));
+    PAV_LAUNCH(ctx, "pack_spans_kernel", pack_spans_kernel, (uint32_t)((total + 3) / 4), 256, 0, s.d_ascii.as<uint4>(),
+               s.d_two.as<uint32_t>(), s.d_mask.as<uint32_t>(), s.d_dirty.as<uint8_t>(), ctx->d_spans.as<SpanDev>(),
+               (uint32_t)sd.size(), (uint32_t)total, s.arena / 16);
+    return wait_planes(ctx);
 }
 
 }  // namespace pav
@@ -320,7 +388,9 @@ int pav_seq_load(pav_ctx *ctx, int role, uint32_t n_seq, const uint8_t *const *a
     PAV_HIP(ctx, hipMemcpyAsync(s.d_len.p, len, sizeof(uint64_t) * n_seq, hipMemcpyHostToDevice, ctx->stream));
     s.n = n_seq; s.arena = a; s.total = total;                               // run_pack reads the layout from the store
     s.off = off; s.len.assign(len, len + n_seq);
-    int rc = run_pack(ctx, s, ctx->stream);
+    // contigs: planes on demand ("lazy contig pack" above); the reference is packed now
+    s.planes_full = false;
+    int rc = (role == PAV_ROLE_REF || eager_pack()) ? run_pack(ctx, s, ctx->stream) : PAV_OK;
     if (rc == PAV_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)     // inputs are borrowed only for the duration of the call
         rc = fail(ctx, PAV_E_HIP, "pav_seq_load: upload / pack failed");
     if (rc != PAV_OK) { s.n = 0; s.arena = s.total = 0; s.off.clear(); s.len.clear(); return rc; }
@@ -337,6 +407,13 @@ int pav_seq_share(pav_ctx *ctx, const pav_ctx *from, int role) {
     ctx->pack_pending[role] = false;
     ctx->cigar_loaded = ctx->cigar_called = false;
     ctx->seq.p[role] = from->seq.p[role];
+    // a shared store is read from several streams: its planes are made whole here, once, and stay so (pav_seq_pack
+    // re-packs a shared store in full; the lazy contig pack is for stores with one user)
+    if (!ctx->seq[role].planes_full) {
+        const int rc = run_pack(ctx, ctx->seq[role], ctx->stream);
+        if (rc != PAV_OK) return rc;
+        PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return PAV_OK;
 }
 
@@ -345,6 +422,10 @@ int pav_seq_pack(pav_ctx *ctx, int role) {
     PAV_HIP(ctx, hipSetDevice(ctx->device));
     // Asynchronous on the side stream: everything queued so far on the main stream may still read the old planes, so
     // the pack first waits for the main stream; consumers of the planes wait for pack_done (pav::wait_planes).
+    if (role == PAV_ROLE_TIG && !eager_pack() && ctx->seq.p[role].use_count() == 1) {
+        ctx->seq[role].planes_full = false;           // readers pack what they need (need_planes_full / need_planes_spans)
+        return PAV_OK;
+    }
     hipEvent_t *ev = &ctx->pack_done[role];
     PAV_HIP(ctx, hipEventRecord(*ev, ctx->stream));
     PAV_HIP(ctx, hipStreamWaitEvent(ctx->stream2, *ev, 0));
@@ -362,6 +443,12 @@ int pav_mem_info(pav_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes) {
     PAV_HIP(ctx, hipMemGetInfo(&f, &t));
     if (free_bytes) *free_bytes = f;
     if (total_bytes) *total_bytes = t;
+    return PAV_OK;
+}
+
+int pav_kde_work(const pav_ctx *ctx, double out[3]) {
+    if (!ctx || !out) return PAV_E_ARG;
+    for (int i = 0; i < 3; ++i) out[i] = ctx->kde_work[i];
     return PAV_OK;
 }
 

@@ -1609,7 +1609,16 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     const SeqView RV = RS.view(), TV = TS.view();
 
     // ---- k-mer states and compaction -------------------------------------------------------------------------
-    { int rcw = wait_planes(ctx); if (rcw != PAV_OK) return rcw; }
+    {   // the contig planes are packed on demand (ctx.hip "lazy contig pack"): the blocks under the regions of this batch, plus
+        // what the 64-base windows of the scans read past a region's end
+        std::vector<PlaneSpan> spans;
+        if (!TS.planes_full) {
+            spans.reserve(n_jobs);
+            for (uint32_t j = 0; j < n_jobs; ++j) spans.push_back(PlaneSpan{D->h_jobs[j].tig_abs, (uint64_t)D->h_jobs[j].tig_len + 128});
+        }
+        const int rcw = need_planes_spans(ctx, PAV_ROLE_TIG, spans);
+        if (rcw != PAV_OK) return rcw;
+    }
     if (!items.empty()) {
         PAV_LAUNCH(ctx, "k_bucket_ref", k_bucket_ref, n_tiles_r, 256, 0, d_jobs, d_tjr, RV, k, D->lists.as<uint32_t>(),
                    D->bcount.as<uint32_t>(), d_stat);
@@ -1994,16 +2003,18 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
                 D->results[j].n_eval = (uint64_t)D->h_kde[j].n_samp + hs[j].fill_n;
                 for (uint32_t f = 0; f < hs[j].fill_n; f += 64) ftiles.push_back(EvalTile{j, f, std::min<uint32_t>(64, hs[j].fill_n - f), 1});
             }
-            if (timing && pass == 0) {
-                double pairs = 0, points = 0, big = 0;
+            if (pass == 0) {                                             // work counters (pav_kde_work)
+                double pairs = 0, points = 0, big = 0, data_pairs = 0;
                 for (uint32_t j = 0; j < n_jobs; ++j) {
                     const JobKde &kd = D->h_kde[j];
                     if (!kd.finalised) continue;
                     const double pts = (double)kd.n_samp + hs[j].fill_n, runs = (double)kd.n_run[0] + kd.n_run[1] + kd.n_run[2];
                     points += pts; pairs += pts * runs;
+                    data_pairs += pts * ((double)hs[j].m[0] + hs[j].m[1] + hs[j].m[2]);
                     if (runs > 256) big += pts * runs;
                 }
-                fprintf(stderr, "[pav timing]   kde work: %.3g evaluation points, %.3g (point, run) pairs (%.1f runs per point; %.0f %% of the pairs in jobs with > 256 runs)\n",
+                ctx->kde_work[0] += points; ctx->kde_work[1] += pairs; ctx->kde_work[2] += data_pairs;
+                if (timing) fprintf(stderr, "[pav timing]   kde work: %.3g evaluation points, %.3g (point, run) pairs (%.1f runs per point; %.0f %% of the pairs in jobs with > 256 runs)\n",
                         points, pairs, points ? pairs / points : 0.0, pairs ? 100.0 * big / pairs : 0.0);
             }
             if (!ftiles.empty()) {

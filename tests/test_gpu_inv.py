@@ -571,6 +571,57 @@ def test_guard_on_everything_equals_direct_mode(built, gpu_ctx, cap):
     assert n_ok >= 4
 
 
+def test_contig_planes_on_demand_equal_the_full_pack(built, gpu_ctx, monkeypatch):
+    """Lazy contig pack (ctx.hip): with the contig planes packed on demand - homology windows decoded from the ASCII arena, the
+    blocks under the scanned regions packed per batch, everything packed for verify mode - the SNV / indel records (homology
+    columns included), the flagged loci, the scan log, the calls and their density tables, and the verify counters are the ones
+    the full pack at load time gives (PAV_EAGER_PACK=1).  The contigs carry N runs and lower case, half of the rows are reverse."""
+    hap = synth.config2(seed=919, scale=0.01, threads=4, pair_frac=0.01)
+    names = hap.ref.names
+    k_util = KmerUtil(31)
+    rng = np.random.default_rng(4)
+    tig_seqs = {n: a.copy() for n, a in hap.tig_seqs.items()}
+    for n in hap.tig_names[:6]:                                # N runs inside the contigs: next to and inside homology windows
+        a = tig_seqs[n]
+        for s0 in rng.integers(0, max(1, a.shape[0] - 50), 20):
+            a[int(s0):int(s0) + int(rng.integers(1, 40))] = ord('N')
+    from pav_amd import cigarcall
+
+    def run(eager):
+        monkeypatch.setenv('PAV_EAGER_PACK', '1' if eager else '0')
+        gpu_ctx._inv_loaded = None
+        gpu_ctx.seq_load(_lib.PAV_ROLE_REF, names, [hap.ref.seqs[n] for n in names])
+        gpu_ctx.seq_load(_lib.PAV_ROLE_TIG, hap.tig_names, [tig_seqs[n] for n in hap.tig_names])
+        aln, text, off = cigarcall.pack_alignments(hap.df_align, names, hap.tig_names)
+        gpu_ctx.cigar_load(aln, text, off)
+        gpu_ctx._inv_loaded = ('ref.fa', 'tig.fa')
+        out = []
+        for rep in range(2):                                  # second pass: after pav_seq_pack (planes stale again / re-packed)
+            if rep:
+                gpu_ctx.seq_pack(_lib.PAV_ROLE_TIG)
+            counts = gpu_ctx.cigar_call()
+            snv, indel, blob = gpu_ctx.cigar_fetch(counts)
+            index = hap.df_align['INDEX'].to_numpy(dtype='int64')
+            trim = hap.df_trim[['POS', 'END', 'INDEX']].set_index('INDEX').astype(int).reindex(list(index), fill_value=-1)
+            _, loci, _ = gpu_ctx.cigar_flag(trim['POS'].to_numpy(dtype='int64'), trim['END'].to_numpy(dtype='int64'),
+                                            gpu_ctx.flag_params(sig_filter=_lib.SIG_SINGLE_CLUSTER))
+            regions = pavinv.loci_regions(gpu_ctx, loci)
+            log, found = io.StringIO(), io.StringIO()
+            calls = pavinv.scan_for_inv_batch(regions, 'ref.fa', 'tig.fa', AlignLift(hap.df_trim, hap.tig_lengths), k_util, log=log,
+                                              ctx=gpu_ctx, eager_tables=False, found_out=found)
+            tables = {c.id: sha(np.concatenate([c.df[k].to_numpy().astype(np.float64) for k in ('INDEX', 'STATE', 'KERN_FWD', 'KERN_REV')]))
+                      for c in calls if c is not None and not isinstance(c, RuntimeError)}
+            out.append((sha(snv.tobytes()), sha(indel.tobytes()), sha(bytes(blob)), loci.tobytes(), log.getvalue(), found.getvalue(), tables))
+        out.append(gpu_ctx.cigar_verify())
+        return out, len(regions)
+
+    lazy, n_regions = run(False)
+    eager, _ = run(True)
+    assert n_regions >= 10 and len(lazy[0][6]) >= 1
+    assert lazy[0] == lazy[1] and eager[0] == eager[1]
+    assert lazy == eager
+
+
 def test_concurrent_haplotype_lanes_equal_sequential_runs(built, gpu_ctx):
     """bench.py's lanes in small: four haplotypes resident at once - one context each, sharing the reference planes - run
     the whole chain (CIGAR-call -> flagging -> scan of the flagged loci with lazy tables) from four host threads at the same
