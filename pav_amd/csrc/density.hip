@@ -826,14 +826,26 @@ __device__ __forceinline__ double kde_state(const double *__restrict__ ps, uint3
 //   + (f(a) + f(b)) / 2 + (f1(b) - f1(a)) / 12 - (f3(b) - f3(a)) / 720 + (f5(b) - f5(a)) / 30240,
 // where fm is the m-th derivative: fm(t) = (-1)^m He_m(u) f / h^m, u = (t - x)/h.  The next term is below
 // 27 / (1.2e6 h^7): < 1e-15 for h >= 32.
-__device__ __forceinline__ double run_sum_em(double ua, double ub, double h, double inv_h) {
+__device__ __forceinline__ double run_sum_em(double ua, double ub, double h, double inv_h, bool more) {
     const double fa = exp(-(ua * ua) / 2), fb = exp(-(ub * ub) / 2);
     const double s = 0.70710678118654752440;
     double integ;
-    if (ua >= 0.0) integ = erfc(ua * s) - erfc(ub * s);
-    else if (ub <= 0.0) integ = erfc(-ub * s) - erfc(-ua * s);
-    else integ = erf(ub * s) - erf(ua * s);
-    integ *= h * 1.25331413731550025121;                               // sqrt(pi / 2)
+    const double wd = ub - ua, u_near = fmax(1.0, ua >= 0.0 ? ua : (ub <= 0.0 ? -ub : 0.0));
+    if (wd * u_near < 0.0625) {
+        // A run much shorter than the bandwidth: the erfc difference cancels - relative error ~ eps / (wd max(1, |u|)) - while a
+        // four-point Gauss-Legendre rule has relative error 5.6e-10 wd^8 max(105, u^8) < 1e-17 under the same condition
+        // (f^(8) = He_8(u) f).  Such runs used to be summed term by term, up to h / 16 exp each: the longest tiles of a launch.
+        const double c = 0.5 * (ua + ub), r = 0.5 * wd;
+        const double x1 = r * 0.33998104358485626480, x2 = r * 0.86113631159405257522;
+        const double g1 = exp(-((c - x1) * (c - x1)) / 2) + exp(-((c + x1) * (c + x1)) / 2);
+        const double g2 = exp(-((c - x2) * (c - x2)) / 2) + exp(-((c + x2) * (c + x2)) / 2);
+        integ = r * (0.65214515486254614263 * g1 + 0.34785484513745385737 * g2) * h;
+    } else {
+        if (ua >= 0.0) integ = erfc(ua * s) - erfc(ub * s);
+        else if (ub <= 0.0) integ = erfc(-ub * s) - erfc(-ua * s);
+        else integ = erf(ub * s) - erf(ua * s);
+        integ *= h * 1.25331413731550025121;                           // sqrt(pi / 2)
+    }
     const double ua2 = ua * ua, ub2 = ub * ub;
     const double h3a = ua * (ua2 - 3.0), h3b = ub * (ub2 - 3.0);
     const double h5a = ua * (ua2 * (ua2 - 10.0) + 15.0), h5b = ub * (ub2 * (ub2 - 10.0) + 15.0);
@@ -841,7 +853,25 @@ __device__ __forceinline__ double run_sum_em(double ua, double ub, double h, dou
     const double d1 = (ua * fa - ub * fb) * inv_h;                     // f1(b) - f1(a)
     const double d3 = (h3a * fa - h3b * fb) * inv_h * ih2;             // f3(b) - f3(a)
     const double d5 = (h5a * fa - h5b * fb) * inv_h * ih2 * ih2;       // f5(b) - f5(a)
-    return integ + 0.5 * (fa + fb) + d1 / 12.0 - d3 / 720.0 + d5 / 30240.0;
+    double sum = integ + 0.5 * (fa + fb) + d1 / 12.0 - d3 / 720.0 + d5 / 30240.0;
+    if (more) {
+        // On a flank of the kernel consecutive terms fall by e^(-a) per element, a = |u| / h, and the series converges like
+        // (a / 2 pi)^(2k): the terms up to f5 reach 1e-15 for a < 0.08 only.  B8 .. B14 (f7 .. f13, Hermite recurrence) carry it
+        // to a = 0.65 - relative remainder 2 (a / 2 pi)^16 < 4e-16 - which covers every flank for h >= 60.
+        double pa = h5a, pb = h5b, qa = ua2 * (ua2 - 6.0) + 3.0, qb = ub2 * (ub2 - 6.0) + 3.0;   // He_5, He_4
+        double ihm = inv_h * ih2 * ih2;                                                          // h^-5
+        const double c[4] = {-1.0 / 1209600.0, 1.0 / 47900160.0, -691.0 / 1307674368000.0, 1.0 / 74724249600.0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int m = 5 + 2 * k;                                   // He_m, He_(m-1) -> He_(m+2), He_(m+1)
+            const double ea = ua * pa - (double)m * qa, eb = ub * pb - (double)m * qb;               // He_(m+1)
+            const double oa = ua * ea - (double)(m + 1) * pa, ob = ub * eb - (double)(m + 1) * pb;   // He_(m+2)
+            pa = oa; pb = ob; qa = ea; qb = eb;
+            ihm *= ih2;
+            sum += c[k] * ((pa * fa - pb * fb) * ihm);
+        }
+    }
+    return sum;
 }
 
 // Tail of a run seen from far away with a narrow kernel: consecutive terms fall by exp(-u/h) per step, so the sum is
@@ -864,8 +894,8 @@ __device__ __forceinline__ double run_sum_tail(uint32_t first, int step, uint32_
 // Partial sum over the runs first, first + stride, ...: the waves of a workgroup share the runs of an evaluation point.
 __device__ __forceinline__ double kde_state_runs(const RunDev *__restrict__ runs, uint32_t n_run, uint32_t first, uint32_t stride,
                                                  uint32_t xi, double h, double inv_h) {
-    const double short_len = fmax(16.0, h * 0.0625);                  // short runs: direct terms (also bounds the
-    const double x = (double)xi, xs = x * inv_h;                       // cancellation in the erfc difference)
+    const double short_len = 16.0;                                     // short runs: direct terms
+    const double x = (double)xi, xs = x * inv_h;
     double sum = 0.0;
     for (uint32_t r = first; r < n_run; r += stride) {
         const RunDev rn = runs[r];
@@ -875,10 +905,10 @@ __device__ __forceinline__ double kde_state_runs(const RunDev *__restrict__ runs
                                                                        // the run is zero in scipy's sum as well
         if ((double)(rn.b - rn.a) < short_len) {
             for (uint32_t i = rn.a; i <= rn.b; ++i) { const double u = (double)i * inv_h - xs; sum += exp(-(u * u) / 2); }
-        } else if (near * inv_h * inv_h > 0.1) {                       // u/h > 0.1: steep tail
+        } else if (near * inv_h * inv_h > 0.65) {                      // |u| / h > 0.65: steep flank of a narrow kernel (h < 60)
             sum += da >= 0.0 ? run_sum_tail(rn.a, 1, rn.b - rn.a + 1, inv_h, xs) : run_sum_tail(rn.b, -1, rn.b - rn.a + 1, inv_h, xs);
         } else {
-            sum += run_sum_em(fma((double)rn.a, inv_h, -xs), fma((double)rn.b, inv_h, -xs), h, inv_h);
+            sum += run_sum_em(fma((double)rn.a, inv_h, -xs), fma((double)rn.b, inv_h, -xs), h, inv_h, near * inv_h * inv_h > 0.05);
         }
     }
     return sum;
