@@ -52,8 +52,8 @@ def _free_port():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=4)
+    ap.add_argument('--steps', type=int, default=64)
+    ap.add_argument('--warmup', type=int, default=8)
     ap.add_argument('--scale', type=float, default=1.0, help='shrink every sequence length (tests only; 1.0 = the named workload)')
     ap.add_argument('--seed', type=int, default=1002)
     ap.add_argument('--cpu-sample-bp', type=float, default=4e9,
@@ -519,6 +519,13 @@ def main():
                         'point_data_pairs_per_launch': kde[2] / kern_[dom]['launches'],
                         'executed': {'tflops': round(ex, 2), 'frac': round(ex / FP64_VECTOR_PEAK_TFLOPS, 4),
                                      'model': '150 flop per (point, run) pair'}}
+            if dom == 'walk_snv' and kern_[dom]['avg_ms'] > 0:
+                # one byte of each ASCII arena per SNV row, ~470 bases apart: every byte costs a 32 B sector of its own.  The rate at
+                # which HBM delivers isolated sectors was measured with nothing else in the kernel (tools/ubench/gather_rate.hip)
+                gs = 2.0 * n_snv / (kern_[dom]['avg_ms'] * 1e-3) / 1e9
+                head['isolated_sectors'] = {'per_launch': 2 * int(n_snv), 'achieved_gsectors_per_s': round(gs, 1),
+                                            'measured_peak_gsectors_per_s': 39.7, 'source': 'profiles/r02_gather_rate.txt',
+                                            'frac': round(gs / 39.7, 3)}
             head.update({'avg_kernel_ms': round(kern_[dom]['avg_ms'], 4), 'launches_per_step': round(kern_[dom]['launches'] / args.steps, 2)})
             return kern_, {**head,
                            'kernels_ms': {k: round(v['avg_ms'], 4) for k, v in sorted(kern_.items())},

@@ -574,9 +574,10 @@ __device__ __forceinline__ int popc128(u128 x) { return __popcll((uint64_t)x) + 
 // Positions are arena offsets in bases.  Arenas below 2^32 bases (a human genome is 3.1 G) run the kernel on 32-bit
 // positions: half the descriptor bytes in LDS, and every address is a scalar base + a 32-bit lane offset (one VALU op
 // instead of 64-bit shifts and adds).  WIDE keeps the high words beside them.
-// Where the time goes (bench haplotype, 0.30 ms, SQ counters in DESIGN.md section 5): 111 M vector instructions = 0.18 ms of
-// issue on 1024 SIMDs, 1.63 GB of HBM = 0.25 ms at the streaming rate of pack_kernel; the two overlap to 0.30 ms.  With the
-// loads of the loop compiled out the kernel still takes 0.255 ms, with the loop compiled out 0.07 ms (the scan + descriptors).
+// Where the time goes (bench haplotype, 0.30 ms, SQ counters in DESIGN.md section 5): 111 M vector instructions = 0.09 ms of
+// issue on 1024 SIMD-32, 1.63 GB of HBM = 0.25 ms at the streaming rate of pack_kernel.  With the loads of the loop compiled out
+// the kernel still takes 0.255 ms, with the loop compiled out 0.07 ms (the scan + descriptors): a step is a dependent chain
+// (LDS, ballot, LDS, loads, LDS, compare) and four waves per SIMD take turns on it.
 // Tried and dropped: 5 waves / SIMD via amdgpu_waves_per_eu (96 VGPRs: +5 %), one unaligned 2-byte load of the dirty pair
 // (+5 %), non-temporal window loads (no change), one or four pieces per lane and step, one workgroup per chunk (no change).
 template <bool WIDE> struct VPos { typedef uint32_t type; };
