@@ -60,6 +60,10 @@ int pav_kde_work(const pav_ctx *ctx, double out[3]);
  * uploaded as ASCII (kept in HBM for case-exact REF/ALT/SEQ output) and packed on the device into a 2-bit
  * plane (A0 C1 G2 T3, case folded) plus a 1-bit non-ACGT plane: the "upper-case view" the reference builds
  * with str.upper().  Reverse-complemented contigs are never materialised; kernels index them in place.
+ * The reference (PAV_ROLE_REF) is packed in full by this call.  The contig planes (PAV_ROLE_TIG) are filled on demand:
+ * the breakpoint-homology scans of pav_cigar_call / pav_homology decode their windows from the ASCII arena, a density
+ * batch packs the blocks under its regions first, pav_cigar_verify and pav_seq_share pack everything (identical results;
+ * the full pack is the largest kernel of a pass otherwise).  PAV_EAGER_PACK=1 in the environment packs contigs here too.
  */
 int pav_seq_load(pav_ctx *ctx, int role, uint32_t n_seq, const uint8_t *const *ascii, const uint64_t *len);
 /* Use the store `from` holds for `role` (no copy: both contexts read the same planes in HBM; they must be on the same GPU).
@@ -86,9 +90,11 @@ const uint8_t *pav_fasta_seq(const pav_fasta *fa, uint32_t record);     /* valid
 int pav_fasta_kind(const pav_fasta *fa);                                 /* 0 plain text, 1 gzip stream, 2 BGZF      */
 /* pav_seq_load + pav_seq_set_names of the chosen records, in the order given. */
 int pav_seq_load_fasta(pav_ctx *ctx, int role, const pav_fasta *fa, uint32_t n_records, const uint32_t *records);
-/* Re-run the pack kernel on the resident ASCII.  Asynchronous: it runs on a side stream and overlaps whatever the
- * next calls queue that does not read the packed planes (CIGAR tokenizer, walk, SNV emission); kernels that do read
- * them (homology, k-mer kernels) wait for it on the device.  pav_sync() waits for both streams. */
+/* The resident ASCII of `role` has changed (or a new haplotype's pass begins): its planes are stale.  PAV_ROLE_TIG with one
+ * user: marks them so - readers fill what they need (pav_seq_load above).  PAV_ROLE_REF, a shared store, or PAV_EAGER_PACK=1:
+ * re-runs the pack kernel over the whole arena, asynchronously on a side stream - it overlaps whatever the next calls queue
+ * that does not read the packed planes (CIGAR tokenizer, walk, SNV emission); kernels that do read them wait for it on the
+ * device.  pav_sync() waits for both streams. */
 int pav_seq_pack(pav_ctx *ctx, int role);
 int pav_seq_count(const pav_ctx *ctx, int role, uint32_t *n_seq, uint64_t *total_bases);
 
