@@ -77,28 +77,44 @@ __global__ __launch_bounds__(256) void k_cluster_emit(const uint64_t *__restrict
 
 // One atomic per workgroup for a per-thread partial count: thousands of waves adding to one word serialise at ~11 ns each
 // (k_indel_keys spent 0.18 of its 0.20 ms there with one atomic per wave).  All 256 threads of the block must call it.
-__device__ __forceinline__ void block_add(unsigned long long v, unsigned long long *counter) {
+__device__ __forceinline__ void block_add(unsigned long long v, unsigned long long *counter, uint32_t *block_total = nullptr) {
     __shared__ unsigned long long part[4];
     for (int o = WAVE / 2; o; o >>= 1) v += __shfl_down(v, o);
     __syncthreads();                                                    // `part` may still be read from a previous call
     if ((threadIdx.x & (WAVE - 1)) == 0) part[threadIdx.x / WAVE] = v;
     __syncthreads();
-    if (threadIdx.x == 0) { const unsigned long long t = part[0] + part[1] + part[2] + part[3]; if (t) atomicAdd(counter, t); }
+    if (threadIdx.x == 0) {
+        const unsigned long long t = part[0] + part[1] + part[2] + part[3];
+        if (t) atomicAdd(counter, t);
+        if (block_total) *block_total = (uint32_t)t;
+    }
 }
+
+// The key kernels work on tiles of KEY_TILE rows, KEY_PER per lane (all their loads issued before the first use): keys (sentinel = row filtered out) go to keys[], the number of real keys of the tile to tile_cnt[] - what the
+// compaction below needs.  (A grid-stride loop with one 16-byte load in flight per lane ran at a third of this rate, and
+// rocprim::select needed 0.09 ms for the 6.5 M SNV keys.)
+constexpr int KEY_PER = 8, KEY_TILE = 256 * KEY_PER;
 
 // cluster key of every SNV row: rank << 40 | POS (the midpoint of [POS, POS + 1) is POS).
 __global__ __launch_bounds__(256) void k_snv_keys(const pav_snv *__restrict__ snv, uint64_t n, const pav_aln *__restrict__ aln,
                                                   const uint16_t *__restrict__ rank, const long long *__restrict__ tpos,
                                                   const long long *__restrict__ tend, unsigned long long *__restrict__ keys,
-                                                  unsigned long long *__restrict__ n_pass, unsigned long long sentinel) {
+                                                  unsigned long long *__restrict__ n_pass, unsigned long long sentinel,
+                                                  uint32_t *__restrict__ tile_cnt) {
+    const uint64_t i0 = (uint64_t)blockIdx.x * KEY_TILE + threadIdx.x;     // rows i0, i0 + 256, ...: consecutive lanes, consecutive rows
+    pav_snv s[KEY_PER];
+#pragma unroll
+    for (int u = 0; u < KEY_PER; ++u) s[u] = snv[i0 + 256 * u < n ? i0 + 256 * u : n - 1];
     unsigned long long mine = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
-        const pav_snv s = snv[i];
-        const bool pass = (long long)s.pos > tpos[s.aln] && (long long)s.pos + 1 < tend[s.aln];
-        keys[i] = pass ? ((unsigned long long)rank[aln[s.aln].ref_id] << CM_SHIFT | s.pos) : sentinel;
+#pragma unroll
+    for (int u = 0; u < KEY_PER; ++u) {
+        const uint64_t i = i0 + 256 * u;
+        if (i >= n) break;
+        const bool pass = (long long)s[u].pos > tpos[s[u].aln] && (long long)s[u].pos + 1 < tend[s[u].aln];
+        keys[i] = pass ? ((unsigned long long)rank[aln[s[u].aln].ref_id] << CM_SHIFT | s[u].pos) : sentinel;
         mine += pass;
     }
-    block_add(mine, n_pass);
+    block_add(mine, n_pass, tile_cnt + blockIdx.x);
 }
 
 // cluster key of every indel row < 50 bp: rank << 38 | POS << 6 | (END - POS): the (#CHROM, POS, END) order of the table.
@@ -106,19 +122,87 @@ __global__ __launch_bounds__(256) void k_indel_keys(const pav_indel *__restrict_
                                                     const uint16_t *__restrict__ rank, const long long *__restrict__ tpos,
                                                     const long long *__restrict__ tend, unsigned long long *__restrict__ keys,
                                                     unsigned long long *__restrict__ counters, unsigned long long tag,
-                                                    unsigned long long sentinel) {
+                                                    unsigned long long sentinel, uint32_t *__restrict__ tile_cnt) {
+    const uint64_t i0 = (uint64_t)blockIdx.x * KEY_TILE + threadIdx.x;
     unsigned long long n_pass = 0, n_small = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
-        const pav_indel v = ind[i];
-        const bool pass = (long long)v.pos > tpos[v.aln] && (long long)v.end < tend[v.aln];
-        const bool small = pass && v.svlen < 50;
-        keys[i] = small ? (tag | (unsigned long long)rank[aln[v.aln].ref_id] << 38 | (unsigned long long)v.pos << 6 | (v.end - v.pos))
-                        : sentinel;
+    uint32_t pos[KEY_PER], end[KEY_PER], svlen[KEY_PER], al[KEY_PER];
+#pragma unroll
+    for (int u = 0; u < KEY_PER; ++u) {                                  // 64-byte records: only the fields the key needs
+        const pav_indel &v = ind[i0 + 256 * u < n ? i0 + 256 * u : n - 1];
+        pos[u] = v.pos; end[u] = v.end; svlen[u] = v.svlen; al[u] = v.aln;
+    }
+#pragma unroll
+    for (int u = 0; u < KEY_PER; ++u) {
+        const uint64_t i = i0 + 256 * u;
+        if (i >= n) break;
+        const bool pass = (long long)pos[u] > tpos[al[u]] && (long long)end[u] < tend[al[u]];
+        const bool small = pass && svlen[u] < 50;
+        keys[i] = small ? (tag | (unsigned long long)rank[aln[al[u]].ref_id] << 38 | (unsigned long long)pos[u] << 6 | (end[u] - pos[u]))
+                             : sentinel;
         n_pass += pass;
         n_small += small;
     }
     block_add(n_pass, counters);
-    block_add(n_small, counters + 1);
+    block_add(n_small, counters + 1, tile_cnt + blockIdx.x);
+}
+
+// Exclusive scan of the tile counts of one table per workgroup (blockIdx.x = table): tile_off[t] = real keys before tile t.
+struct TileScanArgs { const uint32_t *cnt[2]; uint64_t *off[2]; uint32_t n_tiles[2]; };
+__global__ __launch_bounds__(1024) void k_key_tile_scan(TileScanArgs A) {
+    __shared__ uint64_t wsum[16];
+    const uint32_t *cnt = A.cnt[blockIdx.x];
+    uint64_t *off = A.off[blockIdx.x];
+    const uint32_t n = A.n_tiles[blockIdx.x], per = (n + 1023) / 1024;
+    const uint32_t t0 = threadIdx.x * per, t1 = t0 + per < n ? t0 + per : n;
+    uint64_t mine = 0;
+    for (uint32_t t = t0; t < t1; ++t) mine += cnt[t];
+    uint64_t inc = mine;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint64_t y = __shfl_up(inc, d); if (lane >= d) inc += y; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint64_t base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    uint64_t run = base + inc - mine;
+    for (uint32_t t = t0; t < t1; ++t) { off[t] = run; run += cnt[t]; }
+}
+
+// Stable compaction of the real keys (table order) of both tables: blockIdx.x < tiles[0] -> SNV tile, else indel tile.
+struct CompactKeysArgs {
+    const unsigned long long *in[2]; unsigned long long *out[2]; const uint64_t *off[2]; uint64_t n[2]; uint32_t tiles0;
+    unsigned long long low;                                             // RealKey
+};
+__global__ __launch_bounds__(256) void k_compact_keys(CompactKeysArgs A) {
+    __shared__ uint32_t wsum[4];
+    const int t = blockIdx.x < A.tiles0 ? 0 : 1;
+    const uint32_t tile = blockIdx.x - (t ? A.tiles0 : 0u);
+    const uint64_t n = A.n[t], i0 = (uint64_t)tile * KEY_TILE + (uint64_t)threadIdx.x * KEY_PER;
+    const unsigned long long *in = A.in[t];
+    unsigned long long k[KEY_PER];
+    uint32_t mine = 0;
+    if (i0 + KEY_PER <= n) {
+        typedef unsigned long long u64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));   // the indel keys start at an odd key when n_snv is odd
+        const u64x2_a8 *p = reinterpret_cast<const u64x2_a8 *>(in + i0);
+#pragma unroll
+        for (int u = 0; u < KEY_PER / 2; ++u) { const u64x2_a8 v = p[u]; k[2 * u] = v.x; k[2 * u + 1] = v.y; }
+    } else {
+#pragma unroll
+        for (int u = 0; u < KEY_PER; ++u) k[u] = i0 + u < n ? in[i0 + u] : ~0ull;   // ~0: a sentinel for every table
+    }
+#pragma unroll
+    for (int u = 0; u < KEY_PER; ++u) mine += (k[u] & A.low) != A.low;
+    uint32_t inc = mine;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(inc, d); if (lane >= d) inc += y; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    unsigned long long *out = A.out[t] + A.off[t][tile] + base + inc - mine;
+#pragma unroll
+    for (int u = 0; u < KEY_PER; ++u) if ((k[u] & A.low) != A.low) *out++ = k[u];
 }
 
 __global__ __launch_bounds__(256) void k_indel_mid(unsigned long long *__restrict__ keys, uint64_t n, unsigned long long tag) {
@@ -572,25 +656,29 @@ int pav_cigar_flag(pav_ctx *ctx, const int64_t *trim_pos, const int64_t *trim_en
     if (n_keys) {
         PAV_HIP(ctx, S->a.reserve(8 * n_keys)); PAV_HIP(ctx, S->b.reserve(8 * n_keys));
         k_in = S->a.as<unsigned long long>(); k_sorted = S->b.as<unsigned long long>();
+        // keys of both tables (sentinels for the rows the FILTER drops), then - the common case first - the real keys of both
+        // compacted in table order (tile counts -> one scan -> scatter) and a look whether they rise (d_cnt[3])
+        const uint32_t tiles_snv = (uint32_t)((n_snv + KEY_TILE - 1) / KEY_TILE), tiles_ind = (uint32_t)((n_ind + KEY_TILE - 1) / KEY_TILE);
+        PAV_HIP(ctx, S->tmp.reserve(12 * ((size_t)tiles_snv + tiles_ind) + 64));
+        uint64_t *d_toff = S->tmp.as<uint64_t>();                                       // tile offsets (snv | indel), then tile counts
+        uint32_t *d_tcnt = reinterpret_cast<uint32_t *>(d_toff + tiles_snv + tiles_ind);
         if (n_snv)
-            PAV_LAUNCH(ctx, "k_snv_keys", k_snv_keys, (uint32_t)std::min<uint64_t>((n_snv + 255) / 256, 4u * (uint32_t)ctx->n_cu), 256, 0, ctx->d_snv.as<pav_snv>(), n_snv, d_aln, d_rank,
-                       d_tp, d_te, k_in, d_cnt, tag - 1);
+            PAV_LAUNCH(ctx, "k_snv_keys", k_snv_keys, tiles_snv, 256, 0, ctx->d_snv.as<pav_snv>(), n_snv, d_aln, d_rank,
+                       d_tp, d_te, k_in, d_cnt, tag - 1, d_tcnt);
         if (n_ind)
-            PAV_LAUNCH(ctx, "k_indel_keys", k_indel_keys, (uint32_t)std::min<uint64_t>((n_ind + 255) / 256, 4u * (uint32_t)ctx->n_cu), 256, 0, ctx->d_indel.as<pav_indel>(), n_ind, d_aln, d_rank,
-                       d_tp, d_te, k_in + n_snv, d_cnt + 1, tag, tag | (tag - 1));
-        // the common case first: compact the real keys of both tables in table order and look whether they rise (d_cnt[3])
-        const RealKey real{tag - 1};
-        unsigned long long *d_sel = d_cnt + 6;                      // select's own counts (= d_cnt[0], d_cnt[2])
+            PAV_LAUNCH(ctx, "k_indel_keys", k_indel_keys, tiles_ind, 256, 0, ctx->d_indel.as<pav_indel>(), n_ind, d_aln, d_rank,
+                       d_tp, d_te, k_in + n_snv, d_cnt + 1, tag, tag | (tag - 1), d_tcnt + tiles_snv);
+        TileScanArgs TS;
+        TS.cnt[0] = d_tcnt; TS.cnt[1] = d_tcnt + tiles_snv; TS.off[0] = d_toff; TS.off[1] = d_toff + tiles_snv;
+        TS.n_tiles[0] = tiles_snv; TS.n_tiles[1] = tiles_ind;
+        PAV_LAUNCH(ctx, "k_key_tile_scan", k_key_tile_scan, 2, 1024, 0, TS);
+        CompactKeysArgs CK;
+        CK.in[0] = k_in; CK.in[1] = k_in + n_snv; CK.out[0] = k_sorted; CK.out[1] = k_sorted + n_snv;
+        CK.off[0] = d_toff; CK.off[1] = d_toff + tiles_snv; CK.n[0] = n_snv; CK.n[1] = n_ind; CK.tiles0 = tiles_snv; CK.low = tag - 1;
+        PAV_LAUNCH(ctx, "k_compact_keys", k_compact_keys, tiles_snv + tiles_ind, 256, 0, CK);
         for (int t = 0; t < 2; ++t) {
             const uint64_t n_t = t == 0 ? n_snv : n_ind, at = t == 0 ? 0 : n_snv;
             if (!n_t) continue;
-            size_t bytes = 0;
-            PAV_HIP(ctx, rocprim::select(nullptr, bytes, k_in + at, k_sorted + at, d_sel + t, (size_t)n_t, real, st));
-            PAV_HIP(ctx, S->tmp.reserve(bytes + 16));
-            const int tok = prof_begin(ctx, "rocprim::select");
-            const hipError_t e = rocprim::select(S->tmp.p, bytes, k_in + at, k_sorted + at, d_sel + t, (size_t)n_t, real, st);
-            prof_end(ctx, tok);
-            PAV_HIP(ctx, e);
             PAV_LAUNCH(ctx, "k_check_sorted", k_check_sorted, (uint32_t)std::min<uint64_t>((n_t + 255) / 256, 4u * (uint32_t)ctx->n_cu), 256, 0,
                        k_sorted + at, d_cnt + (t == 0 ? 0 : 2), d_cnt + 3);
         }
