@@ -66,8 +66,9 @@ def main():
     ap.add_argument('--lanes', type=int, default=0,
                     help='haplotypes resident per GPU, one context + host thread each, sharing one resident reference; the K steps '
                          'go round them (default 0 = auto: 4 = h1 + h2 of two phased diploid samples, the per-GPU share of '
-                         'configs[2] / [3], when the process may use >= 6 CPUs per rank - every lane is a host thread that polls its '
-                         'stream - else 2, else 1; 1 = one haplotype, no overlap)')
+                         'configs[2] / [3], when the process may use >= 4 CPUs per rank - every lane is a host thread that polls its '
+                         'stream; measured on an MI355X box with taskset: 4 lanes on 4 cores 1.3 Tbp/s, on 2 cores 0.88; 2 lanes on 2 '
+                         'cores 1.07; 1 lane 0.62 - else 2 with >= 2 CPUs, else 1; 1 = one haplotype, no overlap)')
     ap.add_argument('--pair-frac', type=float, default=PAIR_FRAC, help='generator: fraction of indel events emitted as a matched DEL + INS')
     ap.add_argument('--eager-tables', action='store_true',
                     help='copy the density tables of every inversion call to pinned host memory inside the timed region (round-1 '
@@ -129,7 +130,7 @@ def main():
     threads = args.threads or max(1, effective_cpus() // max(1, world))
     threads = min(threads, 16)
     cpus_per_rank = effective_cpus() / max(1, world)
-    n_lanes = args.lanes if args.lanes > 0 else (4 if cpus_per_rank >= 6 else (2 if cpus_per_rank >= 3 else 1))
+    n_lanes = args.lanes if args.lanes > 0 else (4 if cpus_per_rank >= 4 else (2 if cpus_per_rank >= 2 else 1))   # measured: 4 lanes want 4 cores, 2 want 2
     gen_kw = {'pair_frac': args.pair_frac} if args.workload == 'cigar+inv' and args.pair_frac > 0 else {}
 
     # ---- synthetic inputs (host) -> HBM -----------------------------------------------------------------------
