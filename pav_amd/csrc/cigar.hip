@@ -574,10 +574,10 @@ __device__ __forceinline__ int popc128(u128 x) { return __popcll((uint64_t)x) + 
 // Positions are arena offsets in bases.  Arenas below 2^32 bases (a human genome is 3.1 G) run the kernel on 32-bit
 // positions: half the descriptor bytes in LDS, and every address is a scalar base + a 32-bit lane offset (one VALU op
 // instead of 64-bit shifts and adds).  WIDE keeps the high words beside them.
-// Where the time goes (bench haplotype, 0.30 ms, SQ counters in DESIGN.md section 5): 111 M vector instructions = 0.09 ms of
-// issue on 1024 SIMD-32, 1.63 GB of HBM = 0.25 ms at the streaming rate of pack_kernel.  With the loads of the loop compiled out
-// the kernel still takes 0.255 ms, with the loop compiled out 0.07 ms (the scan + descriptors): a step is a dependent chain
-// (LDS, ballot, LDS, loads, LDS, compare) and four waves per SIMD take turns on it.
+// Where the time goes (bench haplotype, 0.30 ms, SQ counters in DESIGN.md section 5): 111 M vector instructions at four cycles
+// each = 0.18 ms of issue on 1024 SIMDs, 1.63 GB of HBM = 0.25 ms at the streaming rate of pack_kernel; four waves per SIMD
+// overlap the two to 0.30 ms.  With the loads of the loop compiled out the kernel takes 0.255 ms, with the loop compiled out
+// 0.07 ms (the scan + descriptors).
 // Tried and dropped: 5 waves / SIMD via amdgpu_waves_per_eu (96 VGPRs: +5 %), one unaligned 2-byte load of the dirty pair
 // (+5 %), non-temporal window loads (no change), one or four pieces per lane and step, one workgroup per chunk (no change).
 template <bool WIDE> struct VPos { typedef uint32_t type; };
@@ -709,14 +709,16 @@ __global__ __launch_bounds__(256) void verify_kernel(VerifyArgs A) {
             if ((uint32_t)__builtin_amdgcn_readfirstlane(s_pre[mid]) <= p0) c0 = mid; else hi = mid;
         }
     }
-    for (uint32_t base = p0; base < p1; base += VU * VPIECE) {
+    // The owners of a step's pieces (LDS only: run starts, marks, ballot) are worked out one step ahead, after the loads of the
+    // current step have been issued: four dependent LDS round trips per step leave the chain that the four waves of a SIMD have
+    // to hide.  No branch around it - past the last step it reads clamped slots and marks nothing.
+    auto owners = [&](const uint32_t base, uint32_t (&q)[VU]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < VU; ++u) {                                   // run c0 + 1 + i starts at piece base + 1 + s
             const uint32_t s = s_pre[min(c0 + 1 + (uint32_t)u * VPIECE + (uint32_t)lane, n_slots)] - base - 1;
             if (s < VU * VPIECE) mark[wave][s] = 1;
         }
         // mark[i]: a run starts at piece base + 1 + i; piece base + l belongs to run c0 + (marks below l)
-        uint32_t q[VU];
 #pragma unroll
         for (int u = 0; u < VU; ++u) {
             const uint32_t m = mark[wave][u * VPIECE + lane];
@@ -725,7 +727,10 @@ __global__ __launch_bounds__(256) void verify_kernel(VerifyArgs A) {
             q[u] = __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, c0));
             c0 += (uint32_t)__popcll(M);
         }
-
+    };
+    uint32_t q[VU], q_next[VU];
+    if (p0 < p1) owners(p0, q);
+    for (uint32_t base = p0; base < p1; base += VU * VPIECE) {
         uint32_t n[VU], flags[VU], lsh[VU];
         uint8_t dr[VU], dt[VU];                                             // summary bytes of the blocks a window touches (used after all loads are out)
         pos_t pr[VU], pt[VU];
@@ -760,6 +765,7 @@ __global__ __launch_bounds__(256) void verify_kernel(VerifyArgs A) {
             xr[u] = window_at<pos_t>(A.ref.two, pr[u]);
             xt[u] = window_at<pos_t>(A.tig.two, s0);
         }
+        owners(base + VU * VPIECE, q_next);                             // while the loads above are in flight
 #pragma unroll
         for (int u = 0; u < VU; ++u) {
             uint32_t r[4], t[4];
@@ -814,6 +820,8 @@ __global__ __launch_bounds__(256) void verify_kernel(VerifyArgs A) {
             if (flags[u] & 1u) bad_x += bad;
             if (bad) bad_slot = min(bad_slot, q[u]);
         }
+#pragma unroll
+        for (int u = 0; u < VU; ++u) q[u] = q_next[u];
     }
     unsigned long long n_eq = len_eq, bad_eq = bad_tot - bad_x, nx = len_x, bx = bad_x;
     unsigned long long first_bad = bad_slot == ~0u ? ~0ull : (unsigned long long)chunk * WALK_CHUNK + slot0 + (unsigned long long)d_op[bad_slot];
