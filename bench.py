@@ -4,26 +4,31 @@ bench.py - aligned Gbp/s through CIGAR-call + k-mer inversion scan on MI355X (BA
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (config.workload): one synthetic hg38-shaped haplotype per GPU (24 reference sequences with hg38 no-ALT
-lengths, ~3.0 Gbp aligned, SURVEY.md section 8(d) profile, seed 1002) through the WHOLE path the metric names:
-CIGAR-call, inversion-signature flagging of the fresh calls, and the k-mer density scan of every flagged region
-(BASELINE configs[2] at one haplotype per GPU).  The CIGAR-call-only figure of configs[1] is measured in the same run
-and reported as the "cigar_only" object (or as `value` with --workload cigar).  With N > 1 every rank processes its
-own haplotype (seed 1002*64 + rank) against the same reference: weak scaling, no data-path collective (SURVEY.md
-section 8(e)); torch.distributed (RCCL) is used only for the barrier and the max-over-ranks of the timed region.
+Workload (config.workload): synthetic hg38-shaped haplotypes (24 reference sequences with hg38 no-ALT lengths, ~3.0 Gbp
+aligned each, SURVEY.md section 8(d) profile, seed 1002) through the WHOLE path the metric names: CIGAR-call,
+inversion-signature flagging of the fresh calls, and the k-mer density scan of every flagged region - the per-GPU share of
+BASELINE configs[2] / [3]: L haplotypes resident per GPU against one resident reference (--lanes; one context and one host
+thread each), the K steps go round them.  The CIGAR-call-only figure of configs[1] is measured in the same run and reported
+as the "cigar_only" object (or as `value` with --workload cigar).  With N > 1 every rank has its own L haplotypes (seed
+1002*64 + rank*L + lane) against the same reference: weak scaling, no data-path collective (SURVEY.md section 8(e));
+torch.distributed (RCCL) is used only for the barrier, the max-over-ranks of the timed region and the sum of the bases.
 
 A "step" is one pass of the hot path over one haplotype with inputs already resident in HBM
 (reference ASCII + packed planes, contig ASCII, alignment tables, CIGAR text):
-    pack contigs (2-bit + non-ACGT planes)  ->  tokenise CIGAR text  ->  prefix-scan walk  ->  SNV/INDEL emission
-    ->  left-shift + breakpoint homology  ->  SEQ gather            (call records stay in HBM, D2H reported separately)
-    ->  FILTER + sort + cluster sweeps + INS/DEL matching  ->  flagged loci
-    ->  per flagged region: lift-over, k-mer sets, STATE_MER, KDE, STATE runs, expansion rounds, inversion calls
-        (the density tables of all calls are copied to pinned host memory inside the timed region).
+    contig planes marked stale (filled on demand below)  ->  tokenise CIGAR text  ->  prefix-scan walk  ->  SNV/INDEL emission
+    ->  left-shift + breakpoint homology (contig windows decoded from the ASCII arena)  ->  SEQ gather
+        (call records stay in HBM, D2H reported separately)
+    ->  FILTER + key compaction + cluster sweeps + INS/DEL matching  ->  flagged loci
+    ->  per flagged region: lift-over, pack of the blocks under the region, k-mer sets, STATE_MER, KDE, STATE runs,
+        expansion rounds, inversion calls (the density tables of the calls stay packed in HBM; --eager-tables copies them
+        to pinned host memory inside the step).
 
-Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed on the library's stream; "alone" = the same
-launch with nothing beside it), "cpu_baseline" (oracle/ scalar C port timed on a bounded sample of the same workload, rank 0,
-N = 1 only), "cigar_only" (BASELINE configs[1]), "verify_mode" (CIGAR-call + a pass over both packed sequences that checks
-every = / X base; SURVEY.md section 8(d), never mixed into `value`), "inv_scan" and "end_to_end" (writers / readers).
+Extra objects on the JSON line: "roofline" (the kernel with the largest share of a pass, HIP-event timed on the library's
+streams, one lane alone; "path" = the whole pass against SURVEY 8(d)'s byte model), "contig_pack_alone" (the streaming pack of
+a whole contig arena - verify mode, PAV_EAGER_PACK=1 - with nothing beside it), "cpu_baseline" (oracle/ scalar C port timed on
+a bounded sample of the same workload, rank 0, N = 1 only), "cigar_only" (BASELINE configs[1]), "verify_mode" (CIGAR-call + a
+pass over both packed sequences that checks every = / X base; SURVEY.md section 8(d), never mixed into `value`), "inv_scan"
+and "end_to_end" (writers / readers), "per_rank" and "load_balance".
 """
 
 import argparse
