@@ -615,8 +615,13 @@ def test_contig_planes_on_demand_equal_the_full_pack(built, gpu_ctx, monkeypatch
         out.append(gpu_ctx.cigar_verify())
         return out, len(regions)
 
+    work0 = gpu_ctx.kde_work()
     lazy, n_regions = run(False)
+    work1 = gpu_ctx.kde_work()
     eager, _ = run(True)
+    # pav_kde_work: cumulative counters - evaluation points, (point, run) pairs, (point, data point) pairs of scipy's double loop
+    d_pts, d_runs, d_data = (b - a for a, b in zip(work0, work1))
+    assert d_pts > 1000 and d_runs >= d_pts and d_data > 100 * d_runs
     assert n_regions >= 10 and len(lazy[0][6]) >= 1
     assert lazy[0] == lazy[1] and eager[0] == eager[1]
     assert lazy == eager
