@@ -2034,18 +2034,19 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
                 for (uint32_t f = 0; f < hs[j].fill_n; f += 64) ftiles.push_back(EvalTile{j, f, std::min<uint32_t>(64, hs[j].fill_n - f), 1});
             }
             if (pass == 0) {                                             // work counters (pav_kde_work)
-                double pairs = 0, points = 0, big = 0, data_pairs = 0;
+                double pairs = 0, points = 0, big = 0, data_pairs = 0, rows_all = 0, rows_norev = 0;
                 for (uint32_t j = 0; j < n_jobs; ++j) {
                     const JobKde &kd = D->h_kde[j];
                     if (!kd.finalised) continue;
+                    rows_all += kd.n; if (hs[j].m[2] == 0) rows_norev += kd.n;
                     const double pts = (double)kd.n_samp + hs[j].fill_n, runs = (double)kd.n_run[0] + kd.n_run[1] + kd.n_run[2];
                     points += pts; pairs += pts * runs;
                     data_pairs += pts * ((double)hs[j].m[0] + hs[j].m[1] + hs[j].m[2]);
                     if (runs > 256) big += pts * runs;
                 }
                 ctx->kde_work[0] += points; ctx->kde_work[1] += pairs; ctx->kde_work[2] += data_pairs;
-                if (timing) fprintf(stderr, "[pav timing]   kde work: %.3g evaluation points, %.3g (point, run) pairs (%.1f runs per point; %.0f %% of the pairs in jobs with > 256 runs)\n",
-                        points, pairs, points ? pairs / points : 0.0, pairs ? 100.0 * big / pairs : 0.0);
+                if (timing) fprintf(stderr, "[pav timing]   kde work: %.3g evaluation points, %.3g (point, run) pairs (%.1f runs per point; %.0f %% of the pairs in jobs with > 256 runs); %.3g table rows, %.0f %% in jobs without REV k-mers\n",
+                        points, pairs, points ? pairs / points : 0.0, pairs ? 100.0 * big / pairs : 0.0, rows_all, rows_all ? 100.0 * rows_norev / rows_all : 0.0);
             }
             if (!ftiles.empty()) {
                 PAV_HIP(ctx, D->ftiles.reserve(sizeof(EvalTile) * ftiles.size()));
