@@ -723,9 +723,10 @@ __global__ __launch_bounds__(256) void k_pscale(const JobDev *__restrict__ jobs,
                                                 const uint32_t *__restrict__ l1, const uint32_t *__restrict__ l2,
                                                 double *__restrict__ p0, double *__restrict__ p1, double *__restrict__ p2) {
     const uint64_t ap = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint32_t j = tile_job[ap / DTILE];
+    const uint32_t j = __builtin_amdgcn_readfirstlane(tile_job[(uint64_t)blockIdx.x * 256 / DTILE]);   // a workgroup lies in one tile
+    // few jobs need scaled positions (states summed term by term): look at the two words that say so before the 200-byte descriptor
+    if (!kde[j].finalised || !kde[j].ps_mask) return;
     const JobKde kd = kde[j];
-    if (!kd.finalised) return;
     const uint64_t t = ap - jobs[j].tpos_off;
     if ((kd.ps_mask & 1u) && t < kd.m[0]) p0[ap] = (double)l0[ap] * kd.inv_h[0];
     if ((kd.ps_mask & 2u) && t < kd.m[1]) p1[ap] = (double)l1[ap] * kd.inv_h[1];
@@ -1107,7 +1108,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinArgs A) {
     __shared__ int8_t s_state[256];
     const GuardArgs &G = A.G;
     const uint64_t ap = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint32_t j = A.tile_job[ap / DTILE];
+    const uint32_t j = A.tile_job[(uint64_t)blockIdx.x * 256 / DTILE];    // a workgroup lies in one tile: job and descriptor through the scalar cache
     const JobKde kd = A.kde[j];
     const uint64_t off = A.jobs[j].tpos_off;
     const uint32_t n = kd.finalised ? kd.n : A.stat[j].n_rows;
@@ -1281,7 +1282,7 @@ __global__ __launch_bounds__(256) void k_heads(const JobDev *__restrict__ jobs, 
                                                const uint32_t *__restrict__ index, HeadEvent *__restrict__ events,
                                                uint32_t cap, uint32_t *__restrict__ ev_count) {
     const uint64_t ap = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint32_t j = tile_job[ap / DTILE];
+    const uint32_t j = tile_job[(uint64_t)blockIdx.x * 256 / DTILE];
     const uint32_t n = stat[j].n_rows;
     const uint64_t r = ap - jobs[j].tpos_off;
     if (r >= n) return;
@@ -1374,26 +1375,39 @@ __global__ __launch_bounds__(256) void k_gather_calls(const GatherCall *__restri
                                                       uint8_t *__restrict__ o_match) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
-    uint32_t lo = 0, hi = n_calls;                       // last call with dst_off <= t
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (calls[mid].dst_off <= t) lo = mid; else hi = mid; }
-    const GatherCall c = calls[lo];
-    const uint64_t src = c.src_off + (t - c.dst_off);
-    const uint32_t ix = index[src];
-    const unsigned long long km = kmer[src];
-    o_index[t] = ix; o_sm[t] = state_mer[src]; o_st[t] = state[src];
-    o_k0[t] = k0[src]; o_k1[t] = k1[src]; o_k2[t] = k2[src]; o_kmer[t] = km;
-    const int64_t q = (int64_t)ix + c.base;                            // QRY_INDEX (inv.py:519)
-    uint8_t f = 0;
-    if (q >= c.up_pos && q < c.up_end - k) f = 1;                      // inv.py:524-527
-    if (q >= c.dn_pos && q < c.dn_end - k) f = 2;                      // inv.py:529-532
-    uint8_t m = 0;
-    if (f) {                                                           // raw KMER against canonical sets (inv.py:537-553)
-        const bool in_up = table_has(keys + c.key_up, 0, c.mask_up, km), in_dn = table_has(keys + c.key_dn, 0, c.mask_dn, km);
-        const bool same = f == 1 ? in_up : in_dn, other = f == 1 ? in_dn : in_up;
-        m = same ? (other ? 3 : 1) : (other ? 2 : 3);                  // KMER_LOC_STATE: NA / OTHER / SAME / NA
+    // last call with dst_off <= t.  The calls of the workgroup's first and last row are found with uniform arguments (scalar
+    // loads); nearly always they are the same call and every lane takes its 80-byte descriptor through the scalar cache
+    const uint32_t t_first = blockIdx.x * 256, t_last = min(t_first + 255u, total - 1);
+    uint32_t lo = 0, hi = n_calls, lo_last = 0;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (calls[mid].dst_off <= t_first) lo = mid; else hi = mid; }
+    hi = n_calls; lo_last = lo;
+    while (hi - lo_last > 1) { const uint32_t mid = (lo_last + hi) >> 1; if (calls[mid].dst_off <= t_last) lo_last = mid; else hi = mid; }
+    auto row = [&](const GatherCall &c) __attribute__((always_inline)) {
+        const uint64_t src = c.src_off + (t - c.dst_off);
+        const uint32_t ix = index[src];
+        const unsigned long long km = kmer[src];
+        o_index[t] = ix; o_sm[t] = state_mer[src]; o_st[t] = state[src];
+        o_k0[t] = k0[src]; o_k1[t] = k1[src]; o_k2[t] = k2[src]; o_kmer[t] = km;
+        const int64_t q = (int64_t)ix + c.base;                            // QRY_INDEX (inv.py:519)
+        uint8_t f = 0;
+        if (q >= c.up_pos && q < c.up_end - k) f = 1;                      // inv.py:524-527
+        if (q >= c.dn_pos && q < c.dn_end - k) f = 2;                      // inv.py:529-532
+        uint8_t m = 0;
+        if (f) {                                                           // raw KMER against canonical sets (inv.py:537-553)
+            const bool in_up = table_has(keys + c.key_up, 0, c.mask_up, km), in_dn = table_has(keys + c.key_dn, 0, c.mask_dn, km);
+            const bool same = f == 1 ? in_up : in_dn, other = f == 1 ? in_dn : in_up;
+            m = same ? (other ? 3 : 1) : (other ? 2 : 3);                  // KMER_LOC_STATE: NA / OTHER / SAME / NA
+        }
+        o_flank[t] = f;
+        o_match[t] = m;
+    };
+    if (lo_last == lo) {
+        row(calls[lo]);
+    } else {                                             // a call boundary inside the workgroup: every lane searches for itself
+        hi = lo_last + 1;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (calls[mid].dst_off <= t) lo = mid; else hi = mid; }
+        row(calls[lo]);
     }
-    o_flank[t] = f;
-    o_match[t] = m;
 }
 
 int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls, uint64_t k1_rows, CallStage &stage, bool copy_now) {
