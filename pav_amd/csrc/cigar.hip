@@ -141,13 +141,14 @@ __global__ __launch_bounds__(256) void tok_emit(const uint8_t *__restrict__ text
         flags &= flags - 1;
         const int lp = 32 + (int)threadIdx.x * 16 + j;  // position of the op character in s_txt
         const uint32_t ch = s_txt[lp];
-        // digits in front of the op character (never more than 19 contribute)
-        uint64_t val = 0, mul = 1;
+        // digits in front of the op character: nine of them fit 32-bit arithmetic (64-bit multiplies are several instructions
+        // each) and are more than the 2^28 limit allows; any non-zero digit beyond them is an overflow as well
+        uint32_t val = 0, mul = 1;
         int nd = 0;
         bool over = false;
         int q = lp - 1;
         while (q >= 0 && is_digit(s_txt[q])) {
-            if (nd < 18) { val += (uint64_t)(s_txt[q] - '0') * mul; mul *= 10; } else if (s_txt[q] != '0') over = true;
+            if (nd < 9) { val += (uint32_t)(s_txt[q] - '0') * mul; mul *= 10; } else if (s_txt[q] != '0') over = true;
             ++nd; --q;
         }
         int64_t g = (int64_t)b0 - 32 + q;               // global position of the first non-digit before the token
@@ -158,9 +159,9 @@ __global__ __launch_bounds__(256) void tok_emit(const uint8_t *__restrict__ text
         int kind = 0;
         if (nd == 0) kind = PAV_CIGAR_ERR_MISSING_LEN;              // align.py:310 (checked before the op set)
         else if (code < 0) kind = PAV_CIGAR_ERR_UNKNOWN_OP;         // align.py:315
-        else if (over || val >= (1ull << 28)) kind = PAV_CIGAR_ERR_LEN_OVERFLOW;
+        else if (over || val >= (1u << 28)) kind = PAV_CIGAR_ERR_LEN_OVERFLOW;
         if (kind) atomicMin(tok_err, (unsigned long long)(((uint64_t)(g + 1)) << 3 | (uint64_t)kind));
-        ops[ord] = kind ? 0x7u /* a zero-length '=' keeps the stream well formed; the call fails anyway */ : ((uint32_t)val << 4 | (uint32_t)code);
+        ops[ord] = kind ? 0x7u /* a zero-length '=' keeps the stream well formed; the call fails anyway */ : (val << 4 | (uint32_t)code);
         ++ord;
     }
 }
