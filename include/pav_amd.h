@@ -72,7 +72,11 @@ int pav_seq_load(pav_ctx *ctx, int role, uint32_t n_seq, const uint8_t *const *a
  * with its own streams, contigs, alignment tables and results, drivable from its own host thread - all sharing the
  * reference context's PAV_ROLE_REF store.  The planes are freed with their last user.  A later pav_seq_load for that
  * role gives the context a store of its own again; re-packing a shared store (pav_seq_pack) while others use it is
- * the caller's race.  Record names (pav_seq_set_names) are per context and are not copied. */
+ * the caller's race.  Record names (pav_seq_set_names) are per context and are not copied.
+ * Ordering: a pack `from` has queued and not finished (an asynchronous pav_seq_pack) is waited for here, and every reader of
+ * the planes on either context orders itself behind the store's last full pack, whichever context queued it.  A store whose
+ * planes are still on demand (PAV_ROLE_TIG after pav_seq_load) is packed in full by this call: `from` must not be driven
+ * from another thread while it runs. */
 int pav_seq_share(pav_ctx *ctx, const pav_ctx *from, int role);
 
 /* Native FASTA reader (host only; no context needed).  Replaces pysam.FastaFile(path).fetch(name) of the reference

@@ -248,7 +248,7 @@ def call_records(ctx, df_align, ref_names=None, tig_names=None):
     return snv, indel, blob, counts
 
 
-def make_insdel_snv_calls(df_align, ref_fa_name, tig_fa_name, hap, version_id=True, ctx=None, device_id=0):
+def make_insdel_snv_calls(df_align, ref_fa_name, tig_fa_name, hap, version_id=False, ctx=None, device_id=0):
     """
     Parse variants from CIGAR strings (GPU).  Same contract as pavlib/cigarcall.py:24-36.
 
@@ -256,9 +256,10 @@ def make_insdel_snv_calls(df_align, ref_fa_name, tig_fa_name, hap, version_id=Tr
     :param ref_fa_name: Reference FASTA file name.
     :param tig_fa_name: Contig FASTA file name.
     :param hap: String identifying the haplotype ("h1", "h2").
-    :param version_id: Version duplicate variant IDs if `True`.  The rule passes `False`
-        (rules/call.snakefile:810); `True` needs svpoplib.variant.version_id, which is not vendored in the
-        reference snapshot, so it raises NotImplementedError here.
+    :param version_id: Version duplicate variant IDs if `True`.  DEFAULT DIFFERS FROM THE REFERENCE (`True` there,
+        pavlib/cigarcall.py:24): the only caller, rule call_cigar, passes `False` (rules/call.snakefile:810), and `True`
+        needs svpoplib.variant.version_id, which is not vendored in the reference snapshot (empty dep/svpop), so it
+        raises NotImplementedError here - a default call must not fail.
     :param ctx: Optional live :class:`pav_amd._lib.Context` (sequences are (re)loaded into it).
     :param device_id: GPU to use when no context is given.
 

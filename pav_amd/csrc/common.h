@@ -67,12 +67,19 @@ struct SeqStore {
     std::vector<uint64_t> off, len;
     DevBuf d_ascii, d_two, d_mask, d_dirty, d_off, d_len;
     int device = -1;                      // where the planes live (shared stores: all users sit on this device)
-    bool planes_full = false;             // pack_kernel has run over the whole arena since the ASCII last changed
+    bool planes_full = false;             // a pack of the whole arena has been QUEUED since the ASCII last changed; it has run
+                                          // only behind pack_event: every reader's stream waits for it (pav::wait_planes)
+    hipEvent_t pack_event = nullptr;      // recorded behind the last full pack, on whichever context's stream ran it
+    uint64_t pack_gen = 0;                // counts full packs; a context remembers the last one its main stream waited for
     SeqView view() const {
         return SeqView{d_ascii.as<uint8_t>(), d_two.as<uint32_t>(), d_mask.as<uint32_t>(), d_dirty.as<uint8_t>(),
                        d_off.as<uint64_t>(), d_len.as<uint64_t>(), n, planes_full ? 1u : 0u};
     }
-    void release() { for (DevBuf *b : {&d_ascii, &d_two, &d_mask, &d_dirty, &d_off, &d_len}) b->release(); n = 0; arena = total = 0; planes_full = false; }
+    void release() {
+        for (DevBuf *b : {&d_ascii, &d_two, &d_mask, &d_dirty, &d_off, &d_len}) b->release();
+        if (pack_event) { (void)hipEventDestroy(pack_event); pack_event = nullptr; }
+        n = 0; arena = total = 0; planes_full = false;
+    }
     SeqStore() = default;
     SeqStore(const SeqStore &) = delete;
     SeqStore &operator=(const SeqStore &) = delete;
@@ -105,8 +112,9 @@ struct pav_ctx {
     bool tables_pending_prev = false;        // scan does not wait for them (the two are swapped when a scan starts)
     hipEvent_t snv_ready = nullptr, snv_done = nullptr;   // pav_cigar_call: the SNV rows are written on stream2 (behind the pack),
                                                           // next to the homology scans of the main stream
-    hipEvent_t pack_done[2] = {nullptr, nullptr};   // recorded after a pack on stream2; consumers of the planes wait on it
+    hipEvent_t pack_done[2] = {nullptr, nullptr};   // pav_seq_pack: orders the side stream's pack behind the main stream
     bool pack_pending[2] = {false, false};
+    uint64_t seen_pack_gen[2] = {0, 0};   // SeqStore::pack_gen of the last full pack the main stream waits behind (per role)
     std::string err;
     char dev_name[256] = {0};
     int n_cu = 0;

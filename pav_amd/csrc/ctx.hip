@@ -44,9 +44,18 @@ void prof_end(pav_ctx *ctx, int token, hipStream_t st) {
     (void)hipEventRecord(ctx->prof_pending[(size_t)token].b, st ? st : ctx->stream);
 }
 
+// Everything the caller launches next on ctx->stream runs behind the last full pack of both stores - whichever context
+// queued it, on whichever stream (a shared store is packed by one of its users; SeqStore::planes_full only says that the
+// pack has been queued).
 int wait_planes(pav_ctx *ctx) {
-    for (int r = 0; r < 2; ++r)
-        if (ctx->pack_pending[r]) { PAV_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->pack_done[r], 0)); ctx->pack_pending[r] = false; }
+    for (int r = 0; r < 2; ++r) {
+        SeqStore &s = ctx->seq[r];
+        if (s.pack_event && s.pack_gen != ctx->seen_pack_gen[r]) {
+            PAV_HIP(ctx, hipStreamWaitEvent(ctx->stream, s.pack_event, 0));
+            ctx->seen_pack_gen[r] = s.pack_gen;
+        }
+        ctx->pack_pending[r] = false;
+    }
     return PAV_OK;
 }
 
@@ -115,12 +124,17 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint4 *__restrict__ asc
 }
 
 static int run_pack(pav_ctx *ctx, SeqStore &s, hipStream_t st) {
-    s.planes_full = true;
-    if (s.arena == 0) return PAV_OK;
+    if (s.arena == 0) { s.planes_full = true; return PAV_OK; }
     const uint64_t n16 = s.arena / 16;
     const uint64_t blocks = (n16 + 256 * PACK_U - 1) / (256 * PACK_U);
     PAV_LAUNCH_ON(ctx, st, "pack_kernel", pack_kernel, (uint32_t)blocks, 256, 0, s.d_ascii.as<uint4>(),
                   s.d_two.as<uint32_t>(), s.d_mask.as<uint32_t>(), s.d_dirty.as<uint8_t>(), n16);
+    // the planes are whole behind this event; readers on other streams (this context's main stream, other contexts that
+    // share the store) wait for it in wait_planes
+    if (!s.pack_event) PAV_HIP(ctx, hipEventCreateWithFlags(&s.pack_event, hipEventDisableTiming));
+    PAV_HIP(ctx, hipEventRecord(s.pack_event, st));
+    s.pack_gen += 1;
+    s.planes_full = true;
     return PAV_OK;
 }
 
@@ -309,7 +323,7 @@ void pav_destroy(pav_ctx *ctx) {
     for (int r = 0; r < 2; ++r) ctx->seq.p[r].reset();              // the planes go with their last user
     DevBuf *bufs[] = {&ctx->d_aln, &ctx->d_text, &ctx->d_text_off, &ctx->d_ops, &ctx->d_op_off, &ctx->d_chunk,
                       &ctx->d_chunk2, &ctx->d_rowbase, &ctx->d_totals, &ctx->d_snv, &ctx->d_indel,
-                      &ctx->d_seqblob, &ctx->d_tmp, &ctx->ix_text, &ctx->ix_off, &ctx->ix_pos, &ctx->ix_ops, &ctx->ix_op_off,
+                      &ctx->d_seqblob, &ctx->d_tmp, &ctx->d_spans, &ctx->ix_text, &ctx->ix_off, &ctx->ix_pos, &ctx->ix_ops, &ctx->ix_op_off,
                       &ctx->ix_chunk, &ctx->ix_chunk2, &ctx->ix_rowbase, &ctx->ix_begin, &ctx->ix_err};
     for (DevBuf *b : bufs) b->release();
     (void)hipStreamDestroy(ctx->stream);
@@ -407,13 +421,20 @@ int pav_seq_share(pav_ctx *ctx, const pav_ctx *from, int role) {
     ctx->pack_pending[role] = false;
     ctx->cigar_loaded = ctx->cigar_called = false;
     ctx->seq.p[role] = from->seq.p[role];
+    ctx->seen_pack_gen[role] = 0;
     // a shared store is read from several streams: its planes are made whole here, once, and stay so (pav_seq_pack
     // re-packs a shared store in full; the lazy contig pack is for stores with one user)
-    if (!ctx->seq[role].planes_full) {
-        const int rc = run_pack(ctx, ctx->seq[role], ctx->stream);
+    SeqStore &s = ctx->seq[role];
+    if (!s.planes_full) {
+        // A store that is packed on demand (contigs) becomes shared: this context packs it in full.  `from` must be idle
+        // during this call (include/pav_amd.h) - its kernels queued earlier may still decode the ASCII arena, which the pack
+        // only reads; the ones it launches after this call see planes_full and wait for pack_event.
+        const int rc = run_pack(ctx, s, ctx->stream);
         if (rc != PAV_OK) return rc;
-        PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+    // a pack the owner (or another sharer) has queued but not finished - e.g. an asynchronous pav_seq_pack on its side
+    // stream - is waited for here, and again by every plane reader of this context through wait_planes
+    if (s.pack_event) PAV_HIP(ctx, hipEventSynchronize(s.pack_event));
     return PAV_OK;
 }
 
@@ -429,9 +450,8 @@ int pav_seq_pack(pav_ctx *ctx, int role) {
     hipEvent_t *ev = &ctx->pack_done[role];
     PAV_HIP(ctx, hipEventRecord(*ev, ctx->stream));
     PAV_HIP(ctx, hipStreamWaitEvent(ctx->stream2, *ev, 0));
-    int rc = run_pack(ctx, ctx->seq[role], ctx->stream2);
+    int rc = run_pack(ctx, ctx->seq[role], ctx->stream2);   // records the store's pack_event: what every reader waits for
     if (rc != PAV_OK) return rc;
-    PAV_HIP(ctx, hipEventRecord(*ev, ctx->stream2));
     ctx->pack_pending[role] = true;
     return PAV_OK;
 }

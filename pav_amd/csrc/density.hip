@@ -1993,6 +1993,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     // The density stage runs once in the regular case.  It is repeated with every job summed term by term (force_direct) only
     // when the guard's list overflowed.
     bool fallback = false;
+    double work_add[3] = {0, 0, 0};
     for (int attempt = 0; attempt < 2; ++attempt) {
         const bool force_direct = attempt == 1;
         bool any_ps = false;
@@ -2030,7 +2031,11 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
         uint32_t processed = 0;                                        // list entries whose sampled sites have been evaluated again
         bool overflow = false;
         for (uint32_t pass = 0; ; ++pass) {
-            if (pass > 64) return fail(ctx, PAV_E_STATE, "pav_density_batch: the near-tie guard did not settle");
+            if (pass > 64) {                                             // windows flipping between quiet and filled: does not settle
+                if (force_direct) return fail(ctx, PAV_E_STATE, "pav_density_batch: the near-tie guard did not settle in direct mode");
+                overflow = true;                                         // same way out as a full list: everything in scipy's order
+                break;
+            }
             G.pass = pass;
             KA.G = G; RA.G = G;
             // ---- windows between sampled sites: interpolate or queue for evaluation (readback 2: fill counts) ----------
@@ -2058,7 +2063,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
                     data_pairs += pts * ((double)hs[j].m[0] + hs[j].m[1] + hs[j].m[2]);
                     if (runs > 256) big += pts * runs;
                 }
-                ctx->kde_work[0] += points; ctx->kde_work[1] += pairs; ctx->kde_work[2] += data_pairs;
+                work_add[0] = points; work_add[1] = pairs; work_add[2] = data_pairs;   // of the attempt that is kept (added below)
                 if (timing) fprintf(stderr, "[pav timing]   kde work: %.3g evaluation points, %.3g (point, run) pairs (%.1f runs per point; %.0f %% of the pairs in jobs with > 256 runs); %.3g table rows, %.0f %% in jobs without REV k-mers\n",
                         points, pairs, points ? pairs / points : 0.0, pairs ? 100.0 * big / pairs : 0.0, rows_all, rows_all ? 100.0 * rows_norev / rows_all : 0.0);
             }
@@ -2097,6 +2102,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
         if (force_direct) return fail(ctx, PAV_E_STATE, "pav_density_batch: guard list overflow in direct mode");
         fallback = true;
     }
+    for (int q = 0; q < 3; ++q) ctx->kde_work[q] += work_add[q];
     if (G.g) {                                                         // guard counters of every job (read with the run heads)
         for (uint32_t j = 0; j < n_jobs; ++j) {
             pav_den_result &r = D->results[j];

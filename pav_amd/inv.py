@@ -149,14 +149,17 @@ def get_srs_tree(srs_tuple_list):
     """``[(region size limit, state-run-smooth factor), ...]`` -> lookup of the factor by region size, as
     ``pavlib.inv.get_srs_tree`` (pavlib/inv.py:564-620): the factor given with a limit applies from that limit up to the next
     one; below the first limit it is 20 (or the limit if smaller); no list = 20 everywhere.  Same checks and messages, in
-    the order the reference meets them (a malformed element fails on the reference's message concatenation: TypeError)."""
+    the order the reference meets them (a malformed element: RuntimeError when it is a str, else the TypeError of the
+    reference's message concatenation)."""
     tree = SrsTree()
     if srs_tuple_list is None or len(srs_tuple_list) == 0:
         tree.add(0, np.inf, DEFAULT_STATE_RUN_SMOOTH)
         return tree
     for item in srs_tuple_list:
         if len(item) != 2:
-            raise TypeError('can only concatenate str (not "{}") to str'.format(type(item).__name__))
+            # the message is built by concatenation as in inv.py:573: a str element raises this RuntimeError, anything else
+            # the TypeError of the concatenation itself
+            raise RuntimeError('Element in "state run smooth" tuple list that is not length 2: ' + item)
     lower = factor = None
     for limit, value in sorted(srs_tuple_list):
         limit, value = int(limit), int(value)
@@ -442,6 +445,16 @@ def _drive(ctx, scans, params, max_batch_bp=64_000_000):
         live = nxt + rest
 
 
+def _check_k_size(k_util):
+    """k-mers are 2-bit packed into one 64-bit word on the device (k <= 31, ``PAV_E_LIMIT`` in include/pav_amd.h); kanapy's
+    Python integers have no such limit, so ``inv_k_size >= 32`` in config.json is refused here with the reason instead of a
+    generic device error - before any device work."""
+    k = int(k_util.k_size)
+    if not 1 <= k <= 31:
+        raise RuntimeError('k-mer size {} is not supported by pav_amd (1..31): k-mers are packed 2 bits per base into one '
+                           '64-bit word on the device; set inv_k_size <= 31'.format(k))
+
+
 def scan_for_inv(region_flag, ref_fa_name, tig_fa_name, align_lift, k_util, n_tree=None, max_region_size=None, threads=1,
                  log=None, srs_tree=None, min_exp_count=DEFAULT_MIN_EXP_COUNT, ctx=None, device_id=0):
     """
@@ -449,6 +462,7 @@ def scan_for_inv(region_flag, ref_fa_name, tig_fa_name, align_lift, k_util, n_tr
 
     :return: An ``InvCall`` describing the inversion found or ``None``.  ``threads`` is accepted for compatibility.
     """
+    _check_k_size(k_util)
     own = ctx is None
     if own:
         ctx = _lib.Context(device_id)
@@ -623,6 +637,7 @@ def scan_for_inv_batch(region_flags, ref_fa_name, tig_fa_name, align_lift, k_uti
 
     ``found_out``: where the 'INV Found: ...' lines the reference prints (pavlib/inv.py:408) go (native driver; default
     ``sys.stdout``) - callers that scan from several threads give each its own sink."""
+    _check_k_size(k_util)
     own = ctx is None
     if own:
         ctx = _lib.Context(device_id)
@@ -643,15 +658,19 @@ def scan_for_inv_batch(region_flags, ref_fa_name, tig_fa_name, align_lift, k_uti
         private = [io.StringIO() if want_text else None for _ in region_flags]
         scans = [_Scan(rf, ref_fa_name, tig_fa_name, align_lift, k_util, n_tree, max_region_size, private[i], srs_tree,
                        min_exp_count, ref_index, tig_index) for i, rf in enumerate(region_flags)]
-        _drive(ctx, scans, density.den_params(k=k_util.k_size))
-        if logs is not None:
-            for sink, buf in zip(logs, private):
-                if sink is not None and buf.getvalue():
-                    sink.write(buf.getvalue())
-                    sink.flush()
-        if log is not None:
-            log.write(''.join(buf.getvalue() for buf in private))
-            log.flush()
+        try:
+            _drive(ctx, scans, density.den_params(k=k_util.k_size))
+        finally:
+            # also when a scan raised: what the scans wrote so far reaches the caller's sinks, as with the reference's
+            # streaming log (pavlib/inv.py:623-640)
+            if logs is not None:
+                for sink, buf in zip(logs, private):
+                    if sink is not None and buf.getvalue():
+                        sink.write(buf.getvalue())
+                        sink.flush()
+            if log is not None:
+                log.write(''.join(buf.getvalue() for buf in private))
+                log.flush()
     finally:
         if own:
             ctx.close()

@@ -208,8 +208,10 @@ def _table(rows, columns):
 
 def scan_for_events(df, df_tig_fai, hap, ref_fa_name, tig_fa_name, k_size, n_tree=None, threads=1, log=sys.stdout,
                     density_out_dir=None, max_tig_dist_prop=None, max_ref_dist_prop=None, srs_tree=None, max_region_size=None,
-                    version_id=True, ctx=None, device_id=0):
-    """Same arguments and return value as ``pavlib.lgsv.scan_for_events``: ``(df_ins, df_del, df_inv)``."""
+                    version_id=False, ctx=None, device_id=0):
+    """Same arguments and return value as ``pavlib.lgsv.scan_for_events``: ``(df_ins, df_del, df_inv)``.  ``version_id``
+    defaults to ``False`` here (``True`` in the reference, pavlib/lgsv.py:31-36, whose only caller passes ``False``,
+    call_lg.snakefile:98): ``True`` raises, see below and INTEGRATION.md section 5."""
     if version_id:
         raise NotImplementedError('version_id=True needs svpoplib.variant.version_id (un-vendored submodule); '
                                   'rule call_lg_discover passes version_id=False (call_lg.snakefile:98)')
