@@ -86,7 +86,19 @@ def main():
     ap.add_argument('--eager-pack', action='store_true',
                     help='pack the whole contig arena at the start of every pass (PAV_EAGER_PACK=1: the round-1 behaviour) instead of on demand')
     ap.add_argument('--no-build', action='store_true', help='do not (re)build the libraries: the profile scripts build first, outside the profiler')
+    ap.add_argument('--repeats', type=int, default=5,
+                    help='the timed region of exactly K steps is run this many times back to back; `value` / `ms_per_step` are those of the '
+                         'median region (one region = K steps, so steps x ms_per_step is one timed region), min / max / all in `repeats`')
+    ap.add_argument('--reference', choices=['hg38', 'chm13'], default='hg38',
+                    help="'hg38' (default): the hg38-shaped reference of configs[1]-[3]; 'chm13': BASELINE configs[4] - T2T-CHM13v2.0 lengths, "
+                         'no N runs, seed 1005, the cohort batched --lanes (default 8) haplotypes per GPU against one resident reference; the '
+                         'line then carries `hbm` (peak use, pav_mem_info) and every lane\'s records_match vs the oracle')
     args = ap.parse_args()
+    if args.reference == 'chm13':
+        if args.seed == 1002:
+            args.seed = 1005                                   # config n uses seed 1000 + n
+        if args.lanes == 0:
+            args.lanes = 8
 
     # ---- before anything touches the GPU: the N-rank launch and the build ------------------------------------------------
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -137,6 +149,10 @@ def main():
     cpus_per_rank = effective_cpus() / max(1, world)
     n_lanes = args.lanes if args.lanes > 0 else (4 if cpus_per_rank >= 4 else (2 if cpus_per_rank >= 2 else 1))   # measured: 4 lanes want 4 cores, 2 want 2
     gen_kw = {'pair_frac': args.pair_frac} if args.workload == 'cigar+inv' and args.pair_frac > 0 else {}
+    if rank == 0:
+        print(f'[bench] {world} rank(s) x {n_lanes} lane(s) per GPU (--lanes {args.lanes}: 0 = auto), {cpus_per_rank:.1f} usable CPUs per rank '
+              f'(affinity / cgroup quota / world size), reference {args.reference}, {args.repeats} timed region(s) of {args.steps} steps',
+              file=sys.stderr, flush=True)
 
     # ---- synthetic inputs (host) -> HBM -----------------------------------------------------------------------
     # One lane = one haplotype resident on the GPU: its own context (streams, contigs, alignment tables, results) sharing the
@@ -152,7 +168,8 @@ def main():
             ln = Lane()
             ln.idx = li
             t0 = time.time()
-            ln.hap = synth.config2(seed=args.seed, scale=args.scale, hap_index=rank * n_lanes + li, ref=ref_, threads=threads, **gen_kw)
+            make_hap = synth.config5 if args.reference == 'chm13' else synth.config2
+            ln.hap = make_hap(seed=args.seed, scale=args.scale, hap_index=rank * n_lanes + li, ref=ref_, threads=threads, **gen_kw)
             ref_ = ln.hap.ref
             ln.t_gen = time.time() - t0
             ln.ctx = _lib.Context(local_rank)
@@ -169,6 +186,22 @@ def main():
             ln.t_h2d = time.time() - t0
             ln.tig_bases = int(sum(ln.hap.tig_seqs[n].shape[0] for n in ln.hap.tig_names))
             ln.tig_len = ln.hap.tig_lengths
+            ln.records_match = None
+            if args.reference == 'chm13' and not args.no_cpu_baseline:
+                # every resident haplotype against the oracle's scalar walk, while its host copy still exists (untimed)
+                from oracle import oracle
+                c_ = ln.ctx.cigar_call()
+                snv_, indel_, blob_ = ln.ctx.cigar_fetch(c_)
+                o_snv, o_indel, o_blob, err_ = oracle.cigar_call([ref_.seqs[n] for n in names_], [ln.hap.tig_seqs[n] for n in ln.hap.tig_names],
+                                                                 ln.aln, ln.text, ln.off)
+                ok_ = err_.kind == 0 and snv_.tobytes() == o_snv.tobytes() and blob_.tobytes() == o_blob.tobytes()
+                for f in o_indel.dtype.names:
+                    if f != 'pad':
+                        ok_ = ok_ and bool(np.array_equal(indel_[f], o_indel[f]))
+                st_ = ln.hap.stats
+                ok_ = ok_ and (c_.n_ops, c_.n_snv, c_.n_indel, c_.aligned_bases) == (st_['n_ops'], st_['n_snv'], st_['n_ins'] + st_['n_del'], st_['aligned_bp'])
+                ln.records_match = bool(ok_)
+                del snv_, indel_, blob_, o_snv, o_indel, o_blob
             if world > 1 or li > 0:                          # host copies are only needed for the N = 1 CPU baseline (lane 0)
                 ln.hap.tig_seqs.clear()
             lanes_.append(ln)
@@ -301,8 +334,14 @@ def main():
     warmup_run = max(args.warmup, 2 * n_lanes)
     run_steps(warmup_run)
 
-    # ---- timed region: exactly K steps, profiling off ---------------------------------------------------
-    t_local, t_max = timed(args.steps)
+    # ---- timed region: exactly K steps, profiling off; run R times back to back, the median region is the line's --------
+    free_min = [min(ln.ctx.mem_info()[0] for ln in lanes)]
+    regions = []
+    for _ in range(max(1, args.repeats)):
+        regions.append(timed(args.steps))
+        free_min.append(lanes[0].ctx.mem_info()[0])
+    order = sorted(range(len(regions)), key=lambda i: regions[i][1])
+    t_local, t_max = regions[order[len(order) // 2]]            # median by the max-over-ranks time (upper median for even R)
     counts = lanes[0].counts
     aligned_steps = float(sum(lanes[s % n_lanes].counts.aligned_bases for s in range(args.steps)))   # bp of the K passes of this rank
     if world > 1:
@@ -549,6 +588,7 @@ def main():
                       0.5 * n_snv)
         scan_bytes = 80.0 * scanned_bp
         sum_kernel_ms = sum(v['avg_ms'] * v['launches'] for v in kern.values()) / args.steps
+        t_single_s = t_single if t_single is not None else t_local      # --lanes 1: the timed region is the single lane
         roofline['path'] = {
             'bound': 'hbm', 'unit': 'GB/s', 'peak': HBM_PEAK_GBS,
             'algorithmic_bytes_per_step': {'cigar_call': round(path_bytes), 'kmer_scan': round(scan_bytes),
@@ -561,7 +601,12 @@ def main():
                             'regions (pack_spans_kernel), verify mode packs everything (DESIGN.md section 3.1)'),
             'sum_kernel_ms_per_step': round(sum_kernel_ms, 3),
             'ms_per_step_over_sum_kernel_ms': round(ms_per_step / sum_kernel_ms, 3) if sum_kernel_ms else None,
-            'single_lane_ms_per_step': None if t_single is None else round(t_single / args.steps * 1e3, 4),
+            'single_lane_ms_per_step': round(t_single_s / args.steps * 1e3, 4),
+            # ONE lane alone (one host thread, one haplotype, nothing of another haplotype beside it): its wall time per pass against
+            # the device work of a pass - 1.0 = the host never keeps the GPU waiting
+            'single_lane': {'ms_per_step': round(t_single_s / args.steps * 1e3, 4),
+                            'over_sum_kernel_ms': round(t_single_s / args.steps * 1e3 / sum_kernel_ms, 3) if sum_kernel_ms else None,
+                            'value': round(float(lanes[0].counts.aligned_bases) * args.steps / t_single_s / 1e9, 2), 'unit': 'Gbp/s'},
             'note': 'SURVEY 8(d) bytes of one pass / ms_per_step: the path is bound by scattered 64 B sector fetches, dependent '
                     'launches and host control, not by streamed bytes (DESIGN.md section 3); sum_kernel_ms_per_step = HIP-event '
                     'time of every kernel of one pass, measured with one lane running alone'}
@@ -753,7 +798,9 @@ def main():
                                    'DEL + INS pairs: MATCH_INDEL)'}
             inv_report = {'flagging': flag_report, 'scanned_loci': len(out),
                           'near_tie_guard': {'n_near_tie': int(sum(getattr(o, 'n_near_tie', 0) for o in out if o is not None and not isinstance(o, RuntimeError))),
-                                             'note': 'float decisions of the calls\' scans within 1e-9 (re-evaluated in scipy\'s order)'}, 'calls': sum(1 for o in out if o is not None and not isinstance(o, RuntimeError)),
+                                             'n_unresolved': int(sum(getattr(o, 'n_unresolved', 0) for o in out if o is not None and not isinstance(o, RuntimeError))),
+                                             'note': 'float decisions of the calls\' scans within 1e-9 (re-evaluated in scipy\'s order); '
+                                                     'n_unresolved: still within 1e-13 afterwards (must be 0 for the discrete outputs to be pinned)'}, 'calls': sum(1 for o in out if o is not None and not isinstance(o, RuntimeError)),
                           'planted': hap.stats['n_inv'], 'scan_iterations': iters, 'scanned_bp': scanned,
                           'device_ms_per_step': round(sum(v['avg_ms'] * v['launches'] for v in den.values()) / args.steps, 3),
                           'host_ms': {'align_table_once': round(lanes[0].t_lift_ms, 1), 'scan_for_inv_batch_last_step': round(lanes[0].t_scan_ms, 1)},
@@ -766,18 +813,29 @@ def main():
             'metric': metric,
             'value': round(value, 2), 'unit': 'Gbp/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'u8/u32 (integer + byte)', 'data': 'synthetic',
+            'dtype': 'u8/u32 + f64 (KDE)', 'data': 'synthetic',
             'config': {'workload': ('BASELINE configs[1]: one hg38-shaped haplotype, CIGAR-call only, one haplotype per GPU'
                                     if args.workload == 'cigar' else
-                                    f'BASELINE configs[2] / [3] per-GPU share: {n_lanes} hg38-shaped haplotype(s) (h1 + h2 of phased diploid samples) '
+                                    (f'BASELINE configs[4] per-GPU batch: {n_lanes} haplotype(s) of the synthetic cohort vs a T2T-CHM13-shaped reference '
+                                     '(24 sequences, CHM13v2.0 lengths, no N runs) ' if args.reference == 'chm13' else
+                                     f'BASELINE configs[2] / [3] per-GPU share: {n_lanes} hg38-shaped haplotype(s) (h1 + h2 of phased diploid samples) ') +
                                     'resident per GPU against one resident reference; a step = one haplotype through CIGAR-call + '
                                     'signature flagging + k-mer inversion density scan of every locus the flagging marks TRY_INV; the '
                                     'steps go round the haplotypes (configs[1] = CIGAR-call only: see cigar_only)'),
                        'scale': args.scale, 'seed': args.seed, 'aligned_bp_per_gpu': int(counts.aligned_bases),
                        'n_aln': int(aln.shape[0]), 'n_ops': int(n_ops), 'n_snv': int(n_snv), 'n_indel': int(n_indel),
-                       'lanes_per_gpu': n_lanes, 'pair_frac': args.pair_frac if gen_kw else 0.0, 'warmup_steps_run': warmup_run,
+                       'lanes_per_gpu': n_lanes, 'lanes_arg': args.lanes, 'usable_cpus_per_rank': round(cpus_per_rank, 2),
+                       'reference': args.reference,
+                       'pair_frac': args.pair_frac if gen_kw else 0.0, 'warmup_steps_run': warmup_run,
                        'call_tables': 'copied to pinned host memory inside the step' if args.eager_tables else 'resident in HBM (D2H in host.d2h_density_tables_s)',
                        'parallelism': f'{world} GPU(s) x {n_lanes} resident haplotype(s), one host thread each; no collective'},
+            'repeats': {'regions': len(regions), 'steps_per_region': args.steps, 'choice': 'median region by max-over-ranks time',
+                        'ms_per_step_median': round(t_max / args.steps * 1e3, 4),
+                        'ms_per_step_min': round(min(r[1] for r in regions) / args.steps * 1e3, 4),
+                        'ms_per_step_max': round(max(r[1] for r in regions) / args.steps * 1e3, 4),
+                        'ms_per_step_all': [round(r[1] / args.steps * 1e3, 4) for r in regions],
+                        'value_min': round(aligned_total / max(r[1] for r in regions) / 1e9, 2),
+                        'value_max': round(aligned_total / min(r[1] for r in regions) / 1e9, 2)},
             'per_rank': per_rank,
             'load_balance': {'max_over_mean_ms': round(max(r['ms_per_step'] for r in per_rank) / (sum(r['ms_per_step'] for r in per_rank) / len(per_rank)), 4),
                              'max_over_mean_cigar_text': round(max(r['cigar_text_bytes'] for r in per_rank) /
@@ -793,6 +851,14 @@ def main():
                 'achieved': round(tig_bases * 1.375 / (pack_alone[1] / pack_alone[0] * 1e-3) / 1e9, 1), 'unit': 'GB/s', 'peak': HBM_PEAK_GBS,
                 'frac': round(tig_bases * 1.375 / (pack_alone[1] / pack_alone[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 'in_the_path': bool(eager_pack)},
+            'hbm': {'total_gb': round(lanes[0].ctx.mem_info()[1] / 1e9, 1),
+                    'peak_used_gb': round((lanes[0].ctx.mem_info()[1] - min(free_min)) / 1e9, 2),
+                    'resident_haplotypes': n_lanes,
+                    'records_match_per_lane': [ln.records_match for ln in lanes],
+                    'note': 'pav_mem_info around every timed region (minimum free seen): one packed reference + per haplotype its contig '
+                            'ASCII arena and on-demand planes, alignment tables, call records, flagging and density scratch, call tables; '
+                            'records_match_per_lane: every resident haplotype\'s SNV / INDEL / SEQ records vs the oracle\'s scalar walk '
+                            'and the generator\'s counts, checked once before the timed region (--reference chm13 only, else null)'},
             'host': {'generate_s': round(t_gen, 1), 'h2d_and_ref_pack_s': round(t_h2d, 2), 'd2h_records_s': round(t_d2h, 3),
                      'd2h_density_tables_s': None if t_d2h_tables is None else round(t_d2h_tables, 4),
                      'density_tables_mb': None if tables_mb is None else round(tables_mb, 1),

@@ -332,14 +332,24 @@ def config1(seed=1001):
     return hap
 
 
-def config2(seed=1002, scale=1.0, hap_index=0, ref=None, lengths=None, threads=8, **kw):
-    """One haplotype vs an hg38-shaped reference (24 sequences); ``scale`` shrinks every length."""
+def config2(seed=1002, scale=1.0, hap_index=0, ref=None, lengths=None, threads=8, n_runs=True, **kw):
+    """One haplotype vs an hg38-shaped reference (24 sequences); ``scale`` shrinks every length.  ``n_runs=False``: a
+    reference without N runs (a T2T assembly)."""
     if ref is None:
+        n_every = int(50_000_000 * max(scale, 0.02)) if scale < 1 else 50_000_000
         ref = make_reference(seed, scaled_lengths(lengths or HG38_LENGTHS, scale), threads=threads,
-                             n_every=int(50_000_000 * max(scale, 0.02)) if scale < 1 else 50_000_000,
+                             n_every=n_every if n_runs else 0,
                              inv_every=int(25_000_000 * max(scale, 0.02)) if scale < 1 else 25_000_000)
     med = max(20_000, int(1_000_000 * min(1.0, scale * 10)))
     return make_haplotype(ref, seed * 64 + hap_index, f'h{hap_index + 1}', seg_median=med, threads=threads, **kw)
+
+
+def config5(seed=1005, scale=1.0, hap_index=0, ref=None, threads=8, **kw):
+    """BASELINE.json configs[4]: one haplotype of the synthetic cohort against a
+    T2T-CHM13-shaped reference - 24 sequences with the CHM13v2.0 lengths (3.1 Gbp), no N runs; the cohort is
+    ``hap_index`` = 0..63 (32 samples x h1 / h2), batched 8 per GPU against ONE resident reference."""
+    return config2(seed=seed, scale=scale, hap_index=hap_index, ref=ref, lengths=CHM13_LENGTHS, threads=threads,
+                   n_runs=False, **kw)
 
 
 # ---------------------------------------------------------------------------------------------------------

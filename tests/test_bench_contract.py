@@ -1,81 +1,104 @@
-"""The bench line contract (driver + judge read it): checked on the committed round profiles, which are verbatim outputs of
-bench.py on an MI355X (tools/scripts/profile_round.sh).  No GPU needed."""
+"""The bench line contract (driver + judge read it), checked on a line bench.py produces HERE: the GPU test runs
+``bench.py --scale 0.01`` on the box and checks the schema and the line's internal arithmetic - every figure that is derived
+from another must follow from it.  No absolute performance number is asserted (a committed profile is an artefact, not
+behaviour); what a regression of bench.py would break is asserted."""
 import json
 import os
+import subprocess
+import sys
 
 import pytest
 
-PROFILES = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles')
-BASELINE = os.path.join(os.path.dirname(PROFILES), 'BASELINE.json')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def load(name):
-    with open(os.path.join(PROFILES, name)) as fh:
-        return json.loads(fh.read().strip().splitlines()[-1])
+def _base():
+    with open(os.path.join(ROOT, 'BASELINE.json')) as fh:
+        return json.load(fh)
 
 
-@pytest.mark.parametrize('name', ['r01_full_path_bench.json', 'r01_cigar_only_bench.json', 'r02_full_path_bench.json',
-                                  'r02_cigar_only_bench.json'])
-def test_bench_line_has_the_contract_fields(name):
-    line = load(name)
+def test_bench_flags_and_metric_name_without_a_gpu():
+    """The driver's command line parses, and the metric string is BASELINE.json's (no GPU: --help stops before any device work)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--help'], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    for flag in ('--gpus', '--steps', '--warmup', '--lanes', '--repeats', '--reference', '--workload'):
+        assert flag in out.stdout, flag
+    with open(os.path.join(ROOT, 'bench.py')) as fh:
+        assert repr(_base()['metric']) in fh.read()
+
+
+def _run_bench(*extra):
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--scale', '0.01', '--steps', '4', '--warmup', '2', '--repeats', '3',
+           '--cpu-sample-regions', '12'] + list(extra)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, 'bench.py must print exactly one JSON line'
+    return json.loads(lines[0]), out.stderr
+
+
+@pytest.fixture(scope='module')
+def line(built):
+    return _run_bench()
+
+
+@pytest.mark.gpu
+def test_bench_line_schema_and_arithmetic(line):
+    line, stderr = line
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
-                'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+                'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'repeats', 'per_rank', 'hbm'):
         assert key in line, key
+    assert line['metric'] == _base()['metric']
     assert line['unit'] == 'Gbp/s' and line['higher_is_better'] is True and line['scaling'] == 'weak' and line['vs_baseline'] is None
     assert line['data'] == 'synthetic' and 'workload' in line['config'] and 'model' not in line['config']
-    # value = aligned bp of the timed passes (all ranks) / slowest rank's time; round 2 lists every rank's bp per pass
-    per_pass = sum(r['aligned_bp'] for r in line['per_rank']) if 'per_rank' in line else line['config']['aligned_bp_per_gpu'] * line['n_gpus']
+    assert (line['n_gpus'], line['steps'], line['warmup']) == (1, 4, 2)
+    assert 'f64' in line['dtype'] and 'u8' in line['dtype']                      # integer / byte path + the FP64 kernel densities
+    # value = aligned bp of the K passes of one region / that region's time
+    per_pass = sum(r['aligned_bp'] for r in line['per_rank'])
     assert abs(line['value'] - per_pass / (line['ms_per_step'] * 1e-3) / 1e9) < 0.01 * line['value']
+    # the repeated timed region: the line is the median region, the spread is reported
+    rep = line['repeats']
+    assert rep['regions'] == 3 and rep['steps_per_region'] == line['steps'] and len(rep['ms_per_step_all']) == 3
+    assert rep['ms_per_step_median'] == line['ms_per_step'] == sorted(rep['ms_per_step_all'])[1]
+    assert rep['ms_per_step_min'] <= line['ms_per_step'] <= rep['ms_per_step_max'] and rep['value_min'] <= line['value'] <= rep['value_max']
+    cfg = line['config']
+    assert cfg['lanes_per_gpu'] >= 1 and cfg['usable_cpus_per_rank'] > 0 and 'lanes_arg' in cfg and cfg['reference'] == 'hg38'
+    assert str(cfg['lanes_per_gpu']) + ' lane(s) per GPU' in stderr                # said up front, where a scaling run's reader sees it
     r = line['roofline']
     assert r['bound'] in ('hbm', 'mfma') and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
     if r['bound'] == 'hbm':
         assert r['unit'] == 'GB/s' and r['peak'] == 8000.0
-        assert abs(r['achieved'] - r['algorithmic_bytes_per_launch'] / (r['avg_kernel_ms'] * 1e-3) / 1e9) < 0.01 * r['achieved']
-        if 'isolated_sectors' in r:
-            # a kernel that fetches isolated bytes (walk_snv): its traffic is judged against one 32 B sector per byte, and its
-            # rate against the measured isolated-sector rate of the HBM system (tools/ubench/gather_rate.hip)
-            sec = r['isolated_sectors']
-            assert abs(sec['achieved_gsectors_per_s'] - sec['per_launch'] / (r['avg_kernel_ms'] * 1e-3) / 1e9) < 0.02 * sec['achieved_gsectors_per_s']
-            assert 0.8 < line['roofline']['traffic_over_algorithmic']['walk_snv_over_sector_granular_model'] < 1.2
-        else:
-            assert r['traffic'] is None or 0.9 < r['traffic'] / r['algorithmic_bytes_per_launch'] < 1.5     # no wasted re-reads
-    else:                                                              # the kernel densities: FP64 vector flops (25 per pair)
+        assert abs(r['achieved'] - r['algorithmic_bytes_per_launch'] / (r['avg_kernel_ms'] * 1e-3) / 1e9) < 0.01 * r['achieved'] + 0.1
+    else:
         assert r['unit'] == 'TFLOP/s' and r['peak'] == 78.6
-        assert abs(r['achieved'] - r['algorithmic_flops_per_launch'] / (r['avg_kernel_ms'] * 1e-3) / 1e12) < 0.01 * r['achieved']
+    p = r['path']
+    total = p['algorithmic_bytes_per_step']['cigar_call'] + p['algorithmic_bytes_per_step']['kmer_scan']
+    assert abs(p['achieved'] - total / (line['ms_per_step'] * 1e-3) / 1e9) < 0.01 * p['achieved'] + 0.1
+    assert abs(p['frac'] - p['achieved'] / 8000.0) < 1e-3
+    assert p['sum_kernel_ms_per_step'] > 0 and p['single_lane'] ['ms_per_step'] > 0
+    assert abs(p['single_lane']['over_sum_kernel_ms'] - p['single_lane']['ms_per_step'] / p['sum_kernel_ms_per_step']) < 0.01
     c = line['cpu_baseline']
     assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['unit'] == 'Gbp/s' and c['sample']
-    assert c['records_match_gpu'] is True
-
-
-def test_round2_line_carries_the_path_roofline_and_the_reference_figures():
-    line = load('r02_full_path_bench.json')
-    p = line['roofline']['path']
-    total = p['algorithmic_bytes_per_step']['cigar_call'] + p['algorithmic_bytes_per_step']['kmer_scan']
-    assert abs(p['achieved'] - total / (line['ms_per_step'] * 1e-3) / 1e9) < 0.01 * p['achieved']
-    assert abs(p['frac'] - p['achieved'] / 8000.0) < 1e-3 and p['frac'] < 0.2           # the path is not byte-bound, and says so
-    assert p['ms_per_step_over_sum_kernel_ms'] <= 1.15                                  # the step is device-bound
-    ratios = line['roofline']['traffic_over_algorithmic']
-    assert ratios['source'] == 'profiles/r02_pmc.json'
-    # the streaming pack of the whole contig arena left the path this round (planes on demand); it is still measured, alone
-    pack = line['contig_pack_alone']
-    assert pack['in_the_path'] is False and pack['frac'] > 0.7 and line['roofline']['path']['algorithmic_bytes_per_step']['contig_pack_not_in_the_model'] == 0
-    assert 0.8 < ratios['walk_snv_over_sector_granular_model'] < 1.2                     # walk_snv: one sector per isolated byte
-    ref = line['cpu_baseline']['reference_python']
-    assert ref['cigar_call_Mbp_per_s'] == 2.1 and ref['density_scan_kbp_per_s'] == 2.5 and 'hardware' in ref
-    assert line['host']['cpu_baseline_cores_all'] == line['cpu_baseline']['all_cores']['cores']
-    assert line['config']['lanes_per_gpu'] >= 1 and line['config']['call_tables'].startswith('resident in HBM')
-    assert line['value'] > 1.5 * load('r01_full_path_bench.json')['value']
-
-
-@pytest.mark.parametrize('name', ['r01_full_path_bench.json', 'r02_full_path_bench.json'])
-def test_headline_is_the_whole_metric_path(name):
-    with open(BASELINE) as fh:
-        base = json.load(fh)
-    line = load(name)
-    assert line['metric'] == base['metric']
-    assert line['inv_scan']['calls'] > 0 and line['inv_scan']['flagging']['planted_inversions_flagged'] > 0
-    assert line['cpu_baseline']['density_tables_match_gpu'] is True
+    assert c['records_match_gpu'] is True and c['density_tables_match_gpu'] is True
+    assert c['reference_python']['cigar_call_Mbp_per_s'] == 2.1 and 'hardware' in c['reference_python']
+    inv = line['inv_scan']
+    assert inv['calls'] > 0 and inv['flagging']['planted_inversions_flagged'] > 0
+    assert inv['near_tie_guard']['n_unresolved'] == 0 and inv['near_tie_guard']['n_near_tie'] >= 0
     co = line['cigar_only']                                                     # BASELINE configs[1] measured in the same run
-    assert co['unit'] == 'Gbp/s' and co['value'] > line['value']
-    assert co['roofline']['kernel'] == ('pack_kernel' if name.startswith('r01') else 'walk_snv')    # r02: no full pack in the path
-    assert line['value'] >= 50.0                                                # north-star target on one MI355X
+    assert co['unit'] == 'Gbp/s' and co['value'] > line['value'] and co['roofline']['bound'] == 'hbm'
+    v = line['verify_mode']
+    assert v['bases_contradicting_the_cigar'] == 0 and v['bases_checked'] == line['config']['aligned_bp_per_gpu']
+    h = line['hbm']
+    assert 0 < h['peak_used_gb'] < h['total_gb'] and h['resident_haplotypes'] == cfg['lanes_per_gpu']
+
+
+@pytest.mark.gpu
+def test_bench_chm13_cohort_batch_in_small(built):
+    """BASELINE configs[4] through bench.py's own switch, shrunk: T2T-CHM13-shaped reference, eight haplotypes resident against
+    it, the whole path on all eight lanes; every lane's records are checked against the oracle before the timed region."""
+    line, _ = _run_bench('--reference', 'chm13', '--scale', '0.004')
+    cfg = line['config']
+    assert cfg['reference'] == 'chm13' and cfg['lanes_per_gpu'] == 8 and cfg['seed'] == 1005 and 'configs[4]' in cfg['workload']
+    assert line['hbm']['records_match_per_lane'] == [True] * 8
+    assert line['inv_scan']['calls'] > 0 and line['inv_scan']['near_tie_guard']['n_unresolved'] == 0
+    assert line['value'] > 0

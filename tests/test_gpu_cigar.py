@@ -112,6 +112,37 @@ def test_tables_byte_exact_vs_reference(built, gpu_ctx, case):
     assert util.frame_text(df_insdel) == util.golden_text(case, 'insdel')
 
 
+def test_config1_one_megabase_contig(built, gpu_ctx, tmp_path):
+    """BASELINE.json configs[0]: one 1 Mb contig vs a 1 Mb chr20 slice through the drop-in entry point
+    (make_insdel_snv_calls, from FASTA files as the rule calls it).  The tables as text equal what pavlib.cigarcall itself wrote
+    for the same seeded input (tests/golden/config1.json, digests), the native writer produces the same bytes, and every device
+    record equals the oracle's."""
+    hap, gold = util.config1_case()
+    names = hap.ref.names
+    ref_fa, tig_fa = str(tmp_path / 'ref.fa'), str(tmp_path / 'tig.fa')
+    synth.write_fasta(ref_fa, names, hap.ref.seqs, line=80)
+    synth.write_fasta(tig_fa, hap.tig_names, hap.tig_seqs, line=80)
+    df_snv, df_insdel = cigarcall.make_insdel_snv_calls(hap.df_align, ref_fa, tig_fa, 'h1', version_id=False, ctx=gpu_ctx)
+    util.assert_config1_tables(rules.apply_trim_filter(df_snv, hap.df_trim), rules.apply_trim_filter(df_insdel, hap.df_trim), gold)
+    # records vs the oracle (same marshalled inputs)
+    snv, indel, blob, counts = cigarcall.call_records(gpu_ctx, hap.df_align)
+    o_snv, o_indel, o_blob, err = util.oracle_records(names, [hap.ref.seqs[n] for n in names], hap.tig_names,
+                                                      [hap.tig_seqs[n] for n in hap.tig_names], hap.df_align)
+    assert err.kind == 0
+    util.assert_records_equal(snv, o_snv, 'snv')
+    util.assert_records_equal(indel, o_indel, 'indel')
+    assert blob.tobytes() == o_blob.tobytes()
+    assert (counts.n_ops, counts.aligned_bases) == (hap.stats['n_ops'], hap.stats['aligned_bp'])
+    # the native table writer on the same resident records
+    index = hap.df_align['INDEX'].to_numpy(dtype='int64')
+    trim = hap.df_trim[['POS', 'END', 'INDEX']].set_index('INDEX').astype(int).reindex(list(index), fill_value=-1)
+    o1, o2 = str(tmp_path / 'snv.bed'), str(tmp_path / 'insdel.bed')
+    gpu_ctx.cigar_write_tables('h1', index, trim['POS'].to_numpy(dtype='int64'), trim['END'].to_numpy(dtype='int64'), o1, o2)
+    for name, path in (('snv', o1), ('insdel', o2)):
+        with open(path, 'rb') as fh:
+            util.assert_config1_text(name, fh.read(), gold)
+
+
 def test_public_entry_point(built, gpu_ctx, tmp_path):
     """make_insdel_snv_calls / rules.call_cigar: the drop-in surface, from files, all 10 batches merged."""
     d, df_align, df_trim = util.golden_case('cigar_synth')

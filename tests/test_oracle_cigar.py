@@ -26,6 +26,20 @@ def test_tables_byte_exact(built, case):
     assert util.frame_text(df_insdel) == util.golden_text(case, 'insdel')
 
 
+def test_config1_one_megabase_contig_vs_reference_digest(built):
+    """BASELINE.json configs[0] (one 1 Mb contig vs a 1 Mb chr20 slice, the reference's own CPU-runnable case): the oracle's
+    tables, with the FILTER of rule call_cigar, as text == what pavlib.cigarcall wrote for the same seeded input in the build
+    container (md5 committed by tools/refharness/gen_golden_cigar.py; the 2 MB of sequence are regenerated from the seed)."""
+    from pav_amd import cigarcall, rules
+    hap, gold = util.config1_case()
+    names = hap.ref.names
+    snv, indel, blob, err = util.oracle_records(names, [hap.ref.seqs[n] for n in names], hap.tig_names,
+                                                [hap.tig_seqs[n] for n in hap.tig_names], hap.df_align)
+    assert err.kind == 0
+    df_snv, df_insdel = cigarcall.records_to_frames(snv, indel, blob, hap.df_align, 'h1')
+    util.assert_config1_tables(rules.apply_trim_filter(df_snv, hap.df_trim), rules.apply_trim_filter(df_insdel, hap.df_trim), gold)
+
+
 def test_empty_table(built):
     d, df_align, df_trim = util.golden_case('cigar_empty')
     df_snv, df_insdel = util.oracle_frames(d, df_align, df_trim, with_filter=False)

@@ -75,3 +75,31 @@ def assert_records_equal(a, b, what):
             continue
         bad = np.flatnonzero(a[name] != b[name])
         assert bad.size == 0, f'{what}.{name}: {bad.size} mismatches, first at {bad[0]}: {a[bad[0]]} vs {b[bad[0]]}'
+
+
+def config1_case():
+    """BASELINE.json configs[0] regenerated from its seed + the digests of what pavlib wrote for it (tests/golden/config1.json,
+    written by tools/refharness/gen_golden_cigar.py).  Asserts that the generator still produces the inputs the reference saw."""
+    import hashlib
+    from pav_amd import synth
+    with open(os.path.join(GOLD, 'config1.json')) as fh:
+        gold = json.load(fh)
+    hap = synth.config1()
+    md5 = lambda b: hashlib.md5(b).hexdigest()   # noqa: E731
+    assert md5(hap.ref.seqs['chr20'].tobytes()) == gold['inputs']['ref_md5'], 'synth.config1() no longer generates the committed case'
+    assert md5(b''.join(hap.tig_seqs[n].tobytes() for n in hap.tig_names)) == gold['inputs']['tig_md5']
+    assert md5(hap.df_align.to_csv(sep='\t', index=False).encode()) == gold['inputs']['align_tsv_md5']
+    return hap, gold
+
+
+def assert_config1_text(name, text, gold):
+    import hashlib
+    assert len(text) == gold[name]['tsv_bytes'], name
+    assert hashlib.md5(text).hexdigest() == gold[name]['tsv_md5'], f'{name} table differs from what pavlib wrote for configs[0]'
+
+
+def assert_config1_tables(df_snv, df_insdel, gold):
+    """The two tables of rule call_cigar as text against the digests of the reference's own output."""
+    for name, df in (('snv', df_snv), ('insdel', df_insdel)):
+        assert df.shape[0] == gold[name]['rows'], name
+        assert_config1_text(name, frame_text(df).encode(), gold)

@@ -6,7 +6,8 @@ Generate the CIGAR-call golden vectors by running the *reference itself* (pavlib
 Outputs (committed): tests/golden/cigar_<case>/
     ref.fa(.fai)  tig.fa(.fai)  align.tsv  trim.tsv        inputs
     snv.tsv  insdel.tsv                                    what rule call_cigar writes (incl. FILTER)
-and tests/golden/cigar_errors.json, tests/golden/kat.json (homology / tokenizer / Region known answers).
+and tests/golden/cigar_errors.json, tests/golden/kat.json (homology / tokenizer / Region known answers),
+tests/golden/config1.json (BASELINE configs[0]: digests of the reference's output on the regenerable 1 Mb case).
 
 The FILTER step is the body of rule call_cigar (rules/call.snakefile:813-842), a Snakemake ``run:`` block that
 cannot be imported; it is restated below on the frames the reference function returned.
@@ -296,8 +297,50 @@ def case_kat():
     print('kat', len(hom), 'homology answers;', len(tok), 'tokenizer answers')
 
 
+# ---------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[0]: one 1 Mb contig vs a 1 Mb "chr20 slice" through pavlib.cigarcall itself.
+# The 2 MB of sequence are regenerated from the seed (pav_amd.synth.config1) wherever the case is needed; what is committed
+# is the digest of what the reference wrote for it: tests/golden/config1.json (md5 of the two TSV texts, row counts, and the
+# md5 of the generated inputs, so that a drifting generator is told apart from a drifting caller).
+# ---------------------------------------------------------------------------------------------------------
+
+def case_config1():
+    import hashlib
+    import tempfile
+    import time
+    hap = synth.config1()
+    with tempfile.TemporaryDirectory(prefix='pav_config1_') as d:
+        synth.write_fasta(os.path.join(d, 'ref.fa'), hap.ref.names, hap.ref.seqs, line=80)
+        synth.write_fasta(os.path.join(d, 'tig.fa'), hap.tig_names, hap.tig_seqs, line=80)
+        t0 = time.time()
+        snv, insdel = run_reference(d, hap.df_align, hap.df_trim)
+        wall = time.time() - t0
+        text = {}
+        for name in ('snv', 'insdel'):
+            with open(os.path.join(d, name + '.tsv'), 'rb') as fh:
+                text[name] = fh.read()
+    md5 = lambda b: hashlib.md5(b).hexdigest()   # noqa: E731
+    align_text = hap.df_align.to_csv(sep='\t', index=False).encode()
+    out = {
+        'config': 'BASELINE.json configs[0]: pav_amd.synth.config1(seed=1001) - one 1 Mb contig vs a 1 Mb chr20 slice',
+        'reference': 'pavlib.cigarcall.make_insdel_snv_calls(version_id=False) + the FILTER step of rule call_cigar '
+                     '(rules/call.snakefile:813-842), run by tools/refharness/gen_golden_cigar.py',
+        'inputs': {'ref_md5': md5(hap.ref.seqs['chr20'].tobytes()),
+                   'tig_md5': md5(b''.join(hap.tig_seqs[n].tobytes() for n in hap.tig_names)),
+                   'align_tsv_md5': md5(align_text), 'n_aln': int(hap.df_align.shape[0])},
+        'snv': {'rows': int(snv.shape[0]), 'tsv_md5': md5(text['snv']), 'tsv_bytes': len(text['snv'])},
+        'insdel': {'rows': int(insdel.shape[0]), 'tsv_md5': md5(text['insdel']), 'tsv_bytes': len(text['insdel']),
+                   'max_left_shift': int(insdel['LEFT_SHIFT'].max())},
+    }
+    with open(os.path.join(GOLD, 'config1.json'), 'w') as fh:
+        json.dump(out, fh, indent=1)
+        fh.write('\n')
+    print('config1', snv.shape, insdel.shape, 'reference wall %.2f s' % wall)
+
+
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)
     case_synth()
     case_edge()
     case_kat()
+    case_config1()
