@@ -192,7 +192,6 @@ __global__ __launch_bounds__(256) void row_ops(const uint8_t *__restrict__ text,
     }
 }
 
-// ---- the walk --------------------------------------------------------------------------------------------
 __device__ __forceinline__ void op_contrib(uint32_t op, uint64_t (&c)[NQ]) {
     const uint32_t code = op & 15u;
     const uint64_t len = op >> 4;
@@ -205,6 +204,324 @@ __device__ __forceinline__ void op_contrib(uint32_t op, uint64_t (&c)[NQ]) {
     c[5] = (eq || x) ? len : 0;                   // aligned bases (metric numerator)
 }
 
+// ---- tile tokenizer (pav_cigar_call) ------------------------------------------------------------------------
+// The call path tokenises and sums in ONE pass and has no host-visible intermediate: a 4096-byte text tile holds at most 2048
+// valid operations (>= one digit + the operation character each), so tile t owns the 2048 operation slots
+// [t * 2048, (t + 1) * 2048) of a PADDED operation array - its operations first, OP_PAD (no operation) behind them - and the
+// 2048-operation chunk every walk / verify workgroup works on IS the tile: nothing has to be counted before an operation can be
+// stored, and the exclusive prefix a chunk needs is the prefix over the tiles before it (tile_scan, one workgroup per
+// quantity).  "Slot ordinal" s = t * 2048 + i is monotone in walk order; the real ordinal of the operation in slot s is
+// tile_pre[NQ][t] + i.  (Round 2: tok_count -> scan_counts -> host sync -> tok_emit -> row_ops -> walk_reduce -> walk_chunks ->
+// row_base -> row_check = eight launches and a synchronisation for what tok_tiles + tile_scan do; a single-pass scan with
+// decoupled look-back was not taken: a hand-off between workgroups costs 1 - 3 us on this chip (per-XCD L2s, agent-scope
+// release / acquire) and 8.5 k tiles advance 64 per hop at best - slower than one more kernel boundary.)
+constexpr uint32_t OP_PAD = 0xFu;        // code 15, length 0: contributes nothing, is no operation (op_contrib, walk_emit)
+constexpr int NT = NQ + 1;               // per-tile sums: the NQ walk quantities + [NQ] the operation count
+static_assert(TOK_CHUNK == 2 * WALK_CHUNK, "a text tile owns one chunk of operation slots");
+
+constexpr uint64_t op_lut(bool hi) {     // nibble (c & 15) of the half selected by (c & 16): BAM code of the character, 15 = none
+    uint64_t v = ~0ull;
+    const char ops[] = "MIDNSHP=X";
+    for (int k = 0; k < 9; ++k) {
+        const int idx = ops[k] & 31;
+        if ((idx >= 16) == hi) { const int sh = 4 * (idx & 15); v = (v & ~(0xFull << sh)) | ((uint64_t)k << sh); }
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t op_code_lut(uint32_t c) {      // the nine characters differ in (c & 31); '=' is the one below 64
+    const uint64_t lut = (c & 16u) ? op_lut(true) : op_lut(false);
+    const uint32_t code = (uint32_t)(lut >> (4u * (c & 15u))) & 15u;
+    return (c >> 5) == (code == 7u ? 1u : 2u) ? code : 15u;
+}
+// bit i (0..3): byte i of x is not an ASCII digit
+__device__ __forceinline__ uint32_t nondigit4(uint32_t x) {
+    const uint32_t t = x ^ 0x30303030u;                                // digits become 0..9
+    uint32_t nz = ((((t & 0x7F7F7F7Fu) + 0x76767676u) | t) & 0x80808080u) >> 7;
+    return (nz | (nz >> 7) | (nz >> 14) | (nz >> 21)) & 0xFu;
+}
+__device__ __forceinline__ uint32_t nondigit16(const uint4 &v) {
+    return nondigit4(v.x) | nondigit4(v.y) << 4 | nondigit4(v.z) << 8 | nondigit4(v.w) << 12;
+}
+struct TokArgs {
+    const uint8_t *text; uint64_t T;                 // text bytes (the buffer is padded with '0' to whole tiles)
+    const uint64_t *text_off; uint32_t n_aln, n_tiles;
+    uint32_t *ops;                                   // [n_tiles * 2048] padded operations
+    uint64_t *tile_agg;                              // [NT][n_tiles + 1]
+    uint32_t *tile_last;                             // [n_tiles] last operation of the tile (OP_PAD: none)
+    uint32_t *chunk_row;                             // [n_tiles] a row at or before the row of the tile's first operation
+    uint64_t *op_slot;                               // [n_aln + 1] slot ordinal of the row's first operation
+    uint32_t *row_tile, *row_i;                      // [n_aln + 1] that slot as (tile, index)
+    uint64_t *row_local;                             // [2 (n_aln + 1)] reference / query advance of the tile's operations before it
+    unsigned long long *tok_err, *err_op;
+};
+
+// Token error at the operation character at global byte position pos (rare path): the key is the byte position of the
+// token's first digit, as the sequential tokenizer would report it.
+__device__ __noinline__ void tok_error(const uint8_t *__restrict__ text, uint64_t pos, int kind, unsigned long long *tok_err) {
+    uint64_t g = pos;
+    while (g > 0 && is_digit(text[g - 1])) --g;
+    atomicMin(tok_err, (unsigned long long)(g << 3 | (uint64_t)kind));
+}
+// Exact length of the token whose operation character is at pos, however many digits it has (rare path: > 9 digits behind it)
+__device__ __noinline__ uint32_t tok_long_value(const uint8_t *__restrict__ text, uint64_t pos) {
+    uint64_t g = pos;
+    while (g > 0 && is_digit(text[g - 1])) --g;
+    uint32_t val = 0;
+    for (; g < pos; ++g) { const uint32_t nv = val * 10u + (uint32_t)(text[g] - '0'); val = val >= (1u << 28) ? val : nv; }
+    return val;
+}
+
+// First index in [0, n) with off[idx] >= key (n when none): 64-ary search by one wave, uniform result; a handful of L2 reads.
+__device__ __forceinline__ uint32_t row_lower_bound(const uint64_t *__restrict__ off, uint32_t n, uint64_t key, uint32_t lane) {
+    uint32_t lo = 0, hi = n;                            // off[i] < key for i < lo, off[i] >= key for i >= hi
+    while (hi > lo) {
+        const uint32_t step = (hi - lo + 63) / 64;
+        const uint32_t idx = lo + lane * step;
+        const bool below = idx < hi && off[idx] < key;
+        const uint32_t nb = (uint32_t)__popcll(__ballot(below));      // probes below the key: a prefix, off is sorted
+        if (step == 1) return lo + nb;
+        const uint32_t nhi = nb < 64 && lo + nb * step < hi ? lo + nb * step : hi;
+        lo = nb ? lo + (nb - 1) * step + 1 : lo;
+        hi = nb ? nhi : lo;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void tok_tiles(TokArgs A) {
+    __shared__ uint32_t s_ops[TOK_CHUNK + 8];          // the tile's operations, compact (a malformed tile can hold 4096 characters)
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint16_t s_mask[256], s_pre[256];       // per lane: non-digit bits of its 16 bytes, operations before them
+    __shared__ uint64_t s_red[4 * NT];
+    __shared__ uint64_t s_adv[2 * 256];                // per lane: reference / query advance of the tile's operations before its eight
+    const uint32_t t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t b0 = (uint64_t)t * TOK_CHUNK, p0 = b0 + (uint64_t)threadIdx.x * 16;
+    const uint4 v = *reinterpret_cast<const uint4 *>(A.text + p0);
+    uint4 pv = make_uint4(0x2a2a2a2au, 0x2a2a2a2au, 0x2a2a2a2au, 0x2a2a2a2au);      // '*': in front of the text
+    if (p0) pv = *reinterpret_cast<const uint4 *>(A.text + p0 - 16);
+    const uint32_t ndm = nondigit16(v), ndp = nondigit16(pv);
+    // ---- operations before this lane's bytes (tile-local) ----
+    uint32_t cnt = __popc(ndm), inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(inc, d); if ((int)lane >= d) inc += y; }
+    if (lane == 63) s_wave[wave] = inc;
+    s_mask[threadIdx.x] = (uint16_t)ndm;
+    __syncthreads();
+    uint32_t base = inc - cnt, n_t = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const uint32_t x = s_wave[w]; if (w < (int)wave) base += x; n_t += x; }
+    s_pre[threadIdx.x] = (uint16_t)base;
+    // ---- carry: the digits that end the 16 bytes in front (at most the last nine count; more: the long path below) ----
+    const uint32_t nd0 = ndp ? (uint32_t)__clz((int)ndp) - 16u : 16u;      // trailing digit bytes of pv
+    const uint32_t pw[4] = {pv.x, pv.y, pv.z, pv.w}, w4[4] = {v.x, v.y, v.z, v.w};
+    uint32_t val = 0;
+#pragma unroll
+    for (int i = 7; i < 16; ++i) {
+        const uint32_t d = ((pw[i >> 2] >> (8 * (i & 3))) & 0xFFu) - 48u;
+        const uint32_t nv = (val << 3) + (val << 1) + d;
+        val = (uint32_t)i >= 16u - nd0 ? (val >= (1u << 28) ? val : nv) : 0u;
+    }
+    bool any = nd0 != 0, lng = nd0 > 9;                 // digits seen since the last operation; more of them than the carry holds
+    uint32_t k = base, bad = 0;                         // bad: bit j = the operation at byte j needs the error path
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t c = (w4[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        if (ndm >> j & 1u) {
+            const uint32_t code = op_code_lut(c);
+            if (lng) val = tok_long_value(A.text, p0 + j);
+            const bool err = !any || code == 15u || val >= (1u << 28);
+            bad |= (uint32_t)err << j;
+            s_ops[k] = err ? 0x7u /* a zero-length '=' keeps the stream well formed; the call fails anyway */ : (val << 4 | code);
+            ++k; val = 0; any = false; lng = false;
+        } else {
+            const uint32_t d = c - 48u, nv = (val << 3) + (val << 1) + d;
+            val = val >= (1u << 28) ? val : nv;
+            any = true;
+        }
+    }
+    if (bad) {                                          // first error of every malformed token, in the reference's order of checks
+        for (uint32_t m = bad; m; m &= m - 1) {
+            const int j = __ffs((int)m) - 1;
+            const uint64_t pos = p0 + (uint64_t)j;
+            const uint32_t c = A.text[pos];
+            int kind = PAV_CIGAR_ERR_LEN_OVERFLOW;
+            if (pos == 0 || !is_digit(A.text[pos - 1])) kind = PAV_CIGAR_ERR_MISSING_LEN;          // align.py:310 (checked before the op set)
+            else if (op_code_lut(c) == 15u) kind = PAV_CIGAR_ERR_UNKNOWN_OP;                        // align.py:315
+            tok_error(A.text, pos, kind, A.tok_err);
+        }
+    }
+    __syncthreads();
+    // ---- eight consecutive operations per lane: sums, first illegal operation; the padded tile goes out ----
+    const uint32_t n_real = n_t < (uint32_t)WALK_CHUNK ? n_t : (uint32_t)WALK_CHUNK;    // more: a token without digits, the call fails
+    uint32_t o[OPS_PER_LANE];
+    const uint32_t i0 = threadIdx.x * OPS_PER_LANE;
+#pragma unroll
+    for (int j = 0; j < OPS_PER_LANE; ++j) o[j] = i0 + j < n_real ? s_ops[i0 + j] : OP_PAD;
+    uint4 *out = reinterpret_cast<uint4 *>(A.ops + (uint64_t)t * WALK_CHUNK + i0);
+    out[0] = make_uint4(o[0], o[1], o[2], o[3]);
+    out[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    uint64_t run[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) run[q] = 0;
+    unsigned long long ill = ~0ull;                     // first M / N / P of the lane (cigarcall.py:289-307), as a slot ordinal
+#pragma unroll
+    for (int j = 0; j < OPS_PER_LANE; ++j) {
+        uint64_t c6[NQ];
+        op_contrib(o[j], c6);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) run[q] += c6[q];
+        const uint32_t code = o[j] & 15u;
+        if ((code == 0u || code == 3u || code == 6u) && ill == ~0ull) ill = (uint64_t)t * WALK_CHUNK + i0 + j;
+    }
+    if (__ballot(ill != ~0ull)) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const unsigned long long y = __shfl_xor(ill, d); ill = y < ill ? y : ill; }
+        if (lane == 0 && ill != ~0ull) atomicMin(A.err_op, ill);
+    }
+    // rows that start in this tile (text_off in [b0, b0 + 4096)): [rlo, rhi); most tiles have none
+    const uint32_t rlo = row_lower_bound(A.text_off, A.n_aln + 1, b0, lane);
+    const uint32_t rhi = row_lower_bound(A.text_off, A.n_aln + 1, b0 + TOK_CHUNK, lane);
+    if (rhi > rlo) {                                    // (uniform)
+        // exclusive block scan of the advances: a row's base is the tile prefix + the advance of the tile's operations before it
+        uint64_t ex[2] = {run[0], run[1]}, tt[2];
+        block_excl_scan<2>(ex, tt, s_red);
+        s_adv[2 * threadIdx.x] = ex[0]; s_adv[2 * threadIdx.x + 1] = ex[1];
+        __syncthreads();
+        for (uint32_t r = rlo + threadIdx.x; r < rhi; r += 256) {
+            const uint32_t off = (uint32_t)(A.text_off[r] - b0);
+            const uint32_t L = off >> 4, jb = off & 15u;
+            uint32_t i = (uint32_t)s_pre[L] + __popc((uint32_t)s_mask[L] & ((1u << jb) - 1u));     // operations of the tile before the row
+            if (i > n_real) i = n_real;
+            uint32_t rt = t, ri = i;
+            uint64_t a = 0, b = 0;
+            if (i >= n_real) { rt = t + 1; ri = 0; }    // behind the tile's last operation: the first slot of the next tile
+            else {                                      // the owner lane's base + the advance of operations [8 (i / 8), i)
+                const uint32_t own = i >> 3;
+                a = s_adv[2 * own]; b = s_adv[2 * own + 1];
+                for (uint32_t x = own * 8; x < i; ++x) {
+                    uint64_t c6[NQ];
+                    op_contrib(s_ops[x], c6);
+                    a += c6[0]; b += c6[1];
+                }
+            }
+            A.row_tile[r] = rt; A.row_i[r] = ri;
+            A.op_slot[r] = (uint64_t)rt * WALK_CHUNK + ri;
+            A.row_local[2ull * r] = a; A.row_local[2ull * r + 1] = b;
+            // a row whose text ends inside a length: IndexError in the reference (align.py:307)
+            if (r > 0) {
+                const uint64_t e = A.text_off[r], pb = A.text_off[r - 1];
+                if (e > pb && is_digit(A.text[e - 1])) {
+                    uint64_t q = e - 1;
+                    while (q > pb && is_digit(A.text[q - 1])) --q;
+                    atomicMin(A.tok_err, (unsigned long long)(q << 3 | (uint64_t)PAV_CIGAR_ERR_TRUNCATED));
+                }
+            }
+        }
+    }
+    // ---- tile sums ----
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) run[q] += __shfl_xor(run[q], d);
+    }
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) s_red[wave * NT + q] = run[q];
+    __syncthreads();
+    if (threadIdx.x < NQ)
+        A.tile_agg[(uint64_t)threadIdx.x * (A.n_tiles + 1) + t] =
+            s_red[threadIdx.x] + s_red[NT + threadIdx.x] + s_red[2 * NT + threadIdx.x] + s_red[3 * NT + threadIdx.x];
+    else if (threadIdx.x == NQ) {
+        A.tile_agg[(uint64_t)NQ * (A.n_tiles + 1) + t] = n_real;
+        A.tile_last[t] = n_real ? s_ops[n_real - 1] : OP_PAD;
+        const uint32_t before = rlo ? rlo - 1 : 0;        // its operations may end in front of this tile: the walk moves on from there
+        A.chunk_row[t] = A.n_aln && before >= A.n_aln ? A.n_aln - 1 : before;
+    }
+}
+
+// One workgroup per tile quantity: exclusive prefix over the tiles, in place (tile_agg[q][n_tiles] = the total, which also goes
+// straight into the host's pinned status block: no copy, no second readback).  Then the per-row values that need a prefix:
+// workgroup NQ: the real operation ordinal of every row's first operation (op_off); 0 / 1: the rows' reference / query base
+// (rowbase) and the first row whose advance does not fit the record it names (the reference raises IndexError at the first X base
+// past the end, cigarcall.py:104-105; here such a row is refused before any kernel reads past a record); 2: the error words.
+struct ScanArgs {
+    uint64_t *tile_agg; uint32_t n_tiles, n_aln;
+    const uint32_t *row_tile, *row_i; const uint64_t *row_local;
+    uint64_t *op_off, *rowbase;
+    const pav_aln *aln; SeqView ref, tig;
+    const unsigned long long *tok_err, *err_op;
+    volatile uint64_t *host_status;                  // [0, NT) totals, [NT] token error key, [NT + 1] illegal operation slot,
+};                                                   // [NT + 2] / [NT + 3] first row that overruns its reference / query record
+
+__global__ __launch_bounds__(256) void tile_scan(ScanArgs A) {
+    constexpr int PER = 16;
+    __shared__ uint64_t lds[4];
+    __shared__ uint64_t tile[256 * (PER + 1)];
+    const uint32_t q = blockIdx.x, n = A.n_tiles;
+    uint64_t *x = A.tile_agg + (uint64_t)q * (n + 1);
+    uint64_t carry = 0;
+    for (uint32_t base = 0; base < n; base += 256 * PER) {
+        uint64_t c[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { const uint32_t i = base + k * 256 + threadIdx.x; c[k] = i < n ? x[i] : 0ull; }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { const uint32_t j = k * 256 + threadIdx.x; tile[j + j / PER] = c[k]; }
+        __syncthreads();
+        uint64_t v[1] = {0}, tot[1];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { c[k] = tile[threadIdx.x * (PER + 1) + k]; v[0] += c[k]; }
+        block_excl_scan<1>(v, tot, lds);
+        uint64_t run = carry + v[0];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const uint32_t i = base + threadIdx.x * PER + k;
+            if (i < n) x[i] = run;
+            run += c[k];
+        }
+        carry += tot[0];
+    }
+    if (threadIdx.x == 0) { x[n] = carry; A.host_status[q] = carry; }
+    if (q == 2 && threadIdx.x == 0) { A.host_status[NT] = *A.tok_err; A.host_status[NT + 1] = *A.err_op; }
+    if (q != (uint32_t)NQ && q > 1) return;
+    // the prefixes this workgroup has just written are read back past its L1 (agent-scope loads are served by the L2)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    auto pre = [&](uint32_t i) { return __hip_atomic_load(x + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    if (q == (uint32_t)NQ) {
+        for (uint32_t r = threadIdx.x; r <= A.n_aln; r += 256) A.op_off[r] = pre(A.row_tile[r]) + A.row_i[r];
+        return;
+    }
+    __shared__ unsigned long long red[4];
+    unsigned long long bad = ~0ull;
+    for (uint32_t r = threadIdx.x; r <= A.n_aln; r += 256) {
+        const uint64_t here = pre(A.row_tile[r]) + A.row_local[2ull * r + q];
+        A.rowbase[2ull * r + q] = here;
+        if (r < A.n_aln) {
+            const uint64_t adv = pre(A.row_tile[r + 1]) + A.row_local[2ull * (r + 1) + q] - here;
+            const pav_aln a = A.aln[r];
+            const bool over = q == 0 ? (uint64_t)a.pos + adv > A.ref.len[a.ref_id] : adv > A.tig.len[a.tig_id];
+            if (over && r < bad) bad = r;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const unsigned long long y = __shfl_xor(bad, d); bad = y < bad ? y : bad; }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = bad;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) bad = red[w] < bad ? red[w] : bad;
+        A.host_status[NT + 2 + q] = bad;
+    }
+}
+
+// Contiguous operation array (pav_cigar_fetch_ops, the error path): tile t's operations go to their real ordinals.
+__global__ __launch_bounds__(256) void ops_compact(const uint32_t *__restrict__ ops_pad, const uint64_t *__restrict__ pre_n,
+                                                   uint32_t *__restrict__ out) {
+    const uint32_t t = blockIdx.x;
+    const uint64_t a = pre_n[t], n = pre_n[t + 1] - a;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) out[a + i] = ops_pad[(uint64_t)t * WALK_CHUNK + i];
+}
+
+// ---- the walk --------------------------------------------------------------------------------------------
 __device__ __forceinline__ void load_ops(const uint32_t *__restrict__ ops, uint64_t n_ops, uint64_t first,
                                          uint32_t (&o)[OPS_PER_LANE]) {
     if (first + OPS_PER_LANE <= n_ops) {
@@ -217,175 +534,40 @@ __device__ __forceinline__ void load_ops(const uint32_t *__restrict__ ops, uint6
     }
 }
 
-__global__ __launch_bounds__(256) void walk_reduce(const uint32_t *__restrict__ ops, uint64_t n_ops,
-                                                   uint64_t *__restrict__ chunk_sum /* [n_chunks][NQ] */,
-                                                   unsigned long long *__restrict__ err_op) {
-    __shared__ uint64_t lds[4 * NQ];
-    uint32_t o[OPS_PER_LANE];
-    const uint64_t first = (uint64_t)blockIdx.x * WALK_CHUNK + (uint64_t)threadIdx.x * OPS_PER_LANE;
-    load_ops(ops, n_ops, first, o);
-    uint64_t s[NQ] = {0, 0, 0, 0, 0, 0};
-    unsigned long long bad = ~0ull;                                    // first M / N / P op of the lane (cigarcall.py:289-307)
-#pragma unroll
-    for (int j = 0; j < OPS_PER_LANE; ++j) {
-        uint64_t c[NQ];
-        op_contrib(o[j], c);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) s[q] += c[q];
-        const uint32_t code = o[j] & 15u;
-        if ((code == 0u || code == 3u || code == 6u || code > 8u) && bad == ~0ull) bad = first + j;
-    }
-    if (__ballot(bad != ~0ull)) {                                      // rare: the first one in walk order wins
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { const unsigned long long y = __shfl_xor(bad, d); bad = y < bad ? y : bad; }
-        if ((threadIdx.x & 63) == 0 && bad != ~0ull) atomicMin(err_op, bad);
-    }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) s[q] += __shfl_xor(s[q], d);
-    }
-    if ((threadIdx.x & 63) == 0)
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) lds[(threadIdx.x >> 6) * NQ + q] = s[q];
-    __syncthreads();
-    if (threadIdx.x < NQ)
-        chunk_sum[(uint64_t)blockIdx.x * NQ + threadIdx.x] =
-            lds[threadIdx.x] + lds[NQ + threadIdx.x] + lds[2 * NQ + threadIdx.x] + lds[3 * NQ + threadIdx.x];
-}
-
-// Single workgroup: exclusive scan of the per-chunk sums; totals[NQ] = grand totals.  Tiles of 1024 chunks through LDS, four
-// consecutive chunks per lane (see scan_counts): 63 -> ~20 us for the 4.4 k chunks of a haplotype.
-__global__ __launch_bounds__(256) void walk_chunks(const uint64_t *__restrict__ chunk_sum, uint64_t *__restrict__ chunk_pre,
-                                                   uint64_t *__restrict__ totals, uint32_t n_chunks,
-                                                   volatile uint64_t *host_status) {
-    constexpr int PER = 4, WORDS = PER * NQ;                              // u64 words per lane and tile
-    __shared__ uint64_t lds[4 * NQ];
-    __shared__ uint64_t tile[256 * WORDS];
-    uint64_t carry[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) carry[q] = 0;
-    const uint64_t n_words = (uint64_t)n_chunks * NQ;
-    for (uint32_t base = 0; base < n_chunks; base += 256 * PER) {
-        uint64_t w[WORDS];
-#pragma unroll
-        for (int k = 0; k < WORDS; ++k) {
-            const uint64_t i = (uint64_t)base * NQ + (uint64_t)k * 256 + threadIdx.x;
-            w[k] = i < n_words ? chunk_sum[i] : 0ull;
-        }
-#pragma unroll
-        for (int k = 0; k < WORDS; ++k) tile[k * 256 + threadIdx.x] = w[k];
-        __syncthreads();
-        uint64_t v[NQ], tot[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) v[q] = 0;
-#pragma unroll
-        for (int k = 0; k < WORDS; ++k) { w[k] = tile[threadIdx.x * WORDS + k]; v[k % NQ] += w[k]; }
-        block_excl_scan<NQ>(v, tot, lds);
-#pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            const uint32_t i = base + threadIdx.x * PER + j;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                if (i < n_chunks) chunk_pre[(uint64_t)i * NQ + q] = carry[q] + v[q];
-                v[q] += w[j * NQ + q];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) carry[q] += tot[q];
-    }
-    if (threadIdx.x < NQ) {
-        uint64_t mine = 0;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) if ((int)threadIdx.x == q) mine = carry[q];
-        totals[threadIdx.x] = mine;
-        chunk_pre[(uint64_t)n_chunks * NQ + threadIdx.x] = mine;           // read by rows that start at n_ops
-        if (host_status) host_status[threadIdx.x] = mine;
-    } else if (threadIdx.x <= NQ + 1 && host_status) host_status[threadIdx.x] = totals[threadIdx.x];   // tokenizer error key (tok_emit /
-                                                                       // row_ops ran before us), illegal-op ordinal (walk_reduce)
-    // the status block goes straight into the host's pinned words (mapped into the device's address space): one copy fewer per
-    // call (and under rocprofv3, where copies run as shader kernels, such a copy did not retire before the concurrent pack)
-}
-
-// One wave per row: running (ref, tig) advance of all ops before the row's first op; and for every 2048-operation chunk that
-// starts inside the row, the row (chunk_row: the walk / verify workgroups start from it instead of searching op_off with
-// ten dependent loads each).
-__global__ __launch_bounds__(256) void row_base(const uint32_t *__restrict__ ops, const uint64_t *__restrict__ op_off,
-                                                const uint64_t *__restrict__ chunk_pre, uint64_t *__restrict__ rowbase,
-                                                uint32_t *__restrict__ chunk_row, uint32_t n_aln) {
-    const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= n_aln) return;
-    const int lane = threadIdx.x & 63;
-    const uint64_t first = op_off[r], next = op_off[r + 1];
-    const uint64_t c = first / WALK_CHUNK;
-    for (uint64_t cc = (first + WALK_CHUNK - 1) / WALK_CHUNK + lane; cc * WALK_CHUNK < next; cc += 64) chunk_row[cc] = r;
-    uint64_t a = 0, b = 0;
-    for (uint64_t i = c * WALK_CHUNK + lane; i < first; i += 64) {
-        uint64_t q[NQ];
-        op_contrib(ops[i], q);
-        a += q[0]; b += q[1];
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d); b += __shfl_xor(b, d); }
-    if (lane == 0) {
-        rowbase[2ull * r] = chunk_pre[c * NQ + 0] + a;
-        rowbase[2ull * r + 1] = chunk_pre[c * NQ + 1] + b;
-    }
-}
-
-// Single workgroup: every row's span against the records it names - POS + reference advance must fit the reference record, the
-// query advance the contig (pavlib indexes Python strings: an X base past the end raises IndexError, cigarcall.py:104-105;
-// here any row that does not fit is refused before a kernel reads past a record).  host_status[NQ + 2] = first such row or ~0.
-__global__ __launch_bounds__(256) void row_check(const pav_aln *__restrict__ aln, const uint64_t *__restrict__ rowbase,
-                                                 const uint64_t *__restrict__ totals, SeqView ref, SeqView tig, uint32_t n_aln,
-                                                 volatile uint64_t *host_status) {
-    __shared__ unsigned long long red[4];
-    unsigned long long bad = ~0ull;
-    for (uint32_t r = threadIdx.x; r < n_aln; r += 256) {
-        const uint64_t ra = (r + 1 < n_aln ? rowbase[2ull * (r + 1)] : totals[0]) - rowbase[2ull * r];
-        const uint64_t ta = (r + 1 < n_aln ? rowbase[2ull * (r + 1) + 1] : totals[1]) - rowbase[2ull * r + 1];
-        const pav_aln a = aln[r];
-        if ((uint64_t)a.pos + ra > ref.len[a.ref_id] || ta > tig.len[a.tig_id]) { if (r < bad) bad = r; }
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { const unsigned long long y = __shfl_xor(bad, d); bad = y < bad ? y : bad; }
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = bad;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w) bad = red[w] < bad ? red[w] : bad;
-        host_status[NQ + 2] = bad;
-    }
-}
-
 struct WalkArgs {
-    const uint32_t *ops; uint64_t n_ops;
-    const uint64_t *op_off; const pav_aln *aln; uint32_t n_aln;
-    const uint64_t *chunk_pre; const uint64_t *rowbase; const uint32_t *chunk_row;
+    const uint32_t *ops;                 // padded: tile t owns slots [t * 2048, (t + 1) * 2048)
+    const uint64_t *op_slot;             // [n_aln + 1] slot ordinal of every row's first operation
+    const uint64_t *op_off;              // ... and its real ordinal
+    const pav_aln *aln; uint32_t n_aln, n_tiles;
+    const uint64_t *tile_pre;            // [NT][n_tiles + 1] exclusive prefix of the tile sums
+    const uint64_t *rowbase; const uint32_t *chunk_row, *tile_last;
     SeqView ref, tig;
     pav_snv *snv; pav_indel *indel;
-    unsigned long long *err_op;          // smallest global ordinal of an illegal op (M, N, P)
 };
 
-// Emit SNV rows and INDEL stubs.  Each lane owns 8 consecutive ops; the block scan gives every op its running positions and
-// its output slots, so the output order is exactly the reference's (row, op, base) order.  INDEL stubs (one per I / D op) are
-// written where they are met.  SNV rows are written flat: every op leaves its first output slot and positions in LDS, then
-// lane t of the workgroup builds rows t, t + 256, ... of the chunk (binary search for the owning 'X' run) - complete rows with
-// REF / ALT read from the ASCII planes (cigarcall.py:104-105), stored 16 B per lane to consecutive addresses.  (First version:
-// each lane wrote the rows of its own ops, 64 scattered 16-byte stores per instruction and 209 VGPRs, and a second kernel
-// re-read every row to add the bases; beside the HBM-saturating pack that walk took 0.49 ms.)
-// Two instances of the same walk: WALK_INDEL writes the stubs (and reports illegal ops) - little traffic, it runs beside the
-// contig pack; WALK_SNV writes the SNV rows - 0.4 GB of scattered byte fetches - behind the pack on the side stream, beside the
-// homology scans, so that the pack keeps HBM to itself (one kernel doing both beside the pack stretched it from 0.70 to 0.85 ms).
+// Emit SNV rows and INDEL stubs.  One workgroup per tile of operation slots; each lane owns 8 consecutive slots; the block scan
+// on top of the tile prefix gives every operation its running positions and its output slots, so the output order is exactly the
+// reference's (row, op, base) order.  INDEL stubs (one per I / D op) are written where they are met.  SNV rows are written
+// flat: every op leaves its first output slot and positions in LDS, then lane t of the workgroup builds rows t, t + 256, ... of
+// the tile (binary search for the owning 'X' run) - complete rows with REF / ALT read from the ASCII planes
+// (cigarcall.py:104-105), stored 16 B per lane to consecutive addresses.
+// Two instances of the same walk: WALK_INDEL writes the stubs - little traffic, on the critical path of the homology scans;
+// WALK_SNV writes the SNV rows - 13 M isolated sector fetches per haplotype - on the side stream beside the homology scans.
 constexpr int WALK_INDEL = 1, WALK_SNV = 2;
 template <int MODE>
 __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
     __shared__ uint64_t lds[4 * NQ];
     constexpr int NSLOT = MODE == WALK_SNV ? WALK_CHUNK : 1;
-    __shared__ uint32_t s_pre[NSLOT + 1];               // first SNV row of the op, relative to the chunk's first row
+    __shared__ uint32_t s_pre[NSLOT + 1];               // first SNV row of the op, relative to the tile's first row
     __shared__ uint32_t d_pos[NSLOT], d_q0[NSLOT], d_row[NSLOT];   // 'X' ops: POS, stored contig position of base 0, row | rev << 31
-    const uint64_t first = (uint64_t)blockIdx.x * WALK_CHUNK + (uint64_t)threadIdx.x * OPS_PER_LANE;
+    const uint32_t t = blockIdx.x;
+    const uint64_t first = (uint64_t)t * WALK_CHUNK + (uint64_t)threadIdx.x * OPS_PER_LANE;      // slot ordinal
     uint32_t o[OPS_PER_LANE];
-    load_ops(A.ops, A.n_ops, first, o);
+    {
+        const uint4 a = *reinterpret_cast<const uint4 *>(A.ops + first), b = *reinterpret_cast<const uint4 *>(A.ops + first + 4);
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    }
+    const uint64_t stride = (uint64_t)A.n_tiles + 1;
     uint64_t run[NQ] = {0, 0, 0, 0, 0, 0}, tot[NQ];
 #pragma unroll
     for (int j = 0; j < OPS_PER_LANE; ++j) {
@@ -395,43 +577,42 @@ __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
         for (int q = 0; q < NQ; ++q) run[q] += c[q];
     }
     block_excl_scan<NQ>(run, tot, lds);
-    const uint64_t snv_base = A.chunk_pre[(uint64_t)blockIdx.x * NQ + 2];
-    const uint32_t n_rows = (uint32_t)tot[2];            // SNV rows of this chunk
+    const uint64_t snv_base = A.tile_pre[2 * stride + t];
+    const uint32_t n_rows = (uint32_t)tot[2];            // SNV rows of this tile
+    if (MODE == WALK_SNV && n_rows == 0) return;         // (uniform)
+    if (MODE == WALK_INDEL && tot[3] == 0) return;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) if (q != 2) run[q] += A.chunk_pre[(uint64_t)blockIdx.x * NQ + q];
-
-    // row of this lane's first op: the row of the chunk's first op comes from row_base (chunk_row), lanes walk on
-    const uint32_t row0 = A.chunk_row[blockIdx.x];
+    for (int q = 0; q < NQ; ++q) if (q != 2) run[q] += A.tile_pre[(uint64_t)q * stride + t];
+    const uint64_t real0 = A.tile_pre[(uint64_t)NQ * stride + t] + (uint64_t)threadIdx.x * OPS_PER_LANE;   // real ordinal of this lane's first slot
+                                                                                                             // (only meaningful for operations: they lead the tile)
+    // row of this lane's first op: a row at or before the tile's first op comes from tok_tiles (chunk_row), lanes walk on
+    const uint32_t row0 = A.chunk_row[t];
     const pav_aln al0 = A.aln[row0];
     const uint64_t roff0 = A.ref.off[al0.ref_id], toff0 = A.tig.off[al0.tig_id];
     const uint32_t slot0 = threadIdx.x * OPS_PER_LANE;
-    if (first >= A.n_ops) {
-        if constexpr (MODE == WALK_SNV) {
-#pragma unroll
-            for (int j = 0; j < OPS_PER_LANE; ++j) s_pre[slot0 + j] = n_rows;
-        }
-    } else {
+    {
         uint32_t row = row0;
-        uint64_t row_end = A.op_off[row + 1];
+        uint64_t row_end = A.op_slot[row + 1];
         pav_aln al = al0;
-        if (row_end <= first) {
-            do { ++row; row_end = A.op_off[row + 1]; } while (row_end <= first);      // rows without ops are skipped
+        if (row_end <= first && row + 1 < A.n_aln) {           // (slots behind the last row's operations stay with the last row: padding)
+            do { ++row; row_end = A.op_slot[row + 1]; } while (row_end <= first && row + 1 < A.n_aln);     // rows without ops are skipped
             al = A.aln[row];
         }
         uint64_t rb_ref = A.rowbase[2ull * row], rb_tig = A.rowbase[2ull * row + 1];
         uint64_t tlen = A.tig.len[al.tig_id];
-        uint64_t row_begin = A.op_off[row];                    // kept in a register: no load inside the per-op branches below
-        uint32_t prev = first > 0 ? A.ops[first - 1] : 0x5u;   // last_op / last_oplen carried across lanes
+        uint64_t row_begin = A.op_off[row];                    // real ordinal; kept in a register: no load inside the per-op branches below
+        // last_op / last_oplen carried across lanes: the operation in the slot in front, or the last one of the tile in front
+        uint32_t prev = threadIdx.x ? A.ops[first - 1] : (t ? A.tile_last[t - 1] : OP_PAD);
 #pragma unroll
         for (int j = 0; j < OPS_PER_LANE; ++j) {
             const uint64_t k = first + j;
             if constexpr (MODE == WALK_SNV) s_pre[slot0 + j] = (uint32_t)run[2];
-            if (k >= A.n_ops) continue;                // (the padding ops contribute nothing: run[2] stays at the total)
-            while (k >= row_end) {                     // next row (rows without ops are skipped)
-                ++row; row_begin = row_end; row_end = A.op_off[row + 1];
+            while (k >= row_end && row + 1 < A.n_aln) {        // next row (rows without ops are skipped)
+                ++row; row_end = A.op_slot[row + 1];
                 al = A.aln[row];
                 rb_ref = A.rowbase[2ull * row]; rb_tig = A.rowbase[2ull * row + 1];
                 tlen = A.tig.len[al.tig_id];
+                row_begin = A.op_off[row];
             }
             const uint32_t code = o[j] & 15u, len = o[j] >> 4;
             const int64_t pos_ref = (int64_t)al.pos + (int64_t)(run[0] - rb_ref);
@@ -447,14 +628,14 @@ __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
                 if constexpr (MODE == WALK_INDEL) {
                 pav_indel r;
                 r.aln = row;
-                r.op_index = (uint32_t)(k - row_begin) + 1;                    // cigar_index, cigarcall.py:89
+                r.op_index = (uint32_t)(real0 + j - row_begin) + 1;            // cigar_index, cigarcall.py:89
                 r.pos = (uint32_t)pos_ref;                                     // un-shifted; finalised by homology_kernel
                 r.end = 0;
                 r.svlen = len;
                 r.qry_pos = (uint32_t)pos_tig;                                 // oriented, un-shifted
                 r.qry_end = 0;
                 // last_op / last_oplen (cigarcall.py:149-151,310-311): previous op of the same row
-                const bool has_prev = k > row_begin;                           // first op of a row: last_op is None
+                const bool has_prev = real0 + j > row_begin;                   // first op of a row: last_op is None
                 r.left_shift = (has_prev && (prev & 15u) == 7u) ? (prev >> 4) : 0u;   // shift cap; 0 when last_op != '='
                 r.hom_ref_l = r.hom_ref_r = r.hom_tig_l = r.hom_tig_r = 0;
                 r.seq_off = run[4];
@@ -463,9 +644,7 @@ __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
                 for (int b = 0; b < 7; ++b) r.pad[b] = 0;
                 A.indel[run[3]] = r;
                 }
-            } else if (code != 7 && code != 4 && code != 5) {                  // M, N, P: cigarcall.py:289-307
-                // reported by walk_reduce (before any row is emitted); nothing to write for it
-            }
+            }                                                                  // M, N, P: reported by tok_tiles before any row is emitted
             uint64_t c[NQ];
             op_contrib(o[j], c);
 #pragma unroll
@@ -499,7 +678,7 @@ __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
             pos[u] = d_pos[lo] + i;
             qp[u] = (rw[u] >> 31) ? d_q0[lo] - i : d_q0[lo] + i;
             roff[u] = roff0; toff[u] = toff0;
-            if ((rw[u] & 0x7FFFFFFFu) != row0) {            // chunk that crosses into another row
+            if ((rw[u] & 0x7FFFFFFFu) != row0) {            // tile that crosses into another row
                 const pav_aln al = A.aln[rw[u] & 0x7FFFFFFFu];
                 roff[u] = A.ref.off[al.ref_id]; toff[u] = A.tig.off[al.tig_id];
             }
@@ -525,9 +704,9 @@ __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
 // workgroup then cuts its runs into 64-base pieces, one lane per piece (one unaligned 64-base window of each 2-bit plane,
 // reversed and complemented for reverse-strand rows).
 struct VerifyArgs {
-    const uint32_t *ops; uint64_t n_ops;
-    const uint64_t *op_off; const pav_aln *aln; uint32_t n_aln;
-    const uint64_t *chunk_pre; const uint64_t *rowbase; const uint32_t *chunk_row;
+    const uint32_t *ops;                 // padded tiles of operation slots, as WalkArgs
+    const uint64_t *op_slot; const pav_aln *aln; uint32_t n_aln, n_tiles;
+    const uint64_t *tile_pre; const uint64_t *rowbase; const uint32_t *chunk_row;
     SeqView ref, tig;
     unsigned long long *cnt;             // [0] '=' bases, [1] of them different, [2] 'X' bases, [3] of them equal, [4] first bad op
 };
@@ -611,9 +790,12 @@ __global__ __launch_bounds__(256) void verify_kernel(VerifyArgs A) {
     constexpr uint32_t EVEN = 0x55555555u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t chunk = blockIdx.x / VSPLIT, slot0 = (blockIdx.x % VSPLIT) * VSLOTS;
-    const uint64_t first = (uint64_t)chunk * WALK_CHUNK + (uint64_t)threadIdx.x * OPS_PER_LANE;
+    const uint64_t first = (uint64_t)chunk * WALK_CHUNK + (uint64_t)threadIdx.x * OPS_PER_LANE;      // slot ordinal
     uint32_t o[OPS_PER_LANE];
-    load_ops(A.ops, A.n_ops, first, o);
+    {
+        const uint4 a = *reinterpret_cast<const uint4 *>(A.ops + first), b = *reinterpret_cast<const uint4 *>(A.ops + first + 4);
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    }
     const bool mine_half = threadIdx.x * OPS_PER_LANE >= slot0 && threadIdx.x * OPS_PER_LANE < slot0 + VSLOTS;
     const uint32_t my0 = threadIdx.x * OPS_PER_LANE - slot0;             // this lane's first operation within the part (its 8 ops lie in one part)
     // one block scan: the two positions, and (runs | pieces) of this part packed in one word.  The runs are cut into 64-base
@@ -632,8 +814,8 @@ __global__ __launch_bounds__(256) void verify_kernel(VerifyArgs A) {
         if (np[j]) { if (code == 8) len_x += len; else len_eq += len; }    // the bases checked are counted here, not per piece
     }
     block_excl_scan<3>(run, tot, lds);
-    run[0] += A.chunk_pre[(uint64_t)chunk * NQ + 0];
-    run[1] += A.chunk_pre[(uint64_t)chunk * NQ + 1];
+    run[0] += A.tile_pre[chunk];
+    run[1] += A.tile_pre[(uint64_t)A.n_tiles + 1 + chunk];
     const uint32_t n_slots = (uint32_t)(tot[2] >> PK_SHIFT), n_pieces = (uint32_t)(tot[2] & ((1ull << PK_SHIFT) - 1));
     if (threadIdx.x <= VPIECE) {
         uint32_t m[4];
@@ -651,10 +833,10 @@ __global__ __launch_bounds__(256) void verify_kernel(VerifyArgs A) {
         if (WIDE) d_hi[n_slots] = make_uint2(0u, 0u);
         d_op[n_slots] = 0;
     }
-    if (first < A.n_ops && mine_half) {
+    if (mine_half && n_slots) {                                          // (n_slots: uniform; a tile of padding has no runs)
         uint32_t row = A.chunk_row[chunk];
-        uint64_t row_end = A.op_off[row + 1];
-        while (row_end <= first) { ++row; row_end = A.op_off[row + 1]; }
+        uint64_t row_end = A.op_slot[row + 1];
+        while (row_end <= first && row + 1 < A.n_aln) { ++row; row_end = A.op_slot[row + 1]; }
         // per row: ra = r0 + (reference bases before the op), ta = t0 +/- (contig bases before the op).  Forward rows: first
         // base of the run; reverse rows: the stored base that is oriented base 0 of the run (the run goes downwards)
         uint64_t r0, t0;
@@ -671,9 +853,8 @@ __global__ __launch_bounds__(256) void verify_kernel(VerifyArgs A) {
 #pragma unroll
         for (int j = 0; j < OPS_PER_LANE; ++j) {
             const uint64_t k = first + j;
-            if (k >= A.n_ops) break;
-            if (k >= row_end) {
-                do { ++row; row_end = A.op_off[row + 1]; } while (k >= row_end);
+            if (k >= row_end && row + 1 < A.n_aln) {
+                do { ++row; row_end = A.op_slot[row + 1]; } while (k >= row_end && row + 1 < A.n_aln);
                 enter_row(row);
             }
             const uint32_t code = o[j] & 15u, len = o[j] >> 4;
@@ -825,7 +1006,8 @@ __global__ __launch_bounds__(256) void verify_kernel(VerifyArgs A) {
         for (int u = 0; u < VU; ++u) q[u] = q_next[u];
     }
     unsigned long long n_eq = len_eq, bad_eq = bad_tot - bad_x, nx = len_x, bx = bad_x;
-    unsigned long long first_bad = bad_slot == ~0u ? ~0ull : (unsigned long long)chunk * WALK_CHUNK + slot0 + (unsigned long long)d_op[bad_slot];
+    // real ordinal of the operation: the tile's operations lead its slots
+    unsigned long long first_bad = bad_slot == ~0u ? ~0ull : A.tile_pre[(uint64_t)NQ * (A.n_tiles + 1) + chunk] + slot0 + (unsigned long long)d_op[bad_slot];
 #pragma unroll
     for (int dd = 32; dd >= 1; dd >>= 1) {
         n_eq += __shfl_xor(n_eq, dd); bad_eq += __shfl_xor(bad_eq, dd); nx += __shfl_xor(nx, dd); bx += __shfl_xor(bx, dd);
@@ -1294,12 +1476,17 @@ __device__ __forceinline__ uint32_t right_hom(const SeqRef &t, int64_t pos, cons
 
 // One lane per INS/DEL stub: left shift, then the four breakpoint homologies in lockstep (wave_hom_scan4), then the final
 // coordinates.  The scans are wave-uniform calls (long scans are finished cooperatively), so no lane leaves early.
-__global__ __launch_bounds__(256) void homology_kernel(pav_indel *__restrict__ indel, uint64_t n_indel,
-                                                       const pav_aln *__restrict__ aln, SeqView R, SeqView T,
-                                                       uint32_t *__restrict__ seq_blk) {
+// Epilogue: the SEQ column (cigarcall.py:145,163,221).  The records of a wave are consecutive and so are their sequences in the
+// blob: the wave copies the span byte by byte, lane = output byte (coalesced stores), the record that owns a byte is found among
+// the wave's 64 by a search over shuffled offsets - and for an INS the bytes come from the contig lines the scans above have just
+// fetched.  (Round 2 had a separate seq_gather kernel that re-read every record: one launch and 64 B per record more.)
+__global__ __launch_bounds__(64) void homology_kernel(pav_indel *__restrict__ indel, uint64_t n_indel,
+                                                      const pav_aln *__restrict__ aln, SeqView R, SeqView T,
+                                                      uint8_t *__restrict__ blob) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const bool active = i < n_indel;
-    pav_indel r = indel[active ? i : 0];
+    pav_indel r = indel[active ? i : n_indel - 1];
     const pav_aln al = aln[r.aln];
     const int rev = al.rev != 0;
     const SeqRef ref = seq_ref(R, al.ref_id, 0), tig = seq_ref(T, al.tig_id, rev);
@@ -1318,56 +1505,46 @@ __global__ __launch_bounds__(256) void homology_kernel(pav_indel *__restrict__ i
                                {tig, sv_pos_tig - 1, sv_pos_tig, -1}, {tig, p_tr, tig_len - p_tr, +1}};
     uint32_t hom[4];
     wave_hom_scan4(active, sides, svs, sv_at, oplen, hom);
-    if (!active) return;
-    r.hom_ref_l = hom[0]; r.hom_ref_r = hom[1]; r.hom_tig_l = hom[2]; r.hom_tig_r = hom[3];
-    if (ins) {
-        r.pos = (uint32_t)sv_pos_ref; r.end = (uint32_t)(sv_pos_ref + 1);           // :157-158
-        if (rev) { r.qry_end = (uint32_t)(tig_len - sv_pos_tig); r.qry_pos = r.qry_end - (uint32_t)oplen; }   // :167-169
-        else { r.qry_pos = (uint32_t)sv_pos_tig; r.qry_end = (uint32_t)(sv_pos_tig + oplen); }                // :171-173
-    } else {
-        r.pos = (uint32_t)pos_ref; r.end = (uint32_t)(pos_ref + oplen);             // :258 (un-shifted)
-        const int64_t q = rev ? tig_len - sv_pos_tig : sv_pos_tig;                  // :239-242
-        r.qry_pos = (uint32_t)q; r.qry_end = (uint32_t)(q + 1);
+    const uint64_t seq_off = r.seq_off;
+    if (active) {
+        r.hom_ref_l = hom[0]; r.hom_ref_r = hom[1]; r.hom_tig_l = hom[2]; r.hom_tig_r = hom[3];
+        if (ins) {
+            r.pos = (uint32_t)sv_pos_ref; r.end = (uint32_t)(sv_pos_ref + 1);           // :157-158
+            if (rev) { r.qry_end = (uint32_t)(tig_len - sv_pos_tig); r.qry_pos = r.qry_end - (uint32_t)oplen; }   // :167-169
+            else { r.qry_pos = (uint32_t)sv_pos_tig; r.qry_end = (uint32_t)(sv_pos_tig + oplen); }                // :171-173
+        } else {
+            r.pos = (uint32_t)pos_ref; r.end = (uint32_t)(pos_ref + oplen);             // :258 (un-shifted)
+            const int64_t q = rev ? tig_len - sv_pos_tig : sv_pos_tig;                  // :239-242
+            r.qry_pos = (uint32_t)q; r.qry_end = (uint32_t)(q + 1);
+        }
+        r.left_shift = (uint32_t)shift;
+        indel[i] = r;
     }
-    r.left_shift = (uint32_t)shift;
-    indel[i] = r;
-    // seq_gather: this record owns the first byte of every 256-byte block of the SEQ blob that starts inside its sequence
-    for (uint64_t blk = (r.seq_off + 255) >> 8; (blk << 8) < r.seq_off + (uint64_t)oplen; ++blk) seq_blk[blk] = (uint32_t)i;
-}
-
-// SEQ blob (cigarcall.py:145,163,221): one lane per output byte (coalesced stores).  The record that owns the first byte of a
-// 256-byte block comes from homology_kernel (seq_blk); the offsets of the 257 records from there on are staged in LDS and
-// searched there - a lane used to search all of indel[] in global memory, twenty dependent loads per byte.
-// (A lane-per-record variant with cooperative long copies measured 30 % slower.)
-__global__ __launch_bounds__(256) void seq_gather(const pav_indel *__restrict__ indel, uint64_t n_indel,
-                                                  const pav_aln *__restrict__ aln, SeqView R, SeqView T,
-                                                  uint8_t *__restrict__ blob, uint64_t n_bytes, const uint32_t *__restrict__ seq_blk) {
-    __shared__ uint64_t s_off[257];
-    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t lo0 = seq_blk[blockIdx.x];
-    for (uint32_t t = threadIdx.x; t < 257; t += 256) s_off[t] = lo0 + t < n_indel ? indel[lo0 + t].seq_off : ~0ull;
+    // ---- SEQ bytes of the wave's records: INS seq_tig[sv_pos_tig : +oplen] (oriented), DEL seq_ref[pos_ref : +oplen] ----
+    // byte k of this lane's sequence sits at arena position s0 + sdir * k of the contig (complemented on reverse rows) / reference
+    const int flags = (ins ? 1 : 0) | ((ins && rev) ? 2 : 0);
+    const int64_t s0 = ins ? (int64_t)tig.off + (rev ? tig_len - 1 - sv_at : sv_at) : (int64_t)ref.off + pos_ref;
+    // (the owner search below takes a different path in every lane: the wave's 64 offsets go through LDS, not through shuffles,
+    //  which would read lanes that have left the loop)
+    __shared__ uint32_t s_rel[64];
+    __shared__ int64_t s_src[64];
+    __shared__ int s_fl[64];
+    const uint64_t span0 = (uint64_t)__shfl((long long)seq_off, 0);                     // lane 0 is active in every launched wave
+    const uint32_t n_act = n_indel - (uint64_t)blockIdx.x * 64 < 64 ? (uint32_t)(n_indel - (uint64_t)blockIdx.x * 64) : 64u;
+    s_rel[lane] = active ? (uint32_t)(seq_off - span0) : 0xFFFFFFFFu;                    // < 2^28 * 64
+    s_src[lane] = s0; s_fl[lane] = flags;
     __syncthreads();
-    if (b >= n_bytes) return;
-    uint64_t lo = 0, hi = 257;                         // last record with seq_off <= b
-    if (s_off[256] <= b) { lo = 256; hi = n_indel - lo0; }   // only with records of length 0 in between: search on in global memory
-    while (hi - lo > 1) {
-        const uint64_t mid = (lo + hi) >> 1;
-        const uint64_t v = mid <= 256 ? s_off[mid] : indel[lo0 + mid].seq_off;
-        if (v <= b) lo = mid; else hi = mid;
+    const uint32_t span = s_rel[n_act - 1] + (uint32_t)__shfl((int)oplen, (int)n_act - 1);
+    for (uint32_t b = (uint32_t)lane; b < span; b += 64) {
+        uint32_t lo = 0, hi = n_act;                    // last record whose sequence starts at or before byte b
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_rel[mid] <= b) lo = mid; else hi = mid; }
+        const uint32_t k = b - s_rel[lo];
+        const int64_t base = s_src[lo];
+        const int fl = s_fl[lo];
+        const uint8_t *plane = (fl & 1) ? T.ascii : R.ascii;
+        const uint8_t c = plane[(fl & 2) ? base - (int64_t)k : base + (int64_t)k];
+        blob[span0 + b] = (fl & 2) ? comp_ascii(c) : c;
     }
-    const pav_indel r = indel[lo0 + lo];
-    const pav_aln al = aln[r.aln];
-    const int64_t k = (int64_t)(b - r.seq_off);
-    uint8_t c;
-    if (r.svtype == 0) {                               // INS: seq_tig[sv_pos_tig : +oplen]
-        const int rev = al.rev != 0;
-        const uint64_t tlen = T.len[al.tig_id];
-        const int64_t sv_pos_tig = rev ? (int64_t)tlen - (int64_t)r.qry_end : (int64_t)r.qry_pos;
-        c = ascii_at(T.ascii, T.off[al.tig_id], tlen, rev, sv_pos_tig + k);
-    } else {                                           // DEL: seq_ref[pos_ref : +oplen]
-        c = R.ascii[R.off[al.ref_id] + r.pos + (uint64_t)k];
-    }
-    blob[b] = c;
 }
 
 __global__ void homology_query_kernel(const pav_hom_query *__restrict__ q, uint32_t n, SeqView R, SeqView T,
@@ -1419,6 +1596,45 @@ int pav_cigar_load(pav_ctx *ctx, uint32_t n_aln, const pav_aln *aln, const uint8
     return PAV_OK;
 }
 
+static int pav_cigar_fetch_ops_unchecked(pav_ctx *ctx, uint32_t *ops, uint64_t *op_off);
+
+namespace {
+// Device buffers of the tile tokenizer + walk, carved out of the context's grow-only buffers.  Every size follows from the text
+// size and the row count, so nothing has to be read back before the kernels can be queued.
+struct CallBufs {
+    uint32_t n_tiles = 0;
+    uint32_t *ops = nullptr;                 // [n_tiles * 2048] padded operation slots
+    uint64_t *tile_pre = nullptr;            // [NT][n_tiles + 1]
+    uint32_t *tile_last = nullptr, *chunk_row = nullptr;
+    uint64_t *op_off = nullptr, *op_slot = nullptr, *rowbase = nullptr, *row_local = nullptr;
+    uint32_t *row_tile = nullptr, *row_i = nullptr;
+    unsigned long long *tok_err = nullptr, *err_op = nullptr;
+};
+
+int call_bufs(pav_ctx *ctx, CallBufs &B, bool reserve) {
+    const uint64_t Tpad = (ctx->text_bytes + 1 + TOK_CHUNK - 1) / TOK_CHUNK * TOK_CHUNK;
+    const size_t n_tiles = (size_t)(Tpad / TOK_CHUNK), rows = (size_t)ctx->n_aln + 2;
+    if (n_tiles >= 0x7FFFFFFFull / WALK_CHUNK * 2) return fail(ctx, PAV_E_LIMIT, "pav_cigar_call: CIGAR text too large");
+    if (reserve) {
+        PAV_HIP(ctx, ctx->d_ops.reserve(sizeof(uint32_t) * (n_tiles * WALK_CHUNK + 16)));
+        PAV_HIP(ctx, ctx->d_chunk.reserve(sizeof(uint64_t) * NT * (n_tiles + 1)));
+        PAV_HIP(ctx, ctx->d_chunk2.reserve(2 * sizeof(uint32_t) * (n_tiles + 1)));
+        PAV_HIP(ctx, ctx->d_op_off.reserve(2 * sizeof(uint64_t) * rows));
+        PAV_HIP(ctx, ctx->d_rowbase.reserve((4 * sizeof(uint64_t) + 2 * sizeof(uint32_t)) * rows));
+        PAV_HIP(ctx, ctx->d_totals.reserve(2 * sizeof(uint64_t)));
+    }
+    B.n_tiles = (uint32_t)n_tiles;
+    B.ops = ctx->d_ops.as<uint32_t>();
+    B.tile_pre = ctx->d_chunk.as<uint64_t>();
+    B.tile_last = ctx->d_chunk2.as<uint32_t>(); B.chunk_row = B.tile_last + n_tiles + 1;
+    B.op_off = ctx->d_op_off.as<uint64_t>(); B.op_slot = B.op_off + rows;
+    B.rowbase = ctx->d_rowbase.as<uint64_t>(); B.row_local = B.rowbase + 2 * rows;
+    B.row_tile = reinterpret_cast<uint32_t *>(B.row_local + 2 * rows); B.row_i = B.row_tile + rows;
+    B.tok_err = ctx->d_totals.as<unsigned long long>(); B.err_op = B.tok_err + 1;
+    return PAV_OK;
+}
+}  // namespace
+
 int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
     if (!ctx) return PAV_E_ARG;
     if (!ctx->cigar_loaded) return fail(ctx, PAV_E_STATE, "pav_cigar_call: pav_cigar_load has not been called");
@@ -1427,62 +1643,32 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
     memset(&ctx->cigar_err, 0, sizeof ctx->cigar_err);
     ctx->cigar_called = false;
     const uint32_t n_aln = ctx->n_aln;
-    const uint64_t T = ctx->text_bytes;
-    const uint64_t Tpad = round_up(T + 1, TOK_CHUNK);
-    const uint32_t n_tchunks = (uint32_t)(Tpad / TOK_CHUNK);
-
-    // one status block on the device, d_totals: [0, NQ) walk totals, [NQ] tokenizer error key, [NQ + 1] illegal-op ordinal.
-    // It comes back with a single copy into pinned host memory (h_status): several small copies into pageable memory
-    // cost hundreds of microseconds each under the concurrent pack.
-    PAV_HIP(ctx, ctx->d_totals.reserve((NQ + 2) * sizeof(uint64_t)));
-    PAV_HIP(ctx, hipMemsetAsync(ctx->d_totals.p, 0, NQ * sizeof(uint64_t), ctx->stream));
-    PAV_HIP(ctx, hipMemsetAsync(ctx->d_totals.as<uint64_t>() + NQ, 0xFF, 2 * sizeof(uint64_t), ctx->stream));
-    unsigned long long *d_tok_err = ctx->d_totals.as<unsigned long long>() + NQ;
-    unsigned long long *d_err_op = d_tok_err + 1;
+    CallBufs B;
+    { const int rcb = call_bufs(ctx, B, true); if (rcb != PAV_OK) return rcb; }
     uint64_t *h_status = ctx->h_status;
 
-    // --- tokenise -------------------------------------------------------------------------------------
-    PAV_HIP(ctx, ctx->d_chunk.reserve(sizeof(uint32_t) * n_tchunks + sizeof(uint64_t) * ((size_t)n_tchunks + 1) + 64));
-    uint32_t *d_tcnt = ctx->d_chunk.as<uint32_t>();
-    uint64_t *d_tpre = reinterpret_cast<uint64_t *>(ctx->d_chunk.as<uint8_t>() + round_up(sizeof(uint32_t) * n_tchunks, 16));
-    PAV_LAUNCH(ctx, "tok_count", tok_count, n_tchunks, 256, 0, ctx->d_text.as<uint4>(), d_tcnt);
-    PAV_LAUNCH(ctx, "scan_counts", scan_counts, 1, 256, 0, d_tcnt, d_tpre, n_tchunks, h_status);
+    // --- tokenise + sum (one pass over the text), prefix over the tiles: two launches, one synchronisation ------------------
+    PAV_HIP(ctx, hipMemsetAsync(B.tok_err, 0xFF, 2 * sizeof(uint64_t), ctx->stream));
+    TokArgs TA;
+    TA.text = ctx->d_text.as<uint8_t>(); TA.T = ctx->text_bytes; TA.text_off = ctx->d_text_off.as<uint64_t>();
+    TA.n_aln = n_aln; TA.n_tiles = B.n_tiles;
+    TA.ops = B.ops; TA.tile_agg = B.tile_pre; TA.tile_last = B.tile_last; TA.chunk_row = B.chunk_row;
+    TA.op_slot = B.op_slot; TA.row_tile = B.row_tile; TA.row_i = B.row_i; TA.row_local = B.row_local;
+    TA.tok_err = B.tok_err; TA.err_op = B.err_op;
+    PAV_LAUNCH(ctx, "tok_tiles", tok_tiles, B.n_tiles, 256, 0, TA);
+    ScanArgs SA;
+    SA.tile_agg = B.tile_pre; SA.n_tiles = B.n_tiles; SA.n_aln = n_aln;
+    SA.row_tile = B.row_tile; SA.row_i = B.row_i; SA.row_local = B.row_local; SA.op_off = B.op_off; SA.rowbase = B.rowbase;
+    SA.aln = ctx->d_aln.as<pav_aln>(); SA.ref = ctx->seq[PAV_ROLE_REF].view(); SA.tig = ctx->seq[PAV_ROLE_TIG].view();
+    SA.tok_err = B.tok_err; SA.err_op = B.err_op; SA.host_status = h_status;
+    PAV_LAUNCH(ctx, "tile_scan", tile_scan, NT, 256, 0, SA);
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const uint64_t n_ops = h_status[0];
-    ctx->n_ops = n_ops;
-    PAV_HIP(ctx, ctx->d_ops.reserve(sizeof(uint32_t) * (n_ops + 16)));
-    PAV_HIP(ctx, ctx->d_op_off.reserve(sizeof(uint64_t) * ((size_t)n_aln + 1)));
-    PAV_LAUNCH(ctx, "tok_emit", tok_emit, n_tchunks, 256, 0, ctx->d_text.as<uint8_t>(), d_tpre, ctx->d_ops.as<uint32_t>(),
-               d_tok_err);
-    PAV_LAUNCH(ctx, "row_ops", row_ops, (n_aln + 1 + 3) / 4, 256, 0, ctx->d_text.as<uint8_t>(),
-               ctx->d_text_off.as<uint64_t>(), d_tpre, ctx->d_op_off.as<uint64_t>(), n_aln, d_tok_err);
-
-    // --- walk: reduce, chunk scan, row bases -------------------------------------------------------------
-    const uint32_t n_wchunks = (uint32_t)((n_ops + WALK_CHUNK - 1) / WALK_CHUNK);
-    uint64_t totals[NQ] = {0, 0, 0, 0, 0, 0};
-    uint64_t errs[2] = {~0ull, ~0ull};
-    uint64_t *d_csum = nullptr, *d_cpre = nullptr;
-    if (n_wchunks) {
-        PAV_HIP(ctx, ctx->d_chunk2.reserve(2 * sizeof(uint64_t) * NQ * ((size_t)n_wchunks + 1)));
-        d_csum = ctx->d_chunk2.as<uint64_t>();
-        d_cpre = d_csum + (size_t)NQ * (n_wchunks + 1);
-        PAV_HIP(ctx, ctx->d_rowbase.reserve(2 * sizeof(uint64_t) * ((size_t)n_aln + 1) + sizeof(uint32_t) * ((size_t)n_wchunks + 1)));
-        PAV_LAUNCH(ctx, "walk_reduce", walk_reduce, n_wchunks, 256, 0, ctx->d_ops.as<uint32_t>(), n_ops, d_csum, d_err_op);
-        PAV_LAUNCH(ctx, "walk_chunks", walk_chunks, 1, 256, 0, d_csum, d_cpre, ctx->d_totals.as<uint64_t>(), n_wchunks, h_status);
-        PAV_LAUNCH(ctx, "row_base", row_base, (n_aln + 3) / 4, 256, 0, ctx->d_ops.as<uint32_t>(),
-                   ctx->d_op_off.as<uint64_t>(), d_cpre, ctx->d_rowbase.as<uint64_t>(),
-                   reinterpret_cast<uint32_t *>(ctx->d_rowbase.as<uint64_t>() + 2 * ((size_t)n_aln + 1)), n_aln);
-        PAV_LAUNCH(ctx, "row_check", row_check, 1, 256, 0, ctx->d_aln.as<pav_aln>(), ctx->d_rowbase.as<uint64_t>(),
-                   ctx->d_totals.as<uint64_t>(), ctx->seq[PAV_ROLE_REF].view(), ctx->seq[PAV_ROLE_TIG].view(), n_aln, h_status);
-    } else {
-        h_status[NQ + 2] = ~0ull;
-        PAV_HIP(ctx, hipMemcpyAsync(h_status, ctx->d_totals.p, (NQ + 2) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    }
-    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t totals[NQ];
     for (int q = 0; q < NQ; ++q) totals[q] = h_status[q];
-    errs[0] = h_status[NQ];
-    errs[1] = h_status[NQ + 1];
-    const uint64_t range_row = h_status[NQ + 2];
+    const uint64_t n_ops = h_status[NQ];
+    ctx->n_ops = n_ops;
+    const uint64_t errs[2] = {h_status[NT], h_status[NT + 1]};
+    const uint64_t range_row = h_status[NT + 2] < h_status[NT + 3] ? h_status[NT + 2] : h_status[NT + 3];
     // Any error is known by now (malformed token, illegal operation, a row that does not fit its records): nothing is emitted,
     // the kernels below would walk garbage or read past a record.
     const bool refuse = errs[0] != ~0ull || errs[1] != ~0ull || range_row != ~0ull;
@@ -1493,41 +1679,33 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
     ctx->counts.seq_bytes = totals[4];
     ctx->counts.aligned_bases = totals[5];
 
-    // --- emit + homology + SEQ gather ---------------------------------------------------------------------
-    if (n_wchunks && !refuse) {
+    // --- emit + homology (+ SEQ column) ---------------------------------------------------------------------
+    const char *stage = getenv("PAV_CIGAR_STAGE");      // debugging: "scan" stops behind the tokenizer / prefix kernels
+    if (n_ops && !refuse && !(stage && !strcmp(stage, "scan"))) {
         PAV_HIP(ctx, ctx->d_snv.reserve(sizeof(pav_snv) * (totals[2] + 1)));
         PAV_HIP(ctx, ctx->d_indel.reserve(sizeof(pav_indel) * (totals[3] + 1)));
-        const uint64_t blob_bytes = round_up(totals[4] + 16, 16);                 // SEQ bytes, then seq_gather's block index
-        PAV_HIP(ctx, ctx->d_seqblob.reserve(blob_bytes + sizeof(uint32_t) * (totals[4] / 256 + 2)));
-        uint32_t *d_seq_blk = reinterpret_cast<uint32_t *>(ctx->d_seqblob.as<uint8_t>() + blob_bytes);
+        PAV_HIP(ctx, ctx->d_seqblob.reserve(round_up(totals[4] + 16, 16)));
         WalkArgs A;
-        A.ops = ctx->d_ops.as<uint32_t>(); A.n_ops = n_ops;
-        A.op_off = ctx->d_op_off.as<uint64_t>(); A.aln = ctx->d_aln.as<pav_aln>(); A.n_aln = n_aln;
-        A.chunk_pre = d_cpre; A.rowbase = ctx->d_rowbase.as<uint64_t>();
-        A.chunk_row = reinterpret_cast<const uint32_t *>(A.rowbase + 2 * ((size_t)n_aln + 1));
-        A.ref = ctx->seq[PAV_ROLE_REF].view(); A.tig = ctx->seq[PAV_ROLE_TIG].view();
+        A.ops = B.ops; A.op_slot = B.op_slot; A.op_off = B.op_off; A.aln = ctx->d_aln.as<pav_aln>(); A.n_aln = n_aln;
+        A.n_tiles = B.n_tiles; A.tile_pre = B.tile_pre; A.rowbase = B.rowbase; A.chunk_row = B.chunk_row; A.tile_last = B.tile_last;
+        A.ref = SA.ref; A.tig = SA.tig;
         A.snv = ctx->d_snv.as<pav_snv>(); A.indel = ctx->d_indel.as<pav_indel>();
-        A.err_op = d_err_op;
-        PAV_LAUNCH(ctx, "walk_indel", walk_emit<WALK_INDEL>, n_wchunks, 256, 0, A);
-        // SNV rows: on the side stream, i.e. behind the contig pack when one is in flight (it is the HBM-bound kernel of the step
-        // and the rows cost 0.4 GB of scattered fetches), and behind the stubs: next to the homology scans of the main stream
-        // (beside walk_indel the two walks slowed each other down, and the stubs are on the critical path)
+        // SNV rows: on the side stream, next to the stubs and the homology scans of the main stream (13 M isolated sector
+        // fetches; the scans draw on the same budget and are on the critical path of the flagging that follows)
         if (totals[2]) {
             PAV_HIP(ctx, hipEventRecord(ctx->snv_ready, ctx->stream));
             PAV_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->snv_ready, 0));
-            PAV_LAUNCH_ON(ctx, ctx->stream2, "walk_snv", walk_emit<WALK_SNV>, n_wchunks, 256, 0, A);
+            PAV_LAUNCH_ON(ctx, ctx->stream2, "walk_snv", walk_emit<WALK_SNV>, B.n_tiles, 256, 0, A);
             PAV_HIP(ctx, hipEventRecord(ctx->snv_done, ctx->stream2));
         }
         if (totals[3]) {
+            PAV_LAUNCH(ctx, "walk_indel", walk_emit<WALK_INDEL>, B.n_tiles, 256, 0, A);
             { int rcw = wait_planes(ctx); if (rcw != PAV_OK) return rcw; }   // the packed planes may still be in flight
+            if (!(stage && !strcmp(stage, "indel")))
             // one wave per workgroup: the wave lifetimes are heavy-tailed (one long tandem repeat keeps a wave for tens of
             // microseconds), and a 256-lane workgroup holds its CU slot until the slowest of its four waves is done (0.34 -> 0.22 ms)
             PAV_LAUNCH(ctx, "homology_kernel", homology_kernel, (uint32_t)((totals[3] + 63) / 64), 64, 0,
-                       ctx->d_indel.as<pav_indel>(), totals[3], ctx->d_aln.as<pav_aln>(), A.ref, A.tig, d_seq_blk);
-            if (totals[4])
-                PAV_LAUNCH(ctx, "seq_gather", seq_gather, (uint32_t)((totals[4] + 255) / 256), 256, 0,
-                           ctx->d_indel.as<pav_indel>(), totals[3], ctx->d_aln.as<pav_aln>(), A.ref, A.tig,
-                           ctx->d_seqblob.as<uint8_t>(), totals[4], d_seq_blk);
+                       ctx->d_indel.as<pav_indel>(), totals[3], ctx->d_aln.as<pav_aln>(), A.ref, A.tig, ctx->d_seqblob.as<uint8_t>());
         }
         if (totals[2]) PAV_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->snv_done, 0));   // later readers of the SNV rows use this stream
     }
@@ -1538,7 +1716,7 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
     if (refuse) {
         // Resolve on the host (error path only): fetch op offsets and, for an illegal op, the row's ops.
         std::vector<uint64_t> op_off((size_t)n_aln + 1), text_off((size_t)n_aln + 1);
-        PAV_HIP(ctx, hipMemcpy(op_off.data(), ctx->d_op_off.p, sizeof(uint64_t) * op_off.size(), hipMemcpyDeviceToHost));
+        PAV_HIP(ctx, hipMemcpy(op_off.data(), B.op_off, sizeof(uint64_t) * op_off.size(), hipMemcpyDeviceToHost));
         PAV_HIP(ctx, hipMemcpy(text_off.data(), ctx->d_text_off.p, sizeof(uint64_t) * text_off.size(), hipMemcpyDeviceToHost));
         auto row_of = [&](const std::vector<uint64_t> &off, uint64_t x) {
             uint32_t lo = 0, hi = n_aln;
@@ -1563,12 +1741,17 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
             tok_ord = ((uint64_t)tok.aln << 32) | (uint64_t)(before + 1);
         }
         if (errs[1] != ~0ull) {
-            const uint64_t k = errs[1];
+            // the illegal operation is known by its slot: real ordinal = operations before its tile + its index in the tile
+            const uint64_t tile = errs[1] / WALK_CHUNK;
+            uint64_t pre_n = 0;
+            PAV_HIP(ctx, hipMemcpy(&pre_n, B.tile_pre + (size_t)NQ * (B.n_tiles + 1) + tile, sizeof pre_n, hipMemcpyDeviceToHost));
+            const uint64_t k = pre_n + errs[1] % WALK_CHUNK;
             ill.aln = row_of(op_off, k);
             const uint64_t first = op_off[ill.aln];
-            std::vector<uint32_t> rops((size_t)(k - first + 1));
-            PAV_HIP(ctx, hipMemcpy(rops.data(), ctx->d_ops.as<uint32_t>() + first, sizeof(uint32_t) * rops.size(),
-                                   hipMemcpyDeviceToHost));
+            std::vector<uint32_t> all((size_t)n_ops);
+            std::vector<uint64_t> dummy((size_t)n_aln + 1);
+            { const int rcf = pav_cigar_fetch_ops_unchecked(ctx, all.data(), dummy.data()); if (rcf != PAV_OK) return rcf; }
+            std::vector<uint32_t> rops(all.begin() + (ptrdiff_t)first, all.begin() + (ptrdiff_t)k + 1);
             std::vector<pav_aln> al(1);
             PAV_HIP(ctx, hipMemcpy(al.data(), ctx->d_aln.as<pav_aln>() + ill.aln, sizeof(pav_aln), hipMemcpyDeviceToHost));
             uint64_t pr = al[0].pos, pt = 0;
@@ -1599,6 +1782,22 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
     return PAV_OK;
 }
 
+// The operations live in padded tiles on the device (tok_tiles); callers get them contiguous, at their real ordinals.
+static int pav_cigar_fetch_ops_unchecked(pav_ctx *ctx, uint32_t *ops, uint64_t *op_off) {
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    CallBufs B;
+    { const int rcb = call_bufs(ctx, B, false); if (rcb != PAV_OK) return rcb; }
+    if (ops && ctx->n_ops) {
+        PAV_HIP(ctx, ctx->d_tmp.reserve(sizeof(uint32_t) * (ctx->n_ops + 16)));
+        PAV_LAUNCH(ctx, "ops_compact", ops_compact, B.n_tiles, 256, 0, B.ops, B.tile_pre + (size_t)NQ * (B.n_tiles + 1), ctx->d_tmp.as<uint32_t>());
+        PAV_HIP(ctx, hipMemcpyAsync(ops, ctx->d_tmp.p, sizeof(uint32_t) * ctx->n_ops, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (op_off)
+        PAV_HIP(ctx, hipMemcpyAsync(op_off, B.op_off, sizeof(uint64_t) * ((size_t)ctx->n_aln + 1), hipMemcpyDeviceToHost, ctx->stream));
+    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PAV_OK;
+}
+
 int pav_cigar_error(const pav_ctx *ctx, pav_cigar_err *err) {
     if (!ctx || !err) return PAV_E_ARG;
     *err = ctx->cigar_err;
@@ -1625,27 +1824,25 @@ int pav_cigar_verify(pav_ctx *ctx, pav_verify_counts *out) {
     PAV_HIP(ctx, hipSetDevice(ctx->device));
     memset(out, 0, sizeof *out);
     out->first_bad_op = ~0ull;
-    const uint64_t n_ops = ctx->n_ops;
-    const uint32_t n_wchunks = (uint32_t)((n_ops + WALK_CHUNK - 1) / WALK_CHUNK);
-    if (!n_wchunks) return PAV_OK;
+    if (!ctx->n_ops) return PAV_OK;
+    CallBufs B;
+    { const int rcb = call_bufs(ctx, B, false); if (rcb != PAV_OK) return rcb; }
     PAV_HIP(ctx, ctx->d_tmp.reserve(64));
     unsigned long long *d_cnt = ctx->d_tmp.as<unsigned long long>();
     PAV_HIP(ctx, hipMemsetAsync(d_cnt, 0, 32, ctx->stream));
     PAV_HIP(ctx, hipMemsetAsync(d_cnt + 4, 0xFF, 8, ctx->stream));
     { int rcw = need_planes_full(ctx, PAV_ROLE_TIG); if (rcw != PAV_OK) return rcw; }   // verify streams both arenas: the contig planes are packed here if they are not
     VerifyArgs A;
-    A.ops = ctx->d_ops.as<uint32_t>(); A.n_ops = n_ops;
-    A.op_off = ctx->d_op_off.as<uint64_t>(); A.aln = ctx->d_aln.as<pav_aln>(); A.n_aln = ctx->n_aln;
-    A.chunk_pre = ctx->d_chunk2.as<uint64_t>() + (size_t)NQ * (n_wchunks + 1); A.rowbase = ctx->d_rowbase.as<uint64_t>();
-    A.chunk_row = reinterpret_cast<const uint32_t *>(A.rowbase + 2 * ((size_t)ctx->n_aln + 1));
+    A.ops = B.ops; A.op_slot = B.op_slot; A.aln = ctx->d_aln.as<pav_aln>(); A.n_aln = ctx->n_aln; A.n_tiles = B.n_tiles;
+    A.tile_pre = B.tile_pre; A.rowbase = B.rowbase; A.chunk_row = B.chunk_row;
     A.ref = ctx->seq[PAV_ROLE_REF].view(); A.tig = ctx->seq[PAV_ROLE_TIG].view();
     A.cnt = d_cnt;
     // 32-bit positions when both arenas (padding included) stay below 2^32 bases; PAV_VERIFY_WIDE=1 forces the 64-bit kernel (tests)
     const char *force_wide = getenv("PAV_VERIFY_WIDE");
     const bool wide = (force_wide && *force_wide == '1') || ctx->seq[PAV_ROLE_REF].arena + 128 >= (1ull << 32) ||
                       ctx->seq[PAV_ROLE_TIG].arena + 128 >= (1ull << 32);
-    if (wide) PAV_LAUNCH(ctx, "verify_kernel", verify_kernel<true>, VSPLIT * n_wchunks, 256, 0, A);
-    else      PAV_LAUNCH(ctx, "verify_kernel", verify_kernel<false>, VSPLIT * n_wchunks, 256, 0, A);
+    if (wide) PAV_LAUNCH(ctx, "verify_kernel", verify_kernel<true>, VSPLIT * B.n_tiles, 256, 0, A);
+    else      PAV_LAUNCH(ctx, "verify_kernel", verify_kernel<false>, VSPLIT * B.n_tiles, 256, 0, A);
     unsigned long long h[5];
     PAV_HIP(ctx, hipMemcpyAsync(h, d_cnt, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1657,13 +1854,7 @@ int pav_cigar_verify(pav_ctx *ctx, pav_verify_counts *out) {
 int pav_cigar_fetch_ops(pav_ctx *ctx, uint32_t *ops, uint64_t *op_off) {
     if (!ctx) return PAV_E_ARG;
     if (!ctx->cigar_loaded) return fail(ctx, PAV_E_STATE, "pav_cigar_fetch_ops: nothing loaded");
-    PAV_HIP(ctx, hipSetDevice(ctx->device));
-    if (ops && ctx->n_ops)
-        PAV_HIP(ctx, hipMemcpyAsync(ops, ctx->d_ops.p, sizeof(uint32_t) * ctx->n_ops, hipMemcpyDeviceToHost, ctx->stream));
-    if (op_off)
-        PAV_HIP(ctx, hipMemcpyAsync(op_off, ctx->d_op_off.p, sizeof(uint64_t) * ((size_t)ctx->n_aln + 1), hipMemcpyDeviceToHost, ctx->stream));
-    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return PAV_OK;
+    return pav_cigar_fetch_ops_unchecked(ctx, ops, op_off);
 }
 
 int pav_align_index(pav_ctx *ctx, uint32_t n_aln, const uint32_t *row_pos, const uint8_t *cigar_text, const uint64_t *cigar_off,

@@ -177,21 +177,22 @@ struct PlaneSpan { uint64_t abs, len; };
 int need_planes_spans(pav_ctx *ctx, int role, const std::vector<PlaneSpan> &spans);
 int prof_flush(pav_ctx *ctx);
 
+// PAV_SYNC_EACH=1 (debugging): wait for every kernel and name it on stderr, so that a memory fault points at its launch
+bool sync_each();
 #define PAV_LAUNCH_ON(ctx, st, name, kernel, grid, block, shmem, ...)                               \
     do {                                                                                           \
         int tok__ = pav::prof_begin((ctx), name, (st));                                            \
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (shmem), (st), __VA_ARGS__);           \
         pav::prof_end((ctx), tok__, (st));                                                         \
         PAV_HIP((ctx), hipGetLastError());                                                         \
+        if (pav::sync_each()) {                                                                    \
+            fprintf(stderr, "[pav launch] %s grid %u x %u ... ", name, (unsigned)(grid), (unsigned)(block)); fflush(stderr); \
+            PAV_HIP((ctx), hipStreamSynchronize(st));                                              \
+            fprintf(stderr, "done\n");                                                             \
+        }                                                                                          \
     } while (0)
 
-#define PAV_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                                      \
-    do {                                                                                           \
-        int tok__ = pav::prof_begin((ctx), name);                                                  \
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (shmem), (ctx)->stream, __VA_ARGS__);  \
-        pav::prof_end((ctx), tok__);                                                               \
-        PAV_HIP((ctx), hipGetLastError());                                                         \
-    } while (0)
+#define PAV_LAUNCH(ctx, name, kernel, grid, block, shmem, ...) PAV_LAUNCH_ON(ctx, (ctx)->stream, name, kernel, grid, block, shmem, __VA_ARGS__)
 
 // ---- density.hip internals used by the native scan driver ---------------------------------------------------------
 struct CallFetch {              // one call of the batch still resident on the device

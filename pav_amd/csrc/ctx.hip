@@ -18,6 +18,8 @@ int fail(pav_ctx *ctx, int code, const char *fmt, ...) {
     return code;
 }
 
+bool sync_each() { const char *e = getenv("PAV_SYNC_EACH"); return e && *e == '1'; }
+
 // ---- profiling ------------------------------------------------------------------------------------------
 int prof_begin(pav_ctx *ctx, const char *name, hipStream_t st) {
     if (!st) st = ctx->stream;

@@ -59,7 +59,10 @@ def test_rule_call_lg_discover(gpu_ctx, batch, tmp_path):
 def test_version_id_not_available(gpu_ctx):
     df = pd.read_csv(os.path.join(D, 'align.tsv.gz'), sep='\t')
     with pytest.raises(NotImplementedError):
-        lgsv.scan_for_events(df, None, 'h1', os.path.join(D, 'ref.fa'), os.path.join(D, 'tig.fa'), 31, ctx=gpu_ctx)
+        lgsv.scan_for_events(df, None, 'h1', os.path.join(D, 'ref.fa'), os.path.join(D, 'tig.fa'), 31, version_id=True, ctx=gpu_ctx)
+    from pav_amd import cigarcall
+    with pytest.raises(NotImplementedError):        # asked for: refused with the reason; the default (False here) works
+        cigarcall.make_insdel_snv_calls(df, os.path.join(D, 'ref.fa'), os.path.join(D, 'tig.fa'), 'h1', version_id=True, ctx=gpu_ctx)
 
 
 def test_match_bp_quirk():
