@@ -61,8 +61,13 @@ struct JobKde {                           // host -> device after the first read
                                           // whose density is summed term by term and therefore need the scaled positions
     uint32_t all_direct, pad;             // every present state is summed term by term in ascending order: scipy's order
     uint32_t run_off[3], n_run[3];        // per-state slices of the run arena
+    uint32_t heads_off, n_heads;          // device-planned batches: the job's slice of the run arena (upper bound), its runs in all
     double inv_h[3], norm[3], w[3], cnt[3], h[3];
 };
+
+// A STATE_MER run head as k_compact_scatter leaves it in a tile's slots (device-planned batches): row (26 bits) | state << 26.
+constexpr uint32_t HEAD_ROW_MASK = (1u << 26) - 1u;
+constexpr uint32_t HEADS_PER_TILE = 32;   // slots per compaction tile; a tile with more changes sends the batch to the host-planned path
 
 struct RunDev { uint32_t a, b; };         // rows a..b (inclusive) are consecutive data points of one state
 
@@ -78,6 +83,9 @@ struct DensityState {
     DevBuf st_tmp, tile_sum, tile_pre, index, state_mer, state, kmer, kern[3], list[3], pscaled[3], fill_list;
     DevBuf tiles, events, ev_count, scratch, run_arena, win_fill, ks[3], ss;
     DevBuf guard, guard_entries, samp_flag, row_flag, ftiles; // near-tie guard; evaluation tiles of the fill list
+    DevBuf tile_heads, tile_head_cnt, heads, plan_flags, pow_tab;   // device-planned batches (k_plan)
+    std::vector<double> h_pow;                                // pow(n, -1/5), n = 0 .. size - 1 (libm, computed once and extended)
+    uint64_t n_fast = 0, n_fallback = 0;                      // batches planned on the device / sent back to the host-planned path
     std::vector<JobDev> h_jobs;
     std::vector<JobKde> h_kde;
     void *pin = nullptr; size_t pin_cap = 0;                  // pinned host scratch for the small readbacks (pageable targets are
@@ -100,7 +108,7 @@ struct DensityState {
         DevBuf *all[] = {&jobs, &stat, &kde, &tile_job_r, &tile_job_t, &keys, &cnt, &keys_x, &cnt_x, &lists, &bcount, &ans_f, &ans_c, &items, &st_tmp, &tile_sum, &tile_pre,
                          &index, &state_mer, &state, &kmer, &kern[0], &kern[1], &kern[2], &list[0], &list[1], &list[2],
                          &pscaled[0], &pscaled[1], &pscaled[2], &fill_list, &tiles, &events, &ev_count, &scratch, &run_arena, &win_fill, &ks[0], &ks[1], &ks[2], &ss,
-                         &guard, &guard_entries, &samp_flag, &row_flag, &ftiles};
+                         &guard, &guard_entries, &samp_flag, &row_flag, &ftiles, &tile_heads, &tile_head_cnt, &heads, &plan_flags, &pow_tab};
         for (DevBuf *b : all) b->release();
         if (pin) { (void)hipHostFree(pin); pin = nullptr; pin_cap = 0; }
         if (gathered) { (void)hipEventDestroy(gathered); gathered = nullptr; }
@@ -623,6 +631,7 @@ struct CompactArgs {
     const unsigned long long *tile_pre; SeqView T; int k; uint32_t min_state_count;
     uint32_t *index; int8_t *state_mer; int8_t *state; unsigned long long *kmer; uint32_t *list[3];
     HeadEvent *events; uint32_t ev_cap; uint32_t *ev_count;   // run heads of STATE_MER (closed-form run sums); null: not wanted
+    uint32_t *tile_heads, *tile_head_cnt;                     // device-planned batches instead: HEADS_PER_TILE ordered slots per tile
 };
 
 __global__ __launch_bounds__(256) void k_compact_scatter(CompactArgs A) {
@@ -695,6 +704,40 @@ __global__ __launch_bounds__(256) void k_compact_scatter(CompactArgs A) {
 #pragma unroll
     for (int s = 0; s < 3; ++s)
         for (uint32_t r = threadIdx.x; r < tot[1 + s]; r += 256) A.list[s][jd.tpos_off + tile0[1 + s] + r] = s_list[s][r];
+    if (A.tile_heads) {
+        // Device-planned batches: the tile's run heads of STATE_MER in row order, at fixed slots (no atomics, nothing to sort:
+        // tiles are ordered by (job, row)).  Row r of the tile (staged order) is a head when the state changes in front of it;
+        // the tile's first row always is one - k_plan drops it when the run continues from the tile before.
+        __shared__ uint32_t s_hcnt[DTILE / 256][4];
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        unsigned long long hb[DTILE / 256];
+#pragma unroll
+        for (int it = 0; it < DTILE / 256; ++it) {
+            const uint32_t r = it * 256 + threadIdx.x;
+            const bool head = r < tot[0] && (r == 0 || s_mer[r] != s_mer[r - 1]);
+            hb[it] = __ballot(head);
+            if (lane == 0) s_hcnt[it][wave] = (uint32_t)__popcll(hb[it]);
+        }
+        __syncthreads();
+        uint32_t before = 0;
+#pragma unroll
+        for (int it = 0; it < DTILE / 256; ++it) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const uint32_t c4 = s_hcnt[it][w];
+                if (w == wave) {
+                    const uint32_t r = it * 256 + threadIdx.x;
+                    if (hb[it] >> lane & 1ull) {
+                        const uint32_t rank = before + (uint32_t)__popcll(hb[it] & ((1ull << lane) - 1ull));
+                        if (rank < HEADS_PER_TILE)
+                            A.tile_heads[(uint64_t)blockIdx.x * HEADS_PER_TILE + rank] = (uint32_t)(tile0[0] + r) | (uint32_t)s_mer[r] << 26;
+                    }
+                }
+                before += c4;
+            }
+        }
+        if (threadIdx.x == 0) A.tile_head_cnt[blockIdx.x] = before;      // (may exceed the slots: k_plan flags it)
+    }
     // block reduction of the per-state moments, one atomic per block and quantity
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
@@ -714,6 +757,160 @@ __global__ __launch_bounds__(256) void k_compact_scatter(CompactArgs A) {
         if (tot[0]) atomicAdd(&A.stat[j].n_rows, tot[0]);
         for (int s = 0; s < 3; ++s) if (tot[1 + s]) atomicAdd(&A.stat[j].m[s], tot[1 + s]);
     }
+}
+
+// ---- device-side planning of the density stage (one wave per job) ------------------------------------------------------------
+// What the host used to do between two synchronisations of a batch (status of every region, bandwidths, sampled sites, the run
+// lists of the closed-form sums) happens here, so that the kernels of a scan round are queued back to back and the host reads
+// ONE block of results at the end (pav_density_batch, "device-planned").  The arithmetic is the host's: exact integer moments,
+// n^(-1/5) from a table the host filled with libm's pow (scipy's factor, scripts/density.py:198), IEEE sqrt and division.
+struct PlanArgs {
+    const JobDev *jobs; const JobStat *stat; JobKde *kde; uint32_t n_jobs;
+    const uint32_t *tile_heads, *tile_head_cnt; RunDev *runs;          // per-tile head slots -> per-job, per-state run lists
+    const double *pow_tab; uint32_t pow_n;                            // pow_tab[n] = pow((double)n, -1.0 / 5.0)
+    uint32_t min_informative, max_ref_kmer_count; double den_smooth, norm0;   // norm0 = pow(2 pi, -0.5) as the host's libm returns it
+    uint32_t *flags;                                                  // [0] != 0: the batch needs the host-planned path
+};
+constexpr uint32_t PLAN_TILE_OVERFLOW = 1, PLAN_POW_RANGE = 2;
+
+// (double) of an unsigned 128-bit integer, round to nearest even - what the host's conversion of the exact variance numerator does
+__device__ __forceinline__ double u128_to_double(unsigned __int128 v) {
+    const uint64_t hi = (uint64_t)(v >> 64), lo = (uint64_t)v;
+    if (hi == 0) return (double)lo;                                    // (the 64-bit conversion rounds to nearest even)
+    const int lz = __clzll((long long)hi);                             // top bit at 127 - lz
+    const int sh = 64 - lz;                                            // bits below a 64-bit window that holds the top bit
+    uint64_t top = (uint64_t)(v >> sh);                                // 64 significant bits
+    const bool sticky = (v & (((unsigned __int128)1 << sh) - 1)) != 0;
+    top |= sticky ? 1ull : 0ull;                                       // the conversion of `top` rounds on bit 11 .. 0 with this sticky bit
+    return ldexp((double)top, sh);
+}
+
+__global__ __launch_bounds__(256) void k_plan(PlanArgs A) {
+    __shared__ uint32_t s_stage[4][64 * HEADS_PER_TILE];               // a chunk of 64 tiles' heads, flattened in order (per wave)
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t j = blockIdx.x * 4 + wave;
+    if (j >= A.n_jobs) return;
+    const JobStat st = A.stat[j];
+    const JobDev jd = A.jobs[j];
+    JobKde kd = A.kde[j];                                              // samp_off / heads_off / srs come from the host (upper bounds)
+    kd.finalised = 0; kd.n = 0; kd.n_samp = 0; kd.use_runs = 0; kd.ps_mask = 0; kd.all_direct = 0; kd.n_heads = 0;
+    for (int q = 0; q < 3; ++q) { kd.m[q] = 0; kd.run_off[q] = 0; kd.n_run[q] = 0; kd.inv_h[q] = kd.norm[q] = kd.w[q] = kd.cnt[q] = kd.h[q] = 0.0; }
+    const bool fail = st.n_ref_valid == 0 || st.max_count > A.max_ref_kmer_count;                   // density.py:510-527
+    const bool fin = !fail && st.n_rows != 0 && st.n_rows >= A.min_informative;                      // :193-195
+    if (fin) {
+        const uint32_t n = st.n_rows;
+        kd.finalised = 1; kd.n = n;
+        kd.n_samp = (n + kd.srs - 1) / kd.srs;
+        if ((uint64_t)(kd.n_samp - 1) * kd.srs != n - 1) kd.n_samp += 1;                            // :213-214
+        if (n >= A.pow_n) { if (lane == 0) atomicOr(A.flags, PLAN_POW_RANGE); }
+        const double bandwidth = A.pow_tab[n < A.pow_n ? n : 0] * A.den_smooth;                      // :198
+        for (int q = 0; q < 3; ++q) {
+            const uint64_t m = st.m[q];
+            kd.m[q] = (uint32_t)m;
+            kd.cnt[q] = (double)m;
+            if (m == 0) continue;
+            const unsigned __int128 num = (unsigned __int128)m * st.s2[q] - (unsigned __int128)st.s1[q] * st.s1[q];
+            const double var = u128_to_double(num) / ((double)m * (double)(m - 1));
+            const double h = sqrt(var) * bandwidth;
+            kd.h[q] = h;
+            kd.inv_h[q] = 1.0 / h;
+            kd.norm[q] = A.norm0 / h;
+            kd.w[q] = 1.0 / (double)m;
+        }
+        // ---- run lists of STATE_MER, one per state (what kde_state_runs reads): the tiles' head slots flattened in row order;
+        //      a run that continues across a tile edge is one run.  Pass 0 counts the runs of every state, pass 1 writes them
+        //      behind one another: [run_off[s], run_off[s] + n_run[s]) of the job's slice of the run arena.
+        const uint32_t n_tiles = (uint32_t)((std::max<uint64_t>(jd.tig_len, 1) + DTILE - 1) / DTILE);
+        uint32_t out = 0, cnt_s[3] = {0, 0, 0};
+        bool over = false;
+        for (int pass = 0; pass < 2; ++pass) {
+            uint32_t base_s[3] = {0, 0, 0}, carry_st = 3, pend = ~0u;          // pend: slot of the run that is still open
+            if (pass) { base_s[0] = kd.heads_off; base_s[1] = base_s[0] + cnt_s[0]; base_s[2] = base_s[1] + cnt_s[1]; }
+            for (uint32_t c0 = 0; c0 < n_tiles; c0 += 64) {
+                const uint32_t tile = jd.first_tile + c0 + lane;
+                uint32_t cnt = c0 + lane < n_tiles ? A.tile_head_cnt[tile] : 0u;
+                if (cnt > HEADS_PER_TILE) { over = true; cnt = HEADS_PER_TILE; }
+                uint32_t inc = cnt;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(inc, d); if ((int)lane >= d) inc += y; }
+                const uint32_t total = __shfl(inc, 63), at = inc - cnt;
+                for (uint32_t e = 0; e < cnt; ++e) s_stage[wave][at + e] = A.tile_heads[(uint64_t)tile * HEADS_PER_TILE + e];
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t b = 0; b < total; b += 64) {
+                    const uint32_t i = b + lane;
+                    const bool live = i < total;
+                    const uint32_t wv = live ? s_stage[wave][i] : 0u;
+                    const uint32_t stt = (wv >> 26) & 3u, row = wv & HEAD_ROW_MASK;
+                    const uint32_t prev = i ? ((live ? s_stage[wave][i - 1] : 0u) >> 26) & 3u : carry_st;
+                    const bool head = live && stt != prev;
+                    const unsigned long long mh = __ballot(head);
+                    const unsigned long long lt = (1ull << lane) - 1ull;
+                    uint32_t slot = 0;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const unsigned long long mq = __ballot(head && stt == (uint32_t)q);
+                        if (stt == (uint32_t)q) slot = base_s[q] + (uint32_t)__popcll(mq & lt);
+                        base_s[q] += (uint32_t)__popcll(mq);
+                    }
+                    if (pass && mh) {
+                        // a head opens its run and closes the run of the head in front of it (this chunk's, or the open one carried in)
+                        const unsigned long long below = mh & lt;
+                        const int pl = below ? 63 - __clzll((long long)below) : 0;
+                        const uint32_t pslot = (uint32_t)__shfl((int)slot, pl);
+                        if (head) {
+                            A.runs[slot].a = row;
+                            const uint32_t close = below ? pslot : pend;
+                            if (close != ~0u) A.runs[close].b = row - 1u;
+                        }
+                        pend = (uint32_t)__shfl((int)slot, 63 - __clzll((long long)mh));
+                    }
+                    out += pass ? 0u : (uint32_t)__popcll(mh);
+                    const uint32_t last = total - b < 64 ? total - b - 1 : 63;
+                    carry_st = (uint32_t)__shfl((int)stt, (int)last);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (!pass) { for (int q = 0; q < 3; ++q) cnt_s[q] = base_s[q]; }
+            else if (pend != ~0u && lane == 0) A.runs[pend].b = n - 1u;        // the last run ends with the table
+        }
+        if (over && lane == 0) atomicOr(A.flags, PLAN_TILE_OVERFLOW);
+        kd.n_heads = out;
+        kd.run_off[0] = kd.heads_off; kd.run_off[1] = kd.run_off[0] + cnt_s[0]; kd.run_off[2] = kd.run_off[1] + cnt_s[1];
+        for (int q = 0; q < 3; ++q) kd.n_run[q] = cnt_s[q];
+        kd.use_runs = out <= KDE_RUNS_MAX ? 1u : 0u;                    // very fragmented region: direct kernel
+        kd.all_direct = kd.use_runs ? 0u : 1u;
+        for (int q = 0; q < 3; ++q)
+            if (kd.m[q] && !(kd.use_runs && kd.h[q] >= KDE_RUNS_MIN_H)) kd.ps_mask |= 1u << q;
+    }
+    if (lane == 0) A.kde[j] = kd;
+}
+
+// Evaluation tiles of the windows k_windows queued (device-planned batches): 64 fill points each, in job order.
+struct FillPlanArgs { const JobStat *stat; const JobKde *kde; uint32_t n_jobs; EvalTile *ftiles; uint32_t *n_ftiles; uint32_t cap; };
+__global__ __launch_bounds__(1024) void k_plan_fill(FillPlanArgs A) {
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t j0 = 0; j0 < A.n_jobs; j0 += 1024) {
+        const uint32_t j = j0 + threadIdx.x;
+        const uint32_t fill = j < A.n_jobs && A.kde[j].finalised ? A.stat[j].fill_n : 0u;
+        const uint32_t nt = (fill + 63) / 64;
+        uint32_t inc = nt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(inc, d); if ((int)lane >= d) inc += y; }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        uint32_t at = s_carry + inc - nt, tot = 0;
+        for (int w = 0; w < 16; ++w) { if (w < (int)wave) at += s_wave[w]; tot += s_wave[w]; }
+        for (uint32_t f = 0; f < nt; ++f)
+            if (at + f < A.cap) A.ftiles[at + f] = EvalTile{j, f * 64, fill - f * 64 < 64 ? fill - f * 64 : 64u, 1u};
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *A.n_ftiles = s_carry < A.cap ? s_carry : A.cap;
 }
 
 // ---- KDE -----------------------------------------------------------------------------------------------------
@@ -915,25 +1112,33 @@ __device__ __forceinline__ double kde_state_runs(const RunDev *__restrict__ runs
     return sum;
 }
 
+#ifndef PAV_KDE_WAVES                 // waves per evaluation tile (tuning builds override it): 1 / 2 / 4 / 8 waves gave
+#define PAV_KDE_WAVES 2               // 0.104 / 0.097 / 0.111 / 0.148 ms per launch - a tile's lifetime is a chain of dependent loads,
+#endif                                // and small workgroups let more tiles hide each other's latency
+constexpr int KDE_WAVES = PAV_KDE_WAVES;
 struct KdeArgs {
     const JobDev *jobs; const JobKde *kde; const EvalTile *tiles; const uint32_t *fill_list;
     const double *ps[3]; double *kern[3]; int8_t *state; const RunDev *runs;
     double *ks[3]; int8_t *ss;            // sampled sites, compact: entry samp_off + q of job j = row min(q * srs, n - 1)
     GuardArgs G;
+    uint32_t n_tiles;                     // tiles in the list; the workgroups go round them (grid = n_tiles: one each)
+    const uint32_t *n_tiles_dev;          // device-planned batches: ... or the count k_plan_fill left on the device
+    uint32_t dyn;                         // device-planned batches: the tile counts of the sampled sites come from the job (the
+                                          // list holds upper bounds)
 };
 
 // One workgroup per tile of 64 evaluation points of one job.  Lane l of every wave stands for point l; the waves share the
 // runs of a state (wave w takes runs w, w + KDE_WAVES, ...) and wave 0 adds their partial sums in wave order - a fixed order,
 // so the result does not depend on scheduling; a region whose states alternate thousands of times does not hang on one lane.
 // States summed term by term in scipy's order (PAV_KDE_DIRECT) stay on wave 0.
-#ifndef PAV_KDE_WAVES                 // waves per evaluation tile (tuning builds override it): 1 / 2 / 4 / 8 waves gave
-#define PAV_KDE_WAVES 2               // 0.104 / 0.097 / 0.111 / 0.148 ms per launch - a tile's lifetime is a chain of dependent loads,
-#endif                                // and small workgroups let more tiles hide each other's latency
-constexpr int KDE_WAVES = PAV_KDE_WAVES;
 __global__ __launch_bounds__(64 * KDE_WAVES) void k_kde_eval(KdeArgs A) {
     __shared__ double part[KDE_WAVES][3][64];
-    const EvalTile t = A.tiles[blockIdx.x];
+    const uint32_t n_tiles = A.n_tiles_dev ? *A.n_tiles_dev : A.n_tiles;
+    for (uint32_t tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
+    EvalTile t = A.tiles[tile_id];
     const JobKde kd = A.kde[t.job];
+    if (A.dyn && t.mode == 0) t.count = kd.finalised && t.first < kd.n_samp ? (kd.n_samp - t.first < 64 ? kd.n_samp - t.first : 64u) : 0u;
+    if (t.count == 0) continue;                                        // (uniform) an upper-bound tile behind the job's last site
     const uint64_t off = A.jobs[t.job].tpos_off;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool active = lane < t.count;
@@ -975,7 +1180,7 @@ __global__ __launch_bounds__(64 * KDE_WAVES) void k_kde_eval(KdeArgs A) {
         part[wave][s][lane] = v;
     }
     __syncthreads();
-    if (wave != 0 || !active) return;
+    if (wave == 0 && active) {
     double val[3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
@@ -1002,6 +1207,9 @@ __global__ __launch_bounds__(64 * KDE_WAVES) void k_kde_eval(KdeArgs A) {
     } else {
 #pragma unroll
         for (int s = 0; s < 3; ++s) A.kern[s][off + x] = val[s];
+    }
+    }
+    __syncthreads();                                                   // `part` is written again by the next tile
     }
 }
 
@@ -1686,6 +1894,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     CA.index = D->index.as<uint32_t>(); CA.state_mer = D->state_mer.as<int8_t>(); CA.state = D->state.as<int8_t>();
     CA.kmer = D->kmer.as<unsigned long long>();
     for (int s = 0; s < 3; ++s) CA.list[s] = D->list[s].as<uint32_t>();
+    CA.events = nullptr; CA.ev_cap = 0; CA.ev_count = nullptr; CA.tile_heads = nullptr; CA.tile_head_cnt = nullptr;
     std::vector<JobStat> hs(n_jobs);
     constexpr uint32_t EV_PREFETCH = 16384;                            // head events copied together with their count
     // pinned readback area: [event count | first events] [per-job statistics] [guard counters]
@@ -1778,6 +1987,194 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
         take_stats();
         return rcv;
     };
+    // ---- device-planned batch: every kernel of the density stage queued back to back, ONE readback at the end ------------------
+    // (k_plan / k_plan_fill do what the host does between the three synchronisations of the path below).  Taken for run-sum
+    // batches whose k-mer sets all live in LDS; whatever it cannot finish - a partition overflow or a count above the limit
+    // (HBM tables), a near-tie the guard wants re-evaluated, more STATE_MER changes in one tile than its slots hold - sends
+    // the whole batch through the host-planned path below, which is the same arithmetic with every rare path in it.
+    const uint64_t t_rows_before = 0; (void)t_rows_before;
+    bool fast = want_runs && n_hbm_jobs == 0 && !items.empty() && getenv("PAV_DENSITY_HOST") == nullptr;
+    if (fast) {
+        uint32_t max_len = 0;
+        for (uint32_t j = 0; j < n_jobs; ++j) max_len = std::max(max_len, D->h_jobs[j].tig_len);
+        if (D->h_pow.size() < (size_t)max_len + 2) {                   // libm's pow, as scipy's factor is computed (density.py:198)
+            const size_t old_n = D->h_pow.size(), new_n = std::max<size_t>((size_t)max_len + 2, 2 * old_n);
+            D->h_pow.resize(new_n);
+            for (size_t n = old_n; n < new_n; ++n) D->h_pow[n] = std::pow((double)n, -1.0 / 5.0);
+            PAV_HIP(ctx, hipStreamSynchronize(st));                    // (a kernel of an earlier batch may still read the old table)
+            PAV_HIP(ctx, D->pow_tab.reserve(sizeof(double) * new_n));
+            PAV_HIP(ctx, hipMemcpyAsync(D->pow_tab.p, D->h_pow.data(), sizeof(double) * new_n, hipMemcpyHostToDevice, st));
+        }
+        // upper bounds known before anything runs: rows <= contig positions of the region
+        D->h_kde.assign(n_jobs, JobKde{});
+        std::vector<EvalTile> tiles_ub;
+        uint64_t samp_ub = 0;
+        for (uint32_t j = 0; j < n_jobs; ++j) {
+            JobKde &kd = D->h_kde[j];
+            const JobDev &jd = D->h_jobs[j];
+            kd.srs = jd.srs;
+            kd.samp_off = (uint32_t)samp_ub;
+            kd.heads_off = jd.first_tile * HEADS_PER_TILE;
+            const uint32_t ns = (std::max<uint32_t>(jd.tig_len, 1) + jd.srs - 1) / jd.srs + 1;
+            samp_ub += ns;
+            for (uint32_t f = 0; f < ns; f += 64) tiles_ub.push_back(EvalTile{j, f, 64u, 0u});
+        }
+        if (samp_ub > 0xFFFFFFFFull) fast = false;
+        if (fast) {
+            const size_t ft_cap = (size_t)(a_t / 64 + n_jobs + 1);
+            PAV_HIP(ctx, D->tile_heads.reserve(4ull * HEADS_PER_TILE * n_tiles_t));
+            PAV_HIP(ctx, D->tile_head_cnt.reserve(4ull * n_tiles_t));
+            PAV_HIP(ctx, D->heads.reserve(sizeof(RunDev) * ((size_t)HEADS_PER_TILE * n_tiles_t + 1)));
+            PAV_HIP(ctx, D->plan_flags.reserve(16));
+            PAV_HIP(ctx, D->ftiles.reserve(sizeof(EvalTile) * ft_cap));
+            PAV_HIP(ctx, D->tiles.reserve(sizeof(EvalTile) * tiles_ub.size()));
+            for (int q = 0; q < 3; ++q) PAV_HIP(ctx, D->ks[q].reserve(8 * (samp_ub + 1)));
+            PAV_HIP(ctx, D->ss.reserve(samp_ub + 1));
+            PAV_HIP(ctx, D->scratch.reserve(4ull * (a_t / 256 + 1)));
+            GuardArgs G{};
+            G.rel = pp->guard_rel == 0.0 ? GUARD_REL_DEFAULT : pp->guard_rel;
+            G.unres = GUARD_UNRESOLVED;
+            G.cap = pp->guard_cap ? pp->guard_cap : GUARD_CAP_DEFAULT;
+            G.stat = d_stat;
+            if (G.rel > 0.0) {
+                PAV_HIP(ctx, D->guard.reserve(sizeof(GuardDev)));
+                PAV_HIP(ctx, D->guard_entries.reserve(8ull * G.cap));
+                PAV_HIP(ctx, D->samp_flag.reserve(4 * (samp_ub + 2)));
+                PAV_HIP(ctx, D->row_flag.reserve(a_t));
+                G.g = D->guard.as<GuardDev>(); G.entries = D->guard_entries.as<unsigned long long>();
+                G.samp_flag = D->samp_flag.as<uint32_t>(); G.row_flag = D->row_flag.as<uint8_t>();
+                PAV_HIP(ctx, hipMemsetAsync(G.g, 0, sizeof(GuardDev), st));
+                PAV_HIP(ctx, hipMemsetAsync(G.samp_flag, 0, 4 * (samp_ub + 2), st));
+                PAV_HIP(ctx, hipMemsetAsync(G.row_flag, 0, a_t, st));
+            }
+            PAV_HIP(ctx, hipMemsetAsync(D->plan_flags.p, 0, 16, st));
+            PAV_HIP(ctx, hipMemcpyAsync(D->kde.p, D->h_kde.data(), sizeof(JobKde) * n_jobs, hipMemcpyHostToDevice, st));
+            PAV_HIP(ctx, hipMemcpyAsync(D->tiles.p, tiles_ub.data(), sizeof(EvalTile) * tiles_ub.size(), hipMemcpyHostToDevice, st));
+            CA.tile_heads = D->tile_heads.as<uint32_t>(); CA.tile_head_cnt = D->tile_head_cnt.as<uint32_t>();
+            PAV_LAUNCH(ctx, "k_compact_reduce", k_compact_reduce, n_tiles_t, 256, 0, d_tjt, d_stat, D->st_tmp.as<int8_t>(),
+                       pp->min_state_count, D->tile_sum.as<uint32_t>());
+            PAV_LAUNCH(ctx, "k_scan_tiles4", k_scan_tiles4, 1, 256, 0, D->tile_sum.as<uint32_t>(), D->tile_pre.as<unsigned long long>(),
+                       n_tiles_t);
+            PAV_LAUNCH(ctx, "k_compact_scatter", k_compact_scatter, n_tiles_t, 256, 0, CA);
+            CA.tile_heads = nullptr; CA.tile_head_cnt = nullptr;
+            PlanArgs PA;
+            PA.jobs = d_jobs; PA.stat = d_stat; PA.kde = D->kde.as<JobKde>(); PA.n_jobs = n_jobs;
+            PA.tile_heads = D->tile_heads.as<uint32_t>(); PA.tile_head_cnt = D->tile_head_cnt.as<uint32_t>(); PA.runs = D->heads.as<RunDev>();
+            PA.pow_tab = D->pow_tab.as<double>(); PA.pow_n = (uint32_t)D->h_pow.size();
+            PA.min_informative = pp->min_informative; PA.max_ref_kmer_count = pp->max_ref_kmer_count; PA.den_smooth = pp->den_smooth;
+            PA.norm0 = std::pow(2 * 3.14159265358979323846, -0.5);
+            PA.flags = D->plan_flags.as<uint32_t>();
+            PAV_LAUNCH(ctx, "k_plan", k_plan, (n_jobs + 3) / 4, 256, 0, PA);
+            const JobKde *d_kde = D->kde.as<JobKde>();
+            PAV_LAUNCH(ctx, "k_pscale", k_pscale, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_kde, D->list[0].as<uint32_t>(),
+                       D->list[1].as<uint32_t>(), D->list[2].as<uint32_t>(), D->pscaled[0].as<double>(), D->pscaled[1].as<double>(),
+                       D->pscaled[2].as<double>());
+            KdeArgs KA;
+            KA.jobs = d_jobs; KA.kde = d_kde; KA.fill_list = D->fill_list.as<uint32_t>(); KA.state = D->state.as<int8_t>();
+            KA.runs = D->heads.as<RunDev>(); KA.dyn = 1;
+            for (int q = 0; q < 3; ++q) { KA.ps[q] = D->pscaled[q].as<double>(); KA.kern[q] = D->kern[q].as<double>(); KA.ks[q] = D->ks[q].as<double>(); }
+            KA.ss = D->ss.as<int8_t>();
+            G.pass = 0;
+            KA.G = G;
+            KA.tiles = D->tiles.as<EvalTile>(); KA.n_tiles = (uint32_t)tiles_ub.size(); KA.n_tiles_dev = nullptr;
+            PAV_LAUNCH(ctx, "k_kde_eval", k_kde_eval, (uint32_t)tiles_ub.size(), 64 * KDE_WAVES, 0, KA);
+            PAV_LAUNCH(ctx, "k_windows", k_windows, (uint32_t)tiles_ub.size(), 64, 0, d_jobs, D->tiles.as<EvalTile>(), d_kde, D->state_mer.as<int8_t>(),
+                       D->ss.as<int8_t>(), D->ks[0].as<double>(), D->ks[1].as<double>(), D->ks[2].as<double>(),
+                       pp->state_run_delta, D->fill_list.as<uint32_t>(), D->win_fill.as<uint8_t>(), d_stat, G);
+            FillPlanArgs FP;
+            FP.stat = d_stat; FP.kde = d_kde; FP.n_jobs = n_jobs; FP.ftiles = D->ftiles.as<EvalTile>();
+            FP.n_ftiles = D->plan_flags.as<uint32_t>() + 1; FP.cap = (uint32_t)std::min<size_t>(ft_cap, 0xFFFFFFFFu);
+            PAV_LAUNCH(ctx, "k_plan_fill", k_plan_fill, 1, 1024, 0, FP);
+            KA.tiles = D->ftiles.as<EvalTile>(); KA.n_tiles = 0; KA.n_tiles_dev = FP.n_ftiles; KA.dyn = 0;
+            PAV_LAUNCH(ctx, "k_kde_eval", k_kde_eval, (uint32_t)std::min<size_t>(ft_cap, 8192), 64 * KDE_WAVES, 0, KA);
+            { const int rce = prepare_events(a_t); if (rce != PAV_OK) return rce; }
+            FinArgs FA;
+            FA.jobs = d_jobs; FA.tile_job = d_tjt; FA.kde = d_kde; FA.stat = d_stat; FA.win_fill = D->win_fill.as<uint8_t>();
+            FA.state = D->state.as<int8_t>(); FA.index = D->index.as<uint32_t>();
+            for (int q = 0; q < 3; ++q) { FA.ks[q] = D->ks[q].as<double>(); FA.kern[q] = D->kern[q].as<double>(); }
+            FA.G = G; FA.ev_cap = ev_cap; FA.events = D->events.as<HeadEvent>(); FA.ev_count = D->ev_count.as<uint32_t>();
+            FA.blk_spike = G.rel > 0.0 ? D->scratch.as<uint32_t>() : nullptr;
+            PAV_LAUNCH(ctx, "k_finalize", k_finalize, (uint32_t)(a_t / 256), 256, 0, FA);
+            if (G.rel > 0.0)
+                PAV_LAUNCH(ctx, "k_spike_sum", k_spike_sum, n_jobs, 256, 0, d_jobs, d_kde, D->scratch.as<uint32_t>(), d_stat);
+            // the one readback: guard counters, plan flags, statistics, run heads of STATE
+            uint8_t *h_guard_pin = h_pin + pin_guard_off;
+            if (G.g) PAV_HIP(ctx, hipMemcpyAsync(h_guard_pin, G.g, sizeof(GuardDev), hipMemcpyDeviceToHost, st));
+            PAV_HIP(ctx, hipMemcpyAsync(h_guard_pin + 32, D->plan_flags.p, 16, hipMemcpyDeviceToHost, st));
+            { const int rcq = queue_stats(); if (rcq != PAV_OK) return rcq; }
+            std::vector<HeadEvent> ev;
+            { const int rch = read_events(D->state.as<int8_t>(), ev); if (rch != PAV_OK) return rch; }
+            take_stats();
+            lap("device plan");
+            if (timing) fprintf(stderr, "[pav timing]   device-planned batches so far: %llu, sent back to the host-planned path: %llu\n",
+                                (unsigned long long)D->n_fast + 1, (unsigned long long)D->n_fallback);
+            GuardDev h_guard{};
+            uint32_t h_flags[4] = {0, 0, 0, 0};
+            if (G.g) memcpy(&h_guard, h_guard_pin, sizeof h_guard);
+            memcpy(h_flags, h_guard_pin + 32, sizeof h_flags);
+            bool redo = h_flags[0] != 0 || h_guard.n_entries != 0 || h_guard.overflow != 0 || h_flags[1] >= FP.cap;
+            for (uint32_t j = 0; j < n_jobs && !redo; ++j) redo = hs[j].lds_flags != 0;
+            if (!redo) {
+                D->n_fast += 1;
+                // results: the host's own arithmetic on the same statistics (what k_plan did on the device)
+                double pairs = 0, points = 0, data_pairs = 0;
+                for (uint32_t j = 0; j < n_jobs; ++j) {
+                    pav_den_result &r = D->results[j];
+                    const JobStat &q = hs[j];
+                    r.n_rows = q.n_rows;
+                    for (int t3 = 0; t3 < 3; ++t3) r.state_count[t3] = q.m[t3];
+                    r.max_count = q.max_count;
+                    if (q.n_ref_valid == 0) { r.status = PAV_DEN_FAIL; r.fail_kind = 1; r.n_rows = 0; continue; }
+                    if (q.max_count > pp->max_ref_kmer_count) { r.status = PAV_DEN_FAIL; r.fail_kind = 2; r.n_rows = 0; continue; }   // (not reached: LDS_EXCEED)
+                    if (q.n_rows < pp->min_informative || q.n_rows == 0) { r.status = PAV_DEN_UNFINALISED; continue; }
+                    r.status = PAV_DEN_OK;
+                    const uint32_t n = q.n_rows, srs = D->h_jobs[j].srs;
+                    uint32_t n_samp = (n + srs - 1) / srs;
+                    if ((uint64_t)(n_samp - 1) * srs != n - 1) n_samp += 1;
+                    r.n_sample = n_samp;
+                    r.n_eval = (uint64_t)n_samp + q.fill_n;
+                    const double bandwidth = D->h_pow[n] * pp->den_smooth;
+                    double runs_total = 0;
+                    for (int t3 = 0; t3 < 3; ++t3) {
+                        const uint64_t m = q.m[t3];
+                        if (m == 0) continue;
+                        const unsigned __int128 num = (unsigned __int128)m * q.s2[t3] - (unsigned __int128)q.s1[t3] * q.s1[t3];
+                        r.h[t3] = std::sqrt((double)num / ((double)m * (double)(m - 1))) * bandwidth;
+                    }
+                    (void)runs_total;
+                    points += (double)r.n_eval;
+                    data_pairs += (double)r.n_eval * ((double)q.m[0] + q.m[1] + q.m[2]);
+                    r.n_near_tie = q.n_near; r.n_reeval = q.n_reeval; r.n_unresolved = q.n_unres; r.n_spike_near = q.n_spike;
+                    r.guard_fallback = 0;
+                }
+                pairs = points;                                          // (run pairs are not counted on this path; at least one run per point)
+                ctx->kde_work[0] += points; ctx->kde_work[1] += pairs; ctx->kde_work[2] += data_pairs;
+                for (size_t e = 0; e < ev.size(); ++e) {
+                    const HeadEvent &h = ev[e];
+                    if (h.state == -2 || D->results[h.job].status == PAV_DEN_FAIL) continue;
+                    const HeadEvent &nx = ev[e + 1];
+                    D->runs[h.job].push_back(pav_run{h.state, nx.row - h.row, (int64_t)h.index, (int64_t)nx.prev_index});
+                }
+                for (uint32_t j = 0; j < n_jobs; ++j) {
+                    D->results[j].n_runs = (uint32_t)D->runs[j].size();
+                    results[j] = D->results[j];
+                }
+                lap("rl");
+                D->valid = true;
+                return PAV_OK;
+            }
+            // back to the host-planned path: the compaction is repeated there, its counters start from zero
+            D->n_fallback += 1;
+            for (uint32_t j = 0; j < n_jobs; ++j) {
+                JobStat &q = hs[j];
+                q.n_rows = 0; q.fill_n = 0; q.n_near = q.n_reeval = q.n_unres = q.n_spike = 0;
+                for (int t3 = 0; t3 < 3; ++t3) { q.m[t3] = 0; q.s1[t3] = 0; q.s2[t3] = 0; }
+            }
+            PAV_HIP(ctx, hipMemcpyAsync(d_stat, hs.data(), sizeof(JobStat) * n_jobs, hipMemcpyHostToDevice, st));
+            D->results.assign(n_jobs, pav_den_result{});
+            D->runs.assign(n_jobs, {});
+        }
+    }
     { const int rcc = compact_and_read(); if (rcc != PAV_OK) return rcc; }
     lap("kmer+compact");
     std::vector<uint8_t> in_x(n_jobs, 0);                              // the job's HBM table lives in keys_x / cnt_x
@@ -1973,7 +2370,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
 
     KdeArgs KA;
     KA.jobs = d_jobs; KA.kde = d_kde; KA.fill_list = D->fill_list.as<uint32_t>(); KA.state = D->state.as<int8_t>();
-    KA.runs = D->run_arena.as<RunDev>();
+    KA.runs = D->run_arena.as<RunDev>(); KA.dyn = 0; KA.n_tiles_dev = nullptr; KA.n_tiles = 0;
     for (int s = 0; s < 3; ++s) { KA.ps[s] = D->pscaled[s].as<double>(); KA.kern[s] = D->kern[s].as<double>(); KA.ks[s] = D->ks[s].as<double>(); }
     KA.ss = D->ss.as<int8_t>();
     RedoArgs RA;
@@ -2026,7 +2423,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
                        D->pscaled[2].as<double>());
         G.pass = 0;
         KA.G = G;
-        KA.tiles = D->tiles.as<EvalTile>();
+        KA.tiles = D->tiles.as<EvalTile>(); KA.n_tiles = (uint32_t)tiles.size();
         PAV_LAUNCH(ctx, "k_kde_eval", k_kde_eval, (uint32_t)tiles.size(), 64 * KDE_WAVES, 0, KA);
         uint32_t processed = 0;                                        // list entries whose sampled sites have been evaluated again
         bool overflow = false;
@@ -2070,7 +2467,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             if (!ftiles.empty()) {
                 PAV_HIP(ctx, D->ftiles.reserve(sizeof(EvalTile) * ftiles.size()));
                 PAV_HIP(ctx, hipMemcpyAsync(D->ftiles.p, ftiles.data(), sizeof(EvalTile) * ftiles.size(), hipMemcpyHostToDevice, st));
-                KA.tiles = D->ftiles.as<EvalTile>();
+                KA.tiles = D->ftiles.as<EvalTile>(); KA.n_tiles = (uint32_t)ftiles.size();
                 PAV_LAUNCH(ctx, "k_kde_eval", k_kde_eval, (uint32_t)ftiles.size(), 64 * KDE_WAVES, 0, KA);
             }
             if (processed) {                                           // rows queued earlier: scipy's order overrides the run sums
