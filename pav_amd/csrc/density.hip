@@ -509,7 +509,8 @@ __global__ __launch_bounds__(LDS_THREADS) void k_kmer_lds(const PartItem *__rest
 // jobs with HBM tables were done by k_tig_state.
 __global__ __launch_bounds__(256) void k_state_combine(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
                                                        const uint8_t *__restrict__ ans_f, const uint8_t *__restrict__ ans_c,
-                                                       int8_t *__restrict__ st_tmp, JobStat *__restrict__ stat) {
+                                                       int8_t *__restrict__ st_tmp, JobStat *__restrict__ stat,
+                                                       uint32_t *__restrict__ tile_cnt /* [tiles][4]: [1 + s] rows of state s; null: not wanted */) {
     __shared__ uint32_t red[4][3];
     const uint32_t j = tile_job[blockIdx.x];
     if (!jobs[j].n_parts) return;
@@ -541,7 +542,62 @@ __global__ __launch_bounds__(256) void k_state_combine(const JobDev *__restrict_
     if (threadIdx.x < 3) {
         const uint32_t v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
         if (v) atomicAdd(&stat[j].st_count[threadIdx.x], v);
+        if (tile_cnt) tile_cnt[(uint64_t)blockIdx.x * 4 + 1 + threadIdx.x] = v;
     }
+}
+
+// Device-planned batches: the compaction prefix straight from k_state_combine's per-tile state counts - a state whose job total
+// is below the minimum is dropped (density.py:181-190) - one workgroup per counter ([0] rows kept, [1 + s] rows of state s kept),
+// 4096 tiles per step.  Replaces k_compact_reduce + the single-workgroup k_scan_tiles4 of the host-planned path.
+__global__ __launch_bounds__(256) void k_scan_tiles_keep(const uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_job,
+                                                        const JobStat *__restrict__ stat, uint32_t min_state_count,
+                                                        unsigned long long *__restrict__ tile_pre, uint32_t n_tiles) {
+    constexpr int PER = 16;
+    __shared__ uint32_t lds[4];
+    __shared__ uint32_t tile[256 * (PER + 1)];
+    const uint32_t q = blockIdx.x;
+    unsigned long long carry = 0;
+    for (uint32_t base = 0; base < n_tiles; base += 256 * PER) {
+        uint32_t c[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const uint32_t i = base + k * 256 + threadIdx.x;
+            uint32_t v = 0;
+            if (i < n_tiles) {
+                const JobStat &js = stat[tile_job[i]];
+                if (q) v = js.st_count[q - 1] >= min_state_count ? tile_cnt[(uint64_t)i * 4 + q] : 0u;
+                else
+#pragma unroll
+                    for (int s3 = 0; s3 < 3; ++s3) v += js.st_count[s3] >= min_state_count ? tile_cnt[(uint64_t)i * 4 + 1 + s3] : 0u;
+            }
+            c[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { const uint32_t jx = k * 256 + threadIdx.x; tile[jx + jx / PER] = c[k]; }
+        __syncthreads();
+        uint32_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { c[k] = tile[threadIdx.x * (PER + 1) + k]; sum += c[k]; }
+        uint32_t inc = sum;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(inc, d); if (lane >= d) inc += y; }
+        if (lane == 63) lds[wave] = inc;
+        __syncthreads();
+        uint32_t before = inc - sum, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { if (w < wave) before += lds[w]; tot += lds[w]; }
+        unsigned long long run = carry + before;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const uint32_t i = base + threadIdx.x * PER + k;
+            if (i < n_tiles) tile_pre[(uint64_t)i * 4 + q] = run;
+            run += c[k];
+        }
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_pre[(uint64_t)n_tiles * 4 + q] = carry;
 }
 
 // ---- compaction to informative rows (scripts/density.py:178-203) ----------------------------------------------
@@ -1880,7 +1936,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
                    pp->max_ref_kmer_count, D->lists.as<uint32_t>(), D->bcount.as<uint32_t>(), D->ans_f.as<uint8_t>(),
                    D->ans_c.as<uint8_t>(), d_stat);
         PAV_LAUNCH(ctx, "k_state_combine", k_state_combine, n_tiles_t, 256, 0, d_jobs, d_tjt, D->ans_f.as<uint8_t>(),
-                   D->ans_c.as<uint8_t>(), D->st_tmp.as<int8_t>(), d_stat);
+                   D->ans_c.as<uint8_t>(), D->st_tmp.as<int8_t>(), d_stat, D->tile_sum.as<uint32_t>());
     }
     if (n_hbm_jobs) {
         PAV_LAUNCH(ctx, "k_ref_insert", k_ref_insert, (uint32_t)(a_r / 256), 256, 0, d_jobs, d_tjr, RV, k, pp->max_ref_kmer_count,
@@ -2051,10 +2107,8 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             PAV_HIP(ctx, hipMemcpyAsync(D->kde.p, D->h_kde.data(), sizeof(JobKde) * n_jobs, hipMemcpyHostToDevice, st));
             PAV_HIP(ctx, hipMemcpyAsync(D->tiles.p, tiles_ub.data(), sizeof(EvalTile) * tiles_ub.size(), hipMemcpyHostToDevice, st));
             CA.tile_heads = D->tile_heads.as<uint32_t>(); CA.tile_head_cnt = D->tile_head_cnt.as<uint32_t>();
-            PAV_LAUNCH(ctx, "k_compact_reduce", k_compact_reduce, n_tiles_t, 256, 0, d_tjt, d_stat, D->st_tmp.as<int8_t>(),
-                       pp->min_state_count, D->tile_sum.as<uint32_t>());
-            PAV_LAUNCH(ctx, "k_scan_tiles4", k_scan_tiles4, 1, 256, 0, D->tile_sum.as<uint32_t>(), D->tile_pre.as<unsigned long long>(),
-                       n_tiles_t);
+            PAV_LAUNCH(ctx, "k_scan_tiles_keep", k_scan_tiles_keep, 4, 256, 0, D->tile_sum.as<uint32_t>(), d_tjt, d_stat, pp->min_state_count,
+                       D->tile_pre.as<unsigned long long>(), n_tiles_t);
             PAV_LAUNCH(ctx, "k_compact_scatter", k_compact_scatter, n_tiles_t, 256, 0, CA);
             CA.tile_heads = nullptr; CA.tile_head_cnt = nullptr;
             PlanArgs PA;
@@ -2097,6 +2151,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             PAV_LAUNCH(ctx, "k_finalize", k_finalize, (uint32_t)(a_t / 256), 256, 0, FA);
             if (G.rel > 0.0)
                 PAV_LAUNCH(ctx, "k_spike_sum", k_spike_sum, n_jobs, 256, 0, d_jobs, d_kde, D->scratch.as<uint32_t>(), d_stat);
+            lap("enqueue");
             // the one readback: guard counters, plan flags, statistics, run heads of STATE
             uint8_t *h_guard_pin = h_pin + pin_guard_off;
             if (G.g) PAV_HIP(ctx, hipMemcpyAsync(h_guard_pin, G.g, sizeof(GuardDev), hipMemcpyDeviceToHost, st));
