@@ -601,6 +601,9 @@ __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
         uint64_t rb_ref = A.rowbase[2ull * row], rb_tig = A.rowbase[2ull * row + 1];
         uint64_t tlen = A.tig.len[al.tig_id];
         uint64_t row_begin = A.op_off[row];                    // real ordinal; kept in a register: no load inside the per-op branches below
+        // the stubs carry what the homology scans need to know about the row's records (offsets, lengths): one load there, not four
+        uint64_t s_roff = 0, s_toff = 0, s_rlen = 0;
+        if constexpr (MODE == WALK_INDEL) { s_roff = A.ref.off[al.ref_id]; s_toff = A.tig.off[al.tig_id]; s_rlen = A.ref.len[al.ref_id]; }
         // last_op / last_oplen carried across lanes: the operation in the slot in front, or the last one of the tile in front
         uint32_t prev = threadIdx.x ? A.ops[first - 1] : (t ? A.tile_last[t - 1] : OP_PAD);
 #pragma unroll
@@ -613,6 +616,7 @@ __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
                 rb_ref = A.rowbase[2ull * row]; rb_tig = A.rowbase[2ull * row + 1];
                 tlen = A.tig.len[al.tig_id];
                 row_begin = A.op_off[row];
+                if constexpr (MODE == WALK_INDEL) { s_roff = A.ref.off[al.ref_id]; s_toff = A.tig.off[al.tig_id]; s_rlen = A.ref.len[al.ref_id]; }
             }
             const uint32_t code = o[j] & 15u, len = o[j] >> 4;
             const int64_t pos_ref = (int64_t)al.pos + (int64_t)(run[0] - rb_ref);
@@ -630,18 +634,20 @@ __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
                 r.aln = row;
                 r.op_index = (uint32_t)(real0 + j - row_begin) + 1;            // cigar_index, cigarcall.py:89
                 r.pos = (uint32_t)pos_ref;                                     // un-shifted; finalised by homology_kernel
-                r.end = 0;
+                r.end = (uint32_t)s_rlen;                                      // stub only: length of the reference record
                 r.svlen = len;
                 r.qry_pos = (uint32_t)pos_tig;                                 // oriented, un-shifted
-                r.qry_end = 0;
+                r.qry_end = (uint32_t)tlen;                                    // stub only: length of the contig
                 // last_op / last_oplen (cigarcall.py:149-151,310-311): previous op of the same row
                 const bool has_prev = real0 + j > row_begin;                   // first op of a row: last_op is None
                 r.left_shift = (has_prev && (prev & 15u) == 7u) ? (prev >> 4) : 0u;   // shift cap; 0 when last_op != '='
-                r.hom_ref_l = r.hom_ref_r = r.hom_tig_l = r.hom_tig_r = 0;
+                r.hom_ref_l = (uint32_t)s_roff; r.hom_ref_r = (uint32_t)(s_roff >> 32);       // stub only: arena offsets of the two records
+                r.hom_tig_l = (uint32_t)s_toff; r.hom_tig_r = (uint32_t)(s_toff >> 32);
                 r.seq_off = run[4];
                 r.svtype = code == 1 ? 0 : 1;
 #pragma unroll
                 for (int b = 0; b < 7; ++b) r.pad[b] = 0;
+                r.pad[0] = (uint8_t)rev;                                       // stub only: strand of the row
                 A.indel[run[3]] = r;
                 }
             }                                                                  // M, N, P: reported by tok_tiles before any row is emitted
@@ -1222,15 +1228,24 @@ __device__ __forceinline__ int first_stop(uint64_t a, uint64_t b, uint32_t bad, 
 // Shared scan: t is walked from t_pos in direction dir for at most avail bases; seq_sv = sv[sv_pos, sv_pos+svlen)
 // is walked circularly from its last base backwards (dir < 0) or its first base forwards (dir > 0).
 // At most max_steps windows are examined; `done` tells whether the scan ended (mismatch, non-ACGT or edge).
+// One period of seq_sv in forward order (svlen <= 32), fetched once per INS / DEL and shared by its scans: the scan that walks
+// backwards reads it reversed.
+struct Period { uint64_t c; uint32_t m; };
+__device__ __forceinline__ void period_in_scan_order(const Period &per, int dir, int L, uint64_t &pc, uint32_t &pm) {
+    if (dir > 0) { pc = per.c; pm = per.m; }
+    else { pc = reverse_groups(per.c, L); pm = __brev(per.m) >> (32 - L); }
+}
+
 __device__ uint32_t hom_scan(const SeqRef &t, int64_t t_pos, int dir, int64_t avail, const SeqRef &sv, int64_t sv_pos,
-                             int64_t svlen, int max_steps, bool &done) {
+                             int64_t svlen, int max_steps, bool &done, const Period *per = nullptr) {
     done = true;
     if (svlen <= 0 || avail <= 0) return 0;
     int64_t h = 0;
     if (svlen <= 32) {
         const int L = (int)svlen;
         uint64_t pc; uint32_t pm;
-        fetch_run(sv, dir < 0 ? sv_pos + svlen - 1 : sv_pos, dir, L, pc, pm);
+        if (per) period_in_scan_order(*per, dir, L, pc, pm);
+        else fetch_run(sv, dir < 0 ? sv_pos + svlen - 1 : sv_pos, dir, L, pc, pm);
         const int reps = 32 / L, n = reps * L;
         uint64_t P = pc; uint32_t M = pm;
         for (int r = 1; r < reps; ++r) { P |= pc << (2 * L * r); M |= pm << (L * r); }
@@ -1271,11 +1286,11 @@ __device__ __forceinline__ int64_t bcast64(int64_t v, int src) { return (int64_t
 // the c-th window, so a 5 kb homology costs a handful of steps instead of ~160 dependent ones.
 // Must be called by all 64 lanes; `active` masks lanes without work.  `h0` resumes a scan known to match up to h0.
 __device__ uint32_t wave_hom_scan(bool active, const SeqRef &t, int64_t t_pos, int dir, int64_t avail, const SeqRef &sv,
-                                  int64_t sv_pos, int64_t svlen) {
+                                  int64_t sv_pos, int64_t svlen, const Period *per = nullptr) {
     const int lane = threadIdx.x & 63;
     bool done = true;
     uint32_t res = 0;
-    if (active) res = hom_scan(t, t_pos, dir, avail, sv, sv_pos, svlen, 3, done);
+    if (active) res = hom_scan(t, t_pos, dir, avail, sv, sv_pos, svlen, 3, done, per);
     unsigned long long pending = __ballot(active && !done);
     while (pending) {
         const int src = __ffsll((long long)pending) - 1;
@@ -1349,7 +1364,8 @@ __device__ uint32_t wave_hom_scan(bool active, const SeqRef &t, int64_t t_pos, i
 // Up to three windows per scan and lane; scans still running are finished by the whole wave as in wave_hom_scan.
 struct ScanSide { SeqRef t; int64_t t_pos, avail; int dir; };
 
-__device__ void wave_hom_scan4(bool active, const ScanSide (&sc)[4], const SeqRef &sv, int64_t sv_pos, int64_t svlen, uint32_t (&res)[4]) {
+__device__ void wave_hom_scan4(bool active, const ScanSide (&sc)[4], const SeqRef &sv, int64_t sv_pos, int64_t svlen, uint32_t (&res)[4],
+                               const Period &per) {
     const int lane = threadIdx.x & 63;
     int64_t h[4] = {0, 0, 0, 0};
     bool done[4];
@@ -1362,8 +1378,8 @@ __device__ void wave_hom_scan4(bool active, const ScanSide (&sc)[4], const SeqRe
     if (active && periodic && svlen > 0) {
         const int L = (int)svlen;
         uint64_t pc[2]; uint32_t pm[2];
-        fetch_run(sv, sv_pos + svlen - 1, -1, L, pc[0], pm[0]);
-        fetch_run(sv, sv_pos, +1, L, pc[1], pm[1]);
+        period_in_scan_order(per, -1, L, pc[0], pm[0]);
+        period_in_scan_order(per, +1, L, pc[1], pm[1]);
         const int reps = 32 / L;
         n = reps * L;
 #pragma unroll
@@ -1465,8 +1481,9 @@ __device__ __forceinline__ uint32_t left_hom(const SeqRef &t, int64_t pos, const
     bool done;
     return hom_scan(t, pos, -1, pos + 1, sv, sv_pos, svlen, 0x7FFFFFFF, done);
 }
-__device__ __forceinline__ uint32_t wave_left_hom(bool active, const SeqRef &t, int64_t pos, const SeqRef &sv, int64_t sv_pos, int64_t svlen) {
-    return wave_hom_scan(active, t, pos, -1, pos + 1, sv, sv_pos, svlen);
+__device__ __forceinline__ uint32_t wave_left_hom(bool active, const SeqRef &t, int64_t pos, const SeqRef &sv, int64_t sv_pos, int64_t svlen,
+                                                  const Period *per) {
+    return wave_hom_scan(active, t, pos, -1, pos + 1, sv, sv_pos, svlen, per);
 }
 
 // right_homology(pos_tig, seq_tig, seq_sv)  call.py:595-647: walks downstream while hom_len < len - pos_tig
@@ -1477,6 +1494,7 @@ __device__ __forceinline__ uint32_t right_hom(const SeqRef &t, int64_t pos, cons
 
 // One lane per INS/DEL stub: left shift, then the four breakpoint homologies in lockstep (wave_hom_scan4), then the final
 // coordinates.  The scans are wave-uniform calls (long scans are finished cooperatively), so no lane leaves early.
+// (Four waves per SIMD instead of three - amdgpu_waves_per_eu(4, 4): 128 VGPRs, 112 B of scratch per lane - measured 9 % slower.)
 // Epilogue: the SEQ column (cigarcall.py:145,163,221).  The records of a wave are consecutive and so are their sequences in the
 // blob: the wave copies the span byte by byte, lane = output byte (coalesced stores), the record that owns a byte is found among
 // the wave's 64 by a search over shuffled offsets - and for an INS the bytes come from the contig lines the scans above have just
@@ -1488,24 +1506,38 @@ __global__ __launch_bounds__(64) void homology_kernel(pav_indel *__restrict__ in
     const int lane = threadIdx.x & 63;
     const bool active = i < n_indel;
     pav_indel r = indel[active ? i : n_indel - 1];
-    const pav_aln al = aln[r.aln];
-    const int rev = al.rev != 0;
-    const SeqRef ref = seq_ref(R, al.ref_id, 0), tig = seq_ref(T, al.tig_id, rev);
+    // everything about the row's records comes with the stub (walk_indel): no look-ups of the alignment row and the record tables
+    const int rev = r.pad[0] != 0;
+    (void)aln;
+    SeqRef ref, tig;
+    ref.off = (uint64_t)r.hom_ref_l | (uint64_t)r.hom_ref_r << 32; ref.len = r.end; ref.rev = 0;
+    tig.off = (uint64_t)r.hom_tig_l | (uint64_t)r.hom_tig_r << 32; tig.len = r.qry_end; tig.rev = rev;
+    if (R.packed) { ref.two = R.two; ref.mask = R.mask; ref.dirty = R.dirty; } else { ref.two = nullptr; ref.mask = nullptr; ref.dirty = R.ascii; }
+    if (T.packed) { tig.two = T.two; tig.mask = T.mask; tig.dirty = T.dirty; } else { tig.two = nullptr; tig.mask = nullptr; tig.dirty = T.ascii; }
+    r.pad[0] = 0;
     const int64_t pos_ref = r.pos, pos_tig = r.qry_pos, oplen = r.svlen, tig_len = (int64_t)tig.len;
     const bool ins = r.svtype == 0;
     const SeqRef svs = ins ? tig : ref;                // seq = seq_tig[pos_tig:+oplen] / seq_ref[pos_ref:+oplen]
     int64_t sv_at = ins ? pos_tig : pos_ref;
     // last_op == '=' (cigarcall.py:149-155 / :225-231): shift = min(last_oplen, left_homology(pos_ref - 1, REF, SEQ))
-    const uint32_t hs = wave_left_hom(active && r.left_shift != 0, ref, pos_ref - 1, svs, sv_at, oplen);
+    // a short SV sequence is one period of the circular comparison: fetched once, shared by the five scans (it used to be
+    // fetched by the shift scan and twice more - in either order - by the breakpoint scans: for an INS three windows of the ASCII arena)
+    const bool periodic = active && oplen > 0 && oplen <= 32;
+    Period per{0, 0};
+    if (periodic) fetch_run(svs, sv_at, +1, (int)oplen, per.c, per.m);
+    const uint32_t hs = wave_left_hom(active && r.left_shift != 0, ref, pos_ref - 1, svs, sv_at, oplen, periodic ? &per : nullptr);
     const int64_t shift = r.left_shift ? ((int64_t)hs < (int64_t)r.left_shift ? (int64_t)hs : (int64_t)r.left_shift) : 0;
     const int64_t sv_pos_ref = pos_ref - shift, sv_pos_tig = pos_tig - shift;
-    if (ins && shift) sv_at = sv_pos_tig;              // INS: seq re-sliced at the shifted position (:162-163)
+    if (ins && shift) {                                // INS: seq re-sliced at the shifted position (:162-163)
+        sv_at = sv_pos_tig;
+        if (periodic) fetch_run(svs, sv_at, +1, (int)oplen, per.c, per.m);
+    }
     // INS: :178-182;  DEL: :247-251
     const int64_t p_rr = ins ? sv_pos_ref : sv_pos_ref + oplen, p_tr = ins ? sv_pos_tig + oplen : sv_pos_tig;
     const ScanSide sides[4] = {{ref, sv_pos_ref - 1, sv_pos_ref, -1}, {ref, p_rr, (int64_t)ref.len - p_rr, +1},
                                {tig, sv_pos_tig - 1, sv_pos_tig, -1}, {tig, p_tr, tig_len - p_tr, +1}};
     uint32_t hom[4];
-    wave_hom_scan4(active, sides, svs, sv_at, oplen, hom);
+    wave_hom_scan4(active, sides, svs, sv_at, oplen, hom, per);
     const uint64_t seq_off = r.seq_off;
     if (active) {
         r.hom_ref_l = hom[0]; r.hom_ref_r = hom[1]; r.hom_tig_l = hom[2]; r.hom_tig_r = hom[3];
@@ -1695,7 +1727,8 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
         if (totals[3]) PAV_LAUNCH(ctx, "walk_indel", walk_emit<WALK_INDEL>, B.n_tiles, 256, 0, A);
         // SNV rows: on the side stream, beside the homology scans of the main stream (13 M isolated sector fetches; the scans
         // draw on the same budget)
-        if (totals[2]) {
+        const bool skip_snv = stage && !strcmp(stage, "hom");     // debugging: the homology scans with nothing beside them
+        if (totals[2] && !skip_snv) {
             PAV_HIP(ctx, hipEventRecord(ctx->snv_ready, ctx->stream));
             PAV_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->snv_ready, 0));
             PAV_LAUNCH_ON(ctx, ctx->stream2, "walk_snv", walk_emit<WALK_SNV>, B.n_tiles, 256, 0, A);
@@ -1708,7 +1741,7 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
             PAV_LAUNCH(ctx, "homology_kernel", homology_kernel, (uint32_t)((totals[3] + 63) / 64), 64, 0,
                        ctx->d_indel.as<pav_indel>(), totals[3], ctx->d_aln.as<pav_aln>(), A.ref, A.tig, ctx->d_seqblob.as<uint8_t>());
         }
-        if (totals[2]) PAV_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->snv_done, 0));   // later readers of the SNV rows use this stream
+        if (totals[2] && !skip_snv) PAV_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->snv_done, 0));   // later readers of the SNV rows use this stream
     }
     if (counts) *counts = ctx->counts;
     ctx->cigar_called = true;

@@ -16,9 +16,11 @@ def main():
     ap.add_argument('--steps', type=int, default=40)
     ap.add_argument('--scale', type=float, default=1.0)
     ap.add_argument('--seed', type=int, default=1002)
+    ap.add_argument('--no-build', action='store_true', help='under rocprofv3: everything is built beforehand')
     args = ap.parse_args()
-    import __graft_entry__ as g
-    g.build_cpu_side()
+    if not args.no_build:
+        import __graft_entry__ as g
+        g.build_cpu_side()
     from pav_amd import _lib, cigarcall, synth
     hap = synth.config2(seed=args.seed, scale=args.scale, threads=8, pair_frac=0.009)
     names = hap.ref.names
