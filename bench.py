@@ -498,7 +498,7 @@ def main():
                     m = _re.search(r':(\d+)-(\d+)', ln.split(': ')[1])
                     scanned_bp += int(m.group(2)) - int(m.group(1)) + 1
         pmc = None                                            # committed PMC summary of this workload, newest round first
-        for pmc_name in ('r02_pmc.json', 'r01_pmc.json'):
+        for pmc_name in ('r03_pmc.json', 'r02_pmc.json', 'r01_pmc.json'):
             try:
                 with open(os.path.join(ROOT, 'profiles', pmc_name)) as fh:
                     cand = json.load(fh)
@@ -508,6 +508,39 @@ def main():
                     break
             except (OSError, KeyError, ValueError):
                 pass
+
+        # walk_snv reads ONE byte of each ASCII arena per SNV row; the SNVs of a haplotype lie ~1000 bases apart except inside
+        # inversions, so nearly every byte costs a memory line of its own, and the fabric moves 64 B per isolated byte
+        # (TCC_EA0_RDREQ_32B = 0, profiles/r03_cigar_emission_counters.txt).  The kernel is therefore priced in distinct 64 B lines
+        # (counted here from the rows the device produced) against the rate at which the memory system delivers isolated lines
+        # (tools/ubench/gather_rate.hip, the maximum over its variants with a 16 B store per row beside the loads, as in the kernel).
+        line_roof = {'with_stores': None, 'loads_only': None, 'source': 'profiles/r03_gather_rate.txt'}
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r03_gather_rate.txt')) as fh:
+                for ln_ in fh:
+                    if '->' in ln_ and 'G isolated' in ln_:
+                        rate_ = float(ln_.split('->')[1].split('G')[0])
+                        key_ = 'with_stores' if '16 B stored' in ln_ and 'nt loads' not in ln_ else ('loads_only' if 'nothing stored' in ln_ and 'nt loads' not in ln_ else None)
+                        if key_ and (line_roof[key_] is None or rate_ > line_roof[key_]):
+                            line_roof[key_] = rate_
+        except OSError:
+            pass
+        snv_lines = None
+        if snv.shape[0]:
+            a64 = snv['aln'].astype(np.int64) << 40
+            snv_lines = int(np.unique(a64 | (snv['pos'].astype(np.int64) >> 6)).shape[0] + np.unique(a64 | (snv['qry_pos'].astype(np.int64) >> 6)).shape[0])
+
+        def isolated_lines(kernel_, avg_ms_):
+            if kernel_ != 'walk_snv' or snv_lines is None:
+                return None
+            rate = snv_lines / (avg_ms_ * 1e-3) / 1e9
+            peak = line_roof['with_stores']
+            return {'distinct_64B_lines_per_launch': snv_lines, 'achieved_glines_per_s': round(rate, 1),
+                    'measured_peak_glines_per_s': peak, 'measured_peak_loads_only': line_roof['loads_only'], 'source': line_roof['source'],
+                    'frac': None if not peak else round(rate / peak, 3),
+                    'note': 'distinct 64 B lines of the two ASCII arenas the SNV rows touch (counted from the rows); the kernel time here is '
+                            'what it takes beside homology_kernel, which draws on the same budget (3.96 M more line fetches per pass): '
+                            'profiles/r03_cigar_emission_counters.txt has both kernels alone and together'}
 
         def make_roofline(prof_, want=None, kde=None):
             """Dominant kernel (largest total time in the profiled steps) against the HBM roofline: algorithmic bytes per
@@ -519,13 +552,10 @@ def main():
             alg_bytes = {
                 'verify_kernel': 0.5 * float(counts.aligned_bases),           # the two 2-bit planes; masks only where marked dirty
                 'pack_kernel': tig_bases * (1.0 + 0.25 + 0.125),
-                'tok_count': float(text.shape[0]),
-                'tok_emit': float(text.shape[0]) + 4.0 * n_ops,
-                'walk_reduce': 4.0 * n_ops,
+                'tok_tiles': float(text.shape[0]) + 4.0 * n_ops,               # CIGAR text in, operation words out
                 'walk_snv': 4.0 * n_ops + 16.0 * n_snv + 2.0 * n_snv,          # ops, SNV rows out, REF / ALT bytes in
                 'walk_indel': 4.0 * n_ops + 64.0 * n_indel,
-                'homology_kernel': 128.0 * n_indel,
-                'seq_gather': 2.0 * counts.seq_bytes + 64.0 * n_indel,          # SEQ bytes in and out + every INS / DEL record (where to copy from)
+                'homology_kernel': 128.0 * n_indel + 2.0 * counts.seq_bytes,    # stub in, record out, SEQ bytes in and out
                 'rocprim::radix_sort_keys': 7 * 16.0 * n_snv,               # 56 key bits = 7 passes over 8 B keys, in + out
                 'k_snv_keys': 24.0 * n_snv, 'k_indel_keys': 72.0 * n_indel,
             }
@@ -564,13 +594,8 @@ def main():
                         'point_data_pairs_per_launch': kde[2] / kern_[dom]['launches'],
                         'executed': {'tflops': round(ex, 2), 'frac': round(ex / FP64_VECTOR_PEAK_TFLOPS, 4),
                                      'model': '150 flop per (point, run) pair'}}
-            if dom == 'walk_snv' and kern_[dom]['avg_ms'] > 0:
-                # one byte of each ASCII arena per SNV row, ~470 bases apart: every byte costs a 32 B sector of its own.  The rate at
-                # which HBM delivers isolated sectors was measured with nothing else in the kernel (tools/ubench/gather_rate.hip)
-                gs = 2.0 * n_snv / (kern_[dom]['avg_ms'] * 1e-3) / 1e9
-                head['isolated_sectors'] = {'per_launch': 2 * int(n_snv), 'achieved_gsectors_per_s': round(gs, 1),
-                                            'measured_peak_gsectors_per_s': 39.7, 'source': 'profiles/r02_gather_rate.txt',
-                                            'frac': round(gs / 39.7, 3)}
+            if dom in ('walk_snv', 'homology_kernel') and kern_[dom]['avg_ms'] > 0:
+                head['isolated_lines'] = isolated_lines(dom, kern_[dom]['avg_ms'])
             head.update({'avg_kernel_ms': round(kern_[dom]['avg_ms'], 4), 'launches_per_step': round(kern_[dom]['launches'] / args.steps, 2)})
             return kern_, {**head,
                            'kernels_ms': {k: round(v['avg_ms'], 4) for k, v in sorted(kern_.items())},
@@ -621,14 +646,12 @@ def main():
                     ab = gbs * 1e9 * kern[k_]['avg_ms'] * 1e-3
                     if ab > 0:
                         ratios[k_] = round(tr / ab, 2)
-            # walk_snv reads ONE byte per SNV from each ASCII plane; SNVs lie ~470 bases apart, so every byte costs a 32 B sector
-            # of its own (tools/ubench/gather_rate.hip, profiles/r02_gather_rate.txt): its traffic against that granularity
-            sector = None
-            if 'walk_snv' in pmc.get('fetch_kib', {}) and 'walk_snv' in pmc.get('write_kib', {}):
-                sector = round((pmc['fetch_kib']['walk_snv'] + pmc['write_kib']['walk_snv']) * 1024.0 /
-                               (4.0 * n_ops + 16.0 * n_snv + 2 * 32.0 * n_snv), 2)
+            line_model = None
+            if 'walk_snv' in pmc.get('fetch_kib', {}) and 'walk_snv' in pmc.get('write_kib', {}) and snv_lines:
+                line_model = round((pmc['fetch_kib']['walk_snv'] + pmc['write_kib']['walk_snv']) * 1024.0 /
+                                   (4.0 * n_ops + 16.0 * n_snv + 64.0 * snv_lines), 2)
             roofline['traffic_over_algorithmic'] = {'source': pmc.get('file'), 'ratio': ratios,
-                                                    'walk_snv_over_sector_granular_model': sector}
+                                                    'walk_snv_over_line_granular_model': line_model}
 
         def add_alone(roof):
             if pack_alone and pack_alone[0] and roof['kernel'] == 'pack_kernel':

@@ -36,6 +36,9 @@ def main():
     ap.add_argument('--inv-sig-filter', default='svindel', help="config inv_sig_filter (reference default 'svindel')")
     ap.add_argument('--threads', type=int, default=min(64, effective_cpus()),
                     help='host threads of the native table writers (text + gzip members; the library default is 16)')
+    ap.add_argument('--gzip-level', type=int, default=1,
+                    help='deflate level of the native writers (the library default is 6; pandas / gzip.open use 9).  The text inside is '
+                         'the same at every level; level 1 compresses 3 - 4 x faster and 25 - 35 % larger')
     args = ap.parse_args()
     import torch  # noqa: F401  first: one HIP runtime per process (pav_amd/_lib.py)
     import __graft_entry__ as g
@@ -69,14 +72,20 @@ def main():
 
     with _lib.Context(0) as ctx:
         # ---- sequences ---------------------------------------------------------------------------------------------
+        # the contig file is parsed on a second thread while the reference is parsed and uploaded (the readers and the upload
+        # release the GIL): parse, H2D and pack of the two files overlap
+        import threading
         t = time.time()
-        fa_ref, fa_tig = open_fasta(ref_fa), open_fasta(tig_fa)
-        stage('sequences: parse FASTA', t)
-        t = time.time()
+        box = {}
+        th = threading.Thread(target=lambda: box.__setitem__('tig', open_fasta(tig_fa)))
+        th.start()
+        fa_ref = open_fasta(ref_fa)
         ctx.seq_load_fasta(_lib.PAV_ROLE_REF, fa_ref.native, fa_ref.record_numbers(fa_ref.names))
+        th.join()
+        fa_tig = box['tig']
         ctx.seq_load_fasta(_lib.PAV_ROLE_TIG, fa_tig.native, fa_tig.record_numbers(fa_tig.names))
         ctx.sync()
-        stage('sequences: H2D + pack', t)
+        stage('sequences: parse FASTA, H2D + pack (the two files overlapped)', t)
         # ---- call: all rows, merged tables -----------------------------------------------------------------------------
         t = time.time()
         table, trim_table = _lib.BedTable(bed, with_cigar=True), _lib.BedTable(bed_trim, with_cigar=False)
@@ -91,7 +100,7 @@ def main():
         t = time.time()
         n_snv, n_ins = ctx.cigar_write_tables('h1', index, tp, te, snv_path=os.path.join(work, 'snv_snv_h1.bed.gz'),
                                               insdel_path=os.path.join(work, 'svindel_insdel_h1.bed.gz'), call_batch=cols['CALL_BATCH'],
-                                              threads=args.threads)
+                                              threads=args.threads, gzip_level=args.gzip_level)
         stage('call: merged tables (sort, text, gzip)', t)
         # ---- flag ----------------------------------------------------------------------------------------------------------
         t = time.time()
@@ -118,22 +127,24 @@ def main():
         den_dir = os.path.join(work, 'density_table')
         os.makedirs(den_dir, exist_ok=True)
         ctx.inv_write_tables([i for i, _ in calls], [os.path.join(den_dir, f'density_{c.id}_h1.tsv.gz') for _, c in calls],
-                             threads=args.threads)
+                             threads=args.threads, gzip_level=args.gzip_level)
         stage('scan: density tables (text, gzip)', t)
         t = time.time()
         rows = [rules.inv_bed_row(c, 'h1', df_try.iloc[i]['TYPE'] if 'TYPE' in df_try else 'NA', tig_fa) for i, c in calls]
+        stage('scan: INV BED rows (regions, SEQ of every call)', t)
+        t = time.time()
         if rows:
-            pd.concat(rows, axis=1).T.sort_values(['#CHROM', 'POS', 'END', 'ID']).to_csv(os.path.join(work, 'sv_inv_h1.bed.gz'), sep='\t',
-                                                                                        index=False, compression='gzip')
+            pd.concat(rows, axis=1).T.sort_values(['#CHROM', 'POS', 'END', 'ID']).to_csv(
+                os.path.join(work, 'sv_inv_h1.bed.gz'), sep='\t', index=False, compression={'method': 'gzip', 'compresslevel': args.gzip_level})
         with open(os.path.join(work, 'inv_call_h1.log'), 'w') as fh:
             fh.write(log.getvalue())
-        stage('scan: INV BED + log', t)
+        stage('scan: INV BED table (sort, text, gzip) + log', t)
     total = round(sum(stages.values()), 3)
     sizes = {f: os.path.getsize(os.path.join(work, f)) for f in sorted(os.listdir(work)) if os.path.isfile(os.path.join(work, f))}
     print(json.dumps({'workload': f'one synthetic hg38-shaped haplotype, seed {args.seed}, scale {args.scale}', 'aligned_bp': aligned_bp,
                       'snv_rows': n_snv, 'insdel_rows': n_ins, 'flagged_regions': int(df_flag.shape[0]), 'scanned_regions': len(regions),
                       'inv_calls': len(calls), 'stages_s': stages, 'total_s': total,
-                      'end_to_end_Gbp_per_s': round(aligned_bp / total / 1e9, 3), 'writer_threads': args.threads, 'inputs_written_s': round(t_inputs, 1),
+                      'end_to_end_Gbp_per_s': round(aligned_bp / total / 1e9, 3), 'writer_threads': args.threads, 'gzip_level': args.gzip_level, 'inputs_written_s': round(t_inputs, 1),
                       'host_cores': os.cpu_count(), 'usable_cores': effective_cpus(), 'file_bytes': sizes}), flush=True)
     if args.out is None:
         shutil.rmtree(work, ignore_errors=True)

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""cProfile of the host side of one lane's steps (CIGAR-call -> flagging -> scan), to see what Python costs per step.
+    python tools/prof_step.py [--steps 30] [--scale 1.0]"""
+import argparse, cProfile, io, os, pstats, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--scale', type=float, default=1.0)
+    args = ap.parse_args()
+    import __graft_entry__ as g
+    g.build_cpu_side()
+    import numpy as np
+    from pav_amd import _lib, cigarcall, synth, inv as pavinv
+    from pav_amd.align import AlignLift
+    from pav_amd.kmer import KmerUtil
+    hap = synth.config2(seed=1002, scale=args.scale, threads=8, pair_frac=0.009)
+    names = hap.ref.names
+    ctx = _lib.Context(0)
+    ctx.seq_load(_lib.PAV_ROLE_REF, names, [hap.ref.seqs[n] for n in names])
+    ctx.seq_load(_lib.PAV_ROLE_TIG, hap.tig_names, [hap.tig_seqs[n] for n in hap.tig_names])
+    ctx.cigar_load(*cigarcall.pack_alignments(hap.df_align, names, hap.tig_names))
+    ctx._inv_loaded = ('ref.fa', 'tig.fa')
+    index = hap.df_align['INDEX'].to_numpy(dtype='int64')
+    trim = hap.df_trim[['POS', 'END', 'INDEX']].set_index('INDEX').astype(int).reindex(list(index), fill_value=-1)
+    tp, te = trim['POS'].to_numpy(dtype='int64'), trim['END'].to_numpy(dtype='int64')
+    lift = AlignLift(hap.df_trim, hap.tig_lengths)
+    k_util = KmerUtil(31)
+    params = ctx.flag_params(sig_filter=_lib.SIG_SINGLE_CLUSTER)
+    found = io.StringIO()
+
+    def step():
+        ctx.seq_pack(_lib.PAV_ROLE_TIG)
+        ctx.cigar_call()
+        flag = ctx.cigar_flag(tp, te, params)
+        regions = pavinv.loci_regions(ctx, flag[1])
+        log = io.StringIO()
+        found.seek(0); found.truncate()
+        return pavinv.scan_for_inv_batch(regions, 'ref.fa', 'tig.fa', lift, k_util, log=log, ctx=ctx, eager_tables=False, found_out=found)
+    for _ in range(4):
+        step()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.sync()
+    print('ms per step (one lane, no profiler): %.3f' % ((time.perf_counter() - t0) / args.steps * 1e3))
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(args.steps):
+        step()
+    ctx.sync()
+    pr.disable()
+    s = io.StringIO()
+    pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(28)
+    print(s.getvalue()[:6000])
+    ctx.close()
+
+if __name__ == '__main__':
+    main()
