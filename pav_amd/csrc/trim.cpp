@@ -8,6 +8,7 @@
 // costs only the operations inside the overlap.  The pair loop itself is sequential by definition (a trimmed record is
 // the input of the next pair) and runs on the host inside the library.
 #include "common.h"
+#include "trim_dev.h"
 
 #include <algorithm>
 #include <atomic>
@@ -43,6 +44,10 @@ struct TrimState {
     pav_trim_err err{};
     std::string text;                       // CIGAR strings of the last pav_trim_fetch
     std::vector<uint64_t> text_off;
+    // device side of the passes (trim_dev.hip): the operations stay resident, rows / order / scratch go up per pass
+    DevBuf d_ops, d_rows, d_order, d_group, d_scratch, d_meta, d_err;
+    uint64_t n_dev_passes = 0;
+    ~TrimState() { for (DevBuf *b : {&d_ops, &d_rows, &d_order, &d_group, &d_scratch, &d_meta, &d_err}) b->release(); }
 };
 
 TrimState *tstate(pav_ctx *ctx) {
@@ -352,6 +357,123 @@ pav_trim_count count_cigar(const TrimState &S, const Cigar &c) {
     return cnt;
 }
 
+// ---- device passes (trim_dev.hip) -----------------------------------------------------------------------------------------
+RowDev to_dev(const Row &r) {
+    RowDev d{};
+    d.f = r.f;
+    d.c.a = r.c.a; d.c.b = r.c.b; d.c.len_first = r.c.len_first; d.c.len_last = r.c.len_last;
+    d.c.n_pre = (uint8_t)r.c.pre.size(); d.c.n_post = (uint8_t)r.c.post.size(); d.c.modified = r.c.modified ? 1 : 0;
+    for (size_t k = 0; k < r.c.pre.size() && k < 2; ++k) { d.c.pre_len[k] = r.c.pre[k].len; d.c.pre_code[k] = r.c.pre[k].code; }
+    for (size_t k = 0; k < r.c.post.size() && k < 2; ++k) { d.c.post_len[k] = r.c.post[k].len; d.c.post_code[k] = r.c.post[k].code; }
+    return d;
+}
+void from_dev(const RowDev &d, Row &r) {
+    r.f = d.f;
+    r.c.a = d.c.a; r.c.b = d.c.b; r.c.len_first = d.c.len_first; r.c.len_last = d.c.len_last; r.c.modified = d.c.modified != 0;
+    r.c.pre.clear(); r.c.post.clear();
+    for (uint32_t k = 0; k < d.c.n_pre; ++k) r.c.pre.push_back(Op{d.c.pre_len[k], d.c.pre_code[k]});
+    for (uint32_t k = 0; k < d.c.n_post; ++k) r.c.post.push_back(Op{d.c.post_len[k], d.c.post_code[k]});
+}
+TrimFail fail_of(const TrimFailDev &f) {
+    TrimFail t;
+    t.kind = f.kind; t.op_index = f.op_index; t.op_len = f.op_len; t.op_char = (uint32_t)OP_CHARS[f.op_code < 9 ? f.op_code : 0];
+    t.diff_bp = f.diff_bp; t.side = f.side;
+    return t;
+}
+bool host_passes() { const char *e = getenv("PAV_TRIM_HOST"); return e && *e == '1'; }
+
+// One pass on the device: the groups (records of one contig / one chromosome, consecutive in `ord`) get a wave each.
+int pass_device(pav_ctx *ctx, TrimState *S, const std::vector<uint32_t> &ord, int mode, int64_t min_len, bool match_tig) {
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = ord.size(), n_rows = S->rows.size();
+    if (n == 0) return PAV_OK;
+    for (const Row &r : S->rows) if (r.c.pre.size() > 2 || r.c.post.size() > 2) return fail(ctx, PAV_E_STATE, "pav_trim_pass: a record carries more than two clipping operations at one end");
+    std::vector<uint32_t> group_off;
+    std::vector<unsigned long long> cap, off;
+    unsigned long long bytes = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const pav_trim_row &f = S->rows[ord[i]].f;
+        const bool new_group = i == 0 || (mode == PAV_TRIM_QUERY ? f.qry_id != S->rows[ord[i - 1]].f.qry_id : f.chrom != S->rows[ord[i - 1]].f.chrom);
+        if (new_group) { group_off.push_back((uint32_t)i); cap.push_back(0); }
+        const Cigar &c = S->rows[ord[i]].c;
+        cap.back() = std::max<unsigned long long>(cap.back(), (c.b - c.a) + 8);
+    }
+    group_off.push_back((uint32_t)n);
+    const uint32_t n_groups = (uint32_t)cap.size();
+    for (uint32_t g = 0; g < n_groups; ++g) { cap[g] = (cap[g] + 1) & ~1ull; off.push_back(bytes); bytes += 2ull * cap[g] * 56ull; }
+    std::vector<RowDev> dev(n_rows);
+    for (size_t i = 0; i < n_rows; ++i) dev[i] = to_dev(S->rows[i]);
+    hipStream_t st = ctx->stream;
+    PAV_HIP(ctx, S->d_rows.reserve(sizeof(RowDev) * n_rows));
+    PAV_HIP(ctx, S->d_order.reserve(4 * n));
+    PAV_HIP(ctx, S->d_group.reserve(4 * ((size_t)n_groups + 1)));
+    PAV_HIP(ctx, S->d_meta.reserve(16ull * n_groups));
+    PAV_HIP(ctx, S->d_scratch.reserve(bytes + 64));
+    PAV_HIP(ctx, S->d_err.reserve(8 + (sizeof(TrimFailDev) + 8) * (size_t)n_groups));
+    unsigned long long *d_key = S->d_err.as<unsigned long long>();
+    unsigned long long *d_slot_key = d_key + 1;
+    TrimFailDev *d_slots = reinterpret_cast<TrimFailDev *>(d_slot_key + n_groups);
+    PAV_HIP(ctx, hipMemcpyAsync(S->d_rows.p, dev.data(), sizeof(RowDev) * n_rows, hipMemcpyHostToDevice, st));
+    PAV_HIP(ctx, hipMemcpyAsync(S->d_order.p, ord.data(), 4 * n, hipMemcpyHostToDevice, st));
+    PAV_HIP(ctx, hipMemcpyAsync(S->d_group.p, group_off.data(), 4 * group_off.size(), hipMemcpyHostToDevice, st));
+    PAV_HIP(ctx, hipMemcpyAsync(S->d_meta.p, off.data(), 8ull * n_groups, hipMemcpyHostToDevice, st));
+    PAV_HIP(ctx, hipMemcpyAsync(S->d_meta.as<unsigned long long>() + n_groups, cap.data(), 8ull * n_groups, hipMemcpyHostToDevice, st));
+    PAV_HIP(ctx, hipMemsetAsync(d_key, 0xFF, 8 + 8ull * n_groups, st));
+    TrimPassArgs A;
+    A.ops = S->d_ops.as<uint32_t>(); A.rows = S->d_rows.as<RowDev>(); A.order = S->d_order.as<uint32_t>(); A.group_off = S->d_group.as<uint32_t>();
+    A.scratch = S->d_scratch.as<uint8_t>(); A.scratch_off = S->d_meta.as<unsigned long long>(); A.scratch_cap = A.scratch_off + n_groups;
+    A.min_len = min_len; A.mode = mode; A.match_tig = match_tig ? 1 : 0;
+    A.err_key = d_key; A.err_slots = d_slots; A.err_slot_key = d_slot_key;
+    { const int rcl = trim_launch_pass(ctx, A, n_groups); if (rcl != PAV_OK) return rcl; }
+    unsigned long long key = ~0ull;
+    PAV_HIP(ctx, hipMemcpyAsync(&key, d_key, 8, hipMemcpyDeviceToHost, st));
+    PAV_HIP(ctx, hipMemcpyAsync(dev.data(), S->d_rows.p, sizeof(RowDev) * n_rows, hipMemcpyDeviceToHost, st));
+    PAV_HIP(ctx, hipStreamSynchronize(st));
+    S->n_dev_passes += 1;
+    if (key != ~0ull) {                                              // the pair the sequential loop would have failed on first
+        std::vector<unsigned long long> keys(n_groups);
+        std::vector<TrimFailDev> slots(n_groups);
+        PAV_HIP(ctx, hipMemcpy(keys.data(), d_slot_key, 8ull * n_groups, hipMemcpyDeviceToHost));
+        PAV_HIP(ctx, hipMemcpy(slots.data(), d_slots, sizeof(TrimFailDev) * n_groups, hipMemcpyDeviceToHost));
+        for (uint32_t g = 0; g < n_groups; ++g)
+            if (keys[g] == key) return record_fail(ctx, S, fail_of(slots[g]), slots[g].row_l, slots[g].row_r);
+        return fail(ctx, PAV_E_STATE, "pav_trim_pass: a device pass failed without a record of the failure");
+    }
+    for (size_t i = 0; i < n_rows; ++i) from_dev(dev[i], S->rows[i]);
+    return PAV_OK;
+}
+
+int pair_device(pav_ctx *ctx, TrimState *S, uint32_t row_l, uint32_t row_r, int mode, int rev_l, int rev_r) {
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    RowDev dev[2] = {to_dev(S->rows[row_l]), to_dev(S->rows[row_r])};
+    const unsigned long long cap1 = (std::max(S->rows[row_l].c.b - S->rows[row_l].c.a, S->rows[row_r].c.b - S->rows[row_r].c.a) + 9) & ~1ull;
+    const unsigned long long meta[2] = {0ull, cap1};
+    hipStream_t st = ctx->stream;
+    PAV_HIP(ctx, S->d_rows.reserve(sizeof(RowDev) * 2));
+    PAV_HIP(ctx, S->d_meta.reserve(16));
+    PAV_HIP(ctx, S->d_scratch.reserve(2ull * cap1 * 56ull + 64));
+    PAV_HIP(ctx, S->d_err.reserve(8 + sizeof(TrimFailDev) + 8));
+    unsigned long long *d_key = S->d_err.as<unsigned long long>();
+    PAV_HIP(ctx, hipMemcpyAsync(S->d_rows.p, dev, sizeof dev, hipMemcpyHostToDevice, st));
+    PAV_HIP(ctx, hipMemcpyAsync(S->d_meta.p, meta, sizeof meta, hipMemcpyHostToDevice, st));
+    PAV_HIP(ctx, hipMemsetAsync(d_key, 0xFF, 16, st));
+    TrimPassArgs A{};
+    A.ops = S->d_ops.as<uint32_t>(); A.rows = S->d_rows.as<RowDev>();
+    A.scratch = S->d_scratch.as<uint8_t>(); A.scratch_off = S->d_meta.as<unsigned long long>(); A.scratch_cap = A.scratch_off + 1;
+    A.mode = mode; A.err_key = d_key; A.err_slot_key = d_key + 1; A.err_slots = reinterpret_cast<TrimFailDev *>(d_key + 2);
+    { const int rcl = trim_launch_pair(ctx, A, rev_l, rev_r); if (rcl != PAV_OK) return rcl; }
+    unsigned long long key = ~0ull;
+    TrimFailDev tf{};
+    PAV_HIP(ctx, hipMemcpyAsync(&key, d_key, 8, hipMemcpyDeviceToHost, st));
+    PAV_HIP(ctx, hipMemcpyAsync(&tf, d_key + 2, sizeof tf, hipMemcpyDeviceToHost, st));
+    PAV_HIP(ctx, hipMemcpyAsync(dev, S->d_rows.p, sizeof dev, hipMemcpyDeviceToHost, st));
+    PAV_HIP(ctx, hipStreamSynchronize(st));
+    if (key != ~0ull) return record_fail(ctx, S, fail_of(tf), row_l, row_r);
+    from_dev(dev[0], S->rows[row_l]);
+    from_dev(dev[1], S->rows[row_r]);
+    return PAV_OK;
+}
+
 template <class F> void parallel_rows(size_t n, F &&fn) {
     const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     const size_t nt = std::min<size_t>(hw, (n + 63) / 64);
@@ -390,6 +512,9 @@ int pav_trim_load(pav_ctx *ctx, uint32_t n, const pav_trim_row *rows, const uint
     S->op_off.assign((size_t)n + 1, 0);
     rc = pav_align_index(ctx, n, zero_pos.data(), cigar_text, cigar_off, &n_ops, S->ops.data(), S->op_off.data(), nullptr, nullptr);
     if (rc != PAV_OK) return rc;
+    // the passes run on the device (trim_dev.hip): the operations stay resident there
+    PAV_HIP(ctx, S->d_ops.reserve(sizeof(uint32_t) * (n_ops + 16)));
+    if (n_ops) PAV_HIP(ctx, hipMemcpy(S->d_ops.p, S->ops.data(), sizeof(uint32_t) * n_ops, hipMemcpyHostToDevice));
     S->rows.resize(n);
     for (uint32_t i = 0; i < n; ++i) {
         Row &r = S->rows[i];
@@ -411,7 +536,10 @@ int pav_trim_pass(pav_ctx *ctx, uint32_t n_order, const uint32_t *order, int mod
         seen[i] = 1;
     }
     S->err = pav_trim_err{};
-    return mode == PAV_TRIM_QUERY ? pass_query(ctx, S, ord, min_trim_tig_len) : pass_subject(ctx, S, ord, min_trim_tig_len, match_tig != 0);
+    // PAV_TRIM_HOST=1: the same loops on the host (one thread) - kept as the cross-check of the device pass
+    if (host_passes())
+        return mode == PAV_TRIM_QUERY ? pass_query(ctx, S, ord, min_trim_tig_len) : pass_subject(ctx, S, ord, min_trim_tig_len, match_tig != 0);
+    return pass_device(ctx, S, ord, mode, min_trim_tig_len, match_tig != 0);
 }
 
 int pav_trim_pair(pav_ctx *ctx, uint32_t row_l, uint32_t row_r, int mode, int rev_l, int rev_r) {
@@ -419,6 +547,7 @@ int pav_trim_pair(pav_ctx *ctx, uint32_t row_l, uint32_t row_r, int mode, int re
     TrimState *S = tstate(ctx);
     if (row_l >= S->rows.size() || row_r >= S->rows.size() || row_l == row_r) return fail(ctx, PAV_E_ARG, "pav_trim_pair: no such pair of loaded rows");
     S->err = pav_trim_err{};
+    if (!host_passes()) return pair_device(ctx, S, row_l, row_r, mode, rev_l, rev_r);
     Row l = S->rows[row_l], r = S->rows[row_r];
     TrimFail tf;
     if (!trim_record(*S, l, r, mode == PAV_TRIM_QUERY, rev_l != 0, rev_r != 0, tf)) return record_fail(ctx, S, tf, row_l, row_r);
