@@ -287,19 +287,55 @@ def main():
         """n passes of the hot path, one haplotype each: step s goes to lane s mod L; the lanes run on their own host threads
         (the library releases the GIL inside its calls), so one haplotype's kernels fill the gaps of the other's host work."""
         use = lanes if only is None else [only]
+        for ln in use:
+            ln.n_done = 0
         if len(use) == 1:
             for _ in range(n):
                 step(use[0], workload)
+            use[0].n_done = n
             return
         err = []
 
-        def worker(ln):
+        # The lanes take their steps from one counter: a lane that gets ahead takes the next step, so a region does not end with
+        # one lane finishing its fixed share alone (20-step regions: 2.59 -> 2.16 ms per step on the same box; 64-step regions
+        # were at 2.1 already).  PAV_BENCH_STAGGER = cigar | step starts lane i behind lane i - 1's first CIGAR-call / first step
+        # (measured: 2.29 / 2.88 ms per step - no help; default: all lanes start at once)
+        counter = [0]
+        lock = threading.Lock()
+        started = [threading.Event() for _ in use]
+        stagger = os.environ.get('PAV_BENCH_STAGGER', 'none')
+
+        def take():
+            with lock:
+                if counter[0] >= n:
+                    return False
+                counter[0] += 1
+                return True
+
+        def worker(k, ln):
             try:
-                for _ in range(ln.idx, n, len(use)):
-                    step(ln, workload)
+                if k and stagger != 'none':
+                    started[k - 1].wait()
+                first = True
+                while take():
+                    ln.n_done += 1
+                    if first and stagger == 'cigar':
+                        ln.ctx.seq_pack(_lib.PAV_ROLE_TIG)
+                        ln.counts = ln.ctx.cigar_call()
+                        started[k].set()
+                        if workload == 'cigar+verify':
+                            ln.verify = ln.ctx.cigar_verify()
+                        if workload == 'cigar+inv':
+                            inv_step(ln)
+                    else:
+                        step(ln, workload)
+                        started[k].set()
+                    first = False
+                started[k].set()
             except BaseException as ex:      # noqa: BLE001 - re-raised on the main thread
+                started[k].set()
                 err.append(ex)
-        ths = [threading.Thread(target=worker, args=(ln,)) for ln in use]
+        ths = [threading.Thread(target=worker, args=(k, ln)) for k, ln in enumerate(use)]
         for t in ths:
             t.start()
         for t in ths:
@@ -337,13 +373,15 @@ def main():
     # ---- timed region: exactly K steps, profiling off; run R times back to back, the median region is the line's --------
     free_min = [min(ln.ctx.mem_info()[0] for ln in lanes)]
     regions = []
+    region_bp = []                                               # aligned bp of the K passes of each region (this rank): the lanes' shares vary
     for _ in range(max(1, args.repeats)):
         regions.append(timed(args.steps))
+        region_bp.append(float(sum(ln.n_done * ln.counts.aligned_bases for ln in lanes)))
         free_min.append(lanes[0].ctx.mem_info()[0])
     order = sorted(range(len(regions)), key=lambda i: regions[i][1])
     t_local, t_max = regions[order[len(order) // 2]]            # median by the max-over-ranks time (upper median for even R)
     counts = lanes[0].counts
-    aligned_steps = float(sum(lanes[s % n_lanes].counts.aligned_bases for s in range(args.steps)))   # bp of the K passes of this rank
+    aligned_steps = region_bp[order[len(order) // 2]]           # bp of the K passes of this rank in the region the line reports
     if world > 1:
         ab = torch.tensor([aligned_steps], dtype=torch.float64, device=comm_device)
         dist.all_reduce(ab, op=dist.ReduceOp.SUM)
@@ -530,6 +568,23 @@ def main():
             a64 = snv['aln'].astype(np.int64) << 40
             snv_lines = int(np.unique(a64 | (snv['pos'].astype(np.int64) >> 6)).shape[0] + np.unique(a64 | (snv['qry_pos'].astype(np.int64) >> 6)).shape[0])
 
+        def emission_phase(kern_):
+            # walk_snv (side stream) and homology_kernel (main stream) run beside each other and draw on one budget of isolated
+            # line fetches: the phase as a whole against the line-rate roof
+            if snv_lines is None or not pmc or 'walk_snv' not in kern_ or 'homology_kernel' not in kern_:
+                return None
+            hom_lines = pmc.get('fetch_kib', {}).get('homology_kernel')
+            if not hom_lines:
+                return None
+            hom_lines = hom_lines * 1024.0 / 64.0
+            t_ms = max(kern_['walk_snv']['avg_ms'], kern_['homology_kernel']['avg_ms'])
+            rate = (snv_lines + hom_lines) / (t_ms * 1e-3) / 1e9
+            peak = line_roof['with_stores']
+            return {'line_fetches_per_pass': int(snv_lines + hom_lines), 'phase_ms': round(t_ms, 4), 'achieved_glines_per_s': round(rate, 1),
+                    'measured_peak_glines_per_s': peak, 'frac': None if not peak else round(rate / peak, 3),
+                    'note': 'distinct lines of the SNV rows + fabric reads of homology_kernel (FETCH_SIZE / 64 B, ' + str(pmc.get('file')) +
+                            ') over the longer of the two kernels, which run beside each other'}
+
         def isolated_lines(kernel_, avg_ms_):
             if kernel_ != 'walk_snv' or snv_lines is None:
                 return None
@@ -605,6 +660,7 @@ def main():
                                                     for k in sorted(alg_bytes) if k in kern_ and kern_[k]['avg_ms'] > 0}}
 
         kern, roofline = make_roofline(prof, kde=kde_leg)
+        roofline['emission_phase'] = emission_phase(kern)
         # ---- the honest roofline of the PATH (SURVEY.md section 8(d) byte model; the pack above is pre-processing the model
         #      has no term for): algorithmic bytes of one step / step time.  CIGAR-call: 4 B / op + 64 B / row + 16 B / SNV +
         #      40 B / indel + 2-bit SV bases + 0.5 B per scanned homology base (window bound: 128 B / indel) + 0.5 B per X base;

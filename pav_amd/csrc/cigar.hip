@@ -720,7 +720,8 @@ struct VerifyArgs {
 
 typedef unsigned __int128 u128;
 constexpr uint32_t VPIECE = 64;                                        // bases per lane and step
-constexpr int VSPLIT = 2;                                              // workgroups per 2048-operation chunk
+constexpr int VSPLIT = 1;                                              // workgroups per tile of 2048 operation slots (round 3: the padded tiles of
+                                                                       // tok_tiles are about half full - a tile is the work half a chunk was; 2: 0.41 ms)
 
 // Five dwords from the dword that holds base a (4-byte aligned 16-byte load + 1 dword): the 64-base window is bits [2 (a & 15), + 128).
 struct W5 { uint32_t w[5]; };

@@ -4,16 +4,16 @@
 # profiles/<round>_* through tools/prof_summary.py.  Everything is built first, outside the profiler: bench.py runs with
 # --no-build, so no compiler is ever started from a process the profiler's preload has attached to.
 set -x
-ROUND=${1:-r02}
+ROUND=${1:-r03}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$ROUND
 mkdir -p $O
 python3 -c 'import __graft_entry__ as g; g.build()' > $O/build.log 2>&1 || exit 1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O/prof_full -o full -- python3 $R/bench.py --no-cpu-baseline --no-build > $O/full_bench_under_rocprof.json 2> $O/prof_full.err
-rocprofv3 --kernel-trace --stats -d $O/prof_cigar -o cigar -- python3 $R/bench.py --workload cigar --no-cpu-baseline --no-build > $O/cigar_bench_under_rocprof.json 2> $O/prof_cigar.err
-rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o f -- python3 $R/bench.py --no-cpu-baseline --no-build --steps 4 --warmup 4 > $O/pmc_bench.json 2> $O/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o w -- python3 $R/bench.py --no-cpu-baseline --no-build --steps 4 --warmup 4 > /dev/null 2> $O/pmc_write.err
+timeout -k 5 900 rocprofv3 --kernel-trace --stats -d $O/prof_full -o full -- python3 $R/bench.py --no-cpu-baseline --no-build > $O/full_bench_under_rocprof.json 2> $O/prof_full.err
+timeout -k 5 900 rocprofv3 --kernel-trace --stats -d $O/prof_cigar -o cigar -- python3 $R/bench.py --workload cigar --no-cpu-baseline --no-build > $O/cigar_bench_under_rocprof.json 2> $O/prof_cigar.err
+timeout -k 5 600 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o f -- python3 $R/bench.py --no-cpu-baseline --no-build --steps 4 --warmup 4 > $O/pmc_bench.json 2> $O/pmc_fetch.err
+timeout -k 5 600 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o w -- python3 $R/bench.py --no-cpu-baseline --no-build --steps 4 --warmup 4 > /dev/null 2> $O/pmc_write.err
 cd $R
 P=$O/profiles
 mkdir -p $P
@@ -32,5 +32,8 @@ cp $O/cigar_bench_under_rocprof.json $P/${ROUND}_cigar_only_bench_under_rocprof.
 cp $P/${ROUND}_pmc.json $R/profiles/${ROUND}_pmc.json
 python3 bench.py --no-build > $P/${ROUND}_full_path_bench.json 2> $O/bench_full.err
 python3 bench.py --no-build --workload cigar > $P/${ROUND}_cigar_only_bench.json 2> $O/bench_cigar.err
+# one lane and two lanes: how far one host thread gets
+python3 bench.py --no-build --no-cpu-baseline --lanes 1 > $P/${ROUND}_full_path_bench_lanes1.json 2> $O/bench_l1.err
+python3 bench.py --no-build --no-cpu-baseline --lanes 2 > $P/${ROUND}_full_path_bench_lanes2.json 2> $O/bench_l2.err
 find $O -name "*.db" -delete
 ls -la $P; du -sh $O
