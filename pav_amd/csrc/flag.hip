@@ -35,6 +35,11 @@ struct FlagState {
     std::vector<pav_flag_rgn> table[4];                       // insdel_sv, insdel_indel, cluster_indel, cluster_snv
     std::vector<pav_flag_rgn> single;                         // result of the array-level entry points
     std::vector<pav_flag_locus> loci;
+    // device-planned pav_cigar_flag: INS / DEL rows of both vartypes, pinned result block, what the small inputs held last time
+    DevBuf plan;
+    void *pin = nullptr;
+    std::vector<uint8_t> small_seen;
+    const void *small_at = nullptr;
 };
 
 FlagState *fstate(pav_ctx *ctx) {
@@ -374,6 +379,242 @@ __global__ __launch_bounds__(256) void k_check_sorted(const unsigned long long *
     if (__ballot(bad) && (threadIdx.x & 63) == 0) *unsorted = 1;
 }
 
+// ---- pav_cigar_flag planned on the device (round 3) ----------------------------------------------------------------------
+// Nothing in the stage waits for a count: every launch is sized by what the host knows beforehand (all SNV / INS-DEL rows), the
+// real counts stay on the device and every kernel reads them there.  The four INS / DEL row sets are compacted in table order
+// (tile counts from k_indel_keys_cls, one scan, one ordered scatter), so no sort is needed as long as the table rises; the two
+// cluster sweeps are one scan + one emit over both key tables; the two matches one scan + one launch.  One synchronisation at
+// the end.  A table that does not rise shows in that read-back (d_cnt[3]) and the stage runs again on the general path.
+
+constexpr int CLS = 4;                                        // DEL sv, INS sv, DEL indel, INS indel (d_cnt words 8 .. 11)
+constexpr uint32_t FIRST_HITS = 4096;                         // hits per list written straight to pinned host memory
+
+struct FlagPin {                                              // the pinned result block
+    unsigned long long cnt[16];
+    ClusterHit sweep[2][FIRST_HITS];
+    MatchHit match[2][FIRST_HITS];
+};
+
+__device__ __forceinline__ int insdel_class(bool pass, uint32_t svlen, uint32_t svtype, uint32_t lo_indel) {
+    if (!pass) return -1;
+    const int t = svlen >= 50 ? 0 : (svlen >= lo_indel ? 1 : -1);       // :497, :504-505
+    return t < 0 ? -1 : 2 * t + (svtype == 0 ? 1 : 0);
+}
+
+// k_indel_keys + the tile's rows per INS / DEL class (four 16-bit fields of one word: a tile has 2048 rows)
+__global__ __launch_bounds__(256) void k_indel_keys_cls(const pav_indel *__restrict__ ind, uint64_t n, const pav_aln *__restrict__ aln,
+                                                        const uint16_t *__restrict__ rank, const long long *__restrict__ tpos,
+                                                        const long long *__restrict__ tend, unsigned long long *__restrict__ keys,
+                                                        unsigned long long *__restrict__ counters, unsigned long long tag,
+                                                        unsigned long long sentinel, uint32_t *__restrict__ tile_cnt,
+                                                        unsigned long long *__restrict__ tile_cls, uint32_t lo_indel) {
+    const uint64_t i0 = (uint64_t)blockIdx.x * KEY_TILE + threadIdx.x;
+    unsigned long long n_pass = 0, n_small = 0, cls = 0;
+    uint32_t pos[KEY_PER], end[KEY_PER], svlen[KEY_PER], al[KEY_PER], ty[KEY_PER];
+#pragma unroll
+    for (int u = 0; u < KEY_PER; ++u) {
+        const pav_indel &v = ind[i0 + 256 * u < n ? i0 + 256 * u : n - 1];
+        pos[u] = v.pos; end[u] = v.end; svlen[u] = v.svlen; al[u] = v.aln; ty[u] = v.svtype;
+    }
+#pragma unroll
+    for (int u = 0; u < KEY_PER; ++u) {
+        const uint64_t i = i0 + 256 * u;
+        if (i >= n) break;
+        const bool pass = (long long)pos[u] > tpos[al[u]] && (long long)end[u] < tend[al[u]];
+        const bool small = pass && svlen[u] < 50;
+        keys[i] = small ? (tag | (unsigned long long)rank[aln[al[u]].ref_id] << 38 | (unsigned long long)pos[u] << 6 | (end[u] - pos[u]))
+                             : sentinel;
+        n_pass += pass;
+        n_small += small;
+        const int c = insdel_class(pass, svlen[u], ty[u], lo_indel);
+        if (c >= 0) cls += 1ull << (16 * c);
+    }
+    block_add(n_pass, counters);
+    block_add(n_small, counters + 1, tile_cnt + blockIdx.x);
+    // the class fields cannot carry into each other (2048 rows per tile at most in all four together)
+    __shared__ unsigned long long part[4];
+    for (int o = WAVE / 2; o; o >>= 1) cls += __shfl_down(cls, o);
+    if ((threadIdx.x & (WAVE - 1)) == 0) part[threadIdx.x / WAVE] = cls;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cls[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+// k_key_tile_scan for six sequences: workgroups 0 / 1 the key tables, 2 .. 5 the INS / DEL classes (totals to cls_total)
+struct TileScan6Args {
+    const uint32_t *cnt[2]; uint64_t *off[2]; uint32_t n_tiles[2];
+    const unsigned long long *tile_cls; uint32_t *cls_off[CLS]; unsigned long long *cls_total;
+};
+__global__ __launch_bounds__(1024) void k_key_tile_scan6(TileScan6Args A) {
+    __shared__ uint64_t wsum[16];
+    const int q = blockIdx.x, c = q - 2;
+    const uint32_t n = A.n_tiles[q < 2 ? q : 1], per = (n + 1023) / 1024;
+    const uint32_t t0 = threadIdx.x * per < n ? threadIdx.x * per : n, t1 = t0 + per < n ? t0 + per : n;
+    auto at = [&](uint32_t t) -> uint64_t { return q < 2 ? A.cnt[q][t] : (A.tile_cls[t] >> (16 * c)) & 0xffffull; };
+    uint64_t mine = 0;
+    for (uint32_t t = t0; t < t1; ++t) mine += at(t);
+    uint64_t inc = mine;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint64_t y = __shfl_up(inc, d); if (lane >= d) inc += y; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint64_t base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    uint64_t run = base + inc - mine;
+    if (q < 2) for (uint32_t t = t0; t < t1; ++t) { A.off[q][t] = run; run += at(t); }
+    else {
+        for (uint32_t t = t0; t < t1; ++t) { A.cls_off[c][t] = (uint32_t)run; run += at(t); }
+        if (threadIdx.x == 1023) A.cls_total[c] = run;
+    }
+}
+
+// The rows of the four INS / DEL classes in table order: tile t writes behind cls_off[c][t].  Lane l owns rows 8 l .. 8 l + 7 of
+// the tile (the 64-byte records are read field-wise either way: one line per record).
+struct SplitArgs {
+    const pav_indel *ind; uint64_t n; const pav_aln *aln; const uint16_t *rank; const long long *tpos, *tend;
+    const uint32_t *cls_off[CLS];
+    unsigned long long *key[CLS], *val[CLS];                  // DEL: rank << 32 | POS, rank << 32 | END; INS: rank << 32 | POS, SVLEN
+    uint32_t lo_indel;
+};
+__global__ __launch_bounds__(256) void k_insdel_split_ordered(SplitArgs A) {
+    __shared__ unsigned long long wsum[4];
+    const uint64_t i0 = (uint64_t)blockIdx.x * KEY_TILE + (uint64_t)threadIdx.x * KEY_PER;
+    uint32_t pos[KEY_PER], end[KEY_PER], svlen[KEY_PER], al[KEY_PER], ty[KEY_PER];
+#pragma unroll
+    for (int u = 0; u < KEY_PER; ++u) {
+        const pav_indel &v = A.ind[i0 + u < A.n ? i0 + u : A.n - 1];
+        pos[u] = v.pos; end[u] = v.end; svlen[u] = v.svlen; al[u] = v.aln; ty[u] = v.svtype;
+    }
+    int cls[KEY_PER];
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int u = 0; u < KEY_PER; ++u) {
+        cls[u] = -1;
+        if (i0 + u < A.n && svlen[u] >= (A.lo_indel < 50 ? A.lo_indel : 50u)) {
+            const bool pass = (long long)pos[u] > A.tpos[al[u]] && (long long)end[u] < A.tend[al[u]];
+            cls[u] = insdel_class(pass, svlen[u], ty[u], A.lo_indel);
+        }
+        if (cls[u] >= 0) mine += 1ull << (16 * cls[u]);
+    }
+    unsigned long long inc = mine;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long y = __shfl_up(inc, d); if (lane >= d) inc += y; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    if (!mine) return;
+    unsigned long long before = inc - mine;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+#pragma unroll
+    for (int u = 0; u < KEY_PER; ++u) {
+        const int c = cls[u];
+        if (c < 0) continue;
+        const uint64_t s = (uint64_t)A.cls_off[c][blockIdx.x] + ((before >> (16 * c)) & 0xffffull);
+        before += 1ull << (16 * c);
+        const unsigned long long r = (unsigned long long)A.rank[A.aln[al[u]].ref_id] << 32;
+        A.key[c][s] = r | pos[u];
+        A.val[c][s] = (c & 1) ? (unsigned long long)svlen[u] : (r | end[u]);
+    }
+}
+
+// Both compacted key tables as the sweep sees them: rows [0, n_snv) hold SNV keys (cnt[0] of them real), rows [n_snv, ...) the
+// INS-DEL keys < 50 bp (cnt[2] real).  Rows behind the real ones are never read.
+struct KeyView {
+    const unsigned long long *k; uint64_t n_snv; unsigned long long tag; const unsigned long long *cnt;
+    __device__ __forceinline__ bool real(uint64_t i, uint64_t &local, uint64_t &n_real) const {
+        const bool ind = i >= n_snv;
+        local = ind ? i - n_snv : i;
+        n_real = cnt[ind ? 2 : 0];
+        return local < n_real;
+    }
+    __device__ __forceinline__ void at(uint64_t i, uint32_t &chrom, int64_t &mid) const {
+        unsigned long long x = k[i];
+        if (i >= n_snv) {                                                     // k_indel_mid: (END + POS) // 2, :643
+            x &= ~tag;
+            chrom = (uint32_t)(x >> 38);
+            mid = (int64_t)((2 * ((x >> 6) & 0xffffffffull) + (x & 63)) >> 1);
+        } else { chrom = (uint32_t)(x >> CM_SHIFT); mid = (int64_t)(x & CM_MID); }
+    }
+    __device__ __forceinline__ bool opens(uint64_t i, int64_t win) const {   // rows i - 1 and i of one table, both real
+        uint32_t ca, cb; int64_t ma, mb;
+        at(i - 1, ca, ma); at(i, cb, mb);
+        return ca != cb || mb >= ma + win;
+    }
+};
+struct OpenRowPlanned {
+    KeyView V; int64_t win; unsigned long long *unsorted;
+    __device__ unsigned long long operator()(unsigned long long i) const {
+        uint64_t local, n_real;
+        if (!V.real(i, local, n_real) || local == 0) return i;
+        if (V.k[i - 1] > V.k[i]) *unsorted = 1;                                // table order is not the rules' iteration order
+        return V.opens(i, win) ? i : 0ull;
+    }
+};
+struct EmitArgs {
+    KeyView V; const unsigned long long *start; uint64_t n; int64_t win, win_min, min_count[2];
+    ClusterHit *hits[2]; uint64_t cap[2]; unsigned long long *n_hits; FlagPin *pin;
+};
+__global__ __launch_bounds__(256) void k_cluster_emit_planned(EmitArgs A) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint64_t local, n_real;
+    if (i >= A.n || !A.V.real(i, local, n_real)) return;
+    if (!(local + 1 == n_real || A.V.opens(i + 1, A.win))) return;            // only the last row of a cluster reports
+    const int t = i >= A.V.n_snv;
+    const uint64_t j = A.start[i];
+    const int64_t count = (int64_t)(i - j) + 1;
+    uint32_t cj, ci; int64_t pos, end;
+    A.V.at(j, cj, pos); A.V.at(i, ci, end);
+    if (count >= A.min_count[t] && end - pos >= A.win_min) {
+        const unsigned long long slot = atomicAdd(A.n_hits + t, 1ull);
+        const ClusterHit h{j, pos, end, count, ci, 0};
+        if (slot < A.cap[t]) A.hits[t][slot] = h;
+        if (slot < FIRST_HITS) A.pin->sweep[t][slot] = h;
+    }
+}
+
+// Input of the running maximum of rank << 32 | END over the DEL rows of both vartypes, one sequence: vartype 1 follows vartype 0
+// n_ind rows later and carries bit 63, so the maximum restarts there; rows behind the real ones count as 0.  Looks at the order
+// of the DEL keys on the way.
+constexpr unsigned long long VT1 = 1ull << 63;
+struct DelEndPlanned {
+    const unsigned long long *key[2], *end[2]; uint64_t n_ind; const unsigned long long *cnt; unsigned long long *unsorted;
+    __device__ unsigned long long operator()(unsigned long long i) const {
+        const int t = i >= n_ind;
+        const uint64_t local = t ? i - n_ind : i, n_real = cnt[8 + 2 * t];
+        if (local >= n_real) return t ? VT1 : 0ull;
+        if (local && key[t][local - 1] > key[t][local]) *unsorted = 1;
+        return end[t][local] | (t ? VT1 : 0ull);
+    }
+};
+
+// k_ins_match for both vartypes (first / second half of the grid), counts on the device; del_max from the scan above (vartype 1 carries VT1)
+struct MatchArgs {
+    const unsigned long long *ins_key[2], *ins_len[2], *del_key[2], *del_max[2]; const unsigned long long *cnt;
+    long long flank_cluster; MatchHit *hits[2]; unsigned long long *n_hits; FlagPin *pin; uint32_t blocks_per_t;
+};
+__global__ __launch_bounds__(256) void k_ins_match_planned(MatchArgs A) {
+    const int t = blockIdx.x >= A.blocks_per_t;
+    const uint64_t i = (uint64_t)(blockIdx.x - (t ? A.blocks_per_t : 0u)) * 256 + threadIdx.x, n_del = A.cnt[8 + 2 * t], n_ins = A.cnt[9 + 2 * t];
+    if (i >= n_ins || n_del == 0) return;
+    const unsigned long long *del_key = A.del_key[t], *del_max = A.del_max[t], vt = t ? VT1 : 0ull;
+    const unsigned long long r = A.ins_key[t][i] >> 32;
+    const long long pos = (long long)(A.ins_key[t][i] & 0xffffffffull), flank = (long long)A.ins_len[t][i] * A.flank_cluster;
+    const long long lo = pos - flank, hi = pos + flank;
+    if (hi <= lo || hi <= 0) return;
+    const uint64_t seg = lower_bound_u64(del_key, 0, n_del, r << 32);
+    const uint64_t j = hi > 0xffffffffll ? lower_bound_u64(del_key, seg, n_del, (r + 1) << 32)
+                                         : lower_bound_u64(del_key, seg, n_del, r << 32 | (unsigned long long)hi);
+    if (j == seg) return;
+    const long long max_end = (long long)(del_max[j - 1] & 0xffffffffull);
+    if (max_end <= lo) return;
+    uint64_t first = seg;
+    if (lo >= 0) first = lower_bound_u64(del_max, seg, j, (vt | r << 32 | (unsigned long long)lo) + 1);
+    const unsigned long long s = atomicAdd(A.n_hits + t, 1ull);
+    const MatchHit h{r << 32 | (del_key[first] & 0xffffffffull), max_end};
+    A.hits[t][s] = h;
+    if (s < FIRST_HITS) A.pin->match[t][s] = h;
+}
+
 // ---- device drivers ----------------------------------------------------------------------------------------------------
 
 int sort_keys(pav_ctx *ctx, FlagState *S, unsigned long long *in, unsigned long long *out, uint64_t n, unsigned end_bit) {
@@ -492,6 +733,112 @@ int run_match(pav_ctx *ctx, FlagState *S, uint64_t n_del, uint64_t n_ins, int64_
     return PAV_OK;
 }
 
+// pav_cigar_flag planned on the device (see above).  d_cnt zeroed, trim table and ranks uploaded by the caller.  *again: the tables
+// do not rise in table order - nothing was produced, the caller takes the general path.
+int flag_planned(pav_ctx *ctx, FlagState *S, const pav_flag_params *P, unsigned long long *d_cnt, const long long *d_tp, const long long *d_te,
+                 const uint16_t *d_rank, unsigned long long tag, unsigned long long pass_counts[2], bool *again) {
+    hipStream_t st = ctx->stream;
+    const uint64_t n_snv = ctx->counts.n_snv, n_ind = ctx->counts.n_indel, n_keys = n_snv + n_ind;
+    const pav_aln *d_aln = ctx->d_aln.as<pav_aln>();
+    *again = false;
+    if (!S->pin) PAV_HIP(ctx, hipHostMalloc(&S->pin, sizeof(FlagPin), hipHostMallocDefault));
+    FlagPin *pin = static_cast<FlagPin *>(S->pin);
+    const uint32_t tiles_snv = (uint32_t)((n_snv + KEY_TILE - 1) / KEY_TILE), tiles_ind = (uint32_t)((n_ind + KEY_TILE - 1) / KEY_TILE);
+    const uint32_t lo_indel = (uint32_t)std::min<int64_t>(std::max<int64_t>(P->insdel_min_svlen, 0), 0xffffffffll);
+
+    PAV_HIP(ctx, S->a.reserve(8 * n_keys)); PAV_HIP(ctx, S->b.reserve(8 * n_keys)); PAV_HIP(ctx, S->start.reserve(8 * n_keys));
+    unsigned long long *k_in = S->a.as<unsigned long long>(), *k_sorted = S->b.as<unsigned long long>();
+    // tile arrays: offsets of the key tiles, their counts, class word and class offsets of the INS-DEL tiles
+    PAV_HIP(ctx, S->c.reserve(12 * ((size_t)tiles_snv + tiles_ind) + (8 + 4 * CLS) * (size_t)tiles_ind + 64));
+    uint64_t *d_toff = S->c.as<uint64_t>();
+    unsigned long long *d_tcls = reinterpret_cast<unsigned long long *>(d_toff + tiles_snv + tiles_ind);
+    uint32_t *d_tcnt = reinterpret_cast<uint32_t *>(d_tcls + tiles_ind);
+    uint32_t *d_cls_off = d_tcnt + tiles_snv + tiles_ind;
+    // rows of the four classes (keys, values: n_ind each), then the running maximum over the DEL rows of both vartypes (2 n_ind)
+    PAV_HIP(ctx, S->plan.reserve(8 * (2 * CLS + 2) * (size_t)n_ind + 64));
+    unsigned long long *cls_key[CLS], *cls_val[CLS], *del_max = S->plan.as<unsigned long long>() + 2 * CLS * n_ind;
+    for (int c = 0; c < CLS; ++c) { cls_key[c] = S->plan.as<unsigned long long>() + 2 * c * n_ind; cls_val[c] = cls_key[c] + n_ind; }
+    const uint64_t cap[2] = {sweep_cap(n_snv, P->cluster_min_snv), sweep_cap(n_ind, P->cluster_min_indel)};
+    PAV_HIP(ctx, S->hits_b[0].reserve(sizeof(ClusterHit) * cap[0])); PAV_HIP(ctx, S->hits_b[1].reserve(sizeof(ClusterHit) * cap[1]));
+    PAV_HIP(ctx, S->hits_b[2].reserve(sizeof(MatchHit) * (n_ind + 1))); PAV_HIP(ctx, S->hits_b[3].reserve(sizeof(MatchHit) * (n_ind + 1)));
+
+    const KeyView V{k_sorted, n_snv, tag, d_cnt};
+    auto opens = rocprim::make_transform_iterator(rocprim::counting_iterator<unsigned long long>(0), OpenRowPlanned{V, P->cluster_win, d_cnt + 3});
+    const DelEndPlanned DE{{cls_key[0], cls_key[2]}, {cls_val[0], cls_val[2]}, n_ind, d_cnt, d_cnt + 3};
+    auto del_end = rocprim::make_transform_iterator(rocprim::counting_iterator<unsigned long long>(0), DE);
+    size_t bytes = 0, bytes2 = 0;
+    PAV_HIP(ctx, rocprim::inclusive_scan(nullptr, bytes, opens, S->start.as<unsigned long long>(), (size_t)n_keys,
+                                         rocprim::maximum<unsigned long long>(), st));
+    if (n_ind) PAV_HIP(ctx, rocprim::inclusive_scan(nullptr, bytes2, del_end, del_max, (size_t)(2 * n_ind), rocprim::maximum<unsigned long long>(), st));
+    PAV_HIP(ctx, S->tmp.reserve(std::max(bytes, bytes2) + 16));
+
+    if (n_snv)
+        PAV_LAUNCH(ctx, "k_snv_keys", k_snv_keys, tiles_snv, 256, 0, ctx->d_snv.as<pav_snv>(), n_snv, d_aln, d_rank, d_tp, d_te, k_in, d_cnt,
+                   tag - 1, d_tcnt);
+    if (n_ind)
+        PAV_LAUNCH(ctx, "k_indel_keys_cls", k_indel_keys_cls, tiles_ind, 256, 0, ctx->d_indel.as<pav_indel>(), n_ind, d_aln, d_rank, d_tp, d_te,
+                   k_in + n_snv, d_cnt + 1, tag, tag | (tag - 1), d_tcnt + tiles_snv, d_tcls, lo_indel);
+    TileScan6Args TS;
+    TS.cnt[0] = d_tcnt; TS.cnt[1] = d_tcnt + tiles_snv; TS.off[0] = d_toff; TS.off[1] = d_toff + tiles_snv;
+    TS.n_tiles[0] = tiles_snv; TS.n_tiles[1] = tiles_ind; TS.tile_cls = d_tcls; TS.cls_total = d_cnt + 8;
+    for (int c = 0; c < CLS; ++c) TS.cls_off[c] = d_cls_off + (size_t)c * tiles_ind;
+    PAV_LAUNCH(ctx, "k_key_tile_scan6", k_key_tile_scan6, 2 + CLS, 1024, 0, TS);
+    CompactKeysArgs CK;
+    CK.in[0] = k_in; CK.in[1] = k_in + n_snv; CK.out[0] = k_sorted; CK.out[1] = k_sorted + n_snv;
+    CK.off[0] = d_toff; CK.off[1] = d_toff + tiles_snv; CK.n[0] = n_snv; CK.n[1] = n_ind; CK.tiles0 = tiles_snv; CK.low = tag - 1;
+    PAV_LAUNCH(ctx, "k_compact_keys", k_compact_keys, tiles_snv + tiles_ind, 256, 0, CK);
+    if (n_ind) {
+        SplitArgs SA;
+        SA.ind = ctx->d_indel.as<pav_indel>(); SA.n = n_ind; SA.aln = d_aln; SA.rank = d_rank; SA.tpos = d_tp; SA.tend = d_te; SA.lo_indel = lo_indel;
+        for (int c = 0; c < CLS; ++c) { SA.cls_off[c] = TS.cls_off[c]; SA.key[c] = cls_key[c]; SA.val[c] = cls_val[c]; }
+        PAV_LAUNCH(ctx, "k_insdel_split_ordered", k_insdel_split_ordered, tiles_ind, 256, 0, SA);
+    }
+    {   // both cluster sweeps (rule call_inv_cluster)
+        const int tok = prof_begin(ctx, "rocprim::inclusive_scan");
+        const hipError_t e = rocprim::inclusive_scan(S->tmp.p, bytes, opens, S->start.as<unsigned long long>(), (size_t)n_keys,
+                                                     rocprim::maximum<unsigned long long>(), st);
+        prof_end(ctx, tok);
+        PAV_HIP(ctx, e);
+        EmitArgs EA;
+        EA.V = V; EA.start = S->start.as<unsigned long long>(); EA.n = n_keys; EA.win = EA.win_min = P->cluster_win;
+        EA.min_count[0] = P->cluster_min_snv; EA.min_count[1] = P->cluster_min_indel;
+        EA.hits[0] = S->hits_b[0].as<ClusterHit>(); EA.hits[1] = S->hits_b[1].as<ClusterHit>(); EA.cap[0] = cap[0]; EA.cap[1] = cap[1];
+        EA.n_hits = d_cnt + 4; EA.pin = pin;
+        PAV_LAUNCH(ctx, "k_cluster_emit_planned", k_cluster_emit_planned, (uint32_t)((n_keys + 255) / 256), 256, 0, EA);
+    }
+    if (n_ind) {   // both matches (rule call_inv_flag_insdel_cluster)
+        const int tok = prof_begin(ctx, "rocprim::inclusive_scan");
+        const hipError_t e = rocprim::inclusive_scan(S->tmp.p, bytes2, del_end, del_max, (size_t)(2 * n_ind), rocprim::maximum<unsigned long long>(), st);
+        prof_end(ctx, tok);
+        PAV_HIP(ctx, e);
+        MatchArgs MA;
+        for (int t = 0; t < 2; ++t) {
+            MA.del_key[t] = cls_key[2 * t]; MA.ins_key[t] = cls_key[2 * t + 1]; MA.ins_len[t] = cls_val[2 * t + 1];
+            MA.del_max[t] = del_max + (size_t)t * n_ind; MA.hits[t] = S->hits_b[2 + t].as<MatchHit>();
+        }
+        MA.cnt = d_cnt; MA.flank_cluster = P->insdel_flank_cluster; MA.n_hits = d_cnt + 12; MA.pin = pin;
+        MA.blocks_per_t = (uint32_t)((n_ind + 255) / 256);
+        PAV_LAUNCH(ctx, "k_ins_match_planned", k_ins_match_planned, 2 * MA.blocks_per_t, 256, 0, MA);
+    }
+    PAV_HIP(ctx, hipMemcpyAsync(pin->cnt, d_cnt, 128, hipMemcpyDeviceToHost, st));
+    PAV_HIP(ctx, hipStreamSynchronize(st));                                                 // the one synchronisation of the stage
+    const unsigned long long *c = pin->cnt;
+    if (c[3]) { *again = true; return PAV_OK; }
+    pass_counts[0] = c[0]; pass_counts[1] = c[1];
+    if (c[4] > cap[0] || c[5] > cap[1]) return fail(ctx, PAV_E_LIMIT, "flag: cluster output overflow (%llu / %llu hits)", c[4], c[5]);
+    for (int q = 0; q < 2; ++q) {
+        std::vector<ClusterHit> sh(c[4 + q]);
+        if (c[4 + q] > FIRST_HITS) PAV_HIP(ctx, hipMemcpy(sh.data(), S->hits_b[q].p, sizeof(ClusterHit) * sh.size(), hipMemcpyDeviceToHost));
+        else std::copy(pin->sweep[q], pin->sweep[q] + sh.size(), sh.begin());
+        sweep_collect(sh, S->table[q == 0 ? 3 : 2]);
+        std::vector<MatchHit> mh(c[12 + q]);
+        if (c[12 + q] > FIRST_HITS) PAV_HIP(ctx, hipMemcpy(mh.data(), S->hits_b[2 + q].p, sizeof(MatchHit) * mh.size(), hipMemcpyDeviceToHost));
+        else std::copy(pin->match[q], pin->match[q] + mh.size(), mh.begin());
+        merge_matches(mh, P->insdel_flank_merge, S->table[q]);
+    }
+    return PAV_OK;
+}
+
 }  // namespace
 }  // namespace pav
 
@@ -504,8 +851,9 @@ void pav_flag_release(pav_ctx *ctx) {
     FlagState *S = static_cast<FlagState *>(ctx->flag);
     DevBuf *bufs[] = {&S->a, &S->b, &S->c, &S->d, &S->tmp, &S->hits, &S->cnt, &S->small, &S->start,
                       &S->split[0][0], &S->split[0][1], &S->split[0][2], &S->split[0][3], &S->split[1][0], &S->split[1][1],
-                      &S->split[1][2], &S->split[1][3], &S->hits_b[0], &S->hits_b[1], &S->hits_b[2], &S->hits_b[3]};
+                      &S->split[1][2], &S->split[1][3], &S->hits_b[0], &S->hits_b[1], &S->hits_b[2], &S->hits_b[3], &S->plan};
     for (DevBuf *b : bufs) b->release();
+    if (S->pin) (void)hipHostFree(S->pin);
     delete S;
     ctx->flag = nullptr;
 }
@@ -633,11 +981,17 @@ int pav_cigar_flag(pav_ctx *ctx, const int64_t *trim_pos, const int64_t *trim_en
     long long *d_tp = reinterpret_cast<long long *>(S->small.as<uint8_t>() + 128), *d_te = d_tp + n_aln;
     uint16_t *d_rank = reinterpret_cast<uint16_t *>(d_te + n_aln);
     PAV_HIP(ctx, hipMemsetAsync(d_cnt, 0, 128, st));
-    if (n_aln) {
-        PAV_HIP(ctx, hipMemcpyAsync(d_tp, trim_pos, 8 * (size_t)n_aln, hipMemcpyHostToDevice, st));
-        PAV_HIP(ctx, hipMemcpyAsync(d_te, trim_end, 8 * (size_t)n_aln, hipMemcpyHostToDevice, st));
+    // the trim table and the ranks go up when they differ from what is there (a caller that flags pass after pass sends the same)
+    std::vector<uint8_t> up(16 * (size_t)n_aln + 2 * (size_t)n_ref);
+    if (n_aln) { memcpy(up.data(), trim_pos, 8 * (size_t)n_aln); memcpy(up.data() + 8 * (size_t)n_aln, trim_end, 8 * (size_t)n_aln); }
+    if (n_ref) memcpy(up.data() + 16 * (size_t)n_aln, rank.data(), 2 * (size_t)n_ref);
+    if (S->small_at != S->small.p || up != S->small_seen) {
+        S->small_at = nullptr;
+        if (!up.empty()) PAV_HIP(ctx, hipMemcpyAsync(d_tp, up.data(), up.size(), hipMemcpyHostToDevice, st));
+        PAV_HIP(ctx, hipStreamSynchronize(st));                          // `up` is pageable: the copy has read it when this returns
+        S->small_seen.swap(up);
+        S->small_at = S->small.p;
     }
-    if (n_ref) PAV_HIP(ctx, hipMemcpyAsync(d_rank, rank.data(), 2 * (size_t)n_ref, hipMemcpyHostToDevice, st));
     const pav_aln *d_aln = ctx->d_aln.as<pav_aln>();
     unsigned long long cnt[8] = {0};
     int rc;
@@ -653,6 +1007,20 @@ int pav_cigar_flag(pav_ctx *ctx, const int64_t *trim_pos, const int64_t *trim_en
     const unsigned long long tag = 1ull << (CM_SHIFT + rank_bits);
     const uint64_t n_keys = n_snv + n_ind;
     unsigned long long *k_in = nullptr, *k_sorted = nullptr;
+    bool planned = false;
+    if (n_keys && getenv("PAV_FLAG_HOST") == nullptr) {                  // round 3: planned on the device, one synchronisation
+        bool again = false;
+        unsigned long long pc[2] = {0, 0};
+        if ((rc = flag_planned(ctx, S, P, d_cnt, d_tp, d_te, d_rank, tag, pc, &again)) != PAV_OK) return rc;
+        lap("planned");
+        planned = !again;
+        if (planned) { res->n_snv_pass = pc[0]; res->n_indel_pass = pc[1]; }
+        else {
+            for (auto &t : S->table) t.clear();
+            PAV_HIP(ctx, hipMemsetAsync(d_cnt, 0, 128, st));
+        }
+    }
+    if (!planned) {
     if (n_keys) {
         PAV_HIP(ctx, S->a.reserve(8 * n_keys)); PAV_HIP(ctx, S->b.reserve(8 * n_keys));
         k_in = S->a.as<unsigned long long>(); k_sorted = S->b.as<unsigned long long>();
@@ -753,6 +1121,7 @@ int pav_cigar_flag(pav_ctx *ctx, const int64_t *trim_pos, const int64_t *trim_en
     if (c3[0] || c3[1]) PAV_HIP(ctx, hipStreamSynchronize(st));                         // readback 4
     for (int t = 0; t < 2; ++t) merge_matches(match_hits[t], P->insdel_flank_merge, S->table[t]);
     lap("hits+merge");
+    }
 
     // ---- flagged regions (rule call_inv_merge_flagged_loci) ----------------------------------------------------------------
     for (int t = 0; t < 4; ++t) { res->tables[t] = S->table[t].data(); res->n[t] = S->table[t].size(); }
