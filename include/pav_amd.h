@@ -403,7 +403,9 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
 /* what 0: the region's log lines (log_bytes + 1 buffer); what 1: the RuntimeError text (error_bytes + 1). */
 int pav_inv_text(pav_ctx *ctx, uint32_t region, int what, char *buf, uint32_t buf_len);
 /* The same texts for every region of the last scan at once: region i is buf[off[i] .. off[i + 1]) (no terminators); off has
- * n_regions + 1 entries; buf_len >= the sum of log_bytes (what 0) / error_bytes (what 1). */
+ * n_regions + 1 entries; buf_len >= the sum of log_bytes (what 0) / error_bytes (what 1).  what 2: the line scan_for_inv prints
+ * for a region with an inversion signature ('INV Found: outer=..., inner=... (ref outer=..., inner=...)' + newline,
+ * pavlib/inv.py:408), empty for the other regions.  buf NULL: only off is filled (the sizes). */
 int pav_inv_texts(pav_ctx *ctx, int what, char *buf, uint64_t buf_len, uint64_t *off);
 /* Density table of a call incl. FLANK (0 '' / 1 UP / 2 DN) and MATCH (0 '' / 1 SAME / 2 OTHER / 3 NaN). */
 int pav_inv_table(pav_ctx *ctx, uint32_t region, int64_t *index, int8_t *state_mer, int8_t *state, double *kern_fwd,

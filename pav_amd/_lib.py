@@ -673,11 +673,14 @@ class Context:
         self._check(self.lib.pav_inv_text(self.handle, region, what, buf, n_bytes + 1), 'pav_inv_text')
         return buf.value.decode()
 
-    def inv_texts(self, what, n_regions, total_bytes, joined=False):
-        """Log (what 0) or error (what 1) text of every region of the last scan: list of str (``joined``: one string, the
-        texts in region order)."""
-        buf = ctypes.create_string_buffer(int(total_bytes) + 1)
+    def inv_texts(self, what, n_regions, total_bytes=None, joined=False):
+        """Log (what 0) / error (what 1) text or 'INV Found' line (what 2) of every region of the last scan: list of str
+        (``joined``: one string, the texts in region order).  ``total_bytes`` None: asked from the library first."""
         off = np.zeros(n_regions + 1, dtype=np.uint64)
+        if total_bytes is None:
+            self._check(self.lib.pav_inv_texts(self.handle, what, None, 0, _ptr(off)), 'pav_inv_texts')
+            total_bytes = int(off[n_regions])
+        buf = ctypes.create_string_buffer(int(total_bytes) + 1)
         self._check(self.lib.pav_inv_texts(self.handle, what, buf, int(total_bytes), _ptr(off)), 'pav_inv_texts')
         raw = buf.raw
         if joined:

@@ -28,10 +28,16 @@ struct InvState {
     // lift-over index (pav_inv_load_alignments)
     std::vector<LiftRow> rows;
     std::vector<uint32_t> ops, sub_begin, qry_begin;
-    std::vector<uint32_t> coarse[2];                        // every 64th entry of sub_begin / qry_begin: the first level of op_at
+    // first level of op_at, per axis: a record's begins are cut into position buckets of 2^shift bases (about 16 operations per
+    // bucket on average); bucket[bucket_off[row] + b] = operations of the record (relative to its first) that begin before
+    // base + (b << shift).  One read bounds the search in the 36 MB begin array to a few lines.
+    struct Buckets { std::vector<uint32_t> first; std::vector<uint64_t> off; std::vector<uint8_t> shift; std::vector<uint32_t> base; } buckets[2];
     std::vector<uint64_t> op_off;
     std::vector<std::vector<uint32_t>> by_ref, by_tig;      // rows per reference / contig record, sorted by start
     std::vector<int64_t> by_ref_maxlen, by_tig_maxlen;
+    // the same rows as columns (start, end, largest end so far), for the point queries of the lifts
+    struct Spans { std::vector<int64_t> begin, end, max_end; };
+    std::vector<Spans> span_ref, span_tig;
     std::vector<std::string> names[2];
     mutable std::vector<int8_t> row_checked;                // 0 not yet, 1 usable, 2 has N / P operations
     bool loaded = false;
@@ -39,6 +45,7 @@ struct InvState {
     std::vector<pav_inv_result> results;
     std::vector<std::string> logs;
     std::vector<std::string> errors;
+    std::vector<std::string> found;                          // 'INV Found: ...' line of a region (inv.py:408), or empty
     std::vector<std::unique_ptr<InvTable>> tables;
     // Pinned host memory for the call tables: blocks persist across scans (pinning is expensive) and are bump-allocated.
     // Two arenas alternate between scans: the tables of a scan live until the next pav_inv_scan_batch, and that next scan
@@ -135,31 +142,43 @@ public:
         r.pos = new_pos; r.end = new_end;
     }
 
-    // records of one sequence whose [begin, end) contains pos
-    void containing(const std::vector<uint32_t> &recs, int64_t maxlen, bool ref_axis, int64_t pos, std::vector<uint32_t> &hits) const {
+    // records of one sequence whose [begin, end) contains pos, by rising begin: the rows that begin at or before pos, walked from
+    // the last one back until no earlier row reaches pos (a walk over every row that begins within the longest record of the
+    // sequence before pos was a third of a microsecond per query)
+    void containing(const std::vector<uint32_t> &recs, const InvState::Spans &sp, int64_t pos, std::vector<uint32_t> &hits) const {
         hits.clear();
-        auto begin_of = [&](uint32_t r) { return ref_axis ? S->rows[r].pos : S->rows[r].qry_pos; };
-        auto end_of = [&](uint32_t r) { return ref_axis ? S->rows[r].end : S->rows[r].qry_end; };
-        // recs sorted by begin: first candidate has begin >= pos - maxlen, last has begin <= pos
-        size_t lo = std::lower_bound(recs.begin(), recs.end(), pos - maxlen, [&](uint32_t r, int64_t v) { return begin_of(r) < v; }) - recs.begin();
-        for (size_t i = lo; i < recs.size() && begin_of(recs[i]) <= pos; ++i)
-            if (end_of(recs[i]) > pos) hits.push_back(recs[i]);
+        size_t i = (size_t)(std::upper_bound(sp.begin.begin(), sp.begin.end(), pos) - sp.begin.begin());
+        while (i > 0 && sp.max_end[i - 1] > pos) {
+            --i;
+            if (sp.end[i] > pos) hits.push_back(recs[i]);
+        }
+        std::reverse(hits.begin(), hits.end());
     }
 
-    // point lookup in one record's operation table; axis 0 = subject, 1 = query.  Returns op index or -1.
-    int64_t op_at(uint32_t row, int axis, int64_t pos) const {
+    // the begins of one record's operation table that bound `v` (see op_at): [lo, hi) holds the first begin above v, or hi is it
+    void window(uint32_t row, int axis, uint32_t v, const uint32_t *&lo, const uint32_t *&hi) const {
         const uint64_t a = S->op_off[row], b = S->op_off[row + 1];
         const uint32_t *beg = (axis == 0 ? S->sub_begin.data() : S->qry_begin.data());
-        const uint32_t *first = beg + a, *last = beg + b;
+        const InvState::Buckets &B = S->buckets[axis];
+        lo = hi = beg + a;
+        if (a == b || v < B.base[row]) return;                               // nothing begins at or before v
+        const uint64_t nb = B.off[row + 1] - B.off[row] - 1;                 // buckets of the record (one more entry closes the last)
+        const uint64_t q = std::min<uint64_t>((uint64_t)(v - B.base[row]) >> B.shift[row], nb - 1);
+        const uint32_t *e = B.first.data() + B.off[row] + q;
+        lo = beg + a + e[0]; hi = beg + a + e[1];
+    }
+    // point lookup in one record's operation table; axis 0 = subject, 1 = query.  Returns op index or -1.
+    int64_t op_at(uint32_t row, int axis, int64_t pos) const {
+        const uint32_t *beg = (axis == 0 ? S->sub_begin.data() : S->qry_begin.data());
+        const uint32_t *first = beg + S->op_off[row];
         if (pos < 0) return -1;
-        // two levels: every 64th begin (1 MB for a haplotype, stays in the host caches) bounds the search in the 36 MB array to
-        // one 256-byte window - a lookup used to miss the cache at most of its ~20 probes (0.3 -> 1.6 ms per scan round
-        // between a warm and a cold host cache)
+        // two levels: a position bucket bounds the search in the 36 MB array to a few lines - a plain binary search missed the
+        // cache at most of its ~20 probes (0.3 -> 1.6 ms per scan round between a warm and a cold host cache), and so did the
+        // search of a sampled array in front of it, at the last-level cache
         const uint32_t v = (uint32_t)std::min<int64_t>(pos, 0xFFFFFFFFll);
-        const uint32_t *cs = S->coarse[axis].data();
-        const uint64_t ma = (a + 63) / 64, mb = (b + 63) / 64;               // samples at 64 m with a <= 64 m < b
-        const uint64_t mc = (uint64_t)(std::upper_bound(cs + ma, cs + mb, v) - cs);
-        const uint32_t *it = std::upper_bound(mc == ma ? first : beg + (mc - 1) * 64, mc == mb ? last : beg + mc * 64, v);
+        const uint32_t *wlo, *whi;
+        window(row, axis, v, wlo, whi);
+        const uint32_t *it = std::upper_bound(wlo, whi, v);
         if (it == first) return -1;
         const uint64_t k = (uint64_t)(it - beg) - 1;
         const uint32_t code = S->ops[k] & 15u, len = S->ops[k] >> 4;
@@ -195,7 +214,7 @@ public:
     bool lift_to_qry(int ref_id, int64_t pos, Lifted &out, std::string &err) const {
         out = Lifted();
         std::vector<uint32_t> hits;
-        if ((size_t)ref_id < S->by_ref.size()) containing(S->by_ref[(size_t)ref_id], S->by_ref_maxlen[(size_t)ref_id], true, pos, hits);
+        if ((size_t)ref_id < S->by_ref.size()) containing(S->by_ref[(size_t)ref_id], S->span_ref[(size_t)ref_id], pos, hits);
         if (hits.size() != 1) return true;
         const uint32_t row = hits[0];
         if (!check_row_ops(row, err)) return false;
@@ -241,7 +260,7 @@ public:
         out = Lifted();
         const int64_t pos_org = pos;
         std::vector<uint32_t> hits;
-        if ((size_t)tig_id < S->by_tig.size()) containing(S->by_tig[(size_t)tig_id], S->by_tig_maxlen[(size_t)tig_id], false, pos, hits);
+        if ((size_t)tig_id < S->by_tig.size()) containing(S->by_tig[(size_t)tig_id], S->span_tig[(size_t)tig_id], pos, hits);
         if (hits.size() == 0 && gap) { subject_gap(tig_id, pos, out); return true; }
         if (hits.size() != 1) return true;
         const uint32_t row = hits[0];
@@ -390,8 +409,26 @@ int pav_inv_load_alignments(pav_ctx *ctx, uint32_t n, const pav_inv_aln *aln, co
     if (n == 0) S->op_off.assign(1, 0);
     for (int axis = 0; axis < 2; ++axis) {
         const std::vector<uint32_t> &src = axis == 0 ? S->sub_begin : S->qry_begin;
-        S->coarse[axis].resize((size_t)(n_ops + 63) / 64 + 1);
-        for (uint64_t m = 0; m * 64 < n_ops; ++m) S->coarse[axis][m] = src[m * 64];
+        InvState::Buckets &B = S->buckets[axis];
+        B.first.clear(); B.off.assign((size_t)n + 1, 0); B.shift.assign(n, 0); B.base.assign(n, 0);
+        for (uint32_t r = 0; r < n; ++r) {
+            const uint64_t a = S->op_off[r], b = S->op_off[r + 1];
+            B.off[r] = B.first.size();
+            if (a == b) continue;
+            const uint32_t base = src[a];
+            const uint64_t span = (uint64_t)src[b - 1] - base + 1, want = (b - a + 15) / 16;
+            unsigned sh = 0;
+            while (((span - 1) >> sh) + 1 > want) ++sh;
+            const uint64_t nb = ((span - 1) >> sh) + 1;
+            B.shift[r] = (uint8_t)sh; B.base[r] = base;
+            uint64_t k = a;
+            for (uint64_t q = 0; q < nb; ++q) {                           // operations that begin before the bucket's first base
+                while (k < b && (uint64_t)(src[k] - base) < (q << sh)) ++k;
+                B.first.push_back((uint32_t)(k - a));
+            }
+            B.first.push_back((uint32_t)(b - a));
+        }
+        B.off[n] = B.first.size();
     }
     S->by_ref.assign(ctx->seq[PAV_ROLE_REF].n, {}); S->by_tig.assign(ctx->seq[PAV_ROLE_TIG].n, {});
     S->by_ref_maxlen.assign(ctx->seq[PAV_ROLE_REF].n, 0); S->by_tig_maxlen.assign(ctx->seq[PAV_ROLE_TIG].n, 0);
@@ -402,6 +439,22 @@ int pav_inv_load_alignments(pav_ctx *ctx, uint32_t n, const pav_inv_aln *aln, co
     }
     for (auto &v : S->by_ref) std::stable_sort(v.begin(), v.end(), [&](uint32_t a, uint32_t b) { return S->rows[a].pos < S->rows[b].pos; });
     for (auto &v : S->by_tig) std::stable_sort(v.begin(), v.end(), [&](uint32_t a, uint32_t b) { return S->rows[a].qry_pos < S->rows[b].qry_pos; });
+    for (int axis = 0; axis < 2; ++axis) {
+        const auto &by = axis == 0 ? S->by_ref : S->by_tig;
+        auto &spans = axis == 0 ? S->span_ref : S->span_tig;
+        spans.assign(by.size(), {});
+        for (size_t q = 0; q < by.size(); ++q) {
+            InvState::Spans &sp = spans[q];
+            int64_t run = INT64_MIN;
+            for (uint32_t r : by[q]) {
+                const LiftRow &x = S->rows[r];
+                sp.begin.push_back(axis == 0 ? x.pos : x.qry_pos);
+                sp.end.push_back(axis == 0 ? x.end : x.qry_end);
+                run = std::max(run, sp.end.back());
+                sp.max_end.push_back(run);
+            }
+        }
+    }
     S->row_checked.assign(n, 0);
     S->loaded = true;
     return PAV_OK;
@@ -419,6 +472,7 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
     S->results.assign(n_regions, pav_inv_result{});
     S->logs.assign(n_regions, std::string());
     S->errors.assign(n_regions, std::string());
+    S->found.assign(n_regions, std::string());
     // this scan fills the arena of the scan before the last one: only *its* copies must have landed (they have, long ago);
     // the copies of the last scan may still be travelling into the other arena
     std::swap(ctx->tables_done, ctx->tables_done_prev);
@@ -491,6 +545,29 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
         t_batch += now() - t0;
         if (rc != PAV_OK) return rc;
         const double t_q0 = now();
+        auto inv_bounds = [&](const Scan &sc, Rgn &t_outer, Rgn &t_inner) -> int {   // 0: bounds set; 1: no inverted state; 2: run too short (max_run in t_outer.pos)
+            const auto &rl = sc.state_rl;
+            bool any_inv = false; uint32_t max_run = 0;
+            const pav_run *inv_first = nullptr, *inv_last = nullptr;
+            for (const auto &x : rl) if (x.state == 2) { any_inv = true; max_run = std::max(max_run, x.count); if (!inv_first) inv_first = &x; inv_last = &x; }
+            if (!any_inv) return 1;
+            if (max_run < 100) { t_outer.pos = max_run; return 2; }               // MIN_INV_KMER_RUN
+            t_outer.role = t_inner.role = PAV_ROLE_TIG; t_outer.chrom = t_inner.chrom = sc.region_tig.chrom;
+            t_outer.is_rev = t_inner.is_rev = sc.region_tig.is_rev;
+            t_outer.pos = rl[1].pos + sc.region_tig.pos; t_outer.end = rl[rl.size() - 2].end + sc.region_tig.pos + k;
+            t_inner.pos = inv_first->pos + sc.region_tig.pos; t_inner.end = inv_last->end + sc.region_tig.pos + k;
+            if (t_outer.pos > t_outer.end) std::swap(t_outer.pos, t_outer.end);
+            if (t_inner.pos > t_inner.end) std::swap(t_inner.pos, t_inner.end);
+            return 0;
+        };
+        for (uint32_t j = 0; j < jobs.size(); ++j) {                               // the state runs of every job
+            Scan &sc = scans[owners[j]];
+            const pav_den_result &r = res[j];
+            sc.state_rl.clear();
+            if (r.status == PAV_DEN_FAIL || r.n_rows == 0) continue;
+            sc.state_rl.resize(r.n_runs);
+            if (r.n_runs) { rc = pav_density_runs(ctx, j, sc.state_rl.data()); if (rc != PAV_OK) return rc; }
+        }
         std::vector<uint32_t> next;
         std::vector<CallFetch> round_calls; std::vector<uint32_t> round_owner; std::vector<uint8_t> round_k1;   // round_k1: the call has FWDREV k-mers
         for (uint32_t j = 0; j < jobs.size(); ++j) {
@@ -512,32 +589,21 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
                 finish(i, PAV_INV_NONE); continue;
             }
             if (r.n_rows == 0) { log(i, "No informative reference k-mers in forward or reverse orientation in region"); finish(i, PAV_INV_NONE); continue; }
-            sc.state_rl.resize(r.n_runs);
-            if (r.n_runs) { rc = pav_density_runs(ctx, j, sc.state_rl.data()); if (rc != PAV_OK) return rc; }
             sc.n_rows = r.n_rows;
-            const auto &rl = sc.state_rl;
+            const auto &rl = sc.state_rl;                                            // fetched above
             if (rl.size() == 1 && (rl[0].state == 0 || rl[0].state == -1) && sc.expansion_count >= min_exp_count) {
                 log(i, "Found no inverted k-mer states after " + fmt_i(sc.expansion_count) + " expansion(s)");
                 finish(i, PAV_INV_NONE); continue;
             }
             if (rl.size() > 2 && rl.front().state == 0 && rl.back().state == 0) {
                 // ---- characterise, inv.py:353-454 ----------------------------------------------------------
-                bool any_inv = false; uint32_t max_run = 0;
-                for (const auto &x : rl) if (x.state == 2) { any_inv = true; max_run = std::max(max_run, x.count); }
-                if (!any_inv) { log(i, "No inverted states found"); finish(i, PAV_INV_NONE); continue; }
-                if (max_run < 100) {                                                 // MIN_INV_KMER_RUN
-                    log(i, "Longest run of strictly inverted k-mers (" + fmt_i(max_run) + ") does not meet the minimum threshold (100)");
+                Rgn t_outer, t_inner;
+                const int why = inv_bounds(sc, t_outer, t_inner);
+                if (why == 1) { log(i, "No inverted states found"); finish(i, PAV_INV_NONE); continue; }
+                if (why == 2) {
+                    log(i, "Longest run of strictly inverted k-mers (" + fmt_i(t_outer.pos) + ") does not meet the minimum threshold (100)");
                     finish(i, PAV_INV_NONE); continue;
                 }
-                const pav_run *inv_first = nullptr, *inv_last = nullptr;
-                for (const auto &x : rl) if (x.state == 2) { if (!inv_first) inv_first = &x; inv_last = &x; }
-                Rgn t_outer, t_inner;
-                t_outer.role = t_inner.role = PAV_ROLE_TIG; t_outer.chrom = t_inner.chrom = sc.region_tig.chrom;
-                t_outer.is_rev = t_inner.is_rev = sc.region_tig.is_rev;
-                t_outer.pos = rl[1].pos + sc.region_tig.pos; t_outer.end = rl[rl.size() - 2].end + sc.region_tig.pos + k;
-                t_inner.pos = inv_first->pos + sc.region_tig.pos; t_inner.end = inv_last->end + sc.region_tig.pos + k;
-                if (t_outer.pos > t_outer.end) std::swap(t_outer.pos, t_outer.end);
-                if (t_inner.pos > t_inner.end) std::swap(t_inner.pos, t_inner.end);
                 Rgn r_outer, r_inner; bool ok = false; std::string err;
                 if (!D.region_to_sub(t_outer, false, r_outer, ok, err)) { S->errors[i] = err; finish(i, PAV_INV_ERROR); continue; }
                 if (!ok) { log(i, "Failed lifting outer INV region to reference: " + D.base1(t_outer)); finish(i, PAV_INV_NONE); continue; }
@@ -547,7 +613,9 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
                 pav_inv_result &out = S->results[i];
                 set_rgn(out.tig_outer, t_outer); set_rgn(out.tig_inner, t_inner); set_rgn(out.ref_outer, r_outer); set_rgn(out.ref_inner, r_inner);
                 set_rgn(out.ref_discovery, sc.region_ref); set_rgn(out.tig_discovery, sc.region_tig);
-                out.found = 1;                                                      // 'INV Found:' is printed by the caller (inv.py:408)
+                out.found = 1;                                                      // the caller prints the line (inv.py:408)
+                S->found[i] = "INV Found: outer=" + D.base1(t_outer) + ", inner=" + D.base1(t_inner) + " (ref outer=" + D.base1(r_outer) +
+                              ", inner=" + D.base1(r_inner) + ")\n";
                 if ((double)r_outer.len() < (double)t_outer.len() * 0.6) {
                     log(i, "Reference region too short: Reference region length (" + fmt_commas(r_outer.len()) + ") is not within " + fmt_f2(60.0) +
                            "% of the contig region length (" + fmt_commas(t_outer.len()) + ")");
@@ -642,14 +710,16 @@ int pav_inv_text(pav_ctx *ctx, uint32_t region, int what, char *buf, uint32_t bu
 }
 
 int pav_inv_texts(pav_ctx *ctx, int what, char *buf, uint64_t buf_len, uint64_t *off) {
-    if (!ctx || !off || (what != 0 && what != 1)) return PAV_E_ARG;
+    if (!ctx || !off || what < 0 || what > 2) return PAV_E_ARG;
     InvState *S = istate(ctx);
-    const std::vector<std::string> &src = what == 0 ? S->logs : S->errors;
+    const std::vector<std::string> &src = what == 0 ? S->logs : what == 1 ? S->errors : S->found;
     uint64_t at = 0;
     for (size_t i = 0; i < src.size(); ++i) {
         off[i] = at;
-        if (at + src[i].size() > buf_len || (src[i].size() && !buf)) return fail(ctx, PAV_E_ARG, "pav_inv_texts: buffer too small");
-        if (!src[i].empty()) memcpy(buf + at, src[i].data(), src[i].size());
+        if (buf) {                                                       // no buffer: only the offsets (the sizes) are wanted
+            if (at + src[i].size() > buf_len) return fail(ctx, PAV_E_ARG, "pav_inv_texts: buffer too small");
+            if (!src[i].empty()) memcpy(buf + at, src[i].data(), src[i].size());
+        }
         at += src[i].size();
     }
     off[src.size()] = at;

@@ -71,37 +71,54 @@ class InvCall:
         return self.id
 
 
+class _NativeBatch:
+    """What the calls of one native scan share: the result records of the regions with something to report (columns as
+    plain lists), the record names, the flagged regions, and where the density tables live."""
+
+    def __init__(self, sub, hit, names, region_flags, table_of):
+        self.sub, self.hit, self.names, self.region_flags, self.table_of = sub, hit, names, region_flags, table_of
+        ro = sub['ref_outer']
+        self.ro_seq, self.ro_pos, self.ro_end = ro['seq_id'].tolist(), ro['pos'].tolist(), ro['end'].tolist()
+
+
 class _NativeInvCall(InvCall):
-    """InvCall made by the native driver: ``id`` / ``svlen`` are set at once, the six regions are decoded from the driver's
-    result record on first access (a batch of a thousand regions yields a hundred calls with six regions each; building
-    them eagerly was most of the Python time of a scan)."""
+    """InvCall made by the native driver.  Everything is decoded from the driver's result record on first access (a batch of
+    a thousand regions yields a hundred calls with six regions each; building them eagerly was most of the Python time of a
+    scan): the object starts as (batch, row in the batch, region number)."""
 
     _FIELDS = {'region_ref_outer': ('ref_outer', 0, False), 'region_ref_inner': ('ref_inner', 0, False),
                'region_tig_outer': ('tig_outer', 1, True), 'region_tig_inner': ('tig_inner', 1, True),
                'region_ref_discovery': ('ref_discovery', 0, False), 'region_tig_discovery': ('tig_discovery', 1, True)}
 
-    def __init__(self, record, names, region_flag, df):     # noqa: super().__init__ not called: the regions stay lazy
-        self._record, self._names = record, names
-        self.region_flag = region_flag
-        self._df = df
-        self.native_table = None
-        ro = record['ref_outer']
-        self.n_near_tie, self.n_unresolved = int(record['n_near_tie']), int(record['n_unresolved'])   # near-tie guard (pav_amd.h)
-        self.svlen = int(ro['end']) - int(ro['pos'])
-        self.id = '{}-{}-INV-{}'.format(names[0][int(ro['seq_id'])], int(ro['pos']) + 1, self.svlen)
+    def __init__(self, batch, q, i):     # noqa: super().__init__ not called: the attributes stay lazy
+        self._batch, self._q, self._i = batch, q, i
 
     def __getattr__(self, name):                             # reached only while the attribute has not been built yet
-        spec = _NativeInvCall._FIELDS.get(name)
-        if spec is None:
+        if name in ('_batch', '_q', '_i'):
             raise AttributeError(name)
-        g = self._record[spec[0]]
-        n_aln, aln = g['n_aln'].tolist(), g['aln_index'].tolist()
-        region = seq.Region(self._names[spec[1]][int(g['seq_id'])], int(g['pos']), int(g['end']),
-                            is_rev=bool(g['is_rev']) if spec[2] else False,
-                            pos_aln_index=(tuple(aln[0][:n_aln[0]]),) if n_aln[0] else None,
-                            end_aln_index=(tuple(aln[1][:n_aln[1]]),) if n_aln[1] else None)
-        setattr(self, name, region)
-        return region
+        b, q = self._batch, self._q
+        spec = _NativeInvCall._FIELDS.get(name)
+        if spec is not None:
+            g = b.sub[q][spec[0]]
+            n_aln, aln = g['n_aln'].tolist(), g['aln_index'].tolist()
+            value = seq.Region(b.names[spec[1]][int(g['seq_id'])], int(g['pos']), int(g['end']),
+                               is_rev=bool(g['is_rev']) if spec[2] else False,
+                               pos_aln_index=(tuple(aln[0][:n_aln[0]]),) if n_aln[0] else None,
+                               end_aln_index=(tuple(aln[1][:n_aln[1]]),) if n_aln[1] else None)
+        elif name == 'svlen':
+            value = b.ro_end[q] - b.ro_pos[q]
+        elif name == 'id':
+            value = '{}-{}-INV-{}'.format(b.names[0][b.ro_seq[q]], b.ro_pos[q] + 1, b.ro_end[q] - b.ro_pos[q])
+        elif name == 'region_flag':
+            value = b.region_flags[self._i]
+        elif name in ('n_near_tie', 'n_unresolved'):                                  # near-tie guard (pav_amd.h)
+            value = int(b.sub[q][name])
+        elif name in ('_df', 'native_table'):
+            value = b.table_of(self._i)[0 if name == '_df' else 1]
+        else:
+            raise AttributeError(name)
+        setattr(self, name, value)
+        return value
 
 
 class _Interval:
@@ -550,40 +567,30 @@ def _native_scan(ctx, region_flags, align_lift, k_util, max_region_size, logs, s
     errors = ctx.inv_texts(1, n_rgn, int(resv['error_bytes'].sum(dtype=np.int64))) if (outcome == _lib.INV_ERROR).any() else None
     out = [None] * n_rgn
     hit = np.flatnonzero((found != 0) | (outcome != _lib.INV_NONE))
-    sub = resv[hit]                                                   # the few regions with something to report, as plain lists
-
+    sub = resv[hit]                                                   # the few regions with something to report
     names = (ref_names, tig_names)
 
-    def base1(field, which):                                           # Region.to_base1_string of one result field, all hits
-        g = sub[field]
-        nm = names[which]
-        return ['{}:{}-{}'.format(nm[c], p + 1, e) for c, p, e in zip(g['seq_id'].tolist(), g['pos'].tolist(), g['end'].tolist())]
-
-    sub_found, sub_outcome = sub['found'].tolist(), sub['outcome'].tolist()
-    found_lines = []
-    if any(sub_found):
-        t_out, t_in, r_out, r_in = base1('tig_outer', 1), base1('tig_inner', 1), base1('ref_outer', 0), base1('ref_inner', 0)
+    if eager_tables:
+        def table_of(i):
+            sl = slice(int(row_off[i]), int(row_off[i + 1]))
+            cols = {name: arr[sl] for name, arr in all_cols.items()}
+            flank, match = all_flank[sl], all_match[sl]
+            return (lambda: density.table_frame(cols, finalised=True, extra=_flank_match_text(flank, match))), (ctx, i, generation)
+    else:
+        def table_of(i):                        # views of the library's pinned host copy; valid until the next scan
+            def df():
+                cols, flank, match = ctx.inv_table_view(i, generation)
+                return density.table_frame(cols, finalised=True, extra=_flank_match_text(flank.copy(), match.copy()))
+            return df, (ctx, i, generation)     # native_table: the library's host copy, Context.inv_write_tables writes it as text
+    batch = _NativeBatch(sub, hit, names, region_flags, table_of)
+    sub_outcome = sub['outcome'].tolist()
     for q, i in enumerate(hit.tolist()):
-        if sub_found[q]:
-            found_lines.append('INV Found: outer={}, inner={} (ref outer={}, inner={})'.format(t_out[q], t_in[q], r_out[q], r_in[q]))
         if sub_outcome[q] == _lib.INV_ERROR:
             out[i] = RuntimeError(errors[i])
         elif sub_outcome[q] == _lib.INV_CALL:
-            if eager_tables:
-                sl = slice(int(row_off[i]), int(row_off[i + 1]))
-                cols = {name: arr[sl] for name, arr in all_cols.items()}
-                flank, match = all_flank[sl], all_match[sl]
-
-                def df(cols=cols, flank=flank, match=match):
-                    return density.table_frame(cols, finalised=True, extra=_flank_match_text(flank, match))
-            else:
-                def df(i=i):                    # views of the library's pinned host copy; valid until the next scan
-                    cols, flank, match = ctx.inv_table_view(i, generation)
-                    return density.table_frame(cols, finalised=True, extra=_flank_match_text(flank.copy(), match.copy()))
-            out[i] = _NativeInvCall(sub[q], names, region_flags[i], df)
-            out[i].native_table = (ctx, i, generation)   # the library's host copy: Context.inv_write_tables writes it as text
-    if found_lines:
-        print('\n'.join(found_lines), file=found_out)                   # inv.py:408, one line per region in region order
+            out[i] = _NativeInvCall(batch, q, i)
+    if found.any():                                                    # inv.py:408, one line per region in region order
+        print(ctx.inv_texts(2, n_rgn, joined=True)[0], end='', file=found_out)
     _lap('results')
     return out
 
