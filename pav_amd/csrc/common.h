@@ -23,8 +23,10 @@ constexpr uint64_t SEQ_ALIGN = 256;      // every record starts on a 256-base bo
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    bool view = false;                    // p points into another buffer's allocation (alias): never freed from here
     hipError_t reserve(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
+        if (view) { p = nullptr; cap = 0; view = false; }                     // outgrown: from here on an allocation of its own
         if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
         size_t want = bytes + bytes / 8 + 256;
         hipError_t e = hipMalloc(&p, want);
@@ -32,7 +34,13 @@ struct DevBuf {
         cap = want;
         return hipSuccess;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    // Make this buffer `bytes` of another allocation (several small buffers laid out in one arena travel in one copy and are
+    // cleared by one fill).  An allocation of its own is given up.
+    void alias(void *q, size_t bytes) {
+        if (p && !view) (void)hipFree(p);
+        p = q; cap = bytes; view = true;
+    }
+    void release() { if (p && !view) (void)hipFree(p); p = nullptr; cap = 0; view = false; }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 

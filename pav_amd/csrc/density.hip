@@ -84,6 +84,21 @@ struct DensityState {
     DevBuf tiles, events, ev_count, scratch, run_arena, win_fill, ks[3], ss;
     DevBuf guard, guard_entries, samp_flag, row_flag, ftiles; // near-tie guard; evaluation tiles of the fill list
     DevBuf tile_heads, tile_head_cnt, heads, plan_flags, pow_tab;   // device-planned batches (k_plan)
+    // The small per-batch buffers are slices of two arenas: what the host sends (jobs, tile -> job maps, partition items, KDE
+    // descriptors, evaluation tiles) travels in ONE copy out of a pinned staging block; what the kernels count into (event
+    // count, guard, plan flags, statistics, event list, bucket counts, guard flags) is cleared by two fills and its front
+    // comes back in ONE copy.  (Separate pageable copies and fills cost ~10 us each with the stream idle in between: a dozen per
+    // scan round.)
+    DevBuf in_arena, zero_arena;
+    void *pin_in = nullptr; size_t pin_in_cap = 0;
+    void *pinned_in(size_t bytes) {
+        if (bytes <= pin_in_cap) return pin_in;
+        if (pin_in) (void)hipHostFree(pin_in);
+        pin_in = nullptr; pin_in_cap = 0;
+        if (hipHostMalloc(&pin_in, bytes + bytes / 2 + 4096, hipHostMallocDefault) != hipSuccess) { pin_in = nullptr; return nullptr; }
+        pin_in_cap = bytes + bytes / 2 + 4096;
+        return pin_in;
+    }
     std::vector<double> h_pow;                                // pow(n, -1/5), n = 0 .. size - 1 (libm, computed once and extended)
     uint64_t n_fast = 0, n_fallback = 0;                      // batches planned on the device / sent back to the host-planned path
     std::vector<JobDev> h_jobs;
@@ -108,9 +123,11 @@ struct DensityState {
         DevBuf *all[] = {&jobs, &stat, &kde, &tile_job_r, &tile_job_t, &keys, &cnt, &keys_x, &cnt_x, &lists, &bcount, &ans_f, &ans_c, &items, &st_tmp, &tile_sum, &tile_pre,
                          &index, &state_mer, &state, &kmer, &kern[0], &kern[1], &kern[2], &list[0], &list[1], &list[2],
                          &pscaled[0], &pscaled[1], &pscaled[2], &fill_list, &tiles, &events, &ev_count, &scratch, &run_arena, &win_fill, &ks[0], &ks[1], &ks[2], &ss,
-                         &guard, &guard_entries, &samp_flag, &row_flag, &ftiles, &tile_heads, &tile_head_cnt, &heads, &plan_flags, &pow_tab};
+                         &guard, &guard_entries, &samp_flag, &row_flag, &ftiles, &tile_heads, &tile_head_cnt, &heads, &plan_flags, &pow_tab,
+                         &in_arena, &zero_arena};
         for (DevBuf *b : all) b->release();
         if (pin) { (void)hipHostFree(pin); pin = nullptr; pin_cap = 0; }
+        if (pin_in) { (void)hipHostFree(pin_in); pin_in = nullptr; pin_in_cap = 0; }
         if (gathered) { (void)hipEventDestroy(gathered); gathered = nullptr; }
     }
 };
@@ -1866,20 +1883,60 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             for (uint32_t p = 0; p < D->h_jobs[j].n_parts; ++p) items.push_back(PartItem{j, p});
     }
 
-    PAV_HIP(ctx, D->jobs.reserve(sizeof(JobDev) * n_jobs));
-    PAV_HIP(ctx, D->stat.reserve(sizeof(JobStat) * n_jobs));
-    PAV_HIP(ctx, D->kde.reserve(sizeof(JobKde) * n_jobs));
-    PAV_HIP(ctx, D->tile_job_r.reserve(4ull * n_tiles_r));
-    PAV_HIP(ctx, D->tile_job_t.reserve(4ull * n_tiles_t));
+    // ---- what is known before anything runs (device-planned batches: upper bounds; rows <= contig positions of the region) -----
+    const bool want_runs = pp->kde_mode != PAV_KDE_DIRECT;
+    bool fast = want_runs && n_hbm_jobs == 0 && !items.empty() && getenv("PAV_DENSITY_HOST") == nullptr;
+    D->h_kde.assign(n_jobs, JobKde{});
+    std::vector<EvalTile> tiles_ub;
+    uint64_t samp_ub = 0;
+    for (uint32_t j = 0; j < n_jobs; ++j) {
+        JobKde &kd = D->h_kde[j];
+        const JobDev &jd = D->h_jobs[j];
+        kd.srs = jd.srs;
+        kd.samp_off = (uint32_t)samp_ub;
+        kd.heads_off = jd.first_tile * HEADS_PER_TILE;
+        const uint32_t ns = (std::max<uint32_t>(jd.tig_len, 1) + jd.srs - 1) / jd.srs + 1;
+        samp_ub += ns;
+        if (fast) for (uint32_t f = 0; f < ns; f += 64) tiles_ub.push_back(EvalTile{j, f, 64u, 0u});
+    }
+    if (samp_ub > 0xFFFFFFFFull) { fast = false; tiles_ub.clear(); }
+    // the event list as large as either path asks for (prepare_events)
+    uint32_t ev_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(65536, (a_t + 16ull * n_tiles_t) / 16 + 4ull * n_jobs), 0x7FFFFFFF);
+
+    // ---- the two arenas of small buffers ------------------------------------------------------------------------------------
+    struct Slice { DevBuf *buf; const void *src; size_t bytes, at; };
+    auto lay = [](std::vector<Slice> &v, size_t at0) { size_t at = at0; for (Slice &x : v) { x.at = at; at += (x.bytes + 255) / 256 * 256; } return at; };
+    std::vector<Slice> in_sl = {{&D->jobs, D->h_jobs.data(), sizeof(JobDev) * n_jobs, 0}, {&D->tile_job_r, tile_job_r.data(), 4ull * n_tiles_r, 0},
+                                {&D->tile_job_t, tile_job_t.data(), 4ull * n_tiles_t, 0}, {&D->items, items.data(), sizeof(PartItem) * items.size(), 0},
+                                {&D->kde, fast ? D->h_kde.data() : nullptr, sizeof(JobKde) * n_jobs, 0},
+                                {&D->tiles, tiles_ub.data(), sizeof(EvalTile) * tiles_ub.size(), 0}};
+    const size_t in_bytes = lay(in_sl, 0);
+    // front of the zero arena = what comes back: event count (64) | guard (64) | plan flags (64) | statistics | event list
+    constexpr size_t ZH = 192;
+    std::vector<Slice> z_sl = {{&D->stat, nullptr, sizeof(JobStat) * n_jobs, 0}, {&D->events, nullptr, sizeof(HeadEvent) * (size_t)ev_cap, 0},
+                               {&D->bcount, nullptr, 4 * n_bcount, 0}, {&D->samp_flag, nullptr, 4 * (samp_ub + 2), 0}, {&D->row_flag, nullptr, a_t, 0}};
+    const size_t z_bytes = lay(z_sl, ZH);
+    PAV_HIP(ctx, D->in_arena.reserve(in_bytes + 256));
+    PAV_HIP(ctx, D->zero_arena.reserve(z_bytes + 256));
+    uint8_t *h_in = static_cast<uint8_t *>(D->pinned_in(in_bytes + 256));
+    if (!h_in) return fail(ctx, PAV_E_HIP, "pav_density_batch: cannot pin host memory for the batch descriptors");
+    for (const Slice &x : in_sl) {
+        x.buf->alias(D->in_arena.as<uint8_t>() + x.at, (x.bytes + 255) / 256 * 256);
+        if (x.src && x.bytes) memcpy(h_in + x.at, x.src, x.bytes);
+    }
+    for (const Slice &x : z_sl) x.buf->alias(D->zero_arena.as<uint8_t>() + x.at, (x.bytes + 255) / 256 * 256);
+    D->ev_count.alias(D->zero_arena.as<uint8_t>(), 64);
+    D->guard.alias(D->zero_arena.as<uint8_t>() + 64, 64);
+    D->plan_flags.alias(D->zero_arena.as<uint8_t>() + 128, 64);
+    static_assert(sizeof(GuardDev) <= 64, "the guard block has 64 bytes in the zero arena");
+
     PAV_HIP(ctx, D->keys.reserve(8 * a_h));
     PAV_HIP(ctx, D->cnt.reserve(4 * a_h));
     if (!items.empty()) {
         if (n_bcount > 0xFFFFFFFFull) return fail(ctx, PAV_E_LIMIT, "pav_density_batch: too many k-mer partitions in one batch");
         PAV_HIP(ctx, D->lists.reserve(4 * n_lists));
-        PAV_HIP(ctx, D->bcount.reserve(4 * n_bcount));
         PAV_HIP(ctx, D->ans_f.reserve(a_t));
         PAV_HIP(ctx, D->ans_c.reserve(a_t));
-        PAV_HIP(ctx, D->items.reserve(sizeof(PartItem) * items.size()));
     }
     PAV_HIP(ctx, D->st_tmp.reserve(a_t + 64));
     PAV_HIP(ctx, D->tile_sum.reserve(16ull * n_tiles_t));
@@ -1897,17 +1954,12 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     }
     hipStream_t st = ctx->stream;
     lap("plan+alloc");
-    PAV_HIP(ctx, hipMemcpyAsync(D->jobs.p, D->h_jobs.data(), sizeof(JobDev) * n_jobs, hipMemcpyHostToDevice, st));
-    PAV_HIP(ctx, hipMemcpyAsync(D->tile_job_r.p, tile_job_r.data(), 4ull * n_tiles_r, hipMemcpyHostToDevice, st));
-    PAV_HIP(ctx, hipMemcpyAsync(D->tile_job_t.p, tile_job_t.data(), 4ull * n_tiles_t, hipMemcpyHostToDevice, st));
-    PAV_HIP(ctx, hipMemsetAsync(D->stat.p, 0, sizeof(JobStat) * n_jobs, st));
+    PAV_HIP(ctx, hipMemcpyAsync(D->in_arena.p, h_in, in_bytes, hipMemcpyHostToDevice, st));
+    PAV_HIP(ctx, hipMemsetAsync(D->zero_arena.p, 0, z_sl[1].at, st));                                  // event count .. statistics
+    PAV_HIP(ctx, hipMemsetAsync(D->zero_arena.as<uint8_t>() + z_sl[2].at, 0, z_bytes - z_sl[2].at, st));   // bucket counts, guard flags
     if (a_h) {
         PAV_HIP(ctx, hipMemsetAsync(D->keys.p, 0xFF, 8 * a_h, st));
         PAV_HIP(ctx, hipMemsetAsync(D->cnt.p, 0, 4 * a_h, st));
-    }
-    if (!items.empty()) {
-        PAV_HIP(ctx, hipMemcpyAsync(D->items.p, items.data(), sizeof(PartItem) * items.size(), hipMemcpyHostToDevice, st));
-        PAV_HIP(ctx, hipMemsetAsync(D->bcount.p, 0, 4 * n_bcount, st));
     }
 
     const JobDev *d_jobs = D->jobs.as<JobDev>();
@@ -1956,7 +2008,9 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     // pinned readback area: [event count | first events] [per-job statistics] [guard counters]
     const size_t pin_stat_off = (sizeof(HeadEvent) * (size_t)EV_PREFETCH + 64 + 63) / 64 * 64;
     const size_t pin_guard_off = pin_stat_off + (sizeof(JobStat) * (size_t)n_jobs + 63) / 64 * 64;
-    uint8_t *h_pin = static_cast<uint8_t *>(D->pinned(pin_guard_off + 64));
+    // (the device-planned path reads the front of the zero arena into the same block)
+    const uint32_t ev_first = std::min<uint32_t>(ev_cap, std::max<uint32_t>(4096u, 4u * n_jobs));   // run heads that come back with their count
+    uint8_t *h_pin = static_cast<uint8_t *>(D->pinned(std::max(pin_guard_off, z_sl[1].at + sizeof(HeadEvent) * (size_t)ev_first) + 64));
     if (!h_pin) return fail(ctx, PAV_E_HIP, "pav_density_batch: cannot pin host memory for the readbacks");
     auto queue_stats = [&]() -> int {                                  // in front of a synchronisation that follows
         PAV_HIP(ctx, hipMemcpyAsync(h_pin + pin_stat_off, d_stat, sizeof(JobStat) * n_jobs, hipMemcpyDeviceToHost, st));
@@ -1972,12 +2026,11 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     };
     // Run heads of a per-row state array: events sorted by (job, row).  The kernels that produce the arrays write the events
     // themselves (STATE_MER: k_compact_scatter, STATE: k_finalize); k_heads only repeats the work when the event buffer was too small.
-    uint32_t ev_cap = 0;
-    auto prepare_events = [&](uint64_t hint) -> int {
+    auto prepare_events = [&](uint64_t hint, bool cleared = false) -> int {     // cleared: the count is zero already (the batch's fill)
         ev_cap = std::max(ev_cap, (uint32_t)std::min<uint64_t>(std::max<uint64_t>(65536, hint / 16 + 4ull * n_jobs), 0x7FFFFFFF));
         PAV_HIP(ctx, D->events.reserve(sizeof(HeadEvent) * (size_t)ev_cap));
         PAV_HIP(ctx, D->ev_count.reserve(16));
-        PAV_HIP(ctx, hipMemsetAsync(D->ev_count.p, 0, 4, st));
+        if (!cleared) PAV_HIP(ctx, hipMemsetAsync(D->ev_count.p, 0, 4, st));
         return PAV_OK;
     };
     auto launch_heads = [&](const int8_t *d_state) -> int {
@@ -2022,7 +2075,6 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     };
     // compaction to the informative rows, then readback 1: per-job counts and moments -> status, bandwidths (host, libm:
     // same arithmetic as scipy)
-    const bool want_runs = pp->kde_mode != PAV_KDE_DIRECT;
     std::vector<HeadEvent> mev;                                        // run heads of STATE_MER (closed-form run sums)
     auto compact_and_read = [&]() -> int {
         CA.events = nullptr; CA.ev_cap = 0; CA.ev_count = nullptr;
@@ -2048,8 +2100,6 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     // batches whose k-mer sets all live in LDS; whatever it cannot finish - a partition overflow or a count above the limit
     // (HBM tables), a near-tie the guard wants re-evaluated, more STATE_MER changes in one tile than its slots hold - sends
     // the whole batch through the host-planned path below, which is the same arithmetic with every rare path in it.
-    const uint64_t t_rows_before = 0; (void)t_rows_before;
-    bool fast = want_runs && n_hbm_jobs == 0 && !items.empty() && getenv("PAV_DENSITY_HOST") == nullptr;
     if (fast) {
         uint32_t max_len = 0;
         for (uint32_t j = 0; j < n_jobs; ++j) max_len = std::max(max_len, D->h_jobs[j].tig_len);
@@ -2061,29 +2111,12 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             PAV_HIP(ctx, D->pow_tab.reserve(sizeof(double) * new_n));
             PAV_HIP(ctx, hipMemcpyAsync(D->pow_tab.p, D->h_pow.data(), sizeof(double) * new_n, hipMemcpyHostToDevice, st));
         }
-        // upper bounds known before anything runs: rows <= contig positions of the region
-        D->h_kde.assign(n_jobs, JobKde{});
-        std::vector<EvalTile> tiles_ub;
-        uint64_t samp_ub = 0;
-        for (uint32_t j = 0; j < n_jobs; ++j) {
-            JobKde &kd = D->h_kde[j];
-            const JobDev &jd = D->h_jobs[j];
-            kd.srs = jd.srs;
-            kd.samp_off = (uint32_t)samp_ub;
-            kd.heads_off = jd.first_tile * HEADS_PER_TILE;
-            const uint32_t ns = (std::max<uint32_t>(jd.tig_len, 1) + jd.srs - 1) / jd.srs + 1;
-            samp_ub += ns;
-            for (uint32_t f = 0; f < ns; f += 64) tiles_ub.push_back(EvalTile{j, f, 64u, 0u});
-        }
-        if (samp_ub > 0xFFFFFFFFull) fast = false;
-        if (fast) {
+        {
             const size_t ft_cap = (size_t)(a_t / 64 + n_jobs + 1);
             PAV_HIP(ctx, D->tile_heads.reserve(4ull * HEADS_PER_TILE * n_tiles_t));
             PAV_HIP(ctx, D->tile_head_cnt.reserve(4ull * n_tiles_t));
             PAV_HIP(ctx, D->heads.reserve(sizeof(RunDev) * ((size_t)HEADS_PER_TILE * n_tiles_t + 1)));
-            PAV_HIP(ctx, D->plan_flags.reserve(16));
             PAV_HIP(ctx, D->ftiles.reserve(sizeof(EvalTile) * ft_cap));
-            PAV_HIP(ctx, D->tiles.reserve(sizeof(EvalTile) * tiles_ub.size()));
             for (int q = 0; q < 3; ++q) PAV_HIP(ctx, D->ks[q].reserve(8 * (samp_ub + 1)));
             PAV_HIP(ctx, D->ss.reserve(samp_ub + 1));
             PAV_HIP(ctx, D->scratch.reserve(4ull * (a_t / 256 + 1)));
@@ -2092,20 +2125,11 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             G.unres = GUARD_UNRESOLVED;
             G.cap = pp->guard_cap ? pp->guard_cap : GUARD_CAP_DEFAULT;
             G.stat = d_stat;
-            if (G.rel > 0.0) {
-                PAV_HIP(ctx, D->guard.reserve(sizeof(GuardDev)));
+            if (G.rel > 0.0) {                                           // guard block and flags: slices of the zero arena, cleared
                 PAV_HIP(ctx, D->guard_entries.reserve(8ull * G.cap));
-                PAV_HIP(ctx, D->samp_flag.reserve(4 * (samp_ub + 2)));
-                PAV_HIP(ctx, D->row_flag.reserve(a_t));
                 G.g = D->guard.as<GuardDev>(); G.entries = D->guard_entries.as<unsigned long long>();
                 G.samp_flag = D->samp_flag.as<uint32_t>(); G.row_flag = D->row_flag.as<uint8_t>();
-                PAV_HIP(ctx, hipMemsetAsync(G.g, 0, sizeof(GuardDev), st));
-                PAV_HIP(ctx, hipMemsetAsync(G.samp_flag, 0, 4 * (samp_ub + 2), st));
-                PAV_HIP(ctx, hipMemsetAsync(G.row_flag, 0, a_t, st));
             }
-            PAV_HIP(ctx, hipMemsetAsync(D->plan_flags.p, 0, 16, st));
-            PAV_HIP(ctx, hipMemcpyAsync(D->kde.p, D->h_kde.data(), sizeof(JobKde) * n_jobs, hipMemcpyHostToDevice, st));
-            PAV_HIP(ctx, hipMemcpyAsync(D->tiles.p, tiles_ub.data(), sizeof(EvalTile) * tiles_ub.size(), hipMemcpyHostToDevice, st));
             CA.tile_heads = D->tile_heads.as<uint32_t>(); CA.tile_head_cnt = D->tile_head_cnt.as<uint32_t>();
             PAV_LAUNCH(ctx, "k_scan_tiles_keep", k_scan_tiles_keep, 4, 256, 0, D->tile_sum.as<uint32_t>(), d_tjt, d_stat, pp->min_state_count,
                        D->tile_pre.as<unsigned long long>(), n_tiles_t);
@@ -2141,7 +2165,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             PAV_LAUNCH(ctx, "k_plan_fill", k_plan_fill, 1, 1024, 0, FP);
             KA.tiles = D->ftiles.as<EvalTile>(); KA.n_tiles = 0; KA.n_tiles_dev = FP.n_ftiles; KA.dyn = 0;
             PAV_LAUNCH(ctx, "k_kde_eval", k_kde_eval, (uint32_t)std::min<size_t>(ft_cap, 8192), 64 * KDE_WAVES, 0, KA);
-            { const int rce = prepare_events(a_t); if (rce != PAV_OK) return rce; }
+            { const int rce = prepare_events(a_t, true); if (rce != PAV_OK) return rce; }
             FinArgs FA;
             FA.jobs = d_jobs; FA.tile_job = d_tjt; FA.kde = d_kde; FA.stat = d_stat; FA.win_fill = D->win_fill.as<uint8_t>();
             FA.state = D->state.as<int8_t>(); FA.index = D->index.as<uint32_t>();
@@ -2152,22 +2176,32 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             if (G.rel > 0.0)
                 PAV_LAUNCH(ctx, "k_spike_sum", k_spike_sum, n_jobs, 256, 0, d_jobs, d_kde, D->scratch.as<uint32_t>(), d_stat);
             lap("enqueue");
-            // the one readback: guard counters, plan flags, statistics, run heads of STATE
-            uint8_t *h_guard_pin = h_pin + pin_guard_off;
-            if (G.g) PAV_HIP(ctx, hipMemcpyAsync(h_guard_pin, G.g, sizeof(GuardDev), hipMemcpyDeviceToHost, st));
-            PAV_HIP(ctx, hipMemcpyAsync(h_guard_pin + 32, D->plan_flags.p, 16, hipMemcpyDeviceToHost, st));
-            { const int rcq = queue_stats(); if (rcq != PAV_OK) return rcq; }
-            std::vector<HeadEvent> ev;
-            { const int rch = read_events(D->state.as<int8_t>(), ev); if (rch != PAV_OK) return rch; }
-            take_stats();
+            // the one readback: the front of the zero arena - event count, guard counters, plan flags, statistics, run heads of STATE
+            const uint32_t pre = ev_first;
+            const size_t rb_events = z_sl[1].at, rb_bytes = rb_events + sizeof(HeadEvent) * (size_t)pre;
+            uint8_t *h_rb = h_pin;
+            PAV_HIP(ctx, hipMemcpyAsync(h_rb, D->zero_arena.p, rb_bytes, hipMemcpyDeviceToHost, st));
+            PAV_HIP(ctx, hipStreamSynchronize(st));
             lap("device plan");
             if (timing) fprintf(stderr, "[pav timing]   device-planned batches so far: %llu, sent back to the host-planned path: %llu\n",
                                 (unsigned long long)D->n_fast + 1, (unsigned long long)D->n_fallback);
+            uint32_t n_ev = 0;
             GuardDev h_guard{};
             uint32_t h_flags[4] = {0, 0, 0, 0};
-            if (G.g) memcpy(&h_guard, h_guard_pin, sizeof h_guard);
-            memcpy(h_flags, h_guard_pin + 32, sizeof h_flags);
-            bool redo = h_flags[0] != 0 || h_guard.n_entries != 0 || h_guard.overflow != 0 || h_flags[1] >= FP.cap;
+            memcpy(&n_ev, h_rb, 4);
+            if (G.g) memcpy(&h_guard, h_rb + 64, sizeof h_guard);
+            memcpy(h_flags, h_rb + 128, sizeof h_flags);
+            memcpy(hs.data(), h_rb + z_sl[0].at, sizeof(JobStat) * n_jobs);
+            std::vector<HeadEvent> ev;
+            const bool ev_lost = n_ev > ev_cap;                                  // more run heads than the list holds: the other path
+            if (!ev_lost) {
+                ev.resize(n_ev);
+                if (n_ev) memcpy(ev.data(), h_rb + rb_events, sizeof(HeadEvent) * std::min(n_ev, pre));
+                if (n_ev > pre)
+                    PAV_HIP(ctx, hipMemcpy(ev.data() + pre, D->events.as<HeadEvent>() + pre, sizeof(HeadEvent) * (n_ev - pre), hipMemcpyDeviceToHost));
+                std::sort(ev.begin(), ev.end(), [](const HeadEvent &x, const HeadEvent &y) { return x.job != y.job ? x.job < y.job : x.row < y.row; });
+            }
+            bool redo = ev_lost || h_flags[0] != 0 || h_guard.n_entries != 0 || h_guard.overflow != 0 || h_flags[1] >= FP.cap;
             for (uint32_t j = 0; j < n_jobs && !redo; ++j) redo = hs[j].lds_flags != 0;
             if (!redo) {
                 D->n_fast += 1;

@@ -465,6 +465,7 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
     if (!ctx || !pp || (n_regions && (!regions || !results))) return fail(ctx, PAV_E_ARG, "pav_inv_scan_batch: null argument");
     InvState *S = istate(ctx);
     if (!S->loaded) return fail(ctx, PAV_E_STATE, "pav_inv_scan_batch: pav_inv_load_alignments has not been called");
+    const double t_entry = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     Driver D(ctx, S);
     const int k = pp->den.k;
     const int64_t max_region_size = pp->max_region_size;
@@ -688,6 +689,7 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
         next.insert(next.end(), rest.begin(), rest.end());
         live.swap(next);
     }
+    if (timing) fprintf(stderr, "[pav timing] inv_scan_batch setup %.2f ms\n", (t_start - t_entry) * 1e3);
     if (timing) fprintf(stderr, "[pav timing] inv_scan_batch %.1f ms: density_batch %.1f, call tables + annotate %.1f, lift + jobs %.2f (lifting %.2f), decisions %.2f\n",
                         (now() - t_start) * 1e3, t_batch * 1e3, t_table * 1e3, t_pre * 1e3, t_lift * 1e3, t_post * 1e3);
     for (uint32_t i = 0; i < n_regions; ++i) {

@@ -9,9 +9,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--scale', type=float, default=1.0)
+    ap.add_argument('--no-build', action='store_true', help='everything is built already (under rocprofv3: no compiler from this process)')
+    ap.add_argument('--plain', action='store_true', help='timed steps only, no cProfile pass')
     args = ap.parse_args()
-    import __graft_entry__ as g
-    g.build_cpu_side()
+    if not args.no_build:
+        import __graft_entry__ as g
+        g.build_cpu_side()
     import numpy as np
     from pav_amd import _lib, cigarcall, synth, inv as pavinv
     from pav_amd.align import AlignLift
@@ -31,13 +34,25 @@ def main():
     params = ctx.flag_params(sig_filter=_lib.SIG_SINGLE_CLUSTER)
     found = io.StringIO()
 
+    timing = bool(os.environ.get('PAV_TIMING'))
+
     def step():
+        t = [time.perf_counter()]
+
+        def lap(what):
+            if timing:
+                now = time.perf_counter()
+                print('[pav timing] step %-14s %.2f ms' % (what, (now - t[0]) * 1e3), file=sys.stderr)
+                t[0] = now
         ctx.seq_pack(_lib.PAV_ROLE_TIG)
         ctx.cigar_call()
+        lap('pack+call')
         flag = ctx.cigar_flag(tp, te, params)
+        lap('flag')
         regions = pavinv.loci_regions(ctx, flag[1])
         log = io.StringIO()
         found.seek(0); found.truncate()
+        lap('regions')
         return pavinv.scan_for_inv_batch(regions, 'ref.fa', 'tig.fa', lift, k_util, log=log, ctx=ctx, eager_tables=False, found_out=found)
     for _ in range(4):
         step()
@@ -47,6 +62,9 @@ def main():
         step()
     ctx.sync()
     print('ms per step (one lane, no profiler): %.3f' % ((time.perf_counter() - t0) / args.steps * 1e3))
+    if args.plain:
+        ctx.close()
+        return
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(args.steps):
