@@ -7,6 +7,7 @@
 // vectors the reference produced.
 #include "common.h"
 #include "textio.h"
+#include "pool.h"
 
 #include <algorithm>
 #include <cmath>
@@ -24,6 +25,22 @@ struct InvTable {           // density table of one call: views into a pinned ho
     uint64_t *kmer = nullptr; uint8_t *flank = nullptr, *match = nullptr;
 };
 
+struct Rgn {                                                  // pavlib.seq.Region (only what the scan uses)
+    int chrom = -1; int role = 0;
+    int64_t pos = 0, end = 0;
+    bool is_rev = false;
+    int64_t aln[2][2] = {{0, 0}, {0, 0}}; int n_aln[2] = {0, 0};   // pos_aln_index / end_aln_index (flattened)
+    int64_t len() const { return end - pos; }
+};
+
+struct Scan {                       // per flagged region
+    Rgn flag, region_ref, region_tig;
+    int expansion_count = 0;
+    bool done = false;
+    std::vector<pav_run> state_rl;
+    uint32_t n_rows = 0;
+};
+
 struct InvState {
     // lift-over index (pav_inv_load_alignments)
     std::vector<LiftRow> rows;
@@ -39,7 +56,9 @@ struct InvState {
     struct Spans { std::vector<int64_t> begin, end, max_end; };
     std::vector<Spans> span_ref, span_tig;
     std::vector<std::string> names[2];
-    mutable std::vector<int8_t> row_checked;                // 0 not yet, 1 usable, 2 has N / P operations
+    std::vector<uint8_t> row_bad;                           // first N (3) / P (6) operation code of a record, 0: none (lift.py:463-471)
+    std::unique_ptr<HostPool> pool;                         // helper threads of the per-region host loops (pav_inv_scan_batch)
+    std::vector<Scan> scans;                                // per-region state of the running scan (kept: its vectors keep their memory)
     bool loaded = false;
     // last scan
     std::vector<pav_inv_result> results;
@@ -103,13 +122,6 @@ static std::string fmt_commas(int64_t v) {                   // '{:,d}'
 }
 static std::string fmt_f2(double v) { char b[64]; snprintf(b, sizeof b, "%.2f", v); return b; }   // '{:.2f}'
 
-struct Rgn {                                                  // pavlib.seq.Region (only what the scan uses)
-    int chrom = -1; int role = 0;
-    int64_t pos = 0, end = 0;
-    bool is_rev = false;
-    int64_t aln[2][2] = {{0, 0}, {0, 0}}; int n_aln[2] = {0, 0};   // pos_aln_index / end_aln_index (flattened)
-    int64_t len() const { return end - pos; }
-};
 
 struct Lifted { bool ok = false; int id = -1; int64_t pos = 0; int rev = 0; bool rev_none = false; int64_t idx[2] = {0, 0}; int n_idx = 0; };
 
@@ -195,19 +207,12 @@ public:
         d0 = axis == 0 ? S->qry_begin[k] : S->sub_begin[k];
         d1 = match ? d0 + len : d0 + 1;
     }
-    bool check_row_ops(uint32_t row, std::string &err) const {       // errors _add_align raises (lift.py:463-471)
-        if (S->row_checked[row] == 1) return true;
-        S->row_checked[row] = 1;
-        for (uint64_t k = S->op_off[row]; k < S->op_off[row + 1]; ++k) {
-            const uint32_t code = S->ops[k] & 15u;
-            if (code == 3 || code == 6) {
-                err = std::string("Unhandled CIGAR operation: ") + (code == 3 ? "N" : "P") + ": Alignment " +
-                      name(PAV_ROLE_REF, (int)S->rows[row].ref_id) + ":" + fmt_i(S->rows[row].pos) + " (" + name(PAV_ROLE_TIG, (int)S->rows[row].tig_id) + ")";
-                S->row_checked[row] = 0;                          // raise again on the next use, like the reference
-                return false;
-            }
-        }
-        return true;
+    bool check_row_ops(uint32_t row, std::string &err) const {       // errors _add_align raises (lift.py:463-471), on every use
+        const uint32_t code = S->row_bad[row];
+        if (!code) return true;
+        err = std::string("Unhandled CIGAR operation: ") + (code == 3 ? "N" : "P") + ": Alignment " +
+              name(PAV_ROLE_REF, (int)S->rows[row].ref_id) + ":" + fmt_i(S->rows[row].pos) + " (" + name(PAV_ROLE_TIG, (int)S->rows[row].tig_id) + ")";
+        return false;
     }
 
     // AlignLift.lift_to_qry (lift.py:187-272).  false + err on RuntimeError.
@@ -357,13 +362,6 @@ static int tables_on_host(pav_ctx *ctx, InvState *S) {
     return wait_tables(ctx);
 }
 
-struct Scan {                       // per flagged region
-    Rgn flag, region_ref, region_tig;
-    int expansion_count = 0;
-    bool done = false;
-    std::vector<pav_run> state_rl;
-    uint32_t n_rows = 0;
-};
 
 }  // namespace pav
 
@@ -455,7 +453,20 @@ int pav_inv_load_alignments(pav_ctx *ctx, uint32_t n, const pav_inv_aln *aln, co
             }
         }
     }
-    S->row_checked.assign(n, 0);
+    S->row_bad.assign(n, 0);
+    for (uint32_t r = 0; r < n; ++r)
+        for (uint64_t q = S->op_off[r]; q < S->op_off[r + 1]; ++q) {
+            const uint32_t code = S->ops[q] & 15u;
+            if (code == 3 || code == 6) { S->row_bad[r] = (uint8_t)code; break; }
+        }
+    if (!S->pool) {
+        // PAV_HOST_THREADS = n: n - 1 helper threads next to the caller's.  Default none: on the bench box (a CPU quota shared
+        // with the runtime's own threads) three helpers made a one-lane pass slower, 3.2 -> 3.5 ms - their spinning between
+        // the loops of a round costs more than the loops (0.1 - 0.2 ms each) gain
+        const char *e = getenv("PAV_HOST_THREADS");
+        const int helpers = e ? std::max(0, atoi(e) - 1) : 0;
+        S->pool = std::make_unique<HostPool>(helpers);
+    }
     S->loaded = true;
     return PAV_OK;
 }
@@ -466,22 +477,31 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
     InvState *S = istate(ctx);
     if (!S->loaded) return fail(ctx, PAV_E_STATE, "pav_inv_scan_batch: pav_inv_load_alignments has not been called");
     const double t_entry = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    S->pool->wake();                                                     // the first per-region loop is a few microseconds away
     Driver D(ctx, S);
+    auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tl[6] = {0};
     const int k = pp->den.k;
     const int64_t max_region_size = pp->max_region_size;
     const int min_exp_count = pp->min_exp_count;
     S->results.assign(n_regions, pav_inv_result{});
-    S->logs.assign(n_regions, std::string());
-    S->errors.assign(n_regions, std::string());
-    S->found.assign(n_regions, std::string());
+    // (texts and per-region state are emptied, not rebuilt: a thousand regions append five lines each, and a string that grows
+    // from nothing is reallocated five times on the way)
+    for (std::vector<std::string> *v : {&S->logs, &S->errors, &S->found}) { v->resize(n_regions); for (std::string &x : *v) x.clear(); }
+    tl[0] = tnow();
     // this scan fills the arena of the scan before the last one: only *its* copies must have landed (they have, long ago);
     // the copies of the last scan may still be travelling into the other arena
     std::swap(ctx->tables_done, ctx->tables_done_prev);
     std::swap(ctx->tables_pending, ctx->tables_pending_prev);
     { const int rcw = wait_tables(ctx); if (rcw != PAV_OK) return rcw; }
+    tl[1] = tnow();
     S->tables.clear(); S->tables.resize(n_regions);
     S->next_pinned();
-    std::vector<Scan> scans(n_regions);
+    tl[2] = tnow();
+    std::vector<Scan> &scans = S->scans;
+    scans.resize(n_regions);
+    for (Scan &sc : scans) { sc.flag = sc.region_ref = sc.region_tig = Rgn(); sc.expansion_count = 0; sc.done = false; sc.state_rl.clear(); sc.n_rows = 0; }
+    tl[3] = tnow();
     auto log = [&](uint32_t i, const std::string &m) { S->logs[i] += m; S->logs[i] += '\n'; };
     auto srs_of = [&](int64_t len) -> uint32_t {
         for (uint32_t i = 0; i < pp->n_srs; ++i) if ((double)len >= pp->srs[i].begin && (double)len < pp->srs[i].end) return pp->srs[i].value;
@@ -493,17 +513,24 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
         for (int e = 0; e < 2; ++e) { o.n_aln[e] = (uint32_t)r.n_aln[e]; for (int q = 0; q < 2; ++q) o.aln_index[e][q] = r.aln[e][q]; }
     };
 
+    // The loops over regions below do per-region work only (lifts through the alignment table, log lines): they run on the
+    // caller's thread and the helpers of S->pool, and whatever depends on the order of the regions follows in a serial pass.
+    HostPool &pool = *S->pool;
+    constexpr size_t CHUNK = 32;
     std::vector<uint32_t> live;
-    for (uint32_t i = 0; i < n_regions; ++i) {
-        Scan &sc = scans[i];
+    for (uint32_t i = 0; i < n_regions; ++i)
         if (regions[i].ref_id >= ctx->seq[PAV_ROLE_REF].n) return fail(ctx, PAV_E_ARG, "pav_inv_scan_batch: region %u: unknown reference record", i);
+    pool.run(n_regions, CHUNK, [&](size_t ii) {
+        const uint32_t i = (uint32_t)ii;
+        Scan &sc = scans[i];
         sc.flag.role = PAV_ROLE_REF; sc.flag.chrom = (int)regions[i].ref_id; sc.flag.pos = (int64_t)regions[i].pos; sc.flag.end = (int64_t)regions[i].end;
         if (sc.flag.pos > sc.flag.end) { std::swap(sc.flag.pos, sc.flag.end); sc.flag.is_rev = true; }
         log(i, "Scanning for inversions in flagged region: " + D.base1(sc.flag) + " (flagged region record id = " + D.region_id(sc.flag) + ")");   // inv.py:194-199
         sc.region_ref = sc.flag;
         D.expand(sc.region_ref, 4000, 0.5);                                          // INITIAL_EXPAND, inv.py:203-204
-        live.push_back(i);
-    }
+    });
+    for (uint32_t i = 0; i < n_regions; ++i) live.push_back(i);
+    tl[4] = tnow();
 
     const uint64_t max_batch_bp = 64000000ull;
     const bool timing = getenv("PAV_TIMING") != nullptr;
@@ -514,34 +541,53 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
         std::vector<pav_den_job> jobs; std::vector<uint32_t> owners, rest;
         uint64_t budget = 0;
         const double t_p0 = now();
-        for (uint32_t i : live) {
-            if (budget > max_batch_bp && !jobs.empty()) { rest.push_back(i); continue; }
+        // top of the while-loop, inv.py:223-260.  Lifts first (every live region, no side effects) ...
+        struct Pre { uint8_t kind; uint32_t job; Rgn tig; std::string err; };   // kind 0: too large, 1: lift raised, 2: not liftable, 3: lifted
+        std::vector<Pre> pre(live.size());
+        pool.run(live.size(), CHUNK, [&](size_t q) {
+            const Scan &sc = scans[live[q]];
+            Pre &x = pre[q];
+            if (0 < max_region_size && max_region_size < sc.region_ref.len()) { x.kind = 0; return; }
+            bool ok = false;
+            x.kind = !D.region_to_qry(sc.region_ref, x.tig, ok, x.err) ? 1 : ok ? 3 : 2;
+        });
+        t_lift += now() - t_p0;
+        // ... then which of them this round takes (a budget of bases per batch, in region order) ...
+        std::vector<uint32_t> taken;                                              // positions in `live`
+        for (uint32_t q = 0; q < live.size(); ++q) {
+            if (budget > max_batch_bp && !owners.empty()) { rest.push_back(live[q]); continue; }
+            taken.push_back(q);
+            if (pre[q].kind != 3) continue;
+            pre[q].job = (uint32_t)owners.size();
+            owners.push_back(live[q]);
+            budget += (uint64_t)scans[live[q]].region_ref.len() + (uint64_t)pre[q].tig.len();
+        }
+        jobs.assign(owners.size(), pav_den_job{});
+        // ... then their log lines and job descriptors
+        pool.run(taken.size(), CHUNK, [&](size_t t) {
+            const uint32_t q = taken[t], i = live[q];
             Scan &sc = scans[i];
-            // top of the while-loop, inv.py:223-260
-            if (0 < max_region_size && max_region_size < sc.region_ref.len()) {
+            Pre &x = pre[q];
+            if (x.kind == 0) {
                 log(i, "Region size exceeds max: " + D.base1(sc.region_ref) + " (" + fmt_i(sc.region_ref.len()) + " > " + fmt_i(max_region_size) + ")");
-                finish(i, PAV_INV_NONE); continue;
+                finish(i, PAV_INV_NONE); return;
             }
-            bool ok = false; std::string err;
-            const double t_l0 = timing ? now() : 0.0;
-            const bool lifted = D.region_to_qry(sc.region_ref, sc.region_tig, ok, err);
-            if (timing) t_lift += now() - t_l0;
-            if (!lifted) { S->errors[i] = err; finish(i, PAV_INV_ERROR); continue; }
-            if (!ok) { log(i, "Could not lift reference region onto contigs: " + D.base1(sc.region_ref)); finish(i, PAV_INV_NONE); continue; }
+            if (x.kind == 1) { S->errors[i] = x.err; finish(i, PAV_INV_ERROR); return; }
+            if (x.kind == 2) { log(i, "Could not lift reference region onto contigs: " + D.base1(sc.region_ref)); finish(i, PAV_INV_NONE); return; }
+            sc.region_tig = x.tig;
             sc.expansion_count += 1;
             log(i, "Scanning region: " + D.base1(sc.region_ref));
-            pav_den_job j{};
+            pav_den_job &j = jobs[x.job];
             j.ref_id = (uint32_t)sc.region_ref.chrom; j.tig_id = (uint32_t)sc.region_tig.chrom;
             j.ref_pos = (uint64_t)sc.region_ref.pos; j.ref_end = (uint64_t)sc.region_ref.end;
             j.tig_pos = (uint64_t)sc.region_tig.pos; j.tig_end = (uint64_t)sc.region_tig.end;
             j.ref_rc = sc.region_tig.is_rev ? 1 : 0; j.state_run_smooth = srs_of(sc.region_tig.len());
-            jobs.push_back(j); owners.push_back(i);
-            budget += (uint64_t)sc.region_ref.len() + (uint64_t)sc.region_tig.len();
-        }
+        });
         if (jobs.empty()) { live.swap(rest); continue; }
         std::vector<pav_den_result> res(jobs.size());
         double t0 = now();
         t_pre += t0 - t_p0;
+        if (timing) fprintf(stderr, "[pav timing]   scan round: %zu jobs, lift + jobs %.2f ms\n", jobs.size(), (t0 - t_p0) * 1e3);
         int rc = pav_density_batch(ctx, (uint32_t)jobs.size(), jobs.data(), &pp->den, res.data());
         t_batch += now() - t0;
         if (rc != PAV_OK) return rc;
@@ -561,17 +607,11 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
             if (t_inner.pos > t_inner.end) std::swap(t_inner.pos, t_inner.end);
             return 0;
         };
-        for (uint32_t j = 0; j < jobs.size(); ++j) {                               // the state runs of every job
-            Scan &sc = scans[owners[j]];
-            const pav_den_result &r = res[j];
-            sc.state_rl.clear();
-            if (r.status == PAV_DEN_FAIL || r.n_rows == 0) continue;
-            sc.state_rl.resize(r.n_runs);
-            if (r.n_runs) { rc = pav_density_runs(ctx, j, sc.state_rl.data()); if (rc != PAV_OK) return rc; }
-        }
-        std::vector<uint32_t> next;
-        std::vector<CallFetch> round_calls; std::vector<uint32_t> round_owner; std::vector<uint8_t> round_k1;   // round_k1: the call has FWDREV k-mers
-        for (uint32_t j = 0; j < jobs.size(); ++j) {
+        // after the density call, per region (inv.py:268-351) ...
+        struct Dec { uint8_t what = 0, k1 = 0; CallFetch cf{}; };                   // what 0: finished, 1: expanded, 2: call, 3: internal error
+        std::vector<Dec> dec(jobs.size());
+        pool.run(jobs.size(), CHUNK, [&](size_t jj) {
+            const uint32_t j = (uint32_t)jj;
             const uint32_t i = owners[j];
             Scan &sc = scans[i];
             const pav_den_result &r = res[j];
@@ -587,29 +627,31 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
                                   D.base1(sc.region_ref) + "\n";
                 }
                 log(i, "Received return code 125 from scripts/density.py for region " + D.base1(sc.region_ref) + ":\n" + stderr_text);
-                finish(i, PAV_INV_NONE); continue;
+                finish(i, PAV_INV_NONE); return;
             }
-            if (r.n_rows == 0) { log(i, "No informative reference k-mers in forward or reverse orientation in region"); finish(i, PAV_INV_NONE); continue; }
+            if (r.n_rows == 0) { log(i, "No informative reference k-mers in forward or reverse orientation in region"); finish(i, PAV_INV_NONE); return; }
+            sc.state_rl.resize(r.n_runs);
+            if (r.n_runs && pav_density_runs(ctx, j, sc.state_rl.data()) != PAV_OK) { dec[j].what = 3; return; }
             sc.n_rows = r.n_rows;
-            const auto &rl = sc.state_rl;                                            // fetched above
+            const auto &rl = sc.state_rl;
             if (rl.size() == 1 && (rl[0].state == 0 || rl[0].state == -1) && sc.expansion_count >= min_exp_count) {
                 log(i, "Found no inverted k-mer states after " + fmt_i(sc.expansion_count) + " expansion(s)");
-                finish(i, PAV_INV_NONE); continue;
+                finish(i, PAV_INV_NONE); return;
             }
             if (rl.size() > 2 && rl.front().state == 0 && rl.back().state == 0) {
                 // ---- characterise, inv.py:353-454 ----------------------------------------------------------
                 Rgn t_outer, t_inner;
                 const int why = inv_bounds(sc, t_outer, t_inner);
-                if (why == 1) { log(i, "No inverted states found"); finish(i, PAV_INV_NONE); continue; }
+                if (why == 1) { log(i, "No inverted states found"); finish(i, PAV_INV_NONE); return; }
                 if (why == 2) {
                     log(i, "Longest run of strictly inverted k-mers (" + fmt_i(t_outer.pos) + ") does not meet the minimum threshold (100)");
-                    finish(i, PAV_INV_NONE); continue;
+                    finish(i, PAV_INV_NONE); return;
                 }
                 Rgn r_outer, r_inner; bool ok = false; std::string err;
-                if (!D.region_to_sub(t_outer, false, r_outer, ok, err)) { S->errors[i] = err; finish(i, PAV_INV_ERROR); continue; }
-                if (!ok) { log(i, "Failed lifting outer INV region to reference: " + D.base1(t_outer)); finish(i, PAV_INV_NONE); continue; }
+                if (!D.region_to_sub(t_outer, false, r_outer, ok, err)) { S->errors[i] = err; finish(i, PAV_INV_ERROR); return; }
+                if (!ok) { log(i, "Failed lifting outer INV region to reference: " + D.base1(t_outer)); finish(i, PAV_INV_NONE); return; }
                 bool ok2 = false;
-                if (!D.region_to_sub(t_inner, true, r_inner, ok2, err)) { S->errors[i] = err; finish(i, PAV_INV_ERROR); continue; }
+                if (!D.region_to_sub(t_inner, true, r_inner, ok2, err)) { S->errors[i] = err; finish(i, PAV_INV_ERROR); return; }
                 if (!ok2) r_inner = r_outer;
                 pav_inv_result &out = S->results[i];
                 set_rgn(out.tig_outer, t_outer); set_rgn(out.tig_inner, t_inner); set_rgn(out.ref_outer, r_outer); set_rgn(out.ref_inner, r_inner);
@@ -620,12 +662,12 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
                 if ((double)r_outer.len() < (double)t_outer.len() * 0.6) {
                     log(i, "Reference region too short: Reference region length (" + fmt_commas(r_outer.len()) + ") is not within " + fmt_f2(60.0) +
                            "% of the contig region length (" + fmt_commas(t_outer.len()) + ")");
-                    finish(i, PAV_INV_NONE); continue;
+                    finish(i, PAV_INV_NONE); return;
                 }
                 if ((double)t_outer.len() < (double)r_outer.len() * 0.6) {
                     log(i, "Contig region too short: Contig region length (" + fmt_commas(t_outer.len()) + ") is not within " + fmt_f2(60.0) +
                            "% of the reference region length (" + fmt_commas(r_outer.len()) + ")");
-                    finish(i, PAV_INV_NONE); continue;
+                    finish(i, PAV_INV_NONE); return;
                 }
                 // density table + FLANK / MATCH (inv.py:440-442, 457-561): queued for the end of this round, while the batch
                 // is still resident.  The annotation receives the *reference* discovery start (inv.py:441).
@@ -637,12 +679,12 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
                 cf.base = sc.region_ref.pos;
                 cf.tig_up_pos = std::min(t_outer.pos, t_inner.pos); cf.tig_up_end = std::max(t_outer.pos, t_inner.pos);
                 cf.tig_dn_pos = std::min(t_inner.end, t_outer.end); cf.tig_dn_end = std::max(t_inner.end, t_outer.end);
-                round_calls.push_back(cf); round_owner.push_back(i); round_k1.push_back(r.state_count[1] != 0);
+                dec[j].what = 2; dec[j].cf = cf; dec[j].k1 = r.state_count[1] != 0;
                 out.n_rows = n;
                 out.svlen = (uint64_t)r_outer.len();
                 log(i, "Found inversion: " + D.name(PAV_ROLE_REF, r_outer.chrom) + "-" + fmt_i(r_outer.pos + 1) + "-INV-" + fmt_i(r_outer.len()));
                 finish(i, PAV_INV_CALL);
-                continue;
+                return;
             }
             // Expand, inv.py:309-342
             const int64_t last_len = sc.region_ref.len();
@@ -650,10 +692,19 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
             double balance = 0.5;
             if (rl.size() > 2) { if (rl.front().state == 0) balance = 0.25; else if (rl.back().state == 0) balance = 0.75; }
             D.expand(sc.region_ref, expand_bp, balance);
-            if (sc.region_ref.len() == last_len) { log(i, "Reached reference limits, cannot expand"); finish(i, PAV_INV_NONE); continue; }
-            next.push_back(i);
+            if (sc.region_ref.len() == last_len) { log(i, "Reached reference limits, cannot expand"); finish(i, PAV_INV_NONE); return; }
+            dec[j].what = 1;
+        });
+        // ... and, in region order, the calls of the round and the regions that go on
+        std::vector<uint32_t> next;
+        std::vector<CallFetch> round_calls; std::vector<uint32_t> round_owner; std::vector<uint8_t> round_k1;   // round_k1: the call has FWDREV k-mers
+        for (uint32_t j = 0; j < jobs.size(); ++j) {
+            if (dec[j].what == 3) return fail(ctx, PAV_E_STATE, "pav_inv_scan_batch: the state runs of job %u could not be read", j);
+            if (dec[j].what == 2) { round_calls.push_back(dec[j].cf); round_owner.push_back(owners[j]); round_k1.push_back(dec[j].k1); }
+            else if (dec[j].what == 1) next.push_back(owners[j]);
         }
         t_post += now() - t_q0;
+        if (timing) fprintf(stderr, "[pav timing]   scan round: decisions %.2f ms, %zu calls\n", (now() - t_q0) * 1e3, round_calls.size());
         if (!round_calls.empty()) {                                          // one pinned block, one synchronisation per round
             double t0 = now();
             // one pinned block per round, column-major over the whole round: K0 | K1 | K2 | KMER | INDEX | STATE_MER | STATE |
@@ -689,7 +740,8 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
         next.insert(next.end(), rest.begin(), rest.end());
         live.swap(next);
     }
-    if (timing) fprintf(stderr, "[pav timing] inv_scan_batch setup %.2f ms\n", (t_start - t_entry) * 1e3);
+    if (timing) fprintf(stderr, "[pav timing] inv_scan_batch setup %.2f ms: texts %.3f, wait tables %.3f, tables %.3f, scans %.3f, first lines %.3f\n", (t_start - t_entry) * 1e3,
+                        (tl[0] - t_entry) * 1e3, (tl[1] - tl[0]) * 1e3, (tl[2] - tl[1]) * 1e3, (tl[3] - tl[2]) * 1e3, (tl[4] - tl[3]) * 1e3);
     if (timing) fprintf(stderr, "[pav timing] inv_scan_batch %.1f ms: density_batch %.1f, call tables + annotate %.1f, lift + jobs %.2f (lifting %.2f), decisions %.2f\n",
                         (now() - t_start) * 1e3, t_batch * 1e3, t_table * 1e3, t_pre * 1e3, t_lift * 1e3, t_post * 1e3);
     for (uint32_t i = 0; i < n_regions; ++i) {
