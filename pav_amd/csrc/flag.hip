@@ -541,26 +541,88 @@ struct KeyView {
         return ca != cb || mb >= ma + win;
     }
 };
-struct OpenRowPlanned {
-    KeyView V; int64_t win; unsigned long long *unsorted;
-    __device__ unsigned long long operator()(unsigned long long i) const {
-        uint64_t local, n_real;
-        if (!V.real(i, local, n_real) || local == 0) return i;
-        if (V.k[i - 1] > V.k[i]) *unsorted = 1;                                // table order is not the rules' iteration order
-        return V.opens(i, win) ? i : 0ull;
+// Both cluster sweeps (rule call_inv_cluster, :646-684) without a scan over all rows.  k_open_blocks notes, for every 256 rows, the
+// last row that opens a cluster; k_cluster_sweep lets the last row of each cluster find the cluster's first row: it walks back
+// while fewer than min_count rows are behind it (nearly every cluster is a single row and ends the walk at once; a cluster
+// that short is not reported anyway), and the clusters that pass are finished by the whole wave - the rest of the row's own
+// block 64 rows per step, then 64 block notes per step (16 K rows): the inverted stretches this stage exists to find make
+// clusters of tens of thousands of rows.  (The max-scan over "row opens a cluster" this replaces wrote and re-read 8 bytes per
+// row: 0.10 ms for the two launches of the scan and the emit.)
+struct OpenBlocksArgs { KeyView V; uint64_t n; int64_t win; uint32_t *last_open; unsigned long long *unsorted; };
+__global__ __launch_bounds__(256) void k_open_blocks(OpenBlocksArgs A) {
+    __shared__ uint32_t wbest[4];
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint64_t local = 0, n_real = 0;
+    const bool real = i < A.n && A.V.real(i, local, n_real);
+    if (real && local && A.V.k[i - 1] > A.V.k[i]) *A.unsorted = 1;            // table order is not the rules' iteration order
+    const bool op = real && (local == 0 || A.V.opens(i, A.win));
+    const unsigned long long m = __ballot(op);
+    if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = m ? (uint32_t)(threadIdx.x + 64 - __clzll((long long)m)) : 0u;   // 1 + thread of the last one
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t best = 0;
+        for (int w = 0; w < 4; ++w) if (wbest[w]) best = wbest[w];
+        A.last_open[blockIdx.x] = best;                                        // 1 + offset in the block, 0: no row of the block opens a cluster
     }
-};
-struct EmitArgs {
-    KeyView V; const unsigned long long *start; uint64_t n; int64_t win, win_min, min_count[2];
+}
+
+struct SweepArgs {
+    KeyView V; uint64_t n; int64_t win, win_min, min_count[2]; const uint32_t *last_open;
     ClusterHit *hits[2]; uint64_t cap[2]; unsigned long long *n_hits; FlagPin *pin;
 };
-__global__ __launch_bounds__(256) void k_cluster_emit_planned(EmitArgs A) {
+__global__ __launch_bounds__(256) void k_cluster_sweep(SweepArgs A) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    uint64_t local, n_real;
-    if (i >= A.n || !A.V.real(i, local, n_real)) return;
-    if (!(local + 1 == n_real || A.V.opens(i + 1, A.win))) return;            // only the last row of a cluster reports
+    const int lane = threadIdx.x & 63;
+    uint64_t local = 0, n_real = 0;
+    const bool real = i < A.n && A.V.real(i, local, n_real);
+    const uint64_t first = i - local;                                         // first row of the table
     const int t = i >= A.V.n_snv;
-    const uint64_t j = A.start[i];
+    const bool closes = real && (local + 1 == n_real || A.V.opens(i + 1, A.win));
+    bool search = closes, report = false;
+    uint64_t j = i;
+    if (search) {
+        const int64_t need = A.min_count[t] > 1 ? A.min_count[t] : 1;
+        int64_t behind = 1;                                                    // rows j .. i
+        while (j != first && !A.V.opens(j, A.win) && behind < need) { --j; ++behind; }
+        if (behind < need) search = false;                                     // the cluster starts at j and is too short to report
+        else if (j == first || A.V.opens(j, A.win)) { search = false; report = true; }
+    }
+    // the clusters of the wave that are long enough and not yet walked to their start, one after the other
+    unsigned long long todo = __ballot(search);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        uint64_t at = __shfl(j, leader);                                       // no row above `at` (up to the leader's) opens a cluster
+        const uint64_t lo = __shfl(first, leader);
+        const KeyView V = A.V;
+        uint64_t got = ~0ull;
+        const uint64_t blk0 = at & ~255ull;                                    // rest of the block of `at`
+        while (got == ~0ull) {
+            const bool valid = at >= lo + (uint64_t)lane && at - (uint64_t)lane >= blk0;
+            const uint64_t row = at - (uint64_t)lane;
+            const bool op = valid && (row == lo || V.opens(row, A.win));
+            const unsigned long long m = __ballot(op);
+            if (m) { got = at - (uint64_t)(__ffsll((long long)m) - 1); break; }
+            if (at < blk0 + 64) break;
+            at -= 64;
+        }
+        if (got == ~0ull) {                                                    // the blocks before: the nearest with a note holds the row
+            uint64_t b = blk0 / 256;                                           // (the table's first row opens, so there is one)
+            for (;;) {
+                const bool valid = b >= (uint64_t)lane + 1;
+                const uint32_t note = valid ? A.last_open[b - 1 - (uint64_t)lane] : 0u;
+                const unsigned long long m = __ballot(note != 0);
+                if (m) {
+                    const int src = __ffsll((long long)m) - 1;
+                    got = (b - 1 - (uint64_t)src) * 256 + (uint64_t)__shfl(note, src) - 1;
+                    break;
+                }
+                b -= 64;
+            }
+        }
+        if (lane == leader) { j = got; report = true; }
+        todo &= todo - 1;
+    }
+    if (!report) return;
     const int64_t count = (int64_t)(i - j) + 1;
     uint32_t cj, ci; int64_t pos, end;
     A.V.at(j, cj, pos); A.V.at(i, ci, end);
@@ -746,7 +808,7 @@ int flag_planned(pav_ctx *ctx, FlagState *S, const pav_flag_params *P, unsigned 
     const uint32_t tiles_snv = (uint32_t)((n_snv + KEY_TILE - 1) / KEY_TILE), tiles_ind = (uint32_t)((n_ind + KEY_TILE - 1) / KEY_TILE);
     const uint32_t lo_indel = (uint32_t)std::min<int64_t>(std::max<int64_t>(P->insdel_min_svlen, 0), 0xffffffffll);
 
-    PAV_HIP(ctx, S->a.reserve(8 * n_keys)); PAV_HIP(ctx, S->b.reserve(8 * n_keys)); PAV_HIP(ctx, S->start.reserve(8 * n_keys));
+    PAV_HIP(ctx, S->a.reserve(8 * n_keys)); PAV_HIP(ctx, S->b.reserve(8 * n_keys));
     unsigned long long *k_in = S->a.as<unsigned long long>(), *k_sorted = S->b.as<unsigned long long>();
     // tile arrays: offsets of the key tiles, their counts, class word and class offsets of the INS-DEL tiles
     PAV_HIP(ctx, S->c.reserve(12 * ((size_t)tiles_snv + tiles_ind) + (8 + 4 * CLS) * (size_t)tiles_ind + 64));
@@ -763,12 +825,9 @@ int flag_planned(pav_ctx *ctx, FlagState *S, const pav_flag_params *P, unsigned 
     PAV_HIP(ctx, S->hits_b[2].reserve(sizeof(MatchHit) * (n_ind + 1))); PAV_HIP(ctx, S->hits_b[3].reserve(sizeof(MatchHit) * (n_ind + 1)));
 
     const KeyView V{k_sorted, n_snv, tag, d_cnt};
-    auto opens = rocprim::make_transform_iterator(rocprim::counting_iterator<unsigned long long>(0), OpenRowPlanned{V, P->cluster_win, d_cnt + 3});
     const DelEndPlanned DE{{cls_key[0], cls_key[2]}, {cls_val[0], cls_val[2]}, n_ind, d_cnt, d_cnt + 3};
     auto del_end = rocprim::make_transform_iterator(rocprim::counting_iterator<unsigned long long>(0), DE);
     size_t bytes = 0, bytes2 = 0;
-    PAV_HIP(ctx, rocprim::inclusive_scan(nullptr, bytes, opens, S->start.as<unsigned long long>(), (size_t)n_keys,
-                                         rocprim::maximum<unsigned long long>(), st));
     if (n_ind) PAV_HIP(ctx, rocprim::inclusive_scan(nullptr, bytes2, del_end, del_max, (size_t)(2 * n_ind), rocprim::maximum<unsigned long long>(), st));
     PAV_HIP(ctx, S->tmp.reserve(std::max(bytes, bytes2) + 16));
 
@@ -794,17 +853,16 @@ int flag_planned(pav_ctx *ctx, FlagState *S, const pav_flag_params *P, unsigned 
         PAV_LAUNCH(ctx, "k_insdel_split_ordered", k_insdel_split_ordered, tiles_ind, 256, 0, SA);
     }
     {   // both cluster sweeps (rule call_inv_cluster)
-        const int tok = prof_begin(ctx, "rocprim::inclusive_scan");
-        const hipError_t e = rocprim::inclusive_scan(S->tmp.p, bytes, opens, S->start.as<unsigned long long>(), (size_t)n_keys,
-                                                     rocprim::maximum<unsigned long long>(), st);
-        prof_end(ctx, tok);
-        PAV_HIP(ctx, e);
-        EmitArgs EA;
-        EA.V = V; EA.start = S->start.as<unsigned long long>(); EA.n = n_keys; EA.win = EA.win_min = P->cluster_win;
-        EA.min_count[0] = P->cluster_min_snv; EA.min_count[1] = P->cluster_min_indel;
-        EA.hits[0] = S->hits_b[0].as<ClusterHit>(); EA.hits[1] = S->hits_b[1].as<ClusterHit>(); EA.cap[0] = cap[0]; EA.cap[1] = cap[1];
-        EA.n_hits = d_cnt + 4; EA.pin = pin;
-        PAV_LAUNCH(ctx, "k_cluster_emit_planned", k_cluster_emit_planned, (uint32_t)((n_keys + 255) / 256), 256, 0, EA);
+        const uint32_t n_blocks = (uint32_t)((n_keys + 255) / 256);
+        PAV_HIP(ctx, S->start.reserve(4ull * n_blocks));
+        OpenBlocksArgs OB{V, n_keys, P->cluster_win, S->start.as<uint32_t>(), d_cnt + 3};
+        PAV_LAUNCH(ctx, "k_open_blocks", k_open_blocks, n_blocks, 256, 0, OB);
+        SweepArgs SW;
+        SW.V = V; SW.n = n_keys; SW.win = SW.win_min = P->cluster_win; SW.last_open = S->start.as<uint32_t>();
+        SW.min_count[0] = P->cluster_min_snv; SW.min_count[1] = P->cluster_min_indel;
+        SW.hits[0] = S->hits_b[0].as<ClusterHit>(); SW.hits[1] = S->hits_b[1].as<ClusterHit>(); SW.cap[0] = cap[0]; SW.cap[1] = cap[1];
+        SW.n_hits = d_cnt + 4; SW.pin = pin;
+        PAV_LAUNCH(ctx, "k_cluster_sweep", k_cluster_sweep, n_blocks, 256, 0, SW);
     }
     if (n_ind) {   // both matches (rule call_inv_flag_insdel_cluster)
         const int tok = prof_begin(ctx, "rocprim::inclusive_scan");

@@ -130,3 +130,42 @@ def test_long_clusters_and_ties(gpu_ctx):
     got = [(int(r['chrom']), int(r['pos']), int(r['end']), int(r['count'])) for r in rec]
     assert got == [tuple(int(x) for x in w) for w in want]
     assert max(w[3] for w in want) > 1000
+
+
+def test_planned_stage_equals_general_path(built, monkeypatch):
+    """pav_cigar_flag planned on the device (ordered INS / DEL split, scan-free sweeps, one synchronisation) against the general
+    path of round 2 (PAV_FLAG_HOST=1: counts read back, radix-sorted DEL rows, max-scan sweeps) on a synthetic haplotype whose
+    planted inversions make clusters of thousands of rows - longer than a 256-row block and than what one lane walks."""
+    from pav_amd import _lib, cigarcall, synth
+    hap = synth.config2(seed=77, scale=0.03, threads=4, pair_frac=0.01)
+    names = hap.ref.names
+    ctx = _lib.Context(0)
+    try:
+        ctx.seq_load(_lib.PAV_ROLE_REF, names, [hap.ref.seqs[n] for n in names])
+        ctx.seq_load(_lib.PAV_ROLE_TIG, hap.tig_names, [hap.tig_seqs[n] for n in hap.tig_names])
+        ctx.cigar_load(*cigarcall.pack_alignments(hap.df_align, names, hap.tig_names))
+        ctx.cigar_call()
+        index = hap.df_align['INDEX'].to_numpy(dtype='int64')
+        trim = hap.df_trim[['POS', 'END', 'INDEX']].set_index('INDEX').astype(int).reindex(list(index), fill_value=-1)
+        tp, te = trim['POS'].to_numpy(dtype='int64'), trim['END'].to_numpy(dtype='int64')
+        got = {}
+        for mode in ('planned', 'general'):
+            if mode == 'general':
+                monkeypatch.setenv('PAV_FLAG_HOST', '1')
+            tables, loci, cnt = ctx.cigar_flag(tp, te, ctx.flag_params(sig_filter=_lib.SIG_SINGLE_CLUSTER))
+            got[mode] = ({k: v.copy() for k, v in tables.items()}, loci.copy(), dict(cnt))
+        monkeypatch.delenv('PAV_FLAG_HOST')
+        for name in got['planned'][0]:
+            assert got['planned'][0][name].tobytes() == got['general'][0][name].tobytes(), name
+        assert got['planned'][1].tobytes() == got['general'][1].tobytes() and got['planned'][2] == got['general'][2]
+        snv = got['planned'][0]['cluster_snv']
+        assert len(snv) > 5 and int(snv['count'].max()) > 1000 and len(got['planned'][0]['insdel_indel']) > 0
+        # a second call on the same context (trim table and ranks already on the device) gives the same
+        tables, loci, cnt = ctx.cigar_flag(tp, te, ctx.flag_params(sig_filter=_lib.SIG_SINGLE_CLUSTER))
+        assert loci.tobytes() == got['planned'][1].tobytes()
+        # ... and a changed trim table is noticed
+        tp2 = tp.copy(); tp2[:] = np.iinfo(np.int64).max // 2
+        tables, loci, cnt = ctx.cigar_flag(tp2, te, ctx.flag_params(sig_filter=_lib.SIG_SINGLE_CLUSTER))
+        assert cnt['n_snv_pass'] == 0 and cnt['n_indel_pass'] == 0 and len(loci) == 0
+    finally:
+        ctx.close()
