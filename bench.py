@@ -283,7 +283,7 @@ def main():
             inv_step(ln)
             lap('flag + scan')
 
-    def run_steps(n, workload=args.workload, only=None):
+    def run_steps(n, workload=args.workload, only=None, fixed_share=False):
         """n passes of the hot path, one haplotype each: step s goes to lane s mod L; the lanes run on their own host threads
         (the library releases the GIL inside its calls), so one haplotype's kernels fill the gaps of the other's host work."""
         use = lanes if only is None else [only]
@@ -305,8 +305,15 @@ def main():
         started = [threading.Event() for _ in use]
         stagger = os.environ.get('PAV_BENCH_STAGGER', 'none')
 
-        def take():
+        share = [0] * len(use)                                  # fixed_share (warm-up): every lane runs ceil(n / L) steps, whatever its pace
+
+        def take(k=None):
             with lock:
+                if fixed_share:
+                    if share[k] >= (n + len(use) - 1) // len(use):
+                        return False
+                    share[k] += 1
+                    return True
                 if counter[0] >= n:
                     return False
                 counter[0] += 1
@@ -317,7 +324,7 @@ def main():
                 if k and stagger != 'none':
                     started[k - 1].wait()
                 first = True
-                while take():
+                while take(k):
                     ln.n_done += 1
                     if first and stagger == 'cigar':
                         ln.ctx.seq_pack(_lib.PAV_ROLE_TIG)
@@ -365,10 +372,12 @@ def main():
             return t_c, float(tt_.item())
         return t_c, t_c
 
-    # Untimed warm-up: W steps as asked, but at least two per lane - a lane's buffers are sized by its first pass and the two
-    # alternating table arenas of its scan by its first two
+    # Untimed warm-up: W steps as asked, but at least two per lane, in equal shares (not from the shared counter of the timed
+    # regions: a lane that is still allocating would be overtaken and start its first pass inside a timed region - an 80 ms
+    # outlier) - a lane's buffers are sized by its first pass and the two alternating table arenas of its scan by its first two
     warmup_run = max(args.warmup, 2 * n_lanes)
-    run_steps(warmup_run)
+    run_steps(warmup_run, fixed_share=True)
+    warmup_run = ((warmup_run + n_lanes - 1) // n_lanes) * n_lanes
 
     # ---- timed region: exactly K steps, profiling off; run R times back to back, the median region is the line's --------
     free_min = [min(ln.ctx.mem_info()[0] for ln in lanes)]

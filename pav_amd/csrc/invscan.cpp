@@ -525,7 +525,6 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
         Scan &sc = scans[i];
         sc.flag.role = PAV_ROLE_REF; sc.flag.chrom = (int)regions[i].ref_id; sc.flag.pos = (int64_t)regions[i].pos; sc.flag.end = (int64_t)regions[i].end;
         if (sc.flag.pos > sc.flag.end) { std::swap(sc.flag.pos, sc.flag.end); sc.flag.is_rev = true; }
-        log(i, "Scanning for inversions in flagged region: " + D.base1(sc.flag) + " (flagged region record id = " + D.region_id(sc.flag) + ")");   // inv.py:194-199
         sc.region_ref = sc.flag;
         D.expand(sc.region_ref, 4000, 0.5);                                          // INITIAL_EXPAND, inv.py:203-204
     });
@@ -744,6 +743,12 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
                         (tl[0] - t_entry) * 1e3, (tl[1] - tl[0]) * 1e3, (tl[2] - tl[1]) * 1e3, (tl[3] - tl[2]) * 1e3, (tl[4] - tl[3]) * 1e3);
     if (timing) fprintf(stderr, "[pav timing] inv_scan_batch %.1f ms: density_batch %.1f, call tables + annotate %.1f, lift + jobs %.2f (lifting %.2f), decisions %.2f\n",
                         (now() - t_start) * 1e3, t_batch * 1e3, t_table * 1e3, t_pre * 1e3, t_lift * 1e3, t_post * 1e3);
+    // the first line of every region's log (inv.py:194-199) is written now, with the last kernels of the scan still running: it
+    // depends on the flagged region alone, and a thousand of them were 0.08 ms in front of the first round
+    pool.run(n_regions, CHUNK, [&](size_t i) {
+        const Scan &sc = scans[i];
+        S->logs[i].insert(0, "Scanning for inversions in flagged region: " + D.base1(sc.flag) + " (flagged region record id = " + D.region_id(sc.flag) + ")\n");
+    });
     for (uint32_t i = 0; i < n_regions; ++i) {
         S->results[i].log_bytes = (uint32_t)S->logs[i].size();
         S->results[i].error_bytes = (uint32_t)S->errors[i].size();

@@ -497,6 +497,29 @@ def scan_for_inv(region_flag, ref_fa_name, tig_fa_name, align_lift, k_util, n_tr
     return sc.result
 
 
+_DEFAULT_SRS = []
+
+
+def _native_srs(srs_tree):
+    """The state-run-smooth lookup as the array of ``pav_srs`` the native driver takes; built once per tree (a scan per pass of
+    a haplotype asks with the same tree every time)."""
+    if srs_tree is None:
+        if not _DEFAULT_SRS:
+            _DEFAULT_SRS.append(get_srs_tree(None))
+        srs_tree = _DEFAULT_SRS[0]
+    ivs = list(getattr(srs_tree, 'intervals', None) or srs_tree)      # SrsTree or a real intervaltree.IntervalTree
+    key = tuple((float(iv.begin), float(iv.end), int(iv.data)) for iv in ivs)
+    cached = getattr(srs_tree, '_pav_native_srs', None)
+    if cached is None or cached[0] != key:
+        arr = (_lib.Srs * max(1, len(ivs)))(*[_lib.Srs(b, e, d, 0) for b, e, d in key])
+        cached = (key, arr, len(ivs))
+        try:
+            srs_tree._pav_native_srs = cached
+        except AttributeError:                                        # an object without a __dict__: built every time
+            pass
+    return cached[1], cached[2]
+
+
 def _native_scan(ctx, region_flags, align_lift, k_util, max_region_size, logs, srs_tree, min_exp_count, ref_index, tig_index,
                  eager_tables=True, log=None, found_out=None):
     """All regions through the library's native driver (pav_inv_scan_batch, csrc/invscan.cpp)."""
@@ -529,11 +552,9 @@ def _native_scan(ctx, region_flags, align_lift, k_util, max_region_size, logs, s
         ctx.inv_load_alignments(aln, text, off)
         align_lift._native_loaded = ctx
         _lap('load_alignments')
-    tree = get_srs_tree(None) if srs_tree is None else srs_tree
-    ivs = list(getattr(tree, 'intervals', None) or tree)            # SrsTree or a real intervaltree.IntervalTree
-    srs = (_lib.Srs * max(1, len(ivs)))(*[_lib.Srs(float(iv.begin), float(iv.end), int(iv.data), 0) for iv in ivs])
+    srs, n_srs = _native_srs(srs_tree)
     params = _lib.InvParams(int(MAX_REGION_SIZE if max_region_size is None else max_region_size),
-                            int(DEFAULT_MIN_EXP_COUNT if min_exp_count is None else min_exp_count), len(ivs),
+                            int(DEFAULT_MIN_EXP_COUNT if min_exp_count is None else min_exp_count), n_srs,
                             ctypes.cast(srs, ctypes.POINTER(_lib.Srs)), density.den_params(k=k_util.k_size),
                             0 if eager_tables else 1, 0)
     regions = np.zeros(len(region_flags), dtype=_lib.INV_REGION_DTYPE)
