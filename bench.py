@@ -372,10 +372,10 @@ def main():
             return t_c, float(tt_.item())
         return t_c, t_c
 
-    # Untimed warm-up: W steps as asked, but at least two per lane, in equal shares (not from the shared counter of the timed
+    # Untimed warm-up: W steps as asked, but at least three per lane, in equal shares (not from the shared counter of the timed
     # regions: a lane that is still allocating would be overtaken and start its first pass inside a timed region - an 80 ms
     # outlier) - a lane's buffers are sized by its first pass and the two alternating table arenas of its scan by its first two
-    warmup_run = max(args.warmup, 2 * n_lanes)
+    warmup_run = max(args.warmup, 3 * n_lanes)
     run_steps(warmup_run, fixed_share=True)
     warmup_run = ((warmup_run + n_lanes - 1) // n_lanes) * n_lanes
 

@@ -143,7 +143,7 @@ def main():
     sizes = {f: os.path.getsize(os.path.join(work, f)) for f in sorted(os.listdir(work)) if os.path.isfile(os.path.join(work, f))}
     print(json.dumps({'workload': f'one synthetic hg38-shaped haplotype, seed {args.seed}, scale {args.scale}', 'aligned_bp': aligned_bp,
                       'snv_rows': n_snv, 'insdel_rows': n_ins, 'flagged_regions': int(df_flag.shape[0]), 'scanned_regions': len(regions),
-                      'inv_calls': len(calls), 'stages_s': stages, 'total_s': total,
+                      'inv_calls': len(calls), 'inv_sig_filter': args.inv_sig_filter, 'stages_s': stages, 'total_s': total,
                       'end_to_end_Gbp_per_s': round(aligned_bp / total / 1e9, 3), 'writer_threads': args.threads, 'gzip_level': args.gzip_level, 'inputs_written_s': round(t_inputs, 1),
                       'host_cores': os.cpu_count(), 'usable_cores': effective_cpus(), 'file_bytes': sizes}), flush=True)
     if args.out is None:

@@ -165,10 +165,10 @@ def busy(db, out, a, b, mark='k_kmer_lds'):
         t[0] += 1
         t[1] += e - s
     total = sum(v[1] for v in per.values())
-    packs = per.get('walk_chunks', [0, 0.0])[0]            # one per pav_cigar_call = one per pass
+    packs = per.get('tok_tiles', [0, 0.0])[0]              # one per pav_cigar_call = one per pass
     with open(out, 'w') as fh:
         fh.write(f'# device occupancy, window of {(w1 - w0) / 1e6:.2f} ms starting {(w0 - t_first) / 1e6:.2f} ms after the first kernel ({db})\n')
-        fh.write(f'# passes in the window (walk_chunks launches: one per CIGAR-call): {packs}  ->  {(w1 - w0) / 1e6 / max(1, packs):.3f} ms of wall time per pass\n')
+        fh.write(f'# passes in the window (tok_tiles launches: one per CIGAR-call): {packs}  ->  {(w1 - w0) / 1e6 / max(1, packs):.3f} ms of wall time per pass\n')
         fh.write(f'wall_ms {(w1 - w0) / 1e6:.3f}   busy_ms (>= 1 kernel running) {union / 1e6:.3f} = {union / (w1 - w0):.3f} of wall   '
                  f'sum_of_kernel_ms {total / 1e6:.3f} = {total / (w1 - w0):.3f} of wall (kernels of the lanes overlap)\n')
         fh.write(f'{"kernel":34s} {"launches":>8s} {"total_ms":>10s} {"per_pass_ms":>12s}\n')
