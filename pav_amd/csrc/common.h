@@ -34,6 +34,16 @@ struct DevBuf {
         cap = want;
         return hipSuccess;
     }
+    // At least `bytes`, and when it has to grow exactly `bytes` (buffers that change hands must not outgrow each other in turn)
+    hipError_t reserve_exact(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (view) { p = nullptr; cap = 0; view = false; }
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = bytes;
+        return hipSuccess;
+    }
     // Make this buffer `bytes` of another allocation (several small buffers laid out in one arena travel in one copy and are
     // cleared by one fill).  An allocation of its own is given up.
     void alias(void *q, size_t bytes) {
@@ -211,23 +221,28 @@ struct CallFetch {              // one call of the batch still resident on the d
 // The packed call tables of one scan round on the device (+ the flank k-mer sets and descriptors in front of / behind them)
 // and the copies that bring them to the host block of the round.
 struct CallStage {
-    DevBuf buf;
+    DevBuf buf;                           // the columns: packed rows of the round's calls, or - a round whose calls make up most of the
+                                          // batch - the batch's own column block, handed over without a copy (density_fetch_calls)
+    DevBuf aux;                           // flank k-mer sets and descriptors
     std::vector<uint8_t> desc_host;
     struct Copy { const void *src; size_t dst_off; size_t bytes; };   // dst_off: into the round's host block
     Copy copies[2];
     int n_copies = 0;
-    uint64_t rows = 0;                    // table rows of the round; host block = whole-round columns K0 | K1 | K2 | KMER | INDEX |
-    void *host = nullptr;                 // STATE_MER | STATE | FLANK | MATCH (40 bytes per row), bound by the caller before stage_copy
-    struct Entry { uint32_t owner; uint32_t n; uint64_t row0; bool has_k1; };   // the calls of the round in block order
+    uint64_t rows = 0;                    // rows per column of the block (packed: the calls' rows; handed over: the batch's rows); host
+    void *host = nullptr;                 // block = whole-round columns K0 | K1 | K2 | KMER | INDEX | STATE_MER | STATE | FLANK | MATCH
+                                          // (40 bytes per row), bound by the caller before stage_copy
+    std::vector<uint64_t> row0;           // first row of every call in the columns, in the order of the calls given (density_fetch_calls)
+    struct Entry { uint32_t owner; uint32_t n; uint64_t row0; bool has_k1; };   // the calls of the round
     std::vector<Entry> entries;
+    void release() { buf.release(); aux.release(); }
 };
-// Density tables + FLANK / MATCH of all calls of the last batch, packed into `stage` in the host block's column order.
-// k1_rows: rows of the leading calls whose KERN_FWDREV column is wanted; the column of the calls behind them (no FWDREV
-// k-mers: all zeros, scripts/density.py:313-323) is not sent over PCIe.  = all rows to copy everything.
-// The copies that bring the block to stage.host are left in stage.copies for stage_copy(); with copy_now the copy stream is
-// made to wait for the gather and they are queued at once (stage.host must be bound), otherwise the tables stay in HBM until
-// a reader asks for them.
-int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls, uint64_t k1_rows, CallStage &stage, bool copy_now);
+// Density tables + FLANK / MATCH of all calls of the last batch, put into `stage` in the host block's column order; fills
+// stage.rows and stage.row0.  k1_rows (packed rounds): rows of the leading calls whose KERN_FWDREV column is wanted; the column of
+// the calls behind them (no FWDREV k-mers: all zeros, scripts/density.py:313-323) is not sent over PCIe.  = all rows to copy
+// everything.  The copies that bring the block to stage.host are left in stage.copies: the tables stay in HBM until a reader asks
+// for them (stage_copy), or the caller binds stage.host and calls density_copy_now.
+int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls, uint64_t k1_rows, CallStage &stage);
+int density_copy_now(pav_ctx *ctx, CallStage &stage);     // the copy stream waits for the stage's kernels, then stage_copy
 int stage_copy(pav_ctx *ctx, CallStage &stage);
 
 // ---- device helpers shared by kernels ---------------------------------------------------------------------

@@ -90,6 +90,10 @@ struct DensityState {
     // comes back in ONE copy.  (Separate pageable copies and fills cost ~10 us each with the stream idle in between: a dozen per
     // scan round.)
     DevBuf in_arena, zero_arena;
+    // The columns of the density tables (KERN x 3, KMER, INDEX, STATE_MER, STATE, and FLANK / MATCH of the calls) are slices of one
+    // block in the order of a round's host block: a round whose calls are most of the batch hands the block to its stage as it is.
+    DevBuf table_block, flank, match;
+    uint64_t block_rows = 0;
     void *pin_in = nullptr; size_t pin_in_cap = 0;
     void *pinned_in(size_t bytes) {
         if (bytes <= pin_in_cap) return pin_in;
@@ -124,7 +128,7 @@ struct DensityState {
                          &index, &state_mer, &state, &kmer, &kern[0], &kern[1], &kern[2], &list[0], &list[1], &list[2],
                          &pscaled[0], &pscaled[1], &pscaled[2], &fill_list, &tiles, &events, &ev_count, &scratch, &run_arena, &win_fill, &ks[0], &ks[1], &ks[2], &ss,
                          &guard, &guard_entries, &samp_flag, &row_flag, &ftiles, &tile_heads, &tile_head_cnt, &heads, &plan_flags, &pow_tab,
-                         &in_arena, &zero_arena};
+                         &in_arena, &zero_arena, &table_block, &flank, &match};
         for (DevBuf *b : all) b->release();
         if (pin) { (void)hipHostFree(pin); pin = nullptr; pin_cap = 0; }
         if (pin_in) { (void)hipHostFree(pin_in); pin_in = nullptr; pin_in_cap = 0; }
@@ -439,6 +443,7 @@ __global__ __launch_bounds__(LDS_THREADS) void k_kmer_lds(const PartItem *__rest
     __shared__ uint32_t cnt4[LDS_SLOTS / 4];
     __shared__ uint32_t flags;
     const PartItem it = items[blockIdx.x];
+    if (it.job == ~0u) return;                                          // padding of the XCD-grouped order
     const JobDev jd = jobs[it.job];
     const uint32_t P = jd.n_parts;
     for (int s = threadIdx.x; s < LDS_SLOTS; s += LDS_THREADS) keys[s] = EMPTY_KEY;
@@ -1691,8 +1696,37 @@ __global__ __launch_bounds__(256) void k_gather_calls(const GatherCall *__restri
     }
 }
 
-int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls, uint64_t k1_rows, CallStage &stage, bool copy_now) {
+// FLANK / MATCH of the calls' rows where they are (a round whose column block goes to the stage as a whole): what k_gather_calls
+// does, without the copy.  Workgroup b works on 256 rows of the calls counted through (dst_off), as there.
+__global__ __launch_bounds__(256) void k_annotate_calls(const GatherCall *__restrict__ calls, uint32_t n_calls, uint32_t total, int k,
+                                                        const uint32_t *__restrict__ index, const unsigned long long *__restrict__ kmer,
+                                                        const unsigned long long *__restrict__ keys, uint8_t *__restrict__ flank,
+                                                        uint8_t *__restrict__ match) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    uint32_t lo = 0, hi = n_calls;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (calls[mid].dst_off <= t) lo = mid; else hi = mid; }
+    const GatherCall &c = calls[lo];
+    const uint64_t src = c.src_off + (t - c.dst_off);
+    const int64_t q = (int64_t)index[src] + c.base;                        // QRY_INDEX (inv.py:519)
+    uint8_t f = 0;
+    if (q >= c.up_pos && q < c.up_end - k) f = 1;                          // inv.py:524-527
+    if (q >= c.dn_pos && q < c.dn_end - k) f = 2;                          // inv.py:529-532
+    uint8_t m = 0;
+    if (f) {                                                               // raw KMER against canonical sets (inv.py:537-553)
+        const unsigned long long km = kmer[src];
+        const bool in_up = table_has(keys + c.key_up, 0, c.mask_up, km), in_dn = table_has(keys + c.key_dn, 0, c.mask_dn, km);
+        const bool same = f == 1 ? in_up : in_dn, other = f == 1 ? in_dn : in_up;
+        m = same ? (other ? 3 : 1) : (other ? 2 : 3);                      // KMER_LOC_STATE: NA / OTHER / SAME / NA
+    }
+    flank[src] = f;
+    match[src] = m;
+}
+
+int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls, uint64_t k1_rows, CallStage &stage) {
     stage.n_copies = 0;
+    stage.row0.clear();
+    stage.rows = 0;
     if (calls.empty()) return PAV_OK;
     DensityState *D = dstate(ctx);
     if (!D->valid) return fail(ctx, PAV_E_STATE, "density_fetch_calls: no batch resident");
@@ -1721,20 +1755,20 @@ int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls, uint6
         keys += (uint64_t)cap_up + cap_dn;
         total += f.n;
     }
-    // device staging, owned by the caller for as long as the tables may be asked for:
-    // [hash keys][packed columns in the host block's order][descriptors]
-    const uint64_t col_bytes = total * 40;
+    // A round whose calls are most of the batch (the second round of a haplotype: 46 regions grown to ~200 kbp, all of them calls)
+    // keeps its tables where the batch wrote them: the batch's column block changes hands with the stage's (the one a scan before
+    // the last handed over), and only FLANK / MATCH are computed.  Packing such a round read and wrote 80 bytes per row - 0.15 ms,
+    // the largest kernel of the scan after the k-mer sets.  PAV_CALL_GATHER=1: always pack.
+    const uint64_t a_t = D->block_rows;
+    const bool dense = total * 2 >= a_t && getenv("PAV_CALL_GATHER") == nullptr;
+    // device staging, owned by the caller for as long as the tables may be asked for: aux = [hash keys][descriptors],
+    // buf = the columns in the host block's order
+    const uint64_t col_bytes = (dense ? a_t : total) * 40;
     const uint64_t desc_bytes = sizeof(GatherCall) * gc.size() + sizeof(CanonJob) * cj.size();
     if (!D->gathered) PAV_HIP(ctx, hipEventCreateWithFlags(&D->gathered, hipEventDisableTiming));
-    PAV_HIP(ctx, stage.buf.reserve(8ull * keys + col_bytes + desc_bytes + 512));
-    unsigned long long *d_keys = stage.buf.as<unsigned long long>();
-    uint8_t *d_cols = reinterpret_cast<uint8_t *>(d_keys + keys);
-    double *g_k0 = reinterpret_cast<double *>(d_cols), *g_k1 = g_k0 + total, *g_k2 = g_k1 + total;
-    unsigned long long *g_kmer = reinterpret_cast<unsigned long long *>(g_k2 + total);
-    uint32_t *g_index = reinterpret_cast<uint32_t *>(g_kmer + total);
-    int8_t *g_sm = reinterpret_cast<int8_t *>(g_index + total), *g_st = g_sm + total;
-    uint8_t *g_fl = reinterpret_cast<uint8_t *>(g_st + total), *g_ma = g_fl + total;
-    GatherCall *d_gc = reinterpret_cast<GatherCall *>(d_cols + (col_bytes + 63) / 64 * 64);
+    PAV_HIP(ctx, stage.aux.reserve(8ull * keys + desc_bytes + 512));
+    unsigned long long *d_keys = stage.aux.as<unsigned long long>();
+    GatherCall *d_gc = reinterpret_cast<GatherCall *>(d_keys + keys);
     CanonJob *d_cj = reinterpret_cast<CanonJob *>(d_gc + gc.size());
     std::vector<uint8_t> &desc_host = stage.desc_host;                 // stays alive until the upload has run
     desc_host.resize(desc_bytes);
@@ -1744,26 +1778,51 @@ int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls, uint6
     PAV_HIP(ctx, hipMemcpyAsync(d_gc, desc_host.data(), desc_bytes, hipMemcpyHostToDevice, st));
     { int rcw = wait_planes(ctx); if (rcw != PAV_OK) return rcw; }
     if (tiles) PAV_LAUNCH(ctx, "k_canon_insert", k_canon_insert_batch, tiles, 256, 0, RV, d_cj, (uint32_t)cj.size(), k, d_keys);
-    PAV_LAUNCH(ctx, "k_gather_calls", k_gather_calls, (uint32_t)((total + 255) / 256), 256, 0, d_gc, (uint32_t)gc.size(), (uint32_t)total, k,
-               D->index.as<uint32_t>(), D->state_mer.as<int8_t>(), D->state.as<int8_t>(), D->kern[0].as<double>(), D->kern[1].as<double>(),
-               D->kern[2].as<double>(), D->kmer.as<unsigned long long>(), d_keys, g_index, g_sm, g_st, g_k0, g_k1, g_k2, g_kmer, g_fl, g_ma);
     // Host side (invscan.cpp): the round's block is laid out as whole-round columns, K0 | K1 | K2 | KMER | INDEX | STATE_MER |
-    // STATE | FLANK | MATCH, exactly like the packed device columns: one copy (two when the tail of K1 stays behind).
-    stage.rows = total;
-    if (k1_rows >= total) {
-        stage.copies[stage.n_copies++] = CallStage::Copy{d_cols, 0, col_bytes};
-    } else {                                                        // K0 | leading part of K1, then K2 | ... | MATCH
-        stage.copies[stage.n_copies++] = CallStage::Copy{d_cols, 0, 8ull * (total + k1_rows)};
-        stage.copies[stage.n_copies++] = CallStage::Copy{g_k2, 16ull * total, col_bytes - 16ull * total};
+    // STATE | FLANK | MATCH, exactly like the device columns: one copy (two when the tail of K1 stays behind).
+    if (dense) {
+        PAV_LAUNCH(ctx, "k_annotate_calls", k_annotate_calls, (uint32_t)((total + 255) / 256), 256, 0, d_gc, (uint32_t)gc.size(), (uint32_t)total, k,
+                   D->index.as<uint32_t>(), D->kmer.as<unsigned long long>(), d_keys, D->flank.as<uint8_t>(), D->match.as<uint8_t>());
+        // the blocks change hands (host side only: the kernels above and the views of the batch keep their addresses); the block
+        // the batch gets is never smaller than the one it gives, so the next batch does not allocate
+        PAV_HIP(ctx, stage.buf.reserve_exact(D->table_block.cap));
+        std::swap(stage.buf, D->table_block);
+        stage.rows = a_t;
+        for (const GatherCall &g : gc) stage.row0.push_back(g.src_off);
+        stage.copies[stage.n_copies++] = CallStage::Copy{stage.buf.p, 0, col_bytes};
+    } else {
+        PAV_HIP(ctx, stage.buf.reserve(col_bytes + 64));
+        uint8_t *d_cols = stage.buf.as<uint8_t>();
+        double *g_k0 = reinterpret_cast<double *>(d_cols), *g_k1 = g_k0 + total, *g_k2 = g_k1 + total;
+        unsigned long long *g_kmer = reinterpret_cast<unsigned long long *>(g_k2 + total);
+        uint32_t *g_index = reinterpret_cast<uint32_t *>(g_kmer + total);
+        int8_t *g_sm = reinterpret_cast<int8_t *>(g_index + total), *g_st = g_sm + total;
+        uint8_t *g_fl = reinterpret_cast<uint8_t *>(g_st + total), *g_ma = g_fl + total;
+        PAV_LAUNCH(ctx, "k_gather_calls", k_gather_calls, (uint32_t)((total + 255) / 256), 256, 0, d_gc, (uint32_t)gc.size(), (uint32_t)total, k,
+                   D->index.as<uint32_t>(), D->state_mer.as<int8_t>(), D->state.as<int8_t>(), D->kern[0].as<double>(), D->kern[1].as<double>(),
+                   D->kern[2].as<double>(), D->kmer.as<unsigned long long>(), d_keys, g_index, g_sm, g_st, g_k0, g_k1, g_k2, g_kmer, g_fl, g_ma);
+        stage.rows = total;
+        for (const GatherCall &g : gc) stage.row0.push_back(g.dst_off);
+        if (k1_rows >= total) {
+            stage.copies[stage.n_copies++] = CallStage::Copy{d_cols, 0, col_bytes};
+        } else {                                                        // K0 | leading part of K1, then K2 | ... | MATCH
+            stage.copies[stage.n_copies++] = CallStage::Copy{d_cols, 0, 8ull * (total + k1_rows)};
+            stage.copies[stage.n_copies++] = CallStage::Copy{g_k2, 16ull * total, col_bytes - 16ull * total};
+        }
     }
     if (getenv("PAV_TIMING")) fprintf(stderr, "[pav timing]   call tables: %zu calls, %llu rows (%.1f MB %s), %llu hash slots, %u insert tiles\n",
-                                      calls.size(), (unsigned long long)total, (col_bytes - 8.0 * (double)(total - std::min<uint64_t>(k1_rows, total))) / 1e6,
-                                      copy_now ? "to the host" : "packed, resident", (unsigned long long)keys, tiles);
-    if (!copy_now) return PAV_OK;                                   // the tables stay in HBM until somebody asks (stage_copy)
-    // the copy runs on the copy stream behind the scan (wait_tables() before the host reads the block)
-    // (a hand-rolled 64-workgroup copy kernel was tried instead of the runtime's copy to keep the chip free for the next
-    // step: 16.6 ms per step against 13.9 ms, the runtime's copy is the better one)
-    PAV_HIP(ctx, hipEventRecord(D->gathered, st));
+                                      calls.size(), (unsigned long long)total, (double)col_bytes / 1e6,
+                                      dense ? "resident, the batch's own block" : "packed, resident", (unsigned long long)keys, tiles);
+    return PAV_OK;                                                  // the tables stay in HBM until somebody asks (stage_copy)
+}
+
+// The copy runs on the copy stream behind the scan (wait_tables() before the host reads the block).
+// (a hand-rolled 64-workgroup copy kernel was tried instead of the runtime's copy to keep the chip free for the next
+// step: 16.6 ms per step against 13.9 ms, the runtime's copy is the better one)
+int density_copy_now(pav_ctx *ctx, CallStage &stage) {
+    DensityState *D = dstate(ctx);
+    if (!D->gathered) PAV_HIP(ctx, hipEventCreateWithFlags(&D->gathered, hipEventDisableTiming));
+    PAV_HIP(ctx, hipEventRecord(D->gathered, ctx->stream));
     PAV_HIP(ctx, hipStreamWaitEvent(ctx->stream3, D->gathered, 0));
     return stage_copy(ctx, stage);
 }
@@ -1874,13 +1933,34 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     }
     D->arena_t = a_t;
     const uint32_t n_tiles_r = (uint32_t)tile_job_r.size(), n_tiles_t = (uint32_t)tile_job_t.size();
-    {   // one workgroup per (job, partition); the long scans first
+    {   // One workgroup per (job, partition), the long scans first - and all partitions of a job on ONE XCD (workgroup b runs on
+        // XCD b % 8, observed; used for speed only): the workgroups of a job answer into the same byte arrays, one byte per
+        // contig k-mer at scattered positions, and read the same windows of the planes.  Spread over the eight L2s every line of
+        // the answers left the chip once per XCD that had touched it (205 MB written per launch for 20 MB of answers); in one L2
+        // the lines fill up before they go.  PAV_XCD_GROUP=0: the plain order.
         std::vector<uint32_t> order;
         for (uint32_t j = 0; j < n_jobs; ++j) if (D->h_jobs[j].n_parts) order.push_back(j);
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
             return (uint64_t)D->h_jobs[a].ref_len + D->h_jobs[a].tig_len > (uint64_t)D->h_jobs[b].ref_len + D->h_jobs[b].tig_len; });
-        for (uint32_t j : order)
-            for (uint32_t p = 0; p < D->h_jobs[j].n_parts; ++p) items.push_back(PartItem{j, p});
+        static const bool group = [] { const char *e = getenv("PAV_XCD_GROUP"); return !(e && e[0] == '0'); }();
+        if (!group) {
+            for (uint32_t j : order)
+                for (uint32_t p = 0; p < D->h_jobs[j].n_parts; ++p) items.push_back(PartItem{j, p});
+        } else {
+            constexpr int XCDS = 8;
+            std::vector<PartItem> q[XCDS];
+            for (uint32_t j : order) {                                   // longest first, each to the shortest queue
+                int best = 0;
+                for (int x = 1; x < XCDS; ++x) if (q[x].size() < q[best].size()) best = x;
+                for (uint32_t p = 0; p < D->h_jobs[j].n_parts; ++p) q[best].push_back(PartItem{j, p});
+            }
+            size_t longest = 0;
+            for (int x = 0; x < XCDS; ++x) longest = std::max(longest, q[x].size());
+            items.reserve(longest * XCDS);
+            for (size_t r = 0; r < longest; ++r)
+                for (int x = 0; x < XCDS; ++x) items.push_back(r < q[x].size() ? q[x][r] : PartItem{~0u, 0u});   // ~0: nothing to do
+            while (!items.empty() && items.back().job == ~0u) items.pop_back();
+        }
     }
 
     // ---- what is known before anything runs (device-planned batches: upper bounds; rows <= contig positions of the region) -----
@@ -1941,14 +2021,21 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     PAV_HIP(ctx, D->st_tmp.reserve(a_t + 64));
     PAV_HIP(ctx, D->tile_sum.reserve(16ull * n_tiles_t));
     PAV_HIP(ctx, D->tile_pre.reserve(32ull * (n_tiles_t + 1)));
-    PAV_HIP(ctx, D->index.reserve(4 * a_t));
-    PAV_HIP(ctx, D->state_mer.reserve(a_t));
-    PAV_HIP(ctx, D->state.reserve(a_t));
-    PAV_HIP(ctx, D->kmer.reserve(8 * a_t));
+    PAV_HIP(ctx, D->table_block.reserve(40ull * a_t + 64));          // K0 | K1 | K2 | KMER | INDEX | STATE_MER | STATE | FLANK | MATCH, a_t rows each
+    {
+        uint8_t *tb = D->table_block.as<uint8_t>();
+        for (int s = 0; s < 3; ++s) D->kern[s].alias(tb + 8ull * s * a_t, 8ull * a_t);
+        D->kmer.alias(tb + 24ull * a_t, 8ull * a_t);
+        D->index.alias(tb + 32ull * a_t, 4ull * a_t);
+        D->state_mer.alias(tb + 36ull * a_t, a_t);
+        D->state.alias(tb + 37ull * a_t, a_t);
+        D->flank.alias(tb + 38ull * a_t, a_t);
+        D->match.alias(tb + 39ull * a_t, a_t);
+        D->block_rows = a_t;
+    }
     PAV_HIP(ctx, D->fill_list.reserve(4 * a_t));
     PAV_HIP(ctx, D->win_fill.reserve(a_t));
     for (int s = 0; s < 3; ++s) {
-        PAV_HIP(ctx, D->kern[s].reserve(8 * a_t));
         PAV_HIP(ctx, D->list[s].reserve(4 * a_t));
         PAV_HIP(ctx, D->pscaled[s].reserve(8 * a_t));
     }

@@ -95,7 +95,7 @@ struct InvState {
     void next_pinned() { cur_set ^= 1; for (auto &b : pinned_sets[cur_set]) b.used = 0; stage_used = 0; }
     void free_pinned() {
         for (auto &set : pinned_sets) { for (auto &b : set) (void)hipHostFree(b.p); set.clear(); }
-        for (auto &set : stage_sets) { for (auto &st : set) st->buf.release(); set.clear(); }
+        for (auto &set : stage_sets) { for (auto &st : set) st->release(); set.clear(); }
     }
     void *pin_alloc(size_t bytes) {
         auto &pinned = pinned_sets[cur_set];
@@ -722,17 +722,19 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
             CallStage &stg = S->next_stage();
             stg.entries.clear();
             stg.host = nullptr;
-            size_t o = 0;
+            (void)rows;
+            rc = density_fetch_calls(ctx, round_calls, k1_rows, stg);     // queued; says where every call's rows sit (stg.row0, stg.rows)
+            if (rc != PAV_OK) return rc;
             for (size_t c = 0; c < round_calls.size(); ++c) {
-                stg.entries.push_back(CallStage::Entry{round_owner[c], round_calls[c].n, o, round_k1[c] != 0});
+                stg.entries.push_back(CallStage::Entry{round_owner[c], round_calls[c].n, stg.row0[c], round_k1[c] != 0});
                 auto tab = std::make_unique<InvTable>();            // rows known now; the columns are bound with the host block
                 tab->n = round_calls[c].n;
                 S->tables[round_owner[c]] = std::move(tab);
-                o += round_calls[c].n;
             }
-            stg.rows = rows;
-            if (!pp->lazy_tables) { const int rcb = bind_round(ctx, S, stg); if (rcb != PAV_OK) return rcb; }
-            rc = density_fetch_calls(ctx, round_calls, k1_rows, stg, pp->lazy_tables == 0);
+            if (!pp->lazy_tables) {
+                rc = bind_round(ctx, S, stg);
+                if (rc == PAV_OK) rc = density_copy_now(ctx, stg);
+            }
             t_table += now() - t0;
             if (rc != PAV_OK) return rc;
         }
