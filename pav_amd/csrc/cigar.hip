@@ -1605,6 +1605,7 @@ int pav_cigar_load(pav_ctx *ctx, uint32_t n_aln, const pav_aln *aln, const uint8
     if (!ctx) return PAV_E_ARG;
     if (n_aln && (!aln || !cigar_off)) return fail(ctx, PAV_E_ARG, "pav_cigar_load: null input");
     PAV_HIP(ctx, hipSetDevice(ctx->device));
+    { const int rch = wait_homology(ctx); if (rch != PAV_OK) return rch; }     // the scans of the last call read the alignment rows
     const uint64_t T = n_aln ? cigar_off[n_aln] : 0;
     if (T && !cigar_text) return fail(ctx, PAV_E_ARG, "pav_cigar_load: null CIGAR text");
     for (uint32_t r = 0; r < n_aln; ++r) {
@@ -1673,6 +1674,7 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
     if (!ctx) return PAV_E_ARG;
     if (!ctx->cigar_loaded) return fail(ctx, PAV_E_STATE, "pav_cigar_call: pav_cigar_load has not been called");
     PAV_HIP(ctx, hipSetDevice(ctx->device));
+    { const int rch = wait_homology(ctx); if (rch != PAV_OK) return rch; }     // the scans of the last call: their records are rewritten
     memset(&ctx->counts, 0, sizeof ctx->counts);
     memset(&ctx->cigar_err, 0, sizeof ctx->cigar_err);
     ctx->cigar_called = false;
@@ -1724,25 +1726,25 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
         A.n_tiles = B.n_tiles; A.tile_pre = B.tile_pre; A.rowbase = B.rowbase; A.chunk_row = B.chunk_row; A.tile_last = B.tile_last;
         A.ref = SA.ref; A.tig = SA.tig;
         A.snv = ctx->d_snv.as<pav_snv>(); A.indel = ctx->d_indel.as<pav_indel>();
-        // The stubs first: they and the homology scans are the critical path (the flagging that follows waits for them).
+        // The stubs first; then the homology scans (+ SEQ) on the side stream and the SNV rows on this one, next to each other
+        // (13 M isolated line fetches; the scans draw on the same budget).  What follows a call on this stream - the flagging,
+        // the inversion scan - reads POS / END / SVLEN of the stubs and the SNV rows, never the homology columns or SEQ: it is
+        // not made to wait for the scans (round 2 had them on this stream: the flagging, and the host work behind it, began
+        // 0.1 ms later).  Readers of the finished records wait (wait_homology: fetch, table writers, the next call).
         if (totals[3]) PAV_LAUNCH(ctx, "walk_indel", walk_emit<WALK_INDEL>, B.n_tiles, 256, 0, A);
-        // SNV rows: on the side stream, beside the homology scans of the main stream (13 M isolated sector fetches; the scans
-        // draw on the same budget)
         const bool skip_snv = stage && !strcmp(stage, "hom");     // debugging: the homology scans with nothing beside them
-        if (totals[2] && !skip_snv) {
-            PAV_HIP(ctx, hipEventRecord(ctx->snv_ready, ctx->stream));
-            PAV_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->snv_ready, 0));
-            PAV_LAUNCH_ON(ctx, ctx->stream2, "walk_snv", walk_emit<WALK_SNV>, B.n_tiles, 256, 0, A);
-            PAV_HIP(ctx, hipEventRecord(ctx->snv_done, ctx->stream2));
-        }
         if (totals[3] && !(stage && !strcmp(stage, "indel"))) {
             { int rcw = wait_planes(ctx); if (rcw != PAV_OK) return rcw; }   // the packed planes may still be in flight
+            PAV_HIP(ctx, hipEventRecord(ctx->snv_ready, ctx->stream));       // (the stubs are written, the planes packed)
+            PAV_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->snv_ready, 0));
             // one wave per workgroup: the wave lifetimes are heavy-tailed (one long tandem repeat keeps a wave for tens of
             // microseconds), and a 256-lane workgroup holds its CU slot until the slowest of its four waves is done (0.34 -> 0.22 ms)
-            PAV_LAUNCH(ctx, "homology_kernel", homology_kernel, (uint32_t)((totals[3] + 63) / 64), 64, 0,
-                       ctx->d_indel.as<pav_indel>(), totals[3], ctx->d_aln.as<pav_aln>(), A.ref, A.tig, ctx->d_seqblob.as<uint8_t>());
+            PAV_LAUNCH_ON(ctx, ctx->stream2, "homology_kernel", homology_kernel, (uint32_t)((totals[3] + 63) / 64), 64, 0,
+                          ctx->d_indel.as<pav_indel>(), totals[3], ctx->d_aln.as<pav_aln>(), A.ref, A.tig, ctx->d_seqblob.as<uint8_t>());
+            PAV_HIP(ctx, hipEventRecord(ctx->hom_done, ctx->stream2));
+            ctx->hom_pending = true;
         }
-        if (totals[2] && !skip_snv) PAV_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->snv_done, 0));   // later readers of the SNV rows use this stream
+        if (totals[2] && !skip_snv) PAV_LAUNCH(ctx, "walk_snv", walk_emit<WALK_SNV>, B.n_tiles, 256, 0, A);
     }
     if (counts) *counts = ctx->counts;
     ctx->cigar_called = true;
@@ -1843,6 +1845,7 @@ int pav_cigar_fetch(pav_ctx *ctx, pav_snv *snv, pav_indel *indel, uint8_t *seq_b
     if (!ctx) return PAV_E_ARG;
     if (!ctx->cigar_called) return fail(ctx, PAV_E_STATE, "pav_cigar_fetch: no successful pav_cigar_call to fetch from");
     PAV_HIP(ctx, hipSetDevice(ctx->device));
+    { const int rch = wait_homology(ctx); if (rch != PAV_OK) return rch; }
     if (snv && ctx->counts.n_snv)
         PAV_HIP(ctx, hipMemcpyAsync(snv, ctx->d_snv.p, sizeof(pav_snv) * ctx->counts.n_snv, hipMemcpyDeviceToHost, ctx->stream));
     if (indel && ctx->counts.n_indel)

@@ -128,6 +128,8 @@ struct pav_ctx {
     bool tables_pending = false;
     hipEvent_t tables_done_prev = nullptr;   // same for the scan before it: its tables live in the other pinned arena, so a new
     bool tables_pending_prev = false;        // scan does not wait for them (the two are swapped when a scan starts)
+    hipEvent_t hom_done = nullptr;        // pav_cigar_call: recorded behind the homology scans on stream2 (wait_homology)
+    bool hom_pending = false;
     hipEvent_t snv_ready = nullptr, snv_done = nullptr;   // pav_cigar_call: the SNV rows are written on stream2 (behind the pack),
                                                           // next to the homology scans of the main stream
     hipEvent_t pack_done[2] = {nullptr, nullptr};   // pav_seq_pack: orders the side stream's pack behind the main stream
@@ -186,6 +188,7 @@ int fail(pav_ctx *ctx, int code, const char *fmt, ...);
 int prof_begin(pav_ctx *ctx, const char *name, hipStream_t st = nullptr);
 void prof_end(pav_ctx *ctx, int token, hipStream_t st = nullptr);
 int wait_tables(pav_ctx *ctx);            // host waits until every queued call-table copy has landed
+int wait_homology(pav_ctx *ctx);          // make ctx->stream wait for the homology scans of the last pav_cigar_call (stream2)
 int wait_planes(pav_ctx *ctx);            // make ctx->stream wait for any pack still running on stream2
 // Contig planes are packed on demand (ctx.hip "lazy contig pack"): a consumer that streams the whole arena calls
 // need_planes_full, one that reads spans [abs, abs + len) calls need_planes_spans; both order the pack before what the caller

@@ -61,6 +61,13 @@ int wait_planes(pav_ctx *ctx) {
     return PAV_OK;
 }
 
+int wait_homology(pav_ctx *ctx) {
+    if (!ctx->hom_pending) return PAV_OK;
+    PAV_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->hom_done, 0));
+    ctx->hom_pending = false;
+    return PAV_OK;
+}
+
 int wait_tables(pav_ctx *ctx) {
     if (!ctx->tables_pending) return PAV_OK;
     PAV_HIP(ctx, hipEventSynchronize(ctx->tables_done));
@@ -293,6 +300,7 @@ pav_ctx *pav_create(int device_id) {
         (e = hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, prio_lo)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->tables_done, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->tables_done_prev, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->hom_done, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->snv_ready, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&ctx->snv_done, hipEventDisableTiming)) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void **>(&ctx->h_status), 256, hipHostMallocDefault)) != hipSuccess ||
@@ -333,6 +341,7 @@ void pav_destroy(pav_ctx *ctx) {
     (void)hipStreamDestroy(ctx->stream3);
     (void)hipEventDestroy(ctx->tables_done);
     (void)hipEventDestroy(ctx->tables_done_prev);
+    (void)hipEventDestroy(ctx->hom_done);
     (void)hipEventDestroy(ctx->snv_ready);
     (void)hipEventDestroy(ctx->snv_done);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
@@ -355,6 +364,7 @@ int pav_sync(pav_ctx *ctx) {
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream3));
     ctx->tables_pending = false;
     ctx->tables_pending_prev = false;
+    ctx->hom_pending = false;
     return PAV_OK;
 }
 
@@ -373,6 +383,7 @@ int pav_seq_load(pav_ctx *ctx, int role, uint32_t n_seq, const uint8_t *const *a
         total += len[i];
     }
     PAV_HIP(ctx, hipSetDevice(ctx->device));
+    { const int rch = wait_homology(ctx); if (rch != PAV_OK) return rch; }     // the scans of the last call read the arenas
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream2));   // a re-pack of the old arena may still be running
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->pack_pending[role] = false;
@@ -420,6 +431,7 @@ int pav_seq_share(pav_ctx *ctx, const pav_ctx *from, int role) {
     PAV_HIP(ctx, hipSetDevice(ctx->device));
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream2));
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->hom_pending = false;
     ctx->pack_pending[role] = false;
     ctx->cigar_loaded = ctx->cigar_called = false;
     ctx->seq.p[role] = from->seq.p[role];

@@ -1704,23 +1704,35 @@ __global__ __launch_bounds__(256) void k_annotate_calls(const GatherCall *__rest
                                                         uint8_t *__restrict__ match) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
-    uint32_t lo = 0, hi = n_calls;
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (calls[mid].dst_off <= t) lo = mid; else hi = mid; }
-    const GatherCall &c = calls[lo];
-    const uint64_t src = c.src_off + (t - c.dst_off);
-    const int64_t q = (int64_t)index[src] + c.base;                        // QRY_INDEX (inv.py:519)
-    uint8_t f = 0;
-    if (q >= c.up_pos && q < c.up_end - k) f = 1;                          // inv.py:524-527
-    if (q >= c.dn_pos && q < c.dn_end - k) f = 2;                          // inv.py:529-532
-    uint8_t m = 0;
-    if (f) {                                                               // raw KMER against canonical sets (inv.py:537-553)
-        const unsigned long long km = kmer[src];
-        const bool in_up = table_has(keys + c.key_up, 0, c.mask_up, km), in_dn = table_has(keys + c.key_dn, 0, c.mask_dn, km);
-        const bool same = f == 1 ? in_up : in_dn, other = f == 1 ? in_dn : in_up;
-        m = same ? (other ? 3 : 1) : (other ? 2 : 3);                      // KMER_LOC_STATE: NA / OTHER / SAME / NA
+    // the call of the workgroup's first and last row with uniform arguments (scalar loads), as in k_gather_calls
+    const uint32_t t_first = blockIdx.x * 256, t_last = min(t_first + 255u, total - 1);
+    uint32_t lo = 0, hi = n_calls, lo_last = 0;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (calls[mid].dst_off <= t_first) lo = mid; else hi = mid; }
+    hi = n_calls; lo_last = lo;
+    while (hi - lo_last > 1) { const uint32_t mid = (lo_last + hi) >> 1; if (calls[mid].dst_off <= t_last) lo_last = mid; else hi = mid; }
+    auto row = [&](const GatherCall &c) __attribute__((always_inline)) {
+        const uint64_t src = c.src_off + (t - c.dst_off);
+        const int64_t q = (int64_t)index[src] + c.base;                    // QRY_INDEX (inv.py:519)
+        uint8_t f = 0;
+        if (q >= c.up_pos && q < c.up_end - k) f = 1;                      // inv.py:524-527
+        if (q >= c.dn_pos && q < c.dn_end - k) f = 2;                      // inv.py:529-532
+        uint8_t m = 0;
+        if (f) {                                                           // raw KMER against canonical sets (inv.py:537-553)
+            const unsigned long long km = kmer[src];
+            const bool in_up = table_has(keys + c.key_up, 0, c.mask_up, km), in_dn = table_has(keys + c.key_dn, 0, c.mask_dn, km);
+            const bool same = f == 1 ? in_up : in_dn, other = f == 1 ? in_dn : in_up;
+            m = same ? (other ? 3 : 1) : (other ? 2 : 3);                  // KMER_LOC_STATE: NA / OTHER / SAME / NA
+        }
+        flank[src] = f;
+        match[src] = m;
+    };
+    if (lo_last == lo) {
+        row(calls[lo]);
+    } else {                                             // a call boundary inside the workgroup: every lane searches for itself
+        hi = lo_last + 1;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (calls[mid].dst_off <= t) lo = mid; else hi = mid; }
+        row(calls[lo]);
     }
-    flank[src] = f;
-    match[src] = m;
 }
 
 int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls, uint64_t k1_rows, CallStage &stage) {

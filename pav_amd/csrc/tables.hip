@@ -135,6 +135,7 @@ extern "C" int pav_cigar_write_tables(pav_ctx *ctx, const pav_table_opts *o, uin
         PAV_HIP(ctx, hipMemcpyAsync(snv.data(), d_out, sizeof(SnvOut) * n_snv, hipMemcpyDeviceToHost, st));
     }
     // ---- INDEL rows: records + SEQ blob to the host, stable sort there ------------------------------------------
+    { const int rch = wait_homology(ctx); if (rch != PAV_OK) return rch; }
     std::vector<pav_indel> ind(n_ind);
     std::vector<uint8_t> blob(ctx->counts.seq_bytes + 1);
     if (n_ind && o->insdel_path) {
