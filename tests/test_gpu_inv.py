@@ -627,6 +627,49 @@ def test_contig_planes_on_demand_equal_the_full_pack(built, gpu_ctx, monkeypatch
     assert lazy == eager
 
 
+@pytest.mark.parametrize('eager', [False, True])
+def test_dense_round_hands_its_block_over(built, gpu_ctx, monkeypatch, capfd, eager):
+    """A scan round whose calls make up most of its batch keeps its tables in the batch's own column block (density_fetch_calls:
+    the block changes hands with the stage, FLANK / MATCH are computed in place); PAV_CALL_GATHER=1 packs every round as round 2
+    did.  Every column of every call, the log and the results must be the same - for tables copied inside the scan (eager) and
+    for tables read afterwards (lazy), and over two scans in a row (the blocks rotate)."""
+    from pav_amd import cigarcall
+    hap = synth.config2(seed=919, scale=0.01, threads=4, pair_frac=0.01)
+    names = hap.ref.names
+    k_util = KmerUtil(31)
+    gpu_ctx._inv_loaded = None
+    gpu_ctx.seq_load(_lib.PAV_ROLE_REF, names, [hap.ref.seqs[n] for n in names])
+    gpu_ctx.seq_load(_lib.PAV_ROLE_TIG, hap.tig_names, [hap.tig_seqs[n] for n in hap.tig_names])
+    gpu_ctx.cigar_load(*cigarcall.pack_alignments(hap.df_align, names, hap.tig_names))
+    gpu_ctx._inv_loaded = ('ref.fa', 'tig.fa')
+    gpu_ctx.cigar_call()
+    index = hap.df_align['INDEX'].to_numpy(dtype='int64')
+    trim = hap.df_trim[['POS', 'END', 'INDEX']].set_index('INDEX').astype(int).reindex(list(index), fill_value=-1)
+    _, loci, _ = gpu_ctx.cigar_flag(trim['POS'].to_numpy(dtype='int64'), trim['END'].to_numpy(dtype='int64'),
+                                    gpu_ctx.flag_params(sig_filter=_lib.SIG_SINGLE_CLUSTER))
+    regions = pavinv.loci_regions(gpu_ctx, loci)
+    lift = AlignLift(hap.df_trim, hap.tig_lengths)
+    monkeypatch.setenv('PAV_TIMING', '1')                       # the library says which way a round's tables went
+
+    def scan():
+        log, found = io.StringIO(), io.StringIO()
+        calls = pavinv.scan_for_inv_batch(regions, 'ref.fa', 'tig.fa', lift, k_util, log=log, ctx=gpu_ctx, eager_tables=eager,
+                                          found_out=found)
+        tables = {c.id: c.df.to_csv(sep='\t', index=False) for c in calls if c is not None and not isinstance(c, RuntimeError)}
+        return log.getvalue(), found.getvalue(), tables
+
+    capfd.readouterr()
+    handed = [scan(), scan()]
+    said = capfd.readouterr().err
+    monkeypatch.setenv('PAV_CALL_GATHER', '1')
+    packed = scan()
+    said_packed = capfd.readouterr().err
+    assert "the batch's own block" in said and "the batch's own block" not in said_packed and 'packed, resident' in said_packed
+    assert len(packed[2]) >= 3
+    assert handed[0] == packed and handed[1] == packed
+    assert any(('UP' in t or 'DN' in t) for t in packed[2].values())     # FLANK annotated in place
+
+
 def test_concurrent_haplotype_lanes_equal_sequential_runs(built, gpu_ctx):
     """bench.py's lanes in small: four haplotypes resident at once - one context each, sharing the reference planes - run
     the whole chain (CIGAR-call -> flagging -> scan of the flagged loci with lazy tables) from four host threads at the same
