@@ -169,3 +169,69 @@ def test_planned_stage_equals_general_path(built, monkeypatch):
         assert cnt['n_snv_pass'] == 0 and cnt['n_indel_pass'] == 0 and len(loci) == 0
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize('kind', ['snv_only', 'indel_only', 'ins_only', 'one_row_each'])
+def test_planned_stage_on_one_sided_tables(built, monkeypatch, kind):
+    """Tables with nothing in one of the branches - no INS / DEL rows at all, no SNV rows, insertions without a single deletion
+    (the matches have nothing to search), one row of each - through the planned stage and through the general path."""
+    from pav_amd import _lib
+    rng = np.random.default_rng(11)
+    n = 60_000
+    ref = rng.integers(0, 4, n).astype(np.uint8)
+    tig = ref.copy()
+    ops = []                                                   # (code, length) over the reference; the contig is edited to match
+    pos = 0
+    tig_parts = []
+    def eq(m):
+        nonlocal pos
+        ops.append('%d=' % m); tig_parts.append(ref[pos:pos + m]); pos += m
+    def snv():
+        nonlocal pos
+        ops.append('1X'); tig_parts.append(np.array([(ref[pos] + 1) & 3], dtype=np.uint8)); pos += 1
+    def ins(m):
+        ops.append('%dI' % m); tig_parts.append(rng.integers(0, 4, m).astype(np.uint8))
+    def dele(m):
+        nonlocal pos
+        ops.append('%dD' % m); pos += m
+    eq(500)
+    if kind == 'snv_only':
+        for _ in range(400):
+            snv(); eq(int(rng.integers(2, 9)))
+    elif kind == 'indel_only':
+        for i in range(300):
+            (ins if i % 2 else dele)(int(rng.integers(4, 60))); eq(int(rng.integers(20, 60)))
+    elif kind == 'ins_only':
+        for _ in range(200):
+            ins(int(rng.integers(4, 90))); eq(int(rng.integers(5, 40)))
+    else:
+        snv(); eq(100); ins(7); eq(100); dele(9); eq(100)
+    eq(500)
+    tig = np.concatenate(tig_parts)
+    lut = np.frombuffer(b'ACGT', dtype=np.uint8)
+    ctx = _lib.Context(0)
+    try:
+        ctx.seq_load(_lib.PAV_ROLE_REF, ['chr1'], [lut[ref]])
+        ctx.seq_load(_lib.PAV_ROLE_TIG, ['tig1'], [lut[tig]])
+        aln = np.zeros(1, dtype=_lib.ALN_DTYPE)
+        text = np.frombuffer(''.join(ops).encode(), dtype=np.uint8)
+        ctx.cigar_load(aln, text, np.array([0, text.shape[0]], dtype=np.uint64))
+        counts = ctx.cigar_call()
+        assert (counts.n_snv == 0) == (kind in ('indel_only', 'ins_only')) and (counts.n_indel == 0) == (kind == 'snv_only')
+        tp, te = np.array([-1], dtype=np.int64), np.array([1 << 40], dtype=np.int64)
+        got = {}
+        for mode in ('planned', 'general'):
+            if mode == 'general':
+                monkeypatch.setenv('PAV_FLAG_HOST', '1')
+            tables, loci, cnt = ctx.cigar_flag(tp, te, ctx.flag_params(sig_filter=_lib.SIG_SINGLE_CLUSTER))
+            got[mode] = ({k: v.tobytes() for k, v in tables.items()}, loci.tobytes(), dict(cnt), {k: len(v) for k, v in tables.items()})
+        assert got['planned'] == got['general']
+        sizes = got['planned'][3]
+        if kind == 'snv_only':
+            assert sizes['cluster_snv'] >= 1 and sizes['insdel_indel'] == 0
+        if kind == 'indel_only':
+            assert sizes['cluster_indel'] >= 1 and sizes['insdel_indel'] + sizes['insdel_sv'] >= 1
+        if kind == 'ins_only':
+            assert sizes['insdel_indel'] == 0 and sizes['insdel_sv'] == 0
+    finally:
+        ctx.close()
