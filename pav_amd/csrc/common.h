@@ -128,6 +128,8 @@ struct pav_ctx {
     bool tables_pending = false;
     hipEvent_t tables_done_prev = nullptr;   // same for the scan before it: its tables live in the other pinned arena, so a new
     bool tables_pending_prev = false;        // scan does not wait for them (the two are swapped when a scan starts)
+    bool den_scan_only = false;           // set by the inversion-scan driver around pav_density_batch: only run lists and the tables of
+                                          // regions that can become calls will be read (density.hip, fwd_only)
     hipEvent_t hom_done = nullptr;        // pav_cigar_call: recorded behind the homology scans on stream2 (wait_homology)
     bool hom_pending = false;
     hipEvent_t snv_ready = nullptr, snv_done = nullptr;   // pav_cigar_call: the SNV rows are written on stream2 (behind the pack),

@@ -49,6 +49,7 @@ struct JobStat {                          // written by kernels, zeroed per batc
     uint32_t n_rows;
     uint32_t m[3], fill_n;
     uint32_t lds_flags, pad;              // k_kmer_lds: LDS_EXCEED (a count passed the limit), LDS_OVERFLOW (partition table full)
+    uint32_t inv_first, last1;            // k_state_combine: 0xFFFFFFFF - first / 1 + last contig position with a FWD k-mer (scan-only batches)
     uint32_t n_near, n_reeval, n_unres, n_spike;   // near-tie guard (include/pav_amd.h)
     unsigned long long s1[3], s2[3];      // sum / sum of squares of the row numbers of each state
     unsigned long long max_key;           // packed (first position << 32 | slot) of the max-count k-mer (failure path)
@@ -119,6 +120,7 @@ struct DensityState {
     hipEvent_t gathered = nullptr;        // the packed call tables of a round are complete (main stream)
     std::vector<pav_den_result> results;
     std::vector<std::vector<pav_run>> runs;
+    std::vector<uint8_t> no_table;                            // per job: its table was not built (scan-only batch, FWD k-mers only)
     pav_den_params params{};
     uint32_t n_jobs = 0;
     uint64_t arena_t = 0;
@@ -532,10 +534,12 @@ __global__ __launch_bounds__(LDS_THREADS) void k_kmer_lds(const PartItem *__rest
 __global__ __launch_bounds__(256) void k_state_combine(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
                                                        const uint8_t *__restrict__ ans_f, const uint8_t *__restrict__ ans_c,
                                                        int8_t *__restrict__ st_tmp, JobStat *__restrict__ stat,
-                                                       uint32_t *__restrict__ tile_cnt /* [tiles][4]: [1 + s] rows of state s; null: not wanted */) {
+                                                       uint32_t *__restrict__ tile_cnt /* [tiles][4]: [1 + s] rows of state s; null: not wanted */,
+                                                       int want_span = 0) {
     __shared__ uint32_t red[4][3];
     const uint32_t j = tile_job[blockIdx.x];
     if (!jobs[j].n_parts) return;
+    uint32_t fwd_lo = ~0u, fwd_hi = 0;
     const uint64_t at = (uint64_t)blockIdx.x * DTILE + (uint64_t)threadIdx.x * 8;
     const uint64_t f8 = *reinterpret_cast<const uint64_t *>(ans_f + at), c8 = *reinterpret_cast<const uint64_t *>(ans_c + at);
     uint64_t out = 0;
@@ -549,9 +553,17 @@ __global__ __launch_bounds__(256) void k_state_combine(const JobDev *__restrict_
             st = in_f ? (in_r ? 1 : 0) : (in_r ? 2 : -1);            // KMER_ORIENTATION_STATE
         }
         if (st >= 0) n[st]++;
+        if (st == 0) { if (fwd_lo == ~0u) fwd_lo = (uint32_t)t; fwd_hi = (uint32_t)t; }
         out |= (uint64_t)(uint8_t)(int8_t)st << (8 * t);
     }
     *reinterpret_cast<uint64_t *>(st_tmp + at) = out;
+    if (want_span) {                                                   // first / last position of the region with a FWD k-mer
+        const uint32_t i0 = (uint32_t)(at - jobs[j].tpos_off);
+        uint32_t inv_first = fwd_lo == ~0u ? 0u : 0xFFFFFFFFu - (i0 + fwd_lo), last1 = fwd_lo == ~0u ? 0u : i0 + fwd_hi + 1u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { inv_first = max(inv_first, (uint32_t)__shfl_xor((int)inv_first, d)); last1 = max(last1, (uint32_t)__shfl_xor((int)last1, d)); }
+        if ((threadIdx.x & 63) == 0 && last1) { atomicMax(&stat[j].inv_first, inv_first); atomicMax(&stat[j].last1, last1); }
+    }
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
 #pragma unroll
@@ -647,6 +659,16 @@ __device__ __forceinline__ void block_scan4(uint32_t (&v)[4], uint32_t (&total)[
     __syncthreads();
 }
 
+// A region whose k-mers are all FWD once the low-count states are dropped (1 025 of the 1 126 flagged regions of the bench
+// haplotype: a cluster of SNVs or indels, not an inversion).  Its STATE column is 0 in every row whatever the densities are -
+// the other two kernel columns are zero, arg-max takes the first (scripts/density.py:300-342) - so the scan driver knows its
+// outcome from the counts alone: one run of state 0 over its rows, "Found no inverted k-mer states".  In a batch the driver
+// marks scan-only (pav_ctx::den_scan_only) such a region is neither compacted nor evaluated; its run comes from the first and
+// last contig position with a FWD k-mer (k_state_combine).  Its table does not exist: pav_density_table refuses.
+__device__ __host__ __forceinline__ bool fwd_only(const JobStat &js, uint32_t min_state_count) {
+    return js.st_count[1] < min_state_count && js.st_count[2] < min_state_count;
+}
+
 __device__ __forceinline__ int keep_state(int st, const JobStat &js, uint32_t min_state_count) {
     if (st < 0) return -1;
     return js.st_count[st] >= min_state_count ? st : -1;               // low-count states are dropped (density.py:181-190)
@@ -710,6 +732,7 @@ struct CompactArgs {
     uint32_t *index; int8_t *state_mer; int8_t *state; unsigned long long *kmer; uint32_t *list[3];
     HeadEvent *events; uint32_t ev_cap; uint32_t *ev_count;   // run heads of STATE_MER (closed-form run sums); null: not wanted
     uint32_t *tile_heads, *tile_head_cnt;                     // device-planned batches instead: HEADS_PER_TILE ordered slots per tile
+    int scan_only;                                            // tables of regions with FWD k-mers only are not wanted (fwd_only below)
 };
 
 __global__ __launch_bounds__(256) void k_compact_scatter(CompactArgs A) {
@@ -722,6 +745,7 @@ __global__ __launch_bounds__(256) void k_compact_scatter(CompactArgs A) {
     const uint32_t j = A.tile_job[blockIdx.x];
     const JobDev jd = A.jobs[j];
     const JobStat js = A.stat[j];
+    if (A.scan_only && fwd_only(js, A.min_state_count)) return;       // nobody will read this region's rows
     const uint64_t base = (uint64_t)blockIdx.x * DTILE + (uint64_t)threadIdx.x * 8;
     const uint64_t packed = *reinterpret_cast<const uint64_t *>(A.st_tmp + base);
     int st[8];
@@ -1894,6 +1918,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     D->params = *pp;
     D->results.assign(n_jobs, pav_den_result{});
     D->runs.assign(n_jobs, {});
+    D->no_table.assign(n_jobs, 0);
     if (n_jobs == 0) { D->valid = true; return PAV_OK; }
     const SeqStore &RS = ctx->seq[PAV_ROLE_REF], &TS = ctx->seq[PAV_ROLE_TIG];
     const int k = pp->k;
@@ -1978,6 +2003,8 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     // ---- what is known before anything runs (device-planned batches: upper bounds; rows <= contig positions of the region) -----
     const bool want_runs = pp->kde_mode != PAV_KDE_DIRECT;
     bool fast = want_runs && n_hbm_jobs == 0 && !items.empty() && getenv("PAV_DENSITY_HOST") == nullptr;
+    // the caller reads run lists only, and tables of calls: regions with FWD k-mers only are settled from their counts (fwd_only)
+    const bool scan_only = fast && ctx->den_scan_only && getenv("PAV_SCAN_FULL") == nullptr;
     D->h_kde.assign(n_jobs, JobKde{});
     std::vector<EvalTile> tiles_ub;
     uint64_t samp_ub = 0;
@@ -2087,7 +2114,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
                    pp->max_ref_kmer_count, D->lists.as<uint32_t>(), D->bcount.as<uint32_t>(), D->ans_f.as<uint8_t>(),
                    D->ans_c.as<uint8_t>(), d_stat);
         PAV_LAUNCH(ctx, "k_state_combine", k_state_combine, n_tiles_t, 256, 0, d_jobs, d_tjt, D->ans_f.as<uint8_t>(),
-                   D->ans_c.as<uint8_t>(), D->st_tmp.as<int8_t>(), d_stat, D->tile_sum.as<uint32_t>());
+                   D->ans_c.as<uint8_t>(), D->st_tmp.as<int8_t>(), d_stat, D->tile_sum.as<uint32_t>(), scan_only ? 1 : 0);
     }
     if (n_hbm_jobs) {
         PAV_LAUNCH(ctx, "k_ref_insert", k_ref_insert, (uint32_t)(a_r / 256), 256, 0, d_jobs, d_tjr, RV, k, pp->max_ref_kmer_count,
@@ -2101,7 +2128,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     CA.index = D->index.as<uint32_t>(); CA.state_mer = D->state_mer.as<int8_t>(); CA.state = D->state.as<int8_t>();
     CA.kmer = D->kmer.as<unsigned long long>();
     for (int s = 0; s < 3; ++s) CA.list[s] = D->list[s].as<uint32_t>();
-    CA.events = nullptr; CA.ev_cap = 0; CA.ev_count = nullptr; CA.tile_heads = nullptr; CA.tile_head_cnt = nullptr;
+    CA.events = nullptr; CA.ev_cap = 0; CA.ev_count = nullptr; CA.tile_heads = nullptr; CA.tile_head_cnt = nullptr; CA.scan_only = 0;
     std::vector<JobStat> hs(n_jobs);
     constexpr uint32_t EV_PREFETCH = 16384;                            // head events copied together with their count
     // pinned readback area: [event count | first events] [per-job statistics] [guard counters]
@@ -2229,11 +2256,11 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
                 G.g = D->guard.as<GuardDev>(); G.entries = D->guard_entries.as<unsigned long long>();
                 G.samp_flag = D->samp_flag.as<uint32_t>(); G.row_flag = D->row_flag.as<uint8_t>();
             }
-            CA.tile_heads = D->tile_heads.as<uint32_t>(); CA.tile_head_cnt = D->tile_head_cnt.as<uint32_t>();
+            CA.tile_heads = D->tile_heads.as<uint32_t>(); CA.tile_head_cnt = D->tile_head_cnt.as<uint32_t>(); CA.scan_only = scan_only ? 1 : 0;
             PAV_LAUNCH(ctx, "k_scan_tiles_keep", k_scan_tiles_keep, 4, 256, 0, D->tile_sum.as<uint32_t>(), d_tjt, d_stat, pp->min_state_count,
                        D->tile_pre.as<unsigned long long>(), n_tiles_t);
             PAV_LAUNCH(ctx, "k_compact_scatter", k_compact_scatter, n_tiles_t, 256, 0, CA);
-            CA.tile_heads = nullptr; CA.tile_head_cnt = nullptr;
+            CA.tile_heads = nullptr; CA.tile_head_cnt = nullptr; CA.scan_only = 0;
             PlanArgs PA;
             PA.jobs = d_jobs; PA.stat = d_stat; PA.kde = D->kde.as<JobKde>(); PA.n_jobs = n_jobs;
             PA.tile_heads = D->tile_heads.as<uint32_t>(); PA.tile_head_cnt = D->tile_head_cnt.as<uint32_t>(); PA.runs = D->heads.as<RunDev>();
@@ -2284,6 +2311,17 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             lap("device plan");
             if (timing) fprintf(stderr, "[pav timing]   device-planned batches so far: %llu, sent back to the host-planned path: %llu\n",
                                 (unsigned long long)D->n_fast + 1, (unsigned long long)D->n_fallback);
+            if (timing) {
+                double rows_all = 0, rows_fwd_only = 0, rows_norev = 0; uint32_t jobs_fwd_only = 0;
+                const JobStat *q = reinterpret_cast<const JobStat *>(h_rb + z_sl[0].at);
+                for (uint32_t j = 0; j < n_jobs; ++j) {
+                    rows_all += q[j].n_rows;
+                    if (q[j].m[2] == 0) rows_norev += q[j].n_rows;
+                    if (q[j].m[1] == 0 && q[j].m[2] == 0) { rows_fwd_only += q[j].n_rows; ++jobs_fwd_only; }
+                }
+                fprintf(stderr, "[pav timing]   rows %.3g: %.0f %% in jobs without REV k-mers, %.0f %% in %u of %u jobs with FWD k-mers only\n", rows_all,
+                        rows_all ? 100 * rows_norev / rows_all : 0.0, rows_all ? 100 * rows_fwd_only / rows_all : 0.0, jobs_fwd_only, n_jobs);
+            }
             uint32_t n_ev = 0;
             GuardDev h_guard{};
             uint32_t h_flags[4] = {0, 0, 0, 0};
@@ -2304,6 +2342,14 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             for (uint32_t j = 0; j < n_jobs && !redo; ++j) redo = hs[j].lds_flags != 0;
             if (!redo) {
                 D->n_fast += 1;
+                if (scan_only)                                             // regions settled from their counts: rows = their FWD k-mers
+                    for (uint32_t j = 0; j < n_jobs; ++j) {
+                        JobStat &q = hs[j];
+                        if (!fwd_only(q, pp->min_state_count)) continue;
+                        const uint32_t n = q.st_count[0] >= pp->min_state_count ? q.st_count[0] : 0u;
+                        q.n_rows = n; q.m[0] = n; q.m[1] = q.m[2] = 0; q.fill_n = 0;
+                        D->no_table[j] = 1;
+                    }
                 // results: the host's own arithmetic on the same statistics (what k_plan did on the device)
                 double pairs = 0, points = 0, data_pairs = 0;
                 for (uint32_t j = 0; j < n_jobs; ++j) {
@@ -2317,6 +2363,10 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
                     if (q.n_rows < pp->min_informative || q.n_rows == 0) { r.status = PAV_DEN_UNFINALISED; continue; }
                     r.status = PAV_DEN_OK;
                     const uint32_t n = q.n_rows, srs = D->h_jobs[j].srs;
+                    if (D->no_table[j]) {                                // one run of state 0 over its rows (INDEX of the first and the last)
+                        D->runs[j].push_back(pav_run{0, n, (int64_t)(0xFFFFFFFFu - q.inv_first), (int64_t)q.last1 - 1});
+                        continue;
+                    }
                     uint32_t n_samp = (n + srs - 1) / srs;
                     if ((uint64_t)(n_samp - 1) * srs != n - 1) n_samp += 1;
                     r.n_sample = n_samp;
@@ -2729,6 +2779,7 @@ int pav_density_table(pav_ctx *ctx, uint32_t job, int64_t *index, int8_t *state_
                       double *kern_fwdrev, double *kern_rev, uint64_t *kmer) {
     if (!ctx) return PAV_E_ARG;
     DensityState *D = dstate(ctx);
+    if (job < D->no_table.size() && D->no_table[job]) return fail(ctx, PAV_E_STATE, "the table of job %u was not built (scan-only batch, a region with FWD k-mers only)", job);
     if (!D->valid || job >= D->n_jobs) return fail(ctx, PAV_E_STATE, "pav_density_table: no such job in the last batch");
     PAV_HIP(ctx, hipSetDevice(ctx->device));
     const uint32_t n = D->results[job].n_rows;
@@ -2758,6 +2809,7 @@ int pav_density_annotate(pav_ctx *ctx, uint32_t job, uint32_t ref_id, uint64_t r
                          int64_t tig_up_end, int64_t tig_dn_pos, int64_t tig_dn_end, uint8_t *flank, uint8_t *match) {
     if (!ctx || !flank || !match) return PAV_E_ARG;
     DensityState *D = dstate(ctx);
+    if (job < D->no_table.size() && D->no_table[job]) return fail(ctx, PAV_E_STATE, "the table of job %u was not built (scan-only batch, a region with FWD k-mers only)", job);
     if (!D->valid || job >= D->n_jobs) return fail(ctx, PAV_E_STATE, "pav_density_annotate: no such job in the last batch");
     const SeqStore &RS = ctx->seq[PAV_ROLE_REF];
     if (ref_id >= RS.n || ref_up_end > RS.len[ref_id] || ref_dn_end > RS.len[ref_id])

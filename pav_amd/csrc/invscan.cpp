@@ -587,7 +587,9 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
         double t0 = now();
         t_pre += t0 - t_p0;
         if (timing) fprintf(stderr, "[pav timing]   scan round: %zu jobs, lift + jobs %.2f ms\n", jobs.size(), (t0 - t_p0) * 1e3);
+        ctx->den_scan_only = true;                                          // a call needs REV k-mers: tables of FWD-only regions are never asked for
         int rc = pav_density_batch(ctx, (uint32_t)jobs.size(), jobs.data(), &pp->den, res.data());
+        ctx->den_scan_only = false;
         t_batch += now() - t0;
         if (rc != PAV_OK) return rc;
         const double t_q0 = now();
