@@ -372,11 +372,6 @@ def main():
             return t_c, float(tt_.item())
         return t_c, t_c
 
-    # Untimed warm-up: W steps as asked, but at least three per lane, in equal shares (not from the shared counter of the timed
-    # regions: a lane that is still allocating would be overtaken and start its first pass inside a timed region - an 80 ms
-    # outlier) - a lane's buffers are sized by its first pass and the two alternating table arenas of its scan by its first two
-    warmup_run = max(args.warmup, 3 * n_lanes)
-    run_steps(warmup_run, fixed_share=True)
     # The haplotypes built above are tens of millions of long-lived Python objects (tables, arrays, strings).  A full collection of
     # the cyclic garbage collector walks all of them - 80 ms with every lane's thread stopped, once every few hundred passes: one
     # timed region in ten came out three times as long as its neighbours.  They are moved to the permanent generation (what
@@ -384,6 +379,11 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
+    # Untimed warm-up: W steps as asked, but at least three per lane, in equal shares (not from the shared counter of the timed
+    # regions: a lane that is still allocating would be overtaken and start its first pass inside a timed region - an 80 ms
+    # outlier) - a lane's buffers are sized by its first pass and the two alternating table arenas of its scan by its first two
+    warmup_run = max(args.warmup, 3 * n_lanes)
+    run_steps(warmup_run, fixed_share=True)
     warmup_run = ((warmup_run + n_lanes - 1) // n_lanes) * n_lanes
 
     # ---- timed region: exactly K steps, profiling off; run R times back to back, the median region is the line's --------

@@ -670,6 +670,48 @@ def test_dense_round_hands_its_block_over(built, gpu_ctx, monkeypatch, capfd, ea
     assert any(('UP' in t or 'DN' in t) for t in packed[2].values())     # FLANK annotated in place
 
 
+def test_regions_with_forward_kmers_only_are_settled_from_their_counts(built, gpu_ctx, monkeypatch, capfd):
+    """The native scan marks its density batches scan-only: a region whose k-mers are all FWD (after the low-count states are
+    dropped) has STATE 0 in every row whatever the densities are, so it is neither compacted nor evaluated and its run list is
+    made from its counts.  PAV_SCAN_FULL=1 evaluates every region as the density API does.  Log, 'INV Found' lines, calls and
+    their tables must be the same; most flagged regions of a haplotype are of that kind."""
+    import re
+    from pav_amd import cigarcall
+    hap = synth.config2(seed=919, scale=0.01, threads=4, pair_frac=0.01)
+    names = hap.ref.names
+    k_util = KmerUtil(31)
+    gpu_ctx._inv_loaded = None
+    gpu_ctx.seq_load(_lib.PAV_ROLE_REF, names, [hap.ref.seqs[n] for n in names])
+    gpu_ctx.seq_load(_lib.PAV_ROLE_TIG, hap.tig_names, [hap.tig_seqs[n] for n in hap.tig_names])
+    gpu_ctx.cigar_load(*cigarcall.pack_alignments(hap.df_align, names, hap.tig_names))
+    gpu_ctx._inv_loaded = ('ref.fa', 'tig.fa')
+    gpu_ctx.cigar_call()
+    index = hap.df_align['INDEX'].to_numpy(dtype='int64')
+    trim = hap.df_trim[['POS', 'END', 'INDEX']].set_index('INDEX').astype(int).reindex(list(index), fill_value=-1)
+    _, loci, _ = gpu_ctx.cigar_flag(trim['POS'].to_numpy(dtype='int64'), trim['END'].to_numpy(dtype='int64'),
+                                    gpu_ctx.flag_params(sig_filter=_lib.SIG_SINGLE_CLUSTER))
+    regions = pavinv.loci_regions(gpu_ctx, loci)
+    lift = AlignLift(hap.df_trim, hap.tig_lengths)
+    monkeypatch.setenv('PAV_TIMING', '1')
+
+    def scan():
+        log, found = io.StringIO(), io.StringIO()
+        calls = pavinv.scan_for_inv_batch(regions, 'ref.fa', 'tig.fa', lift, k_util, log=log, ctx=gpu_ctx, eager_tables=False, found_out=found)
+        tables = {c.id: sha(c.df.to_csv(sep='\t', index=False).encode()) for c in calls if c is not None and not isinstance(c, RuntimeError)}
+        outcome = [None if c is None else (str(c) if isinstance(c, RuntimeError) else c.id) for c in calls]
+        return log.getvalue(), found.getvalue(), tables, outcome
+
+    capfd.readouterr()
+    short = scan()
+    said = capfd.readouterr().err
+    monkeypatch.setenv('PAV_SCAN_FULL', '1')
+    full = scan()
+    assert short == full and len(full[2]) >= 3
+    m = re.search(r'in (\d+) of (\d+) jobs with FWD k-mers only', said)
+    assert m and int(m.group(1)) >= 5 and int(m.group(1)) < int(m.group(2))
+    assert 'Found no inverted k-mer states after 1 expansion(s)' in full[0]
+
+
 def test_concurrent_haplotype_lanes_equal_sequential_runs(built, gpu_ctx):
     """bench.py's lanes in small: four haplotypes resident at once - one context each, sharing the reference planes - run
     the whole chain (CIGAR-call -> flagging -> scan of the flagged loci with lazy tables) from four host threads at the same
