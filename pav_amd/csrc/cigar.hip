@@ -1727,10 +1727,11 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
         A.ref = SA.ref; A.tig = SA.tig;
         A.snv = ctx->d_snv.as<pav_snv>(); A.indel = ctx->d_indel.as<pav_indel>();
         // The stubs first; then the homology scans (+ SEQ) on the side stream and the SNV rows on this one, next to each other
-        // (13 M isolated line fetches; the scans draw on the same budget).  What follows a call on this stream - the flagging,
-        // the inversion scan - reads POS / END / SVLEN of the stubs and the SNV rows, never the homology columns or SEQ: it is
-        // not made to wait for the scans (round 2 had them on this stream: the flagging, and the host work behind it, began
-        // 0.1 ms later).  Readers of the finished records wait (wait_homology: fetch, table writers, the next call).
+        // (13 M isolated line fetches; the scans draw on the same budget).  Everything queued on this stream after the call is
+        // ordered behind the scans (wait_homology below): they left-shift an insertion through its homology and write POS / END /
+        // QRY_POS / QRY_END of every INS / DEL row - the stubs of walk_indel carry record offsets in those fields - so the
+        // flagging, which reads POS / END, must not start before them.  (Letting it start early was tried: the race showed as
+        // one failure in six runs of the eight-lane CHM13 test.)
         if (totals[3]) PAV_LAUNCH(ctx, "walk_indel", walk_emit<WALK_INDEL>, B.n_tiles, 256, 0, A);
         const bool skip_snv = stage && !strcmp(stage, "hom");     // debugging: the homology scans with nothing beside them
         if (totals[3] && !(stage && !strcmp(stage, "indel"))) {
@@ -1745,6 +1746,7 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
             ctx->hom_pending = true;
         }
         if (totals[2] && !skip_snv) PAV_LAUNCH(ctx, "walk_snv", walk_emit<WALK_SNV>, B.n_tiles, 256, 0, A);
+        { const int rch = wait_homology(ctx); if (rch != PAV_OK) return rch; }       // later readers of the INS / DEL rows use this stream
     }
     if (counts) *counts = ctx->counts;
     ctx->cigar_called = true;
