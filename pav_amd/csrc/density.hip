@@ -557,12 +557,18 @@ __global__ __launch_bounds__(256) void k_state_combine(const JobDev *__restrict_
         out |= (uint64_t)(uint8_t)(int8_t)st << (8 * t);
     }
     *reinterpret_cast<uint64_t *>(st_tmp + at) = out;
-    if (want_span) {                                                   // first / last position of the region with a FWD k-mer
-        const uint32_t i0 = (uint32_t)(at - jobs[j].tpos_off);
-        uint32_t inv_first = fwd_lo == ~0u ? 0u : 0xFFFFFFFFu - (i0 + fwd_lo), last1 = fwd_lo == ~0u ? 0u : i0 + fwd_hi + 1u;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { inv_first = max(inv_first, (uint32_t)__shfl_xor((int)inv_first, d)); last1 = max(last1, (uint32_t)__shfl_xor((int)last1, d)); }
-        if ((threadIdx.x & 63) == 0 && last1) { atomicMax(&stat[j].inv_first, inv_first); atomicMax(&stat[j].last1, last1); }
+    // first / last position of the region with a FWD k-mer (scan-only batches): lanes hold rising positions, so a wave's first
+    // is its lowest lane's and its last its highest lane's; one pair of atomics per workgroup
+    __shared__ uint32_t span[4][2];
+    if (want_span) {
+        const unsigned long long has = __ballot(fwd_lo != ~0u);
+        const int lane = threadIdx.x & 63;
+        if (has) {
+            const int lo_lane = __ffsll((long long)has) - 1, hi_lane = 63 - __clzll((long long)has);
+            const uint32_t i0 = (uint32_t)(at - jobs[j].tpos_off);
+            if (lane == lo_lane) span[threadIdx.x >> 6][0] = 0xFFFFFFFFu - (i0 + fwd_lo);
+            if (lane == hi_lane) span[threadIdx.x >> 6][1] = i0 + fwd_hi + 1u;
+        } else if (lane == 0) { span[threadIdx.x >> 6][0] = 0u; span[threadIdx.x >> 6][1] = 0u; }
     }
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
@@ -577,6 +583,11 @@ __global__ __launch_bounds__(256) void k_state_combine(const JobDev *__restrict_
         const uint32_t v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
         if (v) atomicAdd(&stat[j].st_count[threadIdx.x], v);
         if (tile_cnt) tile_cnt[(uint64_t)blockIdx.x * 4 + 1 + threadIdx.x] = v;
+    }
+    if (want_span && threadIdx.x >= 64 && threadIdx.x < 66) {         // (a lane of another wave than the one busy with the counts)
+        const int q = threadIdx.x - 64;
+        const uint32_t v = max(max(span[0][q], span[1][q]), max(span[2][q], span[3][q]));
+        if (v) atomicMax(q ? &stat[j].last1 : &stat[j].inv_first, v);
     }
 }
 
