@@ -38,8 +38,8 @@ struct JobDev {
     uint64_t rpos_off;                    // job start in the reference-position arena
     uint64_t tpos_off;                    // job start in the contig-position / row arena
     uint32_t n_parts;                     // > 0: LDS-resident k-mer set split into n_parts partitions; 0: hash table in HBM
-    uint32_t bucket_off;                  // first of the job's 3 x n_parts list counters (reference, forward, reverse complement)
-    uint64_t list_off_r, list_off_t;      // first entry of the job's reference lists / of its 2 x n_parts contig lists
+    uint32_t bucket_off;                  // first of the job's 2 x n_parts list counters (reference, contig)
+    uint64_t list_off_r, list_off_t;      // first entry of the job's n_parts reference lists / of its n_parts contig lists
     uint32_t cap_r, cap_t;                // entries per list
 };
 
@@ -307,11 +307,15 @@ __global__ __launch_bounds__(256) void k_tig_state(const JobDev *__restrict__ jo
 // resident haplotypes the big workgroup waits for a whole free CU, and the step went from 3.85 to 3.55 ms with the small one.)
 //   k_bucket_ref / k_bucket_tig  one workgroup per 2048-position tile: every k-mer is hashed once and its position is
 //                                appended to the list of its partition (ranks from an LDS histogram, one global atomic
-//                                per (tile, partition) to reserve the slots); a contig k-mer goes to two lists, one for
-//                                its forward key and one for its reverse-complement key
-//   k_kmer_lds                   reads its three lists densely: inserts, then probes and writes one answer byte per question
+//                                per (tile, partition) to reserve the slots)
+//   k_kmer_lds                   reads its two lists densely: inserts, then probes and writes the two answer bytes of a position
 //   k_state_combine              STATE_MER from the two answers per position (+ per-state counts)
-// Counts (scripts/density.py:516-527) are bytes holding occurrences - 1; a count that passes the limit only raises a flag
+// The sets are keyed by the CANONICAL k-mer - the smaller of a k-mer and its reverse complement - with one occurrence count
+// per orientation: "the contig k-mer is in the reference set" and "its reverse complement is" are then ONE question (same
+// canonical key; same / other orientation), so a contig k-mer goes to one list and is looked up once.  (Round 2 kept the
+// oriented reference k-mers and asked twice: two list entries and two probes per contig position.)  For even k a k-mer can
+// be its own reverse complement: both answers are then the same.
+// Counts (scripts/density.py:516-527) are bytes holding occurrences, per orientation; a count that passes the limit only raises a flag
 // and the exact maximum and its k-mer come from the HBM-table kernels on that failure path.
 constexpr int LDS_SLOTS = PAV_LDS_SLOTS;
 constexpr int LDS_THREADS = PAV_LDS_THREADS;
@@ -330,6 +334,16 @@ __device__ __forceinline__ uint32_t khash(uint64_t key) {
     return h;
 }
 __device__ __forceinline__ uint32_t kpart(uint32_t h, uint32_t n_parts) { return ((h >> 16) * n_parts) >> 16; }
+
+// x: the k bases of a window in window order (kmer_from_words).  The k-mer as the reference spells it (kanapy order) is
+// rev_groups(x), its reverse complement x ^ mask; the canonical key is the smaller one, `other` says that it is the reverse
+// complement (the k-mer is in the orientation opposite to its canonical form).
+__device__ __forceinline__ uint64_t canon_key(uint64_t x, int k, bool *other = nullptr, bool *self_rc = nullptr) {
+    const uint64_t f = rev_groups(x, k), c = x ^ kmer_mask(k);
+    if (other) *other = c < f;
+    if (self_rc) *self_rc = c == f;
+    return c < f ? c : f;
+}
 
 // List capacity per (job, partition): the mean plus 25 % (> 20 sigma at 7 k entries) plus slack for small means.
 static uint32_t bucket_cap(uint64_t n_pos, uint32_t n_parts) {
@@ -366,7 +380,7 @@ __global__ __launch_bounds__(256) void k_bucket_ref(const JobDev *__restrict__ j
         const uint64_t x = kmer_from_words(kw[t], at[t], k);
         pid[t] = ~0u;
         if (inside[t] && (!dirt[t] || kmer_clean(R.mask, at[t], k))) {
-            pid[t] = kpart(khash(jd.ref_rc ? (x ^ kmer_mask(k)) : rev_groups(x, k)), P);
+            pid[t] = kpart(khash(canon_key(x, k)), P);
             rank[t] = atomicAdd(&hist[pid[t]], 1u);
             any = true;
         }
@@ -390,15 +404,15 @@ __global__ __launch_bounds__(256) void k_bucket_ref(const JobDev *__restrict__ j
 __global__ __launch_bounds__(256) void k_bucket_tig(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
                                                     SeqView T, int k, uint32_t *__restrict__ lists, uint32_t *__restrict__ bcount,
                                                     uint8_t *__restrict__ ans_f, JobStat *__restrict__ stat) {
-    __shared__ uint32_t hist[2 * LDS_MAX_PARTS], base[2 * LDS_MAX_PARTS];
+    __shared__ uint32_t hist[LDS_MAX_PARTS], base[LDS_MAX_PARTS];
     const uint32_t j = tile_job[blockIdx.x];
     const JobDev jd = jobs[j];
     const uint32_t P = jd.n_parts;
     if (!P) return;
-    for (uint32_t p = threadIdx.x; p < 2 * P; p += 256) hist[p] = 0;
+    for (uint32_t p = threadIdx.x; p < P; p += 256) hist[p] = 0;
     __syncthreads();
     const uint64_t i0 = (uint64_t)blockIdx.x * DTILE - jd.tpos_off;
-    uint32_t pf[8], pc[8], rf[8], rc[8];
+    uint32_t pf[8], rf[8];
     KmerWords kw[8]; uint64_t at[8]; uint32_t dirt[8]; bool inside[8];          // as in k_bucket_ref
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -413,25 +427,21 @@ __global__ __launch_bounds__(256) void k_bucket_tig(const JobDev *__restrict__ j
         const uint64_t x = kmer_from_words(kw[t], at[t], k);
         pf[t] = ~0u;
         if (inside[t] && (!dirt[t] || kmer_clean(T.mask, at[t], k))) {
-            pf[t] = kpart(khash(rev_groups(x, k)), P);
-            pc[t] = P + kpart(khash(x ^ kmer_mask(k)), P);
+            pf[t] = kpart(khash(canon_key(x, k)), P);
             rf[t] = atomicAdd(&hist[pf[t]], 1u);
-            rc[t] = atomicAdd(&hist[pc[t]], 1u);
         }
         ans_f[(uint64_t)blockIdx.x * DTILE + t * 256 + threadIdx.x] = pf[t] == ~0u ? (uint8_t)ANS_INVALID : (uint8_t)ANS_ABSENT;
     }
     __syncthreads();
-    for (uint32_t p = threadIdx.x; p < 2 * P; p += 256)
+    for (uint32_t p = threadIdx.x; p < P; p += 256)
         if (hist[p]) base[p] = atomicAdd(&bcount[jd.bucket_off + P + p], hist[p]);
     __syncthreads();
     bool over = false;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         if (pf[t] == ~0u) continue;
-        const uint32_t pos = (uint32_t)(i0 + t * 256 + threadIdx.x);
-        const uint32_t sf = base[pf[t]] + rf[t], sc = base[pc[t]] + rc[t];
-        if (sf < jd.cap_t) lists[jd.list_off_t + (uint64_t)pf[t] * jd.cap_t + sf] = pos; else over = true;
-        if (sc < jd.cap_t) lists[jd.list_off_t + (uint64_t)pc[t] * jd.cap_t + sc] = pos; else over = true;
+        const uint32_t sf = base[pf[t]] + rf[t];
+        if (sf < jd.cap_t) lists[jd.list_off_t + (uint64_t)pf[t] * jd.cap_t + sf] = (uint32_t)(i0 + t * 256 + threadIdx.x); else over = true;
     }
     if (over) atomicOr(&stat[j].lds_flags, LDS_OVERFLOW);
 }
@@ -441,19 +451,19 @@ __global__ __launch_bounds__(LDS_THREADS) void k_kmer_lds(const PartItem *__rest
                                                           const uint32_t *__restrict__ lists, const uint32_t *__restrict__ bcount,
                                                           uint8_t *__restrict__ ans_f, uint8_t *__restrict__ ans_c,
                                                           JobStat *__restrict__ stat) {
-    __shared__ unsigned long long keys[LDS_SLOTS];
-    __shared__ uint32_t cnt4[LDS_SLOTS / 4];
+    __shared__ unsigned long long keys[LDS_SLOTS];                     // canonical k-mers
+    __shared__ uint32_t cnt2[LDS_SLOTS / 2];                           // per slot two bytes: occurrences in the canonical / the other orientation
     __shared__ uint32_t flags;
     const PartItem it = items[blockIdx.x];
     if (it.job == ~0u) return;                                          // padding of the XCD-grouped order
     const JobDev jd = jobs[it.job];
     const uint32_t P = jd.n_parts;
     for (int s = threadIdx.x; s < LDS_SLOTS; s += LDS_THREADS) keys[s] = EMPTY_KEY;
-    for (int s = threadIdx.x; s < LDS_SLOTS / 4; s += LDS_THREADS) cnt4[s] = 0;
+    for (int s = threadIdx.x; s < LDS_SLOTS / 2; s += LDS_THREADS) cnt2[s] = 0;
     if (threadIdx.x == 0) flags = 0;
     __syncthreads();
 
-    // reference k-mers of this partition -> LDS set with byte counts
+    // reference k-mers of this partition -> LDS set with byte counts per orientation
     {
         const uint32_t n = min(bcount[jd.bucket_off + it.part], jd.cap_r);
         const uint32_t *list = lists + jd.list_off_r + (uint64_t)it.part * jd.cap_r;
@@ -472,16 +482,18 @@ __global__ __launch_bounds__(LDS_THREADS) void k_kmer_lds(const PartItem *__rest
 #pragma unroll
             for (int u = 0; u < KU; ++u) {
                 if (!ok[u]) continue;
-                const uint64_t key = jd.ref_rc ? (x[u] ^ kmer_mask(k)) : rev_groups(x[u], k);
+                bool other, self_rc;
+                const uint64_t key = canon_key(x[u], k, &other, &self_rc);
+                // the set holds the region's k-mers as they are (-r: reverse-complemented): which orientation of the key that is
+                const uint32_t o = self_rc ? 0u : (uint32_t)(other != (jd.ref_rc != 0));
                 uint32_t s = khash(key) & (LDS_SLOTS - 1);
                 int probes = 0;
                 while (true) {
                     const unsigned long long old = atomicCAS(&keys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
-                    if (old == EMPTY_KEY) break;
-                    if (old == key) {
-                        const uint32_t sh = 8 * (s & 3);
-                        const uint32_t prev = (atomicAdd(&cnt4[s >> 2], 1u << sh) >> sh) & 0xFFu;     // occurrences - 2
-                        if (prev + 2 > limit) my_flags |= LDS_EXCEED;
+                    if (old == EMPTY_KEY || old == key) {
+                        const uint32_t sh = 16 * (s & 1) + 8 * o;
+                        const uint32_t prev = (atomicAdd(&cnt2[s >> 1], 1u << sh) >> sh) & 0xFFu;        // occurrences so far
+                        if (prev + 1 > limit) my_flags |= LDS_EXCEED;
                         break;
                     }
                     s = (s + 1) & (LDS_SLOTS - 1);
@@ -494,14 +506,10 @@ __global__ __launch_bounds__(LDS_THREADS) void k_kmer_lds(const PartItem *__rest
     __syncthreads();
     if (threadIdx.x == 0 && flags) atomicOr(&stat[it.job].lds_flags, flags);
 
-    // contig k-mers: the forward key and the reverse-complement key are two independent questions, each answered by the
-    // partition its key hashes to
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {
-        const uint32_t b = (1 + side) * P + it.part;
-        const uint32_t n = min(bcount[jd.bucket_off + b], jd.cap_t);
-        const uint32_t *list = lists + jd.list_off_t + (uint64_t)(side * P + it.part) * jd.cap_t;
-        uint8_t *ans = side ? ans_c : ans_f;
+    // contig k-mers: "is it in the set" and "is its reverse complement" are the two orientation counts of its canonical key
+    {
+        const uint32_t n = min(bcount[jd.bucket_off + P + it.part], jd.cap_t);
+        const uint32_t *list = lists + jd.list_off_t + (uint64_t)it.part * jd.cap_t;
         for (uint32_t e0 = threadIdx.x; e0 < n; e0 += KU * LDS_THREADS) {
             uint32_t pos[KU]; uint64_t x[KU]; bool ok[KU];
 #pragma unroll
@@ -514,16 +522,23 @@ __global__ __launch_bounds__(LDS_THREADS) void k_kmer_lds(const PartItem *__rest
 #pragma unroll
             for (int u = 0; u < KU; ++u) {
                 if (!ok[u]) continue;
-                const uint64_t key = side ? (x[u] ^ kmer_mask(k)) : rev_groups(x[u], k);
+                bool other, self_rc;
+                const uint64_t key = canon_key(x[u], k, &other, &self_rc);
                 uint32_t s = khash(key) & (LDS_SLOTS - 1);
-                uint32_t a = ANS_ABSENT;
+                uint32_t same = 0, opposite = 0;
                 for (int probes = 0; probes < LDS_SLOTS; ++probes) {
                     const unsigned long long cur = keys[s];
-                    if (cur == key) { a = ANS_PRESENT; break; }
+                    if (cur == key) {
+                        const uint32_t w = cnt2[s >> 1] >> (16 * (s & 1));
+                        const uint32_t c0 = w & 0xFFu, c1 = (w >> 8) & 0xFFu;
+                        same = other ? c1 : c0; opposite = self_rc ? c0 : (other ? c0 : c1);
+                        break;
+                    }
                     if (cur == EMPTY_KEY) break;
                     s = (s + 1) & (LDS_SLOTS - 1);
                 }
-                ans[jd.tpos_off + pos[u]] = (uint8_t)a;
+                ans_f[jd.tpos_off + pos[u]] = (uint8_t)(same ? ANS_PRESENT : ANS_ABSENT);
+                ans_c[jd.tpos_off + pos[u]] = (uint8_t)(opposite ? ANS_PRESENT : ANS_ABSENT);
             }
         }
     }
@@ -1962,11 +1977,11 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
         const uint64_t parts = std::max<uint64_t>(1, (n_ref_kmers + LDS_FILL - 1) / LDS_FILL);
         if (lds_sets && parts <= LDS_MAX_PARTS) {
             jd.n_parts = (uint32_t)parts;
-            jd.bucket_off = (uint32_t)n_bcount; n_bcount += 3 * parts;
+            jd.bucket_off = (uint32_t)n_bcount; n_bcount += 2 * parts;
             jd.cap_r = bucket_cap(jd.ref_len, jd.n_parts);
             jd.cap_t = bucket_cap(jd.tig_len, jd.n_parts);
             jd.list_off_r = n_lists; n_lists += parts * jd.cap_r;
-            jd.list_off_t = n_lists; n_lists += 2 * parts * jd.cap_t;
+            jd.list_off_t = n_lists; n_lists += parts * jd.cap_t;
         } else {
             const uint32_t cap = pow2_at_least(2ull * jd.ref_len + 2);
             jd.ht_off = a_h; jd.ht_mask = cap - 1; a_h += cap;
