@@ -457,6 +457,45 @@ def test_density_vs_oracle_seeded(built, gpu_ctx, seed, mode, kmer):
     assert n_final >= 4
 
 
+@pytest.mark.parametrize('k', [6, 12, 31])
+@pytest.mark.parametrize('ref_rc', [False, True])
+def test_kmer_states_for_even_k_and_palindromes(built, gpu_ctx, k, ref_rc):
+    """The LDS k-mer sets are keyed by the canonical k-mer with one count per orientation.  For even k a k-mer can be its own
+    reverse complement (both membership answers are then the same count); with k = 6 nearly every k-mer of a few kbp occurs in
+    both orientations.  STATE_MER / INDEX / KMER and the per-state counts against the scalar oracle and against the HBM-table
+    kernels (oriented keys, two probes: an independent implementation), with and without -r."""
+    from oracle import oracle
+    rng = np.random.default_rng(100 + k)
+    lut = np.frombuffer(b'ACGT', dtype=np.uint8)
+    n = 6000 if k > 6 else 700
+    ref = lut[rng.integers(0, 4, n)]
+    pal = np.frombuffer(b'ACGTACGTTGCATGCAGAATTCGGATCC' * 4, dtype=np.uint8)          # runs of self-reverse-complement words
+    ref[100:100 + pal.shape[0]] = pal
+    tig = ref.copy()
+    cut = n // 3
+    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+    tig[cut:2 * cut] = np.array([comp[int(b)] for b in tig[cut:2 * cut][::-1]], dtype=np.uint8)   # an inverted third
+    tig[10:40] = lut[rng.integers(0, 4, 30)]
+    gpu_ctx._inv_loaded = None
+    gpu_ctx.seq_load(_lib.PAV_ROLE_REF, ['chrP'], [ref])
+    gpu_ctx.seq_load(_lib.PAV_ROLE_TIG, ['tigP'], [tig])
+    job = _lib.DenJob(0, 0, 0, n, 0, n, 1 if ref_rc else 0, 20)
+    limit = 250
+    o = oracle.density(ref, tig, ref_rc, oracle.den_params(k=k, min_informative=10, min_state_count=1, max_ref_kmer_count=limit))
+    got = {}
+    for kmer in (_lib.KMER_LDS, _lib.KMER_HBM):
+        res = gpu_ctx.density_batch([job], pavden.den_params(k=k, kmer_mode=kmer, min_informative=10, min_state_count=1,
+                                                             max_ref_kmer_count=limit))[0]
+        assert res.status == o['status'] and res.n_rows == o['n'], (kmer, res.status, o['status'])
+        cols = gpu_ctx.density_table(0, res.n_rows)
+        got[kmer] = {c: cols[c].copy() for c in ('INDEX', 'STATE_MER', 'STATE', 'KMER')}
+        for c in ('INDEX', 'STATE_MER', 'KMER'):
+            assert np.array_equal(cols[c], o[c]), (kmer, c)
+    assert all(np.array_equal(got[_lib.KMER_LDS][c], got[_lib.KMER_HBM][c]) for c in got[_lib.KMER_LDS])
+    present = set(np.unique(o['STATE_MER']).tolist())
+    assert {0, 2} <= present or {1} <= present                    # forward and inverted (or both-orientation) k-mers are there
+
+
 NEARTIE = ['argmax_search', 'argmax_mirror', 'delta_above', 'delta_below']
 
 
