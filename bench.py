@@ -422,11 +422,15 @@ def main():
     ctx.prof_enable(False)
     t_single = None
     if n_lanes > 1:                                           # and timed without the events: what one lane alone achieves
-        fence()
-        t_a = time.perf_counter()
-        run_steps(args.steps, only=lanes[0])
-        ctx.sync()
-        t_single = time.perf_counter() - t_a
+        run_steps(3, only=lanes[0])                            # (the first passes after the event-profiled leg are not representative)
+        singles = []
+        for _ in range(3):                                    # the median of three regions, as for the line itself
+            fence()
+            t_a = time.perf_counter()
+            run_steps(args.steps, only=lanes[0])
+            ctx.sync()
+            singles.append(time.perf_counter() - t_a)
+        t_single = sorted(singles)[1]
 
     # ---- configs[1] in the same run: K steps of CIGAR-call only, timed and event-profiled the same way ----------------
     def side_leg(workload):
