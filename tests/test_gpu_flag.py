@@ -171,13 +171,13 @@ def test_planned_stage_equals_general_path(built, monkeypatch):
         ctx.close()
 
 
-@pytest.mark.parametrize('kind', ['snv_only', 'indel_only', 'ins_only', 'one_row_each'])
+@pytest.mark.parametrize('kind', ['snv_only', 'indel_only', 'ins_only', 'one_row_each', 'long_cluster'])
 def test_planned_stage_on_one_sided_tables(built, monkeypatch, kind):
     """Tables with nothing in one of the branches - no INS / DEL rows at all, no SNV rows, insertions without a single deletion
     (the matches have nothing to search), one row of each - through the planned stage and through the general path."""
     from pav_amd import _lib
     rng = np.random.default_rng(11)
-    n = 60_000
+    n = 60_000 if kind != 'long_cluster' else 260_000
     ref = rng.integers(0, 4, n).astype(np.uint8)
     tig = ref.copy()
     ops = []                                                   # (code, length) over the reference; the contig is edited to match
@@ -204,6 +204,15 @@ def test_planned_stage_on_one_sided_tables(built, monkeypatch, kind):
     elif kind == 'ins_only':
         for _ in range(200):
             ins(int(rng.integers(4, 90))); eq(int(rng.integers(5, 40)))
+    elif kind == 'long_cluster':                                # one cluster of 45 000 SNV rows (176 blocks of 256: the wave walks the
+        for _ in range(300):                                    # block notes 64 at a time), short ones around it
+            snv(); eq(int(rng.integers(2, 9)))
+        eq(300)
+        for _ in range(45_000):
+            snv(); eq(int(rng.integers(1, 4)))
+        eq(300)
+        for _ in range(25):
+            snv(); eq(3)
     else:
         snv(); eq(100); ins(7); eq(100); dele(9); eq(100)
     eq(500)
@@ -217,7 +226,7 @@ def test_planned_stage_on_one_sided_tables(built, monkeypatch, kind):
         text = np.frombuffer(''.join(ops).encode(), dtype=np.uint8)
         ctx.cigar_load(aln, text, np.array([0, text.shape[0]], dtype=np.uint64))
         counts = ctx.cigar_call()
-        assert (counts.n_snv == 0) == (kind in ('indel_only', 'ins_only')) and (counts.n_indel == 0) == (kind == 'snv_only')
+        assert (counts.n_snv == 0) == (kind in ('indel_only', 'ins_only')) and (counts.n_indel == 0) == (kind in ('snv_only', 'long_cluster'))
         tp, te = np.array([-1], dtype=np.int64), np.array([1 << 40], dtype=np.int64)
         got = {}
         for mode in ('planned', 'general'):
@@ -229,6 +238,9 @@ def test_planned_stage_on_one_sided_tables(built, monkeypatch, kind):
         sizes = got['planned'][3]
         if kind == 'snv_only':
             assert sizes['cluster_snv'] >= 1 and sizes['insdel_indel'] == 0
+        if kind == 'long_cluster':
+            rec = np.frombuffer(got['planned'][0]['cluster_snv'], dtype=_lib.FLAG_RGN_DTYPE)
+            assert sorted(rec['count'].tolist()) == [300, 45_000]          # (the 25-row cluster behind them spans 100 bp: too short)
         if kind == 'indel_only':
             assert sizes['cluster_indel'] >= 1 and sizes['insdel_indel'] + sizes['insdel_sv'] >= 1
         if kind == 'ins_only':
