@@ -1238,14 +1238,14 @@ __device__ __forceinline__ void period_in_scan_order(const Period &per, int dir,
 }
 
 __device__ uint32_t hom_scan(const SeqRef &t, int64_t t_pos, int dir, int64_t avail, const SeqRef &sv, int64_t sv_pos,
-                             int64_t svlen, int max_steps, bool &done, const Period *per = nullptr) {
+                             int64_t svlen, int max_steps, bool &done, bool has_per = false, Period per = Period{0, 0}) {
     done = true;
     if (svlen <= 0 || avail <= 0) return 0;
     int64_t h = 0;
     if (svlen <= 32) {
         const int L = (int)svlen;
         uint64_t pc; uint32_t pm;
-        if (per) period_in_scan_order(*per, dir, L, pc, pm);
+        if (has_per) period_in_scan_order(per, dir, L, pc, pm);
         else fetch_run(sv, dir < 0 ? sv_pos + svlen - 1 : sv_pos, dir, L, pc, pm);
         const int reps = 32 / L, n = reps * L;
         uint64_t P = pc; uint32_t M = pm;
@@ -1287,11 +1287,11 @@ __device__ __forceinline__ int64_t bcast64(int64_t v, int src) { return (int64_t
 // the c-th window, so a 5 kb homology costs a handful of steps instead of ~160 dependent ones.
 // Must be called by all 64 lanes; `active` masks lanes without work.  `h0` resumes a scan known to match up to h0.
 __device__ uint32_t wave_hom_scan(bool active, const SeqRef &t, int64_t t_pos, int dir, int64_t avail, const SeqRef &sv,
-                                  int64_t sv_pos, int64_t svlen, const Period *per = nullptr) {
+                                  int64_t sv_pos, int64_t svlen, bool has_per = false, Period per = Period{0, 0}) {
     const int lane = threadIdx.x & 63;
     bool done = true;
     uint32_t res = 0;
-    if (active) res = hom_scan(t, t_pos, dir, avail, sv, sv_pos, svlen, 3, done, per);
+    if (active) res = hom_scan(t, t_pos, dir, avail, sv, sv_pos, svlen, 3, done, has_per, per);
     unsigned long long pending = __ballot(active && !done);
     while (pending) {
         const int src = __ffsll((long long)pending) - 1;
@@ -1483,8 +1483,8 @@ __device__ __forceinline__ uint32_t left_hom(const SeqRef &t, int64_t pos, const
     return hom_scan(t, pos, -1, pos + 1, sv, sv_pos, svlen, 0x7FFFFFFF, done);
 }
 __device__ __forceinline__ uint32_t wave_left_hom(bool active, const SeqRef &t, int64_t pos, const SeqRef &sv, int64_t sv_pos, int64_t svlen,
-                                                  const Period *per) {
-    return wave_hom_scan(active, t, pos, -1, pos + 1, sv, sv_pos, svlen, per);
+                                                  bool has_per, Period per) {      // (by value: a pointer to the caller's copy kept it in scratch memory)
+    return wave_hom_scan(active, t, pos, -1, pos + 1, sv, sv_pos, svlen, has_per, per);
 }
 
 // right_homology(pos_tig, seq_tig, seq_sv)  call.py:595-647: walks downstream while hom_len < len - pos_tig
@@ -1526,7 +1526,7 @@ __global__ __launch_bounds__(64) void homology_kernel(pav_indel *__restrict__ in
     const bool periodic = active && oplen > 0 && oplen <= 32;
     Period per{0, 0};
     if (periodic) fetch_run(svs, sv_at, +1, (int)oplen, per.c, per.m);
-    const uint32_t hs = wave_left_hom(active && r.left_shift != 0, ref, pos_ref - 1, svs, sv_at, oplen, periodic ? &per : nullptr);
+    const uint32_t hs = wave_left_hom(active && r.left_shift != 0, ref, pos_ref - 1, svs, sv_at, oplen, periodic, per);
     const int64_t shift = r.left_shift ? ((int64_t)hs < (int64_t)r.left_shift ? (int64_t)hs : (int64_t)r.left_shift) : 0;
     const int64_t sv_pos_ref = pos_ref - shift, sv_pos_tig = pos_tig - shift;
     if (ins && shift) {                                // INS: seq re-sliced at the shifted position (:162-163)

@@ -695,9 +695,20 @@ __device__ __host__ __forceinline__ bool fwd_only(const JobStat &js, uint32_t mi
     return js.st_count[1] < min_state_count && js.st_count[2] < min_state_count;
 }
 
-__device__ __forceinline__ int keep_state(int st, const JobStat &js, uint32_t min_state_count) {
+// The three STATE_MER counts of a region in registers.  (The kernels used to copy the whole JobStat and index st_count[] with the
+// row's state: a dynamically indexed private array lives in scratch memory, so every lane wrote 128 B of JobStat through the caches
+// to HBM - WRITE_SIZE of k_compact_scatter was 235 MB per launch for 120 MB of rows.)
+struct StateCounts { uint32_t c0, c1, c2; };
+__device__ __forceinline__ StateCounts state_counts(const JobStat *stat, uint32_t j) {
+    return StateCounts{stat[j].st_count[0], stat[j].st_count[1], stat[j].st_count[2]};
+}
+__device__ __forceinline__ bool fwd_only(const StateCounts &sc, uint32_t min_state_count) {
+    return sc.c1 < min_state_count && sc.c2 < min_state_count;
+}
+__device__ __forceinline__ int keep_state(int st, const StateCounts &sc, uint32_t min_state_count) {
     if (st < 0) return -1;
-    return js.st_count[st] >= min_state_count ? st : -1;               // low-count states are dropped (density.py:181-190)
+    const uint32_t n = st == 0 ? sc.c0 : st == 1 ? sc.c1 : sc.c2;
+    return n >= min_state_count ? st : -1;                             // low-count states are dropped (density.py:181-190)
 }
 
 __global__ __launch_bounds__(256) void k_compact_reduce(const uint32_t *__restrict__ tile_job, const JobStat *__restrict__ stat,
@@ -705,7 +716,7 @@ __global__ __launch_bounds__(256) void k_compact_reduce(const uint32_t *__restri
                                                         uint32_t *__restrict__ tile_sum /* [tiles][4] */) {
     __shared__ uint32_t lds[16];
     const uint32_t j = tile_job[blockIdx.x];
-    const JobStat js = stat[j];
+    const StateCounts js = state_counts(stat, j);
     const uint64_t base = (uint64_t)blockIdx.x * DTILE + (uint64_t)threadIdx.x * 8;
     const uint64_t packed = *reinterpret_cast<const uint64_t *>(st_tmp + base);
     uint32_t c[4] = {0, 0, 0, 0};
@@ -770,7 +781,7 @@ __global__ __launch_bounds__(256) void k_compact_scatter(CompactArgs A) {
     __shared__ int8_t s_mer[DTILE];
     const uint32_t j = A.tile_job[blockIdx.x];
     const JobDev jd = A.jobs[j];
-    const JobStat js = A.stat[j];
+    const StateCounts js = state_counts(A.stat, j);
     if (A.scan_only && fwd_only(js, A.min_state_count)) return;       // nobody will read this region's rows
     const uint64_t base = (uint64_t)blockIdx.x * DTILE + (uint64_t)threadIdx.x * 8;
     const uint64_t packed = *reinterpret_cast<const uint64_t *>(A.st_tmp + base);
