@@ -1586,9 +1586,14 @@ __global__ void homology_query_kernel(const pav_hom_query *__restrict__ q, uint3
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const pav_hom_query h = q[i];
-    const SeqView &a = h.role == PAV_ROLE_REF ? R : T;
-    const SeqView &b = h.sv_role == PAV_ROLE_REF ? R : T;
-    const SeqRef t = seq_ref(a, (uint32_t)h.seq_id, h.rev != 0), sv = seq_ref(b, (uint32_t)h.sv_seq_id, h.sv_rev != 0);
+    // (one store or the other, field by field: a reference picked at run time would keep both views in scratch memory)
+    auto pick = [&](bool is_ref, uint32_t id, int rev) {
+        const bool packed = (is_ref ? R.packed : T.packed) != 0;
+        const uint64_t off = is_ref ? R.off[id] : T.off[id], len = is_ref ? R.len[id] : T.len[id];
+        if (packed) return SeqRef{is_ref ? R.two : T.two, is_ref ? R.mask : T.mask, is_ref ? R.dirty : T.dirty, off, len, rev};
+        return SeqRef{nullptr, nullptr, is_ref ? R.ascii : T.ascii, off, len, rev};
+    };
+    const SeqRef t = pick(h.role == PAV_ROLE_REF, (uint32_t)h.seq_id, h.rev != 0), sv = pick(h.sv_role == PAV_ROLE_REF, (uint32_t)h.sv_seq_id, h.sv_rev != 0);
     out[i] = h.dir == 0 ? left_hom(t, h.pos, sv, h.sv_pos, h.svlen) : right_hom(t, h.pos, sv, h.sv_pos, h.svlen);
 }
 
