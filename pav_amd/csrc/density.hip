@@ -458,89 +458,96 @@ __global__ __launch_bounds__(LDS_THREADS) void k_kmer_lds(const PartItem *__rest
     if (it.job == ~0u) return;                                          // padding of the XCD-grouped order
     const JobDev jd = jobs[it.job];
     const uint32_t P = jd.n_parts;
+    const uint32_t n_ref = min(bcount[jd.bucket_off + it.part], jd.cap_r), n_tig = min(bcount[jd.bucket_off + P + it.part], jd.cap_t);
+    const uint32_t *list_r = lists + jd.list_off_r + (uint64_t)it.part * jd.cap_r;
+    const uint32_t *list_t = lists + jd.list_off_t + (uint64_t)it.part * jd.cap_t;
+
+    // The kernel is a chain of latencies - list entry -> window of the plane -> LDS table - once for the reference k-mers and once
+    // for the contig k-mers, and a partition is about one step of the workgroup in either list (KU entries per lane).  The first
+    // step of BOTH lists is therefore put in flight before the table is cleared: its positions, then its windows, wait in
+    // registers while the reference k-mers go in.  (Round 3; before, the four round trips ran one after the other: 0.104 ms.)
+    uint32_t pos_r[KU], pos_t[KU]; bool ok_r[KU], ok_t[KU];
+    KmerWords kw_r[KU], kw_t[KU];
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+        const uint32_t e = threadIdx.x + u * LDS_THREADS;
+        ok_r[u] = e < n_ref; pos_r[u] = n_ref ? list_r[ok_r[u] ? e : n_ref - 1] : 0u;
+        ok_t[u] = e < n_tig; pos_t[u] = n_tig ? list_t[ok_t[u] ? e : n_tig - 1] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < KU; ++u) { kw_r[u] = kmer_words(R.two, jd.ref_abs + pos_r[u]); kw_t[u] = kmer_words(T.two, jd.tig_abs + pos_t[u]); }
+
     for (int s = threadIdx.x; s < LDS_SLOTS; s += LDS_THREADS) keys[s] = EMPTY_KEY;
     for (int s = threadIdx.x; s < LDS_SLOTS / 2; s += LDS_THREADS) cnt2[s] = 0;
     if (threadIdx.x == 0) flags = 0;
     __syncthreads();
 
     // reference k-mers of this partition -> LDS set with byte counts per orientation
-    {
-        const uint32_t n = min(bcount[jd.bucket_off + it.part], jd.cap_r);
-        const uint32_t *list = lists + jd.list_off_r + (uint64_t)it.part * jd.cap_r;
-        uint32_t my_flags = 0;
-        // KU list entries per lane and step: their positions, then their windows are fetched before the first insert, so
-        // that a lane has several global loads in flight (the kernel is latency-bound: 16 waves per CU, dependent loads)
-        for (uint32_t e0 = threadIdx.x; e0 < n; e0 += KU * LDS_THREADS) {
-            uint32_t pos[KU]; uint64_t x[KU]; bool ok[KU];
-#pragma unroll
-            for (int u = 0; u < KU; ++u) { const uint32_t e = e0 + u * LDS_THREADS; ok[u] = e < n; pos[u] = list[ok[u] ? e : n - 1]; }
-            KmerWords kw[KU];
-#pragma unroll
-            for (int u = 0; u < KU; ++u) kw[u] = kmer_words(R.two, jd.ref_abs + pos[u]);
-#pragma unroll
-            for (int u = 0; u < KU; ++u) x[u] = kmer_from_words(kw[u], jd.ref_abs + pos[u], k);
-#pragma unroll
-            for (int u = 0; u < KU; ++u) {
-                if (!ok[u]) continue;
-                bool other, self_rc;
-                const uint64_t key = canon_key(x[u], k, &other, &self_rc);
-                // the set holds the region's k-mers as they are (-r: reverse-complemented): which orientation of the key that is
-                const uint32_t o = self_rc ? 0u : (uint32_t)(other != (jd.ref_rc != 0));
-                uint32_t s = khash(key) & (LDS_SLOTS - 1);
-                int probes = 0;
-                while (true) {
-                    const unsigned long long old = atomicCAS(&keys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
-                    if (old == EMPTY_KEY || old == key) {
-                        const uint32_t sh = 16 * (s & 1) + 8 * o;
-                        const uint32_t prev = (atomicAdd(&cnt2[s >> 1], 1u << sh) >> sh) & 0xFFu;        // occurrences so far
-                        if (prev + 1 > limit) my_flags |= LDS_EXCEED;
-                        break;
-                    }
-                    s = (s + 1) & (LDS_SLOTS - 1);
-                    if (++probes >= LDS_SLOTS) { my_flags |= LDS_OVERFLOW; break; }
-                }
+    uint32_t my_flags = 0;
+    auto insert = [&](uint64_t x) __attribute__((always_inline)) {
+        bool other, self_rc;
+        const uint64_t key = canon_key(x, k, &other, &self_rc);
+        // the set holds the region's k-mers as they are (-r: reverse-complemented): which orientation of the key that is
+        const uint32_t o = self_rc ? 0u : (uint32_t)(other != (jd.ref_rc != 0));
+        uint32_t s = khash(key) & (LDS_SLOTS - 1);
+        int probes = 0;
+        while (true) {
+            const unsigned long long old = atomicCAS(&keys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+            if (old == EMPTY_KEY || old == key) {
+                const uint32_t sh = 16 * (s & 1) + 8 * o;
+                const uint32_t prev = (atomicAdd(&cnt2[s >> 1], 1u << sh) >> sh) & 0xFFu;        // occurrences so far
+                if (prev + 1 > limit) my_flags |= LDS_EXCEED;
+                break;
             }
+            s = (s + 1) & (LDS_SLOTS - 1);
+            if (++probes >= LDS_SLOTS) { my_flags |= LDS_OVERFLOW; break; }
         }
-        if (my_flags) atomicOr(&flags, my_flags);
+    };
+#pragma unroll
+    for (int u = 0; u < KU; ++u) if (ok_r[u]) insert(kmer_from_words(kw_r[u], jd.ref_abs + pos_r[u], k));
+    for (uint32_t e0 = threadIdx.x + KU * LDS_THREADS; e0 < n_ref; e0 += KU * LDS_THREADS) {         // a partition longer than one step
+        uint32_t pos[KU]; bool ok[KU]; KmerWords kw[KU];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) { const uint32_t e = e0 + u * LDS_THREADS; ok[u] = e < n_ref; pos[u] = list_r[ok[u] ? e : n_ref - 1]; }
+#pragma unroll
+        for (int u = 0; u < KU; ++u) kw[u] = kmer_words(R.two, jd.ref_abs + pos[u]);
+#pragma unroll
+        for (int u = 0; u < KU; ++u) if (ok[u]) insert(kmer_from_words(kw[u], jd.ref_abs + pos[u], k));
     }
+    if (my_flags) atomicOr(&flags, my_flags);
     __syncthreads();
     if (threadIdx.x == 0 && flags) atomicOr(&stat[it.job].lds_flags, flags);
 
     // contig k-mers: "is it in the set" and "is its reverse complement" are the two orientation counts of its canonical key
-    {
-        const uint32_t n = min(bcount[jd.bucket_off + P + it.part], jd.cap_t);
-        const uint32_t *list = lists + jd.list_off_t + (uint64_t)it.part * jd.cap_t;
-        for (uint32_t e0 = threadIdx.x; e0 < n; e0 += KU * LDS_THREADS) {
-            uint32_t pos[KU]; uint64_t x[KU]; bool ok[KU];
-#pragma unroll
-            for (int u = 0; u < KU; ++u) { const uint32_t e = e0 + u * LDS_THREADS; ok[u] = e < n; pos[u] = list[ok[u] ? e : n - 1]; }
-            KmerWords kw[KU];
-#pragma unroll
-            for (int u = 0; u < KU; ++u) kw[u] = kmer_words(T.two, jd.tig_abs + pos[u]);
-#pragma unroll
-            for (int u = 0; u < KU; ++u) x[u] = kmer_from_words(kw[u], jd.tig_abs + pos[u], k);
-#pragma unroll
-            for (int u = 0; u < KU; ++u) {
-                if (!ok[u]) continue;
-                bool other, self_rc;
-                const uint64_t key = canon_key(x[u], k, &other, &self_rc);
-                uint32_t s = khash(key) & (LDS_SLOTS - 1);
-                uint32_t same = 0, opposite = 0;
-                for (int probes = 0; probes < LDS_SLOTS; ++probes) {
-                    const unsigned long long cur = keys[s];
-                    if (cur == key) {
-                        const uint32_t w = cnt2[s >> 1] >> (16 * (s & 1));
-                        const uint32_t c0 = w & 0xFFu, c1 = (w >> 8) & 0xFFu;
-                        same = other ? c1 : c0; opposite = self_rc ? c0 : (other ? c0 : c1);
-                        break;
-                    }
-                    if (cur == EMPTY_KEY) break;
-                    s = (s + 1) & (LDS_SLOTS - 1);
-                }
-                ans_f[jd.tpos_off + pos[u]] = (uint8_t)(same ? ANS_PRESENT : ANS_ABSENT);
-                ans_c[jd.tpos_off + pos[u]] = (uint8_t)(opposite ? ANS_PRESENT : ANS_ABSENT);
+    auto answer = [&](uint64_t x, uint32_t pos) __attribute__((always_inline)) {
+        bool other, self_rc;
+        const uint64_t key = canon_key(x, k, &other, &self_rc);
+        uint32_t s = khash(key) & (LDS_SLOTS - 1);
+        uint32_t same = 0, opposite = 0;
+        for (int probes = 0; probes < LDS_SLOTS; ++probes) {
+            const unsigned long long cur = keys[s];
+            if (cur == key) {
+                const uint32_t w = cnt2[s >> 1] >> (16 * (s & 1));
+                const uint32_t c0 = w & 0xFFu, c1 = (w >> 8) & 0xFFu;
+                same = other ? c1 : c0; opposite = self_rc ? c0 : (other ? c0 : c1);
+                break;
             }
+            if (cur == EMPTY_KEY) break;
+            s = (s + 1) & (LDS_SLOTS - 1);
         }
+        ans_f[jd.tpos_off + pos] = (uint8_t)(same ? ANS_PRESENT : ANS_ABSENT);
+        ans_c[jd.tpos_off + pos] = (uint8_t)(opposite ? ANS_PRESENT : ANS_ABSENT);
+    };
+#pragma unroll
+    for (int u = 0; u < KU; ++u) if (ok_t[u]) answer(kmer_from_words(kw_t[u], jd.tig_abs + pos_t[u], k), pos_t[u]);
+    for (uint32_t e0 = threadIdx.x + KU * LDS_THREADS; e0 < n_tig; e0 += KU * LDS_THREADS) {
+        uint32_t pos[KU]; bool ok[KU]; KmerWords kw[KU];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) { const uint32_t e = e0 + u * LDS_THREADS; ok[u] = e < n_tig; pos[u] = list_t[ok[u] ? e : n_tig - 1]; }
+#pragma unroll
+        for (int u = 0; u < KU; ++u) kw[u] = kmer_words(T.two, jd.tig_abs + pos[u]);
+#pragma unroll
+        for (int u = 0; u < KU; ++u) if (ok[u]) answer(kmer_from_words(kw[u], jd.tig_abs + pos[u], k), pos[u]);
     }
 }
 
