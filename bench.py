@@ -147,7 +147,9 @@ def main():
     threads = args.threads or max(1, effective_cpus() // max(1, world))
     threads = min(threads, 16)
     cpus_per_rank = effective_cpus() / max(1, world)
-    n_lanes = args.lanes if args.lanes > 0 else (4 if cpus_per_rank >= 4 else (2 if cpus_per_rank >= 2 else 1))   # measured: 4 lanes want 4 cores, 2 want 2
+    # measured: a lane wants a core; six lanes fill the GPU (round 3, 20-step regions: 4 / 5 / 6 / 8 lanes = 1 870 / 2 010 / 2 090 / 2 090
+    # Gbp/s - with the host gaps of a pass shortened the fifth and sixth lane find room that four lanes left; round 2: four)
+    n_lanes = args.lanes if args.lanes > 0 else (6 if cpus_per_rank >= 6 else (4 if cpus_per_rank >= 4 else (2 if cpus_per_rank >= 2 else 1)))
     gen_kw = {'pair_frac': args.pair_frac} if args.workload == 'cigar+inv' and args.pair_frac > 0 else {}
     if rank == 0:
         print(f'[bench] {world} rank(s) x {n_lanes} lane(s) per GPU (--lanes {args.lanes}: 0 = auto), {cpus_per_rank:.1f} usable CPUs per rank '
