@@ -9,6 +9,9 @@
 #include "textio.h"
 #include "pool.h"
 
+#include <sys/mman.h>
+#include <new>
+
 #include <algorithm>
 #include <cmath>
 #include <map>
@@ -41,10 +44,40 @@ struct Scan {                       // per flagged region
     uint32_t n_rows = 0;
 };
 
+// The lift tables of a haplotype (operations and their begins on both axes: 3 x 36 MB) are read at random - two point queries per
+// flagged region and scan round, each three dependent misses.  On 4 KiB pages every miss is a TLB miss as well (and with six
+// resident haplotypes in one process the page tables themselves fall out of the caches: the same lookups took twice as long as
+// in a process with one); the tables sit on 2 MiB pages.
+template <class T> class HugeArray {
+public:
+    HugeArray() = default;
+    HugeArray(const HugeArray &) = delete;
+    HugeArray &operator=(const HugeArray &) = delete;
+    ~HugeArray() { free(p_); }
+    void resize(size_t n) {                                  // contents are not kept
+        if (n > cap_) {
+            free(p_);
+            const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + (2u << 20) - 1) & ~((size_t)(2u << 20) - 1);
+            p_ = static_cast<T *>(aligned_alloc(2u << 20, bytes));
+            if (!p_) throw std::bad_alloc();
+            if (!getenv("PAV_NO_HUGE")) (void)madvise(p_, bytes, MADV_HUGEPAGE);
+            cap_ = bytes / sizeof(T);
+        }
+        n_ = n;
+    }
+    T *data() { return p_; }
+    const T *data() const { return p_; }
+    size_t size() const { return n_; }
+    T &operator[](size_t i) { return p_[i]; }
+    const T &operator[](size_t i) const { return p_[i]; }
+private:
+    T *p_ = nullptr; size_t n_ = 0, cap_ = 0;
+};
+
 struct InvState {
     // lift-over index (pav_inv_load_alignments)
     std::vector<LiftRow> rows;
-    std::vector<uint32_t> ops, sub_begin, qry_begin;
+    HugeArray<uint32_t> ops, sub_begin, qry_begin;
     // first level of op_at, per axis: a record's begins are cut into position buckets of 2^shift bases (about 16 operations per
     // bucket on average); bucket[bucket_off[row] + b] = operations of the record (relative to its first) that begin before
     // base + (b << shift).  One read bounds the search in the 36 MB begin array to a few lines.
@@ -406,7 +439,7 @@ int pav_inv_load_alignments(pav_ctx *ctx, uint32_t n, const pav_inv_aln *aln, co
     if (rc != PAV_OK) return rc;
     if (n == 0) S->op_off.assign(1, 0);
     for (int axis = 0; axis < 2; ++axis) {
-        const std::vector<uint32_t> &src = axis == 0 ? S->sub_begin : S->qry_begin;
+        const HugeArray<uint32_t> &src = axis == 0 ? S->sub_begin : S->qry_begin;
         InvState::Buckets &B = S->buckets[axis];
         B.first.clear(); B.off.assign((size_t)n + 1, 0); B.shift.assign(n, 0); B.base.assign(n, 0);
         for (uint32_t r = 0; r < n; ++r) {
