@@ -644,7 +644,12 @@ class Context:
     def inv_scan_batch(self, regions, params):
         regions = np.ascontiguousarray(regions, dtype=INV_REGION_DTYPE)
         n = regions.shape[0]
-        res = (InvResult * max(n, 1))()
+        # the result block is kept between scans of the same size (half a megabyte of fresh zeroed memory per scan of a thousand
+        # regions otherwise); like the table views it is valid until the next scan on this context
+        cached = getattr(self, '_inv_res_buf', None)
+        if cached is None or len(cached) != max(n, 1):
+            cached = self._inv_res_buf = (InvResult * max(n, 1))()
+        res = cached
         self._inv_generation = getattr(self, '_inv_generation', 0) + 1      # invalidates table views of earlier scans
         self._check(self.lib.pav_inv_scan_batch(self.handle, n, _ptr(regions), ctypes.byref(params), res), 'pav_inv_scan_batch')
         return res
