@@ -171,13 +171,13 @@ def test_planned_stage_equals_general_path(built, monkeypatch):
         ctx.close()
 
 
-@pytest.mark.parametrize('kind', ['snv_only', 'indel_only', 'ins_only', 'one_row_each', 'long_cluster'])
+@pytest.mark.parametrize('kind', ['snv_only', 'indel_only', 'ins_only', 'one_row_each', 'long_cluster', 'many_hits'])
 def test_planned_stage_on_one_sided_tables(built, monkeypatch, kind):
     """Tables with nothing in one of the branches - no INS / DEL rows at all, no SNV rows, insertions without a single deletion
     (the matches have nothing to search), one row of each - through the planned stage and through the general path."""
     from pav_amd import _lib
     rng = np.random.default_rng(11)
-    n = 60_000 if kind != 'long_cluster' else 260_000
+    n = {'long_cluster': 260_000, 'many_hits': 5_000_000}.get(kind, 60_000)
     ref = rng.integers(0, 4, n).astype(np.uint8)
     tig = ref.copy()
     ops = []                                                   # (code, length) over the reference; the contig is edited to match
@@ -213,6 +213,13 @@ def test_planned_stage_on_one_sided_tables(built, monkeypatch, kind):
         eq(300)
         for _ in range(25):
             snv(); eq(3)
+    elif kind == 'many_hits':                                   # more hits in every list than come back with the counters (4096 each)
+        for g in range(4500):
+            for _ in range(22):                                 # a cluster of 22 SNVs over 220 bp ...
+                snv(); eq(9)
+            eq(150)
+            ins(int(rng.integers(5, 12))); eq(3); dele(int(rng.integers(5, 12)))              # ... and an INS next to a DEL
+            eq(2600 if g % 10 == 9 else 300)                    # (matches closer than 2 kbp merge into one interval)
     else:
         snv(); eq(100); ins(7); eq(100); dele(9); eq(100)
     eq(500)
@@ -238,6 +245,8 @@ def test_planned_stage_on_one_sided_tables(built, monkeypatch, kind):
         sizes = got['planned'][3]
         if kind == 'snv_only':
             assert sizes['cluster_snv'] >= 1 and sizes['insdel_indel'] == 0
+        if kind == 'many_hits':
+            assert sizes['cluster_snv'] == 4500 and sizes['insdel_indel'] == 449       # 450 merged intervals, the last never written (:575-583)
         if kind == 'long_cluster':
             rec = np.frombuffer(got['planned'][0]['cluster_snv'], dtype=_lib.FLAG_RGN_DTYPE)
             assert sorted(rec['count'].tolist()) == [300, 45_000]          # (the 25-row cluster behind them spans 100 bp: too short)
