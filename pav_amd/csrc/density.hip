@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void k_tig_state(const JobDev *__restrict__ jo
 // and the exact maximum and its k-mer come from the HBM-table kernels on that failure path.
 constexpr int LDS_SLOTS = PAV_LDS_SLOTS;
 constexpr int LDS_THREADS = PAV_LDS_THREADS;
-constexpr int KU = 4;                                 // list entries a lane of k_kmer_lds has in flight
+constexpr int KU = 2048 / LDS_THREADS;                // list entries a lane of k_kmer_lds has in flight: a step covers 2048 entries, about a partition
 constexpr uint32_t LDS_FILL = LDS_SLOTS * 7 / 16;   // k-mers per partition aimed at (load factor 0.44)
 constexpr uint32_t LDS_MAX_PARTS = 1024;             // histogram size of the bucket kernels (regions up to 1.8 Mbp; MAX_REGION_SIZE is 1.2 Mbp)
 constexpr uint32_t LDS_MAX_LIMIT = 250;              // byte counts: the limit must stay below the wrap
