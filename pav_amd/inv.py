@@ -641,7 +641,10 @@ def loci_regions(ctx, loci, only_try_inv=True):
     chromosome name in str order, as the flag tables sort) -> :class:`RegionColumns` of the loci rule call_inv_batch would
     hand to ``scan_for_inv``: those with TRY_INV (rules/call_inv.snakefile:145-146, 185-196)."""
     names = ctx.seq_names(_lib.PAV_ROLE_REF)
-    by_rank = np.array(sorted(range(len(names)), key=lambda i: names[i]), dtype=np.uint32)
+    cached = getattr(ctx, '_ref_by_rank', None)                      # (the order of the record names: the same for every pass of a context)
+    if cached is None or cached[0] is not names:
+        cached = ctx._ref_by_rank = (names, np.array(sorted(range(len(names)), key=lambda i: names[i]), dtype=np.uint32))
+    by_rank = cached[1]
     sel = loci[loci['try_inv'] != 0] if only_try_inv else loci
     return RegionColumns(by_rank[sel['chrom']] if sel.shape[0] else np.zeros(0, np.uint32), sel['pos'], sel['end'], names)
 
