@@ -1765,41 +1765,53 @@ __global__ __launch_bounds__(256) void k_gather_calls(const GatherCall *__restri
 }
 
 // FLANK / MATCH of the calls' rows where they are (a round whose column block goes to the stage as a whole): what k_gather_calls
-// does, without the copy.  Workgroup b works on 256 rows of the calls counted through (dst_off), as there.
-__global__ __launch_bounds__(256) void k_annotate_calls(const GatherCall *__restrict__ calls, uint32_t n_calls, uint32_t total, int k,
+// does, without the copy.  A lane takes four consecutive rows of the block (one 16-byte load of INDEX, two 4-byte stores);
+// `calls` is sorted by src_off here, rows of the block that belong to no call are left alone.
+__global__ __launch_bounds__(256) void k_annotate_calls(const GatherCall *__restrict__ calls, uint32_t n_calls, uint64_t block_rows, int k,
                                                         const uint32_t *__restrict__ index, const unsigned long long *__restrict__ kmer,
                                                         const unsigned long long *__restrict__ keys, uint8_t *__restrict__ flank,
                                                         uint8_t *__restrict__ match) {
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= total) return;
-    // the call of the workgroup's first and last row with uniform arguments (scalar loads), as in k_gather_calls
-    const uint32_t t_first = blockIdx.x * 256, t_last = min(t_first + 255u, total - 1);
+    const uint64_t p0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p0 >= block_rows) return;
+    // the call of the workgroup's first and last row with uniform arguments (scalar loads); nearly always the same call
+    const uint64_t w_first = (uint64_t)blockIdx.x * 1024, w_last = min(w_first + 1023, block_rows - 1);
     uint32_t lo = 0, hi = n_calls, lo_last = 0;
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (calls[mid].dst_off <= t_first) lo = mid; else hi = mid; }
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (calls[mid].src_off <= w_first) lo = mid; else hi = mid; }
     hi = n_calls; lo_last = lo;
-    while (hi - lo_last > 1) { const uint32_t mid = (lo_last + hi) >> 1; if (calls[mid].dst_off <= t_last) lo_last = mid; else hi = mid; }
-    auto row = [&](const GatherCall &c) __attribute__((always_inline)) {
-        const uint64_t src = c.src_off + (t - c.dst_off);
-        const int64_t q = (int64_t)index[src] + c.base;                    // QRY_INDEX (inv.py:519)
-        uint8_t f = 0;
+    while (hi - lo_last > 1) { const uint32_t mid = (lo_last + hi) >> 1; if (calls[mid].src_off <= w_last) lo_last = mid; else hi = mid; }
+    auto one = [&](const GatherCall &c, uint32_t ix, uint64_t src, uint8_t &f, uint8_t &m) __attribute__((always_inline)) {
+        const int64_t q = (int64_t)ix + c.base;                            // QRY_INDEX (inv.py:519)
+        f = 0; m = 0;
         if (q >= c.up_pos && q < c.up_end - k) f = 1;                      // inv.py:524-527
         if (q >= c.dn_pos && q < c.dn_end - k) f = 2;                      // inv.py:529-532
-        uint8_t m = 0;
         if (f) {                                                           // raw KMER against canonical sets (inv.py:537-553)
             const unsigned long long km = kmer[src];
             const bool in_up = table_has(keys + c.key_up, 0, c.mask_up, km), in_dn = table_has(keys + c.key_dn, 0, c.mask_dn, km);
             const bool same = f == 1 ? in_up : in_dn, other = f == 1 ? in_dn : in_up;
             m = same ? (other ? 3 : 1) : (other ? 2 : 3);                  // KMER_LOC_STATE: NA / OTHER / SAME / NA
         }
-        flank[src] = f;
-        match[src] = m;
     };
     if (lo_last == lo) {
-        row(calls[lo]);
-    } else {                                             // a call boundary inside the workgroup: every lane searches for itself
-        hi = lo_last + 1;
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (calls[mid].dst_off <= t) lo = mid; else hi = mid; }
-        row(calls[lo]);
+        const GatherCall &c = calls[lo];
+        if (p0 >= c.src_off && p0 + 3 < c.src_off + c.n) {                 // four rows of one call: the common case
+            const uint4 ix = *reinterpret_cast<const uint4 *>(index + p0);
+            uint8_t f[4], m[4];
+            one(c, ix.x, p0, f[0], m[0]); one(c, ix.y, p0 + 1, f[1], m[1]); one(c, ix.z, p0 + 2, f[2], m[2]); one(c, ix.w, p0 + 3, f[3], m[3]);
+            *reinterpret_cast<uint32_t *>(flank + p0) = (uint32_t)f[0] | (uint32_t)f[1] << 8 | (uint32_t)f[2] << 16 | (uint32_t)f[3] << 24;
+            *reinterpret_cast<uint32_t *>(match + p0) = (uint32_t)m[0] | (uint32_t)m[1] << 8 | (uint32_t)m[2] << 16 | (uint32_t)m[3] << 24;
+            return;
+        }
+    }
+    for (int r = 0; r < 4; ++r) {                                          // an edge of a call, or a boundary inside the workgroup
+        const uint64_t p = p0 + r;
+        if (p >= block_rows) break;
+        uint32_t a = lo; hi = lo_last + 1;
+        while (hi - a > 1) { const uint32_t mid = (a + hi) >> 1; if (calls[mid].src_off <= p) a = mid; else hi = mid; }
+        const GatherCall &c = calls[a];
+        if (p < c.src_off || p >= c.src_off + c.n) continue;
+        uint8_t f, m;
+        one(c, index[p], p, f, m);
+        flank[p] = f; match[p] = m;
     }
 }
 
@@ -1852,7 +1864,11 @@ int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls, uint6
     CanonJob *d_cj = reinterpret_cast<CanonJob *>(d_gc + gc.size());
     std::vector<uint8_t> &desc_host = stage.desc_host;                 // stays alive until the upload has run
     desc_host.resize(desc_bytes);
-    memcpy(desc_host.data(), gc.data(), sizeof(GatherCall) * gc.size());
+    if (dense) {                                                       // k_annotate_calls walks the block: the descriptors by first row
+        std::vector<GatherCall> by_row(gc);
+        std::sort(by_row.begin(), by_row.end(), [](const GatherCall &x, const GatherCall &y) { return x.src_off < y.src_off; });
+        memcpy(desc_host.data(), by_row.data(), sizeof(GatherCall) * by_row.size());
+    } else memcpy(desc_host.data(), gc.data(), sizeof(GatherCall) * gc.size());
     if (!cj.empty()) memcpy(desc_host.data() + sizeof(GatherCall) * gc.size(), cj.data(), sizeof(CanonJob) * cj.size());
     PAV_HIP(ctx, hipMemsetAsync(d_keys, 0xFF, 8ull * keys, st));
     PAV_HIP(ctx, hipMemcpyAsync(d_gc, desc_host.data(), desc_bytes, hipMemcpyHostToDevice, st));
@@ -1861,7 +1877,7 @@ int density_fetch_calls(pav_ctx *ctx, const std::vector<CallFetch> &calls, uint6
     // Host side (invscan.cpp): the round's block is laid out as whole-round columns, K0 | K1 | K2 | KMER | INDEX | STATE_MER |
     // STATE | FLANK | MATCH, exactly like the device columns: one copy (two when the tail of K1 stays behind).
     if (dense) {
-        PAV_LAUNCH(ctx, "k_annotate_calls", k_annotate_calls, (uint32_t)((total + 255) / 256), 256, 0, d_gc, (uint32_t)gc.size(), (uint32_t)total, k,
+        PAV_LAUNCH(ctx, "k_annotate_calls", k_annotate_calls, (uint32_t)((a_t + 1023) / 1024), 256, 0, d_gc, (uint32_t)gc.size(), a_t, k,
                    D->index.as<uint32_t>(), D->kmer.as<unsigned long long>(), d_keys, D->flank.as<uint8_t>(), D->match.as<uint8_t>());
         // the blocks change hands (host side only: the kernels above and the views of the batch keep their addresses); the block
         // the batch gets is never smaller than the one it gives, so the next batch does not allocate
