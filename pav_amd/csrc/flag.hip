@@ -577,15 +577,33 @@ __global__ __launch_bounds__(256) void k_cluster_sweep(SweepArgs A) {
     const bool real = i < A.n && A.V.real(i, local, n_real);
     const uint64_t first = i - local;                                         // first row of the table
     const int t = i >= A.V.n_snv;
-    const bool closes = real && (local + 1 == n_real || A.V.opens(i + 1, A.win));
+    // the row, the one behind it and the one in front are asked for together: whether the row closes a cluster and whether it
+    // opens one (a single-row cluster: nearly every row) are then answered by one round trip to memory, not by two in a row
+    uint32_t c_prev = 0, c_own = 0, c_next = 0; int64_t m_prev = 0, m_own = 0, m_next = 0;
+    const bool has_prev = real && local != 0, has_next = real && local + 1 != n_real;
+    if (real) A.V.at(i, c_own, m_own);
+    if (has_prev) A.V.at(i - 1, c_prev, m_prev);
+    if (has_next) A.V.at(i + 1, c_next, m_next);
+    const bool closes = real && (!has_next || c_own != c_next || m_next >= m_own + A.win);
+    const bool opens_own = !has_prev || c_prev != c_own || m_own >= m_prev + A.win;
     bool search = closes, report = false;
     uint64_t j = i;
+    // The rows of a wave are consecutive: where the row's cluster starts inside the wave is in the wave's "opens a cluster" bits -
+    // no load, no walk (a third of the SNV rows sit in clusters of two to five).  Only a cluster that began before the wave's
+    // first row is walked, and only while it is still too short to report.
+    const unsigned long long ob = __ballot(real && opens_own);
     if (search) {
         const int64_t need = A.min_count[t] > 1 ? A.min_count[t] : 1;
-        int64_t behind = 1;                                                    // rows j .. i
-        while (j != first && !A.V.opens(j, A.win) && behind < need) { --j; ++behind; }
-        if (behind < need) search = false;                                     // the cluster starts at j and is too short to report
-        else if (j == first || A.V.opens(j, A.win)) { search = false; report = true; }
+        const unsigned long long upto = ob & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+        int64_t behind;                                                        // rows j .. i
+        bool start_known;
+        if (upto) { const int sl = 63 - __clzll((long long)upto); j = i - (uint64_t)(lane - sl); behind = lane - sl + 1; start_known = true; }
+        else { j = i - (uint64_t)lane; behind = lane + 1; start_known = false; }   // the wave's first row: it does not open the cluster
+        while (!start_known && behind < need) {
+            --j; ++behind;
+            start_known = j == first || A.V.opens(j, A.win);
+        }
+        if (start_known) { search = false; report = behind >= need; }          // (a cluster with fewer rows is not reported)
     }
     // the clusters of the wave that are long enough and not yet walked to their start, one after the other
     unsigned long long todo = __ballot(search);

@@ -9,7 +9,7 @@ O=$R/gpurun_out/$ROUND
 mkdir -p $O/profiles
 python3 -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1 || exit 1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL \
+timeout -k 5 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL \
     -d $O/pmc_sq -o s -- python3 $R/bench.py --no-cpu-baseline --no-build --lanes 1 --steps 3 --warmup 2 > $O/pmc_sq_bench.json 2> $O/pmc_sq.err
 cd $R
 python3 tools/prof_summary.py sq $(find $O/pmc_sq -name "*.db" | head -1) $O/profiles/${ROUND}_full_path_pmc_sq.txt > /dev/null
