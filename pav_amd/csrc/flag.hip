@@ -203,11 +203,17 @@ __global__ __launch_bounds__(256) void k_compact_keys(CompactKeysArgs A) {
     for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(inc, d); if (lane >= d) inc += y; }
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
-    uint32_t base = 0;
-    for (int w = 0; w < wave; ++w) base += wsum[w];
-    unsigned long long *out = A.out[t] + A.off[t][tile] + base + inc - mine;
+    uint32_t base = 0, total = 0;
+    for (int w = 0; w < 4; ++w) { if (w < wave) base += wsum[w]; total += wsum[w]; }
+    // the tile's real keys are put in order in LDS and leave with coalesced stores (a lane storing its up to eight keys one
+    // after the other kept the store queue full: the waves were issue-stalled two thirds of their time)
+    __shared__ unsigned long long stage[KEY_TILE];
+    uint32_t at = base + inc - mine;
 #pragma unroll
-    for (int u = 0; u < KEY_PER; ++u) if ((k[u] & A.low) != A.low) *out++ = k[u];
+    for (int u = 0; u < KEY_PER; ++u) if ((k[u] & A.low) != A.low) stage[at++] = k[u];
+    __syncthreads();
+    unsigned long long *out = A.out[t] + A.off[t][tile];
+    for (uint32_t r = threadIdx.x; r < total; r += 256) out[r] = stage[r];
 }
 
 __global__ __launch_bounds__(256) void k_indel_mid(unsigned long long *__restrict__ keys, uint64_t n, unsigned long long tag) {
