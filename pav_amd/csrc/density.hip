@@ -351,6 +351,45 @@ static uint32_t bucket_cap(uint64_t n_pos, uint32_t n_parts) {
     return (uint32_t)(n_pos / n_parts + n_pos / n_parts / 4 + 256);
 }
 
+// Output stage of the bucket kernels.  hist[p] = entries of this tile for partition p, base[p] = their first slot in the partition's
+// list (reserved with one global atomic).  The entries are put in partition order in LDS and leave run by run: consecutive lanes
+// store consecutive slots of one list (a lane storing its eight entries to eight unrelated lists kept the waves issue-stalled 40 %
+// of their time: every such store instruction is 64 separate lines).
+struct BucketStage { uint32_t lstart[LDS_MAX_PARTS + 1]; uint32_t pos[DTILE]; uint16_t pid[DTILE]; uint32_t wsum[4]; };
+__device__ __forceinline__ bool bucket_flush(BucketStage &S, uint32_t P, const uint32_t *hist, const uint32_t *base, const uint32_t (&pid)[8],
+                                             const uint32_t (&rank)[8], uint32_t pos0, uint32_t *__restrict__ list0, uint32_t cap) {
+    // exclusive prefix of hist over the partitions: four per lane
+    const uint32_t p0 = threadIdx.x * 4;
+    uint32_t h[4], mine = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { h[q] = p0 + q < P ? hist[p0 + q] : 0u; mine += h[q]; }
+    uint32_t inc = mine;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(inc, d); if (lane >= d) inc += y; }
+    if (lane == 63) S.wsum[wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - mine, total = 0;
+    for (int w = 0; w < 4; ++w) { if (w < wave) run += S.wsum[w]; total += S.wsum[w]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { if (p0 + q < P) S.lstart[p0 + q] = run; run += h[q]; }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        if (pid[t] == ~0u) continue;
+        const uint32_t at = S.lstart[pid[t]] + rank[t];
+        S.pos[at] = pos0 + t * 256 + threadIdx.x;
+        S.pid[at] = (uint16_t)pid[t];
+    }
+    __syncthreads();
+    bool over = false;
+    for (uint32_t r = threadIdx.x; r < total; r += 256) {
+        const uint32_t p = S.pid[r], slot = base[p] + (r - S.lstart[p]);
+        if (slot < cap) list0[(uint64_t)p * cap + slot] = S.pos[r]; else over = true;
+    }
+    return over;
+}
+
 __global__ __launch_bounds__(256) void k_bucket_ref(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
                                                     SeqView R, int k, uint32_t *__restrict__ lists, uint32_t *__restrict__ bcount,
                                                     JobStat *__restrict__ stat) {
@@ -389,14 +428,8 @@ __global__ __launch_bounds__(256) void k_bucket_ref(const JobDev *__restrict__ j
     for (uint32_t p = threadIdx.x; p < P; p += 256)
         if (hist[p]) base[p] = atomicAdd(&bcount[jd.bucket_off + p], hist[p]);
     __syncthreads();
-    bool over = false;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        if (pid[t] == ~0u) continue;
-        const uint32_t slot = base[pid[t]] + rank[t];
-        if (slot < jd.cap_r) lists[jd.list_off_r + (uint64_t)pid[t] * jd.cap_r + slot] = (uint32_t)(i0 + t * 256 + threadIdx.x);
-        else over = true;
-    }
+    __shared__ BucketStage stage;
+    const bool over = bucket_flush(stage, P, hist, base, pid, rank, (uint32_t)i0, lists + jd.list_off_r, jd.cap_r);
     if (over) atomicOr(&stat[j].lds_flags, LDS_OVERFLOW);
     if (block_any && threadIdx.x == 0) stat[j].n_ref_valid = 1;       // only "any" matters (scripts/density.py:510-513)
 }
@@ -436,13 +469,8 @@ __global__ __launch_bounds__(256) void k_bucket_tig(const JobDev *__restrict__ j
     for (uint32_t p = threadIdx.x; p < P; p += 256)
         if (hist[p]) base[p] = atomicAdd(&bcount[jd.bucket_off + P + p], hist[p]);
     __syncthreads();
-    bool over = false;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        if (pf[t] == ~0u) continue;
-        const uint32_t sf = base[pf[t]] + rf[t];
-        if (sf < jd.cap_t) lists[jd.list_off_t + (uint64_t)pf[t] * jd.cap_t + sf] = (uint32_t)(i0 + t * 256 + threadIdx.x); else over = true;
-    }
+    __shared__ BucketStage stage;
+    const bool over = bucket_flush(stage, P, hist, base, pf, rf, (uint32_t)i0, lists + jd.list_off_t, jd.cap_t);
     if (over) atomicOr(&stat[j].lds_flags, LDS_OVERFLOW);
 }
 
