@@ -547,36 +547,34 @@ struct KeyView {
         return ca != cb || mb >= ma + win;
     }
 };
-// Both cluster sweeps (rule call_inv_cluster, :646-684) without a scan over all rows.  k_open_blocks notes, for every 256 rows, the
-// last row that opens a cluster; k_cluster_sweep lets the last row of each cluster find the cluster's first row: it walks back
+// Both cluster sweeps (rule call_inv_cluster, :646-684) without a scan over all rows.  k_cluster_sweep notes, for every 256 rows, the
+// last row that opens a cluster, and lets the last row of each cluster find the cluster's first row (k_cluster_resolve for the long ones): it walks back
 // while fewer than min_count rows are behind it (nearly every cluster is a single row and ends the walk at once; a cluster
 // that short is not reported anyway), and the clusters that pass are finished by the whole wave - the rest of the row's own
 // block 64 rows per step, then 64 block notes per step (16 K rows): the inverted stretches this stage exists to find make
 // clusters of tens of thousands of rows.  (The max-scan over "row opens a cluster" this replaces wrote and re-read 8 bytes per
 // row: 0.10 ms for the two launches of the scan and the emit.)
-struct OpenBlocksArgs { KeyView V; uint64_t n; int64_t win; uint32_t *last_open; unsigned long long *unsorted; };
-__global__ __launch_bounds__(256) void k_open_blocks(OpenBlocksArgs A) {
-    __shared__ uint32_t wbest[4];
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    uint64_t local = 0, n_real = 0;
-    const bool real = i < A.n && A.V.real(i, local, n_real);
-    if (real && local && A.V.k[i - 1] > A.V.k[i]) *A.unsorted = 1;            // table order is not the rules' iteration order
-    const bool op = real && (local == 0 || A.V.opens(i, A.win));
-    const unsigned long long m = __ballot(op);
-    if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = m ? (uint32_t)(threadIdx.x + 64 - __clzll((long long)m)) : 0u;   // 1 + thread of the last one
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t best = 0;
-        for (int w = 0; w < 4; ++w) if (wbest[w]) best = wbest[w];
-        A.last_open[blockIdx.x] = best;                                        // 1 + offset in the block, 0: no row of the block opens a cluster
+struct SweepArgs {
+    KeyView V; uint64_t n; int64_t win, win_min, min_count[2]; uint32_t *last_open;
+    ClusterHit *hits[2]; uint64_t cap[2]; unsigned long long *n_hits, *unsorted; FlagPin *pin;
+    unsigned long long *pending; unsigned long long *n_pending; uint64_t pending_cap;   // closers of long clusters: (row, where the walk stands)
+};
+__device__ __forceinline__ void sweep_report(const SweepArgs &A, uint64_t i, uint64_t j) {
+    const int t = i >= A.V.n_snv;
+    const int64_t count = (int64_t)(i - j) + 1;
+    uint32_t cj, ci; int64_t pos, end;
+    A.V.at(j, cj, pos); A.V.at(i, ci, end);
+    if (count >= A.min_count[t] && end - pos >= A.win_min) {
+        const unsigned long long slot = atomicAdd(A.n_hits + t, 1ull);
+        const ClusterHit h{j, pos, end, count, ci, 0};
+        if (slot < A.cap[t]) A.hits[t][slot] = h;
+        if (slot < FIRST_HITS) A.pin->sweep[t][slot] = h;
     }
 }
-
-struct SweepArgs {
-    KeyView V; uint64_t n; int64_t win, win_min, min_count[2]; const uint32_t *last_open;
-    ClusterHit *hits[2]; uint64_t cap[2]; unsigned long long *n_hits; FlagPin *pin;
-};
+// Pass 1: every row.  Leaves the block notes (last row of every 256 that opens a cluster - a by-product of the bits the rows need
+// anyway), reports the clusters whose first row it finds within min_count rows, and hands the closers of longer clusters to pass 2.
 __global__ __launch_bounds__(256) void k_cluster_sweep(SweepArgs A) {
+    __shared__ uint32_t wbest[4];
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     uint64_t local = 0, n_real = 0;
@@ -588,42 +586,54 @@ __global__ __launch_bounds__(256) void k_cluster_sweep(SweepArgs A) {
     uint32_t c_prev = 0, c_own = 0, c_next = 0; int64_t m_prev = 0, m_own = 0, m_next = 0;
     const bool has_prev = real && local != 0, has_next = real && local + 1 != n_real;
     if (real) A.V.at(i, c_own, m_own);
-    if (has_prev) A.V.at(i - 1, c_prev, m_prev);
+    if (has_prev) { A.V.at(i - 1, c_prev, m_prev); if (A.V.k[i - 1] > A.V.k[i]) *A.unsorted = 1; }   // table order is not the rules' iteration order
     if (has_next) A.V.at(i + 1, c_next, m_next);
     const bool closes = real && (!has_next || c_own != c_next || m_next >= m_own + A.win);
     const bool opens_own = !has_prev || c_prev != c_own || m_own >= m_prev + A.win;
-    bool search = closes, report = false;
-    uint64_t j = i;
     // The rows of a wave are consecutive: where the row's cluster starts inside the wave is in the wave's "opens a cluster" bits -
     // no load, no walk (a third of the SNV rows sit in clusters of two to five).  Only a cluster that began before the wave's
     // first row is walked, and only while it is still too short to report.
     const unsigned long long ob = __ballot(real && opens_own);
-    if (search) {
-        const int64_t need = A.min_count[t] > 1 ? A.min_count[t] : 1;
-        const unsigned long long upto = ob & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
-        int64_t behind;                                                        // rows j .. i
-        bool start_known;
-        if (upto) { const int sl = 63 - __clzll((long long)upto); j = i - (uint64_t)(lane - sl); behind = lane - sl + 1; start_known = true; }
-        else { j = i - (uint64_t)lane; behind = lane + 1; start_known = false; }   // the wave's first row: it does not open the cluster
-        while (!start_known && behind < need) {
-            --j; ++behind;
-            start_known = j == first || A.V.opens(j, A.win);
-        }
-        if (start_known) { search = false; report = behind >= need; }          // (a cluster with fewer rows is not reported)
+    if (lane == 0) wbest[threadIdx.x >> 6] = ob ? (uint32_t)(threadIdx.x + 64 - __clzll((long long)ob)) : 0u;     // 1 + thread of the wave's last opening row
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t best = 0;
+        for (int w = 0; w < 4; ++w) if (wbest[w]) best = wbest[w];
+        A.last_open[blockIdx.x] = best;                                        // 1 + offset in the block, 0: no row of the block opens a cluster
     }
-    // the clusters of the wave that are long enough and not yet walked to their start, one after the other
-    unsigned long long todo = __ballot(search);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        uint64_t at = __shfl(j, leader);                                       // no row above `at` (up to the leader's) opens a cluster
-        const uint64_t lo = __shfl(first, leader);
-        const KeyView V = A.V;
+    if (!closes) return;
+    const int64_t need = A.min_count[t] > 1 ? A.min_count[t] : 1;
+    const unsigned long long upto = ob & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+    uint64_t j;
+    int64_t behind;                                                            // rows j .. i
+    bool start_known;
+    if (upto) { const int sl = 63 - __clzll((long long)upto); j = i - (uint64_t)(lane - sl); behind = lane - sl + 1; start_known = true; }
+    else { j = i - (uint64_t)lane; behind = lane + 1; start_known = false; }   // the wave's first row: it does not open the cluster
+    while (!start_known && behind < need) {
+        --j; ++behind;
+        start_known = j == first || A.V.opens(j, A.win);
+    }
+    if (start_known) { if (behind >= need) sweep_report(A, i, j); return; }    // (a cluster with fewer rows is not reported)
+    const unsigned long long slot = atomicAdd(A.n_pending, 1ull);              // long, and its first row not found yet: pass 2
+    if (slot < A.pending_cap) { A.pending[2 * slot] = i; A.pending[2 * slot + 1] = j; }
+}
+// Pass 2: one wave per long cluster.  No row in (j, i] opens a cluster; the wave looks at the rest of j's block 64 rows per step,
+// then at 64 block notes (16 K rows) per step - the inverted stretches this stage exists to find make clusters of 10^4 rows.
+__global__ __launch_bounds__(64) void k_cluster_resolve(SweepArgs A) {
+    const int lane = threadIdx.x;
+    const unsigned long long n_pend = min(*A.n_pending, (unsigned long long)A.pending_cap);
+    for (unsigned long long e = blockIdx.x; e < n_pend; e += gridDim.x) {
+        const uint64_t i = A.pending[2 * e];
+        uint64_t at = A.pending[2 * e + 1];
+        uint64_t local, n_real;
+        (void)A.V.real(i, local, n_real);
+        const uint64_t lo = i - local;
         uint64_t got = ~0ull;
         const uint64_t blk0 = at & ~255ull;                                    // rest of the block of `at`
         while (got == ~0ull) {
             const bool valid = at >= lo + (uint64_t)lane && at - (uint64_t)lane >= blk0;
             const uint64_t row = at - (uint64_t)lane;
-            const bool op = valid && (row == lo || V.opens(row, A.win));
+            const bool op = valid && (row == lo || A.V.opens(row, A.win));
             const unsigned long long m = __ballot(op);
             if (m) { got = at - (uint64_t)(__ffsll((long long)m) - 1); break; }
             if (at < blk0 + 64) break;
@@ -643,18 +653,7 @@ __global__ __launch_bounds__(256) void k_cluster_sweep(SweepArgs A) {
                 b -= 64;
             }
         }
-        if (lane == leader) { j = got; report = true; }
-        todo &= todo - 1;
-    }
-    if (!report) return;
-    const int64_t count = (int64_t)(i - j) + 1;
-    uint32_t cj, ci; int64_t pos, end;
-    A.V.at(j, cj, pos); A.V.at(i, ci, end);
-    if (count >= A.min_count[t] && end - pos >= A.win_min) {
-        const unsigned long long slot = atomicAdd(A.n_hits + t, 1ull);
-        const ClusterHit h{j, pos, end, count, ci, 0};
-        if (slot < A.cap[t]) A.hits[t][slot] = h;
-        if (slot < FIRST_HITS) A.pin->sweep[t][slot] = h;
+        if (lane == 0) sweep_report(A, i, got);
     }
 }
 
@@ -878,15 +877,17 @@ int flag_planned(pav_ctx *ctx, FlagState *S, const pav_flag_params *P, unsigned 
     }
     {   // both cluster sweeps (rule call_inv_cluster)
         const uint32_t n_blocks = (uint32_t)((n_keys + 255) / 256);
-        PAV_HIP(ctx, S->start.reserve(4ull * n_blocks));
-        OpenBlocksArgs OB{V, n_keys, P->cluster_win, S->start.as<uint32_t>(), d_cnt + 3};
-        PAV_LAUNCH(ctx, "k_open_blocks", k_open_blocks, n_blocks, 256, 0, OB);
+        const uint64_t pend_cap = n_keys / 2 + 64;                             // (a long cluster has at least two rows)
+        PAV_HIP(ctx, S->start.reserve(4ull * n_blocks + 64 + 16 * pend_cap));
         SweepArgs SW;
         SW.V = V; SW.n = n_keys; SW.win = SW.win_min = P->cluster_win; SW.last_open = S->start.as<uint32_t>();
+        SW.pending = reinterpret_cast<unsigned long long *>(S->start.as<uint8_t>() + ((4ull * n_blocks + 63) & ~63ull));
+        SW.n_pending = d_cnt + 6; SW.pending_cap = pend_cap;
         SW.min_count[0] = P->cluster_min_snv; SW.min_count[1] = P->cluster_min_indel;
         SW.hits[0] = S->hits_b[0].as<ClusterHit>(); SW.hits[1] = S->hits_b[1].as<ClusterHit>(); SW.cap[0] = cap[0]; SW.cap[1] = cap[1];
-        SW.n_hits = d_cnt + 4; SW.pin = pin;
+        SW.n_hits = d_cnt + 4; SW.unsorted = d_cnt + 3; SW.pin = pin;
         PAV_LAUNCH(ctx, "k_cluster_sweep", k_cluster_sweep, n_blocks, 256, 0, SW);
+        PAV_LAUNCH(ctx, "k_cluster_resolve", k_cluster_resolve, 1024, 64, 0, SW);
     }
     if (n_ind) {   // both matches (rule call_inv_flag_insdel_cluster)
         const int tok = prof_begin(ctx, "rocprim::inclusive_scan");
