@@ -387,6 +387,12 @@ def main():
     warmup_run = max(args.warmup, 3 * n_lanes)
     run_steps(warmup_run, fixed_share=True)
     warmup_run = ((warmup_run + n_lanes - 1) // n_lanes) * n_lanes
+    if n_lanes > 1:
+        # ... and a lead-in from the shared counter, as the timed regions run: the lanes leave the warm-up in step (all of them at
+        # their CIGAR-call at once) and need a few passes to spread over each other's gaps - the first timed region of a run was
+        # a third slower than the others
+        run_steps(4 * n_lanes)
+        warmup_run += 4 * n_lanes
 
     # ---- timed region: exactly K steps, profiling off; run R times back to back, the median region is the line's --------
     free_min = [min(ln.ctx.mem_info()[0] for ln in lanes)]
