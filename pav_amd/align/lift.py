@@ -78,13 +78,8 @@ class AlignLift:
         self.df_fai = df_fai
         self.cache_align = cache_align
         self._dev = None
-        if ctx is not None and df.shape[0]:
-            cig = [str(c).encode() for c in df['CIGAR']]
-            off = np.zeros(len(cig) + 1, dtype=np.uint64)
-            off[1:] = np.cumsum([len(c) for c in cig], dtype=np.uint64)
-            ops, op_off, sub_b, qry_b = ctx.align_index(df['POS'].to_numpy(dtype=np.uint32),
-                                                         np.frombuffer(b''.join(cig), dtype=np.uint8), off)
-            self._dev = (ops, op_off.astype(np.int64), sub_b, qry_b, {ix: i for i, ix in enumerate(df.index)})
+        self._dev_ctx = ctx if df.shape[0] else None          # the index is built when the first lift through this object needs it:
+                                                                # the native scan driver keeps its own and never asks
         if len(set(df.index)) != df.shape[0]:
             raise RuntimeError('Cannot create AlignLift object with duplicate index values')
         # per subject / per query: list of (begin, end, index); lookups need "exactly one record contains pos"
@@ -229,6 +224,17 @@ class AlignLift:
             self._tables.move_to_end(index)
             return
         self._check_and_clear()
+        if self._dev is None and self._dev_ctx is not None:
+            df, ctx, self._dev_ctx = self.df, self._dev_ctx, None
+            cig = [str(c).encode() for c in df['CIGAR']]
+            off = np.zeros(len(cig) + 1, dtype=np.uint64)
+            off[1:] = np.cumsum([len(c) for c in cig], dtype=np.uint64)
+            try:
+                ops, op_off, sub_b, qry_b = ctx.align_index(df['POS'].to_numpy(dtype=np.uint32),
+                                                             np.frombuffer(b''.join(cig), dtype=np.uint8), off)
+                self._dev = (ops, op_off.astype(np.int64), sub_b, qry_b, {ix: i for i, ix in enumerate(df.index)})
+            except Exception:                                  # noqa: BLE001 - e.g. the context has been closed since: the host tokenizer
+                self._dev = None                               # below gives the same tables, record by record
         if self._dev is not None:
             ops_all, op_off, sub_all, qry_all, where = self._dev
             r = where[index]
