@@ -632,6 +632,10 @@ def main():
             # tok_count's event time is mostly queueing behind the high-priority pack (0.01 ms with nothing beside it): ranked by that
             own = {k: (call_alone['kernels_ms'].get(k, v['avg_ms']) if k == 'tok_count' else v['avg_ms']) for k, v in kern_.items()}
             dom = want or max(kern_, key=lambda k: own[k] * kern_[k]['launches'])
+            # walk_snv and homology_kernel run beside each other and end within a few per cent of each other: the line keeps
+            # to walk_snv (the kernel the committed counters and the line-rate model are about) unless the other is clearly longer
+            if want is None and 'walk_snv' in kern_ and own['walk_snv'] * kern_['walk_snv']['launches'] >= 0.95 * own[dom] * kern_[dom]['launches']:
+                dom = 'walk_snv'
             alg_bytes = {
                 'verify_kernel': 0.5 * float(counts.aligned_bases),           # the two 2-bit planes; masks only where marked dirty
                 'pack_kernel': tig_bases * (1.0 + 0.25 + 0.125),
@@ -645,7 +649,8 @@ def main():
             # k-mer kernels: per scanned base 0.375 B of packed planes (reference + contig), three 4 B list entries written by
             # the bucket kernels and read by k_kmer_lds, two answer bytes; HBM-table kernels as SURVEY.md section 8(d);
             # `scanned_bp` = region bases over all scan iterations of a step, spread over the launches (one per round)
-            for kname, per_base in (('k_bucket_ref', 4.375), ('k_bucket_tig', 9.375), ('k_kmer_lds', 14.75),
+            # (round 3: canonical k-mer sets - one 4 B list entry per contig base instead of two)
+            for kname, per_base in (('k_bucket_ref', 4.375), ('k_bucket_tig', 5.375), ('k_kmer_lds', 10.75),
                                     ('k_ref_insert', 8.375), ('k_tig_state', 17.375), ('k_compact_scatter', 19.0)):
                 if kname in kern_ and kern_[kname]['launches'] and scanned_bp:
                     alg_bytes[kname] = per_base * scanned_bp * args.steps / kern_[kname]['launches']
