@@ -646,7 +646,7 @@ def main():
                 'rocprim::radix_sort_keys': 7 * 16.0 * n_snv,               # 56 key bits = 7 passes over 8 B keys, in + out
                 'k_snv_keys': 24.0 * n_snv, 'k_indel_keys': 72.0 * n_indel,
             }
-            # k-mer kernels: per scanned base 0.375 B of packed planes (reference + contig), three 4 B list entries written by
+            # k-mer kernels: per scanned base 0.375 B of packed planes (reference + contig), two 4 B list entries (three before the canonical sets of round 3) written by
             # the bucket kernels and read by k_kmer_lds, two answer bytes; HBM-table kernels as SURVEY.md section 8(d);
             # `scanned_bp` = region bases over all scan iterations of a step, spread over the launches (one per round)
             # (round 3: canonical k-mer sets - one 4 B list entry per contig base instead of two)
