@@ -209,9 +209,37 @@ def main():
             lanes_.append(ln)
         return lanes_
 
+    def host_memory_available_gb():
+        """MemAvailable of the node, capped by the cgroup's limit where there is one (GB); 0.0 when it cannot be read."""
+        try:
+            avail = 0.0
+            with open('/proc/meminfo') as fh:
+                for line in fh:
+                    if line.startswith('MemAvailable:'):
+                        avail = float(line.split()[1]) * 1024.0
+            for lim, cur in (('/sys/fs/cgroup/memory.max', '/sys/fs/cgroup/memory.current'),
+                             ('/sys/fs/cgroup/memory/memory.limit_in_bytes', '/sys/fs/cgroup/memory/memory.usage_in_bytes')):
+                if os.path.exists(lim) and os.path.exists(cur):
+                    with open(lim) as fh:
+                        text_ = fh.read().strip()
+                    if text_.isdigit() and int(text_) < (1 << 60):
+                        with open(cur) as fh:
+                            avail = min(avail, float(int(text_) - int(fh.read().strip())))
+            return max(0.0, avail) / 1e9
+        except Exception:                                     # noqa: BLE001 - unknown: the careful way below
+            return 0.0
+
+    # With several ranks on a node the ranks prepare their haplotypes at the same time when the node's memory allows it (a rank
+    # holds the reference and one haplotype on the host while it generates and uploads: < 20 GB), each on its share of the cores;
+    # otherwise they take turns.  (Six lanes on eight ranks are 48 haplotypes: one after the other, three minutes before the first pass.)
+    all_at_once = False
+    if world > 1:
+        enough = torch.tensor([1.0 if host_memory_available_gb() >= 24.0 * world else 0.0], dtype=torch.float64, device=comm_device)
+        dist.all_reduce(enough, op=dist.ReduceOp.MIN)         # (every rank asks the node; all of them must agree)
+        all_at_once = float(enough.item()) > 0.5
     lanes = None
-    for turn in range(world):
-        if turn == rank:
+    for turn in range(1 if all_at_once else world):
+        if all_at_once or turn == rank:
             lanes = prepare()
             ref_lengths = {n: int(lanes[0].hap.ref.seqs[n].shape[0]) for n in lanes[0].hap.ref.names}
             if world > 1:
