@@ -35,5 +35,11 @@ python3 bench.py --no-build --workload cigar > $P/${ROUND}_cigar_only_bench.json
 # one lane and two lanes: how far one host thread gets
 python3 bench.py --no-build --no-cpu-baseline --lanes 1 > $P/${ROUND}_full_path_bench_lanes1.json 2> $O/bench_l1.err
 python3 bench.py --no-build --no-cpu-baseline --lanes 2 > $P/${ROUND}_full_path_bench_lanes2.json 2> $O/bench_l2.err
+# one lane under the kernel + copy trace: the timeline of a pass (where the GPU waits for the host), and the SQ counter pass
+cd /tmp
+timeout -k 5 300 rocprofv3 --kernel-trace --memory-copy-trace -d $O/tl -o tl -- python3 $R/tools/prof_step.py --no-build --plain --steps 12 > $O/tl.log 2>&1
+cd $R
+python3 tools/prof_summary.py timeline $(find $O/tl -name "*.db" | head -1) $P/${ROUND}_single_lane_timeline_8ms.txt 8 > /dev/null
 find $O -name "*.db" -delete
+bash tools/scripts/profile_sq.sh $ROUND > $O/profile_sq.log 2>&1
 ls -la $P; du -sh $O
