@@ -163,6 +163,8 @@ def _den_protos(lib):
     lib.orc_density_kern.argtypes = [P, ctypes.c_int]
     lib.orc_density_free.restype = None
     lib.orc_density_free.argtypes = [P]
+    lib.orc_density_set_threads.restype = None
+    lib.orc_density_set_threads.argtypes = [ctypes.c_int]
     lib.orc_rl_encode.restype = ctypes.c_uint32
     lib.orc_rl_encode.argtypes = [P, P, ctypes.c_uint32, P, ctypes.c_uint32]
     lib.orc_annotate.restype = None
@@ -182,10 +184,12 @@ def _copy(ptr, n, dtype):
     return out
 
 
-def density(ref_seq, tig_seq, ref_rc, params=None):
-    """scripts/density.py on extracted region sequences (uint8 ASCII arrays).  Returns a dict of arrays + info."""
+def density(ref_seq, tig_seq, ref_rc, params=None, threads=1):
+    """scripts/density.py on extracted region sequences (uint8 ASCII arrays).  Returns a dict of arrays + info.
+    ``threads``: evaluation points of the KDE in parallel (each summed by one thread in scipy's order: same bits)."""
     lib = load()
     _den_protos(lib)
+    lib.orc_density_set_threads(int(threads))
     params = params or den_params()
     ref_seq = np.ascontiguousarray(ref_seq, dtype=np.uint8)
     tig_seq = np.ascontiguousarray(tig_seq, dtype=np.uint8)

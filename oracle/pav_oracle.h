@@ -119,6 +119,9 @@ typedef struct orc_density orc_density;
 /* scripts/density.py main + get_smoothed_density on an already extracted reference / contig region (ASCII). */
 orc_density *orc_density_run(const uint8_t *ref_seq, uint64_t ref_len, const uint8_t *tig_seq, uint64_t tig_len,
                              int ref_rc, const orc_den_params *pp);
+/* Threads for the KDE of the calls that follow (default 1: the scalar port; tests of 0.1 - 1.2 Mbp regions raise it).  Every
+ * evaluation point is summed by one thread in scipy's order, so the result does not depend on the count. */
+void orc_density_set_threads(int n);
 const orc_density_info *orc_density_get_info(const orc_density *);
 const int64_t *orc_density_index(const orc_density *);
 const int8_t *orc_density_state_mer(const orc_density *);

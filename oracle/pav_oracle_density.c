@@ -84,13 +84,26 @@ void orc_density_free(orc_density *d) {
 
 typedef struct { uint64_t n; const double *p_scaled; double inv_h, norm, w, count; } kde1;
 
+/* Evaluation points are independent of each other, so large regions (tests of 0.1 - 1.2 Mbp) may spread them over threads;
+ * the sum of ONE point is always accumulated by one thread in scipy's order, so the table does not depend on the count. */
+static int g_threads = 1;
+void orc_density_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+
 /* scipy gaussian_kernel_estimate for d = 1: for one evaluation point, data ascending (the loop order in which
- * scipy accumulates estimate[j]) */
+ * scipy accumulates estimate[j]).  Data points further than 39 bandwidths from the point are stepped over: their terms are
+ * exp(-760.5) or less, which is exactly 0.0 in IEEE double (the smallest subnormal is exp(-744.4)), and est + 0.0 == est
+ * bit for bit - the scaled positions ascend, so the points that matter are one range found by bisection. */
+static uint64_t first_ge(const double *p, uint64_t n, double v) {
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) { uint64_t mid = lo + (hi - lo) / 2; if (p[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
 static double kde_eval(const kde1 *kd, double x) {
     if (kd->n == 0) return 0.0;                                /* density.py:84,92,100: zeros for an absent state */
     const double xs = x * kd->inv_h;
     double est = 0.0;
-    for (uint64_t i = 0; i < kd->n; ++i) {
+    const uint64_t i0 = first_ge(kd->p_scaled, kd->n, xs - 39.0), i1 = first_ge(kd->p_scaled, kd->n, xs + 39.0);
+    for (uint64_t i = i0; i < i1; ++i) {
         const double r = kd->p_scaled[i] - xs;
         const double arg = exp(-(r * r) / 2) * kd->norm;
         est += kd->w * arg;
@@ -180,15 +193,18 @@ orc_density *orc_density_run(const uint8_t *ref_seq, uint64_t ref_len, const uin
     uint64_t *samp = malloc(8 * (n_samp + 2));
     for (uint64_t q = 0; q < n_samp; ++q) samp[q] = q * srs;
     if (n_samp == 0 || samp[n_samp - 1] != n - 1) samp[n_samp++] = n - 1;
-    uint64_t n_eval = 0;
+    uint64_t n_eval = n_samp;
+    #pragma omp parallel for schedule(dynamic, 16) num_threads(g_threads)
     for (uint64_t q = 0; q < n_samp; ++q) {
         const uint64_t x = samp[q];
         for (int s = 0; s < 3; ++s) d->kern[s][x] = kde_eval(&kd[s], (double)x);
         d->state[x] = (int8_t)argmax3(d->kern[0][x], d->kern[1][x], d->kern[2][x]);
-        ++n_eval;
     }
-    /* windows between sampled sites (density.py:257-286): interpolate or compute */
-    for (uint64_t q = 0; q + 1 < n_samp; ++q) {
+    /* windows between sampled sites (density.py:257-286): interpolate or compute.  A window reads the two sampled sites at
+     * its ends and writes the rows between them: windows are independent. */
+    const uint64_t n_win = n_samp - 1;                          /* n_samp >= 1 */
+    #pragma omp parallel for schedule(dynamic, 4) reduction(+ : n_eval) num_threads(g_threads)
+    for (uint64_t q = 0; q < n_win; ++q) {
         const uint64_t a = samp[q], b = samp[q + 1];
         if (b == a + 1) continue;
         int state_change = d->state[a] != d->state[b];
@@ -198,7 +214,7 @@ orc_density *orc_density_run(const uint8_t *ref_seq, uint64_t ref_len, const uin
         if (state_change || dmax > pp->state_run_delta) {
             for (uint64_t x = a + 1; x < b; ++x) {
                 for (int s = 0; s < 3; ++s) d->kern[s][x] = kde_eval(&kd[s], (double)x);
-                ++n_eval;
+                n_eval += 1;
             }
         } else {                                                /* np.interp: slope * (x - x0) + y0 (density.py:121-151) */
             for (int s = 0; s < 3; ++s) {

@@ -9,6 +9,7 @@
 #include <condition_variable>
 #include <cstddef>
 #include <cstdint>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -22,7 +23,7 @@ public:
         for (int t = 0; t < helpers; ++t) threads_.emplace_back([this] { loop(); });
     }
     ~HostPool() {
-        { std::lock_guard<std::mutex> lk(m_); stop_ = true; gen_.fetch_add(1); }
+        { std::lock_guard<std::mutex> lk(m_); stop_.store(true); gen_.fetch_add(1); }
         cv_.notify_all();
         for (auto &t : threads_) t.join();
     }
@@ -36,7 +37,9 @@ public:
         cv_.notify_all();
     }
 
-    // f(i) for every i in [0, n), in chunks of `chunk` taken by whoever is free; returns when all calls have returned
+    // f(i) for every i in [0, n), in chunks of `chunk` taken by whoever is free; returns when all calls have returned.
+    // An exception thrown by f - on the caller's thread or on a helper - ends the loop early (indices not yet taken are
+    // skipped) and is rethrown here, on the caller's thread, once no helper is inside the loop any more.
     template <class F> void run(size_t n, size_t chunk, F &&f) {
         if (threads_.empty() || n <= chunk) { for (size_t i = 0; i < n; ++i) f(i); return; }
         fn_ = [&f](size_t i) { f(i); };
@@ -49,6 +52,13 @@ public:
         work();
         open_.store(0);
         while (active_.load() != 0) cpu_relax();                      // helpers inside work(); one that arrives now sees open_ == 0
+        fn_ = nullptr;                                                // the functor refers to the caller's frame
+        if (failed_.load()) {
+            std::exception_ptr e;
+            { std::lock_guard<std::mutex> lk(m_); e = err_; err_ = nullptr; }
+            failed_.store(false);
+            std::rethrow_exception(e);
+        }
     }
 
 private:
@@ -59,12 +69,19 @@ private:
         std::this_thread::yield();
 #endif
     }
-    void work() {
-        for (;;) {
-            const size_t a = next_.fetch_add(chunk_);
-            if (a >= n_) break;
-            const size_t b = a + chunk_ < n_ ? a + chunk_ : n_;
-            for (size_t i = a; i < b; ++i) fn_(i);
+    void work() noexcept {
+        try {
+            for (;;) {
+                const size_t a = next_.fetch_add(chunk_);
+                if (a >= n_) break;
+                const size_t b = a + chunk_ < n_ ? a + chunk_ : n_;
+                for (size_t i = a; i < b; ++i) fn_(i);
+            }
+        } catch (...) {
+            next_.store(n_);                                          // nobody takes another chunk
+            std::lock_guard<std::mutex> lk(m_);
+            if (!err_) err_ = std::current_exception();               // the first one is reported
+            failed_.store(true);
         }
     }
     void loop() {
@@ -80,7 +97,7 @@ private:
                 }
             }
             seen = gen_.load();
-            if (stop_) return;
+            if (stop_.load()) return;
             active_.fetch_add(1);
             if (open_.load() == seen) work();                         // too late for loop `seen`: its state may be gone already
             active_.fetch_sub(1);
@@ -94,7 +111,9 @@ private:
     std::atomic<size_t> next_{0};
     std::atomic<int> active_{0};
     std::atomic<uint64_t> open_{0};                                   // generation whose loop may be joined, 0: none
-    bool stop_ = false;
+    std::atomic<bool> stop_{false};
+    std::atomic<bool> failed_{false};
+    std::exception_ptr err_;                                          // guarded by m_
     std::function<void(size_t)> fn_;
     size_t n_ = 0, chunk_ = 1;
 };

@@ -332,6 +332,39 @@ def config1(seed=1001):
     return hap
 
 
+def large_inversions(seed=1049):
+    """Two chromosomes with one large planted inversion each, aligned end to end by one contig each - the case behind
+    tests/golden/inv_large (regions of 337 / 462 kbp after two expansion rounds, `pavlib/inv.py:310-351`).
+    Returns (ref, hap, flags); flags = [(chrom, pos, end, type, scan kwargs)] - the flagged regions sit INSIDE the
+    inversions so that the scan has to expand.
+
+      chrA 1.0 Mbp  inversion 400 000 - 550 000 (150 kb, 3 kb inverted-repeat flanks), contig stored forward,
+                    flagged at its centre: 54 k -> 135 k -> 337 kbp
+      chrB 1.3 Mbp  inversion 500 000 - 700 000 (200 kb, no repeat), a 5 kb N run at 360 000, contig stored
+                    reverse-complemented, flagged off centre (the contig carries the mirror image of the interval, so a
+                    region shares k-mers with it only where it overlaps its own mirror image about 600 000):
+                    74 k (REV only) -> 185 k (FWD flank on one side: states [0, 2]) -> 462 kbp
+    """
+    lengths = {'chrA': 1_000_000, 'chrB': 1_300_000}
+    ref = make_reference(seed, lengths, n_every=0, inv_every=0, threads=1)
+    ref.seqs['chrB'][360_000:365_000] = ord('N')
+    plan = [Inversion('chrA', 400_000, 550_000, 3_000), Inversion('chrB', 500_000, 700_000, 0)]
+    for v in plan:
+        s = ref.seqs[v.chrom]
+        if v.repeat:
+            s[v.end - v.repeat:v.end] = revcomp(s[v.pos:v.pos + v.repeat])
+    ref.inversions = plan
+    # the strand of a row is drawn from the haplotype's generator; seed 1049 gives chrA forward, chrB reverse
+    hap = make_haplotype(ref, seed * 64, 'h1', segments={n: [(0, L)] for n, L in lengths.items()}, rev_frac=0.5,
+                         threads=1, decoys_per_inv=0, zone_factor=1, zone_pad=1_000)
+    assert hap.df_align['REV'].tolist() == [False, True], 'large_inversions: the generator no longer draws these strands'
+    flags = [('chrA', 450_000, 500_000, 'CLUSTER_SNV', None),
+             ('chrB', 535_000, 605_000, 'CLUSTER_SNV', None),
+             ('chrB', 520_000, 560_000, 'CLUSTER_SNV', None),         # shares no k-mer with its mirror image
+             ('chrB', 358_000, 361_000, 'CLUSTER_INDEL', None)]       # beside / inside the N run, FWD only
+    return ref, hap, flags
+
+
 def config2(seed=1002, scale=1.0, hap_index=0, ref=None, lengths=None, threads=8, n_runs=True, **kw):
     """One haplotype vs an hg38-shaped reference (24 sequences); ``scale`` shrinks every length.  ``n_runs=False``: a
     reference without N runs (a T2T assembly)."""

@@ -1,6 +1,7 @@
 """Full-size parity (BASELINE configs[1] / configs[2] at scale 1.0, seed 1002 - the haplotype bench.py times): the device
 records of the whole hg38-shaped haplotype against the scalar oracle, byte for byte, and the density tables of the first
-scan iteration of >= 300 flagged loci (integer columns exact, KERN_* to 1e-12).  Needs ~12 GB of host memory and ~1 minute."""
+scan iteration of >= 300 flagged loci of ANY size (integer columns exact, KERN_* to 1e-12), the complete scan against the
+calls of an oracle-driven scan, and the last iterations of the largest calls row by row.  Needs ~12 GB of host memory."""
 import numpy as np
 import pandas as pd
 import pytest
@@ -13,15 +14,43 @@ pytestmark = pytest.mark.gpu
 KERN = ('KERN_FWD', 'KERN_FWDREV', 'KERN_REV')
 
 
+_FULL = {}
+
+
+def fullsize(ctx):
+    """The bench haplotype resident on the session context, its records called and its loci flagged - once for the tests of this
+    module that look at it (generating it takes a minute and 12 GB; test_chm13_* drops it before it needs the memory)."""
+    if 'hap' not in _FULL:
+        hap = synth.config2(seed=1002, scale=1.0, threads=8, pair_frac=0.009)
+        names = hap.ref.names
+        ctx._inv_loaded = None
+        ctx.seq_load(_lib.PAV_ROLE_REF, names, [hap.ref.seqs[n] for n in names])
+        ctx.seq_load(_lib.PAV_ROLE_TIG, hap.tig_names, [hap.tig_seqs[n] for n in hap.tig_names])
+        snv, indel, blob, counts = cigarcall.call_records(ctx, hap.df_align)
+        index = hap.df_align['INDEX'].to_numpy(dtype='int64')
+        trim = hap.df_trim[['POS', 'END', 'INDEX']].set_index('INDEX').astype(int).reindex(list(index), fill_value=-1)
+        tables, loci, _ = ctx.cigar_flag(trim['POS'].to_numpy(dtype='int64'), trim['END'].to_numpy(dtype='int64'),
+                                         ctx.flag_params(sig_filter=_lib.SIG_SINGLE_CLUSTER))
+        # the scans below name their sequences by these paths; only the .fai of the reference is ever read (inv.py:201)
+        import os
+        import tempfile
+        import oracle_scan
+        d = tempfile.mkdtemp(prefix='pav_fullsize_')
+        fa = (os.path.join(d, 'ref.fa'), os.path.join(d, 'tig.fa'))
+        oracle_scan.write_fai(fa[0] + '.fai', names, hap.ref.lengths)
+        _FULL.update(hap=hap, records=(snv, indel, blob, counts), tables=tables, loci=loci,
+                     lift=AlignLift(hap.df_trim, hap.tig_lengths), fa=fa)
+        ctx._inv_loaded = fa
+    return _FULL
+
+
 def test_full_size_haplotype_is_bit_exact_vs_the_oracle(built, gpu_ctx):
     from oracle import oracle
-    hap = synth.config2(seed=1002, scale=1.0, threads=8, pair_frac=0.009)
-    names = hap.ref.names
     ctx = gpu_ctx
-    ctx._inv_loaded = None
-    ctx.seq_load(_lib.PAV_ROLE_REF, names, [hap.ref.seqs[n] for n in names])
-    ctx.seq_load(_lib.PAV_ROLE_TIG, hap.tig_names, [hap.tig_seqs[n] for n in hap.tig_names])
-    snv, indel, blob, counts = cigarcall.call_records(ctx, hap.df_align)
+    full = fullsize(ctx)
+    hap = full['hap']
+    names = hap.ref.names
+    snv, indel, blob, counts = full['records']
     assert counts.aligned_bases == hap.stats['aligned_bp'] > 3.0e9 and counts.n_snv > 6_000_000 and counts.n_indel > 500_000
 
     # ---- CIGAR-call: every record of the haplotype ------------------------------------------------------------------
@@ -33,14 +62,11 @@ def test_full_size_haplotype_is_bit_exact_vs_the_oracle(built, gpu_ctx):
     assert blob.tobytes() == o_blob.tobytes()
     del o_snv, o_indel, o_blob
 
-    # ---- flagging of those calls -> loci -> first scan iteration of the first 300 liftable loci ----------------------------
-    index = hap.df_align['INDEX'].to_numpy(dtype='int64')
-    trim = hap.df_trim[['POS', 'END', 'INDEX']].set_index('INDEX').astype(int).reindex(list(index), fill_value=-1)
-    tables, loci, _ = ctx.cigar_flag(trim['POS'].to_numpy(dtype='int64'), trim['END'].to_numpy(dtype='int64'),
-                                     ctx.flag_params(sig_filter=_lib.SIG_SINGLE_CLUSTER))
+    # ---- flagging of those calls -> loci -> first scan iteration of the first 320 liftable loci, whatever their size -----
+    tables, loci = full['tables'], full['loci']
     regions = pavinv.loci_regions(ctx, loci)
     assert len(regions) >= 900 and len(tables['cluster_snv']) >= 90          # ~1 k flagged loci per haplotype
-    lift = AlignLift(hap.df_trim, hap.tig_lengths)
+    lift = full['lift']
     fai = pd.Series(hap.ref.lengths)
     ref_i, tig_i = {n: i for i, n in enumerate(names)}, {n: i for i, n in enumerate(hap.tig_names)}
     jobs, pairs = [], []
@@ -50,17 +76,19 @@ def test_full_size_haplotype_is_bit_exact_vs_the_oracle(built, gpu_ctx):
             t = lift.lift_region_to_qry(r)
         except RuntimeError:
             t = None
-        if t is None or len(r) > 80_000:
+        if t is None:
             continue
         jobs.append(_lib.DenJob(ref_i[r.chrom], tig_i[t.chrom], r.pos, r.end, t.pos, t.end, 1 if t.is_rev else 0, 20))
         pairs.append((r, t))
         if len(jobs) >= 320:
             break
-    assert len(jobs) >= 300
+    assert len(jobs) >= 300 and max(len(r) for r, _ in pairs) > 100_000
     res = ctx.density_batch(jobs, pavden.den_params())
     n_final = near = 0
+    threads = util.usable_cpus()
     for j, ((r, t), g) in enumerate(zip(pairs, res)):
-        o = oracle.density(hap.ref.seqs[r.chrom][r.pos:r.end], hap.tig_seqs[t.chrom][t.pos:t.end], t.is_rev)
+        o = oracle.density(hap.ref.seqs[r.chrom][r.pos:r.end], hap.tig_seqs[t.chrom][t.pos:t.end], t.is_rev,
+                           threads=threads if len(r) > 30_000 else 1)
         assert g.status == o['status'], (r, t)
         if o['status'] == 125:
             continue
@@ -76,7 +104,82 @@ def test_full_size_haplotype_is_bit_exact_vs_the_oracle(built, gpu_ctx):
             for c in KERN:
                 assert np.allclose(cols[c], o[c], rtol=1e-12, atol=1e-300), (c, r)
     assert n_final >= 250
-    print(f'{len(jobs)} loci, {n_final} finalised tables equal the oracle; {near} near-tie decisions re-evaluated')
+    print(f'{len(jobs)} loci (largest region {max(len(r) for r, _ in pairs)} bp), {n_final} finalised tables equal the oracle; '
+          f'{near} near-tie decisions re-evaluated')
+
+
+def test_full_size_inversion_calls_vs_the_oracle_driven_scan(built, gpu_ctx):
+    """The COMPLETE scan of the bench haplotype - every flagged locus, every expansion round, up to regions of ~0.5 Mbp -
+    against tests/golden/fullsize_inv_calls.json: the calls the Python state machine makes when the CPU oracle answers every
+    density job (tools/gen_fullsize_inv_digest.py; neither the density kernels nor the native driver take part in it).  Both
+    drivers on the device must give the same regions in, the same calls (ids, outer / inner / discovery regions on both
+    sequences, table rows, STATE / STATE_MER digests) and the same log text out.  Then the LAST iteration of the 20 calls with
+    the largest discovery regions - the second round of their scans, 100 - 500 kbp - is run again as one density batch and
+    compared with the oracle row by row (integer columns exact, KERN_* to 1e-12)."""
+    import contextlib
+    import hashlib
+    import io
+    import json
+    import os
+    import oracle_scan
+    from oracle import oracle
+    from pav_amd.kmer import KmerUtil
+    ctx = gpu_ctx
+    full = fullsize(ctx)
+    hap, lift = full['hap'], full['lift']
+    names = hap.ref.names
+    with open(os.path.join(util.GOLD, 'fullsize_inv_calls.json')) as fh:
+        gold = json.load(fh)
+    regions = pavinv.loci_regions(ctx, full['loci'])
+    assert len(regions) == gold['n_regions']
+    assert hashlib.sha1('\n'.join(f'{r.chrom}:{r.pos}-{r.end}' for r in regions).encode()).hexdigest() == gold['regions_sha1']
+    k_util = KmerUtil(31)
+    want = {c['region']: c for c in gold['calls']}
+    sha = lambda a: hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()   # noqa: E731
+    calls_native = None
+    for native in (True, False):
+        log = io.StringIO()
+        ctx._inv_loaded = full['fa']
+        with contextlib.redirect_stdout(io.StringIO()):                 # the Python driver prints 'INV Found' (inv.py:408)
+            out = pavinv.scan_for_inv_batch(regions, full['fa'][0], full['fa'][1], lift, k_util, log=log, ctx=ctx, native=native,
+                                            eager_tables=False, found_out=io.StringIO())
+        assert not any(isinstance(c, RuntimeError) for c in out)
+        got = {i: c for i, c in enumerate(out) if c is not None}
+        assert sorted(got) == sorted(want), (native, sorted(set(got) ^ set(want)))
+        for i, c in got.items():
+            rec = oracle_scan.call_record(c)
+            for k2, v in rec.items():
+                assert want[i][k2] == v, (native, i, k2)
+            df = c.df
+            assert df.shape[0] == want[i]['n_rows'], (native, i)
+            assert sha(df['STATE'].to_numpy(dtype=np.int8)) == want[i]['state_sha1'], (native, c.id)
+            assert sha(df['STATE_MER'].to_numpy(dtype=np.int8)) == want[i]['state_mer_sha1'], (native, c.id)
+        text = log.getvalue()
+        assert text.count('\n') == gold['log_lines'] and hashlib.sha1(text.encode()).hexdigest() == gold['log_sha1'], native
+        if native:
+            calls_native = got
+            assert sum(c.n_unresolved for c in got.values()) == 0
+    assert len(want) >= 90
+
+    # ---- the last iteration of the 20 largest calls, row by row vs the oracle -------------------------------------------------
+    big = sorted(calls_native.values(), key=lambda c: -len(c.region_ref_discovery))[:20]
+    ref_i, tig_i = {n: i for i, n in enumerate(names)}, {n: i for i, n in enumerate(hap.tig_names)}
+    pairs = [(c.region_ref_discovery, c.region_tig_discovery) for c in big]
+    jobs = [_lib.DenJob(ref_i[r.chrom], tig_i[t.chrom], r.pos, r.end, t.pos, t.end, 1 if t.is_rev else 0, 20) for r, t in pairs]
+    res = ctx.density_batch(jobs, pavden.den_params())
+    threads = util.usable_cpus()
+    for j, ((r, t), g) in enumerate(zip(pairs, res)):
+        o = oracle.density(hap.ref.seqs[r.chrom][r.pos:r.end], hap.tig_seqs[t.chrom][t.pos:t.end], t.is_rev, threads=threads)
+        assert g.status == o['status'] == 0 and g.n_rows == o['n'] == want[big[j]._i]['n_rows']
+        cols = ctx.density_table(j, g.n_rows)
+        for c in ('INDEX', 'STATE_MER', 'STATE', 'KMER'):
+            assert np.array_equal(cols[c], o[c]), (c, r)
+        assert ctx.density_runs(j, g.n_runs) == oracle.rl_encode(o['STATE'], o['INDEX'])
+        assert g.n_unresolved == 0
+        for c in KERN:
+            assert np.allclose(cols[c], o[c], rtol=1e-12, atol=1e-300), (c, r)
+    print(f'{len(want)} calls of {len(regions)} regions equal the oracle-driven scan (both drivers); last iterations of the 20 largest '
+          f'({min(len(r) for r, _ in pairs)} - {max(len(r) for r, _ in pairs)} bp) equal the oracle row by row')
 
 
 def test_chm13_cohort_batch_of_eight_full_size(built, gpu_ctx):
@@ -94,6 +197,7 @@ def test_chm13_cohort_batch_of_eight_full_size(built, gpu_ctx):
     from pav_amd.kmer import KmerUtil
     n_lanes = 8
     k_util = KmerUtil(31)
+    _FULL.clear()                                               # the bench haplotype of the tests above: 12 GB of host memory
     free0, total = gpu_ctx.mem_info()
     hap0 = synth.config5(seed=1005, scale=1.0, hap_index=0, threads=8, pair_frac=0.009)
     ref = hap0.ref

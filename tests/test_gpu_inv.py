@@ -94,6 +94,141 @@ MODES = [(_lib.KDE_RUNS, _lib.KMER_LDS), (_lib.KDE_DIRECT, _lib.KMER_LDS), (_lib
 MODE_IDS = ['runs-lds', 'direct-lds', 'runs-hbm']
 
 
+# ---- large regions (tests/golden/inv_large; 0.1 - 1.2 Mbp vs the oracle) --------------------------------------------------------
+
+def check_large_call(d, rec, call):
+    """A call of tests/golden/inv_large against the reference's digests: regions, BED row (SEQ by sha1), integer columns by
+    sha1, KERN_* at the committed sample of rows."""
+    g = rec['call']
+    assert call is not None and call.id == g['id'] and call.svlen == g['svlen']
+    for name in ('region_ref_outer', 'region_ref_inner', 'region_tig_outer', 'region_tig_inner', 'region_ref_discovery',
+                 'region_tig_discovery'):
+        assert region_dict(getattr(call, name)) == g[name], name
+    row = rules.inv_bed_row(call, 'h1', rec['flag']['type'], os.path.join(d, 'tig.fa'))
+    got = {k: (int(v) if isinstance(v, (int, np.integer)) else v) for k, v in row.items()}
+    seq = got.pop('SEQ')
+    got['SEQ_sha1'], got['SEQ_len'] = hashlib.sha1(seq.encode()).hexdigest(), len(seq)
+    assert got == g['bed_row']
+    df = call.df
+    assert df.shape[0] == g['n_rows']
+    assert sha(df['INDEX'].to_numpy(dtype=np.int64)) == g['index_sha1']
+    assert sha(df['STATE_MER'].to_numpy(dtype=np.int8)) == g['state_mer_sha1']
+    assert sha(df['STATE'].to_numpy(dtype=np.int8)) == g['state_sha1']
+    assert sha(df['KMER'].to_numpy(dtype=np.uint64)) == g['kmer_sha1']
+    assert hashlib.sha1('\n'.join(df['FLANK'].tolist()).encode()).hexdigest() == g['flank_sha1']
+    assert hashlib.sha1('\n'.join(df['MATCH'].fillna('NA').tolist()).encode()).hexdigest() == g['match_sha1']
+    t = np.load(os.path.join(GOLD, 'inv_large', 'kern_%s.npz' % g['id']))
+    for c in KERN:
+        assert np.allclose(df[c].to_numpy()[t['rows']], t[c], rtol=RTOL, atol=1e-300), c
+
+
+@pytest.mark.parametrize('native', [False, True], ids=['python-driver', 'native-driver'])
+def test_large_regions_scan_vs_reference(built, gpu_ctx, native, capsys):
+    """pavlib.inv.scan_for_inv itself on a 150 kb and a 200 kb inversion flagged INSIDE (tools/refharness/
+    gen_golden_inv_large.py): two expansion rounds each, regions of 54 k -> 135 k -> 337 kbp (forward contig, inverted-repeat
+    flanks) and 74 k -> 185 k ([REV, FWD]: the balanced expansion of inv.py:329-332) -> 462 kbp (reverse-complemented contig,
+    an N run inside), 9 - 260 LDS partitions per k-mer set, multi-tile run sums.  Both scan drivers: the same log lines, calls,
+    regions, BED rows, table digests; KERN_* to 1e-12 at the sampled rows."""
+    d, ref, hap, gold = util.inv_large_case()
+    gpu_ctx._inv_loaded = None
+    lift = AlignLift(hap.df_trim, hap.tig_lengths)
+    k_util = KmerUtil(31)
+    flags = [pavseq.Region(r['flag']['chrom'], r['flag']['pos'], r['flag']['end']) for r in gold['scans']]
+    logs = [io.StringIO() for _ in flags]
+    out = pavinv.scan_for_inv_batch(flags, os.path.join(d, 'ref.fa'), os.path.join(d, 'tig.fa'), lift, k_util, logs=logs,
+                                    ctx=gpu_ctx, native=native)
+    n_calls = 0
+    for rec, call, log in zip(gold['scans'], out, logs):
+        assert not isinstance(call, RuntimeError), call
+        assert log.getvalue().splitlines() == rec['log'], rec['flag']
+        if rec['call'] is None:
+            assert call is None
+        else:
+            check_large_call(d, rec, call)
+            n_calls += 1
+            if native:
+                assert call.n_unresolved == 0
+    assert n_calls == 2
+
+
+@pytest.mark.parametrize('mode,kmer', MODES, ids=MODE_IDS)
+def test_large_regions_density_iterations_vs_reference(built, gpu_ctx, mode, kmer):
+    """pav_density_batch on every (region_ref, region_tig) pair the reference scanned in tests/golden/inv_large (up to 462 kbp),
+    one batch, every kernel mode: row counts, INDEX / STATE_MER / STATE digests and rl_encoder runs exact, KERN_* sums to 1e-12."""
+    d, ref, hap, gold = util.inv_large_case()
+    gpu_ctx._inv_loaded = None
+    pavinv.ensure_sequences(gpu_ctx, os.path.join(d, 'ref.fa'), os.path.join(d, 'tig.fa'))
+    ref_i = {n: i for i, n in enumerate(gpu_ctx.seq_names(_lib.PAV_ROLE_REF))}
+    tig_i = {n: i for i, n in enumerate(gpu_ctx.seq_names(_lib.PAV_ROLE_TIG))}
+    its = [it for rec in gold['scans'] for it in rec['iterations'] if it['region_tig'] is not None]
+    jobs = [_lib.DenJob(ref_i[it['region_ref']['chrom']], tig_i[it['region_tig']['chrom']], it['region_ref']['pos'],
+                        it['region_ref']['end'], it['region_tig']['pos'], it['region_tig']['end'],
+                        1 if it['region_tig']['is_rev'] else 0, 20) for it in its]
+    assert max(j.ref_end - j.ref_pos for j in jobs) > 450_000
+    res = gpu_ctx.density_batch(jobs, pavden.den_params(kde_mode=mode, kmer_mode=kmer))
+    for j, (it, r) in enumerate(zip(its, res)):
+        if 'n_rows' not in it:
+            assert r.status == _lib.DEN_FAIL or r.n_rows == 0
+            continue
+        assert r.status == (_lib.DEN_OK if it['finalised'] else _lib.DEN_UNFINALISED) and r.n_rows == it['n_rows']
+        cols = gpu_ctx.density_table(j, r.n_rows)
+        assert sha(cols['INDEX']) == it['index_sha1'] and sha(cols['STATE_MER']) == it['state_mer_sha1']
+        assert sha(cols['STATE']) == it['state_sha1']
+        assert [list(x) for x in gpu_ctx.density_runs(j, r.n_runs)] == it['state_rl']
+        assert r.n_unresolved == 0
+        if it['finalised']:
+            assert np.allclose([cols[c].sum() for c in KERN], it['kern_sum'], rtol=1e-12, atol=0)
+
+
+_LARGE_ORACLE = {}
+LARGE_REGIONS = [('chrA', 425_000, 525_000), ('chrA', 275_000, 675_000), ('chrA', 1_000, 999_000),
+                 ('chrB', 550_000, 650_000), ('chrB', 400_000, 800_000), ('chrB', 50_000, 1_250_000)]
+
+
+@pytest.mark.parametrize('mode,kmer', MODES, ids=MODE_IDS)
+def test_density_vs_oracle_on_large_regions(built, gpu_ctx, mode, kmer):
+    """Regions of 100 kbp, 400 kbp and 1.0 / 1.2 Mbp (MAX_REGION_SIZE, pavlib/inv.py:23) - forward contig (chrA, here with an N
+    run in the reference AND one in the contig) and reverse-complemented contig (chrB, N run in the reference) - through
+    pav_density_batch in every kernel mode against the scalar oracle (evaluation points spread over the host's cores, each
+    summed in scipy's order): status, row count, INDEX / STATE_MER / STATE / KMER exact, run lists exact, bandwidths
+    bit-identical, KERN_* to 1e-12 in EVERY row.  The oracle's tables are computed once for the three modes (~1 minute)."""
+    from oracle import oracle
+    d, ref0, hap0, gold = util.inv_large_case()
+    names, tnames = ref0.names, hap0.tig_names
+    seqs = {n: ref0.seqs[n].copy() for n in names}
+    tseqs = {n: hap0.tig_seqs[n].copy() for n in tnames}
+    lift = AlignLift(hap0.df_trim, hap0.tig_lengths)
+    seqs['chrA'][300_000:304_000] = ord('N')                              # k-mers skipped on both sides (density.py:48-50)
+    ta = lift.lift_region_to_qry(pavseq.Region('chrA', 600_000, 602_500))
+    tseqs[ta.chrom][ta.pos:ta.end] = ord('n')
+    gpu_ctx._inv_loaded = None
+    gpu_ctx.seq_load(_lib.PAV_ROLE_REF, names, [seqs[n] for n in names])
+    gpu_ctx.seq_load(_lib.PAV_ROLE_TIG, tnames, [tseqs[n] for n in tnames])
+    ref_i, tig_i = {n: i for i, n in enumerate(names)}, {n: i for i, n in enumerate(tnames)}
+    pairs = []
+    for c, p, e in LARGE_REGIONS:
+        r = pavseq.Region(c, p, e)
+        pairs.append((r, lift.lift_region_to_qry(r)))
+    jobs = [_lib.DenJob(ref_i[r.chrom], tig_i[t.chrom], r.pos, r.end, t.pos, t.end, 1 if t.is_rev else 0, 20) for r, t in pairs]
+    res = gpu_ctx.density_batch(jobs, pavden.den_params(kde_mode=mode, kmer_mode=kmer))
+    threads = util.usable_cpus()
+    for j, ((r, t), g) in enumerate(zip(pairs, res)):
+        if j not in _LARGE_ORACLE:
+            _LARGE_ORACLE[j] = oracle.density(seqs[r.chrom][r.pos:r.end], tseqs[t.chrom][t.pos:t.end], t.is_rev, threads=threads)
+        o = _LARGE_ORACLE[j]
+        assert g.status == o['status'] == 0 and g.n_rows == o['n'] > 0.9 * (len(r) - 8_000), r
+        cols = gpu_ctx.density_table(j, g.n_rows)
+        for c in ('INDEX', 'STATE_MER', 'STATE', 'KMER'):
+            assert np.array_equal(cols[c], o[c]), (c, r)
+        assert gpu_ctx.density_runs(j, g.n_runs) == oracle.rl_encode(o['STATE'], o['INDEX'])
+        assert g.n_eval == o['n_eval'] and g.n_unresolved == 0
+        assert np.allclose(list(g.h), o['h'], rtol=0, atol=0)
+        for c in KERN:
+            assert np.allclose(cols[c], o[c], rtol=RTOL, atol=1e-300), (c, r)
+    assert len(pairs[5][0]) == 1_200_000 and res[5].n_rows > 1_100_000
+
+
+
 @pytest.mark.parametrize('mode,kmer', MODES, ids=MODE_IDS)
 @pytest.mark.parametrize('case', INV_CASES)
 def test_density_iterations_vs_reference(built, gpu_ctx, case, mode, kmer):
@@ -428,7 +563,7 @@ def test_density_vs_oracle_seeded(built, gpu_ctx, seed, mode, kmer):
             t = lift.lift_region_to_qry(r)
         except RuntimeError:
             t = None
-        if t is None or len(r) > 60_000:
+        if t is None:
             continue
         jobs.append(_lib.DenJob(ref_i[r.chrom], tig_i[t.chrom], r.pos, r.end, t.pos, t.end, 1 if t.is_rev else 0, 20))
         pairs.append((r, t))
@@ -438,7 +573,8 @@ def test_density_vs_oracle_seeded(built, gpu_ctx, seed, mode, kmer):
     res = gpu_ctx.density_batch(jobs, pavden.den_params(kde_mode=mode, kmer_mode=kmer))
     n_final = 0
     for j, ((r, t), g) in enumerate(zip(pairs, res)):
-        o = oracle.density(hap.ref.seqs[r.chrom][r.pos:r.end], hap.tig_seqs[t.chrom][t.pos:t.end], t.is_rev)
+        o = oracle.density(hap.ref.seqs[r.chrom][r.pos:r.end], hap.tig_seqs[t.chrom][t.pos:t.end], t.is_rev,
+                           threads=util.usable_cpus() if len(r) > 30_000 else 1)
         assert g.status == o['status'], (r, t)
         if o['status'] == 125:
             assert g.fail_kind == o['fail_kind']

@@ -137,6 +137,105 @@ def test_oracle_density_matches_reference(built, case):
             assert np.array_equal(np.array(['', 'SAME', 'OTHER', 'NA'])[match], g['MATCH'])
 
 
+def test_oracle_density_matches_reference_on_large_regions(built):
+    """tests/golden/inv_large: the reference's own scans of a 150 kb and a 200 kb inversion, flagged inside, so that the regions
+    grow over two expansion rounds to 337 / 462 kbp (forward and reverse-complemented contig, an N run in the largest).  The
+    oracle on every iteration the reference executed: row count, INDEX / STATE_MER / STATE / KMER digests, rl_encoder runs
+    exact; KERN_* sums and the committed sample of table rows (every 499th + every row near a state change) to 1e-12."""
+    from oracle import oracle
+    d, ref, hap, gold = util.inv_large_case()
+    threads = min(8, util.usable_cpus())
+    n_big = 0
+    for rec in gold['scans']:
+        o = None
+        for it in rec['iterations']:
+            rr, rt = it['region_ref'], it['region_tig']
+            o = oracle.density(ref.seqs[rr['chrom']][rr['pos']:rr['end']], hap.tig_seqs[rt['chrom']][rt['pos']:rt['end']],
+                               rt['is_rev'], threads=threads)
+            if 'n_rows' not in it:
+                assert o['status'] == 125 or o['n'] == 0
+                continue
+            assert o['status'] == (0 if it['finalised'] else 1) and o['n'] == it['n_rows']
+            assert sha(o['INDEX']) == it['index_sha1'] and sha(o['STATE_MER']) == it['state_mer_sha1']
+            assert sha(o['STATE']) == it['state_sha1']
+            assert [list(r) for r in oracle.rl_encode(o['STATE'], o['INDEX'])] == it['state_rl']
+            if it['finalised']:
+                assert np.allclose([float(o[c].sum()) for c in ('KERN_FWD', 'KERN_FWDREV', 'KERN_REV')], it['kern_sum'],
+                                   rtol=1e-12, atol=0)
+            n_big += rr['end'] - rr['pos'] > 300_000
+        if rec['call'] is not None:
+            call = rec['call']
+            g = np.load(os.path.join(GOLD, 'inv_large', 'kern_%s.npz' % call['id']))
+            assert o['n'] == call['n_rows'] and sha(o['KMER']) == call['kmer_sha1']
+            for c in ('KERN_FWD', 'KERN_FWDREV', 'KERN_REV'):
+                assert np.allclose(o[c][g['rows']], g[c], rtol=1e-12, atol=1e-300), c
+    assert n_big == 2
+
+
+def _region_dict(r):
+    def aln(x):
+        return None if x is None else [[int(w) for w in v] if isinstance(v, (tuple, list)) else int(v) for v in x]
+    return {'chrom': r.chrom, 'pos': int(r.pos), 'end': int(r.end), 'is_rev': bool(r.is_rev),
+            'pos_aln_index': aln(r.pos_aln_index), 'end_aln_index': aln(r.end_aln_index)}
+
+
+@pytest.mark.parametrize('case', INV_CASES + ['inv_large'])
+def test_oracle_driven_scan_matches_reference(built, case, capsys):
+    """The WHOLE scan without a GPU: pav_amd.inv's Python state machine (expansion, stop rules, lifts, breakpoints, log text)
+    answered by the oracle's tables (tests/oracle_scan.py) against what pavlib.inv.scan_for_inv did on every flagged region of
+    the golden cases - same log lines, same None / InvCall, same six regions, same iterations.  This pair is what pins the
+    full-size INV calls (tests/golden/fullsize_inv_calls.json)."""
+    import oracle_scan
+    if case == 'inv_large':
+        d, ref, hap, gold = util.inv_large_case()
+        scans, lift = gold['scans'], AlignLift(hap.df_trim, hap.tig_lengths)
+        ref_names, ref_seqs, tig_names, tig_seqs = ref.names, ref.seqs, hap.tig_names, hap.tig_seqs
+    else:
+        d = os.path.join(GOLD, case)
+        rf, tf = open_fasta(os.path.join(d, 'ref.fa')), open_fasta(os.path.join(d, 'tig.fa'))
+        ref_names, ref_seqs, tig_names, tig_seqs = rf.names, {n: rf[n] for n in rf.names}, tf.names, {n: tf[n] for n in tf.names}
+        lift = AlignLift(pd.read_csv(os.path.join(d, 'align.tsv'), sep='\t'), read_fai(os.path.join(d, 'tig.fa.fai')))
+        with open(os.path.join(d, 'scans.json')) as fh:
+            scans = json.load(fh)
+    k_util = KmerUtil(31)
+    threads = min(8, util.usable_cpus())
+    for rec in scans:
+        f = rec['flag']
+        try:
+            out, log, ctx = oracle_scan.oracle_scan([pavseq.Region(f['chrom'], f['pos'], f['end'])], ref_names, ref_seqs, tig_names,
+                                                    tig_seqs, lift, k_util, threads=threads, **rec['kwargs'])
+            call = out[0]
+        except RuntimeError as ex:
+            call = ex
+        if rec.get('error'):
+            assert isinstance(call, RuntimeError) and str(call) == rec['error']
+            continue
+        assert log.splitlines() == rec['log'], f
+        its = [it for it in rec['iterations'] if it['region_tig'] is not None]
+        assert len(ctx.iterations) == len(its)
+        for got, it in zip(ctx.iterations, its):
+            assert (got[1], got[2], got[4], got[5], bool(got[6])) == (it['region_ref']['pos'], it['region_ref']['end'],
+                                                                     it['region_tig']['pos'], it['region_tig']['end'],
+                                                                     it['region_tig']['is_rev'])
+            assert got[8] == it.get('state_rl', [])
+        if rec['call'] is None:
+            assert call is None
+            continue
+        g = rec['call']
+        assert call.id == g['id'] and call.svlen == g['svlen']
+        for name in ('region_ref_outer', 'region_ref_inner', 'region_tig_outer', 'region_tig_inner', 'region_ref_discovery',
+                     'region_tig_discovery'):
+            assert _region_dict(getattr(call, name)) == g[name], name
+        df = call.df
+        if case == 'inv_large':
+            assert df.shape[0] == g['n_rows'] and sha(df['STATE'].to_numpy(dtype=np.int8)) == g['state_sha1']
+            assert {str(k): int(v) for k, v in df['FLANK'].value_counts().items()} == g['flank_counts']
+        else:
+            t = np.load(os.path.join(d, 'density_%s.npz' % g['id']))
+            assert np.array_equal(df['STATE'].to_numpy(), t['STATE']) and np.array_equal(df['FLANK'].to_numpy(dtype=str), t['FLANK'])
+            assert np.array_equal(df['MATCH'].fillna('NA').to_numpy(dtype=str), t['MATCH'])
+
+
 NEARTIE = ['argmax_search', 'argmax_mirror', 'delta_above', 'delta_below']
 
 

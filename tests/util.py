@@ -103,3 +103,36 @@ def assert_config1_tables(df_snv, df_insdel, gold):
     for name, df in (('snv', df_snv), ('insdel', df_insdel)):
         assert df.shape[0] == gold[name]['rows'], name
         assert_config1_text(name, frame_text(df).encode(), gold)
+
+
+_INV_LARGE = {}
+
+
+def inv_large_case():
+    """tests/golden/inv_large (tools/refharness/gen_golden_inv_large.py): the reference's scans of two 150 / 200 kb
+    inversions whose regions grow to 337 / 462 kbp.  The 4.6 Mbp of sequence are regenerated from the seed (asserting the md5
+    of what the reference saw) and written as FASTA files into a scratch directory once per session.
+    -> (dir with ref.fa / tig.fa, ref, hap, golden dict)"""
+    import hashlib
+    import tempfile
+    from pav_amd import synth
+    if not _INV_LARGE:
+        with open(os.path.join(GOLD, 'inv_large', 'scans.json')) as fh:
+            gold = json.load(fh)
+        ref, hap, flags = synth.large_inversions()
+        md5 = lambda b: hashlib.md5(b).hexdigest()   # noqa: E731
+        assert md5(b''.join(ref.seqs[n].tobytes() for n in ref.names)) == gold['inputs']['ref_md5'], \
+            'synth.large_inversions() no longer generates the committed case'
+        assert md5(b''.join(hap.tig_seqs[n].tobytes() for n in hap.tig_names)) == gold['inputs']['tig_md5']
+        assert md5(hap.df_trim.to_csv(sep='\t', index=False).encode()) == gold['inputs']['align_tsv_md5']
+        assert [(f[0], f[1], f[2]) for f in flags] == [(s['flag']['chrom'], s['flag']['pos'], s['flag']['end']) for s in gold['scans']]
+        d = tempfile.mkdtemp(prefix='pav_inv_large_')
+        synth.write_fasta(os.path.join(d, 'ref.fa'), ref.names, ref.seqs)
+        synth.write_fasta(os.path.join(d, 'tig.fa'), hap.tig_names, hap.tig_seqs)
+        _INV_LARGE['case'] = (d, ref, hap, gold)
+    return _INV_LARGE['case']
+
+
+def usable_cpus():
+    from pav_amd import shard
+    return max(1, int(shard.effective_cpus()))
