@@ -12,7 +12,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, '_build', 'libpavoracle.so')
+# PAV_ORACLE_LIB: another build of the same sources (tests/test_host_sanitize.py points it at the ASan + UBSan build)
+LIB_PATH = os.environ.get('PAV_ORACLE_LIB') or os.path.join(_HERE, '_build', 'libpavoracle.so')
 
 ALN_DTYPE = np.dtype([('ref_id', '<u4'), ('tig_id', '<u4'), ('pos', '<u4'), ('rev', '<u4')])
 SNV_DTYPE = np.dtype([('aln', '<u4'), ('pos', '<u4'), ('qry_pos', '<u4'), ('ref', 'u1'), ('alt', 'u1'),

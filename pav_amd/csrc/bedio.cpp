@@ -50,7 +50,11 @@ bool parse_i64(const char *b, const char *e, int64_t &v) {
     bool neg = false;
     if (*b == '-') { neg = true; ++b; if (b == e) return false; }
     int64_t x = 0;
-    for (; b < e; ++b) { if (*b < '0' || *b > '9') return false; x = x * 10 + (*b - '0'); }
+    for (; b < e; ++b) {
+        if (*b < '0' || *b > '9') return false;
+        if (x > (INT64_MAX - 9) / 10) return false;                    // does not fit: refused like any other non-number
+        x = x * 10 + (*b - '0');
+    }
     v = neg ? -x : x;
     return true;
 }

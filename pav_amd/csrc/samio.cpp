@@ -71,7 +71,11 @@ bool parse_int(const uint8_t *b, const uint8_t *e, int64_t &v) {
     bool neg = false;
     if (*b == '-') { neg = true; if (++b == e) return false; }
     int64_t x = 0;
-    for (; b < e; ++b) { if (*b < '0' || *b > '9') return false; x = x * 10 + (*b - '0'); }
+    for (; b < e; ++b) {
+        if (*b < '0' || *b > '9') return false;
+        if (x > (INT64_MAX - 9) / 10) return false;                    // does not fit: refused like any other non-number
+        x = x * 10 + (*b - '0');
+    }
     v = neg ? -x : x;
     return true;
 }
@@ -101,7 +105,8 @@ void parse_line(const uint8_t *b, const uint8_t *e, int64_t index, int min_mapq,
     for (const uint8_t *p = cb; p < ce;) {
         int64_t len = 0;
         const uint8_t *d = p;
-        while (p < ce && *p >= '0' && *p <= '9') len = len * 10 + (*p++ - '0');
+        while (p < ce && *p >= '0' && *p <= '9') { len = len * 10 + (*p++ - '0'); if (len >= (int64_t)1 << 28) break; }
+        // (a length of 2^28 or more does not exist in BAM and is refused by the device tokenizer as well: PAV_E_LIMIT)
         if (p == d || p == ce || op_code(*p) < 0) { out.bad = true; out.error = "malformed CIGAR"; return; }
         ops.push_back(Op{op_code(*p++), len});
     }
