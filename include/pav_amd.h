@@ -549,7 +549,11 @@ typedef struct {            /* count_cigar of a record's current CIGAR (input of
 int pav_trim_load(pav_ctx *ctx, uint32_t n, const pav_trim_row *rows, const uint8_t *cigar_text, const uint64_t *cigar_off);
 /* One pass of the pair loop over the rows listed in `order` (loaded row numbers in the reference's iteration order:
  * QRY_ID / QRY_LEN descending for PAV_TRIM_QUERY, trim.py:64-66; #CHROM / END - POS descending for PAV_TRIM_SUBJECT,
- * trim.py:267-274).  PAV_E_TRIM + pav_trim_error when the reference would have raised. */
+ * trim.py:267-274).  PAV_E_TRIM + pav_trim_error when the reference would have raised; the loaded table is undefined from then
+ * on (the reference returns none either): pav_trim_pass / pav_trim_pair / pav_trim_fetch with counts or cigar_bytes answer
+ * PAV_E_STATE until the next pav_trim_load; pav_trim_fetch of the rows alone still works - the two rows of the error record
+ * stand as the failing pair met them (the coordinates the reference's message prints), every other row is unspecified.
+ * (A failing pav_trim_pair leaves both rows as they were.) */
 int pav_trim_pass(pav_ctx *ctx, uint32_t n_order, const uint32_t *order, int mode, int64_t min_trim_tig_len, int match_tig);
 /* trim_alignment_record (trim.py:357-599) on two loaded rows: record_l = row_l, record_r = row_r, rev_l / rev_r as in
  * the reference (trim that record from its downstream end).  Both rows are replaced by their trimmed versions. */

@@ -229,12 +229,13 @@ class AlignLift:
             cig = [str(c).encode() for c in df['CIGAR']]
             off = np.zeros(len(cig) + 1, dtype=np.uint64)
             off[1:] = np.cumsum([len(c) for c in cig], dtype=np.uint64)
-            try:
+            if getattr(ctx, 'handle', None):
+                # a device or library failure here (out of memory, PAV_E_LIMIT, a HIP fault) is raised, not papered over
                 ops, op_off, sub_b, qry_b = ctx.align_index(df['POS'].to_numpy(dtype=np.uint32),
                                                              np.frombuffer(b''.join(cig), dtype=np.uint8), off)
                 self._dev = (ops, op_off.astype(np.int64), sub_b, qry_b, {ix: i for i, ix in enumerate(df.index)})
-            except Exception:                                  # noqa: BLE001 - e.g. the context has been closed since: the host tokenizer
-                self._dev = None                               # below gives the same tables, record by record
+            # (a context that has been closed since this object was made: the host tokenizer below gives the same tables,
+            #  record by record)
         if self._dev is not None:
             ops_all, op_off, sub_all, qry_all, where = self._dev
             r = where[index]

@@ -1560,19 +1560,19 @@ __global__ __launch_bounds__(64) void homology_kernel(pav_indel *__restrict__ in
     const int64_t s0 = ins ? (int64_t)tig.off + (rev ? tig_len - 1 - sv_at : sv_at) : (int64_t)ref.off + pos_ref;
     // (the owner search below takes a different path in every lane: the wave's 64 offsets go through LDS, not through shuffles,
     //  which would read lanes that have left the loop)
-    __shared__ uint32_t s_rel[64];
+    __shared__ uint64_t s_rel[64];                  // 64 sequences of up to 2^28 bases each: 2^34, more than 32 bits hold
     __shared__ int64_t s_src[64];
     __shared__ int s_fl[64];
     const uint64_t span0 = (uint64_t)__shfl((long long)seq_off, 0);                     // lane 0 is active in every launched wave
     const uint32_t n_act = n_indel - (uint64_t)blockIdx.x * 64 < 64 ? (uint32_t)(n_indel - (uint64_t)blockIdx.x * 64) : 64u;
-    s_rel[lane] = active ? (uint32_t)(seq_off - span0) : 0xFFFFFFFFu;                    // < 2^28 * 64
+    s_rel[lane] = active ? seq_off - span0 : ~0ull;
     s_src[lane] = s0; s_fl[lane] = flags;
     __syncthreads();
-    const uint32_t span = s_rel[n_act - 1] + (uint32_t)__shfl((int)oplen, (int)n_act - 1);
-    for (uint32_t b = (uint32_t)lane; b < span; b += 64) {
+    const uint64_t span = s_rel[n_act - 1] + (uint64_t)(uint32_t)__shfl((int)oplen, (int)n_act - 1);
+    for (uint64_t b = (uint64_t)lane; b < span; b += 64) {
         uint32_t lo = 0, hi = n_act;                    // last record whose sequence starts at or before byte b
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_rel[mid] <= b) lo = mid; else hi = mid; }
-        const uint32_t k = b - s_rel[lo];
+        const uint64_t k = b - s_rel[lo];
         const int64_t base = s_src[lo];
         const int fl = s_fl[lo];
         const uint8_t *plane = (fl & 1) ? T.ascii : R.ascii;

@@ -47,6 +47,10 @@ struct TrimState {
     // device side of the passes (trim_dev.hip): the operations stay resident, rows / order / scratch go up per pass
     DevBuf d_ops, d_rows, d_order, d_group, d_scratch, d_meta, d_err;
     uint64_t n_dev_passes = 0;
+    // a pass that failed leaves the rows undefined: the sequential host loops have trimmed every pair in front of the failing
+    // one, the device pass copies nothing back - so after PAV_E_TRIM from pav_trim_pass the table answers PAV_E_STATE on both
+    // paths until the next pav_trim_load (the reference raises there as well and never returns a table)
+    bool undefined = false;
     ~TrimState() { for (DevBuf *b : {&d_ops, &d_rows, &d_order, &d_group, &d_scratch, &d_meta, &d_err}) b->release(); }
 };
 
@@ -435,6 +439,10 @@ int pass_device(pav_ctx *ctx, TrimState *S, const std::vector<uint32_t> &ord, in
         std::vector<TrimFailDev> slots(n_groups);
         PAV_HIP(ctx, hipMemcpy(keys.data(), d_slot_key, 8ull * n_groups, hipMemcpyDeviceToHost));
         PAV_HIP(ctx, hipMemcpy(slots.data(), d_slots, sizeof(TrimFailDev) * n_groups, hipMemcpyDeviceToHost));
+        // the rows come back as they are: the two of the error record stand as the failing pair met them (the pairs in front of
+        // it in their group are done, the pair itself changed nothing) - what the reference prints in its message, and what the
+        // host loops leave; every other row is unspecified and the table is marked undefined by the caller
+        for (size_t i = 0; i < n_rows; ++i) from_dev(dev[i], S->rows[i]);
         for (uint32_t g = 0; g < n_groups; ++g)
             if (keys[g] == key) return record_fail(ctx, S, fail_of(slots[g]), slots[g].row_l, slots[g].row_r);
         return fail(ctx, PAV_E_STATE, "pav_trim_pass: a device pass failed without a record of the failure");
@@ -502,6 +510,7 @@ int pav_trim_load(pav_ctx *ctx, uint32_t n, const pav_trim_row *rows, const uint
     if (!ctx || (n && (!rows || !cigar_text || !cigar_off))) return PAV_E_ARG;
     TrimState *S = tstate(ctx);
     S->rows.clear();
+    S->undefined = false;
     S->err = pav_trim_err{};
     // tokenise every CIGAR once, on the device (same kernels as the call path)
     std::vector<uint32_t> zero_pos(n, 0u);
@@ -535,18 +544,22 @@ int pav_trim_pass(pav_ctx *ctx, uint32_t n_order, const uint32_t *order, int mod
         if (i >= S->rows.size() || seen[i]) return fail(ctx, PAV_E_ARG, "pav_trim_pass: order is not a set of loaded rows");
         seen[i] = 1;
     }
+    if (S->undefined) return fail(ctx, PAV_E_STATE, "pav_trim_pass: the table is undefined after a failed pass; call pav_trim_load again");
     S->err = pav_trim_err{};
     // PAV_TRIM_HOST=1: the same loops on the host (one thread) - kept as the cross-check of the device pass
-    if (host_passes())
-        return mode == PAV_TRIM_QUERY ? pass_query(ctx, S, ord, min_trim_tig_len) : pass_subject(ctx, S, ord, min_trim_tig_len, match_tig != 0);
-    return pass_device(ctx, S, ord, mode, min_trim_tig_len, match_tig != 0);
+    const int rc = host_passes()
+        ? (mode == PAV_TRIM_QUERY ? pass_query(ctx, S, ord, min_trim_tig_len) : pass_subject(ctx, S, ord, min_trim_tig_len, match_tig != 0))
+        : pass_device(ctx, S, ord, mode, min_trim_tig_len, match_tig != 0);
+    if (rc != PAV_OK) S->undefined = true;
+    return rc;
 }
 
 int pav_trim_pair(pav_ctx *ctx, uint32_t row_l, uint32_t row_r, int mode, int rev_l, int rev_r) {
     if (!ctx || (mode != PAV_TRIM_QUERY && mode != PAV_TRIM_SUBJECT)) return PAV_E_ARG;
     TrimState *S = tstate(ctx);
     if (row_l >= S->rows.size() || row_r >= S->rows.size() || row_l == row_r) return fail(ctx, PAV_E_ARG, "pav_trim_pair: no such pair of loaded rows");
-    S->err = pav_trim_err{};
+    if (S->undefined) return fail(ctx, PAV_E_STATE, "pav_trim_pair: the table is undefined after a failed pass; call pav_trim_load again");
+    S->err = pav_trim_err{};                                        // (a pair that fails leaves both rows as they were, on both paths)
     if (!host_passes()) return pair_device(ctx, S, row_l, row_r, mode, rev_l, rev_r);
     Row l = S->rows[row_l], r = S->rows[row_r];
     TrimFail tf;
@@ -565,6 +578,10 @@ int pav_trim_error(const pav_ctx *ctx, pav_trim_err *err) {
 int pav_trim_fetch(pav_ctx *ctx, pav_trim_row *rows, pav_trim_count *counts, uint64_t *cigar_bytes) {
     if (!ctx) return PAV_E_ARG;
     TrimState *S = tstate(ctx);
+    // after a failed pass only the plain rows may be read (the two of the error record are as the failing pair met them: the
+    // mirror prints their coordinates in the reference's message); counts and CIGAR strings of an undefined table are refused
+    if (S->undefined && (counts || cigar_bytes))
+        return fail(ctx, PAV_E_STATE, "pav_trim_fetch: the table is undefined after a failed pass; call pav_trim_load again");
     const size_t n = S->rows.size();
     if (rows) for (size_t i = 0; i < n; ++i) { rows[i] = S->rows[i].f; rows[i].modified = S->rows[i].c.modified ? 1 : 0; }
     if (counts) parallel_rows(n, [&](size_t i) { counts[i] = count_cigar(*S, S->rows[i].c); });

@@ -115,3 +115,45 @@ def test_device_passes_equal_the_host_loops(gpu_ctx, monkeypatch):
         out[name] = tuple(d.to_csv(sep='\t', index=False) for d in (tig, ref, both))
     assert out['device'] == out['host']
     assert out['device'][0] != df0.to_csv(sep='\t', index=False)              # something was trimmed
+
+
+@pytest.mark.parametrize('which', ['Illegal operation', 'Found no cut-sites'])
+def test_a_failing_pass_reports_the_same_pair_on_both_paths_and_poisons_the_table(gpu_ctx, monkeypatch, which):
+    """A pass over a table in which ONE pair cannot be trimmed (an M operation inside the overlap / no cut site: the error
+    records of tests/golden/trim_kat.json put behind a pair that trims fine): the device pass and the host loops raise the
+    reference's message with the same error record (kind, rows, operation), and the loaded table is undefined afterwards on
+    both paths - pav_trim_fetch / pav_trim_pass answer PAV_E_STATE until the table is loaded again."""
+    from pav_amd import _lib
+    from pav_amd.align import trim as trimmod
+    with open(os.path.join(GOLD, 'trim_kat.json')) as fh:
+        items = json.load(fh)
+    bad = next(it for it in items if 'error' in it and which in it['error'][1] and it['match_coord'] == 'query')
+    good = next(it for it in items if 'error' not in it and it['match_coord'] == 'query' and it['l']['QRY_ID'] == it['r']['QRY_ID']
+                and it['l']['QRY_ID'] != bad['l']['QRY_ID'])
+    rows = [dict(good['l']), dict(good['r']), dict(bad['l']), dict(bad['r'])]
+    for i, r in enumerate(rows):
+        r['INDEX'] = i
+        for c in ('TRIM_REF_L', 'TRIM_REF_R', 'TRIM_QRY_L', 'TRIM_QRY_R'):
+            r[c] = 0
+    df = pd.DataFrame(rows)
+    fai = pd.Series({r['QRY_ID']: int(r['QRY_LEN']) for r in rows})
+    seen = {}
+    for name, env in (('device', None), ('host', '1')):
+        if env is None:
+            monkeypatch.delenv('PAV_TRIM_HOST', raising=False)
+        else:
+            monkeypatch.setenv('PAV_TRIM_HOST', env)
+        with pytest.raises(RuntimeError) as ei:
+            trim_alignments(df, 1, fai, mode='tig', ctx=gpu_ctx)
+        cause = ei.value.__cause__ if isinstance(ei.value.__cause__, _lib.TrimDeviceError) else ei.value.__context__
+        err = cause.detail
+        rows_after, _, _ = gpu_ctx.trim_fetch(with_cigar=False, with_counts=False)
+        seen[name] = (str(ei.value), err.kind, err.row_l, err.row_r, err.op_index, err.op_char,
+                      rows_after[[err.row_l, err.row_r]].tobytes())
+        with pytest.raises(_lib.PavDeviceError, match='undefined after a failed pass'):
+            gpu_ctx.trim_fetch()
+        with pytest.raises(_lib.PavDeviceError, match='undefined after a failed pass'):
+            gpu_ctx.trim_pass([0, 1], _lib.TRIM_QUERY, 1)
+    assert seen['device'] == seen['host'], seen
+    assert which in seen['device'][0]
+    trim_alignments(df.iloc[:2], 1, fai, mode='tig', ctx=gpu_ctx)             # a fresh load makes the context usable again
