@@ -368,6 +368,8 @@ class Context:
         ptrs = (ctypes.c_void_p * max(n, 1))(*[a.ctypes.data for a in arrays])
         lens = (ctypes.c_uint64 * max(n, 1))(*[a.shape[0] for a in arrays])
         self._check(self.lib.pav_seq_load(self.handle, role, n, ptrs, lens), 'pav_seq_load')
+        if role == PAV_ROLE_REF:
+            self._ref_resident = None                     # (cigarcall.load_reference marks a whole reference file as resident)
         self._seq_names[role] = [str(x) for x in names]
         cnames = (ctypes.c_char_p * max(n, 1))(*[x.encode() for x in self._seq_names[role]])
         self._check(self.lib.pav_seq_set_names(self.handle, role, n, cnames), 'pav_seq_set_names')
@@ -376,6 +378,8 @@ class Context:
         """Read ``other``'s resident records of ``role`` (same GPU) instead of holding a copy: one context per haplotype, one
         reference for all of them (``pav_seq_share``)."""
         self._check(self.lib.pav_seq_share(self.handle, other.handle, role), 'pav_seq_share')
+        if role == PAV_ROLE_REF:
+            self._ref_resident = getattr(other, '_ref_resident', None)
         self._seq_names[role] = list(other._seq_names[role])
         n = len(self._seq_names[role])
         cnames = (ctypes.c_char_p * max(n, 1))(*[x.encode() for x in self._seq_names[role]])
@@ -385,6 +389,8 @@ class Context:
         """Upload records (indexes into ``fasta``, a :class:`FastaFile`) straight from the library's parse buffers."""
         rec = np.ascontiguousarray(records, dtype=np.uint32)
         self._check(self.lib.pav_seq_load_fasta(self.handle, role, fasta.handle, rec.shape[0], _ptr(rec)), 'pav_seq_load_fasta')
+        if role == PAV_ROLE_REF:
+            self._ref_resident = None
         self._seq_names[role] = [fasta.names[int(i)] for i in rec]
 
     def seq_pack(self, role):

@@ -58,9 +58,43 @@ def pack_alignments(df_align, ref_names, tig_names):
     return aln, text, off
 
 
+def _file_key(path):
+    import os
+    st = os.stat(path)
+    return (os.path.realpath(str(path)), st.st_size, st.st_mtime_ns)
+
+
+def load_reference(ctx, ref_fa_name):
+    """Make every record of ``ref_fa_name`` resident on the context and remember it: later ``load_sequences`` calls with the
+    same file keep the reference where it is (a cohort's haplotypes are called one after the other against ONE resident
+    reference, ``pav_amd.cohort``; the packed planes of an hg38-sized reference are 4.3 GB and 0.3 s of work per upload)."""
+    key = _file_key(ref_fa_name)
+    if getattr(ctx, '_ref_resident', None) != key:
+        ref_fa = open_fasta(ref_fa_name)
+        ctx.seq_load_fasta(_lib.PAV_ROLE_REF, ref_fa.native, ref_fa.record_numbers(ref_fa.names))
+        ctx._ref_resident = key
+    return ctx.seq_names(_lib.PAV_ROLE_REF)
+
+
 def load_sequences(ctx, ref_fa_name, tig_fa_name, df_align=None, names=None):
     """Upload the records the alignment table touches (all records when ``df_align`` is None); ``names`` gives the two
-    sets of record names directly."""
+    sets of record names directly.  A reference made resident by :func:`load_reference` stays (records are found by name)."""
+    keep_ref = getattr(ctx, '_ref_resident', None) is not None and ctx._ref_resident == _file_key(ref_fa_name)
+    if keep_ref:
+        tig_fa = open_fasta(tig_fa_name)
+        resident = ctx.seq_names(_lib.PAV_ROLE_REF)
+        if names is not None or (df_align is not None and df_align.shape[0]):
+            want_ref = {str(c) for c in (names[0] if names is not None else df_align['#CHROM'])}
+            want_tig = {str(c) for c in (names[1] if names is not None else df_align['QRY_ID'])}
+            tig_names = [n for n in tig_fa.names if n in want_tig]
+            missing = (want_ref - set(resident)) | (want_tig - set(tig_names))
+            if missing:
+                raise KeyError(f'sequence(s) {sorted(missing)} of the alignment table are not in the FASTA files')
+        else:
+            tig_names = list(tig_fa.names)
+        ctx.seq_load_fasta(_lib.PAV_ROLE_TIG, tig_fa.native, tig_fa.record_numbers(tig_names))
+        return list(resident), tig_names
+    ctx._ref_resident = None
     ref_fa = open_fasta(ref_fa_name)
     tig_fa = open_fasta(tig_fa_name)
     if names is not None or (df_align is not None and df_align.shape[0]):

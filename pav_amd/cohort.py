@@ -1,0 +1,285 @@
+"""
+A cohort on the GPUs of one node: ``run_cohort(jobs, n_gpus, out_dir, ref_fa)``.
+
+PAV treats haplotypes independently (README.md:83-86) and, inside a haplotype, its CALL_BATCH alignment batches (rule
+call_cigar, rules/call.snakefile:792-846) and its flagged-region BATCHes (rule call_inv_batch, rules/call_inv.snakefile:115-311);
+Snakemake runs them as separate jobs and exchanges files.  Here there is one process per GPU and no data-path collective
+(SURVEY.md section 8(e)):
+
+* ``len(jobs) >= n_gpus`` - BASELINE configs[3] (16 haplotypes -> 8 GPUs in two waves) and configs[4] (64 haplotypes, 8 per GPU):
+  whole haplotypes are dealt to the ranks longest-processing-time first (cost = size of the alignment table, i.e. CIGAR text) and
+  every rank runs :func:`pav_amd.rules.call_haplotype` on its haplotypes one after the other against ONE resident reference.
+* fewer haplotypes than GPUs (or ``split=True``): the ranks that share a haplotype split its CALL_BATCH jobs, the lead rank
+  merges them as rule call_cigar_merge does (:765-786) and flags the merged tables (the five flag rules), the ranks split the
+  flagged-region BATCH jobs, the lead rank merges them as rule call_inv_batch_merge does (call_inv.snakefile:101-112, incl.
+  ``drop_duplicates('ID')``).  Files are the exchange medium, as in the reference.
+
+``torch.distributed`` carries the barriers between the stages and the manifests (host objects); RCCL / xGMI move no data.  The
+ranks are either the processes of a launcher (``torch.distributed.run``: RANK / WORLD_SIZE in the environment) or started here,
+as child processes, before anything in this process touches a GPU.
+
+The work of a rank is done by an *engine* (``DeviceEngine``: the library on one GPU).  The engine is a parameter so that the
+plumbing - planning, stage order, merges, manifests - can be driven on a machine without a GPU by a stand-in (tests); the
+product default fails loudly without the HIP library and a GPU.
+"""
+import os
+import socket
+from dataclasses import asdict, dataclass
+
+from . import rules, shard
+
+
+@dataclass
+class HaplotypeJob:
+    asm_name: str
+    hap: str
+    tig_fa: str                 # temp/{asm}/align/contigs_{hap}.fa.gz (+ .fai)
+    bed: str                    # results/{asm}/align/trim-none/aligned_tig_{hap}.bed.gz
+    bed_trim: str               # results/{asm}/align/trim-tigref/aligned_tig_{hap}.bed.gz
+    cost: float = 0.0           # 0: the size of `bed` (CIGAR text dominates it)
+
+    def weight(self):
+        return float(self.cost) if self.cost else float(os.path.getsize(self.bed))
+
+
+def plan(jobs, world, split=False):
+    """-> ``world`` lists of work items ``(job number, part, n_parts, lead rank)``.  Whole haplotypes (n_parts == 1) by LPT when
+    there are at least as many as ranks and ``split`` is off; otherwise every haplotype gets a contiguous group of ranks (in
+    proportion to its weight, at least one) whose first member is its lead."""
+    out = [[] for _ in range(world)]
+    if not jobs:
+        return out
+    w = [j.weight() for j in jobs]
+    if len(jobs) >= world and not split:
+        for r, mine in enumerate(shard.assign_lpt(w, world)):
+            out[r] = [(j, 0, 1, r) for j in mine]
+        return out
+    # groups of ranks per haplotype: largest-remainder apportionment of the ranks, every haplotype at least one; with more
+    # haplotypes than ranks (split forced) the haplotypes are dealt round and share ranks whole
+    if len(jobs) > world:
+        for r, mine in enumerate(shard.assign_lpt(w, world)):
+            out[r] = [(j, 0, 1, r) for j in mine]
+        return out
+    total = sum(w) or 1.0
+    share = [max(1, int(world * x / total)) for x in w]
+    while sum(share) > world:
+        share[max(range(len(jobs)), key=lambda i: (share[i], -w[i]))] -= 1
+    while sum(share) < world:
+        share[max(range(len(jobs)), key=lambda i: w[i] / share[i])] += 1
+    r0 = 0
+    for j, n in enumerate(share):
+        for p in range(n):
+            out[r0 + p].append((j, p, n, r0))
+        r0 += n
+    return out
+
+
+class DeviceEngine:
+    """One rank's worker: a context on one GPU and the reference resident on it."""
+
+    def __init__(self, device_id, ref_fa, config=None, threads=0, gzip_level=0):
+        self.device_id, self.ref_fa, self.config = int(device_id), ref_fa, dict(config or {})
+        self.threads, self.gzip_level = threads, gzip_level
+        self.ctx = None
+
+    def open(self):
+        from . import _lib, cigarcall
+        self.ctx = _lib.Context(self.device_id)                  # raises without the HIP library / a GPU: there is no CPU path
+        cigarcall.load_reference(self.ctx, self.ref_fa)
+
+    def close(self):
+        if self.ctx is not None:
+            self.ctx.close()
+            self.ctx = None
+
+    # ---- whole haplotype ----------------------------------------------------------------------------------------------
+    def call_haplotype(self, job, out_dir):
+        return rules.call_haplotype(job.bed, job.bed_trim, job.tig_fa, self.ref_fa, job.asm_name, job.hap, out_dir, ctx=self.ctx,
+                                    config=self.config, threads=self.threads, gzip_level=self.gzip_level)
+
+    # ---- the jobs of a haplotype that several ranks share -------------------------------------------------------------------
+    def call_cigar_batches(self, job, P, batches):
+        for b in batches:
+            rules.call_cigar_files(job.bed, job.bed_trim, job.tig_fa, self.ref_fa, job.hap, b, P['cigar_batch_insdel'][b],
+                                   P['cigar_batch_snv'][b], ctx=self.ctx, threads=self.threads)
+
+    def flag_tables(self, job, P):
+        cfg = self.config
+        rules.call_inv_cluster([P['insdel']], 'indel', P['cluster_indel'], ctx=self.ctx,
+                               cluster_win=cfg.get('inv_sig_cluster_win', 200), cluster_min_snv=cfg.get('inv_sig_cluster_snv_min', 20),
+                               cluster_min_indel=cfg.get('inv_sig_cluster_indel_min', 10))
+        rules.call_inv_cluster([P['snv']], 'snv', P['cluster_snv'], ctx=self.ctx,
+                               cluster_win=cfg.get('inv_sig_cluster_win', 200), cluster_min_snv=cfg.get('inv_sig_cluster_snv_min', 20),
+                               cluster_min_indel=cfg.get('inv_sig_cluster_indel_min', 10))
+        for vartype in ('sv', 'indel'):
+            rules.call_inv_flag_insdel_cluster(P['insdel'], vartype, P['insdel_' + vartype], ctx=self.ctx,
+                                               flank_cluster=cfg.get('inv_sig_insdel_cluster_flank', 2),
+                                               flank_merge=cfg.get('inv_sig_insdel_merge_flank', 2000),
+                                               cluster_min_svlen=cfg.get('inv_sig_cluster_svlen_min', 4))
+        rules.call_inv_merge_flagged_loci(P['insdel_sv'], P['insdel_indel'], P['cluster_indel'], P['cluster_snv'], P['flagged_regions'],
+                                          ctx=self.ctx, flank=cfg.get('inv_sig_merge_flank', 500),
+                                          batch_count=cfg.get('inv_sig_batch_count', 60), inv_sig_filter=cfg.get('inv_sig_filter', 'svindel'))
+
+    def call_inv_batches(self, job, P, batches):
+        cfg = self.config
+        for b in batches:
+            rules.call_inv_batch(P['flagged_regions'], job.bed_trim, job.tig_fa, job.tig_fa + '.fai', self.ref_fa, job.hap, b,
+                                 bed_out=P['inv_batch'][b], log_path=P['inv_log'][b], density_out_dir=P['density_dir'],
+                                 k_size=cfg.get('inv_k_size', 31), inv_region_limit=cfg.get('inv_region_limit'),
+                                 inv_min_expand=cfg.get('inv_min_expand'), srs_list=cfg.get('srs_list'), ctx=self.ctx)
+
+
+def _default_engine(rank, device_id, ref_fa, config):
+    return DeviceEngine(device_id, ref_fa, config)
+
+
+def _barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+
+
+def run_rank(rank, world, jobs, out_dir, ref_fa, config=None, engine_factory=None, split=False, share_gpu=False):
+    """The work of one rank (the process group, if any, is up).  Returns this rank's manifests: one per whole haplotype it ran,
+    one per shared haplotype it leads."""
+    config = dict(config or {})
+    batch_count = int(config.get('inv_sig_batch_count', 60))
+    items = plan(jobs, world, split)
+    mine = items[rank]
+    engine = (engine_factory or _default_engine)(rank, 0 if share_gpu else rank, ref_fa, config)
+    manifests = []
+    shared = sorted({(j, n, lead) for its in items for (j, p, n, lead) in its if n > 1})
+    engine.open()
+    try:
+        for (j, p, n, lead) in mine:
+            if n == 1:
+                m = engine.call_haplotype(jobs[j], out_dir)
+                m['rank'], m['mode'] = rank, 'whole haplotype'
+                manifests.append(m)
+        # the shared haplotypes advance stage by stage; every rank meets every barrier (a rank without a part just passes)
+        my_part = {j: (p, n) for (j, p, n, lead) in mine if n > 1}
+        paths = {j: rules.haplotype_paths(out_dir, jobs[j].asm_name, jobs[j].hap, batch_count) for (j, n, lead) in shared}
+        for j in my_part:
+            rules._makedirs_for(paths[j])
+        for j, (p, n) in my_part.items():                                       # stage 1: rule call_cigar, batches p, p + n, ...
+            engine.call_cigar_batches(jobs[j], paths[j], list(range(p, rules.CALL_CIGAR_BATCH_COUNT, n)))
+        if shared:
+            _barrier(world)
+        for (j, n, lead) in shared:                                             # stage 2 (lead): call_cigar_merge + the five flag rules
+            if lead == rank:
+                P = paths[j]
+                rules.call_cigar_merge(P['cigar_batch_insdel'], P['cigar_batch_snv'], P['insdel'], P['snv'])
+                engine.flag_tables(jobs[j], P)
+        if shared:
+            _barrier(world)
+        for j, (p, n) in my_part.items():                                       # stage 3: rule call_inv_batch, batches p, p + n, ...
+            engine.call_inv_batches(jobs[j], paths[j], list(range(p, batch_count, n)))
+        if shared:
+            _barrier(world)
+        for (j, n, lead) in shared:                                             # stage 4 (lead): call_inv_batch_merge
+            if lead == rank:
+                P = paths[j]
+                df = rules.call_inv_batch_merge(P['inv_batch'], P['inv'])
+                manifests.append({'asm_name': jobs[j].asm_name, 'hap': jobs[j].hap, 'rank': rank, 'mode': f'shared by {n} ranks',
+                                  'inv_calls': int(df.shape[0]), 'files': {k: P[k] for k in ('snv', 'insdel', 'flagged_regions', 'inv')}})
+    finally:
+        engine.close()
+    return manifests
+
+
+def _gather(manifests, world):
+    if world <= 1:
+        return manifests
+    import torch.distributed as dist
+    buf = [None] * world
+    dist.all_gather_object(buf, manifests)
+    return [m for part in buf for m in part]
+
+
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def _child(rank, world, port, backend, args, queue):
+    os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'RANK': str(rank), 'WORLD_SIZE': str(world),
+                       'LOCAL_RANK': str(rank)})
+    import torch
+    import torch.distributed as dist
+    jobs, out_dir, ref_fa, config, engine_factory, split, share_gpu = args
+    if backend == 'nccl':
+        torch.cuda.set_device(0 if share_gpu else rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0 if share_gpu else rank))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        ms = _gather(run_rank(rank, world, jobs, out_dir, ref_fa, config, engine_factory, split, share_gpu), world)
+        dist.barrier()
+        if rank == 0:
+            queue.put(ms)
+    finally:
+        dist.destroy_process_group()
+
+
+def run_cohort(jobs, n_gpus, out_dir, ref_fa, config=None, engine_factory=None, split=False, backend=None, share_gpu=False,
+               timeout=None):
+    """Call every haplotype of ``jobs`` (:class:`HaplotypeJob`) on ``n_gpus`` GPUs of this node; files under ``out_dir`` with the
+    reference's relative names (:func:`pav_amd.rules.haplotype_paths`).  Returns the manifests of all haplotypes (on every rank
+    when the ranks were started by a launcher).
+
+    ``backend``: process-group backend of the control plane - default ``'nccl'`` (RCCL) with one GPU per rank, ``'gloo'`` with
+    ``share_gpu`` (tests: every rank on GPU 0) or without a GPU (stand-in engines).  ``engine_factory(rank, device_id, ref_fa,
+    config)`` must be importable by the child processes (a module-level function)."""
+    jobs = [j if isinstance(j, HaplotypeJob) else HaplotypeJob(**j) for j in jobs]
+    os.makedirs(out_dir, exist_ok=True)
+    if 'RANK' in os.environ and 'WORLD_SIZE' in os.environ and int(os.environ['WORLD_SIZE']) > 1:
+        import torch.distributed as dist                       # the ranks exist already (torch.distributed.run)
+        rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+        if world != n_gpus:
+            raise ValueError(f'run_cohort(n_gpus={n_gpus}) inside a job of WORLD_SIZE={world}')
+        if not dist.is_initialized():
+            import torch
+            be = backend or ('gloo' if share_gpu else 'nccl')
+            if be == 'nccl':
+                local = int(os.environ.get('LOCAL_RANK', rank))
+                torch.cuda.set_device(local)
+                dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+            else:
+                dist.init_process_group(be)
+        return _gather(run_rank(rank, world, jobs, out_dir, ref_fa, config, engine_factory, split, share_gpu), world)
+    if n_gpus <= 1:
+        return run_rank(0, 1, jobs, out_dir, ref_fa, config, engine_factory, split, share_gpu)
+    import torch.multiprocessing as mp
+    be = backend or ('gloo' if share_gpu else 'nccl')
+    mctx = mp.get_context('spawn')                             # fresh interpreters: nothing of this process's GPU state is inherited
+    queue = mctx.Queue()
+    port = _free_port()
+    args = (jobs, out_dir, ref_fa, config, engine_factory, split, share_gpu)
+    procs = [mctx.Process(target=_child, args=(r, n_gpus, port, be, args, queue)) for r in range(n_gpus)]
+    for p in procs:
+        p.start()
+    try:
+        result = None
+        import queue as _q
+        waited = 0.0
+        while result is None:
+            try:
+                result = queue.get(timeout=1.0)
+            except _q.Empty:
+                waited += 1.0
+                dead = [p for p in procs if p.exitcode not in (None, 0)]
+                if dead:
+                    raise RuntimeError(f'run_cohort: rank process(es) failed with exit code(s) {[p.exitcode for p in dead]}')
+                if timeout is not None and waited > timeout:
+                    raise TimeoutError(f'run_cohort: no result after {timeout} s')
+        for p in procs:
+            p.join(timeout=120)
+        bad = [p.exitcode for p in procs if p.exitcode != 0]
+        if bad:
+            raise RuntimeError(f'run_cohort: rank process(es) ended with exit code(s) {bad}')
+        return result
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()                                   # the exact processes started above

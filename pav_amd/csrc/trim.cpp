@@ -380,7 +380,9 @@ void from_dev(const RowDev &d, Row &r) {
 }
 TrimFail fail_of(const TrimFailDev &f) {
     TrimFail t;
-    t.kind = f.kind; t.op_index = f.op_index; t.op_len = f.op_len; t.op_char = (uint32_t)OP_CHARS[f.op_code < 9 ? f.op_code : 0];
+    t.kind = f.kind; t.op_index = f.op_index; t.op_len = f.op_len;
+    // (the operation fields describe an illegal operation only; the host loops leave them zero for the other kinds)
+    t.op_char = f.kind == PAV_TRIM_ERR_ILLEGAL_OP ? (uint32_t)OP_CHARS[f.op_code < 9 ? f.op_code : 0] : 0u;
     t.diff_bp = f.diff_bp; t.side = f.side;
     return t;
 }

@@ -406,6 +406,178 @@ def call_inv_flag(bed, bed_trim, tig_fa_name, ref_fa_name, out=None, ctx=None, d
 
 
 # ---------------------------------------------------------------------------------------------------------
+# One haplotype, files to files: call_cigar x 10 -> call_cigar_merge -> the five flag rules -> call_inv_batch x N -> merge
+# ---------------------------------------------------------------------------------------------------------
+
+def haplotype_paths(out_dir, asm_name, hap, batch_count=60):
+    """The files the rule chain of one haplotype reads and writes, under ``out_dir`` with the reference's relative names
+    (rules/call.snakefile:755-803, rules/call_inv.snakefile:94-131, 326-331, 485-487, 605-607)."""
+    import os
+    j = lambda *p: os.path.join(out_dir, *p)                                          # noqa: E731
+    return {
+        'cigar_batch_insdel': [j('temp', asm_name, 'cigar', 'batched', f'insdel_{hap}_{b}.bed.gz') for b in range(CALL_CIGAR_BATCH_COUNT)],
+        'cigar_batch_snv': [j('temp', asm_name, 'cigar', 'batched', f'snv.bed_{hap}_{b}.gz') for b in range(CALL_CIGAR_BATCH_COUNT)],
+        'insdel': j('temp', asm_name, 'cigar', 'merged', f'svindel_insdel_{hap}.bed.gz'),
+        'snv': j('temp', asm_name, 'cigar', 'merged', f'snv_snv_{hap}.bed.gz'),
+        'insdel_sv': j('temp', asm_name, 'inv_caller', 'flag', f'insdel_sv_{hap}.bed.gz'),
+        'insdel_indel': j('temp', asm_name, 'inv_caller', 'flag', f'insdel_indel_{hap}.bed.gz'),
+        'cluster_indel': j('temp', asm_name, 'inv_caller', 'flag', f'cluster_indel_{hap}.bed.gz'),
+        'cluster_snv': j('temp', asm_name, 'inv_caller', 'flag', f'cluster_snv_{hap}.bed.gz'),
+        'flagged_regions': j('results', asm_name, 'inv_caller', f'flagged_regions_{hap}.bed.gz'),
+        'inv_batch': [j('temp', asm_name, 'inv_caller', 'batch', hap, f'inv_call_{b}.bed.gz') for b in range(batch_count)],
+        'inv_log': [j('log', asm_name, 'inv_caller', 'log', hap, f'inv_call_{b}.log') for b in range(batch_count)],
+        'density_dir': j('results', asm_name, 'inv_caller', 'density_table'),
+        'inv': j('temp', asm_name, 'inv_caller', f'sv_inv_{hap}.bed.gz'),
+    }
+
+
+def _makedirs_for(paths):
+    import os
+    for v in paths.values():
+        for f in (v if isinstance(v, list) else [v]):
+            os.makedirs(f if f.endswith('density_table') else os.path.dirname(f), exist_ok=True)
+
+
+def call_haplotype(bed, bed_trim, tig_fa_name, ref_fa_name, asm_name, hap, out_dir, ctx=None, device_id=0, config=None, threads=0,
+                   gzip_level=0, timings=None):
+    """The whole call path of ONE haplotype on one GPU, from its files to its files - what the rules call_cigar (all ten
+    CALL_BATCH jobs) -> call_cigar_merge -> call_inv_cluster x 2 / call_inv_flag_insdel_cluster x 2 -> call_inv_merge_flagged_loci
+    -> call_inv_batch (all batches) -> call_inv_batch_merge produce, with the calls made once and kept resident between the
+    stages: every alignment row is called at once and the merged tables come from the native writer, the signature flagging
+    runs on the resident records (``pav_cigar_flag``), ONE scan covers the flagged regions of all batches; the per-batch INV
+    tables, logs and density tables are then written batch by batch in the reference's order (duplicate calls are dropped per
+    batch, then across batches by the merge rule's own code), so every file equals the rule chain's.
+
+    ``config``: the per-assembly configuration keys of the rules (inv_sig_filter, inv_sig_batch_count, inv_sig_merge_flank,
+    inv_sig_cluster_*, inv_sig_insdel_*, inv_k_size, inv_region_limit, inv_min_expand, srs_list).  A reference made resident
+    by ``cigarcall.load_reference`` stays resident.  Returns a manifest dict (counts + file names)."""
+    import io
+    import time
+    import numpy as np
+    from . import _lib, flag, inv as pavinv, seq as pavseq
+    from .align import AlignLift
+    from .fasta import read_fai
+    from .kmer import KmerUtil
+    cfg = dict(config or {})
+    batch_count = int(cfg.get('inv_sig_batch_count', 60))
+    P = haplotype_paths(out_dir, asm_name, hap, batch_count)
+    _makedirs_for(P)
+    t_last = [time.perf_counter()]
+
+    def lap(name):
+        if timings is not None:
+            now = time.perf_counter()
+            timings[name] = timings.get(name, 0.0) + now - t_last[0]
+            t_last[0] = now
+    ctx, own = _with_ctx(ctx, device_id)
+    table = trim_table = None
+    try:
+        table, trim_table = _lib.BedTable(bed, with_cigar=True), _lib.BedTable(bed_trim, with_cigar=False)
+        cols = table.fetch()
+        cigarcall.load_reference(ctx, ref_fa_name)
+        cigarcall.load_sequences(ctx, ref_fa_name, tig_fa_name)                        # every contig record: the scan may lift anywhere
+        ctx._inv_loaded = (str(ref_fa_name), str(tig_fa_name))
+        lap('sequences')
+        index = ctx.cigar_load_bed(table, -1)
+        try:
+            counts = ctx.cigar_call()
+        except _lib.CigarDeviceError as ex:
+            if ex.detail is None:
+                raise
+            cigarcall._raise_reference_error(ex.detail, pd.DataFrame({
+                '#CHROM': [table.chrom_names[i] for i in cols['#CHROM']], 'POS': cols['POS'],
+                'QRY_ID': [table.qry_names[i] for i in cols['QRY_ID']], 'INDEX': cols['INDEX']}))
+        tc = trim_table.fetch()
+        trim = pd.DataFrame({'POS': tc['POS'], 'END': tc['END']}, index=tc['INDEX']).astype(int).reindex(list(index), fill_value=-1)
+        tp, te = trim['POS'].to_numpy(dtype='int64'), trim['END'].to_numpy(dtype='int64')
+        lap('tables in + CIGAR-call')
+        call_batch = cols['CALL_BATCH'] if table.n_rows else np.zeros(0, dtype=np.int64)
+        n_snv, n_insdel = ctx.cigar_write_tables(hap, index, tp, te, snv_path=P['snv'], insdel_path=P['insdel'], threads=threads,
+                                                 gzip_level=gzip_level, call_batch=call_batch)
+        lap('merged SNV / INS-DEL tables')
+        flag_cfg = {}
+        for key, name in (('inv_sig_cluster_win', 'cluster_win'), ('inv_sig_cluster_snv_min', 'cluster_min_snv'),
+                          ('inv_sig_cluster_indel_min', 'cluster_min_indel'), ('inv_sig_insdel_cluster_flank', 'insdel_flank_cluster'),
+                          ('inv_sig_insdel_merge_flank', 'insdel_flank_merge'), ('inv_sig_cluster_svlen_min', 'insdel_min_svlen'),
+                          ('inv_sig_merge_flank', 'merge_flank'), ('inv_sig_batch_count', 'batch_count')):
+            if key in cfg:
+                flag_cfg[name] = int(cfg[key])
+        res = flag.flag_from_calls(ctx, tp, te, inv_sig_filter=cfg.get('inv_sig_filter', 'svindel'), **flag_cfg)
+        for name in FLAG_OUTPUTS:
+            _write_bed(res[name], P[name])
+        lap('flag tables')
+        df_flag = pd.read_csv(P['flagged_regions'], sep='\t', header=0)                # as rule call_inv_batch reads it (:144)
+        k_util = KmerUtil(int(cfg.get('inv_k_size', 31)))
+        srs_tree = pavinv.get_srs_tree(cfg.get('srs_list'))
+        sel = df_flag.loc[df_flag['BATCH'] >= 0] if df_flag.shape[0] else df_flag
+        results, logs = [], []
+        if sel.shape[0]:
+            align_lift = AlignLift(pd.read_csv(bed_trim, sep='\t'), read_fai(str(tig_fa_name) + '.fai'), ctx=ctx)
+            regions = [pavseq.Region(c, p, e) for c, p, e in zip(sel['#CHROM'], sel['POS'], sel['END'])]
+            logs = [io.StringIO() for _ in regions]
+            lap('lift-over index')
+            results = pavinv.scan_for_inv_batch(regions, ref_fa_name, tig_fa_name, align_lift, k_util,
+                                                max_region_size=cfg.get('inv_region_limit'), logs=logs, srs_tree=srs_tree,
+                                                min_exp_count=cfg.get('inv_min_expand'), ctx=ctx, eager_tables=False,
+                                                found_out=io.StringIO())
+            lap('scan')
+        # ---- per batch, in the order the reference's jobs see the rows: INV table, log, density tables ----------------------
+        where = {ix: q for q, ix in enumerate(sel.index)}
+        native_tables, n_calls = [], 0
+        for b in range(batch_count):
+            rows_b = df_flag.loc[df_flag['BATCH'] == b] if df_flag.shape[0] else df_flag
+            id_set, call_list = set(), []
+            with open(P['inv_log'][b], 'w') as log_file:
+                for ix, row in rows_b.iterrows():
+                    r = results[where[ix]]
+                    log_file.write(logs[where[ix]].getvalue())
+                    if isinstance(r, RuntimeError):                                       # :198-200
+                        log_file.write('RuntimeError in scan_for_inv(): {}\n'.format(r))
+                        r = None
+                    if r is not None and r.id not in id_set:                             # :203
+                        call_list.append(inv_bed_row(r, hap, row['TYPE'], tig_fa_name))
+                        id_set.add(r.id)
+                        path = '{}/density_{}_{}.tsv.gz'.format(P['density_dir'], r.id, hap)
+                        nt = r.native_table
+                        if nt is not None and nt[0] is ctx and nt[2] == ctx._inv_generation and callable(r._df):
+                            native_tables.append((nt[1], path))
+                        else:
+                            r.df.to_csv(path, sep='\t', index=False, compression='gzip')
+            if rows_b.shape[0] == 0:
+                df_bed = pd.DataFrame([], columns=list(INV_BED_COLUMNS))                  # :148-167
+            elif call_list:
+                df_bed = pd.concat(call_list, axis=1).T.sort_values(['#CHROM', 'POS', 'END', 'ID'])   # :297
+            else:
+                df_bed = pd.DataFrame([], columns=[c for c in INV_BED_COLUMNS if c != 'FILTER'])       # :300-308 (sic)
+            df_bed.to_csv(P['inv_batch'][b], sep='\t', index=False, compression='gzip')
+            n_calls += len(call_list)
+        lap('INV batch tables + logs')
+        if native_tables:
+            # a call found through two flagged regions is written once per batch that holds it, as the jobs of the rule would:
+            # the same file name, the same table
+            ctx.inv_write_tables([r for r, _ in native_tables], [p for _, p in native_tables], threads=threads, gzip_level=gzip_level)
+        lap('density tables')
+        df_inv = call_inv_batch_merge(P['inv_batch'], P['inv'])
+        lap('INV merge')
+        return {'asm_name': asm_name, 'hap': hap, 'aligned_bp': int(counts.aligned_bases), 'snv_rows': int(n_snv),
+                'insdel_rows': int(n_insdel), 'flagged_regions': int(df_flag.shape[0]), 'scanned_regions': int(sel.shape[0]),
+                'inv_calls_in_batches': int(n_calls), 'inv_calls': int(df_inv.shape[0]),
+                'files': {k: P[k] for k in ('snv', 'insdel', 'flagged_regions', 'inv')}}
+    finally:
+        for t in (table, trim_table):
+            if t is not None:
+                t.close()
+        if own:
+            ctx.close()
+
+
+def run_cohort(jobs, n_gpus, out_dir, ref_fa, **kw):
+    """Many haplotypes on the GPUs of one node, one process per GPU, haplotypes dealt longest-first: see :mod:`pav_amd.cohort`."""
+    from . import cohort
+    return cohort.run_cohort(jobs, n_gpus, out_dir, ref_fa, **kw)
+
+
+# ---------------------------------------------------------------------------------------------------------
 # rules align_trim_tig / align_trim_tigref (rules/align.snakefile:54-97)
 # ---------------------------------------------------------------------------------------------------------
 
