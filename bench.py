@@ -280,6 +280,10 @@ def main():
             ln.lift = AlignLift(ln.hap.df_trim, ln.tig_len)
             ln.t_lift_ms = (time.perf_counter() - t_a) * 1e3
             ln.found = io.StringIO()
+            # the same table as the arrays pav_inv_load_alignments takes (the `with_lift_index` leg rebuilds the index per step)
+            ri_ = {n: i for i, n in enumerate(ln.ctx.seq_names(_lib.PAV_ROLE_REF))}
+            ti_ = {n: i for i, n in enumerate(ln.ctx.seq_names(_lib.PAV_ROLE_TIG))}
+            ln.lift_arrays = pavinv.pack_lift_table(ln.lift, ri_, ti_)
 
     def inv_step(ln):
         """Flagged loci of the fresh calls -> scan of every locus with TRY_INV (rules/call_inv.snakefile:145-196)."""
@@ -309,7 +313,14 @@ def main():
         lap('cigar_call')
         if workload == 'cigar+verify':
             ln.verify = ln.ctx.cigar_verify()
-        if workload == 'cigar+inv':
+        if workload == 'cigar+inv+lift':
+            # what a cohort run pays per haplotype on top of a step: the lift-over index of the trimmed table (tokenised and
+            # scanned on the device, brought to the host lookup tables) - the reference builds its AlignLift inside every
+            # call_inv_batch job (rules/call_inv.snakefile:174-177)
+            ln.ctx.inv_load_alignments(*ln.lift_arrays)
+            ln.lift._native_loaded = ln.ctx
+            lap('lift index')
+        if workload in ('cigar+inv', 'cigar+inv+lift'):
             inv_step(ln)
             lap('flag + scan')
 
@@ -362,7 +373,7 @@ def main():
                         started[k].set()
                         if workload == 'cigar+verify':
                             ln.verify = ln.ctx.cigar_verify()
-                        if workload == 'cigar+inv':
+                        if workload in ('cigar+inv', 'cigar+inv+lift'):
                             inv_step(ln)
                     else:
                         step(ln, workload)
@@ -440,12 +451,32 @@ def main():
         aligned_total = float(ab.item())
         per_rank = [None] * world
         dist.all_gather_object(per_rank, {'rank': rank, 'ms_per_step': round(t_local / args.steps * 1e3, 4),
+                                          'lanes_per_gpu': n_lanes, 'usable_cpus': round(cpus_per_rank, 2),
                                           'aligned_bp': aligned_steps / args.steps,
                                           'cigar_text_bytes': int(sum(ln.text.shape[0] for ln in lanes))})
     else:
         aligned_total = aligned_steps
-        per_rank = [{'rank': 0, 'ms_per_step': round(t_local / args.steps * 1e3, 4), 'aligned_bp': aligned_steps / args.steps,
+        per_rank = [{'rank': 0, 'ms_per_step': round(t_local / args.steps * 1e3, 4), 'lanes_per_gpu': n_lanes,
+                     'usable_cpus': round(cpus_per_rank, 2), 'aligned_bp': aligned_steps / args.steps,
                      'cigar_text_bytes': int(sum(ln.text.shape[0] for ln in lanes))}]
+
+    # ---- the timed region once more with HIP events around every kernel of EVERY lane: which kernel takes the most device time
+    #      in the regime the line is measured in (kernels of other lanes beside it), and how much longer than alone -----------
+    lanes_prof, t_lanes_prof = None, None
+    if n_lanes > 1:
+        for ln in lanes:
+            ln.ctx.prof_reset()
+            ln.ctx.prof_enable(True)
+        _, t_lanes_prof = timed(args.steps)
+        lanes_prof = [ln.ctx.prof_read() for ln in lanes]
+        for ln in lanes:
+            ln.ctx.prof_enable(False)
+            ln.ctx.prof_reset()
+    # ---- the step plus the lift-over index of the trimmed table, rebuilt inside every step (reported beside `value`) ---------
+    t_with_lift = None
+    if args.workload == 'cigar+inv':
+        run_steps(max(2, n_lanes), 'cigar+inv+lift')
+        _, t_with_lift = timed(args.steps, 'cigar+inv+lift')
 
     # ---- the same steps on ONE lane with HIP events around every kernel (roofline leg): nothing of another haplotype
     #      beside them, so the sum of the kernel times is the device work of a step ---------------------------------------
@@ -592,7 +623,7 @@ def main():
                     m = _re.search(r':(\d+)-(\d+)', ln.split(': ')[1])
                     scanned_bp += int(m.group(2)) - int(m.group(1)) + 1
         pmc = None                                            # committed PMC summary of this workload, newest round first
-        for pmc_name in ('r03_pmc.json', 'r02_pmc.json', 'r01_pmc.json'):
+        for pmc_name in ('r04_pmc.json', 'r03_pmc.json', 'r02_pmc.json', 'r01_pmc.json'):
             try:
                 with open(os.path.join(ROOT, 'profiles', pmc_name)) as fh:
                     cand = json.load(fh)
@@ -608,15 +639,25 @@ def main():
         # (TCC_EA0_RDREQ_32B = 0, profiles/r03_cigar_emission_counters.txt).  The kernel is therefore priced in distinct 64 B lines
         # (counted here from the rows the device produced) against the rate at which the memory system delivers isolated lines
         # (tools/ubench/gather_rate.hip, the maximum over its variants with a 16 B store per row beside the loads, as in the kernel).
-        line_roof = {'with_stores': None, 'loads_only': None, 'source': 'profiles/r03_gather_rate.txt'}
+        # The roof: the MAXIMUM over the ubench variants that load the way the kernel does - walk_snv stores a 16 B row per pair of
+        # loads and its loads are non-temporal, so every `16 B stored` variant counts, nt loads included (round 3 left those out and
+        # priced the kernel against 40.4 G lines/s; the same ubench reaches 45.7 with nt loads); `loads_only` = the maximum with
+        # nothing stored, the ceiling of the memory system for this access pattern
+        line_roof = {'with_stores': None, 'with_stores_variant': None, 'loads_only': None, 'loads_only_variant': None,
+                     'source': 'profiles/r03_gather_rate.txt'}
+        for cand_ in ('r04_gather_rate.txt', 'r03_gather_rate.txt'):
+            if os.path.exists(os.path.join(ROOT, 'profiles', cand_)):
+                line_roof['source'] = 'profiles/' + cand_
+                break
         try:
-            with open(os.path.join(ROOT, 'profiles', 'r03_gather_rate.txt')) as fh:
+            with open(os.path.join(ROOT, line_roof['source'])) as fh:
                 for ln_ in fh:
-                    if '->' in ln_ and 'G isolated' in ln_:
+                    if '->' in ln_ and 'G isolated' in ln_ and not ln_.startswith('maximum'):
                         rate_ = float(ln_.split('->')[1].split('G')[0])
-                        key_ = 'with_stores' if '16 B stored' in ln_ and 'nt loads' not in ln_ else ('loads_only' if 'nothing stored' in ln_ and 'nt loads' not in ln_ else None)
+                        key_ = 'with_stores' if '16 B stored' in ln_ else ('loads_only' if 'nothing stored' in ln_ else None)
                         if key_ and (line_roof[key_] is None or rate_ > line_roof[key_]):
                             line_roof[key_] = rate_
+                            line_roof[key_ + '_variant'] = ' '.join(ln_.split('avg')[0].split())
         except OSError:
             pass
         snv_lines = None
@@ -637,7 +678,8 @@ def main():
             rate = (snv_lines + hom_lines) / (t_ms * 1e-3) / 1e9
             peak = line_roof['with_stores']
             return {'line_fetches_per_pass': int(snv_lines + hom_lines), 'phase_ms': round(t_ms, 4), 'achieved_glines_per_s': round(rate, 1),
-                    'measured_peak_glines_per_s': peak, 'frac': None if not peak else round(rate / peak, 3),
+                    'measured_peak_glines_per_s': peak, 'peak_variant': line_roof['with_stores_variant'],
+                    'frac': None if not peak else round(rate / peak, 3),
                     'note': 'distinct lines of the SNV rows + fabric reads of homology_kernel (FETCH_SIZE / 64 B, ' + str(pmc.get('file')) +
                             ') over the longer of the two kernels, which run beside each other'}
 
@@ -647,7 +689,8 @@ def main():
             rate = snv_lines / (avg_ms_ * 1e-3) / 1e9
             peak = line_roof['with_stores']
             return {'distinct_64B_lines_per_launch': snv_lines, 'achieved_glines_per_s': round(rate, 1),
-                    'measured_peak_glines_per_s': peak, 'measured_peak_loads_only': line_roof['loads_only'], 'source': line_roof['source'],
+                    'measured_peak_glines_per_s': peak, 'peak_variant': line_roof['with_stores_variant'],
+                    'measured_peak_loads_only': line_roof['loads_only'], 'source': line_roof['source'],
                     'frac': None if not peak else round(rate / peak, 3),
                     'note': 'distinct 64 B lines of the two ASCII arenas the SNV rows touch (counted from the rows); the kernel time here is '
                             'what it takes beside homology_kernel, which draws on the same budget (3.96 M more line fetches per pass): '
@@ -657,13 +700,8 @@ def main():
             """Dominant kernel (largest total time in the profiled steps) against the HBM roofline: algorithmic bytes per
             launch / average launch duration from HIP events on the library's streams."""
             kern_ = {k: {'launches': v[0], 'avg_ms': v[1] / max(1, v[0])} for k, v in prof_.items()}
-            # tok_count's event time is mostly queueing behind the high-priority pack (0.01 ms with nothing beside it): ranked by that
-            own = {k: (call_alone['kernels_ms'].get(k, v['avg_ms']) if k == 'tok_count' else v['avg_ms']) for k, v in kern_.items()}
-            dom = want or max(kern_, key=lambda k: own[k] * kern_[k]['launches'])
-            # walk_snv and homology_kernel run beside each other and end within a few per cent of each other: the line keeps
-            # to walk_snv (the kernel the committed counters and the line-rate model are about) unless the other is clearly longer
-            if want is None and 'walk_snv' in kern_ and own['walk_snv'] * kern_['walk_snv']['launches'] >= 0.95 * own[dom] * kern_[dom]['launches']:
-                dom = 'walk_snv'
+            own = {k: v['avg_ms'] for k, v in kern_.items()}
+            dom = want or max(kern_, key=lambda k: own[k] * kern_[k]['launches'])       # the true arg-max of total time, no tie-breaks
             alg_bytes = {
                 'verify_kernel': 0.5 * float(counts.aligned_bases),           # the two 2-bit planes (SURVEY 8(d)); masks only where marked dirty
                 'pack_kernel': tig_bases * (1.0 + 0.25 + 0.125),
@@ -710,8 +748,8 @@ def main():
                         'point_data_pairs_per_launch': kde[2] / kern_[dom]['launches'],
                         'executed': {'tflops': round(ex, 2), 'frac': round(ex / FP64_VECTOR_PEAK_TFLOPS, 4),
                                      'model': '150 flop per (point, run) pair'}}
-            if dom in ('walk_snv', 'homology_kernel') and kern_[dom]['avg_ms'] > 0:
-                head['isolated_lines'] = isolated_lines(dom, kern_[dom]['avg_ms'])
+            if 'walk_snv' in kern_ and kern_['walk_snv']['avg_ms'] > 0:              # the line-rate model of walk_snv, whichever kernel leads
+                head['isolated_lines'] = isolated_lines('walk_snv', kern_['walk_snv']['avg_ms'])
             head.update({'avg_kernel_ms': round(kern_[dom]['avg_ms'], 4), 'launches_per_step': round(kern_[dom]['launches'] / args.steps, 2)})
             return kern_, {**head,
                            'kernels_ms': {k: round(v['avg_ms'], 4) for k, v in sorted(kern_.items())},
@@ -722,6 +760,54 @@ def main():
 
         kern, roofline = make_roofline(prof, kde=kde_leg)
         roofline['emission_phase'] = emission_phase(kern)
+        roofline['dominant_measured'] = roofline['kernel']           # (the arg-max of total event time, one lane alone; no substitution)
+        if lanes_prof:
+            # the same ranking in the regime the line is measured in: every lane running, HIP events around every kernel of every lane
+            tot = {}
+            for pr_ in lanes_prof:
+                for k_, v_ in pr_.items():
+                    a_ = tot.setdefault(k_, [0, 0.0])
+                    a_[0] += v_[0]
+                    a_[1] += v_[1]
+            dev_ms = sum(v_[1] for v_ in tot.values()) / args.steps
+            top = sorted(tot, key=lambda k_: -tot[k_][1])
+            dom_l = top[0]
+            lds = None
+            for lds_name in ('r04_lds_counters.json',):
+                try:
+                    with open(os.path.join(ROOT, 'profiles', lds_name)) as fh:
+                        lds = json.load(fh)
+                    lds['file'] = 'profiles/' + lds_name
+                except (OSError, ValueError):
+                    pass
+
+            def lds_roof(k_, avg_ms_):
+                # LDS-array cycles of a launch (SQ_LDS_IDX_ACTIVE, summed over the CUs; committed counter pass taken with the same
+                # lanes running) against what 256 CUs offer in the launch's duration at 2.4 GHz: the fraction of the LDS arrays'
+                # time the kernel keeps busy; `conflict` = the share of those cycles that are bank-conflict replays
+                if not lds or k_ not in lds.get('kernels', {}) or avg_ms_ <= 0:
+                    return None
+                c_ = lds['kernels'][k_]
+                peak_cyc = 256 * 2.4e9 * avg_ms_ * 1e-3
+                return {'bound': 'lds', 'lds_array_cycles_per_launch': c_['lds_idx_active'], 'peak_cycles_in_launch': round(peak_cyc),
+                        'frac': round(c_['lds_idx_active'] / peak_cyc, 4), 'bank_conflict_share': c_.get('bank_conflict_share'),
+                        'lds_instructions_per_launch': c_.get('insts_lds'), 'source': lds.get('file'),
+                        'note': 'SQ_LDS_IDX_ACTIVE / (256 CUs x 2.4 GHz x launch duration); guide: 256 B per clock and CU'}
+            roofline['timed_region'] = {
+                'lanes': n_lanes, 'kernel': dom_l, 'ms_per_step_profiled': round(t_lanes_prof / args.steps * 1e3, 4),
+                'device_ms_per_step': round(dev_ms, 3),
+                'share_of_device_time': round(tot[dom_l][1] / args.steps / dev_ms, 4) if dev_ms else None,
+                'avg_kernel_ms': round(tot[dom_l][1] / max(1, tot[dom_l][0]), 4),
+                'avg_kernel_ms_alone': round(kern[dom_l]['avg_ms'], 4) if dom_l in kern else None,
+                'lds': lds_roof(dom_l, tot[dom_l][1] / max(1, tot[dom_l][0])),
+                'kernels': {k_: {'ms_per_step': round(tot[k_][1] / args.steps, 4), 'share': round(tot[k_][1] / args.steps / dev_ms, 4),
+                                 'avg_ms': round(tot[k_][1] / max(1, tot[k_][0]), 4),
+                                 'over_alone': round(tot[k_][1] / max(1, tot[k_][0]) / kern[k_]['avg_ms'], 2) if k_ in kern and kern[k_]['avg_ms'] > 0 else None,
+                                 'lds': lds_roof(k_, tot[k_][1] / max(1, tot[k_][0]))}
+                            for k_ in top[:12]},
+                'note': 'per-kernel HIP-event sums over ALL lanes of one more region of K steps with every lane running (kernels of other '
+                        'haplotypes beside each launch): the dominant kernel of the regime `value` is measured in; device_ms_per_step '
+                        'counts overlapping kernels once each, so it exceeds ms_per_step'}
         # ---- the honest roofline of the PATH (SURVEY.md section 8(d) byte model; the pack above is pre-processing the model
         #      has no term for): algorithmic bytes of one step / step time.  CIGAR-call: 4 B / op + 64 B / row + 16 B / SNV +
         #      40 B / indel + 2-bit SV bases + 0.5 B per scanned homology base (window bound: 128 B / indel) + 0.5 B per X base;
@@ -982,6 +1068,12 @@ def main():
                                                                (sum(r['cigar_text_bytes'] for r in per_rank) / len(per_rank)), 4),
                              'note': 'haplotype -> GPU; every rank holds whole haplotypes (weak scaling), so the balance is the '
                                      'haplotypes\' own size spread'},
+            'with_lift_index': None if t_with_lift is None else {
+                'value': round(aligned_total / t_with_lift / 1e9, 2), 'unit': 'Gbp/s', 'ms_per_step': round(t_with_lift / args.steps * 1e3, 4),
+                'lift_index_ms_per_step': round((t_with_lift - t_max) / args.steps * 1e3, 4),
+                'note': 'the same K steps with the lift-over index of the trimmed alignment table rebuilt inside every step '
+                        '(pav_inv_load_alignments: tokenise + scan on the device, lookup tables on the host) - what a cohort run pays '
+                        'per haplotype; `value` keeps the index resident like the other inputs'},
             'roofline': roofline, 'cpu_baseline': cpu, 'cigar_only': cigar_only, 'verify_mode': verify_mode, 'inv_scan': inv_report,
             'end_to_end': e2e,
             # the streaming pack of the whole contig arena (verify mode, PAV_EAGER_PACK=1): timed with nothing beside it

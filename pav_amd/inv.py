@@ -520,6 +520,26 @@ def _native_srs(srs_tree):
     return cached[1], cached[2]
 
 
+def pack_lift_table(align_lift, ref_index, tig_index):
+    """The trimmed alignment table of an :class:`pav_amd.align.AlignLift` as the arrays ``pav_inv_load_alignments`` takes: row
+    records (record numbers of the two stores, spans, strand, INDEX), the CIGAR strings as one text block, their offsets."""
+    df = align_lift.df
+    n = df.shape[0]
+    aln = np.zeros(n, dtype=_lib.INV_ALN_DTYPE)
+    if n:
+        aln['ref_id'] = [ref_index[str(c)] for c in df['#CHROM']]
+        aln['tig_id'] = [tig_index[str(c)] for c in df['QRY_ID']]
+        for col, name in (('pos', 'POS'), ('end', 'END'), ('qry_pos', 'QRY_POS'), ('qry_end', 'QRY_END'), ('index', 'INDEX')):
+            aln[col] = df[name].to_numpy(dtype=np.int64)
+        aln['rev'] = [1 if bool(v) else 0 for v in df['REV']]
+    cig = [str(c).encode() for c in df['CIGAR']] if n else []
+    off = np.zeros(n + 1, dtype=np.uint64)
+    if n:
+        off[1:] = np.cumsum([len(c) for c in cig], dtype=np.uint64)
+    text = np.frombuffer(b''.join(cig), dtype=np.uint8) if n else np.zeros(0, dtype=np.uint8)
+    return aln, text, off
+
+
 def _native_scan(ctx, region_flags, align_lift, k_util, max_region_size, logs, srs_tree, min_exp_count, ref_index, tig_index,
                  eager_tables=True, log=None, found_out=None):
     """All regions through the library's native driver (pav_inv_scan_batch, csrc/invscan.cpp)."""
@@ -533,21 +553,8 @@ def _native_scan(ctx, region_flags, align_lift, k_util, max_region_size, logs, s
             t = time.perf_counter()
             print('[pav timing] _native_scan %-18s %.1f ms' % (what, (t - _t[0]) * 1e3), file=__import__('sys').stderr)
             _t[0] = t
-    df = align_lift.df
-    n = df.shape[0]
     if getattr(align_lift, '_native_loaded', None) is not ctx:
-        aln = np.zeros(n, dtype=_lib.INV_ALN_DTYPE)
-        if n:
-            aln['ref_id'] = [ref_index[str(c)] for c in df['#CHROM']]
-            aln['tig_id'] = [tig_index[str(c)] for c in df['QRY_ID']]
-            for col, name in (('pos', 'POS'), ('end', 'END'), ('qry_pos', 'QRY_POS'), ('qry_end', 'QRY_END'), ('index', 'INDEX')):
-                aln[col] = df[name].to_numpy(dtype=np.int64)
-            aln['rev'] = [1 if bool(v) else 0 for v in df['REV']]
-        cig = [str(c).encode() for c in df['CIGAR']] if n else []
-        off = np.zeros(n + 1, dtype=np.uint64)
-        if n:
-            off[1:] = np.cumsum([len(c) for c in cig], dtype=np.uint64)
-        text = np.frombuffer(b''.join(cig), dtype=np.uint8) if n else np.zeros(0, dtype=np.uint8)
+        aln, text, off = pack_lift_table(align_lift, ref_index, tig_index)
         _lap('marshal table')
         ctx.inv_load_alignments(aln, text, off)
         align_lift._native_loaded = ctx

@@ -92,8 +92,8 @@ def _golden_checks(tree, case, asm, hap):
 def test_two_ranks_on_one_gpu_equal_the_unsharded_run_and_the_reference_tables(built, tmp_path, split):
     """The real engine, two rank processes sharing GPU 0 (gloo control plane): three haplotypes dealt to two ranks (one resident
     reference per rank, haplotypes one after the other) / one haplotype shared by both ranks.  All files equal the one-rank
-    run's; the merged SNV / INS-DEL tables and the five flag tables equal what the reference's rule bodies wrote
-    (tests/golden/flag_hap, flag_sparse)."""
+    run's; the merged SNV / INS-DEL tables and the five flag tables of sampleA h1 equal what the reference's rule bodies wrote
+    (tests/golden/flag_hap)."""
     if split:
         jobs = [ce.golden_job('flag_hap', 'sampleA', 'h1')]
     else:
@@ -113,8 +113,8 @@ def test_two_ranks_on_one_gpu_equal_the_unsharded_run_and_the_reference_tables(b
     for k in a:
         assert a[k] == b[k], k
     assert any('/density_table/' in k for k in a)
-    if not split:
-        _golden_checks(b, 'flag_sparse', 'sampleA', 'h2')
+    # (sampleA h2 = the contigs of flag_sparse against THIS reference: a second, different haplotype for the equality above; its
+    #  golden tables were made with another reference and do not apply)
     # (single_cluster changes TRY_INV / BATCH of the flagged regions only; the other tables are the default configuration's)
     tree = {k: v for k, v in b.items()}
     cfg_default = tmp_path / 'default'

@@ -117,6 +117,31 @@ def sq(db, out):
     print(open(out).read())
 
 
+def ldsjson(db, out, lanes='6'):
+    """LDS counters of one --pmc pass (SQ_LDS_IDX_ACTIVE, SQ_LDS_BANK_CONFLICT, SQ_INSTS_LDS, SQ_LDS_ADDR_CONFLICT) per kernel,
+    averaged per launch, as the JSON bench.py reads for its LDS roofline (roofline.timed_region.*.lds)."""
+    import json
+    cur = sqlite3.connect(db).cursor()
+    per = {}
+    for n, c, k, a in cur.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
+                                  "group by kernel_name, counter_name"):
+        per.setdefault(short(n), {})[c] = (k, a)
+    doc = {'source': f'rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAVE_CYCLES around bench.py --lanes {lanes} '
+                     '(tools/scripts/profile_round.sh); averages per launch, summed over the CUs',
+           'lanes': int(lanes), 'kernels': {}}
+    for k, c in sorted(per.items(), key=lambda kv: -kv[1].get('SQ_LDS_IDX_ACTIVE', (0, 0.0))[1]):
+        act = c.get('SQ_LDS_IDX_ACTIVE', (0, 0.0))[1]
+        if act <= 0:
+            continue
+        doc['kernels'][k] = {'launches': c['SQ_LDS_IDX_ACTIVE'][0], 'lds_idx_active': round(act, 1),
+                             'bank_conflict_share': round(c.get('SQ_LDS_BANK_CONFLICT', (0, 0.0))[1] / act, 4),
+                             'insts_lds': round(c.get('SQ_INSTS_LDS', (0, 0.0))[1], 1),
+                             'wave_cycles': round(c.get('SQ_WAVE_CYCLES', (0, 0.0))[1], 1)}
+    with open(out, 'w') as fh:
+        json.dump(doc, fh, indent=1)
+    print(open(out).read())
+
+
 def timeline(db, out, last_ms=30.0):
     cur = sqlite3.connect(db).cursor()
     ev = [(s, e, short(n)) for n, s, e in cur.execute('select name, start, end from kernels')]
@@ -182,6 +207,8 @@ if __name__ == '__main__':
         busy(*sys.argv[2:7])
     elif sys.argv[1] == 'pmcjson':
         pmcjson(*sys.argv[2:6])
+    elif sys.argv[1] == 'ldsjson':
+        ldsjson(*sys.argv[2:5])
     elif sys.argv[1] == 'timeline':
         timeline(sys.argv[2], sys.argv[3], float(sys.argv[4]) if len(sys.argv) > 4 else 30.0)
     else:
