@@ -230,7 +230,9 @@ def run_cohort(jobs, n_gpus, out_dir, ref_fa, config=None, engine_factory=None, 
 
     ``backend``: process-group backend of the control plane - default ``'nccl'`` (RCCL) with one GPU per rank, ``'gloo'`` with
     ``share_gpu`` (tests: every rank on GPU 0) or without a GPU (stand-in engines).  ``engine_factory(rank, device_id, ref_fa,
-    config)`` must be importable by the child processes (a module-level function)."""
+    config)`` must be importable by the child processes (a module-level function).  The children are started with
+    ``multiprocessing``'s *spawn* method: a script that calls this with ``n_gpus > 1`` needs the usual
+    ``if __name__ == '__main__':`` guard around its top-level code."""
     jobs = [j if isinstance(j, HaplotypeJob) else HaplotypeJob(**j) for j in jobs]
     os.makedirs(out_dir, exist_ok=True)
     if 'RANK' in os.environ and 'WORLD_SIZE' in os.environ and int(os.environ['WORLD_SIZE']) > 1:

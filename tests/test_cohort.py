@@ -118,6 +118,6 @@ def test_two_ranks_on_one_gpu_equal_the_unsharded_run_and_the_reference_tables(b
     # (single_cluster changes TRY_INV / BATCH of the flagged regions only; the other tables are the default configuration's)
     tree = {k: v for k, v in b.items()}
     cfg_default = tmp_path / 'default'
-    cohort.run_cohort(jobs[:1], 1, str(cfg_default), ref_fa, config=CFG)
+    cohort.run_cohort(jobs[:1], 1, str(cfg_default), ref_fa, config={})          # the reference's defaults: 60 batches, svindel
     _golden_checks(ce.tree_text(cfg_default), 'flag_hap', 'sampleA', 'h1')
     assert tree['temp/sampleA/cigar/merged/snv_snv_h1.bed.gz'] == ce.tree_text(cfg_default)['temp/sampleA/cigar/merged/snv_snv_h1.bed.gz']
