@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libpav_amd.so')
+# PAV_AMD_LIB: another build of the same library (tuning builds of tools/bench_variants.py); there is still no CPU path behind it
+LIB_PATH = os.environ.get('PAV_AMD_LIB') or os.path.join(_HERE, 'lib', 'libpav_amd.so')
 
 PAV_ROLE_REF, PAV_ROLE_TIG = 0, 1
 PAV_OK, PAV_E_ARG, PAV_E_HIP, PAV_E_NODEV, PAV_E_CIGAR, PAV_E_STATE, PAV_E_LIMIT, PAV_E_TRIM = 0, -1, -2, -3, -4, -5, -6, -7

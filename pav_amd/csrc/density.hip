@@ -502,8 +502,13 @@ __global__ __launch_bounds__(LDS_THREADS) void k_kmer_lds(const PartItem *__rest
         ok_r[u] = e < n_ref; pos_r[u] = n_ref ? list_r[ok_r[u] ? e : n_ref - 1] : 0u;
         ok_t[u] = e < n_tig; pos_t[u] = n_tig ? list_t[ok_t[u] ? e : n_tig - 1] : 0u;
     }
+#ifdef PAV_KMER_LATE_TIG                     // tuning build: the contig windows are fetched behind the inserts (16 registers fewer)
+#pragma unroll
+    for (int u = 0; u < KU; ++u) kw_r[u] = kmer_words(R.two, jd.ref_abs + pos_r[u]);
+#else
 #pragma unroll
     for (int u = 0; u < KU; ++u) { kw_r[u] = kmer_words(R.two, jd.ref_abs + pos_r[u]); kw_t[u] = kmer_words(T.two, jd.tig_abs + pos_t[u]); }
+#endif
 
     for (int s = threadIdx.x; s < LDS_SLOTS; s += LDS_THREADS) keys[s] = EMPTY_KEY;
     for (int s = threadIdx.x; s < LDS_SLOTS / 2; s += LDS_THREADS) cnt2[s] = 0;
@@ -542,6 +547,10 @@ __global__ __launch_bounds__(LDS_THREADS) void k_kmer_lds(const PartItem *__rest
 #pragma unroll
         for (int u = 0; u < KU; ++u) if (ok[u]) insert(kmer_from_words(kw[u], jd.ref_abs + pos[u], k));
     }
+#ifdef PAV_KMER_LATE_TIG
+#pragma unroll
+    for (int u = 0; u < KU; ++u) kw_t[u] = kmer_words(T.two, jd.tig_abs + pos_t[u]);
+#endif
     if (my_flags) atomicOr(&flags, my_flags);
     __syncthreads();
     if (threadIdx.x == 0 && flags) atomicOr(&stat[it.job].lds_flags, flags);

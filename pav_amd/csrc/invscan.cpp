@@ -8,6 +8,7 @@
 #include "common.h"
 #include "textio.h"
 #include "pool.h"
+#include "lift_dev.h"
 
 #include <sys/mman.h>
 #include <new>
@@ -90,6 +91,12 @@ struct InvState {
     std::vector<Spans> span_ref, span_tig;
     std::vector<std::string> names[2];
     std::vector<uint8_t> row_bad;                           // first N (3) / P (6) operation code of a record, 0: none (lift.py:463-471)
+    // The same index on the device (lift_dev.hip; the default): the operation tables stay where pav_align_index built them, the
+    // point lifts of a scan round are one kernel.  PAV_LIFT_HOST=1 keeps the host tables above instead (the cross-check).
+    bool on_device = false;
+    DevBuf d_ops, d_begin, d_small, d_q, d_a;
+    LiftTables dev{};
+    void *h_qa = nullptr; size_t h_qa_cap = 0;              // pinned: queries up, answers down
     std::unique_ptr<HostPool> pool;                         // helper threads of the per-region host loops (pav_inv_scan_batch)
     std::vector<Scan> scans;                                // per-region state of the running scan (kept: its vectors keep their memory)
     bool loaded = false;
@@ -127,6 +134,8 @@ struct InvState {
     }
     void next_pinned() { cur_set ^= 1; for (auto &b : pinned_sets[cur_set]) b.used = 0; stage_used = 0; }
     void free_pinned() {
+        if (h_qa) { (void)hipHostFree(h_qa); h_qa = nullptr; h_qa_cap = 0; }
+        for (DevBuf *b : {&d_ops, &d_begin, &d_small, &d_q, &d_a}) b->release();
         for (auto &set : pinned_sets) { for (auto &b : set) (void)hipHostFree(b.p); set.clear(); }
         for (auto &set : stage_sets) { for (auto &st : set) st->release(); set.clear(); }
     }
@@ -322,6 +331,92 @@ public:
         return true;
     }
 
+    // ---- point lifts in batches: the device index (lift_dev.hip) or, with PAV_LIFT_HOST=1, the host functions above ----------
+    struct Point { LiftAnswer a; std::string err; };                   // a.status >= LIFT_ERR_OP: `err` is the RuntimeError text
+    std::string lift_error(const LiftQuery &q, const LiftAnswer &a) const {
+        const LiftRow &r = S->rows[a.row];
+        if (a.status == LIFT_ERR_OP) {
+            uint32_t code = 3;
+            if (!S->on_device) code = S->row_bad[a.row];
+            else code = (uint32_t)a.id;                                // (the kernel leaves the record's flag in `id` for this status)
+            return std::string("Unhandled CIGAR operation: ") + (code == 3 ? "N" : "P") + ": Alignment " +
+                   name(PAV_ROLE_REF, (int)r.ref_id) + ":" + fmt_i(r.pos) + " (" + name(PAV_ROLE_TIG, (int)r.tig_id) + ")";
+        }
+        if (a.status == LIFT_ERR_NO_MATCH_QRY)
+            return "Program bug: Found no matches in a lift-tree for a record withing a global to-query tree: " + name(PAV_ROLE_REF, q.seq) + ":" +
+                   fmt_i(q.pos) + " (index=" + fmt_i(r.index) + ")";
+        return "Found no matches in a lift-tree for a record within a global to-subject tree: " + name(PAV_ROLE_TIG, q.seq) + ":" +
+               fmt_i(q.pos) + " (index=" + fmt_i(r.index) + ", gap=" + (q.gap ? "True" : "False") + ")";
+    }
+    int lift_batch(const std::vector<LiftQuery> &q, std::vector<Point> &out) const {
+        out.assign(q.size(), Point{});
+        if (q.empty()) return PAV_OK;
+        if (!S->on_device) {
+            for (size_t i = 0; i < q.size(); ++i) {
+                Lifted l; std::string err;
+                const bool fine = q[i].axis == 0 ? lift_to_qry(q[i].seq, q[i].pos, l, err) : lift_to_sub(q[i].seq, q[i].pos, q[i].gap != 0, l, err);
+                LiftAnswer &a = out[i].a;
+                if (!fine) { a.status = LIFT_ERR_OP; out[i].err = err; continue; }
+                a.status = l.ok ? LIFT_OK : LIFT_NONE; a.id = l.id; a.pos = l.pos; a.rev = l.rev; a.rev_none = l.rev_none ? 1 : 0;
+                a.n_idx = l.n_idx; a.idx[0] = l.idx[0]; a.idx[1] = l.idx[1];
+            }
+            return PAV_OK;
+        }
+        const size_t nq = q.size(), bytes_q = sizeof(LiftQuery) * nq, bytes_a = sizeof(LiftAnswer) * nq;
+        if (bytes_q + bytes_a > S->h_qa_cap) {
+            if (S->h_qa) (void)hipHostFree(S->h_qa);
+            S->h_qa = nullptr; S->h_qa_cap = 0;
+            const size_t cap = (bytes_q + bytes_a) * 2 + 4096;
+            PAV_HIP(ctx, hipHostMalloc(&S->h_qa, cap, hipHostMallocDefault));
+            S->h_qa_cap = cap;
+        }
+        PAV_HIP(ctx, S->d_q.reserve(bytes_q));
+        PAV_HIP(ctx, S->d_a.reserve(bytes_a));
+        uint8_t *h = static_cast<uint8_t *>(S->h_qa);
+        memcpy(h, q.data(), bytes_q);
+        hipStream_t st = ctx->stream;
+        PAV_HIP(ctx, hipMemcpyAsync(S->d_q.p, h, bytes_q, hipMemcpyHostToDevice, st));
+        const int rc = lift_points(ctx, S->dev, S->d_q.as<LiftQuery>(), S->d_a.as<LiftAnswer>(), (uint32_t)nq);
+        if (rc != PAV_OK) return rc;
+        PAV_HIP(ctx, hipMemcpyAsync(h + bytes_q, S->d_a.p, bytes_a, hipMemcpyDeviceToHost, st));
+        PAV_HIP(ctx, hipStreamSynchronize(st));
+        const LiftAnswer *a = reinterpret_cast<const LiftAnswer *>(h + bytes_q);
+        for (size_t i = 0; i < nq; ++i) {
+            out[i].a = a[i];
+            if (a[i].status >= LIFT_ERR_OP) out[i].err = lift_error(q[i], a[i]);
+        }
+        return PAV_OK;
+    }
+    // lift_region_to_qry (lift.py:304-331) from the answers for region.pos and region.end; false + err on RuntimeError
+    bool region_from_qry_points(const Point &pa, const Point &pb, Rgn &q, bool &ok, std::string &err) const {
+        ok = false;
+        if (pa.a.status >= LIFT_ERR_OP) { err = pa.err; return false; }
+        if (pb.a.status >= LIFT_ERR_OP) { err = pb.err; return false; }
+        const LiftAnswer &a = pa.a, &b = pb.a;
+        if (a.status != LIFT_OK || b.status != LIFT_OK || a.id != b.id || a.rev != b.rev) return true;
+        q = Rgn(); q.role = PAV_ROLE_TIG; q.chrom = a.id; q.pos = a.pos; q.end = b.pos; q.is_rev = a.rev != 0;
+        q.aln[0][0] = a.idx[0]; q.aln[1][0] = b.idx[0]; q.n_aln[0] = q.n_aln[1] = 1;
+        if (q.pos > q.end) { std::swap(q.pos, q.end); std::swap(q.aln[0], q.aln[1]); }   // Region swaps reversed coordinates
+        ok = true;
+        return true;
+    }
+    // lift_region_to_sub (lift.py:274-302) from the two answers
+    bool region_from_sub_points(const Point &pa, const Point &pb, Rgn &s, bool &ok, std::string &err) const {
+        ok = false;
+        if (pa.a.status >= LIFT_ERR_OP) { err = pa.err; return false; }
+        if (pb.a.status >= LIFT_ERR_OP) { err = pb.err; return false; }
+        const LiftAnswer &a = pa.a, &b = pb.a;
+        if (a.status != LIFT_OK || b.status != LIFT_OK) return true;
+        if (a.id != b.id || (!a.rev_none && !b.rev_none && a.rev != b.rev)) return true;
+        s = Rgn(); s.role = PAV_ROLE_REF; s.chrom = a.id; s.pos = a.pos; s.end = b.pos; s.is_rev = false;
+        for (int i = 0; i < a.n_idx; ++i) s.aln[0][i] = a.idx[i];
+        for (int i = 0; i < b.n_idx; ++i) s.aln[1][i] = b.idx[i];
+        s.n_aln[0] = a.n_idx; s.n_aln[1] = b.n_idx;
+        if (s.pos > s.end) { std::swap(s.pos, s.end); std::swap(s.aln[0], s.aln[1]); std::swap(s.n_aln[0], s.n_aln[1]); }
+        ok = true;
+        return true;
+    }
+
     // lift_region_to_qry (lift.py:304-331): ok=false => None
     bool region_to_qry(const Rgn &r, Rgn &q, bool &ok, std::string &err) const {
         Lifted a, b; ok = false;
@@ -434,7 +529,27 @@ int pav_inv_load_alignments(pav_ctx *ctx, uint32_t n, const pav_inv_aln *aln, co
     uint64_t n_ops = 0;
     int rc = pav_align_index(ctx, n, row_pos.data(), cigar_text, cigar_off, &n_ops, nullptr, nullptr, nullptr, nullptr);
     if (rc != PAV_OK) return rc;
-    S->ops.resize(n_ops + 1); S->sub_begin.resize(n_ops + 1); S->qry_begin.resize(n_ops + 1); S->op_off.resize((size_t)n + 1);
+    const char *e_host = getenv("PAV_LIFT_HOST");
+    const bool host_tables = e_host && e_host[0] == '1';
+    S->on_device = !host_tables;
+    S->op_off.resize((size_t)n + 1);
+    if (S->on_device) {
+        // the tables stay in HBM: the context's index buffers are scratch (the next pav_align_index overwrites them), so they are
+        // copied device to device (109 MB for a haplotype: 0.05 ms); only the per-record operation ranges come to the host
+        hipStream_t st = ctx->stream;
+        PAV_HIP(ctx, hipSetDevice(ctx->device));
+        PAV_HIP(ctx, S->d_ops.reserve(4 * (n_ops + 16)));
+        PAV_HIP(ctx, S->d_begin.reserve(8 * (n_ops + 16)));
+        if (n_ops) {
+            PAV_HIP(ctx, hipMemcpyAsync(S->d_ops.p, ctx->ix_ops.p, 4 * n_ops, hipMemcpyDeviceToDevice, st));
+            PAV_HIP(ctx, hipMemcpyAsync(S->d_begin.p, ctx->ix_begin.p, 8 * n_ops, hipMemcpyDeviceToDevice, st));
+        }
+        if (n) PAV_HIP(ctx, hipMemcpyAsync(S->op_off.data(), ctx->ix_op_off.p, sizeof(uint64_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, st));
+        PAV_HIP(ctx, hipStreamSynchronize(st));
+        if (n == 0) S->op_off.assign(1, 0);
+        S->ops.resize(0); S->sub_begin.resize(0); S->qry_begin.resize(0);
+    } else {
+    S->ops.resize(n_ops + 1); S->sub_begin.resize(n_ops + 1); S->qry_begin.resize(n_ops + 1);
     rc = pav_align_index(ctx, n, row_pos.data(), cigar_text, cigar_off, &n_ops, S->ops.data(), S->op_off.data(), S->sub_begin.data(), S->qry_begin.data());
     if (rc != PAV_OK) return rc;
     if (n == 0) S->op_off.assign(1, 0);
@@ -460,6 +575,7 @@ int pav_inv_load_alignments(pav_ctx *ctx, uint32_t n, const pav_inv_aln *aln, co
             B.first.push_back((uint32_t)(b - a));
         }
         B.off[n] = B.first.size();
+    }
     }
     S->by_ref.assign(ctx->seq[PAV_ROLE_REF].n, {}); S->by_tig.assign(ctx->seq[PAV_ROLE_TIG].n, {});
     S->by_ref_maxlen.assign(ctx->seq[PAV_ROLE_REF].n, 0); S->by_tig_maxlen.assign(ctx->seq[PAV_ROLE_TIG].n, 0);
@@ -487,11 +603,72 @@ int pav_inv_load_alignments(pav_ctx *ctx, uint32_t n, const pav_inv_aln *aln, co
         }
     }
     S->row_bad.assign(n, 0);
-    for (uint32_t r = 0; r < n; ++r)
-        for (uint64_t q = S->op_off[r]; q < S->op_off[r + 1]; ++q) {
-            const uint32_t code = S->ops[q] & 15u;
-            if (code == 3 || code == 6) { S->row_bad[r] = (uint8_t)code; break; }
+    if (!S->on_device) {
+        for (uint32_t r = 0; r < n; ++r)
+            for (uint64_t q = S->op_off[r]; q < S->op_off[r + 1]; ++q) {
+                const uint32_t code = S->ops[q] & 15u;
+                if (code == 3 || code == 6) { S->row_bad[r] = (uint8_t)code; break; }
+            }
+    } else {
+        // the small tables of the device index in one block: records | per axis: sequence offsets, records by begin, begin, end,
+        // running maximum of end | contig records in table order
+        const uint32_t n_seq[2] = {ctx->seq[PAV_ROLE_REF].n, ctx->seq[PAV_ROLE_TIG].n};
+        std::vector<LiftRowDev> rows(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            const LiftRow &r = S->rows[i];
+            rows[i] = LiftRowDev{r.ref_id, r.tig_id, r.pos, r.end, r.qry_pos, r.qry_end, r.index, S->op_off[i], S->op_off[i + 1],
+                                 ctx->seq[PAV_ROLE_TIG].len[r.tig_id], r.rev, 0u};
         }
+        auto pad = [](size_t x) { return (x + 63) / 64 * 64; };
+        size_t at = 0, o_rows = at; at += pad(sizeof(LiftRowDev) * n);
+        size_t o_off[2], o_rw[2], o_b[2], o_e[2], o_m[2];
+        size_t cnt[2] = {0, 0};
+        for (int axis = 0; axis < 2; ++axis) { const auto &by = axis == 0 ? S->by_ref : S->by_tig; for (const auto &v : by) cnt[axis] += v.size(); }
+        for (int axis = 0; axis < 2; ++axis) {
+            o_off[axis] = at; at += pad(4 * ((size_t)n_seq[axis] + 1));
+            o_rw[axis] = at; at += pad(4 * cnt[axis]);
+            o_b[axis] = at; at += pad(8 * cnt[axis]); o_e[axis] = at; at += pad(8 * cnt[axis]); o_m[axis] = at; at += pad(8 * cnt[axis]);
+        }
+        const size_t o_tab = at; at += pad(4 * cnt[1]);
+        std::vector<uint8_t> blk(at + 64, 0);
+        if (n) memcpy(blk.data() + o_rows, rows.data(), sizeof(LiftRowDev) * n);
+        for (int axis = 0; axis < 2; ++axis) {
+            const auto &by = axis == 0 ? S->by_ref : S->by_tig;
+            const auto &spans = axis == 0 ? S->span_ref : S->span_tig;
+            uint32_t *off = reinterpret_cast<uint32_t *>(blk.data() + o_off[axis]), *rw = reinterpret_cast<uint32_t *>(blk.data() + o_rw[axis]);
+            int64_t *b = reinterpret_cast<int64_t *>(blk.data() + o_b[axis]), *e = reinterpret_cast<int64_t *>(blk.data() + o_e[axis]),
+                    *m = reinterpret_cast<int64_t *>(blk.data() + o_m[axis]);
+            uint32_t run = 0;
+            for (size_t q = 0; q < by.size(); ++q) {
+                off[q] = run;
+                for (size_t t = 0; t < by[q].size(); ++t) { rw[run + t] = by[q][t]; b[run + t] = spans[q].begin[t]; e[run + t] = spans[q].end[t]; m[run + t] = spans[q].max_end[t]; }
+                if (axis == 1) {
+                    uint32_t *tab = reinterpret_cast<uint32_t *>(blk.data() + o_tab) + run;
+                    std::copy(by[q].begin(), by[q].end(), tab);
+                    std::sort(tab, tab + by[q].size());                   // table order
+                }
+                run += (uint32_t)by[q].size();
+            }
+            off[by.size()] = run;
+        }
+        PAV_HIP(ctx, hipSetDevice(ctx->device));
+        PAV_HIP(ctx, S->d_small.reserve(blk.size()));
+        PAV_HIP(ctx, hipMemcpyAsync(S->d_small.p, blk.data(), blk.size(), hipMemcpyHostToDevice, ctx->stream));
+        uint8_t *d = S->d_small.as<uint8_t>();
+        LiftTables &T = S->dev;
+        T.ops = S->d_ops.as<uint32_t>(); T.sub = S->d_begin.as<uint32_t>(); T.qry = S->d_begin.as<uint32_t>() + n_ops;
+        T.rows = reinterpret_cast<LiftRowDev *>(d + o_rows); T.n_rows = n;
+        for (int axis = 0; axis < 2; ++axis) {
+            T.seq_off[axis] = reinterpret_cast<const uint32_t *>(d + o_off[axis]); T.seq_rows[axis] = reinterpret_cast<const uint32_t *>(d + o_rw[axis]);
+            T.begin[axis] = reinterpret_cast<const int64_t *>(d + o_b[axis]); T.end[axis] = reinterpret_cast<const int64_t *>(d + o_e[axis]);
+            T.max_end[axis] = reinterpret_cast<const int64_t *>(d + o_m[axis]);
+            T.n_seq[axis] = n_seq[axis];
+        }
+        T.tig_table = reinterpret_cast<const uint32_t *>(d + o_tab);
+        rc = lift_row_flags(ctx, T);
+        if (rc != PAV_OK) return rc;
+        PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));                     // `blk` is a local buffer
+    }
     if (!S->pool) {
         // PAV_HOST_THREADS = n: n - 1 helper threads next to the caller's.  Default none: on the bench box (a CPU quota shared
         // with the runtime's own threads) three helpers made a one-lane pass slower, 3.2 -> 3.5 ms - their spinning between
@@ -576,13 +753,27 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
         // top of the while-loop, inv.py:223-260.  Lifts first (every live region, no side effects) ...
         struct Pre { uint8_t kind; uint32_t job; Rgn tig; std::string err; };   // kind 0: too large, 1: lift raised, 2: not liftable, 3: lifted
         std::vector<Pre> pre(live.size());
-        pool.run(live.size(), CHUNK, [&](size_t q) {
-            const Scan &sc = scans[live[q]];
-            Pre &x = pre[q];
-            if (0 < max_region_size && max_region_size < sc.region_ref.len()) { x.kind = 0; return; }
-            bool ok = false;
-            x.kind = !D.region_to_qry(sc.region_ref, x.tig, ok, x.err) ? 1 : ok ? 3 : 2;
-        });
+        {   // both ends of every live region in one batch of point lifts (lift_dev.hip; PAV_LIFT_HOST=1: the host tables)
+            std::vector<LiftQuery> lq;
+            std::vector<uint32_t> first(live.size(), ~0u);
+            lq.reserve(2 * live.size());
+            for (size_t q = 0; q < live.size(); ++q) {
+                const Scan &sc = scans[live[q]];
+                if (0 < max_region_size && max_region_size < sc.region_ref.len()) { pre[q].kind = 0; continue; }
+                first[q] = (uint32_t)lq.size();
+                lq.push_back(LiftQuery{0, sc.region_ref.chrom, 0, 0, sc.region_ref.pos});
+                lq.push_back(LiftQuery{0, sc.region_ref.chrom, 0, 0, sc.region_ref.end});
+            }
+            std::vector<Driver::Point> lp;
+            const int rcl = D.lift_batch(lq, lp);
+            if (rcl != PAV_OK) return rcl;
+            pool.run(live.size(), CHUNK, [&](size_t q) {
+                if (first[q] == ~0u) return;
+                Pre &x = pre[q];
+                bool ok = false;
+                x.kind = !D.region_from_qry_points(lp[first[q]], lp[first[q] + 1], x.tig, ok, x.err) ? 1 : ok ? 3 : 2;
+            });
+        }
         t_lift += now() - t_p0;
         // ... then which of them this round takes (a budget of bases per batch, in region order) ...
         std::vector<uint32_t> taken;                                              // positions in `live`
@@ -642,8 +833,10 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
             return 0;
         };
         // after the density call, per region (inv.py:268-351) ...
-        struct Dec { uint8_t what = 0, k1 = 0; CallFetch cf{}; };                   // what 0: finished, 1: expanded, 2: call, 3: internal error
-        std::vector<Dec> dec(jobs.size());
+        struct Dec { uint8_t what = 0, k1 = 0; CallFetch cf{}; };                   // what 0: finished, 1: expanded, 2: call, 3: internal error,
+        std::vector<Dec> dec(jobs.size());                                           //      4: flanked, its breakpoints wait for their lifts
+        struct Cand { Rgn t_outer, t_inner; };
+        std::vector<Cand> cand(jobs.size());
         pool.run(jobs.size(), CHUNK, [&](size_t jj) {
             const uint32_t j = (uint32_t)jj;
             const uint32_t i = owners[j];
@@ -681,11 +874,44 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
                     log(i, "Longest run of strictly inverted k-mers (" + fmt_i(t_outer.pos) + ") does not meet the minimum threshold (100)");
                     finish(i, PAV_INV_NONE); return;
                 }
+                cand[j].t_outer = t_outer; cand[j].t_inner = t_inner;
+                dec[j].what = 4;                                                    // lifted below, all flanked regions of the round at once
+                return;
+            }
+            // Expand, inv.py:309-342
+            const int64_t last_len = sc.region_ref.len();
+            const int64_t expand_bp = (int64_t)(int32_t)((double)last_len * 1.5);        // np.int32(len * EXPAND_FACTOR)
+            double balance = 0.5;
+            if (rl.size() > 2) { if (rl.front().state == 0) balance = 0.25; else if (rl.back().state == 0) balance = 0.75; }
+            D.expand(sc.region_ref, expand_bp, balance);
+            if (sc.region_ref.len() == last_len) { log(i, "Reached reference limits, cannot expand"); finish(i, PAV_INV_NONE); return; }
+            dec[j].what = 1;
+        });
+        {   // the breakpoint regions of the flanked jobs -> reference (inv.py:393-406): outer ends without, inner ends with the gap rule
+            std::vector<LiftQuery> lq;
+            std::vector<uint32_t> pend;
+            for (uint32_t j = 0; j < jobs.size(); ++j) {
+                if (dec[j].what != 4) continue;
+                pend.push_back(j);
+                const Cand &c = cand[j];
+                lq.push_back(LiftQuery{1, c.t_outer.chrom, 0, 0, c.t_outer.pos}); lq.push_back(LiftQuery{1, c.t_outer.chrom, 0, 0, c.t_outer.end});
+                lq.push_back(LiftQuery{1, c.t_inner.chrom, 1, 0, c.t_inner.pos}); lq.push_back(LiftQuery{1, c.t_inner.chrom, 1, 0, c.t_inner.end});
+            }
+            std::vector<Driver::Point> lp;
+            const int rcl = D.lift_batch(lq, lp);
+            if (rcl != PAV_OK) return rcl;
+            pool.run(pend.size(), CHUNK, [&](size_t pp_) {
+                const uint32_t j = pend[pp_];
+                const uint32_t i = owners[j];
+                Scan &sc = scans[i];
+                const pav_den_result &r = res[j];
+                const Rgn &t_outer = cand[j].t_outer, &t_inner = cand[j].t_inner;
+                dec[j].what = 0;
                 Rgn r_outer, r_inner; bool ok = false; std::string err;
-                if (!D.region_to_sub(t_outer, false, r_outer, ok, err)) { S->errors[i] = err; finish(i, PAV_INV_ERROR); return; }
+                if (!D.region_from_sub_points(lp[4 * pp_], lp[4 * pp_ + 1], r_outer, ok, err)) { S->errors[i] = err; finish(i, PAV_INV_ERROR); return; }
                 if (!ok) { log(i, "Failed lifting outer INV region to reference: " + D.base1(t_outer)); finish(i, PAV_INV_NONE); return; }
                 bool ok2 = false;
-                if (!D.region_to_sub(t_inner, true, r_inner, ok2, err)) { S->errors[i] = err; finish(i, PAV_INV_ERROR); return; }
+                if (!D.region_from_sub_points(lp[4 * pp_ + 2], lp[4 * pp_ + 3], r_inner, ok2, err)) { S->errors[i] = err; finish(i, PAV_INV_ERROR); return; }
                 if (!ok2) r_inner = r_outer;
                 pav_inv_result &out = S->results[i];
                 set_rgn(out.tig_outer, t_outer); set_rgn(out.tig_inner, t_inner); set_rgn(out.ref_outer, r_outer); set_rgn(out.ref_inner, r_inner);
@@ -718,17 +944,8 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
                 out.svlen = (uint64_t)r_outer.len();
                 log(i, "Found inversion: " + D.name(PAV_ROLE_REF, r_outer.chrom) + "-" + fmt_i(r_outer.pos + 1) + "-INV-" + fmt_i(r_outer.len()));
                 finish(i, PAV_INV_CALL);
-                return;
-            }
-            // Expand, inv.py:309-342
-            const int64_t last_len = sc.region_ref.len();
-            const int64_t expand_bp = (int64_t)(int32_t)((double)last_len * 1.5);        // np.int32(len * EXPAND_FACTOR)
-            double balance = 0.5;
-            if (rl.size() > 2) { if (rl.front().state == 0) balance = 0.25; else if (rl.back().state == 0) balance = 0.75; }
-            D.expand(sc.region_ref, expand_bp, balance);
-            if (sc.region_ref.len() == last_len) { log(i, "Reached reference limits, cannot expand"); finish(i, PAV_INV_NONE); return; }
-            dec[j].what = 1;
-        });
+            });
+        }
         // ... and, in region order, the calls of the round and the regions that go on
         std::vector<uint32_t> next;
         std::vector<CallFetch> round_calls; std::vector<uint32_t> round_owner; std::vector<uint8_t> round_k1;   // round_k1: the call has FWDREV k-mers

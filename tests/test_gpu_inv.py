@@ -397,6 +397,33 @@ def test_batched_scan_vs_reference(built, gpu_ctx, case, native):
                 check_call(d, rec, call)
 
 
+@pytest.mark.parametrize('case', ['inv_hap', 'inv_nolift', 'inv_rev'])
+def test_device_lifts_equal_the_host_tables(built, gpu_ctx, case, monkeypatch, capfd):
+    """The native driver lifts the ends of every region and the breakpoints of every flanked region in batches on the device
+    (csrc/lift_dev.hip: the operation tables never leave HBM); PAV_LIFT_HOST=1 keeps the host lookup tables of round 3.  Same
+    logs, same calls, same regions - and both equal the reference's (test_batched_scan_vs_reference runs the default)."""
+    d, lift, scans = load_case(gpu_ctx, case)
+    flags = [pavseq.Region(r['flag']['chrom'], r['flag']['pos'], r['flag']['end']) for r in scans if not r['kwargs']]
+    got = {}
+    for name, env in (('device', None), ('host', '1')):
+        if env is None:
+            monkeypatch.delenv('PAV_LIFT_HOST', raising=False)
+        else:
+            monkeypatch.setenv('PAV_LIFT_HOST', env)
+        lift._native_loaded = None                                   # the index is built again, on the other side
+        logs = [io.StringIO() for _ in flags]
+        out = pavinv.scan_for_inv_batch(flags, os.path.join(d, 'ref.fa'), os.path.join(d, 'tig.fa'), lift, KmerUtil(31), logs=logs,
+                                        ctx=gpu_ctx, native=True)
+        got[name] = ([lg.getvalue() for lg in logs],
+                     [None if c is None else (str(c) if isinstance(c, RuntimeError) else
+                                              (c.id, [region_dict(getattr(c, n)) for n in ('region_ref_outer', 'region_ref_inner',
+                                                                                            'region_tig_outer', 'region_tig_inner')]))
+                      for c in out])
+    assert got['device'] == got['host']
+    want = [r['log'] for r in scans if not r['kwargs']]
+    assert [t.splitlines() for t in got['device'][0]] == want
+
+
 @pytest.mark.parametrize('native', [True, False])
 def test_batch_log_sink_equals_the_sequential_log(built, gpu_ctx, native):
     """``log=``: one file-like object for the whole batch, as rule call_inv_batch hands its log file to every scan_for_inv

@@ -11,6 +11,7 @@ def main():
     ap.add_argument('--scale', type=float, default=1.0)
     ap.add_argument('--no-build', action='store_true', help='everything is built already (under rocprofv3: no compiler from this process)')
     ap.add_argument('--plain', action='store_true', help='timed steps only, no cProfile pass')
+    ap.add_argument('--kernels', action='store_true', help='after the timed steps: the same steps with HIP events around every kernel, averages as JSON')
     args = ap.parse_args()
     if not args.no_build:
         import __graft_entry__ as g
@@ -62,6 +63,17 @@ def main():
         step()
     ctx.sync()
     print('ms per step (one lane, no profiler): %.3f' % ((time.perf_counter() - t0) / args.steps * 1e3))
+    if args.kernels:
+        import json
+        ctx.prof_reset()
+        ctx.prof_enable(True)
+        for _ in range(args.steps):
+            step()
+        ctx.sync()
+        prof = ctx.prof_read()
+        ctx.prof_enable(False)
+        per = {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
+        print('KERNELS ' + json.dumps({'lib': _lib.LIB_PATH, 'sum_ms_per_step': round(sum(per.values()), 4), 'ms_per_step': per}))
     if args.plain:
         ctx.close()
         return
