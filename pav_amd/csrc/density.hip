@@ -319,7 +319,10 @@ __global__ __launch_bounds__(256) void k_tig_state(const JobDev *__restrict__ jo
 // and the exact maximum and its k-mer come from the HBM-table kernels on that failure path.
 constexpr int LDS_SLOTS = PAV_LDS_SLOTS;
 constexpr int LDS_THREADS = PAV_LDS_THREADS;
-constexpr int KU = 2048 / LDS_THREADS;                // list entries a lane of k_kmer_lds has in flight: a step covers 2048 entries, about a partition
+#ifndef PAV_LDS_STEP
+#define PAV_LDS_STEP 2048
+#endif
+constexpr int KU = PAV_LDS_STEP / LDS_THREADS;        // list entries a lane of k_kmer_lds has in flight: a step covers 2048 entries, about a partition
 constexpr uint32_t LDS_FILL = LDS_SLOTS * 7 / 16;   // k-mers per partition aimed at (load factor 0.44)
 constexpr uint32_t LDS_MAX_PARTS = 1024;             // histogram size of the bucket kernels (regions up to 1.8 Mbp; MAX_REGION_SIZE is 1.2 Mbp)
 constexpr uint32_t LDS_MAX_LIMIT = 250;              // byte counts: the limit must stay below the wrap
@@ -502,7 +505,8 @@ __global__ __launch_bounds__(LDS_THREADS) void k_kmer_lds(const PartItem *__rest
         ok_r[u] = e < n_ref; pos_r[u] = n_ref ? list_r[ok_r[u] ? e : n_ref - 1] : 0u;
         ok_t[u] = e < n_tig; pos_t[u] = n_tig ? list_t[ok_t[u] ? e : n_tig - 1] : 0u;
     }
-#ifdef PAV_KMER_LATE_TIG                     // tuning build: the contig windows are fetched behind the inserts (16 registers fewer)
+#ifndef PAV_KMER_EARLY_TIG                   // the contig windows are fetched behind the inserts (16 registers fewer; 0.197 -> 0.190 ms per pass);
+                                            // PAV_KMER_EARLY_TIG (tuning build): together with the reference windows, round 3's order
 #pragma unroll
     for (int u = 0; u < KU; ++u) kw_r[u] = kmer_words(R.two, jd.ref_abs + pos_r[u]);
 #else
@@ -547,7 +551,7 @@ __global__ __launch_bounds__(LDS_THREADS) void k_kmer_lds(const PartItem *__rest
 #pragma unroll
         for (int u = 0; u < KU; ++u) if (ok[u]) insert(kmer_from_words(kw[u], jd.ref_abs + pos[u], k));
     }
-#ifdef PAV_KMER_LATE_TIG
+#ifndef PAV_KMER_EARLY_TIG
 #pragma unroll
     for (int u = 0; u < KU; ++u) kw_t[u] = kmer_words(T.two, jd.tig_abs + pos_t[u]);
 #endif
@@ -816,12 +820,17 @@ struct CompactArgs {
     int scan_only;                                            // tables of regions with FWD k-mers only are not wanted (fwd_only below)
 };
 
-__global__ __launch_bounds__(256) void k_compact_scatter(CompactArgs A) {
+#ifndef PAV_COMPACT_WAVES
+#define PAV_COMPACT_WAVES 4            // waves per SIMD the compiler is asked to fit the kernel into (129 VGPRs without: 3)
+#endif
+__global__ __launch_bounds__(256, PAV_COMPACT_WAVES) void k_compact_scatter(CompactArgs A) {
     __shared__ uint32_t lds[16];
     __shared__ unsigned long long red[4][7];
     // the tile's kept rows are staged in LDS in row order and leave with coalesced stores
     __shared__ unsigned long long s_kmer[DTILE];
-    __shared__ uint32_t s_index[DTILE], s_list[3][DTILE];
+    // the three per-state lists share ONE array (a row belongs to one state: their entries add up to the tile's rows): state s
+    // starts behind the rows of the states in front of it - 34 KiB of LDS per workgroup instead of 50, four workgroups per CU
+    __shared__ uint32_t s_index[DTILE], s_list1[DTILE];
     __shared__ int8_t s_mer[DTILE];
     const uint32_t j = A.tile_job[blockIdx.x];
     const JobDev jd = A.jobs[j];
@@ -843,6 +852,7 @@ __global__ __launch_bounds__(256) void k_compact_scatter(CompactArgs A) {
     for (int q = 0; q < 4; ++q)
         tile0[q] = A.tile_pre[(uint64_t)blockIdx.x * 4 + q] - A.tile_pre[(uint64_t)jd.first_tile * 4 + q];
     unsigned long long s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0};
+    const uint32_t lbase[3] = {0u, tot[1], tot[1] + tot[2]};
     // the lane's eight k-mers start at consecutive bases: one 64-base window of the 2-bit plane (a 4-byte-aligned 16-byte load +
     // one dword), fetched before the loop - a window per kept k-mer inside the branch cost eight dependent rounds of loads, and
     // the non-ACGT plane is not needed (a kept k-mer is a valid one)
@@ -867,7 +877,7 @@ __global__ __launch_bounds__(256) void k_compact_scatter(CompactArgs A) {
         s_index[lr] = (uint32_t)i;
         s_mer[lr] = (int8_t)st[t];
         s_kmer[lr] = rev_groups(x, A.k);
-        s_list[st[t]][c[1 + st[t]]++] = (uint32_t)row;                 // INDEX_DEN of the state's data points, ascending
+        s_list1[lbase[st[t]] + c[1 + st[t]]++] = (uint32_t)row;        // INDEX_DEN of the state's data points, ascending
         s1[st[t]] += row; s2[st[t]] += row * row;
     }
     __syncthreads();
@@ -886,7 +896,7 @@ __global__ __launch_bounds__(256) void k_compact_scatter(CompactArgs A) {
     }
 #pragma unroll
     for (int s = 0; s < 3; ++s)
-        for (uint32_t r = threadIdx.x; r < tot[1 + s]; r += 256) A.list[s][jd.tpos_off + tile0[1 + s] + r] = s_list[s][r];
+        for (uint32_t r = threadIdx.x; r < tot[1 + s]; r += 256) A.list[s][jd.tpos_off + tile0[1 + s] + r] = s_list1[lbase[s] + r];
     if (A.tile_heads) {
         // Device-planned batches: the tile's run heads of STATE_MER in row order, at fixed slots (no atomics, nothing to sort:
         // tiles are ordered by (job, row)).  Row r of the tile (staged order) is a head when the state changes in front of it;

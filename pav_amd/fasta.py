@@ -68,6 +68,13 @@ def open_fasta(path, cache=True):
     return _CACHE[key]
 
 
+def forget(path):
+    """Drop a memoised file (a cohort's contig files are read once each: 3 GB of host memory per haplotype otherwise)."""
+    path = os.path.abspath(str(path))
+    for key in [k for k in _CACHE if k[0] == path]:
+        del _CACHE[key]
+
+
 _FAI_CACHE = {}
 
 

@@ -472,9 +472,16 @@ def call_haplotype(bed, bed_trim, tig_fa_name, ref_fa_name, asm_name, hap, out_d
     ctx, own = _with_ctx(ctx, device_id)
     table = trim_table = None
     try:
+        # the contig file is parsed on a second thread while the tables are parsed and - the first time - the reference is parsed,
+        # uploaded and packed (the native readers and the upload release the GIL)
+        import threading
+        from . import fasta as pavfasta
+        th = threading.Thread(target=pavfasta.open_fasta, args=(tig_fa_name,))
+        th.start()
         table, trim_table = _lib.BedTable(bed, with_cigar=True), _lib.BedTable(bed_trim, with_cigar=False)
         cols = table.fetch()
         cigarcall.load_reference(ctx, ref_fa_name)
+        th.join()
         cigarcall.load_sequences(ctx, ref_fa_name, tig_fa_name)                        # every contig record: the scan may lift anywhere
         ctx._inv_loaded = (str(ref_fa_name), str(tig_fa_name))
         lap('sequences')
@@ -567,6 +574,8 @@ def call_haplotype(bed, bed_trim, tig_fa_name, ref_fa_name, asm_name, hap, out_d
         for t in (table, trim_table):
             if t is not None:
                 t.close()
+        from . import fasta as pavfasta2
+        pavfasta2.forget(tig_fa_name)                              # (the reference stays memoised; a haplotype's contigs are read once)
         if own:
             ctx.close()
 

@@ -981,7 +981,8 @@ def test_concurrent_haplotype_lanes_equal_sequential_runs(built, gpu_ctx):
 
 def test_files_to_files_tool(built, tmp_path):
     """tools/bench_e2e.py at a small scale: FASTA + alignment tables in, every output file of the rule chain out (merged
-    SNV / INS-DEL tables, five flag tables, INV BED, density tables, log), through the native readers and writers."""
+    SNV / INS-DEL tables, five flag tables, INV BED, density tables, log), through the native readers and writers
+    (pav_amd.rules.call_haplotype: the reference's file names under <out>/out)."""
     import gzip
     import subprocess
     import sys
@@ -992,15 +993,19 @@ def test_files_to_files_tool(built, tmp_path):
     assert p.returncode == 0, p.stderr[-2000:]
     line = json.loads(p.stdout.strip().splitlines()[-1])
     assert line['snv_rows'] > 1000 and line['insdel_rows'] > 100 and line['aligned_bp'] > 10_000_000
-    assert line['scanned_regions'] == line['flagged_regions'] > 0
-    for name in ('snv_snv_h1.bed.gz', 'svindel_insdel_h1.bed.gz', 'flag_flagged_regions_h1.bed.gz', 'inv_call_h1.log'):
-        assert (out / name).exists(), name
-    with gzip.open(out / 'snv_snv_h1.bed.gz', 'rt') as fh:
+    assert 0 < line['scanned_regions'] <= line['flagged_regions']
+    res = out / 'out'
+    names = {'snv': res / 'temp/sample/cigar/merged/snv_snv_h1.bed.gz', 'insdel': res / 'temp/sample/cigar/merged/svindel_insdel_h1.bed.gz',
+             'flagged': res / 'results/sample/inv_caller/flagged_regions_h1.bed.gz', 'inv': res / 'temp/sample/inv_caller/sv_inv_h1.bed.gz',
+             'log0': res / 'log/sample/inv_caller/log/h1/inv_call_0.log'}
+    for name, path in names.items():
+        assert path.exists(), name
+    with gzip.open(names['snv'], 'rt') as fh:
         snv = pd.read_csv(fh, sep='\t')
     assert snv.shape[0] == line['snv_rows'] and list(snv.columns[:4]) == ['#CHROM', 'POS', 'END', 'ID']
     key = list(zip(snv['#CHROM'], snv['POS']))
     assert key == sorted(key)                                                    # merged order of rule call_cigar_merge
     if line['inv_calls']:
-        inv = pd.read_csv(out / 'sv_inv_h1.bed.gz', sep='\t')
+        inv = pd.read_csv(names['inv'], sep='\t')
         assert inv.shape[0] == line['inv_calls']
-        assert len(os.listdir(out / 'density_table')) == line['inv_calls']
+        assert len(os.listdir(res / 'results/sample/inv_caller/density_table')) == line['inv_calls']

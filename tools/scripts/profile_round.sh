@@ -4,7 +4,7 @@
 # profiles/<round>_* through tools/prof_summary.py.  Everything is built first, outside the profiler: bench.py runs with
 # --no-build, so no compiler is ever started from a process the profiler's preload has attached to.
 set -x
-ROUND=${1:-r03}
+ROUND=${1:-r04}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$ROUND
 mkdir -p $O
@@ -42,4 +42,7 @@ cd $R
 python3 tools/prof_summary.py timeline $(find $O/tl -name "*.db" | head -1) $P/${ROUND}_single_lane_timeline_8ms.txt 8 > /dev/null
 find $O -name "*.db" -delete
 bash tools/scripts/profile_sq.sh $ROUND > $O/profile_sq.log 2>&1
+# files to files on the bench's own workload (pair_frac 0.009, inv_sig_filter single_cluster), deflate level 1 and the library's 6
+python3 tools/bench_e2e.py --inv-sig-filter single_cluster --gzip-level 1 > $P/${ROUND}_e2e_files_to_files.json 2> $O/e2e1.err
+python3 tools/bench_e2e.py --inv-sig-filter single_cluster --gzip-level 6 > $P/${ROUND}_e2e_files_to_files_gzip6.json 2> $O/e2e6.err
 ls -la $P; du -sh $O
