@@ -1072,7 +1072,7 @@ def main():
                 'value': round(aligned_total / t_with_lift / 1e9, 2), 'unit': 'Gbp/s', 'ms_per_step': round(t_with_lift / args.steps * 1e3, 4),
                 'lift_index_ms_per_step': round((t_with_lift - t_max) / args.steps * 1e3, 4),
                 'note': 'the same K steps with the lift-over index of the trimmed alignment table rebuilt inside every step '
-                        '(pav_inv_load_alignments: tokenise + scan on the device, lookup tables on the host) - what a cohort run pays '
+                        '(pav_inv_load_alignments: tokenise + scan on the device, the operation tables stay there - lift_dev.hip) - what a cohort run pays '
                         'per haplotype; `value` keeps the index resident like the other inputs'},
             'roofline': roofline, 'cpu_baseline': cpu, 'cigar_only': cigar_only, 'verify_mode': verify_mode, 'inv_scan': inv_report,
             'end_to_end': e2e,

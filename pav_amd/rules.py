@@ -264,13 +264,15 @@ def call_inv_batch(bed_flag, bed_aln, tig_fa, fai, ref_fa, hap, batch, bed_out=N
     return df_bed
 
 
-def call_inv_batch_merge(bed_list, bed_out=None):
-    """Body of rule call_inv_batch_merge (call_inv.snakefile:101-112)."""
+def call_inv_batch_merge(bed_list, bed_out=None, gzip_level=None):
+    """Body of rule call_inv_batch_merge (call_inv.snakefile:101-112).  ``gzip_level``: deflate level of the output (default:
+    pandas' 9, as the reference writes it; the text inside is the same at every level)."""
     df = pd.concat([pd.read_csv(f, sep='\t') for f in bed_list], axis=0)
     df.drop_duplicates('ID', inplace=True)
     df = df.sort_values(['#CHROM', 'POS', 'END', 'ID'])
     if bed_out is not None:
-        df.to_csv(bed_out, sep='\t', index=False, compression='gzip')
+        df.to_csv(bed_out, sep='\t', index=False,
+                  compression='gzip' if gzip_level is None else {'method': 'gzip', 'compresslevel': int(gzip_level)})
     return df
 
 
@@ -556,7 +558,9 @@ def call_haplotype(bed, bed_trim, tig_fa_name, ref_fa_name, asm_name, hap, out_d
                 df_bed = pd.concat(call_list, axis=1).T.sort_values(['#CHROM', 'POS', 'END', 'ID'])   # :297
             else:
                 df_bed = pd.DataFrame([], columns=[c for c in INV_BED_COLUMNS if c != 'FILTER'])       # :300-308 (sic)
-            df_bed.to_csv(P['inv_batch'][b], sep='\t', index=False, compression='gzip')
+            # (the per-batch tables are temporary files, read back by the merge below: the SEQ column - whole inversions - is most of
+            #  their bytes and deflate level 9, pandas' default, most of their time; level 1 here)
+            df_bed.to_csv(P['inv_batch'][b], sep='\t', index=False, compression={'method': 'gzip', 'compresslevel': 1})
             n_calls += len(call_list)
         lap('INV batch tables + logs')
         if native_tables:
@@ -564,7 +568,7 @@ def call_haplotype(bed, bed_trim, tig_fa_name, ref_fa_name, asm_name, hap, out_d
             # the same file name, the same table
             ctx.inv_write_tables([r for r, _ in native_tables], [p for _, p in native_tables], threads=threads, gzip_level=gzip_level)
         lap('density tables')
-        df_inv = call_inv_batch_merge(P['inv_batch'], P['inv'])
+        df_inv = call_inv_batch_merge(P['inv_batch'], P['inv'], gzip_level=gzip_level or 6)
         lap('INV merge')
         return {'asm_name': asm_name, 'hap': hap, 'aligned_bp': int(counts.aligned_bases), 'snv_rows': int(n_snv),
                 'insdel_rows': int(n_insdel), 'flagged_regions': int(df_flag.shape[0]), 'scanned_regions': int(sel.shape[0]),

@@ -28,6 +28,9 @@ sed -i "1i # Command: rocprofv3 --kernel-trace --stats -- python3 bench.py --no-
 sed -i "1i # Command: rocprofv3 --kernel-trace --stats -- python3 bench.py --workload cigar --no-cpu-baseline --no-build   (tools/scripts/profile_round.sh)" $P/${ROUND}_cigar_only_kernel_stats.txt
 cp $O/full_bench_under_rocprof.json $P/${ROUND}_full_path_bench_under_rocprof.json
 cp $O/cigar_bench_under_rocprof.json $P/${ROUND}_cigar_only_bench_under_rocprof.json
+# the SQ / LDS counter passes come first: bench.py's LDS roofline (roofline.timed_region.*.lds) reads this round's counters
+bash tools/scripts/profile_sq.sh $ROUND > $O/profile_sq.log 2>&1
+cp $P/${ROUND}_lds_counters.json $R/profiles/${ROUND}_lds_counters.json
 # plain runs (no profiler): the lines of record.  The PMC summary is copied first so that bench.py finds this round's traffic.
 cp $P/${ROUND}_pmc.json $R/profiles/${ROUND}_pmc.json
 python3 bench.py --no-build > $P/${ROUND}_full_path_bench.json 2> $O/bench_full.err
@@ -41,7 +44,6 @@ timeout -k 5 300 rocprofv3 --kernel-trace --memory-copy-trace -d $O/tl -o tl -- 
 cd $R
 python3 tools/prof_summary.py timeline $(find $O/tl -name "*.db" | head -1) $P/${ROUND}_single_lane_timeline_8ms.txt 8 > /dev/null
 find $O -name "*.db" -delete
-bash tools/scripts/profile_sq.sh $ROUND > $O/profile_sq.log 2>&1
 # files to files on the bench's own workload (pair_frac 0.009, inv_sig_filter single_cluster), deflate level 1 and the library's 6
 python3 tools/bench_e2e.py --inv-sig-filter single_cluster --gzip-level 1 > $P/${ROUND}_e2e_files_to_files.json 2> $O/e2e1.err
 python3 tools/bench_e2e.py --inv-sig-filter single_cluster --gzip-level 6 > $P/${ROUND}_e2e_files_to_files_gzip6.json 2> $O/e2e6.err
