@@ -30,7 +30,7 @@ def _load(ctx, df):
         rows['qry_id'] = _codes(df['QRY_ID'])
         for f, c in _TRIM_COLS:
             rows[f] = df[c].to_numpy(dtype=np.int64)
-        rows['rev'] = [1 if bool(v) else 0 for v in df['REV']]
+        rows['rev'] = df['REV'].to_numpy().astype(bool).astype(np.int32)
     cig = [str(c).encode() for c in df['CIGAR']]
     off = np.zeros(n + 1, dtype=np.uint64)
     if n:
@@ -160,6 +160,29 @@ def check_record(row, cnt, df_tig_fai):
         raise RuntimeError('QRY_END > tig_len ({} > {}) {}'.format(row['QRY_END'], tig_len, where))
 
 
+def check_records(df, counts, df_tig_fai):
+    """``check_record`` for every row of ``df`` (``counts``: the rows' pav_trim_count records, same order), as the loop of
+    trim.py:352-353 would raise: the first row that fails, with the first of its checks that fails.  The tests run as array
+    expressions; the one offending row goes through :func:`check_record` for its message."""
+    n = df.shape[0]
+    if n == 0:
+        return
+    col = {c: df[c].to_numpy(dtype=np.int64) for c in ('QRY_LEN', 'QRY_POS', 'QRY_END', 'POS', 'END')}
+    tig_len = df['QRY_ID'].map(df_tig_fai)
+    if tig_len.isna().any():
+        i = int(np.flatnonzero(tig_len.isna().to_numpy())[0])
+        bad_first = i
+    else:
+        tl = tig_len.to_numpy(dtype=np.int64)
+        bad = (counts['err_kind'] != 0) | (col['QRY_LEN'] != tl) | (col['QRY_POS'] >= col['QRY_END']) | (col['POS'] >= col['END']) | \
+              (col['POS'] < 0) | (col['QRY_POS'] < 0) | (col['POS'] + counts['ref_bp'] != col['END']) | \
+              (col['QRY_POS'] + counts['tig_bp'] != col['QRY_END']) | (col['QRY_END'] > tl)
+        if not bad.any():
+            return
+        bad_first = int(np.flatnonzero(bad)[0])
+    check_record(df.iloc[bad_first], counts[bad_first], df_tig_fai)       # raises with the reference's message
+
+
 def trim_alignments(df, min_trim_tig_len, tig_fai, match_tig=False, mode='both', ctx=None, device_id=0):
     """Same arguments and result as ``pavlib.align.trim_alignments`` (trim.py:11-354); ``tig_fai`` may be a path or a
     Series of contig lengths."""
@@ -184,14 +207,16 @@ def trim_alignments(df, min_trim_tig_len, tig_fai, match_tig=False, mode='both',
     own = ctx is None
     if own:
         ctx = _lib.Context(device_id)
+    counts = None                     # count_cigar of every record's current CIGAR, from the pass that ran last (pav_trim_count)
     try:
         if do_trim_tig:
             df.sort_values(['QRY_ID', 'QRY_LEN'], ascending=(True, False), inplace=True)     # :64
             df.reset_index(inplace=True, drop=True)
             _load(ctx, df)
             _run_pass(ctx, df, np.arange(df.shape[0], dtype=np.uint32), _lib.TRIM_QUERY, min_trim_tig_len, False)
-            rows, _, cigars = ctx.trim_fetch(with_counts=False)
+            rows, counts, cigars = ctx.trim_fetch(with_counts=not do_trim_ref)
             df = _store(df, rows, cigars)
+            df['_LOADED_ROW'] = np.arange(df.shape[0])
             df = df.loc[df['INDEX'] >= 0].copy()                                              # :253
         if do_trim_ref:
             df = df.loc[
@@ -199,8 +224,9 @@ def trim_alignments(df, min_trim_tig_len, tig_fai, match_tig=False, mode='both',
             ].reset_index(drop=True)                                                          # :267-274
             _load(ctx, df)
             _run_pass(ctx, df, np.arange(df.shape[0], dtype=np.uint32), _lib.TRIM_SUBJECT, min_trim_tig_len, match_tig)
-            rows, _, cigars = ctx.trim_fetch(with_counts=False)
+            rows, counts, cigars = ctx.trim_fetch(with_counts=True)
             df = _store(df, rows, cigars)
+            df['_LOADED_ROW'] = np.arange(df.shape[0])
             df = df.loc[df['INDEX'] >= 0].copy()                                              # :333
 
         # Post trim formatting (:342-354)
@@ -210,11 +236,11 @@ def trim_alignments(df, min_trim_tig_len, tig_fai, match_tig=False, mode='both',
         df = df.sort_values(['#CHROM', 'POS', 'END', 'QRY_ID'], ascending=[True, True, False, True])
 
         df_tig_fai = tig_fai if isinstance(tig_fai, pd.Series) else fasta.read_fai(tig_fai)
+        # check_record of every row (:352-353): count_cigar of a record's final CIGAR is what the library holds for the row since
+        # the last pass - the table is not loaded and tokenised a third time for it
+        loaded = df.pop('_LOADED_ROW').to_numpy() if '_LOADED_ROW' in df else None
         if df.shape[0]:
-            _load(ctx, df)                                                                    # count_cigar of the final strings
-            _, counts, _ = ctx.trim_fetch(with_cigar=False)
-            for i in range(df.shape[0]):
-                check_record(df.iloc[i], counts[i], df_tig_fai)
+            check_records(df, counts[loaded], df_tig_fai)
     finally:
         if own:
             ctx.close()

@@ -99,6 +99,44 @@ def test_check_record_messages():
         ptrim.check_record(row, cnt, pd.Series({'tigA': 400}))
 
 
+def test_check_records_raises_what_the_row_loop_would():
+    """check_records (array expressions over the table) against the loop of check_record over its rows (trim.py:352-353): the
+    same first failing row and message for every kind of failure, and silence on a clean table."""
+    rng = np.random.default_rng(5)
+    n = 40
+    base = pd.DataFrame({'INDEX': np.arange(n), 'QRY_ID': ['tig%d' % (i % 3) for i in range(n)], 'QRY_POS': 10, 'QRY_END': 110, 'QRY_LEN': 500,
+                         '#CHROM': 'chr1', 'POS': 1000 + 10 * np.arange(n), 'END': 1100 + 10 * np.arange(n)})
+    fai = pd.Series({'tig0': 500, 'tig1': 500, 'tig2': 500})
+    cnt0 = np.zeros(n, dtype=_lib.TRIM_COUNT_DTYPE)
+    cnt0['ref_bp'], cnt0['tig_bp'] = 100, 100
+    ptrim.check_records(base, cnt0, fai)                                  # clean
+
+    def loop(df, cnt):
+        for i in range(df.shape[0]):
+            ptrim.check_record(df.iloc[i], cnt[i], fai)
+    breaks = [('err_kind', lambda d, c, i: c.__setitem__('err_kind', np.where(np.arange(n) == i, 9, c['err_kind']))),
+              ('QRY_LEN', lambda d, c, i: d.__setitem__('QRY_LEN', np.where(np.arange(n) == i, 400, d['QRY_LEN']))),
+              ('QRY_POS>=END', lambda d, c, i: d.__setitem__('QRY_POS', np.where(np.arange(n) == i, 200, d['QRY_POS']))),
+              ('POS>=END', lambda d, c, i: d.__setitem__('POS', np.where(np.arange(n) == i, 10 ** 6, d['POS']))),
+              ('POS<0', lambda d, c, i: d.__setitem__('POS', np.where(np.arange(n) == i, -5, d['POS']))),
+              ('ref_bp', lambda d, c, i: c.__setitem__('ref_bp', np.where(np.arange(n) == i, 99, c['ref_bp']))),
+              ('tig_bp', lambda d, c, i: c.__setitem__('tig_bp', np.where(np.arange(n) == i, 101, c['tig_bp']))),
+              ('QRY_END>len', lambda d, c, i: (d.__setitem__('QRY_END', np.where(np.arange(n) == i, 610, d['QRY_END'])),
+                                               c.__setitem__('tig_bp', np.where(np.arange(n) == i, 600, c['tig_bp']))))]
+    for name, brk in breaks:
+        for _ in range(3):
+            d, c = base.copy(), cnt0.copy()
+            rows = sorted(set(int(x) for x in rng.integers(0, n, 3)))
+            for i in rows:
+                brk(d, c, i)
+            with pytest.raises(RuntimeError) as want:
+                loop(d, c)
+            with pytest.raises(RuntimeError) as got:
+                ptrim.check_records(d, c, fai)
+            assert str(got.value) == str(want.value), name
+            assert 'INDEX=%d,' % rows[0] in str(got.value)
+
+
 def test_interval_set_and_lgsv_constants():
     t = IntervalSet()
     t[100:200] = True
