@@ -424,6 +424,34 @@ def test_device_lifts_equal_the_host_tables(built, gpu_ctx, case, monkeypatch, c
     assert [t.splitlines() for t in got['device'][0]] == want
 
 
+def test_lift_errors_equal_on_every_path(built, gpu_ctx, monkeypatch, tmp_path):
+    """A record with an N operation: AlignLift refuses it when it is first used (lift.py:463-471: 'Unhandled CIGAR operation: N:
+    Alignment chrom:pos (contig)').  scan_for_inv raises that RuntimeError; the batch drivers hand it back per region.  The device
+    lifts (an error code + the record, formatted on the host), the host tables and the Python driver's AlignLift give the same text."""
+    d, lift0, scans = load_case(gpu_ctx, 'inv_fwd')
+    df = pd.read_csv(os.path.join(d, 'align.tsv'), sep='\t')
+    cig = df.loc[0, 'CIGAR']
+    m = __import__('re').search(r'(\d+)=', cig)
+    n = int(m.group(1))
+    assert n > 20
+    df.loc[0, 'CIGAR'] = cig[:m.start()] + f'{n - 10}=10N' + cig[m.end():]
+    flag = pavseq.Region(scans[1]['flag']['chrom'], scans[1]['flag']['pos'], scans[1]['flag']['end'])
+    texts = {}
+    for name, env, native in (('device', None, True), ('host', '1', True), ('python', None, False)):
+        if env is None:
+            monkeypatch.delenv('PAV_LIFT_HOST', raising=False)
+        else:
+            monkeypatch.setenv('PAV_LIFT_HOST', env)
+        lift = AlignLift(df, read_fai(os.path.join(d, 'tig.fa.fai')))
+        out = pavinv.scan_for_inv_batch([flag], os.path.join(d, 'ref.fa'), os.path.join(d, 'tig.fa'), lift, KmerUtil(31), ctx=gpu_ctx,
+                                        native=native)
+        assert isinstance(out[0], RuntimeError), (name, out[0])
+        texts[name] = str(out[0])
+    assert texts['device'] == texts['host'] == texts['python']
+    row = df.iloc[0]
+    assert texts['device'] == 'Unhandled CIGAR operation: N: Alignment {}:{} ({})'.format(row['#CHROM'], row['POS'], row['QRY_ID'])
+
+
 @pytest.mark.parametrize('native', [True, False])
 def test_batch_log_sink_equals_the_sequential_log(built, gpu_ctx, native):
     """``log=``: one file-like object for the whole batch, as rule call_inv_batch hands its log file to every scan_for_inv
