@@ -77,6 +77,20 @@ def test_bench_line_schema_and_arithmetic(line):
     assert abs(p['frac'] - p['achieved'] / 8000.0) < 1e-3
     assert p['sum_kernel_ms_per_step'] > 0 and p['single_lane'] ['ms_per_step'] > 0
     assert abs(p['single_lane']['over_sum_kernel_ms'] - p['single_lane']['ms_per_step'] / p['sum_kernel_ms_per_step']) < 0.01
+    # round 4: the arg-max is reported as measured; the regime of the line (all lanes running) has its own ranking; the step that
+    # also rebuilds the lift-over index is reported beside `value`; a scaling run's reader finds the lanes in per_rank
+    kms = r['kernels_ms']
+    assert r['dominant_measured'] == r['kernel'] and r['kernel'] in kms
+    if cfg['lanes_per_gpu'] > 1:
+        tr = r['timed_region']
+        assert tr['lanes'] == cfg['lanes_per_gpu'] and tr['kernel'] in tr['kernels']
+        shares = [v['share'] for v in tr['kernels'].values()]
+        assert shares == sorted(shares, reverse=True) and abs(tr['share_of_device_time'] - shares[0]) < 1e-3
+        assert tr['device_ms_per_step'] >= max(v['ms_per_step'] for v in tr['kernels'].values())
+    w = line['with_lift_index']
+    assert w['unit'] == 'Gbp/s' and w['value'] > 0 and w['ms_per_step'] > 0
+    assert abs(w['lift_index_ms_per_step'] - (w['ms_per_step'] - line['ms_per_step'])) < 0.01 * w['ms_per_step'] + 1e-3
+    assert all(pr['lanes_per_gpu'] == cfg['lanes_per_gpu'] and pr['usable_cpus'] > 0 for pr in line['per_rank'])
     c = line['cpu_baseline']
     assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['unit'] == 'Gbp/s' and c['sample']
     assert c['records_match_gpu'] is True and c['density_tables_match_gpu'] is True
