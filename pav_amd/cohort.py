@@ -24,7 +24,7 @@ product default fails loudly without the HIP library and a GPU.
 """
 import os
 import socket
-from dataclasses import asdict, dataclass
+from dataclasses import dataclass
 
 from . import rules, shard
 

@@ -9,8 +9,6 @@ import tempfile
 from concurrent.futures import ThreadPoolExecutor
 from types import SimpleNamespace
 
-import numpy as np
-
 from pav_amd import _lib, density as pavden, inv as pavinv
 
 

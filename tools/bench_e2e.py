@@ -13,7 +13,6 @@ Timed stages, each with the rule(s) of the reference it stands for:
     python tools/bench_e2e.py [--scale 1.0] [--out DIR]
 """
 import argparse
-import io
 import json
 import os
 import shutil
@@ -44,12 +43,8 @@ def main():
     import torch  # noqa: F401  first: one HIP runtime per process (pav_amd/_lib.py)
     import __graft_entry__ as g
     g.build_cpu_side()
-    import numpy as np
     import pandas as pd
-    from pav_amd import _lib, cigarcall, flag, rules, synth, inv as pavinv, seq as pavseq
-    from pav_amd.align import AlignLift
-    from pav_amd.fasta import open_fasta, read_fai
-    from pav_amd.kmer import KmerUtil
+    from pav_amd import _lib, rules, synth
 
     work = args.out or tempfile.mkdtemp(prefix='pav_e2e_')
     os.makedirs(work, exist_ok=True)
