@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""pav_amd.rules.run_cohort on synthetic haplotypes, files to files: H haplotypes of one reference (hg38-shaped, shrunk by --scale)
+are written as FASTA + alignment tables, then called by 1 rank and by R ranks (on a one-GPU box the ranks share GPU 0: what this
+measures there is the runner itself - process start-up, one resident reference per rank, LPT, files - not GPU scaling).
+    python tools/bench_cohort.py [--scale 0.2] [--haplotypes 4] [--ranks 2]
+"""
+import argparse
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--scale', type=float, default=0.2)
+    ap.add_argument('--haplotypes', type=int, default=4)
+    ap.add_argument('--ranks', type=int, default=2)
+    ap.add_argument('--seed', type=int, default=1004)
+    args = ap.parse_args()
+    import __graft_entry__ as g
+    g.build_cpu_side()
+    from pav_amd import cohort, synth
+    from pav_amd.shard import effective_cpus
+    work = tempfile.mkdtemp(prefix='pav_cohort_')
+    try:
+        t0 = time.time()
+        ref = None
+        jobs = []
+        aligned = 0
+        for h in range(args.haplotypes):
+            hap = synth.config2(seed=args.seed, scale=args.scale, hap_index=h, ref=ref, threads=min(16, effective_cpus()), pair_frac=0.009)
+            ref = hap.ref
+            asm, hname = f'sample{h // 2}', f'h{h % 2 + 1}'
+            d = os.path.join(work, 'in', asm)
+            os.makedirs(d, exist_ok=True)
+            if h == 0:
+                synth.write_fasta(os.path.join(work, 'in', 'ref.fa'), ref.names, ref.seqs, line=80)
+            tig = os.path.join(d, f'contigs_{hname}.fa')
+            synth.write_fasta(tig, hap.tig_names, hap.tig_seqs, line=80)
+            bed, bed_trim = os.path.join(d, f'aligned_tig_{hname}.bed.gz'), os.path.join(d, f'aligned_tig_{hname}.trim.bed.gz')
+            df = hap.df_align.copy()
+            if 'CALL_BATCH' not in df:
+                df['CALL_BATCH'] = df['INDEX'] % 10
+            df.to_csv(bed, sep='\t', index=False, compression={'method': 'gzip', 'compresslevel': 1})
+            hap.df_trim.to_csv(bed_trim, sep='\t', index=False, compression={'method': 'gzip', 'compresslevel': 1})
+            jobs.append(cohort.HaplotypeJob(asm, hname, tig, bed, bed_trim))
+            aligned += hap.stats['aligned_bp']
+            del hap
+        t_inputs = time.time() - t0
+        out = {}
+        cfg = {'inv_sig_filter': 'single_cluster'}
+        for world in (1, args.ranks):
+            t0 = time.time()
+            ms = cohort.run_cohort(jobs, world, os.path.join(work, f'out{world}'), os.path.join(work, 'in', 'ref.fa'), config=cfg,
+                                   share_gpu=True, timeout=3600)
+            dt = time.time() - t0
+            out[f'{world}_rank' + ('s' if world > 1 else '')] = {
+                'wall_s': round(dt, 2), 'haplotypes_per_s': round(len(jobs) / dt, 3), 'aligned_Gbp_per_s': round(aligned / dt / 1e9, 3),
+                'inv_calls': sum(m['inv_calls'] for m in ms), 'ranks_used': sorted({m['rank'] for m in ms})}
+        print(json.dumps({'workload': f'{args.haplotypes} synthetic haplotypes, scale {args.scale}, seed {args.seed}, one reference; files to files through '
+                                      'pav_amd.rules.run_cohort (whole haplotypes per rank, the ranks share GPU 0 on a one-GPU box)',
+                          'aligned_bp': aligned, 'inputs_written_s': round(t_inputs, 1), 'usable_cores': effective_cpus(), **out}))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+if __name__ == '__main__':
+    main()
