@@ -564,9 +564,13 @@ def call_haplotype(bed, bed_trim, tig_fa_name, ref_fa_name, asm_name, hap, out_d
             n_calls += len(call_list)
         lap('INV batch tables + logs')
         if native_tables:
-            # a call found through two flagged regions is written once per batch that holds it, as the jobs of the rule would:
-            # the same file name, the same table
-            ctx.inv_write_tables([r for r, _ in native_tables], [p for _, p in native_tables], threads=threads, gzip_level=gzip_level)
+            # A call found through two flagged regions of different batches names the same file twice; the reference's batch jobs
+            # would each write it (whichever job runs last wins there).  Here every file is written once, by the call of the
+            # last batch that holds it - one writer per file.
+            last = {}
+            for rgn, path in native_tables:
+                last[path] = rgn
+            ctx.inv_write_tables(list(last.values()), list(last.keys()), threads=threads, gzip_level=gzip_level)
         lap('density tables')
         df_inv = call_inv_batch_merge(P['inv_batch'], P['inv'], gzip_level=gzip_level or 6)
         lap('INV merge')
