@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """pav_amd.rules.run_cohort on synthetic haplotypes, files to files: H haplotypes of one reference (hg38-shaped, shrunk by --scale)
-are written as FASTA + alignment tables, then called by 1 rank and by R ranks (on a one-GPU box the ranks share GPU 0: what this
-measures there is the runner itself - process start-up, one resident reference per rank, LPT, files - not GPU scaling).
-    python tools/bench_cohort.py [--scale 0.2] [--haplotypes 4] [--ranks 2]
+are written as FASTA + alignment tables, then called by 1 rank and - when the box has them - by one rank per GPU.
+    python tools/bench_cohort.py [--scale 0.25] [--haplotypes 4] [--ranks N] [--share-gpu]
+--share-gpu puts all ranks on GPU 0 (what the tests do on tiny inputs).  It is NOT a way to use one GPU harder: two PROCESSES
+time-slice a GPU, and a path of thousands of short kernels with a synchronisation every few of them then runs an order of
+magnitude slower (measured: 4 haplotypes in 12 s with one rank, 504 s with two ranks on one GPU,
+profiles/r04_cohort_two_ranks_one_gpu.json).  Several haplotypes per GPU are threads of ONE process (bench.py's lanes).
 """
 import argparse
 import json
@@ -18,9 +21,10 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--scale', type=float, default=0.2)
+    ap.add_argument('--scale', type=float, default=0.25)
     ap.add_argument('--haplotypes', type=int, default=4)
-    ap.add_argument('--ranks', type=int, default=2)
+    ap.add_argument('--ranks', type=int, default=0, help='ranks of the second run (0 = one per visible GPU; skipped on a one-GPU box)')
+    ap.add_argument('--share-gpu', action='store_true', help='all ranks on GPU 0 (see above: a correctness device, not a fast one)')
     ap.add_argument('--seed', type=int, default=1004)
     args = ap.parse_args()
     import __graft_entry__ as g
@@ -55,16 +59,20 @@ def main():
         t_inputs = time.time() - t0
         out = {}
         cfg = {'inv_sig_filter': 'single_cluster'}
-        for world in (1, args.ranks):
+        import torch
+        n_dev = torch.cuda.device_count()                      # (counting devices does not initialise the GPU in this process)
+        ranks = args.ranks or n_dev
+        worlds = [1] + ([ranks] if ranks > 1 and (args.share_gpu or ranks <= n_dev) else [])
+        for world in worlds:
             t0 = time.time()
             ms = cohort.run_cohort(jobs, world, os.path.join(work, f'out{world}'), os.path.join(work, 'in', 'ref.fa'), config=cfg,
-                                   share_gpu=True, timeout=3600)
+                                   share_gpu=args.share_gpu, timeout=3600)
             dt = time.time() - t0
             out[f'{world}_rank' + ('s' if world > 1 else '')] = {
                 'wall_s': round(dt, 2), 'haplotypes_per_s': round(len(jobs) / dt, 3), 'aligned_Gbp_per_s': round(aligned / dt / 1e9, 3),
                 'inv_calls': sum(m['inv_calls'] for m in ms), 'ranks_used': sorted({m['rank'] for m in ms})}
         print(json.dumps({'workload': f'{args.haplotypes} synthetic haplotypes, scale {args.scale}, seed {args.seed}, one reference; files to files through '
-                                      'pav_amd.rules.run_cohort (whole haplotypes per rank, the ranks share GPU 0 on a one-GPU box)',
+                                      'pav_amd.rules.run_cohort (whole haplotypes per rank)' + (', all ranks on GPU 0' if args.share_gpu else ''), 'gpus_visible': n_dev,
                           'aligned_bp': aligned, 'inputs_written_s': round(t_inputs, 1), 'usable_cores': effective_cpus(), **out}))
     finally:
         shutil.rmtree(work, ignore_errors=True)
