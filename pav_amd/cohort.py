@@ -8,7 +8,8 @@ Snakemake runs them as separate jobs and exchanges files.  Here there is one pro
 
 * ``len(jobs) >= n_gpus`` - BASELINE configs[3] (16 haplotypes -> 8 GPUs in two waves) and configs[4] (64 haplotypes, 8 per GPU):
   whole haplotypes are dealt to the ranks longest-processing-time first (cost = size of the alignment table, i.e. CIGAR text) and
-  every rank runs :func:`pav_amd.rules.call_haplotype` on its haplotypes one after the other against ONE resident reference.
+  every rank runs :func:`pav_amd.rules.call_haplotype` on its haplotypes against ONE resident reference - one after the other, or
+  ``config['pav_amd_lanes']`` of them at a time on contexts of their own (threads of the rank's process; configs[4]).
 * fewer haplotypes than GPUs (or ``split=True``): the ranks that share a haplotype split its CALL_BATCH jobs, the lead rank
   merges them as rule call_cigar_merge does (:765-786) and flags the merged tables (the five flag rules), the ranks split the
   flagged-region BATCH jobs, the lead rank merges them as rule call_inv_batch_merge does (call_inv.snakefile:101-112, incl.
@@ -75,27 +76,67 @@ def plan(jobs, world, split=False):
 
 
 class DeviceEngine:
-    """One rank's worker: a context on one GPU and the reference resident on it."""
+    """One rank's worker: the reference resident on one GPU and ``lanes`` contexts that read it (``pav_seq_share``) - a rank calls
+    up to ``lanes`` of its haplotypes at the same time, one host thread each (BASELINE configs[4]: several haplotypes resident per
+    GPU; the file stages of one haplotype - FASTA parse, text, deflate - run beside the kernels of another)."""
 
-    def __init__(self, device_id, ref_fa, config=None, threads=0, gzip_level=0):
+    def __init__(self, device_id, ref_fa, config=None, threads=0, gzip_level=0, lanes=1):
         self.device_id, self.ref_fa, self.config = int(device_id), ref_fa, dict(config or {})
-        self.threads, self.gzip_level = threads, gzip_level
-        self.ctx = None
+        self.threads, self.gzip_level, self.lanes = threads, gzip_level, max(1, int(lanes))
+        self.ctx, self.lane_ctx = None, []
 
     def open(self):
         from . import _lib, cigarcall
         self.ctx = _lib.Context(self.device_id)                  # raises without the HIP library / a GPU: there is no CPU path
         cigarcall.load_reference(self.ctx, self.ref_fa)
+        self.lane_ctx = [self.ctx]
+        for _ in range(1, self.lanes):
+            c = _lib.Context(self.device_id)
+            c.seq_share(self.ctx, _lib.PAV_ROLE_REF)             # the same planes in HBM; the mark of the resident file travels with them
+            self.lane_ctx.append(c)
 
     def close(self):
-        if self.ctx is not None:
-            self.ctx.close()
-            self.ctx = None
+        for c in self.lane_ctx[::-1]:
+            c.close()
+        self.ctx, self.lane_ctx = None, []
 
-    # ---- whole haplotype ----------------------------------------------------------------------------------------------
-    def call_haplotype(self, job, out_dir):
-        return rules.call_haplotype(job.bed, job.bed_trim, job.tig_fa, self.ref_fa, job.asm_name, job.hap, out_dir, ctx=self.ctx,
+    # ---- whole haplotypes ---------------------------------------------------------------------------------------------
+    def call_haplotype(self, job, out_dir, ctx=None):
+        return rules.call_haplotype(job.bed, job.bed_trim, job.tig_fa, self.ref_fa, job.asm_name, job.hap, out_dir, ctx=ctx or self.ctx,
                                     config=self.config, threads=self.threads, gzip_level=self.gzip_level)
+
+    def call_haplotypes(self, jobs, out_dir):
+        """All of a rank's whole haplotypes, ``lanes`` at a time; manifests in the order of ``jobs``."""
+        if self.lanes == 1 or len(jobs) <= 1:
+            return [self.call_haplotype(j, out_dir) for j in jobs]
+        import queue
+        import threading
+        free = queue.Queue()
+        for c in self.lane_ctx:
+            free.put(c)
+        out, errs = [None] * len(jobs), []
+
+        def work(i):
+            c = free.get()
+            try:
+                out[i] = self.call_haplotype(jobs[i], out_dir, ctx=c)
+            except BaseException as ex:                          # noqa: BLE001 - raised again on the rank's main thread
+                errs.append(ex)
+            finally:
+                free.put(c)
+        sem = threading.Semaphore(self.lanes)
+
+        def run(i):
+            with sem:
+                work(i)
+        ths = [threading.Thread(target=run, args=(i,)) for i in range(len(jobs))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if errs:
+            raise errs[0]
+        return out
 
     # ---- the jobs of a haplotype that several ranks share -------------------------------------------------------------------
     def call_cigar_batches(self, job, P, batches):
@@ -130,7 +171,7 @@ class DeviceEngine:
 
 
 def _default_engine(rank, device_id, ref_fa, config):
-    return DeviceEngine(device_id, ref_fa, config)
+    return DeviceEngine(device_id, ref_fa, config, lanes=int((config or {}).get('pav_amd_lanes', 1)))
 
 
 def _barrier(world):
@@ -151,11 +192,11 @@ def run_rank(rank, world, jobs, out_dir, ref_fa, config=None, engine_factory=Non
     shared = sorted({(j, n, lead) for its in items for (j, p, n, lead) in its if n > 1})
     engine.open()
     try:
-        for (j, p, n, lead) in mine:
-            if n == 1:
-                m = engine.call_haplotype(jobs[j], out_dir)
-                m['rank'], m['mode'] = rank, 'whole haplotype'
-                manifests.append(m)
+        whole = [jobs[j] for (j, p, n, lead) in mine if n == 1]
+        many = getattr(engine, 'call_haplotypes', None)
+        for m in (many(whole, out_dir) if many else [engine.call_haplotype(j, out_dir) for j in whole]):
+            m['rank'], m['mode'] = rank, 'whole haplotype'
+            manifests.append(m)
         # the shared haplotypes advance stage by stage; every rank meets every barrier (a rank without a part just passes)
         my_part = {j: (p, n) for (j, p, n, lead) in mine if n > 1}
         paths = {j: rules.haplotype_paths(out_dir, jobs[j].asm_name, jobs[j].hap, batch_count) for (j, n, lead) in shared}

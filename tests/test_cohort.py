@@ -91,7 +91,7 @@ def _golden_checks(tree, case, asm, hap):
 @pytest.mark.parametrize('split', [False, True], ids=['whole-haplotypes', 'one-haplotype-shared'])
 def test_two_ranks_on_one_gpu_equal_the_unsharded_run_and_the_reference_tables(built, tmp_path, split):
     """The real engine, two rank processes sharing GPU 0 (gloo control plane): three haplotypes dealt to two ranks (one resident
-    reference per rank, haplotypes one after the other) / one haplotype shared by both ranks.  All files equal the one-rank
+    reference per rank, two haplotypes at a time on contexts that share it) / one haplotype shared by both ranks.  All files equal the one-rank
     run's; the merged SNV / INS-DEL tables and the five flag tables of sampleA h1 equal what the reference's rule bodies wrote
     (tests/golden/flag_hap)."""
     if split:
@@ -102,7 +102,7 @@ def test_two_ranks_on_one_gpu_equal_the_unsharded_run_and_the_reference_tables(b
     cfg = dict(CFG, inv_sig_filter='single_cluster')
     one, two = tmp_path / 'one', tmp_path / 'two'
     m1 = cohort.run_cohort(jobs, 1, str(one), ref_fa, config=cfg)
-    m2 = cohort.run_cohort(jobs, 2, str(two), ref_fa, config=cfg, share_gpu=True, split=split, timeout=900)
+    m2 = cohort.run_cohort(jobs, 2, str(two), ref_fa, config=dict(cfg, pav_amd_lanes=2), share_gpu=True, split=split, timeout=900)
     key = lambda m: (m['asm_name'], m['hap'], m['inv_calls'])   # noqa: E731
     assert sorted(map(key, m1)) == sorted(map(key, m2)) and len(m1) == len(jobs)
     assert {m['rank'] for m in m2} == ({0} if split else {0, 1})

@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--ranks', type=int, default=0, help='ranks of the second run (0 = one per visible GPU; skipped on a one-GPU box)')
     ap.add_argument('--share-gpu', action='store_true', help='all ranks on GPU 0 (see above: a correctness device, not a fast one)')
     ap.add_argument('--seed', type=int, default=1004)
+    ap.add_argument('--lanes', type=int, nargs='+', default=[1, 4], help="haplotypes a rank calls at the same time (config 'pav_amd_lanes'); one run per value")
     args = ap.parse_args()
     import __graft_entry__ as g
     g.build_cpu_side()
@@ -64,13 +65,15 @@ def main():
         ranks = args.ranks or n_dev
         worlds = [1] + ([ranks] if ranks > 1 and (args.share_gpu or ranks <= n_dev) else [])
         for world in worlds:
-            t0 = time.time()
-            ms = cohort.run_cohort(jobs, world, os.path.join(work, f'out{world}'), os.path.join(work, 'in', 'ref.fa'), config=cfg,
-                                   share_gpu=args.share_gpu, timeout=3600)
-            dt = time.time() - t0
-            out[f'{world}_rank' + ('s' if world > 1 else '')] = {
-                'wall_s': round(dt, 2), 'haplotypes_per_s': round(len(jobs) / dt, 3), 'aligned_Gbp_per_s': round(aligned / dt / 1e9, 3),
-                'inv_calls': sum(m['inv_calls'] for m in ms), 'ranks_used': sorted({m['rank'] for m in ms})}
+            for lanes in args.lanes:
+                t0 = time.time()
+                ms = cohort.run_cohort(jobs, world, os.path.join(work, f'out{world}_{lanes}'), os.path.join(work, 'in', 'ref.fa'),
+                                       config=dict(cfg, pav_amd_lanes=lanes), share_gpu=args.share_gpu, timeout=3600)
+                dt = time.time() - t0
+                out[f'{world}_rank' + ('s' if world > 1 else '') + f'_{lanes}_lanes'] = {
+                    'wall_s': round(dt, 2), 'haplotypes_per_s': round(len(jobs) / dt, 3), 'aligned_Gbp_per_s': round(aligned / dt / 1e9, 3),
+                    'inv_calls': sum(m['inv_calls'] for m in ms), 'ranks_used': sorted({m['rank'] for m in ms})}
+                shutil.rmtree(os.path.join(work, f'out{world}_{lanes}'), ignore_errors=True)
         print(json.dumps({'workload': f'{args.haplotypes} synthetic haplotypes, scale {args.scale}, seed {args.seed}, one reference; files to files through '
                                       'pav_amd.rules.run_cohort (whole haplotypes per rank)' + (', all ranks on GPU 0' if args.share_gpu else ''), 'gpus_visible': n_dev,
                           'aligned_bp': aligned, 'inputs_written_s': round(t_inputs, 1), 'usable_cores': effective_cpus(), **out}))
