@@ -22,7 +22,7 @@ static inline void put_u64(std::string &s, uint64_t v) {
     do { b[n++] = (char)('0' + v % 10); v /= 10; } while (v);
     while (n) s.push_back(b[--n]);
 }
-static inline void put_i64(std::string &s, int64_t v) { if (v < 0) { s.push_back('-'); put_u64(s, (uint64_t)(-v)); } else put_u64(s, (uint64_t)v); }
+static inline void put_i64(std::string &s, int64_t v) { if (v < 0) { s.push_back('-'); put_u64(s, 0 - (uint64_t)v); } else put_u64(s, (uint64_t)v); }
 // csv.QUOTE_MINIMAL with delimiter '\t' and quotechar '"' (what DataFrame.to_csv uses)
 [[maybe_unused]] static std::string csv_field(const std::string &f) {
     if (f.find_first_of("\t\"\n\r") == std::string::npos) return f;
