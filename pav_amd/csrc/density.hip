@@ -80,7 +80,7 @@ struct EvalTile { uint32_t job, first, count, mode; };   // mode 0: sampled site
 struct HeadEvent { uint32_t job, row; int32_t state; uint32_t index, prev_index; uint32_t pad; };
 
 struct DensityState {
-    DevBuf jobs, stat, kde, tile_job_r, tile_job_t, keys, cnt, keys_x, cnt_x, lists, bcount, ans_f, ans_c, items;
+    DevBuf jobs, stat, kde, tile_job_r, tile_job_t, keys, cnt, keys_x, cnt_x, lists, bcount, items;
     DevBuf st_tmp, tile_sum, tile_pre, index, state_mer, state, kmer, kern[3], list[3], pscaled[3], fill_list;
     DevBuf tiles, events, ev_count, scratch, run_arena, win_fill, ks[3], ss;
     DevBuf guard, guard_entries, samp_flag, row_flag, ftiles; // near-tie guard; evaluation tiles of the fill list
@@ -126,7 +126,7 @@ struct DensityState {
     uint64_t arena_t = 0;
     bool valid = false;
     void release() {
-        DevBuf *all[] = {&jobs, &stat, &kde, &tile_job_r, &tile_job_t, &keys, &cnt, &keys_x, &cnt_x, &lists, &bcount, &ans_f, &ans_c, &items, &st_tmp, &tile_sum, &tile_pre,
+        DevBuf *all[] = {&jobs, &stat, &kde, &tile_job_r, &tile_job_t, &keys, &cnt, &keys_x, &cnt_x, &lists, &bcount, &items, &st_tmp, &tile_sum, &tile_pre,
                          &index, &state_mer, &state, &kmer, &kern[0], &kern[1], &kern[2], &list[0], &list[1], &list[2],
                          &pscaled[0], &pscaled[1], &pscaled[2], &fill_list, &tiles, &events, &ev_count, &scratch, &run_arena, &win_fill, &ks[0], &ks[1], &ks[2], &ss,
                          &guard, &guard_entries, &samp_flag, &row_flag, &ftiles, &tile_heads, &tile_head_cnt, &heads, &plan_flags, &pow_tab,
@@ -308,8 +308,8 @@ __global__ __launch_bounds__(256) void k_tig_state(const JobDev *__restrict__ jo
 //   k_bucket_ref / k_bucket_tig  one workgroup per 2048-position tile: every k-mer is hashed once and its position is
 //                                appended to the list of its partition (ranks from an LDS histogram, one global atomic
 //                                per (tile, partition) to reserve the slots)
-//   k_kmer_lds                   reads its two lists densely: inserts, then probes and writes the two answer bytes of a position
-//   k_state_combine              STATE_MER from the two answers per position (+ per-state counts)
+//   k_kmer_lds                   reads its two lists densely: inserts, then probes and writes STATE_MER of the positions whose k-mer is in a set
+//   k_state_combine              per-tile and per-job counts of the states
 // The sets are keyed by the CANONICAL k-mer - the smaller of a k-mer and its reverse complement - with one occurrence count
 // per orientation: "the contig k-mer is in the reference set" and "its reverse complement is" are then ONE question (same
 // canonical key; same / other orientation), so a contig k-mer goes to one list and is looked up once.  (Round 2 kept the
@@ -326,7 +326,6 @@ constexpr int KU = PAV_LDS_STEP / LDS_THREADS;        // list entries a lane of 
 constexpr uint32_t LDS_FILL = LDS_SLOTS * 7 / 16;   // k-mers per partition aimed at (load factor 0.44)
 constexpr uint32_t LDS_MAX_PARTS = 1024;             // histogram size of the bucket kernels (regions up to 1.8 Mbp; MAX_REGION_SIZE is 1.2 Mbp)
 constexpr uint32_t LDS_MAX_LIMIT = 250;              // byte counts: the limit must stay below the wrap
-constexpr uint32_t ANS_ABSENT = 0, ANS_PRESENT = 1, ANS_INVALID = 0xFF;
 constexpr uint32_t LDS_EXCEED = 1, LDS_OVERFLOW = 2;
 
 struct PartItem { uint32_t job, part; };
@@ -439,7 +438,7 @@ __global__ __launch_bounds__(256) void k_bucket_ref(const JobDev *__restrict__ j
 
 __global__ __launch_bounds__(256) void k_bucket_tig(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
                                                     SeqView T, int k, uint32_t *__restrict__ lists, uint32_t *__restrict__ bcount,
-                                                    uint8_t *__restrict__ ans_f, JobStat *__restrict__ stat) {
+                                                    int8_t *__restrict__ st_tmp, JobStat *__restrict__ stat) {
     __shared__ uint32_t hist[LDS_MAX_PARTS], base[LDS_MAX_PARTS];
     const uint32_t j = tile_job[blockIdx.x];
     const JobDev jd = jobs[j];
@@ -466,7 +465,7 @@ __global__ __launch_bounds__(256) void k_bucket_tig(const JobDev *__restrict__ j
             pf[t] = kpart(khash(canon_key(x, k)), P);
             rf[t] = atomicAdd(&hist[pf[t]], 1u);
         }
-        ans_f[(uint64_t)blockIdx.x * DTILE + t * 256 + threadIdx.x] = pf[t] == ~0u ? (uint8_t)ANS_INVALID : (uint8_t)ANS_ABSENT;
+        st_tmp[(uint64_t)blockIdx.x * DTILE + t * 256 + threadIdx.x] = (int8_t)-1;      // no window here, or a k-mer in neither set: k_kmer_lds writes the others
     }
     __syncthreads();
     for (uint32_t p = threadIdx.x; p < P; p += 256)
@@ -477,12 +476,18 @@ __global__ __launch_bounds__(256) void k_bucket_tig(const JobDev *__restrict__ j
     if (over) atomicOr(&stat[j].lds_flags, LDS_OVERFLOW);
 }
 
+// Slot layout of k_kmer_lds: bits 0..61 the canonical k-mer (k <= 31), bit 62 / 63: the set holds it in its canonical / in the
+// other orientation.  A probe of the answer phase is then ONE LDS read (round 3: key, then the count bytes of the slot).
+constexpr unsigned long long KEY_BITS = (1ull << 62) - 1ull;
+constexpr int KEY_O_SHIFT = 62;
+
+// ABL / ABL_W: ablations for the tuning build (PAV_TUNING, tools/build_variant.sh): the product launches <0, 0>
+template <int ABL, int ABL_W>
 __global__ __launch_bounds__(LDS_THREADS) void k_kmer_lds(const PartItem *__restrict__ items, const JobDev *__restrict__ jobs,
                                                           SeqView R, SeqView T, int k, uint32_t limit,
                                                           const uint32_t *__restrict__ lists, const uint32_t *__restrict__ bcount,
-                                                          uint8_t *__restrict__ ans_f, uint8_t *__restrict__ ans_c,
-                                                          JobStat *__restrict__ stat) {
-    __shared__ unsigned long long keys[LDS_SLOTS];                     // canonical k-mers
+                                                          int8_t *__restrict__ st_tmp, JobStat *__restrict__ stat) {
+    __shared__ unsigned long long keys[LDS_SLOTS];                     // canonical k-mers + orientation bits
     __shared__ uint32_t cnt2[LDS_SLOTS / 2];                           // per slot two bytes: occurrences in the canonical / the other orientation
     __shared__ uint32_t flags;
     const PartItem it = items[blockIdx.x];
@@ -492,11 +497,12 @@ __global__ __launch_bounds__(LDS_THREADS) void k_kmer_lds(const PartItem *__rest
     const uint32_t n_ref = min(bcount[jd.bucket_off + it.part], jd.cap_r), n_tig = min(bcount[jd.bucket_off + P + it.part], jd.cap_t);
     const uint32_t *list_r = lists + jd.list_off_r + (uint64_t)it.part * jd.cap_r;
     const uint32_t *list_t = lists + jd.list_off_t + (uint64_t)it.part * jd.cap_t;
+    constexpr uint32_t M = LDS_SLOTS - 1;
 
     // The kernel is a chain of latencies - list entry -> window of the plane -> LDS table - once for the reference k-mers and once
     // for the contig k-mers, and a partition is about one step of the workgroup in either list (KU entries per lane).  The first
-    // step of BOTH lists is therefore put in flight before the table is cleared: its positions, then its windows, wait in
-    // registers while the reference k-mers go in.  (Round 3; before, the four round trips ran one after the other: 0.104 ms.)
+    // step of BOTH lists is therefore put in flight before the table is cleared: its positions, then the reference windows, wait
+    // in registers while the table is cleared; the contig windows are fetched behind the inserts.
     uint32_t pos_r[KU], pos_t[KU]; bool ok_r[KU], ok_t[KU];
     KmerWords kw_r[KU], kw_t[KU];
 #pragma unroll
@@ -505,98 +511,114 @@ __global__ __launch_bounds__(LDS_THREADS) void k_kmer_lds(const PartItem *__rest
         ok_r[u] = e < n_ref; pos_r[u] = n_ref ? list_r[ok_r[u] ? e : n_ref - 1] : 0u;
         ok_t[u] = e < n_tig; pos_t[u] = n_tig ? list_t[ok_t[u] ? e : n_tig - 1] : 0u;
     }
-#ifndef PAV_KMER_EARLY_TIG                   // the contig windows are fetched behind the inserts (16 registers fewer; 0.197 -> 0.190 ms per pass);
-                                            // PAV_KMER_EARLY_TIG (tuning build): together with the reference windows, round 3's order
 #pragma unroll
-    for (int u = 0; u < KU; ++u) kw_r[u] = kmer_words(R.two, jd.ref_abs + pos_r[u]);
-#else
-#pragma unroll
-    for (int u = 0; u < KU; ++u) { kw_r[u] = kmer_words(R.two, jd.ref_abs + pos_r[u]); kw_t[u] = kmer_words(T.two, jd.tig_abs + pos_t[u]); }
-#endif
+    for (int u = 0; u < KU; ++u) {
+        if constexpr (ABL_W) kw_r[u] = KmerWords{(uint64_t)pos_r[u] * 0x9E3779B97F4A7C15ull, (uint64_t)pos_r[u] * 0xC2B2AE3D27D4EB4Full};
+        else kw_r[u] = kmer_words(R.two, jd.ref_abs + pos_r[u]);
+    }
 
     for (int s = threadIdx.x; s < LDS_SLOTS; s += LDS_THREADS) keys[s] = EMPTY_KEY;
     for (int s = threadIdx.x; s < LDS_SLOTS / 2; s += LDS_THREADS) cnt2[s] = 0;
     if (threadIdx.x == 0) flags = 0;
     __syncthreads();
 
-    // reference k-mers of this partition -> LDS set with byte counts per orientation
+    // One entry after the other, each with its own probe loop.  Tuning builds of round 4 (profiles/r04_kmer_ablation.txt) put the
+    // first probe of all KU entries in flight, or probed in rounds over the KU entries until the wave's last entry had its slot:
+    // both are SLOWER (0.25 - 0.35 ms per pass against 0.20) - with 32 waves per CU the latency of a probe is covered already,
+    // and the extra compare-and-swaps of entries that are done cost more than the waiting they remove.
     uint32_t my_flags = 0;
-    auto insert = [&](uint64_t x) __attribute__((always_inline)) {
-        bool other, self_rc;
-        const uint64_t key = canon_key(x, k, &other, &self_rc);
-        // the set holds the region's k-mers as they are (-r: reverse-complemented): which orientation of the key that is
-        const uint32_t o = self_rc ? 0u : (uint32_t)(other != (jd.ref_rc != 0));
-        uint32_t s = khash(key) & (LDS_SLOTS - 1);
-        int probes = 0;
-        while (true) {
-            const unsigned long long old = atomicCAS(&keys[s], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
-            if (old == EMPTY_KEY || old == key) {
-                const uint32_t sh = 16 * (s & 1) + 8 * o;
-                const uint32_t prev = (atomicAdd(&cnt2[s >> 1], 1u << sh) >> sh) & 0xFFu;        // occurrences so far
-                if (prev + 1 > limit) my_flags |= LDS_EXCEED;
-                break;
+    auto insert_step = [&](const KmerWords (&kw)[KU], const uint32_t (&pos)[KU], const bool (&ok)[KU]) __attribute__((always_inline)) {
+        if constexpr (ABL == 3 || ABL == 5) {
+            uint64_t acc = 0;
+            for (int u = 0; u < KU; ++u) acc += kw[u].v0 ^ kw[u].v1 ^ pos[u];
+            if (acc == 0x123456789ull && ok[0]) my_flags |= 4;
+            return;
+        }
+#pragma unroll
+        for (int u = 0; u < KU; ++u) if (ok[u]) {
+            bool other, self_rc;
+            const uint64_t key = canon_key(kmer_from_words(kw[u], jd.ref_abs + pos[u], k), k, &other, &self_rc);
+            // the set holds the region's k-mers as they are (-r: reverse-complemented): which orientation of the key that is
+            const uint32_t o = self_rc ? 0u : (uint32_t)(other != (jd.ref_rc != 0));
+            const unsigned long long want = key | 1ull << (KEY_O_SHIFT + o);
+            uint32_t s = khash(key) & M;
+            int probes = 0;
+            while (true) {
+                const unsigned long long od = atomicCAS(&keys[s], (unsigned long long)EMPTY_KEY, want);
+                if (od == EMPTY_KEY || ((od ^ want) & KEY_BITS) == 0) {
+                    if (od != EMPTY_KEY && !(od & want & ~KEY_BITS)) atomicOr(&keys[s], want & ~KEY_BITS);   // seen before, in the other orientation only
+                    const uint32_t sh = 16 * (s & 1) + 8 * o;
+                    const uint32_t prev = (atomicAdd(&cnt2[s >> 1], 1u << sh) >> sh) & 0xFFu;                // occurrences so far (the limit of
+                    if (prev + 1 > limit) my_flags |= LDS_EXCEED;                                            // scripts/density.py:516-527)
+                    break;
+                }
+                s = (s + 1) & M;
+                if (++probes >= LDS_SLOTS) { my_flags |= LDS_OVERFLOW; break; }
             }
-            s = (s + 1) & (LDS_SLOTS - 1);
-            if (++probes >= LDS_SLOTS) { my_flags |= LDS_OVERFLOW; break; }
         }
     };
-#pragma unroll
-    for (int u = 0; u < KU; ++u) if (ok_r[u]) insert(kmer_from_words(kw_r[u], jd.ref_abs + pos_r[u], k));
-    for (uint32_t e0 = threadIdx.x + KU * LDS_THREADS; e0 < n_ref; e0 += KU * LDS_THREADS) {         // a partition longer than one step
+    insert_step(kw_r, pos_r, ok_r);
+    for (uint32_t e0 = threadIdx.x + KU * LDS_THREADS; e0 - threadIdx.x < n_ref; e0 += KU * LDS_THREADS) {   // a partition longer than one step
         uint32_t pos[KU]; bool ok[KU]; KmerWords kw[KU];
 #pragma unroll
         for (int u = 0; u < KU; ++u) { const uint32_t e = e0 + u * LDS_THREADS; ok[u] = e < n_ref; pos[u] = list_r[ok[u] ? e : n_ref - 1]; }
 #pragma unroll
         for (int u = 0; u < KU; ++u) kw[u] = kmer_words(R.two, jd.ref_abs + pos[u]);
-#pragma unroll
-        for (int u = 0; u < KU; ++u) if (ok[u]) insert(kmer_from_words(kw[u], jd.ref_abs + pos[u], k));
+        insert_step(kw, pos, ok);
     }
-#ifndef PAV_KMER_EARLY_TIG
 #pragma unroll
-    for (int u = 0; u < KU; ++u) kw_t[u] = kmer_words(T.two, jd.tig_abs + pos_t[u]);
-#endif
+    for (int u = 0; u < KU; ++u) {
+        if constexpr (ABL_W) kw_t[u] = KmerWords{(uint64_t)pos_t[u] * 0x9E3779B97F4A7C15ull, (uint64_t)pos_t[u] * 0xC2B2AE3D27D4EB4Full};
+        else kw_t[u] = kmer_words(T.two, jd.tig_abs + pos_t[u]);
+    }
     if (my_flags) atomicOr(&flags, my_flags);
     __syncthreads();
     if (threadIdx.x == 0 && flags) atomicOr(&stat[it.job].lds_flags, flags);
 
-    // contig k-mers: "is it in the set" and "is its reverse complement" are the two orientation counts of its canonical key
-    auto answer = [&](uint64_t x, uint32_t pos) __attribute__((always_inline)) {
-        bool other, self_rc;
-        const uint64_t key = canon_key(x, k, &other, &self_rc);
-        uint32_t s = khash(key) & (LDS_SLOTS - 1);
-        uint32_t same = 0, opposite = 0;
-        for (int probes = 0; probes < LDS_SLOTS; ++probes) {
-            const unsigned long long cur = keys[s];
-            if (cur == key) {
-                const uint32_t w = cnt2[s >> 1] >> (16 * (s & 1));
-                const uint32_t c0 = w & 0xFFu, c1 = (w >> 8) & 0xFFu;
-                same = other ? c1 : c0; opposite = self_rc ? c0 : (other ? c0 : c1);
-                break;
-            }
-            if (cur == EMPTY_KEY) break;
-            s = (s + 1) & (LDS_SLOTS - 1);
+    // contig k-mers: "is it in the set" and "is its reverse complement" are the two orientation bits of its canonical key.
+    // STATE_MER (scripts/density.py:38-43,165-175: KMER_ORIENTATION_STATE) goes straight to the tile array - k_bucket_tig has
+    // put -1 at every position, a k-mer in neither set leaves it there.
+    auto answer_step = [&](const KmerWords (&kw)[KU], const uint32_t (&pos)[KU], const bool (&ok)[KU]) __attribute__((always_inline)) {
+        if constexpr (ABL == 2 || ABL == 5) {
+            uint64_t acc = 0;
+            for (int u = 0; u < KU; ++u) acc += kw[u].v0 ^ kw[u].v1 ^ pos[u];
+            if (acc == 0x123456789ull && ok[0]) st_tmp[0] = 1;
+            return;
         }
-        ans_f[jd.tpos_off + pos] = (uint8_t)(same ? ANS_PRESENT : ANS_ABSENT);
-        ans_c[jd.tpos_off + pos] = (uint8_t)(opposite ? ANS_PRESENT : ANS_ABSENT);
-    };
 #pragma unroll
-    for (int u = 0; u < KU; ++u) if (ok_t[u]) answer(kmer_from_words(kw_t[u], jd.tig_abs + pos_t[u], k), pos_t[u]);
-    for (uint32_t e0 = threadIdx.x + KU * LDS_THREADS; e0 < n_tig; e0 += KU * LDS_THREADS) {
+        for (int u = 0; u < KU; ++u) if (ok[u]) {
+            bool other, self_rc;
+            const uint64_t key = canon_key(kmer_from_words(kw[u], jd.tig_abs + pos[u], k), k, &other, &self_rc);
+            uint32_t s = khash(key) & M;
+            for (int probes = 0; probes < LDS_SLOTS; ++probes) {
+                const unsigned long long cur = keys[s];
+                if ((cur & KEY_BITS) == key) {                              // (EMPTY has all 62 bits set: no k-mer is that key)
+                    const bool c0 = (cur >> KEY_O_SHIFT) & 1ull, c1 = cur >> 63;
+                    const bool same = other ? c1 : c0, opposite = self_rc ? c0 : (other ? c0 : c1);
+                    if constexpr (ABL != 1) st_tmp[jd.tpos_off + pos[u]] = (int8_t)(same ? (opposite ? 1 : 0) : 2);
+                    else if (same && opposite && pos[u] == 0xFFFFFFF0u) st_tmp[0] = 1;
+                    break;
+                }
+                if (cur == EMPTY_KEY) break;
+                s = (s + 1) & M;
+            }
+        }
+    };
+    answer_step(kw_t, pos_t, ok_t);
+    for (uint32_t e0 = threadIdx.x + KU * LDS_THREADS; e0 - threadIdx.x < n_tig; e0 += KU * LDS_THREADS) {
         uint32_t pos[KU]; bool ok[KU]; KmerWords kw[KU];
 #pragma unroll
         for (int u = 0; u < KU; ++u) { const uint32_t e = e0 + u * LDS_THREADS; ok[u] = e < n_tig; pos[u] = list_t[ok[u] ? e : n_tig - 1]; }
 #pragma unroll
         for (int u = 0; u < KU; ++u) kw[u] = kmer_words(T.two, jd.tig_abs + pos[u]);
-#pragma unroll
-        for (int u = 0; u < KU; ++u) if (ok[u]) answer(kmer_from_words(kw[u], jd.tig_abs + pos[u], k), pos[u]);
+        answer_step(kw, pos, ok);
     }
 }
 
-// STATE_MER from the two membership answers (scripts/density.py:38-43,165-175), one workgroup per tile, 8 positions per lane;
-// jobs with HBM tables were done by k_tig_state.
+// Per-tile and per-job counts of the STATE_MER values k_kmer_lds has written (+ the span of FWD k-mers for scan-only batches),
+// one workgroup per tile, 8 positions per lane; jobs with HBM tables were done by k_tig_state.
 __global__ __launch_bounds__(256) void k_state_combine(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
-                                                       const uint8_t *__restrict__ ans_f, const uint8_t *__restrict__ ans_c,
-                                                       int8_t *__restrict__ st_tmp, JobStat *__restrict__ stat,
+                                                       const int8_t *__restrict__ st_tmp, JobStat *__restrict__ stat,
                                                        uint32_t *__restrict__ tile_cnt /* [tiles][4]: [1 + s] rows of state s; null: not wanted */,
                                                        int want_span = 0) {
     __shared__ uint32_t red[4][3];
@@ -604,22 +626,14 @@ __global__ __launch_bounds__(256) void k_state_combine(const JobDev *__restrict_
     if (!jobs[j].n_parts) return;
     uint32_t fwd_lo = ~0u, fwd_hi = 0;
     const uint64_t at = (uint64_t)blockIdx.x * DTILE + (uint64_t)threadIdx.x * 8;
-    const uint64_t f8 = *reinterpret_cast<const uint64_t *>(ans_f + at), c8 = *reinterpret_cast<const uint64_t *>(ans_c + at);
-    uint64_t out = 0;
+    const uint64_t s8 = *reinterpret_cast<const uint64_t *>(st_tmp + at);
     uint32_t n[3] = {0, 0, 0};
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-        const uint32_t f = (uint32_t)(f8 >> (8 * t)) & 0xFFu, c = (uint32_t)(c8 >> (8 * t)) & 0xFFu;
-        int st = -1;
-        if (f != ANS_INVALID) {
-            const bool in_f = f == ANS_PRESENT, in_r = c == ANS_PRESENT;
-            st = in_f ? (in_r ? 1 : 0) : (in_r ? 2 : -1);            // KMER_ORIENTATION_STATE
-        }
+        const int st = (int)(int8_t)(uint8_t)(s8 >> (8 * t));
         if (st >= 0) n[st]++;
         if (st == 0) { if (fwd_lo == ~0u) fwd_lo = (uint32_t)t; fwd_hi = (uint32_t)t; }
-        out |= (uint64_t)(uint8_t)(int8_t)st << (8 * t);
     }
-    *reinterpret_cast<uint64_t *>(st_tmp + at) = out;
     // first / last position of the region with a FWD k-mer (scan-only batches): lanes hold rising positions, so a wave's first
     // is its lowest lane's and its last its highest lane's; one pair of atomics per workgroup
     __shared__ uint32_t span[4][2];
@@ -2161,8 +2175,6 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     if (!items.empty()) {
         if (n_bcount > 0xFFFFFFFFull) return fail(ctx, PAV_E_LIMIT, "pav_density_batch: too many k-mer partitions in one batch");
         PAV_HIP(ctx, D->lists.reserve(4 * n_lists));
-        PAV_HIP(ctx, D->ans_f.reserve(a_t));
-        PAV_HIP(ctx, D->ans_c.reserve(a_t));
     }
     PAV_HIP(ctx, D->st_tmp.reserve(a_t + 64));
     PAV_HIP(ctx, D->tile_sum.reserve(16ull * n_tiles_t));
@@ -2216,12 +2228,25 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
         PAV_LAUNCH(ctx, "k_bucket_ref", k_bucket_ref, n_tiles_r, 256, 0, d_jobs, d_tjr, RV, k, D->lists.as<uint32_t>(),
                    D->bcount.as<uint32_t>(), d_stat);
         PAV_LAUNCH(ctx, "k_bucket_tig", k_bucket_tig, n_tiles_t, 256, 0, d_jobs, d_tjt, TV, k, D->lists.as<uint32_t>(),
-                   D->bcount.as<uint32_t>(), D->ans_f.as<uint8_t>(), d_stat);
-        PAV_LAUNCH(ctx, "k_kmer_lds", k_kmer_lds, (uint32_t)items.size(), LDS_THREADS, 0, D->items.as<PartItem>(), d_jobs, RV, TV, k,
-                   pp->max_ref_kmer_count, D->lists.as<uint32_t>(), D->bcount.as<uint32_t>(), D->ans_f.as<uint8_t>(),
-                   D->ans_c.as<uint8_t>(), d_stat);
-        PAV_LAUNCH(ctx, "k_state_combine", k_state_combine, n_tiles_t, 256, 0, d_jobs, d_tjt, D->ans_f.as<uint8_t>(),
-                   D->ans_c.as<uint8_t>(), D->st_tmp.as<int8_t>(), d_stat, D->tile_sum.as<uint32_t>(), scan_only ? 1 : 0);
+                   D->bcount.as<uint32_t>(), D->st_tmp.as<int8_t>(), d_stat);
+#ifdef PAV_TUNING             // an ablated instance in front of the real one, into a scratch array: what each part of the kernel costs
+        if (const char *abl = getenv("PAV_KMER_ABL")) {
+            static DevBuf scratch, scratch_stat;                                  // (flags of the ablated run go nowhere that is read)
+            PAV_HIP(ctx, scratch.reserve(a_t + 64));
+            PAV_HIP(ctx, scratch_stat.reserve(sizeof(JobStat) * n_jobs));
+            JobStat *no_stat = scratch_stat.as<JobStat>();
+#define PAV_ABL_LAUNCH(A, W) PAV_LAUNCH(ctx, "k_kmer_abl", (k_kmer_lds<A, W>), (uint32_t)items.size(), LDS_THREADS, 0, D->items.as<PartItem>(), d_jobs, RV, TV, k, \
+                   pp->max_ref_kmer_count, D->lists.as<uint32_t>(), D->bcount.as<uint32_t>(), scratch.as<int8_t>(), no_stat)
+            const std::string a = abl;
+            if (a == "0") PAV_ABL_LAUNCH(0, 0); else if (a == "1") PAV_ABL_LAUNCH(1, 0); else if (a == "2") PAV_ABL_LAUNCH(2, 0);
+            else if (a == "3") PAV_ABL_LAUNCH(3, 0); else if (a == "5") PAV_ABL_LAUNCH(5, 0); else if (a == "w") PAV_ABL_LAUNCH(0, 1);
+            else if (a == "5w") PAV_ABL_LAUNCH(5, 1); else if (a == "1w") PAV_ABL_LAUNCH(1, 1);
+        }
+#endif
+        PAV_LAUNCH(ctx, "k_kmer_lds", (k_kmer_lds<0, 0>), (uint32_t)items.size(), LDS_THREADS, 0, D->items.as<PartItem>(), d_jobs, RV, TV, k,
+                   pp->max_ref_kmer_count, D->lists.as<uint32_t>(), D->bcount.as<uint32_t>(), D->st_tmp.as<int8_t>(), d_stat);
+        PAV_LAUNCH(ctx, "k_state_combine", k_state_combine, n_tiles_t, 256, 0, d_jobs, d_tjt, D->st_tmp.as<int8_t>(), d_stat,
+                   D->tile_sum.as<uint32_t>(), scan_only ? 1 : 0);
     }
     if (n_hbm_jobs) {
         PAV_LAUNCH(ctx, "k_ref_insert", k_ref_insert, (uint32_t)(a_r / 256), 256, 0, d_jobs, d_tjr, RV, k, pp->max_ref_kmer_count,

@@ -42,6 +42,9 @@ def main():
             continue
         diff = {n: (base['ms_per_step'].get(n), v) for n, v in k['ms_per_step'].items()
                 if base['ms_per_step'].get(n) is None or abs(v - base['ms_per_step'][n]) > 0.03 * max(v, base['ms_per_step'][n], 1e-9)}
+        watch = os.environ.get('PAV_VARIANT_WATCH')
+        if watch:
+            print(f'{name:9s} {watch}: ' + ', '.join(f'{w} {k["ms_per_step"].get(w)} ms in {k.get("launches_per_step", {}).get(w)} launches' for w in watch.split(',')), flush=True)
         print(f'{name:9s} one lane {ms:.3f} ms/step  kernels {k["sum_ms_per_step"]:.3f} ms/step  ' +
               ' '.join(f'{n}: {a} -> {b}' for n, (a, b) in sorted(diff.items(), key=lambda kv: -abs((kv[1][0] or 0) - kv[1][1]))[:10]), flush=True)
 

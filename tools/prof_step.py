@@ -73,7 +73,8 @@ def main():
         prof = ctx.prof_read()
         ctx.prof_enable(False)
         per = {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
-        print('KERNELS ' + json.dumps({'lib': _lib.LIB_PATH, 'sum_ms_per_step': round(sum(per.values()), 4), 'ms_per_step': per}))
+        print('KERNELS ' + json.dumps({'lib': _lib.LIB_PATH, 'sum_ms_per_step': round(sum(per.values()), 4), 'ms_per_step': per,
+                                       'launches_per_step': {k: round(v[0] / args.steps, 2) for k, v in prof.items()}}))
     if args.plain:
         ctx.close()
         return
