@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -128,6 +129,8 @@ struct pav_ctx {
     bool tables_pending = false;
     hipEvent_t tables_done_prev = nullptr;   // same for the scan before it: its tables live in the other pinned arena, so a new
     bool tables_pending_prev = false;        // scan does not wait for them (the two are swapped when a scan starts)
+    std::function<void()> den_overlap;    // set by the inversion-scan driver around pav_density_batch: host work that does not depend on
+                                          // the batch (log texts), run once while the batch's kernels are executing
     bool den_scan_only = false;           // set by the inversion-scan driver around pav_density_batch: only run lists and the tables of
                                           // regions that can become calls will be read (density.hip, fwd_only)
     hipEvent_t hom_done = nullptr;        // pav_cigar_call: recorded behind the homology scans on stream2 (wait_homology)

@@ -2038,7 +2038,8 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     D->n_jobs = n_jobs;
     D->params = *pp;
     D->results.assign(n_jobs, pav_den_result{});
-    D->runs.assign(n_jobs, {});
+    D->runs.resize(n_jobs);                                              // (cleared, not rebuilt: a thousand small vectors keep their blocks)
+    for (auto &r : D->runs) r.clear();
     D->no_table.assign(n_jobs, 0);
     if (n_jobs == 0) { D->valid = true; return PAV_OK; }
     const SeqStore &RS = ctx->seq[PAV_ROLE_REF], &TS = ctx->seq[PAV_ROLE_TIG];
@@ -2055,6 +2056,8 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     std::vector<PartItem> items;
     uint32_t n_hbm_jobs = 0;
     uint64_t n_lists = 0, n_bcount = 0;
+    uint64_t total_parts = 0, max_parts = 0, samp_ub = 0, n_eval_tiles_ub = 0;
+    D->h_kde.assign(n_jobs, JobKde{});
     for (uint32_t j = 0; j < n_jobs; ++j) {
         const pav_den_job &q = jobs[j];
         if (q.ref_id >= RS.n || q.tig_id >= TS.n) return fail(ctx, PAV_E_ARG, "pav_density_batch: job %u references a sequence that is not loaded", j);
@@ -2077,6 +2080,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             jd.cap_t = bucket_cap(jd.tig_len, jd.n_parts);
             jd.list_off_r = n_lists; n_lists += parts * jd.cap_r;
             jd.list_off_t = n_lists; n_lists += parts * jd.cap_t;
+            total_parts += parts; max_parts = std::max<uint64_t>(max_parts, parts);
         } else {
             const uint32_t cap = pow2_at_least(2ull * jd.ref_len + 2);
             jd.ht_off = a_h; jd.ht_mask = cap - 1; a_h += cap;
@@ -2088,10 +2092,23 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
         tile_job_r.insert(tile_job_r.end(), tr, j);
         tile_job_t.insert(tile_job_t.end(), tt, j);
         a_r += tr * DTILE; a_t += tt * DTILE;
+        // what is known before anything runs (device-planned batches: upper bounds; rows <= contig positions of the region)
+        JobKde &kd = D->h_kde[j];
+        kd.srs = jd.srs;
+        kd.samp_off = (uint32_t)samp_ub;
+        kd.heads_off = jd.first_tile * HEADS_PER_TILE;
+        const uint32_t ns = (std::max<uint32_t>(jd.tig_len, 1) + jd.srs - 1) / jd.srs + 1;
+        samp_ub += ns;
+        n_eval_tiles_ub += (ns + 63) / 64;
     }
     D->arena_t = a_t;
     const uint32_t n_tiles_r = (uint32_t)tile_job_r.size(), n_tiles_t = (uint32_t)tile_job_t.size();
-    {   // One workgroup per (job, partition), the long scans first - and all partitions of a job on ONE XCD (workgroup b runs on
+    const bool have_lds = total_parts > 0;
+    // The partition items and the evaluation tiles are planned BEHIND the launch of the bucket kernels, which do not read them
+    // (plan_behind below): their slices of the input arena are sized from bounds here.  XCD-grouped items are padded: the longest
+    // of the eight queues is at most total / 8 + the largest job.
+    const size_t items_ub = have_lds ? (size_t)(total_parts + 8 * max_parts) : 0;
+    auto plan_items = [&]() {   // One workgroup per (job, partition), the long scans first - and all partitions of a job on ONE XCD (workgroup b runs on
         // XCD b % 8, observed; used for speed only): the workgroups of a job answer into the same byte arrays, one byte per
         // contig k-mer at scattered positions, and read the same windows of the planes.  Spread over the eight L2s every line of
         // the answers left the chip once per XCD that had touched it (205 MB written per launch for 20 MB of answers); in one L2
@@ -2119,38 +2136,37 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
                 for (int x = 0; x < XCDS; ++x) items.push_back(r < q[x].size() ? q[x][r] : PartItem{~0u, 0u});   // ~0: nothing to do
             while (!items.empty() && items.back().job == ~0u) items.pop_back();
         }
-    }
+    };
 
-    // ---- what is known before anything runs (device-planned batches: upper bounds; rows <= contig positions of the region) -----
     const bool want_runs = pp->kde_mode != PAV_KDE_DIRECT;
-    bool fast = want_runs && n_hbm_jobs == 0 && !items.empty() && getenv("PAV_DENSITY_HOST") == nullptr;
+    bool fast = want_runs && n_hbm_jobs == 0 && have_lds && getenv("PAV_DENSITY_HOST") == nullptr && samp_ub <= 0xFFFFFFFFull;
     // the caller reads run lists only, and tables of calls: regions with FWD k-mers only are settled from their counts (fwd_only)
     const bool scan_only = fast && ctx->den_scan_only && getenv("PAV_SCAN_FULL") == nullptr;
-    D->h_kde.assign(n_jobs, JobKde{});
     std::vector<EvalTile> tiles_ub;
-    uint64_t samp_ub = 0;
-    for (uint32_t j = 0; j < n_jobs; ++j) {
-        JobKde &kd = D->h_kde[j];
-        const JobDev &jd = D->h_jobs[j];
-        kd.srs = jd.srs;
-        kd.samp_off = (uint32_t)samp_ub;
-        kd.heads_off = jd.first_tile * HEADS_PER_TILE;
-        const uint32_t ns = (std::max<uint32_t>(jd.tig_len, 1) + jd.srs - 1) / jd.srs + 1;
-        samp_ub += ns;
-        if (fast) for (uint32_t f = 0; f < ns; f += 64) tiles_ub.push_back(EvalTile{j, f, 64u, 0u});
-    }
-    if (samp_ub > 0xFFFFFFFFull) { fast = false; tiles_ub.clear(); }
+    const size_t tiles_cap = fast ? (size_t)n_eval_tiles_ub : 0;
+    auto plan_tiles = [&]() {
+        if (!fast) return;
+        tiles_ub.reserve(tiles_cap);
+        for (uint32_t j = 0; j < n_jobs; ++j) {
+            const JobDev &jd = D->h_jobs[j];
+            const uint32_t ns = (std::max<uint32_t>(jd.tig_len, 1) + jd.srs - 1) / jd.srs + 1;
+            for (uint32_t f = 0; f < ns; f += 64) tiles_ub.push_back(EvalTile{j, f, 64u, 0u});
+        }
+    };
     // the event list as large as either path asks for (prepare_events)
     uint32_t ev_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(65536, (a_t + 16ull * n_tiles_t) / 16 + 4ull * n_jobs), 0x7FFFFFFF);
 
     // ---- the two arenas of small buffers ------------------------------------------------------------------------------------
     struct Slice { DevBuf *buf; const void *src; size_t bytes, at; };
     auto lay = [](std::vector<Slice> &v, size_t at0) { size_t at = at0; for (Slice &x : v) { x.at = at; at += (x.bytes + 255) / 256 * 256; } return at; };
+    // (the first four go up in front of the bucket kernels, the last two behind their launch)
     std::vector<Slice> in_sl = {{&D->jobs, D->h_jobs.data(), sizeof(JobDev) * n_jobs, 0}, {&D->tile_job_r, tile_job_r.data(), 4ull * n_tiles_r, 0},
-                                {&D->tile_job_t, tile_job_t.data(), 4ull * n_tiles_t, 0}, {&D->items, items.data(), sizeof(PartItem) * items.size(), 0},
+                                {&D->tile_job_t, tile_job_t.data(), 4ull * n_tiles_t, 0},
                                 {&D->kde, fast ? D->h_kde.data() : nullptr, sizeof(JobKde) * n_jobs, 0},
-                                {&D->tiles, tiles_ub.data(), sizeof(EvalTile) * tiles_ub.size(), 0}};
+                                {&D->items, nullptr, sizeof(PartItem) * items_ub, 0},
+                                {&D->tiles, nullptr, sizeof(EvalTile) * tiles_cap, 0}};
     const size_t in_bytes = lay(in_sl, 0);
+    const size_t in_front = in_sl[4].at;
     // front of the zero arena = what comes back: event count (64) | guard (64) | plan flags (64) | statistics | event list
     constexpr size_t ZH = 192;
     std::vector<Slice> z_sl = {{&D->stat, nullptr, sizeof(JobStat) * n_jobs, 0}, {&D->events, nullptr, sizeof(HeadEvent) * (size_t)ev_cap, 0},
@@ -2172,7 +2188,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
 
     PAV_HIP(ctx, D->keys.reserve(8 * a_h));
     PAV_HIP(ctx, D->cnt.reserve(4 * a_h));
-    if (!items.empty()) {
+    if (have_lds) {
         if (n_bcount > 0xFFFFFFFFull) return fail(ctx, PAV_E_LIMIT, "pav_density_batch: too many k-mer partitions in one batch");
         PAV_HIP(ctx, D->lists.reserve(4 * n_lists));
     }
@@ -2199,7 +2215,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     }
     hipStream_t st = ctx->stream;
     lap("plan+alloc");
-    PAV_HIP(ctx, hipMemcpyAsync(D->in_arena.p, h_in, in_bytes, hipMemcpyHostToDevice, st));
+    PAV_HIP(ctx, hipMemcpyAsync(D->in_arena.p, h_in, in_front, hipMemcpyHostToDevice, st));
     PAV_HIP(ctx, hipMemsetAsync(D->zero_arena.p, 0, z_sl[1].at, st));                                  // event count .. statistics
     PAV_HIP(ctx, hipMemsetAsync(D->zero_arena.as<uint8_t>() + z_sl[2].at, 0, z_bytes - z_sl[2].at, st));   // bucket counts, guard flags
     if (a_h) {
@@ -2224,11 +2240,22 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
         const int rcw = need_planes_spans(ctx, PAV_ROLE_TIG, spans);
         if (rcw != PAV_OK) return rcw;
     }
-    if (!items.empty()) {
+    if (have_lds) {
         PAV_LAUNCH(ctx, "k_bucket_ref", k_bucket_ref, n_tiles_r, 256, 0, d_jobs, d_tjr, RV, k, D->lists.as<uint32_t>(),
                    D->bcount.as<uint32_t>(), d_stat);
         PAV_LAUNCH(ctx, "k_bucket_tig", k_bucket_tig, n_tiles_t, 256, 0, d_jobs, d_tjt, TV, k, D->lists.as<uint32_t>(),
                    D->bcount.as<uint32_t>(), D->st_tmp.as<int8_t>(), d_stat);
+    }
+    {   // plan_behind: the partition items (XCD order) and the evaluation tiles, while the bucket kernels run
+        plan_items();
+        plan_tiles();
+        if (items.size() > items_ub || tiles_ub.size() > tiles_cap) return fail(ctx, PAV_E_STATE, "pav_density_batch: plan bounds (%zu / %zu items, %zu / %zu tiles)", items.size(), items_ub, tiles_ub.size(), tiles_cap);
+        if (!items.empty()) memcpy(h_in + in_sl[4].at, items.data(), sizeof(PartItem) * items.size());
+        if (!tiles_ub.empty()) memcpy(h_in + in_sl[5].at, tiles_ub.data(), sizeof(EvalTile) * tiles_ub.size());
+        if (in_bytes > in_front) PAV_HIP(ctx, hipMemcpyAsync(D->in_arena.as<uint8_t>() + in_front, h_in + in_front, in_bytes - in_front, hipMemcpyHostToDevice, st));
+        lap("plan behind");
+    }
+    if (have_lds) {
 #ifdef PAV_TUNING             // an ablated instance in front of the real one, into a scratch array: what each part of the kernel costs
         if (const char *abl = getenv("PAV_KMER_ABL")) {
             static DevBuf scratch, scratch_stat;                                  // (flags of the ablated run go nowhere that is read)
@@ -2439,6 +2466,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             const size_t rb_events = z_sl[1].at, rb_bytes = rb_events + sizeof(HeadEvent) * (size_t)pre;
             uint8_t *h_rb = h_pin;
             PAV_HIP(ctx, hipMemcpyAsync(h_rb, D->zero_arena.p, rb_bytes, hipMemcpyDeviceToHost, st));
+            if (ctx->den_overlap) { auto f = std::move(ctx->den_overlap); ctx->den_overlap = nullptr; f(); lap("overlapped"); }   // the caller's deferred host work
             PAV_HIP(ctx, hipStreamSynchronize(st));
             lap("device plan");
             if (timing) fprintf(stderr, "[pav timing]   device-planned batches so far: %llu, sent back to the host-planned path: %llu\n",
@@ -2468,7 +2496,22 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
                 if (n_ev) memcpy(ev.data(), h_rb + rb_events, sizeof(HeadEvent) * std::min(n_ev, pre));
                 if (n_ev > pre)
                     PAV_HIP(ctx, hipMemcpy(ev.data() + pre, D->events.as<HeadEvent>() + pre, sizeof(HeadEvent) * (n_ev - pre), hipMemcpyDeviceToHost));
-                std::sort(ev.begin(), ev.end(), [](const HeadEvent &x, const HeadEvent &y) { return x.job != y.job ? x.job < y.job : x.row < y.row; });
+                // by (job, row): a counting pass over the jobs, then the handful of heads of each job by row (a comparison sort of
+                // the whole list was 0.05 ms of a thousand-region round)
+                bool in_range = true;
+                std::vector<uint32_t> at(n_jobs + 1, 0);
+                for (const HeadEvent &h : ev) { if (h.job >= n_jobs) { in_range = false; break; } at[h.job + 1]++; }
+                if (in_range) {
+                    for (uint32_t j = 0; j < n_jobs; ++j) at[j + 1] += at[j];
+                    std::vector<HeadEvent> by(ev.size());
+                    std::vector<uint32_t> put(at.begin(), at.end() - 1);
+                    for (const HeadEvent &h : ev) by[put[h.job]++] = h;
+                    for (uint32_t j = 0; j < n_jobs; ++j) {
+                        HeadEvent *b = by.data() + at[j], *e = by.data() + at[j + 1];
+                        if (e - b > 1) std::sort(b, e, [](const HeadEvent &x, const HeadEvent &y) { return x.row < y.row; });
+                    }
+                    ev.swap(by);
+                } else std::sort(ev.begin(), ev.end(), [](const HeadEvent &x, const HeadEvent &y) { return x.job != y.job ? x.job < y.job : x.row < y.row; });
             }
             bool redo = ev_lost || h_flags[0] != 0 || h_guard.n_entries != 0 || h_guard.overflow != 0 || h_flags[1] >= FP.cap;
             for (uint32_t j = 0; j < n_jobs && !redo; ++j) redo = hs[j].lds_flags != 0;

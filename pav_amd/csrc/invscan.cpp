@@ -746,6 +746,26 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
     double t_batch = 0, t_table = 0, t_pre = 0, t_post = 0, t_lift = 0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_start = now();
+    // point lifts of the regions of the NEXT round, asked for together with the breakpoint lifts of this one
+    std::vector<Driver::Point> carried; std::vector<uint32_t> carried_first; bool carried_valid = false;
+    auto queue_region_lifts = [&](const std::vector<uint32_t> &rgns, std::vector<LiftQuery> &lq, std::vector<uint32_t> &first) {
+        first.assign(rgns.size(), ~0u);
+        lq.reserve(lq.size() + 2 * rgns.size());
+        for (size_t q = 0; q < rgns.size(); ++q) {
+            const Scan &sc = scans[rgns[q]];
+            if (0 < max_region_size && max_region_size < sc.region_ref.len()) continue;      // too large: no lift (reported in the round)
+            first[q] = (uint32_t)lq.size();
+            lq.push_back(LiftQuery{0, sc.region_ref.chrom, 0, 0, sc.region_ref.pos});
+            lq.push_back(LiftQuery{0, sc.region_ref.chrom, 0, 0, sc.region_ref.end});
+        }
+    };
+    // "Found no inverted k-mer states ..." of the regions a round has settled (a thousand of them in the first round): a region that
+    // ends gets no further line, so its last one is written while the next round's kernels run, or behind the last round
+    std::vector<std::pair<uint32_t, int>> notes;                          // (region, expansions)
+    auto flush_notes = [&]() {
+        pool.run(notes.size(), CHUNK, [&](size_t q) { log(notes[q].first, "Found no inverted k-mer states after " + fmt_i(notes[q].second) + " expansion(s)"); });
+        notes.clear();
+    };
     while (!live.empty()) {
         std::vector<pav_den_job> jobs; std::vector<uint32_t> owners, rest;
         uint64_t budget = 0;
@@ -753,22 +773,20 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
         // top of the while-loop, inv.py:223-260.  Lifts first (every live region, no side effects) ...
         struct Pre { uint8_t kind; uint32_t job; Rgn tig; std::string err; };   // kind 0: too large, 1: lift raised, 2: not liftable, 3: lifted
         std::vector<Pre> pre(live.size());
-        {   // both ends of every live region in one batch of point lifts (lift_dev.hip; PAV_LIFT_HOST=1: the host tables)
-            std::vector<LiftQuery> lq;
-            std::vector<uint32_t> first(live.size(), ~0u);
-            lq.reserve(2 * live.size());
-            for (size_t q = 0; q < live.size(); ++q) {
-                const Scan &sc = scans[live[q]];
-                if (0 < max_region_size && max_region_size < sc.region_ref.len()) { pre[q].kind = 0; continue; }
-                first[q] = (uint32_t)lq.size();
-                lq.push_back(LiftQuery{0, sc.region_ref.chrom, 0, 0, sc.region_ref.pos});
-                lq.push_back(LiftQuery{0, sc.region_ref.chrom, 0, 0, sc.region_ref.end});
-            }
-            std::vector<Driver::Point> lp;
-            const int rcl = D.lift_batch(lq, lp);
-            if (rcl != PAV_OK) return rcl;
+        {   // both ends of every live region through the alignment table: point lifts on the device (lift_dev.hip; PAV_LIFT_HOST=1:
+            // the host tables).  The first round asks for them here; later rounds find them done - they travelled with the
+            // breakpoint lifts of the round before (one round trip to the device per round, not two).
+            std::vector<uint32_t> first;
+            if (!carried_valid) {
+                std::vector<LiftQuery> lq;
+                queue_region_lifts(live, lq, first);
+                const int rcl = D.lift_batch(lq, carried);
+                if (rcl != PAV_OK) return rcl;
+            } else first.swap(carried_first);
+            carried_valid = false;
+            const std::vector<Driver::Point> &lp = carried;
             pool.run(live.size(), CHUNK, [&](size_t q) {
-                if (first[q] == ~0u) return;
+                if (first[q] == ~0u) { pre[q].kind = 0; return; }
                 Pre &x = pre[q];
                 bool ok = false;
                 x.kind = !D.region_from_qry_points(lp[first[q]], lp[first[q] + 1], x.tig, ok, x.err) ? 1 : ok ? 3 : 2;
@@ -798,8 +816,7 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
             if (x.kind == 1) { S->errors[i] = x.err; finish(i, PAV_INV_ERROR); return; }
             if (x.kind == 2) { log(i, "Could not lift reference region onto contigs: " + D.base1(sc.region_ref)); finish(i, PAV_INV_NONE); return; }
             sc.region_tig = x.tig;
-            sc.expansion_count += 1;
-            log(i, "Scanning region: " + D.base1(sc.region_ref));
+            sc.expansion_count += 1;                                        // (its "Scanning region" line is written while the batch runs)
             pav_den_job &j = jobs[x.job];
             j.ref_id = (uint32_t)sc.region_ref.chrom; j.tig_id = (uint32_t)sc.region_tig.chrom;
             j.ref_pos = (uint64_t)sc.region_ref.pos; j.ref_end = (uint64_t)sc.region_ref.end;
@@ -812,8 +829,19 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
         t_pre += t0 - t_p0;
         if (timing) fprintf(stderr, "[pav timing]   scan round: %zu jobs, lift + jobs %.2f ms\n", jobs.size(), (t0 - t_p0) * 1e3);
         ctx->den_scan_only = true;                                          // a call needs REV k-mers: tables of FWD-only regions are never asked for
+        // Texts that nothing in this round depends on are written while the round's kernels run (pav_density_batch calls back once,
+        // between its last launch and its synchronisation): the decision lines of the round before, then this round's first lines.
+        bool overlapped = false;
+        auto texts = [&]() {
+            overlapped = true;
+            flush_notes();
+            pool.run(owners.size(), CHUNK, [&](size_t j) { const uint32_t i = owners[j]; log(i, "Scanning region: " + D.base1(scans[i].region_ref)); });
+        };
+        ctx->den_overlap = texts;
         int rc = pav_density_batch(ctx, (uint32_t)jobs.size(), jobs.data(), &pp->den, res.data());
+        ctx->den_overlap = nullptr;
         ctx->den_scan_only = false;
+        if (!overlapped && rc == PAV_OK) texts();                           // (a batch that took the host-planned path from the start)
         t_batch += now() - t0;
         if (rc != PAV_OK) return rc;
         const double t_q0 = now();
@@ -833,7 +861,7 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
             return 0;
         };
         // after the density call, per region (inv.py:268-351) ...
-        struct Dec { uint8_t what = 0, k1 = 0; CallFetch cf{}; };                   // what 0: finished, 1: expanded, 2: call, 3: internal error,
+        struct Dec { uint8_t what = 0, k1 = 0; int note = 0; CallFetch cf{}; };                   // what 0: finished, 1: expanded, 2: call, 3: internal error,
         std::vector<Dec> dec(jobs.size());                                           //      4: flanked, its breakpoints wait for their lifts
         struct Cand { Rgn t_outer, t_inner; };
         std::vector<Cand> cand(jobs.size());
@@ -862,7 +890,7 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
             sc.n_rows = r.n_rows;
             const auto &rl = sc.state_rl;
             if (rl.size() == 1 && (rl[0].state == 0 || rl[0].state == -1) && sc.expansion_count >= min_exp_count) {
-                log(i, "Found no inverted k-mer states after " + fmt_i(sc.expansion_count) + " expansion(s)");
+                dec[j].note = sc.expansion_count;                                   // most regions end here: the line is written later (flush_notes)
                 finish(i, PAV_INV_NONE); return;
             }
             if (rl.size() > 2 && rl.front().state == 0 && rl.back().state == 0) {
@@ -887,7 +915,12 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
             if (sc.region_ref.len() == last_len) { log(i, "Reached reference limits, cannot expand"); finish(i, PAV_INV_NONE); return; }
             dec[j].what = 1;
         });
-        {   // the breakpoint regions of the flanked jobs -> reference (inv.py:393-406): outer ends without, inner ends with the gap rule
+        // the regions that go on, in region order (known now: a flanked region ends in this round, as a call or not)
+        std::vector<uint32_t> next;
+        for (uint32_t j = 0; j < jobs.size(); ++j) if (dec[j].what == 1) next.push_back(owners[j]);
+        next.insert(next.end(), rest.begin(), rest.end());
+        {   // the breakpoint regions of the flanked jobs -> reference (inv.py:393-406): outer ends without, inner ends with the gap rule;
+            // behind them in the same batch the region ends of the next round
             std::vector<LiftQuery> lq;
             std::vector<uint32_t> pend;
             for (uint32_t j = 0; j < jobs.size(); ++j) {
@@ -897,9 +930,14 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
                 lq.push_back(LiftQuery{1, c.t_outer.chrom, 0, 0, c.t_outer.pos}); lq.push_back(LiftQuery{1, c.t_outer.chrom, 0, 0, c.t_outer.end});
                 lq.push_back(LiftQuery{1, c.t_inner.chrom, 1, 0, c.t_inner.pos}); lq.push_back(LiftQuery{1, c.t_inner.chrom, 1, 0, c.t_inner.end});
             }
+            const size_t n_cand_q = lq.size();
+            queue_region_lifts(next, lq, carried_first);
             std::vector<Driver::Point> lp;
             const int rcl = D.lift_batch(lq, lp);
             if (rcl != PAV_OK) return rcl;
+            carried.assign(lp.begin() + (ptrdiff_t)n_cand_q, lp.end());
+            for (uint32_t &f : carried_first) if (f != ~0u) f -= (uint32_t)n_cand_q;
+            carried_valid = true;
             pool.run(pend.size(), CHUNK, [&](size_t pp_) {
                 const uint32_t j = pend[pp_];
                 const uint32_t i = owners[j];
@@ -947,12 +985,11 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
             });
         }
         // ... and, in region order, the calls of the round and the regions that go on
-        std::vector<uint32_t> next;
         std::vector<CallFetch> round_calls; std::vector<uint32_t> round_owner; std::vector<uint8_t> round_k1;   // round_k1: the call has FWDREV k-mers
         for (uint32_t j = 0; j < jobs.size(); ++j) {
             if (dec[j].what == 3) return fail(ctx, PAV_E_STATE, "pav_inv_scan_batch: the state runs of job %u could not be read", j);
             if (dec[j].what == 2) { round_calls.push_back(dec[j].cf); round_owner.push_back(owners[j]); round_k1.push_back(dec[j].k1); }
-            else if (dec[j].what == 1) next.push_back(owners[j]);
+            if (dec[j].note) notes.emplace_back(owners[j], dec[j].note);
         }
         t_post += now() - t_q0;
         if (timing) fprintf(stderr, "[pav timing]   scan round: decisions %.2f ms, %zu calls\n", (now() - t_q0) * 1e3, round_calls.size());
@@ -990,9 +1027,9 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
             t_table += now() - t0;
             if (rc != PAV_OK) return rc;
         }
-        next.insert(next.end(), rest.begin(), rest.end());
         live.swap(next);
     }
+    flush_notes();
     if (timing) fprintf(stderr, "[pav timing] inv_scan_batch setup %.2f ms: texts %.3f, wait tables %.3f, tables %.3f, scans %.3f, first lines %.3f\n", (t_start - t_entry) * 1e3,
                         (tl[0] - t_entry) * 1e3, (tl[1] - tl[0]) * 1e3, (tl[2] - tl[1]) * 1e3, (tl[3] - tl[2]) * 1e3, (tl[4] - tl[3]) * 1e3);
     if (timing) fprintf(stderr, "[pav timing] inv_scan_batch %.1f ms: density_batch %.1f, call tables + annotate %.1f, lift + jobs %.2f (lifting %.2f), decisions %.2f\n",
