@@ -2240,15 +2240,19 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
         const int rcw = need_planes_spans(ctx, PAV_ROLE_TIG, spans);
         if (rcw != PAV_OK) return rcw;
     }
+    lap("copies+spans");
     if (have_lds) {
         PAV_LAUNCH(ctx, "k_bucket_ref", k_bucket_ref, n_tiles_r, 256, 0, d_jobs, d_tjr, RV, k, D->lists.as<uint32_t>(),
                    D->bcount.as<uint32_t>(), d_stat);
         PAV_LAUNCH(ctx, "k_bucket_tig", k_bucket_tig, n_tiles_t, 256, 0, d_jobs, d_tjt, TV, k, D->lists.as<uint32_t>(),
                    D->bcount.as<uint32_t>(), D->st_tmp.as<int8_t>(), d_stat);
     }
+    lap("buckets out");
     {   // plan_behind: the partition items (XCD order) and the evaluation tiles, while the bucket kernels run
         plan_items();
+        lap("items");
         plan_tiles();
+        lap("tiles");
         if (items.size() > items_ub || tiles_ub.size() > tiles_cap) return fail(ctx, PAV_E_STATE, "pav_density_batch: plan bounds (%zu / %zu items, %zu / %zu tiles)", items.size(), items_ub, tiles_ub.size(), tiles_cap);
         if (!items.empty()) memcpy(h_in + in_sl[4].at, items.data(), sizeof(PartItem) * items.size());
         if (!tiles_ub.empty()) memcpy(h_in + in_sl[5].at, tiles_ub.data(), sizeof(EvalTile) * tiles_ub.size());
@@ -2489,6 +2493,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             if (G.g) memcpy(&h_guard, h_rb + 64, sizeof h_guard);
             memcpy(h_flags, h_rb + 128, sizeof h_flags);
             memcpy(hs.data(), h_rb + z_sl[0].at, sizeof(JobStat) * n_jobs);
+            lap("rl: stats");
             std::vector<HeadEvent> ev;
             const bool ev_lost = n_ev > ev_cap;                                  // more run heads than the list holds: the other path
             if (!ev_lost) {
@@ -2513,6 +2518,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
                     ev.swap(by);
                 } else std::sort(ev.begin(), ev.end(), [](const HeadEvent &x, const HeadEvent &y) { return x.job != y.job ? x.job < y.job : x.row < y.row; });
             }
+            lap("rl: events");
             bool redo = ev_lost || h_flags[0] != 0 || h_guard.n_entries != 0 || h_guard.overflow != 0 || h_flags[1] >= FP.cap;
             for (uint32_t j = 0; j < n_jobs && !redo; ++j) redo = hs[j].lds_flags != 0;
             if (!redo) {
@@ -2560,6 +2566,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
                     r.n_near_tie = q.n_near; r.n_reeval = q.n_reeval; r.n_unresolved = q.n_unres; r.n_spike_near = q.n_spike;
                     r.guard_fallback = 0;
                 }
+                lap("rl: results");
                 pairs = points;                                          // (run pairs are not counted on this path; at least one run per point)
                 ctx->kde_work[0] += points; ctx->kde_work[1] += pairs; ctx->kde_work[2] += data_pairs;
                 for (size_t e = 0; e < ev.size(); ++e) {
