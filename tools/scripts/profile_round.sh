@@ -38,6 +38,9 @@ python3 bench.py --no-build --workload cigar > $P/${ROUND}_cigar_only_bench.json
 # one lane and two lanes: how far one host thread gets
 python3 bench.py --no-build --no-cpu-baseline --lanes 1 > $P/${ROUND}_full_path_bench_lanes1.json 2> $O/bench_l1.err
 python3 bench.py --no-build --no-cpu-baseline --lanes 2 > $P/${ROUND}_full_path_bench_lanes2.json 2> $O/bench_l2.err
+python3 bench.py --no-build --no-cpu-baseline --lanes 4 > $P/${ROUND}_full_path_bench_lanes4.json 2> $O/bench_l4.err
+# what each phase of the pass costs per haplotype with 1 .. 8 lanes (tools/lane_scaling.py)
+python3 tools/lane_scaling.py --no-build --kernels > $O/lane_scaling.out 2> $O/lane_scaling.err
 # one lane under the kernel + copy trace: the timeline of a pass (where the GPU waits for the host), and the SQ counter pass
 cd /tmp
 timeout -k 5 300 rocprofv3 --kernel-trace --memory-copy-trace -d $O/tl -o tl -- python3 $R/tools/prof_step.py --no-build --plain --steps 12 > $O/tl.log 2>&1
