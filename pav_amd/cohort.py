@@ -180,6 +180,35 @@ def _barrier(world):
         dist.barrier()
 
 
+class _GpuTurn:
+    """``share_gpu`` (several rank PROCESSES on GPU 0: tests and dry runs only): the ranks take turns with the device, one stage
+    of one rank at a time, through a lock file (in the temporary directory, named after the output directory).  Two processes that keep one GPU busy at the same time
+    are time-sliced by the driver and a pass can take 40 x as long (profiles/r04_cohort_two_ranks_one_gpu.json); a production
+    run has one process per GPU (lanes are threads of it) and takes no lock."""
+
+    def __init__(self, on, out_dir):
+        import hashlib
+        import tempfile
+        key = hashlib.sha1(os.path.abspath(str(out_dir)).encode()).hexdigest()[:16]
+        self.path = os.path.join(tempfile.gettempdir(), f'pav_amd_gpu_turn_{key}.lock') if on else None
+        self.fh = None
+
+    def __enter__(self):
+        if self.path:
+            import fcntl
+            self.fh = open(self.path, 'a')
+            fcntl.flock(self.fh, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        if self.fh:
+            import fcntl
+            fcntl.flock(self.fh, fcntl.LOCK_UN)
+            self.fh.close()
+            self.fh = None
+        return False
+
+
 def run_rank(rank, world, jobs, out_dir, ref_fa, config=None, engine_factory=None, split=False, share_gpu=False):
     """The work of one rank (the process group, if any, is up).  Returns this rank's manifests: one per whole haplotype it ran,
     one per shared haplotype it leads."""
@@ -190,11 +219,15 @@ def run_rank(rank, world, jobs, out_dir, ref_fa, config=None, engine_factory=Non
     engine = (engine_factory or _default_engine)(rank, 0 if share_gpu else rank, ref_fa, config)
     manifests = []
     shared = sorted({(j, n, lead) for its in items for (j, p, n, lead) in its if n > 1})
-    engine.open()
+    turn = _GpuTurn(share_gpu and world > 1, out_dir)
+    with turn:
+        engine.open()
     try:
         whole = [jobs[j] for (j, p, n, lead) in mine if n == 1]
         many = getattr(engine, 'call_haplotypes', None)
-        for m in (many(whole, out_dir) if many else [engine.call_haplotype(j, out_dir) for j in whole]):
+        with turn:
+            done = many(whole, out_dir) if many else [engine.call_haplotype(j, out_dir) for j in whole]
+        for m in done:
             m['rank'], m['mode'] = rank, 'whole haplotype'
             manifests.append(m)
         # the shared haplotypes advance stage by stage; every rank meets every barrier (a rank without a part just passes)
@@ -203,18 +236,21 @@ def run_rank(rank, world, jobs, out_dir, ref_fa, config=None, engine_factory=Non
         for j in my_part:
             rules._makedirs_for(paths[j])
         for j, (p, n) in my_part.items():                                       # stage 1: rule call_cigar, batches p, p + n, ...
-            engine.call_cigar_batches(jobs[j], paths[j], list(range(p, rules.CALL_CIGAR_BATCH_COUNT, n)))
+            with turn:
+                engine.call_cigar_batches(jobs[j], paths[j], list(range(p, rules.CALL_CIGAR_BATCH_COUNT, n)))
         if shared:
             _barrier(world)
         for (j, n, lead) in shared:                                             # stage 2 (lead): call_cigar_merge + the five flag rules
             if lead == rank:
                 P = paths[j]
                 rules.call_cigar_merge(P['cigar_batch_insdel'], P['cigar_batch_snv'], P['insdel'], P['snv'])
-                engine.flag_tables(jobs[j], P)
+                with turn:
+                    engine.flag_tables(jobs[j], P)
         if shared:
             _barrier(world)
         for j, (p, n) in my_part.items():                                       # stage 3: rule call_inv_batch, batches p, p + n, ...
-            engine.call_inv_batches(jobs[j], paths[j], list(range(p, batch_count, n)))
+            with turn:
+                engine.call_inv_batches(jobs[j], paths[j], list(range(p, batch_count, n)))
         if shared:
             _barrier(world)
         for (j, n, lead) in shared:                                             # stage 4 (lead): call_inv_batch_merge
