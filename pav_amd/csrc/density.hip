@@ -481,9 +481,9 @@ __global__ __launch_bounds__(256) void k_bucket_tig(const JobDev *__restrict__ j
 constexpr unsigned long long KEY_BITS = (1ull << 62) - 1ull;
 constexpr int KEY_O_SHIFT = 62;
 
-// ABL / ABL_W: ablations for the tuning build (PAV_TUNING, tools/build_variant.sh): the product launches <0, 0>
+// ABL / ABL_W: ablations for the tuning build (PAV_TUNING, tools/build_variant.sh); the product kernel is the <0, 0> body
 template <int ABL, int ABL_W>
-__global__ __launch_bounds__(LDS_THREADS) void k_kmer_lds(const PartItem *__restrict__ items, const JobDev *__restrict__ jobs,
+__device__ __forceinline__ void kmer_lds_body(const PartItem *__restrict__ items, const JobDev *__restrict__ jobs,
                                                           SeqView R, SeqView T, int k, uint32_t limit,
                                                           const uint32_t *__restrict__ lists, const uint32_t *__restrict__ bcount,
                                                           int8_t *__restrict__ st_tmp, JobStat *__restrict__ stat) {
@@ -614,6 +614,22 @@ __global__ __launch_bounds__(LDS_THREADS) void k_kmer_lds(const PartItem *__rest
         answer_step(kw, pos, ok);
     }
 }
+
+__global__ __launch_bounds__(LDS_THREADS) void k_kmer_lds(const PartItem *__restrict__ items, const JobDev *__restrict__ jobs,
+                                                          SeqView R, SeqView T, int k, uint32_t limit,
+                                                          const uint32_t *__restrict__ lists, const uint32_t *__restrict__ bcount,
+                                                          int8_t *__restrict__ st_tmp, JobStat *__restrict__ stat) {
+    kmer_lds_body<0, 0>(items, jobs, R, T, k, limit, lists, bcount, st_tmp, stat);
+}
+#ifdef PAV_TUNING
+template <int ABL, int ABL_W>
+__global__ __launch_bounds__(LDS_THREADS) void k_kmer_abl(const PartItem *__restrict__ items, const JobDev *__restrict__ jobs,
+                                                          SeqView R, SeqView T, int k, uint32_t limit,
+                                                          const uint32_t *__restrict__ lists, const uint32_t *__restrict__ bcount,
+                                                          int8_t *__restrict__ st_tmp, JobStat *__restrict__ stat) {
+    kmer_lds_body<ABL, ABL_W>(items, jobs, R, T, k, limit, lists, bcount, st_tmp, stat);
+}
+#endif
 
 // Per-tile and per-job counts of the STATE_MER values k_kmer_lds has written (+ the span of FWD k-mers for scan-only batches),
 // one workgroup per tile, 8 positions per lane; jobs with HBM tables were done by k_tig_state.
@@ -2266,7 +2282,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             PAV_HIP(ctx, scratch.reserve(a_t + 64));
             PAV_HIP(ctx, scratch_stat.reserve(sizeof(JobStat) * n_jobs));
             JobStat *no_stat = scratch_stat.as<JobStat>();
-#define PAV_ABL_LAUNCH(A, W) PAV_LAUNCH(ctx, "k_kmer_abl", (k_kmer_lds<A, W>), (uint32_t)items.size(), LDS_THREADS, 0, D->items.as<PartItem>(), d_jobs, RV, TV, k, \
+#define PAV_ABL_LAUNCH(A, W) PAV_LAUNCH(ctx, "k_kmer_abl", (k_kmer_abl<A, W>), (uint32_t)items.size(), LDS_THREADS, 0, D->items.as<PartItem>(), d_jobs, RV, TV, k, \
                    pp->max_ref_kmer_count, D->lists.as<uint32_t>(), D->bcount.as<uint32_t>(), scratch.as<int8_t>(), no_stat)
             const std::string a = abl;
             if (a == "0") PAV_ABL_LAUNCH(0, 0); else if (a == "1") PAV_ABL_LAUNCH(1, 0); else if (a == "2") PAV_ABL_LAUNCH(2, 0);
@@ -2274,7 +2290,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             else if (a == "5w") PAV_ABL_LAUNCH(5, 1); else if (a == "1w") PAV_ABL_LAUNCH(1, 1);
         }
 #endif
-        PAV_LAUNCH(ctx, "k_kmer_lds", (k_kmer_lds<0, 0>), (uint32_t)items.size(), LDS_THREADS, 0, D->items.as<PartItem>(), d_jobs, RV, TV, k,
+        PAV_LAUNCH(ctx, "k_kmer_lds", k_kmer_lds, (uint32_t)items.size(), LDS_THREADS, 0, D->items.as<PartItem>(), d_jobs, RV, TV, k,
                    pp->max_ref_kmer_count, D->lists.as<uint32_t>(), D->bcount.as<uint32_t>(), D->st_tmp.as<int8_t>(), d_stat);
         PAV_LAUNCH(ctx, "k_state_combine", k_state_combine, n_tiles_t, 256, 0, d_jobs, d_tjt, D->st_tmp.as<int8_t>(), d_stat,
                    D->tile_sum.as<uint32_t>(), scan_only ? 1 : 0);
