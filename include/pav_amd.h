@@ -211,6 +211,14 @@ typedef struct {
                                      (pandas would re-read numeric names as integers and order them numerically)         */
 } pav_table_opts;
 int pav_cigar_write_tables(pav_ctx *ctx, const pav_table_opts *opts, uint64_t *n_snv_rows, uint64_t *n_insdel_rows);
+/* The same write in two halves.  _begin does the device part (order, FILTER, record streams to host memory the library
+ * owns; every array of `opts` is copied) and starts the host part - text, gzip members, the files - on a thread of its own;
+ * the context may go on with pav_cigar_flag / the inversion scan meanwhile (they read the resident records, the writer no
+ * longer does).  _end waits for the files and reports the writer's error, if any.  One write at a time per context;
+ * pav_destroy waits for a write that was never ended.  (rules/call.snakefile:765-786 is a job of its own in the reference:
+ * nothing downstream of it on this path reads the two tables.) */
+int pav_cigar_write_tables_begin(pav_ctx *ctx, const pav_table_opts *opts);
+int pav_cigar_write_tables_end(pav_ctx *ctx, uint64_t *n_snv_rows, uint64_t *n_insdel_rows);
 
 /* Lift-over tables for pavlib.align.AlignLift (pavlib/align/lift.py:380-476, `_add_align`): tokenises every row's
  * CIGAR on the device and returns, per operation, the subject position where it starts (absolute, row POS included)

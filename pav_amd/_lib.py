@@ -195,6 +195,8 @@ SYMBOLS = {
     'pav_cigar_fetch': (ctypes.c_int, [_P, _P, _P, _P]),
     'pav_cigar_fetch_ops': (ctypes.c_int, [_P, _P, _P]),
     'pav_cigar_write_tables': (ctypes.c_int, [_P, _P, _P, _P]),
+    'pav_cigar_write_tables_begin': (ctypes.c_int, [_P, _P]),
+    'pav_cigar_write_tables_end': (ctypes.c_int, [_P, _P, _P]),
     'pav_align_index': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P, _P, _P, _P, _P, _P]),
     'pav_homology': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P]),
     'pav_density_batch': (ctypes.c_int, [_P, ctypes.c_uint32, _P, _P, _P]),
@@ -436,9 +438,11 @@ class Context:
         return snv, indel, blob
 
     def cigar_write_tables(self, hap, align_index, trim_pos=None, trim_end=None, snv_path=None, insdel_path=None,
-                           gzip_level=0, threads=0, call_batch=None):
+                           gzip_level=0, threads=0, call_batch=None, background=False):
         """Write the SNV / INS-DEL tables of the last cigar_call natively (sorted, FILTER, pandas-identical text).
-        ``call_batch`` (CALL_BATCH of every alignment row): write the merged tables of rule call_cigar_merge instead."""
+        ``call_batch`` (CALL_BATCH of every alignment row): write the merged tables of rule call_cigar_merge instead.
+        ``background``: return when the device part is done (the text and the gzip members are made on a thread of the
+        library's own); :meth:`cigar_write_wait` waits for the files and returns the two row counts."""
         cb = None if call_batch is None else np.ascontiguousarray(call_batch, dtype=np.int64)
         align_index = np.ascontiguousarray(align_index, dtype=np.int64)
         tp = None if trim_pos is None else np.ascontiguousarray(trim_pos, dtype=np.int64)
@@ -447,9 +451,18 @@ class Context:
                          None if te is None else te.ctypes.data, None if snv_path is None else str(snv_path).encode(),
                          None if insdel_path is None else str(insdel_path).encode(), int(gzip_level), int(threads),
                          None if cb is None else cb.ctypes.data)
+        if background:
+            self._check(self.lib.pav_cigar_write_tables_begin(self.handle, ctypes.byref(opts)), 'pav_cigar_write_tables_begin')
+            return None
         n1, n2 = ctypes.c_uint64(0), ctypes.c_uint64(0)
         self._check(self.lib.pav_cigar_write_tables(self.handle, ctypes.byref(opts), ctypes.byref(n1), ctypes.byref(n2)),
                     'pav_cigar_write_tables')
+        return int(n1.value), int(n2.value)
+
+    def cigar_write_wait(self):
+        """Wait for a write begun with ``cigar_write_tables(..., background=True)``; -> (SNV rows, INS / DEL rows)."""
+        n1, n2 = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._check(self.lib.pav_cigar_write_tables_end(self.handle, ctypes.byref(n1), ctypes.byref(n2)), 'pav_cigar_write_tables_end')
         return int(n1.value), int(n2.value)
 
     # ---- alignment trimming ---------------------------------------------------------------------------------------

@@ -167,6 +167,7 @@ struct pav_ctx {
     void *invscan = nullptr;              // native scan driver state (invscan.cpp)
     void *flag = nullptr;                 // flagging scratch + results (flag.hip)
     void *trim = nullptr;                 // alignment trimming state (trim.cpp)
+    void *table_writer = nullptr;         // a table write in two halves (tables.hip: pav_cigar_write_tables_begin / _end)
 
     // profiling
     bool prof_on = false;
@@ -180,6 +181,7 @@ namespace pav {
 extern thread_local std::string g_err;   // pav_last_error(NULL)
 
 int fail(pav_ctx *ctx, int code, const char *fmt, ...);
+void table_writer_release(pav_ctx *ctx);                             // tables.hip: joins a pending writer thread
 
 #define PAV_HIP(ctx, call)                                                                         \
     do {                                                                                           \

@@ -324,6 +324,7 @@ void pav_destroy(pav_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream3);
     (void)hipStreamSynchronize(ctx->stream2);
     (void)hipStreamSynchronize(ctx->stream);
+    table_writer_release(ctx);
     pav_density_release(ctx);
     pav_invscan_release(ctx);
     pav_flag_release(ctx);

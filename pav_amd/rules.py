@@ -473,6 +473,7 @@ def call_haplotype(bed, bed_trim, tig_fa_name, ref_fa_name, asm_name, hap, out_d
             t_last[0] = now
     ctx, own = _with_ctx(ctx, device_id)
     table = trim_table = None
+    writing = False
     try:
         # the contig file is parsed on a second thread while the tables are parsed and - the first time - the reference is parsed,
         # uploaded and packed (the native readers and the upload release the GIL)
@@ -480,7 +481,7 @@ def call_haplotype(bed, bed_trim, tig_fa_name, ref_fa_name, asm_name, hap, out_d
         from . import fasta as pavfasta
         th = threading.Thread(target=pavfasta.open_fasta, args=(tig_fa_name,))
         th.start()
-        table, trim_table = _lib.BedTable(bed, with_cigar=True), _lib.BedTable(bed_trim, with_cigar=False)
+        table, trim_table = _lib.BedTable(bed, with_cigar=True), _lib.BedTable(bed_trim, with_cigar=True)
         cols = table.fetch()
         cigarcall.load_reference(ctx, ref_fa_name)
         th.join()
@@ -501,8 +502,11 @@ def call_haplotype(bed, bed_trim, tig_fa_name, ref_fa_name, asm_name, hap, out_d
         tp, te = trim['POS'].to_numpy(dtype='int64'), trim['END'].to_numpy(dtype='int64')
         lap('tables in + CIGAR-call')
         call_batch = cols['CALL_BATCH'] if table.n_rows else np.zeros(0, dtype=np.int64)
-        n_snv, n_insdel = ctx.cigar_write_tables(hap, index, tp, te, snv_path=P['snv'], insdel_path=P['insdel'], threads=threads,
-                                                 gzip_level=gzip_level, call_batch=call_batch)
+        # the device part of the writer now, its host part (text, gzip members) on a thread of the library's own beside the stages
+        # below - nothing on this path reads the two tables (rule call_cigar_merge is a leaf for the inversion rules)
+        ctx.cigar_write_tables(hap, index, tp, te, snv_path=P['snv'], insdel_path=P['insdel'], threads=threads,
+                               gzip_level=gzip_level, call_batch=call_batch, background=True)
+        writing = True
         lap('merged SNV / INS-DEL tables')
         flag_cfg = {}
         for key, name in (('inv_sig_cluster_win', 'cluster_win'), ('inv_sig_cluster_snv_min', 'cluster_min_snv'),
@@ -521,7 +525,14 @@ def call_haplotype(bed, bed_trim, tig_fa_name, ref_fa_name, asm_name, hap, out_d
         sel = df_flag.loc[df_flag['BATCH'] >= 0] if df_flag.shape[0] else df_flag
         results, logs = [], []
         if sel.shape[0]:
-            align_lift = AlignLift(pd.read_csv(bed_trim, sep='\t'), read_fai(str(tig_fa_name) + '.fai'), ctx=ctx)
+            # the trimmed table as rule call_inv_batch reads it (:174-177), from the columns the native reader has parsed already
+            off = tc['CIGAR_OFF'].astype(np.int64) if 'CIGAR_OFF' in tc else np.zeros(trim_table.n_rows + 1, dtype=np.int64)
+            text = tc['CIGAR_TEXT'].tobytes() if 'CIGAR_TEXT' in tc else b''
+            df_trim = pd.DataFrame({
+                '#CHROM': [trim_table.chrom_names[i] for i in tc['#CHROM'].tolist()], 'POS': tc['POS'], 'END': tc['END'], 'INDEX': tc['INDEX'],
+                'QRY_ID': [trim_table.qry_names[i] for i in tc['QRY_ID'].tolist()], 'QRY_POS': tc['QRY_POS'], 'QRY_END': tc['QRY_END'],
+                'REV': tc['REV'], 'CIGAR': [text[a:b].decode() for a, b in zip(off[:-1].tolist(), off[1:].tolist())]})
+            align_lift = AlignLift(df_trim, read_fai(str(tig_fa_name) + '.fai'), ctx=ctx)
             regions = [pavseq.Region(c, p, e) for c, p, e in zip(sel['#CHROM'], sel['POS'], sel['END'])]
             logs = [io.StringIO() for _ in regions]
             lap('lift-over index')
@@ -532,37 +543,26 @@ def call_haplotype(bed, bed_trim, tig_fa_name, ref_fa_name, asm_name, hap, out_d
             lap('scan')
         # ---- per batch, in the order the reference's jobs see the rows: INV table, log, density tables ----------------------
         where = {ix: q for q, ix in enumerate(sel.index)}
-        native_tables, n_calls = [], 0
+        # first which calls each batch keeps (:203) and where their density tables go: the native writer starts on those - a
+        # thread of its own, the library's formatting and gzip threads behind it - while the batch tables, the logs and the merge
+        # are made here
+        native_tables, kept, n_calls = [], [], 0
         for b in range(batch_count):
             rows_b = df_flag.loc[df_flag['BATCH'] == b] if df_flag.shape[0] else df_flag
-            id_set, call_list = set(), []
-            with open(P['inv_log'][b], 'w') as log_file:
-                for ix, row in rows_b.iterrows():
-                    r = results[where[ix]]
-                    log_file.write(logs[where[ix]].getvalue())
-                    if isinstance(r, RuntimeError):                                       # :198-200
-                        log_file.write('RuntimeError in scan_for_inv(): {}\n'.format(r))
-                        r = None
-                    if r is not None and r.id not in id_set:                             # :203
-                        call_list.append(inv_bed_row(r, hap, row['TYPE'], tig_fa_name))
-                        id_set.add(r.id)
-                        path = '{}/density_{}_{}.tsv.gz'.format(P['density_dir'], r.id, hap)
-                        nt = r.native_table
-                        if nt is not None and nt[0] is ctx and nt[2] == ctx._inv_generation and callable(r._df):
-                            native_tables.append((nt[1], path))
-                        else:
-                            r.df.to_csv(path, sep='\t', index=False, compression='gzip')
-            if rows_b.shape[0] == 0:
-                df_bed = pd.DataFrame([], columns=list(INV_BED_COLUMNS))                  # :148-167
-            elif call_list:
-                df_bed = pd.concat(call_list, axis=1).T.sort_values(['#CHROM', 'POS', 'END', 'ID'])   # :297
-            else:
-                df_bed = pd.DataFrame([], columns=[c for c in INV_BED_COLUMNS if c != 'FILTER'])       # :300-308 (sic)
-            # (the per-batch tables are temporary files, read back by the merge below: the SEQ column - whole inversions - is most of
-            #  their bytes and deflate level 9, pandas' default, most of their time; level 1 here)
-            df_bed.to_csv(P['inv_batch'][b], sep='\t', index=False, compression={'method': 'gzip', 'compresslevel': 1})
-            n_calls += len(call_list)
-        lap('INV batch tables + logs')
+            id_set, keep_b = set(), []
+            for ix, row in rows_b.iterrows():
+                r = results[where[ix]]
+                if r is None or isinstance(r, RuntimeError) or r.id in id_set:
+                    continue
+                id_set.add(r.id)
+                path = '{}/density_{}_{}.tsv.gz'.format(P['density_dir'], r.id, hap)
+                nt = r.native_table
+                native = nt is not None and nt[0] is ctx and nt[2] == ctx._inv_generation and callable(r._df)
+                if native:
+                    native_tables.append((nt[1], path))
+                keep_b.append((ix, None if native else path))
+            kept.append((rows_b, dict(keep_b)))
+        table_writer = table_error = None
         if native_tables:
             # A call found through two flagged regions of different batches names the same file twice; the reference's batch jobs
             # would each write it (whichever job runs last wins there).  Here every file is written once, by the call of the
@@ -570,15 +570,61 @@ def call_haplotype(bed, bed_trim, tig_fa_name, ref_fa_name, asm_name, hap, out_d
             last = {}
             for rgn, path in native_tables:
                 last[path] = rgn
-            ctx.inv_write_tables(list(last.values()), list(last.keys()), threads=threads, gzip_level=gzip_level)
+            table_error = []
+
+            def write_density():
+                try:
+                    ctx.inv_write_tables(list(last.values()), list(last.keys()), threads=threads, gzip_level=gzip_level)
+                except BaseException as ex:                                               # noqa: BLE001 - re-raised on the caller's thread
+                    table_error.append(ex)
+            table_writer = threading.Thread(target=write_density)
+            table_writer.start()
+        try:
+            for b in range(batch_count):
+                rows_b, keep_b = kept[b]
+                call_list = []
+                with open(P['inv_log'][b], 'w') as log_file:
+                    for ix, row in rows_b.iterrows():
+                        r = results[where[ix]]
+                        log_file.write(logs[where[ix]].getvalue())
+                        if isinstance(r, RuntimeError):                                       # :198-200
+                            log_file.write('RuntimeError in scan_for_inv(): {}\n'.format(r))
+                        if ix in keep_b:
+                            call_list.append(inv_bed_row(r, hap, row['TYPE'], tig_fa_name))
+                            if keep_b[ix] is not None:
+                                r.df.to_csv(keep_b[ix], sep='\t', index=False, compression='gzip')
+                if rows_b.shape[0] == 0:
+                    df_bed = pd.DataFrame([], columns=list(INV_BED_COLUMNS))                  # :148-167
+                elif call_list:
+                    df_bed = pd.concat(call_list, axis=1).T.sort_values(['#CHROM', 'POS', 'END', 'ID'])   # :297
+                else:
+                    df_bed = pd.DataFrame([], columns=[c for c in INV_BED_COLUMNS if c != 'FILTER'])       # :300-308 (sic)
+                # (the per-batch tables are temporary files, read back by the merge below: the SEQ column - whole inversions - is most
+                #  of their bytes and deflate level 9, pandas' default, most of their time; level 1 here)
+                df_bed.to_csv(P['inv_batch'][b], sep='\t', index=False, compression={'method': 'gzip', 'compresslevel': 1})
+                n_calls += len(call_list)
+            lap('INV batch tables + logs')
+            df_inv = call_inv_batch_merge(P['inv_batch'], P['inv'], gzip_level=gzip_level or 6)
+            lap('INV merge')
+        finally:
+            if table_writer is not None:
+                table_writer.join()
+        if table_error:
+            raise table_error[0]
         lap('density tables')
-        df_inv = call_inv_batch_merge(P['inv_batch'], P['inv'], gzip_level=gzip_level or 6)
-        lap('INV merge')
+        writing = False
+        n_snv, n_insdel = ctx.cigar_write_wait()
+        lap('merged SNV / INS-DEL tables')
         return {'asm_name': asm_name, 'hap': hap, 'aligned_bp': int(counts.aligned_bases), 'snv_rows': int(n_snv),
                 'insdel_rows': int(n_insdel), 'flagged_regions': int(df_flag.shape[0]), 'scanned_regions': int(sel.shape[0]),
                 'inv_calls_in_batches': int(n_calls), 'inv_calls': int(df_inv.shape[0]),
                 'files': {k: P[k] for k in ('snv', 'insdel', 'flagged_regions', 'inv')}}
     finally:
+        if writing:                                                # an error on the way: the writer thread is waited for all the same
+            try:
+                ctx.cigar_write_wait()
+            except Exception:                                      # noqa: BLE001 - the error that brought us here is the one to report
+                pass
         for t in (table, trim_table):
             if t is not None:
                 t.close()

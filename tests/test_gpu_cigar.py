@@ -202,6 +202,40 @@ def test_native_table_writer_vs_reference_text(built, gpu_ctx, tmp_path, case):
             assert fh.read() == util.golden_text(case, 'insdel')
 
 
+def test_table_write_in_two_halves_equals_the_reference_text(built, gpu_ctx, tmp_path):
+    """pav_cigar_write_tables_begin / _end: the host half of the writer runs on a thread of the library's own while the context
+    goes on (here: a flagging pass); the files equal the reference's text; a second begin before the end, an end without a begin and a plain write in between are
+    refused with PAV_E_STATE; an unwritable path is reported by the end."""
+    import gzip
+    d, df_align, df_trim = util.golden_case('cigar_synth')
+    _load_case(gpu_ctx, d)
+    cigarcall.call_records(gpu_ctx, df_align)
+    index = df_align['INDEX'].to_numpy(dtype='int64')
+    trim = df_trim.reindex(list(index), fill_value=-1)
+    tp, te = trim['POS'].to_numpy(dtype='int64'), trim['END'].to_numpy(dtype='int64')
+    with pytest.raises(_lib.PavDeviceError):
+        gpu_ctx.cigar_write_wait()                                   # nothing begun
+    p_snv, p_ins = str(tmp_path / 'snv.tsv.gz'), str(tmp_path / 'insdel.tsv.gz')
+    assert gpu_ctx.cigar_write_tables('h1', index, tp.copy(), te.copy(), snv_path=p_snv, insdel_path=p_ins, threads=3, background=True) is None
+    with pytest.raises(_lib.PavDeviceError):
+        gpu_ctx.cigar_write_tables('h1', index, tp, te, snv_path=p_snv + '.2', insdel_path=p_ins + '.2', background=True)
+    with pytest.raises(_lib.PavDeviceError):
+        gpu_ctx.cigar_write_tables('h1', index, tp, te, snv_path=p_snv + '.3', insdel_path=p_ins + '.3')
+    flagged = gpu_ctx.cigar_flag(tp, te, gpu_ctx.flag_params())      # the context works on beside the writer
+    n_snv, n_ins = gpu_ctx.cigar_write_wait()
+    with gzip.open(p_snv, 'rt') as fh:
+        text = fh.read()
+    assert text == util.golden_text('cigar_synth', 'snv') and n_snv == text.count('\n') - 1
+    with gzip.open(p_ins, 'rt') as fh:
+        text = fh.read()
+    assert text == util.golden_text('cigar_synth', 'insdel') and n_ins == text.count('\n') - 1
+    assert flagged is not None
+    gpu_ctx.cigar_write_tables('h1', index, tp, te, snv_path=str(tmp_path / 'no-such-dir' / 'snv.tsv'), insdel_path=p_ins, background=True)
+    with pytest.raises(_lib.PavDeviceError, match='cannot open'):
+        gpu_ctx.cigar_write_wait()
+    assert gpu_ctx.cigar_write_tables('h1', index, tp, te, snv_path=p_snv, insdel_path=p_ins) == (n_snv, n_ins)   # usable afterwards
+
+
 def test_native_rule_files_equal_the_reference_rules(built, gpu_ctx, tmp_path):
     """rules.call_cigar_files x 10 batches -> call_cigar_merge vs the reference rules' merged output."""
     import gzip
