@@ -741,7 +741,9 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
     for (uint32_t i = 0; i < n_regions; ++i) live.push_back(i);
     tl[4] = tnow();
 
-    const uint64_t max_batch_bp = 64000000ull;
+    // bases (reference + contig) of the regions one density batch takes; the regions behind the budget wait for the next batch
+    // of the same round.  PAV_SCAN_BATCH_BP: tests shrink it to run that path on small cases.
+    const uint64_t max_batch_bp = [] { const char *e = getenv("PAV_SCAN_BATCH_BP"); const long long v = e ? atoll(e) : 0; return v > 0 ? (uint64_t)v : 64000000ull; }();
     const bool timing = getenv("PAV_TIMING") != nullptr;
     double t_batch = 0, t_table = 0, t_pre = 0, t_post = 0, t_lift = 0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };

@@ -397,6 +397,28 @@ def test_batched_scan_vs_reference(built, gpu_ctx, case, native):
                 check_call(d, rec, call)
 
 
+@pytest.mark.parametrize('budget', ['1', '30000', '120000'])
+def test_small_batch_budget_gives_the_reference_results(built, gpu_ctx, monkeypatch, budget):
+    """The native driver takes the regions of a round in batches of at most 64 Mbp (reference + contig bases); the regions behind
+    the budget wait, are lifted again with the next batch's regions and scanned then.  PAV_SCAN_BATCH_BP shrinks the budget so
+    that the golden cases run that path - one region per batch, a few, most: logs and calls equal the reference's."""
+    monkeypatch.setenv('PAV_SCAN_BATCH_BP', budget)
+    for case in ('inv_hap', 'inv_rev'):
+        d, lift, scans = load_case(gpu_ctx, case)
+        recs = [r for r in scans if not r['kwargs']]
+        regions = [pavseq.Region(r['flag']['chrom'], r['flag']['pos'], r['flag']['end']) for r in recs]
+        logs = [io.StringIO() for _ in regions]
+        out = pavinv.scan_for_inv_batch(regions, os.path.join(d, 'ref.fa'), os.path.join(d, 'tig.fa'), lift, KmerUtil(31), logs=logs,
+                                        ctx=gpu_ctx, native=True)
+        assert len(recs) >= 2
+        for rec, call, lg in zip(recs, out, logs):
+            assert lg.getvalue().splitlines() == rec['log'], (case, rec['flag'], budget)
+            if rec['call'] is None:
+                assert call is None
+            else:
+                check_call(d, rec, call)
+
+
 @pytest.mark.parametrize('case', ['inv_hap', 'inv_nolift', 'inv_rev'])
 def test_device_lifts_equal_the_host_tables(built, gpu_ctx, case, monkeypatch, capfd):
     """The native driver lifts the ends of every region and the breakpoints of every flanked region in batches on the device
