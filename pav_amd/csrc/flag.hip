@@ -36,7 +36,7 @@ struct FlagState {
     std::vector<pav_flag_rgn> single;                         // result of the array-level entry points
     std::vector<pav_flag_locus> loci;
     // device-planned pav_cigar_flag: INS / DEL rows of both vartypes, pinned result block, what the small inputs held last time
-    DevBuf plan;
+    DevBuf plan, delmax;                                      // delmax: tile maxima of the running maximum (k_delmax_*)
     void *pin = nullptr;
     std::vector<uint8_t> small_seen;
     const void *small_at = nullptr;
@@ -672,6 +672,67 @@ struct DelEndPlanned {
     }
 };
 
+// The running maximum itself, two launches (the planned path; rocprim::inclusive_scan - an init kernel and a look-back scan,
+// 0.032 ms - did this in round 3): k_delmax_tiles reduces tiles of 2048 elements to their maxima; k_delmax_apply takes the
+// maximum of the tiles in front of its own as carry-in, scans its tile on top of it and writes the values.  The input is
+// read twice: 16 B per element, 1.2 M elements.
+constexpr int DM_TILE = 2048;                                    // 8 rows of 256 consecutive elements, one per lane
+struct DelMaxArgs { DelEndPlanned in; unsigned long long *out, *tile_max; uint64_t n; uint32_t n_tiles; };
+
+__device__ __forceinline__ unsigned long long umax64(unsigned long long a, unsigned long long b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned long long wave_incl_max(unsigned long long v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long y = (unsigned long long)__shfl_up((long long)v, d);
+        if (lane >= d) v = umax64(v, y);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_delmax_tiles(DelMaxArgs A) {
+    __shared__ unsigned long long wmax[4];
+    const uint64_t i0 = (uint64_t)blockIdx.x * DM_TILE + threadIdx.x;            // element q * 256 + lane of the tile: coalesced
+    unsigned long long m = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) if (i0 + q * 256 < A.n) m = umax64(m, A.in(i0 + q * 256));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = umax64(m, (unsigned long long)__shfl_xor((long long)m, d));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) A.tile_max[blockIdx.x] = umax64(umax64(wmax[0], wmax[1]), umax64(wmax[2], wmax[3]));
+}
+
+__global__ __launch_bounds__(256) void k_delmax_apply(DelMaxArgs A) {
+    __shared__ unsigned long long wsum[8][4];
+    const uint64_t i0 = (uint64_t)blockIdx.x * DM_TILE + threadIdx.x;            // element q * 256 + lane of the tile
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned long long inc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const unsigned long long v = i0 + q * 256 < A.n ? A.in(i0 + q * 256) : 0ull;
+        inc[q] = wave_incl_max(v);                                        // inclusive over the lanes of this wave, row q
+        if (lane == 63) wsum[q][wave] = inc[q];
+    }
+    // the tile's carry-in: the maximum of the tiles in front of it (a few hundred values from the L2: every block reduces its own
+    // prefix - a carry kernel between the two launches, or a last-block-done pass with its device-scope fences, costs more)
+    __shared__ unsigned long long cmax[4];
+    unsigned long long c = 0;
+    for (uint32_t t = threadIdx.x; t < blockIdx.x; t += 256) c = umax64(c, A.tile_max[t]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c = umax64(c, (unsigned long long)__shfl_xor((long long)c, d));
+    if (lane == 0) cmax[wave] = c;
+    __syncthreads();
+    unsigned long long before = umax64(umax64(cmax[0], cmax[1]), umax64(cmax[2], cmax[3]));   // everything in front of (row q, this wave)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        unsigned long long mine = before;
+        for (int w = 0; w < wave; ++w) mine = umax64(mine, wsum[q][w]);
+        if (i0 + q * 256 < A.n) A.out[i0 + q * 256] = umax64(mine, inc[q]);
+        before = umax64(umax64(before, wsum[q][0]), umax64(umax64(wsum[q][1], wsum[q][2]), wsum[q][3]));
+    }
+}
+
 // k_ins_match for both vartypes (first / second half of the grid), counts on the device; del_max from the scan above (vartype 1 carries VT1)
 struct MatchArgs {
     const unsigned long long *ins_key[2], *ins_len[2], *del_key[2], *del_max[2]; const unsigned long long *cnt;
@@ -849,10 +910,8 @@ int flag_planned(pav_ctx *ctx, FlagState *S, const pav_flag_params *P, unsigned 
 
     const KeyView V{k_sorted, n_snv, tag, d_cnt};
     const DelEndPlanned DE{{cls_key[0], cls_key[2]}, {cls_val[0], cls_val[2]}, n_ind, d_cnt, d_cnt + 3};
-    auto del_end = rocprim::make_transform_iterator(rocprim::counting_iterator<unsigned long long>(0), DE);
-    size_t bytes = 0, bytes2 = 0;
-    if (n_ind) PAV_HIP(ctx, rocprim::inclusive_scan(nullptr, bytes2, del_end, del_max, (size_t)(2 * n_ind), rocprim::maximum<unsigned long long>(), st));
-    PAV_HIP(ctx, S->tmp.reserve(std::max(bytes, bytes2) + 16));
+    const uint32_t dm_tiles = (uint32_t)((2 * n_ind + DM_TILE - 1) / DM_TILE);      // the running maximum's tile maxima
+    PAV_HIP(ctx, S->delmax.reserve(8ull * dm_tiles + 64));
 
     if (n_snv)
         PAV_LAUNCH(ctx, "k_snv_keys", k_snv_keys, tiles_snv, 256, 0, ctx->d_snv.as<pav_snv>(), n_snv, d_aln, d_rank, d_tp, d_te, k_in, d_cnt,
@@ -890,10 +949,11 @@ int flag_planned(pav_ctx *ctx, FlagState *S, const pav_flag_params *P, unsigned 
         PAV_LAUNCH(ctx, "k_cluster_resolve", k_cluster_resolve, 1024, 64, 0, SW);
     }
     if (n_ind) {   // both matches (rule call_inv_flag_insdel_cluster)
-        const int tok = prof_begin(ctx, "rocprim::inclusive_scan");
-        const hipError_t e = rocprim::inclusive_scan(S->tmp.p, bytes2, del_end, del_max, (size_t)(2 * n_ind), rocprim::maximum<unsigned long long>(), st);
-        prof_end(ctx, tok);
-        PAV_HIP(ctx, e);
+        DelMaxArgs DM;
+        DM.in = DE; DM.out = del_max; DM.n = 2 * n_ind; DM.n_tiles = dm_tiles;
+        DM.tile_max = S->delmax.as<unsigned long long>();
+        PAV_LAUNCH(ctx, "k_delmax_tiles", k_delmax_tiles, dm_tiles, 256, 0, DM);
+        PAV_LAUNCH(ctx, "k_delmax_apply", k_delmax_apply, dm_tiles, 256, 0, DM);
         MatchArgs MA;
         for (int t = 0; t < 2; ++t) {
             MA.del_key[t] = cls_key[2 * t]; MA.ins_key[t] = cls_key[2 * t + 1]; MA.ins_len[t] = cls_val[2 * t + 1];
@@ -934,7 +994,7 @@ void pav_flag_release(pav_ctx *ctx) {
     FlagState *S = static_cast<FlagState *>(ctx->flag);
     DevBuf *bufs[] = {&S->a, &S->b, &S->c, &S->d, &S->tmp, &S->hits, &S->cnt, &S->small, &S->start,
                       &S->split[0][0], &S->split[0][1], &S->split[0][2], &S->split[0][3], &S->split[1][0], &S->split[1][1],
-                      &S->split[1][2], &S->split[1][3], &S->hits_b[0], &S->hits_b[1], &S->hits_b[2], &S->hits_b[3], &S->plan};
+                      &S->split[1][2], &S->split[1][3], &S->hits_b[0], &S->hits_b[1], &S->hits_b[2], &S->hits_b[3], &S->plan, &S->delmax};
     for (DevBuf *b : bufs) b->release();
     if (S->pin) (void)hipHostFree(S->pin);
     delete S;
