@@ -148,7 +148,9 @@ def main():
     threads = min(threads, 16)
     cpus_per_rank = effective_cpus() / max(1, world)
     # measured: a lane wants a core; six lanes fill the GPU (round 3, 20-step regions: 4 / 5 / 6 / 8 lanes = 1 870 / 2 010 / 2 090 / 2 090
-    # Gbp/s - with the host gaps of a pass shortened the fifth and sixth lane find room that four lanes left; round 2: four)
+    # Gbp/s - with the host gaps of a pass shortened the fifth and sixth lane find room that four lanes left; round 2: four;
+    # round 4: 2 / 4 / 6 lanes = 1.65 - 1.79 / 2.25 - 2.33 / 2.26 - 2.36 Tbp/s: four lanes reach the sum of the per-phase floors,
+    # profiles/r04_lane_scaling.txt - six are kept where the CPUs allow it, they cost nothing and smooth short timed regions)
     n_lanes = args.lanes if args.lanes > 0 else (6 if cpus_per_rank >= 6 else (4 if cpus_per_rank >= 4 else (2 if cpus_per_rank >= 2 else 1)))
     gen_kw = {'pair_frac': args.pair_frac} if args.workload == 'cigar+inv' and args.pair_frac > 0 else {}
     if rank == 0:
