@@ -7,7 +7,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def run(name, steps):
     env = dict(os.environ)
-    if name != 'base':
+    if name.startswith('env:'):                                   # the product build with an environment switch, e.g. env:PAV_LIFT_COPY=1
+        k, v = name[4:].split('=', 1)
+        env[k] = v
+    elif name != 'base':
         env['PAV_AMD_LIB'] = os.path.join(ROOT, 'pav_amd', 'lib', 'variants', f'libpav_amd_{name}.so')
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'prof_step.py'), '--no-build', '--plain', '--steps', str(steps)], env=env, capture_output=True, text=True)
     for ln in out.stdout.splitlines():
