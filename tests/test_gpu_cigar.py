@@ -234,6 +234,16 @@ def test_table_write_in_two_halves_equals_the_reference_text(built, gpu_ctx, tmp
     with pytest.raises(_lib.PavDeviceError, match='cannot open'):
         gpu_ctx.cigar_write_wait()
     assert gpu_ctx.cigar_write_tables('h1', index, tp, te, snv_path=p_snv, insdel_path=p_ins) == (n_snv, n_ins)   # usable afterwards
+    # a context that is closed with a write under way waits for it: the files are complete
+    with _lib.Context(0) as other:
+        _load_case(other, d)
+        cigarcall.call_records(other, df_align)
+        q_snv, q_ins = str(tmp_path / 'late_snv.tsv.gz'), str(tmp_path / 'late_insdel.tsv.gz')
+        other.cigar_write_tables('h1', index, tp, te, snv_path=q_snv, insdel_path=q_ins, threads=2, background=True)
+    with gzip.open(q_snv, 'rt') as fh:
+        assert fh.read() == util.golden_text('cigar_synth', 'snv')
+    with gzip.open(q_ins, 'rt') as fh:
+        assert fh.read() == util.golden_text('cigar_synth', 'insdel')
 
 
 def test_native_rule_files_equal_the_reference_rules(built, gpu_ctx, tmp_path):
