@@ -1059,3 +1059,22 @@ def test_files_to_files_tool(built, tmp_path):
         inv = pd.read_csv(names['inv'], sep='\t')
         assert inv.shape[0] == line['inv_calls']
         assert len(os.listdir(res / 'results/sample/inv_caller/density_table')) == line['inv_calls']
+
+
+def test_measurement_tools_run_on_a_small_case(built):
+    """tools/lane_scaling.py and tools/batch_probe.py (the round-4 measurements of DESIGN.md section 5) on a shrunk haplotype:
+    both finish, print their summary line, and every lane count / batch size reports a positive time and the same call counts."""
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'lane_scaling.py'), '--no-build', '--scale', '0.004', '--lanes', '1,2',
+                          '--steps', '2', '--phases', 'call,all'], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('LANE_SCALING ')][0][len('LANE_SCALING '):])
+    assert set(rec) == {'call', 'all'} and all(rec[p][n]['ms_per_pass'] > 0 for p in rec for n in ('1', '2'))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'batch_probe.py'), '--no-build', '--scale', '0.004', '--batch', '1,2',
+                          '--steps', '2'], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('BATCH_PROBE ')][0][len('BATCH_PROBE '):])
+    assert rec['1']['ms_per_haplotype'] > 0 and rec['2']['n_snv'] > rec['1']['n_snv'] > 0
