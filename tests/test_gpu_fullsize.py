@@ -108,6 +108,40 @@ def test_full_size_haplotype_is_bit_exact_vs_the_oracle(built, gpu_ctx):
           f'{near} near-tie decisions re-evaluated')
 
 
+def test_full_size_scan_with_helper_threads(built, gpu_ctx, monkeypatch):
+    """The native driver's per-region loops on four host threads (PAV_HOST_THREADS; csrc/pool.h) over the 1 128 loci of the bench
+    haplotype - the loops the golden cases are too small to share out: the same regions, calls and log text as the digest of the
+    oracle-driven scan (tests/golden/fullsize_inv_calls.json), three scans in a row."""
+    import hashlib
+    import io
+    import json
+    import os
+    import oracle_scan
+    from pav_amd.kmer import KmerUtil
+    full = fullsize(gpu_ctx)
+    with open(os.path.join(util.GOLD, 'fullsize_inv_calls.json')) as fh:
+        gold = json.load(fh)
+    want = {c['region']: c for c in gold['calls']}
+    monkeypatch.setenv('PAV_HOST_THREADS', '4')
+    lift = AlignLift(full['hap'].df_trim, full['hap'].tig_lengths)       # an index of its own: the helpers are made with it
+    with _lib.Context(0) as ctx:
+        ctx.seq_share(gpu_ctx, _lib.PAV_ROLE_REF)
+        ctx.seq_share(gpu_ctx, _lib.PAV_ROLE_TIG)
+        ctx._inv_loaded = full['fa']
+        regions = pavinv.loci_regions(ctx, full['loci'])
+        for rep in range(3):
+            log = io.StringIO()
+            out = pavinv.scan_for_inv_batch(regions, full['fa'][0], full['fa'][1], lift, KmerUtil(31), log=log, ctx=ctx, native=True,
+                                            eager_tables=False, found_out=io.StringIO())
+            got = {i: c for i, c in enumerate(out) if c is not None}
+            assert sorted(got) == sorted(want), rep
+            for i, c in got.items():
+                for k2, v in oracle_scan.call_record(c).items():
+                    assert want[i][k2] == v, (rep, i, k2)
+            text = log.getvalue()
+            assert text.count('\n') == gold['log_lines'] and hashlib.sha1(text.encode()).hexdigest() == gold['log_sha1'], rep
+
+
 def test_full_size_inversion_calls_vs_the_oracle_driven_scan(built, gpu_ctx):
     """The COMPLETE scan of the bench haplotype - every flagged locus, every expansion round, up to regions of ~0.5 Mbp -
     against tests/golden/fullsize_inv_calls.json: the calls the Python state machine makes when the CPU oracle answers every

@@ -397,6 +397,28 @@ def test_batched_scan_vs_reference(built, gpu_ctx, case, native):
                 check_call(d, rec, call)
 
 
+def test_scan_with_helper_threads_gives_the_reference_results(built, monkeypatch):
+    """PAV_HOST_THREADS = 4: the per-region loops of the native driver (lift results -> regions, job descriptors, decisions, the
+    texts written while a round's kernels run) are shared with three helper threads (csrc/pool.h).  Logs and calls equal the
+    reference's, as with the caller's thread alone."""
+    monkeypatch.setenv('PAV_HOST_THREADS', '4')
+    with _lib.Context(0) as ctx:                                      # a context of its own: the pool is made with the first index
+        for case in ('inv_hap', 'inv_rev', 'inv_nolift'):
+            d, lift, scans = load_case(ctx, case)
+            recs = [r for r in scans if not r['kwargs']]
+            regions = [pavseq.Region(r['flag']['chrom'], r['flag']['pos'], r['flag']['end']) for r in recs]
+            for rep in range(3):                                      # (threads: more than one go)
+                logs = [io.StringIO() for _ in regions]
+                out = pavinv.scan_for_inv_batch(regions, os.path.join(d, 'ref.fa'), os.path.join(d, 'tig.fa'), lift, KmerUtil(31), logs=logs,
+                                                ctx=ctx, native=True)
+                for rec, call, lg in zip(recs, out, logs):
+                    assert lg.getvalue().splitlines() == rec['log'], (case, rec['flag'], rep)
+                    if rec['call'] is None:
+                        assert call is None
+                    else:
+                        check_call(d, rec, call)
+
+
 @pytest.mark.parametrize('budget', ['1', '30000', '120000'])
 def test_small_batch_budget_gives_the_reference_results(built, gpu_ctx, monkeypatch, budget):
     """The native driver takes the regions of a round in batches of at most 64 Mbp (reference + contig bases); the regions behind
