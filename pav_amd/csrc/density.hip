@@ -81,7 +81,7 @@ struct HeadEvent { uint32_t job, row; int32_t state; uint32_t index, prev_index;
 
 struct DensityState {
     DevBuf jobs, stat, kde, tile_job_r, tile_job_t, keys, cnt, keys_x, cnt_x, lists, bcount, items;
-    DevBuf st_tmp, tile_sum, tile_pre, index, state_mer, state, kmer, kern[3], list[3], pscaled[3], fill_list;
+    DevBuf st_tmp, tile_sum, tile_pre, index, state_mer, state, kmer, kern[3], list[3], fill_list;
     DevBuf tiles, events, ev_count, scratch, run_arena, win_fill, ks[3], ss;
     DevBuf guard, guard_entries, samp_flag, row_flag, ftiles; // near-tie guard; evaluation tiles of the fill list
     DevBuf tile_heads, tile_head_cnt, heads, plan_flags, pow_tab;   // device-planned batches (k_plan)
@@ -128,7 +128,7 @@ struct DensityState {
     void release() {
         DevBuf *all[] = {&jobs, &stat, &kde, &tile_job_r, &tile_job_t, &keys, &cnt, &keys_x, &cnt_x, &lists, &bcount, &items, &st_tmp, &tile_sum, &tile_pre,
                          &index, &state_mer, &state, &kmer, &kern[0], &kern[1], &kern[2], &list[0], &list[1], &list[2],
-                         &pscaled[0], &pscaled[1], &pscaled[2], &fill_list, &tiles, &events, &ev_count, &scratch, &run_arena, &win_fill, &ks[0], &ks[1], &ks[2], &ss,
+                         &fill_list, &tiles, &events, &ev_count, &scratch, &run_arena, &win_fill, &ks[0], &ks[1], &ks[2], &ss,
                          &guard, &guard_entries, &samp_flag, &row_flag, &ftiles, &tile_heads, &tile_head_cnt, &heads, &plan_flags, &pow_tab,
                          &in_arena, &zero_arena, &table_block, &flank, &match};
         for (DevBuf *b : all) b->release();
@@ -1137,22 +1137,6 @@ __global__ __launch_bounds__(1024) void k_plan_fill(FillPlanArgs A) {
 }
 
 // ---- KDE -----------------------------------------------------------------------------------------------------
-// points_ = data * (1 / h): what scipy's solve_triangular computes for a 1x1 cho_cov.
-__global__ __launch_bounds__(256) void k_pscale(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
-                                                const JobKde *__restrict__ kde, const uint32_t *__restrict__ l0,
-                                                const uint32_t *__restrict__ l1, const uint32_t *__restrict__ l2,
-                                                double *__restrict__ p0, double *__restrict__ p1, double *__restrict__ p2) {
-    const uint64_t ap = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint32_t j = __builtin_amdgcn_readfirstlane(tile_job[(uint64_t)blockIdx.x * 256 / DTILE]);   // a workgroup lies in one tile
-    // few jobs need scaled positions (states summed term by term): look at the two words that say so before the 200-byte descriptor
-    if (!kde[j].finalised || !kde[j].ps_mask) return;
-    const JobKde kd = kde[j];
-    const uint64_t t = ap - jobs[j].tpos_off;
-    if ((kd.ps_mask & 1u) && t < kd.m[0]) p0[ap] = (double)l0[ap] * kd.inv_h[0];
-    if ((kd.ps_mask & 2u) && t < kd.m[1]) p1[ap] = (double)l1[ap] * kd.inv_h[1];
-    if ((kd.ps_mask & 4u) && t < kd.m[2]) p2[ap] = (double)l2[ap] * kd.inv_h[2];
-}
-
 __device__ __forceinline__ int argmax3(double a, double b, double c) {   // np.argmax: first maximum wins
     int m = 0; double v = a;
     if (b > v) { v = b; m = 1; }
@@ -1214,8 +1198,16 @@ __device__ __forceinline__ double uniform_f64(double v) {          // the first 
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
+// points_ = data * (1 / h) - what scipy's solve_triangular computes for a 1x1 cho_cov - made where it is read: the positions of a
+// state's rows times the state's 1 / h (round 3 kept them as arrays of doubles, written by a kernel of their own, k_pscale:
+// 8 B per row and state, and a launch per round that most jobs left at its first branch).
+struct ScaledList {
+    const uint32_t *l; double inv_h;
+    __device__ __forceinline__ double operator[](uint32_t i) const { return (double)l[i] * inv_h; }
+};
+
 // First index i in [0, m) with ps[i] >= v (ps ascending; wave-uniform arguments: scalar loads).
-__device__ __forceinline__ uint32_t ps_lower_bound(const double *__restrict__ ps, uint32_t m, double v) {
+__device__ __forceinline__ uint32_t ps_lower_bound(const ScaledList ps, uint32_t m, double v) {
     uint32_t lo = 0, hi = m;
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (ps[mid] < v) lo = mid + 1; else hi = mid; }
     return lo;
@@ -1224,7 +1216,7 @@ __device__ __forceinline__ uint32_t ps_lower_bound(const double *__restrict__ ps
 // gaussian_kernel_estimate (scipy/stats/_stats.pyx) for one state at one evaluation point; `ps` is wave-uniform so
 // the data stream goes through the scalar cache.  Accumulation order = data ascending, as in scipy.  [lo, hi): the data
 // points that can contribute to any point of the wave (everything outside adds exact zeros).
-__device__ __forceinline__ double kde_state(const double *__restrict__ ps, uint32_t lo, uint32_t hi, double xs, double norm, double w) {
+__device__ __forceinline__ double kde_state(const ScaledList ps, uint32_t lo, uint32_t hi, double xs, double norm, double w) {
     double est = 0.0;
     uint32_t i = lo;
     for (; i + 4 <= hi; i += 4) {
@@ -1341,7 +1333,7 @@ __device__ __forceinline__ double kde_state_runs(const RunDev *__restrict__ runs
 constexpr int KDE_WAVES = PAV_KDE_WAVES;
 struct KdeArgs {
     const JobDev *jobs; const JobKde *kde; const EvalTile *tiles; const uint32_t *fill_list;
-    const double *ps[3]; double *kern[3]; int8_t *state; const RunDev *runs;
+    const uint32_t *list[3]; double *kern[3]; int8_t *state; const RunDev *runs;      // list: the rows of each state (positions)
     double *ks[3]; int8_t *ss;            // sampled sites, compact: entry samp_off + q of job j = row min(q * srs, n - 1)
     GuardArgs G;
     uint32_t n_tiles;                     // tiles in the list; the workgroups go round them (grid = n_tiles: one each)
@@ -1390,7 +1382,7 @@ __global__ __launch_bounds__(64 * KDE_WAVES) void k_kde_eval(KdeArgs A) {
             double xlo = active ? xs : INFINITY, xhi = active ? xs : -INFINITY;
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) { xlo = fmin(xlo, __shfl_xor(xlo, d)); xhi = fmax(xhi, __shfl_xor(xhi, d)); }
-            const double *ps = A.ps[s] + off;
+            const ScaledList ps{A.list[s] + off, kd.inv_h[s]};
             uint32_t lo = __builtin_amdgcn_readfirstlane(ps_lower_bound(ps, kd.m[s], uniform_f64(xlo) - KDE_ZERO_R));
             uint32_t hi = __builtin_amdgcn_readfirstlane(ps_lower_bound(ps, kd.m[s], uniform_f64(xhi) + KDE_ZERO_R));
             if (kd.use_runs) {
@@ -2227,7 +2219,6 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     PAV_HIP(ctx, D->win_fill.reserve(a_t));
     for (int s = 0; s < 3; ++s) {
         PAV_HIP(ctx, D->list[s].reserve(4 * a_t));
-        PAV_HIP(ctx, D->pscaled[s].reserve(8 * a_t));
     }
     hipStream_t st = ctx->stream;
     lap("plan+alloc");
@@ -2449,13 +2440,10 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             PA.flags = D->plan_flags.as<uint32_t>();
             PAV_LAUNCH(ctx, "k_plan", k_plan, (n_jobs + 3) / 4, 256, 0, PA);
             const JobKde *d_kde = D->kde.as<JobKde>();
-            PAV_LAUNCH(ctx, "k_pscale", k_pscale, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_kde, D->list[0].as<uint32_t>(),
-                       D->list[1].as<uint32_t>(), D->list[2].as<uint32_t>(), D->pscaled[0].as<double>(), D->pscaled[1].as<double>(),
-                       D->pscaled[2].as<double>());
             KdeArgs KA;
             KA.jobs = d_jobs; KA.kde = d_kde; KA.fill_list = D->fill_list.as<uint32_t>(); KA.state = D->state.as<int8_t>();
             KA.runs = D->heads.as<RunDev>(); KA.dyn = 1;
-            for (int q = 0; q < 3; ++q) { KA.ps[q] = D->pscaled[q].as<double>(); KA.kern[q] = D->kern[q].as<double>(); KA.ks[q] = D->ks[q].as<double>(); }
+            for (int q = 0; q < 3; ++q) { KA.list[q] = D->list[q].as<uint32_t>(); KA.kern[q] = D->kern[q].as<double>(); KA.ks[q] = D->ks[q].as<double>(); }
             KA.ss = D->ss.as<int8_t>();
             G.pass = 0;
             KA.G = G;
@@ -2807,7 +2795,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     KdeArgs KA;
     KA.jobs = d_jobs; KA.kde = d_kde; KA.fill_list = D->fill_list.as<uint32_t>(); KA.state = D->state.as<int8_t>();
     KA.runs = D->run_arena.as<RunDev>(); KA.dyn = 0; KA.n_tiles_dev = nullptr; KA.n_tiles = 0;
-    for (int s = 0; s < 3; ++s) { KA.ps[s] = D->pscaled[s].as<double>(); KA.kern[s] = D->kern[s].as<double>(); KA.ks[s] = D->ks[s].as<double>(); }
+    for (int s = 0; s < 3; ++s) { KA.list[s] = D->list[s].as<uint32_t>(); KA.kern[s] = D->kern[s].as<double>(); KA.ks[s] = D->ks[s].as<double>(); }
     KA.ss = D->ss.as<int8_t>();
     RedoArgs RA;
     RA.jobs = d_jobs; RA.kde = d_kde; RA.ss = D->ss.as<int8_t>(); RA.win_fill = D->win_fill.as<uint8_t>();
@@ -2854,9 +2842,6 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             PAV_HIP(ctx, hipMemcpyAsync(d_stat, hs.data(), sizeof(JobStat) * n_jobs, hipMemcpyHostToDevice, st));
         }
         if (any_ps)
-            PAV_LAUNCH(ctx, "k_pscale", k_pscale, (uint32_t)(a_t / 256), 256, 0, d_jobs, d_tjt, d_kde, D->list[0].as<uint32_t>(),
-                       D->list[1].as<uint32_t>(), D->list[2].as<uint32_t>(), D->pscaled[0].as<double>(), D->pscaled[1].as<double>(),
-                       D->pscaled[2].as<double>());
         G.pass = 0;
         KA.G = G;
         KA.tiles = D->tiles.as<EvalTile>(); KA.n_tiles = (uint32_t)tiles.size();
