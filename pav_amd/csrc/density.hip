@@ -1480,7 +1480,7 @@ struct FinArgs {
     const JobDev *jobs; const uint32_t *tile_job; const JobKde *kde; const JobStat *stat;
     const uint8_t *win_fill; const double *ks[3]; double *kern[3]; int8_t *state; const uint32_t *index;
     HeadEvent *events; uint32_t ev_cap; uint32_t *ev_count;
-    GuardArgs G; uint32_t *blk_spike;
+    GuardArgs G; uint32_t *blk_spike; int spike_add = 0;
 };
 
 // Densities of row x of a finalised job before the spike rule: a sampled site comes from the compact arrays, a row of an
@@ -1577,7 +1577,12 @@ __global__ __launch_bounds__(256) void k_finalize(FinArgs A) {
     const unsigned long long bal = __ballot(spike_near);
     if ((threadIdx.x & 63) == 0) s_spike[threadIdx.x >> 6] = (uint32_t)__popcll(bal);
     __syncthreads();
-    if (A.blk_spike && threadIdx.x == 0) A.blk_spike[blockIdx.x] = s_spike[0] + s_spike[1] + s_spike[2] + s_spike[3];
+    if (threadIdx.x == 0 && (A.blk_spike || A.spike_add)) {
+        const uint32_t c = s_spike[0] + s_spike[1] + s_spike[2] + s_spike[3];
+        // device-planned batches run this kernel once: the (rare) counts are added where they are read; the host-planned path may
+        // repeat it and sums the blocks' plain stores afterwards (k_spike_sum)
+        if (A.spike_add) { if (c) atomicAdd(&G.stat[j].n_spike, c); } else A.blk_spike[blockIdx.x] = c;
+    }
     if (!live) return;
     // run heads
     bool head = x == 0;
@@ -2465,10 +2470,8 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             FA.state = D->state.as<int8_t>(); FA.index = D->index.as<uint32_t>();
             for (int q = 0; q < 3; ++q) { FA.ks[q] = D->ks[q].as<double>(); FA.kern[q] = D->kern[q].as<double>(); }
             FA.G = G; FA.ev_cap = ev_cap; FA.events = D->events.as<HeadEvent>(); FA.ev_count = D->ev_count.as<uint32_t>();
-            FA.blk_spike = G.rel > 0.0 ? D->scratch.as<uint32_t>() : nullptr;
+            FA.blk_spike = nullptr; FA.spike_add = G.rel > 0.0 ? 1 : 0;
             PAV_LAUNCH(ctx, "k_finalize", k_finalize, (uint32_t)(a_t / 256), 256, 0, FA);
-            if (G.rel > 0.0)
-                PAV_LAUNCH(ctx, "k_spike_sum", k_spike_sum, n_jobs, 256, 0, d_jobs, d_kde, D->scratch.as<uint32_t>(), d_stat);
             lap("enqueue");
             // the one readback: the front of the zero arena - event count, guard counters, plan flags, statistics, run heads of STATE
             const uint32_t pre = ev_first;
