@@ -453,25 +453,24 @@ struct ScanArgs {
     volatile uint64_t *host_status;                  // [0, NT) totals, [NT] token error key, [NT + 1] illegal operation slot,
 };                                                   // [NT + 2] / [NT + 3] first row that overruns its reference / query record
 
-constexpr int TS_THREADS = 1024;                                       // 8192 tiles per step (round 4; 256 lanes, 4096 tiles before)
-__global__ __launch_bounds__(TS_THREADS) void tile_scan(ScanArgs A) {
-    constexpr int PER = 8, T = TS_THREADS, W = TS_THREADS / 64;
-    __shared__ uint64_t lds[W];
-    __shared__ uint64_t tile[T * (PER + 1)];
+__global__ __launch_bounds__(256) void tile_scan(ScanArgs A) {
+    constexpr int PER = 16;
+    __shared__ uint64_t lds[4];
+    __shared__ uint64_t tile[256 * (PER + 1)];
     const uint32_t q = blockIdx.x, n = A.n_tiles;
     uint64_t *x = A.tile_agg + (uint64_t)q * (n + 1);
     uint64_t carry = 0;
-    for (uint32_t base = 0; base < n; base += T * PER) {
+    for (uint32_t base = 0; base < n; base += 256 * PER) {
         uint64_t c[PER];
 #pragma unroll
-        for (int k = 0; k < PER; ++k) { const uint32_t i = base + k * T + threadIdx.x; c[k] = i < n ? x[i] : 0ull; }
+        for (int k = 0; k < PER; ++k) { const uint32_t i = base + k * 256 + threadIdx.x; c[k] = i < n ? x[i] : 0ull; }
 #pragma unroll
-        for (int k = 0; k < PER; ++k) { const uint32_t j = k * T + threadIdx.x; tile[j + j / PER] = c[k]; }
+        for (int k = 0; k < PER; ++k) { const uint32_t j = k * 256 + threadIdx.x; tile[j + j / PER] = c[k]; }
         __syncthreads();
         uint64_t v[1] = {0}, tot[1];
 #pragma unroll
         for (int k = 0; k < PER; ++k) { c[k] = tile[threadIdx.x * (PER + 1) + k]; v[0] += c[k]; }
-        block_excl_scan<1, W>(v, tot, lds);
+        block_excl_scan<1>(v, tot, lds);
         uint64_t run = carry + v[0];
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
@@ -489,12 +488,12 @@ __global__ __launch_bounds__(TS_THREADS) void tile_scan(ScanArgs A) {
     __syncthreads();
     auto pre = [&](uint32_t i) { return __hip_atomic_load(x + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     if (q == (uint32_t)NQ) {
-        for (uint32_t r = threadIdx.x; r <= A.n_aln; r += T) A.op_off[r] = pre(A.row_tile[r]) + A.row_i[r];
+        for (uint32_t r = threadIdx.x; r <= A.n_aln; r += 256) A.op_off[r] = pre(A.row_tile[r]) + A.row_i[r];
         return;
     }
-    __shared__ unsigned long long red[W];
+    __shared__ unsigned long long red[4];
     unsigned long long bad = ~0ull;
-    for (uint32_t r = threadIdx.x; r <= A.n_aln; r += T) {
+    for (uint32_t r = threadIdx.x; r <= A.n_aln; r += 256) {
         const uint64_t here = pre(A.row_tile[r]) + A.row_local[2ull * r + q];
         A.rowbase[2ull * r + q] = here;
         if (r < A.n_aln) {
@@ -509,7 +508,7 @@ __global__ __launch_bounds__(TS_THREADS) void tile_scan(ScanArgs A) {
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = bad;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < W; ++w) bad = red[w] < bad ? red[w] : bad;
+        for (int w = 1; w < 4; ++w) bad = red[w] < bad ? red[w] : bad;
         A.host_status[NT + 2 + q] = bad;
     }
 }
@@ -1703,7 +1702,7 @@ int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
     SA.row_tile = B.row_tile; SA.row_i = B.row_i; SA.row_local = B.row_local; SA.op_off = B.op_off; SA.rowbase = B.rowbase;
     SA.aln = ctx->d_aln.as<pav_aln>(); SA.ref = ctx->seq[PAV_ROLE_REF].view(); SA.tig = ctx->seq[PAV_ROLE_TIG].view();
     SA.tok_err = B.tok_err; SA.err_op = B.err_op; SA.host_status = h_status;
-    PAV_LAUNCH(ctx, "tile_scan", tile_scan, NT, TS_THREADS, 0, SA);
+    PAV_LAUNCH(ctx, "tile_scan", tile_scan, NT, 256, 0, SA);
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     uint64_t totals[NQ];
     for (int q = 0; q < NQ; ++q) totals[q] = h_status[q];
