@@ -686,21 +686,20 @@ __global__ __launch_bounds__(256) void k_state_combine(const JobDev *__restrict_
 
 // Device-planned batches: the compaction prefix straight from k_state_combine's per-tile state counts - a state whose job total
 // is below the minimum is dropped (density.py:181-190) - one workgroup per counter ([0] rows kept, [1 + s] rows of state s kept),
-// 8192 tiles per step.  Replaces k_compact_reduce + the single-workgroup k_scan_tiles4 of the host-planned path.
-constexpr int STK_THREADS = 1024, STK_PER = 8;                         // 8192 tiles per step: a thousand-region round is one step
-__global__ __launch_bounds__(STK_THREADS) void k_scan_tiles_keep(const uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_job,
-                                                                const JobStat *__restrict__ stat, uint32_t min_state_count,
-                                                                unsigned long long *__restrict__ tile_pre, uint32_t n_tiles) {
-    constexpr int PER = STK_PER, T = STK_THREADS, W = STK_THREADS / 64;
-    __shared__ uint32_t lds[W];
-    __shared__ uint32_t tile[T * (PER + 1)];
+// 4096 tiles per step.  Replaces k_compact_reduce + the single-workgroup k_scan_tiles4 of the host-planned path.
+__global__ __launch_bounds__(256) void k_scan_tiles_keep(const uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_job,
+                                                        const JobStat *__restrict__ stat, uint32_t min_state_count,
+                                                        unsigned long long *__restrict__ tile_pre, uint32_t n_tiles) {
+    constexpr int PER = 16;
+    __shared__ uint32_t lds[4];
+    __shared__ uint32_t tile[256 * (PER + 1)];
     const uint32_t q = blockIdx.x;
     unsigned long long carry = 0;
-    for (uint32_t base = 0; base < n_tiles; base += T * PER) {
+    for (uint32_t base = 0; base < n_tiles; base += 256 * PER) {
         uint32_t c[PER];
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            const uint32_t i = base + k * T + threadIdx.x;
+            const uint32_t i = base + k * 256 + threadIdx.x;
             uint32_t v = 0;
             if (i < n_tiles) {
                 const JobStat &js = stat[tile_job[i]];
@@ -712,7 +711,7 @@ __global__ __launch_bounds__(STK_THREADS) void k_scan_tiles_keep(const uint32_t 
             c[k] = v;
         }
 #pragma unroll
-        for (int k = 0; k < PER; ++k) { const uint32_t jx = k * T + threadIdx.x; tile[jx + jx / PER] = c[k]; }
+        for (int k = 0; k < PER; ++k) { const uint32_t jx = k * 256 + threadIdx.x; tile[jx + jx / PER] = c[k]; }
         __syncthreads();
         uint32_t sum = 0;
 #pragma unroll
@@ -725,7 +724,7 @@ __global__ __launch_bounds__(STK_THREADS) void k_scan_tiles_keep(const uint32_t 
         __syncthreads();
         uint32_t before = inc - sum, tot = 0;
 #pragma unroll
-        for (int w = 0; w < W; ++w) { if (w < wave) before += lds[w]; tot += lds[w]; }
+        for (int w = 0; w < 4; ++w) { if (w < wave) before += lds[w]; tot += lds[w]; }
         unsigned long long run = carry + before;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
@@ -2433,7 +2432,7 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
                 G.samp_flag = D->samp_flag.as<uint32_t>(); G.row_flag = D->row_flag.as<uint8_t>();
             }
             CA.tile_heads = D->tile_heads.as<uint32_t>(); CA.tile_head_cnt = D->tile_head_cnt.as<uint32_t>(); CA.scan_only = scan_only ? 1 : 0;
-            PAV_LAUNCH(ctx, "k_scan_tiles_keep", k_scan_tiles_keep, 4, STK_THREADS, 0, D->tile_sum.as<uint32_t>(), d_tjt, d_stat, pp->min_state_count,
+            PAV_LAUNCH(ctx, "k_scan_tiles_keep", k_scan_tiles_keep, 4, 256, 0, D->tile_sum.as<uint32_t>(), d_tjt, d_stat, pp->min_state_count,
                        D->tile_pre.as<unsigned long long>(), n_tiles_t);
             PAV_LAUNCH(ctx, "k_compact_scatter", k_compact_scatter, n_tiles_t, 256, 0, CA);
             CA.tile_heads = nullptr; CA.tile_head_cnt = nullptr; CA.scan_only = 0;
