@@ -133,10 +133,15 @@ def main():
     comm_device = 'cuda' if args.backend == 'nccl' else 'cpu'
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if args.backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-        else:
-            dist.init_process_group(args.backend)
+    # the first contact with the other ranks, before any work: device count, one all_reduce that must sum to the world size, one
+    # distinct GPU per rank (pav_amd/shard.py) - a fabric / IPC problem ends the run here with a message
+    from pav_amd.shard import first_contact
+    if args.backend == 'nccl':
+        gpu_info = first_contact('nccl', rank, world, local_rank, share_gpu=args.share_gpu)
+    else:
+        gpu_info = first_contact(args.backend, rank, world, local_rank, share_gpu=True)
+        gpu_info['device_name'] = torch.cuda.get_device_name(local_rank)
+    print(f"[bench] rank {rank}/{world}: {gpu_info['device_name']} {gpu_info['pci_bus_id']}", file=sys.stderr, flush=True)
 
     import io
     import threading
@@ -453,12 +458,14 @@ def main():
         aligned_total = float(ab.item())
         per_rank = [None] * world
         dist.all_gather_object(per_rank, {'rank': rank, 'ms_per_step': round(t_local / args.steps * 1e3, 4),
+                                          'device_name': lanes[0].ctx.device_name, 'pci_bus_id': lanes[0].ctx.pci_bus_id,
                                           'lanes_per_gpu': n_lanes, 'usable_cpus': round(cpus_per_rank, 2),
                                           'aligned_bp': aligned_steps / args.steps,
                                           'cigar_text_bytes': int(sum(ln.text.shape[0] for ln in lanes))})
     else:
         aligned_total = aligned_steps
-        per_rank = [{'rank': 0, 'ms_per_step': round(t_local / args.steps * 1e3, 4), 'lanes_per_gpu': n_lanes,
+        per_rank = [{'rank': 0, 'ms_per_step': round(t_local / args.steps * 1e3, 4), 'device_name': lanes[0].ctx.device_name,
+                     'pci_bus_id': lanes[0].ctx.pci_bus_id, 'lanes_per_gpu': n_lanes,
                      'usable_cpus': round(cpus_per_rank, 2), 'aligned_bp': aligned_steps / args.steps,
                      'cigar_text_bytes': int(sum(ln.text.shape[0] for ln in lanes))}]
 
@@ -625,7 +632,7 @@ def main():
                     m = _re.search(r':(\d+)-(\d+)', ln.split(': ')[1])
                     scanned_bp += int(m.group(2)) - int(m.group(1)) + 1
         pmc = None                                            # committed PMC summary of this workload, newest round first
-        for pmc_name in ('r04_pmc.json', 'r03_pmc.json', 'r02_pmc.json', 'r01_pmc.json'):
+        for pmc_name in ('r05_pmc.json', 'r04_pmc.json', 'r03_pmc.json', 'r02_pmc.json', 'r01_pmc.json'):
             try:
                 with open(os.path.join(ROOT, 'profiles', pmc_name)) as fh:
                     cand = json.load(fh)
@@ -647,7 +654,7 @@ def main():
         # nothing stored, the ceiling of the memory system for this access pattern
         line_roof = {'with_stores': None, 'with_stores_variant': None, 'loads_only': None, 'loads_only_variant': None,
                      'source': 'profiles/r03_gather_rate.txt'}
-        for cand_ in ('r04_gather_rate.txt', 'r03_gather_rate.txt'):
+        for cand_ in ('r05_gather_rate.txt', 'r04_gather_rate.txt', 'r03_gather_rate.txt'):
             if os.path.exists(os.path.join(ROOT, 'profiles', cand_)):
                 line_roof['source'] = 'profiles/' + cand_
                 break
@@ -673,8 +680,8 @@ def main():
             if snv_lines is None or not pmc or 'walk_snv' not in kern_ or 'homology_kernel' not in kern_:
                 return None
             hom_lines = pmc.get('fetch_kib', {}).get('homology_kernel')
-            if not hom_lines:
-                return None
+            if not hom_lines or not _lib.kernel_sources_match(pmc.get('provenance'), 'homology_kernel'):
+                return None                                   # (no counter of this source of the kernel: nothing quoted)
             hom_lines = hom_lines * 1024.0 / 64.0
             t_ms = max(kern_['walk_snv']['avg_ms'], kern_['homology_kernel']['avg_ms'])
             rate = (snv_lines + hom_lines) / (t_ms * 1e-3) / 1e9
@@ -725,14 +732,21 @@ def main():
             # HBM traffic of the dominant kernel from the committed PMC summary of the same workload (profiles/r01_pmc.json;
             # separate rocprofv3 --pmc passes).  FETCH_SIZE is doubled for the 16 B/lane streaming kernels as the guide prescribes.
             traffic = None
-            if pmc and dom in pmc.get('fetch_kib', {}) and dom in pmc.get('write_kib', {}):
+            # a committed counter is quoted only for the source it was taken on: the profile's provenance stamp
+            # (tools/prof_summary.py) must name the same cigar.hip / density.hip ... as the library that runs here
+            pmc_fresh = bool(pmc) and _lib.kernel_sources_match(pmc.get('provenance'), dom)
+            if pmc and pmc_fresh and dom in pmc.get('fetch_kib', {}) and dom in pmc.get('write_kib', {}):
                 fx = 2.0 if dom in ('pack_kernel', 'verify_kernel') else 1.0          # 16 B/lane streams (verify: its 2-bit windows)
                 traffic = (pmc['fetch_kib'][dom] * fx + pmc['write_kib'][dom]) * 1024.0
             a_bytes = alg_bytes.get(dom)
             achieved = a_bytes / (kern_[dom]['avg_ms'] * 1e-3) / 1e9 if a_bytes and kern_[dom]['avg_ms'] > 0 else None
             head = {'kernel': dom, 'bound': 'hbm', 'achieved': None if achieved is None else round(achieved, 1),
                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
-                    'traffic': traffic, 'algorithmic_bytes_per_launch': a_bytes}
+                    'traffic': traffic, 'algorithmic_bytes_per_launch': a_bytes,
+                    'pmc_source': None if not pmc else {'file': pmc.get('file'), 'commit': (pmc.get('provenance') or {}).get('commit'),
+                                                        'library_source_sha16': (pmc.get('provenance') or {}).get('library_source_sha16'),
+                                                        'running_library_source_sha16': _lib.source_fingerprint()['library_source_sha16'],
+                                                        'kernel_source_unchanged': pmc_fresh}}
             if dom == 'k_kde_eval' and kde and kern_[dom]['launches'] and kern_[dom]['avg_ms'] > 0:
                 # the kernel densities: FP64 exp work, no bytes to speak of.  Algorithmic flops = SURVEY 8(d): 25 per (evaluation
                 # point, data point) pair of scipy's double loop.  The kernel does not run that loop - a run of consecutive
@@ -775,13 +789,14 @@ def main():
             top = sorted(tot, key=lambda k_: -tot[k_][1])
             dom_l = top[0]
             lds = None
-            for lds_name in ('r04_lds_counters.json',):
+            for lds_name in ('r05_lds_counters.json', 'r04_lds_counters.json'):
                 try:
                     with open(os.path.join(ROOT, 'profiles', lds_name)) as fh:
                         lds = json.load(fh)
                     lds['file'] = 'profiles/' + lds_name
+                    break
                 except (OSError, ValueError):
-                    pass
+                    lds = None
 
             def lds_roof(k_, avg_ms_):
                 # LDS-array cycles of a launch (SQ_LDS_IDX_ACTIVE, summed over the CUs; committed counter pass taken with the same
@@ -789,6 +804,9 @@ def main():
                 # time the kernel keeps busy; `conflict` = the share of those cycles that are bank-conflict replays
                 if not lds or k_ not in lds.get('kernels', {}) or avg_ms_ <= 0:
                     return None
+                if not _lib.kernel_sources_match(lds.get('provenance'), k_):
+                    return {'bound': 'lds', 'frac': None, 'source': lds.get('file'),
+                            'note': 'the committed counters were taken on another source of this kernel (provenance stamp differs): not quoted'}
                 c_ = lds['kernels'][k_]
                 peak_cyc = 256 * 2.4e9 * avg_ms_ * 1e-3
                 return {'bound': 'lds', 'lds_array_cycles_per_launch': c_['lds_idx_active'], 'peak_cycles_in_launch': round(peak_cyc),
@@ -845,7 +863,8 @@ def main():
             ratios = {}
             model = make_roofline(prof)[1]
             for k_, gbs in model['modelled_kernels_gbs'].items():
-                if k_ in pmc.get('fetch_kib', {}) and k_ in pmc.get('write_kib', {}) and kern[k_]['avg_ms'] > 0:
+                if k_ in pmc.get('fetch_kib', {}) and k_ in pmc.get('write_kib', {}) and kern[k_]['avg_ms'] > 0 \
+                        and _lib.kernel_sources_match(pmc.get('provenance'), k_):
                     fx = 2.0 if k_ in ('pack_kernel', 'verify_kernel') else 1.0
                     tr = (pmc['fetch_kib'][k_] * fx + pmc['write_kib'][k_]) * 1024.0
                     ab = gbs * 1e9 * kern[k_]['avg_ms'] * 1e-3
@@ -855,7 +874,8 @@ def main():
             if 'walk_snv' in pmc.get('fetch_kib', {}) and 'walk_snv' in pmc.get('write_kib', {}) and snv_lines:
                 line_model = round((pmc['fetch_kib']['walk_snv'] + pmc['write_kib']['walk_snv']) * 1024.0 /
                                    (4.0 * n_ops + 16.0 * n_snv + 64.0 * snv_lines), 2)
-            roofline['traffic_over_algorithmic'] = {'source': pmc.get('file'), 'ratio': ratios,
+            roofline['traffic_over_algorithmic'] = {'source': pmc.get('file'), 'source_commit': (pmc.get('provenance') or {}).get('commit'),
+                                                    'only_kernels_whose_source_is_unchanged_since': True, 'ratio': ratios,
                                                     'walk_snv_over_line_granular_model': line_model}
 
         def add_alone(roof):

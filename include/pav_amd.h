@@ -47,6 +47,7 @@ pav_ctx *pav_create(int device_id);               /* NULL on failure; then pav_l
 void pav_destroy(pav_ctx *ctx);
 const char *pav_last_error(const pav_ctx *ctx);
 int pav_device_name(const pav_ctx *ctx, char *buf, int buf_len);
+int pav_device_pci_bus_id(const pav_ctx *ctx, char *buf, int buf_len);   /* "0000:c5:00.0" (buf_len >= 16): which GPU a rank drives */
 int pav_sync(pav_ctx *ctx);                       /* hipStreamSynchronize on the context's stream          */
 int pav_mem_info(pav_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);   /* HBM of the context's GPU (hipMemGetInfo) */
 /* Density work done by the context since it was created (for roofline accounting, bench.py): out[0] evaluation points of

@@ -181,6 +181,7 @@ SYMBOLS = {
     'pav_destroy': (None, [_P]),
     'pav_last_error': (ctypes.c_char_p, [_P]),
     'pav_device_name': (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int]),
+    'pav_device_pci_bus_id': (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int]),
     'pav_sync': (ctypes.c_int, [_P]),
     'pav_mem_info': (ctypes.c_int, [_P, _P, _P]),
     'pav_kde_work': (ctypes.c_int, [_P, _P]),
@@ -276,6 +277,54 @@ def _preload_hip_runtime():
             pass
 
 
+def source_fingerprint():
+    """What the library at LIB_PATH was built from, for the provenance stamp of committed profiles (tools/prof_summary.py writes
+    it, bench.py compares it): sha256 (16 hex digits) of every file under csrc/ and of include/pav_amd.h, the kernels each file
+    defines, the build flags of __graft_entry__.build_hip, and the git commit when the tree has one (the GPU box's copy has not)."""
+    import hashlib
+    import re
+    import subprocess
+    csrc = os.path.join(_HERE, 'csrc')
+    files, kernels = {}, {}
+    for path in sorted([os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(os.path.dirname(_HERE), 'include', 'pav_amd.h')]):
+        if not os.path.isfile(path):
+            continue
+        with open(path, 'rb') as fh:
+            data = fh.read()
+        name = os.path.basename(path)
+        files[name] = hashlib.sha256(data).hexdigest()[:16]
+        for k in re.findall(rb'__global__(?:\s+__launch_bounds__\s*\([^)]*\))?\s+void\s+(\w+)\s*\(', data):
+            kernels[k.decode()] = name
+        for k in re.findall(rb'PAV_LAUNCH(?:_ON)?\s*\([^"\n]*"(\w+)"', data):    # launch labels (walk_snv = walk_emit<WALK_SNV>)
+            kernels.setdefault(k.decode(), name)
+    commit = None
+    try:
+        r = subprocess.run(['git', '-C', os.path.dirname(_HERE), 'rev-parse', 'HEAD'], capture_output=True, text=True, timeout=10)
+        if r.returncode == 0:
+            commit = r.stdout.strip()
+            d = subprocess.run(['git', '-C', os.path.dirname(_HERE), 'status', '--porcelain', '--', 'pav_amd/csrc', 'include'],
+                               capture_output=True, text=True, timeout=10)
+            if d.stdout.strip():
+                commit += '+dirty'
+    except (OSError, subprocess.SubprocessError):
+        pass
+    whole = hashlib.sha256(''.join(f'{k}:{v};' for k, v in sorted(files.items())).encode()).hexdigest()[:16]
+    return {'library_source_sha16': whole, 'files': files, 'kernel_file': kernels, 'commit': commit,
+            'build_flags': '--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off'}
+
+
+def kernel_sources_match(stamp, kernel):
+    """True when the committed profile `stamp` (a source_fingerprint() of the run it was taken on) was taken on the same source
+    of `kernel` as the library here: the file that defines it, common.h and the public header are unchanged."""
+    if not stamp or 'files' not in stamp:
+        return False
+    now = source_fingerprint()
+    f = now['kernel_file'].get(kernel.split('<')[0])
+    if f is None:
+        return False
+    return all(stamp['files'].get(x) == now['files'].get(x) for x in (f, 'common.h', 'pav_amd.h'))
+
+
 def load():
     """Load libpav_amd.so and declare every prototype.  Raises PavDeviceError if it is not built."""
     global _LIB
@@ -346,6 +395,12 @@ class Context:
     def device_name(self):
         buf = ctypes.create_string_buffer(256)
         self._check(self.lib.pav_device_name(self.handle, buf, 256), 'pav_device_name')
+        return buf.value.decode()
+
+    @property
+    def pci_bus_id(self):
+        buf = ctypes.create_string_buffer(64)
+        self._check(self.lib.pav_device_pci_bus_id(self.handle, buf, 64), 'pav_device_pci_bus_id')
         return buf.value.decode()
 
     def sync(self):

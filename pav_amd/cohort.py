@@ -30,6 +30,9 @@ from dataclasses import dataclass
 from . import rules, shard
 
 
+SHARE_GPU_MAX_BYTES = 8 << 20       # run_cohort(share_gpu=True): alignment tables above this are refused (test mode only)
+
+
 @dataclass
 class HaplotypeJob:
     asm_name: str
@@ -174,10 +177,25 @@ def _default_engine(rank, device_id, ref_fa, config):
     return DeviceEngine(device_id, ref_fa, config, lanes=int((config or {}).get('pav_amd_lanes', 1)))
 
 
-def _barrier(world):
-    if world > 1:
+def _stage(world, rank, name, fn, sync):
+    """Run one stage of a rank; with ``sync`` the ranks then exchange whether it failed anywhere (the exchange is the stage's
+    barrier).  The failing rank raises its own exception, the others a RuntimeError that names it."""
+    err = None
+    try:
+        fn()
+    except BaseException as ex:                                  # noqa: BLE001 - exchanged, then raised again below
+        err = ex
+        if not (sync and world > 1) or not isinstance(ex, Exception):
+            raise
+    if sync and world > 1:
         import torch.distributed as dist
-        dist.barrier()
+        seen = [None] * world
+        dist.all_gather_object(seen, None if err is None else f'{type(err).__name__}: {err}')
+        if err is not None:
+            raise err
+        bad = [(r, m) for r, m in enumerate(seen) if m is not None]
+        if bad:
+            raise RuntimeError(f"run_cohort: stage '{name}' failed on rank {bad[0][0]}: {bad[0][1]} (this is rank {rank})")
 
 
 class _GpuTurn:
@@ -220,13 +238,20 @@ def run_rank(rank, world, jobs, out_dir, ref_fa, config=None, engine_factory=Non
     manifests = []
     shared = sorted({(j, n, lead) for its in items for (j, p, n, lead) in its if n > 1})
     turn = _GpuTurn(share_gpu and world > 1, out_dir)
-    with turn:
-        engine.open()
+    sync = True                                                # every stage ends with the ranks' error state exchanged (_stage)
     try:
+        def opened():
+            with turn:
+                engine.open()                                  # (inside the try: contexts created before a failure are closed)
+        _stage(world, rank, 'open', opened, sync)
         whole = [jobs[j] for (j, p, n, lead) in mine if n == 1]
         many = getattr(engine, 'call_haplotypes', None)
-        with turn:
-            done = many(whole, out_dir) if many else [engine.call_haplotype(j, out_dir) for j in whole]
+        done = []
+
+        def whole_haplotypes():
+            with turn:
+                done.extend(many(whole, out_dir) if many else [engine.call_haplotype(j, out_dir) for j in whole])
+        _stage(world, rank, 'whole haplotypes', whole_haplotypes, sync)
         for m in done:
             m['rank'], m['mode'] = rank, 'whole haplotype'
             manifests.append(m)
@@ -235,30 +260,37 @@ def run_rank(rank, world, jobs, out_dir, ref_fa, config=None, engine_factory=Non
         paths = {j: rules.haplotype_paths(out_dir, jobs[j].asm_name, jobs[j].hap, batch_count) for (j, n, lead) in shared}
         for j in my_part:
             rules._makedirs_for(paths[j])
-        for j, (p, n) in my_part.items():                                       # stage 1: rule call_cigar, batches p, p + n, ...
-            with turn:
-                engine.call_cigar_batches(jobs[j], paths[j], list(range(p, rules.CALL_CIGAR_BATCH_COUNT, n)))
-        if shared:
-            _barrier(world)
-        for (j, n, lead) in shared:                                             # stage 2 (lead): call_cigar_merge + the five flag rules
-            if lead == rank:
-                P = paths[j]
-                rules.call_cigar_merge(P['cigar_batch_insdel'], P['cigar_batch_snv'], P['insdel'], P['snv'])
+        # (every stage ends with _stage's exchange of the ranks' error state in place of a bare barrier: a rank that fails
+        #  takes its peers down with a message instead of leaving them in the barrier until the group times out)
+        def stage1():                                                           # rule call_cigar, batches p, p + n, ...
+            for j, (p, n) in my_part.items():
                 with turn:
-                    engine.flag_tables(jobs[j], P)
+                    engine.call_cigar_batches(jobs[j], paths[j], list(range(p, rules.CALL_CIGAR_BATCH_COUNT, n)))
+
+        def stage2():                                                           # (lead) call_cigar_merge + the five flag rules
+            for (j, n, lead) in shared:
+                if lead == rank:
+                    P = paths[j]
+                    rules.call_cigar_merge(P['cigar_batch_insdel'], P['cigar_batch_snv'], P['insdel'], P['snv'])
+                    with turn:
+                        engine.flag_tables(jobs[j], P)
+
+        def stage3():                                                           # rule call_inv_batch, batches p, p + n, ...
+            for j, (p, n) in my_part.items():
+                with turn:
+                    engine.call_inv_batches(jobs[j], paths[j], list(range(p, batch_count, n)))
+
+        def stage4():                                                           # (lead) call_inv_batch_merge
+            for (j, n, lead) in shared:
+                if lead == rank:
+                    P = paths[j]
+                    df = rules.call_inv_batch_merge(P['inv_batch'], P['inv'])
+                    manifests.append({'asm_name': jobs[j].asm_name, 'hap': jobs[j].hap, 'rank': rank, 'mode': f'shared by {n} ranks',
+                                      'inv_calls': int(df.shape[0]), 'files': {k: P[k] for k in ('snv', 'insdel', 'flagged_regions', 'inv')}})
         if shared:
-            _barrier(world)
-        for j, (p, n) in my_part.items():                                       # stage 3: rule call_inv_batch, batches p, p + n, ...
-            with turn:
-                engine.call_inv_batches(jobs[j], paths[j], list(range(p, batch_count, n)))
-        if shared:
-            _barrier(world)
-        for (j, n, lead) in shared:                                             # stage 4 (lead): call_inv_batch_merge
-            if lead == rank:
-                P = paths[j]
-                df = rules.call_inv_batch_merge(P['inv_batch'], P['inv'])
-                manifests.append({'asm_name': jobs[j].asm_name, 'hap': jobs[j].hap, 'rank': rank, 'mode': f'shared by {n} ranks',
-                                  'inv_calls': int(df.shape[0]), 'files': {k: P[k] for k in ('snv', 'insdel', 'flagged_regions', 'inv')}})
+            for name, fn in (('call_cigar batches', stage1), ('call_cigar_merge + flagging', stage2),
+                             ('call_inv_batch batches', stage3), ('call_inv_batch_merge', stage4)):
+                _stage(world, rank, name, fn, True)
     finally:
         engine.close()
     return manifests
@@ -282,14 +314,9 @@ def _free_port():
 def _child(rank, world, port, backend, args, queue):
     os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'RANK': str(rank), 'WORLD_SIZE': str(world),
                        'LOCAL_RANK': str(rank)})
-    import torch
     import torch.distributed as dist
     jobs, out_dir, ref_fa, config, engine_factory, split, share_gpu = args
-    if backend == 'nccl':
-        torch.cuda.set_device(0 if share_gpu else rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0 if share_gpu else rank))
-    else:
-        dist.init_process_group(backend, rank=rank, world_size=world)
+    shard.first_contact(backend, rank, world, rank, share_gpu)     # group up, one all_reduce answered, one GPU per rank
     try:
         ms = _gather(run_rank(rank, world, jobs, out_dir, ref_fa, config, engine_factory, split, share_gpu), world)
         dist.barrier()
@@ -311,6 +338,14 @@ def run_cohort(jobs, n_gpus, out_dir, ref_fa, config=None, engine_factory=None, 
     ``multiprocessing``'s *spawn* method: a script that calls this with ``n_gpus > 1`` needs the usual
     ``if __name__ == '__main__':`` guard around its top-level code."""
     jobs = [j if isinstance(j, HaplotypeJob) else HaplotypeJob(**j) for j in jobs]
+    if share_gpu and n_gpus > 1:
+        # several rank PROCESSES on one GPU are time-sliced by the driver: measured 504 s for what one process does in 12.4 s
+        # (profiles/r04_cohort_two_ranks_one_gpu.json).  A mode for tests and dry runs: refused above a toy size.
+        size = sum(os.path.getsize(j.bed) for j in jobs if os.path.exists(j.bed))
+        if size > SHARE_GPU_MAX_BYTES and os.environ.get('PAV_AMD_SHARE_GPU_ANYWAY') != '1':
+            raise ValueError(f'run_cohort(share_gpu=True): the alignment tables add up to {size} bytes (> {SHARE_GPU_MAX_BYTES}); rank '
+                             f'processes that share one GPU are time-sliced and run ~40 x slower than one process with lanes '
+                             f"(config['pav_amd_lanes']).  share_gpu is a test mode; PAV_AMD_SHARE_GPU_ANYWAY=1 overrides")
     os.makedirs(out_dir, exist_ok=True)
     if 'RANK' in os.environ and 'WORLD_SIZE' in os.environ and int(os.environ['WORLD_SIZE']) > 1:
         import torch.distributed as dist                       # the ranks exist already (torch.distributed.run)
@@ -318,14 +353,8 @@ def run_cohort(jobs, n_gpus, out_dir, ref_fa, config=None, engine_factory=None, 
         if world != n_gpus:
             raise ValueError(f'run_cohort(n_gpus={n_gpus}) inside a job of WORLD_SIZE={world}')
         if not dist.is_initialized():
-            import torch
             be = backend or ('gloo' if share_gpu else 'nccl')
-            if be == 'nccl':
-                local = int(os.environ.get('LOCAL_RANK', rank))
-                torch.cuda.set_device(local)
-                dist.init_process_group('nccl', device_id=torch.device('cuda', local))
-            else:
-                dist.init_process_group(be)
+            shard.first_contact(be, rank, world, int(os.environ.get('LOCAL_RANK', rank)), share_gpu)
         return _gather(run_rank(rank, world, jobs, out_dir, ref_fa, config, engine_factory, split, share_gpu), world)
     if n_gpus <= 1:
         return run_rank(0, 1, jobs, out_dir, ref_fa, config, engine_factory, split, share_gpu)
@@ -350,6 +379,8 @@ def run_cohort(jobs, n_gpus, out_dir, ref_fa, config=None, engine_factory=None, 
                 dead = [p for p in procs if p.exitcode not in (None, 0)]
                 if dead:
                     raise RuntimeError(f'run_cohort: rank process(es) failed with exit code(s) {[p.exitcode for p in dead]}')
+                if all(p.exitcode == 0 for p in procs) and queue.empty():
+                    raise RuntimeError('run_cohort: every rank process has ended (exit code 0) and none has sent the manifests')
                 if timeout is not None and waited > timeout:
                     raise TimeoutError(f'run_cohort: no result after {timeout} s')
         for p in procs:

@@ -357,6 +357,15 @@ int pav_device_name(const pav_ctx *ctx, char *buf, int buf_len) {
     return PAV_OK;
 }
 
+// "domain:bus:device.function" of the context's GPU (hipDeviceGetPCIBusId): the ranks of a multi-GPU run print it, so that a
+// scaling line shows N distinct devices
+int pav_device_pci_bus_id(const pav_ctx *ctx, char *buf, int buf_len) {
+    if (!ctx || !buf || buf_len < 16) return PAV_E_ARG;
+    buf[0] = 0;
+    if (hipDeviceGetPCIBusId(buf, buf_len, ctx->device) != hipSuccess) { buf[0] = 0; return PAV_E_HIP; }
+    return PAV_OK;
+}
+
 int pav_sync(pav_ctx *ctx) {
     if (!ctx) return PAV_E_ARG;
     PAV_HIP(ctx, hipSetDevice(ctx->device));

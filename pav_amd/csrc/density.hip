@@ -2820,7 +2820,6 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     double work_add[3] = {0, 0, 0};
     for (int attempt = 0; attempt < 2; ++attempt) {
         const bool force_direct = attempt == 1;
-        bool any_ps = false;
         for (uint32_t j = 0; j < n_jobs; ++j) {                        // same choice as k_kde_eval makes per state
             JobKde &kd = D->h_kde[j];
             if (!kd.finalised) continue;
@@ -2830,7 +2829,6 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
                 if (!kd.m[q]) continue;
                 if (!(kd.use_runs && kd.h[q] >= KDE_RUNS_MIN_H)) kd.ps_mask |= 1u << q;
             }
-            any_ps = any_ps || kd.ps_mask;
         }
         if (attempt == 0) lap("kde host");
         PAV_HIP(ctx, hipMemcpyAsync(D->kde.p, D->h_kde.data(), sizeof(JobKde) * n_jobs, hipMemcpyHostToDevice, st));
@@ -2844,7 +2842,6 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             for (uint32_t j = 0; j < n_jobs; ++j) { JobStat &q = hs[j]; q.fill_n = 0; q.n_near = q.n_reeval = q.n_unres = q.n_spike = 0; }
             PAV_HIP(ctx, hipMemcpyAsync(d_stat, hs.data(), sizeof(JobStat) * n_jobs, hipMemcpyHostToDevice, st));
         }
-        if (any_ps)
         G.pass = 0;
         KA.G = G;
         KA.tiles = D->tiles.as<EvalTile>(); KA.n_tiles = (uint32_t)tiles.size();

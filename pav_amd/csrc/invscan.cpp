@@ -665,7 +665,7 @@ int pav_inv_load_alignments(pav_ctx *ctx, uint32_t n, const pav_inv_aln *aln, co
             T.n_seq[axis] = n_seq[axis];
         }
         T.tig_table = reinterpret_cast<const uint32_t *>(d + o_tab);
-        rc = lift_row_flags(ctx, T);
+        rc = lift_row_flags(ctx, T, n_ops);
         if (rc != PAV_OK) return rc;
         PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));                     // `blk` is a local buffer
     }
@@ -686,6 +686,7 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
     if (!ctx || !pp || (n_regions && (!regions || !results))) return fail(ctx, PAV_E_ARG, "pav_inv_scan_batch: null argument");
     InvState *S = istate(ctx);
     if (!S->loaded) return fail(ctx, PAV_E_STATE, "pav_inv_scan_batch: pav_inv_load_alignments has not been called");
+    PAV_HIP(ctx, hipSetDevice(ctx->device));                           // the first HIP work below is the lift batch's own
     const double t_entry = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     S->pool->wake();                                                     // the first per-region loop is a few microseconds away
     Driver D(ctx, S);

@@ -17,8 +17,9 @@ struct LiftRowDev {                 // one alignment record
     uint64_t op_a, op_b;            // its operations: [op_a, op_b) of the operation arrays
     uint64_t tig_len;               // length of its contig record
     int32_t rev;
-    uint32_t bad;                   // first N (3) / P (6) operation code of the record, 0: none (lift.py:463-471); written by k_lift_row_bad
-};
+    uint32_t bad;                   // 0: the record has no N (3) / P (6) operation (lift.py:463-471); else the code of the first one in the
+};                                  // low four bits (row_bad_code) under its inverted ordinal; written by k_lift_row_bad
+__host__ __device__ inline uint32_t row_bad_code(uint32_t bad) { return bad & 15u; }
 
 struct LiftQuery { int32_t axis /* 0: reference position -> contig (lift_to_qry), 1: contig position -> reference (lift_to_sub) */,
                    seq, gap, pad; int64_t pos; };
@@ -42,7 +43,7 @@ struct LiftTables {                 // device pointers
     uint32_t n_seq[2];
 };
 
-int lift_row_flags(pav_ctx *ctx, const LiftTables &T);                                             // queued on ctx->stream
+int lift_row_flags(pav_ctx *ctx, const LiftTables &T, uint64_t n_ops);                                             // queued on ctx->stream
 int lift_points(pav_ctx *ctx, const LiftTables &T, const LiftQuery *d_q, LiftAnswer *d_a, uint32_t n);   // queued on ctx->stream
 
 }  // namespace pav

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64) void k_lift_points(LiftTables T, const LiftQuer
         if (hits == 1) {
             const LiftRowDev r = T.rows[row];
             A.row = row;
-            if (r.bad) { A.status = LIFT_ERR_OP; A.id = (int32_t)r.bad; }
+            if (r.bad) { A.status = LIFT_ERR_OP; A.id = (int32_t)row_bad_code(r.bad); }
             else {
                 const int64_t k = op_at(T, r, 0, Q.pos);
                 if (k < 0) A.status = LIFT_ERR_NO_MATCH_QRY;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64) void k_lift_points(LiftTables T, const LiftQuer
         else if (hits == 1) {
             const LiftRowDev r = T.rows[row];
             A.row = row;
-            if (r.bad) { A.status = LIFT_ERR_OP; A.id = (int32_t)r.bad; }
+            if (r.bad) { A.status = LIFT_ERR_OP; A.id = (int32_t)row_bad_code(r.bad); }
             else {
                 const int64_t pos = r.rev ? (int64_t)r.tig_len - Q.pos : Q.pos;
                 int64_t k = op_at(T, r, 1, pos);
@@ -120,26 +120,42 @@ __global__ __launch_bounds__(64) void k_lift_points(LiftTables T, const LiftQuer
     out[i] = A;
 }
 
-// first N / P operation of every record (lift.py:463-471): one wave per record, 64 operations per step
-__global__ __launch_bounds__(64) void k_lift_row_bad(LiftTables T) {
-    const uint32_t row = blockIdx.x;
-    if (row >= T.n_rows) return;
-    const uint64_t a = T.rows[row].op_a, b = T.rows[row].op_b;
-    uint32_t found = 0;
-    for (uint64_t k0 = a; k0 < b && !found; k0 += 64) {
-        const uint64_t k = k0 + threadIdx.x;
-        const uint32_t code = k < b ? (T.ops[k] & 15u) : 0u;
-        const unsigned long long m = __ballot(code == 3u || code == 6u);
-        if (m) found = (uint32_t)__shfl((int)code, __ffsll((long long)m) - 1);
+// first N / P operation of every record (lift.py:463-471): a flat grid over ALL operations of the table (a 150 Mb contig is one
+// record of half a million operations: a wave per record walked it 64 at a time, 2.1 ms; this is one read of the array).  An N / P
+// operation is an exception, so the lane that meets one looks its record up by bisection and keeps the EARLIEST one with an
+// atomicMax of ((2^28 - 1 - ordinal within the record) << 4 | code); readers take `bad & 15` (row_bad_code).
+constexpr uint32_t BAD_OPS_PER_LANE = 8;
+__global__ __launch_bounds__(256) void k_lift_row_bad(LiftTables T, uint64_t n_ops) {
+    const uint64_t k0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * BAD_OPS_PER_LANE;
+    if (k0 >= n_ops) return;
+    uint32_t code[BAD_OPS_PER_LANE];
+    if (k0 + BAD_OPS_PER_LANE <= n_ops && (reinterpret_cast<uintptr_t>(T.ops + k0) & 15u) == 0) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(T.ops + k0), b = *reinterpret_cast<const uint4 *>(T.ops + k0 + 4);
+        code[0] = a.x; code[1] = a.y; code[2] = a.z; code[3] = a.w; code[4] = b.x; code[5] = b.y; code[6] = b.z; code[7] = b.w;
+    } else {
+        for (uint32_t j = 0; j < BAD_OPS_PER_LANE; ++j) code[j] = k0 + j < n_ops ? T.ops[k0 + j] : 0u;
     }
-    if (threadIdx.x == 0) T.rows[row].bad = found;
+    for (uint32_t j = 0; j < BAD_OPS_PER_LANE; ++j) {
+        const uint32_t c = code[j] & 15u;
+        if (c != 3u && c != 6u) continue;
+        const uint64_t k = k0 + j;
+        uint32_t lo = 0, hi = T.n_rows;                                // last record whose operations begin at or before k
+        while (hi - lo > 1) { const uint32_t mid = lo + (hi - lo) / 2; if (T.rows[mid].op_a <= k) lo = mid; else hi = mid; }
+        while (lo < T.n_rows && T.rows[lo].op_b <= k) ++lo;            // records without operations share their op_a with the next
+        if (lo >= T.n_rows || k < T.rows[lo].op_a) continue;
+        const uint64_t rel = k - T.rows[lo].op_a;
+        const uint32_t ord = rel < 0x0FFFFFFFull ? (uint32_t)rel : 0x0FFFFFFFu;
+        atomicMax(&T.rows[lo].bad, (0x0FFFFFFFu - ord) << 4 | c);
+    }
 }
 
 }  // namespace
 
-int lift_row_flags(pav_ctx *ctx, const LiftTables &T) {
+int lift_row_flags(pav_ctx *ctx, const LiftTables &T, uint64_t n_ops) {
     if (!T.n_rows) return PAV_OK;
-    PAV_LAUNCH(ctx, "k_lift_row_bad", k_lift_row_bad, T.n_rows, 64, 0, T);
+    if (!n_ops) return PAV_OK;
+    const uint64_t per_block = 256ull * BAD_OPS_PER_LANE;
+    PAV_LAUNCH(ctx, "k_lift_row_bad", k_lift_row_bad, (uint32_t)((n_ops + per_block - 1) / per_block), 256, 0, T, n_ops);
     return PAV_OK;
 }
 

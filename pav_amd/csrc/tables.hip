@@ -300,7 +300,12 @@ int pav_cigar_write_tables_begin(pav_ctx *ctx, const pav_table_opts *o) {
     J->pending = true; J->rc = PAV_OK;
     std::shared_ptr<TableWork> w = J->work;
     try {
-        J->th = std::thread([J, w] { J->rc = table_host_phase(*w); });
+        J->th = std::thread([J, w] {
+            // (an exception that left this thread would end the whole rank process, not this haplotype's write)
+            try { J->rc = table_host_phase(*w); }
+            catch (const std::exception &ex) { J->rc = PAV_E_STATE; w->err = std::string("table writer: ") + ex.what(); }
+            catch (...) { J->rc = PAV_E_STATE; w->err = "table writer: unknown exception"; }
+        });
     } catch (const std::exception &ex) {
         J->pending = false; J->work.reset();
         return fail(ctx, PAV_E_STATE, "pav_cigar_write_tables_begin: cannot start the writer thread: %s", ex.what());

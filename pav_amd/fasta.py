@@ -9,12 +9,14 @@ the arrays are zero-copy views of its buffers.
 """
 
 import os
+import threading
 
 import numpy as np
 
 from . import _lib
 
 _CACHE = {}
+_CACHE_LOCK = threading.Lock()          # lanes of a cohort rank load and forget files from their own threads
 
 
 class Fasta:
@@ -63,16 +65,21 @@ def open_fasta(path, cache=True):
     if not cache:
         return Fasta(path)
     key = (os.path.abspath(path), os.path.getmtime(path))
-    if key not in _CACHE:
-        _CACHE[key] = Fasta(path)
-    return _CACHE[key]
+    with _CACHE_LOCK:
+        fa = _CACHE.get(key)
+    if fa is None:
+        fa = Fasta(path)                      # (outside the lock: lanes load different files side by side)
+        with _CACHE_LOCK:
+            fa = _CACHE.setdefault(key, fa)
+    return fa
 
 
 def forget(path):
     """Drop a memoised file (a cohort's contig files are read once each: 3 GB of host memory per haplotype otherwise)."""
     path = os.path.abspath(str(path))
-    for key in [k for k in _CACHE if k[0] == path]:
-        del _CACHE[key]
+    with _CACHE_LOCK:
+        for key in [k for k in list(_CACHE) if k[0] == path]:
+            del _CACHE[key]
 
 
 _FAI_CACHE = {}

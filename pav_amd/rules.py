@@ -472,7 +472,7 @@ def call_haplotype(bed, bed_trim, tig_fa_name, ref_fa_name, asm_name, hap, out_d
             timings[name] = timings.get(name, 0.0) + now - t_last[0]
             t_last[0] = now
     ctx, own = _with_ctx(ctx, device_id)
-    table = trim_table = None
+    table = trim_table = th = None
     writing = False
     try:
         # the contig file is parsed on a second thread while the tables are parsed and - the first time - the reference is parsed,
@@ -629,6 +629,8 @@ def call_haplotype(bed, bed_trim, tig_fa_name, ref_fa_name, asm_name, hap, out_d
             if t is not None:
                 t.close()
         from . import fasta as pavfasta2
+        if th is not None and th.is_alive():                       # an error before the join: the helper would memoise the file after forget()
+            th.join()
         pavfasta2.forget(tig_fa_name)                              # (the reference stays memoised; a haplotype's contigs are read once)
         if own:
             ctx.close()

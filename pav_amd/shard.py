@@ -39,6 +39,53 @@ def effective_cpus():
     return max(1, n)
 
 
+def first_contact(backend, rank, world, local_rank, share_gpu=False, init=True):
+    """Bring the process group of a multi-GPU run up and PROVE it before any work is queued: enough visible GPUs for the ranks
+    of this node, a one-element ``all_reduce`` whose sum must be the world size (the first RCCL exchange of the job: a fabric /
+    IPC problem shows here, with a message, not as a hang inside the timed region), and - one GPU per rank - every rank on a
+    device of its own (PCI bus ids gathered and compared).  Returns ``{'device_name', 'pci_bus_id'}`` of this rank's GPU (empty
+    strings without one).  ``init=False``: the group exists already, only the checks run."""
+    import torch
+    import torch.distributed as dist
+    info = {'device_name': '', 'pci_bus_id': ''}
+    on_gpu = backend == 'nccl'
+    if on_gpu:
+        n_dev = torch.cuda.device_count()
+        need = 1 if share_gpu else local_rank + 1
+        if n_dev < need:
+            raise RuntimeError(f'rank {rank}: local rank {local_rank} needs GPU {need - 1} but only {n_dev} HIP device(s) are visible '
+                               f'(HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES = {__import__("os").environ.get("HIP_VISIBLE_DEVICES")!r} / '
+                               f'{__import__("os").environ.get("ROCR_VISIBLE_DEVICES")!r}); one process per GPU, no collective moves data')
+        dev = 0 if share_gpu else local_rank
+        torch.cuda.set_device(dev)
+        props = torch.cuda.get_device_properties(dev)
+        info['device_name'] = props.name
+        bus = [getattr(props, a, None) for a in ('pci_domain_id', 'pci_bus_id', 'pci_device_id')]
+        if all(b is not None for b in bus):
+            info['pci_bus_id'] = '{:04x}:{:02x}:{:02x}.0'.format(*bus)
+    if world <= 1:
+        return info
+    if init and not dist.is_initialized():
+        if on_gpu:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0 if share_gpu else local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    one = torch.ones(1, dtype=torch.float32, device='cuda' if on_gpu else 'cpu')
+    try:
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        got = float(one.item())
+    except Exception as ex:                                               # noqa: BLE001 - re-raised with what the user needs to know
+        raise RuntimeError(f'rank {rank}/{world}: the first all_reduce over the {backend} group failed ({ex}); on ROCm check that '
+                           f'HSA_ENABLE_IPC_MODE_LEGACY=0 is exported and that MASTER_ADDR is 127.0.0.1 on a single node') from ex
+    if got != float(world):
+        raise RuntimeError(f'rank {rank}/{world}: the first all_reduce returned {got}, expected {world}')
+    seen = [None] * world
+    dist.all_gather_object(seen, info['pci_bus_id'])
+    if on_gpu and not share_gpu and all(seen) and len(set(seen)) != world:
+        raise RuntimeError(f'{world} ranks but only {len(set(seen))} distinct GPU(s): {seen} - every rank must drive a device of its own')
+    return info
+
+
 def assign_lpt(costs, n_ranks):
     """Greedy longest-processing-time assignment.  Returns ``n_ranks`` lists of item indices (deterministic)."""
     costs = np.asarray(costs, dtype=np.float64)

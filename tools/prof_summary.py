@@ -19,6 +19,17 @@ import sqlite3
 import sys
 
 
+def provenance():
+    """The source the profiled library was built from (pav_amd._lib.source_fingerprint): bench.py quotes a committed counter
+    only when the file that defines the kernel is unchanged since."""
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from pav_amd import _lib
+    fp = _lib.source_fingerprint()
+    fp.pop('kernel_file', None)
+    return fp
+
+
 def short(name):
     import re
     name = name.replace('(anonymous namespace)::', '')
@@ -88,6 +99,7 @@ def pmcjson(fetch_db, write_db, bench_json, out):
                           'against the 3.08 GB ASCII arena) and verify_kernel (16 B/lane windows of the 2-bit planes); '
                           'other kernels are reported raw',
            'fetch_kib': per_kernel(fetch_db, 'FETCH_SIZE'), 'write_kib': per_kernel(write_db, 'WRITE_SIZE')}
+    doc['provenance'] = provenance()
     with open(out, 'w') as fh:
         json.dump(doc, fh, indent=1)
     print(open(out).read())
@@ -137,6 +149,7 @@ def ldsjson(db, out, lanes='6'):
                              'bank_conflict_share': round(c.get('SQ_LDS_BANK_CONFLICT', (0, 0.0))[1] / act, 4),
                              'insts_lds': round(c.get('SQ_INSTS_LDS', (0, 0.0))[1], 1),
                              'wave_cycles': round(c.get('SQ_WAVE_CYCLES', (0, 0.0))[1], 1)}
+    doc['provenance'] = provenance()
     with open(out, 'w') as fh:
         json.dump(doc, fh, indent=1)
     print(open(out).read())
