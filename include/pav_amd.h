@@ -221,6 +221,13 @@ int pav_cigar_write_tables(pav_ctx *ctx, const pav_table_opts *opts, uint64_t *n
 int pav_cigar_write_tables_begin(pav_ctx *ctx, const pav_table_opts *opts);
 int pav_cigar_write_tables_end(pav_ctx *ctx, uint64_t *n_snv_rows, uint64_t *n_insdel_rows);
 
+/* gzip of a host buffer on the device: the compressor of the table writers above (deflate.hip - 64 KiB of text per wave, a sliding
+ * window in LDS, dynamic Huffman blocks joined on byte boundaries into ONE member), exposed for tests and for callers with text
+ * of their own.  `out` receives a complete gzip file (RFC 1952) that inflates to `text`; *out_len its size, PAV_E_LIMIT when
+ * out_cap is smaller (n + n / 2 + 4096 always suffices).  level 1..9 as zlib's (0 = 6): how far the match finder looks.
+ * Replaces the gzip step of DataFrame.to_csv(compression='gzip') (rules/call.snakefile:845-846, rules/call_inv.snakefile:279-291). */
+int pav_gzip_buffer(pav_ctx *ctx, const uint8_t *text, uint64_t n, int level, uint8_t *out, uint64_t out_cap, uint64_t *out_len);
+
 /* Lift-over tables for pavlib.align.AlignLift (pavlib/align/lift.py:380-476, `_add_align`): tokenises every row's
  * CIGAR on the device and returns, per operation, the subject position where it starts (absolute, row POS included)
  * and the query position where it starts (alignment orientation, clipping included).  Advance rules are AlignLift's:

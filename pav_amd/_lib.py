@@ -181,6 +181,8 @@ SYMBOLS = {
     'pav_destroy': (None, [_P]),
     'pav_last_error': (ctypes.c_char_p, [_P]),
     'pav_device_name': (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int]),
+    'pav_gzip_buffer': (ctypes.c_int, [_P, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64,
+                                       ctypes.POINTER(ctypes.c_uint64)]),
     'pav_device_pci_bus_id': (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int]),
     'pav_sync': (ctypes.c_int, [_P]),
     'pav_mem_info': (ctypes.c_int, [_P, _P, _P]),
@@ -402,6 +404,16 @@ class Context:
         buf = ctypes.create_string_buffer(64)
         self._check(self.lib.pav_device_pci_bus_id(self.handle, buf, 64), 'pav_device_pci_bus_id')
         return buf.value.decode()
+
+    def gzip_buffer(self, data, level=0):
+        """gzip of ``data`` (bytes / uint8 array) made on the device; returns bytes (a complete gzip file)."""
+        buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+        n = int(buf.shape[0])
+        out = np.empty(n + n // 2 + 4096, dtype=np.uint8)
+        got = ctypes.c_uint64(0)
+        self._check(self.lib.pav_gzip_buffer(self.handle, buf.ctypes.data if n else None, n, int(level), out.ctypes.data, out.shape[0],
+                                             ctypes.byref(got)), 'pav_gzip_buffer')
+        return out[:got.value].tobytes()
 
     def sync(self):
         self._check(self.lib.pav_sync(self.handle), 'pav_sync')

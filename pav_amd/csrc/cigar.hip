@@ -1609,6 +1609,7 @@ int pav_cigar_load(pav_ctx *ctx, uint32_t n_aln, const pav_aln *aln, const uint8
                    const uint64_t *cigar_off) {
     if (!ctx) return PAV_E_ARG;
     if (n_aln && (!aln || !cigar_off)) return fail(ctx, PAV_E_ARG, "pav_cigar_load: null input");
+    table_writer_quiesce(ctx);                                          // a device table write still reads the rows and the records
     PAV_HIP(ctx, hipSetDevice(ctx->device));
     { const int rch = wait_homology(ctx); if (rch != PAV_OK) return rch; }     // the scans of the last call read the alignment rows
     const uint64_t T = n_aln ? cigar_off[n_aln] : 0;
@@ -1678,6 +1679,7 @@ int call_bufs(pav_ctx *ctx, CallBufs &B, bool reserve) {
 int pav_cigar_call(pav_ctx *ctx, pav_cigar_counts *counts) {
     if (!ctx) return PAV_E_ARG;
     if (!ctx->cigar_loaded) return fail(ctx, PAV_E_STATE, "pav_cigar_call: pav_cigar_load has not been called");
+    table_writer_quiesce(ctx);                                          // a device table write still reads the records this call rewrites
     PAV_HIP(ctx, hipSetDevice(ctx->device));
     { const int rch = wait_homology(ctx); if (rch != PAV_OK) return rch; }     // the scans of the last call: their records are rewritten
     memset(&ctx->counts, 0, sizeof ctx->counts);

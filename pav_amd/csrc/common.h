@@ -168,6 +168,9 @@ struct pav_ctx {
     void *flag = nullptr;                 // flagging scratch + results (flag.hip)
     void *trim = nullptr;                 // alignment trimming state (trim.cpp)
     void *table_writer = nullptr;         // a table write in two halves (tables.hip: pav_cigar_write_tables_begin / _end)
+    hipEvent_t writer_ready = nullptr;    // recorded behind the calls when a device table write begins (tables.hip)
+    void *gz = nullptr;                   // device gzip scratch (deflate.hip)
+    void *textdev = nullptr;              // device table text scratch (textdev.hip)
 
     // profiling
     bool prof_on = false;
@@ -182,6 +185,7 @@ extern thread_local std::string g_err;   // pav_last_error(NULL)
 
 int fail(pav_ctx *ctx, int code, const char *fmt, ...);
 void table_writer_release(pav_ctx *ctx);                             // tables.hip: joins a pending writer thread
+void table_writer_quiesce(pav_ctx *ctx);                             // tables.hip: waits for a write that still reads the resident records
 
 #define PAV_HIP(ctx, call)                                                                         \
     do {                                                                                           \

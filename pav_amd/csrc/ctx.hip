@@ -1,6 +1,8 @@
 // Context, sequence store (ASCII arena -> 2-bit + non-ACGT planes) and HIP-event profiling.
 // gfx950 only; public ABI in include/pav_amd.h.
 #include "common.h"
+#include "devgz.h"
+#include "textdev.h"
 #include <algorithm>
 
 namespace pav {
@@ -325,6 +327,8 @@ void pav_destroy(pav_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream2);
     (void)hipStreamSynchronize(ctx->stream);
     table_writer_release(ctx);
+    pav::gz_release(ctx);
+    pav::textdev_release(ctx);
     pav_density_release(ctx);
     pav_invscan_release(ctx);
     pav_flag_release(ctx);
@@ -345,6 +349,7 @@ void pav_destroy(pav_ctx *ctx) {
     (void)hipEventDestroy(ctx->hom_done);
     (void)hipEventDestroy(ctx->snv_ready);
     (void)hipEventDestroy(ctx->snv_done);
+    if (ctx->writer_ready) (void)hipEventDestroy(ctx->writer_ready);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     (void)hipEventDestroy(ctx->pack_done[0]);
     (void)hipEventDestroy(ctx->pack_done[1]);

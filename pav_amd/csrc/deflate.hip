@@ -1,0 +1,491 @@
+// gzip on the device: text resident in HBM -> conforming gzip members (RFC 1951 / 1952), the output format of
+// DataFrame.to_csv(compression='gzip') in rules call_cigar, call_cigar_merge and call_inv_batch (rules/call.snakefile:845-846,
+// rules/call_inv.snakefile:279-291).  The reference compresses on one host core inside pandas; the host writers of rounds 1-4 did it
+// with zlib on sixteen (1.5 s per haplotype at level 6: 2.2 GB of text).  Here:
+//
+//   * the text of every file is cut into 64 KiB segments; ONE WAVE encodes a segment, start to finish, with no barrier against any
+//     other wave: a zlib-shaped sliding window in its LDS (ring of text, hash heads, chain links), 64 positions per step;
+//   * matches may reach back into the text in front of the segment (it is all in HBM: the window is primed from it), so the file is
+//     one deflate stream; a segment is one dynamic-Huffman block, followed - except the last - by an empty stored block that brings
+//     the stream to a byte boundary (the way parallel gzip implementations join their pieces);
+//   * chain insertion is exact in position order: the 64 lanes of a step link to the head before the step, the lanes that share a
+//     hash inside the step are chained to each other by a ballot loop over the distinct duplicated hashes;
+//   * match search walks the chain per lane; the lazy rule of zlib (take the match at p unless p + 1 has a longer one) is a
+//     function of the per-position lengths, so the parse is a scalar walk over a step's `next position` values;
+//   * tokens go to a scratch of the wave in HBM, counts to LDS; the trees, the block header (deflate_dev.h) and the bit stream -
+//     per 64 tokens a prefix sum of code lengths and LDS atomic ORs - follow in the same wave;
+//   * CRC-32 per segment in a second small kernel (64 lane-chunks joined by the checksum's own algebra), joined per file on the host;
+//   * the segments' outputs are packed into one buffer on the device and cross PCIe once.
+#include "common.h"
+#include "deflate_dev.h"
+#include "devgz.h"
+
+#include <algorithm>
+
+namespace pav {
+
+namespace {
+
+struct GzSegment {
+    uint64_t text_off;        // arena offset of the segment's first byte (a multiple of 256)
+    uint32_t len;             // bytes of text (0 only for an empty file)
+    uint32_t hist;            // bytes of the same file in front of it that matches may reach (a multiple of 256)
+    uint32_t last;            // last segment of its file
+    uint32_t file;
+};
+struct GzSegOut { uint32_t bytes, crc; };      // bytes = 0xFFFFFFFF: the slot was too small (never seen; reported)
+
+struct DeflateArgs {
+    const uint8_t *text; uint64_t text_alloc;
+    const GzSegment *segs; uint32_t n_segs;
+    uint32_t *counter;
+    uint32_t *tok; uint32_t tok_per_wave;
+    uint8_t *slots; uint32_t slot_bytes;
+    GzSegOut *out;
+    uint32_t chain, lazy, nice;
+};
+
+__device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t byte_shift) { return __builtin_amdgcn_alignbyte(hi, lo, byte_shift); }
+
+template <int WBITS, int HBITS>
+__global__ __launch_bounds__(64) void k_deflate(DeflateArgs A) {
+    constexpr uint32_t W = 1u << WBITS, WM = W - 1u, H = 1u << HBITS;
+    constexpr uint32_t AHEAD = 64 + 320;                 // a step reads up to 258 + 3 bytes past its last position
+    constexpr uint32_t MAXDIST = W - AHEAD - 256;        // the ring holds [loaded - W, loaded), loaded < step + AHEAD + 256
+    static_assert(sizeof(dfl::HuffWork) + sizeof(dfl::HeaderWork) + 4 * 192 <= 2 * W, "the tree scratch overlays the chain links");
+    __shared__ uint32_t T[W / 4];
+    __shared__ __attribute__((aligned(16))) uint16_t prev[W];
+    __shared__ uint16_t head[H];
+    __shared__ uint32_t f_ll[288], f_d[32], c_ll[288], c_d[32];
+    __shared__ uint8_t ll_len[288], d_len[32];
+    __shared__ uint32_t stage[128];
+    // after the match phase the chain links are dead: trees and header are built in their place
+    dfl::HuffWork &HW = *reinterpret_cast<dfl::HuffWork *>(prev);
+    dfl::HeaderWork &XW = *reinterpret_cast<dfl::HeaderWork *>(reinterpret_cast<uint8_t *>(prev) + sizeof(dfl::HuffWork));
+    uint32_t *hdr = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(prev) + sizeof(dfl::HuffWork) + sizeof(dfl::HeaderWork));
+
+    const uint32_t lane = threadIdx.x;
+    const uint64_t lane_lt = (1ull << lane) - 1ull;
+    uint32_t *tok = A.tok + (size_t)blockIdx.x * A.tok_per_wave;
+
+    auto get4 = [&](uint32_t pos) -> uint32_t {          // bytes pos .. pos + 3 of the stream, from the ring
+        const uint32_t i = pos & WM, w = i >> 2;
+        return alignbyte(T[(w + 1) & (W / 4 - 1)], T[w], i & 3u);
+    };
+
+    for (;;) {
+        uint32_t seg = 0;
+        if (lane == 0) seg = atomicAdd(A.counter, 1u);
+        seg = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg);
+        if (seg >= A.n_segs) break;
+        const GzSegment sg = A.segs[seg];
+        const uint64_t base = sg.text_off - sg.hist;                    // stream position 0 (256-aligned in the arena)
+        const uint32_t S = sg.hist, E = sg.hist + sg.len;
+        for (uint32_t i = lane; i < W / 2; i += 64) reinterpret_cast<uint32_t *>(prev)[i] = 0;
+        for (uint32_t i = lane; i < H / 2; i += 64) reinterpret_cast<uint32_t *>(head)[i] = 0;
+        for (uint32_t i = lane; i < 288; i += 64) f_ll[i] = 0;
+        if (lane < 32) f_d[lane] = 0;
+        __syncthreads();
+
+        uint32_t loaded = 0, next_free = S, n_tok = 0;
+        uint32_t pv_len = 0, pv_dist = 0, pv_byte = 0, pv_g = 0;
+        bool have_pv = false;
+
+        // tokens of the step at G from its per-position (length, distance, byte); next0 = the length found at G + 64
+        auto parse = [&](uint32_t G, uint32_t len, uint32_t dist, uint32_t byte, uint32_t next0) {
+            uint32_t nl = (uint32_t)__shfl_down((int)len, 1);
+            if (lane == 63) nl = next0;
+            const bool take = len >= 4u && !(len < A.lazy && nl > len);
+            const uint32_t step = take ? len : 1u;
+            uint32_t cur = next_free - G;
+            uint64_t mask = 0;
+            while (cur < 64u) {
+                mask |= 1ull << cur;
+                cur += (uint32_t)__builtin_amdgcn_readlane((int)step, (int)cur);
+            }
+            next_free = G + cur;
+            if (E - G < 64u) mask &= (1ull << (E - G)) - 1ull;          // positions behind the segment's end are nobody's
+            if (!mask) return;
+            if ((mask >> lane) & 1ull) {
+                const uint32_t at = n_tok + (uint32_t)__popcll(mask & lane_lt);
+                if (take) {
+                    tok[at] = 0x80000000u | len << 16 | dist;
+                    uint32_t c, eb, ev;
+                    dfl::len_symbol(len, c, eb, ev); atomicAdd(&f_ll[c], 1u);
+                    dfl::dist_symbol(dist, c, eb, ev); atomicAdd(&f_d[c], 1u);
+                } else {
+                    tok[at] = byte;
+                    atomicAdd(&f_ll[byte], 1u);
+                }
+            }
+            n_tok += (uint32_t)__popcll(mask);
+        };
+
+        for (uint32_t g = 0; g < E; g += 64) {
+            if (loaded < g + AHEAD) {
+                while (loaded < g + AHEAD) {                            // 256 bytes per load, a dword per lane
+                    const uint64_t off = base + loaded + 4ull * lane;
+                    T[((loaded >> 2) + lane) & (W / 4 - 1)] = off + 4 <= A.text_alloc ? *reinterpret_cast<const uint32_t *>(A.text + off) : 0u;
+                    loaded += 256;
+                }
+                __syncthreads();
+            }
+            const uint32_t p = g + lane, p16 = p & 0xFFFFu;
+            const bool hashable = p + 4u <= E;
+            const uint32_t w0 = get4(p);
+            const uint32_t h = (w0 * 2654435761u) >> (32 - HBITS);
+            // ---- link: nearest earlier position with the same hash -------------------------------------------------------
+            uint32_t cand = p16;                                         // distance 0 = none
+            if (hashable) cand = head[h];
+            __syncthreads();
+            if (hashable) head[h] = (uint16_t)p16;
+            __syncthreads();
+            const bool lost = hashable && head[h] != p16;                // somebody else of this step has my hash
+            uint64_t dm = __ballot(lost);
+            while (dm) {
+                const int l = __ffsll((long long)dm) - 1;
+                const uint32_t hl = (uint32_t)__builtin_amdgcn_readlane((int)h, l);
+                const bool in = hashable && h == hl;
+                const uint64_t eq = __ballot(in);
+                if (in) {
+                    const uint64_t lower = eq & lane_lt;
+                    if (lower) cand = (g + 63u - (uint32_t)__clzll((long long)lower)) & 0xFFFFu;
+                    if ((eq >> lane) == 1ull) head[h] = (uint16_t)p16;   // the last of them is the head the next step sees
+                }
+                dm &= ~eq;
+            }
+            if (hashable) prev[p & WM] = (uint16_t)cand;
+            __syncthreads();
+            if (g + 64 <= S) continue;                                   // the text in front of the segment only primes the window
+            // ---- longest match along the chain ---------------------------------------------------------------------------
+            uint32_t best_len = 0, best_dist = 0;
+            if (p >= S && hashable) {
+                const uint32_t maxlen = min(258u, E - p);
+                uint32_t cur = cand, last = 0;
+                for (uint32_t depth = 0; depth < A.chain; ++depth) {
+                    const uint32_t dist = (p - cur) & 0xFFFFu;
+                    if (dist == 0 || dist > MAXDIST || dist > p || dist <= last) break;
+                    last = dist;
+                    const uint32_t q = p - dist;
+                    if (get4(q) == w0) {
+                        uint32_t len = 4;
+                        while (len < maxlen) {
+                            const uint32_t x = get4(p + len) ^ get4(q + len);
+                            if (x) { len += (uint32_t)(__ffs((int)x) - 1) >> 3; break; }
+                            len += 4;
+                        }
+                        len = min(len, maxlen);
+                        if (len > best_len) { best_len = len; best_dist = dist; if (len >= A.nice) break; }
+                    }
+                    cur = prev[q & WM];
+                }
+                // a four-byte match far away costs more bits than four literals of this kind of text
+                if (best_len == 4u && best_dist > 2048u) best_len = 0;
+            }
+            if (have_pv) parse(pv_g, pv_len, pv_dist, pv_byte, (uint32_t)__builtin_amdgcn_readlane((int)best_len, 0));
+            pv_g = g; pv_len = best_len; pv_dist = best_dist; pv_byte = w0 & 0xFFu; have_pv = true;
+        }
+        if (have_pv) parse(pv_g, pv_len, pv_dist, pv_byte, 0u);
+        __syncthreads();
+        if (lane == 0) f_ll[256] += 1u;                                  // end of block
+        __syncthreads();
+
+        // ---- the two trees ------------------------------------------------------------------------------------------
+        for (int tree = 0; tree < 2; ++tree) {
+            uint32_t *freq = tree == 0 ? f_ll : f_d;
+            const int n = tree == 0 ? dfl::N_LL : dfl::N_D;
+            uint32_t used = 0;
+            for (int s0 = 0; s0 < n; s0 += 64) used += (uint32_t)__popcll(__ballot(s0 + (int)lane < n && freq[s0 + lane] != 0));
+            if (used < 2 && lane == 0) {                                 // a complete code needs two symbols (RFC 1951 3.2.7)
+                for (int s = 0; s < n && used < 2; ++s) if (!freq[s]) { freq[s] = 1; ++used; }
+            }
+            used = max(used, 2u);
+            __syncthreads();
+            if (lane == 0) HW.n_used = used;
+            for (int s = (int)lane; s < n; s += 64) if (freq[s]) HW.order[dfl::huff_rank(freq, n, s)] = (uint16_t)s;
+            __syncthreads();
+            if (lane == 0) {
+                dfl::huff_lengths(freq, n, dfl::MAX_BITS, tree == 0 ? ll_len : d_len, HW);
+                dfl::huff_codes(tree == 0 ? ll_len : d_len, n, tree == 0 ? c_ll : c_d, XW.count, XW.next);
+            }
+            __syncthreads();
+        }
+        // ---- header ---------------------------------------------------------------------------------------------------
+        uint32_t hdr_bits = 0;
+        if (lane == 0) {
+            dfl::BitSink sink{hdr, 0};
+            dfl::block_header(sink, sg.last != 0, ll_len, d_len, XW);
+            if ((sink.n_bits & 31u) == 0) hdr[sink.n_bits >> 5] = 0;
+            hdr_bits = sink.n_bits;
+        }
+        hdr_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr_bits);
+        __syncthreads();
+        uint32_t *out_w = reinterpret_cast<uint32_t *>(A.slots + (size_t)seg * A.slot_bytes);
+        const uint32_t slot_words = A.slot_bytes / 4;
+        uint32_t words_done = hdr_bits >> 5, fill = hdr_bits & 31u;
+        bool overflow = false;
+        for (uint32_t i = lane; i < words_done; i += 64) out_w[i] = hdr[i];
+        for (uint32_t i = lane; i < 128; i += 64) stage[i] = 0;
+        __syncthreads();
+        if (lane == 0) stage[0] = fill ? hdr[words_done] : 0u;
+        __syncthreads();
+        // ---- the bit stream: 64 tokens per step ---------------------------------------------------------------------------
+        for (uint32_t t0 = 0; t0 <= n_tok; t0 += 64) {
+            const uint32_t t = t0 + lane;
+            uint64_t bits = 0; uint32_t nbits = 0;
+            if (t < n_tok) {
+                const uint32_t tk = tok[t];
+                if (tk & 0x80000000u) {
+                    const uint32_t len = (tk >> 16) & 0x1FFu, dist = tk & 0xFFFFu;
+                    uint32_t c, eb, ev;
+                    dfl::len_symbol(len, c, eb, ev);
+                    const uint32_t cl = c_ll[c];
+                    bits = cl & 0xFFFFu; nbits = cl >> 16;
+                    bits |= (uint64_t)ev << nbits; nbits += eb;
+                    dfl::dist_symbol(dist, c, eb, ev);
+                    const uint32_t cd = c_d[c];
+                    bits |= (uint64_t)(cd & 0xFFFFu) << nbits; nbits += cd >> 16;
+                    bits |= (uint64_t)ev << nbits; nbits += eb;
+                } else {
+                    const uint32_t cl = c_ll[tk & 0xFFu];
+                    bits = cl & 0xFFFFu; nbits = cl >> 16;
+                }
+            } else if (t == n_tok) {
+                const uint32_t cl = c_ll[256];
+                bits = cl & 0xFFFFu; nbits = cl >> 16;
+            }
+            uint32_t incl = nbits;
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, d); if ((int)lane >= d) incl += v; }
+            const uint32_t total = fill + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (nbits) {
+                const uint32_t off = fill + incl - nbits, wi = off >> 5, sh = off & 31u;
+                const uint64_t lo = bits << sh;
+                const uint32_t hi = sh ? (uint32_t)(bits >> (64u - sh)) : 0u;
+                if ((uint32_t)lo) atomicOr(&stage[wi], (uint32_t)lo);
+                if ((uint32_t)(lo >> 32)) atomicOr(&stage[wi + 1], (uint32_t)(lo >> 32));
+                if (hi) atomicOr(&stage[wi + 2], hi);
+            }
+            __syncthreads();
+            const uint32_t nfull = total >> 5;                           // <= (31 + 64 * 48) / 32 = 96
+            if (words_done + nfull + 4 > slot_words) { overflow = true; break; }
+            for (uint32_t i = lane; i < nfull; i += 64) out_w[words_done + i] = stage[i];
+            const uint32_t carry = stage[nfull];
+            __syncthreads();
+            for (uint32_t i = lane; i < nfull + 3 && i < 128; i += 64) stage[i] = 0;
+            __syncthreads();
+            if (lane == 0) stage[0] = carry;
+            __syncthreads();
+            words_done += nfull; fill = total & 31u;
+        }
+        // ---- end of the segment: the last one pads to a byte, the others append an empty stored block (000, pad, 00 00 FF FF) ------
+        if (!overflow) {
+            if (sg.last) fill = (fill + 7u) & ~7u;
+            else {
+                fill = (fill + 3u + 7u) & ~7u;
+                if (lane == 0) {
+                    const uint64_t v = (uint64_t)0xFFFF0000u << (fill & 31u);
+                    stage[fill >> 5] |= (uint32_t)v;
+                    stage[(fill >> 5) + 1] |= (uint32_t)(v >> 32);
+                }
+                fill += 32u;
+            }
+            __syncthreads();
+            const uint32_t nw = (fill + 31u) >> 5;                       // <= 3
+            if (lane < nw) out_w[words_done + lane] = stage[lane];
+        }
+        if (lane == 0) A.out[seg].bytes = overflow ? 0xFFFFFFFFu : words_done * 4u + (fill >> 3);
+        __syncthreads();
+    }
+}
+
+// CRC-32 of every segment: the lanes take 64 consecutive pieces, the pieces are joined by the checksum's algebra
+__global__ __launch_bounds__(64) void k_crc_segments(const uint8_t *__restrict__ text, const GzSegment *__restrict__ segs, uint32_t n_segs,
+                                                     GzSegOut *__restrict__ out) {
+    __shared__ uint32_t tab[256];
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t i = lane; i < 256; i += 64) tab[i] = dfl::crc_table_entry(i);
+    __syncthreads();
+    const uint32_t seg = blockIdx.x;
+    if (seg >= n_segs) return;
+    const GzSegment sg = segs[seg];
+    const uint8_t *p = text + sg.text_off;
+    const uint32_t piece = (((sg.len + 63u) / 64u) + 3u) & ~3u;
+    const uint32_t a = min(sg.len, lane * piece), b = min(sg.len, a + piece);
+    uint32_t c = 0xFFFFFFFFu;
+    uint32_t i = a;
+    for (; i + 4 <= b; i += 4) {
+        uint32_t w = *reinterpret_cast<const uint32_t *>(p + i);       // (text_off and piece are multiples of four)
+        for (int k = 0; k < 4; ++k) { c = tab[(c ^ w) & 0xFFu] ^ (c >> 8); w >>= 8; }
+    }
+    for (; i < b; ++i) c = tab[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+    c = b > a ? c ^ 0xFFFFFFFFu : 0u;
+    uint32_t t = b > a ? dfl::gf_mul(dfl::gf_xpow8(sg.len - b), c) : 0u;
+    for (int d = 32; d >= 1; d >>= 1) t ^= (uint32_t)__shfl_xor((int)t, d);
+    if (lane == 0) out[seg].crc = t;
+}
+
+// the segments' bytes, one behind the other where the host wants them (dst: byte offsets into `packed`)
+__global__ __launch_bounds__(256) void k_gz_pack(const uint8_t *__restrict__ slots, uint32_t slot_bytes, const GzSegOut *__restrict__ so,
+                                                 const uint64_t *__restrict__ dst, uint32_t n_segs, uint8_t *__restrict__ packed) {
+    const uint32_t seg = blockIdx.x;
+    if (seg >= n_segs) return;
+    const uint32_t n = so[seg].bytes;
+    const uint8_t *s = slots + (size_t)seg * slot_bytes;
+    uint8_t *d = packed + dst[seg];
+    for (uint32_t i = threadIdx.x; i < n; i += 256) d[i] = s[i];
+}
+
+struct GzState {
+    DevBuf segs, out, tok, slots, counter, dst, packed;
+    void *h_out = nullptr; size_t h_out_cap = 0;          // pinned: per-segment sizes + checksums
+    void *h_packed = nullptr; size_t h_packed_cap = 0;    // pinned: the files
+    std::vector<GzSegment> h_segs;
+    std::vector<uint64_t> h_dst;
+    int waves = 0;
+};
+
+int pin_reserve(void *&p, size_t &cap, size_t bytes) {
+    if (bytes <= cap) return PAV_OK;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    const size_t want = bytes + bytes / 4 + 4096;
+    W_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+    cap = want;
+    return PAV_OK;
+}
+
+}  // namespace
+
+void gz_release_slot(pav_ctx *ctx, void **slot) {
+    if (!ctx || !slot || !*slot) return;
+    GzState *G = static_cast<GzState *>(*slot);
+    (void)hipSetDevice(ctx->device);
+    for (DevBuf *b : {&G->segs, &G->out, &G->tok, &G->slots, &G->counter, &G->dst, &G->packed}) b->release();
+    if (G->h_out) (void)hipHostFree(G->h_out);
+    if (G->h_packed) (void)hipHostFree(G->h_packed);
+    delete G;
+    *slot = nullptr;
+}
+void gz_release(pav_ctx *ctx) { if (ctx) gz_release_slot(ctx, &ctx->gz); }
+
+int gz_files(pav_ctx *ctx, void **slot, hipStream_t st, const uint8_t *d_text, uint64_t text_alloc, const std::vector<GzFile> &files, int level,
+             GzOut &out) {
+    out.host = nullptr; out.off.assign(files.size(), 0); out.len.assign(files.size(), 0);
+    if (files.empty()) return PAV_OK;
+    if (!*slot) *slot = new GzState();
+    GzState *G = static_cast<GzState *>(*slot);
+    // window of the match finder: 8 KiB of text behind a position (the rows of these tables repeat their neighbours, not text 30 KiB
+    // back) keeps a wave's LDS at 35 KiB - four waves per CU
+    constexpr int WBITS = 13, HBITS = 12;
+    constexpr uint32_t HIST = 4096;                        // text in front of a segment that primes its window
+    std::vector<GzSegment> &segs = G->h_segs;
+    segs.clear();
+    std::vector<uint32_t> first(files.size() + 1, 0);
+    for (size_t f = 0; f < files.size(); ++f) {
+        const GzFile &F = files[f];
+        if (F.text_off % GZ_TEXT_ALIGN) return fail(nullptr, PAV_E_ARG, "gz_files: file %zu does not start on a %llu-byte boundary", f, (unsigned long long)GZ_TEXT_ALIGN);
+        if (F.text_off + F.text_len + GZ_TEXT_PAD > text_alloc) return fail(nullptr, PAV_E_ARG, "gz_files: file %zu ends less than %llu bytes before the end of the arena", f, (unsigned long long)GZ_TEXT_PAD);
+        first[f] = (uint32_t)segs.size();
+        const uint64_t n = std::max<uint64_t>(1, (F.text_len + GZ_SEGMENT - 1) / GZ_SEGMENT);
+        for (uint64_t s = 0; s < n; ++s) {
+            const uint64_t a = s * GZ_SEGMENT, b = std::min<uint64_t>(F.text_len, a + GZ_SEGMENT);
+            segs.push_back(GzSegment{F.text_off + a, (uint32_t)(b - a), (uint32_t)std::min<uint64_t>(a, HIST), s + 1 == n ? 1u : 0u, (uint32_t)f});
+        }
+    }
+    first[files.size()] = (uint32_t)segs.size();
+    const uint32_t n_segs = (uint32_t)segs.size();
+    if (level <= 0) level = 6;
+    DeflateArgs A{};
+    // how hard to look: chain steps per position, the length from which a match is taken without looking at the next position,
+    // the length that ends a chain walk (zlib's max_chain / max_lazy / nice_length, scaled to what a lock-step wave can afford)
+    if (level <= 1) { A.chain = 4; A.lazy = 8; A.nice = 32; }
+    else if (level <= 3) { A.chain = 8; A.lazy = 16; A.nice = 64; }
+    else if (level <= 6) { A.chain = 16; A.lazy = 32; A.nice = 128; }
+    else { A.chain = 48; A.lazy = 258; A.nice = 258; }
+    if (const char *e = getenv("PAV_GZ_CHAIN")) A.chain = (uint32_t)std::max(1, atoi(e));
+
+    W_HIP(hipSetDevice(ctx->device));
+    if (!G->waves) {
+        int per_cu = 0;
+        W_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_deflate<WBITS, HBITS>, 64, 0));
+        G->waves = std::max(1, per_cu) * std::max(1, ctx->n_cu);
+    }
+    const uint32_t waves = std::min<uint32_t>((uint32_t)G->waves, n_segs);
+    const uint32_t slot_bytes = GZ_SEGMENT + GZ_SEGMENT / 2 + 1024;      // a match can cost more bits than its bytes as literals
+    W_HIP(G->segs.reserve(sizeof(GzSegment) * n_segs));
+    W_HIP(G->out.reserve(sizeof(GzSegOut) * n_segs));
+    W_HIP(G->dst.reserve(8ull * n_segs));
+    W_HIP(G->tok.reserve(4ull * GZ_SEGMENT * waves));
+    W_HIP(G->slots.reserve((size_t)slot_bytes * n_segs));
+    W_HIP(G->counter.reserve(64));
+    { int rc = pin_reserve(G->h_out, G->h_out_cap, sizeof(GzSegOut) * n_segs); if (rc != PAV_OK) return rc; }
+    W_HIP(hipMemcpyAsync(G->segs.p, segs.data(), sizeof(GzSegment) * n_segs, hipMemcpyHostToDevice, st));
+    W_HIP(hipMemsetAsync(G->counter.p, 0, 64, st));
+    A.text = d_text; A.text_alloc = text_alloc; A.segs = G->segs.as<GzSegment>(); A.n_segs = n_segs; A.counter = G->counter.as<uint32_t>();
+    A.tok = G->tok.as<uint32_t>(); A.tok_per_wave = GZ_SEGMENT; A.slots = G->slots.as<uint8_t>(); A.slot_bytes = slot_bytes;
+    A.out = G->out.as<GzSegOut>();
+    W_LAUNCH(st, (k_deflate<WBITS, HBITS>), waves, 64, 0, A);
+    W_LAUNCH(st, k_crc_segments, n_segs, 64, 0, d_text, G->segs.as<GzSegment>(), n_segs, G->out.as<GzSegOut>());
+    W_HIP(hipMemcpyAsync(G->h_out, G->out.p, sizeof(GzSegOut) * n_segs, hipMemcpyDeviceToHost, st));
+    W_HIP(hipStreamSynchronize(st));
+    const GzSegOut *so = static_cast<const GzSegOut *>(G->h_out);
+    // layout of the files: 10-byte header | the segments | CRC-32, ISIZE
+    std::vector<uint64_t> &dst = G->h_dst;
+    dst.resize(n_segs);
+    uint64_t at = 0;
+    std::vector<uint32_t> crc(files.size(), 0);
+    for (size_t f = 0; f < files.size(); ++f) {
+        at = (at + 63) / 64 * 64;
+        out.off[f] = at;
+        at += 10;
+        for (uint32_t s = first[f]; s < first[f + 1]; ++s) {
+            if (so[s].bytes == 0xFFFFFFFFu) return fail(nullptr, PAV_E_LIMIT, "gz_files: segment %u of file %zu outgrew its slot of %u bytes", s - first[f], f, slot_bytes);
+            dst[s] = at; at += so[s].bytes;
+            crc[f] = dfl::crc_join(crc[f], so[s].crc, segs[s].len);
+        }
+        at += 8;
+        out.len[f] = at - out.off[f];
+    }
+    W_HIP(G->packed.reserve(at + 64));
+    { int rc = pin_reserve(G->h_packed, G->h_packed_cap, at + 64); if (rc != PAV_OK) return rc; }
+    W_HIP(hipMemcpyAsync(G->dst.p, dst.data(), 8ull * n_segs, hipMemcpyHostToDevice, st));
+    W_LAUNCH(st, k_gz_pack, n_segs, 256, 0, G->slots.as<uint8_t>(), slot_bytes, G->out.as<GzSegOut>(), G->dst.as<uint64_t>(),
+                  n_segs, G->packed.as<uint8_t>());
+    W_HIP(hipMemcpyAsync(G->h_packed, G->packed.p, at, hipMemcpyDeviceToHost, st));
+    W_HIP(hipStreamSynchronize(st));
+    uint8_t *hp = static_cast<uint8_t *>(G->h_packed);
+    for (size_t f = 0; f < files.size(); ++f) {
+        static const uint8_t hdr[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 0xff};   // deflate, no name, no time, unknown system
+        memcpy(hp + out.off[f], hdr, 10);
+        uint8_t *tr = hp + out.off[f] + out.len[f] - 8;
+        const uint32_t isize = (uint32_t)files[f].text_len;
+        for (int k = 0; k < 4; ++k) { tr[k] = (uint8_t)(crc[f] >> (8 * k)); tr[4 + k] = (uint8_t)(isize >> (8 * k)); }
+    }
+    out.host = hp;
+    return PAV_OK;
+}
+
+}  // namespace pav
+
+using namespace pav;
+
+extern "C" {
+
+// gzip of a host buffer on the device (the table writers' compressor, for tests and for callers with text of their own):
+// uploads `text`, encodes it, returns the gzip member in `out` (*out_len bytes; PAV_E_LIMIT when out_cap is too small).
+int pav_gzip_buffer(pav_ctx *ctx, const uint8_t *text, uint64_t n, int level, uint8_t *out, uint64_t out_cap, uint64_t *out_len) {
+    if (!ctx || (n && !text) || !out || !out_len) return fail(ctx, PAV_E_ARG, "pav_gzip_buffer: null argument");
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t alloc = (n + GZ_TEXT_PAD + 255) / 256 * 256;
+    PAV_HIP(ctx, ctx->d_tmp.reserve(alloc));
+    if (n) PAV_HIP(ctx, hipMemcpyAsync(ctx->d_tmp.p, text, n, hipMemcpyHostToDevice, ctx->stream));
+    PAV_HIP(ctx, hipMemsetAsync(ctx->d_tmp.as<uint8_t>() + n, 0, alloc - n, ctx->stream));
+    GzOut g;
+    const int rc = gz_files(ctx, &ctx->gz, ctx->stream, ctx->d_tmp.as<uint8_t>(), alloc, {GzFile{0, n}}, level, g);
+    if (rc != PAV_OK) return fail(ctx, rc, "%s", pav_last_error(nullptr));
+    *out_len = g.len[0];
+    if (g.len[0] > out_cap) return fail(ctx, PAV_E_LIMIT, "pav_gzip_buffer: %llu bytes of output, room for %llu", (unsigned long long)g.len[0], (unsigned long long)out_cap);
+    memcpy(out, g.host + g.off[0], g.len[0]);
+    return PAV_OK;
+}
+
+}  // extern "C"

@@ -171,50 +171,71 @@ PAV_HD Dec shortest(uint64_t ieee_mant, uint32_t ieee_exp) {
 }
 
 // ---- repr(float) ------------------------------------------------------------------------------------------------------
-// What textio.h put_f64_repr writes (pandas' to_csv of a float64 column: repr; NaN -> the empty na_rep).  `out` needs 24 bytes + 1.
-PAV_HD uint32_t put_f64_repr(uint8_t *out, double v) {
+// What textio.h put_f64_repr writes (pandas' to_csv of a float64 column: repr; NaN -> the empty na_rep).  Two functions with one
+// layout rule: the length, and the bytes (at most 24) - every digit is stored straight at its place, no buffer in between (a
+// kernel that indexed a private array would spill it to scratch memory).
+struct ReprShape { uint64_t digits; int32_t nd, decpt; uint32_t kind; };   // kind 0 NaN, 1 inf, 2 zero, 3 positional, 4 exponent
+PAV_HD ReprShape repr_shape(double v, bool &neg) {
     union { double d; uint64_t u; } cv; cv.d = v;
     const uint64_t bits = cv.u;
-    const bool neg = (bits >> 63) != 0;
+    neg = (bits >> 63) != 0;
     const uint64_t mant = bits & ((1ull << 52) - 1);
     const uint32_t ex = (uint32_t)((bits >> 52) & 0x7FFu);
-    uint32_t n = 0;
-    if (ex == 0x7FFu) {
-        if (mant) return 0;                           // NaN: empty field
-        if (neg) out[n++] = '-';
-        out[n++] = 'i'; out[n++] = 'n'; out[n++] = 'f';
-        return n;
-    }
-    if (neg) out[n++] = '-';
-    if (ex == 0 && mant == 0) { out[n++] = '0'; out[n++] = '.'; out[n++] = '0'; return n; }
+    if (ex == 0x7FFu) return ReprShape{0, 0, 0, mant ? 0u : 1u};
+    if (ex == 0 && mant == 0) return ReprShape{0, 1, 1, 2u};
     const Dec d = shortest(mant, ex);
-    uint8_t dig[20];
-    const int32_t nd = (int32_t)put_u64(dig, d.digits);
-    const int32_t decpt = d.exp + nd;
-    if (decpt > -4 && decpt <= 16) {
-        if (decpt <= 0) {
-            out[n++] = '0'; out[n++] = '.';
-            for (int32_t i = 0; i < -decpt; ++i) out[n++] = '0';
-            for (int32_t i = 0; i < nd; ++i) out[n++] = dig[i];
-        } else if (decpt >= nd) {
-            for (int32_t i = 0; i < nd; ++i) out[n++] = dig[i];
-            for (int32_t i = nd; i < decpt; ++i) out[n++] = '0';
-            out[n++] = '.'; out[n++] = '0';
-        } else {
-            for (int32_t i = 0; i < decpt; ++i) out[n++] = dig[i];
-            out[n++] = '.';
-            for (int32_t i = decpt; i < nd; ++i) out[n++] = dig[i];
-        }
-    } else {
-        out[n++] = dig[0];
-        if (nd > 1) { out[n++] = '.'; for (int32_t i = 1; i < nd; ++i) out[n++] = dig[i]; }
-        out[n++] = 'e';
-        int32_t e = decpt - 1;
-        out[n++] = e < 0 ? '-' : '+';
-        if (e < 0) e = -e;
-        if (e < 10) out[n++] = '0';
-        n += put_u64(out + n, (uint64_t)e);
+    const int32_t nd = (int32_t)dec_len(d.digits), decpt = d.exp + nd;
+    return ReprShape{d.digits, nd, decpt, (decpt > -4 && decpt <= 16) ? 3u : 4u};
+}
+PAV_HD uint32_t f64_repr_len(double v) {
+    bool neg; const ReprShape r = repr_shape(v, neg);
+    const uint32_t sign = neg ? 1u : 0u;
+    if (r.kind == 0) return 0;
+    if (r.kind <= 2) return sign + 3;                                    // inf, 0.0
+    if (r.kind == 3) {
+        if (r.decpt <= 0) return sign + 2u + (uint32_t)(-r.decpt) + (uint32_t)r.nd;
+        if (r.decpt >= r.nd) return sign + (uint32_t)r.decpt + 2u;
+        return sign + (uint32_t)r.nd + 1u;
     }
+    int32_t e = r.decpt - 1; if (e < 0) e = -e;
+    return sign + (uint32_t)r.nd + (r.nd > 1 ? 1u : 0u) + 2u + (e < 10 ? 2u : dec_len((uint64_t)e));
+}
+PAV_HD uint32_t put_f64_repr(uint8_t *out, double v) {
+    bool neg; const ReprShape r = repr_shape(v, neg);
+    uint32_t n = 0;
+    if (r.kind == 0) return 0;                                           // NaN: empty field
+    if (neg) out[n++] = '-';
+    if (r.kind == 1) { out[n++] = 'i'; out[n++] = 'n'; out[n++] = 'f'; return n; }
+    if (r.kind == 2) { out[n++] = '0'; out[n++] = '.'; out[n++] = '0'; return n; }
+    uint64_t dv = r.digits;
+    const int32_t nd = r.nd, decpt = r.decpt;
+    if (r.kind == 3) {
+        if (decpt <= 0) {                                                // 0.000ddd
+            out[n] = '0'; out[n + 1] = '.';
+            for (int32_t i = 0; i < -decpt; ++i) out[n + 2 + i] = '0';
+            const uint32_t at = n + 2u + (uint32_t)(-decpt);
+            for (int32_t i = nd; i-- > 0;) { out[at + i] = (uint8_t)('0' + dv % 10); dv /= 10; }
+            return at + (uint32_t)nd;
+        }
+        if (decpt >= nd) {                                               // ddd000.0
+            for (int32_t i = nd; i-- > 0;) { out[n + i] = (uint8_t)('0' + dv % 10); dv /= 10; }
+            for (int32_t i = nd; i < decpt; ++i) out[n + i] = '0';
+            out[n + decpt] = '.'; out[n + decpt + 1] = '0';
+            return n + (uint32_t)decpt + 2u;
+        }
+        for (int32_t i = nd; i-- > 0;) { out[n + i + (i >= decpt ? 1 : 0)] = (uint8_t)('0' + dv % 10); dv /= 10; }   // dd.ddd
+        out[n + decpt] = '.';
+        return n + (uint32_t)nd + 1u;
+    }
+    for (int32_t i = nd; i-- > 1;) { out[n + 1 + i] = (uint8_t)('0' + dv % 10); dv /= 10; }          // d.ddde+XX
+    out[n] = (uint8_t)('0' + dv);
+    if (nd > 1) { out[n + 1] = '.'; n += (uint32_t)nd + 1u; } else n += 1u;
+    out[n++] = 'e';
+    int32_t e = decpt - 1;
+    out[n++] = e < 0 ? '-' : '+';
+    if (e < 0) e = -e;
+    if (e < 10) out[n++] = '0';
+    n += put_u64(out + n, (uint64_t)e);
     return n;
 }
 

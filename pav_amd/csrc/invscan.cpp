@@ -9,6 +9,7 @@
 #include "textio.h"
 #include "pool.h"
 #include "lift_dev.h"
+#include "textdev.h"
 
 #include <sys/mman.h>
 #include <new>
@@ -1126,9 +1127,48 @@ int pav_inv_table_view(pav_ctx *ctx, uint32_t region, uint32_t *n_rows, const ui
 int pav_inv_write_tables(pav_ctx *ctx, uint32_t n, const uint32_t *regions, const char *const *paths, int threads, int gzip_level) {
     if (!ctx || (n && (!regions || !paths))) return fail(ctx, PAV_E_ARG, "pav_inv_write_tables: null argument");
     InvState *S = istate(ctx);
+    const int level = gzip_level > 0 ? gzip_level : 6;
+    if (device_writer_enabled()) {
+        // The device writer (textdev.hip): rows -> text -> gzip in HBM, straight from the column blocks the scan left resident
+        // (CallStage::buf, one per round: K0 | K1 | K2 | KMER | INDEX | STATE_MER | STATE | FLANK | MATCH); the tables never come to
+        // the host.  A region whose block is not resident any more falls through to the host writer below.
+        std::vector<DenTableDev> tabs; std::vector<std::string> ps;
+        bool all = true;
+        for (uint32_t q = 0; q < n && all; ++q) {
+            if (!paths[q]) return fail(ctx, PAV_E_ARG, "pav_inv_write_tables: null path");
+            if (regions[q] >= S->tables.size() || !S->tables[regions[q]])
+                return fail(ctx, PAV_E_STATE, "pav_inv_write_tables: region %u has no call in the last scan", regions[q]);
+            bool found = false;
+            for (size_t r = 0; r < S->stage_used && !found; ++r) {
+                const CallStage &stg = *S->stage_sets[S->cur_set][r];
+                if (!stg.buf.p || !stg.rows) continue;
+                for (const CallStage::Entry &e : stg.entries) {
+                    if (e.owner != regions[q]) continue;
+                    const size_t rows = stg.rows;
+                    const double *k0 = stg.buf.as<double>(), *k1 = k0 + rows, *k2 = k1 + rows;
+                    const unsigned long long *kmer = reinterpret_cast<const unsigned long long *>(k2 + rows);
+                    const uint32_t *index = reinterpret_cast<const uint32_t *>(kmer + rows);
+                    const int8_t *sm = reinterpret_cast<const int8_t *>(index + rows), *stt = sm + rows;
+                    const uint8_t *fl = reinterpret_cast<const uint8_t *>(stt + rows), *ma = fl + rows;
+                    const size_t o = e.row0;
+                    tabs.push_back(DenTableDev{k0 + o, e.has_k1 ? k1 + o : nullptr, k2 + o, kmer + o, index + o, sm + o, stt + o, fl + o, ma + o, e.n});
+                    ps.emplace_back(paths[q]);
+                    found = true;
+                    break;
+                }
+            }
+            all = all && found;
+        }
+        if (all) {
+            PAV_HIP(ctx, hipSetDevice(ctx->device));
+            PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));          // the scan's last gather / annotate kernels
+            const int rcd = text_density_tables(ctx, tabs, ps, level);
+            if (rcd != PAV_OK) return fail(ctx, rcd, "%s", pav_last_error(nullptr));
+            return PAV_OK;
+        }
+    }
     { const int rcw = tables_on_host(ctx, S); if (rcw != PAV_OK) return rcw; }
     if (threads <= 0) threads = (int)std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
-    const int level = gzip_level > 0 ? gzip_level : 6;
     static const char *FLANK_TEXT[3] = {"", "UP", "DN"};
     static const char *MATCH_TEXT[4] = {"", "SAME", "OTHER", ""};      // 3 = NaN, written as the empty na_rep
     const std::string header = "INDEX\tSTATE_MER\tSTATE\tKERN_FWD\tKERN_FWDREV\tKERN_REV\tKMER\tFLANK\tMATCH\n";

@@ -6,6 +6,7 @@
 //   device : sort keys of the SNV rows, stable radix sort (rocPRIM primitive), gather + FILTER
 //   host   : INDEL order (stable sort; ID tie-break on TYPE then on the decimal *string* of SVLEN), text, gzip (zlib)
 #include "common.h"
+#include "textdev.h"
 #include "textio.h"
 
 #include <rocprim/rocprim.hpp>
@@ -65,10 +66,16 @@ struct TableWork {
     bool have_snv = false, have_insdel = false, with_filter = false, merged = false;
     int threads = 1, level = 6;
     uint64_t n_snv = 0, n_ind = 0;
+    // the device writer (textdev.hip; the default): text and gzip are made in HBM on a stream of the writer's own, from the records
+    // resident in the context - nothing but the files' bytes comes to the host.  `job` then holds what the write needs.
+    bool device = false;
+    pav_ctx *ctx = nullptr;
+    CigarTextJob job;
 };
 struct TableJob { std::shared_ptr<TableWork> work; std::thread th; int rc = PAV_OK; bool pending = false; };
 
 static int table_host_phase(TableWork &W) {
+    if (W.device) return text_cigar_tables(W.ctx, W.job, W.err);
     const std::vector<pav_aln> &aln = W.aln; const std::vector<SnvOut> &snv = W.snv; const std::vector<pav_indel> &ind = W.ind;
     const std::vector<uint8_t> &blob = W.blob, &batch8 = W.batch8; const std::vector<uint16_t> &rank = W.rank;
     const std::vector<std::string> &rnames = W.rnames, &tnames = W.tnames;
@@ -152,6 +159,12 @@ static int table_host_phase(TableWork &W) {
     return PAV_OK;
 }
 
+// a device write reads the records resident in the context: whoever is about to replace them waits for it first
+void table_writer_quiesce(pav_ctx *ctx) {
+    TableJob *J = static_cast<TableJob *>(ctx->table_writer);
+    if (J && J->th.joinable()) J->th.join();
+}
+
 void table_writer_release(pav_ctx *ctx) {
     TableJob *J = static_cast<TableJob *>(ctx->table_writer);
     if (!J) return;
@@ -206,6 +219,28 @@ static int table_device_phase(pav_ctx *ctx, const pav_table_opts *o, TableWork &
     rank.assign(n_ref, 0);
     for (uint32_t i = 0; i < n_ref; ++i) rank[by_name[i]] = (uint16_t)(i && rnames[by_name[i]] == rnames[by_name[i - 1]] ? rank[by_name[i - 1]] : i);
 
+    W.n_snv = n_snv; W.n_ind = n_ind;
+    // ---- the device writer: no record leaves the GPU -----------------------------------------------------------------------------
+    bool plain = csv_field(o->hap) == o->hap;                       // (a name to_csv would quote: the host writer knows how)
+    for (const std::string &nm : rnames) plain = plain && csv_field(nm) == nm;
+    for (const std::string &nm : tnames) plain = plain && csv_field(nm) == nm;
+    if (plain && device_writer_enabled()) {
+        CigarTextJob &J = W.job;
+        J.rnames = rnames; J.tnames = tnames; J.rank = rank; J.batch8 = batch8;
+        J.align_index.assign(o->align_index, o->align_index + n_aln);
+        J.filter = with_filter;
+        if (with_filter) { J.trim_pos.assign(o->trim_pos, o->trim_pos + n_aln); J.trim_end.assign(o->trim_end, o->trim_end + n_aln); }
+        J.hap = o->hap; J.have_snv = o->snv_path != nullptr; J.have_insdel = o->insdel_path != nullptr;
+        if (o->snv_path) J.snv_path = o->snv_path;
+        if (o->insdel_path) J.insdel_path = o->insdel_path;
+        J.level = level; J.n_snv = n_snv; J.n_ind = n_ind;
+        { const int rch = wait_homology(ctx); if (rch != PAV_OK) return rch; }        // the SEQ column and the homology columns
+        if (!ctx->writer_ready) PAV_HIP(ctx, hipEventCreateWithFlags(&ctx->writer_ready, hipEventDisableTiming));
+        PAV_HIP(ctx, hipEventRecord(ctx->writer_ready, st));
+        J.ready = ctx->writer_ready;
+        W.device = true; W.ctx = ctx;
+        return PAV_OK;
+    }
     std::vector<pav_aln> &aln = W.aln;
     aln.resize(n_aln);
     if (n_aln) PAV_HIP(ctx, hipMemcpyAsync(aln.data(), ctx->d_aln.p, sizeof(pav_aln) * n_aln, hipMemcpyDeviceToHost, st));
