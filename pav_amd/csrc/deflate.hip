@@ -21,6 +21,7 @@
 #include "devgz.h"
 
 #include <algorithm>
+#include <chrono>
 
 namespace pav {
 
@@ -373,6 +374,9 @@ int gz_files(pav_ctx *ctx, void **slot, hipStream_t st, const uint8_t *d_text, u
     if (files.empty()) return PAV_OK;
     if (!*slot) *slot = new GzState();
     GzState *G = static_cast<GzState *>(*slot);
+    const bool timing = getenv("PAV_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_a = now();
     // window of the match finder: 8 KiB of text behind a position (the rows of these tables repeat their neighbours, not text 30 KiB
     // back) keeps a wave's LDS at 35 KiB - four waves per CU
     constexpr int WBITS = 13, HBITS = 12;
@@ -428,6 +432,7 @@ int gz_files(pav_ctx *ctx, void **slot, hipStream_t st, const uint8_t *d_text, u
     W_HIP(hipMemcpyAsync(G->h_out, G->out.p, sizeof(GzSegOut) * n_segs, hipMemcpyDeviceToHost, st));
     W_HIP(hipStreamSynchronize(st));
     const GzSegOut *so = static_cast<const GzSegOut *>(G->h_out);
+    const double t_b = now();
     // layout of the files: 10-byte header | the segments | CRC-32, ISIZE
     std::vector<uint64_t> &dst = G->h_dst;
     dst.resize(n_segs);
@@ -461,6 +466,11 @@ int gz_files(pav_ctx *ctx, void **slot, hipStream_t st, const uint8_t *d_text, u
         for (int k = 0; k < 4; ++k) { tr[k] = (uint8_t)(crc[f] >> (8 * k)); tr[4 + k] = (uint8_t)(isize >> (8 * k)); }
     }
     out.host = hp;
+    if (timing) {
+        uint64_t tin = 0; for (const GzFile &F : files) tin += F.text_len;
+        fprintf(stderr, "[pav timing] gz_files: %zu files, %u segments, %.1f MB -> %.1f MB; deflate + crc %.1f ms (%.1f GB/s), pack + copy %.1f ms\n", files.size(), n_segs,
+                (double)tin / 1e6, (double)at / 1e6, (t_b - t_a) * 1e3, (double)tin / 1e9 / std::max(1e-9, t_b - t_a), (now() - t_b) * 1e3);
+    }
     return PAV_OK;
 }
 

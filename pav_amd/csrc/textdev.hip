@@ -10,6 +10,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 
 #include "devgz.h"
@@ -271,7 +272,8 @@ struct TextDev {
     hipStream_t st = nullptr;
     DevBuf len, roff, bsum, text, small, sort_a, sort_b, sort_tmp, snv_out, longs;
     void *gz = nullptr;
-    void *pin = nullptr; size_t pin_cap = 0;
+    void *pin = nullptr; size_t pin_cap = 0;              // descriptors up, totals down
+    void *pin_text = nullptr; size_t pin_text_cap = 0;    // the text of files written without gzip
     int open(pav_ctx *ctx) {
         (void)ctx;
         if (!st) W_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -281,8 +283,9 @@ struct TextDev {
         for (DevBuf *b : {&len, &roff, &bsum, &text, &small, &sort_a, &sort_b, &sort_tmp, &snv_out, &longs}) b->release();
         gz_release_slot(ctx, &gz);
         if (pin) (void)hipHostFree(pin);
+        if (pin_text) (void)hipHostFree(pin_text);
         if (st) (void)hipStreamDestroy(st);
-        pin = nullptr; pin_cap = 0; st = nullptr;
+        pin = pin_text = nullptr; pin_cap = pin_text_cap = 0; st = nullptr;
     }
 };
 struct TextDevState { TextDev cigar, density; };
@@ -292,15 +295,15 @@ TextDevState *tstate(pav_ctx *ctx) {
     return static_cast<TextDevState *>(ctx->textdev);
 }
 
-int pin_reserve(pav_ctx *ctx, TextDev &D, size_t bytes) {
-    (void)ctx;
-    if (bytes <= D.pin_cap) return PAV_OK;
-    if (D.pin) { (void)hipHostFree(D.pin); D.pin = nullptr; D.pin_cap = 0; }
+int pin_grow(void *&p, size_t &cap, size_t bytes) {
+    if (bytes <= cap) return PAV_OK;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
     const size_t want = bytes + bytes / 4 + 4096;
-    W_HIP(hipHostMalloc(&D.pin, want, hipHostMallocDefault));
-    D.pin_cap = want;
+    W_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+    cap = want;
     return PAV_OK;
 }
+int pin_reserve(pav_ctx *ctx, TextDev &D, size_t bytes) { (void)ctx; return pin_grow(D.pin, D.pin_cap, bytes); }
 
 // roff[0 .. n] from len[0 .. n) on D.st
 int scan_lengths(pav_ctx *ctx, TextDev &D, uint64_t n) {
@@ -313,6 +316,8 @@ int scan_lengths(pav_ctx *ctx, TextDev &D, uint64_t n) {
     W_LAUNCH(D.st, k_scan_apply, std::max(1u, nb), 256, 0, D.len.as<uint32_t>(), n, D.bsum.as<uint64_t>(), nb, D.roff.as<uint64_t>());
     return PAV_OK;
 }
+
+double wall_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 bool ends_gz(const std::string &p) { return p.size() > 3 && p.compare(p.size() - 3, 3, ".gz") == 0; }
 
@@ -330,17 +335,20 @@ int emit_files(pav_ctx *ctx, TextDev &D, uint64_t text_alloc, const std::vector<
     for (size_t f = 0; f < files.size(); ++f) if (ends_gz(paths[f])) { gz.push_back(files[f]); gz_ix.push_back(f); }
     if (!gz.empty()) {
         GzOut out;
+        if (getenv("PAV_TIMING")) W_HIP(hipStreamSynchronize(D.st));    // (so that the gzip's own time is what gz_files prints)
         int rc = gz_files(ctx, &D.gz, D.st, D.text.as<uint8_t>(), text_alloc, gz, level, out);
         if (rc != PAV_OK) return rc;
+        const double t0 = wall_now();
         for (size_t q = 0; q < gz.size(); ++q) { rc = write_file(paths[gz_ix[q]], out.host + out.off[q], out.len[q]); if (rc != PAV_OK) return rc; }
+        if (getenv("PAV_TIMING")) fprintf(stderr, "[pav timing] table files written in %.1f ms\n", (wall_now() - t0) * 1e3);
     }
     for (size_t f = 0; f < files.size(); ++f) {
         if (ends_gz(paths[f])) continue;
-        int rc = pin_reserve(ctx, D, files[f].text_len + 64);
+        int rc = pin_grow(D.pin_text, D.pin_text_cap, files[f].text_len + 64);
         if (rc != PAV_OK) return rc;
-        if (files[f].text_len) W_HIP(hipMemcpyAsync(D.pin, D.text.as<uint8_t>() + files[f].text_off, files[f].text_len, hipMemcpyDeviceToHost, D.st));
+        if (files[f].text_len) W_HIP(hipMemcpyAsync(D.pin_text, D.text.as<uint8_t>() + files[f].text_off, files[f].text_len, hipMemcpyDeviceToHost, D.st));
         W_HIP(hipStreamSynchronize(D.st));
-        rc = write_file(paths[f], static_cast<const uint8_t *>(D.pin), files[f].text_len);
+        rc = write_file(paths[f], static_cast<const uint8_t *>(D.pin_text), files[f].text_len);
         if (rc != PAV_OK) return rc;
     }
     return PAV_OK;
@@ -390,7 +398,12 @@ static int text_cigar_tables_impl(pav_ctx *ctx, CigarTextJob &J) {
     const bool filt = J.filter;
     h_snv += filt ? "\tFILTER\n" : "\n"; h_ind += filt ? "\tFILTER\n" : "\n";
     std::vector<uint8_t> blk;
-    auto put = [&](const void *p, size_t bytes) { const size_t at = align_up(blk.size(), 16); blk.resize(at + bytes); if (bytes) memcpy(blk.data() + at, p, bytes); return at; };
+    auto put = [&](const void *p, size_t bytes) {                      // p == nullptr: `bytes` zeros
+        const size_t at = align_up(blk.size(), 16);
+        blk.resize(at + bytes, 0);
+        if (bytes && p) memcpy(blk.data() + at, p, bytes);
+        return at;
+    };
     const size_t o_rblob = put(rn.bytes.data(), rn.bytes.size()), o_roff = put(rn.off.data(), 4 * rn.off.size());
     const size_t o_tblob = put(tn.bytes.data(), tn.bytes.size()), o_toff = put(tn.off.data(), 4 * tn.off.size());
     const size_t o_rank = put(J.rank.data(), 2 * (size_t)n_ref), o_ai = put(J.align_index.data(), 8 * (size_t)n_aln);
@@ -506,7 +519,9 @@ static int text_cigar_tables_impl(pav_ctx *ctx, CigarTextJob &J) {
 }
 
 int text_cigar_tables(pav_ctx *ctx, CigarTextJob &job, std::string &err) {
+    const double t0 = wall_now();
     const int rc = text_cigar_tables_impl(ctx, job);
+    if (getenv("PAV_TIMING")) fprintf(stderr, "[pav timing] device writer, SNV + INS / DEL tables: %.1f ms\n", (wall_now() - t0) * 1e3);
     if (rc != PAV_OK) err = pav_last_error(nullptr);
     return rc;
 }
@@ -518,6 +533,7 @@ int text_density_tables(pav_ctx *ctx, const std::vector<DenTableDev> &tables, co
     TD_CHECK(D.open(ctx));
     hipStream_t st = D.st;
     const uint32_t n_tab = (uint32_t)tables.size();
+    const double t_in = wall_now();
     static const std::string header = "INDEX\tSTATE_MER\tSTATE\tKERN_FWD\tKERN_FWDREV\tKERN_REV\tKMER\tFLANK\tMATCH\n";
     std::vector<uint64_t> row0(n_tab + 1, 0);
     for (uint32_t t = 0; t < n_tab; ++t) row0[t + 1] = row0[t] + tables[t].n;
@@ -563,7 +579,11 @@ int text_density_tables(pav_ctx *ctx, const std::vector<DenTableDev> &tables, co
                   (uint32_t)header.size());
     if (n) W_LAUNCH(st, k_den_rowtext, (uint32_t)((n + 255) / 256), 256, 0, R, n, D.roff.as<uint64_t>(),
                          reinterpret_cast<const uint64_t *>(sm + o_fbase), D.text.as<uint8_t>());
-    return emit_files(ctx, D, text_alloc, files, paths, level);
+    const double t1 = wall_now();
+    const int rce = emit_files(ctx, D, text_alloc, files, paths, level);
+    if (getenv("PAV_TIMING")) fprintf(stderr, "[pav timing] device writer, %u density tables (%llu rows): lengths + offsets %.1f ms (incl. waiting for the stream), gzip + files %.1f ms\n",
+                                      n_tab, (unsigned long long)n, (t1 - t_in) * 1e3, (wall_now() - t1) * 1e3);
+    return rce;
 }
 
 }  // namespace pav

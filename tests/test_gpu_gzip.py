@@ -94,3 +94,35 @@ def test_many_segments_in_one_member(ctx):
     t = table_text(rng, 30_000, 'snv') * 12                    # ~35 MB: several hundred segments, every wave busy
     gz = check(ctx, t, 6)
     assert len(gz) < len(t) // 3
+
+
+def test_table_files_come_from_the_device_writer_and_equal_the_host_writer(tmp_path, monkeypatch):
+    """The two writers of the merged SNV / INS-DEL tables on one seeded haplotype: device (text + gzip in HBM; the default) and host
+    (PAV_WRITER=host: threads + zlib).  Same text after gunzip; the device's files are ONE gzip member each (OS byte 255 in the
+    header, where zlib writes 3) and stay within 1.10 x of the host writer's level-6 size."""
+    import __graft_entry__ as g
+    g.build_cpu_side()
+    from pav_amd import _lib, cigarcall, synth
+    hap = synth.config2(seed=77, scale=0.02, threads=4)
+    names = hap.ref.names
+    with _lib.Context(0) as c:
+        c.seq_load(_lib.PAV_ROLE_REF, names, [hap.ref.seqs[n] for n in names])
+        c.seq_load(_lib.PAV_ROLE_TIG, hap.tig_names, [hap.tig_seqs[n] for n in hap.tig_names])
+        cigarcall.call_records(c, hap.df_align)
+        index = hap.df_align['INDEX'].to_numpy(dtype='int64')
+        trim = hap.df_trim[['POS', 'END', 'INDEX']].set_index('INDEX').astype(int).reindex(list(index), fill_value=-1)
+        tp, te = trim['POS'].to_numpy(dtype='int64'), trim['END'].to_numpy(dtype='int64')
+        batch = (index % 10).astype('int64')
+        out = {}
+        for mode in ('device', 'host'):
+            monkeypatch.setenv('PAV_WRITER', mode)
+            p_snv, p_ins = str(tmp_path / f'snv_{mode}.tsv.gz'), str(tmp_path / f'insdel_{mode}.tsv.gz')
+            n = c.cigar_write_tables('h1', index, tp, te, snv_path=p_snv, insdel_path=p_ins, call_batch=batch, gzip_level=6)
+            out[mode] = (open(p_snv, 'rb').read(), open(p_ins, 'rb').read(), n)
+    assert out['device'][2] == out['host'][2] and out['device'][2][0] > 10000
+    for k in (0, 1):
+        dev, host = out['device'][k], out['host'][k]
+        assert dev[9] == 255 and host[9] == 3
+        assert gzip.decompress(dev) == gzip.decompress(host)
+        assert zlib.decompress(dev, 15 + 16) == gzip.decompress(host)         # one member holds the whole table
+        assert len(dev) <= 1.10 * len(host), (k, len(dev), len(host))
