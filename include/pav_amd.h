@@ -227,6 +227,10 @@ int pav_cigar_write_tables_end(pav_ctx *ctx, uint64_t *n_snv_rows, uint64_t *n_i
  * out_cap is smaller (n + n / 2 + 4096 always suffices).  level 1..9 as zlib's (0 = 6): how far the match finder looks.
  * Replaces the gzip step of DataFrame.to_csv(compression='gzip') (rules/call.snakefile:845-846, rules/call_inv.snakefile:279-291). */
 int pav_gzip_buffer(pav_ctx *ctx, const uint8_t *text, uint64_t n, int level, uint8_t *out, uint64_t out_cap, uint64_t *out_len);
+/* The same for n texts in one launch set (the sixty per-batch INV tables of a haplotype): member i at out + out_off[i], out_len[i]
+ * bytes; out_cap >= sum over i of (lens[i] + lens[i] / 2 + 4096) always suffices. */
+int pav_gzip_buffers(pav_ctx *ctx, uint32_t n, const uint8_t *const *texts, const uint64_t *lens, int level, uint8_t *out, uint64_t out_cap,
+                     uint64_t *out_off, uint64_t *out_len);
 
 /* Lift-over tables for pavlib.align.AlignLift (pavlib/align/lift.py:380-476, `_add_align`): tokenises every row's
  * CIGAR on the device and returns, per operation, the subject position where it starts (absolute, row POS included)

@@ -183,6 +183,8 @@ SYMBOLS = {
     'pav_device_name': (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int]),
     'pav_gzip_buffer': (ctypes.c_int, [_P, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64,
                                        ctypes.POINTER(ctypes.c_uint64)]),
+    'pav_gzip_buffers': (ctypes.c_int, [_P, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.c_int,
+                                        ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     'pav_device_pci_bus_id': (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int]),
     'pav_sync': (ctypes.c_int, [_P]),
     'pav_mem_info': (ctypes.c_int, [_P, _P, _P]),
@@ -414,6 +416,19 @@ class Context:
         self._check(self.lib.pav_gzip_buffer(self.handle, buf.ctypes.data if n else None, n, int(level), out.ctypes.data, out.shape[0],
                                              ctypes.byref(got)), 'pav_gzip_buffer')
         return out[:got.value].tobytes()
+
+    def gzip_buffers(self, texts, level=0):
+        """gzip of every item of ``texts`` (bytes), all in one launch set on the device; returns a list of bytes."""
+        n = len(texts)
+        if n == 0:
+            return []
+        bufs = [np.frombuffer(t, dtype=np.uint8) for t in texts]
+        ptrs = (ctypes.c_void_p * n)(*[b.ctypes.data if b.shape[0] else None for b in bufs])
+        lens = (ctypes.c_uint64 * n)(*[int(b.shape[0]) for b in bufs])
+        out = np.empty(sum(int(b.shape[0]) + int(b.shape[0]) // 2 + 4096 for b in bufs), dtype=np.uint8)
+        off, got = (ctypes.c_uint64 * n)(), (ctypes.c_uint64 * n)()
+        self._check(self.lib.pav_gzip_buffers(self.handle, n, ptrs, lens, int(level), out.ctypes.data, out.shape[0], off, got), 'pav_gzip_buffers')
+        return [out[int(off[i]):int(off[i]) + int(got[i])].tobytes() for i in range(n)]
 
     def sync(self):
         self._check(self.lib.pav_sync(self.handle), 'pav_sync')
@@ -867,10 +882,9 @@ class FastaFile:
         if n == 0:
             return np.zeros(0, dtype=np.uint8)
         buf = (ctypes.c_uint8 * n).from_address(self.lib.pav_fasta_seq(self.handle, i))
+        buf._pav_owner = self            # the view keeps the file's memory alive (the library recycles the buffer of a closed file)
         a = np.frombuffer(buf, dtype=np.uint8)
         a.flags.writeable = False
-        self._keep = getattr(self, '_keep', [])
-        self._keep.append(buf)
         return a
 
     def close(self):

@@ -4,6 +4,9 @@
 #include "devgz.h"
 #include "textdev.h"
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <thread>
 
 namespace pav {
 
@@ -230,6 +233,71 @@ int need_planes_spans(pav_ctx *ctx, int role, const std::vector<PlaneSpan> &span
 
 using namespace pav;
 
+namespace pav {
+
+// Large uploads from pageable host memory (a FASTA file's records: 3 GB per store).  hipMemcpyAsync from pageable memory is staged
+// by the runtime on one thread (10 - 13 GB/s measured: 0.2 s per store, most of the "sequences" stage of a haplotype); here the
+// bytes go through a ring of pinned slots filled by several threads while the slots before them cross PCIe.
+struct UploadRing {
+    static constexpr int SLOTS = 4;
+    static constexpr size_t SLOT_BYTES = 32u << 20;
+    void *slot[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    bool busy[SLOTS] = {false, false, false, false};
+    int next = 0;
+    bool ok = false;
+};
+
+static UploadRing *upload_ring(pav_ctx *ctx) {
+    if (ctx->upload) return static_cast<UploadRing *>(ctx->upload);
+    auto *R = new UploadRing();
+    R->ok = true;
+    for (int i = 0; i < UploadRing::SLOTS && R->ok; ++i)
+        R->ok = hipHostMalloc(&R->slot[i], UploadRing::SLOT_BYTES, hipHostMallocDefault) == hipSuccess &&
+                hipEventCreateWithFlags(&R->ev[i], hipEventDisableTiming) == hipSuccess;
+    ctx->upload = R;
+    return R;
+}
+
+void upload_release(pav_ctx *ctx) {
+    if (!ctx || !ctx->upload) return;
+    auto *R = static_cast<UploadRing *>(ctx->upload);
+    for (int i = 0; i < UploadRing::SLOTS; ++i) { if (R->slot[i]) (void)hipHostFree(R->slot[i]); if (R->ev[i]) (void)hipEventDestroy(R->ev[i]); }
+    delete R;
+    ctx->upload = nullptr;
+}
+
+// dst[0, bytes) on the device <- src (pageable), queued on `st`; returns when every byte has left `src` (not when it has arrived)
+static int staged_upload(pav_ctx *ctx, hipStream_t st, uint8_t *dst, const uint8_t *src, uint64_t bytes) {
+    UploadRing *R = upload_ring(ctx);
+    static const int threads = [] { const char *e = getenv("PAV_UPLOAD_THREADS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 8; }();
+    if (!R->ok || bytes < (4u << 20) || threads <= 1) {
+        PAV_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+        return PAV_OK;
+    }
+    for (uint64_t at = 0; at < bytes; at += UploadRing::SLOT_BYTES) {
+        const uint64_t n = std::min<uint64_t>(UploadRing::SLOT_BYTES, bytes - at);
+        const int k = R->next; R->next = (k + 1) % UploadRing::SLOTS;
+        if (R->busy[k]) { PAV_HIP(ctx, hipEventSynchronize(R->ev[k])); R->busy[k] = false; }
+        uint8_t *stage = static_cast<uint8_t *>(R->slot[k]);
+        const int use = n >= (8u << 20) ? threads : 1;                 // (a thread is not worth starting for a small record)
+        const uint64_t piece = (n + (uint64_t)use - 1) / (uint64_t)use;
+        std::vector<std::thread> pool;
+        for (int t = 1; t < use; ++t) {
+            const uint64_t a = std::min<uint64_t>(n, piece * (uint64_t)t), b = std::min<uint64_t>(n, a + piece);
+            if (b > a) pool.emplace_back([=] { memcpy(stage + a, src + at + a, b - a); });
+        }
+        memcpy(stage, src + at, std::min<uint64_t>(n, piece));
+        for (auto &th : pool) th.join();
+        PAV_HIP(ctx, hipMemcpyAsync(dst + at, stage, n, hipMemcpyHostToDevice, st));
+        PAV_HIP(ctx, hipEventRecord(R->ev[k], st));
+        R->busy[k] = true;
+    }
+    return PAV_OK;
+}
+
+}  // namespace pav
+
 extern "C" {
 
 int pav_abi_version(void) { return PAV_ABI_VERSION; }
@@ -327,6 +395,7 @@ void pav_destroy(pav_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream2);
     (void)hipStreamSynchronize(ctx->stream);
     table_writer_release(ctx);
+    pav::upload_release(ctx);
     pav::gz_release(ctx);
     pav::textdev_release(ctx);
     pav_density_release(ctx);
@@ -415,19 +484,25 @@ int pav_seq_load(pav_ctx *ctx, int role, uint32_t n_seq, const uint8_t *const *a
         ~Guard() { if (armed) c->cigar_loaded = false; }
     } guard{ctx};
     if (a == 0) { guard.armed = false; s.n = n_seq; s.off = off; s.len.assign(len, len + n_seq); return PAV_OK; }
+    const bool timing = getenv("PAV_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_a = now();
     PAV_HIP(ctx, s.d_ascii.reserve(a));
     PAV_HIP(ctx, s.d_two.reserve(a / 4));
     PAV_HIP(ctx, s.d_mask.reserve(a / 8));
     PAV_HIP(ctx, s.d_dirty.reserve((a / 16 + 256 * PACK_U - 1) / (256 * PACK_U) * 16 + 16));   // 16 summary bytes per pack workgroup (+ slack: verify_kernel reads pairs)
     PAV_HIP(ctx, s.d_off.reserve(sizeof(uint64_t) * n_seq));
     PAV_HIP(ctx, s.d_len.reserve(sizeof(uint64_t) * n_seq));
+    const double t_b = now();
     PAV_HIP(ctx, hipMemsetAsync(s.d_ascii.p, 'N', a, ctx->stream));          // padding reads as non-ACGT
     for (uint32_t i = 0; i < n_seq; ++i)
-        if (len[i])
-            PAV_HIP(ctx, hipMemcpyAsync(s.d_ascii.as<uint8_t>() + off[i], ascii[i], len[i], hipMemcpyHostToDevice,
-                                        ctx->stream));
+        if (len[i]) {
+            const int rcu = staged_upload(ctx, ctx->stream, s.d_ascii.as<uint8_t>() + off[i], ascii[i], len[i]);
+            if (rcu != PAV_OK) return rcu;
+        }
     PAV_HIP(ctx, hipMemcpyAsync(s.d_off.p, off.data(), sizeof(uint64_t) * n_seq, hipMemcpyHostToDevice, ctx->stream));
     PAV_HIP(ctx, hipMemcpyAsync(s.d_len.p, len, sizeof(uint64_t) * n_seq, hipMemcpyHostToDevice, ctx->stream));
+    const double t_c = now();
     s.n = n_seq; s.arena = a; s.total = total;                               // run_pack reads the layout from the store
     s.off = off; s.len.assign(len, len + n_seq);
     // contigs: planes on demand ("lazy contig pack" above); the reference is packed now
@@ -436,6 +511,8 @@ int pav_seq_load(pav_ctx *ctx, int role, uint32_t n_seq, const uint8_t *const *a
     if (rc == PAV_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)     // inputs are borrowed only for the duration of the call
         rc = fail(ctx, PAV_E_HIP, "pav_seq_load: upload / pack failed");
     if (rc != PAV_OK) { s.n = 0; s.arena = s.total = 0; s.off.clear(); s.len.clear(); return rc; }
+    if (timing) fprintf(stderr, "[pav timing] seq_load role %d: %.2f GB; device buffers %.1f ms, staging + queueing %.1f ms (%.1f GB/s), pack + drain %.1f ms\n", role,
+                        (double)total / 1e9, (t_b - t_a) * 1e3, (t_c - t_b) * 1e3, (double)total / 1e9 / std::max(1e-9, t_c - t_b), (now() - t_c) * 1e3);
     guard.armed = false;
     return PAV_OK;
 }

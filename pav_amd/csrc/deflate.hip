@@ -43,7 +43,7 @@ struct DeflateArgs {
     uint32_t *tok; uint32_t tok_per_wave;
     uint8_t *slots; uint32_t slot_bytes;
     GzSegOut *out;
-    uint32_t chain, lazy, nice;
+    uint32_t chain, lazy, nice, good;
 };
 
 __device__ __forceinline__ uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t byte_shift) { return __builtin_amdgcn_alignbyte(hi, lo, byte_shift); }
@@ -53,17 +53,19 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs A) {
     constexpr uint32_t W = 1u << WBITS, WM = W - 1u, H = 1u << HBITS;
     constexpr uint32_t AHEAD = 64 + 320;                 // a step reads up to 258 + 3 bytes past its last position
     constexpr uint32_t MAXDIST = W - AHEAD - 256;        // the ring holds [loaded - W, loaded), loaded < step + AHEAD + 256
-    static_assert(sizeof(dfl::HuffWork) + sizeof(dfl::HeaderWork) + 4 * 192 <= 2 * W, "the tree scratch overlays the chain links");
-    __shared__ uint32_t T[W / 4];
-    __shared__ __attribute__((aligned(16))) uint16_t prev[W];
-    __shared__ uint16_t head[H];
+    // the window: ring of text | chain links | hash heads.  Behind the match phase it is dead: trees and header are built in its place
+    constexpr uint32_t LZ_BYTES = W + 2 * W + 2 * H;
+    static_assert(sizeof(dfl::HuffWork) + sizeof(dfl::HeaderWork) + 4 * 192 <= LZ_BYTES, "the tree scratch overlays the window");
+    __shared__ __attribute__((aligned(16))) uint8_t lz[LZ_BYTES];
+    uint32_t *T = reinterpret_cast<uint32_t *>(lz);
+    uint16_t *prev = reinterpret_cast<uint16_t *>(lz + W);
+    uint16_t *head = reinterpret_cast<uint16_t *>(lz + 3 * W);
     __shared__ uint32_t f_ll[288], f_d[32], c_ll[288], c_d[32];
     __shared__ uint8_t ll_len[288], d_len[32];
     __shared__ uint32_t stage[128];
-    // after the match phase the chain links are dead: trees and header are built in their place
-    dfl::HuffWork &HW = *reinterpret_cast<dfl::HuffWork *>(prev);
-    dfl::HeaderWork &XW = *reinterpret_cast<dfl::HeaderWork *>(reinterpret_cast<uint8_t *>(prev) + sizeof(dfl::HuffWork));
-    uint32_t *hdr = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(prev) + sizeof(dfl::HuffWork) + sizeof(dfl::HeaderWork));
+    dfl::HuffWork &HW = *reinterpret_cast<dfl::HuffWork *>(lz);
+    dfl::HeaderWork &XW = *reinterpret_cast<dfl::HeaderWork *>(lz + sizeof(dfl::HuffWork));
+    uint32_t *hdr = reinterpret_cast<uint32_t *>(lz + sizeof(dfl::HuffWork) + sizeof(dfl::HeaderWork));
 
     const uint32_t lane = threadIdx.x;
     const uint64_t lane_lt = (1ull << lane) - 1ull;
@@ -82,8 +84,7 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs A) {
         const GzSegment sg = A.segs[seg];
         const uint64_t base = sg.text_off - sg.hist;                    // stream position 0 (256-aligned in the arena)
         const uint32_t S = sg.hist, E = sg.hist + sg.len;
-        for (uint32_t i = lane; i < W / 2; i += 64) reinterpret_cast<uint32_t *>(prev)[i] = 0;
-        for (uint32_t i = lane; i < H / 2; i += 64) reinterpret_cast<uint32_t *>(head)[i] = 0;
+        for (uint32_t i = lane; i < LZ_BYTES / 4; i += 64) reinterpret_cast<uint32_t *>(lz)[i] = 0;
         for (uint32_t i = lane; i < 288; i += 64) f_ll[i] = 0;
         if (lane < 32) f_d[lane] = 0;
         __syncthreads();
@@ -159,26 +160,42 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs A) {
             __syncthreads();
             if (g + 64 <= S) continue;                                   // the text in front of the segment only primes the window
             // ---- longest match along the chain ---------------------------------------------------------------------------
+            // One flat loop, every lane in one of two states - at a link of its chain, or extending a candidate four bytes at a
+            // time - so the wave's time is the longest lane's own work, not the sum over chain depths of the longest extension at
+            // each depth.  A candidate is extended only if its first four bytes agree and so do the four bytes that END one past the
+            // best length so far (it cannot win otherwise: zlib's scan_end test); links cost more once a good match is in hand.
             uint32_t best_len = 0, best_dist = 0;
-            if (p >= S && hashable) {
+            {
+                bool active = p >= S && hashable, extending = false;
                 const uint32_t maxlen = min(258u, E - p);
-                uint32_t cur = cand, last = 0;
-                for (uint32_t depth = 0; depth < A.chain; ++depth) {
-                    const uint32_t dist = (p - cur) & 0xFFFFu;
-                    if (dist == 0 || dist > MAXDIST || dist > p || dist <= last) break;
-                    last = dist;
-                    const uint32_t q = p - dist;
-                    if (get4(q) == w0) {
-                        uint32_t len = 4;
-                        while (len < maxlen) {
-                            const uint32_t x = get4(p + len) ^ get4(q + len);
-                            if (x) { len += (uint32_t)(__ffs((int)x) - 1) >> 3; break; }
-                            len += 4;
+                uint32_t cur = cand, last = 0, budget = A.chain, q = 0, len = 0, qdist = 0;
+                while (__any(active)) {
+                    if (active) {
+                        if (!extending) {
+                            const uint32_t dist = (p - cur) & 0xFFFFu;
+                            if (budget == 0 || dist == 0 || dist > MAXDIST || dist > p || dist <= last) active = false;
+                            else {
+                                last = dist; q = p - dist; qdist = dist;
+                                budget -= best_len >= A.good ? min(budget, 4u) : 1u;
+                                cur = prev[q & WM];
+                                bool ok = get4(q) == w0;
+                                if (ok && best_len >= 4u && best_len < maxlen) ok = get4(q + best_len - 3u) == get4(p + best_len - 3u);
+                                if (ok) { extending = true; len = 4; }
+                            }
+                        } else {
+                            bool done = len >= maxlen;
+                            if (!done) {
+                                const uint32_t x = get4(p + len) ^ get4(q + len);
+                                if (x) { len += (uint32_t)(__ffs((int)x) - 1) >> 3; done = true; }
+                                else len += 4;
+                            }
+                            if (done) {
+                                len = min(len, maxlen);
+                                if (len > best_len) { best_len = len; best_dist = qdist; if (len >= A.nice || len >= maxlen) active = false; }
+                                extending = false;
+                            }
                         }
-                        len = min(len, maxlen);
-                        if (len > best_len) { best_len = len; best_dist = dist; if (len >= A.nice) break; }
                     }
-                    cur = prev[q & WM];
                 }
                 // a four-byte match far away costs more bits than four literals of this kind of text
                 if (best_len == 4u && best_dist > 2048u) best_len = 0;
@@ -337,12 +354,12 @@ __global__ __launch_bounds__(256) void k_gz_pack(const uint8_t *__restrict__ slo
 }
 
 struct GzState {
-    DevBuf segs, out, tok, slots, counter, dst, packed;
+    DevBuf segs, out, tok, slots, counter, dst, packed, text;   // text: the uploads of pav_gzip_buffers
     void *h_out = nullptr; size_t h_out_cap = 0;          // pinned: per-segment sizes + checksums
     void *h_packed = nullptr; size_t h_packed_cap = 0;    // pinned: the files
     std::vector<GzSegment> h_segs;
     std::vector<uint64_t> h_dst;
-    int waves = 0;
+    int waves = 0, waves_wbits = 0;
 };
 
 int pin_reserve(void *&p, size_t &cap, size_t bytes) {
@@ -360,7 +377,7 @@ void gz_release_slot(pav_ctx *ctx, void **slot) {
     if (!ctx || !slot || !*slot) return;
     GzState *G = static_cast<GzState *>(*slot);
     (void)hipSetDevice(ctx->device);
-    for (DevBuf *b : {&G->segs, &G->out, &G->tok, &G->slots, &G->counter, &G->dst, &G->packed}) b->release();
+    for (DevBuf *b : {&G->segs, &G->out, &G->tok, &G->slots, &G->counter, &G->dst, &G->packed, &G->text}) b->release();
     if (G->h_out) (void)hipHostFree(G->h_out);
     if (G->h_packed) (void)hipHostFree(G->h_packed);
     delete G;
@@ -379,8 +396,8 @@ int gz_files(pav_ctx *ctx, void **slot, hipStream_t st, const uint8_t *d_text, u
     const double t_a = now();
     // window of the match finder: 8 KiB of text behind a position (the rows of these tables repeat their neighbours, not text 30 KiB
     // back) keeps a wave's LDS at 35 KiB - four waves per CU
-    constexpr int WBITS = 13, HBITS = 12;
-    constexpr uint32_t HIST = 4096;                        // text in front of a segment that primes its window
+    const int wbits = [] { const char *e = getenv("PAV_GZ_WBITS"); const int v = e ? atoi(e) : 0; return v == 13 ? 13 : 12; }();
+    const uint32_t HIST = wbits == 13 ? 4096u : 3328u;     // text in front of a segment that primes its window (< the window's reach)
     std::vector<GzSegment> &segs = G->h_segs;
     segs.clear();
     std::vector<uint32_t> first(files.size() + 1, 0);
@@ -401,17 +418,22 @@ int gz_files(pav_ctx *ctx, void **slot, hipStream_t st, const uint8_t *d_text, u
     DeflateArgs A{};
     // how hard to look: chain steps per position, the length from which a match is taken without looking at the next position,
     // the length that ends a chain walk (zlib's max_chain / max_lazy / nice_length, scaled to what a lock-step wave can afford)
-    if (level <= 1) { A.chain = 4; A.lazy = 8; A.nice = 32; }
-    else if (level <= 3) { A.chain = 8; A.lazy = 16; A.nice = 64; }
-    else if (level <= 6) { A.chain = 16; A.lazy = 32; A.nice = 128; }
-    else { A.chain = 48; A.lazy = 258; A.nice = 258; }
+    // (measured on 200 MB of SNV rows / density rows, window 4 KiB, profiles/r05_gzip_variants.json: chain 4 / 8 / 16 / 32 =
+    //  12.2 / 10.0 / 7.5 / 5.1 GB/s at 0.982 / 0.968 / 0.952 / 0.927 of zlib level 6's size - every setting is below zlib-6)
+    if (level <= 3) { A.chain = 4; A.lazy = 16; A.nice = 64; A.good = 16; }
+    else if (level <= 6) { A.chain = 8; A.lazy = 32; A.nice = 128; A.good = 32; }
+    else { A.chain = 32; A.lazy = 258; A.nice = 258; A.good = 64; }
     if (const char *e = getenv("PAV_GZ_CHAIN")) A.chain = (uint32_t)std::max(1, atoi(e));
+    if (const char *e = getenv("PAV_GZ_NICE")) A.nice = (uint32_t)std::max(4, atoi(e));
 
     W_HIP(hipSetDevice(ctx->device));
-    if (!G->waves) {
+    if (!G->waves || G->waves_wbits != wbits) {
         int per_cu = 0;
-        W_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_deflate<WBITS, HBITS>, 64, 0));
+        if (wbits == 13) W_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_deflate<13, 12>, 64, 0));
+        else W_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_deflate<12, 11>, 64, 0));
         G->waves = std::max(1, per_cu) * std::max(1, ctx->n_cu);
+        G->waves_wbits = wbits;
+        if (timing) fprintf(stderr, "[pav timing] gz_files: window 2^%d bytes, %d waves per CU, %d CUs\n", wbits, per_cu, ctx->n_cu);
     }
     const uint32_t waves = std::min<uint32_t>((uint32_t)G->waves, n_segs);
     const uint32_t slot_bytes = GZ_SEGMENT + GZ_SEGMENT / 2 + 1024;      // a match can cost more bits than its bytes as literals
@@ -427,7 +449,8 @@ int gz_files(pav_ctx *ctx, void **slot, hipStream_t st, const uint8_t *d_text, u
     A.text = d_text; A.text_alloc = text_alloc; A.segs = G->segs.as<GzSegment>(); A.n_segs = n_segs; A.counter = G->counter.as<uint32_t>();
     A.tok = G->tok.as<uint32_t>(); A.tok_per_wave = GZ_SEGMENT; A.slots = G->slots.as<uint8_t>(); A.slot_bytes = slot_bytes;
     A.out = G->out.as<GzSegOut>();
-    W_LAUNCH(st, (k_deflate<WBITS, HBITS>), waves, 64, 0, A);
+    if (wbits == 13) W_LAUNCH(st, (k_deflate<13, 12>), waves, 64, 0, A);
+    else W_LAUNCH(st, (k_deflate<12, 11>), waves, 64, 0, A);
     W_LAUNCH(st, k_crc_segments, n_segs, 64, 0, d_text, G->segs.as<GzSegment>(), n_segs, G->out.as<GzSegOut>());
     W_HIP(hipMemcpyAsync(G->h_out, G->out.p, sizeof(GzSegOut) * n_segs, hipMemcpyDeviceToHost, st));
     W_HIP(hipStreamSynchronize(st));
@@ -480,22 +503,47 @@ using namespace pav;
 
 extern "C" {
 
-// gzip of a host buffer on the device (the table writers' compressor, for tests and for callers with text of their own):
-// uploads `text`, encodes it, returns the gzip member in `out` (*out_len bytes; PAV_E_LIMIT when out_cap is too small).
+// gzip of host buffers on the device (the table writers' compressor, for tests and for callers with text of their own): uploads
+// the n texts, encodes them in one launch set, returns the n gzip members one behind the other in `out` (out_off / out_len say
+// where; PAV_E_LIMIT when out_cap is too small: sum of the lengths x 1.5 + 4096 per text always suffices).
+int pav_gzip_buffers(pav_ctx *ctx, uint32_t n, const uint8_t *const *texts, const uint64_t *lens, int level, uint8_t *out, uint64_t out_cap,
+                     uint64_t *out_off, uint64_t *out_len) {
+    if (!ctx || (n && (!texts || !lens || !out || !out_off || !out_len))) return fail(ctx, PAV_E_ARG, "pav_gzip_buffers: null argument");
+    if (!n) return PAV_OK;
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->gz) ctx->gz = new GzState();
+    GzState *G = static_cast<GzState *>(ctx->gz);
+    std::vector<GzFile> files(n);
+    uint64_t at = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (lens[i] && !texts[i]) return fail(ctx, PAV_E_ARG, "pav_gzip_buffers: text %u is null", i);
+        at = (at + GZ_TEXT_ALIGN - 1) / GZ_TEXT_ALIGN * GZ_TEXT_ALIGN;
+        files[i] = GzFile{at, lens[i]};
+        at += lens[i];
+    }
+    const uint64_t alloc = (at + GZ_TEXT_PAD + 255) / 256 * 256;
+    PAV_HIP(ctx, G->text.reserve(alloc));
+    PAV_HIP(ctx, hipMemsetAsync(G->text.p, 0, alloc, ctx->stream));
+    for (uint32_t i = 0; i < n; ++i)
+        if (lens[i]) PAV_HIP(ctx, hipMemcpyAsync(G->text.as<uint8_t>() + files[i].text_off, texts[i], lens[i], hipMemcpyHostToDevice, ctx->stream));
+    GzOut g;
+    const int rc = gz_files(ctx, &ctx->gz, ctx->stream, G->text.as<uint8_t>(), alloc, files, level, g);
+    if (rc != PAV_OK) return fail(ctx, rc, "%s", pav_last_error(nullptr));
+    uint64_t o = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        out_off[i] = o; out_len[i] = g.len[i];
+        if (o + g.len[i] > out_cap) return fail(ctx, PAV_E_LIMIT, "pav_gzip_buffers: the output needs more than the %llu bytes given", (unsigned long long)out_cap);
+        memcpy(out + o, g.host + g.off[i], g.len[i]);
+        o += g.len[i];
+    }
+    return PAV_OK;
+}
+
 int pav_gzip_buffer(pav_ctx *ctx, const uint8_t *text, uint64_t n, int level, uint8_t *out, uint64_t out_cap, uint64_t *out_len) {
     if (!ctx || (n && !text) || !out || !out_len) return fail(ctx, PAV_E_ARG, "pav_gzip_buffer: null argument");
-    PAV_HIP(ctx, hipSetDevice(ctx->device));
-    const uint64_t alloc = (n + GZ_TEXT_PAD + 255) / 256 * 256;
-    PAV_HIP(ctx, ctx->d_tmp.reserve(alloc));
-    if (n) PAV_HIP(ctx, hipMemcpyAsync(ctx->d_tmp.p, text, n, hipMemcpyHostToDevice, ctx->stream));
-    PAV_HIP(ctx, hipMemsetAsync(ctx->d_tmp.as<uint8_t>() + n, 0, alloc - n, ctx->stream));
-    GzOut g;
-    const int rc = gz_files(ctx, &ctx->gz, ctx->stream, ctx->d_tmp.as<uint8_t>(), alloc, {GzFile{0, n}}, level, g);
-    if (rc != PAV_OK) return fail(ctx, rc, "%s", pav_last_error(nullptr));
-    *out_len = g.len[0];
-    if (g.len[0] > out_cap) return fail(ctx, PAV_E_LIMIT, "pav_gzip_buffer: %llu bytes of output, room for %llu", (unsigned long long)g.len[0], (unsigned long long)out_cap);
-    memcpy(out, g.host + g.off[0], g.len[0]);
-    return PAV_OK;
+    uint64_t off = 0;
+    const uint8_t *texts[1] = {text};
+    return pav_gzip_buffers(ctx, 1, texts, &n, level, out, out_cap, &off, out_len);
 }
 
 }  // extern "C"

@@ -47,15 +47,17 @@ PAV_DHD void dist_symbol(uint32_t dist, uint32_t &code, uint32_t &ebits, uint32_
 }
 
 // ---- Huffman code lengths ---------------------------------------------------------------------------------------------
-// Scratch of one tree (LDS on the device): n <= 288 symbols.
-struct HuffWork {
-    uint16_t order[288];             // used symbols, ascending by (count, symbol)
-    uint32_t weight[576];            // leaves in that order, then the internal nodes in the order they are made
-    uint16_t parent[576];
-    uint16_t depth[576];
+// Scratch of one tree (LDS on the device) for up to N symbols.
+template <int N> struct HuffWorkT {
+    uint16_t order[N];               // used symbols, ascending by (count, symbol)
+    uint32_t weight[2 * N];          // leaves in that order, then the internal nodes in the order they are made
+    uint16_t parent[2 * N];
+    uint16_t depth[2 * N];
     uint32_t bl_count[MAX_BITS + 2];
     uint32_t n_used;
 };
+using HuffWork = HuffWorkT<288>;     // the literal / length and distance trees
+using HuffWorkCl = HuffWorkT<20>;    // the code-length tree
 
 // Position of symbol s among the used symbols in (count, symbol) order - the caller runs this for every used symbol (one lane
 // each, or a loop) and stores order[rank] = s: a rank sort, n_used^2 compares spread over the lanes.
@@ -73,7 +75,7 @@ PAV_DHD uint32_t huff_rank(const uint32_t *freq, int n, int s) {
 // in ascending weight), depths top-down, then the length limit on the COUNTS per length - codes deeper than `limit` are folded
 // into it and the Kraft sum is paid back by lengthening the deepest shorter code, one step at a time - and the lengths are dealt
 // to the symbols from the rarest up.  One lane.  len[] of unused symbols = 0.
-PAV_DHD void huff_lengths(const uint32_t *freq, int n, int limit, uint8_t *len, HuffWork &W) {
+template <class Work> PAV_DHD void huff_lengths(const uint32_t *freq, int n, int limit, uint8_t *len, Work &W) {
     const int m = (int)W.n_used;
     for (int s = 0; s < n; ++s) len[s] = 0;
     if (m == 0) return;
@@ -179,7 +181,7 @@ struct HeaderWork {
     uint8_t cl_len[N_CL + 1];
     uint8_t all_len[N_LL + N_D + 4];
     ClItem items[N_LL + N_D + 4];
-    HuffWork tree;
+    HuffWorkCl tree;
 };
 
 // the order the lengths of the code-length code are sent in (3.2.7): 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15, five bits

@@ -9,15 +9,60 @@
 #include "fileio.h"
 
 #include <chrono>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <sys/mman.h>
+
+// Pool of gigabyte host buffers (fileio.h big_take / big_give): the text of a large plain file and the records of a FASTA file are
+// recycled instead of being mapped and unmapped per file.  At most four buffers wait here (two files' text + records: a rank
+// parses a contig file beside the reference's); PAV_FASTA_POOL=0: no pool (buffers are freed on a thread of their own).
+namespace pav {
+namespace {
+struct BigPool {
+    std::mutex mu;
+    static constexpr int N = 4;
+    struct Buf { uint8_t *p; uint64_t cap; } held[N] = {{nullptr, 0}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}};
+    static bool on() { static const bool v = [] { const char *e = getenv("PAV_FASTA_POOL"); return !(e && e[0] == '0'); }(); return v; }
+};
+BigPool g_big;
+}  // namespace
+
+uint8_t *big_take(uint64_t want, uint64_t &cap) {
+    std::lock_guard<std::mutex> g(g_big.mu);
+    int best = -1;
+    for (int i = 0; i < BigPool::N; ++i)
+        if (g_big.held[i].p && g_big.held[i].cap >= want && (best < 0 || g_big.held[i].cap < g_big.held[best].cap)) best = i;
+    if (best < 0) return nullptr;
+    uint8_t *p = g_big.held[best].p; cap = g_big.held[best].cap; g_big.held[best] = BigPool::Buf{nullptr, 0};
+    return p;
+}
+
+void big_give(uint8_t *p, uint64_t cap) {
+    if (!p) return;
+    uint8_t *drop = p;
+    if (BigPool::on()) {
+        std::lock_guard<std::mutex> g(g_big.mu);
+        int slot = -1;
+        for (int i = 0; i < BigPool::N; ++i) if (!g_big.held[i].p) { slot = i; break; }
+        if (slot < 0) {                                                  // full: the smallest one makes room if this one is larger
+            slot = 0;
+            for (int i = 1; i < BigPool::N; ++i) if (g_big.held[i].cap < g_big.held[slot].cap) slot = i;
+            if (g_big.held[slot].cap >= cap) slot = -1;
+        }
+        if (slot >= 0) { drop = g_big.held[slot].p; g_big.held[slot] = BigPool::Buf{p, cap}; }
+    }
+    if (drop) std::thread([drop] { free(drop); }).detach();              // (unmapping gigabytes takes 0.1 - 0.2 s: not on the caller's time)
+}
+}  // namespace pav
 
 struct pav_fasta {
     std::vector<std::string> names;
     std::vector<uint64_t> off, len;          // record i = seq[off[i], off[i] + len[i])
     uint8_t *seq = nullptr;
-    uint64_t bytes = 0;
+    uint64_t bytes = 0, cap = 0;
     int kind = 0;                            // 0 plain, 1 gzip (one stream), 2 BGZF (blocks inflated in parallel)
-    ~pav_fasta() { free(seq); }
+    ~pav_fasta() { pav::big_give(seq, cap); }
 };
 
 using namespace pav;
@@ -32,7 +77,9 @@ int pav_fasta_open(const char *path, int threads, pav_fasta **out) {
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_mark = now();
     auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "[pav timing] fasta %-10s %.3f s (%s)\n", what, t - t_mark, path); t_mark = t; } };
-    FileText ft;
+    // (the mapping of the file is let go on a thread of its own when the records have been copied: see the end)
+    std::unique_ptr<FileText> ftp(new FileText());
+    FileText &ft = *ftp;
     std::string err;
     if (!read_file_text(path, threads, ft, err)) return fail(nullptr, PAV_E_ARG, "pav_fasta_open: %s", err.c_str());
     lap("read");
@@ -104,8 +151,12 @@ int pav_fasta_open(const char *path, int threads, pav_fasta **out) {
     {   // 2 MiB alignment + MADV_HUGEPAGE: the copy pass below touches every page of a fresh 3 GB buffer for the first time - with
         // 4 KiB pages that is 760 k page faults per genome, and they, not the copying, were most of the pass (0.52 s of 0.75 s)
         const uint64_t want = (std::max<uint64_t>(total, 1) + (2ull << 20) - 1) & ~((2ull << 20) - 1);
-        fa->seq = static_cast<uint8_t *>(aligned_alloc(2ull << 20, want));
-        if (fa->seq) (void)madvise(fa->seq, want, MADV_HUGEPAGE);
+        fa->seq = big_take(want, fa->cap);
+        if (!fa->seq) {
+            fa->seq = static_cast<uint8_t *>(aligned_alloc(2ull << 20, want));
+            fa->cap = want;
+            if (fa->seq) (void)madvise(fa->seq, want, MADV_HUGEPAGE);
+        }
     }
     if (!fa->seq) { delete fa; return fail(nullptr, PAV_E_ARG, "pav_fasta_open: out of memory (%llu sequence bytes)", (unsigned long long)total); }
     parallel_for(pieces.size(), threads, [&](size_t i) {
@@ -127,6 +178,8 @@ int pav_fasta_open(const char *path, int threads, pav_fasta **out) {
         }
     });
     lap("copy");
+    ftp.reset();                                             // the text goes back to the pool (a mapped file: unmapped)
+    lap("release");
     *out = fa;
     return PAV_OK;
 }
@@ -136,7 +189,12 @@ const char *pav_fasta_name(const pav_fasta *fa, uint32_t i) { return fa && i < f
 uint64_t pav_fasta_length(const pav_fasta *fa, uint32_t i) { return fa && i < fa->len.size() ? fa->len[i] : 0; }
 const uint8_t *pav_fasta_seq(const pav_fasta *fa, uint32_t i) { return fa && i < fa->off.size() ? fa->seq + fa->off[i] : nullptr; }
 int pav_fasta_kind(const pav_fasta *fa) { return fa ? fa->kind : -1; }
-void pav_fasta_close(pav_fasta *fa) { delete fa; }
+void pav_fasta_close(pav_fasta *fa) {
+    const bool timing = getenv("PAV_TIMING") != nullptr;
+    const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    delete fa;
+    if (timing) fprintf(stderr, "[pav timing] fasta close      %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0);
+}
 
 int pav_seq_load_fasta(pav_ctx *ctx, int role, const pav_fasta *fa, uint32_t n, const uint32_t *records) {
     if (!ctx || !fa || (n && !records)) return fail(ctx, PAV_E_ARG, "pav_seq_load_fasta: null argument");

@@ -481,9 +481,27 @@ def call_haplotype(bed, bed_trim, tig_fa_name, ref_fa_name, asm_name, hap, out_d
         from . import fasta as pavfasta
         th = threading.Thread(target=pavfasta.open_fasta, args=(tig_fa_name,))
         th.start()
-        table, trim_table = _lib.BedTable(bed, with_cigar=True), _lib.BedTable(bed_trim, with_cigar=True)
+        # ... and so are the two alignment tables (one gzip stream each: 0.12 s of inflate apiece, serial by nature), each on a
+        # thread of its own beside the FASTA parsers
+        opened, open_err = {}, []
+
+        def open_table(key, path):
+            try:
+                opened[key] = _lib.BedTable(path, with_cigar=True)
+            except BaseException as ex:                                                   # noqa: BLE001 - raised again on this thread
+                open_err.append(ex)
+        tab_threads = [threading.Thread(target=open_table, args=(k, f)) for k, f in (('bed', bed), ('trim', bed_trim))]
+        for t in tab_threads:
+            t.start()
+        try:
+            cigarcall.load_reference(ctx, ref_fa_name)
+        finally:
+            for t in tab_threads:
+                t.join()
+            table, trim_table = opened.get('bed'), opened.get('trim')
+        if open_err:
+            raise open_err[0]
         cols = table.fetch()
-        cigarcall.load_reference(ctx, ref_fa_name)
         th.join()
         cigarcall.load_sequences(ctx, ref_fa_name, tig_fa_name)                        # every contig record: the scan may lift anywhere
         ctx._inv_loaded = (str(ref_fa_name), str(tig_fa_name))
@@ -580,6 +598,7 @@ def call_haplotype(bed, bed_trim, tig_fa_name, ref_fa_name, asm_name, hap, out_d
             table_writer = threading.Thread(target=write_density)
             table_writer.start()
         try:
+            batch_texts = []
             for b in range(batch_count):
                 rows_b, keep_b = kept[b]
                 call_list = []
@@ -599,12 +618,17 @@ def call_haplotype(bed, bed_trim, tig_fa_name, ref_fa_name, asm_name, hap, out_d
                     df_bed = pd.concat(call_list, axis=1).T.sort_values(['#CHROM', 'POS', 'END', 'ID'])   # :297
                 else:
                     df_bed = pd.DataFrame([], columns=[c for c in INV_BED_COLUMNS if c != 'FILTER'])       # :300-308 (sic)
-                # (the per-batch tables are temporary files, read back by the merge below: the SEQ column - whole inversions - is most
-                #  of their bytes and deflate level 9, pandas' default, most of their time; level 1 here)
-                df_bed.to_csv(P['inv_batch'][b], sep='\t', index=False, compression={'method': 'gzip', 'compresslevel': 1})
+                # (the per-batch tables are temporary files, read back by the merge rule: here their TEXT is kept, gzip'd on the device
+                #  - all sixty in one launch set - and parsed back from memory by the merge, the same bytes pd.read_csv would inflate)
+                batch_texts.append(df_bed.to_csv(None, sep='\t', index=False).encode())
                 n_calls += len(call_list)
+            for path, gz in zip(P['inv_batch'], ctx.gzip_buffers(batch_texts, 1)):
+                with open(path, 'wb') as fh:
+                    fh.write(gz)
             lap('INV batch tables + logs')
-            df_inv = call_inv_batch_merge(P['inv_batch'], P['inv'], gzip_level=gzip_level or 6)
+            df_inv = call_inv_batch_merge([io.BytesIO(t) for t in batch_texts], None)
+            with open(P['inv'], 'wb') as fh:                                              # rule call_inv_batch_merge's to_csv, gzip on the device
+                fh.write(ctx.gzip_buffer(df_inv.to_csv(None, sep='\t', index=False).encode(), gzip_level or 6))
             lap('INV merge')
         finally:
             if table_writer is not None:
