@@ -608,15 +608,21 @@ def main():
                 inv_tables = {'calls': len(calls), 'rows': int(sum(ctx.inv_table_view(i, c.native_table[2])[1].shape[0] for i, c in calls)),
                               'write_density_tables_gzip_s': round(t_den_gz, 3), 'write_density_tables_plain_s': round(t_den_plain, 3),
                               'text_bytes': sum(os.path.getsize(os.path.join(den_dir, f)) for f in os.listdir(den_dir) if f.endswith('.tsv')),
-                              'note': 'pav_inv_write_tables: pandas-identical text from the host copies of the call tables, parallel '
-                                      'gzip members; DataFrame.to_csv needs ~7 us per row plain, ~19 us gzip\'d (measured, 300 k rows)'}
+                              'gzip_bytes': sum(os.path.getsize(os.path.join(den_dir, f)) for f in os.listdir(den_dir) if f.endswith('.tsv.gz')),
+                              'writer': os.environ.get('PAV_WRITER', 'device'),
+                              'note': 'pav_inv_write_tables: pandas-identical text formatted and gzip\'d in HBM from the resident column blocks '
+                                      '(textdev.hip, deflate.hip); only the files\' bytes cross PCIe; PAV_WRITER=host: host threads + zlib.  '
+                                      'DataFrame.to_csv needs ~7 us per row plain, ~19 us gzip\'d (measured, 300 k rows)'}
             e2e = {'rows': n1 + n2, 'write_tables_gzip_s': round(t_gz, 3), 'write_tables_plain_s': round(t_plain, 3),
                    'inv_density_tables': inv_tables,
                    'read_align_table_s': {'parse_gzip_tsv': round(t_parse, 3), 'load_to_device': round(t_load, 3),
                                           'bytes': os.path.getsize(bed_path)},
                    'text_bytes': os.path.getsize(os.path.join(tmp_out, 'snv.bed')) + os.path.getsize(os.path.join(tmp_out, 'insdel.bed')),
-                   'note': 'pav_cigar_write_tables: device sort + FILTER, native TSV text (byte-identical to pandas), parallel gzip '
-                           'members; the pandas mirror needs ~13 us per row, the reference ~410 us per row (BASELINE.md)'}
+                   'gzip_bytes': os.path.getsize(os.path.join(tmp_out, 'snv.bed.gz')) + os.path.getsize(os.path.join(tmp_out, 'insdel.bed.gz')),
+                   'writer': os.environ.get('PAV_WRITER', 'device'),
+                   'note': 'pav_cigar_write_tables: order + FILTER, TSV text (byte-identical to pandas) and gzip (one member per file) all on '
+                           'the device (textdev.hip, deflate.hip: 64 KiB of text per wave); PAV_WRITER=host: host threads + zlib; the pandas '
+                           'mirror needs ~13 us per row, the reference ~410 us per row (BASELINE.md)'}
         finally:
             shutil.rmtree(tmp_out, ignore_errors=True)
 

@@ -230,6 +230,8 @@ class _GpuTurn:
 def run_rank(rank, world, jobs, out_dir, ref_fa, config=None, engine_factory=None, split=False, share_gpu=False):
     """The work of one rank (the process group, if any, is up).  Returns this rank's manifests: one per whole haplotype it ran,
     one per shared haplotype it leads."""
+    import time
+    t_rank = time.time()
     config = dict(config or {})
     batch_count = int(config.get('inv_sig_batch_count', 60))
     items = plan(jobs, world, split)
@@ -291,6 +293,13 @@ def run_rank(rank, world, jobs, out_dir, ref_fa, config=None, engine_factory=Non
             for name, fn in (('call_cigar batches', stage1), ('call_cigar_merge + flagging', stage2),
                              ('call_inv_batch batches', stage3), ('call_inv_batch_merge', stage4)):
                 _stage(world, rank, name, fn, True)
+        # every manifest says which GPU its rank drove and how long the rank worked (a scaling line shows N distinct devices)
+        dev = getattr(engine, 'ctx', None)
+        info = {'rank_wall_s': round(time.time() - t_rank, 3), 'rank_cores': shard.effective_cpus(),
+                'device_name': getattr(dev, 'device_name', '') if dev is not None else '',
+                'pci_bus_id': getattr(dev, 'pci_bus_id', '') if dev is not None else ''}
+        for m in manifests:
+            m.update(info)
     finally:
         engine.close()
     return manifests

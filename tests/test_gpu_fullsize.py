@@ -216,6 +216,77 @@ def test_full_size_inversion_calls_vs_the_oracle_driven_scan(built, gpu_ctx):
           f'({min(len(r) for r, _ in pairs)} - {max(len(r) for r, _ in pairs)} bp) equal the oracle row by row')
 
 
+def test_full_size_loci_vs_the_reference_itself(built, gpu_ctx, monkeypatch):
+    """Loci of the bench haplotype on which the REFERENCE was run (tests/golden/fullsize_loci: pavlib.inv.scan_for_inv ->
+    scripts/density.py -> scipy, unmodified, on the haplotype's own 3 GB FASTA files and its complete alignment table -
+    tools/refharness/gen_golden_fullsize_loci.py): the ten calls with the largest discovery regions (two scan rounds, up to 479
+    kbp), loci of every kind of ending the scan has on this haplotype, the loci with the most rounds, the smallest calls.  The
+    native driver's log text, calls (id, the six regions with their alignment indices, the INV BED row incl. SEQ) and final
+    density tables (INDEX / STATE_MER / STATE digests, FLANK, KERN_* sums to 1e-9) must be the reference's."""
+    import hashlib
+    import io
+    import json
+    import os
+    from pav_amd import rules
+    from pav_amd.kmer import KmerUtil
+    gold_path = os.path.join(util.GOLD, 'fullsize_loci', 'scans.json')
+    with open(gold_path) as fh:
+        gold = json.load(fh)
+    ctx = gpu_ctx
+    full = fullsize(ctx)
+    hap = full['hap']
+    regions = pavinv.loci_regions(ctx, full['loci'])
+    assert len(regions) == gold['n_loci_of_the_haplotype']
+    ctx._inv_loaded = full['fa']
+    logs = [io.StringIO() for _ in regions]
+    out = pavinv.scan_for_inv_batch(regions, full['fa'][0], full['fa'][1], full['lift'], KmerUtil(31), logs=logs, ctx=ctx, native=True,
+                                    eager_tables=False, found_out=io.StringIO())
+    sha = lambda a: hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()   # noqa: E731
+    from pav_amd import seq as pavseq
+    monkeypatch.setattr(pavseq, 'open_fasta', lambda path: hap.tig_seqs)          # the SEQ column: the haplotype is in memory, not in a file
+
+    def rg(d):
+        return None if d is None else (d['chrom'], d['pos'], d['end'], d['is_rev'], d['pos_aln_index'], d['end_aln_index'])
+
+    def ours(r):
+        aln = lambda x: None if x is None else [[int(w) for w in v] if isinstance(v, (tuple, list)) else int(v) for v in x]   # noqa: E731
+        return (r.chrom, int(r.pos), int(r.end), bool(r.is_rev), aln(r.pos_aln_index), aln(r.end_aln_index))
+    n_calls = 0
+    for rec in gold['scans']:
+        i = rec['region']
+        f = rec['flag']
+        assert (regions[i].chrom, int(regions[i].pos), int(regions[i].end)) == (f['chrom'], f['pos'], f['end']), i
+        assert logs[i].getvalue().splitlines() == rec['log'], (i, rec['why'])
+        c = out[i]
+        if rec['error'] is not None:
+            assert isinstance(c, RuntimeError) and str(c) == rec['error'], i
+            continue
+        if rec['call'] is None:
+            assert c is None, (i, rec['why'])
+            continue
+        want = rec['call']
+        assert c is not None and not isinstance(c, RuntimeError), (i, rec['why'])
+        n_calls += 1
+        assert (c.id, int(c.svlen)) == (want['id'], want['svlen'])
+        for nm in ('region_ref_outer', 'region_ref_inner', 'region_tig_outer', 'region_tig_inner', 'region_ref_discovery', 'region_tig_discovery'):
+            assert ours(getattr(c, nm)) == rg(want[nm]), (c.id, nm)
+        df = c.df
+        assert df.shape[0] == want['n_rows'], c.id
+        assert sha(df['INDEX'].to_numpy(dtype=np.int64)) == want['index_sha1'], c.id
+        assert sha(df['STATE_MER'].to_numpy(dtype=np.int8)) == want['state_mer_sha1'], c.id
+        assert sha(df['STATE'].to_numpy(dtype=np.int8)) == want['state_sha1'], c.id
+        assert hashlib.sha1('\n'.join(df['FLANK'].tolist()).encode()).hexdigest() == want['flank_sha1'], c.id
+        for col, v in zip(('KERN_FWD', 'KERN_FWDREV', 'KERN_REV'), want['kern_sum']):
+            assert np.isclose(float(df[col].sum()), v, rtol=1e-9, atol=1e-300), (c.id, col)
+        row = rules.inv_bed_row(c, hap.hap, 'RGN', full['fa'][1])
+        bed = {k2: (int(v) if isinstance(v, (int, np.integer)) else v) for k2, v in row.items()}
+        seq = bed.pop('SEQ')
+        assert (hashlib.sha1(seq.encode()).hexdigest(), len(seq)) == (want['bed_row']['SEQ_sha1'], want['bed_row']['SEQ_len']), c.id
+        for k2, v in bed.items():
+            assert want['bed_row'][k2] == v, (c.id, k2)
+    assert n_calls >= 15 and len(gold['scans']) >= 20
+
+
 def test_chm13_cohort_batch_of_eight_full_size(built, gpu_ctx):
     """BASELINE configs[4] at its real size: a T2T-CHM13-shaped reference (24 sequences, CHM13v2.0
     lengths, 3.1 Gbp, no N runs) packed ONCE, eight haplotypes of the cohort resident against it at the same time (one

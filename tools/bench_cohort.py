@@ -27,6 +27,8 @@ def main():
     ap.add_argument('--share-gpu', action='store_true', help='all ranks on GPU 0 (see above: a correctness device, not a fast one)')
     ap.add_argument('--seed', type=int, default=1004)
     ap.add_argument('--lanes', type=int, nargs='+', default=[1, 4], help="haplotypes a rank calls at the same time (config 'pav_amd_lanes'); one run per value")
+    ap.add_argument('--gpus', type=int, default=0, help='ONE run on this many GPUs (one rank each, --lanes[0] lanes per rank) and ONE JSON line in the '
+                                                       "schema of bench.py: metric haplotypes/s files to files, per-rank wall time, device and cores")
     args = ap.parse_args()
     import __graft_entry__ as g
     g.build_cpu_side()
@@ -60,6 +62,26 @@ def main():
         t_inputs = time.time() - t0
         out = {}
         cfg = {'inv_sig_filter': 'single_cluster'}
+        if args.gpus > 0:
+            lanes = args.lanes[0]
+            t0 = time.time()
+            ms = cohort.run_cohort(jobs, args.gpus, os.path.join(work, 'out'), os.path.join(work, 'in', 'ref.fa'),
+                                   config=dict(cfg, pav_amd_lanes=lanes), share_gpu=args.share_gpu, timeout=3600)
+            dt = time.time() - t0
+            per_rank = {}
+            for m in ms:
+                r = per_rank.setdefault(m['rank'], {'rank': m['rank'], 'haplotypes': 0, 'wall_s': m.get('rank_wall_s'), 'device_name': m.get('device_name'),
+                                                    'pci_bus_id': m.get('pci_bus_id'), 'usable_cores': m.get('rank_cores')})
+                r['haplotypes'] += 1
+            print(json.dumps({'metric': 'haplotypes/s, files to files (pav_amd.rules.run_cohort: FASTA + alignment tables in, every table of the rule chain out)',
+                              'value': round(len(jobs) / dt, 3), 'unit': 'haplotypes/s', 'n_gpus': args.gpus, 'steps': len(jobs), 'warmup': 0,
+                              'ms_per_step': round(dt / len(jobs) * 1e3, 1), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+                              'dtype': 'u8/u32 + f64', 'data': 'synthetic',
+                              'aligned_Gbp_per_s': round(aligned / dt / 1e9, 3), 'wall_s': round(dt, 2), 'per_rank': [per_rank[k] for k in sorted(per_rank)],
+                              'config': {'workload': f'{args.haplotypes} synthetic haplotypes of one hg38-shaped reference, scale {args.scale}, seed {args.seed}',
+                                         'lanes_per_rank': lanes, 'gzip_level': 6, 'writer': os.environ.get('PAV_WRITER', 'device'),
+                                         'inputs_written_s': round(t_inputs, 1), 'includes_process_start': args.gpus > 1}}))
+            return
         import torch
         n_dev = torch.cuda.device_count()                      # (counting devices does not initialise the GPU in this process)
         ranks = args.ranks or n_dev

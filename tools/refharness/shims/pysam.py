@@ -11,7 +11,19 @@ class FastaFile:
     _cache = {}
 
     def __init__(self, path):
+        import os
         self.path = str(path)
+        self._fai = None
+        # a large plain file with an index beside it (the full-size haplotype of gen_golden_fullsize_loci.py: 3 GB per file) is
+        # read by seeking, as pysam itself does; everything else is held in memory
+        if not self.path.endswith('.gz') and os.path.exists(self.path + '.fai') and os.path.getsize(self.path) > (256 << 20):
+            self._fai = {}
+            with open(self.path + '.fai') as fh:
+                for line in fh:
+                    f = line.rstrip('\n').split('\t')
+                    self._fai[f[0]] = (int(f[1]), int(f[2]), int(f[3]), int(f[4]))
+            self._seqs = self._fai
+            return
         if self.path not in FastaFile._cache:
             FastaFile._cache[self.path] = self._read(self.path)
         self._seqs = FastaFile._cache[self.path]
@@ -38,6 +50,17 @@ class FastaFile:
         return list(self._seqs)
 
     def fetch(self, reference=None, start=None, end=None):
+        if self._fai is not None:
+            length, offset, line_bases, line_width = self._fai[str(reference)]
+            a = 0 if start is None else max(0, int(start))
+            b = length if end is None else min(length, int(end))
+            if b <= a:
+                return ''
+            with open(self.path, 'rb') as fh:
+                fh.seek(offset + a + (a // line_bases) * (line_width - line_bases))
+                first = b - 1
+                n_bytes = (first + (first // line_bases) * (line_width - line_bases)) - (a + (a // line_bases) * (line_width - line_bases)) + 1
+                return fh.read(n_bytes).replace(b'\n', b'').decode()
         seq = self._seqs[str(reference)]
         if start is None and end is None:
             return seq
