@@ -14,6 +14,26 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+class StderrCapture:
+    """The library's PAV_TIMING lines (C stdio on fd 2) of the calls made inside the block."""
+
+    def __enter__(self):
+        import tempfile
+        sys.stderr.flush()
+        self.tmp = tempfile.TemporaryFile()
+        self.saved = os.dup(2)
+        os.dup2(self.tmp.fileno(), 2)
+        return self
+
+    def __exit__(self, *exc):
+        os.dup2(self.saved, 2)
+        os.close(self.saved)
+        self.tmp.seek(0)
+        self.text = self.tmp.read().decode(errors='replace')
+        self.tmp.close()
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--mb', type=int, default=200)
@@ -41,6 +61,7 @@ def main():
                   for i, (a, b, m) in enumerate(zip(k[:, 0].tolist(), k[:, 1].tolist(), kmer.tolist()))).encode()
     print(f'[bench_gzip] texts made in {time.time() - t0:.1f} s: snv {len(snv) / 1e6:.1f} MB, density {len(den) / 1e6:.1f} MB', file=sys.stderr)
     out = {}
+    os.environ['PAV_TIMING'] = '1'
     with _lib.Context(0) as ctx:
         for name, text in (('snv', snv), ('density', den)):
             sample = text[:20_000_000]
@@ -51,14 +72,19 @@ def main():
                 wb, ch = v.split(':')
                 os.environ['PAV_GZ_WBITS'], os.environ['PAV_GZ_CHAIN'] = wb, ch
                 ctx.gzip_buffer(buf[:1_000_000], 6)
-                best, size = 1e9, 0
+                best, size, kern = 1e9, 0, 1e9
                 for _ in range(3):
-                    t0 = time.perf_counter()
-                    gz = ctx.gzip_buffer(buf, 6)
-                    best = min(best, time.perf_counter() - t0)
+                    with StderrCapture() as cap:
+                        t0 = time.perf_counter()
+                        gz = ctx.gzip_buffer(buf, 6)
+                        best = min(best, time.perf_counter() - t0)
                     size = len(gz)
+                    for ln in cap.text.splitlines():                     # "[pav timing] gz_files: ...; deflate + crc 21.7 ms (10.0 GB/s), ..."
+                        if 'deflate + crc' in ln:
+                            kern = min(kern, float(ln.split('deflate + crc')[1].split('ms')[0]))
                 assert zlib.decompress(gz, 31) == text
-                res['variants'][v] = {'ms_incl_pcie': round(best * 1e3, 1), 'gb_per_s_incl_pcie': round(len(text) / best / 1e9, 2),
+                res['variants'][v] = {'deflate_plus_crc_ms': kern, 'gb_per_s': round(len(text) / (kern * 1e-3) / 1e9, 2),
+                                      'ms_incl_pcie_from_pageable_memory': round(best * 1e3, 1),
                                       'ratio': round(size / len(text), 4), 'vs_zlib6': round(size / len(text) / z6, 3)}
             out[name] = res
     print(json.dumps(out, indent=1))
