@@ -95,6 +95,20 @@ const uint8_t *pav_fasta_seq(const pav_fasta *fa, uint32_t record);     /* valid
 int pav_fasta_kind(const pav_fasta *fa);                                 /* 0 plain text, 1 gzip stream, 2 BGZF      */
 /* pav_seq_load + pav_seq_set_names of the chosen records, in the order given. */
 int pav_seq_load_fasta(pav_ctx *ctx, int role, const pav_fasta *fa, uint32_t n_records, const uint32_t *records);
+/* Every record of a FASTA file (plain, gzip, BGZF) into the store of `role`, names set - WITHOUT the host-side parse: the file's text
+ * crosses PCIe as it is (a plain file is read in parallel pieces straight into pinned memory; compressed ones are inflated first) and
+ * loses its header lines and line breaks on the device (fastadev.hip).  Same arena bytes as pav_fasta_open + pav_seq_load_fasta of all
+ * records; *n_records = their number.  The two roles of one context may be loaded from two threads at the same time.
+ * Replaces pysam.FastaFile(fa).fetch(name) of whole records (pavlib/cigarcall.py:59-66, pavlib/seq.py:339-351). */
+int pav_seq_load_fasta_path(pav_ctx *ctx, int role, const char *path, int threads, uint32_t *n_records);
+/* ASCII bytes [pos, pos + n) of record `rec` as they stand in the store (case preserved, forward strand): what
+ * pysam.FastaFile.fetch(name, pos, pos + n) returns for a resident record (pavlib/seq.py:339-351, the SEQ column of rule
+ * call_inv_batch, rules/call_inv.snakefile:203-282). */
+int pav_seq_fetch(pav_ctx *ctx, int role, uint32_t rec, uint64_t pos, uint64_t n, uint8_t *out);
+/* n slices in one round trip: slice i = [pos[i], pos[i] + len[i]) of record rec[i], at out + len[0] + ... + len[i - 1]. */
+int pav_seq_fetch_many(pav_ctx *ctx, int role, uint32_t n, const uint32_t *rec, const uint64_t *pos, const uint64_t *len, uint8_t *out);
+const char *pav_seq_name(const pav_ctx *ctx, int role, uint32_t i);      /* NULL: no such record / no names set */
+uint64_t pav_seq_length(const pav_ctx *ctx, int role, uint32_t i);
 /* The resident ASCII of `role` has changed (or a new haplotype's pass begins): its planes are stale.  PAV_ROLE_TIG with one
  * user: marks them so - readers fill what they need (pav_seq_load above).  PAV_ROLE_REF, a shared store, or PAV_EAGER_PACK=1:
  * re-runs the pack kernel over the whole arena, asynchronously on a side stream - it overlaps whatever the next calls queue

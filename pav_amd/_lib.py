@@ -181,6 +181,11 @@ SYMBOLS = {
     'pav_destroy': (None, [_P]),
     'pav_last_error': (ctypes.c_char_p, [_P]),
     'pav_device_name': (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int]),
+    'pav_seq_load_fasta_path': (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32)]),
+    'pav_seq_fetch': (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]),
+    'pav_seq_fetch_many': (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    'pav_seq_name': (ctypes.c_char_p, [_P, ctypes.c_int, ctypes.c_uint32]),
+    'pav_seq_length': (ctypes.c_uint64, [_P, ctypes.c_int, ctypes.c_uint32]),
     'pav_gzip_buffer': (ctypes.c_int, [_P, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64,
                                        ctypes.POINTER(ctypes.c_uint64)]),
     'pav_gzip_buffers': (ctypes.c_int, [_P, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.c_int,
@@ -477,6 +482,40 @@ class Context:
         if role == PAV_ROLE_REF:
             self._ref_resident = None
         self._seq_names[role] = [fasta.names[int(i)] for i in rec]
+
+    def seq_load_fasta_path(self, role, path, threads=0):
+        """Every record of the FASTA file ``path`` into the store of ``role`` without a host-side parse (``pav_seq_load_fasta_path``:
+        the text is uploaded as it is, header lines and line breaks are removed on the device).  Returns the record names."""
+        n = ctypes.c_uint32(0)
+        self._check(self.lib.pav_seq_load_fasta_path(self.handle, role, str(path).encode(), int(threads), ctypes.byref(n)), 'pav_seq_load_fasta_path')
+        if role == PAV_ROLE_REF:
+            self._ref_resident = None
+        self._seq_names[role] = [self.lib.pav_seq_name(self.handle, role, i).decode() for i in range(int(n.value))]
+        return self._seq_names[role]
+
+    def seq_lengths(self, role):
+        return [int(self.lib.pav_seq_length(self.handle, role, i)) for i in range(len(self._seq_names[role]))]
+
+    def seq_fetch(self, role, rec, pos, end):
+        """ASCII bytes [pos, end) of resident record number ``rec`` (uint8 array; forward strand, case preserved)."""
+        n = max(0, int(end) - int(pos))
+        out = np.empty(n, dtype=np.uint8)
+        self._check(self.lib.pav_seq_fetch(self.handle, role, int(rec), int(pos), n, out.ctypes.data if n else None), 'pav_seq_fetch')
+        return out
+
+    def seq_fetch_many(self, role, slices):
+        """``slices``: (record number, pos, end) triples -> list of uint8 arrays, one round trip for all of them."""
+        n = len(slices)
+        if n == 0:
+            return []
+        rec = np.ascontiguousarray([x[0] for x in slices], dtype=np.uint32)
+        pos = np.ascontiguousarray([x[1] for x in slices], dtype=np.uint64)
+        ln = np.ascontiguousarray([max(0, int(x[2]) - int(x[1])) for x in slices], dtype=np.uint64)
+        out = np.empty(int(ln.sum()), dtype=np.uint8)
+        self._check(self.lib.pav_seq_fetch_many(self.handle, role, n, _ptr(rec), _ptr(pos), _ptr(ln), out.ctypes.data if out.shape[0] else None),
+                    'pav_seq_fetch_many')
+        ends = np.cumsum(ln)
+        return [out[int(e - k):int(e)] for e, k in zip(ends, ln)]
 
     def seq_pack(self, role):
         self._check(self.lib.pav_seq_pack(self.handle, role), 'pav_seq_pack')

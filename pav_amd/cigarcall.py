@@ -70,16 +70,28 @@ def load_reference(ctx, ref_fa_name):
     reference, ``pav_amd.cohort``; the packed planes of an hg38-sized reference are 4.3 GB and 0.3 s of work per upload)."""
     key = _file_key(ref_fa_name)
     if getattr(ctx, '_ref_resident', None) != key:
-        ref_fa = open_fasta(ref_fa_name)
-        ctx.seq_load_fasta(_lib.PAV_ROLE_REF, ref_fa.native, ref_fa.record_numbers(ref_fa.names))
+        if device_fasta():
+            ctx.seq_load_fasta_path(_lib.PAV_ROLE_REF, ref_fa_name)      # text up as it is, header lines and line breaks removed on the device
+        else:
+            ref_fa = open_fasta(ref_fa_name)
+            ctx.seq_load_fasta(_lib.PAV_ROLE_REF, ref_fa.native, ref_fa.record_numbers(ref_fa.names))
         ctx._ref_resident = key
     return ctx.seq_names(_lib.PAV_ROLE_REF)
+
+
+def device_fasta():
+    """Whole FASTA files go to the device without a host-side parse (``pav_seq_load_fasta_path``) unless ``PAV_FASTA_DEVICE=0``."""
+    import os
+    return os.environ.get('PAV_FASTA_DEVICE', '1') != '0'
 
 
 def load_sequences(ctx, ref_fa_name, tig_fa_name, df_align=None, names=None):
     """Upload the records the alignment table touches (all records when ``df_align`` is None); ``names`` gives the two
     sets of record names directly.  A reference made resident by :func:`load_reference` stays (records are found by name)."""
     keep_ref = getattr(ctx, '_ref_resident', None) is not None and ctx._ref_resident == _file_key(ref_fa_name)
+    all_records = names is None and not (df_align is not None and df_align.shape[0])
+    if keep_ref and all_records and device_fasta():
+        return list(ctx.seq_names(_lib.PAV_ROLE_REF)), list(ctx.seq_load_fasta_path(_lib.PAV_ROLE_TIG, tig_fa_name))
     if keep_ref:
         tig_fa = open_fasta(tig_fa_name)
         resident = ctx.seq_names(_lib.PAV_ROLE_REF)

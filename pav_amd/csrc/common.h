@@ -169,7 +169,8 @@ struct pav_ctx {
     void *trim = nullptr;                 // alignment trimming state (trim.cpp)
     void *table_writer = nullptr;         // a table write in two halves (tables.hip: pav_cigar_write_tables_begin / _end)
     hipEvent_t writer_ready = nullptr;    // recorded behind the calls when a device table write begins (tables.hip)
-    void *upload = nullptr;               // pinned staging ring of the large host-to-device uploads (ctx.hip: staged_upload)
+    void *upload = nullptr;               // pinned staging rings of the large host-to-device uploads (ctx.hip: staged_upload)
+    void *fa_dev = nullptr;               // device FASTA loader scratch (fastadev.hip)
     void *gz = nullptr;                   // device gzip scratch (deflate.hip)
     void *textdev = nullptr;              // device table text scratch (textdev.hip)
 

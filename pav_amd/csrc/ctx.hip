@@ -2,6 +2,7 @@
 // gfx950 only; public ABI in include/pav_amd.h.
 #include "common.h"
 #include "devgz.h"
+#include "upload.h"
 #include "textdev.h"
 #include <algorithm>
 #include <atomic>
@@ -235,41 +236,31 @@ using namespace pav;
 
 namespace pav {
 
-// Large uploads from pageable host memory (a FASTA file's records: 3 GB per store).  hipMemcpyAsync from pageable memory is staged
-// by the runtime on one thread (10 - 13 GB/s measured: 0.2 s per store, most of the "sequences" stage of a haplotype); here the
-// bytes go through a ring of pinned slots filled by several threads while the slots before them cross PCIe.
-struct UploadRing {
-    static constexpr int SLOTS = 4;
-    static constexpr size_t SLOT_BYTES = 32u << 20;
-    void *slot[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
-    bool busy[SLOTS] = {false, false, false, false};
-    int next = 0;
-    bool ok = false;
-};
+struct UploadRings { UploadRing r[2]; };               // one per role: the two stores of a context may be loaded side by side
 
-static UploadRing *upload_ring(pav_ctx *ctx) {
-    if (ctx->upload) return static_cast<UploadRing *>(ctx->upload);
-    auto *R = new UploadRing();
+UploadRing *upload_ring(pav_ctx *ctx, int which) {
+    if (!ctx->upload) ctx->upload = new UploadRings();
+    UploadRing *R = &static_cast<UploadRings *>(ctx->upload)->r[which & 1];
+    if (R->slot[0] || R->ok) return R;
     R->ok = true;
     for (int i = 0; i < UploadRing::SLOTS && R->ok; ++i)
         R->ok = hipHostMalloc(&R->slot[i], UploadRing::SLOT_BYTES, hipHostMallocDefault) == hipSuccess &&
                 hipEventCreateWithFlags(&R->ev[i], hipEventDisableTiming) == hipSuccess;
-    ctx->upload = R;
     return R;
 }
 
 void upload_release(pav_ctx *ctx) {
     if (!ctx || !ctx->upload) return;
-    auto *R = static_cast<UploadRing *>(ctx->upload);
-    for (int i = 0; i < UploadRing::SLOTS; ++i) { if (R->slot[i]) (void)hipHostFree(R->slot[i]); if (R->ev[i]) (void)hipEventDestroy(R->ev[i]); }
-    delete R;
+    auto *P = static_cast<UploadRings *>(ctx->upload);
+    for (UploadRing &R : P->r)
+        for (int i = 0; i < UploadRing::SLOTS; ++i) { if (R.slot[i]) (void)hipHostFree(R.slot[i]); if (R.ev[i]) (void)hipEventDestroy(R.ev[i]); }
+    delete P;
     ctx->upload = nullptr;
 }
 
 // dst[0, bytes) on the device <- src (pageable), queued on `st`; returns when every byte has left `src` (not when it has arrived)
-static int staged_upload(pav_ctx *ctx, hipStream_t st, uint8_t *dst, const uint8_t *src, uint64_t bytes) {
-    UploadRing *R = upload_ring(ctx);
+int staged_upload(pav_ctx *ctx, hipStream_t st, uint8_t *dst, const uint8_t *src, uint64_t bytes, int which) {
+    UploadRing *R = upload_ring(ctx, which);
     static const int threads = [] { const char *e = getenv("PAV_UPLOAD_THREADS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 8; }();
     if (!R->ok || bytes < (4u << 20) || threads <= 1) {
         PAV_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
@@ -293,6 +284,73 @@ static int staged_upload(pav_ctx *ctx, hipStream_t st, uint8_t *dst, const uint8
         PAV_HIP(ctx, hipEventRecord(R->ev[k], st));
         R->busy[k] = true;
     }
+    return PAV_OK;
+}
+
+}  // namespace pav
+
+namespace pav {
+
+// The records of one role into its store: layout (every record on a 256-base boundary, one pad block behind it), buffers, the
+// arena filled with 'N', then `fill(arena, off)` queues whatever brings the ASCII bytes of record i to arena + off[i] on the
+// context's stream (pav_seq_load: uploads from host arrays; pav_seq_load_fasta_path: a strip kernel over the file's raw text),
+// then offsets, lengths, the pack of a reference, and the wait.
+int seq_store_load(pav_ctx *ctx, int role, uint32_t n_seq, const uint64_t *len, const char *what,
+                   const std::function<int(uint8_t *, const std::vector<uint64_t> &)> &fill) {
+    // lengths are checked and the layout is planned before the store is touched: a refused call leaves it as it was
+    std::vector<uint64_t> off(n_seq, 0);
+    uint64_t a = 0, total = 0;
+    for (uint32_t i = 0; i < n_seq; ++i) {
+        if (len[i] >= 0xFFFFFF00ull)
+            return fail(ctx, PAV_E_LIMIT, "%s: record %u has %llu bases (limit 2^32 - 256)", what, i, (unsigned long long)len[i]);
+        off[i] = a;
+        a += (len[i] + SEQ_ALIGN - 1) / SEQ_ALIGN * SEQ_ALIGN + SEQ_ALIGN;   // one pad block between records
+        total += len[i];
+    }
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    { const int rch = wait_homology(ctx); if (rch != PAV_OK) return rch; }     // the scans of the last call read the arenas
+    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream2));   // a re-pack of the old arena may still be running
+    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pack_pending[role] = false;
+    if (ctx->seq.p[role].use_count() > 1) ctx->seq.p[role] = std::make_shared<SeqStore>();   // other contexts keep the shared one
+    SeqStore &s = ctx->seq[role];
+    s.device = ctx->device;
+    // from here on the old content is gone: results and tables that refer to it are invalid, and so is the store until the
+    // uploads and the pack have succeeded
+    ctx->cigar_called = false;
+    s.n = 0; s.arena = s.total = 0;
+    s.off.clear(); s.len.clear();
+    struct Guard {                                   // any early return below leaves an empty store and no loaded table
+        pav_ctx *c; bool armed = true;
+        ~Guard() { if (armed) c->cigar_loaded = false; }
+    } guard{ctx};
+    if (a == 0) { guard.armed = false; s.n = n_seq; s.off = off; s.len.assign(len, len + n_seq); return PAV_OK; }
+    const bool timing = getenv("PAV_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_a = now();
+    PAV_HIP(ctx, s.d_ascii.reserve(a));
+    PAV_HIP(ctx, s.d_two.reserve(a / 4));
+    PAV_HIP(ctx, s.d_mask.reserve(a / 8));
+    PAV_HIP(ctx, s.d_dirty.reserve((a / 16 + 256 * PACK_U - 1) / (256 * PACK_U) * 16 + 16));   // 16 summary bytes per pack workgroup (+ slack: verify_kernel reads pairs)
+    PAV_HIP(ctx, s.d_off.reserve(sizeof(uint64_t) * n_seq));
+    PAV_HIP(ctx, s.d_len.reserve(sizeof(uint64_t) * n_seq));
+    const double t_b = now();
+    PAV_HIP(ctx, hipMemsetAsync(s.d_ascii.p, 'N', a, ctx->stream));          // padding reads as non-ACGT
+    { const int rcf = fill(s.d_ascii.as<uint8_t>(), off); if (rcf != PAV_OK) return rcf; }
+    PAV_HIP(ctx, hipMemcpyAsync(s.d_off.p, off.data(), sizeof(uint64_t) * n_seq, hipMemcpyHostToDevice, ctx->stream));
+    PAV_HIP(ctx, hipMemcpyAsync(s.d_len.p, len, sizeof(uint64_t) * n_seq, hipMemcpyHostToDevice, ctx->stream));
+    const double t_c = now();
+    s.n = n_seq; s.arena = a; s.total = total;                               // run_pack reads the layout from the store
+    s.off = off; s.len.assign(len, len + n_seq);
+    // contigs: planes on demand ("lazy contig pack" above); the reference is packed now
+    s.planes_full = false;
+    int rc = (role == PAV_ROLE_REF || eager_pack()) ? run_pack(ctx, s, ctx->stream) : PAV_OK;
+    if (rc == PAV_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)     // inputs are borrowed only for the duration of the call
+        rc = fail(ctx, PAV_E_HIP, "%s: upload / pack failed", what);
+    if (rc != PAV_OK) { s.n = 0; s.arena = s.total = 0; s.off.clear(); s.len.clear(); return rc; }
+    if (timing) fprintf(stderr, "[pav timing] %s role %d: %.2f GB; device buffers %.1f ms, fill queued in %.1f ms (%.1f GB/s), pack + drain %.1f ms\n", what, role,
+                        (double)total / 1e9, (t_b - t_a) * 1e3, (t_c - t_b) * 1e3, (double)total / 1e9 / std::max(1e-9, t_c - t_b), (now() - t_c) * 1e3);
+    guard.armed = false;
     return PAV_OK;
 }
 
@@ -396,6 +454,7 @@ void pav_destroy(pav_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     table_writer_release(ctx);
     pav::upload_release(ctx);
+    pav::fastadev_release(ctx);
     pav::gz_release(ctx);
     pav::textdev_release(ctx);
     pav_density_release(ctx);
@@ -455,66 +514,14 @@ int pav_sync(pav_ctx *ctx) {
 int pav_seq_load(pav_ctx *ctx, int role, uint32_t n_seq, const uint8_t *const *ascii, const uint64_t *len) {
     if (!ctx || (role != PAV_ROLE_REF && role != PAV_ROLE_TIG)) return fail(ctx, PAV_E_ARG, "pav_seq_load: bad role");
     if (n_seq && (!ascii || !len)) return fail(ctx, PAV_E_ARG, "pav_seq_load: null input");
-    // lengths are checked and the layout is planned before the store is touched: a refused call leaves it as it was
-    std::vector<uint64_t> off(n_seq, 0);
-    uint64_t a = 0, total = 0;
-    for (uint32_t i = 0; i < n_seq; ++i) {
-        if (len[i] >= 0xFFFFFF00ull)
-            return fail(ctx, PAV_E_LIMIT, "pav_seq_load: record %u has %llu bases (limit 2^32 - 256)", i,
-                        (unsigned long long)len[i]);
-        off[i] = a;
-        a += (len[i] + SEQ_ALIGN - 1) / SEQ_ALIGN * SEQ_ALIGN + SEQ_ALIGN;   // one pad block between records
-        total += len[i];
-    }
-    PAV_HIP(ctx, hipSetDevice(ctx->device));
-    { const int rch = wait_homology(ctx); if (rch != PAV_OK) return rch; }     // the scans of the last call read the arenas
-    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream2));   // a re-pack of the old arena may still be running
-    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->pack_pending[role] = false;
-    if (ctx->seq.p[role].use_count() > 1) ctx->seq.p[role] = std::make_shared<SeqStore>();   // other contexts keep the shared one
-    SeqStore &s = ctx->seq[role];
-    s.device = ctx->device;
-    // from here on the old content is gone: results and tables that refer to it are invalid, and so is the store until the
-    // uploads and the pack have succeeded
-    ctx->cigar_called = false;
-    s.n = 0; s.arena = s.total = 0;
-    s.off.clear(); s.len.clear();
-    struct Guard {                                   // any early return below leaves an empty store and no loaded table
-        pav_ctx *c; bool armed = true;
-        ~Guard() { if (armed) c->cigar_loaded = false; }
-    } guard{ctx};
-    if (a == 0) { guard.armed = false; s.n = n_seq; s.off = off; s.len.assign(len, len + n_seq); return PAV_OK; }
-    const bool timing = getenv("PAV_TIMING") != nullptr;
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t_a = now();
-    PAV_HIP(ctx, s.d_ascii.reserve(a));
-    PAV_HIP(ctx, s.d_two.reserve(a / 4));
-    PAV_HIP(ctx, s.d_mask.reserve(a / 8));
-    PAV_HIP(ctx, s.d_dirty.reserve((a / 16 + 256 * PACK_U - 1) / (256 * PACK_U) * 16 + 16));   // 16 summary bytes per pack workgroup (+ slack: verify_kernel reads pairs)
-    PAV_HIP(ctx, s.d_off.reserve(sizeof(uint64_t) * n_seq));
-    PAV_HIP(ctx, s.d_len.reserve(sizeof(uint64_t) * n_seq));
-    const double t_b = now();
-    PAV_HIP(ctx, hipMemsetAsync(s.d_ascii.p, 'N', a, ctx->stream));          // padding reads as non-ACGT
-    for (uint32_t i = 0; i < n_seq; ++i)
-        if (len[i]) {
-            const int rcu = staged_upload(ctx, ctx->stream, s.d_ascii.as<uint8_t>() + off[i], ascii[i], len[i]);
-            if (rcu != PAV_OK) return rcu;
-        }
-    PAV_HIP(ctx, hipMemcpyAsync(s.d_off.p, off.data(), sizeof(uint64_t) * n_seq, hipMemcpyHostToDevice, ctx->stream));
-    PAV_HIP(ctx, hipMemcpyAsync(s.d_len.p, len, sizeof(uint64_t) * n_seq, hipMemcpyHostToDevice, ctx->stream));
-    const double t_c = now();
-    s.n = n_seq; s.arena = a; s.total = total;                               // run_pack reads the layout from the store
-    s.off = off; s.len.assign(len, len + n_seq);
-    // contigs: planes on demand ("lazy contig pack" above); the reference is packed now
-    s.planes_full = false;
-    int rc = (role == PAV_ROLE_REF || eager_pack()) ? run_pack(ctx, s, ctx->stream) : PAV_OK;
-    if (rc == PAV_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)     // inputs are borrowed only for the duration of the call
-        rc = fail(ctx, PAV_E_HIP, "pav_seq_load: upload / pack failed");
-    if (rc != PAV_OK) { s.n = 0; s.arena = s.total = 0; s.off.clear(); s.len.clear(); return rc; }
-    if (timing) fprintf(stderr, "[pav timing] seq_load role %d: %.2f GB; device buffers %.1f ms, staging + queueing %.1f ms (%.1f GB/s), pack + drain %.1f ms\n", role,
-                        (double)total / 1e9, (t_b - t_a) * 1e3, (t_c - t_b) * 1e3, (double)total / 1e9 / std::max(1e-9, t_c - t_b), (now() - t_c) * 1e3);
-    guard.armed = false;
-    return PAV_OK;
+    return pav::seq_store_load(ctx, role, n_seq, len, "pav_seq_load", [&](uint8_t *arena, const std::vector<uint64_t> &off) {
+        for (uint32_t i = 0; i < n_seq; ++i)
+            if (len[i]) {
+                const int rcu = pav::staged_upload(ctx, ctx->stream, arena + off[i], ascii[i], len[i], role);
+                if (rcu != PAV_OK) return rcu;
+            }
+        return (int)PAV_OK;
+    });
 }
 
 int pav_seq_share(pav_ctx *ctx, const pav_ctx *from, int role) {

@@ -1,0 +1,343 @@
+// A FASTA file straight into a context's sequence store: the file's text crosses PCIe as it is and loses its header lines and
+// line breaks ON THE DEVICE.  What this replaces is pysam.FastaFile(...).fetch(name) of whole records (pavlib/cigarcall.py:59-66,
+// pavlib/seq.py:339-351) - and, inside this library, pav_fasta_open + pav_seq_load_fasta (fastaio.cpp): five host passes over a
+// 3 GB file (read, find records, count line breaks, copy without them, stage for the upload), 1.9 CPU-seconds per file - most of
+// the 0.43 s "sequences" stage of a haplotype on a box whose process may use sixteen cores.  Here the host reads the file once, in
+// parallel pieces, into the pinned slots of the upload ring (compressed files: inflated first, as before), and the device
+//   k_fa_marks    counts the line-break bytes of every 256-byte tile and lists the '>' that start a line,
+//   k_fa_hdr_end  finds where each header line ends,
+//   (prefix sum of the tile counts: scan_dev.h)
+//   k_fa_records  turns every record's body [start, end) into its number of kept bytes,
+//   k_fa_strip    moves every kept byte to its place in the arena: its record's offset + its distance from the body's start
+//                 - the line breaks between the two (tile prefix + a ballot inside the tile).
+// The host sees the header list (a few thousand entries), reads the names from the file, lays the records out as pav_seq_load
+// does (seq_store_load) and sets the names.  Same bytes in the arena as the host parser produces (tests/test_gpu_fasta.py).
+#include "common.h"
+#include "fileio.h"
+#include "scan_dev.h"
+#include "upload.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <thread>
+
+namespace pav {
+
+int pav_seq_set_names_internal(pav_ctx *ctx, int role, const std::vector<std::string> &names);   // invscan.cpp
+
+namespace {
+
+constexpr uint32_t FA_TILE = 256;
+
+struct FaRec { uint64_t body, body_end, breaks_before, arena_off; };     // breaks_before: line-break bytes in raw[0, body)
+
+__device__ __forceinline__ bool is_break(uint8_t c) { return c == '\n' || c == '\r'; }
+
+__global__ __launch_bounds__(256) void k_fa_marks(const uint8_t *__restrict__ raw, uint64_t n, uint32_t *__restrict__ tile_cnt,
+                                                  uint64_t *__restrict__ hdr_pos, uint32_t *__restrict__ n_hdr, uint32_t hdr_cap) {
+    __shared__ uint32_t s_w[4];
+    const uint64_t x = (uint64_t)blockIdx.x * FA_TILE + threadIdx.x;
+    const uint8_t c = x < n ? raw[x] : (uint8_t)'A';
+    const uint32_t w = (uint32_t)__popcll(__ballot(x < n && is_break(c)));
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = w;
+    if (x < n && c == '>' && (x == 0 || raw[x - 1] == '\n')) {
+        const uint32_t at = atomicAdd(n_hdr, 1u);
+        if (at < hdr_cap) hdr_pos[at] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// hdr[i] = start of a header line ('>'); end[i] = position of the '\n' that ends it (n when the file ends first)
+__global__ __launch_bounds__(64) void k_fa_hdr_end(const uint8_t *__restrict__ raw, uint64_t n, const uint64_t *__restrict__ hdr, uint32_t n_hdr,
+                                                   uint64_t *__restrict__ end) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_hdr) return;
+    uint64_t p = hdr[i];
+    while (p < n && raw[p] != '\n') ++p;
+    end[i] = p;
+}
+
+// line-break bytes in raw[0, x): the prefix of x's tile + the ones in the tile before x
+__device__ __forceinline__ uint64_t breaks_before(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ tile_pre, uint64_t x) {
+    const uint64_t t0 = x / FA_TILE * FA_TILE;
+    uint64_t b = tile_pre[x / FA_TILE];
+    for (uint64_t p = t0; p < x; ++p) b += is_break(raw[p]) ? 1u : 0u;
+    return b;
+}
+
+__global__ __launch_bounds__(64) void k_fa_records(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ tile_pre, FaRec *__restrict__ rec,
+                                                   uint32_t n_rec, uint64_t *__restrict__ kept) {
+    const uint32_t r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= n_rec) return;
+    const uint64_t a = rec[r].body, b = rec[r].body_end;
+    const uint64_t ba = breaks_before(raw, tile_pre, a), bb = breaks_before(raw, tile_pre, b);
+    rec[r].breaks_before = ba;
+    kept[r] = (b - a) - (bb - ba);
+}
+
+__global__ __launch_bounds__(256) void k_fa_strip(const uint8_t *__restrict__ raw, uint64_t n, const uint64_t *__restrict__ tile_pre,
+                                                  const FaRec *__restrict__ rec, uint32_t n_rec, uint8_t *__restrict__ arena) {
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_rec;
+    const uint64_t t0 = (uint64_t)blockIdx.x * FA_TILE, x = t0 + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint8_t c = x < n ? raw[x] : (uint8_t)'\n';
+    const bool brk = is_break(c);
+    const unsigned long long m = __ballot(brk);
+    if (lane == 0) s_w[wave] = (uint32_t)__popcll(m);
+    if (threadIdx.x == 0) {                              // last record whose body starts at or before the tile's first byte
+        uint32_t lo = 0, hi = n_rec;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (rec[mid].body <= t0) lo = mid; else hi = mid; }
+        s_rec = lo;
+    }
+    __syncthreads();
+    if (x >= n || brk || n_rec == 0) return;
+    uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    for (uint32_t w = 0; w < wave; ++w) before += s_w[w];
+    uint32_t r = s_rec;
+    while (r + 1 < n_rec && rec[r + 1].body <= x) ++r;  // a tile holds the end of one record and the start of the next at most a few times
+    const FaRec R = rec[r];
+    if (x < R.body || x >= R.body_end) return;           // header lines, the bytes in front of the first record
+    const uint64_t brk_x = tile_pre[blockIdx.x] + before;
+    arena[R.arena_off + (x - R.body) - (brk_x - R.breaks_before)] = c;
+}
+
+struct FaDev {
+    DevBuf raw, tile_cnt, tile_pre, bsum, hdr, hdr_end, rec, kept, counter;
+    void *pin = nullptr; size_t pin_cap = 0;
+};
+
+struct FaDevPair { FaDev role[2]; };                     // one scratch per role: the two stores of a context may be loaded side by side
+
+FaDev *fstate(pav_ctx *ctx, int role) {
+    if (!ctx->fa_dev) ctx->fa_dev = new FaDevPair();
+    return &static_cast<FaDevPair *>(ctx->fa_dev)->role[role];
+}
+
+double wall() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// the whole file -> d_raw, through the pinned ring: `threads` readers fill a slot, the slot crosses PCIe while the next is filled
+int stream_file(pav_ctx *ctx, int role, int fd, uint64_t n, uint8_t *d_raw, int threads) {
+    UploadRing *R = upload_ring(ctx, role);
+    if (!R->ok) return fail(ctx, PAV_E_HIP, "pav_seq_load_fasta_path: no pinned memory for the upload ring");
+    // PAV_FA_MMAP=1: the pieces are copied out of a mapping of the file instead of being read (a page fault per 4 KiB and an munmap of
+    // the whole file - on a thread of its own - against the kernel's copy_to_user)
+    const uint8_t *map = nullptr;
+    if (const char *e = getenv("PAV_FA_MMAP")) if (e[0] == '1' && n) {
+        void *p = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (p != MAP_FAILED) map = static_cast<const uint8_t *>(p);
+    }
+    struct Unmap { const uint8_t *p; uint64_t n; ~Unmap() { if (p) { const uint8_t *q = p; const uint64_t m = n; std::thread([q, m] { munmap(const_cast<uint8_t *>(q), m); }).detach(); } } } unmap{map, n};
+    for (uint64_t at = 0; at < n; at += UploadRing::SLOT_BYTES) {
+        const uint64_t m = std::min<uint64_t>(UploadRing::SLOT_BYTES, n - at);
+        const int k = R->next; R->next = (k + 1) % UploadRing::SLOTS;
+        if (R->busy[k]) { PAV_HIP(ctx, hipEventSynchronize(R->ev[k])); R->busy[k] = false; }
+        uint8_t *stage = static_cast<uint8_t *>(R->slot[k]);
+        const int use = m >= (4u << 20) ? threads : 1;
+        const uint64_t piece = ((m + (uint64_t)use - 1) / (uint64_t)use + 4095) & ~4095ull;
+        std::atomic<int> bad{0};
+        auto read_piece = [&](uint64_t a, uint64_t b) {
+            if (map) { memcpy(stage + a, map + at + a, b - a); return; }
+            while (a < b) {
+                const ssize_t got = pread(fd, stage + a, b - a, (off_t)(at + a));
+                if (got <= 0) { bad = 1; return; }
+                a += (uint64_t)got;
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < use; ++t) {
+            const uint64_t a = std::min<uint64_t>(m, piece * (uint64_t)t), b = std::min<uint64_t>(m, a + piece);
+            if (b > a) pool.emplace_back(read_piece, a, b);
+        }
+        read_piece(0, std::min<uint64_t>(m, piece));
+        for (auto &th : pool) th.join();
+        if (bad) return fail(ctx, PAV_E_ARG, "pav_seq_load_fasta_path: read error");
+        PAV_HIP(ctx, hipMemcpyAsync(d_raw + at, stage, m, hipMemcpyHostToDevice, ctx->stream));
+        PAV_HIP(ctx, hipEventRecord(R->ev[k], ctx->stream));
+        R->busy[k] = true;
+    }
+    return PAV_OK;
+}
+
+}  // namespace
+
+void fastadev_release(pav_ctx *ctx) {
+    if (!ctx || !ctx->fa_dev) return;
+    FaDevPair *P = static_cast<FaDevPair *>(ctx->fa_dev);
+    for (FaDev &X : P->role) {
+        FaDev *F = &X;
+        for (DevBuf *b : {&F->raw, &F->tile_cnt, &F->tile_pre, &F->bsum, &F->hdr, &F->hdr_end, &F->rec, &F->kept, &F->counter}) b->release();
+        if (F->pin) (void)hipHostFree(F->pin);
+    }
+    delete P;
+    ctx->fa_dev = nullptr;
+}
+
+}  // namespace pav
+
+using namespace pav;
+
+extern "C" {
+
+int pav_seq_load_fasta_path(pav_ctx *ctx, int role, const char *path, int threads, uint32_t *n_records) {
+    if (!ctx || !path || (role != PAV_ROLE_REF && role != PAV_ROLE_TIG)) return fail(ctx, PAV_E_ARG, "pav_seq_load_fasta_path: bad argument");
+    if (threads <= 0) threads = std::min(8, default_host_threads());
+    const bool timing = getenv("PAV_TIMING") != nullptr;
+    const double t0 = wall();
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    FaDev *F = fstate(ctx, role);
+    hipStream_t st = ctx->stream;
+    // ---- the text of the file into HBM --------------------------------------------------------------------------------
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(ctx, PAV_E_ARG, "pav_seq_load_fasta_path: cannot open %s", path);
+    struct FdGuard { int fd; ~FdGuard() { if (fd >= 0) close(fd); } } fdg{fd};
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) return fail(ctx, PAV_E_ARG, "pav_seq_load_fasta_path: cannot stat %s", path);
+    uint8_t magic[2] = {0, 0};
+    const bool compressed = pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+    FileText ft;                                             // compressed files: inflated on the host first (BGZF: in parallel)
+    uint64_t n = (uint64_t)sb.st_size;
+    if (compressed) {
+        std::string err;
+        if (!read_file_text(path, default_host_threads(), ft, err)) return fail(ctx, PAV_E_ARG, "pav_seq_load_fasta_path: %s", err.c_str());
+        n = ft.n;
+    }
+    // the previous load's kernels have run (seq_store_load waits), so the scratch can be reused
+    PAV_HIP(ctx, hipStreamSynchronize(st));
+    const uint32_t n_tiles = (uint32_t)((n + FA_TILE - 1) / FA_TILE);
+    const uint32_t hdr_cap = 1u << 22;
+    PAV_HIP(ctx, F->raw.reserve(n + 4096));
+    PAV_HIP(ctx, F->tile_cnt.reserve(4ull * (n_tiles + 8)));
+    PAV_HIP(ctx, F->tile_pre.reserve(8ull * (n_tiles + 8)));
+    PAV_HIP(ctx, F->bsum.reserve(8ull * (n_tiles / SCAN_TILE + 8)));
+    PAV_HIP(ctx, F->hdr.reserve(8ull * hdr_cap));
+    PAV_HIP(ctx, F->counter.reserve(64));
+    if (!F->pin) { PAV_HIP(ctx, hipHostMalloc(&F->pin, 1 << 20, hipHostMallocDefault)); F->pin_cap = 1 << 20; }
+    if (compressed) { const int rc = staged_upload(ctx, st, F->raw.as<uint8_t>(), ft.text, n, role); if (rc != PAV_OK) return rc; }
+    else { const int rc = stream_file(ctx, role, fd, n, F->raw.as<uint8_t>(), threads); if (rc != PAV_OK) return rc; }
+    const double t1 = wall();
+    // ---- records ------------------------------------------------------------------------------------------------------
+    PAV_HIP(ctx, hipMemsetAsync(F->counter.p, 0, 64, st));
+    if (n_tiles) PAV_LAUNCH(ctx, "k_fa_marks", k_fa_marks, n_tiles, 256, 0, F->raw.as<uint8_t>(), n, F->tile_cnt.as<uint32_t>(), F->hdr.as<uint64_t>(),
+                            F->counter.as<uint32_t>(), hdr_cap);
+    { const int rc = scan_u32_to_u64(st, F->tile_cnt.as<uint32_t>(), n_tiles, F->bsum.as<uint64_t>(), F->tile_pre.as<uint64_t>());
+      if (rc != PAV_OK) return fail(ctx, rc, "%s", pav_last_error(nullptr)); }
+    uint32_t *h_n = static_cast<uint32_t *>(F->pin);
+    PAV_HIP(ctx, hipMemcpyAsync(h_n, F->counter.p, 4, hipMemcpyDeviceToHost, st));
+    PAV_HIP(ctx, hipStreamSynchronize(st));
+    const uint32_t n_hdr = *h_n;
+    if (n_hdr > hdr_cap) return fail(ctx, PAV_E_LIMIT, "pav_seq_load_fasta_path: %u records in %s (limit %u)", n_hdr, path, hdr_cap);
+    std::vector<uint64_t> hdr(n_hdr), hend(n_hdr);
+    if (n_hdr) {
+        PAV_HIP(ctx, F->hdr_end.reserve(8ull * n_hdr));
+        // (the list is in the order the workgroups met the headers: sorted here, then their ends are looked up in file order)
+        PAV_HIP(ctx, hipMemcpy(hdr.data(), F->hdr.p, 8ull * n_hdr, hipMemcpyDeviceToHost));
+        std::sort(hdr.begin(), hdr.end());
+        PAV_HIP(ctx, hipMemcpyAsync(F->hdr.p, hdr.data(), 8ull * n_hdr, hipMemcpyHostToDevice, st));
+        PAV_LAUNCH(ctx, "k_fa_hdr_end", k_fa_hdr_end, (n_hdr + 63) / 64, 64, 0, F->raw.as<uint8_t>(), n, F->hdr.as<uint64_t>(), n_hdr, F->hdr_end.as<uint64_t>());
+        PAV_HIP(ctx, hipMemcpyAsync(hend.data(), F->hdr_end.p, 8ull * n_hdr, hipMemcpyDeviceToHost, st));
+        PAV_HIP(ctx, hipStreamSynchronize(st));
+    }
+    // names: the first whitespace-delimited word of the header line, read from the file (or the inflated text)
+    std::vector<std::string> names(n_hdr);
+    std::vector<FaRec> rec(n_hdr);
+    std::vector<uint8_t> line;
+    for (uint32_t i = 0; i < n_hdr; ++i) {
+        const uint64_t a = hdr[i] + 1, b = hend[i];
+        line.resize((size_t)(b > a ? b - a : 0));
+        if (!line.empty()) {
+            if (compressed) memcpy(line.data(), ft.text + a, line.size());
+            else if (pread(fd, line.data(), line.size(), (off_t)a) != (ssize_t)line.size()) return fail(ctx, PAV_E_ARG, "pav_seq_load_fasta_path: read error in %s", path);
+        }
+        size_t p = 0, q;
+        while (p < line.size() && (line[p] == ' ' || line[p] == '\t' || line[p] == '\r')) ++p;
+        for (q = p; q < line.size() && line[q] != ' ' && line[q] != '\t' && line[q] != '\r'; ++q) {}
+        names[i].assign(reinterpret_cast<const char *>(line.data()) + p, q - p);
+        rec[i].body = std::min<uint64_t>(hend[i] + 1, n);
+        rec[i].body_end = i + 1 < n_hdr ? hdr[i + 1] : n;
+        rec[i].breaks_before = 0; rec[i].arena_off = 0;
+    }
+    std::vector<uint64_t> kept(n_hdr, 0);
+    if (n_hdr) {
+        PAV_HIP(ctx, F->rec.reserve(sizeof(FaRec) * n_hdr));
+        PAV_HIP(ctx, F->kept.reserve(8ull * n_hdr));
+        PAV_HIP(ctx, hipMemcpyAsync(F->rec.p, rec.data(), sizeof(FaRec) * n_hdr, hipMemcpyHostToDevice, st));
+        PAV_LAUNCH(ctx, "k_fa_records", k_fa_records, (n_hdr + 63) / 64, 64, 0, F->raw.as<uint8_t>(), F->tile_pre.as<uint64_t>(), F->rec.as<FaRec>(), n_hdr,
+                   F->kept.as<uint64_t>());
+        PAV_HIP(ctx, hipMemcpyAsync(kept.data(), F->kept.p, 8ull * n_hdr, hipMemcpyDeviceToHost, st));
+        PAV_HIP(ctx, hipStreamSynchronize(st));
+    }
+    const double t2 = wall();
+    // ---- the records into the store: the layout of pav_seq_load, the bytes by the strip kernel -----------------------------------
+    const int rc = seq_store_load(ctx, role, n_hdr, kept.data(), "pav_seq_load_fasta_path", [&](uint8_t *arena, const std::vector<uint64_t> &off) {
+        if (!n_hdr) return (int)PAV_OK;
+        // arena offsets into the device records (breaks_before was written there by k_fa_records: only this column goes up)
+        std::vector<FaRec> up(n_hdr);
+        PAV_HIP(ctx, hipMemcpy(up.data(), F->rec.p, sizeof(FaRec) * n_hdr, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n_hdr; ++i) up[i].arena_off = off[i];
+        PAV_HIP(ctx, hipMemcpy(F->rec.p, up.data(), sizeof(FaRec) * n_hdr, hipMemcpyHostToDevice));
+        PAV_LAUNCH(ctx, "k_fa_strip", k_fa_strip, n_tiles, 256, 0, F->raw.as<uint8_t>(), n, F->tile_pre.as<uint64_t>(), F->rec.as<FaRec>(), n_hdr, arena);
+        return (int)PAV_OK;
+    });
+    if (rc != PAV_OK) return rc;
+    const int rcn = pav_seq_set_names_internal(ctx, role, names);
+    if (rcn != PAV_OK) return rcn;
+    if (n_records) *n_records = n_hdr;
+    if (timing) fprintf(stderr, "[pav timing] seq_load_fasta_path role %d: %.2f GB of text; file -> HBM %.1f ms (%.1f GB/s), records %.1f ms, store %.1f ms (%s)\n", role,
+                        (double)n / 1e9, (t1 - t0) * 1e3, (double)n / 1e9 / std::max(1e-9, t1 - t0), (t2 - t1) * 1e3, (wall() - t2) * 1e3, path);
+    return PAV_OK;
+}
+
+// ASCII bytes [pos, pos + n) of record `rec` as they stand in the store (case preserved, forward strand): a device-to-host copy
+int pav_seq_fetch(pav_ctx *ctx, int role, uint32_t rec, uint64_t pos, uint64_t n, uint8_t *out) {
+    if (!ctx || (role != PAV_ROLE_REF && role != PAV_ROLE_TIG) || (n && !out)) return fail(ctx, PAV_E_ARG, "pav_seq_fetch: bad argument");
+    const SeqStore &s = ctx->seq[role];
+    if (rec >= s.n) return fail(ctx, PAV_E_ARG, "pav_seq_fetch: record %u of %u", rec, s.n);
+    if (pos > s.len[rec] || n > s.len[rec] - pos) return fail(ctx, PAV_E_ARG, "pav_seq_fetch: [%llu, +%llu) is outside the record's %llu bases",
+                                                                (unsigned long long)pos, (unsigned long long)n, (unsigned long long)s.len[rec]);
+    if (!n) return PAV_OK;
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    PAV_HIP(ctx, hipMemcpy(out, s.d_ascii.as<uint8_t>() + s.off[rec] + pos, n, hipMemcpyDeviceToHost));
+    return PAV_OK;
+}
+
+// n slices at once: slice i = [pos[i], pos[i] + len[i]) of record rec[i], written to out + (sum of len[0 .. i)).  The copies are queued
+// on the context's copy stream into pinned memory and waited for once (the SEQ columns of a haplotype's INV calls: a hundred slices).
+int pav_seq_fetch_many(pav_ctx *ctx, int role, uint32_t n, const uint32_t *rec, const uint64_t *pos, const uint64_t *len, uint8_t *out) {
+    if (!ctx || (role != PAV_ROLE_REF && role != PAV_ROLE_TIG) || (n && (!rec || !pos || !len || !out))) return fail(ctx, PAV_E_ARG, "pav_seq_fetch_many: bad argument");
+    const SeqStore &s = ctx->seq[role];
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (rec[i] >= s.n || pos[i] > s.len[rec[i]] || len[i] > s.len[rec[i]] - pos[i]) return fail(ctx, PAV_E_ARG, "pav_seq_fetch_many: slice %u is outside its record", i);
+        total += len[i];
+    }
+    if (!total) return PAV_OK;
+    PAV_HIP(ctx, hipSetDevice(ctx->device));
+    FaDev *F = fstate(ctx, role);
+    if (F->pin_cap < total) {
+        if (F->pin) (void)hipHostFree(F->pin);
+        F->pin = nullptr; F->pin_cap = 0;
+        PAV_HIP(ctx, hipHostMalloc(&F->pin, total + total / 4 + (1 << 20), hipHostMallocDefault));
+        F->pin_cap = total + total / 4 + (1 << 20);
+    }
+    uint8_t *stage = static_cast<uint8_t *>(F->pin);
+    uint64_t at = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (len[i]) PAV_HIP(ctx, hipMemcpyAsync(stage + at, s.d_ascii.as<uint8_t>() + s.off[rec[i]] + pos[i], len[i], hipMemcpyDeviceToHost, ctx->stream3));
+        at += len[i];
+    }
+    PAV_HIP(ctx, hipStreamSynchronize(ctx->stream3));
+    memcpy(out, stage, total);
+    return PAV_OK;
+}
+
+const char *pav_seq_name(const pav_ctx *ctx, int role, uint32_t i);       // invscan.cpp (the names live with the scan driver's state)
+
+uint64_t pav_seq_length(const pav_ctx *ctx, int role, uint32_t i) {
+    if (!ctx || (role != PAV_ROLE_REF && role != PAV_ROLE_TIG) || i >= ctx->seq[role].n) return 0;
+    return ctx->seq[role].len[i];
+}
+
+}  // extern "C"

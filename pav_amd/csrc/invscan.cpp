@@ -446,6 +446,7 @@ public:
 };
 
 const std::vector<std::string> &seq_names(pav_ctx *ctx, int role) { return istate(ctx)->names[role]; }
+int pav_seq_set_names_internal(pav_ctx *ctx, int role, const std::vector<std::string> &names) { istate(ctx)->names[role] = names; return PAV_OK; }
 
 // Give a round its pinned host block (whole-round columns: K0 | K1 | K2 | KMER | INDEX | STATE_MER | STATE | FLANK | MATCH, each
 // holding the calls one after the other) and point the tables of its calls into it.
@@ -503,6 +504,13 @@ void pav_invscan_release(pav_ctx *ctx) {
     static_cast<InvState *>(ctx->invscan)->free_pinned();
     delete static_cast<InvState *>(ctx->invscan);
     ctx->invscan = nullptr;
+}
+
+// name of record i of `role` as set by pav_seq_set_names / a FASTA loader (NULL: no such record or no names)
+const char *pav_seq_name(const pav_ctx *ctx, int role, uint32_t i) {
+    if (!ctx || !ctx->invscan || (role != PAV_ROLE_REF && role != PAV_ROLE_TIG)) return nullptr;
+    const InvState *S = static_cast<const InvState *>(ctx->invscan);
+    return i < S->names[role].size() ? S->names[role][i].c_str() : nullptr;
 }
 
 int pav_seq_set_names(pav_ctx *ctx, int role, uint32_t n, const char *const *names) {

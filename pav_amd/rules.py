@@ -173,10 +173,17 @@ def collapse_to_set(items, to_type=None):
     return out
 
 
-def inv_bed_row(inv_call, hap, flag_type, tig_fa):
-    """One INV BED record as rule call_inv_batch builds it (call_inv.snakefile:203-282)."""
-    from . import inv as pavinv, seq as pavseq
-    seq = pavseq.region_seq_fasta(inv_call.region_tig_outer, tig_fa, rev_compl=inv_call.region_tig_outer.is_rev)
+def inv_bed_row(inv_call, hap, flag_type, tig_fa, ctx=None, seq=None):
+    """One INV BED record as rule call_inv_batch builds it (call_inv.snakefile:203-282).  ``ctx``: a context on which the contig
+    file is resident - the SEQ column then comes from HBM instead of a host-side parse of the file; ``seq``: the column itself,
+    fetched by the caller (:func:`inv_seq_columns`: all calls of a haplotype in one round trip)."""
+    from . import _lib, inv as pavinv, seq as pavseq
+    if seq is not None:
+        pass
+    elif ctx is not None:
+        seq = pavseq.region_seq_resident(ctx, _lib.PAV_ROLE_TIG, inv_call.region_tig_outer, rev_compl=inv_call.region_tig_outer.is_rev)
+    else:
+        seq = pavseq.region_seq_fasta(inv_call.region_tig_outer, tig_fa, rev_compl=inv_call.region_tig_outer.is_rev)
     align_index = ','.join(sorted(collapse_to_set(
         (inv_call.region_ref_outer.pos_aln_index, inv_call.region_ref_outer.end_aln_index,
          inv_call.region_ref_inner.pos_aln_index, inv_call.region_ref_inner.end_aln_index), to_type=str)))
@@ -188,6 +195,16 @@ def inv_bed_row(inv_call, hap, flag_type, tig_fa):
          inv_call.region_ref_discovery.to_base1_string(), inv_call.region_tig_discovery.to_base1_string(),
          inv_call.region_flag.region_id(), flag_type, align_index, pavinv.CALL_SOURCE, 'PASS', seq],
         index=INV_BED_COLUMNS)
+
+
+def inv_seq_columns(ctx, calls):
+    """SEQ column of every InvCall of ``calls`` from the contig records resident on ``ctx`` (one device round trip):
+    ``region_seq_fasta(call.region_tig_outer, tig_fa, rev_compl=is_rev)`` of rules/call_inv.snakefile:212 for each."""
+    from . import _lib, seq as pavseq
+    names = {n: i for i, n in enumerate(ctx.seq_names(_lib.PAV_ROLE_TIG))}
+    regions = [c.region_tig_outer for c in calls]
+    parts = ctx.seq_fetch_many(_lib.PAV_ROLE_TIG, [(names[r.chrom], r.pos, r.end) for r in regions])
+    return [(pavseq._COMP[b[::-1]] if r.is_rev else b).tobytes().decode() for r, b in zip(regions, parts)]
 
 
 def call_inv_batch(bed_flag, bed_aln, tig_fa, fai, ref_fa, hap, batch, bed_out=None, log_path=None,
@@ -479,8 +496,10 @@ def call_haplotype(bed, bed_trim, tig_fa_name, ref_fa_name, asm_name, hap, out_d
         # uploaded and packed (the native readers and the upload release the GIL)
         import threading
         from . import fasta as pavfasta
-        th = threading.Thread(target=pavfasta.open_fasta, args=(tig_fa_name,))
-        th.start()
+        dev_fa = cigarcall.device_fasta()
+        if not dev_fa:                                                                # (host parser: the contig file beside the reference)
+            th = threading.Thread(target=pavfasta.open_fasta, args=(tig_fa_name,))
+            th.start()
         # ... and so are the two alignment tables (one gzip stream each: 0.12 s of inflate apiece, serial by nature), each on a
         # thread of its own beside the FASTA parsers
         opened, open_err = {}, []
@@ -493,17 +512,32 @@ def call_haplotype(bed, bed_trim, tig_fa_name, ref_fa_name, asm_name, hap, out_d
         tab_threads = [threading.Thread(target=open_table, args=(k, f)) for k, f in (('bed', bed), ('trim', bed_trim))]
         for t in tab_threads:
             t.start()
+        tig_err, th_tig = [], None
+        if dev_fa:
+            # device loader: the contig file goes up on a thread of its own beside the reference (the two stores of a context may
+            # be loaded side by side, include/pav_amd.h); nothing of either file is parsed on the host
+            def load_tig():
+                try:
+                    ctx.seq_load_fasta_path(_lib.PAV_ROLE_TIG, tig_fa_name)
+                except BaseException as ex:                                               # noqa: BLE001 - raised again on this thread
+                    tig_err.append(ex)
+            th_tig = threading.Thread(target=load_tig)
+            th_tig.start()
         try:
             cigarcall.load_reference(ctx, ref_fa_name)
         finally:
             for t in tab_threads:
                 t.join()
+            if th_tig is not None:
+                th_tig.join()
             table, trim_table = opened.get('bed'), opened.get('trim')
-        if open_err:
-            raise open_err[0]
+        if open_err or tig_err:
+            raise (open_err or tig_err)[0]
         cols = table.fetch()
-        th.join()
-        cigarcall.load_sequences(ctx, ref_fa_name, tig_fa_name)                        # every contig record: the scan may lift anywhere
+        if th is not None:
+            th.join()
+        if not dev_fa:
+            cigarcall.load_sequences(ctx, ref_fa_name, tig_fa_name)                    # every contig record: the scan may lift anywhere
         ctx._inv_loaded = (str(ref_fa_name), str(tig_fa_name))
         lap('sequences')
         index = ctx.cigar_load_bed(table, -1)
@@ -599,6 +633,11 @@ def call_haplotype(bed, bed_trim, tig_fa_name, ref_fa_name, asm_name, hap, out_d
             table_writer.start()
         try:
             batch_texts = []
+            seq_of = {}
+            if dev_fa:                                                            # the SEQ columns of every kept call, one round trip
+                kept_ix = [ix for _, keep_b in kept for ix in keep_b]
+                for ix, sq in zip(kept_ix, inv_seq_columns(ctx, [results[where[ix]] for ix in kept_ix])):
+                    seq_of[ix] = sq
             for b in range(batch_count):
                 rows_b, keep_b = kept[b]
                 call_list = []
@@ -609,7 +648,7 @@ def call_haplotype(bed, bed_trim, tig_fa_name, ref_fa_name, asm_name, hap, out_d
                         if isinstance(r, RuntimeError):                                       # :198-200
                             log_file.write('RuntimeError in scan_for_inv(): {}\n'.format(r))
                         if ix in keep_b:
-                            call_list.append(inv_bed_row(r, hap, row['TYPE'], tig_fa_name))
+                            call_list.append(inv_bed_row(r, hap, row['TYPE'], tig_fa_name, seq=seq_of.get(ix)))
                             if keep_b[ix] is not None:
                                 r.df.to_csv(keep_b[ix], sep='\t', index=False, compression='gzip')
                 if rows_b.shape[0] == 0:

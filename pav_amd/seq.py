@@ -145,6 +145,24 @@ def region_from_id(region_id):
     return Region(chrom, start, start + int(length))
 
 
+def region_seq_resident(ctx, role, region, rev_compl=None):
+    """:func:`region_seq_fasta` for a record that is resident on ``ctx`` (``pav_seq_fetch``): the bases come from HBM, no FASTA
+    file is parsed on the host for them."""
+    names = ctx.seq_names(role)
+    if type(region) is str:
+        rec, flip = names.index(region), bool(rev_compl)
+        bases = ctx.seq_fetch(role, rec, 0, ctx.seq_lengths(role)[rec])
+    elif type(region) is Region:
+        rec = names.index(region.chrom)
+        bases = ctx.seq_fetch(role, rec, region.pos, region.end)
+        flip = bool(region.is_rev if rev_compl is None else rev_compl)
+    else:
+        raise RuntimeError('Unrecognized region type: {}: Expected Region (pavlib.seq) or str'.format(type(region).__name__))
+    if flip:
+        bases = _COMP[bases[::-1]]
+    return bases.tobytes().decode()
+
+
 def region_seq_fasta(region, fa_file_name, rev_compl=None):
     """Bases of a Region - or of the whole record named by a str - as text.  Reverse-complemented when ``rev_compl`` is
     true, or, when it is None, for a Region with ``is_rev`` set."""
