@@ -420,8 +420,8 @@ int gz_files(pav_ctx *ctx, void **slot, hipStream_t st, const uint8_t *d_text, u
     // the length that ends a chain walk (zlib's max_chain / max_lazy / nice_length, scaled to what a lock-step wave can afford)
     // (measured on 200 MB of SNV rows / density rows, window 4 KiB, profiles/r05_gzip_variants.json: chain 4 / 8 / 16 / 32 =
     //  12.2 / 10.0 / 7.5 / 5.1 GB/s at 0.982 / 0.968 / 0.952 / 0.927 of zlib level 6's size - every setting is below zlib-6)
-    if (level <= 3) { A.chain = 4; A.lazy = 16; A.nice = 64; A.good = 16; }
-    else if (level <= 6) { A.chain = 8; A.lazy = 32; A.nice = 128; A.good = 32; }
+    if (level <= 5) { A.chain = 4; A.lazy = 16; A.nice = 64; A.good = 16; }
+    else if (level <= 6) { A.chain = 6; A.lazy = 32; A.nice = 128; A.good = 32; }
     else { A.chain = 32; A.lazy = 258; A.nice = 258; A.good = 64; }
     if (const char *e = getenv("PAV_GZ_CHAIN")) A.chain = (uint32_t)std::max(1, atoi(e));
     if (const char *e = getenv("PAV_GZ_NICE")) A.nice = (uint32_t)std::max(4, atoi(e));

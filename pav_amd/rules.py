@@ -173,7 +173,7 @@ def collapse_to_set(items, to_type=None):
     return out
 
 
-def inv_bed_row(inv_call, hap, flag_type, tig_fa, ctx=None, seq=None):
+def inv_bed_row(inv_call, hap, flag_type, tig_fa, ctx=None, seq=None, as_list=False):
     """One INV BED record as rule call_inv_batch builds it (call_inv.snakefile:203-282).  ``ctx``: a context on which the contig
     file is resident - the SEQ column then comes from HBM instead of a host-side parse of the file; ``seq``: the column itself,
     fetched by the caller (:func:`inv_seq_columns`: all calls of a haplotype in one round trip)."""
@@ -187,14 +187,13 @@ def inv_bed_row(inv_call, hap, flag_type, tig_fa, ctx=None, seq=None):
     align_index = ','.join(sorted(collapse_to_set(
         (inv_call.region_ref_outer.pos_aln_index, inv_call.region_ref_outer.end_aln_index,
          inv_call.region_ref_inner.pos_aln_index, inv_call.region_ref_inner.end_aln_index), to_type=str)))
-    return pd.Series(
-        [inv_call.region_ref_outer.chrom, inv_call.region_ref_outer.pos, inv_call.region_ref_outer.end,
-         inv_call.id, 'INV', inv_call.svlen, hap,
-         inv_call.region_tig_outer.to_base1_string(), '-' if inv_call.region_tig_outer.is_rev else '+', 0,
-         inv_call.region_ref_inner.to_base1_string(), inv_call.region_tig_inner.to_base1_string(),
-         inv_call.region_ref_discovery.to_base1_string(), inv_call.region_tig_discovery.to_base1_string(),
-         inv_call.region_flag.region_id(), flag_type, align_index, pavinv.CALL_SOURCE, 'PASS', seq],
-        index=INV_BED_COLUMNS)
+    values = [inv_call.region_ref_outer.chrom, inv_call.region_ref_outer.pos, inv_call.region_ref_outer.end,
+              inv_call.id, 'INV', inv_call.svlen, hap,
+              inv_call.region_tig_outer.to_base1_string(), '-' if inv_call.region_tig_outer.is_rev else '+', 0,
+              inv_call.region_ref_inner.to_base1_string(), inv_call.region_tig_inner.to_base1_string(),
+              inv_call.region_ref_discovery.to_base1_string(), inv_call.region_tig_discovery.to_base1_string(),
+              inv_call.region_flag.region_id(), flag_type, align_index, pavinv.CALL_SOURCE, 'PASS', seq]
+    return values if as_list else pd.Series(values, index=INV_BED_COLUMNS)
 
 
 def inv_seq_columns(ctx, calls):
@@ -205,6 +204,87 @@ def inv_seq_columns(ctx, calls):
     regions = [c.region_tig_outer for c in calls]
     parts = ctx.seq_fetch_many(_lib.PAV_ROLE_TIG, [(names[r.chrom], r.pos, r.end) for r in regions])
     return [(pavseq._COMP[b[::-1]] if r.is_rev else b).tobytes().decode() for r, b in zip(regions, parts)]
+
+
+# ---- the per-batch INV tables and their merge as text ------------------------------------------------------------------
+# rule call_inv_batch ends with pd.concat(call_list, axis=1).T.sort_values([...]).to_csv(...) (call_inv.snakefile:297-311), rule
+# call_inv_batch_merge reads the sixty files back, concatenates, drops duplicate IDs, sorts and writes (:101-112).  On sixty frames of
+# one to three rows that is 0.25 s of pandas per haplotype - a third of the whole files-to-files time once the device writes the big
+# tables.  The functions below produce the SAME bytes from the row values: the csv module pandas itself writes with (QUOTE_MINIMAL,
+# tab-delimited), Python's stable sort on the same key columns, the column union in order of first appearance.  Values that
+# pandas.read_csv would re-type on the way through the merge (a text field that reads as a number or as NA) make _merge_safe refuse,
+# and the caller then runs the rules' own pandas code; tests/test_gpu_inv.py compares the two paths byte for byte.
+_NA_TEXT = {'', '#N/A', '#N/A N/A', '#NA', '-1.#IND', '-1.#QNAN', '-NaN', '-nan', '1.#IND', '1.#QNAN', '<NA>', 'N/A', 'NA', 'NULL', 'NaN', 'None',
+            'n/a', 'nan', 'null'}
+
+
+def _tsv_text(columns, rows):
+    import csv
+    import io
+    buf = io.StringIO()
+    w = csv.writer(buf, delimiter='\t', lineterminator='\n', quoting=csv.QUOTE_MINIMAL)
+    w.writerow(columns)
+    w.writerows(rows)
+    return buf.getvalue()
+
+
+def _merge_safe(rows):
+    """True when every text field of ``rows`` comes back from pandas.read_csv as the same text (so that the merge rule's round trip
+    through DataFrames changes nothing)."""
+    import re
+    plain_int = re.compile(r'^-?(0|[1-9]\d{0,17})$')                      # reads as int64 and is written back with the same digits
+
+    def reads_as_number(v):
+        try:
+            float(v)
+            return True
+        except ValueError:
+            return False
+    for r in rows:
+        if not isinstance(r[0], str) or plain_int.match(r[0]):              # a numeric #CHROM column would be SORTED as numbers
+            return False
+        for v in r:
+            if not isinstance(v, str):
+                continue
+            if v in _NA_TEXT or v != v.strip() or '\r' in v or '\n' in v or '"' in v or '\t' in v \
+                    or v in ('True', 'False', 'TRUE', 'FALSE', 'true', 'false') or (reads_as_number(v) and not plain_int.match(v)):
+                return False
+    return True
+
+
+def inv_batch_texts(batch_rows):
+    """``batch_rows[b]``: None (the batch has no flagged region: full header, call_inv.snakefile:148-167), or the list of its calls'
+    INV BED rows as lists in INV_BED_COLUMNS order (empty: regions but no call -> the header without FILTER, :300-308 sic).
+    -> (text of every batch table, text of the merged table, number of merged rows), or None when :func:`_merge_safe` refuses."""
+    cols = list(INV_BED_COLUMNS)
+    key = [cols.index(c) for c in ('#CHROM', 'POS', 'END', 'ID')]
+    no_filter = [c for c in cols if c != 'FILTER']
+    texts, merged_cols, merged_rows, seen = [], [], [], set()
+    for rows in batch_rows:
+        if rows is None:
+            texts.append(_tsv_text(cols, []))
+            header = cols
+        elif not rows:
+            texts.append(_tsv_text(no_filter, []))
+            header = no_filter
+        else:
+            if not _merge_safe(rows):
+                return None
+            rows = sorted(rows, key=lambda r: tuple(r[k] for k in key))                 # sort_values: stable, by the four columns
+            texts.append(_tsv_text(cols, rows))
+            header = cols
+            for r in rows:                                                             # drop_duplicates('ID') keeps the first in concat order
+                if r[3] not in seen:
+                    seen.add(r[3])
+                    merged_rows.append(r)
+        for c in header:                                                               # pd.concat: columns in order of first appearance
+            if c not in merged_cols:
+                merged_cols.append(c)
+    merged_rows.sort(key=lambda r: tuple(r[k] for k in key))
+    if merged_cols != cols:
+        pick = [cols.index(c) for c in merged_cols]
+        merged_rows = [[r[k] for k in pick] for r in merged_rows]
+    return texts, _tsv_text(merged_cols, merged_rows), len(merged_rows)
 
 
 def call_inv_batch(bed_flag, bed_aln, tig_fa, fai, ref_fa, hap, batch, bed_out=None, log_path=None,
@@ -471,6 +551,7 @@ def call_haplotype(bed, bed_trim, tig_fa_name, ref_fa_name, asm_name, hap, out_d
     inv_sig_cluster_*, inv_sig_insdel_*, inv_k_size, inv_region_limit, inv_min_expand, srs_list).  A reference made resident
     by ``cigarcall.load_reference`` stays resident.  Returns a manifest dict (counts + file names)."""
     import io
+    import os
     import time
     import numpy as np
     from . import _lib, flag, inv as pavinv, seq as pavseq
@@ -554,11 +635,17 @@ def call_haplotype(bed, bed_trim, tig_fa_name, ref_fa_name, asm_name, hap, out_d
         tp, te = trim['POS'].to_numpy(dtype='int64'), trim['END'].to_numpy(dtype='int64')
         lap('tables in + CIGAR-call')
         call_batch = cols['CALL_BATCH'] if table.n_rows else np.zeros(0, dtype=np.int64)
-        # the device part of the writer now, its host part (text, gzip members) on a thread of the library's own beside the stages
-        # below - nothing on this path reads the two tables (rule call_cigar_merge is a leaf for the inversion rules)
-        ctx.cigar_write_tables(hap, index, tp, te, snv_path=P['snv'], insdel_path=P['insdel'], threads=threads,
-                               gzip_level=gzip_level, call_batch=call_batch, background=True)
-        writing = True
+        # The two merged tables are written on a thread of the library's own beside the stages below - nothing on this path reads them
+        # (rule call_cigar_merge is a leaf for the inversion rules).  The HOST writer starts now (it leaves the GPU alone after its
+        # sort); the DEVICE writer - 0.13 s of text and gzip kernels that fill the GPU - starts behind the flagging and the scan,
+        # which are short and which this thread waits for, and runs beside the host-side stages that follow them.
+        def start_table_writer():
+            ctx.cigar_write_tables(hap, index, tp, te, snv_path=P['snv'], insdel_path=P['insdel'], threads=threads,
+                                   gzip_level=gzip_level, call_batch=call_batch, background=True)
+        writer_late = os.environ.get('PAV_WRITER', 'device') != 'host'
+        if not writer_late:
+            start_table_writer()
+            writing = True
         lap('merged SNV / INS-DEL tables')
         flag_cfg = {}
         for key, name in (('inv_sig_cluster_win', 'cluster_win'), ('inv_sig_cluster_snv_min', 'cluster_min_snv'),
@@ -593,6 +680,10 @@ def call_haplotype(bed, bed_trim, tig_fa_name, ref_fa_name, asm_name, hap, out_d
                                                 min_exp_count=cfg.get('inv_min_expand'), ctx=ctx, eager_tables=False,
                                                 found_out=io.StringIO())
             lap('scan')
+        if writer_late:
+            start_table_writer()
+            writing = True
+            lap('merged SNV / INS-DEL tables')
         # ---- per batch, in the order the reference's jobs see the rows: INV table, log, density tables ----------------------
         where = {ix: q for q, ix in enumerate(sel.index)}
         # first which calls each batch keeps (:203) and where their density tables go: the native writer starts on those - a
@@ -633,6 +724,7 @@ def call_haplotype(bed, bed_trim, tig_fa_name, ref_fa_name, asm_name, hap, out_d
             table_writer.start()
         try:
             batch_texts = []
+            batch_rows = []                                                       # per batch: None / the rows as lists (inv_batch_texts)
             seq_of = {}
             if dev_fa:                                                            # the SEQ columns of every kept call, one round trip
                 kept_ix = [ix for _, keep_b in kept for ix in keep_b]
@@ -648,26 +740,35 @@ def call_haplotype(bed, bed_trim, tig_fa_name, ref_fa_name, asm_name, hap, out_d
                         if isinstance(r, RuntimeError):                                       # :198-200
                             log_file.write('RuntimeError in scan_for_inv(): {}\n'.format(r))
                         if ix in keep_b:
-                            call_list.append(inv_bed_row(r, hap, row['TYPE'], tig_fa_name, seq=seq_of.get(ix)))
+                            call_list.append(inv_bed_row(r, hap, row['TYPE'], tig_fa_name, seq=seq_of.get(ix), as_list=True))
                             if keep_b[ix] is not None:
                                 r.df.to_csv(keep_b[ix], sep='\t', index=False, compression='gzip')
-                if rows_b.shape[0] == 0:
-                    df_bed = pd.DataFrame([], columns=list(INV_BED_COLUMNS))                  # :148-167
-                elif call_list:
-                    df_bed = pd.concat(call_list, axis=1).T.sort_values(['#CHROM', 'POS', 'END', 'ID'])   # :297
-                else:
-                    df_bed = pd.DataFrame([], columns=[c for c in INV_BED_COLUMNS if c != 'FILTER'])       # :300-308 (sic)
-                # (the per-batch tables are temporary files, read back by the merge rule: here their TEXT is kept, gzip'd on the device
-                #  - all sixty in one launch set - and parsed back from memory by the merge, the same bytes pd.read_csv would inflate)
-                batch_texts.append(df_bed.to_csv(None, sep='\t', index=False).encode())
+                batch_rows.append(None if rows_b.shape[0] == 0 else call_list)
                 n_calls += len(call_list)
+            # the per-batch tables (temporary files, read back by the merge rule) and the merged table: their text from the row values
+            # (inv_batch_texts: the bytes the rules' pandas code writes), gzip on the device - all sixty-one in two launch sets
+            fast = None if os.environ.get('PAV_INV_TABLES') == 'pandas' else inv_batch_texts(batch_rows)
+            if fast is not None:
+                texts, merged_text, n_inv = fast
+                batch_texts = [t.encode() for t in texts]
+            else:                                                                 # the rules' own code (:297-311, :101-112)
+                for rows in batch_rows:
+                    if rows is None:
+                        df_bed = pd.DataFrame([], columns=list(INV_BED_COLUMNS))                  # :148-167
+                    elif rows:
+                        df_bed = pd.concat([pd.Series(r, index=INV_BED_COLUMNS) for r in rows], axis=1).T.sort_values(['#CHROM', 'POS', 'END', 'ID'])   # :297
+                    else:
+                        df_bed = pd.DataFrame([], columns=[c for c in INV_BED_COLUMNS if c != 'FILTER'])       # :300-308 (sic)
+                    batch_texts.append(df_bed.to_csv(None, sep='\t', index=False).encode())
             for path, gz in zip(P['inv_batch'], ctx.gzip_buffers(batch_texts, 1)):
                 with open(path, 'wb') as fh:
                     fh.write(gz)
             lap('INV batch tables + logs')
-            df_inv = call_inv_batch_merge([io.BytesIO(t) for t in batch_texts], None)
+            if fast is None:
+                df_merged = call_inv_batch_merge([io.BytesIO(t) for t in batch_texts], None)
+                merged_text, n_inv = df_merged.to_csv(None, sep='\t', index=False), int(df_merged.shape[0])
             with open(P['inv'], 'wb') as fh:                                              # rule call_inv_batch_merge's to_csv, gzip on the device
-                fh.write(ctx.gzip_buffer(df_inv.to_csv(None, sep='\t', index=False).encode(), gzip_level or 6))
+                fh.write(ctx.gzip_buffer(merged_text.encode(), gzip_level or 6))
             lap('INV merge')
         finally:
             if table_writer is not None:
@@ -680,7 +781,7 @@ def call_haplotype(bed, bed_trim, tig_fa_name, ref_fa_name, asm_name, hap, out_d
         lap('merged SNV / INS-DEL tables')
         return {'asm_name': asm_name, 'hap': hap, 'aligned_bp': int(counts.aligned_bases), 'snv_rows': int(n_snv),
                 'insdel_rows': int(n_insdel), 'flagged_regions': int(df_flag.shape[0]), 'scanned_regions': int(sel.shape[0]),
-                'inv_calls_in_batches': int(n_calls), 'inv_calls': int(df_inv.shape[0]),
+                'inv_calls_in_batches': int(n_calls), 'inv_calls': int(n_inv),
                 'files': {k: P[k] for k in ('snv', 'insdel', 'flagged_regions', 'inv')}}
     finally:
         if writing:                                                # an error on the way: the writer thread is waited for all the same
