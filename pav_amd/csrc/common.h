@@ -120,6 +120,21 @@ struct ProfPending { int entry; hipEvent_t a, b; };
 
 }  // namespace pav
 
+namespace pav {
+// The decisions of a scan round on the device (density.hip k_round_decide; invscan.cpp): what the scan driver knows of a job's
+// region when the density batch is queued, and the hook through which the batch - behind its last kernel and in front of its one
+// read-back - derives every job's next lift queries (pavlib/inv.py:297-351, 378-406) and lets the driver queue their lifts.
+struct RoundJobIn { int32_t ref_chrom, tig_chrom, tig_rev, expansion_count; int64_t ref_pos, ref_end, tig_pos, chrom_len; };
+struct RoundHook {
+    const RoundJobIn *d_in = nullptr;     // [n_jobs] on the device
+    void *d_queries = nullptr;            // LiftQuery[4 n_jobs] on the device: a job's breakpoint queries, or its next region's two ends
+    uint32_t n_jobs = 0;
+    int32_t min_exp_count = 1, k = 31;
+    bool ran = false;                     // the batch took the device-planned path and the queries were derived
+    std::function<int()> after;           // queues the lifts of the queries and their way to the host on the context's stream
+};
+}  // namespace pav
+
 struct pav_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -131,6 +146,7 @@ struct pav_ctx {
     bool tables_pending_prev = false;        // scan does not wait for them (the two are swapped when a scan starts)
     std::function<void()> den_overlap;    // set by the inversion-scan driver around pav_density_batch: host work that does not depend on
                                           // the batch (log texts), run once while the batch's kernels are executing
+    pav::RoundHook *den_round = nullptr;  // set by the inversion-scan driver around pav_density_batch (see RoundHook)
     bool den_scan_only = false;           // set by the inversion-scan driver around pav_density_batch: only run lists and the tables of
                                           // regions that can become calls will be read (density.hip, fwd_only)
     hipEvent_t hom_done = nullptr;        // pav_cigar_call: recorded behind the homology scans on stream2 (wait_homology)

@@ -12,6 +12,7 @@
 // evaluation point accumulates its data points in ascending order like scipy's gaussian_kernel_estimate, so the
 // only difference from the reference is the device exp() (<= 1 ulp per term).  Built with -ffp-contract=off.
 #include "common.h"
+#include "lift_dev.h"
 
 #ifndef PAV_LDS_SLOTS                 // slots / threads of a k_kmer_lds workgroup (tuning builds override them)
 #define PAV_LDS_SLOTS 4096
@@ -1704,6 +1705,103 @@ __global__ __launch_bounds__(64) void k_redo(RedoArgs A) {
     }
 }
 
+// ---- the decisions of a scan round, on the device -----------------------------------------------------------------------
+// pavlib/inv.py:297-351 decides from the run-length encoding of STATE what becomes of a region - finished, expanded (:309-342), or
+// flanked by FWD runs and characterised (:353-406) - and the two latter need lifts through the alignment table: the four breakpoint
+// positions of a flanked region, the two ends of an expanded one.  The scan driver (invscan.cpp) took those decisions on the host and
+// then asked the device for the lifts: one more round trip per round.  Here a wave per job gathers the job's run heads from the event
+// list k_finalize has just written, orders them by row, applies the same rules and writes the job's queries (four slots per job,
+// axis -1 = empty); k_lift_points answers them in the same launch set and queries and answers travel with the batch's one read-back.
+// The driver still takes its decisions itself (it writes the reference's log text from them) and uses an answer only when the query
+// beside it IS the query it would have asked: the lift is a pure function of the query, so nothing here has to be trusted.
+constexpr uint32_t ROUND_MAX_HEADS = 512;
+__global__ __launch_bounds__(64) void k_round_decide(const JobStat *__restrict__ stat, const HeadEvent *__restrict__ ev, const uint32_t *__restrict__ ev_count,
+                                                     uint32_t ev_cap, const RoundJobIn *__restrict__ in, LiftQuery *__restrict__ q, uint32_t n_jobs,
+                                                     uint32_t min_state_count, uint32_t min_informative, uint32_t max_ref_kmer_count, int min_exp_count, int k) {
+    __shared__ HeadEvent s_ev[ROUND_MAX_HEADS];
+    __shared__ uint16_t s_order[ROUND_MAX_HEADS];
+    __shared__ uint32_t s_n;
+    const uint32_t j = blockIdx.x, lane = threadIdx.x;
+    if (j >= n_jobs) return;
+    if (lane < 4) { LiftQuery e{}; e.axis = -1; q[4ull * j + lane] = e; }
+    const JobStat S = stat[j];
+    const RoundJobIn I = in[j];
+    const bool failed = S.n_ref_valid == 0 || S.max_count > max_ref_kmer_count;
+    const bool no_table = fwd_only(S, min_state_count);                  // (the driver's batches are scan-only: such a region has no rows)
+    const uint32_t n_rows = no_table ? (S.st_count[0] >= min_state_count ? S.st_count[0] : 0u) : S.n_rows;
+    if (failed || n_rows == 0) return;                                   // inv.py:268-296: the region is finished
+    // what the rules look at: number of runs, the states at both ends, rl[1].pos, rl[-2].end, the REV runs
+    uint32_t n_runs = 0, max_inv = 0;
+    int first_state = 0, last_state = 0;
+    long long r1_pos = 0, rn2_end = 0, inv_first_pos = 0, inv_last_end = 0;
+    bool any_inv = false;
+    if (no_table) { n_runs = n_rows >= min_informative ? 1u : 0u; }
+    else {
+        const uint32_t n_all = *ev_count;
+        if (n_all > ev_cap) return;                                      // (the batch goes to the host-planned path)
+        if (lane == 0) s_n = 0;
+        __syncthreads();
+        for (uint32_t e = lane; e < n_all; e += 64)
+            if (ev[e].job == j) { const uint32_t at = atomicAdd(&s_n, 1u); if (at < ROUND_MAX_HEADS) s_ev[at] = ev[e]; }
+        __syncthreads();
+        const uint32_t n = s_n;
+        if (n > ROUND_MAX_HEADS) return;                                 // too many runs for this shortcut: the driver asks for its lifts itself
+        for (uint32_t a = lane; a < n; a += 64) {                        // order by row (rank sort; rows of a job's heads are distinct)
+            uint32_t rank = 0;
+            const uint32_t ra = s_ev[a].row;
+            for (uint32_t b = 0; b < n; ++b) rank += (s_ev[b].row < ra || (s_ev[b].row == ra && b < a)) ? 1u : 0u;
+            s_order[rank] = (uint16_t)a;
+        }
+        __syncthreads();
+        if (lane != 0) return;
+        long long prev_end = 0;
+        for (uint32_t e = 0; e + 1 < n; ++e) {                           // a run = a head and the head behind it (the last one ends the rows)
+            const HeadEvent h = s_ev[s_order[e]], nx = s_ev[s_order[e + 1]];
+            if (h.state == -2) continue;
+            const long long pos = h.index, end = nx.prev_index;
+            const uint32_t count = nx.row - h.row;
+            if (n_runs == 0) first_state = h.state;
+            if (n_runs == 1) r1_pos = pos;
+            rn2_end = prev_end; prev_end = end;                          // when the loop ends: the end of the run before the last
+            last_state = h.state;
+            if (h.state == 2) {
+                if (!any_inv) inv_first_pos = pos;
+                inv_last_end = end; any_inv = true;
+                max_inv = count > max_inv ? count : max_inv;
+            }
+            ++n_runs;
+        }
+    }
+    if (lane != 0) return;
+    if (n_runs == 1 && (first_state == 0 || first_state == -1) && I.expansion_count >= min_exp_count) return;     // inv.py:297-307
+    LiftQuery out[4];
+    for (int t = 0; t < 4; ++t) { out[t] = LiftQuery{}; out[t].axis = -1; }
+    if (n_runs > 2 && first_state == 0 && last_state == 0) {             // flanked: inv.py:353-406
+        if (!any_inv || max_inv < 100) return;
+        long long o_pos = r1_pos + I.tig_pos, o_end = rn2_end + I.tig_pos + k;
+        long long i_pos = inv_first_pos + I.tig_pos, i_end = inv_last_end + I.tig_pos + k;
+        if (o_pos > o_end) { const long long t = o_pos; o_pos = o_end; o_end = t; }
+        if (i_pos > i_end) { const long long t = i_pos; i_pos = i_end; i_end = t; }
+        out[0] = LiftQuery{1, I.tig_chrom, 0, 0, o_pos}; out[1] = LiftQuery{1, I.tig_chrom, 0, 0, o_end};
+        out[2] = LiftQuery{1, I.tig_chrom, 1, 0, i_pos}; out[3] = LiftQuery{1, I.tig_chrom, 1, 0, i_end};
+    } else {                                                             // expand: inv.py:309-342, Region.expand (seq.py:112-188)
+        const long long last_len = I.ref_end - I.ref_pos;
+        const long long expand_bp = (long long)(int)((double)last_len * 1.5);
+        double balance = 0.5;
+        if (n_runs > 2) { if (first_state == 0) balance = 0.25; else if (last_state == 0) balance = 0.75; }
+        const long long expand_pos = (long long)((double)expand_bp * balance);
+        const long long expand_end = expand_bp - expand_pos > 0 ? expand_bp - expand_pos : 0;
+        long long new_pos = I.ref_pos - expand_pos, new_end = I.ref_end + expand_end;
+        if (new_pos < 0) { new_end += -new_pos; new_pos = 0; }
+        if (new_end > I.chrom_len) { new_pos -= new_end - I.chrom_len; if (new_pos < 0) new_pos = 0; new_end = I.chrom_len; }
+        if (new_end < new_pos) new_end = new_pos = (new_end + new_pos) / 2;
+        if (new_end - new_pos == last_len) return;                       // reached the reference's limits
+        out[0] = LiftQuery{0, I.ref_chrom, 0, 0, new_pos}; out[1] = LiftQuery{0, I.ref_chrom, 0, 0, new_end};
+    }
+    for (int t = 0; t < 4; ++t) q[4ull * j + t] = out[t];
+}
+
+
 // Run heads for rl_encoder (pavlib/density.py:330-361): one event per row that starts a run, plus one end marker.
 __global__ __launch_bounds__(256) void k_heads(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
                                                const JobStat *__restrict__ stat, const int8_t *__restrict__ state,
@@ -2471,6 +2569,13 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             FA.G = G; FA.ev_cap = ev_cap; FA.events = D->events.as<HeadEvent>(); FA.ev_count = D->ev_count.as<uint32_t>();
             FA.blk_spike = nullptr; FA.spike_add = G.rel > 0.0 ? 1 : 0;
             PAV_LAUNCH(ctx, "k_finalize", k_finalize, (uint32_t)(a_t / 256), 256, 0, FA);
+            if (ctx->den_round && ctx->den_round->n_jobs == n_jobs && scan_only) {   // the round's next lifts, derived and answered in this launch set
+                RoundHook &H = *ctx->den_round;
+                PAV_LAUNCH(ctx, "k_round_decide", k_round_decide, n_jobs, 64, 0, d_stat, D->events.as<HeadEvent>(), D->ev_count.as<uint32_t>(), ev_cap, H.d_in,
+                           static_cast<LiftQuery *>(H.d_queries), n_jobs, pp->min_state_count, pp->min_informative, pp->max_ref_kmer_count, H.min_exp_count, H.k);
+                if (H.after) { const int rch = H.after(); if (rch != PAV_OK) return rch; }
+                H.ran = true;
+            }
             lap("enqueue");
             // the one readback: the front of the zero arena - event count, guard counters, plan flags, statistics, run heads of STATE
             const uint32_t pre = ev_first;

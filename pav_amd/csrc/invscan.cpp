@@ -96,11 +96,14 @@ struct InvState {
     // point lifts of a scan round are one kernel.  PAV_LIFT_HOST=1 keeps the host tables above instead (the cross-check).
     bool on_device = false;
     DevBuf d_ops, d_begin, d_small, d_q, d_a;
+    DevBuf d_rin, d_rq, d_ra;                               // a round's decisions on the device: job descriptors in, queries + answers out
+    void *h_round = nullptr; size_t h_round_cap = 0;        // pinned: the descriptors up, the queries and answers down
     LiftTables dev{};
     void *h_qa = nullptr; size_t h_qa_cap = 0;              // pinned: queries up, answers down
     std::unique_ptr<HostPool> pool;                         // helper threads of the per-region host loops (pav_inv_scan_batch)
     std::vector<Scan> scans;                                // per-region state of the running scan (kept: its vectors keep their memory)
     bool loaded = false;
+    uint64_t n_round_dev = 0, n_round_host = 0;             // rounds whose lifts came with the batch / were asked for after it (PAV_TIMING)
     // last scan
     std::vector<pav_inv_result> results;
     std::vector<std::string> logs;
@@ -136,7 +139,8 @@ struct InvState {
     void next_pinned() { cur_set ^= 1; for (auto &b : pinned_sets[cur_set]) b.used = 0; stage_used = 0; }
     void free_pinned() {
         if (h_qa) { (void)hipHostFree(h_qa); h_qa = nullptr; h_qa_cap = 0; }
-        for (DevBuf *b : {&d_ops, &d_begin, &d_small, &d_q, &d_a}) b->release();
+        for (DevBuf *b : {&d_ops, &d_begin, &d_small, &d_q, &d_a, &d_rin, &d_rq, &d_ra}) b->release();
+        if (h_round) { (void)hipHostFree(h_round); h_round = nullptr; h_round_cap = 0; }
         for (auto &set : pinned_sets) { for (auto &b : set) (void)hipHostFree(b.p); set.clear(); }
         for (auto &set : stage_sets) { for (auto &st : set) st->release(); set.clear(); }
     }
@@ -850,7 +854,46 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
             pool.run(owners.size(), CHUNK, [&](size_t j) { const uint32_t i = owners[j]; log(i, "Scanning region: " + D.base1(scans[i].region_ref)); });
         };
         ctx->den_overlap = texts;
+        // The round's decisions are taken on the device too (density.hip k_round_decide), right behind the batch's last kernel: the
+        // breakpoint queries of the flanked regions and the ends of the expanded ones, lifted in the same launch set; queries and
+        // answers come back with the batch.  Below, an answer is used where its query equals the one this driver would ask.
+        RoundHook hook;
+        const size_t nj = jobs.size();
+        const bool dev_round = S->on_device && getenv("PAV_ROUND_HOST") == nullptr && nj > 0;
+        const LiftQuery *h_rq = nullptr; const LiftAnswer *h_ra = nullptr;
+        if (dev_round) {
+            const size_t b_in = sizeof(RoundJobIn) * nj, b_q = sizeof(LiftQuery) * 4 * nj, b_a = sizeof(LiftAnswer) * 4 * nj;
+            if (b_in + b_q + b_a + 256 > S->h_round_cap) {
+                if (S->h_round) (void)hipHostFree(S->h_round);
+                S->h_round = nullptr; S->h_round_cap = 0;
+                const size_t cap = (b_in + b_q + b_a) * 2 + 4096;
+                PAV_HIP(ctx, hipHostMalloc(&S->h_round, cap, hipHostMallocDefault));
+                S->h_round_cap = cap;
+            }
+            PAV_HIP(ctx, S->d_rin.reserve(b_in)); PAV_HIP(ctx, S->d_rq.reserve(b_q)); PAV_HIP(ctx, S->d_ra.reserve(b_a));
+            uint8_t *h = static_cast<uint8_t *>(S->h_round);
+            RoundJobIn *rin = reinterpret_cast<RoundJobIn *>(h);
+            for (size_t j = 0; j < nj; ++j) {
+                const Scan &sc = scans[owners[j]];
+                rin[j] = RoundJobIn{sc.region_ref.chrom, sc.region_tig.chrom, sc.region_tig.is_rev ? 1 : 0, sc.expansion_count,
+                                    sc.region_ref.pos, sc.region_ref.end, sc.region_tig.pos, (int64_t)ctx->seq[PAV_ROLE_REF].len[(size_t)sc.region_ref.chrom]};
+            }
+            PAV_HIP(ctx, hipMemcpyAsync(S->d_rin.p, h, b_in, hipMemcpyHostToDevice, ctx->stream));
+            const size_t o_q = (b_in + 63) / 64 * 64, o_a = o_q + (b_q + 63) / 64 * 64;
+            h_rq = reinterpret_cast<const LiftQuery *>(h + o_q); h_ra = reinterpret_cast<const LiftAnswer *>(h + o_a);
+            hook.d_in = S->d_rin.as<RoundJobIn>(); hook.d_queries = S->d_rq.p; hook.n_jobs = (uint32_t)nj;
+            hook.min_exp_count = min_exp_count; hook.k = k;
+            hook.after = [&, h, o_q, o_a, b_q, b_a, nj]() -> int {
+                const int rcl = lift_points(ctx, S->dev, S->d_rq.as<LiftQuery>(), S->d_ra.as<LiftAnswer>(), (uint32_t)(4 * nj));
+                if (rcl != PAV_OK) return rcl;
+                PAV_HIP(ctx, hipMemcpyAsync(h + o_q, S->d_rq.p, b_q, hipMemcpyDeviceToHost, ctx->stream));
+                PAV_HIP(ctx, hipMemcpyAsync(h + o_a, S->d_ra.p, b_a, hipMemcpyDeviceToHost, ctx->stream));
+                return PAV_OK;
+            };
+            ctx->den_round = &hook;
+        }
         int rc = pav_density_batch(ctx, (uint32_t)jobs.size(), jobs.data(), &pp->den, res.data());
+        ctx->den_round = nullptr;
         ctx->den_overlap = nullptr;
         ctx->den_scan_only = false;
         if (!overlapped && rc == PAV_OK) texts();                           // (a batch that took the host-planned path from the start)
@@ -945,8 +988,39 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
             const size_t n_cand_q = lq.size();
             queue_region_lifts(next, lq, carried_first);
             std::vector<Driver::Point> lp;
-            const int rcl = D.lift_batch(lq, lp);
-            if (rcl != PAV_OK) return rcl;
+            // the device's queries, job by job: a flanked job's four, a continuing job's two.  Every query asked here must be there
+            // (a region that waited for this batch - `rest` - was not part of it: then the batch of lifts is asked as before)
+            bool from_device = hook.ran && rest.empty();
+            if (from_device) {
+                std::vector<uint32_t> slot(lq.size(), ~0u);
+                for (size_t pq = 0; pq < pend.size(); ++pq) for (uint32_t t = 0; t < 4; ++t) slot[4 * pq + t] = 4 * pend[pq] + t;
+                {
+                    size_t nx = 0;
+                    for (uint32_t j = 0; j < jobs.size(); ++j) {
+                        if (dec[j].what != 1) continue;
+                        const uint32_t f = carried_first[nx++];
+                        if (f != ~0u) { slot[f] = 4 * j; slot[f + 1] = 4 * j + 1; }
+                    }
+                }
+                for (size_t i = 0; i < lq.size() && from_device; ++i) {
+                    if (slot[i] == ~0u) { from_device = false; break; }
+                    const LiftQuery &a = lq[i], &b = h_rq[slot[i]];
+                    from_device = a.axis == b.axis && a.seq == b.seq && a.gap == b.gap && a.pos == b.pos;
+                }
+                if (from_device) {
+                    lp.assign(lq.size(), Driver::Point{});
+                    for (size_t i = 0; i < lq.size(); ++i) {
+                        lp[i].a = h_ra[slot[i]];
+                        if (lp[i].a.status >= LIFT_ERR_OP) lp[i].err = D.lift_error(lq[i], lp[i].a);
+                    }
+                    S->n_round_dev += 1;
+                }
+            }
+            if (!from_device) {
+                if (hook.ran) S->n_round_host += 1;
+                const int rcl = D.lift_batch(lq, lp);
+                if (rcl != PAV_OK) return rcl;
+            }
             carried.assign(lp.begin() + (ptrdiff_t)n_cand_q, lp.end());
             for (uint32_t &f : carried_first) if (f != ~0u) f -= (uint32_t)n_cand_q;
             carried_valid = true;
@@ -1044,8 +1118,10 @@ int pav_inv_scan_batch(pav_ctx *ctx, uint32_t n_regions, const pav_inv_region *r
     flush_notes();
     if (timing) fprintf(stderr, "[pav timing] inv_scan_batch setup %.2f ms: texts %.3f, wait tables %.3f, tables %.3f, scans %.3f, first lines %.3f\n", (t_start - t_entry) * 1e3,
                         (tl[0] - t_entry) * 1e3, (tl[1] - tl[0]) * 1e3, (tl[2] - tl[1]) * 1e3, (tl[3] - tl[2]) * 1e3, (tl[4] - tl[3]) * 1e3);
-    if (timing) fprintf(stderr, "[pav timing] inv_scan_batch %.1f ms: density_batch %.1f, call tables + annotate %.1f, lift + jobs %.2f (lifting %.2f), decisions %.2f\n",
-                        (now() - t_start) * 1e3, t_batch * 1e3, t_table * 1e3, t_pre * 1e3, t_lift * 1e3, t_post * 1e3);
+    if (timing) fprintf(stderr, "[pav timing] inv_scan_batch %.1f ms: density_batch %.1f, call tables + annotate %.1f, lift + jobs %.2f (lifting %.2f), decisions %.2f; "
+                        "rounds whose lifts came with the batch / were asked for afterwards so far: %llu / %llu\n",
+                        (now() - t_start) * 1e3, t_batch * 1e3, t_table * 1e3, t_pre * 1e3, t_lift * 1e3, t_post * 1e3,
+                        (unsigned long long)S->n_round_dev, (unsigned long long)S->n_round_host);
     // the first line of every region's log (inv.py:194-199) is written now, with the last kernels of the scan still running: it
     // depends on the flagged region alone, and a thousand of them were 0.08 ms in front of the first round
     pool.run(n_regions, CHUNK, [&](size_t i) {

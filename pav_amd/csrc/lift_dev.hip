@@ -73,6 +73,7 @@ __global__ __launch_bounds__(64) void k_lift_points(LiftTables T, const LiftQuer
     const LiftQuery Q = q[i];
     LiftAnswer A{};
     A.status = LIFT_NONE; A.id = -1;
+    if (Q.axis < 0 || Q.axis > 1) { out[i] = A; return; }              // an empty slot of a round's query block (k_round_decide)
     uint32_t row = 0;
     const int hits = containing(T, Q.axis, Q.seq, Q.pos, row);
     if (Q.axis == 0) {                                                  // AlignLift.lift_to_qry (lift.py:187-272)

@@ -4,7 +4,7 @@
 # profiles/<round>_* through tools/prof_summary.py.  Everything is built first, outside the profiler: bench.py runs with
 # --no-build, so no compiler is ever started from a process the profiler's preload has attached to.
 set -x
-ROUND=${1:-r04}
+ROUND=${1:-r05}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$ROUND
 mkdir -p $O
@@ -31,6 +31,9 @@ cp $O/cigar_bench_under_rocprof.json $P/${ROUND}_cigar_only_bench_under_rocprof.
 # the SQ / LDS counter passes come first: bench.py's LDS roofline (roofline.timed_region.*.lds) reads this round's counters
 bash tools/scripts/profile_sq.sh $ROUND > $O/profile_sq.log 2>&1
 cp $P/${ROUND}_lds_counters.json $R/profiles/${ROUND}_lds_counters.json
+# the line rate of isolated 64 B fetches on THIS box (the roof of walk_snv / homology_kernel in the bench line)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/gather_rate tools/ubench/gather_rate.hip > $O/gather_build.log 2>&1 && /tmp/gather_rate > $P/${ROUND}_gather_rate.txt 2> $O/gather.err
+cp $P/${ROUND}_gather_rate.txt $R/profiles/${ROUND}_gather_rate.txt
 # plain runs (no profiler): the lines of record.  The PMC summary is copied first so that bench.py finds this round's traffic.
 cp $P/${ROUND}_pmc.json $R/profiles/${ROUND}_pmc.json
 python3 bench.py --no-build > $P/${ROUND}_full_path_bench.json 2> $O/bench_full.err
@@ -47,7 +50,20 @@ timeout -k 5 300 rocprofv3 --kernel-trace --memory-copy-trace -d $O/tl -o tl -- 
 cd $R
 python3 tools/prof_summary.py timeline $(find $O/tl -name "*.db" | head -1) $P/${ROUND}_single_lane_timeline_8ms.txt 8 > /dev/null
 find $O -name "*.db" -delete
-# files to files on the bench's own workload (pair_frac 0.009, inv_sig_filter single_cluster), deflate level 1 and the library's 6
-python3 tools/bench_e2e.py --inv-sig-filter single_cluster --gzip-level 1 > $P/${ROUND}_e2e_files_to_files.json 2> $O/e2e1.err
-python3 tools/bench_e2e.py --inv-sig-filter single_cluster --gzip-level 6 > $P/${ROUND}_e2e_files_to_files_gzip6.json 2> $O/e2e6.err
+# files to files on the bench's own workload (pair_frac 0.009, inv_sig_filter single_cluster) at the library's level 6: device writers
+# (the default; three runs, the box is noisy), the host writers for comparison, and the kernel statistics of one such run
+for i in 1 2 3; do python3 tools/bench_e2e.py --inv-sig-filter single_cluster --gzip-level 6 2> $O/e2e_dev_$i.err; done > $P/${ROUND}_e2e_files_to_files.json
+PAV_WRITER=host PAV_FASTA_DEVICE=0 PAV_INV_TABLES=pandas python3 tools/bench_e2e.py --inv-sig-filter single_cluster --gzip-level 6 > $P/${ROUND}_e2e_files_to_files_host_writer.json 2> $O/e2e_host.err
+cd /tmp
+timeout -k 5 600 rocprofv3 --kernel-trace --stats -d $O/prof_e2e -o e2e -- python3 $R/tools/bench_e2e.py --inv-sig-filter single_cluster --gzip-level 6 > /dev/null 2> $O/prof_e2e.err
+cd $R
+python3 tools/prof_summary.py stats $(find $O/prof_e2e -name "*.db" | head -1) $P/${ROUND}_e2e_kernel_stats.txt > /dev/null
+sed -i "1i # Command: rocprofv3 --kernel-trace --stats -- python3 tools/bench_e2e.py --inv-sig-filter single_cluster --gzip-level 6  (one haplotype files to files: FASTA\n# loader, calls, flagging, scan, device text + gzip of the SNV / INS-DEL / density tables)" $P/${ROUND}_e2e_kernel_stats.txt
+find $O -name "*.db" -delete
+# the device gzip alone: GB/s and size against zlib for several search depths and windows
+python3 tools/bench_gzip.py --mb 200 --variants 12:4,12:6,12:8,12:16,12:32,13:8 > $P/${ROUND}_gzip_variants.json 2> $O/gzip.err
+# the product runner: six haplotypes of 0.77 Gbp on one rank, 1 / 2 / 4 lanes; the same with the process pinned to four cores
+python3 tools/bench_cohort.py --haplotypes 6 --lanes 1 2 4 2> $O/cohort.err | tail -1 > $P/${ROUND}_cohort.json
+taskset -c 0-3 python3 tools/bench_cohort.py --haplotypes 6 --lanes 1 2 2> $O/cohort4.err | tail -1 > $P/${ROUND}_cohort_4cores.json
+python3 tools/bench_cohort.py --haplotypes 6 --lanes 2 --gpus 1 2> $O/cohort_line.err | tail -1 > $P/${ROUND}_cohort_line.json
 ls -la $P; du -sh $O

@@ -3,7 +3,7 @@
 # kernel spend their cycles (issuing / parked in s_waitcnt or a barrier / issue-stalled) and what the LDS arrays see
 # (k_kmer_lds, k_bucket_*, verify_kernel stage through LDS).  Summary -> profiles/<round>_full_path_pmc_sq.txt.
 set -x
-ROUND=${1:-r02}
+ROUND=${1:-r05}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$ROUND
 mkdir -p $O/profiles
