@@ -4,7 +4,7 @@
 // with zlib on sixteen (1.5 s per haplotype at level 6: 2.2 GB of text).  Here:
 //
 //   * the text of every file is cut into 64 KiB segments; ONE WAVE encodes a segment, start to finish, with no barrier against any
-//     other wave: a zlib-shaped sliding window in its LDS (ring of text, hash heads, chain links), 64 positions per step;
+//     other wave: a zlib-shaped sliding window in its LDS (a ring of 2 KiB of text, hash heads, chain links), 64 positions per step;
 //   * matches may reach back into the text in front of the segment (it is all in HBM: the window is primed from it), so the file is
 //     one deflate stream; a segment is one dynamic-Huffman block, followed - except the last - by an empty stored block that brings
 //     the stream to a byte boundary (the way parallel gzip implementations join their pieces);
@@ -394,10 +394,10 @@ int gz_files(pav_ctx *ctx, void **slot, hipStream_t st, const uint8_t *d_text, u
     const bool timing = getenv("PAV_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_a = now();
-    // window of the match finder: 8 KiB of text behind a position (the rows of these tables repeat their neighbours, not text 30 KiB
-    // back) keeps a wave's LDS at 35 KiB - four waves per CU
-    const int wbits = [] { const char *e = getenv("PAV_GZ_WBITS"); const int v = e ? atoi(e) : 0; return v == 13 ? 13 : 12; }();
-    const uint32_t HIST = wbits == 13 ? 4096u : 3328u;     // text in front of a segment that primes its window (< the window's reach)
+    // window of the match finder: 2 KiB of text behind a position (the rows of these tables repeat their neighbours, not text 30 KiB
+    // back) keeps a wave's LDS at 11.6 KB - thirteen waves per CU; PAV_GZ_WBITS=12 / 13: 4 / 8 KiB (eight / four waves per CU)
+    const int wbits = [] { const char *e = getenv("PAV_GZ_WBITS"); const int v = e ? atoi(e) : 0; return v == 13 ? 13 : (v == 12 ? 12 : 11); }();
+    const uint32_t HIST = wbits == 13 ? 4096u : (wbits == 12 ? 3328u : 1280u);   // text in front of a segment that primes its window (< the window's reach)
     std::vector<GzSegment> &segs = G->h_segs;
     segs.clear();
     std::vector<uint32_t> first(files.size() + 1, 0);
@@ -418,8 +418,10 @@ int gz_files(pav_ctx *ctx, void **slot, hipStream_t st, const uint8_t *d_text, u
     DeflateArgs A{};
     // how hard to look: chain steps per position, the length from which a match is taken without looking at the next position,
     // the length that ends a chain walk (zlib's max_chain / max_lazy / nice_length, scaled to what a lock-step wave can afford)
-    // (measured on 200 MB of SNV rows / density rows, window 4 KiB, profiles/r05_gzip_variants.json: chain 4 / 8 / 16 / 32 =
-    //  12.2 / 10.0 / 7.5 / 5.1 GB/s at 0.982 / 0.968 / 0.952 / 0.927 of zlib level 6's size - every setting is below zlib-6)
+    // (measured on 200 MB of SNV rows / 150 MB of density rows, profiles/r05_gzip_variants.json.  Window 2 KiB - 11.6 KB of LDS,
+    //  thirteen waves per CU - chain 4 / 6 / 8: 14.3 / 13.0 / 11.8 GB/s on SNV rows at 0.985 / 0.977 / 0.970 of zlib level 6's size,
+    //  19.0 / 16.9 / 15.2 GB/s on density rows at 0.948 / 0.943 / 0.941; window 4 KiB - eight waves per CU - is 15 - 35 % slower at
+    //  the same sizes; 8 KiB slower still.  Every setting is below zlib-6.)
     if (level <= 5) { A.chain = 4; A.lazy = 16; A.nice = 64; A.good = 16; }
     else if (level <= 6) { A.chain = 6; A.lazy = 32; A.nice = 128; A.good = 32; }
     else { A.chain = 32; A.lazy = 258; A.nice = 258; A.good = 64; }
@@ -430,7 +432,8 @@ int gz_files(pav_ctx *ctx, void **slot, hipStream_t st, const uint8_t *d_text, u
     if (!G->waves || G->waves_wbits != wbits) {
         int per_cu = 0;
         if (wbits == 13) W_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_deflate<13, 12>, 64, 0));
-        else W_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_deflate<12, 11>, 64, 0));
+        else if (wbits == 12) W_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_deflate<12, 11>, 64, 0));
+        else W_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_deflate<11, 10>, 64, 0));
         G->waves = std::max(1, per_cu) * std::max(1, ctx->n_cu);
         G->waves_wbits = wbits;
         if (timing) fprintf(stderr, "[pav timing] gz_files: window 2^%d bytes, %d waves per CU, %d CUs\n", wbits, per_cu, ctx->n_cu);
@@ -450,7 +453,8 @@ int gz_files(pav_ctx *ctx, void **slot, hipStream_t st, const uint8_t *d_text, u
     A.tok = G->tok.as<uint32_t>(); A.tok_per_wave = GZ_SEGMENT; A.slots = G->slots.as<uint8_t>(); A.slot_bytes = slot_bytes;
     A.out = G->out.as<GzSegOut>();
     if (wbits == 13) W_LAUNCH(st, (k_deflate<13, 12>), waves, 64, 0, A);
-    else W_LAUNCH(st, (k_deflate<12, 11>), waves, 64, 0, A);
+    else if (wbits == 12) W_LAUNCH(st, (k_deflate<12, 11>), waves, 64, 0, A);
+    else W_LAUNCH(st, (k_deflate<11, 10>), waves, 64, 0, A);
     W_LAUNCH(st, k_crc_segments, n_segs, 64, 0, d_text, G->segs.as<GzSegment>(), n_segs, G->out.as<GzSegOut>());
     W_HIP(hipMemcpyAsync(G->h_out, G->out.p, sizeof(GzSegOut) * n_segs, hipMemcpyDeviceToHost, st));
     W_HIP(hipStreamSynchronize(st));

@@ -52,8 +52,8 @@ python3 tools/prof_summary.py timeline $(find $O/tl -name "*.db" | head -1) $P/$
 find $O -name "*.db" -delete
 # files to files on the bench's own workload (pair_frac 0.009, inv_sig_filter single_cluster) at the library's level 6: device writers
 # (the default; three runs, the box is noisy), the host writers for comparison, and the kernel statistics of one such run
-for i in 1 2 3; do python3 tools/bench_e2e.py --inv-sig-filter single_cluster --gzip-level 6 2> $O/e2e_dev_$i.err; done > $P/${ROUND}_e2e_files_to_files.json
-PAV_WRITER=host PAV_FASTA_DEVICE=0 PAV_INV_TABLES=pandas python3 tools/bench_e2e.py --inv-sig-filter single_cluster --gzip-level 6 > $P/${ROUND}_e2e_files_to_files_host_writer.json 2> $O/e2e_host.err
+python3 tools/bench_e2e.py --inv-sig-filter single_cluster --gzip-level 6 --repeat 4 > $P/${ROUND}_e2e_files_to_files.json 2> $O/e2e_dev.err
+PAV_WRITER=host PAV_FASTA_DEVICE=0 PAV_INV_TABLES=pandas python3 tools/bench_e2e.py --inv-sig-filter single_cluster --gzip-level 6 --repeat 2 > $P/${ROUND}_e2e_files_to_files_host_writer.json 2> $O/e2e_host.err
 cd /tmp
 timeout -k 5 600 rocprofv3 --kernel-trace --stats -d $O/prof_e2e -o e2e -- python3 $R/tools/bench_e2e.py --inv-sig-filter single_cluster --gzip-level 6 > /dev/null 2> $O/prof_e2e.err
 cd $R
@@ -61,7 +61,7 @@ python3 tools/prof_summary.py stats $(find $O/prof_e2e -name "*.db" | head -1) $
 sed -i "1i # Command: rocprofv3 --kernel-trace --stats -- python3 tools/bench_e2e.py --inv-sig-filter single_cluster --gzip-level 6  (one haplotype files to files: FASTA\n# loader, calls, flagging, scan, device text + gzip of the SNV / INS-DEL / density tables)" $P/${ROUND}_e2e_kernel_stats.txt
 find $O -name "*.db" -delete
 # the device gzip alone: GB/s and size against zlib for several search depths and windows
-python3 tools/bench_gzip.py --mb 200 --variants 12:4,12:6,12:8,12:16,12:32,13:8 > $P/${ROUND}_gzip_variants.json 2> $O/gzip.err
+python3 tools/bench_gzip.py --mb 200 --variants 11:4,11:6,11:8,11:32,12:4,12:6,12:8,12:16,13:8 > $P/${ROUND}_gzip_variants.json 2> $O/gzip.err
 # the product runner: six haplotypes of 0.77 Gbp on one rank, 1 / 2 / 4 lanes; the same with the process pinned to four cores
 python3 tools/bench_cohort.py --haplotypes 6 --lanes 1 2 4 2> $O/cohort.err | tail -1 > $P/${ROUND}_cohort.json
 taskset -c 0-3 python3 tools/bench_cohort.py --haplotypes 6 --lanes 1 2 2> $O/cohort4.err | tail -1 > $P/${ROUND}_cohort_4cores.json
