@@ -96,11 +96,19 @@ int pav_fasta_kind(const pav_fasta *fa);                                 /* 0 pl
 /* pav_seq_load + pav_seq_set_names of the chosen records, in the order given. */
 int pav_seq_load_fasta(pav_ctx *ctx, int role, const pav_fasta *fa, uint32_t n_records, const uint32_t *records);
 /* Every record of a FASTA file (plain, gzip, BGZF) into the store of `role`, names set - WITHOUT the host-side parse: the file's text
- * crosses PCIe as it is (a plain file is read in parallel pieces straight into pinned memory; compressed ones are inflated first) and
+ * crosses PCIe as it is - a plain file's text; a BGZF file's members, the form PAV keeps its FASTA files in (rules/call.snakefile:796
+ * contigs_{hap}.fa.gz, data/ref/ref.fa.gz), which are inflated ON THE DEVICE (inflate.hip; PAV_FASTA_INFLATE=host: by host threads); a gzip
+ * stream that is not BGZF is inflated on the host first - read in parallel pieces straight into pinned memory, and the text
  * loses its header lines and line breaks on the device (fastadev.hip).  Same arena bytes as pav_fasta_open + pav_seq_load_fasta of all
  * records; *n_records = their number.  The two roles of one context may be loaded from two threads at the same time.
  * Replaces pysam.FastaFile(fa).fetch(name) of whole records (pavlib/cigarcall.py:59-66, pavlib/seq.py:339-351). */
 int pav_seq_load_fasta_path(pav_ctx *ctx, int role, const char *path, int threads, uint32_t *n_records);
+/* A BGZF file held in host memory -> its text: the members (independent gzip members of at most 64 KiB of text, SAM specification 4.1)
+ * are decoded on the device - a lane per member walks the Huffman codes into tokens, a wave per member resolves the copies in LDS - and
+ * every member's CRC-32 and ISIZE are checked (a corrupt member: PAV_E_ARG, the member named).  *out_len = the text's length, also when
+ * out_cap is too small for it (PAV_E_LIMIT).  The inflate step of pav_seq_load_fasta_path, exposed for tests and for callers with BGZF
+ * data of their own; what pysam.FastaFile does through htslib's bgzf reader (pavlib/cigarcall.py:59-64). */
+int pav_bgzf_inflate(pav_ctx *ctx, const uint8_t *in, uint64_t n_in, uint8_t *out, uint64_t out_cap, uint64_t *out_len);
 /* ASCII bytes [pos, pos + n) of record `rec` as they stand in the store (case preserved, forward strand): what
  * pysam.FastaFile.fetch(name, pos, pos + n) returns for a resident record (pavlib/seq.py:339-351, the SEQ column of rule
  * call_inv_batch, rules/call_inv.snakefile:203-282). */

@@ -188,6 +188,7 @@ SYMBOLS = {
     'pav_seq_length': (ctypes.c_uint64, [_P, ctypes.c_int, ctypes.c_uint32]),
     'pav_gzip_buffer': (ctypes.c_int, [_P, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64,
                                        ctypes.POINTER(ctypes.c_uint64)]),
+    'pav_bgzf_inflate': (ctypes.c_int, [_P, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]),
     'pav_gzip_buffers': (ctypes.c_int, [_P, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.c_int,
                                         ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     'pav_device_pci_bus_id': (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_int]),
@@ -420,6 +421,22 @@ class Context:
         got = ctypes.c_uint64(0)
         self._check(self.lib.pav_gzip_buffer(self.handle, buf.ctypes.data if n else None, n, int(level), out.ctypes.data, out.shape[0],
                                              ctypes.byref(got)), 'pav_gzip_buffer')
+        return out[:got.value].tobytes()
+
+    def bgzf_inflate(self, data):
+        """The text of a BGZF file held in memory (bytes / uint8 array), its members inflated on the device and checked against
+        their CRC-32 and ISIZE; returns bytes.  A corrupt member raises, naming it (``pav_bgzf_inflate``)."""
+        buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+        n = int(buf.shape[0])
+        # ISIZE of every member is in its footer; the text's length is their sum - asked for first with no room (PAV_E_LIMIT answers it)
+        got = ctypes.c_uint64(0)
+        rc = self.lib.pav_bgzf_inflate(self.handle, buf.ctypes.data if n else None, n, None, 0, ctypes.byref(got))
+        if rc == 0 and got.value == 0:
+            return b''
+        if got.value == 0:
+            self._check(rc, 'pav_bgzf_inflate')
+        out = np.empty(int(got.value), dtype=np.uint8)
+        self._check(self.lib.pav_bgzf_inflate(self.handle, buf.ctypes.data, n, out.ctypes.data, out.shape[0], ctypes.byref(got)), 'pav_bgzf_inflate')
         return out[:got.value].tobytes()
 
     def gzip_buffers(self, texts, level=0):

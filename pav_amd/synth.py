@@ -316,6 +316,30 @@ def write_fasta(path, names, seqs, line=0):
         fh.writelines(fai)
 
 
+def bgzip(src, dst, level=6, threads=8, block=65280):
+    """``src`` rewritten as BGZF (SAM specification 4.1: gzip members of ``block`` bytes of text each, the end-of-file member last) -
+    the form PAV keeps its FASTA files in (``bgzip``; rules/align.snakefile).  zlib releases the GIL: the members are made by
+    ``threads`` threads, a few hundred at a time."""
+    import struct
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+
+    def member(chunk):
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = c.compress(chunk) + c.flush()
+        return (b'\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00' + struct.pack('<H', len(body) + 25) + body
+                + struct.pack('<II', zlib.crc32(chunk), len(chunk)))
+
+    with open(src, 'rb') as fi, open(dst, 'wb') as fo, ThreadPoolExecutor(max(1, threads)) as pool:
+        while True:
+            buf = fi.read(block * 64 * max(1, threads))
+            if not buf:
+                break
+            for m in pool.map(member, [buf[a:a + block] for a in range(0, len(buf), block)]):
+                fo.write(m)
+        fo.write(member(b''))
+
+
 def scaled_lengths(lengths, scale):
     return {n: max(20_000, int(L * scale)) for n, L in lengths.items()}
 

@@ -42,6 +42,8 @@ def main():
     ap.add_argument('--repeat', type=int, default=1, help='call the haplotype this many times in the process (fresh output directory, fresh context '
                                                           'and sequences each time); the line reports the LAST run and lists every total - the first '
                                                           'run of a process pays for pinned buffers, device allocations and cold pools')
+    ap.add_argument('--bgzf', action='store_true', help='the two FASTA files bgzipped (ref.fa.gz, contigs_h1.fa.gz) - the form PAV keeps them in '
+                                                        '(rules/call.snakefile:796); PAV_FASTA_INFLATE=host inflates them on host threads instead of the device')
     args = ap.parse_args()
     import torch  # noqa: F401  first: one HIP runtime per process (pav_amd/_lib.py)
     import __graft_entry__ as g
@@ -56,6 +58,12 @@ def main():
     ref_fa, tig_fa = os.path.join(work, 'ref.fa'), os.path.join(work, 'contigs_h1.fa')
     synth.write_fasta(ref_fa, hap.ref.names, hap.ref.seqs, line=args.fasta_line)
     synth.write_fasta(tig_fa, hap.tig_names, hap.tig_seqs, line=args.fasta_line)
+    if args.bgzf:
+        for plain in (ref_fa, tig_fa):
+            synth.bgzip(plain, plain + '.gz', threads=min(16, effective_cpus()))
+            shutil.copyfile(plain + '.fai', plain + '.gz.fai')
+            os.remove(plain)
+        ref_fa, tig_fa = ref_fa + '.gz', tig_fa + '.gz'
     df_align = hap.df_align.copy()
     if 'CALL_BATCH' not in df_align:
         df_align['CALL_BATCH'] = df_align['INDEX'] % 10
@@ -91,6 +99,8 @@ def main():
                       'snv_rows': n_snv, 'insdel_rows': n_ins, 'flagged_regions': int(df_flag.shape[0]), 'scanned_regions': len(regions),
                       'inv_calls': len(calls), 'inv_sig_filter': args.inv_sig_filter, 'stages_s': stages, 'total_s': total, 'runs_total_s': totals,
                       'writer': os.environ.get('PAV_WRITER', 'device'),
+                      'fasta': ('BGZF, inflated on the ' + os.environ.get('PAV_FASTA_INFLATE', 'device')) if args.bgzf else 'plain text',
+                      'fasta_bytes': os.path.getsize(ref_fa) + os.path.getsize(tig_fa),
                       'end_to_end_Gbp_per_s': round(aligned_bp / total / 1e9, 3), 'writer_threads': args.threads, 'gzip_level': args.gzip_level, 'inputs_written_s': round(t_inputs, 1),
                       'host_cores': os.cpu_count(), 'usable_cores': effective_cpus(), 'file_bytes': sizes}), flush=True)
     if args.out is None:
