@@ -241,6 +241,8 @@ void fastadev_release(pav_ctx *ctx) {
     if (!ctx || !ctx->fa_dev) return;
     FaDevPair *P = static_cast<FaDevPair *>(ctx->fa_dev);
     for (FaDev *F : {&P->role[0], &P->role[1], &P->other}) {
+        scratch_give(ctx->device, F->raw);
+        scratch_give(ctx->device, F->comp);
         for (DevBuf *b : {&F->raw, &F->tile_cnt, &F->tile_pre, &F->bsum, &F->hdr, &F->hdr_end, &F->rec, &F->kept, &F->counter, &F->comp, &F->hdr_off, &F->hdr_text}) b->release();
         inflate_release(&F->inflate);
         if (F->pin) (void)hipHostFree(F->pin);
@@ -285,7 +287,7 @@ int pav_seq_load_fasta_path(pav_ctx *ctx, int role, const char *path, int thread
         uint64_t bsize = 0, hdr = 0;
         if (!(e && !strcmp(e, "host")) && got >= 18 && 12ull + (h[10] | (uint32_t)h[11] << 8) <= (uint64_t)got && bgzf_block(h, (size_t)sb.st_size, bsize, hdr)) {
             BgzfWalk walk; walk.size = (uint64_t)sb.st_size;
-            PAV_HIP(ctx, F->comp.reserve((size_t)sb.st_size + 4096));
+            PAV_HIP(ctx, scratch_take(ctx->device, (size_t)sb.st_size + 4096, F->comp));
             const int rc = stream_file(ctx, role, fd, (uint64_t)sb.st_size, F->comp.as<uint8_t>(), threads, &walk);
             if (rc != PAV_OK) return rc;
             if (!walk.bad && walk.next == (uint64_t)sb.st_size) {
@@ -302,7 +304,7 @@ int pav_seq_load_fasta_path(pav_ctx *ctx, int role, const char *path, int thread
     }
     const uint32_t n_tiles = (uint32_t)((n + FA_TILE - 1) / FA_TILE);
     const uint32_t hdr_cap = 1u << 22;
-    PAV_HIP(ctx, F->raw.reserve(n + 4096));
+    PAV_HIP(ctx, scratch_take(ctx->device, n + 4096, F->raw));
     PAV_HIP(ctx, F->tile_cnt.reserve(4ull * (n_tiles + 8)));
     PAV_HIP(ctx, F->tile_pre.reserve(8ull * (n_tiles + 8)));
     PAV_HIP(ctx, F->bsum.reserve(8ull * (n_tiles / SCAN_TILE + 8)));
@@ -394,6 +396,10 @@ int pav_seq_load_fasta_path(pav_ctx *ctx, int role, const char *path, int thread
     const int rcn = pav_seq_set_names_internal(ctx, role, names);
     if (rcn != PAV_OK) return rcn;
     if (n_records) *n_records = n_hdr;
+    // the store is filled and the stream drained (seq_store_load): the file's bytes and its text go back on the process's list of
+    // idle scratch - the other role's load, or the next haplotype's, takes them from there
+    scratch_give(ctx->device, F->raw);
+    scratch_give(ctx->device, F->comp);
     if (timing) fprintf(stderr, "[pav timing] seq_load_fasta_path role %d: %.2f GB of text%s; file -> HBM %.1f ms (%.1f GB/s), records %.1f ms, store %.1f ms (%s)\n", role,
                         (double)n / 1e9, on_device ? " (BGZF, inflated on the device)" : "", (t1 - t0) * 1e3, (double)n / 1e9 / std::max(1e-9, t1 - t0), (t2 - t1) * 1e3, (wall() - t2) * 1e3, path);
     return PAV_OK;
@@ -412,7 +418,7 @@ int pav_bgzf_inflate(pav_ctx *ctx, const uint8_t *in, uint64_t n_in, uint8_t *ou
     if (walk.bad || walk.next != n_in) return fail(ctx, PAV_E_ARG, "pav_bgzf_inflate: not a series of BGZF members (member %zu, byte %llu)", walk.M.in_off.size(),
                                                   (unsigned long long)walk.next);
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    PAV_HIP(ctx, F->comp.reserve((size_t)n_in + 4096));
+    PAV_HIP(ctx, scratch_take(ctx->device, (size_t)n_in + 4096, F->comp));
     if (n_in) PAV_HIP(ctx, hipMemcpyAsync(F->comp.p, in, n_in, hipMemcpyHostToDevice, ctx->stream));
     uint64_t n = 0;
     const int rc = bgzf_inflate_device(ctx, ctx->stream, &F->inflate, F->comp.as<uint8_t>(), walk.M, F->raw, &n, "pav_bgzf_inflate");

@@ -27,6 +27,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 namespace pav {
@@ -294,6 +296,48 @@ const char *status_text(uint32_t s) {
 
 }  // namespace
 
+namespace {
+struct ScratchPool { std::mutex mu; std::vector<std::pair<int, DevBuf>> idle; };
+ScratchPool &scratch_pool() { static ScratchPool *P = new ScratchPool(); return *P; }   // (never destroyed: the HIP runtime may be gone by then)
+constexpr size_t SCRATCH_KEEP = 48ull << 30;
+}  // namespace
+
+hipError_t scratch_take(int device, size_t bytes, DevBuf &b) {
+    if (b.p && !b.view && b.cap >= bytes) return hipSuccess;
+    scratch_give(device, b);
+    ScratchPool &P = scratch_pool();
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        size_t best = P.idle.size();
+        for (size_t i = 0; i < P.idle.size(); ++i)
+            if (P.idle[i].first == device && P.idle[i].second.cap >= bytes && P.idle[i].second.cap <= 2 * bytes + (256ull << 20)
+                && (best == P.idle.size() || P.idle[i].second.cap < P.idle[best].second.cap)) best = i;
+        if (best < P.idle.size()) { b = P.idle[best].second; P.idle.erase(P.idle.begin() + (long)best); return hipSuccess; }
+    }
+    hipError_t e = b.reserve(bytes);
+    if (e != hipSuccess) {                              // out of memory with idle buffers held: let them go and try again
+        std::vector<DevBuf> drop;
+        { std::lock_guard<std::mutex> lk(P.mu); for (auto &x : P.idle) if (x.first == device) drop.push_back(x.second);
+          P.idle.erase(std::remove_if(P.idle.begin(), P.idle.end(), [&](const std::pair<int, DevBuf> &x) { return x.first == device; }), P.idle.end()); }
+        for (DevBuf &d : drop) d.release();
+        (void)hipGetLastError();
+        e = b.reserve(bytes);
+    }
+    return e;
+}
+
+void scratch_give(int device, DevBuf &b) {
+    if (!b.p || b.view) { b.p = nullptr; b.cap = 0; b.view = false; return; }
+    ScratchPool &P = scratch_pool();
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        size_t held = 0;
+        for (auto &x : P.idle) if (x.first == device) held += x.second.cap;
+        if (b.cap >= (64ull << 20) && held + b.cap <= SCRATCH_KEEP) { P.idle.emplace_back(device, b); b.p = nullptr; b.cap = 0; return; }
+    }
+    b.release();
+}
+
 void inflate_release(void **state) {
     if (!state || !*state) return;
     InflateDev *I = static_cast<InflateDev *>(*state);
@@ -311,7 +355,7 @@ int bgzf_inflate_device(pav_ctx *ctx, hipStream_t st, void **state, const uint8_
     const double t0 = wall();
     const uint32_t n = (uint32_t)M.in_off.size();
     *n_text = 0;
-    if (!n) { PAV_HIP(ctx, out.reserve(4096)); return PAV_OK; }
+    if (!n) { PAV_HIP(ctx, scratch_take(ctx->device, 4096, out)); return PAV_OK; }
     const uint32_t batch = std::min(n, BATCH_MEMBERS);
     PAV_HIP(ctx, I->mem.reserve(sizeof(BgzfMember) * (size_t)n));
     PAV_HIP(ctx, I->text_len.reserve(4ull * n));
@@ -319,7 +363,7 @@ int bgzf_inflate_device(pav_ctx *ctx, hipStream_t st, void **state, const uint8_
     PAV_HIP(ctx, I->bsum.reserve(8ull * (n / SCAN_TILE + 8)));
     PAV_HIP(ctx, I->status.reserve(4ull * n));
     PAV_HIP(ctx, I->n_tok.reserve(4ull * batch));
-    PAV_HIP(ctx, I->tok.reserve(4ull * TOK_STRIDE * batch));
+    PAV_HIP(ctx, scratch_take(ctx->device, 4ull * TOK_STRIDE * batch, I->tok));   // (back on the list when the text is there: see the end)
     PAV_HIP(ctx, I->scratch.reserve(sizeof(ifl::LaneScratch) * (size_t)batch));
     const size_t pin_need = std::max<size_t>(sizeof(BgzfMember) * (size_t)n, 4096);
     if (I->pin_cap < pin_need) {
@@ -347,7 +391,7 @@ int bgzf_inflate_device(pav_ctx *ctx, hipStream_t st, void **state, const uint8_
     PAV_HIP(ctx, hipMemcpyAsync(hm, I->mem.as<BgzfMember>() + (n - 1), sizeof(BgzfMember), hipMemcpyDeviceToHost, st));
     PAV_HIP(ctx, hipStreamSynchronize(st));
     const uint64_t total = hm[0].out_off + hm[0].text_len;
-    PAV_HIP(ctx, out.reserve(total + 4096));
+    PAV_HIP(ctx, scratch_take(ctx->device, total + 4096, out));
     const double t1 = wall();
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     if (timing) { for (hipEvent_t &e : ev) PAV_HIP(ctx, hipEventCreate(&e)); PAV_HIP(ctx, hipEventRecord(ev[0], st)); }
@@ -375,6 +419,7 @@ int bgzf_inflate_device(pav_ctx *ctx, hipStream_t st, void **state, const uint8_
     for (uint32_t i = 0; i < n; ++i)
         if (hs[i]) return fail(ctx, PAV_E_ARG, "%s: corrupt BGZF member %u of %u (payload at byte %llu): %s", what, i, n, (unsigned long long)M.in_off[i], status_text(hs[i]));
     *n_text = total;
+    scratch_give(ctx->device, I->tok);
     if (timing) {
         fprintf(stderr, "[pav timing] bgzf_inflate_device: %u members, %.1f MB of text; places %.1f ms, inflate + crc %.1f ms (%.1f GB/s): k_inflate_tokens %.2f ms, k_inflate_resolve (+ CRC-32) %.2f ms\n",
                 n, (double)total / 1e6, (t1 - t0) * 1e3, (wall() - t1) * 1e3, (double)total / 1e9 / std::max(1e-9, wall() - t1), ms_tok, ms_res);
