@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <mutex>
 #include <thread>
 
 namespace pav {
@@ -153,9 +154,14 @@ struct FaDev {
     DevBuf comp, hdr_off, hdr_text;                      // a bgzipped file: its bytes as they are on disk; the header lines packed for the host
     void *inflate = nullptr;                             // scratch of the device inflate (inflate.hip)
     void *pin = nullptr; size_t pin_cap = 0;
+    hipStream_t st = nullptr;                            // the role's own stream: the two files of a haplotype are loaded side by side, one's
+                                                         // upload and inflate beside the other's (their kernels fill a CU's LDS half each)
 };
 
-struct FaDevPair { FaDev role[2]; FaDev other; };        // one scratch per role: the two stores of a context may be loaded side by side
+struct FaDevPair {
+    FaDev role[2]; FaDev other;
+    std::mutex wire;        // one BGZF file crosses PCIe at a time: the first is being inflated while the second crosses, instead of both
+};                          // arriving late and the device idle till then        // one scratch per role: the two stores of a context may be loaded side by side
                                                          // (other: pav_bgzf_inflate)
 
 // The members of a BGZF file, found while its bytes pass through the upload ring: a member's header says how long the member is,
@@ -185,6 +191,8 @@ struct BgzfWalk {
 };
 
 FaDev *fstate(pav_ctx *ctx, int role) {
+    static std::mutex first;                             // (the two roles' loads may be the first users of the context at the same moment)
+    std::lock_guard<std::mutex> lk(first);
     if (!ctx->fa_dev) ctx->fa_dev = new FaDevPair();
     return &static_cast<FaDevPair *>(ctx->fa_dev)->role[role];
 }
@@ -192,7 +200,7 @@ FaDev *fstate(pav_ctx *ctx, int role) {
 double wall() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // the whole file -> d_raw, through the pinned ring: `threads` readers fill a slot, the slot crosses PCIe while the next is filled
-int stream_file(pav_ctx *ctx, int role, int fd, uint64_t n, uint8_t *d_raw, int threads, BgzfWalk *walk = nullptr) {
+int stream_file(pav_ctx *ctx, hipStream_t st, int role, int fd, uint64_t n, uint8_t *d_raw, int threads, BgzfWalk *walk = nullptr) {
     UploadRing *R = upload_ring(ctx, role);
     if (!R->ok) return fail(ctx, PAV_E_HIP, "pav_seq_load_fasta_path: no pinned memory for the upload ring");
     // PAV_FA_MMAP=1: the pieces are copied out of a mapping of the file instead of being read (a page fault per 4 KiB and an munmap of
@@ -228,8 +236,8 @@ int stream_file(pav_ctx *ctx, int role, int fd, uint64_t n, uint8_t *d_raw, int 
         for (auto &th : pool) th.join();
         if (bad) return fail(ctx, PAV_E_ARG, "pav_seq_load_fasta_path: read error");
         if (walk) walk->feed(stage, at, m, fd);
-        PAV_HIP(ctx, hipMemcpyAsync(d_raw + at, stage, m, hipMemcpyHostToDevice, ctx->stream));
-        PAV_HIP(ctx, hipEventRecord(R->ev[k], ctx->stream));
+        PAV_HIP(ctx, hipMemcpyAsync(d_raw + at, stage, m, hipMemcpyHostToDevice, st));
+        PAV_HIP(ctx, hipEventRecord(R->ev[k], st));
         R->busy[k] = true;
     }
     return PAV_OK;
@@ -246,6 +254,7 @@ void fastadev_release(pav_ctx *ctx) {
         for (DevBuf *b : {&F->raw, &F->tile_cnt, &F->tile_pre, &F->bsum, &F->hdr, &F->hdr_end, &F->rec, &F->kept, &F->counter, &F->comp, &F->hdr_off, &F->hdr_text}) b->release();
         inflate_release(&F->inflate);
         if (F->pin) (void)hipHostFree(F->pin);
+        if (F->st) (void)hipStreamDestroy(F->st);
     }
     delete P;
     ctx->fa_dev = nullptr;
@@ -264,7 +273,8 @@ int pav_seq_load_fasta_path(pav_ctx *ctx, int role, const char *path, int thread
     const double t0 = wall();
     PAV_HIP(ctx, hipSetDevice(ctx->device));
     FaDev *F = fstate(ctx, role);
-    hipStream_t st = ctx->stream;
+    if (!F->st) PAV_HIP(ctx, hipStreamCreateWithFlags(&F->st, hipStreamNonBlocking));
+    hipStream_t st = F->st;
     // ---- the text of the file into HBM --------------------------------------------------------------------------------
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return fail(ctx, PAV_E_ARG, "pav_seq_load_fasta_path: cannot open %s", path);
@@ -288,7 +298,9 @@ int pav_seq_load_fasta_path(pav_ctx *ctx, int role, const char *path, int thread
         if (!(e && !strcmp(e, "host")) && got >= 18 && 12ull + (h[10] | (uint32_t)h[11] << 8) <= (uint64_t)got && bgzf_block(h, (size_t)sb.st_size, bsize, hdr)) {
             BgzfWalk walk; walk.size = (uint64_t)sb.st_size;
             PAV_HIP(ctx, scratch_take(ctx->device, (size_t)sb.st_size + 4096, F->comp));
-            const int rc = stream_file(ctx, role, fd, (uint64_t)sb.st_size, F->comp.as<uint8_t>(), threads, &walk);
+            int rc;
+            { std::lock_guard<std::mutex> wire(static_cast<FaDevPair *>(ctx->fa_dev)->wire);
+              rc = stream_file(ctx, st, role, fd, (uint64_t)sb.st_size, F->comp.as<uint8_t>(), threads, &walk); }
             if (rc != PAV_OK) return rc;
             if (!walk.bad && walk.next == (uint64_t)sb.st_size) {
                 const int ri = bgzf_inflate_device(ctx, st, &F->inflate, F->comp.as<uint8_t>(), walk.M, F->raw, &n, path);
@@ -313,11 +325,11 @@ int pav_seq_load_fasta_path(pav_ctx *ctx, int role, const char *path, int thread
     if (!F->pin) { PAV_HIP(ctx, hipHostMalloc(&F->pin, 1 << 20, hipHostMallocDefault)); F->pin_cap = 1 << 20; }
     if (on_device) {}                                        // (the text is there)
     else if (compressed) { const int rc = staged_upload(ctx, st, F->raw.as<uint8_t>(), ft.text, n, role); if (rc != PAV_OK) return rc; }
-    else { const int rc = stream_file(ctx, role, fd, n, F->raw.as<uint8_t>(), threads); if (rc != PAV_OK) return rc; }
+    else { const int rc = stream_file(ctx, st, role, fd, n, F->raw.as<uint8_t>(), threads); if (rc != PAV_OK) return rc; }
     const double t1 = wall();
     // ---- records ------------------------------------------------------------------------------------------------------
     PAV_HIP(ctx, hipMemsetAsync(F->counter.p, 0, 64, st));
-    if (n_tiles) PAV_LAUNCH(ctx, "k_fa_marks", k_fa_marks, (n_tiles + 3) / 4, 256, 0, F->raw.as<uint8_t>(), n, F->tile_cnt.as<uint32_t>(), F->hdr.as<uint64_t>(),
+    if (n_tiles) PAV_LAUNCH_ON(ctx, st, "k_fa_marks", k_fa_marks, (n_tiles + 3) / 4, 256, 0, F->raw.as<uint8_t>(), n, F->tile_cnt.as<uint32_t>(), F->hdr.as<uint64_t>(),
                             F->counter.as<uint32_t>(), hdr_cap);
     { const int rc = scan_u32_to_u64(st, F->tile_cnt.as<uint32_t>(), n_tiles, F->bsum.as<uint64_t>(), F->tile_pre.as<uint64_t>());
       if (rc != PAV_OK) return fail(ctx, rc, "%s", pav_last_error(nullptr)); }
@@ -333,7 +345,7 @@ int pav_seq_load_fasta_path(pav_ctx *ctx, int role, const char *path, int thread
         PAV_HIP(ctx, hipMemcpy(hdr.data(), F->hdr.p, 8ull * n_hdr, hipMemcpyDeviceToHost));
         std::sort(hdr.begin(), hdr.end());
         PAV_HIP(ctx, hipMemcpyAsync(F->hdr.p, hdr.data(), 8ull * n_hdr, hipMemcpyHostToDevice, st));
-        PAV_LAUNCH(ctx, "k_fa_hdr_end", k_fa_hdr_end, (n_hdr + 63) / 64, 64, 0, F->raw.as<uint8_t>(), n, F->hdr.as<uint64_t>(), n_hdr, F->hdr_end.as<uint64_t>());
+        PAV_LAUNCH_ON(ctx, st, "k_fa_hdr_end", k_fa_hdr_end, (n_hdr + 63) / 64, 64, 0, F->raw.as<uint8_t>(), n, F->hdr.as<uint64_t>(), n_hdr, F->hdr_end.as<uint64_t>());
         PAV_HIP(ctx, hipMemcpyAsync(hend.data(), F->hdr_end.p, 8ull * n_hdr, hipMemcpyDeviceToHost, st));
         PAV_HIP(ctx, hipStreamSynchronize(st));
     }
@@ -348,7 +360,7 @@ int pav_seq_load_fasta_path(pav_ctx *ctx, int role, const char *path, int thread
         PAV_HIP(ctx, F->hdr_off.reserve(8ull * n_hdr));
         PAV_HIP(ctx, F->hdr_text.reserve(hoff[n_hdr] + 64));
         PAV_HIP(ctx, hipMemcpyAsync(F->hdr_off.p, hoff.data(), 8ull * n_hdr, hipMemcpyHostToDevice, st));
-        PAV_LAUNCH(ctx, "k_fa_hdr_copy", k_fa_hdr_copy, n_hdr, 64, 0, F->raw.as<uint8_t>(), F->hdr.as<uint64_t>(), F->hdr_end.as<uint64_t>(), F->hdr_off.as<uint64_t>(),
+        PAV_LAUNCH_ON(ctx, st, "k_fa_hdr_copy", k_fa_hdr_copy, n_hdr, 64, 0, F->raw.as<uint8_t>(), F->hdr.as<uint64_t>(), F->hdr_end.as<uint64_t>(), F->hdr_off.as<uint64_t>(),
                    n_hdr, F->hdr_text.as<uint8_t>());
         htext.resize((size_t)hoff[n_hdr] + 1);
         PAV_HIP(ctx, hipMemcpyAsync(htext.data(), F->hdr_text.p, hoff[n_hdr], hipMemcpyDeviceToHost, st));
@@ -375,7 +387,7 @@ int pav_seq_load_fasta_path(pav_ctx *ctx, int role, const char *path, int thread
         PAV_HIP(ctx, F->rec.reserve(sizeof(FaRec) * n_hdr));
         PAV_HIP(ctx, F->kept.reserve(8ull * n_hdr));
         PAV_HIP(ctx, hipMemcpyAsync(F->rec.p, rec.data(), sizeof(FaRec) * n_hdr, hipMemcpyHostToDevice, st));
-        PAV_LAUNCH(ctx, "k_fa_records", k_fa_records, (n_hdr + 63) / 64, 64, 0, F->raw.as<uint8_t>(), F->tile_pre.as<uint64_t>(), F->rec.as<FaRec>(), n_hdr,
+        PAV_LAUNCH_ON(ctx, st, "k_fa_records", k_fa_records, (n_hdr + 63) / 64, 64, 0, F->raw.as<uint8_t>(), F->tile_pre.as<uint64_t>(), F->rec.as<FaRec>(), n_hdr,
                    F->kept.as<uint64_t>());
         PAV_HIP(ctx, hipMemcpyAsync(kept.data(), F->kept.p, 8ull * n_hdr, hipMemcpyDeviceToHost, st));
         PAV_HIP(ctx, hipStreamSynchronize(st));
@@ -411,7 +423,7 @@ int pav_bgzf_inflate(pav_ctx *ctx, const uint8_t *in, uint64_t n_in, uint8_t *ou
     if (!ctx || (n_in && !in) || !out_len) return fail(ctx, PAV_E_ARG, "pav_bgzf_inflate: bad argument");
     *out_len = 0;
     PAV_HIP(ctx, hipSetDevice(ctx->device));
-    if (!ctx->fa_dev) ctx->fa_dev = new FaDevPair();
+    (void)fstate(ctx, 0);
     FaDev *F = &static_cast<FaDevPair *>(ctx->fa_dev)->other;
     BgzfWalk walk; walk.size = n_in;
     walk.feed(in, 0, n_in, -1);
