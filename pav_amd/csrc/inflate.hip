@@ -207,23 +207,29 @@ __global__ __launch_bounds__(64) void k_inflate_resolve(const uint32_t *__restri
             // bytes (the few that do - a distance under eight, shorter than the length - are the wave's, above), and what a copy reads
             // of its own output was written an iteration ago.  A copy of eight bytes or more ends with its last eight bytes written
             // again rather than fewer than eight; a shorter one is two overlapping words, or three bytes.
-            uint32_t k = 0;
-            while (__ballot(go && k < len)) {
+            if (go) {                                     // the first eight bytes of every copy - all there is of most
+                if (PROF) ++pc[2];
+                uint64_t v;
+                __builtin_memcpy(&v, W + src, 8);
+                if (len >= 8u) __builtin_memcpy(W + start, &v, 8);
+                else if (len >= 4u) {
+                    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> (8u * (len - 4u)));
+                    __builtin_memcpy(W + start, &lo, 4);
+                    __builtin_memcpy(W + start + len - 4u, &hi, 4);
+                } else {
+                    const uint16_t lo = (uint16_t)v;
+                    __builtin_memcpy(W + start, &lo, 2);
+                    W[start + 2] = (uint8_t)(v >> 16);
+                }
+            }
+            uint32_t k = 8;
+            while (__ballot(go && k < len)) {             // the rest of the longer ones: a read and a write an iteration
                 if (PROF) ++pc[2];
                 if (go && k < len) {
-                    const uint32_t kk = (len >= 8u && k + 8u > len) ? len - 8u : k;
+                    const uint32_t kk = min(k, len - 8u);
                     uint64_t v;
                     __builtin_memcpy(&v, W + src + kk, 8);
-                    if (len >= 8u) __builtin_memcpy(W + start + kk, &v, 8);
-                    else if (len >= 4u) {
-                        const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> (8u * (len - 4u)));
-                        __builtin_memcpy(W + start, &lo, 4);
-                        __builtin_memcpy(W + start + len - 4u, &hi, 4);
-                    } else {
-                        const uint16_t lo = (uint16_t)v;
-                        __builtin_memcpy(W + start, &lo, 2);
-                        W[start + 2] = (uint8_t)(v >> 16);
-                    }
+                    __builtin_memcpy(W + start + kk, &v, 8);
                     k = kk + 8u;
                 }
             }
