@@ -60,6 +60,19 @@ cd $R
 python3 tools/prof_summary.py stats $(find $O/prof_e2e -name "*.db" | head -1) $P/${ROUND}_e2e_kernel_stats.txt > /dev/null
 sed -i "1i # Command: rocprofv3 --kernel-trace --stats -- python3 tools/bench_e2e.py --inv-sig-filter single_cluster --gzip-level 6  (one haplotype files to files: FASTA\n# loader, calls, flagging, scan, device text + gzip of the SNV / INS-DEL / density tables)" $P/${ROUND}_e2e_kernel_stats.txt
 find $O -name "*.db" -delete
+# the same files bgzipped - the form PAV keeps them in (rules/call.snakefile:796): members inflated on the device (the default), and by
+# host threads; the loader alone on a 3 GB assembly (device inflate / host inflate / plain text, one role and both), with the resolve
+# kernel's own cycle profile, and the kernel statistics of such a load
+python3 tools/bench_e2e.py --inv-sig-filter single_cluster --gzip-level 6 --repeat 6 --bgzf > $P/${ROUND}_e2e_files_to_files_bgzf.json 2> $O/e2e_bgzf.err
+PAV_FASTA_INFLATE=host python3 tools/bench_e2e.py --inv-sig-filter single_cluster --gzip-level 6 --repeat 2 --bgzf > $P/${ROUND}_e2e_files_to_files_bgzf_host_inflate.json 2> $O/e2e_bgzf_host.err
+python3 tools/bench_bgzf.py --mb 3000 2> $O/bgzf.err | tail -1 > $P/${ROUND}_bgzf_loader.json
+PAV_INFLATE_PROFILE=1 python3 tools/bench_bgzf.py --mb 1000 --repeat 1 2> $O/bgzf_prof.err | tail -1 > $P/${ROUND}_bgzf_loader_cycle_profile.json
+cd /tmp
+timeout -k 5 600 rocprofv3 --kernel-trace --stats -d $O/prof_bgzf -o bgzf -- python3 $R/tools/bench_bgzf.py --mb 3000 --repeat 2 > /dev/null 2> $O/prof_bgzf.err
+cd $R
+python3 tools/prof_summary.py stats $(find $O/prof_bgzf -name "*.db" | head -1) $P/${ROUND}_bgzf_loader_kernel_stats.txt > /dev/null
+sed -i "1i # Command: rocprofv3 --kernel-trace --stats -- python3 tools/bench_bgzf.py --mb 3000 --repeat 2  (a 3 GB bgzipped assembly into the sequence store:\n# device inflate, host inflate, plain text; one role twice each, then both roles side by side)" $P/${ROUND}_bgzf_loader_kernel_stats.txt
+find $O -name "*.db" -delete
 # the device gzip alone: GB/s and size against zlib for several search depths and windows
 python3 tools/bench_gzip.py --mb 200 --variants 11:4,11:6,11:8,11:32,12:4,12:6,12:8,12:16,13:8 > $P/${ROUND}_gzip_variants.json 2> $O/gzip.err
 # the product runner: six haplotypes of 0.77 Gbp on one rank, 1 / 2 / 4 lanes; the same with the process pinned to four cores
