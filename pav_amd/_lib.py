@@ -428,14 +428,31 @@ class Context:
         their CRC-32 and ISIZE; returns bytes.  A corrupt member raises, naming it (``pav_bgzf_inflate``)."""
         buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
         n = int(buf.shape[0])
-        # ISIZE of every member is in its footer; the text's length is their sum - asked for first with no room (PAV_E_LIMIT answers it)
+        # the text's length: the sum of the members' ISIZE, read from the footers here when every header is bgzip's own 18 bytes;
+        # otherwise asked of the library with no room for the text (PAV_E_LIMIT answers with the length)
         got = ctypes.c_uint64(0)
-        rc = self.lib.pav_bgzf_inflate(self.handle, buf.ctypes.data if n else None, n, None, 0, ctypes.byref(got))
-        if rc == 0 and got.value == 0:
-            return b''
-        if got.value == 0:
-            self._check(rc, 'pav_bgzf_inflate')
-        out = np.empty(int(got.value), dtype=np.uint8)
+        at, total, plain = 0, 0, True
+        while at < n:
+            if at + 28 > n or buf[at] != 0x1f or buf[at + 1] != 0x8b or buf[at + 10] != 6 or buf[at + 11] != 0 or buf[at + 12] != 66 or buf[at + 13] != 67:
+                plain = False
+                break
+            bsize = int(buf[at + 16]) + (int(buf[at + 17]) << 8) + 1
+            if at + bsize > n:
+                plain = False
+                break
+            total += int(buf[at + bsize - 4]) | int(buf[at + bsize - 3]) << 8 | int(buf[at + bsize - 2]) << 16 | int(buf[at + bsize - 1]) << 24
+            at += bsize
+        if plain:
+            got.value = total
+            if total == 0 and n == 0:
+                return b''
+        else:
+            rc = self.lib.pav_bgzf_inflate(self.handle, buf.ctypes.data if n else None, n, None, 0, ctypes.byref(got))
+            if rc == 0 and got.value == 0:
+                return b''
+            if got.value == 0:
+                self._check(rc, 'pav_bgzf_inflate')
+        out = np.empty(max(1, int(got.value)), dtype=np.uint8)
         self._check(self.lib.pav_bgzf_inflate(self.handle, buf.ctypes.data, n, out.ctypes.data, out.shape[0], ctypes.byref(got)), 'pav_bgzf_inflate')
         return out[:got.value].tobytes()
 

@@ -26,6 +26,8 @@ def main():
     ap.add_argument('--ranks', type=int, default=0, help='ranks of the second run (0 = one per visible GPU; skipped on a one-GPU box)')
     ap.add_argument('--share-gpu', action='store_true', help='all ranks on GPU 0 (see above: a correctness device, not a fast one)')
     ap.add_argument('--seed', type=int, default=1004)
+    ap.add_argument('--bgzf', action='store_true', help='the FASTA files bgzipped (ref.fa.gz, contigs_{hap}.fa.gz: the form PAV keeps them in); their members '
+                                                        'are inflated on the device (PAV_FASTA_INFLATE=host: by host threads)')
     ap.add_argument('--lanes', type=int, nargs='+', default=[1, 4], help="haplotypes a rank calls at the same time (config 'pav_amd_lanes'); one run per value")
     ap.add_argument('--gpus', type=int, default=0, help='ONE run on this many GPUs (one rank each, --lanes[0] lanes per rank) and ONE JSON line in the '
                                                        "schema of bench.py: metric haplotypes/s files to files, per-rank wall time, device and cores")
@@ -50,6 +52,12 @@ def main():
                 synth.write_fasta(os.path.join(work, 'in', 'ref.fa'), ref.names, ref.seqs, line=80)
             tig = os.path.join(d, f'contigs_{hname}.fa')
             synth.write_fasta(tig, hap.tig_names, hap.tig_seqs, line=80)
+            if args.bgzf:
+                for plain in ([os.path.join(work, 'in', 'ref.fa')] if h == 0 else []) + [tig]:
+                    synth.bgzip(plain, plain + '.gz', threads=min(16, effective_cpus()))
+                    shutil.copyfile(plain + '.fai', plain + '.gz.fai')
+                    os.remove(plain)
+                tig += '.gz'
             bed, bed_trim = os.path.join(d, f'aligned_tig_{hname}.bed.gz'), os.path.join(d, f'aligned_tig_{hname}.trim.bed.gz')
             df = hap.df_align.copy()
             if 'CALL_BATCH' not in df:
@@ -60,12 +68,13 @@ def main():
             aligned += hap.stats['aligned_bp']
             del hap
         t_inputs = time.time() - t0
-        out = {}
+        ref_fa = os.path.join(work, 'in', 'ref.fa' + ('.gz' if args.bgzf else ''))
+        out = {'fasta': ('BGZF, inflated on the ' + os.environ.get('PAV_FASTA_INFLATE', 'device')) if args.bgzf else 'plain text'}
         cfg = {'inv_sig_filter': 'single_cluster'}
         if args.gpus > 0:
             lanes = args.lanes[0]
             t0 = time.time()
-            ms = cohort.run_cohort(jobs, args.gpus, os.path.join(work, 'out'), os.path.join(work, 'in', 'ref.fa'),
+            ms = cohort.run_cohort(jobs, args.gpus, os.path.join(work, 'out'), ref_fa,
                                    config=dict(cfg, pav_amd_lanes=lanes), share_gpu=args.share_gpu, timeout=3600)
             dt = time.time() - t0
             per_rank = {}
@@ -79,7 +88,7 @@ def main():
                               'dtype': 'u8/u32 + f64', 'data': 'synthetic',
                               'aligned_Gbp_per_s': round(aligned / dt / 1e9, 3), 'wall_s': round(dt, 2), 'per_rank': [per_rank[k] for k in sorted(per_rank)],
                               'config': {'workload': f'{args.haplotypes} synthetic haplotypes of one hg38-shaped reference, scale {args.scale}, seed {args.seed}',
-                                         'lanes_per_rank': lanes, 'gzip_level': 6, 'writer': os.environ.get('PAV_WRITER', 'device'),
+                                         'lanes_per_rank': lanes, 'gzip_level': 6, 'writer': os.environ.get('PAV_WRITER', 'device'), 'fasta': out['fasta'],
                                          'inputs_written_s': round(t_inputs, 1), 'includes_process_start': args.gpus > 1}}))
             return
         import torch
@@ -89,7 +98,7 @@ def main():
         for world in worlds:
             for lanes in args.lanes:
                 t0 = time.time()
-                ms = cohort.run_cohort(jobs, world, os.path.join(work, f'out{world}_{lanes}'), os.path.join(work, 'in', 'ref.fa'),
+                ms = cohort.run_cohort(jobs, world, os.path.join(work, f'out{world}_{lanes}'), ref_fa,
                                        config=dict(cfg, pav_amd_lanes=lanes), share_gpu=args.share_gpu, timeout=3600)
                 dt = time.time() - t0
                 out[f'{world}_rank' + ('s' if world > 1 else '') + f'_{lanes}_lanes'] = {
