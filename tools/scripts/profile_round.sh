@@ -79,4 +79,6 @@ python3 tools/bench_gzip.py --mb 200 --variants 11:4,11:6,11:8,11:32,12:4,12:6,1
 python3 tools/bench_cohort.py --haplotypes 6 --lanes 1 2 4 2> $O/cohort.err | tail -1 > $P/${ROUND}_cohort.json
 taskset -c 0-3 python3 tools/bench_cohort.py --haplotypes 6 --lanes 1 2 2> $O/cohort4.err | tail -1 > $P/${ROUND}_cohort_4cores.json
 python3 tools/bench_cohort.py --haplotypes 6 --lanes 2 --gpus 1 2> $O/cohort_line.err | tail -1 > $P/${ROUND}_cohort_line.json
+python3 tools/bench_cohort.py --haplotypes 6 --lanes 1 2 4 --bgzf 2> $O/cohort_bgzf.err | tail -1 > $P/${ROUND}_cohort_bgzf.json
+PAV_FASTA_INFLATE=host python3 tools/bench_cohort.py --haplotypes 6 --lanes 2 --bgzf 2>> $O/cohort_bgzf.err | tail -1 > $P/${ROUND}_cohort_bgzf_host_inflate.json
 ls -la $P; du -sh $O
