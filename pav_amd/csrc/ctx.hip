@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <mutex>
 #include <thread>
 
 namespace pav {
@@ -238,10 +239,31 @@ namespace pav {
 
 struct UploadRings { UploadRing r[2]; };               // one per role: the two stores of a context may be loaded side by side
 
+// Rings that outlive their context (a process-wide list): 128 MB of pinned memory cost 21 ms to get and 10 ms to give back
+// (tools/ubench/pin_cost.hip: 0.165 ms per MB), twice per context - a tenth of a haplotype's files to files when every haplotype has a
+// context of its own.  A context takes its rings from the list and returns them; at most four idle rings are kept.
+namespace {
+struct RingPool { std::mutex mu; std::vector<std::pair<int, UploadRing>> idle; };
+RingPool &ring_pool() { static RingPool *P = new RingPool(); return *P; }
+void ring_free(UploadRing &R) {
+    for (int i = 0; i < UploadRing::SLOTS; ++i) { if (R.slot[i]) (void)hipHostFree(R.slot[i]); if (R.ev[i]) (void)hipEventDestroy(R.ev[i]); R.slot[i] = nullptr; R.ev[i] = nullptr; }
+}
+}  // namespace
+
 UploadRing *upload_ring(pav_ctx *ctx, int which) {
-    if (!ctx->upload) ctx->upload = new UploadRings();
+    {
+        static std::mutex first;                       // (the two roles' loads may be the first users of the context at the same moment)
+        std::lock_guard<std::mutex> lk(first);
+        if (!ctx->upload) ctx->upload = new UploadRings();
+    }
     UploadRing *R = &static_cast<UploadRings *>(ctx->upload)->r[which & 1];
     if (R->slot[0] || R->ok) return R;
+    {
+        RingPool &P = ring_pool();
+        std::lock_guard<std::mutex> lk(P.mu);
+        for (size_t i = 0; i < P.idle.size(); ++i)
+            if (P.idle[i].first == ctx->device) { *R = P.idle[i].second; P.idle.erase(P.idle.begin() + (long)i); return R; }
+    }
     R->ok = true;
     for (int i = 0; i < UploadRing::SLOTS && R->ok; ++i)
         R->ok = hipHostMalloc(&R->slot[i], UploadRing::SLOT_BYTES, hipHostMallocDefault) == hipSuccess &&
@@ -252,8 +274,18 @@ UploadRing *upload_ring(pav_ctx *ctx, int which) {
 void upload_release(pav_ctx *ctx) {
     if (!ctx || !ctx->upload) return;
     auto *P = static_cast<UploadRings *>(ctx->upload);
-    for (UploadRing &R : P->r)
-        for (int i = 0; i < UploadRing::SLOTS; ++i) { if (R.slot[i]) (void)hipHostFree(R.slot[i]); if (R.ev[i]) (void)hipEventDestroy(R.ev[i]); }
+    for (UploadRing &R : P->r) {
+        if (!R.slot[0]) continue;
+        bool kept = false;
+        if (R.ok) {
+            for (int i = 0; i < UploadRing::SLOTS; ++i) if (R.busy[i]) { (void)hipEventSynchronize(R.ev[i]); R.busy[i] = false; }
+            R.next = 0;
+            RingPool &G = ring_pool();
+            std::lock_guard<std::mutex> lk(G.mu);
+            if (G.idle.size() < 4) { G.idle.emplace_back(ctx->device, R); kept = true; }
+        }
+        if (!kept) ring_free(R);
+    }
     delete P;
     ctx->upload = nullptr;
 }

@@ -21,6 +21,7 @@
 #include "devgz.h"
 
 #include <algorithm>
+#include <mutex>
 #include <chrono>
 
 namespace pav {
@@ -356,11 +357,45 @@ __global__ __launch_bounds__(256) void k_gz_pack(const uint8_t *__restrict__ slo
 struct GzState {
     DevBuf segs, out, tok, slots, counter, dst, packed, text;   // text: the uploads of pav_gzip_buffers
     void *h_out = nullptr; size_t h_out_cap = 0;          // pinned: per-segment sizes + checksums
-    void *h_packed = nullptr; size_t h_packed_cap = 0;    // pinned: the files
+    void *h_packed = nullptr; size_t h_packed_cap = 0;    // the files (ordinary memory: host_reserve)
     std::vector<GzSegment> h_segs;
     std::vector<uint64_t> h_dst;
     int waves = 0, waves_wbits = 0;
 };
+
+// The files' bytes come back into ordinary memory: a device-to-host copy into it runs at the speed of one into pinned memory on
+// this platform (56 GB/s, tools/ubench/pin_cost.hip), and 300 MB of pinned memory cost 50 ms to get and 25 ms to give back - per
+// context.  The blocks outlive their context (a process-wide list, at most 1 GiB kept): pages touched once stay touched.
+struct HostBlocks { std::mutex mu; std::vector<std::pair<void *, size_t>> idle; };
+HostBlocks &host_blocks() { static HostBlocks *P = new HostBlocks(); return *P; }
+void host_give(void *&p, size_t &cap) {
+    if (!p) return;
+    HostBlocks &H = host_blocks();
+    {
+        std::lock_guard<std::mutex> lk(H.mu);
+        size_t held = 0;
+        for (auto &b : H.idle) held += b.second;
+        if (held + cap <= (1ull << 30)) { H.idle.emplace_back(p, cap); p = nullptr; cap = 0; return; }
+    }
+    free(p); p = nullptr; cap = 0;
+}
+int host_reserve(void *&p, size_t &cap, size_t bytes) {
+    if (bytes <= cap) return PAV_OK;
+    host_give(p, cap);
+    HostBlocks &H = host_blocks();
+    {
+        std::lock_guard<std::mutex> lk(H.mu);
+        size_t best = H.idle.size();
+        for (size_t i = 0; i < H.idle.size(); ++i)
+            if (H.idle[i].second >= bytes && (best == H.idle.size() || H.idle[i].second < H.idle[best].second)) best = i;
+        if (best < H.idle.size()) { p = H.idle[best].first; cap = H.idle[best].second; H.idle.erase(H.idle.begin() + (long)best); return PAV_OK; }
+    }
+    const size_t want = bytes + bytes / 4 + 4096;
+    void *q = nullptr;
+    if (posix_memalign(&q, 4096, want) != 0 || !q) return fail(nullptr, PAV_E_LIMIT, "gz_files: out of host memory (%zu bytes)", want);
+    p = q; cap = want;
+    return PAV_OK;
+}
 
 int pin_reserve(void *&p, size_t &cap, size_t bytes) {
     if (bytes <= cap) return PAV_OK;
@@ -379,7 +414,7 @@ void gz_release_slot(pav_ctx *ctx, void **slot) {
     (void)hipSetDevice(ctx->device);
     for (DevBuf *b : {&G->segs, &G->out, &G->tok, &G->slots, &G->counter, &G->dst, &G->packed, &G->text}) b->release();
     if (G->h_out) (void)hipHostFree(G->h_out);
-    if (G->h_packed) (void)hipHostFree(G->h_packed);
+    host_give(G->h_packed, G->h_packed_cap);
     delete G;
     *slot = nullptr;
 }
@@ -478,7 +513,7 @@ int gz_files(pav_ctx *ctx, void **slot, hipStream_t st, const uint8_t *d_text, u
         out.len[f] = at - out.off[f];
     }
     W_HIP(G->packed.reserve(at + 64));
-    { int rc = pin_reserve(G->h_packed, G->h_packed_cap, at + 64); if (rc != PAV_OK) return rc; }
+    { int rc = host_reserve(G->h_packed, G->h_packed_cap, at + 64); if (rc != PAV_OK) return rc; }
     W_HIP(hipMemcpyAsync(G->dst.p, dst.data(), 8ull * n_segs, hipMemcpyHostToDevice, st));
     W_LAUNCH(st, k_gz_pack, n_segs, 256, 0, G->slots.as<uint8_t>(), slot_bytes, G->out.as<GzSegOut>(), G->dst.as<uint64_t>(),
                   n_segs, G->packed.as<uint8_t>());
