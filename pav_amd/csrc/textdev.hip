@@ -12,6 +12,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
+#include <string>
+#include <thread>
 
 #include "devgz.h"
 #include "fmt_dev.h"
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(256) void k_indel_keys(const pav_indel *__restrict_
 struct TextDev {
     hipStream_t st = nullptr;
     DevBuf len, roff, bsum, text, small, sort_a, sort_b, sort_tmp, snv_out, longs;
-    void *gz = nullptr;
+    void *gz = nullptr, *gz2 = nullptr;                   // gzip scratch; the second one: groups of files compressed while the group before is written
     void *pin = nullptr; size_t pin_cap = 0;              // descriptors up, totals down
     void *pin_text = nullptr; size_t pin_text_cap = 0;    // the text of files written without gzip
     int open(pav_ctx *ctx) {
@@ -235,6 +237,7 @@ struct TextDev {
     void release(pav_ctx *ctx) {
         for (DevBuf *b : {&len, &roff, &bsum, &text, &small, &sort_a, &sort_b, &sort_tmp, &snv_out, &longs}) b->release();
         gz_release_slot(ctx, &gz);
+        gz_release_slot(ctx, &gz2);
         if (pin) (void)hipHostFree(pin);
         if (pin_text) (void)hipHostFree(pin_text);
         if (st) (void)hipStreamDestroy(st);
@@ -283,13 +286,45 @@ int emit_files(pav_ctx *ctx, TextDev &D, uint64_t text_alloc, const std::vector<
     std::vector<GzFile> gz; std::vector<size_t> gz_ix;
     for (size_t f = 0; f < files.size(); ++f) if (ends_gz(paths[f])) { gz.push_back(files[f]); gz_ix.push_back(f); }
     if (!gz.empty()) {
-        GzOut out;
         if (getenv("PAV_TIMING")) W_HIP(hipStreamSynchronize(D.st));    // (so that the gzip's own time is what gz_files prints)
-        int rc = gz_files(ctx, &D.gz, D.st, D.text.as<uint8_t>(), text_alloc, gz, level, out);
-        if (rc != PAV_OK) return rc;
+        // Many files (the density tables of a haplotype: a hundred, 0.85 GB of text): in two groups (PAV_WRITER_GROUPS; a group's compression is whole rounds of the persistent waves: more groups, more part-filled rounds), the files of a group written by
+        // a thread of their own while the next group is compressed (two scratch sets take turns).  One file, or little text: one call.
+        uint64_t total = 0;
+        for (const GzFile &g : gz) total += g.text_len;
+        std::vector<size_t> cut{0};
+        static const uint64_t groups = [] { const char *e = getenv("PAV_WRITER_GROUPS"); const int v = e ? atoi(e) : 0; return (uint64_t)(v > 0 ? v : 2); }();
+        if (gz.size() >= 8 && total >= (64ull << 20) && groups > 1) {
+            uint64_t acc = 0;
+            for (size_t q = 0; q < gz.size(); ++q) {
+                acc += gz[q].text_len;
+                if (acc >= total / groups * cut.size() && cut.size() < groups && q + 1 < gz.size()) cut.push_back(q + 1);
+            }
+        }
+        cut.push_back(gz.size());
+        std::thread writer[2];
+        int rc_w[2] = {PAV_OK, PAV_OK};
+        std::string err_w[2];
+        void **slot[2] = {&D.gz, &D.gz2};
         const double t0 = wall_now();
-        for (size_t q = 0; q < gz.size(); ++q) { rc = write_file(paths[gz_ix[q]], out.host + out.off[q], out.len[q]); if (rc != PAV_OK) return rc; }
-        if (getenv("PAV_TIMING")) fprintf(stderr, "[pav timing] table files written in %.1f ms\n", (wall_now() - t0) * 1e3);
+        int rc = PAV_OK;
+        for (size_t g = 0; g + 1 < cut.size() && rc == PAV_OK; ++g) {
+            const int s2 = (int)(g & 1);
+            if (writer[s2].joinable()) writer[s2].join();          // the group that used this scratch before is on disk
+            if (rc_w[s2] != PAV_OK) break;
+            const std::vector<GzFile> part(gz.begin() + (long)cut[g], gz.begin() + (long)cut[g + 1]);
+            GzOut out;
+            rc = gz_files(ctx, slot[s2], D.st, D.text.as<uint8_t>(), text_alloc, part, level, out);
+            if (rc != PAV_OK) break;
+            const size_t a = cut[g];
+            writer[s2] = std::thread([&, s2, a, out] {
+                for (size_t q = 0; q < out.off.size() && rc_w[s2] == PAV_OK; ++q) rc_w[s2] = write_file(paths[gz_ix[a + q]], out.host + out.off[q], out.len[q]);
+                if (rc_w[s2] != PAV_OK) err_w[s2] = pav_last_error(nullptr);
+            });
+        }
+        for (std::thread &w : writer) if (w.joinable()) w.join();
+        if (rc != PAV_OK) return rc;
+        for (int s2 = 0; s2 < 2; ++s2) if (rc_w[s2] != PAV_OK) return fail(nullptr, rc_w[s2], "%s", err_w[s2].c_str());
+        if (getenv("PAV_TIMING")) fprintf(stderr, "[pav timing] %zu table files compressed and written in %.1f ms (%zu group(s))\n", gz.size(), (wall_now() - t0) * 1e3, cut.size() - 1);
     }
     for (size_t f = 0; f < files.size(); ++f) {
         if (ends_gz(paths[f])) continue;
