@@ -20,6 +20,16 @@ constexpr int WAVE = 64;                 // CDNA wavefront
 constexpr int DIRTY_SHIFT = 10;          // granularity of SeqView::dirty (1024 bases = what one wave packs per load)
 constexpr uint64_t SEQ_ALIGN = 256;      // every record starts on a 256-base boundary of the arena
 
+// ---- device blocks that outlive their context (ctx.hip) --------------------------------------------------------------------
+// A haplotype per context - allocated, used, destroyed - is how Snakemake-style drivers and tools/bench_e2e.py use the library, and a
+// context's large buffers are 25 GB (two sequence stores, the file text and token lists of the loaders, the writers' text).  Freed HBM
+// is cleared by the driver before it is handed out again: every other context of a run waited 0.4 - 0.65 s in hipMalloc for the clearing
+// of what the context before it had freed (`profiles/r05_e2e_soak.txt`).  Blocks of 32 MB and more therefore go back to a process-wide
+// list per GPU instead of to the driver (at most 64 GB kept, the rest freed), and come from it.  dev_block_put waits for the device
+// first, as hipFree does.  PAV_DEVICE_POOL=0: plain hipMalloc / hipFree.
+hipError_t dev_block_get(void **p, size_t *cap, size_t want);
+void dev_block_put(void *p, size_t cap);
+
 // ---- grow-only device buffer ------------------------------------------------------------------------------
 struct DevBuf {
     void *p = nullptr;
@@ -28,30 +38,23 @@ struct DevBuf {
     hipError_t reserve(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
         if (view) { p = nullptr; cap = 0; view = false; }                     // outgrown: from here on an allocation of its own
-        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
-        size_t want = bytes + bytes / 8 + 256;
-        hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) { p = nullptr; return e; }
-        cap = want;
-        return hipSuccess;
+        if (p) { dev_block_put(p, cap); p = nullptr; cap = 0; }
+        return dev_block_get(&p, &cap, bytes + bytes / 8 + 256);
     }
-    // At least `bytes`, and when it has to grow exactly `bytes` (buffers that change hands must not outgrow each other in turn)
+    // At least `bytes`, and when it has to grow `bytes` without the margin (buffers that change hands must not outgrow each other in turn)
     hipError_t reserve_exact(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
         if (view) { p = nullptr; cap = 0; view = false; }
-        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e != hipSuccess) { p = nullptr; return e; }
-        cap = bytes;
-        return hipSuccess;
+        if (p) { dev_block_put(p, cap); p = nullptr; cap = 0; }
+        return dev_block_get(&p, &cap, bytes);
     }
     // Make this buffer `bytes` of another allocation (several small buffers laid out in one arena travel in one copy and are
     // cleared by one fill).  An allocation of its own is given up.
     void alias(void *q, size_t bytes) {
-        if (p && !view) (void)hipFree(p);
+        if (p && !view) dev_block_put(p, cap);
         p = q; cap = bytes; view = true;
     }
-    void release() { if (p && !view) (void)hipFree(p); p = nullptr; cap = 0; view = false; }
+    void release() { if (p && !view) dev_block_put(p, cap); p = nullptr; cap = 0; view = false; }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 

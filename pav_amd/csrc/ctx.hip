@@ -239,6 +239,59 @@ namespace pav {
 
 struct UploadRings { UploadRing r[2]; };               // one per role: the two stores of a context may be loaded side by side
 
+}  // namespace pav
+
+// ---- the process-wide list of idle device blocks (common.h) -------------------------------------------------------------------
+namespace {
+struct BlockPool { std::mutex mu; struct B { int dev; void *p; size_t cap; }; std::vector<B> idle; };
+BlockPool &block_pool() { static BlockPool *P = new BlockPool(); return *P; }    // (never destroyed: the HIP runtime may be gone by then)
+constexpr size_t BLOCK_MIN = 32ull << 20, BLOCK_KEEP = 64ull << 30;
+bool block_pool_on() { static const bool on = [] { const char *e = getenv("PAV_DEVICE_POOL"); return !(e && e[0] == '0'); }(); return on; }
+}  // namespace
+
+hipError_t pav::dev_block_get(void **p, size_t *cap, size_t want) {
+    *p = nullptr; *cap = 0;
+    int dev = 0;
+    if (want >= BLOCK_MIN && block_pool_on() && hipGetDevice(&dev) == hipSuccess) {
+        BlockPool &P = block_pool();
+        std::lock_guard<std::mutex> lk(P.mu);
+        size_t best = P.idle.size();
+        for (size_t i = 0; i < P.idle.size(); ++i)           // the smallest idle block that holds it without wasting more than it holds
+            if (P.idle[i].dev == dev && P.idle[i].cap >= want && P.idle[i].cap <= 2 * want + (256ull << 20)
+                && (best == P.idle.size() || P.idle[i].cap < P.idle[best].cap)) best = i;
+        if (best < P.idle.size()) { *p = P.idle[best].p; *cap = P.idle[best].cap; P.idle.erase(P.idle.begin() + (long)best); return hipSuccess; }
+    }
+    hipError_t e = hipMalloc(p, want);
+    if (e != hipSuccess && block_pool_on()) {               // out of memory with idle blocks held: let them go and try again
+        (void)hipGetLastError();
+        std::vector<BlockPool::B> drop;
+        { BlockPool &P = block_pool(); std::lock_guard<std::mutex> lk(P.mu);
+          for (auto &b : P.idle) if (b.dev == dev) drop.push_back(b);
+          P.idle.erase(std::remove_if(P.idle.begin(), P.idle.end(), [&](const BlockPool::B &b) { return b.dev == dev; }), P.idle.end()); }
+        for (auto &b : drop) (void)hipFree(b.p);
+        e = hipMalloc(p, want);
+    }
+    if (e != hipSuccess) { *p = nullptr; return e; }
+    *cap = want;
+    return hipSuccess;
+}
+
+void pav::dev_block_put(void *p, size_t cap) {
+    if (!p) return;
+    int dev = 0;
+    if (cap >= BLOCK_MIN && block_pool_on() && hipGetDevice(&dev) == hipSuccess) {
+        (void)hipDeviceSynchronize();                       // what hipFree would have waited for: nothing queued still uses the block
+        BlockPool &P = block_pool();
+        std::lock_guard<std::mutex> lk(P.mu);
+        size_t held = 0;
+        for (auto &b : P.idle) if (b.dev == dev) held += b.cap;
+        if (held + cap <= BLOCK_KEEP) { P.idle.push_back(BlockPool::B{dev, p, cap}); return; }
+    }
+    (void)hipFree(p);
+}
+
+namespace pav {
+
 // Rings that outlive their context (a process-wide list): 128 MB of pinned memory cost 21 ms to get and 10 ms to give back
 // (tools/ubench/pin_cost.hip: 0.165 ms per MB), twice per context - a tenth of a haplotype's files to files when every haplotype has a
 // context of its own.  A context takes its rings from the list and returns them; at most four idle rings are kept.

@@ -302,45 +302,13 @@ const char *status_text(uint32_t s) {
 
 }  // namespace
 
-namespace {
-struct ScratchPool { std::mutex mu; std::vector<std::pair<int, DevBuf>> idle; };
-ScratchPool &scratch_pool() { static ScratchPool *P = new ScratchPool(); return *P; }   // (never destroyed: the HIP runtime may be gone by then)
-constexpr size_t SCRATCH_KEEP = 48ull << 30;
-}  // namespace
-
 hipError_t scratch_take(int device, size_t bytes, DevBuf &b) {
-    if (b.p && !b.view && b.cap >= bytes) return hipSuccess;
-    scratch_give(device, b);
-    ScratchPool &P = scratch_pool();
-    {
-        std::lock_guard<std::mutex> lk(P.mu);
-        size_t best = P.idle.size();
-        for (size_t i = 0; i < P.idle.size(); ++i)
-            if (P.idle[i].first == device && P.idle[i].second.cap >= bytes && P.idle[i].second.cap <= 2 * bytes + (256ull << 20)
-                && (best == P.idle.size() || P.idle[i].second.cap < P.idle[best].second.cap)) best = i;
-        if (best < P.idle.size()) { b = P.idle[best].second; P.idle.erase(P.idle.begin() + (long)best); return hipSuccess; }
-    }
-    hipError_t e = b.reserve(bytes);
-    if (e != hipSuccess) {                              // out of memory with idle buffers held: let them go and try again
-        std::vector<DevBuf> drop;
-        { std::lock_guard<std::mutex> lk(P.mu); for (auto &x : P.idle) if (x.first == device) drop.push_back(x.second);
-          P.idle.erase(std::remove_if(P.idle.begin(), P.idle.end(), [&](const std::pair<int, DevBuf> &x) { return x.first == device; }), P.idle.end()); }
-        for (DevBuf &d : drop) d.release();
-        (void)hipGetLastError();
-        e = b.reserve(bytes);
-    }
-    return e;
+    (void)device;                                       // (the block list of common.h is per current device)
+    return b.reserve_exact(bytes);
 }
 
 void scratch_give(int device, DevBuf &b) {
-    if (!b.p || b.view) { b.p = nullptr; b.cap = 0; b.view = false; return; }
-    ScratchPool &P = scratch_pool();
-    {
-        std::lock_guard<std::mutex> lk(P.mu);
-        size_t held = 0;
-        for (auto &x : P.idle) if (x.first == device) held += x.second.cap;
-        if (b.cap >= (64ull << 20) && held + b.cap <= SCRATCH_KEEP) { P.idle.emplace_back(device, b); b.p = nullptr; b.cap = 0; return; }
-    }
+    (void)device;
     b.release();
 }
 

@@ -23,11 +23,9 @@ int bgzf_inflate_device(pav_ctx *ctx, hipStream_t st, void **state, const uint8_
                         const char *what);
 void inflate_release(void **state);
 
-// Large device scratch that outlives a context (a process-wide list per GPU): the file's bytes, its text and the token lists of a
-// 3 GB FASTA are 10 GB a role - a haplotype per context, allocated and freed each time, had the driver clear tens of GB of HBM per
-// haplotype, and every few contexts an allocation waited seconds for it.  scratch_take gives a buffer of at least `bytes` (one from
-// the list when it fits without wasting more than it holds, a new one otherwise); scratch_give returns it (at most 48 GB are kept per
-// GPU; the rest is freed).  The buffer must be idle: no kernel or copy that uses it still queued.
+// The loaders' large scratch - the file's bytes, its text, the token lists: 10 GB a role - is taken for a load and given back after it
+// (the process-wide block list of common.h keeps it for the next load, the other role's or the next haplotype's).  The buffer must be
+// idle when it is given back.
 hipError_t scratch_take(int device, size_t bytes, DevBuf &b);
 void scratch_give(int device, DevBuf &b);
 
