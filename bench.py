@@ -625,6 +625,38 @@ def main():
                            'mirror needs ~13 us per row, the reference ~410 us per row (BASELINE.md)'}
         finally:
             shutil.rmtree(tmp_out, ignore_errors=True)
+        # The input side of a haplotype: a bgzipped FASTA file (the form PAV keeps them in: rules/call.snakefile:796) into the sequence
+        # store - members inflated on the device (inflate.hip) against the same file inflated by host threads, on a 1 GB sample of a
+        # synthetic assembly (tools/bench_bgzf.py has the 3 GB figures; `profiles/r05_bgzf_loader.json`).  Not part of `value`.
+        if e2e is not None and not args.no_cpu_baseline:
+            try:
+                from pav_amd import synth as _synth
+                from tools.bench_bgzf import assembly_text
+                tmp_fa = tempfile.mkdtemp(prefix='pav_bench_fa_')
+                try:
+                    plain, gz = os.path.join(tmp_fa, 'asm.fa'), os.path.join(tmp_fa, 'asm.fa.gz')
+                    n_rec = assembly_text(plain, 1000)
+                    _synth.bgzip(plain, gz, threads=min(16, effective_cpus()))
+                    res = {'text_bytes': os.path.getsize(plain), 'bgzf_bytes': os.path.getsize(gz), 'records': n_rec}
+                    with _lib.Context(0) as c2:
+                        for name, path, env in (('bgzf_device_inflate_s', gz, None), ('bgzf_host_inflate_s', gz, 'host'), ('plain_text_s', plain, None)):
+                            if env:
+                                os.environ['PAV_FASTA_INFLATE'] = env
+                            ts = []
+                            for _ in range(3):
+                                t0 = time.perf_counter()
+                                c2.seq_load_fasta_path(_lib.PAV_ROLE_TIG, path)
+                                c2.sync()
+                                ts.append(round(time.perf_counter() - t0, 4))
+                            os.environ.pop('PAV_FASTA_INFLATE', None)
+                            res[name] = min(ts)
+                    res['note'] = ('pav_seq_load_fasta_path, best of three: file -> pinned ring -> HBM, BGZF members inflated by a lane each (tokens) and a '
+                                   'wave each (copies in an LDS window, CRC-32 checked), header lines and line breaks removed on the device')
+                    e2e['fasta_loader'] = res
+                finally:
+                    shutil.rmtree(tmp_fa, ignore_errors=True)
+            except Exception as ex:                                 # (a measurement beside the line, never the line's failure)
+                e2e['fasta_loader'] = {'error': repr(ex)}
 
     if rank == 0:
         ms_per_step = t_max / args.steps * 1e3
