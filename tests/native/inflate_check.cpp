@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <random>
 #include <string>
 #include <vector>
@@ -175,6 +176,9 @@ int main(int argc, char **argv) {
         { std::vector<uint8_t> t(65536); for (size_t i = 0; i < t.size(); ++i) t[i] = (uint8_t)(i * 7 + (i >> 8)); texts.push_back(t); }
         { std::string s; for (int i = 0; s.size() < 60000; ++i) s += ">tig" + std::to_string(i) + " len=" + std::to_string(i * 977) + "\nACGTTGCA\n"; texts.push_back(std::vector<uint8_t>(s.begin(), s.end())); }
         { std::vector<uint8_t> t(65536); for (size_t i = 0; i < t.size(); ++i) t[i] = (uint8_t)(rng() % 200 < 199 ? 'a' + rng() % 3 : rng()); texts.push_back(t); }   // long codes for the rare bytes
+        { std::vector<uint8_t> t; uint32_t a = 1, b = 1;                      // counts that grow like Fibonacci numbers: codes of every length up to 15 bits
+          for (int i = 0; i < 24; ++i) { t.insert(t.end(), a, (uint8_t)(33 + i)); const uint32_t c = a + b; a = b; b = c; }
+          std::shuffle(t.begin(), t.end(), rng); t.resize(65000); texts.push_back(t); }
         const int strategies[] = {Z_DEFAULT_STRATEGY, Z_FILTERED, Z_HUFFMAN_ONLY, Z_RLE, Z_FIXED};
         for (const auto &t : texts) for (int level = 0; level <= 9; ++level) for (int st : strategies) {
             if (level == 0 && st != Z_DEFAULT_STRATEGY) continue;

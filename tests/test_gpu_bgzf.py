@@ -91,6 +91,31 @@ def test_runs_random_bytes_and_rare_symbols(ctx):
     assert ctx.bgzf_inflate(bgzf(skew, [65280], level=9)) == skew                       # codes longer than the first-level tables
 
 
+def test_codes_of_the_maximum_length(ctx):
+    """Symbol counts that grow like Fibonacci numbers give Huffman codes of every length up to deflate's limit of 15 bits - the
+    canonical walk of the long codes from the first-level table's length to the last - for literals (Huffman-only members) and,
+    with copies at two dozen distances whose counts grow the same way, for the distance code."""
+    fib = [1, 1]
+    while len(fib) < 24:
+        fib.append(fib[-1] + fib[-2])
+    rng = np.random.default_rng(23)
+    sym = np.concatenate([np.full(f, 33 + i, dtype=np.uint8) for i, f in enumerate(fib)])
+    rng.shuffle(sym)
+    text = sym.tobytes()
+    assert ctx.bgzf_inflate(bgzf(text, [65000], level=9, strategy=zlib.Z_HUFFMAN_ONLY)) == text
+    assert ctx.bgzf_inflate(bgzf(text, [65000], level=9)) == text
+    # distances: a block of noise, then copies of 40 bytes from 24 places in it, place i used fib[i] times (scaled down)
+    noise = rng.integers(0, 256, 30000, dtype=np.uint8).tobytes()
+    places = rng.integers(0, 29000, 24)
+    uses = np.concatenate([np.full(max(1, f // 40), i) for i, f in enumerate(fib)])
+    rng.shuffle(uses)
+    body = bytearray(noise)
+    for i in uses[:800].tolist():
+        body += noise[int(places[i]):int(places[i]) + 40] + bytes([int(rng.integers(0, 256))])
+    text = bytes(body)
+    assert ctx.bgzf_inflate(bgzf(text, [65280], level=9)) == text
+
+
 def test_corrupt_members_are_named(ctx):
     from pav_amd import _lib
     rng = np.random.default_rng(13)
