@@ -72,6 +72,13 @@ timeout -k 5 600 rocprofv3 --kernel-trace --stats -d $O/prof_bgzf -o bgzf -- pyt
 cd $R
 python3 tools/prof_summary.py stats $(find $O/prof_bgzf -name "*.db" | head -1) $P/${ROUND}_bgzf_loader_kernel_stats.txt > /dev/null
 sed -i "1i # Command: rocprofv3 --kernel-trace --stats -- python3 tools/bench_bgzf.py --mb 3000 --repeat 2  (a 3 GB bgzipped assembly into the sequence store:\n# device inflate, host inflate, plain text; one role twice each, then both roles side by side)" $P/${ROUND}_bgzf_loader_kernel_stats.txt
+# where the waves of the loader's kernels spend their cycles (issuing / waiting) and what their LDS arrays see: the SQ counters of one load
+cd /tmp
+timeout -k 5 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL \
+    -d $O/pmc_bgzf -o s -- python3 $R/tools/bench_bgzf.py --mb 1000 --repeat 1 > /dev/null 2> $O/pmc_bgzf.err
+cd $R
+python3 tools/prof_summary.py sq $(find $O/pmc_bgzf -name "*.db" | head -1) $P/${ROUND}_bgzf_loader_pmc_sq.txt > /dev/null
+sed -i "1i # Command: rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL -- python3 tools/bench_bgzf.py --mb 1000 --repeat 1" $P/${ROUND}_bgzf_loader_pmc_sq.txt
 find $O -name "*.db" -delete
 # the device gzip alone: GB/s and size against zlib for several search depths and windows
 python3 tools/bench_gzip.py --mb 200 --variants 11:4,11:6,11:8,11:32,12:4,12:6,12:8,12:16,13:8 > $P/${ROUND}_gzip_variants.json 2> $O/gzip.err
