@@ -91,6 +91,28 @@ def test_runs_random_bytes_and_rare_symbols(ctx):
     assert ctx.bgzf_inflate(bgzf(skew, [65280], level=9)) == skew                       # codes longer than the first-level tables
 
 
+def test_both_resolve_kernels(ctx, monkeypatch):
+    """The default resolve kernel keeps a ring of 36 KiB (history + the step's text, flushed as it is made; CRC-32 by k_bgzf_crc);
+    PAV_INFLATE_WINDOW=full runs the first version (the member's whole text in LDS, CRC-32 from the window).  Same text, and both
+    name a corrupt member.  Long runs cut the ring kernel's steps short (a step's text stays under 4 080 bytes) and wrap the ring."""
+    from pav_amd import _lib
+    rng = np.random.default_rng(29)
+    text = fasta_like(rng, 900_000) + b'N' * 200_000 + b'ACGTTGCAAC' * 30_000 + rng.integers(0, 256, 100_000, dtype=np.uint8).tobytes()
+    for sizes in ([65280], [65536, 1, 40000, 17]):
+        data = bgzf(text, sizes)
+        assert ctx.bgzf_inflate(data) == text
+        bad = bytearray(data)
+        bsize = struct.unpack('<H', data[16:18])[0] + 1
+        bad[bsize + 18 + (struct.unpack('<H', data[bsize + 16:bsize + 18])[0] + 1 - 26) // 2] ^= 0x04       # in the middle of the second member's payload
+        with pytest.raises(_lib.PavDeviceError, match='corrupt BGZF member'):
+            ctx.bgzf_inflate(bytes(bad))
+        monkeypatch.setenv('PAV_INFLATE_WINDOW', 'full')
+        assert ctx.bgzf_inflate(data) == text
+        with pytest.raises(_lib.PavDeviceError, match='corrupt BGZF member'):
+            ctx.bgzf_inflate(bytes(bad))
+        monkeypatch.delenv('PAV_INFLATE_WINDOW')
+
+
 def test_codes_of_the_maximum_length(ctx):
     """Symbol counts that grow like Fibonacci numbers give Huffman codes of every length up to deflate's limit of 15 bits - the
     canonical walk of the long codes from the first-level table's length to the last - for literals (Huffman-only members) and,
