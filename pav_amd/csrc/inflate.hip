@@ -12,11 +12,13 @@
 //                      three waves per CU: every member of a 3 GB file is in flight at once.  A code longer than its table is
 //                      walked in registers (ifl::LongCode); tokens leave as 16-byte stores, the stream is read a word ahead -
 //                      a lane that waits for a load waits for every store before it
-//   k_inflate_resolve  a WAVE per member turns the tokens into text in a 64 KiB LDS window: 64 tokens per step, places by a
-//                      prefix sum of their byte counts, literals stored at once, copies eight bytes at a time by the lanes whose
-//                      source is complete (the first pending copy always is), the long ones - runs of N, tandem repeats - by the
-//                      whole wave; the CRC-32 of the text is taken from the window (256 pieces joined by the checksum's algebra)
-//                      and compared with the footer's; the window leaves as 16-byte stores
+//   k_inflate_resolve_ring   a WAVE per member turns the tokens into text in a 36 KiB LDS ring (32 KiB of history + the step's own
+//                      text), flushed to HBM as it is made, four waves a CU: 64 tokens per step, places by a prefix sum of their byte
+//                      counts, literals stored at once, copies eight bytes at a time by the lanes whose source is complete (the first
+//                      pending copy always is), the long ones - runs of N, tandem repeats - by the whole wave
+//                      (k_inflate_resolve, PAV_INFLATE_WINDOW=full: the first version, the member's whole 64 KiB in LDS, two waves a CU)
+//   k_bgzf_crc         a wave per member: CRC-32 of the text in HBM against the footer (a lane 64 bytes of every 4 KiB tile; chains,
+//                      tiles and lanes joined by the checksum's algebra)
 // The text is what zlib's inflate gives for the same members (tests/test_gpu_bgzf.py; the serial decoder alone against zlib on the
 // host: tests/native/inflate_check.cpp).
 #include "inflatedev.h"
