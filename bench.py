@@ -651,7 +651,7 @@ def main():
                             os.environ.pop('PAV_FASTA_INFLATE', None)
                             res[name] = min(ts)
                     res['note'] = ('pav_seq_load_fasta_path, best of three: file -> pinned ring -> HBM, BGZF members inflated by a lane each (tokens) and a '
-                                   'wave each (copies in an LDS window, CRC-32 checked), header lines and line breaks removed on the device')
+                                   'wave each (copies in an LDS ring), every member\'s CRC-32 checked, header lines and line breaks removed on the device')
                     e2e['fasta_loader'] = res
                 finally:
                     shutil.rmtree(tmp_fa, ignore_errors=True)
