@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <string>
 #include <thread>
+#include <vector>
 
 #include "devgz.h"
 #include "fmt_dev.h"
@@ -317,8 +318,19 @@ int emit_files(pav_ctx *ctx, TextDev &D, uint64_t text_alloc, const std::vector<
             if (rc != PAV_OK) break;
             const size_t a = cut[g];
             writer[s2] = std::thread([&, s2, a, out] {
-                for (size_t q = 0; q < out.off.size() && rc_w[s2] == PAV_OK; ++q) rc_w[s2] = write_file(paths[gz_ix[a + q]], out.host + out.off[q], out.len[q]);
-                if (rc_w[s2] != PAV_OK) err_w[s2] = pav_last_error(nullptr);
+                // (a hundred files of 3 MB each: four threads take every fourth - the page cache takes 9 GB/s from one)
+                const size_t n_files = out.off.size(), n_thr = n_files >= 8 ? 4 : 1;
+                std::vector<int> rc_t(n_thr, PAV_OK);
+                std::vector<std::string> err_t(n_thr);
+                auto part = [&](size_t k) {
+                    for (size_t q = k; q < n_files && rc_t[k] == PAV_OK; q += n_thr) rc_t[k] = write_file(paths[gz_ix[a + q]], out.host + out.off[q], out.len[q]);
+                    if (rc_t[k] != PAV_OK) err_t[k] = pav_last_error(nullptr);
+                };
+                std::vector<std::thread> sub;
+                for (size_t k = 1; k < n_thr; ++k) sub.emplace_back(part, k);
+                part(0);
+                for (std::thread &t : sub) t.join();
+                for (size_t k = 0; k < n_thr; ++k) if (rc_t[k] != PAV_OK && rc_w[s2] == PAV_OK) { rc_w[s2] = rc_t[k]; err_w[s2] = err_t[k]; }
             });
         }
         for (std::thread &w : writer) if (w.joinable()) w.join();
