@@ -52,27 +52,35 @@ __device__ __forceinline__ uint32_t load_tile_word(const uint8_t *__restrict__ r
     return w;
 }
 
+constexpr uint32_t FA_TPW = 4;                          // tiles a wave takes: their loads are under way together
+
 __global__ __launch_bounds__(256) void k_fa_marks(const uint8_t *__restrict__ raw, uint64_t n, uint32_t *__restrict__ tile_cnt,
                                                   uint64_t *__restrict__ hdr_pos, uint32_t *__restrict__ n_hdr, uint32_t hdr_cap) {
-    const uint64_t tile = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t tile0 = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * FA_TPW;
     const uint32_t lane = threadIdx.x & 63;
-    const uint64_t x = tile * FA_TILE + 4ull * lane;
-    if (tile * FA_TILE >= n) return;                                       // (whole waves: the ballot below is among live lanes)
-    const uint32_t w = load_tile_word(raw, n, x);
-    uint32_t cnt = (uint32_t)__popc(break_bits(w));
-    for (int d = 32; d >= 1; d >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, d);
-    if (lane == 0) tile_cnt[tile] = cnt;
-    // a '>' that starts a line: the byte in front of it is '\n' (or it is the file's first byte)
-    uint32_t gt = 0;
+    uint32_t ws[FA_TPW];
 #pragma unroll
-    for (uint32_t j = 0; j < 4; ++j) gt |= ((w >> (8 * j)) & 0xFFu) == '>' ? 1u << j : 0u;
-    if (gt) {
-        for (uint32_t j = 0; j < 4; ++j) {
-            if (!((gt >> j) & 1u) || x + j >= n) continue;
-            const uint32_t prev = j ? (w >> (8 * (j - 1))) & 0xFFu : (x ? (uint32_t)raw[x - 1] : (uint32_t)'\n');
-            if (prev != '\n') continue;
-            const uint32_t at = atomicAdd(n_hdr, 1u);
-            if (at < hdr_cap) hdr_pos[at] = x + j;
+    for (uint32_t q = 0; q < FA_TPW; ++q) { const uint64_t x = (tile0 + q) * FA_TILE + 4ull * lane; ws[q] = (tile0 + q) * FA_TILE < n ? load_tile_word(raw, n, x) : 0x41414141u; }
+#pragma unroll
+    for (uint32_t q = 0; q < FA_TPW; ++q) {
+        const uint64_t tile = tile0 + q, x = tile * FA_TILE + 4ull * lane;
+        if (tile * FA_TILE >= n) break;                                    // (whole waves: the reduction below is among live lanes)
+        const uint32_t w = ws[q];
+        uint32_t cnt = (uint32_t)__popc(break_bits(w));
+        for (int d = 32; d >= 1; d >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, d);
+        if (lane == 0) tile_cnt[tile] = cnt;
+        // a '>' that starts a line: the byte in front of it is '\n' (or it is the file's first byte)
+        uint32_t gt = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) gt |= ((w >> (8 * j)) & 0xFFu) == '>' ? 1u << j : 0u;
+        if (gt) {
+            for (uint32_t j = 0; j < 4; ++j) {
+                if (!((gt >> j) & 1u) || x + j >= n) continue;
+                const uint32_t prev = j ? (w >> (8 * (j - 1))) & 0xFFu : (x ? (uint32_t)raw[x - 1] : (uint32_t)'\n');
+                if (prev != '\n') continue;
+                const uint32_t at = atomicAdd(n_hdr, 1u);
+                if (at < hdr_cap) hdr_pos[at] = x + j;
+            }
         }
     }
 }
@@ -107,36 +115,45 @@ __global__ __launch_bounds__(64) void k_fa_records(const uint8_t *__restrict__ r
 
 __global__ __launch_bounds__(256) void k_fa_strip(const uint8_t *__restrict__ raw, uint64_t n, const uint64_t *__restrict__ tile_pre,
                                                   const FaRec *__restrict__ rec, uint32_t n_rec, uint8_t *__restrict__ arena) {
-    const uint64_t tile = (uint64_t)blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (a scalar: the search below loads through the scalar cache)
+    const uint64_t tile0 = ((uint64_t)blockIdx.x * 4 + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * FA_TPW;   // (a scalar: the search below
+                                                                                                                                   // loads through the scalar cache)
     const uint32_t lane = threadIdx.x & 63;
-    const uint64_t t0 = tile * FA_TILE, x = t0 + 4ull * lane;
-    if (t0 >= n || n_rec == 0) return;
-    const uint32_t w = load_tile_word(raw, n, x);
-    uint32_t brk = break_bits(w);
+    if (tile0 * FA_TILE >= n || n_rec == 0) return;
+    uint32_t ws[FA_TPW];
 #pragma unroll
-    for (uint32_t j = 0; j < 4; ++j) if (x + j >= n) brk |= 1u << j;        // (beyond the text: nothing to keep)
-    // line-break bytes of the tile in front of this lane's four: a ballot per byte position
-    uint32_t before = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < 4; ++j) before += (uint32_t)__popcll(__ballot((brk >> j) & 1u) & ((1ull << lane) - 1ull));
-    // last record whose body starts at or before the tile's first byte (the wave's lanes search together: scalar loads)
+    for (uint32_t q = 0; q < FA_TPW; ++q) { const uint64_t x = (tile0 + q) * FA_TILE + 4ull * lane; ws[q] = (tile0 + q) * FA_TILE < n ? load_tile_word(raw, n, x) : 0x0a0a0a0au; }
+    // last record whose body starts at or before the first tile's first byte (the wave's lanes search together: scalar loads)
     uint32_t lo = 0, hi = n_rec;
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (rec[mid].body <= t0) lo = mid; else hi = mid; }
-    uint32_t r = lo;
-    while (r + 1 < n_rec && rec[r + 1].body <= x) ++r;                     // a tile holds the end of one record and the start of the next at most a few times
-    FaRec R = rec[r];
-    const uint64_t brk_x = tile_pre[tile] + before;
-    if (brk == 0 && x >= R.body && x + 4 <= R.body_end) {                  // four kept bytes of one record: one store (any alignment)
-        *reinterpret_cast<uint32_t *>(arena + R.arena_off + (x - R.body) - (brk_x - R.breaks_before)) = w;
-        return;
-    }
-    uint32_t seen = 0;
-    for (uint32_t j = 0; j < 4; ++j) {
-        const uint64_t p = x + j;
-        if ((brk >> j) & 1u) { ++seen; continue; }
-        while (r + 1 < n_rec && rec[r + 1].body <= p) { ++r; R = rec[r]; }
-        if (p < R.body || p >= R.body_end) continue;                       // header lines, the bytes in front of the first record
-        arena[R.arena_off + (p - R.body) - (brk_x + seen - R.breaks_before)] = (uint8_t)(w >> (8 * j));
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (rec[mid].body <= tile0 * FA_TILE) lo = mid; else hi = mid; }
+#pragma unroll
+    for (uint32_t q = 0; q < FA_TPW; ++q) {
+        const uint64_t tile = tile0 + q, t0 = tile * FA_TILE, x = t0 + 4ull * lane;
+        if (t0 >= n) break;
+        const uint32_t w = ws[q];
+        uint32_t brk = break_bits(w);
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) if (x + j >= n) brk |= 1u << j;    // (beyond the text: nothing to keep)
+        // line-break bytes of the tile in front of this lane's four: a ballot per byte position
+        uint32_t before = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) before += (uint32_t)__popcll(__ballot((brk >> j) & 1u) & ((1ull << lane) - 1ull));
+        while (lo + 1 < n_rec && rec[lo + 1].body <= t0) ++lo;             // (the wave's record moves on with the tiles)
+        uint32_t r = lo;
+        while (r + 1 < n_rec && rec[r + 1].body <= x) ++r;                 // a tile holds the end of one record and the start of the next at most a few times
+        FaRec R = rec[r];
+        const uint64_t brk_x = tile_pre[tile] + before;
+        if (brk == 0 && x >= R.body && x + 4 <= R.body_end) {              // four kept bytes of one record: one store (any alignment)
+            *reinterpret_cast<uint32_t *>(arena + R.arena_off + (x - R.body) - (brk_x - R.breaks_before)) = w;
+            continue;
+        }
+        uint32_t seen = 0;
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint64_t p = x + j;
+            if ((brk >> j) & 1u) { ++seen; continue; }
+            while (r + 1 < n_rec && rec[r + 1].body <= p) { ++r; R = rec[r]; }
+            if (p < R.body || p >= R.body_end) continue;                   // header lines, the bytes in front of the first record
+            arena[R.arena_off + (p - R.body) - (brk_x + seen - R.breaks_before)] = (uint8_t)(w >> (8 * j));
+        }
     }
 }
 
@@ -330,7 +347,7 @@ int pav_seq_load_fasta_path(pav_ctx *ctx, int role, const char *path, int thread
     const double t1 = wall();
     // ---- records ------------------------------------------------------------------------------------------------------
     PAV_HIP(ctx, hipMemsetAsync(F->counter.p, 0, 64, st));
-    if (n_tiles) PAV_LAUNCH_ON(ctx, st, "k_fa_marks", k_fa_marks, (n_tiles + 3) / 4, 256, 0, F->raw.as<uint8_t>(), n, F->tile_cnt.as<uint32_t>(), F->hdr.as<uint64_t>(),
+    if (n_tiles) PAV_LAUNCH_ON(ctx, st, "k_fa_marks", k_fa_marks, (n_tiles + 4 * FA_TPW - 1) / (4 * FA_TPW), 256, 0, F->raw.as<uint8_t>(), n, F->tile_cnt.as<uint32_t>(), F->hdr.as<uint64_t>(),
                             F->counter.as<uint32_t>(), hdr_cap);
     { const int rc = scan_u32_to_u64(st, F->tile_cnt.as<uint32_t>(), n_tiles, F->bsum.as<uint64_t>(), F->tile_pre.as<uint64_t>());
       if (rc != PAV_OK) return fail(ctx, rc, "%s", pav_last_error(nullptr)); }
@@ -402,7 +419,7 @@ int pav_seq_load_fasta_path(pav_ctx *ctx, int role, const char *path, int thread
         PAV_HIP(ctx, hipMemcpy(up.data(), F->rec.p, sizeof(FaRec) * n_hdr, hipMemcpyDeviceToHost));
         for (uint32_t i = 0; i < n_hdr; ++i) up[i].arena_off = off[i];
         PAV_HIP(ctx, hipMemcpy(F->rec.p, up.data(), sizeof(FaRec) * n_hdr, hipMemcpyHostToDevice));
-        PAV_LAUNCH(ctx, "k_fa_strip", k_fa_strip, (n_tiles + 3) / 4, 256, 0, F->raw.as<uint8_t>(), n, F->tile_pre.as<uint64_t>(), F->rec.as<FaRec>(), n_hdr, arena);
+        PAV_LAUNCH(ctx, "k_fa_strip", k_fa_strip, (n_tiles + 4 * FA_TPW - 1) / (4 * FA_TPW), 256, 0, F->raw.as<uint8_t>(), n, F->tile_pre.as<uint64_t>(), F->rec.as<FaRec>(), n_hdr, arena);
         return (int)PAV_OK;
     });
     if (rc != PAV_OK) return rc;
