@@ -456,9 +456,13 @@ int gz_files(pav_ctx *ctx, void **slot, hipStream_t st, const uint8_t *d_text, u
     // (measured on 200 MB of SNV rows / 150 MB of density rows, profiles/r05_gzip_variants.json.  Window 2 KiB - 11.6 KB of LDS,
     //  thirteen waves per CU - chain 4 / 6 / 8: 14.3 / 13.0 / 11.8 GB/s on SNV rows at 0.985 / 0.977 / 0.970 of zlib level 6's size,
     //  19.0 / 16.9 / 15.2 GB/s on density rows at 0.948 / 0.943 / 0.941; window 4 KiB - eight waves per CU - is 15 - 35 % slower at
-    //  the same sizes; 8 KiB slower still.  Every setting is below zlib-6.)
-    if (level <= 5) { A.chain = 4; A.lazy = 16; A.nice = 64; A.good = 16; }
-    else if (level <= 6) { A.chain = 6; A.lazy = 32; A.nice = 128; A.good = 32; }
+    //  the same sizes; 8 KiB slower still.  Chain 1 / 2 / 3: 20.3 / 16.1 / 15.1 GB/s on SNV rows at 1.016 / 0.998 / 0.990 of zlib
+    //  level 6's size, 26.3 / 22.4 / 20.6 GB/s on density rows at 0.979 / 0.959 / 0.952.)
+    // Level 6 = three chain steps: 1 - 5 % below zlib-6's size on the haplotype's own rows and a sixth to a fifth faster than the six
+    // steps of the first version, which bought 1 % of size (two steps: on rows of random positions - tests/test_gpu_gzip.py - 10 %
+    // above zlib-6).  Levels below it: one step (zlib-1 .. 5 are 10 - 28 % larger than that); 7 and above: thirty-two.
+    if (level <= 5) { A.chain = 1; A.lazy = 16; A.nice = 64; A.good = 16; }
+    else if (level <= 6) { A.chain = 3; A.lazy = 32; A.nice = 128; A.good = 32; }
     else { A.chain = 32; A.lazy = 258; A.nice = 258; A.good = 64; }
     if (const char *e = getenv("PAV_GZ_CHAIN")) A.chain = (uint32_t)std::max(1, atoi(e));
     if (const char *e = getenv("PAV_GZ_NICE")) A.nice = (uint32_t)std::max(4, atoi(e));
