@@ -81,7 +81,7 @@ python3 tools/prof_summary.py sq $(find $O/pmc_bgzf -name "*.db" | head -1) $P/$
 sed -i "1i # Command: rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL -- python3 tools/bench_bgzf.py --mb 1000 --repeat 1" $P/${ROUND}_bgzf_loader_pmc_sq.txt
 find $O -name "*.db" -delete
 # the device gzip alone: GB/s and size against zlib for several search depths and windows
-python3 tools/bench_gzip.py --mb 200 --variants 11:4,11:6,11:8,11:32,12:4,12:6,12:8,12:16,13:8 > $P/${ROUND}_gzip_variants.json 2> $O/gzip.err
+python3 tools/bench_gzip.py --mb 200 --variants 11:1,11:2,11:3,11:4,11:6,11:8,11:32,12:4,12:6,12:8,12:16,13:8 > $P/${ROUND}_gzip_variants.json 2> $O/gzip.err
 # the product runner: six haplotypes of 0.77 Gbp on one rank, 1 / 2 / 4 lanes; the same with the process pinned to four cores
 python3 tools/bench_cohort.py --haplotypes 6 --lanes 1 2 4 2> $O/cohort.err | tail -1 > $P/${ROUND}_cohort.json
 taskset -c 0-3 python3 tools/bench_cohort.py --haplotypes 6 --lanes 1 2 2> $O/cohort4.err | tail -1 > $P/${ROUND}_cohort_4cores.json
