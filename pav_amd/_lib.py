@@ -519,7 +519,8 @@ class Context:
 
     def seq_load_fasta_path(self, role, path, threads=0):
         """Every record of the FASTA file ``path`` into the store of ``role`` without a host-side parse (``pav_seq_load_fasta_path``:
-        the text is uploaded as it is, header lines and line breaks are removed on the device).  Returns the record names."""
+        the file is uploaded as it is - plain text, or bgzipped as PAV keeps its FASTA files, the BGZF members then inflated on the
+        device and checked against their CRC-32 - header lines and line breaks are removed on the device).  Returns the record names."""
         n = ctypes.c_uint32(0)
         self._check(self.lib.pav_seq_load_fasta_path(self.handle, role, str(path).encode(), int(threads), ctypes.byref(n)), 'pav_seq_load_fasta_path')
         if role == PAV_ROLE_REF:
