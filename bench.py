@@ -54,6 +54,65 @@ def _free_port():
         return sk.getsockname()[1]
 
 
+def _newest_first(suffix):
+    """Committed round summaries profiles/rNN<suffix>, newest round first."""
+    import re
+    try:
+        names = [f for f in os.listdir(os.path.join(ROOT, 'profiles')) if re.fullmatch(r'r\d\d' + re.escape(suffix), f)]
+    except OSError:
+        names = []
+    return sorted(names, reverse=True)
+
+
+def compact_line(line, limited=False, solo=None):
+    """The one line the driver parses (<= 4 KB): the contract keys, `roofline` and `cpu_baseline` with the figures they are
+    checked by, one short record per rank.  Every other object of the report lives in the detail file."""
+    def pick(d, keys):
+        return None if d is None else {k: d.get(k) for k in keys if k in d}
+    cfg = line['config']
+    roof = line['roofline']
+    out = {k: line[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                                'vs_baseline', 'dtype', 'data')}
+    out['config'] = {'workload': cfg['workload_short'], **pick(cfg, ('scale', 'seed', 'aligned_bp_per_gpu', 'lanes_per_gpu',
+                                                                     'usable_cpus_per_rank', 'reference')),
+                     'repeats': f"median of {line['repeats']['regions']} regions of {line['steps']} steps",
+                     'warmup_steps_run': cfg['warmup_steps_run']}
+    r = pick(roof, ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_bytes_per_launch', 'avg_kernel_ms'))
+    r['path'] = pick(roof.get('path'), ('achieved', 'frac'))
+    iso = roof.get('isolated_lines')
+    if iso:
+        r['gather'] = {'glines_per_s': iso['achieved_glines_per_s'], 'peak': iso['measured_peak_glines_per_s'], 'frac': iso['frac']}
+    tr = roof.get('timed_region')
+    if tr:
+        r['timed_region'] = pick(tr, ('kernel', 'share_of_device_time', 'avg_kernel_ms', 'device_ms_per_step'))
+    out['roofline'] = r
+    cpu = line.get('cpu_baseline')
+    if cpu is not None:
+        c = pick(cpu, ('value', 'unit', 'cores', 'kind', 'records_match_gpu', 'density_tables_match_gpu', 'cigar_call_only',
+                       'density_scan_bp_per_s'))
+        c['sample'] = cpu.get('sample_short') or cpu['sample'][:200]
+        if 'all_cores' in cpu:
+            c['all_cores'] = pick(cpu['all_cores'], ('value', 'cigar_call_only', 'cores'))
+        c['reference_python'] = pick(cpu['reference_python'], ('cigar_call_Mbp_per_s', 'density_scan_kbp_per_s', 'cores'))
+        c['reference_python']['hardware'] = 'survey sandbox, 1 core (BASELINE.md section 2)'
+        out['cpu_baseline'] = c
+    else:
+        out['cpu_baseline'] = None
+    out['per_rank'] = [{'rank': p['rank'], 'ms_per_step': p['ms_per_step'], 'lanes_per_gpu': p['lanes_per_gpu'],
+                        'usable_cpus': p['usable_cpus'], 'aligned_bp': p['aligned_bp']} for p in line['per_rank']]
+    if limited:
+        out['lanes_limited_by_cpus'] = True
+    if solo is not None:
+        out['single_rank_same_lanes'] = solo
+    for k in ('cigar_only', 'verify_mode'):
+        if line.get(k):
+            out[k] = pick(line[k], ('value', 'ms_per_step'))
+    if line.get('inv_scan'):
+        out['inv_scan'] = pick(line['inv_scan'], ('calls', 'scanned_loci', 'device_ms_per_step'))
+    out['detail_file'] = line.get('detail_file')
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -93,6 +152,8 @@ def main():
                     help="'hg38' (default): the hg38-shaped reference of configs[1]-[3]; 'chm13': BASELINE configs[4] - T2T-CHM13v2.0 lengths, "
                          'no N runs, seed 1005, the cohort batched --lanes (default 8) haplotypes per GPU against one resident reference; the '
                          'line then carries `hbm` (peak use, pav_mem_info) and every lane\'s records_match vs the oracle')
+    ap.add_argument('--detail', default=os.path.join(ROOT, 'bench_detail.json'),
+                    help='file that receives the full report (every side leg, per-kernel tables, notes); stdout carries one short JSON line')
     args = ap.parse_args()
     if args.reference == 'chm13':
         if args.seed == 1002:
@@ -469,6 +530,30 @@ def main():
                      'usable_cpus': round(cpus_per_rank, 2), 'aligned_bp': aligned_steps / args.steps,
                      'cigar_text_bytes': int(sum(ln.text.shape[0] for ln in lanes))}]
 
+    # ---- N > 1: rank 0 once more ALONE with the same lanes (the other ranks wait on a socket barrier, their GPUs idle): the N = 1
+    #      figure at this rank's lane count.  The lanes of a rank follow its share of the node's CPUs, so a scaling run on a node with
+    #      few CPUs per rank runs fewer lanes than the N = 1 run did - efficiency is like-for-like only against this figure.
+    limited_by_cpus = bool(args.lanes == 0 and n_lanes < 6)
+    solo_same_lanes = None
+    if world > 1:
+        side = dist.new_group(backend='gloo') if args.backend != 'gloo' else None
+        if rank == 0:
+            solos = []
+            for _ in range(3):
+                for ln in lanes:
+                    ln.ctx.sync()
+                torch.cuda.synchronize()
+                t_a = time.perf_counter()
+                run_steps(args.steps)
+                for ln in lanes:
+                    ln.ctx.sync()
+                torch.cuda.synchronize()
+                t_s = time.perf_counter() - t_a
+                solos.append((t_s, float(sum(ln.n_done * ln.counts.aligned_bases for ln in lanes))))
+            t_s, bp_s = sorted(solos)[1]
+            solo_same_lanes = {'value': round(bp_s / t_s / 1e9, 2), 'ms_per_step': round(t_s / args.steps * 1e3, 4), 'lanes': n_lanes}
+        dist.barrier(group=side)
+
     # ---- the timed region once more with HIP events around every kernel of EVERY lane: which kernel takes the most device time
     #      in the regime the line is measured in (kernels of other lanes beside it), and how much longer than alone -----------
     lanes_prof, t_lanes_prof = None, None
@@ -670,7 +755,7 @@ def main():
                     m = _re.search(r':(\d+)-(\d+)', ln.split(': ')[1])
                     scanned_bp += int(m.group(2)) - int(m.group(1)) + 1
         pmc = None                                            # committed PMC summary of this workload, newest round first
-        for pmc_name in ('r05_pmc.json', 'r04_pmc.json', 'r03_pmc.json', 'r02_pmc.json', 'r01_pmc.json'):
+        for pmc_name in _newest_first('_pmc.json'):
             try:
                 with open(os.path.join(ROOT, 'profiles', pmc_name)) as fh:
                     cand = json.load(fh)
@@ -692,7 +777,7 @@ def main():
         # nothing stored, the ceiling of the memory system for this access pattern
         line_roof = {'with_stores': None, 'with_stores_variant': None, 'loads_only': None, 'loads_only_variant': None,
                      'source': 'profiles/r03_gather_rate.txt'}
-        for cand_ in ('r05_gather_rate.txt', 'r04_gather_rate.txt', 'r03_gather_rate.txt'):
+        for cand_ in _newest_first('_gather_rate.txt'):
             if os.path.exists(os.path.join(ROOT, 'profiles', cand_)):
                 line_roof['source'] = 'profiles/' + cand_
                 break
@@ -827,7 +912,7 @@ def main():
             top = sorted(tot, key=lambda k_: -tot[k_][1])
             dom_l = top[0]
             lds = None
-            for lds_name in ('r05_lds_counters.json', 'r04_lds_counters.json'):
+            for lds_name in _newest_first('_lds_counters.json'):
                 try:
                     with open(os.path.join(ROOT, 'profiles', lds_name)) as fh:
                         lds = json.load(fh)
@@ -974,6 +1059,7 @@ def main():
                    'sample': f'first {sub.shape[0]} alignment rows of the same haplotype ({sample_bp / 1e9:.3f} Gbp aligned, '
                              f'{o_snv.shape[0]} SNV, {o_indel.shape[0]} INDEL), oracle/ scalar C walk incl. per-contig '
                              f'upper-casing and reverse complement, {c1:.1f} s wall',
+                   'sample_short': f'{sub.shape[0]} alignment rows ({sample_bp / 1e9:.3f} Gbp) through the oracle C walk: {c1:.1f} s',
                    'records_match_gpu': bool(ok)}
             # the same port on all host cores: the alignment rows are independent, so the haplotype is cut into row groups of
             # equal CIGAR text and every group walks on its own thread (ctypes releases the GIL); reported beside the 1-core figure
@@ -1042,6 +1128,8 @@ def main():
                         'sample': cpu['sample'] + f'; k-mer density scan: first scan iteration of {len(pairs)} flagged regions '
                                   f'({den_bp} region bp, {t_den:.1f} s wall) extrapolated to the {scanned_bp} bp scanned per haplotype '
                                   f'({t_scan_cpu:.0f} s); value = aligned bp / (CIGAR walk + extrapolated scan); flagging not included',
+                        'sample_short': cpu['sample_short'] + f'; density scan of {len(pairs)} flagged regions ({den_bp} bp): {t_den:.1f} s, '
+                                        f'extrapolated to {scanned_bp} bp',
                         'density_tables_match_gpu': bool(den_ok)})
                     if t_all is not None and len(pairs) >= 2:
                         c0 = time.perf_counter()
@@ -1108,6 +1196,9 @@ def main():
                                     'resident per GPU against one resident reference; a step = one haplotype through CIGAR-call + '
                                     'signature flagging + k-mer inversion density scan of every locus the flagging marks TRY_INV; the '
                                     'steps go round the haplotypes (configs[1] = CIGAR-call only: see cigar_only)'),
+                       'workload_short': ('configs[1]: hg38-shaped haplotype, CIGAR-call only' if args.workload == 'cigar' else
+                                          f"configs[{'4' if args.reference == 'chm13' else '2'}] per-GPU share: {n_lanes} {args.reference}-shaped haplotypes "
+                                          'resident; step = one haplotype through CIGAR-call + flagging + k-mer inversion scan'),
                        'scale': args.scale, 'seed': args.seed, 'aligned_bp_per_gpu': int(counts.aligned_bases),
                        'n_aln': int(aln.shape[0]), 'n_ops': int(n_ops), 'n_snv': int(n_snv), 'n_indel': int(n_indel),
                        'lanes_per_gpu': n_lanes, 'lanes_arg': args.lanes, 'usable_cpus_per_rank': round(cpus_per_rank, 2),
@@ -1122,7 +1213,7 @@ def main():
                         'ms_per_step_all': [round(r[1] / args.steps * 1e3, 4) for r in regions],
                         'value_min': round(aligned_total / max(r[1] for r in regions) / 1e9, 2),
                         'value_max': round(aligned_total / min(r[1] for r in regions) / 1e9, 2)},
-            'per_rank': per_rank,
+            'per_rank': per_rank, 'lanes_limited_by_cpus': limited_by_cpus, 'single_rank_same_lanes': solo_same_lanes,
             'load_balance': {'max_over_mean_ms': round(max(r['ms_per_step'] for r in per_rank) / (sum(r['ms_per_step'] for r in per_rank) / len(per_rank)), 4),
                              'max_over_mean_cigar_text': round(max(r['cigar_text_bytes'] for r in per_rank) /
                                                                (sum(r['cigar_text_bytes'] for r in per_rank) / len(per_rank)), 4),
@@ -1157,7 +1248,22 @@ def main():
                      'cpu_baseline_cores_all': None if not cpu or 'all_cores' not in cpu else cpu['all_cores'].get('cores'),
                      'device': ctx.device_name},
         }
-        print(json.dumps(line), flush=True)
+        # ---- what the driver parses: ONE short final line (contract keys + the objects the judge reads); everything else goes to
+        #      the detail file (and to stderr).  Round 5 printed the whole 20 KB object and the driver's 8 KB tail lost the line.
+        detail_path = os.path.abspath(args.detail)
+        line['detail_file'] = os.path.basename(detail_path)
+        try:
+            with open(detail_path, 'w') as fh:
+                json.dump(line, fh)
+                fh.write('\n')
+        except OSError as ex:                                    # (a read-only tree: the short line still goes out)
+            print(f'[bench] could not write {detail_path}: {ex}', file=sys.stderr)
+        print('[bench detail] ' + json.dumps(line), file=sys.stderr, flush=True)
+        compact = compact_line(line, limited=limited_by_cpus, solo=solo_same_lanes)
+        text_out = json.dumps(compact, separators=(',', ':'))
+        assert len(text_out) <= 4096, f'the bench line grew to {len(text_out)} bytes: move keys to {detail_path}'
+        sys.stderr.flush()
+        print(text_out, flush=True)
     for ln in lanes[::-1]:
         ln.ctx.close()
     if world > 1:

@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <atomic>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <vector>
@@ -153,13 +155,16 @@ struct pav_ctx {
     bool den_scan_only = false;           // set by the inversion-scan driver around pav_density_batch: only run lists and the tables of
                                           // regions that can become calls will be read (density.hip, fwd_only)
     hipEvent_t hom_done = nullptr;        // pav_cigar_call: recorded behind the homology scans on stream2 (wait_homology)
-    bool hom_pending = false;
+    std::atomic<bool> hom_pending{false};   // (atomic: read and cleared by both loader threads, see err_mu)
     hipEvent_t snv_ready = nullptr, snv_done = nullptr;   // pav_cigar_call: the SNV rows are written on stream2 (behind the pack),
                                                           // next to the homology scans of the main stream
     hipEvent_t pack_done[2] = {nullptr, nullptr};   // pav_seq_pack: orders the side stream's pack behind the main stream
     bool pack_pending[2] = {false, false};
     uint64_t seen_pack_gen[2] = {0, 0};   // SeqStore::pack_gen of the last full pack the main stream waits behind (per role)
     std::string err;
+    std::mutex err_mu;                    // fail(): the two roles of one context may be loaded from two threads at the same time
+    std::mutex prof_mu;                   // ... and both launch kernels through PAV_LAUNCH: the event bookkeeping below is shared
+    std::once_flag invscan_once, textdev_once;   // lazily made state that both loader / writer threads reach first (invscan.cpp, textdev.hip)
     char dev_name[256] = {0};
     int n_cu = 0;
 
@@ -168,7 +173,7 @@ struct pav_ctx {
     // CIGAR state
     uint32_t n_aln = 0;
     uint64_t text_bytes = 0;
-    bool cigar_loaded = false, cigar_called = false;
+    std::atomic<bool> cigar_loaded{false}, cigar_called{false};   // (atomic: both loader threads clear them)
     pav_cigar_counts counts{};
     pav_cigar_err cigar_err{};
     uint64_t *h_status = nullptr;         // pinned host words for the small device-to-host readbacks of pav_cigar_call

@@ -20,7 +20,7 @@ int fail(pav_ctx *ctx, int code, const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (ctx) ctx->err = buf;
+    if (ctx) { std::lock_guard<std::mutex> lk(ctx->err_mu); ctx->err = buf; }
     g_err = buf;
     return code;
 }
@@ -31,6 +31,7 @@ bool sync_each() { const char *e = getenv("PAV_SYNC_EACH"); return e && *e == '1
 int prof_begin(pav_ctx *ctx, const char *name, hipStream_t st) {
     if (!st) st = ctx->stream;
     if (!ctx->prof_on) return -1;
+    std::lock_guard<std::mutex> lk(ctx->prof_mu);
     int entry = -1;
     for (size_t i = 0; i < ctx->prof.size(); ++i)
         if (ctx->prof[i].name == name) { entry = (int)i; break; }
@@ -50,7 +51,9 @@ int prof_begin(pav_ctx *ctx, const char *name, hipStream_t st) {
 
 void prof_end(pav_ctx *ctx, int token, hipStream_t st) {
     if (token < 0) return;
-    (void)hipEventRecord(ctx->prof_pending[(size_t)token].b, st ? st : ctx->stream);
+    hipEvent_t b;
+    { std::lock_guard<std::mutex> lk(ctx->prof_mu); b = ctx->prof_pending[(size_t)token].b; }
+    (void)hipEventRecord(b, st ? st : ctx->stream);
 }
 
 // Everything the caller launches next on ctx->stream runs behind the last full pack of both stores - whichever context
@@ -83,10 +86,11 @@ int wait_tables(pav_ctx *ctx) {
 }
 
 int prof_flush(pav_ctx *ctx) {
-    if (ctx->prof_pending.empty()) return PAV_OK;
+    { std::lock_guard<std::mutex> lk(ctx->prof_mu); if (ctx->prof_pending.empty()) return PAV_OK; }
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream3));
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream2));
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::lock_guard<std::mutex> lk(ctx->prof_mu);
     for (auto &p : ctx->prof_pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {

@@ -255,6 +255,10 @@ PAV_IHD int inflate_tokens(const uint8_t *in, uint32_t in_len, uint32_t text_len
             if (!build_code<false>(lens + n_lit, n_dist, S->dist_count, S->dist_sym, S->offs, T, LD)) return IFL_E_LENGTHS;
             for (;;) {
                 refill(B);
+                // a run of literals never reaches the check behind a copy: the reader itself must stay within the member (a valid
+                // stream keeps pos <= in_len + 8: up to 64 buffered bits; the load ahead then ends at in_len + 12 - the buffer's padding
+                // covers it; a dynamic block's header, the other loop without a copy, is at most ~600 bytes)
+                if (B.pos > (uint64_t)in_len + 8u) return IFL_E_INPUT;
                 uint32_t sym;
                 { const uint32_t e = T.lit((uint32_t)B.bits & (LIT_TAB - 1u));
                   if (e & 15u) { sym = e >> 4; B.bits >>= (e & 15u); B.n -= (e & 15u); }

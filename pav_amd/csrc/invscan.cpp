@@ -156,7 +156,7 @@ struct InvState {
 };
 
 static InvState *istate(pav_ctx *ctx) {
-    if (!ctx->invscan) ctx->invscan = new InvState();
+    std::call_once(ctx->invscan_once, [ctx] { ctx->invscan = new InvState(); });   // (both roles' loaders name their records here first)
     return static_cast<InvState *>(ctx->invscan);
 }
 

@@ -248,7 +248,7 @@ struct TextDev {
 struct TextDevState { TextDev cigar, density; };
 
 TextDevState *tstate(pav_ctx *ctx) {
-    if (!ctx->textdev) ctx->textdev = new TextDevState();
+    std::call_once(ctx->textdev_once, [ctx] { ctx->textdev = new TextDevState(); });   // (the CIGAR-table and density-table writer threads)
     return static_cast<TextDevState *>(ctx->textdev);
 }
 

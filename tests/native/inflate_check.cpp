@@ -60,8 +60,8 @@ static bool resolve(const std::vector<uint32_t> &tok, uint32_t n, std::vector<ui
 }
 
 static int decode(const std::vector<uint8_t> &stream, uint32_t text_len, std::vector<uint8_t> &text, uint32_t *n_tok_out = nullptr,
-                  std::vector<uint32_t> *tok_out = nullptr) {
-    std::vector<uint8_t> in(stream); in.resize(in.size() + 16, 0);           // (the reader looks a few bytes beyond the stream)
+                  std::vector<uint32_t> *tok_out = nullptr, uint8_t pad = 0) {
+    std::vector<uint8_t> in(stream); in.resize(in.size() + 16, pad);         // (the reader looks a few bytes beyond the stream: 12 at most)
     std::vector<uint32_t> tok(tok_capacity(text_len));
     HostTab T; LaneScratch S; memset(&T, 0, sizeof T); memset(&S, 0, sizeof S);
     uint32_t n = 0;
@@ -199,6 +199,10 @@ int main(int argc, char **argv) {
         { std::vector<uint8_t> bad = {0x07}; CHECK(decode(bad, 0, back) == IFL_E_BTYPE); }      // final block of type 3
         { std::vector<uint8_t> bad = {0x01, 0x05, 0x00, 0x00, 0x00, 'a'}; CHECK(decode(bad, 5, back) == IFL_E_STORED); }
         { std::vector<uint8_t> bad = {0x01, 0x05, 0x00, 0xFA, 0xFF, 'a'}; CHECK(decode(bad, 5, back) == IFL_E_INPUT); }
+        // a last member whose bits go on as literals for ever (fixed block, then 1-bits = literal 255 on and on; the bytes behind the
+        // member look the same): the reader must stop at the member's end, not at ISIZE (ASan is the judge: 16 bytes of padding)
+        { std::vector<uint8_t> bad(10, 0xFF); bad[0] = 0x03 | 0xF8; CHECK(decode(bad, 65536, back, nullptr, nullptr, 0xFF) == IFL_E_INPUT); }
+        { std::vector<uint8_t> bad(3000, 0xFF); bad[0] = 0x03 | 0xF8; CHECK(decode(bad, 65536, back, nullptr, nullptr, 0xFF) == IFL_E_INPUT); }
         // a copy that reaches in front of the text: fixed block, length 3 at distance 1 as the first symbol (257 = 0000001, distance 0 = 00000)
         { std::vector<uint8_t> bad = {0x03 | (0x00 << 3), 0x02, 0x00, 0x00}; const int rc = decode(bad, 3, back); CHECK(rc == IFL_E_DISTANCE); }
         // every single-bit corruption of a short stream ends in an error or in some text - never out of bounds (ASan is the judge)

@@ -27,14 +27,46 @@ def test_bench_flags_and_metric_name_without_a_gpu():
         assert repr(_base()['metric']) in fh.read()
 
 
+def test_short_line_of_an_eight_rank_run_fits_the_driver_tail():
+    """bench.compact_line on a full report (round 5's committed 20 KB line) with eight ranks, the CPU-limited flag and the
+    same-lanes N = 1 figure: <= 4 KB, contract keys present, no prose."""
+    sys.path.insert(0, ROOT)
+    import bench
+    with open(os.path.join(ROOT, 'profiles', 'r05_full_path_bench.json')) as fh:
+        full = json.loads(fh.read().strip().splitlines()[-1])
+    full['config']['workload_short'] = 'configs[2] per-GPU share: 2 hg38-shaped haplotypes resident; step = one haplotype through CIGAR-call + flagging + k-mer inversion scan'
+    full['detail_file'] = 'bench_detail.json'
+    full['n_gpus'] = 8
+    full['per_rank'] = [dict(full['per_rank'][0], rank=r, lanes_per_gpu=2, usable_cpus=2.0) for r in range(8)]
+    short = bench.compact_line(full, limited=True, solo={'value': 1801.5, 'ms_per_step': 1.7101, 'lanes': 2})
+    text = json.dumps(short, separators=(',', ':'))
+    assert len(text) <= 4096, len(text)
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'per_rank'):
+        assert key in short, key
+    assert short['lanes_limited_by_cpus'] is True and short['single_rank_same_lanes']['lanes'] == 2
+    assert [p['rank'] for p in short['per_rank']] == list(range(8)) and all(p['lanes_per_gpu'] == 2 for p in short['per_rank'])
+    assert short['roofline']['frac'] == full['roofline']['frac'] and short['cpu_baseline']['kind'] == 'port'
+    assert '"note"' not in text
+
+
 def _run_bench(*extra):
-    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--scale', '0.01', '--steps', '4', '--warmup', '2', '--repeats', '3',
-           '--cpu-sample-regions', '12'] + list(extra)
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-3000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
-    assert len(lines) == 1, 'bench.py must print exactly one JSON line'
-    return json.loads(lines[0]), out.stderr
+    """Runs bench.py; returns (short line = the LAST stdout line, full report from the detail file, stderr)."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        detail = os.path.join(tmp, 'detail.json')
+        cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--scale', '0.01', '--steps', '4', '--warmup', '2', '--repeats', '3',
+               '--cpu-sample-regions', '12', '--detail', detail] + list(extra)
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+        assert len(lines) == 1, 'bench.py must print exactly one JSON line'
+        last = out.stdout.rstrip('\n').splitlines()[-1]
+        assert last == lines[0], 'the JSON line must be the LAST line of stdout'
+        assert len(last) <= 4096, f'the driver keeps ~8 KB of stdout: the line must stay <= 4 KB, it is {len(last)}'
+        with open(detail) as fh:
+            full = json.load(fh)
+    return json.loads(last), full, out.stderr
 
 
 @pytest.fixture(scope='module')
@@ -44,7 +76,30 @@ def line(built):
 
 @pytest.mark.gpu
 def test_bench_line_schema_and_arithmetic(line):
-    line, stderr = line
+    short, line, stderr = line
+    # ---- the short line: what the driver parses.  Contract keys, roofline and cpu_baseline with the figures they are checked by
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'per_rank', 'detail_file'):
+        assert key in short, key
+        if key not in ('config', 'roofline', 'cpu_baseline', 'per_rank'):
+            assert short[key] == line[key], key                                   # the two views of one run agree
+    assert short['metric'] == _base()['metric'] and 'workload' in short['config'] and 'model' not in short['config']
+    for key in ('scale', 'seed', 'aligned_bp_per_gpu', 'lanes_per_gpu', 'usable_cpus_per_rank', 'reference', 'repeats'):
+        assert key in short['config'], key
+    sr = short['roofline']
+    for key in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_bytes_per_launch', 'avg_kernel_ms', 'path'):
+        assert key in sr, key
+    assert all(sr[k] == line['roofline'][k] for k in ('kernel', 'bound', 'achieved', 'peak', 'frac', 'avg_kernel_ms'))
+    assert abs(sr['frac'] - sr['achieved'] / sr['peak']) < 1e-3 and sr['path']['frac'] == line['roofline']['path']['frac']
+    sc = short['cpu_baseline']
+    for key in ('value', 'unit', 'cores', 'kind', 'sample', 'records_match_gpu', 'cigar_call_only', 'density_scan_bp_per_s', 'reference_python'):
+        assert key in sc, key
+    assert sc['value'] == line['cpu_baseline']['value'] and sc['records_match_gpu'] is True and len(sc['sample']) <= 240
+    assert [p['rank'] for p in short['per_rank']] == [0] and short['per_rank'][0]['lanes_per_gpu'] == short['config']['lanes_per_gpu']
+    per_pass_short = sum(r['aligned_bp'] for r in short['per_rank'])
+    assert abs(short['value'] - per_pass_short / (short['ms_per_step'] * 1e-3) / 1e9) < 0.01 * short['value']
+    assert 'note' not in json.dumps(short)                                      # prose lives in the detail file
+    # ---- the full report (detail file)
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
                 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'repeats', 'per_rank', 'hbm'):
         assert key in line, key
@@ -111,7 +166,8 @@ def test_bench_line_schema_and_arithmetic(line):
 def test_bench_chm13_cohort_batch_in_small(built):
     """BASELINE configs[4] through bench.py's own switch, shrunk: T2T-CHM13-shaped reference, eight haplotypes resident against
     it, the whole path on all eight lanes; every lane's records are checked against the oracle before the timed region."""
-    line, _ = _run_bench('--reference', 'chm13', '--scale', '0.004')
+    short, line, _ = _run_bench('--reference', 'chm13', '--scale', '0.004')
+    assert short['config']['reference'] == 'chm13' and short['config']['lanes_per_gpu'] == 8 and 'configs[4]' in short['config']['workload']
     cfg = line['config']
     assert cfg['reference'] == 'chm13' and cfg['lanes_per_gpu'] == 8 and cfg['seed'] == 1005 and 'configs[4]' in cfg['workload']
     assert line['hbm']['records_match_per_lane'] == [True] * 8

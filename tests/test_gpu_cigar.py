@@ -518,7 +518,7 @@ def test_eight_haplotypes_resident_against_one_reference(built, gpu_ctx):
             c.close()
 
 
-def test_bench_two_ranks_on_one_gpu(built):
+def test_bench_two_ranks_on_one_gpu(built, tmp_path):
     """The N > 1 path of bench.py (staggered prepare, barrier, max-over-ranks time, summed aligned bases) on a one-GPU box:
     two ranks share GPU 0 over gloo.  The driver's real runs use one GPU per rank over RCCL; the rank logic is the same."""
     import json
@@ -532,14 +532,21 @@ def test_bench_two_ranks_on_one_gpu(built):
         port = sk.getsockname()[1]
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--scale', '0.01',
-           '--backend', 'gloo', '--share-gpu', '--no-cpu-baseline']
+           '--backend', 'gloo', '--share-gpu', '--no-cpu-baseline', '--detail', str(tmp_path / 'detail.json')]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
-    assert len(lines) == 1
+    assert len(lines) == 1 and len(lines[0]) <= 4096 and out.stdout.rstrip('\n').splitlines()[-1] == lines[0]
     line = json.loads(lines[0])
+    with open(tmp_path / 'detail.json') as fh:
+        full = json.load(fh)
     assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['value'] > 0 and line['steps'] == 2
-    assert [r['rank'] for r in line['per_rank']] == [0, 1] and line['load_balance']['max_over_mean_ms'] >= 1.0
+    assert [r['rank'] for r in line['per_rank']] == [0, 1] and full['load_balance']['max_over_mean_ms'] >= 1.0
+    # a scaling run's reader: every rank's lanes and CPUs on the short line, and rank 0 alone at the same lane count
+    assert all(r['lanes_per_gpu'] >= 1 and r['usable_cpus'] > 0 for r in line['per_rank'])
+    solo = line['single_rank_same_lanes']
+    assert solo['lanes'] == line['per_rank'][0]['lanes_per_gpu'] and solo['value'] > 0 and solo['ms_per_step'] > 0
+    assert ('lanes_limited_by_cpus' in line) == (line['config']['lanes_per_gpu'] < 6)
     one = synth.config2(seed=1002, scale=0.01, hap_index=0, threads=2).stats['aligned_bp']
     two = synth.config2(seed=1002, scale=0.01, hap_index=1, threads=2).stats['aligned_bp']
     got = line['value'] * 1e9 * line['ms_per_step'] * 1e-3               # aligned bases per step over both ranks
@@ -785,8 +792,9 @@ def test_bench_ranks_over_rccl(built):
                           '--no-cpu-baseline'], capture_output=True, text=True, timeout=1800, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
-    assert len(lines) == 1
+    assert len(lines) == 1 and len(lines[0]) <= 4096
     line = json.loads(lines[0])
     assert line['n_gpus'] == n and line['scaling'] == 'weak' and len(line['per_rank']) == n
+    assert line['single_rank_same_lanes']['lanes'] == line['config']['lanes_per_gpu']
     assert {r['rank'] for r in line['per_rank']} == set(range(n))
     assert abs(line['value'] - sum(r['aligned_bp'] for r in line['per_rank']) / (line['ms_per_step'] * 1e-3) / 1e9) < 0.02 * line['value']

@@ -4,16 +4,16 @@
 # profiles/<round>_* through tools/prof_summary.py.  Everything is built first, outside the profiler: bench.py runs with
 # --no-build, so no compiler is ever started from a process the profiler's preload has attached to.
 set -x
-ROUND=${1:-r05}
+ROUND=${1:-r06}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$ROUND
 mkdir -p $O
 python3 -c 'import __graft_entry__ as g; g.build()' > $O/build.log 2>&1 || exit 1
 cd /tmp && export TMPDIR=/tmp
-timeout -k 5 900 rocprofv3 --kernel-trace --stats -d $O/prof_full -o full -- python3 $R/bench.py --no-cpu-baseline --no-build > $O/full_bench_under_rocprof.json 2> $O/prof_full.err
-timeout -k 5 900 rocprofv3 --kernel-trace --stats -d $O/prof_cigar -o cigar -- python3 $R/bench.py --workload cigar --no-cpu-baseline --no-build > $O/cigar_bench_under_rocprof.json 2> $O/prof_cigar.err
-timeout -k 5 600 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o f -- python3 $R/bench.py --no-cpu-baseline --no-build --steps 4 --warmup 4 > $O/pmc_bench.json 2> $O/pmc_fetch.err
-timeout -k 5 600 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o w -- python3 $R/bench.py --no-cpu-baseline --no-build --steps 4 --warmup 4 > /dev/null 2> $O/pmc_write.err
+timeout -k 5 900 rocprofv3 --kernel-trace --stats -d $O/prof_full -o full -- python3 $R/bench.py --no-cpu-baseline --no-build --detail $O/full_bench_under_rocprof_detail.json > $O/full_bench_under_rocprof.json 2> $O/prof_full.err
+timeout -k 5 900 rocprofv3 --kernel-trace --stats -d $O/prof_cigar -o cigar -- python3 $R/bench.py --workload cigar --no-cpu-baseline --no-build --detail $O/cigar_bench_under_rocprof_detail.json > $O/cigar_bench_under_rocprof.json 2> $O/prof_cigar.err
+timeout -k 5 600 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o f -- python3 $R/bench.py --no-cpu-baseline --no-build --steps 4 --warmup 4 --detail $O/pmc_bench_detail.json > $O/pmc_bench.json 2> $O/pmc_fetch.err
+timeout -k 5 600 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o w -- python3 $R/bench.py --no-cpu-baseline --no-build --steps 4 --warmup 4 --detail /dev/null > /dev/null 2> $O/pmc_write.err
 cd $R
 P=$O/profiles
 mkdir -p $P
@@ -36,12 +36,12 @@ cp $P/${ROUND}_lds_counters.json $R/profiles/${ROUND}_lds_counters.json
 cp $P/${ROUND}_gather_rate.txt $R/profiles/${ROUND}_gather_rate.txt
 # plain runs (no profiler): the lines of record.  The PMC summary is copied first so that bench.py finds this round's traffic.
 cp $P/${ROUND}_pmc.json $R/profiles/${ROUND}_pmc.json
-python3 bench.py --no-build > $P/${ROUND}_full_path_bench.json 2> $O/bench_full.err
-python3 bench.py --no-build --workload cigar > $P/${ROUND}_cigar_only_bench.json 2> $O/bench_cigar.err
+python3 bench.py --no-build --detail $P/${ROUND}_full_path_bench_detail.json > $P/${ROUND}_full_path_bench.json 2> $O/bench_full.err
+python3 bench.py --no-build --workload cigar --detail $P/${ROUND}_cigar_only_bench_detail.json > $P/${ROUND}_cigar_only_bench.json 2> $O/bench_cigar.err
 # one lane and two lanes: how far one host thread gets
-python3 bench.py --no-build --no-cpu-baseline --lanes 1 > $P/${ROUND}_full_path_bench_lanes1.json 2> $O/bench_l1.err
-python3 bench.py --no-build --no-cpu-baseline --lanes 2 > $P/${ROUND}_full_path_bench_lanes2.json 2> $O/bench_l2.err
-python3 bench.py --no-build --no-cpu-baseline --lanes 4 > $P/${ROUND}_full_path_bench_lanes4.json 2> $O/bench_l4.err
+python3 bench.py --no-build --no-cpu-baseline --lanes 1 --detail $P/${ROUND}_full_path_bench_lanes1_detail.json > $P/${ROUND}_full_path_bench_lanes1.json 2> $O/bench_l1.err
+python3 bench.py --no-build --no-cpu-baseline --lanes 2 --detail $P/${ROUND}_full_path_bench_lanes2_detail.json > $P/${ROUND}_full_path_bench_lanes2.json 2> $O/bench_l2.err
+python3 bench.py --no-build --no-cpu-baseline --lanes 4 --detail $P/${ROUND}_full_path_bench_lanes4_detail.json > $P/${ROUND}_full_path_bench_lanes4.json 2> $O/bench_l4.err
 # what each phase of the pass costs per haplotype with 1 .. 8 lanes (tools/lane_scaling.py)
 python3 tools/lane_scaling.py --no-build --kernels > $O/lane_scaling.out 2> $O/lane_scaling.err
 # one lane under the kernel + copy trace: the timeline of a pass (where the GPU waits for the host), and the SQ counter pass
