@@ -24,6 +24,7 @@
 #include "inflatedev.h"
 
 #include "deflate_dev.h"    // the CRC-32 algebra
+#include "crc_wave.h"
 #include "inflate_dev.h"
 #include "scan_dev.h"
 
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(64) void k_inflate_resolve_ring(const uint32_t *__r
 // bytes); the chains of a tile are joined by x^(8 16), a lane's tiles by x^(8 4096), the lanes by x^(8 64) doubling its exponent - the
 // text counted from its END (zeros in front of it change nothing in a register run from zero), the initial value's term added last.
 __global__ __launch_bounds__(64) void k_bgzf_crc(const uint8_t *__restrict__ text, const BgzfMember *__restrict__ mem, uint32_t n_mem, uint32_t *__restrict__ status,
-                                                 uint32_t x16, uint32_t x64, uint32_t x4096) {
+                                                 CrcPowers X) {
     __shared__ uint32_t tab[256];
     const uint32_t lane = threadIdx.x, m = blockIdx.x;
     for (uint32_t i = lane; i < 256; i += 64) tab[i] = dfl::crc_table_entry(i);
@@ -447,38 +448,7 @@ __global__ __launch_bounds__(64) void k_bgzf_crc(const uint8_t *__restrict__ tex
     const BgzfMember M = mem[m];
     const uint32_t n = M.text_len;
     if (!n) { if (lane == 0 && M.crc != 0) status[m] = ST_CRC; return; }
-    const uint8_t *p = text + M.out_off;
-    const uint32_t tiles = (n + 4095u) / 4096u, pad = tiles * 4096u - n;       // `pad` zero bytes in front
-    uint32_t acc = 0;
-    for (uint32_t t = 0; t < tiles; ++t) {
-        const uint32_t base = t * 4096u + lane * 64u;                          // padded position of the lane's 64 bytes
-        uint32_t r[4] = {0, 0, 0, 0};
-        if (base >= pad && (((size_t)(p + (base - pad))) & 3u) == 0) {        // the common tile: all 64 bytes are text, words can be loaded
-            const uint32_t *w = reinterpret_cast<const uint32_t *>(p + (base - pad));
-#pragma unroll
-            for (uint32_t i = 0; i < 4; ++i) {
-                uint32_t v[4];
-#pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) v[j] = w[j * 4 + i];
-#pragma unroll
-                for (uint32_t b8 = 0; b8 < 4; ++b8)
-#pragma unroll
-                    for (uint32_t j = 0; j < 4; ++j) { r[j] = tab[(r[j] ^ v[j]) & 0xFFu] ^ (r[j] >> 8); v[j] >>= 8; }
-            }
-        } else if (base + 64u > pad) {
-            for (uint32_t i = 0; i < 16; ++i)
-#pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) { const uint32_t q = base + j * 16u + i; const uint32_t by = q >= pad ? p[q - pad] : 0u; r[j] = tab[(r[j] ^ by) & 0xFFu] ^ (r[j] >> 8); }
-        }
-        const uint32_t tile = dfl::gf_mul(x16, dfl::gf_mul(x16, dfl::gf_mul(x16, r[0]) ^ r[1]) ^ r[2]) ^ r[3];
-        acc = dfl::gf_mul(x4096, acc) ^ tile;
-    }
-    uint32_t f = x64, v = acc;
-    for (uint32_t d = 1; d < 64; d <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)v, (int)d);
-        v = (lane & d) ? dfl::gf_mul(f, o) ^ v : dfl::gf_mul(f, v) ^ o;
-        f = dfl::gf_mul(f, f);
-    }
+    const uint32_t v = wave_crc_raw(tab, text + M.out_off, n, X);              // (crc_wave.h: the layout and the algebra)
     if (lane == 0 && (v ^ M.crc_init ^ 0xFFFFFFFFu) != M.crc) status[m] = ST_CRC;
 }
 
@@ -608,9 +578,9 @@ int bgzf_inflate_device(pav_ctx *ctx, hipStream_t st, void **state, const uint8_
     }
     float ms_crc = 0;
     if (!full_window) {
-        static const uint32_t x16 = dfl::gf_xpow8(16), x64 = dfl::gf_xpow8(64), x4096 = dfl::gf_xpow8(4096);
+
         if (timing) PAV_HIP(ctx, hipEventRecord(ev[0], st));
-        PAV_LAUNCH_ON(ctx, st, "k_bgzf_crc", k_bgzf_crc, n, 64, 0, out.as<uint8_t>(), I->mem.as<BgzfMember>(), n, I->status.as<uint32_t>(), x16, x64, x4096);
+        PAV_LAUNCH_ON(ctx, st, "k_bgzf_crc", k_bgzf_crc, n, 64, 0, out.as<uint8_t>(), I->mem.as<BgzfMember>(), n, I->status.as<uint32_t>(), crc_powers());
         if (timing) { PAV_HIP(ctx, hipEventRecord(ev[1], st)); PAV_HIP(ctx, hipEventSynchronize(ev[1])); PAV_HIP(ctx, hipEventElapsedTime(&ms_crc, ev[0], ev[1])); }
     }
     uint32_t *hs = static_cast<uint32_t *>(I->pin);

@@ -77,6 +77,42 @@ def test_two_gloo_ranks_equal_the_unsharded_run(built, tmp_path, split):
     _golden_merged_tables(b, 'flag_hap', 'sampleA', 'h1')
 
 
+def test_four_gloo_ranks_uneven_shares_and_a_rank_without_work(built, tmp_path):
+    """World size 4 over gloo, no GPU - what the first 8-GPU run meets in small.  (a) five haplotypes on four ranks: whole
+    haplotypes, one rank takes two (uneven counts).  (b) two haplotypes on four ranks with TWO flagged-region batches: the ranks are
+    shared out by weight, and in a group of more than two ranks the third has no inversion batch at all - it must pass the stages'
+    barriers with nothing to do.  Every file equals the one-rank run's."""
+    ref_fa = os.path.join(GOLD, 'flag_hap', 'ref.fa')
+    five = [ce.golden_job('flag_hap', 'sampleA', 'h1'), ce.golden_job('flag_sparse', 'sampleA', 'h2'), ce.golden_job('flag_sparse', 'sampleB', 'h1'),
+            ce.golden_job('flag_hap', 'sampleB', 'h2'), ce.golden_job('flag_sparse', 'sampleC', 'h1')]
+    p = cohort.plan(five, 4)
+    assert sorted(len(r) for r in p) == [1, 1, 1, 2] and sorted(j for r in p for (j, _, n, _) in r) == [0, 1, 2, 3, 4]
+    one, four = tmp_path / 'one', tmp_path / 'four'
+    m1 = cohort.run_cohort(five, 1, str(one), ref_fa, config=CFG_SC, engine_factory=ce.oracle_engine)
+    m4 = cohort.run_cohort(five, 4, str(four), ref_fa, config=CFG_SC, engine_factory=ce.oracle_engine, backend='gloo', timeout=900)
+    key = lambda m: (m['asm_name'], m['hap'], m['inv_calls'])   # noqa: E731
+    assert sorted(map(key, m1)) == sorted(map(key, m4)) and {m['rank'] for m in m4} == {0, 1, 2, 3}
+    a, b = ce.tree_text(one), ce.tree_text(four)
+    assert sorted(a) == sorted(b)
+    for k in a:
+        assert a[k] == b[k], k
+    # (b) groups of two ranks for one inversion batch each
+    cfg2 = {'inv_sig_batch_count': 1, 'inv_sig_filter': 'single_cluster'}
+    two = [ce.golden_job('flag_hap', 'sampleA', 'h1'), ce.golden_job('flag_sparse', 'sampleA', 'h2')]
+    p = cohort.plan(two, 4)
+    groups = sorted({(j, n) for r in p for (j, _, n, _) in r})
+    assert sum(n for _, n in groups) == 4 and max(n for _, n in groups) >= 2
+    one2, four2 = tmp_path / 'one2', tmp_path / 'four2'
+    s1 = cohort.run_cohort(two, 1, str(one2), ref_fa, config=cfg2, engine_factory=ce.oracle_engine)
+    s4 = cohort.run_cohort(two, 4, str(four2), ref_fa, config=cfg2, engine_factory=ce.oracle_engine, backend='gloo', timeout=900)
+    assert sorted(map(key, s1)) == sorted(map(key, s4))
+    a, b = ce.tree_text(one2), ce.tree_text(four2)
+    assert sorted(k for k in a if '/batched/' not in k) == sorted(k for k in b if '/batched/' not in k)
+    for k in a:
+        if k in b:
+            assert a[k] == b[k], k
+
+
 # ---- GPU ----------------------------------------------------------------------------------------------------------------
 
 def _golden_checks(tree, case, asm, hap):
