@@ -129,10 +129,8 @@ def main():
                          "locus (configs[2]: both haplotypes of a diploid sample per GPU); 'cigar' = BASELINE configs[1], CIGAR-call only")
     ap.add_argument('--lanes', type=int, default=0,
                     help='haplotypes resident per GPU, one context + host thread each, sharing one resident reference; the K steps '
-                         'go round them (default 0 = auto: 4 = h1 + h2 of two phased diploid samples, the per-GPU share of '
-                         'configs[2] / [3], when the process may use >= 4 CPUs per rank - every lane is a host thread that polls its '
-                         'stream; measured on an MI355X box with taskset: 4 lanes on 4 cores 1.3 Tbp/s, on 2 cores 0.88; 2 lanes on 2 '
-                         'cores 1.07; 1 lane 0.62 - else 2 with >= 2 CPUs, else 1; 1 = one haplotype, no overlap)')
+                         'go round them (default 0 = 6: h1 + h2 of three phased diploid samples, the per-GPU share of configs[2] / [3]; '
+                         'a waiting lane yields its core, so six lanes need no six cores; 1 = one haplotype, no overlap)')
     ap.add_argument('--pair-frac', type=float, default=PAIR_FRAC, help='generator: fraction of indel events emitted as a matched DEL + INS')
     ap.add_argument('--eager-tables', action='store_true',
                     help='copy the density tables of every inversion call to pinned host memory inside the timed region (round-1 '
@@ -217,7 +215,10 @@ def main():
     # Gbp/s - with the host gaps of a pass shortened the fifth and sixth lane find room that four lanes left; round 2: four;
     # round 4: 2 / 4 / 6 lanes = 1.65 - 1.79 / 2.25 - 2.33 / 2.26 - 2.36 Tbp/s: four lanes reach the sum of the per-phase floors,
     # profiles/r04_lane_scaling.txt - six are kept where the CPUs allow it, they cost nothing and smooth short timed regions)
-    n_lanes = args.lanes if args.lanes > 0 else (6 if cpus_per_rank >= 6 else (4 if cpus_per_rank >= 4 else (2 if cpus_per_rank >= 2 else 1)))
+    # round 6: a waiting lane no longer holds a core (the library polls an event and yields between the polls, PAV_WAIT in
+    # include/pav_amd.h): six lanes on TWO cores run within a few per cent of six lanes on sixteen (2.38 / 2.32 Tbp/s on one box,
+    # 2.15 on one core; with the runtime's spinning wait 1.62 on two), so the lanes no longer follow the CPUs of a rank
+    n_lanes = args.lanes if args.lanes > 0 else 6
     gen_kw = {'pair_frac': args.pair_frac} if args.workload == 'cigar+inv' and args.pair_frac > 0 else {}
     if rank == 0:
         print(f'[bench] {world} rank(s) x {n_lanes} lane(s) per GPU (--lanes {args.lanes}: 0 = auto), {cpus_per_rank:.1f} usable CPUs per rank '

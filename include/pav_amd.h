@@ -54,6 +54,12 @@ int pav_mem_info(pav_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);   /
  * the kernel densities (sampled + filled), out[1] (point, run of consecutive INDEX values) pairs the closed-form sums went
  * over, out[2] (point, data point) pairs - what scipy's double loop would have gone over (~25 flop each). */
 int pav_kde_work(const pav_ctx *ctx, double out[3]);
+/* Host waits of the CALLING thread since it started (every wait of the library for a stream or an event goes through one function):
+ * out[0] seconds spent waiting, out[1] number of waits.  wall time of a pass - its waits = what the lane's host thread computes
+ * (bench.py `host`; the reference has no counterpart: pavlib runs its stages as separate processes, rules/call_inv.snakefile:145-196).
+ * PAV_WAIT = yield | spin | block picks how a thread waits (default yield: polls an event with sched_yield() in between, so a waiting
+ * lane gives its core to any thread that can run). */
+int pav_wait_stats(double out[2]);
 
 /* ---- sequence store ----------------------------------------------------------------------------------- *
  * Replaces: pysam.FastaFile.fetch of whole records + str.upper() of the whole chromosome / contig per

@@ -195,6 +195,7 @@ SYMBOLS = {
     'pav_sync': (ctypes.c_int, [_P]),
     'pav_mem_info': (ctypes.c_int, [_P, _P, _P]),
     'pav_kde_work': (ctypes.c_int, [_P, _P]),
+    'pav_wait_stats': (ctypes.c_int, [_P]),
     'pav_cigar_verify': (ctypes.c_int, [_P, _P]),
     'pav_seq_load': (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_uint32, _P, _P]),
     'pav_seq_share': (ctypes.c_int, [_P, _P, ctypes.c_int]),
@@ -483,6 +484,12 @@ class Context:
         out = (ctypes.c_double * 3)()
         self._check(self.lib.pav_kde_work(self.handle, out), 'pav_kde_work')
         return float(out[0]), float(out[1]), float(out[2])
+
+    def wait_stats(self):
+        """(seconds the CALLING thread has spent in the library's host waits, number of waits) since the thread started."""
+        out = (ctypes.c_double * 2)()
+        self._check(self.lib.pav_wait_stats(out), 'pav_wait_stats')
+        return float(out[0]), int(out[1])
 
     # -- sequences ----------------------------------------------------------------------------------------
     def seq_load(self, role, names, arrays):

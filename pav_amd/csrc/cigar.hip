@@ -663,6 +663,8 @@ __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
     __syncthreads();
 
     // flat SNV rows: two rows per lane in flight; lanes past the last row repeat it and do not store (no branch around the loads)
+    // (round 6, measured: four or eight rows in flight per lane change nothing - 0.342 / 0.354 against 0.349 ms beside the scans: the
+    //  memory system is full of this kernel's fetches already, about a million outstanding; fewer resident workgroups make it slower)
     constexpr int EMIT_U = 2;
     uint4 *out = reinterpret_cast<uint4 *>(A.snv + snv_base);              // pav_snv = {aln, pos, qry_pos, ref | alt << 8 | pad << 16}
     static_assert(sizeof(pav_snv) == sizeof(uint4), "pav_snv is stored as one 16-byte vector");

@@ -479,18 +479,32 @@ __global__ __launch_bounds__(256) void k_bucket_tig(const JobDev *__restrict__ j
 
 // Slot layout of k_kmer_lds: bits 0..61 the canonical k-mer (k <= 31), bit 62 / 63: the set holds it in its canonical / in the
 // other orientation.  A probe of the answer phase is then ONE LDS read (round 3: key, then the count bytes of the slot).
+#ifndef PAV_KMER_V                    // 0: round 5's probes; 1: counts touched by repeats only; 2: ... and pair reads in the answer phase
+#define PAV_KMER_V 2
+#endif
+constexpr uint32_t PROBE_START_MASK = PAV_KMER_V >= 2 ? ~1u : ~0u;   // pair reads: every walk starts at an even slot
 constexpr unsigned long long KEY_BITS = (1ull << 62) - 1ull;
 constexpr int KEY_O_SHIFT = 62;
 
+#ifdef PAV_KMER_PROF                  // tuning build: cycles of wave 0 of every workgroup per phase of k_kmer_lds (printed by pav_density_release)
+__device__ unsigned long long g_kmer_prof[16];
+#define KPROF_LAP(i) do { if ((threadIdx.x >> 6) == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); \
+                                                         if ((threadIdx.x & 63) == 0) atomicAdd(&g_kmer_prof[i], now_ - kp_clk); kp_clk = now_; } } while (0)
+#else
+#define KPROF_LAP(i) do { } while (0)
+#endif
 // ABL / ABL_W: ablations for the tuning build (PAV_TUNING, tools/build_variant.sh); the product kernel is the <0, 0> body
 template <int ABL, int ABL_W>
 __device__ __forceinline__ void kmer_lds_body(const PartItem *__restrict__ items, const JobDev *__restrict__ jobs,
                                                           SeqView R, SeqView T, int k, uint32_t limit,
                                                           const uint32_t *__restrict__ lists, const uint32_t *__restrict__ bcount,
                                                           int8_t *__restrict__ st_tmp, JobStat *__restrict__ stat) {
-    __shared__ unsigned long long keys[LDS_SLOTS];                     // canonical k-mers + orientation bits
+    __shared__ __attribute__((aligned(16))) unsigned long long keys[LDS_SLOTS];   // canonical k-mers + orientation bits
     __shared__ uint32_t cnt2[LDS_SLOTS / 2];                           // per slot two bytes: occurrences in the canonical / the other orientation
     __shared__ uint32_t flags;
+#ifdef PAV_KMER_PROF
+    unsigned long long kp_clk = __builtin_readcyclecounter();
+#endif
     const PartItem it = items[blockIdx.x];
     if (it.job == ~0u) return;                                          // padding of the XCD-grouped order
     const JobDev jd = jobs[it.job];
@@ -518,10 +532,16 @@ __device__ __forceinline__ void kmer_lds_body(const PartItem *__restrict__ items
         else kw_r[u] = kmer_words(R.two, jd.ref_abs + pos_r[u]);
     }
 
+    KPROF_LAP(0);                                                       // items -> job -> counts; list and window loads issued
     for (int s = threadIdx.x; s < LDS_SLOTS; s += LDS_THREADS) keys[s] = EMPTY_KEY;
     for (int s = threadIdx.x; s < LDS_SLOTS / 2; s += LDS_THREADS) cnt2[s] = 0;
     if (threadIdx.x == 0) flags = 0;
     __syncthreads();
+    KPROF_LAP(1);                                                       // table cleared, barrier
+#ifdef PAV_KMER_PROF
+    { uint64_t acc_ = 0; for (int u = 0; u < KU; ++u) acc_ += kw_r[u].v0 ^ kw_r[u].v1; if (acc_ == 0x123456789ull) flags = 7; }
+    KPROF_LAP(2);                                                       // the reference windows have arrived
+#endif
 
     // One entry after the other, each with its own probe loop.  Tuning builds of round 4 (profiles/r04_kmer_ablation.txt) put the
     // first probe of all KU entries in flight, or probed in rounds over the KU entries until the wave's last entry had its slot:
@@ -542,10 +562,27 @@ __device__ __forceinline__ void kmer_lds_body(const PartItem *__restrict__ items
             // the set holds the region's k-mers as they are (-r: reverse-complemented): which orientation of the key that is
             const uint32_t o = self_rc ? 0u : (uint32_t)(other != (jd.ref_rc != 0));
             const unsigned long long want = key | 1ull << (KEY_O_SHIFT + o);
-            uint32_t s = khash(key) & M;
+            uint32_t s = khash(key) & M & PROBE_START_MASK;
             int probes = 0;
             while (true) {
                 const unsigned long long od = atomicCAS(&keys[s], (unsigned long long)EMPTY_KEY, want);
+#if PAV_KMER_V >= 1
+                // One LDS atomic per k-mer in the common case: the lane that makes the slot (or sets the orientation bit of a slot that
+                // only had the other one) is that orientation's first occurrence and counts nothing; every later one adds 1, so the
+                // byte holds occurrences - 1.  Exactly one lane is first: the compare-and-swap / the fetch-or say which.
+                if (od == EMPTY_KEY) break;
+                if (((od ^ want) & KEY_BITS) == 0) {
+                    const unsigned long long fl = want & ~KEY_BITS;
+                    bool repeat = (od & fl) != 0;
+                    if (!repeat) repeat = (atomicOr(&keys[s], fl) & fl) != 0;
+                    if (repeat) {
+                        const uint32_t sh = 16 * (s & 1) + 8 * o;
+                        const uint32_t prev = (atomicAdd(&cnt2[s >> 1], 1u << sh) >> sh) & 0xFFu;            // repeats so far: this is occurrence prev + 2
+                        if (prev + 2 > limit) my_flags |= LDS_EXCEED;                                        // (the limit of scripts/density.py:516-527)
+                    }
+                    break;
+                }
+#else
                 if (od == EMPTY_KEY || ((od ^ want) & KEY_BITS) == 0) {
                     if (od != EMPTY_KEY && !(od & want & ~KEY_BITS)) atomicOr(&keys[s], want & ~KEY_BITS);   // seen before, in the other orientation only
                     const uint32_t sh = 16 * (s & 1) + 8 * o;
@@ -553,6 +590,7 @@ __device__ __forceinline__ void kmer_lds_body(const PartItem *__restrict__ items
                     if (prev + 1 > limit) my_flags |= LDS_EXCEED;                                            // scripts/density.py:516-527)
                     break;
                 }
+#endif
                 s = (s + 1) & M;
                 if (++probes >= LDS_SLOTS) { my_flags |= LDS_OVERFLOW; break; }
             }
@@ -572,9 +610,15 @@ __device__ __forceinline__ void kmer_lds_body(const PartItem *__restrict__ items
         if constexpr (ABL_W) kw_t[u] = KmerWords{(uint64_t)pos_t[u] * 0x9E3779B97F4A7C15ull, (uint64_t)pos_t[u] * 0xC2B2AE3D27D4EB4Full};
         else kw_t[u] = kmer_words(T.two, jd.tig_abs + pos_t[u]);
     }
+    KPROF_LAP(3);                                                       // inserts of wave 0
     if (my_flags) atomicOr(&flags, my_flags);
     __syncthreads();
+    KPROF_LAP(4);                                                       // barrier behind the inserts (the slowest wave)
     if (threadIdx.x == 0 && flags) atomicOr(&stat[it.job].lds_flags, flags);
+#ifdef PAV_KMER_PROF
+    { uint64_t acc_ = 0; for (int u = 0; u < KU; ++u) acc_ += kw_t[u].v0 ^ kw_t[u].v1; if (acc_ == 0x123456789ull) st_tmp[0] = 7; }
+    KPROF_LAP(5);                                                       // the contig windows have arrived
+#endif
 
     // contig k-mers: "is it in the set" and "is its reverse complement" are the two orientation bits of its canonical key.
     // STATE_MER (scripts/density.py:38-43,165-175: KMER_ORIENTATION_STATE) goes straight to the tile array - k_bucket_tig has
@@ -590,7 +634,25 @@ __device__ __forceinline__ void kmer_lds_body(const PartItem *__restrict__ items
         for (int u = 0; u < KU; ++u) if (ok[u]) {
             bool other, self_rc;
             const uint64_t key = canon_key(kmer_from_words(kw[u], jd.tig_abs + pos[u], k), k, &other, &self_rc);
-            uint32_t s = khash(key) & M;
+            uint32_t s = khash(key) & M & PROBE_START_MASK;
+#if PAV_KMER_V >= 2
+            // a probe reads the PAIR of slots at an even index with one 16-byte LDS load (the inserts start at even slots too and walk
+            // on slot by slot, so the first empty slot of the walk ends it): half the trips round the divergent loop
+            for (int probes = 0; probes < LDS_SLOTS; probes += 2) {
+                const ulonglong2 two = *reinterpret_cast<const ulonglong2 *>(&keys[s]);
+                const bool hit0 = (two.x & KEY_BITS) == key, hit1 = two.x != EMPTY_KEY && (two.y & KEY_BITS) == key;
+                if (hit0 || hit1) {                                         // (EMPTY has all 62 bits set: no k-mer is that key)
+                    const unsigned long long cur = hit0 ? two.x : two.y;
+                    const bool c0 = (cur >> KEY_O_SHIFT) & 1ull, c1 = cur >> 63;
+                    const bool same = other ? c1 : c0, opposite = self_rc ? c0 : (other ? c0 : c1);
+                    if constexpr (ABL != 1) st_tmp[jd.tpos_off + pos[u]] = (int8_t)(same ? (opposite ? 1 : 0) : 2);
+                    else if (same && opposite && pos[u] == 0xFFFFFFF0u) st_tmp[0] = 1;
+                    break;
+                }
+                if (two.x == EMPTY_KEY || two.y == EMPTY_KEY) break;
+                s = (s + 2) & M;
+            }
+#else
             for (int probes = 0; probes < LDS_SLOTS; ++probes) {
                 const unsigned long long cur = keys[s];
                 if ((cur & KEY_BITS) == key) {                              // (EMPTY has all 62 bits set: no k-mer is that key)
@@ -603,6 +665,7 @@ __device__ __forceinline__ void kmer_lds_body(const PartItem *__restrict__ items
                 if (cur == EMPTY_KEY) break;
                 s = (s + 1) & M;
             }
+#endif
         }
     };
     answer_step(kw_t, pos_t, ok_t);
@@ -614,6 +677,10 @@ __device__ __forceinline__ void kmer_lds_body(const PartItem *__restrict__ items
         for (int u = 0; u < KU; ++u) kw[u] = kmer_words(T.two, jd.tig_abs + pos[u]);
         answer_step(kw, pos, ok);
     }
+    KPROF_LAP(6);                                                       // look-ups + STATE_MER stores issued
+#ifdef PAV_KMER_PROF
+    if (threadIdx.x == 0) atomicAdd(&g_kmer_prof[15], 1ull);
+#endif
 }
 
 __global__ __launch_bounds__(LDS_THREADS) void k_kmer_lds(const PartItem *__restrict__ items, const JobDev *__restrict__ jobs,
@@ -2117,6 +2184,15 @@ extern "C" {
 
 void pav_density_release(pav_ctx *ctx) {
     if (!ctx || !ctx->density) return;
+#ifdef PAV_KMER_PROF
+    { unsigned long long h[16] = {0};
+      if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_kmer_prof), sizeof h) == hipSuccess && h[15]) {
+          static const char *nm[7] = {"header+loads issued", "clear+barrier", "ref windows wait", "inserts", "barrier", "tig windows wait", "look-ups"};
+          fprintf(stderr, "[k_kmer_lds profile] %llu workgroups; cycles of wave 0 per workgroup:", h[15]);
+          for (int i = 0; i < 7; ++i) fprintf(stderr, " %s %.0f;", nm[i], (double)h[i] / (double)h[15]);
+          fprintf(stderr, "\n");
+      } }
+#endif
     DensityState *D = static_cast<DensityState *>(ctx->density);
     D->release();
     delete D;

@@ -173,3 +173,32 @@ def test_bench_chm13_cohort_batch_in_small(built):
     assert line['hbm']['records_match_per_lane'] == [True] * 8
     assert line['inv_scan']['calls'] > 0 and line['inv_scan']['near_tie_guard']['n_unresolved'] == 0
     assert line['value'] > 0
+
+
+@pytest.mark.gpu
+def test_six_lanes_do_not_need_six_cores(built, tmp_path):
+    """A lane must not cost a core (the driver's 8-GPU run gives a rank two CPUs): `bench.py --lanes 6` in a FRESH child process
+    whose affinity is cut to two CPUs before it touches the GPU (preexec_fn: between fork and exec) against the same run on every CPU
+    this process may use.  The library's waits poll an event and yield in between (PAV_WAIT, include/pav_amd.h); with the runtime's
+    spinning wait the two-CPU run reached 0.67 of the other.  Half-size haplotypes: the passes must be long enough for the GPU, not
+    the host, to be what is measured; the bound leaves room for a noisy box (measured 0.95 - 1.03)."""
+    cpus = sorted(os.sched_getaffinity(0))
+    if len(cpus) < 4:
+        pytest.skip('needs four CPUs to compare with')
+
+    def run(affinity, tag):
+        detail = str(tmp_path / f'{tag}.json')
+        cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--no-build', '--no-cpu-baseline', '--lanes', '6', '--scale', '0.5', '--steps', '48',
+               '--repeats', '3', '--detail', detail]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT,
+                             preexec_fn=(lambda: os.sched_setaffinity(0, affinity)) if affinity else None)
+        assert out.returncode == 0, out.stderr[-3000:]
+        line = json.loads(out.stdout.rstrip('\n').splitlines()[-1])
+        return line
+    two = run(set(cpus[:2]), 'two')
+    full = run(None, 'all')
+    assert two['config']['usable_cpus_per_rank'] == 2.0 and two['config']['lanes_per_gpu'] == 6 and 'lanes_limited_by_cpus' not in two
+    assert full['config']['usable_cpus_per_rank'] >= 4.0
+    ratio = two['value'] / full['value']
+    print(f"six lanes: {two['value']} Gbp/s on two CPUs, {full['value']} on {full['config']['usable_cpus_per_rank']:.0f}: ratio {ratio:.3f}")
+    assert ratio >= 0.85, (two['value'], full['value'])

@@ -63,6 +63,17 @@ def main():
         step()
     ctx.sync()
     print('ms per step (one lane, no profiler): %.3f' % ((time.perf_counter() - t0) / args.steps * 1e3))
+    # CPU time of this thread per step (time.thread_time: what the lane's host thread computes; a blocked wait costs nothing,
+    # a polling one counts - PAV_WAIT=block shows the work alone)
+    c0, t0, w0 = time.thread_time(), time.perf_counter(), ctx.wait_stats()
+    for _ in range(args.steps):
+        step()
+    ctx.sync()
+    w1 = ctx.wait_stats()
+    wall = (time.perf_counter() - t0) / args.steps * 1e3
+    print('host thread CPU ms per step: %.3f of %.3f ms wall (PAV_WAIT=%s); %.3f ms in %.1f host waits per step: %.3f ms of host work' % (
+        (time.thread_time() - c0) / args.steps * 1e3, wall, os.environ.get('PAV_WAIT', 'yield'), (w1[0] - w0[0]) / args.steps * 1e3,
+        (w1[1] - w0[1]) / args.steps, wall - (w1[0] - w0[0]) / args.steps * 1e3))
     if args.kernels:
         import json
         ctx.prof_reset()
