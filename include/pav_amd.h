@@ -60,6 +60,12 @@ int pav_kde_work(const pav_ctx *ctx, double out[3]);
  * PAV_WAIT = yield | spin | block picks how a thread waits (default yield: polls an event with sched_yield() in between, so a waiting
  * lane gives its core to any thread that can run). */
 int pav_wait_stats(double out[2]);
+/* Large device blocks that a context gives up (sequence arenas, record and table buffers of a destroyed context) wait on a
+ * process-wide list per GPU for the next context - a context per haplotype then pays neither hipMalloc nor the driver's clearing of
+ * freed memory.  At most PAV_DEVICE_POOL_GB (default 24) and a quarter of the device's memory are kept per GPU; PAV_DEVICE_POOL=0
+ * turns the list off.  pav_device_pool_trim gives the idle blocks of one device (device_id < 0: of all) back to the driver and
+ * returns the bytes freed - for a process that goes on to use the GPU with something else. */
+uint64_t pav_device_pool_trim(int device_id);
 
 /* ---- sequence store ----------------------------------------------------------------------------------- *
  * Replaces: pysam.FastaFile.fetch of whole records + str.upper() of the whole chromosome / contig per

@@ -196,6 +196,7 @@ SYMBOLS = {
     'pav_mem_info': (ctypes.c_int, [_P, _P, _P]),
     'pav_kde_work': (ctypes.c_int, [_P, _P]),
     'pav_wait_stats': (ctypes.c_int, [_P]),
+    'pav_device_pool_trim': (ctypes.c_uint64, [ctypes.c_int]),
     'pav_cigar_verify': (ctypes.c_int, [_P, _P]),
     'pav_seq_load': (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_uint32, _P, _P]),
     'pav_seq_share': (ctypes.c_int, [_P, _P, ctypes.c_int]),
@@ -1122,3 +1123,9 @@ class CigarDeviceError(RuntimeError):
 
 def device_count():
     return int(load().pav_device_count())
+
+
+def device_pool_trim(device_id=-1):
+    """Give the idle device blocks the library keeps for the next context (include/pav_amd.h: pav_device_pool_trim) back to the
+    driver; ``device_id`` < 0: of every GPU.  Returns the bytes freed."""
+    return int(load().pav_device_pool_trim(int(device_id)))

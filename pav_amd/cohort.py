@@ -102,6 +102,8 @@ class DeviceEngine:
         for c in self.lane_ctx[::-1]:
             c.close()
         self.ctx, self.lane_ctx = None, []
+        from . import _lib
+        _lib.device_pool_trim(self.device_id)                  # the rank is done with the GPU: nothing idle stays behind for other processes
 
     # ---- whole haplotypes ---------------------------------------------------------------------------------------------
     def call_haplotype(self, job, out_dir, ctx=None):

@@ -27,10 +27,11 @@ constexpr uint64_t SEQ_ALIGN = 256;      // every record starts on a 256-base bo
 // context's large buffers are 25 GB (two sequence stores, the file text and token lists of the loaders, the writers' text).  Freed HBM
 // is cleared by the driver before it is handed out again: every other context of a run waited 0.4 - 0.65 s in hipMalloc for the clearing
 // of what the context before it had freed (`profiles/r05_e2e_soak.txt`).  Blocks of 32 MB and more therefore go back to a process-wide
-// list per GPU instead of to the driver (at most 64 GB kept, the rest freed), and come from it.  dev_block_put waits for the device
+// list per GPU instead of to the driver (at most PAV_DEVICE_POOL_GB = 24 GB and a quarter of the device's memory kept, the rest freed), and come from it.  dev_block_put waits for the device
 // first, as hipFree does.  PAV_DEVICE_POOL=0: plain hipMalloc / hipFree.
 hipError_t dev_block_get(void **p, size_t *cap, size_t want);
 void dev_block_put(void *p, size_t cap);
+size_t dev_pool_trim(int device);        // idle blocks of the device (< 0: all devices) back to the driver; bytes freed
 
 // ---- grow-only device buffer ------------------------------------------------------------------------------
 struct DevBuf {

@@ -9,6 +9,7 @@
 #include <chrono>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 #include <sched.h>
 #include <unistd.h>
 
@@ -311,17 +312,48 @@ struct UploadRings { UploadRing r[2]; };               // one per role: the two 
 }  // namespace pav
 
 // ---- the process-wide list of idle device blocks (common.h) -------------------------------------------------------------------
+// A block remembers the device it was allocated on (not whatever device is current when it comes back); a device's idle blocks are
+// capped at PAV_DEVICE_POOL_GB (default 24: three haplotypes' worth of stores and tables) and at a quarter of the device's memory,
+// so that other processes on the GPU - share_gpu ranks, RCCL, torch - are not starved by memory nobody uses; pav_device_pool_trim
+// gives everything back.
 namespace {
-struct BlockPool { std::mutex mu; struct B { int dev; void *p; size_t cap; }; std::vector<B> idle; };
+struct BlockPool {
+    std::mutex mu;
+    struct B { int dev; void *p; size_t cap; };
+    std::vector<B> idle;
+    std::unordered_map<void *, int> owner;             // every live block of >= BLOCK_MIN: the device it was allocated on
+};
 BlockPool &block_pool() { static BlockPool *P = new BlockPool(); return *P; }    // (never destroyed: the HIP runtime may be gone by then)
-constexpr size_t BLOCK_MIN = 32ull << 20, BLOCK_KEEP = 64ull << 30;
+constexpr size_t BLOCK_MIN = 32ull << 20;
 bool block_pool_on() { static const bool on = [] { const char *e = getenv("PAV_DEVICE_POOL"); return !(e && e[0] == '0'); }(); return on; }
+size_t block_keep(int dev) {
+    static const size_t env_cap = [] { const char *e = getenv("PAV_DEVICE_POOL_GB"); const double gb = e ? atof(e) : 24.0; return (size_t)(gb > 0 ? gb * (double)(1ull << 30) : 0.0); }();
+    static std::mutex mu;
+    static std::unordered_map<int, size_t> quarter;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = quarter.find(dev);
+    if (it == quarter.end()) {
+        hipDeviceProp_t prop;
+        const size_t total = hipGetDeviceProperties(&prop, dev) == hipSuccess ? (size_t)prop.totalGlobalMem : (size_t)64 << 30;
+        it = quarter.emplace(dev, total / 4).first;
+    }
+    return std::min(env_cap, it->second);
+}
+// what hipFree would have waited for - nothing queued on the block's device still uses it - with the caller's device restored
+void sync_device_of(int dev) {
+    int cur = dev;
+    (void)hipGetDevice(&cur);
+    if (cur != dev) (void)hipSetDevice(dev);
+    (void)hipDeviceSynchronize();
+    if (cur != dev) (void)hipSetDevice(cur);
+}
 }  // namespace
 
 hipError_t pav::dev_block_get(void **p, size_t *cap, size_t want) {
     *p = nullptr; *cap = 0;
     int dev = 0;
-    if (want >= BLOCK_MIN && block_pool_on() && hipGetDevice(&dev) == hipSuccess) {
+    const bool pooled = want >= BLOCK_MIN && block_pool_on() && hipGetDevice(&dev) == hipSuccess;
+    if (pooled) {
         BlockPool &P = block_pool();
         std::lock_guard<std::mutex> lk(P.mu);
         size_t best = P.idle.size();
@@ -333,30 +365,44 @@ hipError_t pav::dev_block_get(void **p, size_t *cap, size_t want) {
     hipError_t e = hipMalloc(p, want);
     if (e != hipSuccess && block_pool_on()) {               // out of memory with idle blocks held: let them go and try again
         (void)hipGetLastError();
-        std::vector<BlockPool::B> drop;
-        { BlockPool &P = block_pool(); std::lock_guard<std::mutex> lk(P.mu);
-          for (auto &b : P.idle) if (b.dev == dev) drop.push_back(b);
-          P.idle.erase(std::remove_if(P.idle.begin(), P.idle.end(), [&](const BlockPool::B &b) { return b.dev == dev; }), P.idle.end()); }
-        for (auto &b : drop) (void)hipFree(b.p);
+        (void)hipGetDevice(&dev);
+        pav::dev_pool_trim(dev);
         e = hipMalloc(p, want);
     }
     if (e != hipSuccess) { *p = nullptr; return e; }
     *cap = want;
+    if (pooled) { BlockPool &P = block_pool(); std::lock_guard<std::mutex> lk(P.mu); P.owner[*p] = dev; }
     return hipSuccess;
 }
 
 void pav::dev_block_put(void *p, size_t cap) {
     if (!p) return;
-    int dev = 0;
-    if (cap >= BLOCK_MIN && block_pool_on() && hipGetDevice(&dev) == hipSuccess) {
-        (void)hipDeviceSynchronize();                       // what hipFree would have waited for: nothing queued still uses the block
+    if (cap >= BLOCK_MIN && block_pool_on()) {
         BlockPool &P = block_pool();
-        std::lock_guard<std::mutex> lk(P.mu);
-        size_t held = 0;
-        for (auto &b : P.idle) if (b.dev == dev) held += b.cap;
-        if (held + cap <= BLOCK_KEEP) { P.idle.push_back(BlockPool::B{dev, p, cap}); return; }
+        int dev = -1;
+        { std::lock_guard<std::mutex> lk(P.mu); auto it = P.owner.find(p); if (it != P.owner.end()) dev = it->second; }
+        if (dev >= 0) {
+            sync_device_of(dev);
+            const size_t keep = block_keep(dev);
+            std::lock_guard<std::mutex> lk(P.mu);
+            size_t held = 0;
+            for (auto &b : P.idle) if (b.dev == dev) held += b.cap;
+            if (held + cap <= keep) { P.idle.push_back(BlockPool::B{dev, p, cap}); return; }
+            P.owner.erase(p);
+        }
     }
     (void)hipFree(p);
+}
+
+// every idle block of the device (< 0: of every device) back to the driver; returns the bytes freed
+size_t pav::dev_pool_trim(int device) {
+    std::vector<BlockPool::B> drop;
+    { BlockPool &P = block_pool(); std::lock_guard<std::mutex> lk(P.mu);
+      for (auto &b : P.idle) if (device < 0 || b.dev == device) { drop.push_back(b); P.owner.erase(b.p); }
+      P.idle.erase(std::remove_if(P.idle.begin(), P.idle.end(), [&](const BlockPool::B &b) { return device < 0 || b.dev == device; }), P.idle.end()); }
+    size_t bytes = 0;
+    for (auto &b : drop) { (void)hipFree(b.p); bytes += b.cap; }
+    return bytes;
 }
 
 namespace pav {
@@ -513,6 +559,8 @@ int seq_store_load(pav_ctx *ctx, int role, uint32_t n_seq, const uint64_t *len, 
 extern "C" {
 
 int pav_abi_version(void) { return PAV_ABI_VERSION; }
+
+uint64_t pav_device_pool_trim(int device_id) { return (uint64_t)pav::dev_pool_trim(device_id); }
 
 int pav_wait_stats(double out[2]) {
     if (!out) return PAV_E_ARG;

@@ -292,6 +292,12 @@ int pav_seq_load_fasta_path(pav_ctx *ctx, int role, const char *path, int thread
     FaDev *F = fstate(ctx, role);
     if (!F->st) PAV_HIP(ctx, hipStreamCreateWithFlags(&F->st, hipStreamNonBlocking));
     hipStream_t st = F->st;
+    // whichever way this call ends, the file's bytes and its text go back on the process's list of idle scratch (an error used to
+    // leave gigabytes attached to the context until pav_destroy); the stream is drained first: nothing queued may still read them
+    struct ScratchBack {
+        pav_ctx *ctx; FaDev *F; hipStream_t st;
+        ~ScratchBack() { (void)hipStreamSynchronize(st); (void)hipStreamSynchronize(ctx->stream); scratch_give(ctx->device, F->raw); scratch_give(ctx->device, F->comp); }
+    } scratch_back{ctx, F, st};
     // ---- the text of the file into HBM --------------------------------------------------------------------------------
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return fail(ctx, PAV_E_ARG, "pav_seq_load_fasta_path: cannot open %s", path);
@@ -324,7 +330,9 @@ int pav_seq_load_fasta_path(pav_ctx *ctx, int role, const char *path, int thread
                 const int ri = bgzf_inflate_device(ctx, st, &F->inflate, F->comp.as<uint8_t>(), walk.M, F->raw, &n, path);
                 if (ri != PAV_OK) return ri;
                 on_device = true;
-            }                                                // (a file that starts as BGZF and goes on as something else: the host reader decides)
+            } else if (timing || getenv("PAV_VERBOSE"))      // (a file that starts as BGZF and goes on as something else: the host reader decides)
+                fprintf(stderr, "[pav] %s starts as BGZF but its members do not tile the file (walk stopped at byte %llu of %llu): read again and "
+                                "inflated by the host reader\n", path, (unsigned long long)walk.next, (unsigned long long)sb.st_size);
         }
         if (!on_device) {
             std::string err;
@@ -427,9 +435,7 @@ int pav_seq_load_fasta_path(pav_ctx *ctx, int role, const char *path, int thread
     if (rcn != PAV_OK) return rcn;
     if (n_records) *n_records = n_hdr;
     // the store is filled and the stream drained (seq_store_load): the file's bytes and its text go back on the process's list of
-    // idle scratch - the other role's load, or the next haplotype's, takes them from there
-    scratch_give(ctx->device, F->raw);
-    scratch_give(ctx->device, F->comp);
+    // idle scratch when this function returns (scratch_back) - the other role's load, or the next haplotype's, takes them from there
     if (timing) fprintf(stderr, "[pav timing] seq_load_fasta_path role %d: %.2f GB of text%s; file -> HBM %.1f ms (%.1f GB/s), records %.1f ms, store %.1f ms (%s)\n", role,
                         (double)n / 1e9, on_device ? " (BGZF, inflated on the device)" : "", (t1 - t0) * 1e3, (double)n / 1e9 / std::max(1e-9, t1 - t0), (t2 - t1) * 1e3, (wall() - t2) * 1e3, path);
     return PAV_OK;
@@ -450,6 +456,10 @@ int pav_bgzf_inflate(pav_ctx *ctx, const uint8_t *in, uint64_t n_in, uint8_t *ou
     PAV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     PAV_HIP(ctx, scratch_take(ctx->device, (size_t)n_in + 4096, F->comp));
     if (n_in) PAV_HIP(ctx, hipMemcpyAsync(F->comp.p, in, n_in, hipMemcpyHostToDevice, ctx->stream));
+    struct ScratchBack {
+        pav_ctx *ctx; FaDev *F;
+        ~ScratchBack() { (void)hipStreamSynchronize(ctx->stream); scratch_give(ctx->device, F->raw); scratch_give(ctx->device, F->comp); }
+    } scratch_back{ctx, F};
     uint64_t n = 0;
     const int rc = bgzf_inflate_device(ctx, ctx->stream, &F->inflate, F->comp.as<uint8_t>(), walk.M, F->raw, &n, "pav_bgzf_inflate");
     if (rc != PAV_OK) return rc;

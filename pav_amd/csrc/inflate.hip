@@ -513,7 +513,8 @@ int bgzf_inflate_device(pav_ctx *ctx, hipStream_t st, void **state, const uint8_
     PAV_HIP(ctx, I->bsum.reserve(8ull * (n / SCAN_TILE + 8)));
     PAV_HIP(ctx, I->status.reserve(4ull * n));
     PAV_HIP(ctx, I->n_tok.reserve(4ull * batch));
-    PAV_HIP(ctx, scratch_take(ctx->device, 4ull * TOK_STRIDE * batch, I->tok));   // (back on the list when the text is there: see the end)
+    PAV_HIP(ctx, scratch_take(ctx->device, 4ull * TOK_STRIDE * batch, I->tok));   // (back on the list when this function returns, error or not)
+    struct TokBack { pav_ctx *ctx; InflateDev *I; hipStream_t st; ~TokBack() { (void)hipStreamSynchronize(st); scratch_give(ctx->device, I->tok); } } tok_back{ctx, I, st};
     PAV_HIP(ctx, I->scratch.reserve(sizeof(ifl::LaneScratch) * (size_t)batch));
     const size_t pin_need = std::max<size_t>(sizeof(BgzfMember) * (size_t)n, 4096);
     if (I->pin_cap < pin_need) {
@@ -589,7 +590,6 @@ int bgzf_inflate_device(pav_ctx *ctx, hipStream_t st, void **state, const uint8_
     for (uint32_t i = 0; i < n; ++i)
         if (hs[i]) return fail(ctx, PAV_E_ARG, "%s: corrupt BGZF member %u of %u (payload at byte %llu): %s", what, i, n, (unsigned long long)M.in_off[i], status_text(hs[i]));
     *n_text = total;
-    scratch_give(ctx->device, I->tok);
     if (timing) {
         fprintf(stderr, "[pav timing] bgzf_inflate_device: %u members, %.1f MB of text; places %.1f ms, inflate + crc %.1f ms (%.1f GB/s): k_inflate_tokens %.2f ms, %s %.2f ms, k_bgzf_crc %.2f ms\n",
                 n, (double)total / 1e6, (t1 - t0) * 1e3, (wall() - t1) * 1e3, (double)total / 1e9 / std::max(1e-9, wall() - t1), ms_tok,
