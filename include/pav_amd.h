@@ -296,7 +296,9 @@ int pav_homology(pav_ctx *ctx, uint32_t n, const pav_hom_query *q, uint32_t *out
  * STATE_MER, compaction, scipy gaussian_kde x3, interpolate / fill, spike rule, arg-max STATE) and
  * pavlib.density.rl_encoder (pavlib/density.py:330-361).  A batch of independent (reference region, contig
  * region) jobs is processed per call; tables stay in HBM and are fetched only for regions that become calls.
- * k <= 31.  Float columns follow scipy's arithmetic order (data ascending per evaluation point) with the
+ * k <= 32 (k = 32: the k-mer sets live in HBM tables - pav_den_params.kmer_mode is ignored - because an LDS slot keeps two
+ * orientation bits above a canonical k-mer of at most 62 bits; the reference takes any k, rules/call_inv.snakefile:131, its default
+ * is 31).  Float columns follow scipy's arithmetic order (data ascending per evaluation point) with the
  * device's exp(); they agree with the reference to ~1e-13 relative, STATE / STATE_MER / INDEX / runs exactly.
  */
 typedef struct {

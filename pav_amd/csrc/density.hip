@@ -49,7 +49,9 @@ struct JobStat {                          // written by kernels, zeroed per batc
     uint32_t st_count[3];                 // STATE_MER counts before the min-state-count rule
     uint32_t n_rows;
     uint32_t m[3], fill_n;
-    uint32_t lds_flags, pad;              // k_kmer_lds: LDS_EXCEED (a count passed the limit), LDS_OVERFLOW (partition table full)
+    uint32_t lds_flags, ones_count;       // k_kmer_lds: LDS_EXCEED (a count passed the limit), LDS_OVERFLOW (partition table full);
+                                          // HBM tables, k = 32: occurrences of the one k-mer whose 64 bits are the tables' EMPTY word
+                                          // (thirty-two T as the reference spells it: poly-A / poly-T tracts are real) - kept here
     uint32_t inv_first, last1;            // k_state_combine: 0xFFFFFFFF - first / 1 + last contig position with a FWD k-mer (scan-only batches)
     uint32_t n_near, n_reeval, n_unres, n_spike;   // near-tie guard (include/pav_amd.h)
     unsigned long long s1[3], s2[3];      // sum / sum of squares of the row numbers of each state
@@ -144,7 +146,7 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
     return x;
 }
-__device__ __forceinline__ uint64_t kmer_mask(int k) { return (1ull << (2 * k)) - 1ull; }   // k <= 31
+__device__ __forceinline__ uint64_t kmer_mask(int k) { return k >= 32 ? ~0ull : (1ull << (2 * k)) - 1ull; }   // k <= 32
 
 // Reverse the k 2-bit groups in the low 2k bits: window order (first base lowest) <-> kanapy order (first base highest)
 __device__ __forceinline__ uint64_t rev_groups(uint64_t x, int k) {
@@ -195,6 +197,8 @@ __device__ __forceinline__ uint64_t kmer_from_words(const KmerWords &kw, uint64_
 
 __device__ __forceinline__ bool table_has(const unsigned long long *__restrict__ keys, uint64_t off, uint32_t hmask,
                                           uint64_t key) {
+    if (key == EMPTY_KEY) return false;          // (k = 32: the word of a free slot is never IN a table - k_ref_insert keeps that k-mer's
+                                                 //  count aside, and it is no canonical k-mer, so the flank sets never hold it)
     uint32_t s = (uint32_t)mix64(key) & hmask;
     while (true) {
         const uint64_t cur = keys[off + s];
@@ -249,9 +253,13 @@ __global__ __launch_bounds__(256) void k_ref_insert(const JobDev *__restrict__ j
         valid = kmer_window(R.two, R.mask, jd.ref_abs + i, k, x);
         if (valid) {
             const uint64_t key = jd.ref_rc ? (x ^ kmer_mask(k)) : rev_groups(x, k);   // set of rc(kmer) when -r true
-            bool dup;
-            const uint32_t s = table_insert_dup(keys, jd.ht_off, jd.ht_mask, key, dup);
-            const uint32_t c = dup ? atomicAdd(&cnt[jd.ht_off + s], 1u) + 2u : 1u;
+            uint32_t c;
+            if (key == EMPTY_KEY) c = atomicAdd(&stat[j].ones_count, 1u) + 1u;        // (k = 32 only: the word that marks a free slot)
+            else {
+                bool dup;
+                const uint32_t s = table_insert_dup(keys, jd.ht_off, jd.ht_mask, key, dup);
+                c = dup ? atomicAdd(&cnt[jd.ht_off + s], 1u) + 2u : 1u;
+            }
             if (c > limit) atomicMax(&stat[j].max_count, c);
         }
     }
@@ -269,6 +277,10 @@ __global__ void k_max_kmer(const JobDev *__restrict__ jobs, uint32_t j, SeqView 
         uint64_t x;
         if (!kmer_window(R.two, R.mask, jd.ref_abs + i, k, x)) continue;
         const uint64_t key = jd.ref_rc ? (x ^ kmer_mask(k)) : rev_groups(x, k);
+        if (key == EMPTY_KEY) {                                          // (k = 32: counted in the job's statistics, slot 0xFFFFFFFF stands for it)
+            if (stat[j].ones_count == mx) atomicMin(&stat[j].max_key, ((unsigned long long)i << 32) | 0xFFFFFFFFull);
+            continue;
+        }
         const uint32_t s = table_slot(keys, jd.ht_off, jd.ht_mask, key);
         if (cnt[jd.ht_off + s] + 1u == mx) atomicMin(&stat[j].max_key, ((unsigned long long)i << 32) | s);
     }
@@ -287,8 +299,9 @@ __global__ __launch_bounds__(256) void k_tig_state(const JobDev *__restrict__ jo
     if (i + (uint64_t)k <= jd.tig_len) {
         uint64_t x;
         if (kmer_window(T.two, T.mask, jd.tig_abs + i, k, x)) {
-            const bool in_f = table_has(keys, jd.ht_off, jd.ht_mask, rev_groups(x, k));
-            const bool in_r = table_has(keys, jd.ht_off, jd.ht_mask, x ^ kmer_mask(k));
+            const uint64_t kf = rev_groups(x, k), kr = x ^ kmer_mask(k);
+            const bool in_f = kf == EMPTY_KEY ? stat[j].ones_count != 0 : table_has(keys, jd.ht_off, jd.ht_mask, kf);
+            const bool in_r = kr == EMPTY_KEY ? stat[j].ones_count != 0 : table_has(keys, jd.ht_off, jd.ht_mask, kr);
             st = in_f ? (in_r ? 1 : 0) : (in_r ? 2 : -1);            // KMER_ORIENTATION_STATE, density.py:38-43
         }
     }
@@ -2213,7 +2226,7 @@ uint64_t pav_kmer_canonical(uint64_t kmer, int k) {
 int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, const pav_den_params *pp,
                       pav_den_result *results) {
     if (!ctx || !pp || (n_jobs && (!jobs || !results))) return fail(ctx, PAV_E_ARG, "pav_density_batch: null argument");
-    if (pp->k < 1 || pp->k > 31) return fail(ctx, PAV_E_LIMIT, "pav_density_batch: k = %d is outside 1..31", pp->k);
+    if (pp->k < 1 || pp->k > 32) return fail(ctx, PAV_E_LIMIT, "pav_density_batch: k = %d is outside 1..32", pp->k);
     PAV_HIP(ctx, hipSetDevice(ctx->device));
     DensityState *D = dstate(ctx);
     const bool timing = getenv("PAV_TIMING") != nullptr;
@@ -2238,7 +2251,9 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
     std::vector<uint32_t> tile_job_r, tile_job_t;
     // k-mer sets in LDS unless asked otherwise (params, env), the count limit does not fit a byte, or a region needs
     // more partitions than the bucket kernels' histograms hold (> 1.8 Mbp; the reference's MAX_REGION_SIZE is 1.2 Mbp)
-    const bool lds_sets = pp->kmer_mode != PAV_KMER_HBM && pp->max_ref_kmer_count <= LDS_MAX_LIMIT &&
+    // ... or k = 32: an LDS slot keeps two orientation bits above the 62 bits of a canonical 31-mer; a 32-mer fills the word, its
+    // sets live in the HBM tables (the reference takes any k, rules/call_inv.snakefile:131; PAV's default is 31)
+    const bool lds_sets = pp->kmer_mode != PAV_KMER_HBM && pp->max_ref_kmer_count <= LDS_MAX_LIMIT && pp->k <= 31 &&
                           getenv("PAV_KMER_HBM") == nullptr;
     std::vector<PartItem> items;
     uint32_t n_hbm_jobs = 0;
@@ -2945,7 +2960,8 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
         unsigned long long packed = 0, key = 0;
         PAV_HIP(ctx, hipMemcpyAsync(&packed, &d_stat[j].max_key, sizeof packed, hipMemcpyDeviceToHost, st));
         PAV_HIP(ctx, hipStreamSynchronize(st));
-        PAV_HIP(ctx, hipMemcpy(&key, jk + D->h_jobs[j].ht_off + (packed & 0xFFFFFFFFull), sizeof key, hipMemcpyDeviceToHost));
+        if ((packed & 0xFFFFFFFFull) == 0xFFFFFFFFull) key = ~0ull;       // k = 32: the k-mer that is not in the table (JobStat::ones_count)
+        else PAV_HIP(ctx, hipMemcpy(&key, jk + D->h_jobs[j].ht_off + (packed & 0xFFFFFFFFull), sizeof key, hipMemcpyDeviceToHost));
         // the set holds rc(k-mer) when -r is set; the counter in the reference is keyed by the forward k-mer
         D->results[j].max_kmer = D->h_jobs[j].ref_rc ? pav_kmer_rev_complement(key, k) : key;
     }

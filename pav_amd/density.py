@@ -42,12 +42,17 @@ def table_frame(cols, finalised=True, extra=None):
     table (fewer than --mininf informative k-mers) keeps the early column set of :157-163 with STATE = -1.
     ``extra``: further columns appended in order (FLANK / MATCH of pavlib/inv.py:522-555).  Built in one shot."""
     index = cols['INDEX'].astype(np.int64)
+    # KMER: k <= 31 fits int64 like the reference column; with k = 32 pandas gives the reference's list of Python integers the dtype
+    # uint64 as soon as one of them needs the top bit (pd.DataFrame(tig_mer_stream), scripts/density.py:164) - which a region of
+    # thousands of 32-mers always has; the text of the table is the same digits either way
+    kmer = cols['KMER']
+    kmer = kmer.astype(np.int64) if (kmer.shape[0] == 0 or int(kmer.max()) < (1 << 63)) else kmer.astype(np.uint64)
     if finalised:
         data = {'INDEX': index, 'STATE_MER': cols['STATE_MER'].astype(np.int64), 'STATE': cols['STATE'].astype(np.int64),
                 'KERN_FWD': cols['KERN_FWD'], 'KERN_FWDREV': cols['KERN_FWDREV'], 'KERN_REV': cols['KERN_REV'],
-                'KMER': cols['KMER'].astype(np.int64)}          # k <= 31: fits int64 like the reference column
+                'KMER': kmer}
     else:
-        data = {'KMER': cols['KMER'].astype(np.int64), 'INDEX': index, 'STATE': cols['STATE'].astype(np.int64),
+        data = {'KMER': kmer, 'INDEX': index, 'STATE': cols['STATE'].astype(np.int64),
                 'STATE_MER': cols['STATE_MER'].astype(np.int64)}
     if extra:
         data.update(extra)

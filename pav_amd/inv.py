@@ -463,13 +463,14 @@ def _drive(ctx, scans, params, max_batch_bp=64_000_000):
 
 
 def _check_k_size(k_util):
-    """k-mers are 2-bit packed into one 64-bit word on the device (k <= 31, ``PAV_E_LIMIT`` in include/pav_amd.h); kanapy's
-    Python integers have no such limit, so ``inv_k_size >= 32`` in config.json is refused here with the reason instead of a
-    generic device error - before any device work."""
+    """k-mers are 2-bit packed into one 64-bit word on the device (k <= 32, ``PAV_E_LIMIT`` in include/pav_amd.h; 32-mers use the
+    HBM-table kernels: an LDS slot has no room for the two orientation bits beside 64 bits of k-mer); kanapy's Python integers
+    have no such limit, so ``inv_k_size >= 33`` in config.json is refused here with the reason instead of a generic device
+    error - before any device work."""
     k = int(k_util.k_size)
-    if not 1 <= k <= 31:
-        raise RuntimeError('k-mer size {} is not supported by pav_amd (1..31): k-mers are packed 2 bits per base into one '
-                           '64-bit word on the device; set inv_k_size <= 31'.format(k))
+    if not 1 <= k <= 32:
+        raise RuntimeError('k-mer size {} is not supported by pav_amd (1..32): k-mers are packed 2 bits per base into one '
+                           '64-bit word on the device; set inv_k_size <= 32'.format(k))
 
 
 def scan_for_inv(region_flag, ref_fa_name, tig_fa_name, align_lift, k_util, n_tree=None, max_region_size=None, threads=1,

@@ -36,6 +36,7 @@ class OracleScanContext:
 
     def density_batch(self, jobs, params):
         from oracle import oracle
+        self.k = int(params.k)
         if self.pool > 1 and len(jobs) > 1:             # many small regions: one region per thread (ctypes drops the GIL)
             self.threads = 1
             with ThreadPoolExecutor(self.pool) as ex:
@@ -67,7 +68,7 @@ class OracleScanContext:
         from oracle import oracle
         o = self.tables[j]
         chrom = self.ref[ref_id]
-        return oracle.annotate(o['KMER'], o['INDEX'], 31, qry_index_base, tig_up, tig_dn,
+        return oracle.annotate(o['KMER'], o['INDEX'], getattr(self, 'k', 31), qry_index_base, tig_up, tig_dn,
                                chrom[ref_up[0]:ref_up[1]], chrom[ref_dn[0]:ref_dn[1]])
 
 

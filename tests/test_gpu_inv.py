@@ -17,7 +17,7 @@ from pav_amd.kmer import KmerUtil
 
 pytestmark = pytest.mark.gpu
 GOLD = util.GOLD
-INV_CASES = ['inv_fwd', 'inv_rev', 'inv_small', 'inv_limits', 'inv_nolift', 'inv_hap']
+INV_CASES = ['inv_fwd', 'inv_rev', 'inv_small', 'inv_limits', 'inv_nolift', 'inv_hap', 'inv_k32']   # inv_k32: inv_k_size = 32, poly-T / poly-A tracts
 KERN = ('KERN_FWD', 'KERN_FWDREV', 'KERN_REV')
 RTOL = 1e-12      # KERN_* tolerance vs the reference: device exp() and np.cov's summation order
 
@@ -77,7 +77,7 @@ def check_call(d, rec, call):
 def test_scan_for_inv_vs_reference(built, gpu_ctx, case, capsys):
     """Every flagged region of the golden cases: same log lines, same None / InvCall, same regions, BED row and table."""
     d, lift, scans = load_case(gpu_ctx, case)
-    k_util = KmerUtil(31)
+    k_util = KmerUtil(util.case_k(d))
     for rec in scans:
         f = rec['flag']
         log = io.StringIO()
@@ -243,7 +243,7 @@ def test_density_iterations_vs_reference(built, gpu_ctx, case, mode, kmer):
                         1 if it['region_tig']['is_rev'] else 0, 20) for it in its]
     if not jobs:
         pytest.skip('no liftable iteration in this case')
-    res = gpu_ctx.density_batch(jobs, pavden.den_params(kde_mode=mode, kmer_mode=kmer))
+    res = gpu_ctx.density_batch(jobs, pavden.den_params(k=util.case_k(d), kde_mode=mode, kmer_mode=kmer))
     for j, (it, r) in enumerate(zip(its, res)):
         if 'n_rows' not in it:
             assert r.status == _lib.DEN_FAIL
@@ -379,7 +379,7 @@ def test_batched_scan_vs_reference(built, gpu_ctx, case, native):
     every golden case, grouped by keyword arguments: logs, None / InvCall, regions, BED rows and tables equal the
     reference's sequential results."""
     d, lift, scans = load_case(gpu_ctx, case)
-    k_util = KmerUtil(31)
+    k_util = KmerUtil(util.case_k(d))
     groups = {}
     for rec in scans:
         groups.setdefault(json.dumps(rec['kwargs'], sort_keys=True), []).append(rec)
@@ -729,6 +729,54 @@ def test_kmer_states_for_even_k_and_palindromes(built, gpu_ctx, k, ref_rc):
     assert all(np.array_equal(got[_lib.KMER_LDS][c], got[_lib.KMER_HBM][c]) for c in got[_lib.KMER_LDS])
     present = set(np.unique(o['STATE_MER']).tolist())
     assert {0, 2} <= present or {1} <= present                    # forward and inverted (or both-orientation) k-mers are there
+
+
+@pytest.mark.parametrize('ref_rc', [False, True])
+def test_k32_states_with_the_all_t_kmer(built, gpu_ctx, ref_rc):
+    """inv_k_size = 32: a 32-mer fills the 64-bit word, its sets live in the HBM tables whatever kmer_mode says - and the 32-mer made
+    of T is the word that marks a free table slot, so the library keeps its count aside.  A region with poly-T and poly-A tracts in
+    the reference and the contig (forward third, inverted third, a tract that is only in the contig) against the scalar oracle:
+    STATE_MER / INDEX / KMER / STATE exact, the tracts' rows present; and a low count limit: the all-T k-mer is the one the failure
+    message names (scripts/density.py:519-526) when it is the most frequent.  k = 33 is refused."""
+    from oracle import oracle
+    rng = np.random.default_rng(3200 + int(ref_rc))
+    lut = np.frombuffer(b'ACGT', dtype=np.uint8)
+    n = 9000
+    ref = lut[rng.integers(0, 4, n)]
+    ref[500:560] = ord('T'); ref[1500:1545] = ord('A'); ref[4000:4040] = ord('T'); ref[7000:7050] = ord('A')
+    tig = ref.copy()
+    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+    tig[3000:6000] = np.array([comp[int(b)] for b in tig[3000:6000][::-1]], dtype=np.uint8)      # an inverted third (its poly-T reads poly-A)
+    tig[8000:8040] = ord('T')                                                                     # a tract the reference region lacks here
+    gpu_ctx._inv_loaded = None
+    gpu_ctx.seq_load(_lib.PAV_ROLE_REF, ['chrK'], [ref])
+    gpu_ctx.seq_load(_lib.PAV_ROLE_TIG, ['tigK'], [tig])
+    job = _lib.DenJob(0, 0, 0, n, 0, n, 1 if ref_rc else 0, 20)
+    ones = np.uint64(0xFFFFFFFFFFFFFFFF)
+    for limit in (100, 20):
+        o = oracle.density(ref, tig, ref_rc, oracle.den_params(k=32, min_informative=10, min_state_count=1, max_ref_kmer_count=limit))
+        for kmer in (_lib.KMER_LDS, _lib.KMER_HBM):
+            res = gpu_ctx.density_batch([job], pavden.den_params(k=32, kmer_mode=kmer, min_informative=10, min_state_count=1,
+                                                                 max_ref_kmer_count=limit))[0]
+            assert res.status == (_lib.DEN_FAIL if o['status'] == 125 else (_lib.DEN_OK if o['status'] == 0 else _lib.DEN_UNFINALISED)), (limit, kmer)
+            if o['status'] == 125:
+                assert (res.fail_kind, res.max_count, res.max_kmer) == (o['fail_kind'], o['max_count'], o['max_kmer']), (limit, kmer)
+                continue
+            assert res.n_rows == o['n']
+            cols = gpu_ctx.density_table(0, res.n_rows)
+            for c in ('INDEX', 'STATE_MER', 'STATE', 'KMER'):
+                assert np.array_equal(cols[c], o[c]), (limit, kmer, c)
+            assert int((cols['KMER'] == ones).sum()) > 20 and int((cols['KMER'] == np.uint64(0)).sum()) > 20
+            df = pavden.table_frame(cols)
+            assert df['KMER'].dtype == np.uint64                                     # what pandas makes of Python integers above 2^63
+    # the 20-limit run fails on the all-T (or all-A) tract: 29 occurrences of one 32-mer in a 60-base tract
+    o = oracle.density(ref, tig, ref_rc, oracle.den_params(k=32, min_informative=10, min_state_count=1, max_ref_kmer_count=20))
+    assert o['status'] == 125 and o['max_kmer'] in (0, 0xFFFFFFFFFFFFFFFF)
+    with pytest.raises(RuntimeError, match='k = 33'):
+        gpu_ctx.density_batch([job], pavden.den_params(k=33))
+    with pytest.raises(RuntimeError, match='1..32'):
+        pavinv._check_k_size(KmerUtil(33))
+    pavinv._check_k_size(KmerUtil(32))
 
 
 NEARTIE = ['argmax_search', 'argmax_mirror', 'delta_above', 'delta_below']

@@ -17,7 +17,7 @@ from pav_amd.fasta import open_fasta, read_fai
 from pav_amd.kmer import KmerUtil
 
 GOLD = util.GOLD
-INV_CASES = ['inv_fwd', 'inv_rev', 'inv_small', 'inv_limits', 'inv_nolift', 'inv_hap']
+INV_CASES = ['inv_fwd', 'inv_rev', 'inv_small', 'inv_limits', 'inv_nolift', 'inv_hap', 'inv_k32']   # inv_k32: inv_k_size = 32, poly-T / poly-A tracts
 
 
 def sha(a):
@@ -100,6 +100,7 @@ def test_oracle_density_matches_reference(built, case):
     rl_encoder runs exact; KERN_* within 1e-12 relative (np.cov's summation order is not reproducible, exp is libm's)."""
     from oracle import oracle
     d = os.path.join(GOLD, case)
+    k = util.case_k(d)
     ref, tig = open_fasta(os.path.join(d, 'ref.fa')), open_fasta(os.path.join(d, 'tig.fa'))
     with open(os.path.join(d, 'scans.json')) as fh:
         scans = json.load(fh)
@@ -109,7 +110,7 @@ def test_oracle_density_matches_reference(built, case):
             rr, rt = it['region_ref'], it['region_tig']
             if rt is None:
                 continue
-            o = oracle.density(ref[rr['chrom']][rr['pos']:rr['end']], tig[rt['chrom']][rt['pos']:rt['end']], rt['is_rev'])
+            o = oracle.density(ref[rr['chrom']][rr['pos']:rr['end']], tig[rt['chrom']][rt['pos']:rt['end']], rt['is_rev'], oracle.den_params(k=k))
             if 'n_rows' not in it:
                 assert o['status'] == 125
                 continue
@@ -130,7 +131,7 @@ def test_oracle_density_matches_reference(built, case):
             call = rec['call']
             ro, ri, to, ti = (call[k] for k in ('region_ref_outer', 'region_ref_inner', 'region_tig_outer', 'region_tig_inner'))
             chrom = ref[ro['chrom']]
-            flank, match = oracle.annotate(o['KMER'], o['INDEX'], 31, call['region_ref_discovery']['pos'],
+            flank, match = oracle.annotate(o['KMER'], o['INDEX'], k, call['region_ref_discovery']['pos'],
                                            (to['pos'], ti['pos']), (ti['end'], to['end']),
                                            chrom[ro['pos']:ri['pos']], chrom[ri['end']:ro['end']])
             assert np.array_equal(np.array(['', 'UP', 'DN'])[flank], g['FLANK'])
@@ -197,7 +198,7 @@ def test_oracle_driven_scan_matches_reference(built, case, capsys):
         lift = AlignLift(pd.read_csv(os.path.join(d, 'align.tsv'), sep='\t'), read_fai(os.path.join(d, 'tig.fa.fai')))
         with open(os.path.join(d, 'scans.json')) as fh:
             scans = json.load(fh)
-    k_util = KmerUtil(31)
+    k_util = KmerUtil(31 if case == 'inv_large' else util.case_k(d))
     threads = min(8, util.usable_cpus())
     for rec in scans:
         f = rec['flag']

@@ -12,6 +12,16 @@ from pav_amd.fasta import open_fasta
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
+def case_k(case_dir):
+    """k-mer size a golden inversion case was made with (params.json beside its scans.json; PAV's default 31 without one)."""
+    import json
+    path = os.path.join(case_dir if os.path.isabs(case_dir) else os.path.join(GOLD, case_dir), 'params.json')
+    if not os.path.exists(path):
+        return 31
+    with open(path) as fh:
+        return int(json.load(fh)['k'])
+
+
 def golden_case(name):
     d = os.path.join(GOLD, name)
     df_align = rules.read_align_bed(os.path.join(d, 'align.tsv'))
