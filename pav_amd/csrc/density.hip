@@ -87,7 +87,7 @@ struct DensityState {
     DevBuf st_tmp, tile_sum, tile_pre, index, state_mer, state, kmer, kern[3], list[3], fill_list;
     DevBuf tiles, events, ev_count, scratch, run_arena, win_fill, ks[3], ss;
     DevBuf guard, guard_entries, samp_flag, row_flag, ftiles; // near-tie guard; evaluation tiles of the fill list
-    DevBuf tile_heads, tile_head_cnt, heads, plan_flags, pow_tab;   // device-planned batches (k_plan)
+    DevBuf tile_heads, tile_head_cnt, heads, plan_flags, pow_tab, fin_blocks;   // device-planned batches (k_plan); fin_blocks: k_finalize_blocks' list
     // The small per-batch buffers are slices of two arenas: what the host sends (jobs, tile -> job maps, partition items, KDE
     // descriptors, evaluation tiles) travels in ONE copy out of a pinned staging block; what the kernels count into (event
     // count, guard, plan flags, statistics, event list, bucket counts, guard flags) is cleared by two fills and its front
@@ -132,7 +132,7 @@ struct DensityState {
         DevBuf *all[] = {&jobs, &stat, &kde, &tile_job_r, &tile_job_t, &keys, &cnt, &keys_x, &cnt_x, &lists, &bcount, &items, &st_tmp, &tile_sum, &tile_pre,
                          &index, &state_mer, &state, &kmer, &kern[0], &kern[1], &kern[2], &list[0], &list[1], &list[2],
                          &fill_list, &tiles, &events, &ev_count, &scratch, &run_arena, &win_fill, &ks[0], &ks[1], &ks[2], &ss,
-                         &guard, &guard_entries, &samp_flag, &row_flag, &ftiles, &tile_heads, &tile_head_cnt, &heads, &plan_flags, &pow_tab,
+                         &guard, &guard_entries, &samp_flag, &row_flag, &ftiles, &tile_heads, &tile_head_cnt, &heads, &plan_flags, &pow_tab, &fin_blocks,
                          &in_arena, &zero_arena, &table_block, &flank, &match};
         for (DevBuf *b : all) b->release();
         if (pin) { (void)hipHostFree(pin); pin = nullptr; pin_cap = 0; }
@@ -492,6 +492,9 @@ __global__ __launch_bounds__(256) void k_bucket_tig(const JobDev *__restrict__ j
 
 // Slot layout of k_kmer_lds: bits 0..61 the canonical k-mer (k <= 31), bit 62 / 63: the set holds it in its canonical / in the
 // other orientation.  A probe of the answer phase is then ONE LDS read (round 3: key, then the count bytes of the slot).
+#ifndef PAV_FIN_R                     // table rows a lane of k_finalize_blocks takes
+#define PAV_FIN_R 2
+#endif
 #ifndef PAV_KMER_V                    // 0: round 5's probes; 1: counts touched by repeats only; 2: ... and pair reads in the answer phase
 #define PAV_KMER_V 2
 #endif
@@ -1074,6 +1077,7 @@ struct PlanArgs {
     const double *pow_tab; uint32_t pow_n;                            // pow_tab[n] = pow((double)n, -1.0 / 5.0)
     uint32_t min_informative, max_ref_kmer_count; double den_smooth, norm0;   // norm0 = pow(2 pi, -0.5) as the host's libm returns it
     uint32_t *flags;                                                  // [0] != 0: the batch needs the host-planned path
+    struct FinBlockOut { uint32_t job, row0; } *fin_blocks; uint32_t *n_fin_blocks; uint32_t fin_rows;   // blocks of table rows for k_finalize_blocks
 };
 constexpr uint32_t PLAN_TILE_OVERFLOW = 1, PLAN_POW_RANGE = 2;
 
@@ -1187,6 +1191,14 @@ __global__ __launch_bounds__(256) void k_plan(PlanArgs A) {
             if (kd.m[q] && !(kd.use_runs && kd.h[q] >= KDE_RUNS_MIN_H)) kd.ps_mask |= 1u << q;
     }
     if (lane == 0) A.kde[j] = kd;
+    if (A.fin_blocks) {                                                 // the blocks of this region that hold table rows (k_finalize_blocks)
+        const uint32_t rows = kd.finalised ? kd.n : st.n_rows;
+        const uint32_t nbk = (rows + A.fin_rows - 1) / A.fin_rows;
+        uint32_t base = 0;
+        if (lane == 0 && nbk) base = atomicAdd(A.n_fin_blocks, nbk);
+        base = (uint32_t)__shfl((int)base, 0);
+        for (uint32_t i = lane; i < nbk; i += 64) A.fin_blocks[base + i] = PlanArgs::FinBlockOut{j, i * A.fin_rows};
+    }
 }
 
 // Evaluation tiles of the windows k_windows queued (device-planned batches): 64 fill points each, in job order.
@@ -1680,6 +1692,140 @@ __global__ __launch_bounds__(256) void k_finalize(FinArgs A) {
     if (x == n - 1) {
         const uint32_t e = atomicAdd(A.ev_count, 1u);
         if (e < A.ev_cap) A.events[e] = HeadEvent{j, n, -2, 0u, A.index[ap], 0u};
+    }
+}
+
+// ---- k_finalize over a list of live blocks (device-planned batches) -------------------------------------------------------------
+// k_finalize above is launched over every 256 positions of the batch's arena.  In a scan round most of them hold no table row - the
+// regions that are settled from their counts have none, a region's rows fill only the front of its span - and a workgroup finds that
+// out two dependent loads after it has been placed: two fifths of the kernel's waves did nothing, and what the lanes regime runs out
+// of is wave slots (the SQ counters of a pass add up to ~15 resident waves per CU on average, profiles/r06_full_path_pmc_sq.txt).
+// k_plan, which knows every region's row count, therefore leaves a list of the blocks that HAVE rows; FIN_R rows per lane, their
+// loads issued together (sampled sites, window flag, then the table rows of evaluated windows), so that a wave's dependent round
+// trips are paid once per FIN_R * 64 rows; a fixed grid goes round the list.  Same arithmetic, same events as k_finalize.
+constexpr int FIN_R = PAV_FIN_R;
+constexpr uint32_t FIN_ROWS = 256u * FIN_R;
+struct FinBlock { uint32_t job, row0; };
+
+__global__ __launch_bounds__(256) void k_finalize_blocks(FinArgs A, const FinBlock *__restrict__ blocks, const uint32_t *__restrict__ n_blocks) {
+    __shared__ uint32_t s_spike[4];
+    __shared__ int8_t s_state[FIN_ROWS];
+    const GuardArgs &G = A.G;
+    const uint32_t nb = *n_blocks;
+    for (uint32_t e = blockIdx.x; e < nb; e += gridDim.x) {
+        const FinBlock fb = blocks[e];
+        const uint32_t j = fb.job;
+        const JobKde kd = A.kde[j];
+        const uint64_t off = A.jobs[j].tpos_off;
+        const uint32_t n = kd.finalised ? kd.n : A.stat[j].n_rows;
+        uint32_t x[FIN_R]; bool live[FIN_R]; int st[FIN_R];
+        uint32_t spike_cnt = 0;                                        // rows of this lane within G.rel of the spike threshold
+#pragma unroll
+        for (int r = 0; r < FIN_R; ++r) { x[r] = fb.row0 + (uint32_t)r * 256u + threadIdx.x; live[r] = x[r] < n; st[r] = -1; }
+        if (kd.finalised) {
+            // phase 1: what every row needs - the two sampled sites around it and its window's flag (rows past the end: the last row's)
+            uint32_t q[FIN_R], a[FIN_R], b[FIN_R]; bool at_a[FIN_R], at_b[FIN_R];
+            double ya[FIN_R][3], yb[FIN_R][3]; uint8_t wf[FIN_R];
+#pragma unroll
+            for (int r = 0; r < FIN_R; ++r) {
+                const uint32_t xx = live[r] ? x[r] : n - 1u;
+                q[r] = xx / kd.srs; a[r] = q[r] * kd.srs;
+                b[r] = a[r] + kd.srs; if (b[r] > kd.n - 1u) b[r] = kd.n - 1u;
+                at_a[r] = xx == a[r]; at_b[r] = !at_a[r] && xx == b[r];
+                const uint64_t so = (uint64_t)kd.samp_off + q[r];
+#pragma unroll
+                for (int s = 0; s < 3; ++s) { ya[r][s] = A.ks[s][so]; yb[r][s] = A.ks[s][so + 1]; }   // (so + 1: inside the arrays also behind a job's last site)
+                wf[r] = A.win_fill[off + q[r]];
+            }
+            // phase 2: the table rows of evaluated windows (the others ask for the job's first row: one line a wave)
+            double kv[FIN_R][3];
+#pragma unroll
+            for (int r = 0; r < FIN_R; ++r) {
+                const bool need = live[r] && !at_a[r] && !at_b[r] && wf[r];
+                const uint64_t at = need ? off + x[r] : off;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) kv[r][s] = A.kern[s][at];
+                wf[r] = need ? 1 : 0;
+            }
+#pragma unroll
+            for (int r = 0; r < FIN_R; ++r) {
+                if (!live[r]) continue;
+                const uint64_t ap = off + x[r];
+                double v[3];
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    if (at_a[r]) v[s] = ya[r][s];
+                    else if (at_b[r]) v[s] = yb[r][s];
+                    else if (wf[r]) v[s] = kv[r][s];
+                    else {                                             // np.interp (row_raw above: the same expression)
+                        const double slope = (yb[r][s] - ya[r][s]) / ((double)b[r] - (double)a[r]);
+                        v[s] = slope * ((double)x[r] - (double)a[r]) + ya[r][s];
+                    }
+                }
+                if (G.rel > 0.0 && (fabs(v[0] - 1.0) < G.rel || fabs(v[1] - 1.0) < G.rel || fabs(v[2] - 1.0) < G.rel)) ++spike_cnt;
+                st[r] = spike_argmax(v);
+#pragma unroll
+                for (int s = 0; s < 3; ++s) A.kern[s][ap] = v[s];
+                A.state[ap] = (int8_t)st[r];
+                if (G.rel > 0.0 && near_argmax(v[0], v[1], v[2], G.rel)) {          // (rare: as in k_finalize)
+                    if (G.pass == 0) atomicAdd(&G.stat[j].n_near, 1u);
+                    bool exact;
+                    if (at_a[r] || x[r] == kd.n - 1u) {
+                        const uint32_t qs = at_a[r] ? q[r] : q[r] + 1u;
+                        const uint64_t so = (uint64_t)kd.samp_off + qs;
+                        exact = kd.all_direct || (G.samp_flag[so] & SF_EXACT);
+                        if (!exact) guard_flag_sample(G, j, qs, so);
+                    } else if (A.win_fill[off + q[r]]) {
+                        exact = kd.all_direct || (G.row_flag[ap] & RF_EXACT);
+                        if (!exact) guard_flag_row(G, j, x[r], ap);
+                    } else {
+                        const uint64_t so = (uint64_t)kd.samp_off + q[r];
+                        const bool e0 = kd.all_direct || (G.samp_flag[so] & SF_EXACT), e1 = kd.all_direct || (G.samp_flag[so + 1] & SF_EXACT);
+                        if (!e0) guard_flag_sample(G, j, q[r], so);
+                        if (!e1) guard_flag_sample(G, j, q[r] + 1u, so + 1);
+                        exact = e0 && e1;
+                    }
+                    if (exact && !(G.row_flag[ap] & RF_COUNTED)) {
+                        G.row_flag[ap] |= RF_COUNTED;
+                        if (near_argmax(v[0], v[1], v[2], G.unres)) atomicAdd(&G.stat[j].n_unres, 1u);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < FIN_R; ++r) s_state[r * 256 + threadIdx.x] = (int8_t)st[r];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) spike_cnt += (uint32_t)__shfl_xor((int)spike_cnt, d);
+        if ((threadIdx.x & 63) == 0) s_spike[threadIdx.x >> 6] = spike_cnt;
+        __syncthreads();
+        if (threadIdx.x == 0 && A.spike_add) {
+            const uint32_t c = s_spike[0] + s_spike[1] + s_spike[2] + s_spike[3];
+            if (c) atomicAdd(&G.stat[j].n_spike, c);
+        }
+        // run heads
+#pragma unroll
+        for (int r = 0; r < FIN_R; ++r) {
+            if (!live[r]) continue;
+            const uint64_t ap = off + x[r];
+            const uint32_t i = (uint32_t)r * 256u + threadIdx.x;
+            bool head = x[r] == 0;
+            if (!head) {
+                int prev;
+                if (i > 0) prev = s_state[i - 1];
+                else if (!kd.finalised) prev = -1;
+                else { double pv[3]; row_raw(A, kd, off, x[r] - 1, pv); prev = spike_argmax(pv); }
+                head = prev != st[r];
+            }
+            if (head) {
+                const uint32_t ev = atomicAdd(A.ev_count, 1u);
+                if (ev < A.ev_cap) A.events[ev] = HeadEvent{j, x[r], (int32_t)st[r], A.index[ap], x[r] ? A.index[ap - 1] : 0u, 0u};
+            }
+            if (x[r] == n - 1) {
+                const uint32_t ev = atomicAdd(A.ev_count, 1u);
+                if (ev < A.ev_cap) A.events[ev] = HeadEvent{j, n, -2, 0u, A.index[ap], 0u};
+            }
+        }
+        __syncthreads();                                                // s_state is the next block's
     }
 }
 
@@ -2632,6 +2778,12 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             PA.min_informative = pp->min_informative; PA.max_ref_kmer_count = pp->max_ref_kmer_count; PA.den_smooth = pp->den_smooth;
             PA.norm0 = std::pow(2 * 3.14159265358979323846, -0.5);
             PA.flags = D->plan_flags.as<uint32_t>();
+            // the blocks of FIN_ROWS table rows k_finalize_blocks goes round: at most a_t / FIN_ROWS + one ragged block per region; the
+            // count is the third word of the plan flags (zero arena: cleared with the batch)
+            static const bool fin_list = [] { const char *e = getenv("PAV_FINALIZE_LIST"); return !(e && e[0] == '0'); }();
+            PAV_HIP(ctx, D->fin_blocks.reserve(sizeof(FinBlock) * ((size_t)(a_t / FIN_ROWS) + n_jobs + 1)));
+            PA.fin_blocks = fin_list ? D->fin_blocks.as<PlanArgs::FinBlockOut>() : nullptr;
+            PA.n_fin_blocks = D->plan_flags.as<uint32_t>() + 2; PA.fin_rows = FIN_ROWS;
             PAV_LAUNCH(ctx, "k_plan", k_plan, (n_jobs + 3) / 4, 256, 0, PA);
             const JobKde *d_kde = D->kde.as<JobKde>();
             KdeArgs KA;
@@ -2659,7 +2811,10 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
             for (int q = 0; q < 3; ++q) { FA.ks[q] = D->ks[q].as<double>(); FA.kern[q] = D->kern[q].as<double>(); }
             FA.G = G; FA.ev_cap = ev_cap; FA.events = D->events.as<HeadEvent>(); FA.ev_count = D->ev_count.as<uint32_t>();
             FA.blk_spike = nullptr; FA.spike_add = G.rel > 0.0 ? 1 : 0;
-            PAV_LAUNCH(ctx, "k_finalize", k_finalize, (uint32_t)(a_t / 256), 256, 0, FA);
+            if (fin_list) {
+                const uint32_t grid = (uint32_t)std::min<size_t>((size_t)(a_t / FIN_ROWS) + n_jobs + 1, (size_t)ctx->n_cu * 16);
+                PAV_LAUNCH(ctx, "k_finalize", k_finalize_blocks, grid, 256, 0, FA, D->fin_blocks.as<FinBlock>(), D->plan_flags.as<uint32_t>() + 2);
+            } else PAV_LAUNCH(ctx, "k_finalize", k_finalize, (uint32_t)(a_t / 256), 256, 0, FA);
             if (ctx->den_round && ctx->den_round->n_jobs == n_jobs && scan_only) {   // the round's next lifts, derived and answered in this launch set
                 RoundHook &H = *ctx->den_round;
                 PAV_LAUNCH(ctx, "k_round_decide", k_round_decide, n_jobs, 64, 0, d_stat, D->events.as<HeadEvent>(), D->ev_count.as<uint32_t>(), ev_cap, H.d_in,

@@ -42,6 +42,12 @@ python3 bench.py --no-build --workload cigar --detail $P/${ROUND}_cigar_only_ben
 python3 bench.py --no-build --no-cpu-baseline --lanes 1 --detail $P/${ROUND}_full_path_bench_lanes1_detail.json > $P/${ROUND}_full_path_bench_lanes1.json 2> $O/bench_l1.err
 python3 bench.py --no-build --no-cpu-baseline --lanes 2 --detail $P/${ROUND}_full_path_bench_lanes2_detail.json > $P/${ROUND}_full_path_bench_lanes2.json 2> $O/bench_l2.err
 python3 bench.py --no-build --no-cpu-baseline --lanes 4 --detail $P/${ROUND}_full_path_bench_lanes4_detail.json > $P/${ROUND}_full_path_bench_lanes4.json 2> $O/bench_l4.err
+# six lanes on two cores (what a rank of the driver's 8-GPU run gets) and on one: a waiting lane yields its core (PAV_WAIT, include/pav_amd.h);
+# the same with the runtime's spinning wait for comparison; and what the host thread of ONE lane computes per pass (wall - waits)
+taskset -c 0-1 python3 bench.py --no-build --no-cpu-baseline --detail $P/${ROUND}_full_path_bench_two_cpus_detail.json > $P/${ROUND}_full_path_bench_two_cpus.json 2> $O/bench_2cpu.err
+taskset -c 0 python3 bench.py --no-build --no-cpu-baseline --detail /dev/null > $P/${ROUND}_full_path_bench_one_cpu.json 2> $O/bench_1cpu.err
+PAV_WAIT=spin taskset -c 0-1 python3 bench.py --no-build --no-cpu-baseline --detail /dev/null > $P/${ROUND}_full_path_bench_two_cpus_spin.json 2> $O/bench_2cpu_spin.err
+python3 tools/prof_step.py --no-build --plain --steps 40 2> /dev/null | tail -2 > $P/${ROUND}_single_lane_host_work.txt
 # what each phase of the pass costs per haplotype with 1 .. 8 lanes (tools/lane_scaling.py)
 python3 tools/lane_scaling.py --no-build --kernels > $O/lane_scaling.out 2> $O/lane_scaling.err
 # one lane under the kernel + copy trace: the timeline of a pass (where the GPU waits for the host), and the SQ counter pass
