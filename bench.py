@@ -7,8 +7,8 @@ bench.py - aligned Gbp/s through CIGAR-call + k-mer inversion scan on MI355X (BA
 Workload (config.workload): synthetic hg38-shaped haplotypes (24 reference sequences with hg38 no-ALT lengths, ~3.0 Gbp
 aligned each, SURVEY.md section 8(d) profile, seed 1002) through the WHOLE path the metric names: CIGAR-call,
 inversion-signature flagging of the fresh calls, and the k-mer density scan of every flagged region - the per-GPU share of
-BASELINE configs[2] / [3]: L haplotypes resident per GPU against one resident reference (--lanes; one context and one host
-thread each), the K steps go round them.  The CIGAR-call-only figure of configs[1] is measured in the same run and reported
+BASELINE configs[2] / [3]: L = 6 haplotypes resident per GPU against one resident reference (--lanes; one context and one host
+thread each; a waiting thread yields its core, so the lanes do not follow the CPUs of a rank), the K steps go round them.  The CIGAR-call-only figure of configs[1] is measured in the same run and reported
 as the "cigar_only" object (or as `value` with --workload cigar).  With N > 1 every rank has its own L haplotypes (seed
 1002*64 + rank*L + lane) against the same reference: weak scaling, no data-path collective (SURVEY.md section 8(e));
 torch.distributed (RCCL) is used only for the barrier, the max-over-ranks of the timed region and the sum of the bases.
@@ -23,12 +23,15 @@ A "step" is one pass of the hot path over one haplotype with inputs already resi
         expansion rounds, inversion calls (the density tables of the calls stay packed in HBM; --eager-tables copies them
         to pinned host memory inside the step).
 
-Extra objects on the JSON line: "roofline" (the kernel with the largest share of a pass, HIP-event timed on the library's
-streams, one lane alone; "path" = the whole pass against SURVEY 8(d)'s byte model), "contig_pack_alone" (the streaming pack of
-a whole contig arena - verify mode, PAV_EAGER_PACK=1 - with nothing beside it), "cpu_baseline" (oracle/ scalar C port timed on
-a bounded sample of the same workload, rank 0, N = 1 only), "cigar_only" (BASELINE configs[1]), "verify_mode" (CIGAR-call + a
-pass over both packed sequences that checks every = / X base; SURVEY.md section 8(d), never mixed into `value`), "inv_scan"
-and "end_to_end" (writers / readers), "per_rank" and "load_balance".
+Output: stdout carries ONE short JSON line (<= 4 KB: the contract keys, `roofline`, `cpu_baseline`, one record per rank, the two
+numbers of `cigar_only` / `verify_mode` / `inv_scan`); the full report goes to --detail (default bench_detail.json beside this
+file) and to stderr: "roofline" (the kernel with the largest share of a pass, HIP-event timed on the library's streams, one lane
+alone; "path" = the whole pass against SURVEY 8(d)'s byte model; "timed_region" = the ranking with every lane running),
+"contig_pack_alone", "cpu_baseline" (oracle/ scalar C port timed on a bounded sample of the same workload, rank 0, N = 1 only),
+"cigar_only" (BASELINE configs[1]), "verify_mode" (CIGAR-call + a pass over both packed sequences that checks every = / X base;
+SURVEY.md section 8(d), never mixed into `value`), "inv_scan", "end_to_end" (writers / readers), "per_rank", "load_balance", "hbm",
+"host".  N > 1: "single_rank_same_lanes" = rank 0 alone with the same lanes while the other ranks wait (the N = 1 figure a scaling
+efficiency is to be computed against).
 """
 
 import argparse

@@ -11,6 +11,7 @@
 #include <thread>
 #include <unordered_map>
 #include <sched.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 
 namespace pav {
@@ -46,9 +47,20 @@ int wait_mode() {
     return m;
 }
 // one event per (thread, device, kind): waits are made by the thread that owns the lane, so nothing is shared
+struct WaitEvents {
+    static constexpr int MAX_DEV = 64;
+    hipEvent_t ev[2][MAX_DEV] = {};
+    // a thread that ends (the library's writer and loader threads come and go with every haplotype) gives its events back; the
+    // process's first thread keeps them: it ends with the process, when the runtime may already be gone
+    ~WaitEvents() {
+        if ((long)getpid() == (long)syscall(SYS_gettid)) return;
+        for (auto &row : ev) for (hipEvent_t e : row) if (e) (void)hipEventDestroy(e);
+    }
+};
 hipEvent_t wait_event(int mode) {
-    constexpr int MAX_DEV = 64;
-    thread_local hipEvent_t ev[2][MAX_DEV] = {};
+    constexpr int MAX_DEV = WaitEvents::MAX_DEV;
+    thread_local WaitEvents mine;
+    auto &ev = mine.ev;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
     hipEvent_t &e = ev[mode == WAIT_BLOCK][dev];
