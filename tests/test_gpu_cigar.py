@@ -774,6 +774,40 @@ def _device_count():
     return torch.cuda.device_count()        # counting devices does not initialise the GPU
 
 
+def test_wait_statistics_and_the_device_block_pool(built):
+    """pav_wait_stats: the waits of the CALLING thread (a second thread starts from zero); pav_device_pool_trim: the large blocks a
+    destroyed context leaves on the process's list for the next context are given back to the driver - and a context made afterwards
+    works as before.  PAV_WAIT modes are covered by running the suite under each."""
+    import threading
+    hap = synth.config2(seed=77, scale=0.02, threads=2)
+    names = hap.ref.names
+    with _lib.Context(0) as ctx:
+        w0 = ctx.wait_stats()
+        ctx.seq_load(_lib.PAV_ROLE_REF, names, [hap.ref.seqs[n] for n in names])
+        ctx.seq_load(_lib.PAV_ROLE_TIG, hap.tig_names, [hap.tig_seqs[n] for n in hap.tig_names])
+        ctx.cigar_load(*cigarcall.pack_alignments(hap.df_align, names, hap.tig_names))
+        c1 = ctx.cigar_call()
+        ctx.sync()
+        w1 = ctx.wait_stats()
+        assert w1[1] > w0[1] and w1[0] >= w0[0] >= 0.0
+        other = []
+        t = threading.Thread(target=lambda: other.append(ctx.wait_stats()))
+        t.start(); t.join()
+        assert other[0] == (0.0, 0)                                  # that thread has never waited
+        free_with = ctx.mem_info()[0]
+    kept = _lib.device_pool_trim(0)                                   # the arenas of the context above (>= 32 MB each) were kept
+    assert kept >= 32 << 20
+    assert _lib.device_pool_trim(0) == 0                              # nothing idle is left
+    with _lib.Context(0) as ctx:
+        assert ctx.mem_info()[0] >= free_with                         # the memory is back with the driver
+        ctx.seq_load(_lib.PAV_ROLE_REF, names, [hap.ref.seqs[n] for n in names])
+        ctx.seq_load(_lib.PAV_ROLE_TIG, hap.tig_names, [hap.tig_seqs[n] for n in hap.tig_names])
+        ctx.cigar_load(*cigarcall.pack_alignments(hap.df_align, names, hap.tig_names))
+        c2 = ctx.cigar_call()
+        assert (c2.n_ops, c2.n_snv, c2.n_indel, c2.aligned_bases) == (c1.n_ops, c1.n_snv, c1.n_indel, c1.aligned_bases)
+    _lib.device_pool_trim(-1)
+
+
 @pytest.mark.skipif(_device_count() < 2, reason='needs two GPUs: one rank per GPU over RCCL')
 def test_bench_ranks_over_rccl(built):
     """bench.py --gpus N as the driver launches it: one rank per GPU, RCCL (backend nccl) for the barrier and the max-over-ranks /
