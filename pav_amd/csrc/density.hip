@@ -2461,27 +2461,38 @@ int pav_density_batch(pav_ctx *ctx, uint32_t n_jobs, const pav_den_job *jobs, co
         // contig k-mer at scattered positions, and read the same windows of the planes.  Spread over the eight L2s every line of
         // the answers left the chip once per XCD that had touched it (205 MB written per launch for 20 MB of answers); in one L2
         // the lines fill up before they go.  PAV_XCD_GROUP=0: the plain order.
-        std::vector<uint32_t> order;
-        for (uint32_t j = 0; j < n_jobs; ++j) if (D->h_jobs[j].n_parts) order.push_back(j);
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-            return (uint64_t)D->h_jobs[a].ref_len + D->h_jobs[a].tig_len > (uint64_t)D->h_jobs[b].ref_len + D->h_jobs[b].tig_len; });
+        // (largest region first, ties in job order: one 64-bit key per job - size above, job number inverted below - and a plain sort)
+        std::vector<uint64_t> keyed;
+        keyed.reserve(n_jobs);
+        for (uint32_t j = 0; j < n_jobs; ++j)
+            if (D->h_jobs[j].n_parts) keyed.push_back((((uint64_t)D->h_jobs[j].ref_len + D->h_jobs[j].tig_len) << 31) | (uint64_t)(0x7FFFFFFFu - j));
+        std::sort(keyed.begin(), keyed.end(), std::greater<uint64_t>());
+        std::vector<uint32_t> order(keyed.size());
+        for (size_t o = 0; o < keyed.size(); ++o) order[o] = 0x7FFFFFFFu - (uint32_t)(keyed[o] & 0x7FFFFFFFull);
         static const bool group = [] { const char *e = getenv("PAV_XCD_GROUP"); return !(e && e[0] == '0'); }();
         if (!group) {
             for (uint32_t j : order)
                 for (uint32_t p = 0; p < D->h_jobs[j].n_parts; ++p) items.push_back(PartItem{j, p});
         } else {
             constexpr int XCDS = 8;
-            std::vector<PartItem> q[XCDS];
-            for (uint32_t j : order) {                                   // longest first, each to the shortest queue
+            // longest first, each to the shortest queue; queue x is the items at x, x + 8, x + 16, ... (written in place: a job's
+            // partitions go to consecutive rounds of its queue)
+            size_t fill[XCDS] = {0, 0, 0, 0, 0, 0, 0, 0};
+            std::vector<std::pair<uint8_t, uint32_t>> place(order.size());     // (queue, first round) of every job, in `order`
+            for (size_t o = 0; o < order.size(); ++o) {
                 int best = 0;
-                for (int x = 1; x < XCDS; ++x) if (q[x].size() < q[best].size()) best = x;
-                for (uint32_t p = 0; p < D->h_jobs[j].n_parts; ++p) q[best].push_back(PartItem{j, p});
+                for (int x = 1; x < XCDS; ++x) if (fill[x] < fill[best]) best = x;
+                place[o] = {(uint8_t)best, (uint32_t)fill[best]};
+                fill[best] += D->h_jobs[order[o]].n_parts;
             }
             size_t longest = 0;
-            for (int x = 0; x < XCDS; ++x) longest = std::max(longest, q[x].size());
-            items.reserve(longest * XCDS);
-            for (size_t r = 0; r < longest; ++r)
-                for (int x = 0; x < XCDS; ++x) items.push_back(r < q[x].size() ? q[x][r] : PartItem{~0u, 0u});   // ~0: nothing to do
+            for (int x = 0; x < XCDS; ++x) longest = std::max(longest, fill[x]);
+            items.assign(longest * XCDS, PartItem{~0u, 0u});                     // ~0: nothing to do
+            for (size_t o = 0; o < order.size(); ++o) {
+                const uint32_t j = order[o], np = D->h_jobs[j].n_parts;
+                PartItem *at = items.data() + (size_t)place[o].second * XCDS + place[o].first;
+                for (uint32_t p = 0; p < np; ++p, at += XCDS) *at = PartItem{j, p};
+            }
             while (!items.empty() && items.back().job == ~0u) items.pop_back();
         }
     };
