@@ -554,12 +554,23 @@ struct WalkArgs {
 // Two instances of the same walk: WALK_INDEL writes the stubs - little traffic, on the critical path of the homology scans;
 // WALK_SNV writes the SNV rows - 13 M isolated sector fetches per haplotype - on the side stream beside the homology scans.
 constexpr int WALK_INDEL = 1, WALK_SNV = 2;
+// (the stub walk keeps 152 registers - three waves a SIMD; asked to fit four it spills 100 bytes a lane and takes 0.080 instead of
+//  0.054 ms: measured in round 6, left alone)
 template <int MODE>
 __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
-    __shared__ uint64_t lds[4 * NQ];
     constexpr int NSLOT = MODE == WALK_SNV ? WALK_CHUNK : 1;
-    __shared__ uint32_t s_pre[NSLOT + 1];               // first SNV row of the op, relative to the tile's first row
-    __shared__ uint32_t d_pos[NSLOT], d_q0[NSLOT], d_row[NSLOT];   // 'X' ops: POS, stored contig position of base 0, row | rev << 31
+    // One block of LDS: s_pre | d_pos | d_q0 | d_row, 32 KiB for the SNV walk - five workgroups a CU (160 KiB; the registers allow five).
+    // With 208 bytes more (an unused sentinel entry and a scan scratch of its own) it was four.  The scan's scratch lies over the
+    // front of s_pre: block_excl_scan ends with a barrier and the arrays are written after it.
+    constexpr int SMEM_WORDS = 4 * NSLOT > 8 * NQ ? 4 * NSLOT : 8 * NQ;
+    __shared__ __attribute__((aligned(16))) uint32_t smem[SMEM_WORDS];
+#ifdef PAV_LDS_AB                     // tuning build: 256 bytes more, the workgroup count per CU of round 5
+    __shared__ uint32_t ab_pad[64];
+    if (MODE == WALK_SNV && threadIdx.x == 0) reinterpret_cast<volatile uint32_t *>(ab_pad)[0] = 1;
+#endif
+    uint64_t *lds = reinterpret_cast<uint64_t *>(smem);
+    uint32_t *s_pre = smem;                             // first SNV row of the op, relative to the tile's first row
+    uint32_t *d_pos = smem + NSLOT, *d_q0 = smem + 2 * NSLOT, *d_row = smem + 3 * NSLOT;   // 'X' ops: POS, stored contig position of base 0, row | rev << 31
     const uint32_t t = blockIdx.x;
     const uint64_t first = (uint64_t)t * WALK_CHUNK + (uint64_t)threadIdx.x * OPS_PER_LANE;      // slot ordinal
     uint32_t o[OPS_PER_LANE];
@@ -659,7 +670,6 @@ __global__ __launch_bounds__(256) void walk_emit(WalkArgs A) {
         }
     }
     if constexpr (MODE == WALK_INDEL) return;
-    if (threadIdx.x == 0) s_pre[NSLOT] = n_rows;
     __syncthreads();
 
     // flat SNV rows: two rows per lane in flight; lanes past the last row repeat it and do not store (no branch around the loads)

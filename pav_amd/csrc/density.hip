@@ -406,7 +406,7 @@ __device__ __forceinline__ bool bucket_flush(BucketStage &S, uint32_t P, const u
     return over;
 }
 
-__global__ __launch_bounds__(256) void k_bucket_ref(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
+__global__ __launch_bounds__(256, 6) void k_bucket_ref(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
                                                     SeqView R, int k, uint32_t *__restrict__ lists, uint32_t *__restrict__ bcount,
                                                     JobStat *__restrict__ stat) {
     __shared__ uint32_t hist[LDS_MAX_PARTS], base[LDS_MAX_PARTS];
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void k_bucket_ref(const JobDev *__restrict__ j
     if (block_any && threadIdx.x == 0) stat[j].n_ref_valid = 1;       // only "any" matters (scripts/density.py:510-513)
 }
 
-__global__ __launch_bounds__(256) void k_bucket_tig(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
+__global__ __launch_bounds__(256, 6) void k_bucket_tig(const JobDev *__restrict__ jobs, const uint32_t *__restrict__ tile_job,
                                                     SeqView T, int k, uint32_t *__restrict__ lists, uint32_t *__restrict__ bcount,
                                                     int8_t *__restrict__ st_tmp, JobStat *__restrict__ stat) {
     __shared__ uint32_t hist[LDS_MAX_PARTS], base[LDS_MAX_PARTS];
@@ -517,7 +517,12 @@ __device__ __forceinline__ void kmer_lds_body(const PartItem *__restrict__ items
                                                           int8_t *__restrict__ st_tmp, JobStat *__restrict__ stat) {
     __shared__ __attribute__((aligned(16))) unsigned long long keys[LDS_SLOTS];   // canonical k-mers + orientation bits
     __shared__ uint32_t cnt2[LDS_SLOTS / 2];                           // per slot two bytes: occurrences in the canonical / the other orientation
-    __shared__ uint32_t flags;
+#ifdef PAV_LDS_AB                     // tuning build: three workgroups a CU as in round 5
+    __shared__ uint32_t ab_pad[2];
+    if (threadIdx.x == 0) reinterpret_cast<volatile uint32_t *>(ab_pad)[0] = 1;
+#endif
+    // (40 960 bytes exactly: FOUR workgroups a CU.  A flag word beside the two arrays made it 40 968 and three - found in round 6 from
+    //  the code object's notes; the rare flags go to the job's statistics straight from the waves that raise them.)
 #ifdef PAV_KMER_PROF
     unsigned long long kp_clk = __builtin_readcyclecounter();
 #endif
@@ -551,11 +556,10 @@ __device__ __forceinline__ void kmer_lds_body(const PartItem *__restrict__ items
     KPROF_LAP(0);                                                       // items -> job -> counts; list and window loads issued
     for (int s = threadIdx.x; s < LDS_SLOTS; s += LDS_THREADS) keys[s] = EMPTY_KEY;
     for (int s = threadIdx.x; s < LDS_SLOTS / 2; s += LDS_THREADS) cnt2[s] = 0;
-    if (threadIdx.x == 0) flags = 0;
     __syncthreads();
     KPROF_LAP(1);                                                       // table cleared, barrier
 #ifdef PAV_KMER_PROF
-    { uint64_t acc_ = 0; for (int u = 0; u < KU; ++u) acc_ += kw_r[u].v0 ^ kw_r[u].v1; if (acc_ == 0x123456789ull) flags = 7; }
+    { uint64_t acc_ = 0; for (int u = 0; u < KU; ++u) acc_ += kw_r[u].v0 ^ kw_r[u].v1; if (acc_ == 0x123456789ull) st_tmp[0] = 7; }
     KPROF_LAP(2);                                                       // the reference windows have arrived
 #endif
 
@@ -627,10 +631,13 @@ __device__ __forceinline__ void kmer_lds_body(const PartItem *__restrict__ items
         else kw_t[u] = kmer_words(T.two, jd.tig_abs + pos_t[u]);
     }
     KPROF_LAP(3);                                                       // inserts of wave 0
-    if (my_flags) atomicOr(&flags, my_flags);
+    if (__ballot(my_flags != 0)) {                                      // (rare: a count above the limit, a full table)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) my_flags |= (uint32_t)__shfl_xor((int)my_flags, d);
+        if ((threadIdx.x & 63) == 0) atomicOr(&stat[it.job].lds_flags, my_flags);
+    }
     __syncthreads();
     KPROF_LAP(4);                                                       // barrier behind the inserts (the slowest wave)
-    if (threadIdx.x == 0 && flags) atomicOr(&stat[it.job].lds_flags, flags);
 #ifdef PAV_KMER_PROF
     { uint64_t acc_ = 0; for (int u = 0; u < KU; ++u) acc_ += kw_t[u].v0 ^ kw_t[u].v1; if (acc_ == 0x123456789ull) st_tmp[0] = 7; }
     KPROF_LAP(5);                                                       // the contig windows have arrived
@@ -944,7 +951,10 @@ __global__ __launch_bounds__(256, PAV_COMPACT_WAVES) void k_compact_scatter(Comp
     __shared__ unsigned long long s_kmer[DTILE];
     // the three per-state lists share ONE array (a row belongs to one state: their entries add up to the tile's rows): state s
     // starts behind the rows of the states in front of it - 34 KiB of LDS per workgroup instead of 50, four workgroups per CU
-    __shared__ uint32_t s_index[DTILE], s_list1[DTILE];
+    // (round 6: INDEX is staged as the 16-bit offset of the position in its tile - 31 KiB, FIVE workgroups a CU, which is what the
+    //  registers allow; with a 32-bit INDEX it was 34.4 KiB and four)
+    __shared__ uint32_t s_list1[DTILE];
+    __shared__ uint16_t s_off[DTILE];
     __shared__ int8_t s_mer[DTILE];
     const uint32_t j = A.tile_job[blockIdx.x];
     const JobDev jd = A.jobs[j];
@@ -984,11 +994,10 @@ __global__ __launch_bounds__(256, PAV_COMPACT_WAVES) void k_compact_scatter(Comp
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         if (st[t] < 0) continue;
-        const uint64_t i = i0 + t;                                     // k-mer offset in region_tig = INDEX
         const uint32_t lr = c[0]++;                                    // row inside the tile
         const uint64_t row = tile0[0] + lr;
         const uint64_t x = (t ? (w_lo >> (2 * t) | w_hi << (64 - 2 * t)) : w_lo) & kmer_mask(A.k);
-        s_index[lr] = (uint32_t)i;
+        s_off[lr] = (uint16_t)(threadIdx.x * 8 + t);                   // INDEX = the tile's first offset in region_tig + this
         s_mer[lr] = (int8_t)st[t];
         s_kmer[lr] = rev_groups(x, A.k);
         s_list1[lbase[st[t]] + c[1 + st[t]]++] = (uint32_t)row;        // INDEX_DEN of the state's data points, ascending
@@ -996,8 +1005,9 @@ __global__ __launch_bounds__(256, PAV_COMPACT_WAVES) void k_compact_scatter(Comp
     }
     __syncthreads();
     const uint64_t o0 = jd.tpos_off + tile0[0];
+    const uint32_t tile_i0 = (uint32_t)((uint64_t)blockIdx.x * DTILE - jd.tpos_off);
     for (uint32_t r = threadIdx.x; r < tot[0]; r += 256) {
-        A.index[o0 + r] = s_index[r];
+        A.index[o0 + r] = tile_i0 + s_off[r];
         A.state_mer[o0 + r] = s_mer[r];
         A.state[o0 + r] = -1;                                          // df['STATE'] = -1 (density.py:163)
         A.kmer[o0 + r] = s_kmer[r];
