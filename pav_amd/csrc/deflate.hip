@@ -62,9 +62,13 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs A) {
     uint32_t *T = reinterpret_cast<uint32_t *>(lz);
     uint16_t *prev = reinterpret_cast<uint16_t *>(lz + W);
     uint16_t *head = reinterpret_cast<uint16_t *>(lz + 3 * W);
-    __shared__ uint32_t f_ll[288], f_d[32], c_ll[288], c_d[32];
+    __shared__ uint32_t f_ll[288], f_d[32];
     __shared__ uint8_t ll_len[288], d_len[32];
-    __shared__ uint32_t stage[128];
+    // The codes of both trees and the staging words of the bit stream live where the tree builder's scratch (HuffWork) was: they are
+    // made after BOTH trees have their lengths.  9 792 bytes of LDS a wave instead of 11 584: sixteen waves a CU - what the registers
+    // allow - instead of fourteen.
+    static_assert(sizeof(dfl::HuffWork) >= 4 * (288 + 32 + 128), "codes and bit staging overlay the tree builder's scratch");
+    uint32_t *c_ll = reinterpret_cast<uint32_t *>(lz), *c_d = c_ll + 288, *stage = c_d + 32;
     dfl::HuffWork &HW = *reinterpret_cast<dfl::HuffWork *>(lz);
     dfl::HeaderWork &XW = *reinterpret_cast<dfl::HeaderWork *>(lz + sizeof(dfl::HuffWork));
     uint32_t *hdr = reinterpret_cast<uint32_t *>(lz + sizeof(dfl::HuffWork) + sizeof(dfl::HeaderWork));
@@ -224,12 +228,14 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs A) {
             if (lane == 0) HW.n_used = used;
             for (int s = (int)lane; s < n; s += 64) if (freq[s]) HW.order[dfl::huff_rank(freq, n, s)] = (uint16_t)s;
             __syncthreads();
-            if (lane == 0) {
-                dfl::huff_lengths(freq, n, dfl::MAX_BITS, tree == 0 ? ll_len : d_len, HW);
-                dfl::huff_codes(tree == 0 ? ll_len : d_len, n, tree == 0 ? c_ll : c_d, XW.count, XW.next);
-            }
+            if (lane == 0) dfl::huff_lengths(freq, n, dfl::MAX_BITS, tree == 0 ? ll_len : d_len, HW);
             __syncthreads();
         }
+        if (lane == 0) {                                                 // (HuffWork is dead: the codes go where it was)
+            dfl::huff_codes(ll_len, dfl::N_LL, c_ll, XW.count, XW.next);
+            dfl::huff_codes(d_len, dfl::N_D, c_d, XW.count, XW.next);
+        }
+        __syncthreads();
         // ---- header ---------------------------------------------------------------------------------------------------
         uint32_t hdr_bits = 0;
         if (lane == 0) {

@@ -1449,7 +1449,14 @@ struct KdeArgs {
 // runs of a state (wave w takes runs w, w + KDE_WAVES, ...) and wave 0 adds their partial sums in wave order - a fixed order,
 // so the result does not depend on scheduling; a region whose states alternate thousands of times does not hang on one lane.
 // States summed term by term in scipy's order (PAV_KDE_DIRECT) stay on wave 0.
+#ifndef PAV_KDE_MIN_WAVES             // waves per SIMD asked of the compiler for k_kde_eval (0: no request - 155 registers, three waves)
+#define PAV_KDE_MIN_WAVES 0
+#endif
+#if PAV_KDE_MIN_WAVES
+__global__ __launch_bounds__(64 * KDE_WAVES, PAV_KDE_MIN_WAVES) void k_kde_eval(KdeArgs A) {
+#else
 __global__ __launch_bounds__(64 * KDE_WAVES) void k_kde_eval(KdeArgs A) {
+#endif
     __shared__ double part[KDE_WAVES][3][64];
     const uint32_t n_tiles = A.n_tiles_dev ? *A.n_tiles_dev : A.n_tiles;
     for (uint32_t tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
