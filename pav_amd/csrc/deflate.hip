@@ -471,6 +471,12 @@ int gz_files(pav_ctx *ctx, void **slot, hipStream_t st, const uint8_t *d_text, u
         if (wbits == 13) W_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_deflate<13, 12>, 64, 0));
         else if (wbits == 12) W_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_deflate<12, 11>, 64, 0));
         else W_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_deflate<11, 10>, 64, 0));
+        // The waves are persistent and fill their CUs for the whole launch.  With every register of a SIMD taken (sixteen waves a
+        // CU: 4 x 112 of 512 registers a lane, 64 left) no other kernel's wave fits beside them - the text kernel of the next group of
+        // tables, the CRC kernel, another haplotype's kernels wait for the launch to end: with sixteen the density tables of the bench
+        // took 0.18 s instead of 0.10.  Fourteen leave a wave's worth of registers on two SIMDs of every CU.  PAV_GZ_WAVES_PER_CU.
+        static const int cap = [] { const char *e = getenv("PAV_GZ_WAVES_PER_CU"); return e ? std::max(1, atoi(e)) : 14; }();
+        per_cu = std::min(per_cu, cap);
         G->waves = std::max(1, per_cu) * std::max(1, ctx->n_cu);
         G->waves_wbits = wbits;
         if (timing) fprintf(stderr, "[pav timing] gz_files: window 2^%d bytes, %d waves per CU, %d CUs\n", wbits, per_cu, ctx->n_cu);
