@@ -181,7 +181,7 @@ def test_six_lanes_do_not_need_six_cores(built, tmp_path):
     whose affinity is cut to two CPUs before it touches the GPU (preexec_fn: between fork and exec) against the same run on every CPU
     this process may use.  The library's waits poll an event and yield in between (PAV_WAIT, include/pav_amd.h); with the runtime's
     spinning wait the two-CPU run reached 0.67 of the other.  Half-size haplotypes: the passes must be long enough for the GPU, not
-    the host, to be what is measured; the bound leaves room for a noisy box (measured 0.95 - 1.03)."""
+    the host, to be what is measured; the bound leaves room for a noisy box (measured 0.95 - 1.03; with the spinning wait 0.67)."""
     cpus = sorted(os.sched_getaffinity(0))
     if len(cpus) < 4:
         pytest.skip('needs four CPUs to compare with')
@@ -201,4 +201,4 @@ def test_six_lanes_do_not_need_six_cores(built, tmp_path):
     assert full['config']['usable_cpus_per_rank'] >= 4.0
     ratio = two['value'] / full['value']
     print(f"six lanes: {two['value']} Gbp/s on two CPUs, {full['value']} on {full['config']['usable_cpus_per_rank']:.0f}: ratio {ratio:.3f}")
-    assert ratio >= 0.85, (two['value'], full['value'])
+    assert ratio >= 0.80, (two['value'], full['value'])
