@@ -540,7 +540,12 @@ def main():
     limited_by_cpus = bool(args.lanes == 0 and n_lanes < 6)
     solo_same_lanes = None
     if world > 1:
-        side = dist.new_group(backend='gloo') if args.backend != 'gloo' else None
+        side = None
+        if args.backend != 'gloo':
+            try:                                              # (a socket barrier: the waiting ranks sleep instead of spinning on the device)
+                side = dist.new_group(backend='gloo')
+            except Exception as ex:                           # noqa: BLE001 - no gloo transport on this node: the main group's barrier does
+                print(f'[bench] rank {rank}: no gloo side group ({ex!r}); waiting on the main group', file=sys.stderr, flush=True)
         if rank == 0:
             solos = []
             for _ in range(3):
